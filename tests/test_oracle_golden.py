@@ -1,0 +1,145 @@
+"""Pins oracle/tasu_oracle.py against fixtures produced from the REAL reference (oracle/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_batch, load_npz
+from oracle import tasu_oracle as O
+
+FP32_TOL = dict(rtol=2e-4, atol=2e-5)
+
+
+def close(a, b, **tol):
+    a = (a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).float()
+    b = (b.detach() if isinstance(b, torch.Tensor) else torch.as_tensor(np.asarray(b))).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    torch.testing.assert_close(a, b, **tol)
+
+
+@pytest.mark.parametrize("case", ["text_clean_right", "text_noise_right", "text_clean_left", "text_clean_b1"])
+def test_text_forward_backward_fp32(case, geo, tiny_weights):
+    b, z = golden_batch(case)
+    out, grads = O.loss_and_projector_grads(tiny_weights, b, geo, "fp32")
+    close(out["loss"], z["loss"], rtol=1e-5, atol=1e-6)
+    valid = out["mask"]
+    close(out["logits"][valid], torch.from_numpy(z["logits"])[valid], **FP32_TOL)
+    close(out["acc"], z["acc"], rtol=0, atol=1e-7)
+    for k, g in grads.items():
+        close(g, z["grad." + k[len("encoder_projector."):]], rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["text_clean_right", "text_clean_left"])
+def test_merge_plan(case, geo, tiny_weights):
+    b, z = golden_batch(case)
+    plens = torch.tensor([len(p) for p in b["post_ids"]])
+    plan = O.merge_plan(b["input_ids"], b["attention_mask"], plens, geo["speech_id"])
+    assert np.array_equal(plan["mask"].numpy(), z["merged_mask"].astype(bool))
+    assert np.array_equal(plan["position_ids"].numpy(), z["merged_position_ids"])
+    out = O.forward_text(tiny_weights, b, geo)
+    assert np.array_equal(out["labels"].numpy(), z["merged_labels"])
+    if "merged_embeds" in z:
+        close(out["embeds"], z["merged_embeds"], **FP32_TOL)
+        close(out["proj"], z["proj_out"], **FP32_TOL)
+
+
+def test_merge_rejects_two_sided_padding(geo):
+    ids = torch.tensor([[1, geo["speech_id"], 2], [3, geo["speech_id"], 4]])
+    am = torch.tensor([[0, 1, 1], [1, 1, 0]]).bool()
+    with pytest.raises(ValueError):
+        O.merge_plan(ids, am, torch.tensor([2, 2]), geo["speech_id"])
+
+
+def test_bf16_mode_vs_reference_autocast(geo, tiny_weights):
+    """Oracle bf16 emulation vs the reference's pieces under torch.autocast('cpu', bfloat16)."""
+    b, _ = golden_batch("text_clean_right")
+    z = load_npz("text_clean_right_bf16")
+    out, grads = O.loss_and_projector_grads(tiny_weights, b, geo, "bf16")
+    close(out["proj"], z["proj_out"], rtol=2e-2, atol=2e-3)
+    valid = out["mask"]
+    ref = torch.from_numpy(z["logits"])
+    err = (out["logits"] - ref)[valid].abs().max() / ref[valid].abs().max()
+    assert err < 3e-2, err
+    assert abs(float(out["loss"]) - float(z["loss"])) < 2e-2
+    for k, g in grads.items():
+        r = torch.from_numpy(z["grad." + k[len("encoder_projector."):]])
+        cos = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0)
+        assert cos > 0.995, (k, cos)
+
+
+def test_encoder_ragged(geo, tiny_weights):
+    z = load_npz("encoder_ragged")
+    enc, olens = O.sensevoice_encoder(tiny_weights, torch.from_numpy(z["speech"]), torch.from_numpy(z["speech_lengths"]),
+                                      geo["enc_heads"], geo["enc_kernel"])
+    assert np.array_equal(olens.numpy(), z["olens"])
+    close(enc, z["enc_out"], **FP32_TOL)
+    post = torch.softmax(O.linear(enc, tiny_weights["encoder.ctc.ctc_lo.weight"],
+                                  tiny_weights["encoder.ctc.ctc_lo.bias"], "fp32"), -1)
+    close(post, z["ctc_posterior"], **FP32_TOL)
+
+
+def test_psd_crafted():
+    z = load_npz("psd_crafted")
+    post = torch.from_numpy(z["posterior"])
+    out, nl = O.psd(post, torch.from_numpy(z["lens"]), post, 0)
+    assert np.array_equal(nl.numpy(), z["new_lens"])
+    close(out, z["out"], rtol=1e-6, atol=1e-7)
+    z2 = load_npz("psd_crafted_logprob")
+    lp = post.clamp_min(1e-30).log()
+    out2, nl2 = O.psd(lp, torch.from_numpy(z["lens"]), lp, 0)
+    assert np.array_equal(nl2.numpy(), z2["new_lens"])
+    close(out2, z2["out"], rtol=1e-6, atol=1e-7)
+
+
+def test_psd_empty_batch():
+    post = torch.zeros(2, 4, 5)
+    post[..., 0] = 1.0
+    out, nl = O.psd(post, torch.tensor([4, 0]), post, 0)
+    assert out.shape == (2, 0, 5) and nl.tolist() == [0, 0]
+
+
+def test_audio_path(geo, tiny_weights):
+    b, z = golden_batch("audio_psd_right")
+    W = dict(tiny_weights)
+    W["encoder.ctc.ctc_lo.bias"] = torch.from_numpy(z["encoder.ctc.ctc_lo.bias"])
+    W["encoder.ctc.ctc_lo.weight"] = torch.from_numpy(z["encoder.ctc.ctc_lo.weight"])
+    post, _, lens = O.audio_front(W, b["input_features"], b["input_feature_length"], geo["enc_heads"], geo["enc_kernel"])
+    po, pl = O.psd(post, lens, post, 0)
+    assert np.array_equal(pl.numpy(), z["psd_lens"])
+    assert pl.max() < lens.max(), "fixture must exercise merging/filtering"
+    close(po, z["psd_out"], **FP32_TOL)
+    out, grads = O.loss_and_projector_grads(W, b, geo, "fp32", audio=True)
+    close(out["loss"], z["loss"], rtol=1e-5, atol=1e-6)
+    close(out["logits"][out["mask"]], torch.from_numpy(z["logits"])[out["mask"]], **FP32_TOL)
+    for k, g in grads.items():
+        close(g, z["grad." + k[len("encoder_projector."):]], rtol=2e-4, atol=1e-6)
+
+
+def test_adamw_matches_torch():
+    torch.manual_seed(0)
+    p0 = torch.randn(257)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=5e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0)
+    p, m, v = p0.clone(), torch.zeros(257), torch.zeros(257)
+    for step in range(1, 6):
+        g = torch.randn(257)
+        ref.grad = g.clone()
+        opt.step()
+        O.adamw_step(p, g, m, v, step, 5e-5)
+        torch.testing.assert_close(p, ref.data, rtol=1e-6, atol=1e-8)
+    # weight decay knob (torch default 0.01; DeepSpeed FusedAdam default 0.0)
+    ref2 = torch.nn.Parameter(p0.clone())
+    opt2 = torch.optim.AdamW([ref2], lr=1e-3, eps=1e-6, weight_decay=0.01)
+    p, m, v = p0.clone(), torch.zeros(257), torch.zeros(257)
+    g = torch.randn(257)
+    ref2.grad = g.clone()
+    opt2.step()
+    O.adamw_step(p, g, m, v, 1, 1e-3, weight_decay=0.01)
+    torch.testing.assert_close(p, ref2.data, rtol=1e-6, atol=1e-8)
+
+
+def test_warmup_cosine_shape():
+    lr = [O.lr_for_optimizer_step(k, 5e-5) for k in range(1, 15002)]
+    assert lr[0] == 0.0 and lr[1] == 0.0  # DeepSpeed: optimizer.step() precedes scheduler.step(); log(1)=0
+    assert all(b >= a for a, b in zip(lr[:200], lr[1:201]))
+    assert abs(max(lr) - 5e-5) < 1e-9
+    assert abs(lr[-1] - 5e-5 * 1e-4) < 1e-9
