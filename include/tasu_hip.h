@@ -1,0 +1,177 @@
+/* tasu_hip.h -- C-ABI of libtasu_hip.so: the MI355X (gfx950) kernels behind the TASU alignment hot path
+ * (SenseVoiceSmall -> CTC posterior -> LinearSiLU projector -> Qwen2.5 decoder -> CE, AdamW).
+ *
+ * The reference (PigeonDan1/ps-slm) is pure Python and has NO FFI of its own; its plugin boundary is
+ * `model_factory(train_config, model_config, **kwargs)` (Multitask/model/ps-slm.py:130-181, selected by
+ * Multitask/aispeech_asr_config.py:28 through Multitask/utils/model_utils.py:9-33).  Each entry point below
+ * replaces the PyTorch-eager arithmetic of one span of that model's forward/backward; the span is cited on
+ * every declaration.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory unless stated; no ownership transfer;
+ *     the caller allocates every output and workspace.
+ *   - `stream` is a hipStream_t (NULL = default stream); every call is asynchronous on it.
+ *   - return value: 0 = TASU_OK, 1 = bad argument (nothing launched), 2 = launch failure.
+ *   - bf16 = IEEE bfloat16 stored as uint16; "rows" are contiguous along the last dimension; `ld*` are
+ *     leading dimensions in ELEMENTS.
+ *   - token-major activations: [M, D] with M = B*S.
+ */
+#ifndef TASU_HIP_H_
+#define TASU_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TASU_ABI_VERSION 1
+int tasu_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------- GEMM
+ * C[M,N] (+)= A[M,K] . B[N,K]^T (+ bias[N]);  A, B, bias bf16;  fp32 accumulation on MFMA.
+ * Requirements: K % 64 == 0 (pad K with zeros in the layout), lda % 8 == 0, ldb % 8 == 0, A/B 16-B aligned.
+ * Replaces every nn.Linear on the path: transformers modeling_qwen2.py:206-208 (q/k/v), :192 (o_proj),
+ * :46-48 (gate/up/down), :465 (lm_head); Multitask/model/projector.py:141-143; SenseVoice.py:66-67,109-110;
+ * and their autograd dgrad/wgrad (called with the transposed resident copies).                          */
+#define TASU_GEMM_OUT_BF16 0          /* C bf16  = round(acc + bias)                                    */
+#define TASU_GEMM_OUT_F32 1           /* C fp32  = acc + bias                                           */
+#define TASU_GEMM_OUT_F32_RESID_BF16R 2 /* C fp32 = resid fp32 + bf16_round(acc + bias); resid has ldc, may == C */
+int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                      const float* resid, int M, int N, int K, int out_mode, void* stream);
+
+/* Tiled transpose out[c][r] = in[r][c], bf16 (used to feed wgrad through the NT GEMM). rows<=R and
+ * cols<=C outside [R,C) of `out` up to (Cpad, Rpad) are written as zero so K-padding stays exact.       */
+int tasu_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, int R, int C, int Rpad, int Cpad,
+                        void* stream);
+/* fp32 -> bf16 cast (same layout) and fp32 -> bf16 transposed copy; n / R x C as above.                */
+int tasu_cast_f32_bf16(const void* in, void* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------- RMSNorm
+ * Qwen2RMSNorm (modeling_qwen2.py:247-252): y = bf16(w * (x * rsqrt(mean(x^2) + eps))), x fp32 residual
+ * stream.  rstd[M] is saved for backward.  Backward (frozen weight => dgrad only):
+ * dx += rstd * (w.dy - xhat * mean(w.dy.xhat)).                                                         */
+int tasu_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, float* rstd, int M, int D, float eps,
+                     void* stream);
+/* accumulate != 0: dx += ...; else dx = ...   dx_bf16 (optional) receives bf16(dx) after the update: the
+ * gradient the next dgrad GEMM consumes.                                                                */
+int tasu_rmsnorm_bwd(const void* dy_bf16, const float* x, const float* w, const float* rstd, float* dx,
+                     void* dx_bf16, int accumulate, int M, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- RoPE
+ * cos/sin tables from position ids (modeling_qwen2.py:91-102): tab[m][i] = cos/sin(pos[m] * theta^(-2i/hd)),
+ * i < hd/2, fp32.                                                                                       */
+int tasu_rope_table(const int32_t* pos, float* cos_tab, float* sin_tab, int M, int head_dim, float theta,
+                    void* stream);
+/* Rotate q and k heads of the fused qkv activation IN PLACE (rotate-half convention, modeling_qwen2.py:
+ * 113-135, fp32 math, bf16 result) and emit the transposed copies the attention kernels stream:
+ *   qkv    [M, (H+2G)*128] bf16 : q heads | k heads | v heads
+ *   qt     [B, H, 128, S], kt [B, G, 128, S], vt [B, G, 128, S]  (any of them may be NULL)                */
+int tasu_rope_fwd(void* qkv, const float* cos_tab, const float* sin_tab, void* qt, void* kt, void* vt,
+                  int B, int S, int H, int G, void* stream);
+/* Autograd of the above on dqkv [M,(H+2G)*128]: the q block (dQ in rotated space, written by tasu_attn_bwd_dq)
+ * is un-rotated in place; the k and v blocks are produced from the per-query-head fp32 partials of
+ * tasu_attn_bwd_dkv (sum over the H/G heads of each kv group, un-rotate K, round to bf16).               */
+int tasu_rope_bwd(void* dqkv, const float* dk_part, const float* dv_part, const float* cos_tab,
+                  const float* sin_tab, int B, int S, int H, int G, void* stream);
+
+/* ----------------------------------------------------------------------------------------- attention
+ * Causal grouped-query attention with key padding, head_dim 128, bf16 in/out, fp32 online softmax
+ * (modeling_qwen2.py:150-172 / SDPA).  q/k are read from the (rotated) fused qkv buffer, V through its
+ * transposed copy.  key_mask [B,S] uint8 (1 = attend).  Rows with no visible key produce 0.
+ *   out [M, H*128] bf16,  lse [B,H,S] fp32 (log-sum-exp of the scaled scores, for backward).
+ * causal = 0 gives the bidirectional SANM attention of the encoder (SenseVoice.py:171-207).              */
+int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key_mask, void* out, float* lse, int B, int S,
+                  int H, int G, float scale, int causal, void* stream);
+/* Backward.  prep: delta[b,h,s] = sum_d dO.O and dOt [B,H,128,Spad];  dq: dQ (rotated space) into the q block
+ * of dqkv;  dkv: per-QUERY-head fp32 partials dk_part / dv_part [M, H*128] (no atomics; tasu_rope_bwd sums the
+ * H/G heads of each kv group).  Spad = S rounded up to 64; key_mask is [B, Spad] (pad = 0); lse/delta are
+ * [B, H, Spad]; qt/kt/vt/dOt are [B, heads, 128, Spad] with zero token padding.                           */
+int tasu_attn_bwd_prep(const void* dout, const void* out, float* delta, void* dout_t, int B, int S, int H,
+                       void* stream);
+int tasu_attn_bwd_dq(const void* qkv, const void* kt, const uint8_t* key_mask, const void* dout, const float* lse,
+                     const float* delta, void* dqkv, int B, int S, int H, int G, float scale, int causal,
+                     void* stream);
+int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t* key_mask, const void* dout, const void* dout_t,
+                      const float* lse, const float* delta, float* dk_part, float* dv_part, int B, int S, int H, int G,
+                      float scale, int causal, void* stream);
+
+/* -------------------------------------------------------------------------------------------- SwiGLU
+ * act = bf16(bf16(silu(gate)) * up) on the fused [M, 2I] gate|up activation (modeling_qwen2.py:46-48),
+ * and its backward dgu = [dact*up*silu'(gate) | dact*silu(gate)].                                        */
+int tasu_swiglu_fwd(const void* gu, void* act, int M, int I, void* stream);
+int tasu_swiglu_bwd(const void* dact, const void* gu, void* dgu, int M, int I, void* stream);
+/* Plain SiLU (projector.py:142) fwd/bwd, bf16, and ReLU (SenseVoice.py:63) fwd.                         */
+int tasu_silu_fwd(const void* x, void* y, int64_t n, void* stream);
+int tasu_silu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
+int tasu_relu_fwd(const void* x, void* y, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------- cross entropy + token accuracy
+ * transformers loss_utils.py:49-71 (shift, ignore_index -100, mean) + ps-slm.py:533-535 / utils/metric.py
+ * fused over bf16 logits [M, ldv] (V valid columns).  shift_labels[m] = label the row must predict
+ * (-100 = ignored).  Per row: row_loss[m] = logsumexp - logit[label] (0 if ignored), row_hit[m] = argmax ==
+ * label.  If dlogits != NULL it receives (softmax - onehot) * (*inv_count) as bf16 (zeros for ignored rows
+ * and for pad columns [V, ldv)); dlogits may alias logits.  inv_count is a DEVICE float.                  */
+int tasu_ce_fwd_bwd(const void* logits, int ldv, const int32_t* shift_labels, int M, int V, float* row_loss,
+                    int32_t* row_hit, int32_t* row_argmax, void* dlogits, const float* inv_count, void* stream);
+/* out[0] = mean loss, out[1] = hits / count, out[2] = count, out[3] = 1/count (single block, deterministic) */
+int tasu_ce_reduce(const float* row_loss, const int32_t* row_hit, const int32_t* shift_labels, int M, float* out,
+                   void* stream);
+
+/* ----------------------------------------------------------------------------------------- LayerNorm
+ * fp32 LayerNorm over the first D of Dpad columns (projector.py:139 with D = 25055; SenseVoice.py:270-282):
+ * y = bf16 or fp32 ((x - mean) * rstd * gamma + beta); columns [D, Dpad) of y are zero.
+ * Backward for the (trainable) projector LN parameters only: dgamma[j] = sum_r dy[r,j]*xhat[r,j],
+ * dbeta[j] = sum_r dy[r,j].  (The input is a frozen posterior: no dx.)                                   */
+int tasu_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
+                       int y_is_f32, float* mean, float* rstd, int R, int D, float eps, void* stream);
+#define TASU_LN_BWD_SPLIT 16 /* ws must hold 2 * TASU_LN_BWD_SPLIT * D floats (deterministic two-stage sum) */
+int tasu_layernorm_bwd_params(const void* dy_bf16, int lddy, const float* x, int ldx, const float* mean,
+                              const float* rstd, float* dgamma, float* dbeta, float* ws, int R, int D, void* stream);
+/* column sums of a bf16 [R, C] matrix into fp32 (bias gradients).                                        */
+int tasu_colsum_bf16(const void* x, int ld, float* out, int R, int C, void* stream);
+
+/* ------------------------------------------------------------------ text pseudo-posterior (CPS) builder
+ * ps-slm.py:337-358 / :360-409 on device: row r of out [R, V] fp32 = (1-alpha[r])*onehot(ids[r]) + alpha[r]/V,
+ * ids[r] < 0 => zero row (padding); columns [V, ld) are zero.                                             */
+int tasu_posterior_build(const int32_t* ids, const float* alpha, float* out, int ld, int R, int V, void* stream);
+
+/* ------------------------------------------------------------------------------ embedding + merge
+ * ps-slm.py:525 + :679-873.  The integer plan is made on the host (ps_slm_amd/merge.py):
+ *   src_kind[m]: 0 = zero row (padding), 1 = token (src_idx = token id), 2 = audio (src_idx = row of proj).
+ * x[m,:] (fp32 residual stream) = table[src_idx] | float(proj[src_idx]) | 0.                            */
+int tasu_embed_merge_fwd(const float* table, const void* proj_bf16, const int32_t* src_kind, const int32_t* src_idx,
+                         float* x, int M, int D, void* stream);
+/* dproj[r,:] = bf16(dx[audio_rows[r],:]) for r < n_audio (gather of the gradient rows that hold audio).   */
+int tasu_merge_bwd(const float* dx, const int32_t* audio_rows, void* dproj_bf16, int n_audio, int D, void* stream);
+
+/* --------------------------------------------------------------------------------------------- AdamW
+ * DeepSpeed FusedAdam(adam_w_mode) of Multitask/conf/ds_config.json:4-11 over one flat fp32 buffer:
+ * g' = g*grad_scale; m,v update; p = p*(1-lr*wd) - lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps).  Optionally writes
+ * the bf16 working copy of p.  lr is read from DEVICE memory (*lr) so a captured graph can be replayed.   */
+int tasu_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* lr, float beta1,
+               float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* -------------------------------------------------------------------------- SenseVoice encoder pieces
+ * x[b,t,:] = x*scale + sinusoidal PE (SenseVoice.py:26-50,556-558), fp32 in/out, positions 1..T.         */
+int tasu_sinusoid_pe(const float* x, float* y, int B, int T, int D, float scale, void* stream);
+/* FSMN memory block (SenseVoice.py:124-140): depthwise conv k taps over time on masked v + residual, masked.
+ * v: bf16 column block of the fused qkv activation (row stride ldv), w fp32 [D, k], lens int32 [B];
+ * out fp32 [B*T, D] (added to the attention output by the caller through `accumulate`).                  */
+int tasu_fsmn_fwd(const void* v, int ldv, const float* w, const int32_t* lens, float* out, int B, int T, int D,
+                  int ksize, int accumulate, void* stream);
+/* row softmax over V columns, fp32 in / fp32 out (ps-slm.py:451).                                        */
+int tasu_softmax_rows(const float* x, int ldx, float* y, int ldy, int R, int V, void* stream);
+/* PSD (ps-slm.py:237-317) on device, three launches: per-frame argmax + blank prob; per-utterance segment
+ * plan (one thread per utterance; T is a few hundred); segment-mean gather into the padded output.       */
+int tasu_psd_frame_stats(const float* post, int ldp, const int32_t* lens, int32_t* frame_id, float* frame_blank,
+                         int B, int T, int V, int blank_id, void* stream);
+int tasu_psd_plan(const int32_t* frame_id, const float* frame_blank, const int32_t* lens, int32_t* seg_start,
+                  int32_t* seg_len, int32_t* new_lens, int B, int T, int blank_id, float threshold, void* stream);
+int tasu_psd_gather(const float* post, int ldp, const int32_t* seg_start, const int32_t* seg_len,
+                    const int32_t* new_lens, float* out, int ldo, int B, int T, int Tout, int V, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TASU_HIP_H_ */

@@ -269,5 +269,50 @@ def main():
          post_lens=np.asarray([len(p) for p in gen_ids]))
 
 
+def main_mid():
+    """Kernel-compatible geometry (head_dim 128, odd CTC vocabulary): weights come from
+    ps_slm_amd.synthetic.random_state_dict (seeded) and are loaded into the REAL reference; only inputs'
+    seeds and the reference's outputs are stored."""
+    import dataclasses
+
+    from ps_slm_amd.model import Geometry
+    from ps_slm_amd.synthetic import MID_GEOMETRY, random_state_dict, synthetic_text_batch
+
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    gd = dataclasses.asdict(geo)
+    seed_w, seed_b = 2026, 31
+    sd = random_state_dict(geo, seed_w, with_encoder=True)
+    model = build_reference_model(gd, 0, dict(gt_emb=True, gt_emb_noise=False))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert set(missing) <= {"llm.lm_head.weight"}, missing
+    batch = synthetic_text_batch(geo, 3, seed=seed_b, prompt_len=9, n_audio=21, target_len=17, speech_pos=4,
+                                 feat_frames=12, noise=True, drop_prob=0.15, ragged=True)
+    # the reference draws alpha/keep itself; feed the clean path with the already-dropped ids and emulate the
+    # smoothing through the reference's own noise function by replaying its RNG order is not possible with
+    # external draws, so this fixture uses the CLEAN posterior of the kept ids (alpha = 0).
+    kept = [list(np.asarray(p)[np.asarray(k, dtype=bool)]) for p, k in zip(batch["post_ids"], batch["keeps"])]
+    GT = [" ".join(map(str, k)) for k in kept]
+    r = run_fwd_bwd(model, batch, GT, batch["input_features"], batch["input_feature_length"])
+    g = torch.Generator().manual_seed(5)
+    cols = torch.randperm(geo.llm_vocab, generator=g)[:64].sort().values
+    lg = r.pop("logits")
+    save("mid_text_clean", seed_w=seed_w, seed_b=seed_b, loss=r["loss"], acc=r["acc"], cols=cols,
+         logits_cols=lg[:, :, cols], lse=torch.logsumexp(lg, -1), argmax=lg.argmax(-1),
+         **{k: v for k, v in r.items() if k.startswith("grad.") and k != "grad.ffn.2.weight"},
+         **{"grad.ffn.2.weight.even_rows": r["grad.ffn.2.weight"][::2]})
+    # audio path at mid geometry
+    model.gt_emb = False
+    ra = run_fwd_bwd(model, batch, GT, batch["input_features"], batch["input_feature_length"])
+    lga = ra.pop("logits")
+    save("mid_audio", seed_w=seed_w, seed_b=seed_b, loss=ra["loss"], acc=ra["acc"], cols=cols,
+         logits_cols=lga[:, :, cols], lse=torch.logsumexp(lga, -1), argmax=lga.argmax(-1),
+         **{k: v for k, v in ra.items() if k.startswith("grad.") and k not in ("grad.ffn.2.weight", "grad.ffn.0.weight")})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "mid":
+        main_mid()
+    else:
+        main()
+        main_mid()

@@ -1,0 +1,74 @@
+"""ctypes binding of libtasu_hip.so.  Fails loudly: there is NO fallback path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtasu_hip.so")
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argtypes (all return int); mirrors include/tasu_hip.h one to one
+PROTOTYPES = {
+    "tasu_abi_version": [],
+    "tasu_gemm_nt_bf16": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "tasu_transpose_bf16": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "tasu_cast_f32_bf16": [vp, vp, i64, vp],
+    "tasu_rmsnorm_fwd": [vp, vp, vp, vp, i32, i32, f32, vp],
+    "tasu_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "tasu_rope_table": [vp, vp, vp, i32, i32, f32, vp],
+    "tasu_rope_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "tasu_rope_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "tasu_attn_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "tasu_attn_bwd_prep": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "tasu_attn_bwd_dq": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "tasu_attn_bwd_dkv": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "tasu_swiglu_fwd": [vp, vp, i32, i32, vp],
+    "tasu_swiglu_bwd": [vp, vp, vp, i32, i32, vp],
+    "tasu_silu_fwd": [vp, vp, i64, vp],
+    "tasu_silu_bwd": [vp, vp, vp, i64, vp],
+    "tasu_relu_fwd": [vp, vp, i64, vp],
+    "tasu_ce_fwd_bwd": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp],
+    "tasu_ce_reduce": [vp, vp, vp, i32, vp, vp],
+    "tasu_layernorm_fwd": [vp, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, f32, vp],
+    "tasu_layernorm_bwd_params": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp],
+    "tasu_colsum_bf16": [vp, i32, vp, i32, i32, vp],
+    "tasu_posterior_build": [vp, vp, vp, i32, i32, i32, vp],
+    "tasu_embed_merge_fwd": [vp, vp, vp, vp, vp, i32, i32, vp],
+    "tasu_merge_bwd": [vp, vp, vp, i32, i32, vp],
+    "tasu_adamw": [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, i32, f32, vp],
+    "tasu_sinusoid_pe": [vp, vp, i32, i32, i32, f32, vp],
+    "tasu_fsmn_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "tasu_softmax_rows": [vp, i32, vp, i32, i32, i32, vp],
+    "tasu_psd_frame_stats": [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
+    "tasu_psd_plan": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "tasu_psd_gather": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class TasuLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libtasu_hip.so (built by ``__graft_entry__.build()`` / ``make -C ps_slm_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise TasuLibraryError(f"{LIB_PATH} is missing: build it with `make -C ps_slm_amd/csrc` "
+                               f"(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise TasuLibraryError(f"{LIB_PATH} does not export {name} (stale build?)") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.tasu_abi_version() != ABI_VERSION:
+        raise TasuLibraryError(f"ABI version mismatch: library {lib.tasu_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib

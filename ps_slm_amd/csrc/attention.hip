@@ -1,0 +1,439 @@
+// Flash-style attention for gfx950, head_dim 128, bf16 I/O, fp32 online softmax, MFMA 16x16x32.
+// Replaces the SDPA call inside Qwen2Attention.forward (transformers modeling_qwen2.py:150-172, causal GQA with
+// key padding) and, with causal = 0, the softmax(QK^T)V of MultiHeadedAttentionSANM (SenseVoice.py:171-207).
+//
+// Design ("query index stays on lane&15"): every product is issued so that the index that needs row
+// statistics (the query for fwd/dq, the key for dk/dv) is the MFMA *column* (lane & 15), and the reduced
+// index of the NEXT product is what the accumulator registers enumerate.  A 16x16 score tile then feeds the
+// following MFMA as a register operand with no LDS round trip: the two 16-wide score tiles of a 32-deep
+// k-step are packed as k-slots {4q'+r | 16+4q'+r}, and the other operand is read from LDS in that same
+// permuted order (two 8-byte reads).  Operands whose reduced index is the token index are streamed from
+// pre-transposed [128, S] copies written by the RoPE / prep kernels, so every LDS tile is read along its
+// contiguous dimension with ds_read_b128 / ds_read_b64 and an XOR swizzle (no transposed LDS reads).
+//
+// Tiles: 64 queries x 64 keys per step, 256 threads = 4 waves, each wave owns 16 of the 64 rows.
+#include "common.h"
+#include "../../include/tasu_hip.h"
+
+namespace {
+
+constexpr int HD = 128;
+
+// ---- LDS tile images ---------------------------------------------------------------------------------
+// "row" image : [64 tokens][128 d] bf16, 256-B rows, 16-B chunk c of row r stored at c ^ (r & 15)
+// "tr"  image : [128 d][64 tokens] bf16, 128-B rows, 16-B chunk c of row r stored at c ^ ((r >> 1) & 7)
+constexpr int ROW_TILE_BYTES = 64 * 256;
+constexpr int TR_TILE_BYTES = 128 * 128;
+
+// load a [64][128] tile whose rows are tokens tok0.. of a token-major matrix (row stride ld elements) into
+// the "row" image.  Rows >= nrows are clamped (callers mask them).
+__device__ __forceinline__ void load_row_tile(char* lds, const bf16* g, int ld, int tok0, int nrows) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = i * 256 + threadIdx.x;
+    const int r = idx >> 4, c = idx & 15;
+    const int tok = min(tok0 + r, nrows - 1);
+    const bf16x8 v = *(const bf16x8*)(g + (size_t)tok * ld + c * 8);
+    *(bf16x8*)(lds + r * 256 + ((c ^ (r & 15)) << 4)) = v;
+  }
+}
+// load a [128][64] tile (rows d, columns tokens tok0..tok0+63) of a [128, Spad] matrix into the "tr" image.
+__device__ __forceinline__ void load_tr_tile(char* lds, const bf16* g, int spad, int tok0) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = i * 256 + threadIdx.x;
+    const int r = idx >> 3, c = idx & 7;
+    const bf16x8 v = *(const bf16x8*)(g + (size_t)r * spad + tok0 + c * 8);
+    *(bf16x8*)(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = v;
+  }
+}
+// MFMA operand (16 rows = tile rows sub*16 + (lane&15), k = d in [32ks + 8q', +8)) from a "row" image.
+__device__ __forceinline__ bf16x8 frag_row(const char* lds, int sub, int ks, int lane) {
+  const int r = sub * 16 + (lane & 15);
+  const int c = ks * 4 + (lane >> 4);
+  return *(const bf16x8*)(lds + r * 256 + ((c ^ (lane & 15)) << 4));
+}
+// MFMA operand (16 rows = d in nt*16 + (lane&15), k-slots of token block tb (32 tokens):
+// element j <-> token tb*32 + (j<4 ? 4q'+j : 16+4q'+j-4)) from a "tr" image.
+__device__ __forceinline__ bf16x8 frag_tr(const char* lds, int nt, int tb, int lane) {
+  const int r = nt * 16 + (lane & 15);
+  const int qp = lane >> 4;
+  const int sw = (r >> 1) & 7;
+  const int t0 = tb * 32 + 4 * qp;  // first 4 tokens
+  const int t1 = t0 + 16;           // second 4 tokens
+  const bf16x4 lo = *(const bf16x4*)(lds + r * 128 + (((t0 >> 3) ^ sw) << 4) + (t0 & 7) * 2);
+  const bf16x4 hi = *(const bf16x4*)(lds + r * 128 + (((t1 >> 3) ^ sw) << 4) + (t1 & 7) * 2);
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+// pack two 16-wide score tiles (fp32 accumulators) into the k-slot order frag_tr uses.
+__device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
+  bf16x8 o;
+  o[0] = (bf16)a[0]; o[1] = (bf16)a[1]; o[2] = (bf16)a[2]; o[3] = (bf16)a[3];
+  o[4] = (bf16)b[0]; o[5] = (bf16)b[1]; o[6] = (bf16)b[2]; o[7] = (bf16)b[3];
+  return o;
+}
+// operand straight from global: row `tok` of a token-major matrix, d in [32ks + 8q', +8), ks = 0..3
+__device__ __forceinline__ void load_row_frags(bf16x8 f[4], const bf16* g, int ld, int tok, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) f[ks] = *(const bf16x8*)(g + (size_t)tok * ld + ks * 32 + (lane >> 4) * 8);
+}
+
+constexpr float NEG_INF = -__builtin_inff();
+
+// ======================================================================================= forward
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
+                                                          const uint8_t* __restrict__ kmask, bf16* __restrict__ out,
+                                                          float* __restrict__ lse, int S, int Spad, int H, int G,
+                                                          float scale, int causal) {
+  __shared__ __attribute__((aligned(16))) char smem[ROW_TILE_BYTES + TR_TILE_BYTES];
+  char* sK = smem;
+  char* sVt = smem + ROW_TILE_BYTES;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int g = h / (H / G);
+  const int LD = (H + 2 * G) * HD;
+  const bf16* qbase = qkv + (size_t)b * S * LD + h * HD;
+  const bf16* kbase = qkv + (size_t)b * S * LD + (H + g) * HD;
+  const bf16* vtbase = vt + ((size_t)b * G + g) * HD * Spad;
+  const uint8_t* mrow = kmask + (size_t)b * Spad;
+
+  const int qpos = qt * 64 + wave * 16 + (lane & 15);
+  const int qp = lane >> 4;
+  bf16x8 qf[4];
+  load_row_frags(qf, qbase, LD, min(qpos, S - 1), lane);
+
+  f32x4 o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_INF, l_run = 0.f;
+
+  const int nkt = causal ? (qt + 1) : ((S + 63) >> 6);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    load_row_tile(sK, kbase, LD, kt * 64, S);
+    load_tr_tile(sVt, vtbase, Spad, kt * 64);
+    __syncthreads();
+
+    f32x4 s[4];
+    float tmax = NEG_INF;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a = mfma16(frag_row(sK, st, ks, lane), qf[ks], a);
+      const int key0 = kt * 64 + st * 16 + 4 * qp;
+      const uint32_t mk = *(const uint32_t*)(mrow + key0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + r;
+        const bool ok = ((mk >> (8 * r)) & 0xff) && (!causal || key <= qpos);
+        a[r] = ok ? a[r] * scale : NEG_INF;
+        tmax = fmaxf(tmax, a[r]);
+      }
+      s[st] = a;
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_use);  // m_run = -inf -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[st][r] - m_use);
+        s[st][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) o[nt] *= alpha;
+    const bf16x8 pf0 = pack_pair(s[0], s[1]);
+    const bf16x8 pf1 = pack_pair(s[2], s[3]);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      o[nt] = mfma16(frag_tr(sVt, nt, 0, lane), pf0, o[nt]);
+      o[nt] = mfma16(frag_tr(sVt, nt, 1, lane), pf1, o[nt]);
+    }
+  }
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  if (qpos < S) {
+    bf16* orow = out + ((size_t)b * S + qpos) * (H * HD) + h * HD;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const f32x4 v = o[nt] * inv;
+      *(bf16x4*)(orow + nt * 16 + 4 * qp) = __builtin_convertvector(v, bf16x4);
+    }
+    if (qp == 0) lse[((size_t)b * H + h) * Spad + qpos] = l_tot > 0.f ? m_run + __logf(l_tot) : 0.f;
+  }
+}
+
+// =============================================================================== backward: prep
+// delta[b,h,s] = sum_d dO*O ; dOt[b,h,d,s] = dO[b,s,h,d].  One block per (64 tokens, head, batch).
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
+                                                            float* __restrict__ delta, bf16* __restrict__ dout_t, int S,
+                                                            int Spad, int H) {
+  __shared__ bf16 tile[64][HD + 2];
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int tl = threadIdx.x >> 2, part = threadIdx.x & 3;  // 4 threads per token, 32 d each
+  const int tok = t0 + tl;
+  float acc = 0.f;
+  if (tok < S) {
+    const bf16* dr = dout + ((size_t)b * S + tok) * (H * HD) + h * HD + part * 32;
+    const bf16* orr = out + ((size_t)b * S + tok) * (H * HD) + h * HD + part * 32;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bf16x8 dv = *(const bf16x8*)(dr + c * 8);
+      const bf16x8 ov = *(const bf16x8*)(orr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc += (float)dv[j] * (float)ov[j];
+        tile[tl][part * 32 + c * 8 + j] = dv[j];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) tile[tl][part * 32 + j] = (bf16)0.f;
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  if (part == 0 && tok < S) delta[((size_t)b * H + h) * Spad + tok] = acc;
+  __syncthreads();
+  // transposed write: thread -> d = tid>>1, 32 tokens
+  const int d = threadIdx.x >> 1, half = threadIdx.x & 1;
+  bf16* dst = dout_t + (((size_t)b * H + h) * HD + d) * Spad + t0 + half * 32;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[half * 32 + c * 8 + j][d];
+    *(bf16x8*)(dst + c * 8) = v;
+  }
+}
+
+// =============================================================================== backward: dQ
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ kt_g,
+                                                             const uint8_t* __restrict__ kmask,
+                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                             int S, int Spad, int H, int G, float scale, int causal) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * ROW_TILE_BYTES + TR_TILE_BYTES];
+  char* sK = smem;
+  char* sV = smem + ROW_TILE_BYTES;
+  char* sKt = smem + 2 * ROW_TILE_BYTES;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int g = h / (H / G);
+  const int LD = (H + 2 * G) * HD;
+  const bf16* qbase = qkv + (size_t)b * S * LD + h * HD;
+  const bf16* kbase = qkv + (size_t)b * S * LD + (H + g) * HD;
+  const bf16* vbase = qkv + (size_t)b * S * LD + (H + G + g) * HD;
+  const bf16* ktbase = kt_g + ((size_t)b * G + g) * HD * Spad;
+  const uint8_t* mrow = kmask + (size_t)b * Spad;
+  const int qpos = qt * 64 + wave * 16 + (lane & 15);
+  const int qc = min(qpos, S - 1);
+  const int qp = lane >> 4;
+  bf16x8 qf[4], dof[4];
+  load_row_frags(qf, qbase, LD, qc, lane);
+  load_row_frags(dof, dout + (size_t)b * S * (H * HD) + h * HD, H * HD, qc, lane);
+  const float lse_q = lse[((size_t)b * H + h) * Spad + qc];
+  const float dl_q = delta[((size_t)b * H + h) * Spad + qc];
+
+  f32x4 dq[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = causal ? (qt + 1) : ((S + 63) >> 6);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    load_row_tile(sK, kbase, LD, kt * 64, S);
+    load_row_tile(sV, vbase, LD, kt * 64, S);
+    load_tr_tile(sKt, ktbase, Spad, kt * 64);
+    __syncthreads();
+    f32x4 ds[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        a = mfma16(frag_row(sK, st, ks, lane), qf[ks], a);
+        dp = mfma16(frag_row(sV, st, ks, lane), dof[ks], dp);
+      }
+      const int key0 = kt * 64 + st * 16 + 4 * qp;
+      const uint32_t mk = *(const uint32_t*)(mrow + key0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + r;
+        const bool ok = ((mk >> (8 * r)) & 0xff) && (!causal || key <= qpos);
+        const float p = ok ? __expf(a[r] * scale - lse_q) : 0.f;
+        ds[st][r] = p * (dp[r] - dl_q);
+      }
+    }
+    const bf16x8 f0 = pack_pair(ds[0], ds[1]);
+    const bf16x8 f1 = pack_pair(ds[2], ds[3]);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      dq[nt] = mfma16(frag_tr(sKt, nt, 0, lane), f0, dq[nt]);
+      dq[nt] = mfma16(frag_tr(sKt, nt, 1, lane), f1, dq[nt]);
+    }
+  }
+  if (qpos < S) {
+    bf16* drow = dqkv + ((size_t)b * S + qpos) * LD + h * HD;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const f32x4 v = dq[nt] * scale;
+      *(bf16x4*)(drow + nt * 16 + 4 * qp) = __builtin_convertvector(v, bf16x4);
+    }
+  }
+}
+
+// =============================================================================== backward: dK, dV (per q head)
+// One block per (64 keys, query head h, batch).  Writes fp32 partials dk_part / dv_part [M, H*128]; the 6
+// query heads of a kv head are summed (and K un-rotated) by tasu_gqa_reduce_rope_bwd.
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ qt_g,
+                                                              const uint8_t* __restrict__ kmask,
+                                                              const bf16* __restrict__ dout,
+                                                              const bf16* __restrict__ dout_t,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              float* __restrict__ dk_part, float* __restrict__ dv_part, int S,
+                                                              int Spad, int H, int G, float scale, int causal) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * ROW_TILE_BYTES + 2 * TR_TILE_BYTES];
+  char* sQ = smem;
+  char* sdO = smem + ROW_TILE_BYTES;
+  char* sQt = smem + 2 * ROW_TILE_BYTES;
+  char* sdOt = smem + 2 * ROW_TILE_BYTES + TR_TILE_BYTES;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ktile = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int g = h / (H / G);
+  const int LD = (H + 2 * G) * HD;
+  const bf16* qbase = qkv + (size_t)b * S * LD + h * HD;
+  const bf16* kbase = qkv + (size_t)b * S * LD + (H + g) * HD;
+  const bf16* vbase = qkv + (size_t)b * S * LD + (H + G + g) * HD;
+  const bf16* dobase = dout + (size_t)b * S * (H * HD) + h * HD;
+  const bf16* qtbase = qt_g + ((size_t)b * H + h) * HD * Spad;
+  const bf16* dotbase = dout_t + ((size_t)b * H + h) * HD * Spad;
+  const float* lrow = lse + ((size_t)b * H + h) * Spad;
+  const float* drow = delta + ((size_t)b * H + h) * Spad;
+  const int kpos = ktile * 64 + wave * 16 + (lane & 15);
+  const int kc = min(kpos, S - 1);
+  const int qp = lane >> 4;
+  const bool kvalid = kpos < S && kmask[(size_t)b * Spad + kc] != 0;
+  bf16x8 kf[4], vf[4];
+  load_row_frags(kf, kbase, LD, kc, lane);
+  load_row_frags(vf, vbase, LD, kc, lane);
+
+  f32x4 dk[8], dv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    dk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nqt = (S + 63) >> 6;
+  for (int qtile = causal ? ktile : 0; qtile < nqt; ++qtile) {
+    __syncthreads();
+    load_row_tile(sQ, qbase, LD, qtile * 64, S);
+    load_row_tile(sdO, dobase, H * HD, qtile * 64, S);
+    load_tr_tile(sQt, qtbase, Spad, qtile * 64);
+    load_tr_tile(sdOt, dotbase, Spad, qtile * 64);
+    __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {  // 32 query rows at a time keeps the live set under 256 VGPRs
+      f32x4 pv[2], ds[2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int qs = qb * 2 + q2;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          a = mfma16(frag_row(sQ, qs, ks, lane), kf[ks], a);
+          dp = mfma16(frag_row(sdO, qs, ks, lane), vf[ks], dp);
+        }
+        const int q0 = qtile * 64 + qs * 16 + 4 * qp;  // < Spad
+        const f32x4 l4 = *(const f32x4*)(lrow + q0);
+        const f32x4 d4 = *(const f32x4*)(drow + q0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = q0 + r;
+          const bool ok = kvalid && q < S && (!causal || kpos <= q);
+          const float p = ok ? __expf(a[r] * scale - l4[r]) : 0.f;
+          pv[q2][r] = p;
+          ds[q2][r] = ok ? p * (dp[r] - d4[r]) : 0.f;
+        }
+      }
+      const bf16x8 pf = pack_pair(pv[0], pv[1]);
+      const bf16x8 sf = pack_pair(ds[0], ds[1]);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        dv[nt] = mfma16(frag_tr(sdOt, nt, qb, lane), pf, dv[nt]);
+        dk[nt] = mfma16(frag_tr(sQt, nt, qb, lane), sf, dk[nt]);
+      }
+    }
+  }
+  if (kpos < S) {
+    float* dkr = dk_part + ((size_t)b * S + kpos) * (H * HD) + h * HD;
+    float* dvr = dv_part + ((size_t)b * S + kpos) * (H * HD) + h * HD;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      *(f32x4*)(dkr + nt * 16 + 4 * qp) = dk[nt] * scale;
+      *(f32x4*)(dvr + nt * 16 + 4 * qp) = dv[nt];
+    }
+  }
+}
+
+}  // namespace
+
+static inline bool bad_geo(int B, int S, int H, int G) { return B <= 0 || S <= 0 || H <= 0 || G <= 0 || H % G != 0; }
+static inline int spad_of(int S) { return (S + 63) & ~63; }
+
+extern "C" int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key_mask, void* out, float* lse, int B,
+                             int S, int H, int G, float scale, int causal, void* stream) {
+  if (!qkv || !vt || !key_mask || !out || !lse || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
+  dim3 grid((S + 63) / 64, H, B);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)vt,
+                     key_mask, (bf16*)out, lse, S, spad_of(S), H, G, scale, causal);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+
+extern "C" int tasu_attn_bwd_prep(const void* dout, const void* out, float* delta, void* dout_t, int B, int S, int H,
+                                  void* stream) {
+  if (!dout || !out || !delta || !dout_t || B <= 0 || S <= 0 || H <= 0) return TASU_ERR_ARG;
+  dim3 grid((S + 63) / 64, H, B);
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dout,
+                     (const bf16*)out, delta, (bf16*)dout_t, S, spad_of(S), H);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+
+extern "C" int tasu_attn_bwd_dq(const void* qkv, const void* kt, const uint8_t* key_mask, const void* dout,
+                                const float* lse, const float* delta, void* dqkv, int B, int S, int H, int G,
+                                float scale, int causal, void* stream) {
+  if (!qkv || !kt || !key_mask || !dout || !lse || !delta || !dqkv || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
+  dim3 grid((S + 63) / 64, H, B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)kt,
+                     key_mask, (const bf16*)dout, lse, delta, (bf16*)dqkv, S, spad_of(S), H, G, scale, causal);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+
+extern "C" int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t* key_mask, const void* dout,
+                                 const void* dout_t, const float* lse, const float* delta, float* dk_part,
+                                 float* dv_part, int B, int S, int H, int G, float scale, int causal, void* stream) {
+  if (!qkv || !qt || !key_mask || !dout || !dout_t || !lse || !delta || !dk_part || !dv_part || bad_geo(B, S, H, G))
+    return TASU_ERR_ARG;
+  dim3 grid((S + 63) / 64, H, B);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)qt,
+                     key_mask, (const bf16*)dout, (const bf16*)dout_t, lse, delta, dk_part, dv_part, S, spad_of(S), H, G,
+                     scale, causal);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}

@@ -1,0 +1,216 @@
+// Audio-path helpers around the SenseVoice SANM encoder (Multitask/model/SenseVoice.py) and the PSD
+// down-sampler (Multitask/model/ps-slm.py:237-317).  GEMMs and attention come from gemm.hip / attention.hip.
+#include "common.h"
+#include "../../include/tasu_hip.h"
+
+namespace {
+
+// y = x*scale + PE;  PE(t, d) = sin((t+1) * exp(-d*inc)) for d < D/2, cos(...) for d >= D/2,
+// inc = ln(1e4) / (D/2 - 1)          (SenseVoice.py:26-50, :556-558)
+__global__ void sinusoid_pe_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int D, float scale,
+                                   int64_t total) {
+  const int half = D / 2;
+  const float inc = logf(10000.f) / (float)(half - 1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int t = (int)((i / D) % T);
+    const int k = d < half ? d : d - half;
+    const float ang = (float)(t + 1) * expf(-(float)k * inc);
+    y[i] = x[i] * scale + (d < half ? sinf(ang) : cosf(ang));
+  }
+}
+
+// FSMN memory (SenseVoice.py:124-140): out[b,t,d] (+)= mask_t * (sum_j w[d][j] * vm[t+j-left] + vm[t]), vm = v*mask
+__global__ void fsmn_kernel(const bf16* __restrict__ v, int ldv, const float* __restrict__ w, const int32_t* __restrict__ lens,
+                            float* __restrict__ out, int T, int D, int ksize, int accumulate, int64_t total) {
+  const int left = (ksize - 1) / 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int64_t bt = i / D;
+    const int t = (int)(bt % T);
+    const int b = (int)(bt / T);
+    const int len = lens[b];
+    float r = 0.f;
+    if (t < len) {
+      for (int j = 0; j < ksize; ++j) {
+        const int tt = t + j - left;
+        if (tt >= 0 && tt < len) r += w[d * ksize + j] * (float)v[((size_t)b * T + tt) * ldv + d];
+      }
+      r += (float)v[((size_t)b * T + t) * ldv + d];
+    }
+    out[i] = accumulate ? out[i] + r : r;
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                           int V) {
+  __shared__ float red[4];
+  const float* xr = x + (size_t)blockIdx.x * ldx;
+  float* yr = y + (size_t)blockIdx.x * ldy;
+  float m = -__builtin_inff();
+  for (int c = threadIdx.x; c < V; c += 256) m = fmaxf(m, xr[c]);
+  m = block_max<4>(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) s += expf(xr[c] - m);
+  s = block_sum<4>(s, red);
+  const float inv = 1.f / s;
+  for (int c = threadIdx.x; c < ldy; c += 256) yr[c] = c < V ? expf(xr[c] - m) * inv : 0.f;
+}
+
+// per frame: argmax id (first index on ties) and blank probability.  grid B*T blocks.
+__global__ __launch_bounds__(256) void psd_frame_stats_kernel(const float* __restrict__ post, int ldp,
+                                                              const int32_t* __restrict__ lens, int32_t* __restrict__ fid,
+                                                              float* __restrict__ fblank, int T, int V, int blank_id) {
+  __shared__ float rv[4];
+  __shared__ int ri[4];
+  const int bt = blockIdx.x;
+  const int b = bt / T, t = bt - b * T;
+  if (t >= lens[b]) {
+    if (threadIdx.x == 0) {
+      fid[bt] = -1;
+      fblank[bt] = 0.f;
+    }
+    return;
+  }
+  const float* pr = post + (size_t)bt * ldp;
+  float best = -__builtin_inff();
+  int arg = 0x7fffffff;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    const float f = pr[c];
+    if (f > best) {
+      best = f;
+      arg = c;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oa = __shfl_xor(arg, o, 64);
+    if (ob > best || (ob == best && oa < arg)) {
+      best = ob;
+      arg = oa;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    rv[threadIdx.x >> 6] = best;
+    ri[threadIdx.x >> 6] = arg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i)
+      if (rv[i] > best || (rv[i] == best && ri[i] < arg)) {
+        best = rv[i];
+        arg = ri[i];
+      }
+    fid[bt] = arg;
+    fblank[bt] = pr[blank_id];
+  }
+}
+
+// one thread per utterance: run-length segments of equal non-blank ids (blank frames stay single), blank filter.
+__global__ void psd_plan_kernel(const int32_t* __restrict__ fid, const float* __restrict__ fblank,
+                                const int32_t* __restrict__ lens, int32_t* __restrict__ seg_start, int32_t* __restrict__ seg_len,
+                                int32_t* __restrict__ new_lens, int B, int T, int blank_id, float thr) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int L = lens[b];
+  const int32_t* id = fid + (size_t)b * T;
+  const float* bp = fblank + (size_t)b * T;
+  int n = 0, start = 0;
+  for (int end = 1; end <= L; ++end) {
+    if (end == L || id[end] != id[start] || id[start] == blank_id) {
+      // (blank frames: every frame closes its own segment)
+      const int len = end - start;
+      float s = 0.f;
+      for (int t = start; t < end; ++t) s += bp[t];
+      const float mean = len == 1 ? s : s / (float)len;
+      if (mean < thr) {
+        seg_start[(size_t)b * T + n] = start;
+        seg_len[(size_t)b * T + n] = len;
+        ++n;
+      }
+      start = end;
+    }
+  }
+  new_lens[b] = n;
+}
+
+// out[b, j, :] = mean of post rows seg_start..+len (j < new_lens[b]) else 0.   grid (Tout, B)
+__global__ __launch_bounds__(256) void psd_gather_kernel(const float* __restrict__ post, int ldp,
+                                                         const int32_t* __restrict__ seg_start,
+                                                         const int32_t* __restrict__ seg_len,
+                                                         const int32_t* __restrict__ new_lens, float* __restrict__ out, int ldo,
+                                                         int T, int Tout, int V) {
+  const int j = blockIdx.x, b = blockIdx.y;
+  float* o = out + ((size_t)b * Tout + j) * ldo;
+  if (j >= new_lens[b]) {
+    for (int c = threadIdx.x; c < ldo; c += 256) o[c] = 0.f;
+    return;
+  }
+  const int s0 = seg_start[(size_t)b * T + j], len = seg_len[(size_t)b * T + j];
+  const float* p0 = post + ((size_t)b * T + s0) * ldp;
+  for (int c = threadIdx.x; c < ldo; c += 256) {
+    float s = 0.f;
+    if (c < V) {
+      for (int t = 0; t < len; ++t) s += p0[(size_t)t * ldp + c];
+      if (len > 1) s /= (float)len;
+    }
+    o[c] = s;
+  }
+}
+
+inline int grid_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+}  // namespace
+
+extern "C" int tasu_sinusoid_pe(const float* x, float* y, int B, int T, int D, float scale, void* stream) {
+  if (!x || !y || B <= 0 || T <= 0 || D < 4 || D % 2) return TASU_ERR_ARG;
+  const int64_t total = (int64_t)B * T * D;
+  hipLaunchKernelGGL(sinusoid_pe_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, T, D, scale, total);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+extern "C" int tasu_fsmn_fwd(const void* v, int ldv, const float* w, const int32_t* lens, float* out, int B, int T, int D,
+                             int ksize, int accumulate, void* stream) {
+  if (!v || !w || !lens || !out || B <= 0 || T <= 0 || D <= 0 || ksize <= 0) return TASU_ERR_ARG;
+  const int64_t total = (int64_t)B * T * D;
+  hipLaunchKernelGGL(fsmn_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)v, ldv, w, lens,
+                     out, T, D, ksize, accumulate, total);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+extern "C" int tasu_softmax_rows(const float* x, int ldx, float* y, int ldy, int R, int V, void* stream) {
+  if (!x || !y || R <= 0 || V <= 0 || ldx < V || ldy < V) return TASU_ERR_ARG;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, V);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+extern "C" int tasu_psd_frame_stats(const float* post, int ldp, const int32_t* lens, int32_t* frame_id, float* frame_blank,
+                                    int B, int T, int V, int blank_id, void* stream) {
+  if (!post || !lens || !frame_id || !frame_blank || B <= 0 || T <= 0 || V <= 0 || blank_id < 0 || blank_id >= V)
+    return TASU_ERR_ARG;
+  hipLaunchKernelGGL(psd_frame_stats_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, post, ldp, lens, frame_id,
+                     frame_blank, T, V, blank_id);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+extern "C" int tasu_psd_plan(const int32_t* frame_id, const float* frame_blank, const int32_t* lens, int32_t* seg_start,
+                             int32_t* seg_len, int32_t* new_lens, int B, int T, int blank_id, float threshold,
+                             void* stream) {
+  if (!frame_id || !frame_blank || !lens || !seg_start || !seg_len || !new_lens || B <= 0 || T <= 0) return TASU_ERR_ARG;
+  hipLaunchKernelGGL(psd_plan_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, frame_id, frame_blank, lens,
+                     seg_start, seg_len, new_lens, B, T, blank_id, threshold);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+extern "C" int tasu_psd_gather(const float* post, int ldp, const int32_t* seg_start, const int32_t* seg_len,
+                               const int32_t* new_lens, float* out, int ldo, int B, int T, int Tout, int V, void* stream) {
+  if (!post || !seg_start || !seg_len || !new_lens || !out || B <= 0 || T <= 0 || Tout <= 0 || V <= 0 || ldo < V)
+    return TASU_ERR_ARG;
+  hipLaunchKernelGGL(psd_gather_kernel, dim3(Tout, B), dim3(256), 0, (hipStream_t)stream, post, ldp, seg_start, seg_len,
+                     new_lens, out, ldo, T, Tout, V);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}

@@ -1,0 +1,200 @@
+// RMSNorm (Qwen2RMSNorm, transformers modeling_qwen2.py:247-252) fwd + dgrad, LayerNorm (projector.py:139 over
+// D = 25055; SenseVoice.py:270-282 over 560/512) fwd + parameter gradients, column sums (bias gradients).
+// All HBM-bound: 16-byte accesses, wavefront-shuffle reductions, fp32 statistics.
+#include "common.h"
+#include "../../include/tasu_hip.h"
+
+namespace {
+
+// one wave per row, 4 rows per 256-thread block.  D % 4 == 0.
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          bf16* __restrict__ y, float* __restrict__ rstd, int M, int D,
+                                                          float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * D;
+  float ss = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 v = *(const f32x4*)(xr + c);
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)D + eps);
+  if (lane == 0 && rstd) rstd[row] = r;
+  bf16* yr = y + (size_t)row * D;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 v = *(const f32x4*)(xr + c);
+    const f32x4 g = *(const f32x4*)(w + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[j] * r);
+    *(bf16x4*)(yr + c) = __builtin_convertvector(o, bf16x4);
+  }
+}
+
+// dx += rstd * (w*dy - xhat * mean(w*dy*xhat)),  xhat = x * rstd
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ w, const float* __restrict__ rstd,
+                                                          float* __restrict__ dx, bf16* __restrict__ dxb, int accumulate,
+                                                          int M, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * D;
+  const bf16* dr = dy + (size_t)row * D;
+  const float r = rstd[row];
+  float dot = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 v = *(const f32x4*)(xr + c);
+    const f32x4 g = *(const f32x4*)(w + c);
+    const f32x4 d = __builtin_convertvector(*(const bf16x4*)(dr + c), f32x4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dot += g[j] * d[j] * v[j] * r;
+  }
+  dot = wave_sum(dot) / (float)D;
+  float* dxr = dx + (size_t)row * D;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 v = *(const f32x4*)(xr + c);
+    const f32x4 g = *(const f32x4*)(w + c);
+    const f32x4 d = __builtin_convertvector(*(const bf16x4*)(dr + c), f32x4);
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (accumulate) o = *(const f32x4*)(dxr + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] += r * (g[j] * d[j] - v[j] * r * dot);
+    *(f32x4*)(dxr + c) = o;
+    if (dxb) *(bf16x4*)(dxb + (size_t)row * D + c) = __builtin_convertvector(o, bf16x4);
+  }
+}
+
+// LayerNorm forward: one 256-thread block per row, two-pass statistics (mean, then centered variance).
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            void* __restrict__ y, int ldy, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int D, float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const float* xr = x + (size_t)row * ldx;
+  const bool vec = ((ldx & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
+  const int D4 = vec ? (D & ~3) : 0;
+  float s = 0.f;
+  for (int c = threadIdx.x * 4; c < D4; c += 1024) {
+    const f32x4 v = *(const f32x4*)(xr + c);
+    s += v[0] + v[1] + v[2] + v[3];
+  }
+  for (int c = D4 + threadIdx.x; c < D; c += 256) s += xr[c];
+  const float mu = block_sum<4>(s, red) / (float)D;
+  float q = 0.f;
+  for (int c = threadIdx.x * 4; c < D4; c += 1024) {
+    const f32x4 v = *(const f32x4*)(xr + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q += (v[j] - mu) * (v[j] - mu);
+  }
+  for (int c = D4 + threadIdx.x; c < D; c += 256) q += (xr[c] - mu) * (xr[c] - mu);
+  const float var = block_sum<4>(q, red) / (float)D;
+  const float r = rsqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = r;
+  }
+  for (int c = threadIdx.x; c < ldy; c += 256) {
+    const float o = c < D ? (xr[c] - mu) * r * gamma[c] + beta[c] : 0.f;
+    if (OUT_F32)
+      ((float*)y)[(size_t)row * ldy + c] = o;
+    else
+      ((bf16*)y)[(size_t)row * ldy + c] = (bf16)o;
+  }
+}
+
+// dgamma/dbeta partials: grid (ceil(D/256), RSPLIT); thread = one column; rows r = split, split+RSPLIT, ...
+// ws layout: [RSPLIT][2][Dws] fp32.
+__global__ __launch_bounds__(256) void layernorm_bwd_partial_kernel(const bf16* __restrict__ dy, int lddy,
+                                                                    const float* __restrict__ x, int ldx,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, float* __restrict__ ws,
+                                                                    int R, int D) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int split = blockIdx.y, nsplit = gridDim.y;
+  if (c >= D) return;
+  float dg = 0.f, db = 0.f;
+  for (int r = split; r < R; r += nsplit) {
+    const float d = (float)dy[(size_t)r * lddy + c];
+    const float xh = (x[(size_t)r * ldx + c] - mean[r]) * rstd[r];
+    dg += d * xh;
+    db += d;
+  }
+  ws[((size_t)split * 2 + 0) * D + c] = dg;
+  ws[((size_t)split * 2 + 1) * D + c] = db;
+}
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, int nsplit, int D) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  float dg = 0.f, db = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    dg += ws[((size_t)s * 2 + 0) * D + c];
+    db += ws[((size_t)s * 2 + 1) * D + c];
+  }
+  dgamma[c] = dg;
+  dbeta[c] = db;
+}
+
+// column sums of bf16 [R, C]: grid ceil(C/256); thread = column; fixed row order (deterministic).
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int ld, float* __restrict__ out, int R,
+                                                     int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += (float)x[(size_t)r * ld + c];
+  out[c] = s;
+}
+
+}  // namespace
+
+extern "C" int tasu_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, int M, int D, float eps,
+                                void* stream) {
+  if (!x || !w || !y || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)y, rstd, M, D,
+                     eps);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+extern "C" int tasu_rmsnorm_bwd(const void* dy, const float* x, const float* w, const float* rstd, float* dx, void* dx_bf16,
+                                int accumulate, int M, int D, void* stream) {
+  if (!dy || !x || !w || !rstd || !dx || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, x, w, rstd,
+                     dx, (bf16*)dx_bf16, accumulate, M, D);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+extern "C" int tasu_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
+                                  int y_is_f32, float* mean, float* rstd, int R, int D, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || R <= 0 || D <= 0 || ldx < D || ldy < D) return TASU_ERR_ARG;
+  if (y_is_f32)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(R), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy,
+                       mean, rstd, D, eps);
+  else
+    hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3(R), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy,
+                       mean, rstd, D, eps);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+extern "C" int tasu_layernorm_bwd_params(const void* dy, int lddy, const float* x, int ldx, const float* mean,
+                                         const float* rstd, float* dgamma, float* dbeta, float* ws, int R, int D,
+                                         void* stream) {
+  if (!dy || !x || !mean || !rstd || !dgamma || !dbeta || !ws || R <= 0 || D <= 0) return TASU_ERR_ARG;
+  const int nsplit = TASU_LN_BWD_SPLIT;
+  hipLaunchKernelGGL(layernorm_bwd_partial_kernel, dim3((D + 255) / 256, nsplit), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)dy, lddy, x, ldx, mean, rstd, ws, R, D);
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dgamma,
+                     dbeta, nsplit, D);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+extern "C" int tasu_colsum_bf16(const void* x, int ld, float* out, int R, int C, void* stream) {
+  if (!x || !out || R <= 0 || C <= 0) return TASU_ERR_ARG;
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, out, R, C);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}

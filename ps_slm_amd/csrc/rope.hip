@@ -1,0 +1,160 @@
+// Rotary position embedding for the fused qkv activation + the transposed operand copies that the attention
+// kernels stream.  Reference arithmetic: transformers modeling_qwen2.py:91-135 (fp32 cos/sin from position_ids,
+// rotate-half, result cast to the attention dtype).  HBM-bound; one 64-token x 128-d tile per block, staged
+// through LDS so that both the in-place row write and the [128, S] transposed write are coalesced.
+#include "common.h"
+#include "../../include/tasu_hip.h"
+
+namespace {
+constexpr int HD = 128;
+
+__global__ void rope_table_kernel(const int32_t* __restrict__ pos, float* __restrict__ ct, float* __restrict__ st, int M,
+                                  int half, float theta) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * half) return;
+  const int m = idx / half, i = idx - m * half;
+  const float inv = 1.0f / powf(theta, (float)(2 * i) / (float)(2 * half));
+  const float ang = (float)pos[m] * inv;
+  float s, c;
+  sincosf(ang, &s, &c);
+  ct[idx] = c;
+  st[idx] = s;
+}
+
+// grid (ceil(S/64), H+2G, B)
+__global__ __launch_bounds__(256) void rope_fwd_kernel(bf16* __restrict__ qkv, const float* __restrict__ ct,
+                                                       const float* __restrict__ st, bf16* __restrict__ qt,
+                                                       bf16* __restrict__ kt, bf16* __restrict__ vt, int S, int Spad, int H,
+                                                       int G) {
+  __shared__ bf16 tile[64][HD + 2];
+  const int t0 = blockIdx.x * 64, hh = blockIdx.y, b = blockIdx.z;
+  const int LD = (H + 2 * G) * HD;
+  const int tl = threadIdx.x >> 2, part = threadIdx.x & 3;
+  const int tok = t0 + tl;
+  const bool rotate = hh < H + G;
+  if (tok < S) {
+    bf16* row = qkv + ((size_t)b * S + tok) * LD + hh * HD;
+    bf16x8 a0 = *(const bf16x8*)(row + part * 16), a1 = *(const bf16x8*)(row + part * 16 + 8);
+    bf16x8 b0 = *(const bf16x8*)(row + 64 + part * 16), b1 = *(const bf16x8*)(row + 64 + part * 16 + 8);
+    if (rotate) {
+      const float* cr = ct + ((size_t)b * S + tok) * 64 + part * 16;
+      const float* sr = st + ((size_t)b * S + tok) * 64 + part * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float c0 = cr[j], s0 = sr[j], c1 = cr[8 + j], s1 = sr[8 + j];
+        const float x1 = (float)a0[j], x2 = (float)b0[j];
+        const float y1 = (float)a1[j], y2 = (float)b1[j];
+        a0[j] = (bf16)(x1 * c0 - x2 * s0);
+        b0[j] = (bf16)(x2 * c0 + x1 * s0);
+        a1[j] = (bf16)(y1 * c1 - y2 * s1);
+        b1[j] = (bf16)(y2 * c1 + y1 * s1);
+      }
+      *(bf16x8*)(row + part * 16) = a0;
+      *(bf16x8*)(row + part * 16 + 8) = a1;
+      *(bf16x8*)(row + 64 + part * 16) = b0;
+      *(bf16x8*)(row + 64 + part * 16 + 8) = b1;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      tile[tl][part * 16 + j] = a0[j];
+      tile[tl][part * 16 + 8 + j] = a1[j];
+      tile[tl][64 + part * 16 + j] = b0[j];
+      tile[tl][64 + part * 16 + 8 + j] = b1[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      tile[tl][part * 16 + j] = (bf16)0.f;
+      tile[tl][64 + part * 16 + j] = (bf16)0.f;
+    }
+  }
+  bf16* dstbase;
+  if (hh < H) {
+    if (!qt) return;
+    dstbase = qt + ((size_t)b * H + hh) * HD * Spad;
+  } else if (hh < H + G) {
+    if (!kt) return;
+    dstbase = kt + ((size_t)b * G + (hh - H)) * HD * Spad;
+  } else {
+    if (!vt) return;
+    dstbase = vt + ((size_t)b * G + (hh - H - G)) * HD * Spad;
+  }
+  __syncthreads();
+  const int d = threadIdx.x >> 1, half = threadIdx.x & 1;
+  bf16* dst = dstbase + (size_t)d * Spad + t0 + half * 32;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[half * 32 + c * 8 + j][d];
+    *(bf16x8*)(dst + c * 8) = v;
+  }
+}
+
+// Backward: q block of dqkv holds dQ (rotated space, bf16) -> un-rotate in place.  k/v blocks are produced from
+// the per-query-head fp32 partials: sum over the H/G heads of the group, un-rotate K, round to bf16.
+// grid (M, H + 2G), block 64 (one lane per rotation pair).
+__global__ __launch_bounds__(64) void rope_bwd_kernel(bf16* __restrict__ dqkv, const float* __restrict__ dk_part,
+                                                      const float* __restrict__ dv_part, const float* __restrict__ ct,
+                                                      const float* __restrict__ st, int H, int G) {
+  const int m = blockIdx.x, hh = blockIdx.y, i = threadIdx.x;
+  const int LD = (H + 2 * G) * HD;
+  const int rep = H / G;
+  bf16* row = dqkv + (size_t)m * LD + hh * HD;
+  float y1, y2;
+  if (hh < H) {
+    y1 = (float)row[i];
+    y2 = (float)row[i + 64];
+  } else {
+    const bool isk = hh < H + G;
+    const int g = isk ? hh - H : hh - H - G;
+    const float* src = (isk ? dk_part : dv_part) + (size_t)m * (H * HD) + (size_t)g * rep * HD;
+    y1 = 0.f;
+    y2 = 0.f;
+    for (int r = 0; r < rep; ++r) {
+      y1 += src[r * HD + i];
+      y2 += src[r * HD + i + 64];
+    }
+    if (!isk) {
+      row[i] = (bf16)y1;
+      row[i + 64] = (bf16)y2;
+      return;
+    }
+  }
+  const float c = ct[(size_t)m * 64 + i], s = st[(size_t)m * 64 + i];
+  // forward: y1 = x1 c - x2 s ; y2 = x2 c + x1 s   =>   dx1 = dy1 c + dy2 s ; dx2 = dy2 c - dy1 s
+  row[i] = (bf16)(y1 * c + y2 * s);
+  row[i + 64] = (bf16)(y2 * c - y1 * s);
+}
+}  // namespace
+
+extern "C" int tasu_rope_table(const int32_t* pos, float* cos_tab, float* sin_tab, int M, int head_dim, float theta,
+                               void* stream) {
+  if (!pos || !cos_tab || !sin_tab || M <= 0 || head_dim != HD) return TASU_ERR_ARG;
+  const int n = M * (HD / 2);
+  hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, cos_tab, sin_tab,
+                     M, HD / 2, theta);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+
+extern "C" int tasu_rope_fwd(void* qkv, const float* cos_tab, const float* sin_tab, void* qt, void* kt, void* vt, int B,
+                             int S, int H, int G, void* stream) {
+  if (!qkv || !cos_tab || !sin_tab || B <= 0 || S <= 0 || H <= 0 || G <= 0) return TASU_ERR_ARG;
+  dim3 grid((S + 63) / 64, H + 2 * G, B);
+  hipLaunchKernelGGL(rope_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (bf16*)qkv, cos_tab, sin_tab, (bf16*)qt,
+                     (bf16*)kt, (bf16*)vt, S, (S + 63) & ~63, H, G);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}
+
+extern "C" int tasu_rope_bwd(void* dqkv, const float* dk_part, const float* dv_part, const float* cos_tab,
+                             const float* sin_tab, int B, int S, int H, int G, void* stream) {
+  if (!dqkv || !dk_part || !dv_part || !cos_tab || !sin_tab || B <= 0 || S <= 0 || H <= 0 || G <= 0 || H % G)
+    return TASU_ERR_ARG;
+  dim3 grid(B * S, H + 2 * G);
+  hipLaunchKernelGGL(rope_bwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, (bf16*)dqkv, dk_part, dv_part, cos_tab,
+                     sin_tab, H, G);
+  TASU_CHECK_LAUNCH();
+  return TASU_OK;
+}

@@ -1,0 +1,502 @@
+"""Device-resident TASU model: weights laid out for the gfx950 kernels + the hand-scheduled forward/backward of
+the alignment training step (no autograd tape, no tracing compiler: the graph is fixed because the LLM and the
+encoder are frozen -- Multitask/scripts/finetune_deespeed_sensevoice.sh:44,84 -- so backward is dgrad-only
+through the decoder and wgrad only for the 6 projector tensors).
+
+Reference arithmetic being replaced:
+  slam_model_asr.forward            Multitask/model/ps-slm.py:411-537
+  EncoderProjectorLinearSiLU        Multitask/model/projector.py:129-151
+  Qwen2ForCausalLM.forward / loss   transformers modeling_qwen2.py:423-470, loss/loss_utils.py:49-71
+  token accuracy                    Multitask/utils/metric.py:3-20
+
+Numerics ("bf16" mode = torch.autocast(bfloat16) semantics of Multitask/utils/deepspeed_utils.py:160): bf16 GEMM
+operands/results with fp32 MFMA accumulation, fp32 residual stream, fp32 norms / softmax / loss, fp32 master
+projector weights and optimizer state.
+
+HBM layout (sized for 288 GB: everything stays resident, nothing is recomputed):
+  * every frozen Linear weight twice, bf16: W [out,in] for forward and W^T [in,out] for dgrad, so that one
+    K-contiguous "NT" MFMA kernel serves both;  q/k/v and gate/up are fused along N.
+  * embedding table fp32 (gather) + bf16 lm_head copies [V,D] and [D,Vpad].
+  * projector parameters in ONE flat fp32 buffer (+ flat grad / m / v / bf16 working copy); the 25055-wide K
+    dimension is padded to a multiple of 64 with zeros (pad columns provably stay zero under AdamW).
+  * per layer saved for backward: x_in, x_mid (fp32), rstd1/2, rotated qkv, Q^T/K^T, attention out, lse, gate|up.
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from .merge import build_merge_plan
+from .ops import GEMM_BF16, GEMM_F32, GEMM_RESID, LN_BWD_SPLIT
+
+HD = 128
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Geometry:
+    # Qwen2.5 decoder
+    llm_vocab: int = 151936
+    llm_dim: int = 1536
+    llm_inter: int = 8960
+    llm_layers: int = 28
+    llm_heads: int = 12
+    llm_kv_heads: int = 2
+    rope_theta: float = 1e6
+    rms_eps: float = 1e-6
+    tied: bool = True
+    # projector
+    ctc_vocab: int = 25055
+    bottleneck: int = 2048
+    ln_eps: float = 1e-5
+    # SenseVoiceSmall encoder
+    feat_dim: int = 560
+    enc_dim: int = 512
+    enc_heads: int = 4
+    enc_ffn: int = 2048
+    enc_blocks: int = 50
+    enc_tp_blocks: int = 20
+    enc_kernel: int = 11
+    blank_id: int = 0
+    # tokens
+    speech_id: int = 151665
+    eos_id: int = 151643
+
+    @classmethod
+    def qwen25_1p5b(cls):
+        return cls()
+
+    @classmethod
+    def qwen25_7b(cls):
+        return cls(llm_vocab=152064, llm_dim=3584, llm_inter=18944, llm_layers=28, llm_heads=28, llm_kv_heads=4,
+                   tied=False)
+
+    @classmethod
+    def from_dict(cls, d):
+        names = {f for f in cls.__dataclass_fields__}
+        return cls(**{k: v for k, v in d.items() if k in names})
+
+
+PROJ_NAMES = ("norm.weight", "norm.bias", "ffn.0.weight", "ffn.0.bias", "ffn.2.weight", "ffn.2.bias")
+
+
+class ProjectorParams:
+    """The only trainable tensors (54,512,062 parameters at full geometry) in one flat, padded buffer."""
+
+    def __init__(self, geo: Geometry, device):
+        K, Kp, Hb, Do = geo.ctc_vocab, rup(geo.ctc_vocab, 64), geo.bottleneck, geo.llm_dim
+        self.K, self.Kp, self.Hb, self.Do = K, Kp, Hb, Do
+        shapes = {"norm.weight": (Kp,), "norm.bias": (Kp,), "ffn.0.weight": (Hb, Kp), "ffn.0.bias": (Hb,),
+                  "ffn.2.weight": (Do, Hb), "ffn.2.bias": (Do,)}
+        self.real = {"norm.weight": (K,), "norm.bias": (K,), "ffn.0.weight": (Hb, K), "ffn.0.bias": (Hb,),
+                     "ffn.2.weight": (Do, Hb), "ffn.2.bias": (Do,)}
+        self.offsets, off = {}, 0
+        for n in PROJ_NAMES:
+            self.offsets[n] = (off, shapes[n])
+            off += rup(int(np.prod(shapes[n])), 64)
+        self.numel = off
+        f32 = dict(dtype=torch.float32, device=device)
+        self.p = torch.zeros(off, **f32)
+        self.g = torch.zeros(off, **f32)
+        self.m = torch.zeros(off, **f32)
+        self.v = torch.zeros(off, **f32)
+        self.pb = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        self.w1b_t = torch.zeros(Kp, Hb, dtype=torch.bfloat16, device=device)   # ffn.0.weight^T for dgrad
+        self.w2b_t = torch.zeros(Hb, Do, dtype=torch.bfloat16, device=device)   # ffn.2.weight^T for dgrad
+
+    def view(self, flat, name):
+        off, shp = self.offsets[name]
+        return flat[off:off + int(np.prod(shp))].view(*shp)
+
+    def num_parameters(self):
+        return sum(int(np.prod(s)) for s in self.real.values())
+
+    def load(self, name, t):
+        """t: fp32 tensor with the REFERENCE shape (unpadded)."""
+        dst = self.view(self.p, name)
+        dst.zero_()
+        if dst.dim() == 1:
+            dst[: t.shape[0]].copy_(t)
+        else:
+            dst[:, : t.shape[1]].copy_(t)
+
+    def export(self, name):
+        src = self.view(self.p, name)
+        r = self.real[name]
+        return (src[: r[0]] if src.dim() == 1 else src[:, : r[1]]).detach().clone()
+
+    def export_grad(self, name):
+        src = self.view(self.g, name)
+        r = self.real[name]
+        return (src[: r[0]] if src.dim() == 1 else src[:, : r[1]]).detach().clone()
+
+    def refresh_working_copies(self, ops):
+        """bf16 working copy (skipped when AdamW already wrote it) + the transposed copies for dgrad."""
+        ops.transpose(self.view(self.pb, "ffn.0.weight"), self.w1b_t, self.Hb, self.Kp, self.Hb, self.Kp)
+        ops.transpose(self.view(self.pb, "ffn.2.weight"), self.w2b_t, self.Do, self.Hb, self.Do, self.Hb)
+
+
+class LLMWeights:
+    """Frozen Qwen2 weights, bf16, fused and doubly laid out (see module docstring)."""
+
+    def __init__(self, geo: Geometry, device):
+        self.geo = geo
+        self.device = device
+        self.layers = []
+        self.embed = None      # fp32 [V, D]
+        self.head = None       # bf16 [V, D]
+        self.head_t = None     # bf16 [D, Vpad]
+        self.norm = None       # fp32 [D]
+
+    @staticmethod
+    def _pair(w, device):
+        """fp32 [N,K] -> (bf16 [N,K], bf16 [K,N]) on device.  Load-time layout work (not on the step path)."""
+        wb = w.to(device=device, dtype=torch.bfloat16).contiguous()
+        return wb, wb.t().contiguous()
+
+    def add_layer(self, ln1, wq, bq, wk, bk, wv, bv, wo, ln2, wg, wu, wd):
+        dev = self.device
+        wqkv, wqkv_t = self._pair(torch.cat([wq, wk, wv], 0), dev)
+        wo_b, wo_t = self._pair(wo, dev)
+        wgu, wgu_t = self._pair(torch.cat([wg, wu], 0), dev)
+        wd_b, wd_t = self._pair(wd, dev)
+        self.layers.append(dict(
+            ln1=ln1.to(dev, torch.float32).contiguous(), ln2=ln2.to(dev, torch.float32).contiguous(),
+            wqkv=wqkv, wqkv_t=wqkv_t, bqkv=torch.cat([bq, bk, bv], 0).to(dev, torch.bfloat16).contiguous(),
+            wo=wo_b, wo_t=wo_t, wgu=wgu, wgu_t=wgu_t, wd=wd_b, wd_t=wd_t))
+
+    def set_embed(self, embed, head, norm):
+        geo, dev = self.geo, self.device
+        V, D = geo.llm_vocab, geo.llm_dim
+        Vp = rup(V, 64)
+        self.embed = embed.to(dev, torch.float32).contiguous()
+        hb = head.to(dev, torch.bfloat16).contiguous()
+        self.head = hb
+        self.head_t = torch.zeros(D, Vp, dtype=torch.bfloat16, device=dev)
+        self.head_t[:, :V].copy_(hb.t())
+        self.norm = norm.to(dev, torch.float32).contiguous()
+
+    def load_reference_state_dict(self, sd, pre="llm."):
+        geo = self.geo
+        for l in range(geo.llm_layers):
+            p = f"{pre}model.layers.{l}."
+            self.add_layer(sd[p + "input_layernorm.weight"],
+                           sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"],
+                           sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"],
+                           sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"],
+                           sd[p + "self_attn.o_proj.weight"], sd[p + "post_attention_layernorm.weight"],
+                           sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"], sd[p + "mlp.down_proj.weight"])
+        emb = sd[pre + "model.embed_tokens.weight"]
+        head = sd.get(pre + "lm_head.weight", emb)
+        self.set_embed(emb, head, sd[pre + "model.norm.weight"])
+
+    def init_random(self, seed):
+        """Seeded N(0, 0.02) linears/embedding, ones norms (HF default init), generated ON DEVICE tensor by tensor
+        (no pretrained weights exist on the benchmark box)."""
+        geo, dev = self.geo, self.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+        D, I, H, G = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads
+
+        def rn(*shape):
+            return torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * 0.02
+
+        ones = torch.ones(D, device=dev)
+        for _ in range(geo.llm_layers):
+            self.add_layer(ones, rn(H * HD, D), rn(H * HD), rn(G * HD, D), rn(G * HD), rn(G * HD, D), rn(G * HD),
+                           rn(D, H * HD), ones, rn(I, D), rn(I, D), rn(D, I))
+        emb = rn(geo.llm_vocab, D)
+        self.set_embed(emb, emb if geo.tied else rn(geo.llm_vocab, D), ones)
+
+
+@dataclass
+class StepState:
+    """Everything one training step needs between forward and backward (device tensors + the host plan)."""
+    plan: object = None
+    B: int = 0
+    S: int = 0
+    M: int = 0
+    Ra: int = 0        # projector rows (B * Lmax)
+    Rap: int = 0       # padded to 64
+    dev: dict = field(default_factory=dict)
+    out: object = None
+
+
+class TasuModel:
+    def __init__(self, geo: Geometry, ops, device, keep_logits=True):
+        self.geo, self.ops, self.device = geo, ops, torch.device(device)
+        self.llm = LLMWeights(geo, self.device)
+        self.proj = ProjectorParams(geo, self.device)
+        self.encoder = None            # ps_slm_amd.encoder.EncoderWeights (audio path)
+        self.keep_logits = keep_logits
+        self._ws = {}
+        self.training = True
+
+    # ------------------------------------------------------------------------------------------ weights
+    def load_reference_state_dict(self, sd):
+        """sd: reference-named tensors (``llm.*``, ``encoder_projector.*``, optionally ``encoder.*``)."""
+        self.llm.load_reference_state_dict(sd)
+        for n in PROJ_NAMES:
+            self.proj.load(n, sd["encoder_projector." + n].to(self.device, torch.float32))
+        self.sync_projector_copies()
+        if any(k.startswith("encoder.") for k in sd):
+            from .encoder import EncoderWeights
+            self.encoder = EncoderWeights(self.geo, self.device)
+            self.encoder.load_reference_state_dict(sd)
+
+    def init_random(self, seed=1234, with_encoder=False):
+        self.llm.init_random(seed)
+        geo, dev = self.geo, self.device
+        g = torch.Generator(device=dev).manual_seed(seed + 1)
+        K, Hb, Do = geo.ctc_vocab, geo.bottleneck, geo.llm_dim
+        # nn.LayerNorm: ones/zeros; nn.Linear default (kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(in), 1/sqrt(in)));
+        # ffn.2.bias zeros (projector.py:145-146)
+        def un(shape, fan_in):
+            b = 1.0 / math.sqrt(fan_in)
+            return (torch.rand(*shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1) * b
+        self.proj.load("norm.weight", torch.ones(K, device=dev))
+        self.proj.load("norm.bias", torch.zeros(K, device=dev))
+        self.proj.load("ffn.0.weight", un((Hb, K), K))
+        self.proj.load("ffn.0.bias", un((Hb,), K))
+        self.proj.load("ffn.2.weight", un((Do, Hb), Hb))
+        self.proj.load("ffn.2.bias", torch.zeros(Do, device=dev))
+        self.sync_projector_copies()
+        if with_encoder:
+            from .encoder import EncoderWeights
+            self.encoder = EncoderWeights(self.geo, self.device)
+            self.encoder.init_random(seed + 2)
+
+    def sync_projector_copies(self):
+        self.ops.cast_bf16(self.proj.p, self.proj.pb)
+        self.proj.refresh_working_copies(self.ops)
+
+    def projector_state_dict(self):
+        return {"encoder_projector." + n: self.proj.export(n) for n in PROJ_NAMES}
+
+    def projector_grads(self):
+        return {"encoder_projector." + n: self.proj.export_grad(n) for n in PROJ_NAMES}
+
+    # ------------------------------------------------------------------------------------------ workspace
+    def _buf(self, name, shape, dtype):
+        """Grow-only named buffers: allocated once per capacity, then reused every step."""
+        n = int(np.prod(shape))
+        t = self._ws.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(n, dtype=dtype, device=self.device)
+            self._ws[name] = t
+        return t[:n].view(*shape)
+
+    # ------------------------------------------------------------------------------------------ host prep
+    def prepare_text(self, input_ids, attention_mask, labels, post_ids, alphas=None, keeps=None) -> StepState:
+        """Host side of the text-only branch (ps-slm.py:459-468): apply the CPS draws (drop mask, alpha) to the
+        sentencepiece ids, build the merge plan, and upload all integer inputs in one staging copy."""
+        geo = self.geo
+        B = len(post_ids)
+        kept = []
+        for u, ids in enumerate(post_ids):
+            ids = np.asarray(ids, dtype=np.int64)
+            if alphas is not None and keeps is not None:
+                ids = ids[np.asarray(keeps[u], dtype=bool)]
+            kept.append(ids)
+        lens = np.array([len(k) for k in kept], dtype=np.int64)
+        Lmax = int(lens.max())
+        Ra = B * Lmax
+        Rap = rup(Ra, 64)
+        pid = np.full(Rap, -1, dtype=np.int32)
+        pal = np.zeros(Rap, dtype=np.float32)
+        for u, ids in enumerate(kept):
+            pid[u * Lmax: u * Lmax + len(ids)] = ids
+            if alphas is not None:
+                pal[u * Lmax: u * Lmax + len(ids)] = float(alphas[u])
+        st = self._finish_prepare(input_ids, attention_mask, labels, lens, Lmax)
+        st.dev["post_ids"] = self._upload("post_ids", pid)
+        st.dev["post_alpha"] = self._upload("post_alpha", pal)
+        st.Ra, st.Rap = Ra, Rap
+        return st
+
+    def _upload(self, name, arr):
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        d = self._buf("in_" + name, t.shape, t.dtype)
+        d.copy_(t, non_blocking=True)
+        return d
+
+    def _finish_prepare(self, input_ids, attention_mask, labels, num_audio, Lmax) -> StepState:
+        to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        plan = build_merge_plan(to_np(input_ids), to_np(attention_mask), None if labels is None else to_np(labels),
+                                num_audio, self.geo.speech_id, Lmax)
+        st = StepState(plan=plan, B=plan.B, S=plan.S, M=plan.B * plan.S)
+        st.dev["kind"] = self._upload("kind", plan.src_kind)
+        st.dev["idx"] = self._upload("idx", plan.src_idx)
+        st.dev["key_mask"] = self._upload("key_mask", plan.key_mask)
+        st.dev["pos"] = self._upload("pos", plan.position_ids)
+        st.dev["shift_labels"] = self._upload("shift_labels", plan.shift_labels)
+        st.dev["audio_rows"] = self._upload("audio_rows", plan.audio_rows)
+        st.dev["inv_count"] = self._upload("inv_count", np.array([1.0 / max(plan.count, 1)], dtype=np.float32))
+        return st
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward_projector_text(self, st: StepState):
+        """pseudo-posterior rows -> LayerNorm(25055) -> Linear -> SiLU -> Linear   (projector.py:149-151)."""
+        ops, pr = self.ops, self.proj
+        Rap, K, Kp, Hb, Do = st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
+        post = self._buf("post", (Rap, Kp), torch.float32)
+        ops.posterior_build(st.dev["post_ids"], st.dev["post_alpha"], post, Rap, K)
+        st.dev["post"] = post
+        self._projector_from_posterior(st)
+
+    def _projector_from_posterior(self, st):
+        ops, pr = self.ops, self.proj
+        Rap, K, Kp, Hb, Do = st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
+        post = st.dev["post"]
+        xn = self._buf("xn", (Rap, Kp), torch.bfloat16)
+        mean = self._buf("ln_mean", (Rap,), torch.float32)
+        rstd = self._buf("ln_rstd", (Rap,), torch.float32)
+        ops.layernorm_fwd(post, pr.view(pr.p, "norm.weight"), pr.view(pr.p, "norm.bias"), xn, mean, rstd, Rap, K,
+                          self.geo.ln_eps)
+        h1 = self._buf("h1", (Rap, Hb), torch.bfloat16)
+        ops.gemm(xn, pr.view(pr.pb, "ffn.0.weight"), h1, Rap, Hb, Kp, bias=pr.view(pr.pb, "ffn.0.bias"))
+        a1 = self._buf("a1", (Rap, Hb), torch.bfloat16)
+        ops.silu_fwd(h1, a1)
+        y2 = self._buf("y2", (Rap, Do), torch.bfloat16)
+        ops.gemm(a1, pr.view(pr.pb, "ffn.2.weight"), y2, Rap, Do, Hb, bias=pr.view(pr.pb, "ffn.2.bias"))
+        st.dev.update(xn=xn, ln_mean=mean, ln_rstd=rstd, h1=h1, a1=a1, y2=y2)
+
+    def forward_llm(self, st: StepState, compute_loss=True, need_backward=True):
+        ops, geo, llm = self.ops, self.geo, self.llm
+        B, S, M = st.B, st.S, st.M
+        D, I, H, G, V = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_vocab
+        Spad, Vp, LDQ = st.plan.Spad, rup(V, 64), (H + 2 * G) * HD
+        scale = HD ** -0.5
+        L = geo.llm_layers
+        d = st.dev
+        bf, f32 = torch.bfloat16, torch.float32
+        xs = self._buf("xs", (2 * L + 1, M, D), f32)          # x_in[l] = xs[2l], x_mid[l] = xs[2l+1], final = xs[2L]
+        ops.embed_merge(llm.embed, d["y2"], d["kind"], d["idx"], xs[0], M, D)
+        cos = self._buf("cos", (M, HD // 2), f32)
+        sin = self._buf("sin", (M, HD // 2), f32)
+        ops.rope_table(d["pos"], cos, sin, HD, geo.rope_theta)
+        rstd = self._buf("rstd", (2 * L + 1, M), f32)
+        qkv = self._buf("qkv", (L, M, LDQ), bf)
+        qt = self._buf("qt", (L, B * H * HD * Spad), bf)
+        kt = self._buf("kt", (L, B * G * HD * Spad), bf)
+        vt = self._buf("vt", (B * G * HD * Spad,), bf)
+        ao = self._buf("ao", (L, M, H * HD), bf)
+        lse = self._buf("lse", (L, B * H * Spad), f32)
+        gu = self._buf("gu", (L, M, 2 * I), bf)
+        xn = self._buf("xn_llm", (M, D), bf)
+        act = self._buf("act", (M, I), bf)
+        for l, w in enumerate(llm.layers):
+            x_in, x_mid, x_out = xs[2 * l], xs[2 * l + 1], xs[2 * l + 2]
+            ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], geo.rms_eps)
+            ops.gemm(xn, w["wqkv"], qkv[l], M, LDQ, D, bias=w["bqkv"])
+            ops.rope_fwd(qkv[l], cos, sin, qt[l], kt[l], vt, B, S, H, G)
+            ops.attn_fwd(qkv[l], vt, d["key_mask"], ao[l], lse[l], B, S, H, G, scale, True)
+            ops.gemm(ao[l], w["wo"], x_mid, M, D, H * HD, resid=x_in, mode=GEMM_RESID)
+            ops.rmsnorm_fwd(x_mid, w["ln2"], xn, rstd[2 * l + 1], geo.rms_eps)
+            ops.gemm(xn, w["wgu"], gu[l], M, 2 * I, D)
+            ops.swiglu_fwd(gu[l], act, M, I)
+            ops.gemm(act, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
+        ops.rmsnorm_fwd(xs[2 * L], llm.norm, xn, rstd[2 * L], geo.rms_eps)
+        logits = self._buf("logits", (M, Vp), bf)
+        ops.gemm(xn, llm.head, logits, M, V, D)
+        d.update(xs=xs, cos=cos, sin=sin, rstd=rstd, qkv=qkv, qt=qt, kt=kt, ao=ao, lse=lse, gu=gu, logits=logits)
+        if not compute_loss:
+            return
+        row_loss = self._buf("row_loss", (M,), f32)
+        row_hit = self._buf("row_hit", (M,), torch.int32)
+        row_arg = self._buf("row_arg", (M,), torch.int32)
+        if need_backward and not self.keep_logits:
+            dlogits = logits                                   # overwrite in place (throughput mode)
+        elif need_backward:
+            dlogits = self._buf("dlogits", (M, Vp), bf)
+        else:
+            dlogits = None
+        ops.ce_fwd_bwd(logits, d["shift_labels"], M, V, row_loss, row_hit, row_arg, dlogits, d["inv_count"])
+        res = self._buf("loss_out", (4,), f32)
+        ops.ce_reduce(row_loss, row_hit, d["shift_labels"], M, res)
+        d.update(dlogits=dlogits, loss_out=res, row_arg=row_arg)
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, st: StepState):
+        """dgrad-only through the frozen decoder, then wgrad of the projector into the flat grad buffer."""
+        ops, geo, llm, pr = self.ops, self.geo, self.llm, self.proj
+        B, S, M = st.B, st.S, st.M
+        D, I, H, G, V = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_vocab
+        Spad, Vp, LDQ = st.plan.Spad, rup(V, 64), (H + 2 * G) * HD
+        scale = HD ** -0.5
+        L = geo.llm_layers
+        d = st.dev
+        bf, f32 = torch.bfloat16, torch.float32
+        xs, rstd, cos, sin = d["xs"], d["rstd"], d["cos"], d["sin"]
+        dx = self._buf("dx", (M, D), f32)
+        dxb = self._buf("dxb", (M, D), bf)
+        dn = self._buf("dn", (M, D), bf)                       # gradient wrt a normed activation
+        dact = self._buf("dact", (M, I), bf)
+        dgu = self._buf("dgu", (M, 2 * I), bf)
+        dao = self._buf("dao", (M, H * HD), bf)
+        dao_t = self._buf("dao_t", (B * H * HD * Spad,), bf)
+        delta = self._buf("delta", (B * H * Spad,), f32)
+        dqkv = self._buf("dqkv", (M, LDQ), bf)
+        dkp = self._buf("dkp", (M, H * HD), f32)
+        dvp = self._buf("dvp", (M, H * HD), f32)
+        # lm_head dgrad (K = Vpad: dlogits pad columns are zero) and final norm
+        ops.gemm(d["dlogits"], llm.head_t, dn, M, D, Vp)
+        ops.rmsnorm_bwd(dn, xs[2 * L], llm.norm, rstd[2 * L], dx, dxb, False)
+        for l in range(L - 1, -1, -1):
+            w = llm.layers[l]
+            x_in, x_mid = xs[2 * l], xs[2 * l + 1]
+            ops.gemm(dxb, w["wd_t"], dact, M, I, D)
+            ops.swiglu_bwd(dact, d["gu"][l], dgu, M, I)
+            ops.gemm(dgu, w["wgu_t"], dn, M, D, 2 * I)
+            ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
+            ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)
+            ops.attn_bwd_prep(dao, d["ao"][l], delta, dao_t, B, S, H)
+            ops.attn_bwd_dq(d["qkv"][l], d["kt"][l], d["key_mask"], dao, d["lse"][l], delta, dqkv, B, S, H, G, scale, True)
+            ops.attn_bwd_dkv(d["qkv"][l], d["qt"][l], d["key_mask"], dao, dao_t, d["lse"][l], delta, dkp, dvp, B, S, H, G,
+                             scale, True)
+            ops.rope_bwd(dqkv, dkp, dvp, cos, sin, B, S, H, G)
+            ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)
+            ops.rmsnorm_bwd(dn, x_in, w["ln1"], rstd[2 * l], dx, dxb, True)
+        # merge backward: gradient rows that hold audio -> projector output gradient
+        Rap, K, Kp, Hb, Do = st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
+        audio_rows = d["audio_rows_pad"] if "audio_rows_pad" in d else self._pad_rows(st)
+        dy2 = self._buf("dy2", (Rap, Do), bf)
+        ops.merge_bwd(dx, audio_rows, dy2, Rap, Do)
+        # Linear2: db2, dW2 = dy2^T a1, da1 = dy2 W2
+        ops.colsum(dy2, pr.view(pr.g, "ffn.2.bias"), Rap, Do)
+        dy2_t = self._buf("dy2_t", (Do, Rap), bf)
+        a1_t = self._buf("a1_t", (Hb, Rap), bf)
+        ops.transpose(dy2, dy2_t, Rap, Do, Rap, Do)
+        ops.transpose(d["a1"], a1_t, Rap, Hb, Rap, Hb)
+        ops.gemm(dy2_t, a1_t, pr.view(pr.g, "ffn.2.weight"), Do, Hb, Rap, mode=GEMM_F32)
+        da1 = self._buf("da1", (Rap, Hb), bf)
+        ops.gemm(dy2, pr.w2b_t, da1, Rap, Hb, Do)
+        dh1 = self._buf("dh1", (Rap, Hb), bf)
+        ops.silu_bwd(da1, d["h1"], dh1)
+        # Linear1: db1, dW1 = dh1^T xn, dxn = dh1 W1
+        ops.colsum(dh1, pr.view(pr.g, "ffn.0.bias"), Rap, Hb)
+        dh1_t = self._buf("dh1_t", (Hb, Rap), bf)
+        xn_t = self._buf("xn_t", (Kp, Rap), bf)
+        ops.transpose(dh1, dh1_t, Rap, Hb, Rap, Hb)
+        ops.transpose(d["xn"], xn_t, Rap, Kp, Rap, Kp)
+        ops.gemm(dh1_t, xn_t, pr.view(pr.g, "ffn.0.weight"), Hb, Kp, Rap, mode=GEMM_F32)
+        dxn = self._buf("dxn", (Rap, Kp), bf)
+        ops.gemm(dh1, pr.w1b_t, dxn, Rap, Kp, Hb)
+        ws = self._buf("ln_ws", (2 * LN_BWD_SPLIT * K,), f32)
+        ops.layernorm_bwd_params(dxn, d["post"], d["ln_mean"], d["ln_rstd"], pr.view(pr.g, "norm.weight"),
+                                 pr.view(pr.g, "norm.bias"), ws, Rap, K)
+
+    def _pad_rows(self, st):
+        rows = np.full(st.Rap, -1, dtype=np.int32)
+        rows[: st.Ra] = st.plan.audio_rows
+        st.dev["audio_rows_pad"] = self._upload("audio_rows_pad", rows)
+        return st.dev["audio_rows_pad"]
+
+    # ------------------------------------------------------------------------------------------ results
+    def logits_view(self, st):
+        """[B, S, V] view of the bf16 logits buffer (valid until the next forward)."""
+        V = self.geo.llm_vocab
+        return st.dev["logits"].view(st.B, st.S, -1)[:, :, :V]

@@ -1,0 +1,176 @@
+"""Thin operator layer over the C-ABI (include/tasu_hip.h).  Tensors are containers only: every method passes
+``data_ptr()`` + sizes + the current HIP stream to libtasu_hip.so and returns nothing (outputs are
+caller-allocated).  There is no eager/PyTorch fallback: construction fails if the library is missing.
+
+The method set is the operator interface of the model code (ps_slm_amd/model.py); tests exercise the same
+model code on CPU by injecting tests/fake_ops.py, a torch-CPU double with identical signatures.
+"""
+import torch
+
+from . import _lib
+
+GEMM_BF16, GEMM_F32, GEMM_RESID = 0, 1, 2
+LN_BWD_SPLIT = 16
+
+
+class TasuOpError(RuntimeError):
+    pass
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class HipOps:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise TasuOpError("HipOps needs a ROCm device (torch.cuda.is_available() is False)")
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    @staticmethod
+    def _chk(rc, what):
+        if rc != 0:
+            raise TasuOpError(f"{what} failed with code {rc} ({'bad argument' if rc == 1 else 'launch failure'})")
+
+    # ------------------------------------------------------------------ GEMM & layout
+    def gemm(self, a, b, c, M, N, K, bias=None, resid=None, mode=GEMM_BF16, lda=None, ldb=None, ldc=None):
+        """c[M,N] = a[M,K] @ b[N,K]^T (+bias).  a/b bf16 (leading dims default to their row strides)."""
+        lda = a.stride(0) if lda is None else lda
+        ldb = b.stride(0) if ldb is None else ldb
+        ldc = c.stride(0) if ldc is None else ldc
+        self._chk(self.lib.tasu_gemm_nt_bf16(_p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), _p(resid), M, N, K, mode,
+                                             self._stream()), "tasu_gemm_nt_bf16")
+
+    def transpose(self, src, dst, R, C, Rpad, Cpad):
+        self._chk(self.lib.tasu_transpose_bf16(_p(src), src.stride(0), _p(dst), dst.stride(0), R, C, Rpad, Cpad,
+                                               self._stream()), "tasu_transpose_bf16")
+
+    def cast_bf16(self, src, dst):
+        self._chk(self.lib.tasu_cast_f32_bf16(_p(src), _p(dst), src.numel(), self._stream()), "tasu_cast_f32_bf16")
+
+    # ------------------------------------------------------------------ norms
+    def rmsnorm_fwd(self, x, w, y, rstd, eps):
+        M, D = x.shape
+        self._chk(self.lib.tasu_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), M, D, eps, self._stream()), "tasu_rmsnorm_fwd")
+
+    def rmsnorm_bwd(self, dy, x, w, rstd, dx, dx_bf16, accumulate):
+        M, D = x.shape
+        self._chk(self.lib.tasu_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dx), _p(dx_bf16), int(accumulate), M, D,
+                                            self._stream()), "tasu_rmsnorm_bwd")
+
+    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, R, D, eps):
+        self._chk(self.lib.tasu_layernorm_fwd(_p(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0),
+                                              int(y.dtype == torch.float32), _p(mean), _p(rstd), R, D, eps,
+                                              self._stream()), "tasu_layernorm_fwd")
+
+    def layernorm_bwd_params(self, dy, x, mean, rstd, dgamma, dbeta, ws, R, D):
+        self._chk(self.lib.tasu_layernorm_bwd_params(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(mean), _p(rstd),
+                                                     _p(dgamma), _p(dbeta), _p(ws), R, D, self._stream()),
+                  "tasu_layernorm_bwd_params")
+
+    def colsum(self, x, out, R, Cn):
+        self._chk(self.lib.tasu_colsum_bf16(_p(x), x.stride(0), _p(out), R, Cn, self._stream()), "tasu_colsum_bf16")
+
+    # ------------------------------------------------------------------ rope + attention
+    def rope_table(self, pos, cos, sin, head_dim, theta):
+        self._chk(self.lib.tasu_rope_table(_p(pos), _p(cos), _p(sin), pos.numel(), head_dim, theta, self._stream()),
+                  "tasu_rope_table")
+
+    def rope_fwd(self, qkv, cos, sin, qt, kt, vt, B, S, H, G):
+        self._chk(self.lib.tasu_rope_fwd(_p(qkv), _p(cos), _p(sin), _p(qt), _p(kt), _p(vt), B, S, H, G, self._stream()),
+                  "tasu_rope_fwd")
+
+    def rope_bwd(self, dqkv, dk_part, dv_part, cos, sin, B, S, H, G):
+        self._chk(self.lib.tasu_rope_bwd(_p(dqkv), _p(dk_part), _p(dv_part), _p(cos), _p(sin), B, S, H, G,
+                                         self._stream()), "tasu_rope_bwd")
+
+    def attn_fwd(self, qkv, vt, key_mask, out, lse, B, S, H, G, scale, causal):
+        self._chk(self.lib.tasu_attn_fwd(_p(qkv), _p(vt), _p(key_mask), _p(out), _p(lse), B, S, H, G, scale, int(causal),
+                                         self._stream()), "tasu_attn_fwd")
+
+    def attn_bwd_prep(self, dout, out, delta, dout_t, B, S, H):
+        self._chk(self.lib.tasu_attn_bwd_prep(_p(dout), _p(out), _p(delta), _p(dout_t), B, S, H, self._stream()),
+                  "tasu_attn_bwd_prep")
+
+    def attn_bwd_dq(self, qkv, kt, key_mask, dout, lse, delta, dqkv, B, S, H, G, scale, causal):
+        self._chk(self.lib.tasu_attn_bwd_dq(_p(qkv), _p(kt), _p(key_mask), _p(dout), _p(lse), _p(delta), _p(dqkv), B, S,
+                                            H, G, scale, int(causal), self._stream()), "tasu_attn_bwd_dq")
+
+    def attn_bwd_dkv(self, qkv, qt, key_mask, dout, dout_t, lse, delta, dk_part, dv_part, B, S, H, G, scale, causal):
+        self._chk(self.lib.tasu_attn_bwd_dkv(_p(qkv), _p(qt), _p(key_mask), _p(dout), _p(dout_t), _p(lse), _p(delta),
+                                             _p(dk_part), _p(dv_part), B, S, H, G, scale, int(causal), self._stream()),
+                  "tasu_attn_bwd_dkv")
+
+    # ------------------------------------------------------------------ activations
+    def swiglu_fwd(self, gu, act, M, I):
+        self._chk(self.lib.tasu_swiglu_fwd(_p(gu), _p(act), M, I, self._stream()), "tasu_swiglu_fwd")
+
+    def swiglu_bwd(self, dact, gu, dgu, M, I):
+        self._chk(self.lib.tasu_swiglu_bwd(_p(dact), _p(gu), _p(dgu), M, I, self._stream()), "tasu_swiglu_bwd")
+
+    def silu_fwd(self, x, y):
+        self._chk(self.lib.tasu_silu_fwd(_p(x), _p(y), x.numel(), self._stream()), "tasu_silu_fwd")
+
+    def silu_bwd(self, dy, x, dx):
+        self._chk(self.lib.tasu_silu_bwd(_p(dy), _p(x), _p(dx), x.numel(), self._stream()), "tasu_silu_bwd")
+
+    def relu_fwd(self, x, y):
+        self._chk(self.lib.tasu_relu_fwd(_p(x), _p(y), x.numel(), self._stream()), "tasu_relu_fwd")
+
+    # ------------------------------------------------------------------ loss
+    def ce_fwd_bwd(self, logits, shift_labels, M, V, row_loss, row_hit, row_argmax, dlogits, inv_count):
+        self._chk(self.lib.tasu_ce_fwd_bwd(_p(logits), logits.stride(0), _p(shift_labels), M, V, _p(row_loss),
+                                           _p(row_hit), _p(row_argmax), _p(dlogits), _p(inv_count), self._stream()),
+                  "tasu_ce_fwd_bwd")
+
+    def ce_reduce(self, row_loss, row_hit, shift_labels, M, out):
+        self._chk(self.lib.tasu_ce_reduce(_p(row_loss), _p(row_hit), _p(shift_labels), M, _p(out), self._stream()),
+                  "tasu_ce_reduce")
+
+    # ------------------------------------------------------------------ front end / merge
+    def posterior_build(self, ids, alpha, out, R, V):
+        self._chk(self.lib.tasu_posterior_build(_p(ids), _p(alpha), _p(out), out.stride(0), R, V, self._stream()),
+                  "tasu_posterior_build")
+
+    def embed_merge(self, table, proj, kind, idx, x, M, D):
+        self._chk(self.lib.tasu_embed_merge_fwd(_p(table), _p(proj), _p(kind), _p(idx), _p(x), M, D, self._stream()),
+                  "tasu_embed_merge_fwd")
+
+    def merge_bwd(self, dx, audio_rows, dproj, n, D):
+        self._chk(self.lib.tasu_merge_bwd(_p(dx), _p(audio_rows), _p(dproj), n, D, self._stream()), "tasu_merge_bwd")
+
+    # ------------------------------------------------------------------ optimizer
+    def adamw(self, p, g, m, v, p_bf16, lr_dev, beta1, beta2, eps, wd, step, grad_scale):
+        self._chk(self.lib.tasu_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(lr_dev), beta1, beta2, eps, wd,
+                                      step, grad_scale, self._stream()), "tasu_adamw")
+
+    # ------------------------------------------------------------------ encoder / PSD
+    def sinusoid_pe(self, x, y, B, T, D, scale):
+        self._chk(self.lib.tasu_sinusoid_pe(_p(x), _p(y), B, T, D, scale, self._stream()), "tasu_sinusoid_pe")
+
+    def fsmn_fwd(self, v, ldv, w, lens, out, B, T, D, ksize, accumulate):
+        self._chk(self.lib.tasu_fsmn_fwd(_p(v), ldv, _p(w), _p(lens), _p(out), B, T, D, ksize, int(accumulate),
+                                         self._stream()), "tasu_fsmn_fwd")
+
+    def softmax_rows(self, x, y, R, V):
+        self._chk(self.lib.tasu_softmax_rows(_p(x), x.stride(0), _p(y), y.stride(0), R, V, self._stream()),
+                  "tasu_softmax_rows")
+
+    def psd_frame_stats(self, post, lens, fid, fblank, B, T, V, blank_id):
+        self._chk(self.lib.tasu_psd_frame_stats(_p(post), post.stride(0), _p(lens), _p(fid), _p(fblank), B, T, V, blank_id,
+                                                self._stream()), "tasu_psd_frame_stats")
+
+    def psd_plan(self, fid, fblank, lens, seg_start, seg_len, new_lens, B, T, blank_id, thr):
+        self._chk(self.lib.tasu_psd_plan(_p(fid), _p(fblank), _p(lens), _p(seg_start), _p(seg_len), _p(new_lens), B, T,
+                                         blank_id, thr, self._stream()), "tasu_psd_plan")
+
+    def psd_gather(self, post, seg_start, seg_len, new_lens, out, B, T, Tout, V):
+        self._chk(self.lib.tasu_psd_gather(_p(post), post.stride(0), _p(seg_start), _p(seg_len), _p(new_lens), _p(out),
+                                           out.stride(0), B, T, Tout, V, self._stream()), "tasu_psd_gather")

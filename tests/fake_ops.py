@@ -1,0 +1,332 @@
+"""TEST DOUBLE (never shipped, never imported by ps_slm_amd): a torch-CPU implementation of the operator
+interface of ps_slm_amd/ops.py with the same signatures and the same rounding points as the HIP kernels.
+It lets the CPU test-suite drive the REAL host code (merge plan, buffer bookkeeping, forward/backward
+schedule, engine, DP) end to end and compare it with the oracle, so that the only thing left to check on
+the GPU is the kernels themselves (tests/test_gpu_*.py compare HipOps with this double op by op)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+HD = 128
+GEMM_BF16, GEMM_F32, GEMM_RESID = 0, 1, 2
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+class FakeOps:
+    name = "fake-cpu"
+
+    # ---------------------------------------------------------------- GEMM & layout
+    def gemm(self, a, b, c, M, N, K, bias=None, resid=None, mode=GEMM_BF16, lda=None, ldb=None, ldc=None):
+        assert K % 64 == 0, "K must be a multiple of 64 (layout contract of tasu_gemm_nt_bf16)"
+        A = a.reshape(-1, a.shape[-1])[:M, :K].float()
+        Bm = b.reshape(-1, b.shape[-1])[:N, :K].float()
+        acc = A @ Bm.t()
+        if bias is not None:
+            acc = acc + bias[:N].float()
+        C = c.reshape(-1, c.shape[-1])
+        if mode == GEMM_BF16:
+            C[:M, :N] = _bf(acc)
+        elif mode == GEMM_F32:
+            C[:M, :N] = acc
+        else:
+            R = resid.reshape(-1, resid.shape[-1])
+            C[:M, :N] = R[:M, :N] + _bf(acc).float()
+
+    def transpose(self, src, dst, R, C, Rpad, Cpad):
+        dst[:Cpad, :Rpad] = 0
+        dst[:C, :R] = src[:R, :C].t()
+
+    def cast_bf16(self, src, dst):
+        dst.copy_(_bf(src))
+
+    # ---------------------------------------------------------------- norms
+    def rmsnorm_fwd(self, x, w, y, rstd, eps):
+        r = torch.rsqrt(x.pow(2).mean(-1) + eps)
+        if rstd is not None:
+            rstd.copy_(r)
+        y.copy_(_bf(w * (x * r[:, None])))
+
+    def rmsnorm_bwd(self, dy, x, w, rstd, dx, dx_bf16, accumulate):
+        D = x.shape[-1]
+        d = dy.float()
+        xh = x * rstd[:, None]
+        dot = (w * d * xh).sum(-1, keepdim=True) / D
+        upd = rstd[:, None] * (w * d - xh * dot)
+        if accumulate:
+            dx.add_(upd)
+        else:
+            dx.copy_(upd)
+        if dx_bf16 is not None:
+            dx_bf16.copy_(_bf(dx))
+
+    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, R, D, eps):
+        xr = x[:R, :D]
+        mu = xr.mean(-1)
+        var = ((xr - mu[:, None]) ** 2).mean(-1)
+        r = torch.rsqrt(var + eps)
+        if mean is not None:
+            mean[:R] = mu
+        if rstd is not None:
+            rstd[:R] = r
+        y[:R].zero_()
+        y[:R, :D] = ((xr - mu[:, None]) * r[:, None] * gamma[:D] + beta[:D]).to(y.dtype)
+
+    def layernorm_bwd_params(self, dy, x, mean, rstd, dgamma, dbeta, ws, R, D):
+        d = dy[:R, :D].float()
+        xh = (x[:R, :D] - mean[:R, None]) * rstd[:R, None]
+        dgamma[:D] = (d * xh).sum(0)
+        dbeta[:D] = d.sum(0)
+
+    def colsum(self, x, out, R, Cn):
+        out[:Cn] = x[:R, :Cn].float().sum(0)
+
+    # ---------------------------------------------------------------- rope + attention
+    def rope_table(self, pos, cos, sin, head_dim, theta):
+        inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+        ang = pos.float()[:, None] * inv[None]
+        cos.copy_(ang.cos())
+        sin.copy_(ang.sin())
+
+    @staticmethod
+    def _rot(x, cos, sin, inverse=False):
+        x1, x2 = x[..., :64], x[..., 64:]
+        if inverse:
+            return torch.cat([x1 * cos + x2 * sin, x2 * cos - x1 * sin], -1)
+        return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], -1)
+
+    def rope_fwd(self, qkv, cos, sin, qt, kt, vt, B, S, H, G):
+        Spad = (S + 63) // 64 * 64
+        v = qkv.view(B, S, H + 2 * G, HD)
+        c, s = cos.view(B, S, 1, 64), sin.view(B, S, 1, 64)
+        v[:, :, : H + G] = _bf(self._rot(v[:, :, : H + G].float(), c, s))
+        for dst, lo, n in ((qt, 0, H), (kt, H, G), (vt, H + G, G)):
+            if dst is None:
+                continue
+            t = dst.view(B, n, HD, Spad)
+            t.zero_()
+            t[..., :S] = v[:, :, lo:lo + n].permute(0, 2, 3, 1)
+
+    def rope_bwd(self, dqkv, dk_part, dv_part, cos, sin, B, S, H, G):
+        v = dqkv.view(B, S, H + 2 * G, HD)
+        c, s = cos.view(B, S, 1, 64), sin.view(B, S, 1, 64)
+        rep = H // G
+        dk = dk_part.view(B, S, G, rep, HD).sum(3)
+        dv = dv_part.view(B, S, G, rep, HD).sum(3)
+        v[:, :, :H] = _bf(self._rot(v[:, :, :H].float(), c, s, inverse=True))
+        v[:, :, H:H + G] = _bf(self._rot(dk, c, s, inverse=True))
+        v[:, :, H + G:] = _bf(dv)
+
+    @staticmethod
+    def _allow(key_mask, B, S, causal):
+        km = key_mask.view(B, -1)[:, :S].bool()
+        allow = km[:, None, None, :].expand(B, 1, S, S)
+        if causal:
+            allow = allow & torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None]
+        return allow
+
+    def _qkv_heads(self, qkv, B, S, H, G):
+        v = qkv.view(B, S, H + 2 * G, HD).float()
+        rep = H // G
+        q = v[:, :, :H].permute(0, 2, 1, 3)
+        k = v[:, :, H:H + G].permute(0, 2, 1, 3).repeat_interleave(rep, 1)
+        vv = v[:, :, H + G:].permute(0, 2, 1, 3).repeat_interleave(rep, 1)
+        return q, k, vv
+
+    def attn_fwd(self, qkv, vt, key_mask, out, lse, B, S, H, G, scale, causal):
+        Spad = (S + 63) // 64 * 64
+        q, k, v = self._qkv_heads(qkv, B, S, H, G)
+        sc = (q @ k.transpose(-1, -2)) * scale
+        allow = self._allow(key_mask, B, S, causal)
+        sc = sc.masked_fill(~allow, float("-inf"))
+        m = sc.amax(-1, keepdim=True)
+        m = torch.where(torch.isinf(m), torch.zeros_like(m), m)
+        p = torch.exp(sc - m)
+        l = p.sum(-1, keepdim=True)
+        o = (_bf(p).float() @ v) / torch.where(l > 0, l, torch.ones_like(l))
+        o = torch.where(l > 0, o, torch.zeros_like(o))
+        out.view(B, S, H, HD).copy_(_bf(o.permute(0, 2, 1, 3)))
+        ls = torch.where(l > 0, m + torch.log(l), torch.zeros_like(l))[..., 0]
+        lse.view(B, H, Spad)[..., :S] = ls
+
+    def attn_bwd_prep(self, dout, out, delta, dout_t, B, S, H):
+        Spad = (S + 63) // 64 * 64
+        d = dout.view(B, S, H, HD)
+        delta.view(B, H, Spad)[..., :S] = (d.float() * out.view(B, S, H, HD).float()).sum(-1).permute(0, 2, 1)
+        t = dout_t.view(B, H, HD, Spad)
+        t.zero_()
+        t[..., :S] = d.permute(0, 2, 3, 1)
+
+    def _bwd_common(self, qkv, key_mask, dout, lse, delta, B, S, H, G, scale, causal):
+        Spad = (S + 63) // 64 * 64
+        q, k, v = self._qkv_heads(qkv, B, S, H, G)
+        do = dout.view(B, S, H, HD).float().permute(0, 2, 1, 3)
+        allow = self._allow(key_mask, B, S, causal)
+        ls = lse.view(B, H, Spad)[..., :S]
+        dl = delta.view(B, H, Spad)[..., :S]
+        p = torch.exp((q @ k.transpose(-1, -2)) * scale - ls[..., None])
+        p = torch.where(allow, p, torch.zeros_like(p))
+        dp = do @ v.transpose(-1, -2)
+        ds = p * (dp - dl[..., None])
+        return q, k, v, do, p, ds
+
+    def attn_bwd_dq(self, qkv, kt, key_mask, dout, lse, delta, dqkv, B, S, H, G, scale, causal):
+        q, k, v, do, p, ds = self._bwd_common(qkv, key_mask, dout, lse, delta, B, S, H, G, scale, causal)
+        dq = (_bf(ds).float() @ k) * scale
+        dqkv.view(B, S, H + 2 * G, HD)[:, :, :H] = _bf(dq.permute(0, 2, 1, 3))
+
+    def attn_bwd_dkv(self, qkv, qt, key_mask, dout, dout_t, lse, delta, dk_part, dv_part, B, S, H, G, scale, causal):
+        q, k, v, do, p, ds = self._bwd_common(qkv, key_mask, dout, lse, delta, B, S, H, G, scale, causal)
+        dv = _bf(p).float().transpose(-1, -2) @ do
+        dk = (_bf(ds).float().transpose(-1, -2) @ q) * scale
+        dk_part.view(B, S, H, HD).copy_(dk.permute(0, 2, 1, 3))
+        dv_part.view(B, S, H, HD).copy_(dv.permute(0, 2, 1, 3))
+
+    # ---------------------------------------------------------------- activations
+    def swiglu_fwd(self, gu, act, M, I):
+        g, u = gu[:, :I].float(), gu[:, I:].float()
+        act.copy_(_bf(_bf(F.silu(g)).float() * u))
+
+    def swiglu_bwd(self, dact, gu, dgu, M, I):
+        g, u, d = gu[:, :I].float(), gu[:, I:].float(), dact.float()
+        sg = torch.sigmoid(g)
+        dgu[:, :I] = _bf(d * u * sg * (1 + g * (1 - sg)))
+        dgu[:, I:] = _bf(d * g * sg)
+
+    def silu_fwd(self, x, y):
+        y.copy_(_bf(F.silu(x.float())))
+
+    def silu_bwd(self, dy, x, dx):
+        f = x.float()
+        sg = torch.sigmoid(f)
+        dx.copy_(_bf(dy.float() * sg * (1 + f * (1 - sg))))
+
+    def relu_fwd(self, x, y):
+        y.copy_(torch.relu(x))
+
+    # ---------------------------------------------------------------- loss
+    def ce_fwd_bwd(self, logits, shift_labels, M, V, row_loss, row_hit, row_argmax, dlogits, inv_count):
+        lg = logits[:M, :V].float()
+        lab = shift_labels[:M].long()
+        valid = lab >= 0
+        lse = torch.logsumexp(lg, -1)
+        arg = lg.argmax(-1)
+        safe = lab.clamp_min(0)
+        row_loss[:M] = torch.where(valid, lse - lg.gather(1, safe[:, None])[:, 0], torch.zeros_like(lse))
+        row_hit[:M] = (valid & (arg == lab)).to(row_hit.dtype)
+        if row_argmax is not None:
+            row_argmax[:M] = arg.to(row_argmax.dtype)
+        if dlogits is not None:
+            g = torch.exp(lg - lse[:, None])
+            g[torch.arange(M), safe] -= 1.0
+            g = g * inv_count.float() * valid[:, None]
+            dlogits[:M].zero_()
+            dlogits[:M, :V] = _bf(g)
+
+    def ce_reduce(self, row_loss, row_hit, shift_labels, M, out):
+        c = (shift_labels[:M] >= 0).sum().float()
+        out[0] = row_loss[:M].sum() / c
+        out[1] = row_hit[:M].sum().float() / c
+        out[2] = c
+        out[3] = 1.0 / c
+
+    # ---------------------------------------------------------------- front end / merge
+    def posterior_build(self, ids, alpha, out, R, V):
+        out[:R].zero_()
+        idl = ids[:R].long()
+        ok = idl >= 0
+        a = alpha[:R] if alpha is not None else torch.zeros(R)
+        base = torch.where(ok, a / V, torch.zeros_like(a))
+        out[:R, :V] = base[:, None]
+        rows = torch.nonzero(ok)[:, 0]
+        out[rows, idl[rows]] = (1 - a[rows]) + base[rows]
+
+    def embed_merge(self, table, proj, kind, idx, x, M, D):
+        k, i = kind[:M].long(), idx[:M].long()
+        x[:M].zero_()
+        t = torch.nonzero(k == 1)[:, 0]
+        x[t] = table[i[t]]
+        a = torch.nonzero(k == 2)[:, 0]
+        x[a] = proj.reshape(-1, D)[i[a]].float()
+
+    def merge_bwd(self, dx, audio_rows, dproj, n, D):
+        r = audio_rows[:n].long()
+        dproj[:n].zero_()
+        ok = torch.nonzero(r >= 0)[:, 0]
+        dproj[ok] = _bf(dx[r[ok]])
+
+    # ---------------------------------------------------------------- optimizer
+    def adamw(self, p, g, m, v, p_bf16, lr_dev, beta1, beta2, eps, wd, step, grad_scale):
+        lr = float(lr_dev[0])
+        gr = g * grad_scale
+        m.mul_(beta1).add_(gr, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gr, gr, value=1 - beta2)
+        bc1 = 1 - beta1 ** step
+        bc2 = 1 - beta2 ** step
+        denom = v.sqrt() / math.sqrt(bc2) + eps
+        p.mul_(1 - lr * wd).addcdiv_(m, denom, value=-lr / bc1)
+        if p_bf16 is not None:
+            p_bf16.copy_(_bf(p))
+
+    # ---------------------------------------------------------------- encoder / PSD
+    def sinusoid_pe(self, x, y, B, T, D, scale):
+        pos = torch.arange(1, T + 1, dtype=torch.float32)
+        inc = math.log(10000.0) / (D / 2 - 1)
+        inv = torch.exp(torch.arange(D // 2, dtype=torch.float32) * (-inc))
+        st = pos[:, None] * inv[None]
+        pe = torch.cat([st.sin(), st.cos()], 1)
+        y.view(B, T, D).copy_(x.view(B, T, D) * scale + pe[None])
+
+    def fsmn_fwd(self, v, ldv, w, lens, out, B, T, D, ksize, accumulate):
+        vv = v.reshape(B, T, -1)[..., :D].float()
+        mask = (torch.arange(T)[None] < lens[:, None]).float()[..., None]
+        vm = vv * mask
+        left = (ksize - 1) // 2
+        xp = F.pad(vm.transpose(1, 2), (left, ksize - 1 - left))
+        fs = F.conv1d(xp, w.view(D, 1, ksize), None, groups=D).transpose(1, 2)
+        r = ((fs + vm) * mask).reshape(B * T, D)
+        if accumulate:
+            out.add_(r)
+        else:
+            out.copy_(r)
+
+    def softmax_rows(self, x, y, R, V):
+        y[:R].zero_()
+        y[:R, :V] = torch.softmax(x[:R, :V], -1)
+
+    def psd_frame_stats(self, post, lens, fid, fblank, B, T, V, blank_id):
+        p = post.view(B, T, -1)[..., :V]
+        ids = p.argmax(-1).to(torch.int32)
+        live = torch.arange(T)[None] < lens[:, None]
+        fid.view(B, T).copy_(torch.where(live, ids, torch.full_like(ids, -1)))
+        fblank.view(B, T).copy_(torch.where(live, p[..., blank_id], torch.zeros(B, T)))
+
+    def psd_plan(self, fid, fblank, lens, seg_start, seg_len, new_lens, B, T, blank_id, thr):
+        ss, sl = seg_start.view(B, T), seg_len.view(B, T)
+        for b in range(B):
+            L = int(lens[b])
+            ids, bp = fid.view(B, T)[b], fblank.view(B, T)[b]
+            n, start = 0, 0
+            for end in range(1, L + 1):
+                if end == L or ids[end] != ids[start] or ids[start] == blank_id:
+                    ln = end - start
+                    s = bp[start:end].sum()
+                    mean = s if ln == 1 else s / ln
+                    if mean < thr:
+                        ss[b, n], sl[b, n] = start, ln
+                        n += 1
+                    start = end
+            new_lens[b] = n
+
+    def psd_gather(self, post, seg_start, seg_len, new_lens, out, B, T, Tout, V):
+        p = post.view(B, T, -1)
+        o = out.view(B, Tout, -1)
+        o.zero_()
+        for b in range(B):
+            for j in range(int(new_lens[b])):
+                s0, ln = int(seg_start.view(B, T)[b, j]), int(seg_len.view(B, T)[b, j])
+                seg = p[b, s0:s0 + ln, :V]
+                o[b, j, :V] = seg[0] if ln == 1 else seg.sum(0) / ln

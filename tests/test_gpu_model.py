@@ -1,0 +1,106 @@
+"""End-to-end GPU parity of the training step at the kernel-compatible "mid" geometry:
+HipOps (real kernels through the C-ABI) vs (a) the same host code on the FakeOps CPU double, (b) the oracle in
+bf16-emulation mode, (c) golden vectors produced by the REAL reference in fp32 (bf16 tolerance stated)."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz
+from fake_ops import FakeOps
+from oracle import tasu_oracle as O
+from ps_slm_amd.model import Geometry, TasuModel
+from ps_slm_amd.synthetic import MID_GEOMETRY, random_state_dict, synthetic_text_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def run_text(model, batch):
+    st = model.prepare_text(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["post_ids"],
+                            batch.get("alphas"), batch.get("keeps"))
+    model.forward_projector_text(st)
+    model.forward_llm(st)
+    model.backward(st)
+    if model.device.type == "cuda":
+        torch.cuda.synchronize()
+    return st
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from ps_slm_amd.ops import HipOps
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    sd = random_state_dict(geo, 2026, with_encoder=False)
+    gm = TasuModel(geo, HipOps(), "cuda")
+    gm.load_reference_state_dict(sd)
+    cm = TasuModel(geo, FakeOps(), "cpu")
+    cm.load_reference_state_dict(sd)
+    return geo, sd, gm, cm
+
+
+def cosine(a, b):
+    return float(torch.nn.functional.cosine_similarity(a.flatten().float().cpu(), b.flatten().float().cpu(), dim=0))
+
+
+@pytest.mark.parametrize("ragged,noise,drop", [(False, False, 0.0), (True, True, 0.15)])
+def test_step_vs_double_and_oracle(setup, ragged, noise, drop):
+    geo, sd, gm, cm = setup
+    batch = synthetic_text_batch(geo, 3, seed=31, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12,
+                                 noise=noise, drop_prob=drop, ragged=ragged)
+    sg, sc = run_text(gm, batch), run_text(cm, batch)
+    lg, lc = sg.dev["loss_out"].cpu(), sc.dev["loss_out"]
+    assert abs(float(lg[0]) - float(lc[0])) < 2e-3 and abs(float(lg[1]) - float(lc[1])) <= 1.0 / sc.plan.count + 1e-6
+    valid = torch.from_numpy(sc.plan.key_mask[:, : sc.S].astype(bool))
+    a, b = gm.logits_view(sg).float().cpu()[valid], cm.logits_view(sc).float()[valid]
+    assert float((a - b).abs().max() / b.abs().max()) < 2e-2          # bf16 logits: a few ulps of the logit scale
+    gg, gc = gm.projector_grads(), cm.projector_grads()
+    for k in gc:
+        assert cosine(gg[k], gc[k]) > 0.9995, k
+        assert float((gg[k].cpu() - gc[k]).norm() / gc[k].norm()) < 3e-2, k
+    out, grads = O.loss_and_projector_grads(sd, batch, dataclasses.asdict(geo), "bf16")
+    assert abs(float(lg[0]) - float(out["loss"])) < 5e-3
+    for k, g in grads.items():
+        assert cosine(gg[k], g) > 0.999, k
+
+
+def test_step_vs_reference_golden(setup):
+    """Golden = the real reference in fp32 (tests/golden/mid_text_clean.npz).  Stated bf16 tolerances:
+    |loss - ref| <= 2e-2, logits max-abs error <= 3% of the logit range, projector grads cosine >= 0.995."""
+    geo, sd, gm, _ = setup
+    z = load_npz("mid_text_clean")
+    assert int(z["seed_w"]) == 2026
+    batch = synthetic_text_batch(geo, 3, seed=int(z["seed_b"]), prompt_len=9, n_audio=21, target_len=17, speech_pos=4,
+                                 feat_frames=12, noise=True, drop_prob=0.15, ragged=True)
+    batch["post_ids"] = [list(np.asarray(p)[np.asarray(k, dtype=bool)]) for p, k in zip(batch["post_ids"], batch["keeps"])]
+    del batch["alphas"], batch["keeps"]
+    st = run_text(gm, batch)
+    res = st.dev["loss_out"].cpu()
+    assert abs(float(res[0]) - float(z["loss"])) < 2e-2
+    valid = torch.from_numpy(st.plan.key_mask[:, : st.S].astype(bool))
+    cols = torch.from_numpy(z["cols"])
+    lg = gm.logits_view(st).float().cpu()
+    ref = torch.from_numpy(z["logits_cols"])
+    assert float((lg[:, :, cols] - ref)[valid].abs().max() / ref[valid].abs().max()) < 3e-2
+    gg = gm.projector_grads()
+    for k, g in gg.items():
+        short = "grad." + k[len("encoder_projector."):]
+        if short in z:
+            assert cosine(g, torch.from_numpy(z[short])) > 0.995, k
+
+
+def test_adamw_step_moves_loss_down(setup):
+    """A few optimizer steps on one batch must reduce the loss and keep the K-padding columns exactly zero."""
+    geo, sd, gm, _ = setup
+    batch = synthetic_text_batch(geo, 2, seed=9, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12)
+    lr = torch.tensor([1e-3], device="cuda")
+    losses = []
+    for step in range(1, 6):
+        st = run_text(gm, batch)
+        losses.append(float(st.dev["loss_out"][0]))
+        gm.ops.adamw(gm.proj.p, gm.proj.g, gm.proj.m, gm.proj.v, gm.proj.pb, lr, 0.9, 0.999, 1e-6, 0.0, step, 1.0)
+        gm.proj.refresh_working_copies(gm.ops)
+    assert losses[-1] < losses[0]
+    w1 = gm.proj.view(gm.proj.p, "ffn.0.weight")
+    assert float(w1[:, geo.ctc_vocab:].abs().max()) == 0.0
+    gm.load_reference_state_dict(sd)  # restore for other tests

@@ -1,0 +1,332 @@
+"""GPU parity of every HIP kernel (through the C-ABI via ps_slm_amd.ops.HipOps) against the torch-CPU double in
+tests/fake_ops.py on the same seeded inputs.  Integer / index results must be bit-exact; floating point
+tolerances are stated per test (bf16 results: a few bf16 ulps = rel 2e-2 of the tensor scale; fp32: 1e-4)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from fake_ops import FakeOps
+
+pytestmark = pytest.mark.gpu
+HD = 128
+BF, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from ps_slm_amd.ops import HipOps
+    return HipOps()
+
+
+@pytest.fixture(scope="module")
+def fake():
+    return FakeOps()
+
+
+def dev(t):
+    return None if t is None else t.cuda()
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def run_pair(hip, fake, name, args, outs):
+    """args: list of CPU tensors / scalars; outs: indices of args that are outputs.  Returns (cpu, gpu) outs."""
+    cargs = [a.clone() if isinstance(a, torch.Tensor) else a for a in args]
+    gargs = [a.cuda() if isinstance(a, torch.Tensor) else a for a in args]
+    getattr(fake, name)(*cargs)
+    getattr(hip, name)(*gargs)
+    torch.cuda.synchronize()
+    return [cargs[i] for i in outs], [gargs[i].cpu() for i in outs]
+
+
+def randn(*shape, dtype=F32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 1000, 256), (130, 203, 192), (1, 64, 64),
+                                   (1024, 1536, 1536), (512, 256, 8960)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("bias", [False, True])
+def test_gemm(hip, fake, M, N, K, mode, bias):
+    ldc = (N + 63) // 64 * 64
+    a = randn(M, K, dtype=BF, seed=1)
+    b = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
+    bv = randn(N, dtype=BF, seed=3) if bias else None
+    c = torch.zeros(M, ldc, dtype=BF if mode == 0 else F32)
+    r = randn(M, ldc, seed=4) if mode == 2 else None
+    cc, gc = c.clone(), c.cuda()
+    fake.gemm(a, b, cc, M, N, K, bias=bv, resid=r, mode=mode)
+    hip.gemm(a.cuda(), b.cuda(), gc, M, N, K, bias=dev(bv), resid=dev(r), mode=mode)
+    torch.cuda.synchronize()
+    tol = 1e-2 if mode != 1 else 2e-5 * math.sqrt(K)
+    assert rel_err(gc, cc) < tol
+    assert torch.equal(gc.cpu()[:, N:], cc[:, N:]), "columns beyond N must be untouched"
+
+
+def test_gemm_exact_integers(hip):
+    """A = I (padded), asymmetric B: catches row/col swaps and k-permutation errors exactly."""
+    M = N = K = 128
+    a = torch.eye(M, K).to(BF)
+    b = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] % 7).float().to(BF)   # small ints: exact in bf16?
+    b = (torch.arange(N)[:, None] % 16 + (torch.arange(K)[None, :] % 5) * 16).to(BF)
+    c = torch.zeros(M, N, dtype=F32).cuda()
+    hip.gemm(a.cuda(), b.cuda(), c, M, N, K, mode=1)
+    torch.cuda.synchronize()
+    assert torch.equal(c.cpu(), (a.float() @ b.float().t()))
+
+
+def test_gemm_rejects_bad_k(hip):
+    from ps_slm_amd.ops import TasuOpError
+    a = torch.zeros(64, 96, dtype=BF).cuda()
+    with pytest.raises(TasuOpError):
+        hip.gemm(a, a, torch.zeros(64, 64, dtype=BF).cuda(), 64, 64, 96)
+
+
+def test_transpose_cast(hip, fake):
+    src = randn(100, 203, dtype=BF, seed=5)
+    dst = torch.full((256, 128), 7.0, dtype=BF)
+    (c,), (g,) = run_pair(hip, fake, "transpose", [src, dst, 100, 203, 128, 256], [1])
+    assert torch.equal(c, g)
+    x = randn(1000 * 37 + 3, seed=6)
+    (c,), (g,) = run_pair(hip, fake, "cast_bf16", [x, torch.zeros_like(x, dtype=BF)], [1])
+    assert torch.equal(c, g)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("M,D", [(37, 256), (512, 1536)])
+def test_rmsnorm(hip, fake, M, D):
+    x, w = randn(M, D, seed=1), 1 + 0.1 * randn(D, seed=2)
+    (yc, rc), (yg, rg) = run_pair(hip, fake, "rmsnorm_fwd", [x, w, torch.zeros(M, D, dtype=BF), torch.zeros(M), 1e-6],
+                                  [2, 3])
+    assert rel_err(yg, yc) < 1e-2 and rel_err(rg, rc) < 1e-5
+    dy = randn(M, D, dtype=BF, seed=3)
+    for acc in (False, True):
+        dx0 = randn(M, D, seed=4)
+        (dc, bc), (dg, bg) = run_pair(hip, fake, "rmsnorm_bwd", [dy, x, w, rc, dx0, torch.zeros(M, D, dtype=BF), acc],
+                                      [4, 5])
+        assert rel_err(dg, dc) < 1e-4 and rel_err(bg, bc) < 1e-2
+
+
+@pytest.mark.parametrize("R,D,Dp,out_dtype", [(20, 203, 256, BF), (8, 25055, 25088, BF), (16, 560, 560, F32)])
+def test_layernorm(hip, fake, R, D, Dp, out_dtype):
+    x = torch.zeros(R, Dp)
+    x[:, :D] = randn(R, D, seed=1).abs() * 0.01
+    x[torch.arange(R), torch.arange(R) % D] += 0.9           # posterior-like rows
+    g, b = torch.zeros(Dp), torch.zeros(Dp)
+    g[:D], b[:D] = 1 + 0.1 * randn(D, seed=2), 0.1 * randn(D, seed=3)
+    outs = run_pair(hip, fake, "layernorm_fwd", [x, g, b, torch.zeros(R, Dp, dtype=out_dtype), torch.zeros(R), torch.zeros(R),
+                                                 R, D, 1e-5], [3, 4, 5])
+    (yc, mc, rc), (yg, mg, rg) = outs
+    assert rel_err(yg, yc) < (1e-2 if out_dtype == BF else 1e-4)
+    assert rel_err(mg, mc) < 1e-5 and rel_err(rg, rc) < 1e-4
+    assert float(yg[:, D:].abs().max() if Dp > D else 0) == 0
+    dy = randn(R, Dp, dtype=BF, seed=4)
+    ws = torch.zeros(2 * 16 * D)
+    (gc, bc), (gg, bg) = run_pair(hip, fake, "layernorm_bwd_params", [dy, x, mc, rc, torch.zeros(Dp), torch.zeros(Dp), ws, R, D],
+                                  [4, 5])
+    assert rel_err(gg, gc) < 1e-4 and rel_err(bg, bc) < 1e-4
+
+
+def test_colsum(hip, fake):
+    x = randn(333, 200, dtype=BF, seed=1)
+    (c,), (g,) = run_pair(hip, fake, "colsum", [x, torch.zeros(200), 333, 200], [1])
+    assert rel_err(g, c) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ rope + attention
+def make_mask(B, S, kind):
+    Spad = (S + 63) // 64 * 64
+    m = torch.zeros(B, Spad, dtype=torch.uint8)
+    for b in range(B):
+        n = S - (b * 7) % max(S // 2, 1)
+        if kind == "right":
+            m[b, :n] = 1
+        elif kind == "left":
+            m[b, S - n:S] = 1
+        else:
+            m[b, :S] = 1
+    return m
+
+
+@pytest.mark.parametrize("B,S,H,G", [(2, 100, 4, 2), (2, 256, 12, 2), (1, 64, 2, 1)])
+def test_rope(hip, fake, B, S, H, G):
+    M, LD, Spad = B * S, (H + 2 * G) * HD, (S + 63) // 64 * 64
+    pos = torch.randint(0, S, (M,), dtype=I32)
+    (cc, sc), (cg, sg) = run_pair(hip, fake, "rope_table", [pos, torch.zeros(M, 64), torch.zeros(M, 64), HD, 1e6], [1, 2])
+    assert rel_err(cg, cc) < 1e-5 and rel_err(sg, sc) < 1e-5
+    qkv = randn(M, LD, dtype=BF, seed=1)
+    outs = run_pair(hip, fake, "rope_fwd", [qkv, cc, sc, torch.ones(B * H * HD * Spad, dtype=BF), torch.ones(B * G * HD * Spad, dtype=BF),
+                                            torch.ones(B * G * HD * Spad, dtype=BF), B, S, H, G], [0, 3, 4, 5])
+    for c, g in zip(*outs):
+        assert rel_err(g, c) < 1e-2
+    dqkv = randn(M, LD, dtype=BF, seed=2)
+    dkp, dvp = randn(M, H * HD, seed=3), randn(M, H * HD, seed=4)
+    (c,), (g,) = run_pair(hip, fake, "rope_bwd", [dqkv, dkp, dvp, cc, sc, B, S, H, G], [0])
+    assert rel_err(g, c) < 1e-2
+
+
+@pytest.mark.parametrize("B,S,H,G", [(2, 100, 4, 2), (2, 256, 12, 2), (3, 64, 2, 1), (1, 192, 4, 4)])
+@pytest.mark.parametrize("mask_kind", ["right", "left", "none"])
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_fwd_bwd(hip, fake, B, S, H, G, mask_kind, causal):
+    M, LD, Spad = B * S, (H + 2 * G) * HD, (S + 63) // 64 * 64
+    scale = HD ** -0.5
+    qkv = randn(M, LD, dtype=BF, seed=1)
+    km = make_mask(B, S, mask_kind)
+    cos, sin = torch.ones(M, 64), torch.zeros(M, 64)          # identity rotation: only the transposes matter here
+    qt, kt, vt = (torch.zeros(B * n * HD * Spad, dtype=BF) for n in (H, G, G))
+    fake.rope_fwd(qkv, cos, sin, qt, kt, vt, B, S, H, G)
+    out, lse = torch.zeros(M, H * HD, dtype=BF), torch.zeros(B * H * Spad)
+    (oc, lc), (og, lg) = run_pair(hip, fake, "attn_fwd", [qkv, vt, km, out, lse, B, S, H, G, scale, causal], [3, 4])
+    live = km[:, :S].bool()                                   # query rows that are real tokens
+    oc4, og4 = oc.view(B, S, H, HD), og.view(B, S, H, HD)
+    assert rel_err(og4[live], oc4[live]) < 2e-2
+    lcv, lgv = lc.view(B, H, Spad)[..., :S], lg.view(B, H, Spad)[..., :S]
+    lm = live[:, None, :].expand(B, H, S)
+    assert float((lgv - lcv)[lm].abs().max()) < 2e-3
+    # backward
+    dout = randn(M, H * HD, dtype=BF, seed=2)
+    dout.view(B, S, H, HD)[~live] = 0                          # padded rows carry no gradient in the real model
+    (dc, tc), (dg, tg) = run_pair(hip, fake, "attn_bwd_prep", [dout, oc, torch.zeros(B * H * Spad), torch.ones(B * H * HD * Spad, dtype=BF),
+                                                               B, S, H], [2, 3])
+    assert float((dg.view(B, H, Spad)[..., :S] - dc.view(B, H, Spad)[..., :S]).abs().max()) < 1e-3 * max(1.0, float(dc.abs().max()))
+    assert torch.equal(tg, tc)
+    dqkv = torch.zeros(M, LD, dtype=BF)
+    (qc,), (qg,) = run_pair(hip, fake, "attn_bwd_dq", [qkv, kt, km, dout, lc, dc, dqkv, B, S, H, G, scale, causal], [6])
+    assert rel_err(qg.view(B, S, -1)[:, :, :H * HD], qc.view(B, S, -1)[:, :, :H * HD]) < 2e-2
+    dkp, dvp = torch.zeros(M, H * HD), torch.zeros(M, H * HD)
+    (kc, vc), (kg, vg) = run_pair(hip, fake, "attn_bwd_dkv", [qkv, qt, km, dout, tc, lc, dc, dkp, dvp, B, S, H, G, scale, causal],
+                                  [7, 8])
+    assert rel_err(kg, kc) < 2e-2 and rel_err(vg, vc) < 2e-2
+
+
+def test_attention_online_softmax_rescale(hip, fake):
+    """Force the running-max rescale branch: one late key dominates every earlier tile."""
+    B, S, H, G = 1, 256, 2, 1
+    M, LD, Spad = B * S, (H + 2 * G) * HD, 256
+    qkv = randn(M, LD, dtype=BF, seed=3, scale=0.3)
+    v = qkv.view(B, S, H + 2 * G, HD)
+    v[0, 200, H] = v[0, 255, 0] * 8.0                           # key 200 spikes against query 255 (head 0)
+    km = make_mask(B, S, "none")
+    qt, kt, vt = (torch.zeros(B * n * HD * Spad, dtype=BF) for n in (H, G, G))
+    fake.rope_fwd(qkv, torch.ones(M, 64), torch.zeros(M, 64), qt, kt, vt, B, S, H, G)
+    (oc, lc), (og, lg) = run_pair(hip, fake, "attn_fwd", [qkv, vt, km, torch.zeros(M, H * HD, dtype=BF), torch.zeros(B * H * Spad),
+                                                          B, S, H, G, HD ** -0.5, True], [3, 4])
+    assert rel_err(og, oc) < 2e-2 and float((lg - lc).abs().max()) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ activations
+def test_swiglu_silu_relu(hip, fake):
+    M, I = 77, 512
+    gu = randn(M, 2 * I, dtype=BF, seed=1, scale=2.0)
+    (c,), (g,) = run_pair(hip, fake, "swiglu_fwd", [gu, torch.zeros(M, I, dtype=BF), M, I], [1])
+    assert rel_err(g, c) < 1e-2
+    dact = randn(M, I, dtype=BF, seed=2)
+    (c,), (g,) = run_pair(hip, fake, "swiglu_bwd", [dact, gu, torch.zeros(M, 2 * I, dtype=BF), M, I], [2])
+    assert rel_err(g, c) < 1e-2
+    x = randn(1003, dtype=BF, seed=3, scale=3.0)
+    (c,), (g,) = run_pair(hip, fake, "silu_fwd", [x, torch.zeros_like(x)], [1])
+    assert rel_err(g, c) < 1e-2
+    (c,), (g,) = run_pair(hip, fake, "silu_bwd", [randn(1003, dtype=BF, seed=4), x, torch.zeros_like(x)], [2])
+    assert rel_err(g, c) < 1e-2
+    (c,), (g,) = run_pair(hip, fake, "relu_fwd", [x, torch.zeros_like(x)], [1])
+    assert torch.equal(c, g)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("M,V,ldv", [(50, 1000, 1024), (6, 151936, 151936)])
+def test_cross_entropy(hip, fake, M, V, ldv):
+    lg = torch.zeros(M, ldv, dtype=BF)
+    lg[:, :V] = randn(M, V, dtype=BF, seed=1, scale=3.0)
+    lab = torch.randint(0, V, (M,), dtype=I32)
+    lab[::3] = -100
+    lab[1] = int(lg[1, :V].float().argmax())                   # at least one hit
+    cnt = float((lab >= 0).sum())
+    inv = torch.tensor([1.0 / cnt])
+    args = [lg, lab, M, V, torch.zeros(M), torch.zeros(M, dtype=I32), torch.zeros(M, dtype=I32), torch.ones(M, ldv, dtype=BF), inv]
+    (lc, hc, ac, dc), (lgp, hg, ag, dg) = run_pair(hip, fake, "ce_fwd_bwd", args, [4, 5, 6, 7])
+    assert rel_err(lgp, lc) < 1e-4
+    assert torch.equal(hg, hc) and torch.equal(ag, ac)
+    assert rel_err(dg, dc) < 1e-2
+    (oc,), (og,) = run_pair(hip, fake, "ce_reduce", [lc, hc, lab, M, torch.zeros(4)], [4])
+    assert rel_err(og, oc) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ front end
+def test_posterior_merge_adamw(hip, fake):
+    R, V, ld = 40, 203, 256
+    ids = torch.randint(0, V, (R,), dtype=I32)
+    ids[5::7] = -1
+    alpha = torch.rand(R) * 0.1
+    (c,), (g,) = run_pair(hip, fake, "posterior_build", [ids, alpha, torch.ones(R, ld), R, V], [2])
+    assert torch.equal(c, g)
+    M, D, Vt = 60, 256, 500
+    table, proj = randn(Vt, D, seed=1), randn(R, D, dtype=BF, seed=2)
+    kind = torch.randint(0, 3, (M,), dtype=I32)
+    idx = torch.where(kind == 1, torch.randint(0, Vt, (M,)), torch.randint(0, R, (M,))).to(I32)
+    (c,), (g,) = run_pair(hip, fake, "embed_merge", [table, proj, kind, idx, torch.ones(M, D), M, D], [4])
+    assert torch.equal(c, g)
+    rows = torch.randint(-1, M, (R,), dtype=I32)
+    (c,), (g,) = run_pair(hip, fake, "merge_bwd", [randn(M, D, seed=3), rows, torch.ones(R, D, dtype=BF), R, D], [2])
+    assert torch.equal(c, g)
+    n = 4096 + 64
+    p, gr, m, v = randn(n, seed=4), randn(n, seed=5), randn(n, seed=6).abs() * 0.1, randn(n, seed=7).abs() * 0.01
+    lr = torch.tensor([5e-5])
+    outs = run_pair(hip, fake, "adamw", [p, gr, m, v, torch.zeros(n, dtype=BF), lr, 0.9, 0.999, 1e-6, 0.01, 3, 0.125], [0, 2, 3, 4])
+    for c, g in zip(*outs):
+        assert rel_err(g, c) < 1e-5 if c.dtype == F32 else rel_err(g, c) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ encoder / PSD
+def test_encoder_aux(hip, fake):
+    B, T, D = 2, 37, 80
+    x = randn(B * T, D, seed=1)
+    (c,), (g,) = run_pair(hip, fake, "sinusoid_pe", [x, torch.zeros(B * T, D), B, T, D, 16.0], [1])
+    assert rel_err(g, c) < 1e-5
+    E, ks = 256, 11
+    qkv = randn(B * T, 3 * E, dtype=BF, seed=2)
+    w = randn(E, ks, seed=3, scale=0.2)
+    lens = torch.tensor([37, 20], dtype=I32)
+    vcol = qkv[:, 2 * E:]
+    c = torch.zeros(B * T, E)
+    fake.fsmn_fwd(vcol, 3 * E, w, lens, c, B, T, E, ks, False)
+    gq = qkv.cuda()
+    g = torch.zeros(B * T, E).cuda()
+    hip.fsmn_fwd(gq[:, 2 * E:], 3 * E, w.cuda(), lens.cuda(), g, B, T, E, ks, False)
+    assert rel_err(g, c) < 1e-5
+    R, V, ld = 30, 203, 256
+    lg = randn(R, ld, seed=4, scale=3.0)
+    (c,), (g,) = run_pair(hip, fake, "softmax_rows", [lg, torch.ones(R, ld), R, V], [1])
+    assert rel_err(g, c) < 1e-5 and float(g[:, V:].abs().max()) == 0
+
+
+def test_psd_kernels(hip, fake):
+    from conftest import load_npz
+    z = load_npz("psd_crafted")
+    post = torch.from_numpy(z["posterior"])                     # [B, T, V]
+    B, T, V = post.shape
+    ld = 64
+    p2 = torch.zeros(B * T, ld)
+    p2[:, :V] = post.reshape(B * T, V)
+    lens = torch.from_numpy(z["lens"]).to(I32)
+    (fc, bc), (fg, bg) = run_pair(hip, fake, "psd_frame_stats", [p2, lens, torch.zeros(B * T, dtype=I32), torch.zeros(B * T), B, T, V, 0], [2, 3])
+    assert torch.equal(fc, fg) and torch.equal(bc, bg)
+    outs = run_pair(hip, fake, "psd_plan", [fc, bc, lens, torch.zeros(B * T, dtype=I32), torch.zeros(B * T, dtype=I32),
+                                            torch.zeros(B, dtype=I32), B, T, 0, 0.9], [3, 4, 5])
+    (sc, lc, nc), (sg, lg_, ng) = outs
+    assert torch.equal(nc, ng) and np.array_equal(nc.numpy(), z["new_lens"])
+    for b in range(B):
+        n = int(nc[b])
+        assert torch.equal(sc.view(B, T)[b, :n], sg.view(B, T)[b, :n]) and torch.equal(lc.view(B, T)[b, :n], lg_.view(B, T)[b, :n])
+    Tout = int(nc.max())
+    (oc,), (og,) = run_pair(hip, fake, "psd_gather", [p2, sc, lc, nc, torch.ones(B * Tout, ld), B, T, Tout, V], [4])
+    assert rel_err(og, oc) < 1e-6
+    ref = torch.from_numpy(z["out"])                            # the REAL reference's PSD output
+    torch.testing.assert_close(og.view(B, Tout, ld)[:, :, :V], ref, rtol=1e-5, atol=1e-7)

@@ -1,0 +1,107 @@
+"""Drives the REAL host code (ps_slm_amd.model / merge) on CPU through the FakeOps test double and checks it
+against the oracle.  This pins buffer bookkeeping, the forward/backward schedule and the merge plan; the HIP
+kernels themselves are checked against the same double in tests/test_gpu_*.py."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from fake_ops import FakeOps
+from oracle import tasu_oracle as O
+from ps_slm_amd.model import Geometry, TasuModel
+from ps_slm_amd.synthetic import MID_GEOMETRY, random_state_dict, synthetic_text_batch
+
+
+def build(geo, sd):
+    m = TasuModel(geo, FakeOps(), "cpu")
+    m.load_reference_state_dict(sd)
+    return m
+
+
+def run_text(model, batch):
+    st = model.prepare_text(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["post_ids"],
+                            batch.get("alphas"), batch.get("keeps"))
+    model.forward_projector_text(st)
+    model.forward_llm(st)
+    model.backward(st)
+    return st
+
+
+@pytest.fixture(scope="module")
+def mid():
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    sd = random_state_dict(geo, 7, with_encoder=False)
+    return geo, sd
+
+
+@pytest.mark.parametrize("ragged,noise,drop", [(False, False, 0.0), (True, True, 0.0), (True, True, 0.2)])
+def test_text_step_matches_oracle_bf16(mid, ragged, noise, drop):
+    geo, sd = mid
+    batch = synthetic_text_batch(geo, 3, seed=11, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8,
+                                 noise=noise, drop_prob=drop, ragged=ragged)
+    model = build(geo, sd)
+    st = run_text(model, batch)
+    gd = dataclasses.asdict(geo)
+    out, grads = O.loss_and_projector_grads(sd, batch, gd, "bf16")
+    res = st.dev["loss_out"]
+    assert abs(float(res[0]) - float(out["loss"])) < 5e-3
+    assert abs(float(res[1]) - float(out["acc"])) < 1e-6 + 1.0 / max(st.plan.count, 1)
+    lg = model.logits_view(st).float()
+    ref = out["logits"].detach()
+    valid = out["mask"]
+    assert np.array_equal(st.plan.key_mask[:, : st.S].astype(bool), valid.numpy())
+    err = (lg - ref)[valid].abs().max() / ref[valid].abs().max()
+    assert err < 2e-2, err
+    mine = model.projector_grads()
+    for k, g in grads.items():
+        cos = torch.nn.functional.cosine_similarity(mine[k].flatten(), g.flatten(), dim=0)
+        rel = (mine[k] - g).norm() / g.norm()
+        assert cos > 0.999 and rel < 5e-2, (k, float(cos), float(rel))
+
+
+def test_text_step_close_to_fp32_oracle(mid):
+    geo, sd = mid
+    batch = synthetic_text_batch(geo, 2, seed=5, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8,
+                                 ragged=True)
+    model = build(geo, sd)
+    st = run_text(model, batch)
+    out, grads = O.loss_and_projector_grads(sd, batch, dataclasses.asdict(geo), "fp32")
+    assert abs(float(st.dev["loss_out"][0]) - float(out["loss"])) < 2e-2
+    mine = model.projector_grads()
+    for k, g in grads.items():
+        cos = torch.nn.functional.cosine_similarity(mine[k].flatten(), g.flatten(), dim=0)
+        assert cos > 0.995, (k, float(cos))
+
+
+def test_left_padding_batch(mid):
+    geo, sd = mid
+    batch = synthetic_text_batch(geo, 2, seed=3, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8,
+                                 noise=False, ragged=True)
+    # turn right padding into left padding
+    ids, am, lab = batch["input_ids"].clone(), batch["attention_mask"].clone(), batch["labels"].clone()
+    for b in range(ids.shape[0]):
+        n = int(am[b].sum())
+        L = ids.shape[1]
+        ids[b] = torch.cat([ids[b, n:], ids[b, :n]])
+        am[b] = torch.cat([am[b, n:], am[b, :n]])
+        lab[b] = torch.cat([lab[b, n:], lab[b, :n]])
+    batch.update(input_ids=ids, attention_mask=am, labels=lab)
+    model = build(geo, sd)
+    st = run_text(model, batch)
+    assert st.plan.left_padding
+    out, grads = O.loss_and_projector_grads(sd, batch, dataclasses.asdict(geo), "bf16")
+    assert abs(float(st.dev["loss_out"][0]) - float(out["loss"])) < 5e-3
+    mine = model.projector_grads()
+    for k, g in grads.items():
+        assert torch.nn.functional.cosine_similarity(mine[k].flatten(), g.flatten(), dim=0) > 0.999, k
+
+
+def test_state_dict_roundtrip(mid):
+    geo, sd = mid
+    model = build(geo, sd)
+    out = model.projector_state_dict()
+    for k, v in out.items():
+        assert v.shape == sd[k].shape
+        torch.testing.assert_close(v, sd[k])
+    assert model.proj.num_parameters() == sum(sd[k].numel() for k in out)

@@ -143,3 +143,48 @@ def test_warmup_cosine_shape():
     assert all(b >= a for a, b in zip(lr[:200], lr[1:201]))
     assert abs(max(lr) - 5e-5) < 1e-9
     assert abs(lr[-1] - 5e-5 * 1e-4) < 1e-9
+
+
+# ------------------------------------------------------------------ kernel-compatible ("mid") geometry
+def mid_setup(name):
+    import dataclasses
+
+    from ps_slm_amd.model import Geometry
+    from ps_slm_amd.synthetic import MID_GEOMETRY, random_state_dict, synthetic_text_batch
+
+    z = load_npz(name)
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    sd = random_state_dict(geo, int(z["seed_w"]), with_encoder=True)
+    batch = synthetic_text_batch(geo, 3, seed=int(z["seed_b"]), prompt_len=9, n_audio=21, target_len=17, speech_pos=4,
+                                 feat_frames=12, noise=True, drop_prob=0.15, ragged=True)
+    # the fixture used the clean posterior of the kept ids (see oracle/make_golden.py:main_mid)
+    batch["post_ids"] = [list(np.asarray(p)[np.asarray(k, dtype=bool)]) for p, k in zip(batch["post_ids"], batch["keeps"])]
+    del batch["alphas"], batch["keeps"]
+    return geo, dataclasses.asdict(geo), sd, batch, z
+
+
+def check_mid(out, grads, z, tol):
+    close(out["loss"], z["loss"], rtol=tol, atol=tol)
+    lg = out["logits"].detach()
+    valid = out["mask"]
+    cols = torch.from_numpy(z["cols"])
+    close(lg[:, :, cols][valid], torch.from_numpy(z["logits_cols"])[valid], rtol=20 * tol, atol=20 * tol)
+    close(torch.logsumexp(lg, -1)[valid], torch.from_numpy(z["lse"])[valid], rtol=20 * tol, atol=20 * tol)
+    for k, g in grads.items():
+        short = k[len("encoder_projector."):]
+        if "grad." + short in z:
+            close(g, z["grad." + short], rtol=50 * tol, atol=tol)
+        elif "grad." + short + ".even_rows" in z:
+            close(g[::2], z["grad." + short + ".even_rows"], rtol=50 * tol, atol=tol)
+
+
+def test_mid_text_fp32():
+    geo, gd, sd, batch, z = mid_setup("mid_text_clean")
+    out, grads = O.loss_and_projector_grads(sd, batch, gd, "fp32")
+    check_mid(out, grads, z, 1e-5)
+
+
+def test_mid_audio_fp32():
+    geo, gd, sd, batch, z = mid_setup("mid_audio")
+    out, grads = O.loss_and_projector_grads(sd, batch, gd, "fp32", audio=True)
+    check_mid(out, grads, z, 1e-5)
