@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: train utterances/sec of the TASU alignment step
+(SenseVoiceSmall -> projector -> Qwen2.5-1.5B, text-only CPS recipe, bf16) at N GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over one synthetic batch per GPU: host merge plan + tiny H2D of the
+integer inputs, pseudo-posterior build, projector fwd, 28-layer decoder fwd, lm_head + CE, dgrad-only backward,
+projector wgrad, gradient all-reduce over RCCL (N > 1) and fused AdamW.  Weights are seeded random-init at the
+exact Qwen2.5-1.5B / projector geometry (no pretrained weights exist on the box).  The frozen SenseVoice encoder
+pass, whose result the reference throws away in text-only mode (Multitask/model/ps-slm.py:430-454 vs :459-468),
+is NOT executed (stated in config.workload).
+
+Prints ONE JSON line (rank 0) with `roofline` (MFMA GEMM kernel, timed live with HIP events on the launch
+stream) and, at N = 1, `cpu_baseline` (the oracle's CPU port timed on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+
+
+def gemm_flops_per_utt(geo, S, n_audio):
+    """Algorithmic FLOPs that run inside the MFMA GEMM kernel per utterance (weights only,
+    multiply-add = 2 FLOPs): decoder linears + lm_head, forward and dgrad-only backward, projector fwd + bwd."""
+    D, I, H, G, V, L = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_vocab, geo.llm_layers
+    per_layer = D * (H + 2 * G) * 128 + H * 128 * D + 3 * D * I
+    llm_tok = 2 * (L * per_layer + V * D)
+    proj_tok = 2 * (geo.ctc_vocab * geo.bottleneck + geo.bottleneck * D)
+    return 2 * llm_tok * S + 3 * proj_tok * n_audio
+
+
+def total_flops_per_utt(geo, S, n_audio):
+    """SURVEY.md 8d text-only total (adds causal attention: fwd 2*S*D*L per token, bwd 2.5x)."""
+    attn = geo.llm_layers * 2 * S * geo.llm_heads * 128 * S
+    return gemm_flops_per_utt(geo, S, n_audio) + attn + 2.5 * attn
+
+
+class TimedOps:
+    """Wraps HipOps.gemm with HIP event pairs recorded on the launch stream (torch's current stream)."""
+
+    def __init__(self, ops):
+        self._ops = ops
+        self.enabled = False
+        self.events = []
+
+    def __getattr__(self, name):
+        return getattr(self._ops, name)
+
+    def gemm(self, *a, **k):
+        if not self.enabled:
+            return self._ops.gemm(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._ops.gemm(*a, **k)
+        e1.record()
+        self.events.append((e0, e1))
+
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (CPU port of the reference path, oracle/tasu_oracle.py) at FULL geometry, fp32, B = 1 synthetic
+    utterance, fwd + bwd + AdamW, all host cores; encoder pass skipped like the GPU leg."""
+    import dataclasses
+
+    from oracle import tasu_oracle as O
+    from ps_slm_amd.model import Geometry
+    from ps_slm_amd.synthetic import random_state_dict, synthetic_text_batch
+
+    geo = Geometry.qwen25_1p5b()
+    torch.set_num_threads(os.cpu_count())
+    sd = random_state_dict(geo, 1234, with_encoder=False, scale=0.02)
+    batch = synthetic_text_batch(geo, 1, seed=1234)
+    gd = dataclasses.asdict(geo)
+    m = {k: torch.zeros_like(sd[k]) for k in O.PROJ_KEYS}
+    v = {k: torch.zeros_like(sd[k]) for k in O.PROJ_KEYS}
+    times = []
+    step = 0
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        out, grads = O.loss_and_projector_grads(sd, batch, gd, "fp32")
+        step += 1
+        for k in O.PROJ_KEYS:
+            O.adamw_step(sd[k], grads[k], m[k], v[k], step, 5e-5)
+        times.append(time.perf_counter() - t0)
+        if len(times) >= 2 and (time.perf_counter() - t_start > seconds_budget or len(times) >= 4):
+            break
+    timed = times[1:]
+    return {"value": round(1.0 / (sum(timed) / len(timed)), 4), "unit": "utterances/s", "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": f"oracle/tasu_oracle.py fp32, B=1 utterance (S=256, 104 audio tokens), fwd+bwd+AdamW, "
+                      f"{len(timed)} timed iterations after 1 warm-up, torch {torch.__version__} with {os.cpu_count()} threads, "
+                      f"encoder pass skipped"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
+    ap.add_argument("--model", default="qwen2.5-1.5b", choices=["qwen2.5-1.5b", "qwen2.5-7b", "mid"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--drop-prob", type=float, default=0.0, help="CPS token drop (0 keeps S fixed at 256)")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    from ps_slm_amd.config import DEFAULT_DS_CONFIG, ModelConfig, TrainConfig, load_ds_config
+    from ps_slm_amd.engine import TasuEngine
+    from ps_slm_amd.ps_slm import model_factory
+    from ps_slm_amd.synthetic import synthetic_text_batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    train_config = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=True, ctc_posterior=True,
+                               do_psd=True, use_fp16=True, batching_strategy="dynamic")
+    model_config = ModelConfig(llm_path=f"synthetic:{args.model}", encoder_projector="linear-silu", encoder_dim=25055,
+                               llm_dim={"qwen2.5-1.5b": 1536, "qwen2.5-7b": 3584, "mid": 256}[args.model])
+    model, _ = model_factory(train_config, model_config, device=f"cuda:{local_rank}", init_seed=1234, keep_logits=False)
+    model.drop_prob = args.drop_prob
+    core = model.core
+    timed = TimedOps(core.ops)
+    core.ops = timed
+    engine = TasuEngine(model, load_ds_config(DEFAULT_DS_CONFIG))
+    engine.train()
+    geo = core.geo
+
+    B = args.batch
+    raw = synthetic_text_batch(geo, B, seed=1234 + rank, noise=False)
+    GT = [" ".join(map(str, p)) for p in raw["post_ids"]]
+    batch = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
+                 input_features=None, input_feature_length=None, GT=GT)
+    torch.manual_seed(1234 + rank)          # CPS alpha / keep draws come from the global CPU RNG, like the reference
+
+    def step():
+        out, acc = engine(**batch)
+        engine.backward(out.loss)
+        engine.step()
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timed.enabled = rank == 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timed.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out.loss)
+
+    if rank == 0:
+        S = engine._last_state.S
+        n_audio = len(raw["post_ids"][0])
+        utt_per_s = world * B * args.steps / dt
+        gemm_ms = timed.total_ms()
+        n_launch = len(timed.events)
+        gemm_flops_step = gemm_flops_per_utt(geo, S, n_audio) * B
+        achieved = gemm_flops_step * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        line = {
+            "metric": "train utterances/sec (Qwen2.5-1.5B align)", "value": round(utt_per_s, 2), "unit": "utterances/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"text-only CPS alignment step (fwd+dgrad bwd+projector wgrad+AdamW), {args.model}, "
+                                   f"{B} utterances/GPU x S={S} (25 prompt + {n_audio} audio + 128 target tokens), "
+                                   f"frozen encoder pass skipped, logits for all positions",
+                       "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_nt_kernel (tasu_gemm_nt_bf16)", "launches_per_step": n_launch // max(args.steps, 1),
+                         "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
+                         "algorithmic_gflop_per_launch": round(gemm_flops_step * args.steps / max(n_launch, 1) / 1e9, 2),
+                         "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4),
+                         "whole_step_tflops": round(total_flops_per_utt(geo, S, n_audio) * B * args.steps / dt / 1e12, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.model == "qwen2.5-1.5b":
+            del engine, model, core
+            torch.cuda.empty_cache()
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -398,9 +398,8 @@ extern "C" int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key
                              int S, int H, int G, float scale, int causal, void* stream) {
   if (!qkv || !vt || !key_mask || !out || !lse || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
   dim3 grid((S + 63) / 64, H, B);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)vt,
+  TASU_LAUNCH(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)vt,
                      key_mask, (bf16*)out, lse, S, spad_of(S), H, G, scale, causal);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 
@@ -408,9 +407,8 @@ extern "C" int tasu_attn_bwd_prep(const void* dout, const void* out, float* delt
                                   void* stream) {
   if (!dout || !out || !delta || !dout_t || B <= 0 || S <= 0 || H <= 0) return TASU_ERR_ARG;
   dim3 grid((S + 63) / 64, H, B);
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dout,
+  TASU_LAUNCH(attn_bwd_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dout,
                      (const bf16*)out, delta, (bf16*)dout_t, S, spad_of(S), H);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 
@@ -419,9 +417,8 @@ extern "C" int tasu_attn_bwd_dq(const void* qkv, const void* kt, const uint8_t* 
                                 float scale, int causal, void* stream) {
   if (!qkv || !kt || !key_mask || !dout || !lse || !delta || !dqkv || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
   dim3 grid((S + 63) / 64, H, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)kt,
+  TASU_LAUNCH(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)kt,
                      key_mask, (const bf16*)dout, lse, delta, (bf16*)dqkv, S, spad_of(S), H, G, scale, causal);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 
@@ -431,9 +428,8 @@ extern "C" int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t*
   if (!qkv || !qt || !key_mask || !dout || !dout_t || !lse || !delta || !dk_part || !dv_part || bad_geo(B, S, H, G))
     return TASU_ERR_ARG;
   dim3 grid((S + 63) / 64, H, B);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)qt,
+  TASU_LAUNCH(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)qt,
                      key_mask, (const bf16*)dout, (const bf16*)dout_t, lse, delta, dk_part, dv_part, S, spad_of(S), H, G,
                      scale, causal);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }

@@ -155,16 +155,14 @@ extern "C" int tasu_ce_fwd_bwd(const void* logits, int ldv, const int32_t* shift
                                void* stream) {
   if (!logits || !shift_labels || !row_loss || !row_hit || M <= 0 || V <= 0 || ldv < V || ldv % 8) return TASU_ERR_ARG;
   if (dlogits && !inv_count) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(ce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ldv, shift_labels, V,
+  TASU_LAUNCH(ce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ldv, shift_labels, V,
                      row_loss, row_hit, row_argmax, (bf16*)dlogits, inv_count);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 
 extern "C" int tasu_ce_reduce(const float* row_loss, const int32_t* row_hit, const int32_t* shift_labels, int M, float* out,
                               void* stream) {
   if (!row_loss || !row_hit || !shift_labels || !out || M <= 0) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, row_hit, shift_labels, M, out);
-  TASU_CHECK_LAUNCH();
+  TASU_LAUNCH(ce_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, row_hit, shift_labels, M, out);
   return TASU_OK;
 }

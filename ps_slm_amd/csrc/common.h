@@ -15,10 +15,13 @@ typedef __attribute__((ext_vector_type(8))) float f32x8;
 #define TASU_ERR_ARG 1
 #define TASU_ERR_LAUNCH 2
 
-#define TASU_CHECK_LAUNCH()                                   \
-  do {                                                        \
-    hipError_t e__ = hipGetLastError();                       \
-    if (e__ != hipSuccess) return TASU_ERR_LAUNCH;            \
+// hipGetLastError() is process-wide and sticky across unrelated runtime calls (e.g. a pending hipEventQuery of
+// the host framework leaves hipErrorNotReady behind), so clear it before the launch and read it right after.
+#define TASU_LAUNCH(kernel, grid, block, shmem, stream, ...)                      \
+  do {                                                                            \
+    (void)hipGetLastError();                                                      \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);          \
+    if (hipGetLastError() != hipSuccess) return TASU_ERR_LAUNCH;                  \
   } while (0)
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {

@@ -146,50 +146,43 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restr
 
 extern "C" int tasu_swiglu_fwd(const void* gu, void* act, int M, int I, void* stream) {
   if (!gu || !act || M <= 0 || I <= 0 || I % 8) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for((int64_t)M * I / 8)), dim3(256), 0, (hipStream_t)stream,
+  TASU_LAUNCH(swiglu_fwd_kernel, dim3(grid_for((int64_t)M * I / 8)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16*)gu, (bf16*)act, M, I);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 extern "C" int tasu_swiglu_bwd(const void* dact, const void* gu, void* dgu, int M, int I, void* stream) {
   if (!dact || !gu || !dgu || M <= 0 || I <= 0 || I % 8) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((int64_t)M * I / 8)), dim3(256), 0, (hipStream_t)stream,
+  TASU_LAUNCH(swiglu_bwd_kernel, dim3(grid_for((int64_t)M * I / 8)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16*)dact, (const bf16*)gu, (bf16*)dgu, M, I);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 extern "C" int tasu_silu_fwd(const void* x, void* y, int64_t n, void* stream) {
   if (!x || !y || n <= 0) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(unary_kernel<0>, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n);
-  TASU_CHECK_LAUNCH();
+  TASU_LAUNCH(unary_kernel<0>, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n);
   return TASU_OK;
 }
 extern "C" int tasu_relu_fwd(const void* x, void* y, int64_t n, void* stream) {
   if (!x || !y || n <= 0) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(unary_kernel<1>, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n);
-  TASU_CHECK_LAUNCH();
+  TASU_LAUNCH(unary_kernel<1>, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n);
   return TASU_OK;
 }
 extern "C" int tasu_silu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream) {
   if (!dy || !x || !dx || n <= 0) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy,
+  TASU_LAUNCH(silu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy,
                      (const bf16*)x, (bf16*)dx, n);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 extern "C" int tasu_cast_f32_bf16(const void* in, void* out, int64_t n, void* stream) {
   if (!in || !out || n <= 0) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)in,
+  TASU_LAUNCH(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)in,
                      (bf16*)out, n);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 extern "C" int tasu_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, int R, int C, int Rpad, int Cpad,
                                    void* stream) {
   if (!in || !out || R <= 0 || C <= 0 || Rpad < R || Cpad < C || ld_in < C || ld_out < Rpad) return TASU_ERR_ARG;
   dim3 grid((Rpad + 63) / 64, (Cpad + 63) / 64);
-  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)in, ld_in, (bf16*)out,
+  TASU_LAUNCH(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)in, ld_in, (bf16*)out,
                      ld_out, R, C, Rpad, Cpad);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }

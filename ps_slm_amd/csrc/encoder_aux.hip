@@ -168,49 +168,43 @@ inline int grid_for(int64_t n) {
 extern "C" int tasu_sinusoid_pe(const float* x, float* y, int B, int T, int D, float scale, void* stream) {
   if (!x || !y || B <= 0 || T <= 0 || D < 4 || D % 2) return TASU_ERR_ARG;
   const int64_t total = (int64_t)B * T * D;
-  hipLaunchKernelGGL(sinusoid_pe_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, T, D, scale, total);
-  TASU_CHECK_LAUNCH();
+  TASU_LAUNCH(sinusoid_pe_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, T, D, scale, total);
   return TASU_OK;
 }
 extern "C" int tasu_fsmn_fwd(const void* v, int ldv, const float* w, const int32_t* lens, float* out, int B, int T, int D,
                              int ksize, int accumulate, void* stream) {
   if (!v || !w || !lens || !out || B <= 0 || T <= 0 || D <= 0 || ksize <= 0) return TASU_ERR_ARG;
   const int64_t total = (int64_t)B * T * D;
-  hipLaunchKernelGGL(fsmn_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)v, ldv, w, lens,
+  TASU_LAUNCH(fsmn_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)v, ldv, w, lens,
                      out, T, D, ksize, accumulate, total);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 extern "C" int tasu_softmax_rows(const float* x, int ldx, float* y, int ldy, int R, int V, void* stream) {
   if (!x || !y || R <= 0 || V <= 0 || ldx < V || ldy < V) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, V);
-  TASU_CHECK_LAUNCH();
+  TASU_LAUNCH(softmax_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, V);
   return TASU_OK;
 }
 extern "C" int tasu_psd_frame_stats(const float* post, int ldp, const int32_t* lens, int32_t* frame_id, float* frame_blank,
                                     int B, int T, int V, int blank_id, void* stream) {
   if (!post || !lens || !frame_id || !frame_blank || B <= 0 || T <= 0 || V <= 0 || blank_id < 0 || blank_id >= V)
     return TASU_ERR_ARG;
-  hipLaunchKernelGGL(psd_frame_stats_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, post, ldp, lens, frame_id,
+  TASU_LAUNCH(psd_frame_stats_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, post, ldp, lens, frame_id,
                      frame_blank, T, V, blank_id);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 extern "C" int tasu_psd_plan(const int32_t* frame_id, const float* frame_blank, const int32_t* lens, int32_t* seg_start,
                              int32_t* seg_len, int32_t* new_lens, int B, int T, int blank_id, float threshold,
                              void* stream) {
   if (!frame_id || !frame_blank || !lens || !seg_start || !seg_len || !new_lens || B <= 0 || T <= 0) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(psd_plan_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, frame_id, frame_blank, lens,
+  TASU_LAUNCH(psd_plan_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, frame_id, frame_blank, lens,
                      seg_start, seg_len, new_lens, B, T, blank_id, threshold);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 extern "C" int tasu_psd_gather(const float* post, int ldp, const int32_t* seg_start, const int32_t* seg_len,
                                const int32_t* new_lens, float* out, int ldo, int B, int T, int Tout, int V, void* stream) {
   if (!post || !seg_start || !seg_len || !new_lens || !out || B <= 0 || T <= 0 || Tout <= 0 || V <= 0 || ldo < V)
     return TASU_ERR_ARG;
-  hipLaunchKernelGGL(psd_gather_kernel, dim3(Tout, B), dim3(256), 0, (hipStream_t)stream, post, ldp, seg_start, seg_len,
+  TASU_LAUNCH(psd_gather_kernel, dim3(Tout, B), dim3(256), 0, (hipStream_t)stream, post, ldp, seg_start, seg_len,
                      new_lens, out, ldo, T, Tout, V);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }

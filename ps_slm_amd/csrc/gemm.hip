@@ -188,8 +188,7 @@ int launch(const GemmArgs& a, hipStream_t st) {
     attr_set = true;
   }
   const int nwg = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((gemm_nt_kernel<OUT_MODE, HAS_BIAS>), dim3(nwg), dim3(256), 2 * STAGE_BYTES, st, a);
-  TASU_CHECK_LAUNCH();
+  TASU_LAUNCH((gemm_nt_kernel<OUT_MODE, HAS_BIAS>), dim3(nwg), dim3(256), 2 * STAGE_BYTES, st, a);
   return TASU_OK;
 }
 

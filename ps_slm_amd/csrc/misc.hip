@@ -85,25 +85,22 @@ extern "C" int tasu_abi_version(void) { return TASU_ABI_VERSION; }
 extern "C" int tasu_posterior_build(const int32_t* ids, const float* alpha, float* out, int ld, int R, int V,
                                     void* stream) {
   if (!ids || !out || R <= 0 || V <= 0 || ld < V) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(posterior_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, ids, alpha, out, ld, V);
-  TASU_CHECK_LAUNCH();
+  TASU_LAUNCH(posterior_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, ids, alpha, out, ld, V);
   return TASU_OK;
 }
 
 extern "C" int tasu_embed_merge_fwd(const float* table, const void* proj, const int32_t* src_kind, const int32_t* src_idx,
                                     float* x, int M, int D, void* stream) {
   if (!table || !proj || !src_kind || !src_idx || !x || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(embed_merge_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, (const bf16*)proj,
+  TASU_LAUNCH(embed_merge_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, (const bf16*)proj,
                      src_kind, src_idx, x, M, D);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 
 extern "C" int tasu_merge_bwd(const float* dx, const int32_t* audio_rows, void* dproj, int n_audio, int D, void* stream) {
   if (!dx || !audio_rows || !dproj || n_audio <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(merge_bwd_kernel, dim3((n_audio + 3) / 4), dim3(256), 0, (hipStream_t)stream, dx, audio_rows,
+  TASU_LAUNCH(merge_bwd_kernel, dim3((n_audio + 3) / 4), dim3(256), 0, (hipStream_t)stream, dx, audio_rows,
                      (bf16*)dproj, n_audio, D);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 
@@ -115,8 +112,7 @@ extern "C" int tasu_adamw(float* p, const float* g, float* m, float* v, void* p_
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, lr,
+  TASU_LAUNCH(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, lr,
                      beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }

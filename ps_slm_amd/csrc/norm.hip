@@ -155,29 +155,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
 extern "C" int tasu_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, int M, int D, float eps,
                                 void* stream) {
   if (!x || !w || !y || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)y, rstd, M, D,
+  TASU_LAUNCH(rmsnorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)y, rstd, M, D,
                      eps);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 extern "C" int tasu_rmsnorm_bwd(const void* dy, const float* x, const float* w, const float* rstd, float* dx, void* dx_bf16,
                                 int accumulate, int M, int D, void* stream) {
   if (!dy || !x || !w || !rstd || !dx || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, x, w, rstd,
+  TASU_LAUNCH(rmsnorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, x, w, rstd,
                      dx, (bf16*)dx_bf16, accumulate, M, D);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 extern "C" int tasu_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
                                   int y_is_f32, float* mean, float* rstd, int R, int D, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || R <= 0 || D <= 0 || ldx < D || ldy < D) return TASU_ERR_ARG;
   if (y_is_f32)
-    hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(R), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy,
+    TASU_LAUNCH(layernorm_fwd_kernel<true>, dim3(R), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy,
                        mean, rstd, D, eps);
   else
-    hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3(R), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy,
+    TASU_LAUNCH(layernorm_fwd_kernel<false>, dim3(R), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy,
                        mean, rstd, D, eps);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 extern "C" int tasu_layernorm_bwd_params(const void* dy, int lddy, const float* x, int ldx, const float* mean,
@@ -185,16 +182,14 @@ extern "C" int tasu_layernorm_bwd_params(const void* dy, int lddy, const float* 
                                          void* stream) {
   if (!dy || !x || !mean || !rstd || !dgamma || !dbeta || !ws || R <= 0 || D <= 0) return TASU_ERR_ARG;
   const int nsplit = TASU_LN_BWD_SPLIT;
-  hipLaunchKernelGGL(layernorm_bwd_partial_kernel, dim3((D + 255) / 256, nsplit), dim3(256), 0, (hipStream_t)stream,
+  TASU_LAUNCH(layernorm_bwd_partial_kernel, dim3((D + 255) / 256, nsplit), dim3(256), 0, (hipStream_t)stream,
                      (const bf16*)dy, lddy, x, ldx, mean, rstd, ws, R, D);
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dgamma,
+  TASU_LAUNCH(layernorm_bwd_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dgamma,
                      dbeta, nsplit, D);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 extern "C" int tasu_colsum_bf16(const void* x, int ld, float* out, int R, int C, void* stream) {
   if (!x || !out || R <= 0 || C <= 0) return TASU_ERR_ARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, out, R, C);
-  TASU_CHECK_LAUNCH();
+  TASU_LAUNCH(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, out, R, C);
   return TASU_OK;
 }

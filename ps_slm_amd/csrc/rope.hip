@@ -132,9 +132,8 @@ extern "C" int tasu_rope_table(const int32_t* pos, float* cos_tab, float* sin_ta
                                void* stream) {
   if (!pos || !cos_tab || !sin_tab || M <= 0 || head_dim != HD) return TASU_ERR_ARG;
   const int n = M * (HD / 2);
-  hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, cos_tab, sin_tab,
+  TASU_LAUNCH(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, cos_tab, sin_tab,
                      M, HD / 2, theta);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 
@@ -142,9 +141,8 @@ extern "C" int tasu_rope_fwd(void* qkv, const float* cos_tab, const float* sin_t
                              int S, int H, int G, void* stream) {
   if (!qkv || !cos_tab || !sin_tab || B <= 0 || S <= 0 || H <= 0 || G <= 0) return TASU_ERR_ARG;
   dim3 grid((S + 63) / 64, H + 2 * G, B);
-  hipLaunchKernelGGL(rope_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (bf16*)qkv, cos_tab, sin_tab, (bf16*)qt,
+  TASU_LAUNCH(rope_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (bf16*)qkv, cos_tab, sin_tab, (bf16*)qt,
                      (bf16*)kt, (bf16*)vt, S, (S + 63) & ~63, H, G);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }
 
@@ -153,8 +151,7 @@ extern "C" int tasu_rope_bwd(void* dqkv, const float* dk_part, const float* dv_p
   if (!dqkv || !dk_part || !dv_part || !cos_tab || !sin_tab || B <= 0 || S <= 0 || H <= 0 || G <= 0 || H % G)
     return TASU_ERR_ARG;
   dim3 grid(B * S, H + 2 * G);
-  hipLaunchKernelGGL(rope_bwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, (bf16*)dqkv, dk_part, dv_part, cos_tab,
+  TASU_LAUNCH(rope_bwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, (bf16*)dqkv, dk_part, dv_part, cos_tab,
                      sin_tab, H, G);
-  TASU_CHECK_LAUNCH();
   return TASU_OK;
 }

@@ -249,14 +249,23 @@ class TasuModel:
 
     def init_random(self, seed=1234, with_encoder=False):
         self.llm.init_random(seed)
+        self.init_projector_default(seed + 1)
+        if with_encoder:
+            from .encoder import EncoderWeights
+            self.encoder = EncoderWeights(self.geo, self.device)
+            self.encoder.init_random(seed + 2)
+
+    def init_projector_default(self, seed=42):
+        """Default nn.Module init of EncoderProjectorLinearSiLU (projector.py:137-147) when training starts from
+        pretrained LLM/encoder weights and no projector checkpoint."""
         geo, dev = self.geo, self.device
-        g = torch.Generator(device=dev).manual_seed(seed + 1)
+        g = torch.Generator(device=dev).manual_seed(seed)
         K, Hb, Do = geo.ctc_vocab, geo.bottleneck, geo.llm_dim
-        # nn.LayerNorm: ones/zeros; nn.Linear default (kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(in), 1/sqrt(in)));
-        # ffn.2.bias zeros (projector.py:145-146)
+
         def un(shape, fan_in):
             b = 1.0 / math.sqrt(fan_in)
             return (torch.rand(*shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1) * b
+
         self.proj.load("norm.weight", torch.ones(K, device=dev))
         self.proj.load("norm.bias", torch.zeros(K, device=dev))
         self.proj.load("ffn.0.weight", un((Hb, K), K))
@@ -264,10 +273,15 @@ class TasuModel:
         self.proj.load("ffn.2.weight", un((Do, Hb), Hb))
         self.proj.load("ffn.2.bias", torch.zeros(Do, device=dev))
         self.sync_projector_copies()
-        if with_encoder:
-            from .encoder import EncoderWeights
-            self.encoder = EncoderWeights(self.geo, self.device)
-            self.encoder.init_random(seed + 2)
+
+    def load_encoder_checkpoint(self, path):
+        """funasr SenseVoiceSmall ``model.pt`` (keys ``encoder.*``, ``ctc.ctc_lo.*``, ``embed.weight``)."""
+        from .encoder import EncoderWeights
+        raw = torch.load(path, map_location="cpu")
+        raw = raw.get("state_dict", raw)
+        sd = {"encoder." + k: v.float() for k, v in raw.items()}
+        self.encoder = EncoderWeights(self.geo, self.device)
+        self.encoder.load_reference_state_dict(sd)
 
     def sync_projector_copies(self):
         self.ops.cast_bf16(self.proj.p, self.proj.pb)

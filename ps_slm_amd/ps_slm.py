@@ -1,0 +1,290 @@
+"""Drop-in for the reference's model plugin ``model/ps-slm.py:model_factory`` (selected with
+``++model_config.file=ps_slm_amd/ps_slm.py:model_factory``; contract: Multitask/model/ps-slm.py:130-181, loaded by
+Multitask/utils/model_utils.py:9-33).  Same names, argument meaning and error behaviour; the arithmetic runs in
+the HIP kernels of libtasu_hip.so through ps_slm_amd.model.TasuModel.
+
+What callers get (Multitask/utils/deepspeed_utils.py:205-236, Multitask/inference_batch.py:139-151):
+  model(**batch) -> (outputs, acc)   outputs.loss (0-dim device tensor), outputs.logits [B,S,V] (bf16 view)
+  model.generate(**batch) -> LongTensor [B, n_new]
+  model.parameters() / train() / eval() / state_dict() / load_state_dict(strict=False) with the reference's
+  checkpoint keys ``encoder_projector.{norm,ffn.0,ffn.2}.{weight,bias}`` (Multitask/utils/checkpoint_handler.py:169-182)
+"""
+import json
+import logging
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .model import Geometry, TasuModel
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_SPEECH_TOKEN = "<speech>"
+DEFAULT_IGNORE_TOKEN = -100
+
+
+# ------------------------------------------------------------------------------------------------ tokenizers
+class SyntheticLLMTokenizer:
+    """Stand-in used when ``llm_path`` holds no tokenizer files (the benchmark box has none): whitespace-separated
+    integer strings <-> ids.  Exposes what the model and the entrypoints read (ps-slm.py:27,133-140,672-674)."""
+
+    def __init__(self, geo: Geometry):
+        self.eos_token_id = geo.eos_id
+        self.pad_token_id = geo.eos_id
+        self.bos_token_id = None
+        self.default_speech_token = geo.speech_id
+        self.default_ignore_token = DEFAULT_IGNORE_TOKEN
+        self.vocab_size = geo.llm_vocab
+
+    def encode(self, text):
+        return [int(t) for t in text.split() if t.lstrip("-").isdigit()]
+
+    def batch_decode(self, ids, skip_special_tokens=True, **kw):
+        out = []
+        for row in ids.tolist() if isinstance(ids, torch.Tensor) else ids:
+            toks = [t for t in row if not (skip_special_tokens and t in (self.eos_token_id, self.default_speech_token))]
+            out.append(" ".join(map(str, toks)))
+        return out
+
+
+class SyntheticSentencePiece:
+    """Stand-in for Multitask/model/tokenizer.py:SenseVoiceTokenizer when the BPE model file is absent:
+    "12 7 3" -> [12, 7, 3]; any other word -> a deterministic id in [1, V)."""
+
+    def __init__(self, vocab_size):
+        self._v = vocab_size
+
+    def encode(self, text):
+        return [int(t) % self._v if t.isdigit() else 1 + sum(map(ord, t)) % (self._v - 1) for t in text.split()]
+
+    @property
+    def vocab_size(self):
+        return self._v
+
+
+def setup_tokenizer(train_config, model_config, geo, **kwargs):
+    path = model_config.get("llm_path", None)
+    if path and os.path.isfile(os.path.join(path, "tokenizer_config.json")):
+        from transformers import AutoTokenizer
+        tok = AutoTokenizer.from_pretrained(path)
+        tok.pad_token_id = tok.eos_token_id
+        tok.add_special_tokens({"additional_special_tokens": [DEFAULT_SPEECH_TOKEN]})
+        tok.default_ignore_token = DEFAULT_IGNORE_TOKEN
+        tok.default_speech_token = tok.convert_tokens_to_ids(DEFAULT_SPEECH_TOKEN)
+        return tok
+    return SyntheticLLMTokenizer(geo)
+
+
+def setup_encoder_tokenizer(model_config, geo):
+    path = model_config.get("encoder_path", None)
+    if path and os.path.isfile(os.path.join(path, "chn_jpn_yue_eng_ko_spectok.bpe.model")):
+        import sentencepiece as spm
+        sp = spm.SentencePieceProcessor(model_file=os.path.join(path, "chn_jpn_yue_eng_ko_spectok.bpe.model"))
+        return SimpleNamespace(encode=lambda t: sp.encode(t, out_type=int), vocab_size=sp.vocab_size())
+    return SyntheticSentencePiece(geo.ctc_vocab)
+
+
+# ------------------------------------------------------------------------------------------------ geometry / weights
+def geometry_from_config(model_config) -> Geometry:
+    """HF config.json under llm_path when present; otherwise a named synthetic geometry
+    (``llm_path = synthetic:qwen2.5-1.5b | synthetic:qwen2.5-7b | synthetic:mid``)."""
+    path = str(model_config.get("llm_path", "") or "")
+    cfg_file = os.path.join(path, "config.json")
+    if os.path.isfile(cfg_file):
+        c = json.load(open(cfg_file))
+        hd = c.get("head_dim", c["hidden_size"] // c["num_attention_heads"])
+        if hd != 128:
+            raise ValueError(f"head_dim {hd} is not supported by the gfx950 attention kernels (128 only)")
+        geo = Geometry(llm_vocab=c["vocab_size"], llm_dim=c["hidden_size"], llm_inter=c["intermediate_size"],
+                       llm_layers=c["num_hidden_layers"], llm_heads=c["num_attention_heads"],
+                       llm_kv_heads=c["num_key_value_heads"], rope_theta=float(c.get("rope_theta", 1e6)),
+                       rms_eps=float(c.get("rms_norm_eps", 1e-6)), tied=bool(c.get("tie_word_embeddings", True)))
+    elif path.startswith("synthetic:"):
+        name = path.split(":", 1)[1].lower()
+        if name in ("qwen2.5-1.5b", "1.5b"):
+            geo = Geometry.qwen25_1p5b()
+        elif name in ("qwen2.5-7b", "7b"):
+            geo = Geometry.qwen25_7b()
+        elif name == "mid":
+            from .synthetic import MID_GEOMETRY
+            geo = Geometry.from_dict(MID_GEOMETRY)
+        else:
+            raise ValueError(f"unknown synthetic geometry {name!r}")
+    else:
+        raise FileNotFoundError(f"model_config.llm_path={path!r}: no config.json there and not a 'synthetic:<name>' spec")
+    if model_config.get("encoder_dim", None) not in (None, geo.ctc_vocab) and not path.endswith("mid"):
+        geo.ctc_vocab = int(model_config.encoder_dim)
+    if model_config.get("llm_dim", None) not in (None, geo.llm_dim):
+        raise ValueError(f"model_config.llm_dim={model_config.llm_dim} does not match the LLM hidden size {geo.llm_dim}")
+    return geo
+
+
+def load_hf_llm_state_dict(path):
+    """Reads HF Qwen2 ``*.safetensors`` shards under ``path`` into reference-named (``llm.``-prefixed) CPU tensors."""
+    from safetensors.torch import load_file
+    sd = {}
+    for fn in sorted(os.listdir(path)):
+        if fn.endswith(".safetensors"):
+            for k, v in load_file(os.path.join(path, fn)).items():
+                sd["llm." + k] = v.float()
+    if not sd:
+        raise FileNotFoundError(f"no .safetensors shards under {path}")
+    return sd
+
+
+def model_factory(train_config, model_config, **kwargs):
+    """Same contract as Multitask/model/ps-slm.py:130-181: returns (model, tokenizer)."""
+    if model_config.get("encoder_projector", "linear-silu") != "linear-silu":
+        raise NotImplementedError("only the shipped recipe's projector ('linear-silu', "
+                                  "Multitask/scripts/finetune_deespeed_sensevoice.sh:25) is on the MI355X hot path")
+    if train_config.get("use_peft", False) or not train_config.get("freeze_llm", True):
+        raise NotImplementedError("the MI355X path trains the projector only (freeze_llm=true, use_peft=false: "
+                                  "Multitask/scripts/finetune_deespeed_sensevoice.sh:28,84)")
+    geo = geometry_from_config(model_config)
+    tokenizer = setup_tokenizer(train_config, model_config, geo, **kwargs)
+    if not isinstance(tokenizer, SyntheticLLMTokenizer):
+        geo.speech_id, geo.eos_id = tokenizer.default_speech_token, tokenizer.eos_token_id
+    device = kwargs.get("device", None)
+    if device is None:
+        device = f"cuda:{int(os.environ.get('LOCAL_RANK', train_config.get('device', 0) or 0))}"
+    ops = kwargs.get("ops", None)
+    if ops is None:
+        from .ops import HipOps     # raises if libtasu_hip.so is missing or there is no GPU: no fallback
+        ops = HipOps()
+    core = TasuModel(geo, ops, device, keep_logits=bool(kwargs.get("keep_logits", True)))
+    llm_path = str(model_config.get("llm_path", ""))
+    need_encoder = not train_config.get("gt_emb", False) or bool(kwargs.get("with_encoder", False))
+    if llm_path.startswith("synthetic:"):
+        core.init_random(seed=int(kwargs.get("init_seed", 1234)), with_encoder=need_encoder)
+    else:
+        sd = load_hf_llm_state_dict(llm_path)
+        core.llm.load_reference_state_dict(sd)
+        core.init_projector_default(seed=int(train_config.get("seed", 42)))
+        enc_pt = os.path.join(str(model_config.get("encoder_path", "")), "model.pt")
+        if need_encoder:
+            core.load_encoder_checkpoint(enc_pt)
+    model = slam_model_asr(core, tokenizer, setup_encoder_tokenizer(model_config, geo), train_config, model_config, **kwargs)
+    ckpt_path = kwargs.get("ckpt_path", None)
+    if ckpt_path is not None:
+        logger.info("loading other parts from: %s", ckpt_path)
+        model.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)
+    return model, tokenizer
+
+
+# ------------------------------------------------------------------------------------------------ the model
+class CausalLMOutput:
+    __slots__ = ("loss", "logits")
+
+    def __init__(self, loss, logits):
+        self.loss, self.logits = loss, logits
+
+
+class slam_model_asr:
+    """Mirror of the reference's ``slam_model_asr`` (Multitask/model/ps-slm.py:183-537) over TasuModel."""
+
+    def __init__(self, core: TasuModel, tokenizer, encoder_tokenizer, train_config, model_config, **kwargs):
+        self.core = core
+        self.tokenizer = tokenizer
+        self.encoder_tokenizer = encoder_tokenizer
+        self.train_config, self.model_config = train_config, model_config
+        self.metric = kwargs.get("metric", "acc")
+        self.ctc_posterior = train_config.get("ctc_posterior", True)
+        self.do_psd = train_config.get("do_psd", True)
+        self.voca_trans = train_config.get("voca_trans", False)
+        self.gt_emb = train_config.get("gt_emb", False)
+        self.gt_emb_noise = train_config.get("gt_emb_noise", False)
+        if not self.ctc_posterior or self.voca_trans or train_config.get("top1_emb", False):
+            raise NotImplementedError("only ctc_posterior=true, voca_trans=false, top1_emb=false (the shipped TASU "
+                                      "recipe, Multitask/scripts/finetune_deespeed_sensevoice.sh:31-35) is supported")
+        # knobs of ctc_pseudo_posterior_noise (ps-slm.py:372-375), overridable as attributes like in the reference
+        self.drop_prob, self.insert_prob, self.smooth_low, self.smooth_high = 0.05, 0.0, 0.0, 0.1
+        self.training = True
+        self.last_state = None
+
+    # ---- nn.Module-like surface
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, *a, **k):
+        return self
+
+    def parameters(self):
+        p = self.core.proj.p
+        p.requires_grad_(False)
+        return iter([p])
+
+    def state_dict(self):
+        return self.core.projector_state_dict()
+
+    def load_state_dict(self, sd, strict=False):
+        from .model import PROJ_NAMES
+        missing = []
+        for n in PROJ_NAMES:
+            k = "encoder_projector." + n
+            if k in sd:
+                self.core.proj.load(n, sd[k].to(self.core.device, torch.float32))
+            else:
+                missing.append(k)
+        if strict and missing:
+            raise KeyError(f"missing keys {missing}")
+        self.core.sync_projector_copies()
+        return missing, [k for k in sd if not k.startswith("encoder_projector.")]
+
+    # ---- CPS noise draws: same calls in the same order on the global CPU RNG as ps-slm.py:380-388
+    def draw_noise(self, ids_list):
+        if self.insert_prob != 0.0:
+            raise NotImplementedError("insert_prob != 0 (ps-slm.py:390-399) is not used by the shipped recipe")
+        alphas, keeps = [], []
+        for ids in ids_list:
+            alphas.append(torch.empty(()).uniform_(self.smooth_low, self.smooth_high).item())
+            keeps.append((torch.rand(len(ids)) > self.drop_prob).numpy())
+        return alphas, keeps
+
+    # ---- forward (ps-slm.py:411-537)
+    def forward(self, input_ids=None, input_features=None, attention_mask=None, input_feature_length=None, GT=None,
+                labels=None, **unused):
+        core = self.core
+        if self.gt_emb:
+            ids_list = [self.encoder_tokenizer.encode(t) for t in GT]
+            alphas = keeps = None
+            if self.gt_emb_noise:
+                alphas, keeps = self.draw_noise(ids_list)
+            st = core.prepare_text(input_ids, attention_mask, labels, ids_list, alphas, keeps)
+            core.forward_projector_text(st)
+        else:
+            st = core.prepare_audio(input_ids, attention_mask, labels, input_features, input_feature_length,
+                                    do_psd=self.do_psd)
+        core.forward_llm(st, compute_loss=labels is not None, need_backward=self.training)
+        self.last_state = st
+        if labels is None:
+            return CausalLMOutput(None, core.logits_view(st)), -1
+        res = st.dev["loss_out"]
+        return CausalLMOutput(res[0], core.logits_view(st)), (res[1] if self.metric else -1)
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, input_features=None, attention_mask=None, input_feature_length=None,
+                 targets=None, **kwargs):
+        from .decode import beam_search_generate
+        core = self.core
+        if self.gt_emb:                                     # ps-slm.py:590-598
+            texts = [re.sub(r"[^A-Za-z\s.,!?]+", "", t).lower().strip() for t in targets]
+            ids_list = [self.encoder_tokenizer.encode(t) for t in texts]
+            st = core.prepare_text(input_ids, attention_mask, None, ids_list, None, None)
+            core.forward_projector_text(st)
+        else:
+            st = core.prepare_audio(input_ids, attention_mask, None, input_features, input_feature_length,
+                                    do_psd=self.do_psd)
+        return beam_search_generate(core, st, num_beams=kwargs.get("num_beams", 4),
+                                    max_new_tokens=kwargs.get("max_new_tokens", 200),
+                                    min_length=kwargs.get("min_length", 1),
+                                    length_penalty=kwargs.get("length_penalty", 1.0),
+                                    eos_token_id=self.tokenizer.eos_token_id, pad_token_id=self.tokenizer.pad_token_id)

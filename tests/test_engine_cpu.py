@@ -1,0 +1,172 @@
+"""Host logic on CPU (FakeOps double): plugin surface, config overrides, engine semantics (AdamW + DeepSpeed-style
+WarmupCosineLR ordering), CPS noise RNG parity with the reference, and the N > 1 data-parallel path over gloo."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden_batch, load_npz
+from fake_ops import FakeOps
+from oracle import tasu_oracle as O
+from ps_slm_amd.config import DEFAULT_DS_CONFIG, ModelConfig, RunConfig, TrainConfig, apply_overrides, load_ds_config
+from ps_slm_amd.engine import TasuEngine, warmup_cosine_ratio
+from ps_slm_amd.ps_slm import model_factory
+from ps_slm_amd.synthetic import synthetic_text_batch
+
+
+def make(seed=1234, noise=False, lr=None):
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=noise, ctc_posterior=True, do_psd=True)
+    mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+    model, tok = model_factory(tc, mc, device="cpu", ops=FakeOps(), init_seed=seed)
+    cfg = load_ds_config(DEFAULT_DS_CONFIG)
+    if lr is not None:
+        cfg["lr"] = lr
+    return model, tok, TasuEngine(model, cfg)
+
+
+def to_call(raw):
+    return dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
+                input_features=raw["input_features"], input_feature_length=raw["input_feature_length"],
+                GT=[" ".join(map(str, p)) for p in raw["post_ids"]])
+
+
+def test_config_overrides_match_script_syntax():
+    cfg = apply_overrides(RunConfig(), ["++model_config.encoder_dim=25055", "++train_config.freeze_llm=true",
+                                        "++train_config.gt_emb=true", "++train_config.use_fp16=false", "++metric=acc",
+                                        "++dataset_config.train_max_frame_length=3000", "--local_rank=3",
+                                        "hydra.run.dir=/tmp/x", "++model_config.llm_path=synthetic:mid",
+                                        "++train_config.num_epochs=5", "++model_config.ctc_linear=null"])
+    assert cfg.model_config.encoder_dim == 25055 and cfg.train_config.freeze_llm is True
+    assert cfg.train_config.gt_emb is True and cfg.train_config.use_fp16 is False and cfg.train_config.num_epochs == 5
+    assert cfg.dataset_config.train_max_frame_length == 3000 and cfg.model_config.ctc_linear is None
+    assert cfg.train_config.get("ctc_posterior") is False and cfg.train_config.get("nope", 7) == 7
+    with pytest.raises(ValueError):
+        apply_overrides(RunConfig(), ["garbage"])
+
+
+def test_factory_surface_and_errors():
+    model, tok, eng = make()
+    assert tok.pad_token_id == tok.eos_token_id and tok.default_ignore_token == -100
+    assert sorted(model.state_dict()) == sorted("encoder_projector." + n for n in
+                                                ("norm.weight", "norm.bias", "ffn.0.weight", "ffn.0.bias", "ffn.2.weight", "ffn.2.bias"))
+    with pytest.raises(NotImplementedError):
+        model_factory(TrainConfig(freeze_llm=True, gt_emb=True, ctc_posterior=True), ModelConfig(llm_path="synthetic:mid", encoder_projector="q-former", llm_dim=256),
+                      device="cpu", ops=FakeOps())
+    with pytest.raises(FileNotFoundError):
+        model_factory(TrainConfig(freeze_llm=True, gt_emb=True, ctc_posterior=True), ModelConfig(llm_path="/nonexistent", encoder_projector="linear-silu"),
+                      device="cpu", ops=FakeOps())
+    # invalid attention mask (zeros on both sides) -> the reference's ValueError (ps-slm.py:785)
+    raw = synthetic_text_batch(model.core.geo, 2, seed=1, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8, noise=False)
+    call = to_call(raw)
+    am = call["attention_mask"].clone()
+    am[0, 0] = False
+    am[1, -1] = False
+    call["attention_mask"] = am
+    with pytest.raises(ValueError):
+        model(**call)
+
+
+def test_noise_draws_replay_reference_rng():
+    """Same seed -> the same (alpha, keep) as the reference drew in tests/golden/text_noise_right.npz."""
+    b, z = golden_batch("text_noise_right")
+    model, _, _ = make()
+    # find the seed the generator settled on by replaying candidates exactly like oracle/make_golden.py
+    for seed in range(777, 900):
+        torch.manual_seed(seed)
+        alphas, keeps = model.draw_noise(b["post_ids"])
+        if np.allclose(alphas, z["alphas"], rtol=0, atol=0):
+            assert np.array_equal(np.concatenate(keeps), z["keeps_flat"])
+            return
+    pytest.fail("no seed reproduced the reference's draws")
+
+
+def test_engine_steps_match_oracle_adamw_and_schedule():
+    model, _, eng = make(lr=2e-3)
+    eng.cfg["warmup_num_steps"] = 4
+    core = model.core
+    raw = synthetic_text_batch(core.geo, 2, seed=4, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8, noise=False, ragged=True)
+    from ps_slm_amd.synthetic import random_state_dict  # oracle side: same weights through the state-dict export
+    sd = {}
+    # rebuild a reference-named state dict from the model's own weights for the oracle
+    sd.update({k: v.clone() for k, v in model.state_dict().items()})
+    llm = core.llm
+    geo = core.geo
+    H, G = geo.llm_heads, geo.llm_kv_heads
+    sd["llm.model.embed_tokens.weight"] = llm.embed.clone()
+    sd["llm.model.norm.weight"] = llm.norm.clone()
+    for l, w in enumerate(llm.layers):
+        p = f"llm.model.layers.{l}."
+        q, k, v = w["wqkv"].float().split([H * 128, G * 128, G * 128], 0)
+        bq, bk, bv = w["bqkv"].float().split([H * 128, G * 128, G * 128], 0)
+        g_, u_ = w["wgu"].float().split([geo.llm_inter, geo.llm_inter], 0)
+        sd.update({p + "input_layernorm.weight": w["ln1"], p + "post_attention_layernorm.weight": w["ln2"],
+                   p + "self_attn.q_proj.weight": q, p + "self_attn.q_proj.bias": bq, p + "self_attn.k_proj.weight": k,
+                   p + "self_attn.k_proj.bias": bk, p + "self_attn.v_proj.weight": v, p + "self_attn.v_proj.bias": bv,
+                   p + "self_attn.o_proj.weight": w["wo"].float(), p + "mlp.gate_proj.weight": g_, p + "mlp.up_proj.weight": u_,
+                   p + "mlp.down_proj.weight": w["wd"].float()})
+    gd = dataclasses.asdict(geo)
+    init = {k: sd[k].clone() for k in O.PROJ_KEYS}
+    m = {k: torch.zeros_like(sd[k]) for k in O.PROJ_KEYS}
+    v = {k: torch.zeros_like(sd[k]) for k in O.PROJ_KEYS}
+    losses = []
+    for step in range(1, 7):
+        out, acc = eng(**to_call(raw))
+        eng.backward(out.loss)
+        eng.step()
+        losses.append(float(out.loss))
+        o_out, grads = O.loss_and_projector_grads(sd, raw, gd, "bf16")
+        assert abs(losses[-1] - float(o_out["loss"])) < 1e-2, step
+        lr = O.lr_for_optimizer_step(step, 2e-3, warmup_num_steps=4)
+        assert abs(lr - eng.cfg["lr"] * warmup_cosine_ratio(step - 2, 4)) < 1e-12
+        for k in O.PROJ_KEYS:
+            O.adamw_step(sd[k], grads[k], m[k], v[k], step, lr)
+    assert losses[1] == pytest.approx(losses[0], abs=1e-6), "DeepSpeed ordering: the first two optimizer steps run at lr = 0"
+    assert losses[-1] < losses[0] - 1e-3
+    mine = model.state_dict()
+    # Adam normalises every element to ~lr, so bf16-level gradient noise moves near-zero-gradient elements freely:
+    # compare the UPDATE (param - init) as a whole, not element by element.
+    for k in O.PROJ_KEYS:
+        da, db = (mine[k] - init[k]).flatten(), (sd[k] - init[k]).flatten()
+        assert float(torch.nn.functional.cosine_similarity(da, db, dim=0)) > 0.98, k
+        assert float(da.norm() / db.norm()) == pytest.approx(1.0, abs=0.05), k
+
+
+def _dp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model, _, eng = make(lr=1e-3)
+    eng.sched_iter = 10                      # skip the zero-lr warm-up steps
+    raw = synthetic_text_batch(model.core.geo, 2, seed=100 + rank, prompt_len=9, n_audio=21, target_len=17, speech_pos=4,
+                               feat_frames=8, noise=False)
+    out, _ = eng(**to_call(raw))
+    eng.backward(out.loss)
+    g_local = model.core.proj.g.clone()
+    eng.step()
+    ret[rank] = dict(loss=float(out.loss), grad=g_local, param=model.core.proj.p.clone(),
+                     reduced=eng.reduce_scalars(float(out.loss)), joined=eng.all_have_data(rank == 0))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_gloo():
+    """DeepSpeed semantics: each rank's mean-CE gradient, AVERAGED over ranks, then one AdamW step; replicas stay equal."""
+    world, port = 2, 29000 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, port, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert torch.equal(r0["param"], r1["param"]), "replicas diverged"
+    assert r0["joined"] is False and r1["joined"] is False   # rank 1 had no data -> everybody stops (uneven-data join)
+    assert r0["reduced"][0] == pytest.approx(r0["loss"] + r1["loss"], rel=1e-6)
+    # single-process replay with the averaged gradient
+    model, _, eng = make(lr=1e-3)
+    eng.sched_iter = 10
+    model.core.proj.g.copy_((r0["grad"] + r1["grad"]))
+    eng.world = 2                              # grad_scale = 1/world inside the AdamW kernel
+    eng._last_state = None
+    eng.step()
+    torch.testing.assert_close(model.core.proj.p, r0["param"], rtol=1e-6, atol=1e-7)
