@@ -2,6 +2,11 @@
 import ctypes as C
 import os
 
+# torch bundles its own ROCm runtime (libamdhip64.so inside torch/lib).  It MUST be loaded before libtasu_hip.so so
+# that both share ONE HIP runtime: loading ours first binds it to /opt/rocm's copy and every launch on a torch stream
+# then fails (observed on the GPU box as "launch failure" from the first kernel).
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtasu_hip.so")
 

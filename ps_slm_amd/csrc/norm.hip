@@ -140,14 +140,36 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* 
   dbeta[c] = db;
 }
 
-// column sums of bf16 [R, C]: grid ceil(C/256); thread = column; fixed row order (deterministic).
+// column sums of bf16 [R, C] (bias gradients).  One block = 32 columns x 16 row-lanes: thread t owns the column
+// pair cp = t & 15 (one 4-byte load per row) for rows rl, rl+16, ... (rl = t >> 4); the 16 partial sums of a column
+// are combined through LDS in a fixed order (deterministic, no atomics).  grid = ceil(C/32).
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int ld, float* __restrict__ out, int R,
                                                      int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int r = 0; r < R; ++r) s += (float)x[(size_t)r * ld + c];
-  out[c] = s;
+  __shared__ float red[16][33];
+  const int cp = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 32 + cp * 2;
+  float s0 = 0.f, s1 = 0.f;
+  if (c + 1 < C) {
+    for (int r = rl; r < R; r += 16) {
+      const bf16x2 v = *(const bf16x2*)(x + (size_t)r * ld + c);
+      s0 += (float)v[0];
+      s1 += (float)v[1];
+    }
+  } else if (c < C) {
+    for (int r = rl; r < R; r += 16) s0 += (float)x[(size_t)r * ld + c];
+  }
+  red[rl][cp * 2] = s0;
+  red[rl][cp * 2 + 1] = s1;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int cc = blockIdx.x * 32 + threadIdx.x;
+    if (cc < C) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+      out[cc] = t;
+    }
+  }
 }
 
 }  // namespace
@@ -190,6 +212,7 @@ extern "C" int tasu_layernorm_bwd_params(const void* dy, int lddy, const float* 
 }
 extern "C" int tasu_colsum_bf16(const void* x, int ld, float* out, int R, int C, void* stream) {
   if (!x || !out || R <= 0 || C <= 0) return TASU_ERR_ARG;
-  TASU_LAUNCH(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, out, R, C);
+  if (ld % 2) return TASU_ERR_ARG;
+  TASU_LAUNCH(colsum_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, out, R, C);
   return TASU_OK;
 }
