@@ -160,16 +160,18 @@ int tasu_sinusoid_pe(const float* x, float* y, int B, int T, int D, float scale,
  * out fp32 [B*T, D] (added to the attention output by the caller through `accumulate`).                  */
 int tasu_fsmn_fwd(const void* v, int ldv, const float* w, const int32_t* lens, float* out, int B, int T, int D,
                   int ksize, int accumulate, void* stream);
-/* row softmax over V columns, fp32 in / fp32 out (ps-slm.py:451).                                        */
-int tasu_softmax_rows(const float* x, int ldx, float* y, int ldy, int R, int V, void* stream);
+/* row softmax over V columns, fp32 or bf16 in / fp32 out, pad columns [V, ldy) zeroed (ps-slm.py:451).   */
+int tasu_softmax_rows(const void* x, int x_is_bf16, int ldx, float* y, int ldy, int R, int V, void* stream);
 /* PSD (ps-slm.py:237-317) on device, three launches: per-frame argmax + blank prob; per-utterance segment
  * plan (one thread per utterance; T is a few hundred); segment-mean gather into the padded output.       */
+/* `post` row of (b, t) = b*bstride + t (bstride >= T lets the caller skip the 4 query frames, ps-slm.py:452). */
 int tasu_psd_frame_stats(const float* post, int ldp, const int32_t* lens, int32_t* frame_id, float* frame_blank,
-                         int B, int T, int V, int blank_id, void* stream);
+                         int B, int T, int bstride, int V, int blank_id, void* stream);
 int tasu_psd_plan(const int32_t* frame_id, const float* frame_blank, const int32_t* lens, int32_t* seg_start,
                   int32_t* seg_len, int32_t* new_lens, int B, int T, int blank_id, float threshold, void* stream);
 int tasu_psd_gather(const float* post, int ldp, const int32_t* seg_start, const int32_t* seg_len,
-                    const int32_t* new_lens, float* out, int ldo, int B, int T, int Tout, int V, void* stream);
+                    const int32_t* new_lens, float* out, int ldo, int B, int T, int bstride, int Tout, int V,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -309,6 +309,44 @@ def main_mid():
          logits_cols=lga[:, :, cols], lse=torch.logsumexp(lga, -1), argmax=lga.argmax(-1),
          **{k: v for k, v in ra.items() if k.startswith("grad.") and k not in ("grad.ffn.2.weight", "grad.ffn.0.weight")})
 
+    # audio path with a CTC head biased towards blank / two symbols so that PSD really merges and filters
+    with torch.no_grad():
+        model.encoder.ctc.ctc_lo.weight.mul_(3.0)
+        model.encoder.ctc.ctc_lo.bias.zero_()
+        model.encoder.ctc.ctc_lo.bias[0] = 2.5
+        model.encoder.ctc.ctc_lo.bias[7] = 2.2
+        model.encoder.ctc.ctc_lo.bias[9] = 2.0
+    # piecewise-constant features (+ small noise) so that consecutive frames share their argmax symbol
+    # PSD is discontinuous (argmax ties, the 0.90 blank threshold), so pick an input whose decisions have enough
+    # margin that fp32 and bf16 arithmetic agree on the kept-frame counts (checked with the oracle's bf16 mode).
+    from oracle import tasu_oracle as O
+    sd_b = dict(sd)
+    sd_b["encoder.ctc.ctc_lo.weight"] = model.encoder.ctc.ctc_lo.weight.detach().clone()
+    sd_b["encoder.ctc.ctc_lo.bias"] = model.encoder.ctc.ctc_lo.bias.detach().clone()
+    flen = torch.tensor([40, 31, 23])
+    for feat_seed in range(100, 200):
+        gf = torch.Generator().manual_seed(feat_seed)
+        segs = torch.randn(3, 10, geo.feat_dim, generator=gf).repeat_interleave(4, dim=1)
+        feats = (segs * 3.0 + 0.05 * torch.randn(3, 40, geo.feat_dim, generator=gf)).half().float()
+        with torch.no_grad():
+            q = model.encoder.embed(torch.tensor([[0, 1, 2, 2]])).repeat(3, 1, 1)
+            eo, ol = model.encoder.encoder(torch.cat([q, feats], 1), flen + 4)
+            cp = torch.softmax(model.encoder.ctc.ctc_lo(eo), -1)[:, 4:]
+            po, pl = quiet(model.psd, cp, torch.clamp(ol - 4, min=0), cp, 0)
+        pb, _, lb = O.audio_front(sd_b, feats, flen, geo.enc_heads, geo.enc_kernel, "bf16")
+        _, plb = O.psd(pb, lb, pb, 0)
+        if torch.equal(plb, pl) and int(pl.sum()) < int(flen.sum()) - 10:
+            break
+    else:
+        raise RuntimeError("no robust PSD input found")
+    print("mid_audio_psd: feature seed", feat_seed, "psd lens", pl.tolist())
+    rp = run_fwd_bwd(model, batch, GT, feats, flen)
+    lgp = rp.pop("logits")
+    save("mid_audio_psd", seed_w=seed_w, seed_b=seed_b, input_features=feats.half(), input_feature_length=flen,
+         ctc_bias=model.encoder.ctc.ctc_lo.bias.clone(), ctc_weight_scale=3.0, psd_lens=pl, loss=rp["loss"], acc=rp["acc"],
+         cols=cols, logits_cols=lgp[:, :, cols], lse=torch.logsumexp(lgp, -1),
+         **{k: v for k, v in rp.items() if k.startswith("grad.") and k not in ("grad.ffn.2.weight", "grad.ffn.0.weight")})
+
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mid":

@@ -42,25 +42,27 @@ __global__ void fsmn_kernel(const bf16* __restrict__ v, int ldv, const float* __
   }
 }
 
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                            int V) {
   __shared__ float red[4];
-  const float* xr = x + (size_t)blockIdx.x * ldx;
+  const T* xr = x + (size_t)blockIdx.x * ldx;
   float* yr = y + (size_t)blockIdx.x * ldy;
   float m = -__builtin_inff();
-  for (int c = threadIdx.x; c < V; c += 256) m = fmaxf(m, xr[c]);
+  for (int c = threadIdx.x; c < V; c += 256) m = fmaxf(m, (float)xr[c]);
   m = block_max<4>(m, red);
   float s = 0.f;
-  for (int c = threadIdx.x; c < V; c += 256) s += expf(xr[c] - m);
+  for (int c = threadIdx.x; c < V; c += 256) s += expf((float)xr[c] - m);
   s = block_sum<4>(s, red);
   const float inv = 1.f / s;
-  for (int c = threadIdx.x; c < ldy; c += 256) yr[c] = c < V ? expf(xr[c] - m) * inv : 0.f;
+  for (int c = threadIdx.x; c < ldy; c += 256) yr[c] = c < V ? expf((float)xr[c] - m) * inv : 0.f;
 }
 
 // per frame: argmax id (first index on ties) and blank probability.  grid B*T blocks.
 __global__ __launch_bounds__(256) void psd_frame_stats_kernel(const float* __restrict__ post, int ldp,
                                                               const int32_t* __restrict__ lens, int32_t* __restrict__ fid,
-                                                              float* __restrict__ fblank, int T, int V, int blank_id) {
+                                                              float* __restrict__ fblank, int T, int bstride, int V,
+                                                              int blank_id) {
   __shared__ float rv[4];
   __shared__ int ri[4];
   const int bt = blockIdx.x;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void psd_frame_stats_kernel(const float* __res
     }
     return;
   }
-  const float* pr = post + (size_t)bt * ldp;
+  const float* pr = post + ((size_t)b * bstride + t) * ldp;
   float best = -__builtin_inff();
   int arg = 0x7fffffff;
   for (int c = threadIdx.x; c < V; c += 256) {
@@ -118,8 +120,8 @@ __global__ void psd_plan_kernel(const int32_t* __restrict__ fid, const float* __
   const float* bp = fblank + (size_t)b * T;
   int n = 0, start = 0;
   for (int end = 1; end <= L; ++end) {
-    if (end == L || id[end] != id[start] || id[start] == blank_id) {
-      // (blank frames: every frame closes its own segment)
+    if (end == L || id[end] != id[start] || id[start] == blank_id || blank_id < 0) {
+      // (blank frames: every frame closes its own segment; blank_id < 0: no merging at all = do_psd false)
       const int len = end - start;
       float s = 0.f;
       for (int t = start; t < end; ++t) s += bp[t];
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void psd_gather_kernel(const float* __restrict
                                                          const int32_t* __restrict__ seg_start,
                                                          const int32_t* __restrict__ seg_len,
                                                          const int32_t* __restrict__ new_lens, float* __restrict__ out, int ldo,
-                                                         int T, int Tout, int V) {
+                                                         int T, int bstride, int Tout, int V) {
   const int j = blockIdx.x, b = blockIdx.y;
   float* o = out + ((size_t)b * Tout + j) * ldo;
   if (j >= new_lens[b]) {
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void psd_gather_kernel(const float* __restrict
     return;
   }
   const int s0 = seg_start[(size_t)b * T + j], len = seg_len[(size_t)b * T + j];
-  const float* p0 = post + ((size_t)b * T + s0) * ldp;
+  const float* p0 = post + ((size_t)b * bstride + s0) * ldp;
   for (int c = threadIdx.x; c < ldo; c += 256) {
     float s = 0.f;
     if (c < V) {
@@ -179,17 +181,21 @@ extern "C" int tasu_fsmn_fwd(const void* v, int ldv, const float* w, const int32
                      out, T, D, ksize, accumulate, total);
   return TASU_OK;
 }
-extern "C" int tasu_softmax_rows(const float* x, int ldx, float* y, int ldy, int R, int V, void* stream) {
+extern "C" int tasu_softmax_rows(const void* x, int x_is_bf16, int ldx, float* y, int ldy, int R, int V, void* stream) {
   if (!x || !y || R <= 0 || V <= 0 || ldx < V || ldy < V) return TASU_ERR_ARG;
-  TASU_LAUNCH(softmax_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, V);
+  if (x_is_bf16)
+    TASU_LAUNCH(softmax_rows_kernel<bf16>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, y, ldy, V);
+  else
+    TASU_LAUNCH(softmax_rows_kernel<float>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, y, ldy, V);
   return TASU_OK;
 }
 extern "C" int tasu_psd_frame_stats(const float* post, int ldp, const int32_t* lens, int32_t* frame_id, float* frame_blank,
-                                    int B, int T, int V, int blank_id, void* stream) {
-  if (!post || !lens || !frame_id || !frame_blank || B <= 0 || T <= 0 || V <= 0 || blank_id < 0 || blank_id >= V)
+                                    int B, int T, int bstride, int V, int blank_id, void* stream) {
+  if (!post || !lens || !frame_id || !frame_blank || B <= 0 || T <= 0 || bstride < T || V <= 0 || blank_id < 0 ||
+      blank_id >= V)
     return TASU_ERR_ARG;
   TASU_LAUNCH(psd_frame_stats_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, post, ldp, lens, frame_id,
-                     frame_blank, T, V, blank_id);
+                     frame_blank, T, bstride, V, blank_id);
   return TASU_OK;
 }
 extern "C" int tasu_psd_plan(const int32_t* frame_id, const float* frame_blank, const int32_t* lens, int32_t* seg_start,
@@ -201,10 +207,11 @@ extern "C" int tasu_psd_plan(const int32_t* frame_id, const float* frame_blank, 
   return TASU_OK;
 }
 extern "C" int tasu_psd_gather(const float* post, int ldp, const int32_t* seg_start, const int32_t* seg_len,
-                               const int32_t* new_lens, float* out, int ldo, int B, int T, int Tout, int V, void* stream) {
-  if (!post || !seg_start || !seg_len || !new_lens || !out || B <= 0 || T <= 0 || Tout <= 0 || V <= 0 || ldo < V)
+                               const int32_t* new_lens, float* out, int ldo, int B, int T, int bstride, int Tout, int V,
+                               void* stream) {
+  if (!post || !seg_start || !seg_len || !new_lens || !out || B <= 0 || T <= 0 || bstride < T || Tout <= 0 || V <= 0 || ldo < V)
     return TASU_ERR_ARG;
   TASU_LAUNCH(psd_gather_kernel, dim3(Tout, B), dim3(256), 0, (hipStream_t)stream, post, ldp, seg_start, seg_len,
-                     new_lens, out, ldo, T, Tout, V);
+                     new_lens, out, ldo, T, bstride, Tout, V);
   return TASU_OK;
 }

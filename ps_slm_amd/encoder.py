@@ -1,0 +1,186 @@
+"""Frozen SenseVoiceSmall front end of the audio path on the gfx950 kernels:
+query-token prepend (Multitask/model/ps-slm.py:430-443) -> SANM encoder (Multitask/model/SenseVoice.py:548-579:
+x*sqrt(d)+sinusoidal PE, 1 + 49 layers, after_norm, 20 tp layers, tp_norm) -> CTC head + softmax (ps-slm.py:450-454)
+-> PSD (ps-slm.py:237-317).  Forward only (the encoder is frozen and its input needs no gradient).
+
+Per layer (SenseVoice.py:324-400, pre-norm, eval): LayerNorm fp32 -> fused q|k|v GEMM (bf16, K padded 560->576 for
+layer 0) -> bidirectional 4-head attention with key padding (tasu_attn_fwd, causal=0; V^T from tasu_rope_fwd with an
+identity rotation) -> linear_out GEMM fused with the residual add -> + FSMN memory (depthwise conv over time on
+masked v, tasu_fsmn_fwd) -> LayerNorm -> FFN GEMM / ReLU / GEMM fused with the residual add.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .ops import GEMM_BF16, GEMM_RESID
+
+HD = 128
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class EncoderWeights:
+    def __init__(self, geo, device):
+        self.geo, self.device = geo, torch.device(device)
+        if geo.enc_dim // geo.enc_heads != HD:
+            raise ValueError("the gfx950 attention kernel needs d_k = 128 (SenseVoiceSmall: 512 / 4)")
+        self.layers = []
+        self.embed = None          # fp32 [16, F]
+        self.after_norm = self.tp_norm = None
+        self.ctc_w = self.ctc_b = None
+
+    def _lin(self, w, b, kpad=None):
+        dev = self.device
+        w = w.to(dev, torch.float32)
+        if kpad is not None and kpad != w.shape[1]:
+            wp = torch.zeros(w.shape[0], kpad, device=dev)
+            wp[:, : w.shape[1]] = w
+            w = wp
+        return w.to(torch.bfloat16).contiguous(), b.to(dev, torch.bfloat16).contiguous()
+
+    def _add_layer(self, sd, p, in_dim):
+        dev, f32 = self.device, torch.float32
+        kp = rup(in_dim, 64)
+        wqkv, bqkv = self._lin(sd[p + "self_attn.linear_q_k_v.weight"], sd[p + "self_attn.linear_q_k_v.bias"], kp)
+        wout, bout = self._lin(sd[p + "self_attn.linear_out.weight"], sd[p + "self_attn.linear_out.bias"])
+        w1, b1 = self._lin(sd[p + "feed_forward.w_1.weight"], sd[p + "feed_forward.w_1.bias"])
+        w2, b2 = self._lin(sd[p + "feed_forward.w_2.weight"], sd[p + "feed_forward.w_2.bias"])
+
+        def ln(name, n):
+            g = torch.zeros(rup(n, 64), device=dev)
+            b = torch.zeros(rup(n, 64), device=dev)
+            g[:n] = sd[p + name + ".weight"].to(dev, f32)
+            b[:n] = sd[p + name + ".bias"].to(dev, f32)
+            return g, b
+
+        E, ks = self.geo.enc_dim, self.geo.enc_kernel
+        self.layers.append(dict(in_dim=in_dim, kp=kp, n1=ln("norm1", in_dim), n2=ln("norm2", E), wqkv=wqkv, bqkv=bqkv,
+                                wout=wout, bout=bout, w1=w1, b1=b1, w2=w2, b2=b2,
+                                fsmn=sd[p + "self_attn.fsmn_block.weight"].to(dev, f32).reshape(E, ks).contiguous()))
+
+    def load_reference_state_dict(self, sd, pre="encoder."):
+        geo, dev, f32 = self.geo, self.device, torch.float32
+        self.layers = []
+        self._add_layer(sd, pre + "encoder.encoders0.0.", geo.feat_dim)
+        for i in range(geo.enc_blocks - 1):
+            self._add_layer(sd, f"{pre}encoder.encoders.{i}.", geo.enc_dim)
+        self.n_main = len(self.layers)
+        for i in range(geo.enc_tp_blocks):
+            self._add_layer(sd, f"{pre}encoder.tp_encoders.{i}.", geo.enc_dim)
+        self.embed = sd[pre + "embed.weight"].to(dev, f32).contiguous()
+        self.after_norm = (sd[pre + "encoder.after_norm.weight"].to(dev, f32), sd[pre + "encoder.after_norm.bias"].to(dev, f32))
+        self.tp_norm = (sd[pre + "encoder.tp_norm.weight"].to(dev, f32), sd[pre + "encoder.tp_norm.bias"].to(dev, f32))
+        self.ctc_w, self.ctc_b = self._lin(sd[pre + "ctc.ctc_lo.weight"], sd[pre + "ctc.ctc_lo.bias"])
+
+    def init_random(self, seed):
+        from .synthetic import random_state_dict
+        sd = {k: v for k, v in random_state_dict(self.geo, seed, with_encoder=True).items() if k.startswith("encoder.")}
+        self.load_reference_state_dict(sd)
+
+
+QUERY_ROWS = (0, 1, 2, 2)   # language, event, emotion, textnorm query ids (ps-slm.py:430-442)
+
+
+def encoder_posterior(model, feats, feat_lens):
+    """feats [B, T, F] float (host or device), feat_lens [B].  Returns (post fp32 [B*Te, Kp] device, Te, lens int32
+    device [B]) where row b*Te + 4 + t is frame t of utterance b (first 4 rows = query tokens)."""
+    ops, geo, enc, dev = model.ops, model.geo, model.encoder, model.device
+    if enc is None:
+        raise RuntimeError("the audio path needs encoder weights (model_factory(..., with_encoder=True) or encoder_path)")
+    B, T, Fd = feats.shape
+    E, Hh, Ff, V = geo.enc_dim, geo.enc_heads, geo.enc_ffn, geo.ctc_vocab
+    Te, Kp = T + 4, rup(V, 64)
+    M = B * Te
+    Spad = rup(Te, 64)
+    f32, bf = torch.float32, torch.bfloat16
+    buf = model._buf
+    # [query rows | features]: host-side concat is plumbing (18 MB H2D per 16 utterances, like the reference)
+    x0 = buf("enc_x0", (B, Te, Fd), f32)
+    x0[:, :4].copy_(enc.embed[list(QUERY_ROWS)].unsqueeze(0).expand(B, -1, -1))
+    x0[:, 4:].copy_(feats.to(dev, f32, non_blocking=True))
+    lens_h = (np.asarray(feat_lens.cpu() if isinstance(feat_lens, torch.Tensor) else feat_lens).astype(np.int64) + 4)
+    lens = model._upload("enc_lens", lens_h.astype(np.int32))
+    km = np.zeros((B, Spad), dtype=np.uint8)
+    for b in range(B):
+        km[b, : int(lens_h[b])] = 1
+    key_mask = model._upload("enc_key_mask", km)
+    x = buf("enc_x", (M, Fd), f32)
+    ops.sinusoid_pe(x0.view(M, Fd), x, B, Te, Fd, float(E) ** 0.5)
+    ident_c = buf("enc_cos1", (M, HD // 2), f32)
+    ident_s = buf("enc_sin0", (M, HD // 2), f32)
+    ident_c.fill_(1.0)
+    ident_s.zero_()
+    zero_res = buf("enc_zero", (M, E), f32)
+    zero_res.zero_()
+    qkv = buf("enc_qkv", (M, 3 * E), bf)
+    vt = buf("enc_vt", (B * Hh * HD * Spad,), bf)
+    ao = buf("enc_ao", (M, E), bf)
+    lse = buf("enc_lse", (B * Hh * Spad,), f32)
+    xa = buf("enc_xa", (M, E), f32)
+    xb = buf("enc_xb", (M, E), f32)
+    h = buf("enc_h", (M, Ff), bf)
+    hr = buf("enc_hr", (M, Ff), bf)
+    scale = HD ** -0.5
+    cur = x                                     # layer input (fp32), width in_dim
+    for li, w in enumerate(enc.layers):
+        if li == enc.n_main:                    # after_norm between the main and the tp stacks (SenseVoice.py:569)
+            nxt = xa if cur is not xa else xb
+            ops.layernorm_fwd(cur, enc.after_norm[0], enc.after_norm[1], nxt, None, None, M, E, 1e-5)
+            cur = nxt
+        xn = buf("enc_xn", (M, w["kp"]), bf)
+        ops.layernorm_fwd(cur, w["n1"][0], w["n1"][1], xn, None, None, M, w["in_dim"], 1e-5)
+        ops.gemm(xn, w["wqkv"], qkv, M, 3 * E, w["kp"], bias=w["bqkv"])
+        ops.rope_fwd(qkv, ident_c, ident_s, None, None, vt, B, Te, Hh, Hh)      # identity rotation: only V^T is used
+        ops.attn_fwd(qkv, vt, key_mask, ao, lse, B, Te, Hh, Hh, scale, False)
+        mid = xa if cur is not xa else xb
+        resid = cur if w["in_dim"] == E else zero_res                           # no residual on layer 0 (:372-389)
+        ops.gemm(ao, w["wout"], mid, M, E, E, bias=w["bout"], resid=resid, mode=GEMM_RESID)
+        ops.fsmn_fwd(qkv[:, 2 * E:], 3 * E, w["fsmn"], lens, mid, B, Te, E, geo.enc_kernel, True)
+        xn2 = buf("enc_xn2", (M, E), bf)
+        ops.layernorm_fwd(mid, w["n2"][0], w["n2"][1], xn2, None, None, M, E, 1e-5)
+        ops.gemm(xn2, w["w1"], h, M, Ff, E, bias=w["b1"])
+        ops.relu_fwd(h, hr)
+        out = xb if mid is xa else xa
+        ops.gemm(hr, w["w2"], out, M, E, Ff, bias=w["b2"], resid=mid, mode=GEMM_RESID)
+        cur = out
+    if len(enc.layers) == enc.n_main:           # no tp layers: after_norm still applies
+        nxt = xa if cur is not xa else xb
+        ops.layernorm_fwd(cur, enc.after_norm[0], enc.after_norm[1], nxt, None, None, M, E, 1e-5)
+        cur = nxt
+    encb = buf("enc_outb", (M, E), bf)
+    ops.layernorm_fwd(cur, enc.tp_norm[0], enc.tp_norm[1], encb, None, None, M, E, 1e-5)     # tp_norm, bf16 for the CTC GEMM
+    logits = buf("enc_ctc_logits", (M, Kp), bf)
+    ops.gemm(encb, enc.ctc_w, logits, M, V, E, bias=enc.ctc_b)
+    post = buf("enc_post", (M, Kp), f32)
+    ops.softmax_rows(logits, post, M, V)
+    return post, Te, lens
+
+
+def psd_on_device(model, post, B, T, Te, feat_lens_dev, do_psd=True):
+    """PSD over frames 4.. of every utterance.  Returns (rows fp32 [Rap, Kp], new_lens host int64 [B], Lmax)."""
+    ops, geo = model.ops, model.geo
+    V, Kp = geo.ctc_vocab, rup(geo.ctc_vocab, 64)
+    buf = model._buf
+    body = post[4:]                                  # row (b, t) = b*Te + t of this view
+    fid = buf("psd_fid", (B * T,), torch.int32)
+    fbl = buf("psd_fbl", (B * T,), torch.float32)
+    ss = buf("psd_ss", (B * T,), torch.int32)
+    sl = buf("psd_sl", (B * T,), torch.int32)
+    nl = buf("psd_nl", (B,), torch.int32)
+    ops.psd_frame_stats(body, feat_lens_dev, fid, fbl, B, T, Te, V, geo.blank_id)
+    thr = 0.90 if do_psd else 2.0                    # do_psd=false keeps every frame (ps-slm.py:472-473)
+    blank = geo.blank_id if do_psd else -2           # ... and merges nothing
+    ops.psd_plan(fid, fbl, feat_lens_dev, ss, sl, nl, B, T, blank, thr)
+    new_lens = nl.cpu().numpy().astype(np.int64)     # one small D2H sync per batch (the reference syncs per frame)
+    Lmax = int(new_lens.max()) if B else 0
+    if Lmax == 0:
+        raise ValueError("PSD removed every frame of every utterance (all-blank batch)")
+    Rap = rup(B * Lmax, 64)
+    rows = buf("post", (Rap, Kp), torch.float32)
+    if Rap > B * Lmax:
+        rows[B * Lmax:].zero_()
+    ops.psd_gather(body, ss, sl, nl, rows, B, T, Te, Lmax, V)
+    return rows, new_lens, Lmax

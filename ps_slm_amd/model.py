@@ -331,6 +331,21 @@ class TasuModel:
         st.Ra, st.Rap = Ra, Rap
         return st
 
+    def prepare_audio(self, input_ids, attention_mask, labels, input_features, input_feature_length, do_psd=True) -> StepState:
+        """Audio branch (ps-slm.py:430-454, :469-473, :482): encoder -> CTC posterior -> PSD -> projector."""
+        from .encoder import encoder_posterior, psd_on_device
+        B, T, _ = input_features.shape
+        post, Te, _ = encoder_posterior(self, input_features, input_feature_length)
+        fl = np.asarray(input_feature_length.cpu() if isinstance(input_feature_length, torch.Tensor) else input_feature_length)
+        fl_dev = self._upload("feat_lens", fl.astype(np.int32))
+        rows, new_lens, Lmax = psd_on_device(self, post, B, T, Te, fl_dev, do_psd)
+        st = self._finish_prepare(input_ids, attention_mask, labels, new_lens, Lmax)
+        st.Ra, st.Rap = B * Lmax, rup(B * Lmax, 64)
+        st.dev["post"] = rows
+        st.dev["psd_lens"] = new_lens
+        self._projector_from_posterior(st)
+        return st
+
     def _upload(self, name, arr):
         t = torch.from_numpy(np.ascontiguousarray(arr))
         d = self._buf("in_" + name, t.shape, t.dtype)

@@ -160,17 +160,17 @@ class HipOps:
                                          self._stream()), "tasu_fsmn_fwd")
 
     def softmax_rows(self, x, y, R, V):
-        self._chk(self.lib.tasu_softmax_rows(_p(x), x.stride(0), _p(y), y.stride(0), R, V, self._stream()),
-                  "tasu_softmax_rows")
+        self._chk(self.lib.tasu_softmax_rows(_p(x), int(x.dtype == torch.bfloat16), x.stride(0), _p(y), y.stride(0), R, V,
+                                             self._stream()), "tasu_softmax_rows")
 
-    def psd_frame_stats(self, post, lens, fid, fblank, B, T, V, blank_id):
-        self._chk(self.lib.tasu_psd_frame_stats(_p(post), post.stride(0), _p(lens), _p(fid), _p(fblank), B, T, V, blank_id,
-                                                self._stream()), "tasu_psd_frame_stats")
+    def psd_frame_stats(self, post, lens, fid, fblank, B, T, bstride, V, blank_id):
+        self._chk(self.lib.tasu_psd_frame_stats(_p(post), post.stride(0), _p(lens), _p(fid), _p(fblank), B, T, bstride, V,
+                                                blank_id, self._stream()), "tasu_psd_frame_stats")
 
     def psd_plan(self, fid, fblank, lens, seg_start, seg_len, new_lens, B, T, blank_id, thr):
         self._chk(self.lib.tasu_psd_plan(_p(fid), _p(fblank), _p(lens), _p(seg_start), _p(seg_len), _p(new_lens), B, T,
                                          blank_id, thr, self._stream()), "tasu_psd_plan")
 
-    def psd_gather(self, post, seg_start, seg_len, new_lens, out, B, T, Tout, V):
+    def psd_gather(self, post, seg_start, seg_len, new_lens, out, B, T, bstride, Tout, V):
         self._chk(self.lib.tasu_psd_gather(_p(post), post.stride(0), _p(seg_start), _p(seg_len), _p(new_lens), _p(out),
-                                           out.stride(0), B, T, Tout, V, self._stream()), "tasu_psd_gather")
+                                           out.stride(0), B, T, bstride, Tout, V, self._stream()), "tasu_psd_gather")

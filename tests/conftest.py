@@ -53,3 +53,20 @@ def golden_batch(name):
         b["alphas"] = z["alphas"].tolist()
         b["keeps"] = split_flat(z["keeps_flat"], z["post_lens"])
     return b, z
+
+
+def mid_audio_psd_case():
+    """(geo, state dict, batch, fixture) of tests/golden/mid_audio_psd.npz (see oracle/make_golden.py:main_mid)."""
+    from ps_slm_amd.model import Geometry
+    from ps_slm_amd.synthetic import MID_GEOMETRY, random_state_dict, synthetic_text_batch
+
+    z = load_npz("mid_audio_psd")
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    sd = random_state_dict(geo, int(z["seed_w"]), with_encoder=True)
+    sd["encoder.ctc.ctc_lo.weight"] = sd["encoder.ctc.ctc_lo.weight"] * float(z["ctc_weight_scale"])
+    sd["encoder.ctc.ctc_lo.bias"] = torch.from_numpy(z["ctc_bias"])
+    batch = synthetic_text_batch(geo, 3, seed=int(z["seed_b"]), prompt_len=9, n_audio=21, target_len=17, speech_pos=4,
+                                 feat_frames=12, noise=True, drop_prob=0.15, ragged=True)
+    batch["input_features"] = torch.from_numpy(z["input_features"]).float()
+    batch["input_feature_length"] = torch.from_numpy(z["input_feature_length"])
+    return geo, sd, batch, z

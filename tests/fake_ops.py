@@ -295,10 +295,15 @@ class FakeOps:
 
     def softmax_rows(self, x, y, R, V):
         y[:R].zero_()
-        y[:R, :V] = torch.softmax(x[:R, :V], -1)
+        y[:R, :V] = torch.softmax(x[:R, :V].float(), -1)
 
-    def psd_frame_stats(self, post, lens, fid, fblank, B, T, V, blank_id):
-        p = post.view(B, T, -1)[..., :V]
+    @staticmethod
+    def _post3(post, B, T, bstride):
+        ld = post.stride(0)
+        return torch.as_strided(post, (B, T, post.shape[1]), (bstride * ld, ld, 1))
+
+    def psd_frame_stats(self, post, lens, fid, fblank, B, T, bstride, V, blank_id):
+        p = self._post3(post, B, T, bstride)[..., :V]
         ids = p.argmax(-1).to(torch.int32)
         live = torch.arange(T)[None] < lens[:, None]
         fid.view(B, T).copy_(torch.where(live, ids, torch.full_like(ids, -1)))
@@ -311,7 +316,7 @@ class FakeOps:
             ids, bp = fid.view(B, T)[b], fblank.view(B, T)[b]
             n, start = 0, 0
             for end in range(1, L + 1):
-                if end == L or ids[end] != ids[start] or ids[start] == blank_id:
+                if end == L or ids[end] != ids[start] or ids[start] == blank_id or blank_id < 0:
                     ln = end - start
                     s = bp[start:end].sum()
                     mean = s if ln == 1 else s / ln
@@ -321,9 +326,9 @@ class FakeOps:
                     start = end
             new_lens[b] = n
 
-    def psd_gather(self, post, seg_start, seg_len, new_lens, out, B, T, Tout, V):
-        p = post.view(B, T, -1)
-        o = out.view(B, Tout, -1)
+    def psd_gather(self, post, seg_start, seg_len, new_lens, out, B, T, bstride, Tout, V):
+        p = self._post3(post, B, T, bstride)
+        o = out[: B * Tout].view(B, Tout, -1)
         o.zero_()
         for b in range(B):
             for j in range(int(new_lens[b])):

@@ -104,3 +104,56 @@ def test_adamw_step_moves_loss_down(setup):
     w1 = gm.proj.view(gm.proj.p, "ffn.0.weight")
     assert float(w1[:, geo.ctc_vocab:].abs().max()) == 0.0
     gm.load_reference_state_dict(sd)  # restore for other tests
+
+
+# ------------------------------------------------------------------ audio path on the GPU
+def run_audio(model, batch):
+    st = model.prepare_audio(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["input_features"],
+                             batch["input_feature_length"])
+    model.forward_llm(st)
+    model.backward(st)
+    if model.device.type == "cuda":
+        torch.cuda.synchronize()
+    return st
+
+
+def test_audio_step_with_psd_vs_double_and_reference_golden():
+    """SANM encoder -> CTC softmax -> PSD (merging + blank filter exercised) -> projector -> LLM, fwd + bwd.
+    Golden = real reference fp32; PSD lengths must be bit-exact, loss within 3e-2, grads cosine >= 0.99."""
+    from conftest import mid_audio_psd_case
+    from ps_slm_amd.ops import HipOps
+    geo, sd, batch, z = mid_audio_psd_case()
+    gm = TasuModel(geo, HipOps(), "cuda")
+    gm.load_reference_state_dict(sd)
+    cm = TasuModel(geo, FakeOps(), "cpu")
+    cm.load_reference_state_dict(sd)
+    sg, sc = run_audio(gm, batch), run_audio(cm, batch)
+    assert np.array_equal(sg.dev["psd_lens"], z["psd_lens"]) and np.array_equal(sc.dev["psd_lens"], z["psd_lens"])
+    lg, lc = float(sg.dev["loss_out"][0]), float(sc.dev["loss_out"][0])
+    assert abs(lg - lc) < 3e-3 and abs(lg - float(z["loss"])) < 3e-2
+    a, b = sg.dev["post"][: sg.Ra].cpu(), sc.dev["post"][: sc.Ra]
+    assert float((a - b).abs().max()) < 2e-3                      # PSD'd posterior rows (probabilities)
+    gg, gc = gm.projector_grads(), cm.projector_grads()
+    for k in gc:
+        assert cosine(gg[k], gc[k]) > 0.999, k
+        short = "grad." + k[len("encoder_projector."):]
+        if short in z:
+            assert cosine(gg[k], torch.from_numpy(z[short])) > 0.99, k
+
+
+def test_audio_step_without_merging(setup):
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    from ps_slm_amd.ops import HipOps
+    z = load_npz("mid_audio")
+    sd = random_state_dict(geo, int(z["seed_w"]), with_encoder=True)
+    batch = synthetic_text_batch(geo, 3, seed=int(z["seed_b"]), prompt_len=9, n_audio=21, target_len=17, speech_pos=4,
+                                 feat_frames=12, noise=True, drop_prob=0.15, ragged=True)
+    gm = TasuModel(geo, HipOps(), "cuda")
+    gm.load_reference_state_dict(sd)
+    st = run_audio(gm, batch)
+    assert abs(float(st.dev["loss_out"][0]) - float(z["loss"])) < 3e-2
+    gg = gm.projector_grads()
+    for k, g in gg.items():
+        short = "grad." + k[len("encoder_projector."):]
+        if short in z:
+            assert cosine(g, torch.from_numpy(z[short])) > 0.99, k

@@ -305,6 +305,8 @@ def test_encoder_aux(hip, fake):
     lg = randn(R, ld, seed=4, scale=3.0)
     (c,), (g,) = run_pair(hip, fake, "softmax_rows", [lg, torch.ones(R, ld), R, V], [1])
     assert rel_err(g, c) < 1e-5 and float(g[:, V:].abs().max()) == 0
+    (c,), (g,) = run_pair(hip, fake, "softmax_rows", [lg.to(BF), torch.ones(R, ld), R, V], [1])
+    assert rel_err(g, c) < 1e-5
 
 
 def test_psd_kernels(hip, fake):
@@ -316,7 +318,7 @@ def test_psd_kernels(hip, fake):
     p2 = torch.zeros(B * T, ld)
     p2[:, :V] = post.reshape(B * T, V)
     lens = torch.from_numpy(z["lens"]).to(I32)
-    (fc, bc), (fg, bg) = run_pair(hip, fake, "psd_frame_stats", [p2, lens, torch.zeros(B * T, dtype=I32), torch.zeros(B * T), B, T, V, 0], [2, 3])
+    (fc, bc), (fg, bg) = run_pair(hip, fake, "psd_frame_stats", [p2, lens, torch.zeros(B * T, dtype=I32), torch.zeros(B * T), B, T, T, V, 0], [2, 3])
     assert torch.equal(fc, fg) and torch.equal(bc, bg)
     outs = run_pair(hip, fake, "psd_plan", [fc, bc, lens, torch.zeros(B * T, dtype=I32), torch.zeros(B * T, dtype=I32),
                                             torch.zeros(B, dtype=I32), B, T, 0, 0.9], [3, 4, 5])
@@ -326,7 +328,7 @@ def test_psd_kernels(hip, fake):
         n = int(nc[b])
         assert torch.equal(sc.view(B, T)[b, :n], sg.view(B, T)[b, :n]) and torch.equal(lc.view(B, T)[b, :n], lg_.view(B, T)[b, :n])
     Tout = int(nc.max())
-    (oc,), (og,) = run_pair(hip, fake, "psd_gather", [p2, sc, lc, nc, torch.ones(B * Tout, ld), B, T, Tout, V], [4])
+    (oc,), (og,) = run_pair(hip, fake, "psd_gather", [p2, sc, lc, nc, torch.ones(B * Tout, ld), B, T, T, Tout, V], [4])
     assert rel_err(og, oc) < 1e-6
     ref = torch.from_numpy(z["out"])                            # the REAL reference's PSD output
     torch.testing.assert_close(og.view(B, Tout, ld)[:, :, :V], ref, rtol=1e-5, atol=1e-7)

@@ -105,3 +105,52 @@ def test_state_dict_roundtrip(mid):
         assert v.shape == sd[k].shape
         torch.testing.assert_close(v, sd[k])
     assert model.proj.num_parameters() == sum(sd[k].numel() for k in out)
+
+
+# ------------------------------------------------------------------ audio path (encoder -> CTC -> PSD -> projector -> LLM)
+def test_audio_step_matches_oracle_and_reference_golden():
+    from conftest import load_npz
+    z = load_npz("mid_audio")
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    sd = random_state_dict(geo, int(z["seed_w"]), with_encoder=True)
+    batch = synthetic_text_batch(geo, 3, seed=int(z["seed_b"]), prompt_len=9, n_audio=21, target_len=17, speech_pos=4,
+                                 feat_frames=12, noise=True, drop_prob=0.15, ragged=True)
+    model = build(geo, sd)
+    st = model.prepare_audio(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["input_features"],
+                             batch["input_feature_length"])
+    model.forward_llm(st)
+    model.backward(st)
+    gd = dataclasses.asdict(geo)
+    out, grads = O.loss_and_projector_grads(sd, batch, gd, "bf16", audio=True)
+    assert abs(float(st.dev["loss_out"][0]) - float(out["loss"].detach())) < 1e-2
+    # PSD plan: same kept-frame counts as the oracle (and therefore as the reference, which pins the oracle)
+    post, _, lens = O.audio_front(sd, batch["input_features"], batch["input_feature_length"], geo.enc_heads, geo.enc_kernel, "bf16")
+    _, pl = O.psd(post, lens, post, 0)
+    assert np.array_equal(st.dev["psd_lens"], pl.numpy())
+    mine = model.projector_grads()
+    for k, g in grads.items():
+        cos = torch.nn.functional.cosine_similarity(mine[k].flatten(), g.flatten(), dim=0)
+        assert cos > 0.995, (k, float(cos))
+    # real-reference golden (fp32) within the stated bf16 tolerance
+    assert abs(float(st.dev["loss_out"][0]) - float(z["loss"])) < 3e-2
+    for k, g in mine.items():
+        short = "grad." + k[len("encoder_projector."):]
+        if short in z:
+            assert torch.nn.functional.cosine_similarity(g.flatten(), torch.from_numpy(z[short]).flatten(), dim=0) > 0.99, k
+
+
+def test_audio_psd_step_vs_reference_golden():
+    from conftest import mid_audio_psd_case
+    geo, sd, batch, z = mid_audio_psd_case()
+    model = build(geo, sd)
+    st = model.prepare_audio(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["input_features"],
+                             batch["input_feature_length"])
+    model.forward_llm(st)
+    model.backward(st)
+    assert np.array_equal(st.dev["psd_lens"], z["psd_lens"])
+    assert abs(float(st.dev["loss_out"][0]) - float(z["loss"])) < 3e-2
+    mine = model.projector_grads()
+    for k, g in mine.items():
+        short = "grad." + k[len("encoder_projector."):]
+        if short in z:
+            assert torch.nn.functional.cosine_similarity(g.flatten(), torch.from_numpy(z[short]).flatten(), dim=0) > 0.99, k

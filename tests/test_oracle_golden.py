@@ -188,3 +188,15 @@ def test_mid_audio_fp32():
     geo, gd, sd, batch, z = mid_setup("mid_audio")
     out, grads = O.loss_and_projector_grads(sd, batch, gd, "fp32", audio=True)
     check_mid(out, grads, z, 1e-5)
+
+
+def test_mid_audio_psd_fp32():
+    import dataclasses
+    from conftest import mid_audio_psd_case
+    geo, sd, batch, z = mid_audio_psd_case()
+    gd = dataclasses.asdict(geo)
+    post, _, lens = O.audio_front(sd, batch["input_features"], batch["input_feature_length"], geo.enc_heads, geo.enc_kernel)
+    _, pl = O.psd(post, lens, post, 0)
+    assert np.array_equal(pl.numpy(), z["psd_lens"]) and int(pl.sum()) < int(lens.sum())
+    out, grads = O.loss_and_projector_grads(sd, batch, gd, "fp32", audio=True)
+    check_mid(out, grads, z, 1e-5)
