@@ -132,7 +132,9 @@ def test_audio_step_with_psd_vs_double_and_reference_golden():
     lg, lc = float(sg.dev["loss_out"][0]), float(sc.dev["loss_out"][0])
     assert abs(lg - lc) < 3e-3 and abs(lg - float(z["loss"])) < 3e-2
     a, b = sg.dev["post"][: sg.Ra].cpu(), sc.dev["post"][: sc.Ra]
-    assert float((a - b).abs().max()) < 2e-3                      # PSD'd posterior rows (probabilities)
+    # PSD'd posterior rows are probabilities of bf16 CTC logits: one bf16 ulp of a logit near 8 (0.03) moves a
+    # probability by at most 0.03 * p(1-p) <= 7.5e-3
+    assert float((a - b).abs().max()) < 2e-2
     gg, gc = gm.projector_grads(), cm.projector_grads()
     for k in gc:
         assert cosine(gg[k], gc[k]) > 0.999, k
