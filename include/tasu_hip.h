@@ -173,6 +173,30 @@ int tasu_psd_gather(const float* post, int ldp, const int32_t* seg_start, const 
                     const int32_t* new_lens, float* out, int ldo, int B, int T, int bstride, int Tout, int V,
                     void* stream);
 
+/* ------------------------------------------------------------------------------------------- decode loop
+ * ps-slm.py:660-675 -> HF GenerationMixin beam search (num_beams 4, max_new_tokens 200, greedy-beam) with a KV cache.
+ * Cache layout: k/v cache [M = B*n_beams, ctx, G*128] bf16 (row = beam, position-major so that appending one token
+ * is one contiguous write).
+ * kv_fill: copy the rotated K and V of a prefill qkv activation [B*S, (H+2G)*128] into every beam row of the cache. */
+int tasu_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int S, int H, int G, int n_beams, int ctx,
+                 void* stream);
+/* kv_append: cache[row, pos[row]] = k|v of the single-token qkv activation [M, (H+2G)*128]. */
+int tasu_kv_append(const void* qkv, void* kcache, void* vcache, const int32_t* pos, int M, int H, int G, int ctx,
+                   void* stream);
+/* kv_gather: dst[row, :lens[row]] = src[src_row[row], :lens[row]] -- beam reorder (Cache.reorder_cache). */
+int tasu_kv_gather(const void* src_k, const void* src_v, void* dst_k, void* dst_v, const int32_t* src_row,
+                   const int32_t* lens, int M, int G, int ctx, void* stream);
+/* Single-token GQA attention over the cache: keys [kstart[row], lens[row]) visible (left padding / current length);
+ * out [M, H*128] bf16.  ctx <= 2048, (H/G)*64 <= 1024. */
+int tasu_attn_decode(const void* qkv, const void* kcache, const void* vcache, const int32_t* kstart,
+                     const int32_t* lens, void* out, int M, int H, int G, int ctx, float scale, void* stream);
+/* log_softmax + top-k per row of bf16 logits [M, ld]: out_val[M,k] (descending log-probs), out_idx[M,k] (token ids);
+ * the n_banned ids in `banned` (device) score -inf after the softmax (MinLengthLogitsProcessor). k in {1,2,4,6,8,16}. */
+int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned,
+                      float* out_val, int32_t* out_idx, void* stream);
+/* x[m,:] = table[ids[m],:] (fp32 embedding rows of the last generated tokens). */
+int tasu_embed_rows(const float* table, const int32_t* ids, float* x, int M, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -347,6 +347,32 @@ def main_mid():
          cols=cols, logits_cols=lgp[:, :, cols], lse=torch.logsumexp(lgp, -1),
          **{k: v for k, v in rp.items() if k.startswith("grad.") and k not in ("grad.ffn.2.weight", "grad.ffn.0.weight")})
 
+    # beam-4 generate at the mid geometry: text path (clean posterior of regex-cleaned targets) and audio path,
+    # left-padded prompts as in inference mode (speech_dataset_large.py:242-245)
+    gen_raw = synthetic_text_batch(geo, 2, seed=77, prompt_len=9, n_audio=21, target_len=3, speech_pos=4, feat_frames=12,
+                                   noise=False, ragged=True)
+    P = 9
+    ids_l, am_l = [], []
+    for b in range(2):
+        row = gen_raw["input_ids"][b][gen_raw["attention_mask"][b]][: P - b]      # prompt only, ragged
+        n = P - len(row)
+        ids_l.append(torch.cat([torch.full((n,), geo.eos_id, dtype=torch.long), row]))
+        am_l.append(torch.cat([torch.zeros(n, dtype=torch.bool), torch.ones(len(row), dtype=torch.bool)]))
+    gids, gam = torch.stack(ids_l), torch.stack(am_l)
+    model.gt_emb = True
+    words = ["ab cd ef gh", "x yz"]
+    with torch.no_grad():
+        toks_t = quiet(model.generate, input_ids=gids, input_features=feats[:2], attention_mask=gam,
+                       input_feature_length=flen[:2], max_new_tokens=16, targets=words)
+    word_ids = [model.encoder_tokenizer.encode(t) for t in words]
+    model.gt_emb = False
+    with torch.no_grad():
+        toks_a = quiet(model.generate, input_ids=gids, input_features=feats[:2], attention_mask=gam,
+                       input_feature_length=flen[:2], max_new_tokens=16)
+    save("mid_generate_beam4", seed_w=seed_w, input_ids=gids, attention_mask=gam, tokens_text=toks_t, tokens_audio=toks_a,
+         post_ids_flat=np.concatenate([np.asarray(w) for w in word_ids]), post_lens=np.asarray([len(w) for w in word_ids]))
+    print("mid_generate_beam4 text", toks_t.tolist(), "audio", toks_a.tolist())
+
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mid":

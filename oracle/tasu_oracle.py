@@ -433,3 +433,76 @@ def lr_for_optimizer_step(k, base_lr, **kw):
     and then lr_scheduler.step(), and the scheduler starts at last_batch_iteration = -1, so step k sees
     the ratio of iteration k-2 (steps 1 and 2 run at lr 0 with log warmup).  PARITY UNPINNED."""
     return warmup_cosine_lr(k - 2, base_lr, **kw)
+
+
+# ----------------------------------------------------------------------------- decode: beam search
+def beam_search_generate(W, emb, mask, geo, num_beams=4, max_new_tokens=200, min_length=1, length_penalty=1.0,
+                         eos_token_id=None, pad_token_id=None, mode="fp32"):
+    """slam_model_asr.generate's decode loop (Multitask/model/ps-slm.py:660-675): HF ``generate(inputs_embeds=...,
+    num_beams=4, do_sample=False, early_stopping=False)`` restated (transformers generation/utils.py ``_beam_search``,
+    un-vendored dependency): every step keeps the 2*num_beams best continuations, the first num_beams non-finished
+    ones keep running, finished ones (EOS or max length) among the top num_beams compete for the num_beams result
+    slots with score / (generated_length ** length_penalty); the loop ends when no running beam can beat the worst
+    kept result (heuristic on the current length) or every continuation hit a stopping criterion.  No KV cache here:
+    the whole sequence is re-run every step (CPU oracle, tiny sizes).  Returns new tokens only, [B, n_new]."""
+    B, S, D = emb.shape
+    nb, V = num_beams, lm_head_weight(W).shape[0]
+    eos = geo["eos_id"] if eos_token_id is None else eos_token_id
+    pad = eos if pad_token_id is None else pad_token_id
+    K = 2 * nb
+    NEG = -1.0e9
+    run_seq = torch.full((B, nb, max_new_tokens), pad, dtype=torch.long)
+    fin_seq = run_seq.clone()
+    run_scores = torch.zeros(B, nb)
+    run_scores[:, 1:] = NEG
+    fin_scores = torch.full((B, nb), NEG)
+    fin_len = torch.zeros(B, nb, dtype=torch.long)
+    is_fin = torch.zeros(B, nb, dtype=torch.bool)
+    unsat = torch.ones(B, 1, dtype=torch.bool)
+    top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(K - nb, dtype=torch.bool)])
+    table = W["llm.model.embed_tokens.weight"]
+    emb_b = emb.repeat_interleave(nb, 0)
+    mask_b = mask.repeat_interleave(nb, 0)
+    cur = 0
+    while True:
+        toks = run_seq.view(B * nb, -1)[:, :cur]
+        x = torch.cat([emb_b, table[toks]], 1)
+        m = torch.cat([mask_b.bool(), torch.ones(B * nb, cur, dtype=torch.bool)], 1)
+        pos = (m.long().cumsum(-1) - 1).masked_fill(~m, 1)
+        hid = qwen2_hidden(W, x, m, pos, geo["llm_heads"], geo["llm_kv_heads"], geo.get("rope_theta", 1e6), mode)
+        logits = linear(hid[:, -1], lm_head_weight(W), None, mode).float()
+        logp = torch.log_softmax(logits, -1)
+        if cur < min_length:
+            logp[:, eos] = float("-inf")
+        acc = (logp.view(B, nb, V) + run_scores[:, :, None]).view(B, nb * V)
+        top_lp, top_ix = torch.topk(acc, K)
+        beam_ix, tok = top_ix // V, top_ix % V
+        cand = torch.gather(run_seq, 1, beam_ix[:, :, None].expand(-1, -1, max_new_tokens)).clone()
+        cand[:, :, cur] = tok
+        stop = (tok == eos) | (cur + 1 >= max_new_tokens)
+        # running beams for the next step
+        run_lp = top_lp + stop.float() * NEG
+        nxt = torch.topk(run_lp, nb)[1]
+        run_seq = torch.gather(cand, 1, nxt[:, :, None].expand(-1, -1, max_new_tokens))
+        run_scores = torch.gather(run_lp, 1, nxt)
+        # finished beams
+        just = stop & top_mask[None]
+        sc = top_lp / ((cur + 1) ** length_penalty)
+        sc = sc + (~unsat).float() * NEG + (~just).float() * NEG
+        m_seq = torch.cat([fin_seq, cand], 1)
+        m_sc = torch.cat([fin_scores, sc], 1)
+        m_len = torch.cat([fin_len, torch.full((B, K), cur + 1, dtype=torch.long)], 1)
+        m_fin = torch.cat([is_fin, just], 1)
+        keep = torch.topk(m_sc, nb)[1]
+        fin_seq = torch.gather(m_seq, 1, keep[:, :, None].expand(-1, -1, max_new_tokens))
+        fin_scores = torch.gather(m_sc, 1, keep)
+        fin_len = torch.gather(m_len, 1, keep)
+        is_fin = torch.gather(m_fin, 1, keep)
+        cur += 1
+        best_run = run_scores[:, :1] / (cur ** length_penalty)
+        worst_fin = torch.where(is_fin, fin_scores.min(1, keepdim=True)[0], torch.full_like(fin_scores, NEG))
+        unsat = unsat & (best_run > worst_fin).any(-1, keepdim=True)
+        if not (bool(unsat.any()) and not bool(stop.all())):
+            break
+    n = int(fin_len[:, 0].max())
+    return fin_seq[:, 0, :n]

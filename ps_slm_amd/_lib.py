@@ -47,6 +47,12 @@ PROTOTYPES = {
     "tasu_psd_frame_stats": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "tasu_psd_plan": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "tasu_psd_gather": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tasu_kv_fill": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tasu_kv_append": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "tasu_kv_gather": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "tasu_attn_decode": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "tasu_logprob_topk": [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp],
+    "tasu_embed_rows": [vp, vp, vp, i32, i32, vp],
 }
 
 ABI_VERSION = 1

@@ -1,0 +1,278 @@
+// Decode-loop kernels (Multitask/model/ps-slm.py:660-675 -> HF GenerationMixin beam search, 4 beams): KV cache
+// fill / append / beam reorder, single-token GQA attention over the cache, and the per-row log-softmax + top-k that
+// feeds the beam bookkeeping.  All HBM-bound (weights and KV are read once per step).
+#include "common.h"
+#include "../../include/tasu_hip.h"
+
+namespace {
+constexpr int HD = 128;
+
+// cache[(b*nb + j), s, :] = k|v block of qkv[(b*S + s), :]   for every beam j.   grid (S, B), block 256
+__global__ __launch_bounds__(256) void kv_fill_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kc, bf16* __restrict__ vc,
+                                                      int S, int H, int G, int nb, int ctx) {
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int LD = (H + 2 * G) * HD, W = G * HD;
+  const bf16* src = qkv + ((size_t)b * S + s) * LD + H * HD;
+  for (int c = threadIdx.x * 8; c < 2 * W; c += 256 * 8) {
+    const bf16x8 v = *(const bf16x8*)(src + c);
+    bf16* base = c < W ? kc : vc;
+    const int cc = c < W ? c : c - W;
+    for (int j = 0; j < nb; ++j) *(bf16x8*)(base + (((size_t)(b * nb + j)) * ctx + s) * W + cc) = v;
+  }
+}
+
+// cache[row, pos[row], :] = k|v block of qkv[row, :]     grid (M), block 128
+__global__ __launch_bounds__(128) void kv_append_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kc, bf16* __restrict__ vc,
+                                                        const int32_t* __restrict__ pos, int H, int G, int ctx) {
+  const int row = blockIdx.x;
+  const int LD = (H + 2 * G) * HD, W = G * HD;
+  const bf16* src = qkv + (size_t)row * LD + H * HD;
+  const int p = pos[row];
+  for (int c = threadIdx.x * 8; c < 2 * W; c += 128 * 8) {
+    const bf16x8 v = *(const bf16x8*)(src + c);
+    if (c < W)
+      *(bf16x8*)(kc + ((size_t)row * ctx + p) * W + c) = v;
+    else
+      *(bf16x8*)(vc + ((size_t)row * ctx + p) * W + (c - W)) = v;
+  }
+}
+
+// dst[row, 0:len[row], :] = src[src_row[row], 0:len[row], :]  (beam reorder; ping-pong buffers)   grid (ctx_blocks, M)
+__global__ __launch_bounds__(256) void kv_gather_kernel(const bf16* __restrict__ sk, const bf16* __restrict__ sv, bf16* __restrict__ dk,
+                                                        bf16* __restrict__ dv, const int32_t* __restrict__ src_row,
+                                                        const int32_t* __restrict__ lens, int W, int ctx) {
+  const int row = blockIdx.y;
+  const int n = lens[row];
+  const int sr = src_row[row];
+  const int per = (W / 8);                     // 16-byte chunks per position
+  const size_t total = (size_t)n * per;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t off = i * 8;
+    *(bf16x8*)(dk + (size_t)row * ctx * W + off) = *(const bf16x8*)(sk + (size_t)sr * ctx * W + off);
+    *(bf16x8*)(dv + (size_t)row * ctx * W + off) = *(const bf16x8*)(sv + (size_t)sr * ctx * W + off);
+  }
+}
+
+// Single-token attention.  Block = (row, kv group); wave w = query head g*rep + w.  Phase 1: lane-per-key scores
+// (q in registers, K rows via 16-byte loads), scores staged in LDS; phase 2: lane-per-dim-pair P.V (coalesced V rows).
+// keys in [kstart[row], lens[row]) are visible.  ctx <= MAX_CTX.
+constexpr int MAX_CTX = 2048;
+__global__ void attn_decode_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ kc, const bf16* __restrict__ vc,
+                                   const int32_t* __restrict__ kstart, const int32_t* __restrict__ lens, bf16* __restrict__ out,
+                                   int H, int G, int ctx, float scale) {
+  extern __shared__ float sp[];                 // [rep][n_keys_padded]
+  const int row = blockIdx.x, g = blockIdx.y;
+  const int rep = H / G, W = G * HD, LD = (H + 2 * G) * HD;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int h = g * rep + wave;
+  const int k0 = kstart[row], k1 = lens[row];
+  const int nk = k1 - k0;
+  float* myp = sp + (size_t)wave * ctx;
+  // q row -> registers (fp32, pre-scaled)
+  float q[HD];
+  {
+    const bf16* qr = qkv + (size_t)row * LD + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      const bf16x8 v = *(const bf16x8*)(qr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[c * 8 + j] = (float)v[j] * scale;
+    }
+  }
+  float m = -__builtin_inff();
+  for (int i = lane; i < nk; i += 64) {
+    const bf16* kr = kc + ((size_t)row * ctx + k0 + i) * W + g * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      const bf16x8 v = *(const bf16x8*)(kr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += q[c * 8 + j] * (float)v[j];
+    }
+    myp[i] = s;
+    m = fmaxf(m, s);
+  }
+  m = wave_max(m);
+  float l = 0.f;
+  for (int i = lane; i < nk; i += 64) {
+    const float p = __expf(myp[i] - m);
+    myp[i] = p;
+    l += p;
+  }
+  l = wave_sum(l);
+  __builtin_amdgcn_wave_barrier();              // a wave's LDS accesses are processed in order: its own writes are visible
+  // P.V: lane owns dims 2*lane, 2*lane+1
+  float o0 = 0.f, o1 = 0.f;
+  for (int i = 0; i < nk; ++i) {
+    const float p = (float)(bf16)myp[i];        // bf16-rounded probabilities, like the prefill kernel
+    const bf16x2 v = *(const bf16x2*)(vc + ((size_t)row * ctx + k0 + i) * W + g * HD + 2 * lane);
+    o0 += p * (float)v[0];
+    o1 += p * (float)v[1];
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  bf16x2 o;
+  o[0] = (bf16)(o0 * inv);
+  o[1] = (bf16)(o1 * inv);
+  *(bf16x2*)(out + (size_t)row * (H * HD) + h * HD + 2 * lane) = o;
+}
+
+// per row: lse over V columns, then the k best log-probs (value = logit - lse) with their column ids, descending;
+// columns listed in `banned` (n_banned ids, e.g. EOS while cur_len < min_length) score -inf.   k <= 16.
+constexpr int TOPK_MAX = 16;
+template <int K>
+__global__ __launch_bounds__(256) void logprob_topk_kernel(const bf16* __restrict__ logits, int ld, int V,
+                                                           const int32_t* __restrict__ banned, int n_banned,
+                                                           float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+  __shared__ float red[4];
+  __shared__ float cv[256 * K];
+  __shared__ int ci[256 * K];
+  __shared__ float bestv[4];
+  __shared__ int besti[4], bestslot[4];
+  const int row = blockIdx.x;
+  const bf16* lr = logits + (size_t)row * ld;
+  float tv[K];
+  int ti[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    tv[j] = -__builtin_inff();
+    ti[j] = 0x7fffffff;
+  }
+  float m = -__builtin_inff();
+  for (int c = threadIdx.x; c < V; c += 256) m = fmaxf(m, (float)lr[c]);
+  m = block_max<4>(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    const float f = (float)lr[c];
+    s += __expf(f - m);
+    bool ban = false;
+    for (int b = 0; b < n_banned; ++b) ban |= (banned[b] == c);
+    // thread-local sorted list (descending; on ties the smaller column, seen first, stays ahead)
+    if (!ban && f > tv[K - 1]) {
+      tv[K - 1] = f;
+      ti[K - 1] = c;
+#pragma unroll
+      for (int j = K - 1; j > 0; --j) {
+        if (tv[j] > tv[j - 1]) {
+          const float a = tv[j];
+          tv[j] = tv[j - 1];
+          tv[j - 1] = a;
+          const int b2 = ti[j];
+          ti[j] = ti[j - 1];
+          ti[j - 1] = b2;
+        }
+      }
+    }
+  }
+  s = block_sum<4>(s, red);
+  const float lse = m + __logf(s);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    cv[threadIdx.x * K + j] = tv[j];
+    ci[threadIdx.x * K + j] = ti[j];
+  }
+  __syncthreads();
+  // K rounds of block-wide argmax over the 256 list heads (each list is sorted, so only heads compete)
+  int head = 0;                                   // this thread's next unconsumed entry
+  for (int r = 0; r < K; ++r) {
+    float v = head < K ? cv[threadIdx.x * K + head] : -__builtin_inff();
+    int id = head < K ? ci[threadIdx.x * K + head] : 0x7fffffff;
+    int slot = threadIdx.x;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(id, o, 64);
+      const int os = __shfl_xor(slot, o, 64);
+      if (ov > v || (ov == v && oi < id)) {
+        v = ov;
+        id = oi;
+        slot = os;
+      }
+    }
+    if ((threadIdx.x & 63) == 0) {
+      bestv[threadIdx.x >> 6] = v;
+      besti[threadIdx.x >> 6] = id;
+      bestslot[threadIdx.x >> 6] = slot;
+    }
+    __syncthreads();
+    float bv = bestv[0];
+    int bi = besti[0], bs = bestslot[0];
+    for (int w = 1; w < 4; ++w)
+      if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) {
+        bv = bestv[w];
+        bi = besti[w];
+        bs = bestslot[w];
+      }
+    if (threadIdx.x == bs) ++head;
+    if (threadIdx.x == 0) {
+      out_val[(size_t)row * K + r] = bv - lse;
+      out_idx[(size_t)row * K + r] = bi;
+    }
+    __syncthreads();
+  }
+}
+
+// x[m,:] = table[ids[m], :]  (fp32 embedding rows for the decode step)
+__global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                                         float* __restrict__ x, int M, int D) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const float* src = table + (size_t)ids[m] * D;
+  for (int c = lane * 4; c < D; c += 256) *(f32x4*)(x + (size_t)m * D + c) = *(const f32x4*)(src + c);
+}
+
+}  // namespace
+
+extern "C" int tasu_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int S, int H, int G, int n_beams, int ctx,
+                            void* stream) {
+  if (!qkv || !kcache || !vcache || B <= 0 || S <= 0 || S > ctx || H <= 0 || G <= 0 || n_beams <= 0) return TASU_ERR_ARG;
+  TASU_LAUNCH(kv_fill_kernel, dim3(S, B), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, S,
+              H, G, n_beams, ctx);
+  return TASU_OK;
+}
+extern "C" int tasu_kv_append(const void* qkv, void* kcache, void* vcache, const int32_t* pos, int M, int H, int G, int ctx,
+                              void* stream) {
+  if (!qkv || !kcache || !vcache || !pos || M <= 0 || H <= 0 || G <= 0) return TASU_ERR_ARG;
+  TASU_LAUNCH(kv_append_kernel, dim3(M), dim3(128), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, pos,
+              H, G, ctx);
+  return TASU_OK;
+}
+extern "C" int tasu_kv_gather(const void* src_k, const void* src_v, void* dst_k, void* dst_v, const int32_t* src_row,
+                              const int32_t* lens, int M, int G, int ctx, void* stream) {
+  if (!src_k || !src_v || !dst_k || !dst_v || !src_row || !lens || M <= 0 || G <= 0 || ctx <= 0) return TASU_ERR_ARG;
+  TASU_LAUNCH(kv_gather_kernel, dim3(8, M), dim3(256), 0, (hipStream_t)stream, (const bf16*)src_k, (const bf16*)src_v,
+              (bf16*)dst_k, (bf16*)dst_v, src_row, lens, G * HD, ctx);
+  return TASU_OK;
+}
+extern "C" int tasu_attn_decode(const void* qkv, const void* kcache, const void* vcache, const int32_t* kstart,
+                                const int32_t* lens, void* out, int M, int H, int G, int ctx, float scale, void* stream) {
+  if (!qkv || !kcache || !vcache || !kstart || !lens || !out || M <= 0 || H <= 0 || G <= 0 || H % G || ctx <= 0 ||
+      ctx > MAX_CTX || (H / G) * 64 > 1024)
+    return TASU_ERR_ARG;
+  const int rep = H / G;
+  TASU_LAUNCH(attn_decode_kernel, dim3(M, G), dim3(rep * 64), (size_t)rep * ctx * sizeof(float), (hipStream_t)stream,
+              (const bf16*)qkv, (const bf16*)kcache, (const bf16*)vcache, kstart, lens, (bf16*)out, H, G, ctx, scale);
+  return TASU_OK;
+}
+extern "C" int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned,
+                                 float* out_val, int32_t* out_idx, void* stream) {
+  if (!logits || !out_val || !out_idx || M <= 0 || V <= 0 || ld < V || k <= 0 || k > TOPK_MAX || n_banned < 0 ||
+      (n_banned > 0 && !banned))
+    return TASU_ERR_ARG;
+#define TOPK_CASE(KK)                                                                                                \
+  case KK:                                                                                                           \
+    TASU_LAUNCH(logprob_topk_kernel<KK>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ld, V, banned, \
+                n_banned, out_val, out_idx);                                                                         \
+    return TASU_OK;
+  switch (k) {
+    TOPK_CASE(1) TOPK_CASE(2) TOPK_CASE(4) TOPK_CASE(6) TOPK_CASE(8) TOPK_CASE(16)
+    default:
+      return TASU_ERR_ARG;
+  }
+#undef TOPK_CASE
+}
+extern "C" int tasu_embed_rows(const float* table, const int32_t* ids, float* x, int M, int D, void* stream) {
+  if (!table || !ids || !x || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
+  TASU_LAUNCH(embed_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ids, x, M, D);
+  return TASU_OK;
+}

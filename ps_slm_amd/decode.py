@@ -1,0 +1,172 @@
+"""Decode loop of ``slam_model_asr.generate`` (Multitask/model/ps-slm.py:539-677) on the gfx950 kernels: prefill with
+the training forward kernels, then one single-token step per generated position with a per-beam KV cache.  The beam
+bookkeeping of HF ``generate(num_beams=4, do_sample=False, early_stopping=False)`` (transformers generation/utils.py
+``_beam_search``; dependency not in the reference tree) is restated on the host in numpy: per step the device returns,
+for each of the B*nb live rows, its 2*nb best log-probs (tasu_logprob_topk) -- a superset of the batch's 2*nb best
+continuations -- and the host does the (tiny) selection, finished-beam heap and early-stop heuristic.
+
+Device per step (M = B*nb rows): embedding rows -> 28 x [RMSNorm, qkv GEMM, RoPE, KV append, cache attention, o GEMM +
+residual, RMSNorm, gate|up GEMM, SwiGLU, down GEMM + residual] -> RMSNorm -> lm_head GEMM -> log-softmax top-k ->
+beam reorder of the KV cache (ping-pong gather).  HBM-bound: every step streams the bf16 weights once.
+"""
+import numpy as np
+import torch
+
+from .model import HD, StepState, rup
+from .ops import GEMM_RESID
+
+NEG = -1.0e9
+
+
+class BeamState:
+    """Host restatement of HF's beam-search state update (one call per generated position)."""
+
+    def __init__(self, B, nb, max_new, eos, pad, length_penalty=1.0, min_length=1):
+        self.B, self.nb, self.K, self.max_new = B, nb, 2 * nb, max_new
+        self.eos, self.lp, self.min_length = eos, length_penalty, min_length
+        self.run_seq = np.full((B, nb, max_new), pad, dtype=np.int64)
+        self.fin_seq = self.run_seq.copy()
+        self.run_scores = np.zeros((B, nb), dtype=np.float32)
+        self.run_scores[:, 1:] = NEG
+        self.fin_scores = np.full((B, nb), NEG, dtype=np.float32)
+        self.fin_len = np.zeros((B, nb), dtype=np.int64)
+        self.is_fin = np.zeros((B, nb), dtype=bool)
+        self.unsat = np.ones(B, dtype=bool)
+        self.cur = 0
+        self.done = False
+
+    def ban_eos(self):
+        return self.cur < self.min_length
+
+    def update(self, vals, idx):
+        """vals/idx: [B, nb, K] per-row top-K log-probs (descending) and token ids.  Returns (tokens [B, nb],
+        parent beam [B, nb]) of the beams that keep running."""
+        B, nb, K, cur = self.B, self.nb, self.K, self.cur
+        acc = vals.astype(np.float32) + self.run_scores[:, :, None]
+        flat = acc.reshape(B, nb * K)
+        flat_tok = idx.reshape(B, nb * K)
+        flat_beam = np.repeat(np.arange(nb), K)[None, :].repeat(B, 0)
+        # top-K of the batch's candidates; ties resolved like a flattened [nb * V] top-k (beam, then token id)
+        order = np.lexsort((flat_tok, flat_beam, -flat), axis=-1)[:, :K]
+        top_lp = np.take_along_axis(flat, order, 1)
+        tok = np.take_along_axis(flat_tok, order, 1)
+        beam = np.take_along_axis(flat_beam, order, 1)
+        cand = np.take_along_axis(self.run_seq, beam[:, :, None], 1).copy()
+        cand[:, :, cur] = tok
+        stop = (tok == self.eos) | (cur + 1 >= self.max_new)
+        run_lp = top_lp + stop.astype(np.float32) * NEG
+        nxt = np.argsort(-run_lp, axis=1, kind="stable")[:, :nb]
+        self.run_seq = np.take_along_axis(cand, nxt[:, :, None], 1)
+        self.run_scores = np.take_along_axis(run_lp, nxt, 1)
+        next_tok = np.take_along_axis(tok, nxt, 1)
+        next_parent = np.take_along_axis(beam, nxt, 1)
+        top_mask = np.arange(K)[None, :] < nb
+        just = stop & top_mask
+        sc = top_lp / np.float32((cur + 1) ** self.lp)
+        sc = sc + (~self.unsat)[:, None].astype(np.float32) * NEG + (~just).astype(np.float32) * NEG
+        m_seq = np.concatenate([self.fin_seq, cand], 1)
+        m_sc = np.concatenate([self.fin_scores, sc], 1)
+        m_len = np.concatenate([self.fin_len, np.full((B, K), cur + 1, dtype=np.int64)], 1)
+        m_fin = np.concatenate([self.is_fin, just], 1)
+        keep = np.argsort(-m_sc, axis=1, kind="stable")[:, :nb]
+        self.fin_seq = np.take_along_axis(m_seq, keep[:, :, None], 1)
+        self.fin_scores = np.take_along_axis(m_sc, keep, 1)
+        self.fin_len = np.take_along_axis(m_len, keep, 1)
+        self.is_fin = np.take_along_axis(m_fin, keep, 1)
+        self.cur = cur + 1
+        best_run = self.run_scores[:, :1] / np.float32(self.cur ** self.lp)
+        worst_fin = np.where(self.is_fin, self.fin_scores.min(1, keepdims=True), np.float32(NEG))
+        self.unsat = self.unsat & (best_run > worst_fin).any(-1)
+        self.done = not (self.unsat.any() and not stop.all())
+        return next_tok, next_parent
+
+    def result(self):
+        n = int(self.fin_len[:, 0].max())
+        return self.fin_seq[:, 0, :n]
+
+
+def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, min_length=1, length_penalty=1.0,
+                         eos_token_id=None, pad_token_id=None):
+    """st: a prepared state whose projector output (st.dev['y2']) is ready.  Returns LongTensor [B, n_new] (CPU)."""
+    ops, geo, llm = model.ops, model.geo, model.llm
+    B, S, nb = st.B, st.S, num_beams
+    M, K = B * nb, 2 * nb
+    D, I, H, G, V, L = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_vocab, geo.llm_layers
+    Vp, LDQ, W = rup(V, 64), (H + 2 * G) * HD, G * HD
+    eos = geo.eos_id if eos_token_id is None else eos_token_id
+    pad = eos if pad_token_id is None else pad_token_id
+    ctx = S + max_new_tokens
+    scale = HD ** -0.5
+    bf, f32, i32 = torch.bfloat16, torch.float32, torch.int32
+    buf = model._buf
+    # ---- prefill with the training-forward kernels (no loss)
+    model.forward_llm(st, compute_loss=False, need_backward=False, logits_rows="none")
+    d = st.dev
+    kc = buf("dec_kc", (2, L, M * ctx * W), bf)
+    vc = buf("dec_vc", (2, L, M * ctx * W), bf)
+    for l in range(L):
+        ops.kv_fill(d["qkv"][l], kc[0, l], vc[0, l], B, S, H, G, nb, ctx)
+    valid = st.plan.key_mask[:, :S].sum(1).astype(np.int64)               # real tokens per prompt
+    kstart_h = np.repeat(S - valid, nb).astype(np.int32)                   # left padding is at the front
+    kstart = model._upload("dec_kstart", kstart_h)
+    # logits of the last prompt position of every batch row
+    last_rows = model._upload("dec_last_rows", (np.arange(B, dtype=np.int32) + 1) * S - 1)
+    xl = buf("dec_xlast", (B, D), f32)
+    ops.embed_rows(d["xs"][2 * L], last_rows, xl, B, D)                    # row gather out of the residual stream
+    xn = buf("dec_xn", (M, D), bf)
+    logits = buf("dec_logits", (M, Vp), bf)
+    ops.rmsnorm_fwd(xl, llm.norm, xn[:B], None, geo.rms_eps)
+    ops.gemm(xn, llm.head, logits, B, V, D)
+    tv = buf("dec_topv", (M, K), f32)
+    ti = buf("dec_topi", (M, K), i32)
+    banned = model._upload("dec_banned", np.array([eos], dtype=np.int32))
+    state = BeamState(B, nb, max_new_tokens, eos, pad, length_penalty, min_length)
+    ops.logprob_topk(logits, B, V, K, banned, 1 if state.ban_eos() else 0, tv, ti)
+    v0, i0 = tv[:B].cpu().numpy(), ti[:B].cpu().numpy()
+    vals = np.full((B, nb, K), NEG, dtype=np.float32)                      # beams 1.. start at -1e9 (HF init)
+    idx = np.zeros((B, nb, K), dtype=np.int64)
+    vals[:, 0], idx[:, 0] = v0, i0
+    tok, parent = state.update(vals, idx)                                  # all parents are beam 0: no reorder needed
+    x = buf("dec_x", (M, D), f32)
+    x2 = buf("dec_x2", (M, D), f32)
+    qkv = buf("dec_qkv", (M, LDQ), bf)
+    ao = buf("dec_ao", (M, H * HD), bf)
+    gu = buf("dec_gu", (M, 2 * I), bf)
+    act = buf("dec_act", (M, I), bf)
+    cos = buf("dec_cos", (M, HD // 2), f32)
+    sin = buf("dec_sin", (M, HD // 2), f32)
+    cur_buf = 0
+    while not state.done:
+        t = state.cur                                                       # tokens generated so far (>= 1)
+        ids = model._upload("dec_ids", tok.reshape(-1).astype(np.int32))
+        pos = model._upload("dec_pos", np.repeat(valid + t - 1, nb).astype(np.int32))      # position id of the new token
+        slot = model._upload("dec_slot", np.full(M, S + t - 1, dtype=np.int32))            # its cache slot
+        lens = model._upload("dec_lens", np.full(M, S + t, dtype=np.int32))
+        ops.embed_rows(llm.embed, ids, x, M, D)
+        ops.rope_table(pos, cos, sin, HD, geo.rope_theta)
+        for l, w in enumerate(llm.layers):
+            ops.rmsnorm_fwd(x, w["ln1"], xn, None, geo.rms_eps)
+            ops.gemm(xn, w["wqkv"], qkv, M, LDQ, D, bias=w["bqkv"])
+            ops.rope_fwd(qkv, cos, sin, None, None, None, M, 1, H, G)
+            ops.kv_append(qkv, kc[cur_buf, l], vc[cur_buf, l], slot, M, H, G, ctx)
+            ops.attn_decode(qkv, kc[cur_buf, l], vc[cur_buf, l], kstart, lens, ao, M, H, G, ctx, scale)
+            ops.gemm(ao, w["wo"], x2, M, D, H * HD, resid=x, mode=GEMM_RESID)
+            ops.rmsnorm_fwd(x2, w["ln2"], xn, None, geo.rms_eps)
+            ops.gemm(xn, w["wgu"], gu, M, 2 * I, D)
+            ops.swiglu_fwd(gu, act, M, I)
+            ops.gemm(act, w["wd"], x, M, D, I, resid=x2, mode=GEMM_RESID)
+        ops.rmsnorm_fwd(x, llm.norm, xn, None, geo.rms_eps)
+        ops.gemm(xn, llm.head, logits, M, V, D)
+        ops.logprob_topk(logits, M, V, K, banned, 1 if state.ban_eos() else 0, tv, ti)
+        vals = tv.cpu().numpy().reshape(B, nb, K)                           # one small D2H sync per step
+        idx = ti.cpu().numpy().reshape(B, nb, K).astype(np.int64)
+        tok, parent = state.update(vals, idx)
+        if state.done:
+            break
+        src = (np.arange(B)[:, None] * nb + parent).reshape(-1).astype(np.int32)
+        if not np.array_equal(src, np.arange(M, dtype=np.int32)):
+            src_d = model._upload("dec_src", src)
+            for l in range(L):
+                ops.kv_gather(kc[cur_buf, l], vc[cur_buf, l], kc[1 - cur_buf, l], vc[1 - cur_buf, l], src_d, lens, M, G, ctx)
+            cur_buf = 1 - cur_buf
+    return torch.from_numpy(state.result())

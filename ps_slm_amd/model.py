@@ -393,7 +393,7 @@ class TasuModel:
         ops.gemm(a1, pr.view(pr.pb, "ffn.2.weight"), y2, Rap, Do, Hb, bias=pr.view(pr.pb, "ffn.2.bias"))
         st.dev.update(xn=xn, ln_mean=mean, ln_rstd=rstd, h1=h1, a1=a1, y2=y2)
 
-    def forward_llm(self, st: StepState, compute_loss=True, need_backward=True):
+    def forward_llm(self, st: StepState, compute_loss=True, need_backward=True, logits_rows="all"):
         ops, geo, llm = self.ops, self.geo, self.llm
         B, S, M = st.B, st.S, st.M
         D, I, H, G, V = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_vocab
@@ -428,10 +428,13 @@ class TasuModel:
             ops.gemm(xn, w["wgu"], gu[l], M, 2 * I, D)
             ops.swiglu_fwd(gu[l], act, M, I)
             ops.gemm(act, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
+        d.update(xs=xs, cos=cos, sin=sin, rstd=rstd, qkv=qkv, qt=qt, kt=kt, ao=ao, lse=lse, gu=gu)
+        if logits_rows == "none":                              # decode prefill: the caller projects the last rows only
+            return
         ops.rmsnorm_fwd(xs[2 * L], llm.norm, xn, rstd[2 * L], geo.rms_eps)
         logits = self._buf("logits", (M, Vp), bf)
         ops.gemm(xn, llm.head, logits, M, V, D)
-        d.update(xs=xs, cos=cos, sin=sin, rstd=rstd, qkv=qkv, qt=qt, kt=kt, ao=ao, lse=lse, gu=gu, logits=logits)
+        d.update(logits=logits)
         if not compute_loss:
             return
         row_loss = self._buf("row_loss", (M,), f32)

@@ -174,3 +174,25 @@ class HipOps:
     def psd_gather(self, post, seg_start, seg_len, new_lens, out, B, T, bstride, Tout, V):
         self._chk(self.lib.tasu_psd_gather(_p(post), post.stride(0), _p(seg_start), _p(seg_len), _p(new_lens), _p(out),
                                            out.stride(0), B, T, bstride, Tout, V, self._stream()), "tasu_psd_gather")
+
+    # ------------------------------------------------------------------ decode loop
+    def kv_fill(self, qkv, kc, vc, B, S, H, G, nb, ctx):
+        self._chk(self.lib.tasu_kv_fill(_p(qkv), _p(kc), _p(vc), B, S, H, G, nb, ctx, self._stream()), "tasu_kv_fill")
+
+    def kv_append(self, qkv, kc, vc, pos, M, H, G, ctx):
+        self._chk(self.lib.tasu_kv_append(_p(qkv), _p(kc), _p(vc), _p(pos), M, H, G, ctx, self._stream()), "tasu_kv_append")
+
+    def kv_gather(self, sk, sv, dk, dv, src_row, lens, M, G, ctx):
+        self._chk(self.lib.tasu_kv_gather(_p(sk), _p(sv), _p(dk), _p(dv), _p(src_row), _p(lens), M, G, ctx, self._stream()),
+                  "tasu_kv_gather")
+
+    def attn_decode(self, qkv, kc, vc, kstart, lens, out, M, H, G, ctx, scale):
+        self._chk(self.lib.tasu_attn_decode(_p(qkv), _p(kc), _p(vc), _p(kstart), _p(lens), _p(out), M, H, G, ctx, scale,
+                                            self._stream()), "tasu_attn_decode")
+
+    def logprob_topk(self, logits, M, V, k, banned, n_banned, out_val, out_idx):
+        self._chk(self.lib.tasu_logprob_topk(_p(logits), logits.stride(0), M, V, k, _p(banned), n_banned, _p(out_val),
+                                             _p(out_idx), self._stream()), "tasu_logprob_topk")
+
+    def embed_rows(self, table, ids, x, M, D):
+        self._chk(self.lib.tasu_embed_rows(_p(table), _p(ids), _p(x), M, D, self._stream()), "tasu_embed_rows")

@@ -335,3 +335,53 @@ class FakeOps:
                 s0, ln = int(seg_start.view(B, T)[b, j]), int(seg_len.view(B, T)[b, j])
                 seg = p[b, s0:s0 + ln, :V]
                 o[b, j, :V] = seg[0] if ln == 1 else seg.sum(0) / ln
+
+    # ---------------------------------------------------------------- decode loop
+    def kv_fill(self, qkv, kc, vc, B, S, H, G, nb, ctx):
+        W = G * HD
+        v = qkv.view(B, S, (H + 2 * G) * HD)
+        k4, v4 = kc.view(B, nb, ctx, W), vc.view(B, nb, ctx, W)
+        k4[:, :, :S] = v[:, None, :, H * HD:H * HD + W]
+        v4[:, :, :S] = v[:, None, :, H * HD + W:]
+
+    def kv_append(self, qkv, kc, vc, pos, M, H, G, ctx):
+        W = G * HD
+        k3, v3 = kc.view(M, ctx, W), vc.view(M, ctx, W)
+        r = torch.arange(M)
+        k3[r, pos.long()] = qkv[:M, H * HD:H * HD + W]
+        v3[r, pos.long()] = qkv[:M, H * HD + W:]
+
+    def kv_gather(self, sk, sv, dk, dv, src_row, lens, M, G, ctx):
+        W = G * HD
+        for src, dst in ((sk, dk), (sv, dv)):
+            s3, d3 = src.view(M, ctx, W), dst.view(M, ctx, W)
+            for r in range(M):
+                n = int(lens[r])
+                d3[r, :n] = s3[int(src_row[r]), :n]
+
+    def attn_decode(self, qkv, kc, vc, kstart, lens, out, M, H, G, ctx, scale):
+        W, rep = G * HD, H // G
+        q = qkv[:M, :H * HD].float().view(M, H, HD)
+        k3, v3 = kc.view(M, ctx, G, HD).float(), vc.view(M, ctx, G, HD).float()
+        o = torch.zeros(M, H, HD)
+        for r in range(M):
+            a, b = int(kstart[r]), int(lens[r])
+            for h in range(H):
+                g = h // rep
+                s = (k3[r, a:b, g] @ (q[r, h] * scale))
+                p = torch.exp(s - s.max())
+                o[r, h] = (_bf(p).float() @ v3[r, a:b, g]) / p.sum()
+        out.view(M, H, HD).copy_(_bf(o))
+
+    def logprob_topk(self, logits, M, V, k, banned, n_banned, out_val, out_idx):
+        lg = logits[:M, :V].float()
+        lp = lg - torch.logsumexp(lg, -1, keepdim=True)
+        if n_banned:
+            lp[:, banned[:n_banned].long()] = float("-inf")
+        # descending by value, ties by smaller column (torch.sort is stable on the negated, index-ordered input)
+        v, i = torch.sort(lp, dim=-1, descending=True, stable=True)
+        out_val[:M] = v[:, :k]
+        out_idx[:M] = i[:, :k].to(out_idx.dtype)
+
+    def embed_rows(self, table, ids, x, M, D):
+        x[:M] = table[ids[:M].long()]

@@ -159,3 +159,30 @@ def test_audio_step_without_merging(setup):
         short = "grad." + k[len("encoder_projector."):]
         if short in z:
             assert cosine(g, torch.from_numpy(z[short])) > 0.99, k
+
+
+def test_generate_beam4_on_gpu():
+    """Decode loop on the GPU (KV cache, cache attention, top-k kernel) vs the same host code on the CPU double and
+    the reference's generate() tokens (fp32; bf16 may flip a near-tie late, so a common prefix >= 8 is required)."""
+    from conftest import mid_audio_psd_case, split_flat
+    from ps_slm_amd.decode import beam_search_generate
+    from ps_slm_amd.ops import HipOps
+    geo, sd, batch, _ = mid_audio_psd_case()
+    z = load_npz("mid_generate_beam4")
+    word_ids = split_flat(z["post_ids_flat"], z["post_lens"])
+    ids, am = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    gm = TasuModel(geo, HipOps(), "cuda")
+    gm.load_reference_state_dict(sd)
+    cm = TasuModel(geo, FakeOps(), "cpu")
+    cm.load_reference_state_dict(sd)
+    outs = {}
+    for name, m in (("gpu", gm), ("cpu", cm)):
+        st = m.prepare_text(ids, am, None, word_ids, None, None)
+        m.forward_projector_text(st)
+        outs[name + "_text"] = beam_search_generate(m, st, max_new_tokens=16).numpy()
+        st = m.prepare_audio(ids, am, None, batch["input_features"][:2], batch["input_feature_length"][:2])
+        outs[name + "_audio"] = beam_search_generate(m, st, max_new_tokens=16).numpy()
+    for path, key in (("text", "tokens_text"), ("audio", "tokens_audio")):
+        g, c, r = outs["gpu_" + path], outs["cpu_" + path], z[key]
+        assert ((g == c).cumprod(1).sum(1) >= 8).all(), (path, g, c)
+        assert ((g == r).cumprod(1).sum(1) >= 8).all(), (path, g, r)

@@ -332,3 +332,47 @@ def test_psd_kernels(hip, fake):
     assert rel_err(og, oc) < 1e-6
     ref = torch.from_numpy(z["out"])                            # the REAL reference's PSD output
     torch.testing.assert_close(og.view(B, Tout, ld)[:, :, :V], ref, rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------ decode loop
+def test_decode_kernels(hip, fake):
+    B, S, H, G, nb, ctx = 2, 40, 4, 2, 3, 64
+    M, LD, W = B * nb, (H + 2 * G) * HD, G * HD
+    qkv_p = randn(B * S, LD, dtype=BF, seed=1)
+    kc, vc = torch.zeros(M * ctx * W, dtype=BF), torch.zeros(M * ctx * W, dtype=BF)
+    (kc1, vc1), (kg, vg) = run_pair(hip, fake, "kv_fill", [qkv_p, kc, vc, B, S, H, G, nb, ctx], [1, 2])
+    assert torch.equal(kc1, kg) and torch.equal(vc1, vg)
+    qkv = randn(M, LD, dtype=BF, seed=2)
+    pos = torch.full((M,), S, dtype=I32)
+    (kc2, vc2), (kg, vg) = run_pair(hip, fake, "kv_append", [qkv, kc1, vc1, pos, M, H, G, ctx], [1, 2])
+    assert torch.equal(kc2, kg) and torch.equal(vc2, vg)
+    kstart = torch.tensor([0, 0, 0, 5, 5, 5], dtype=I32)
+    lens = torch.full((M,), S + 1, dtype=I32)
+    (oc,), (og,) = run_pair(hip, fake, "attn_decode", [qkv, kc2, vc2, kstart, lens, torch.zeros(M, H * HD, dtype=BF), M, H, G, ctx,
+                                                       HD ** -0.5], [5])
+    assert rel_err(og, oc) < 2e-2
+    src = torch.tensor([1, 0, 0, 5, 3, 3], dtype=I32)
+    (dk, dv), (gk, gv) = run_pair(hip, fake, "kv_gather", [kc2, vc2, torch.zeros_like(kc2), torch.zeros_like(vc2), src, lens, M, G, ctx],
+                                  [2, 3])
+    assert torch.equal(dk, gk) and torch.equal(dv, gv)
+    V, ld = 1000, 1024
+    lg = torch.zeros(M, ld, dtype=BF)
+    lg[:, :V] = randn(M, V, dtype=BF, seed=3, scale=3.0)
+    banned = torch.tensor([int(lg[0, :V].float().argmax())], dtype=I32)
+    for nban in (0, 1):
+        (vc_, ic_), (vg_, ig_) = run_pair(hip, fake, "logprob_topk", [lg, M, V, 8, banned, nban, torch.zeros(M, 8), torch.zeros(M, 8, dtype=I32)],
+                                          [6, 7])
+        assert torch.equal(ic_, ig_), (ic_, ig_)
+        assert float((vc_ - vg_).abs().max()) < 1e-4
+    table = randn(50, 256, seed=4)
+    ids = torch.randint(0, 50, (M,), dtype=I32)
+    (c,), (g,) = run_pair(hip, fake, "embed_rows", [table, ids, torch.zeros(M, 256), M, 256], [2])
+    assert torch.equal(c, g)
+
+
+def test_logprob_topk_full_vocab(hip, fake):
+    M, V = 4, 151936
+    lg = randn(M, V, dtype=BF, seed=5, scale=3.0)
+    (vc_, ic_), (vg_, ig_) = run_pair(hip, fake, "logprob_topk", [lg, M, V, 8, torch.zeros(1, dtype=I32), 0, torch.zeros(M, 8),
+                                                                  torch.zeros(M, 8, dtype=I32)], [6, 7])
+    assert torch.equal(ic_, ig_) and float((vc_ - vg_).abs().max()) < 1e-4

@@ -154,3 +154,101 @@ def test_audio_psd_step_vs_reference_golden():
         short = "grad." + k[len("encoder_projector."):]
         if short in z:
             assert torch.nn.functional.cosine_similarity(g.flatten(), torch.from_numpy(z[short]).flatten(), dim=0) > 0.99, k
+
+
+# ------------------------------------------------------------------ decode: beam-4 generate
+def gen_case():
+    from conftest import load_npz, mid_audio_psd_case, split_flat
+    geo, sd, batch, _ = mid_audio_psd_case()
+    z = load_npz("mid_generate_beam4")
+    return geo, sd, batch, z, split_flat(z["post_ids_flat"], z["post_lens"])
+
+
+def test_generate_beam4_text_and_audio_vs_reference_tokens():
+    """Product decode loop (KV cache, per-row top-k + host beam bookkeeping) through the CPU double vs the token
+    ids the REAL reference's generate() produced (fp32).  bf16 arithmetic may legitimately flip a near-tie, so the
+    bf16 oracle is the exact comparator and the fp32 reference must agree on a long common prefix."""
+    from ps_slm_amd.decode import beam_search_generate
+    geo, sd, batch, z, word_ids = gen_case()
+    gd = dataclasses.asdict(geo)
+    ids, am = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    model = build(geo, sd)
+    # text path
+    st = model.prepare_text(ids, am, None, word_ids, None, None)
+    model.forward_projector_text(st)
+    toks = beam_search_generate(model, st, max_new_tokens=16).numpy()
+    post, plen = O.pseudo_posterior(word_ids, geo.ctc_vocab)
+    emb, mask, _, _ = O.merge(O.projector(sd, post, "bf16"), plen, sd["llm.model.embed_tokens.weight"][ids], ids, am, None, geo.speech_id)
+    ref16 = O.beam_search_generate(sd, emb.detach(), mask, gd, max_new_tokens=16, mode="bf16").numpy()
+    assert np.array_equal(toks, ref16), (toks, ref16)
+    common = (toks == z["tokens_text"]).cumprod(1).sum(1)
+    assert (common >= 8).all(), (toks, z["tokens_text"])
+    # audio path
+    feats, fl = batch["input_features"][:2], batch["input_feature_length"][:2]
+    st = model.prepare_audio(ids, am, None, feats, fl)
+    toks = beam_search_generate(model, st, max_new_tokens=16).numpy()
+    common = (toks == z["tokens_audio"]).cumprod(1).sum(1)
+    assert (common >= 8).all(), (toks, z["tokens_audio"])
+
+
+def test_beam_state_matches_oracle_on_random_scores():
+    """Host beam bookkeeping vs the oracle's tensor formulation on a synthetic score stream with EOS events."""
+    from ps_slm_amd.decode import BeamState
+    B, nb, V, T, eos = 3, 4, 50, 12, 7
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(64, V, generator=g) * 2.0
+    table[:, eos] += 1.5                                      # make EOS competitive so beams really finish
+
+    class FakeW(dict):
+        pass
+    # drive both implementations with logits that depend only on (step, last token)
+    def logits_for(tokens, t):
+        last = tokens[:, t - 1] if t > 0 else torch.zeros(tokens.shape[0], dtype=torch.long)
+        return table[(last * 7 + t) % 64]
+    state = BeamState(B, nb, T, eos, eos, 1.0, 1)
+    while not state.done:
+        t = state.cur
+        seqs = torch.from_numpy(state.run_seq).view(B * nb, -1)
+        lp = torch.log_softmax(logits_for(seqs, t), -1)
+        if state.ban_eos():
+            lp[:, eos] = float("-inf")
+        v, i = torch.sort(lp, dim=-1, descending=True, stable=True)
+        state.update(v[:, : 2 * nb].numpy().reshape(B, nb, -1), i[:, : 2 * nb].numpy().reshape(B, nb, -1))
+    mine = state.result()
+    # oracle formulation (full [nb*V] top-k)
+    NEG = -1.0e9
+    run_seq = torch.full((B, nb, T), eos, dtype=torch.long)
+    fin_seq, run_sc = run_seq.clone(), torch.zeros(B, nb)
+    run_sc[:, 1:] = NEG
+    fin_sc, fin_len = torch.full((B, nb), NEG), torch.zeros(B, nb, dtype=torch.long)
+    is_fin, unsat = torch.zeros(B, nb, dtype=torch.bool), torch.ones(B, 1, dtype=torch.bool)
+    cur = 0
+    while True:
+        lp = torch.log_softmax(logits_for(run_seq.view(B * nb, -1), cur), -1)
+        if cur < 1:
+            lp[:, eos] = float("-inf")
+        acc = (lp.view(B, nb, V) + run_sc[:, :, None]).view(B, nb * V)
+        top_lp, top_ix = torch.topk(acc, 2 * nb)
+        beam, tok = top_ix // V, top_ix % V
+        cand = torch.gather(run_seq, 1, beam[:, :, None].expand(-1, -1, T)).clone()
+        cand[:, :, cur] = tok
+        stop = (tok == eos) | (cur + 1 >= T)
+        run_lp = top_lp + stop.float() * NEG
+        nxt = torch.topk(run_lp, nb)[1]
+        run_seq = torch.gather(cand, 1, nxt[:, :, None].expand(-1, -1, T))
+        run_sc = torch.gather(run_lp, 1, nxt)
+        just = stop & (torch.arange(2 * nb) < nb)[None]
+        sc = top_lp / (cur + 1) + (~unsat).float() * NEG + (~just).float() * NEG
+        keep = torch.topk(torch.cat([fin_sc, sc], 1), nb)[1]
+        fin_seq = torch.gather(torch.cat([fin_seq, cand], 1), 1, keep[:, :, None].expand(-1, -1, T))
+        fin_len = torch.gather(torch.cat([fin_len, torch.full((B, 2 * nb), cur + 1)], 1), 1, keep)
+        is_fin = torch.gather(torch.cat([is_fin, just], 1), 1, keep)
+        fin_sc = torch.gather(torch.cat([fin_sc, sc], 1), 1, keep)
+        cur += 1
+        worst = torch.where(is_fin, fin_sc.min(1, keepdim=True)[0], torch.full_like(fin_sc, NEG))
+        unsat = unsat & (run_sc[:, :1] / cur > worst).any(-1, keepdim=True)
+        if not (bool(unsat.any()) and not bool(stop.all())):
+            break
+    ref = fin_seq[:, 0, : int(fin_len[:, 0].max())].numpy()
+    assert np.array_equal(mine, ref), (mine, ref)
+    assert (mine == eos).any(), "the stream must exercise the EOS / finished-beam path"

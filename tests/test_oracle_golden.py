@@ -200,3 +200,30 @@ def test_mid_audio_psd_fp32():
     assert np.array_equal(pl.numpy(), z["psd_lens"]) and int(pl.sum()) < int(lens.sum())
     out, grads = O.loss_and_projector_grads(sd, batch, gd, "fp32", audio=True)
     check_mid(out, grads, z, 1e-5)
+
+
+def test_generate_beam4_text_and_audio(geo, tiny_weights):
+    """Beam-4 token ids of the REAL reference's generate() (HF beam search) at the tiny geometry."""
+    from conftest import split_flat
+    # text path (gt_emb: clean posterior of the regex-cleaned targets)
+    z = load_npz("generate_text_beam4")
+    ids, am = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    post_ids = split_flat(z["post_ids_flat"], z["post_lens"])
+    post, plen = O.pseudo_posterior(post_ids, geo["ctc_vocab"])
+    proj = O.projector(tiny_weights, post)
+    emb, mask, _, _ = O.merge(proj, plen, tiny_weights["llm.model.embed_tokens.weight"][ids], ids, am, None, geo["speech_id"])
+    toks = O.beam_search_generate(tiny_weights, emb, mask, geo, max_new_tokens=12)
+    assert np.array_equal(toks.numpy(), z["tokens"]), (toks, z["tokens"])
+    # audio path
+    z = load_npz("generate_audio_beam4")
+    W = dict(tiny_weights)
+    W["encoder.ctc.ctc_lo.bias"] = torch.from_numpy(z["encoder.ctc.ctc_lo.bias"])
+    W["encoder.ctc.ctc_lo.weight"] = torch.from_numpy(z["encoder.ctc.ctc_lo.weight"])
+    ids, am = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    post, _, lens = O.audio_front(W, torch.from_numpy(z["input_features"]), torch.from_numpy(z["input_feature_length"]),
+                                  geo["enc_heads"], geo["enc_kernel"])
+    po, pl = O.psd(post, lens, post, 0)
+    proj = O.projector(W, po)
+    emb, mask, _, _ = O.merge(proj, pl, W["llm.model.embed_tokens.weight"][ids], ids, am, None, geo["speech_id"])
+    toks = O.beam_search_generate(W, emb, mask, geo, max_new_tokens=12)
+    assert np.array_equal(toks.numpy(), z["tokens"]), (toks, z["tokens"])
