@@ -1,0 +1,174 @@
+"""Training entrypoint with the surface of the reference's ``Multitask/finetune_deepspeed.py`` (hydra-style
+``++section.key=value`` overrides, ``--local_rank``, RANK/LOCAL_RANK/WORLD_SIZE from the launcher env, ``deepspeed_config``
+json) and the loop body of ``Multitask/utils/deepspeed_utils.py:train`` (:136-391), with the DeepSpeed engine replaced by
+``TasuEngine`` (RCCL all-reduce + fused AdamW + WarmupCosineLR).
+
+    python -m torch.distributed.run --nproc-per-node 8 -m ps_slm_amd.finetune_deepspeed \
+        ++model_config.llm_path=synthetic:qwen2.5-1.5b ++model_config.encoder_projector=linear-silu \
+        ++train_config.freeze_llm=true ++train_config.gt_emb=true ++train_config.gt_emb_noise=true \
+        ++train_config.ctc_posterior=true ++dataset_config.file=synthetic ++deepspeed_config=conf/ds_config.json
+
+The dataset plugin (``dataset_config.file = "<file>.py:<func>"``, Multitask/utils/dataset_utils.py:28-57) is honoured;
+``dataset_config.file=synthetic`` yields fixed-length synthetic batches in the collator's schema (the reference's
+jsonl/fbank loader is SURVEY section 8f "next").
+"""
+import importlib.machinery
+import importlib.util
+import logging
+import os
+import random
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+from .config import DEFAULT_DS_CONFIG, load_ds_config, parse_args
+from .engine import TasuEngine
+
+logger = logging.getLogger(__name__)
+
+
+def load_module_from_py_file(py_file):
+    """Multitask/utils/dataset_utils.py:14-25."""
+    name = Path(py_file).name
+    loader = importlib.machinery.SourceFileLoader(name, py_file)
+    spec = importlib.util.spec_from_loader(name, loader)
+    module = importlib.util.module_from_spec(spec)
+    loader.exec_module(module)
+    return module
+
+
+def get_custom_model_factory(model_config):
+    """Multitask/utils/model_utils.py:9-33 (same ValueError / FileNotFoundError / AttributeError behaviour)."""
+    path = model_config.get("file", None)
+    if path is None:
+        raise ValueError("must set correct model path")
+    module_path, func_name = path.split(":") if ":" in path else (path, "model_factory")
+    if not module_path.endswith(".py"):
+        raise ValueError(f"Dataset file {module_path} is not a .py file.")
+    p = Path(module_path)
+    if not p.is_file():
+        alt = Path(__file__).resolve().parent.parent / module_path          # relative to the repository root
+        if not alt.is_file():
+            raise FileNotFoundError(f"Dataset py file {p.as_posix()} does not exist or is not a file.")
+        p = alt
+    if p.resolve() == (Path(__file__).resolve().parent / "ps_slm.py"):
+        from . import ps_slm as module                                      # keep package-relative imports working
+    else:
+        module = load_module_from_py_file(p.as_posix())
+    try:
+        return getattr(module, func_name)
+    except AttributeError:
+        logger.info("It seems like the given method name (%s) is not present in the model .py file (%s).", func_name, p)
+        raise
+
+
+class SyntheticDataset:
+    """Pre-batched iterable with a ``collator`` (the contract of MultiTaskDynamicBatchDataset,
+    Multitask/dataset/speech_dataset_large.py:307-330) that yields the SURVEY 8d synthetic utterances."""
+
+    def __init__(self, geo, batch_size, steps, rank, inference=False):
+        self.geo, self.B, self.steps, self.rank, self.inference = geo, batch_size, steps, rank, inference
+
+    def __len__(self):
+        return self.steps * self.B
+
+    def __iter__(self):
+        from .synthetic import synthetic_text_batch
+        for i in range(self.steps):
+            yield synthetic_text_batch(self.geo, self.B, seed=1234 + self.rank + 7919 * i, noise=False)
+
+    def collator(self, raw):
+        b = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], input_features=raw["input_features"],
+                 input_feature_length=raw["input_feature_length"], GT=[" ".join(map(str, p)) for p in raw["post_ids"]])
+        if self.inference:
+            b["keys"] = [f"utt{i}" for i in range(len(b["GT"]))]
+            b["targets"] = b["GT"]
+            n = 25
+            b["input_ids"], b["attention_mask"] = b["input_ids"][:, :n], b["attention_mask"][:, :n]
+        else:
+            b["labels"] = raw["labels"]
+        return b
+
+
+def get_dataset(dataset_config, tokenizer, split, geo, rank, steps=20, batch_size=16):
+    f = dataset_config.get("file", "synthetic")
+    if f == "synthetic" or f is None:
+        return SyntheticDataset(geo, batch_size, steps, rank, inference=(split == "test"))
+    module_path, func_name = f.split(":") if ":" in f else (f, "get_custom_dataset")
+    if not module_path.endswith(".py"):
+        raise ValueError(f"Dataset file {module_path} is not a .py file.")
+    if not Path(module_path).is_file():
+        raise FileNotFoundError(f"Dataset py file {module_path} does not exist or is not a file.")
+    return getattr(load_module_from_py_file(module_path), func_name)(dataset_config, tokenizer, split)
+
+
+def train(engine, dataset, train_config, log_config, rank, world):
+    """Loop body of Multitask/utils/deepspeed_utils.py:190-246 (uneven-data join, forward, backward, step, logging)."""
+    results = {}
+    total_loss, total_acc, steps, utts = 0.0, 0.0, 0, 0
+    t0 = time.perf_counter()
+    for epoch in range(train_config.num_epochs):
+        engine.train()
+        it = iter(dataset)
+        while True:
+            raw = next(it, None)
+            if not engine.all_have_data(raw is not None):      # replaces deepspeed_join's gloo monitored_barrier
+                break
+            batch = dataset.collator(raw)
+            outputs, acc = engine(**batch)
+            loss = outputs.loss
+            engine.backward(loss)
+            engine.step()
+            steps += 1
+            utts += batch["input_ids"].shape[0]
+            if steps % max(1, log_config.log_interval) == 0:
+                l, a = float(loss), float(acc)                 # the only host sync of the loop, every log_interval steps
+                total_loss, total_acc = total_loss + l, total_acc + a
+                if rank == 0:
+                    logger.info("epoch %d step %d loss %.4f acc %.4f lr %.3e  %.1f utt/s", epoch + 1, steps, l, a,
+                                engine.get_lr()[0], world * utts / (time.perf_counter() - t0))
+    n_logged = max(1, steps // max(1, log_config.log_interval))
+    sl, sa = engine.reduce_scalars(total_loss / n_logged, total_acc / n_logged)
+    results["avg_train_loss"], results["avg_train_acc"] = sl / world, sa / world
+    results["steps"], results["utterances_per_s"] = steps, world * utts / max(time.perf_counter() - t0, 1e-9)
+    return results
+
+
+def main(argv=None):
+    cfg = parse_args(sys.argv[1:] if argv is None else argv)
+    train_config, model_config, log_config, dataset_config = cfg.train_config, cfg.model_config, cfg.log_config, cfg.dataset_config
+    logging.basicConfig(level=logging.INFO, format="[%(asctime)s][%(name)s][%(levelname)s] - %(message)s")
+    torch.manual_seed(train_config.seed)
+    random.seed(train_config.seed)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    model_factory = get_custom_model_factory(model_config)
+    model, tokenizer = model_factory(train_config, model_config, ckpt_path=cfg.ckpt_path, metric=cfg.metric,
+                                     device=f"cuda:{local_rank}", keep_logits=False)
+    ds_cfg = load_ds_config(cfg.deepspeed_config) if cfg.deepspeed_config else load_ds_config(DEFAULT_DS_CONFIG)
+    engine = TasuEngine(model, ds_cfg)
+    dataset = get_dataset(dataset_config, tokenizer, "train", model.core.geo, rank,
+                          steps=int(cfg.get("synthetic_steps", 20)), batch_size=int(cfg.get("synthetic_batch", 16)))
+    results = train(engine, dataset, train_config, log_config, rank, world)
+    if rank == 0:
+        for k, v in results.items():
+            logger.info("Key: %s, Value: %s", k, v)
+        if train_config.save_model and train_config.output_dir and not train_config.output_dir.startswith("PATH/"):
+            os.makedirs(train_config.output_dir, exist_ok=True)
+    if train_config.save_model and train_config.output_dir and not train_config.output_dir.startswith("PATH/"):
+        engine.save_checkpoint(os.path.join(train_config.output_dir, "pytorch_model.bin"))
+    if world > 1:
+        dist.destroy_process_group()
+    return results
+
+
+if __name__ == "__main__":
+    main()

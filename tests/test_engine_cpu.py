@@ -170,3 +170,43 @@ def test_data_parallel_two_ranks_gloo():
     eng._last_state = None
     eng.step()
     torch.testing.assert_close(model.core.proj.p, r0["param"], rtol=1e-6, atol=1e-7)
+
+
+def test_plugin_loader_errors_match_reference():
+    from ps_slm_amd.finetune_deepspeed import get_custom_model_factory
+    with pytest.raises(ValueError):
+        get_custom_model_factory(ModelConfig(file="model/ps-slm.txt:model_factory"))
+    with pytest.raises(FileNotFoundError):
+        get_custom_model_factory(ModelConfig(file="nope/ps_slm.py:model_factory"))
+    with pytest.raises(AttributeError):
+        get_custom_model_factory(ModelConfig(file="ps_slm_amd/ps_slm.py:not_there"))
+    assert get_custom_model_factory(ModelConfig(file="ps_slm_amd/ps_slm.py:model_factory")) is model_factory
+
+
+def test_train_loop_and_checkpoint_roundtrip(tmp_path):
+    """The entrypoint's loop body over the synthetic dataset (FakeOps double), then projector-only checkpoint
+    save -> load into a fresh model through model_factory(ckpt_path=...)."""
+    from ps_slm_amd.config import LogConfig
+    from ps_slm_amd.finetune_deepspeed import SyntheticDataset, train
+    model, tok, eng = make(lr=1e-3)
+    eng.sched_iter = 10
+    core = model.core
+    ds = SyntheticDataset(core.geo, 2, 3, 0)
+    import ps_slm_amd.synthetic as syn
+    real = syn.synthetic_text_batch
+    syn.synthetic_text_batch = lambda geo, B, seed, noise=False: real(geo, B, seed=seed, prompt_len=9, n_audio=21, target_len=17,
+                                                                       speech_pos=4, feat_frames=8, noise=noise)
+    try:
+        res = train(eng, ds, TrainConfig(num_epochs=1), LogConfig(log_interval=1), 0, 1)
+    finally:
+        syn.synthetic_text_batch = real
+    assert res["steps"] == 3 and res["avg_train_loss"] > 0
+    path = str(tmp_path / "pytorch_model.bin")
+    eng.save_checkpoint(path)
+    sd = torch.load(path)
+    assert sorted(sd) == sorted(model.state_dict()) and sd["encoder_projector.ffn.0.weight"].shape == (128, 203)
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, ctc_posterior=True, do_psd=True)
+    mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+    m2, _ = model_factory(tc, mc, device="cpu", ops=FakeOps(), init_seed=999, ckpt_path=path)
+    for k, v in m2.state_dict().items():
+        torch.testing.assert_close(v, sd[k])
