@@ -12,15 +12,14 @@
 // c ^ ((r>>1)&7): conflict-free for the 16x16x32 operand read).  The MFMA is issued with the weight fragment
 // as the A operand so that every lane ends up with 4 CONSECUTIVE output columns of one row (8-/16-byte
 // stores).  blockIdx is remapped so that each XCD (private L2) works on a contiguous band of tiles.
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/tasu_hip.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int A_BYTES = BM * BK * 2;  // 16 KiB
-constexpr int B_BYTES = BN * BK * 2;  // 16 KiB
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+constexpr int BK = 64;
 
 struct GemmArgs {
   const bf16* A;
@@ -36,8 +35,14 @@ struct GemmArgs {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int OUT_MODE, bool HAS_BIAS>
+// BM x BN block tile (BM, BN multiples of 32), 2x2 waves, wave tile (BM/2) x (BN/2) = MI x NI MFMA tiles.
+// BN = 96 exists for N = 1536 at M = 4096: 32 x 16 = 512 tiles = exactly two per CU (128x128 would give 384 tiles and
+// leave half of the CUs with one block).
+template <int BM, int BN, int OUT_MODE, bool HAS_BIAS, int SCHED>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+  constexpr int PA = BM / 32, PB = BN / 32;   // 1-KiB pieces (8 rows x 128 B) staged per wave and K-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -62,32 +67,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   // ---- per-lane global source pointers for the pieces this wave stages (4 of A, 4 of B per K-step).
   // piece pc = 8 tile rows x 128 B; lane l -> tile row pc*8 + (l>>3), LDS chunk l&7, which must hold
   // global chunk (l&7) ^ ((row>>1)&7).
-  const bf16* ga[4];
-  const bf16* gb[4];
+  const bf16* ga[PA];
+  const bf16* gb[PB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pc = wave * 4 + i;
-    const int r = pc * 8 + (lane >> 3);
+  for (int i = 0; i < PA; ++i) {
+    const int r = (wave * PA + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    const int ra = min(row0 + r, p.M - 1);
-    const int rb = min(col0 + r, p.N - 1);
-    ga[i] = p.A + (size_t)ra * p.lda + c * 8;
-    gb[i] = p.B + (size_t)rb * p.ldb + c * 8;
+    ga[i] = p.A + (size_t)min(row0 + r, p.M - 1) * p.lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int r = (wave * PB + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    gb[i] = p.B + (size_t)min(col0 + r, p.N - 1) * p.ldb + c * 8;
   }
 
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE_BYTES;
     const int koff = kt * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pc = wave * 4 + i;
-      __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(base + pc * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(base + (wave * PA + i) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pc = wave * 4 + i;
-      __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(base + A_BYTES + pc * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < PB; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(base + A_BYTES + (wave * PB + i) * 1024), 16, 0,
+                                       0);
   };
 
   // ---- per-lane LDS read offsets (bytes) for the two 32-deep k sub-steps.
@@ -96,11 +100,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) roff[kk] = (lane & 15) * 128 + (((kk * 4 + (lane >> 4)) ^ sw) << 4);
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
   stage(0, 0);
@@ -108,32 +112,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* sa = smem + cur * STAGE_BYTES + (wr * 64) * 128;
-    const char* sb = smem + cur * STAGE_BYTES + A_BYTES + (wc * 64) * 128;
+    const char* sa = smem + cur * STAGE_BYTES + (wr * WM) * 128;
+    const char* sb = smem + cur * STAGE_BYTES + A_BYTES + (wc * WN) * 128;
+    // all fragment reads of the K-step are issued up front (both 32-deep sub-steps): the second half lands under
+    // the first half's MFMAs instead of stalling the wave between the two halves.
+    bf16x8 fa[2][MI], fb[2][NI];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(sa + i * 16 * 128 + roff[kk]);
+      for (int i = 0; i < MI; ++i) fa[kk][i] = *(const bf16x8*)(sa + i * 16 * 128 + roff[kk]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(sb + j * 16 * 128 + roff[kk]);
+      for (int j = 0; j < NI; ++j) fb[kk][j] = *(const bf16x8*)(sb + j * 16 * 128 + roff[kk]);
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(fb[kk][j], fa[kk][i], acc[i][j]);
+    if (SCHED == 1) {
+      // pin the issue order (hipcc otherwise re-serialises reads -> wait -> MFMAs per half): first half's reads, then
+      // the second half's reads interleaved one per two MFMAs of the first half, then the remaining MFMAs.
+      __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+#pragma unroll
+      for (int r = 0; r < MI + NI; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * MI * NI - 2 * (MI + NI), 0);
     }
     __syncthreads();
   }
 
-  // ---- epilogue.  acc[i][j][r] = C[m][n], m = row0 + wr*64 + i*16 + (lane&15),
-  //                                        n = col0 + wc*64 + j*16 + (lane>>4)*4 + r.
+  // ---- epilogue.  acc[i][j][r] = C[m][n], m = row0 + wr*WM + i*16 + (lane&15),
+  //                                        n = col0 + wc*WN + j*16 + (lane>>4)*4 + r.
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = row0 + wr * 64 + i * 16 + (lane & 15);
+  for (int i = 0; i < MI; ++i) {
+    const int m = row0 + wr * WM + i * 16 + (lane & 15);
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = col0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+    for (int j = 0; j < NI; ++j) {
+      const int n = col0 + wc * WN + j * 16 + (lane >> 4) * 4;
       if (n >= p.N) continue;
       f32x4 v = acc[i][j];
       if (HAS_BIAS) {
@@ -179,17 +198,52 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
-template <int OUT_MODE, bool HAS_BIAS>
-int launch(const GemmArgs& a, hipStream_t st) {
+template <int BM, int BN, int OUT_MODE, bool HAS_BIAS, int SCHED>
+int launch(GemmArgs a, hipStream_t st) {
+  constexpr int LDS = 2 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<OUT_MODE, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, OUT_MODE, HAS_BIAS, SCHED>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  const int nwg = a.tiles_m * a.tiles_n;
-  TASU_LAUNCH((gemm_nt_kernel<OUT_MODE, HAS_BIAS>), dim3(nwg), dim3(256), 2 * STAGE_BYTES, st, a);
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  TASU_LAUNCH((gemm_nt_kernel<BM, BN, OUT_MODE, HAS_BIAS, SCHED>), dim3(a.tiles_m * a.tiles_n), dim3(256), LDS, st, a);
   return TASU_OK;
+}
+
+int sched_variant() {
+  static const int v = [] {
+    const char* e = getenv("TASU_GEMM_SCHED");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+template <int OUT_MODE, bool HAS_BIAS>
+int launch_tiled(const GemmArgs& a, int bn, hipStream_t st) {
+  if (sched_variant() == 1)
+    return bn == 96 ? launch<128, 96, OUT_MODE, HAS_BIAS, 1>(a, st) : launch<128, 128, OUT_MODE, HAS_BIAS, 1>(a, st);
+  return bn == 96 ? launch<128, 96, OUT_MODE, HAS_BIAS, 0>(a, st) : launch<128, 128, OUT_MODE, HAS_BIAS, 0>(a, st);
+}
+
+// Tile choice: both configurations run 2 blocks per CU (512 slots on 256 CUs).  When the grid is at most two waves of
+// blocks, the tail efficiency tiles / (waves * 512) decides (N = 1536 at M = 4096: 384 tiles of 128x128 fill 75 % of
+// the slots, 512 tiles of 128x96 fill all of them: measured +11...+17 %); larger grids keep the wider tile, whose MFMA
+// per LDS read ratio is better (measured: N = 8960 loses 10 % with the narrow tile).
+int pick_bn(int M, int N) {
+  static const int forced = [] {
+    const char* e = getenv("TASU_GEMM_BN");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 96 || forced == 128) return forced;
+  const long slots = 512;
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t96 = (long)((M + 127) / 128) * ((N + 95) / 96);
+  const long w128 = (t128 + slots - 1) / slots, w96 = (t96 + slots - 1) / slots;
+  if (w128 > 2) return 128;
+  const double e128 = (double)t128 / (double)(w128 * slots), e96 = (double)t96 / (double)(w96 * slots) / 1.08;
+  return e96 > e128 ? 96 : 128;
 }
 
 }  // namespace
@@ -212,17 +266,18 @@ extern "C" int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
   a.lda = lda;
   a.ldb = ldb;
   a.ldc = ldc;
-  a.tiles_m = (M + BM - 1) / BM;
-  a.tiles_n = (N + BN - 1) / BN;
+  a.tiles_m = a.tiles_n = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool hb = bias != nullptr;
+  const int bn = pick_bn(M, N);
   switch (out_mode) {
     case TASU_GEMM_OUT_BF16:
-      return hb ? launch<TASU_GEMM_OUT_BF16, true>(a, st) : launch<TASU_GEMM_OUT_BF16, false>(a, st);
+      return hb ? launch_tiled<TASU_GEMM_OUT_BF16, true>(a, bn, st) : launch_tiled<TASU_GEMM_OUT_BF16, false>(a, bn, st);
     case TASU_GEMM_OUT_F32:
-      return hb ? launch<TASU_GEMM_OUT_F32, true>(a, st) : launch<TASU_GEMM_OUT_F32, false>(a, st);
+      return hb ? launch_tiled<TASU_GEMM_OUT_F32, true>(a, bn, st) : launch_tiled<TASU_GEMM_OUT_F32, false>(a, bn, st);
     case TASU_GEMM_OUT_F32_RESID_BF16R:
-      return hb ? launch<TASU_GEMM_OUT_F32_RESID_BF16R, true>(a, st) : launch<TASU_GEMM_OUT_F32_RESID_BF16R, false>(a, st);
+      return hb ? launch_tiled<TASU_GEMM_OUT_F32_RESID_BF16R, true>(a, bn, st)
+                : launch_tiled<TASU_GEMM_OUT_F32_RESID_BF16R, false>(a, bn, st);
     default:
       return TASU_ERR_ARG;
   }
