@@ -246,7 +246,20 @@ int pick_bn(int M, int N) {
   return e96 > e128 ? 96 : 128;
 }
 
+// 0 = heuristic, 1 = always the 128-wide 2-blocks-per-CU kernel of this file, 2 = always gemm_pipe.hip
+int kernel_choice() {
+  static const int v = [] {
+    const char* e = getenv("TASU_GEMM_KERNEL");
+    if (!e) return 0;
+    return e[0] == 'p' ? 2 : (e[0] == 'v' ? 1 : 0);
+  }();
+  return v;
+}
+
 }  // namespace
+
+int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                            const float* resid, int M, int N, int K, int out_mode, int bn, hipStream_t st);
 
 extern "C" int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                                  const float* resid, int M, int N, int K, int out_mode, void* stream) {
@@ -269,6 +282,21 @@ extern "C" int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
   a.tiles_m = a.tiles_n = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool hb = bias != nullptr;
+  if (kernel_choice() == 2) {
+    static const int pbn = [] {
+      const char* e = getenv("TASU_GEMM_BN");
+      return e ? atoi(e) : 0;
+    }();
+    int bn = pbn;
+    if (bn != 96 && bn != 128) {
+      // one block per CU: prefer the width whose tile count fills whole rounds of 256 blocks
+      const long t128 = (long)((M + 255) / 256) * ((N + 127) / 128), t96 = (long)((M + 255) / 256) * ((N + 95) / 96);
+      const long w128 = (t128 + 255) / 256, w96 = (t96 + 255) / 256;
+      const double e128 = (double)t128 / (double)(w128 * 256), e96 = (double)t96 / (double)(w96 * 256) / 1.06;
+      bn = (w128 <= 3 && e96 > e128) ? 96 : 128;
+    }
+    return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, bn, st);
+  }
   const int bn = pick_bn(M, N);
   switch (out_mode) {
     case TASU_GEMM_OUT_BF16:
