@@ -38,16 +38,22 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // BM x BN block tile (BM, BN multiples of 32), 2x2 waves, wave tile (BM/2) x (BN/2) = MI x NI MFMA tiles.
 // BN = 96 exists for N = 1536 at M = 4096: 32 x 16 = 512 tiles = exactly two per CU (128x128 would give 384 tiles and
 // leave half of the CUs with one block).
-template <int BM, int BN, int OUT_MODE, bool HAS_BIAS, int SCHED>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+// 256 x 256 / 8 waves (2 x 4, wave tile 128 x 64, one block per CU) halves the L2 -> LDS bytes per FLOP of the 128-wide
+// tiles ((BM+BN)/(BM*BN): 1/128 vs 1/64); the 128-wide tiles run at roughly the chip's L2 bandwidth (2 x 32 KB per
+// K-step per CU), which is what caps them near 1 PFLOP/s.
+template <int BM, int BN, int NWM, int NWN, int OUT_MODE, bool HAS_BIAS, int SCHED>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(GemmArgs p) {
+  constexpr int NW = NWM * NWN, NT = 64 * NW;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
-  constexpr int PA = BM / 32, PB = BN / 32;   // 1-KiB pieces (8 rows x 128 B) staged per wave and K-step
+  constexpr int WM = BM / NWM, WN = BN / NWN, MI = WM / 16, NI = WN / 16;
+  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;   // 1-KiB pieces (8 rows x 128 B) staged per wave and K-step
+  static_assert(PA * NW * 8 == BM && PB * NW * 8 == BN, "tile rows must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / NWN, wc = wave % NWN;
+  (void)NT;
 
   // ---- XCD-aware, bijective block -> tile map, then an 8-row-group raster for L2 reuse of the B panel.
   const int nwg = gridDim.x;
@@ -198,18 +204,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int OUT_MODE, bool HAS_BIAS, int SCHED>
+template <int BM, int BN, int NWM, int NWN, int OUT_MODE, bool HAS_BIAS, int SCHED>
 int launch(GemmArgs a, hipStream_t st) {
   constexpr int LDS = 2 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, OUT_MODE, HAS_BIAS, SCHED>,
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, NWM, NWN, OUT_MODE, HAS_BIAS, SCHED>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  TASU_LAUNCH((gemm_nt_kernel<BM, BN, OUT_MODE, HAS_BIAS, SCHED>), dim3(a.tiles_m * a.tiles_n), dim3(256), LDS, st, a);
+  TASU_LAUNCH((gemm_nt_kernel<BM, BN, NWM, NWN, OUT_MODE, HAS_BIAS, SCHED>), dim3(a.tiles_m * a.tiles_n),
+              dim3(64 * NWM * NWN), LDS, st, a);
   return TASU_OK;
 }
 
@@ -223,9 +230,10 @@ int sched_variant() {
 
 template <int OUT_MODE, bool HAS_BIAS>
 int launch_tiled(const GemmArgs& a, int bn, hipStream_t st) {
+  if (bn == 256) return launch<256, 256, 2, 4, OUT_MODE, HAS_BIAS, 1>(a, st);
   if (sched_variant() == 1)
-    return bn == 96 ? launch<128, 96, OUT_MODE, HAS_BIAS, 1>(a, st) : launch<128, 128, OUT_MODE, HAS_BIAS, 1>(a, st);
-  return bn == 96 ? launch<128, 96, OUT_MODE, HAS_BIAS, 0>(a, st) : launch<128, 128, OUT_MODE, HAS_BIAS, 0>(a, st);
+    return bn == 96 ? launch<128, 96, 2, 2, OUT_MODE, HAS_BIAS, 1>(a, st) : launch<128, 128, 2, 2, OUT_MODE, HAS_BIAS, 1>(a, st);
+  return bn == 96 ? launch<128, 96, 2, 2, OUT_MODE, HAS_BIAS, 0>(a, st) : launch<128, 128, 2, 2, OUT_MODE, HAS_BIAS, 0>(a, st);
 }
 
 // Tile choice: both configurations run 2 blocks per CU (512 slots on 256 CUs).  When the grid is at most two waves of
@@ -237,7 +245,12 @@ int pick_bn(int M, int N) {
     const char* e = getenv("TASU_GEMM_BN");
     return e ? atoi(e) : 0;
   }();
-  if (forced == 96 || forced == 128) return forced;
+  if (forced == 96 || forced == 128 || forced == 256) return forced;
+  // 256 x 256 (one block per CU): worth it when the grid is many rounds of 256 blocks, or (almost) exactly one round
+  // (measured on MI355X, M = 4096 / 8192: gate_up +15 %, lm_head +8 %, M = 8192 x N = 1536..2048 +10...18 %;
+  //  560- and 784-tile grids lose 2...3 % against the 128-wide tiles and stay there).
+  const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  if (t256 >= 1024 || (t256 >= 192 && t256 <= 256)) return 256;
   const long slots = 512;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t96 = (long)((M + 127) / 128) * ((N + 95) / 96);
   const long w128 = (t128 + slots - 1) / slots, w96 = (t96 + slots - 1) / slots;
