@@ -40,6 +40,13 @@ int tasu_abi_version(void);
 int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                       const float* resid, int M, int N, int K, int out_mode, void* stream);
 
+/* Weight-streaming variant for M <= 64 rows (the decode step, M = batch x beams): HBM-bound, split-K over the grid
+ * with a deterministic fp32 slab reduction.  workspace: >= ksplit*64*round_up(N,64) floats (16 x 64 x round_up(N,64)
+ * always suffices); may be NULL (no K split).  Same operand rules and out_mode as tasu_gemm_nt_bf16.             */
+int tasu_gemm_skinny_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                          const float* resid, int M, int N, int K, int out_mode, float* workspace,
+                          int64_t workspace_floats, void* stream);
+
 /* Tiled transpose out[c][r] = in[r][c], bf16 (used to feed wgrad through the NT GEMM). rows<=R and
  * cols<=C outside [R,C) of `out` up to (Cpad, Rpad) are written as zero so K-padding stays exact.       */
 int tasu_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, int R, int C, int Rpad, int Cpad,

@@ -53,14 +53,16 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(const bf16* __restrict__
   }
 }
 
-// Single-token attention.  Block = (row, kv group); wave w = query head g*rep + w.  Phase 1: lane-per-key scores
-// (q in registers, K rows via 16-byte loads), scores staged in LDS; phase 2: lane-per-dim-pair P.V (coalesced V rows).
+// Single-token attention.  Block = (row, kv group); wave w = query head g*rep + w.
+// Phase 1 (scores): 16 lanes cooperate on one key (each lane 8 dims = one 16-byte load, so a wave instruction reads 4
+// whole 256-B K rows, fully coalesced), partial dots are reduced with 4 xor-shuffles; scores are staged in LDS.
+// Phase 2 (P.V): lane owns dims 2*lane, 2*lane+1, keys unrolled by 8 for loads in flight (coalesced 256-B V rows).
 // keys in [kstart[row], lens[row]) are visible.  ctx <= MAX_CTX.
 constexpr int MAX_CTX = 2048;
 __global__ void attn_decode_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ kc, const bf16* __restrict__ vc,
                                    const int32_t* __restrict__ kstart, const int32_t* __restrict__ lens, bf16* __restrict__ out,
                                    int H, int G, int ctx, float scale) {
-  extern __shared__ float sp[];                 // [rep][n_keys_padded]
+  extern __shared__ float sp[];                 // [rep][ctx]
   const int row = blockIdx.x, g = blockIdx.y;
   const int rep = H / G, W = G * HD, LD = (H + 2 * G) * HD;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -68,44 +70,59 @@ __global__ void attn_decode_kernel(const bf16* __restrict__ qkv, const bf16* __r
   const int k0 = kstart[row], k1 = lens[row];
   const int nk = k1 - k0;
   float* myp = sp + (size_t)wave * ctx;
-  // q row -> registers (fp32, pre-scaled)
-  float q[HD];
+  const int sub = lane & 15, kq = lane >> 4;    // 16 lanes per key, 4 keys per wave instruction
+  float q[8];
   {
-    const bf16* qr = qkv + (size_t)row * LD + h * HD;
+    const bf16x8 v = *(const bf16x8*)(qkv + (size_t)row * LD + h * HD + sub * 8);
 #pragma unroll
-    for (int c = 0; c < HD / 8; ++c) {
-      const bf16x8 v = *(const bf16x8*)(qr + c * 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) q[c * 8 + j] = (float)v[j] * scale;
-    }
+    for (int j = 0; j < 8; ++j) q[j] = (float)v[j] * scale;
   }
+  const bf16* kbase = kc + ((size_t)row * ctx + k0) * W + g * HD + sub * 8;
   float m = -__builtin_inff();
-  for (int i = lane; i < nk; i += 64) {
-    const bf16* kr = kc + ((size_t)row * ctx + k0 + i) * W + g * HD;
+  for (int i0 = 0; i0 < nk; i0 += 4) {
+    const int i = i0 + kq;
     float s = 0.f;
+    if (i < nk) {
+      const bf16x8 v = *(const bf16x8*)(kbase + (size_t)i * W);
 #pragma unroll
-    for (int c = 0; c < HD / 8; ++c) {
-      const bf16x8 v = *(const bf16x8*)(kr + c * 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += q[c * 8 + j] * (float)v[j];
+      for (int j = 0; j < 8; ++j) s += q[j] * (float)v[j];
     }
-    myp[i] = s;
-    m = fmaxf(m, s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    if (i < nk) {
+      if (sub == 0) myp[i] = s;
+      m = fmaxf(m, s);
+    }
   }
   m = wave_max(m);
+  __builtin_amdgcn_wave_barrier();
   float l = 0.f;
   for (int i = lane; i < nk; i += 64) {
     const float p = __expf(myp[i] - m);
-    myp[i] = p;
+    myp[i] = (float)(bf16)p;                    // bf16-rounded probabilities feed P.V, like the prefill kernel
     l += p;
   }
   l = wave_sum(l);
   __builtin_amdgcn_wave_barrier();              // a wave's LDS accesses are processed in order: its own writes are visible
-  // P.V: lane owns dims 2*lane, 2*lane+1
+  const bf16* vbase = vc + ((size_t)row * ctx + k0) * W + g * HD + 2 * lane;
   float o0 = 0.f, o1 = 0.f;
-  for (int i = 0; i < nk; ++i) {
-    const float p = (float)(bf16)myp[i];        // bf16-rounded probabilities, like the prefill kernel
-    const bf16x2 v = *(const bf16x2*)(vc + ((size_t)row * ctx + k0 + i) * W + g * HD + 2 * lane);
+  int i = 0;
+  for (; i + 8 <= nk; i += 8) {
+    bf16x2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const bf16x2*)(vbase + (size_t)(i + u) * W);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float p = myp[i + u];
+      o0 += p * (float)v[u][0];
+      o1 += p * (float)v[u][1];
+    }
+  }
+  for (; i < nk; ++i) {
+    const float p = myp[i];
+    const bf16x2 v = *(const bf16x2*)(vbase + (size_t)i * W);
     o0 += p * (float)v[0];
     o1 += p * (float)v[1];
   }
@@ -137,28 +154,42 @@ __global__ __launch_bounds__(256) void logprob_topk_kernel(const bf16* __restric
     tv[j] = -__builtin_inff();
     ti[j] = 0x7fffffff;
   }
+  // 16-byte loads (ld % 8 == 0, checked by the host entry); columns >= V are skipped
+  const int nv = (V + 7) / 8;
   float m = -__builtin_inff();
-  for (int c = threadIdx.x; c < V; c += 256) m = fmaxf(m, (float)lr[c]);
+  for (int cv8 = threadIdx.x; cv8 < nv; cv8 += 256) {
+    const bf16x8 x = *(const bf16x8*)(lr + cv8 * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (cv8 * 8 + j < V) m = fmaxf(m, (float)x[j]);
+  }
   m = block_max<4>(m, red);
   float s = 0.f;
-  for (int c = threadIdx.x; c < V; c += 256) {
-    const float f = (float)lr[c];
-    s += __expf(f - m);
-    bool ban = false;
-    for (int b = 0; b < n_banned; ++b) ban |= (banned[b] == c);
-    // thread-local sorted list (descending; on ties the smaller column, seen first, stays ahead)
-    if (!ban && f > tv[K - 1]) {
-      tv[K - 1] = f;
-      ti[K - 1] = c;
+  for (int cv8 = threadIdx.x; cv8 < nv; cv8 += 256) {
+    const bf16x8 x = *(const bf16x8*)(lr + cv8 * 8);
 #pragma unroll
-      for (int j = K - 1; j > 0; --j) {
-        if (tv[j] > tv[j - 1]) {
-          const float a = tv[j];
-          tv[j] = tv[j - 1];
-          tv[j - 1] = a;
-          const int b2 = ti[j];
-          ti[j] = ti[j - 1];
-          ti[j - 1] = b2;
+    for (int j = 0; j < 8; ++j) {
+      const int c = cv8 * 8 + j;
+      if (c >= V) continue;
+      const float f = (float)x[j];
+      s += __expf(f - m);
+      // thread-local sorted list (descending; on ties the smaller column, seen first, stays ahead)
+      if (f > tv[K - 1]) {
+        bool ban = false;
+        for (int b = 0; b < n_banned; ++b) ban |= (banned[b] == c);
+        if (ban) continue;
+        tv[K - 1] = f;
+        ti[K - 1] = c;
+#pragma unroll
+        for (int jj = K - 1; jj > 0; --jj) {
+          if (tv[jj] > tv[jj - 1]) {
+            const float a = tv[jj];
+            tv[jj] = tv[jj - 1];
+            tv[jj - 1] = a;
+            const int b2 = ti[jj];
+            ti[jj] = ti[jj - 1];
+            ti[jj - 1] = b2;
+          }
         }
       }
     }
@@ -256,7 +287,7 @@ extern "C" int tasu_attn_decode(const void* qkv, const void* kcache, const void*
 }
 extern "C" int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned,
                                  float* out_val, int32_t* out_idx, void* stream) {
-  if (!logits || !out_val || !out_idx || M <= 0 || V <= 0 || ld < V || k <= 0 || k > TOPK_MAX || n_banned < 0 ||
+  if (!logits || !out_val || !out_idx || M <= 0 || V <= 0 || ld < V || ld % 8 || k <= 0 || k > TOPK_MAX || n_banned < 0 ||
       (n_banned > 0 && !banned))
     return TASU_ERR_ARG;
 #define TOPK_CASE(KK)                                                                                                \

@@ -136,6 +136,14 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     cos = buf("dec_cos", (M, HD // 2), f32)
     sin = buf("dec_sin", (M, HD // 2), f32)
     cur_buf = 0
+    ws = buf("dec_gemm_ws", (16 * 64 * rup(max(V, 2 * I), 64),), f32)
+
+    def gemm(a, b, c, m, n, k, **kw):
+        if m <= 64:
+            ops.gemm_skinny(a, b, c, m, n, k, ws, **kw)
+        else:
+            ops.gemm(a, b, c, m, n, k, **kw)
+
     while not state.done:
         t = state.cur                                                       # tokens generated so far (>= 1)
         ids = model._upload("dec_ids", tok.reshape(-1).astype(np.int32))
@@ -146,17 +154,17 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
         ops.rope_table(pos, cos, sin, HD, geo.rope_theta)
         for l, w in enumerate(llm.layers):
             ops.rmsnorm_fwd(x, w["ln1"], xn, None, geo.rms_eps)
-            ops.gemm(xn, w["wqkv"], qkv, M, LDQ, D, bias=w["bqkv"])
+            gemm(xn, w["wqkv"], qkv, M, LDQ, D, bias=w["bqkv"])
             ops.rope_fwd(qkv, cos, sin, None, None, None, M, 1, H, G)
             ops.kv_append(qkv, kc[cur_buf, l], vc[cur_buf, l], slot, M, H, G, ctx)
             ops.attn_decode(qkv, kc[cur_buf, l], vc[cur_buf, l], kstart, lens, ao, M, H, G, ctx, scale)
-            ops.gemm(ao, w["wo"], x2, M, D, H * HD, resid=x, mode=GEMM_RESID)
+            gemm(ao, w["wo"], x2, M, D, H * HD, resid=x, mode=GEMM_RESID)
             ops.rmsnorm_fwd(x2, w["ln2"], xn, None, geo.rms_eps)
-            ops.gemm(xn, w["wgu"], gu, M, 2 * I, D)
+            gemm(xn, w["wgu"], gu, M, 2 * I, D)
             ops.swiglu_fwd(gu, act, M, I)
-            ops.gemm(act, w["wd"], x, M, D, I, resid=x2, mode=GEMM_RESID)
+            gemm(act, w["wd"], x, M, D, I, resid=x2, mode=GEMM_RESID)
         ops.rmsnorm_fwd(x, llm.norm, xn, None, geo.rms_eps)
-        ops.gemm(xn, llm.head, logits, M, V, D)
+        gemm(xn, llm.head, logits, M, V, D)
         ops.logprob_topk(logits, M, V, K, banned, 1 if state.ban_eos() else 0, tv, ti)
         vals = tv.cpu().numpy().reshape(B, nb, K)                           # one small D2H sync per step
         idx = ti.cpu().numpy().reshape(B, nb, K).astype(np.int64)

@@ -48,6 +48,12 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_nt_bf16(_p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), _p(resid), M, N, K, mode,
                                              self._stream()), "tasu_gemm_nt_bf16")
 
+    def gemm_skinny(self, a, b, c, M, N, K, ws, bias=None, resid=None, mode=GEMM_BF16):
+        """M <= 64 weight-streaming GEMM (decode step); ws: fp32 workspace tensor."""
+        self._chk(self.lib.tasu_gemm_skinny_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(bias),
+                                                 _p(resid), M, N, K, mode, _p(ws), 0 if ws is None else ws.numel(),
+                                                 self._stream()), "tasu_gemm_skinny_bf16")
+
     def transpose(self, src, dst, R, C, Rpad, Cpad):
         self._chk(self.lib.tasu_transpose_bf16(_p(src), src.stride(0), _p(dst), dst.stride(0), R, C, Rpad, Cpad,
                                                self._stream()), "tasu_transpose_bf16")

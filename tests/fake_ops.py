@@ -36,6 +36,10 @@ class FakeOps:
             R = resid.reshape(-1, resid.shape[-1])
             C[:M, :N] = R[:M, :N] + _bf(acc).float()
 
+    def gemm_skinny(self, a, b, c, M, N, K, ws, bias=None, resid=None, mode=GEMM_BF16):
+        assert M <= 64
+        self.gemm(a, b, c, M, N, K, bias=bias, resid=resid, mode=mode)
+
     def transpose(self, src, dst, R, C, Rpad, Cpad):
         dst[:Cpad, :Rpad] = 0
         dst[:C, :R] = src[:R, :C].t()

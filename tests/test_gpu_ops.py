@@ -376,3 +376,21 @@ def test_logprob_topk_full_vocab(hip, fake):
     (vc_, ic_), (vg_, ig_) = run_pair(hip, fake, "logprob_topk", [lg, M, V, 8, torch.zeros(1, dtype=I32), 0, torch.zeros(M, 8),
                                                                   torch.zeros(M, 8, dtype=I32)], [6, 7])
     assert torch.equal(ic_, ig_) and float((vc_ - vg_).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,mode,bias", [(64, 1536, 8960, 2, False), (64, 2048, 1536, 0, True), (40, 17920, 1536, 0, False),
+                                             (64, 1000, 256, 1, True), (4, 151936, 1536, 0, False), (64, 1536, 1536, 2, False)])
+def test_gemm_skinny(hip, fake, M, N, K, mode, bias):
+    ldc = (N + 63) // 64 * 64
+    a = randn(M, K, dtype=BF, seed=1)
+    b = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
+    bv = randn(N, dtype=BF, seed=3) if bias else None
+    c = torch.zeros(M, ldc, dtype=BF if mode == 0 else F32)
+    r = randn(M, ldc, seed=4) if mode == 2 else None
+    cc, gc = c.clone(), c.cuda()
+    ws = torch.zeros(16 * 64 * ldc).cuda()
+    fake.gemm_skinny(a, b, cc, M, N, K, None, bias=bv, resid=r, mode=mode)
+    hip.gemm_skinny(a.cuda(), b.cuda(), gc, M, N, K, ws, bias=dev(bv), resid=dev(r), mode=mode)
+    torch.cuda.synchronize()
+    assert rel_err(gc, cc) < (1e-2 if mode != 1 else 2e-5 * math.sqrt(K))
+    assert torch.equal(gc.cpu()[:, N:], cc[:, N:])
