@@ -53,84 +53,117 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(const bf16* __restrict__
   }
 }
 
-// Single-token attention.  Block = (row, kv group); wave w = query head g*rep + w.
-// Phase 1 (scores): 16 lanes cooperate on one key (each lane 8 dims = one 16-byte load, so a wave instruction reads 4
-// whole 256-B K rows, fully coalesced), partial dots are reduced with 4 xor-shuffles; scores are staged in LDS.
-// Phase 2 (P.V): lane owns dims 2*lane, 2*lane+1, keys unrolled by 8 for loads in flight (coalesced 256-B V rows).
+// Single-token GQA attention over the cache, flash-decoding style inside one block per (row, kv group):
+// the 8 waves split the KEYS (not the heads), so every K / V row is read once for all REP query heads of the group
+// and the serial chain per wave is nk/8 keys long.
+//   phase 1  scores: 16 lanes per key (one 16-byte load each: a wave instruction reads 4 whole 256-B K rows), REP dot
+//            products per key from q kept in registers, xor-shuffle reduction, scores -> LDS [REP][ctx]
+//   phase 1b softmax statistics per head (wave h), probabilities (bf16-rounded like the prefill kernel) back to LDS
+//   phase 2  P.V: lane owns dims 2*lane, 2*lane+1 of its wave's key range for all REP heads; partials -> LDS
+//   phase 3  cross-wave sum, 1/l, bf16 store
 // keys in [kstart[row], lens[row]) are visible.  ctx <= MAX_CTX.
 constexpr int MAX_CTX = 2048;
-__global__ void attn_decode_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ kc, const bf16* __restrict__ vc,
-                                   const int32_t* __restrict__ kstart, const int32_t* __restrict__ lens, bf16* __restrict__ out,
-                                   int H, int G, int ctx, float scale) {
-  extern __shared__ float sp[];                 // [rep][ctx]
+constexpr int DEC_NW = 8;
+template <int REP>
+__global__ __launch_bounds__(64 * DEC_NW) void attn_decode_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ kc,
+                                                                  const bf16* __restrict__ vc,
+                                                                  const int32_t* __restrict__ kstart,
+                                                                  const int32_t* __restrict__ lens, bf16* __restrict__ out,
+                                                                  int H, int G, int ctx, float scale) {
+  extern __shared__ float sp[];                         // [REP][ctx] scores | [DEC_NW][REP][128] partial outputs | [REP] 1/l
+  float* sc = sp;
+  float* part = sp + (size_t)REP * ctx;
+  float* linv = part + DEC_NW * REP * HD;
   const int row = blockIdx.x, g = blockIdx.y;
-  const int rep = H / G, W = G * HD, LD = (H + 2 * G) * HD;
+  const int W = G * HD, LD = (H + 2 * G) * HD;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int h = g * rep + wave;
-  const int k0 = kstart[row], k1 = lens[row];
-  const int nk = k1 - k0;
-  float* myp = sp + (size_t)wave * ctx;
-  const int sub = lane & 15, kq = lane >> 4;    // 16 lanes per key, 4 keys per wave instruction
-  float q[8];
-  {
-    const bf16x8 v = *(const bf16x8*)(qkv + (size_t)row * LD + h * HD + sub * 8);
+  const int k0 = kstart[row], nk = lens[row] - k0;
+  const int chunk = ((nk + DEC_NW - 1) / DEC_NW + 3) & ~3;     // keys per wave, multiple of 4
+  const int kb = wave * chunk, ke = min(nk, kb + chunk);
+  const int sub = lane & 15, kq = lane >> 4;
+  float q[REP][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = (float)v[j] * scale;
+  for (int h = 0; h < REP; ++h) {
+    const bf16x8 v = *(const bf16x8*)(qkv + (size_t)row * LD + (g * REP + h) * HD + sub * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[h][j] = (float)v[j] * scale;
   }
   const bf16* kbase = kc + ((size_t)row * ctx + k0) * W + g * HD + sub * 8;
-  float m = -__builtin_inff();
-  for (int i0 = 0; i0 < nk; i0 += 4) {
+  for (int i0 = kb; i0 < ke; i0 += 4) {
     const int i = i0 + kq;
-    float s = 0.f;
-    if (i < nk) {
+    float kf[8];
+    if (i < ke) {
       const bf16x8 v = *(const bf16x8*)(kbase + (size_t)i * W);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += q[j] * (float)v[j];
+      for (int j = 0; j < 8; ++j) kf[j] = (float)v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kf[j] = 0.f;
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 8, 64);
-    if (i < nk) {
-      if (sub == 0) myp[i] = s;
-      m = fmaxf(m, s);
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += q[h][j] * kf[j];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      if (sub == 0 && i < ke) sc[h * ctx + i] = s;
     }
   }
-  m = wave_max(m);
-  __builtin_amdgcn_wave_barrier();
-  float l = 0.f;
-  for (int i = lane; i < nk; i += 64) {
-    const float p = __expf(myp[i] - m);
-    myp[i] = (float)(bf16)p;                    // bf16-rounded probabilities feed P.V, like the prefill kernel
-    l += p;
+  __syncthreads();
+  for (int h = wave; h < REP; h += DEC_NW) {               // softmax statistics of head h
+    float m = -__builtin_inff();
+    for (int i = lane; i < nk; i += 64) m = fmaxf(m, sc[h * ctx + i]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int i = lane; i < nk; i += 64) {
+      const float p = __expf(sc[h * ctx + i] - m);
+      sc[h * ctx + i] = (float)(bf16)p;
+      l += p;
+    }
+    l = wave_sum(l);
+    if (lane == 0) linv[h] = l > 0.f ? 1.f / l : 0.f;
   }
-  l = wave_sum(l);
-  __builtin_amdgcn_wave_barrier();              // a wave's LDS accesses are processed in order: its own writes are visible
+  __syncthreads();
   const bf16* vbase = vc + ((size_t)row * ctx + k0) * W + g * HD + 2 * lane;
-  float o0 = 0.f, o1 = 0.f;
-  int i = 0;
-  for (; i + 8 <= nk; i += 8) {
-    bf16x2 v[8];
+  float o[REP][2];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *(const bf16x2*)(vbase + (size_t)(i + u) * W);
+  for (int h = 0; h < REP; ++h) o[h][0] = o[h][1] = 0.f;
+  int i = kb;
+  for (; i + 4 <= ke; i += 4) {
+    bf16x2 v[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float p = myp[i + u];
-      o0 += p * (float)v[u][0];
-      o1 += p * (float)v[u][1];
+    for (int u = 0; u < 4; ++u) v[u] = *(const bf16x2*)(vbase + (size_t)(i + u) * W);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        const float p = sc[h * ctx + i + u];
+        o[h][0] += p * (float)v[u][0];
+        o[h][1] += p * (float)v[u][1];
+      }
+  }
+  for (; i < ke; ++i) {
+    const bf16x2 v = *(const bf16x2*)(vbase + (size_t)i * W);
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      const float p = sc[h * ctx + i];
+      o[h][0] += p * (float)v[0];
+      o[h][1] += p * (float)v[1];
     }
   }
-  for (; i < nk; ++i) {
-    const float p = myp[i];
-    const bf16x2 v = *(const bf16x2*)(vbase + (size_t)i * W);
-    o0 += p * (float)v[0];
-    o1 += p * (float)v[1];
+#pragma unroll
+  for (int h = 0; h < REP; ++h) *(f32x2*)(part + ((wave * REP + h) * HD) + 2 * lane) = f32x2{o[h][0], o[h][1]};
+  __syncthreads();
+  for (int e = threadIdx.x; e < REP * HD; e += 64 * DEC_NW) {
+    const int h = e / HD, d = e - h * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < DEC_NW; ++w2) s += part[(w2 * REP + h) * HD + d];
+    out[(size_t)row * (H * HD) + (g * REP + h) * HD + d] = (bf16)(s * linv[h]);
   }
-  const float inv = l > 0.f ? 1.f / l : 0.f;
-  bf16x2 o;
-  o[0] = (bf16)(o0 * inv);
-  o[1] = (bf16)(o1 * inv);
-  *(bf16x2*)(out + (size_t)row * (H * HD) + h * HD + 2 * lane) = o;
 }
 
 // per row: lse over V columns, then the k best log-probs (value = logit - lse) with their column ids, descending;
@@ -278,12 +311,29 @@ extern "C" int tasu_kv_gather(const void* src_k, const void* src_v, void* dst_k,
 extern "C" int tasu_attn_decode(const void* qkv, const void* kcache, const void* vcache, const int32_t* kstart,
                                 const int32_t* lens, void* out, int M, int H, int G, int ctx, float scale, void* stream) {
   if (!qkv || !kcache || !vcache || !kstart || !lens || !out || M <= 0 || H <= 0 || G <= 0 || H % G || ctx <= 0 ||
-      ctx > MAX_CTX || (H / G) * 64 > 1024)
+      ctx > MAX_CTX)
     return TASU_ERR_ARG;
   const int rep = H / G;
-  TASU_LAUNCH(attn_decode_kernel, dim3(M, G), dim3(rep * 64), (size_t)rep * ctx * sizeof(float), (hipStream_t)stream,
-              (const bf16*)qkv, (const bf16*)kcache, (const bf16*)vcache, kstart, lens, (bf16*)out, H, G, ctx, scale);
-  return TASU_OK;
+  const size_t lds = ((size_t)rep * ctx + DEC_NW * rep * HD + rep) * sizeof(float);
+  if (lds > 160 * 1024) return TASU_ERR_ARG;
+#define DEC_CASE(R)                                                                                                   \
+  case R: {                                                                                                           \
+    static bool attr_set = false;                                                                                     \
+    if (!attr_set) {                                                                                                  \
+      (void)hipFuncSetAttribute((const void*)attn_decode_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                160 * 1024);                                                                          \
+      attr_set = true;                                                                                                \
+    }                                                                                                                 \
+    TASU_LAUNCH(attn_decode_kernel<R>, dim3(M, G), dim3(64 * DEC_NW), lds, (hipStream_t)stream, (const bf16*)qkv,      \
+                (const bf16*)kcache, (const bf16*)vcache, kstart, lens, (bf16*)out, H, G, ctx, scale);                 \
+    return TASU_OK;                                                                                                   \
+  }
+  switch (rep) {
+    DEC_CASE(1) DEC_CASE(2) DEC_CASE(4) DEC_CASE(6) DEC_CASE(7) DEC_CASE(8)
+    default:
+      return TASU_ERR_ARG;
+  }
+#undef DEC_CASE
 }
 extern "C" int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned,
                                  float* out_val, int32_t* out_idx, void* stream) {
