@@ -254,6 +254,12 @@ def main():
         n_launch = len(timed.events)
         gemm_flops_step = gemm_flops_per_utt(geo, S, n_audio) * B
         achieved = gemm_flops_step * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
+        if os.path.isfile(pmc) and args.model == "qwen2.5-1.5b" and B == 16:
+            # measured offline with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction);
+            # bytes per gemm_nt_kernel launch, averaged over the same launches `achieved` averages over
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         line = {
             "metric": "train utterances/sec (Qwen2.5-1.5B align)", "value": round(utt_per_s, 2), "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -263,7 +269,7 @@ def main():
                                    f"frozen encoder pass skipped, logits for all positions",
                        "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": "gemm_nt_kernel (tasu_gemm_nt_bf16)", "launches_per_step": n_launch // max(args.steps, 1),
                          "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
                          "algorithmic_gflop_per_launch": round(gemm_flops_step * args.steps / max(n_launch, 1) / 1e9, 2),
