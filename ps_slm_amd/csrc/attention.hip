@@ -25,26 +25,45 @@ constexpr int HD = 128;
 constexpr int ROW_TILE_BYTES = 64 * 256;
 constexpr int TR_TILE_BYTES = 128 * 128;
 
-// load a [64][128] tile whose rows are tokens tok0.. of a token-major matrix (row stride ld elements) into
-// the "row" image.  Rows >= nrows are clamped (callers mask them).
-__device__ __forceinline__ void load_row_tile(char* lds, const bf16* g, int ld, int tok0, int nrows) {
+// Tile staging is split (issue-early / write-late): fetch_* issues the 4 global loads of a tile into registers, the
+// MFMA work of the previous tile runs while they are in flight, and commit_* writes them to LDS after the barrier.
+struct TileRegs {
+  bf16x8 v[4];
+};
+// [64][128] tile whose rows are tokens tok0.. of a token-major matrix (row stride ld elements); rows >= nrows are
+// clamped (callers mask them).
+__device__ __forceinline__ void fetch_row_tile(TileRegs& t, const bf16* g, int ld, int tok0, int nrows) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = i * 256 + threadIdx.x;
     const int r = idx >> 4, c = idx & 15;
     const int tok = min(tok0 + r, nrows - 1);
-    const bf16x8 v = *(const bf16x8*)(g + (size_t)tok * ld + c * 8);
-    *(bf16x8*)(lds + r * 256 + ((c ^ (r & 15)) << 4)) = v;
+    t.v[i] = *(const bf16x8*)(g + (size_t)tok * ld + c * 8);
   }
 }
-// load a [128][64] tile (rows d, columns tokens tok0..tok0+63) of a [128, Spad] matrix into the "tr" image.
-__device__ __forceinline__ void load_tr_tile(char* lds, const bf16* g, int spad, int tok0) {
+__device__ __forceinline__ void commit_row_tile(char* lds, const TileRegs& t) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = i * 256 + threadIdx.x;
+    const int r = idx >> 4, c = idx & 15;
+    *(bf16x8*)(lds + r * 256 + ((c ^ (r & 15)) << 4)) = t.v[i];
+  }
+}
+// [128][64] tile (rows d, columns tokens tok0..tok0+63) of a [128, Spad] matrix -> "tr" image.
+__device__ __forceinline__ void fetch_tr_tile(TileRegs& t, const bf16* g, int spad, int tok0) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = i * 256 + threadIdx.x;
     const int r = idx >> 3, c = idx & 7;
-    const bf16x8 v = *(const bf16x8*)(g + (size_t)r * spad + tok0 + c * 8);
-    *(bf16x8*)(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = v;
+    t.v[i] = *(const bf16x8*)(g + (size_t)r * spad + tok0 + c * 8);
+  }
+}
+__device__ __forceinline__ void commit_tr_tile(char* lds, const TileRegs& t) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = i * 256 + threadIdx.x;
+    const int r = idx >> 3, c = idx & 7;
+    *(bf16x8*)(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = t.v[i];
   }
 }
 // MFMA operand (16 rows = tile rows sub*16 + (lane&15), k = d in [32ks + 8q', +8)) from a "row" image.
@@ -111,11 +130,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   float m_run = NEG_INF, l_run = 0.f;
 
   const int nkt = causal ? (qt + 1) : ((S + 63) >> 6);
+  TileRegs rK, rVt;
+  fetch_row_tile(rK, kbase, LD, 0, S);
+  fetch_tr_tile(rVt, vtbase, Spad, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-    load_row_tile(sK, kbase, LD, kt * 64, S);
-    load_tr_tile(sVt, vtbase, Spad, kt * 64);
+    commit_row_tile(sK, rK);
+    commit_tr_tile(sVt, rVt);
     __syncthreads();
+    if (kt + 1 < nkt) {
+      fetch_row_tile(rK, kbase, LD, (kt + 1) * 64, S);
+      fetch_tr_tile(rVt, vtbase, Spad, (kt + 1) * 64);
+    }
 
     f32x4 s[4];
     float tmax = NEG_INF;
@@ -251,12 +277,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   for (int i = 0; i < 8; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = causal ? (qt + 1) : ((S + 63) >> 6);
+  TileRegs rK, rV, rKt;
+  fetch_row_tile(rK, kbase, LD, 0, S);
+  fetch_row_tile(rV, vbase, LD, 0, S);
+  fetch_tr_tile(rKt, ktbase, Spad, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-    load_row_tile(sK, kbase, LD, kt * 64, S);
-    load_row_tile(sV, vbase, LD, kt * 64, S);
-    load_tr_tile(sKt, ktbase, Spad, kt * 64);
+    commit_row_tile(sK, rK);
+    commit_row_tile(sV, rV);
+    commit_tr_tile(sKt, rKt);
     __syncthreads();
+    if (kt + 1 < nkt) {
+      fetch_row_tile(rK, kbase, LD, (kt + 1) * 64, S);
+      fetch_row_tile(rV, vbase, LD, (kt + 1) * 64, S);
+      fetch_tr_tile(rKt, ktbase, Spad, (kt + 1) * 64);
+    }
     f32x4 ds[4];
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
@@ -337,13 +372,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16* __rest
     dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int nqt = (S + 63) >> 6;
-  for (int qtile = causal ? ktile : 0; qtile < nqt; ++qtile) {
+  const int q_first = causal ? ktile : 0;
+  TileRegs rQ, rdO, rQt, rdOt;
+  fetch_row_tile(rQ, qbase, LD, q_first * 64, S);
+  fetch_row_tile(rdO, dobase, H * HD, q_first * 64, S);
+  fetch_tr_tile(rQt, qtbase, Spad, q_first * 64);
+  fetch_tr_tile(rdOt, dotbase, Spad, q_first * 64);
+  for (int qtile = q_first; qtile < nqt; ++qtile) {
     __syncthreads();
-    load_row_tile(sQ, qbase, LD, qtile * 64, S);
-    load_row_tile(sdO, dobase, H * HD, qtile * 64, S);
-    load_tr_tile(sQt, qtbase, Spad, qtile * 64);
-    load_tr_tile(sdOt, dotbase, Spad, qtile * 64);
+    commit_row_tile(sQ, rQ);
+    commit_row_tile(sdO, rdO);
+    commit_tr_tile(sQt, rQt);
+    commit_tr_tile(sdOt, rdOt);
     __syncthreads();
+    if (qtile + 1 < nqt) {
+      fetch_row_tile(rQ, qbase, LD, (qtile + 1) * 64, S);
+      fetch_row_tile(rdO, dobase, H * HD, (qtile + 1) * 64, S);
+      fetch_tr_tile(rQt, qtbase, Spad, (qtile + 1) * 64);
+      fetch_tr_tile(rdOt, dotbase, Spad, (qtile + 1) * 64);
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {  // 32 query rows at a time keeps the live set under 256 VGPRs
       f32x4 pv[2], ds[2];
