@@ -91,14 +91,16 @@ int tasu_rope_bwd(void* dqkv, const float* dk_part, const float* dv_part, const 
 int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key_mask, void* out, float* lse, int B, int S,
                   int H, int G, float scale, int causal, void* stream);
 /* Backward.  prep: delta[b,h,s] = sum_d dO.O and dOt [B,H,128,Spad];  dq: dQ (rotated space) into the q block
- * of dqkv;  dkv: per-QUERY-head fp32 partials dk_part / dv_part [M, H*128] (no atomics; tasu_rope_bwd sums the
- * H/G heads of each kv group).  Spad = S rounded up to 64; key_mask is [B, Spad] (pad = 0); lse/delta are
+ * of dqkv;  dkv: fp32 partials dk_part / dv_part [M, (H/HPB)*128] (no atomics; see TASU_ATTN_DKV_HPB).  Spad = S rounded up to 64; key_mask is [B, Spad] (pad = 0); lse/delta are
  * [B, H, Spad]; qt/kt/vt/dOt are [B, heads, 128, Spad] with zero token padding.                           */
 int tasu_attn_bwd_prep(const void* dout, const void* out, float* delta, void* dout_t, int B, int S, int H,
                        void* stream);
 int tasu_attn_bwd_dq(const void* qkv, const void* kt, const uint8_t* key_mask, const void* dout, const float* lse,
                      const float* delta, void* dqkv, int B, int S, int H, int G, float scale, int causal,
                      void* stream);
+/* query heads of one kv group handled (and summed in registers) per block of tasu_attn_bwd_dkv; dk_part / dv_part are
+ * fp32 [M, (H / HPB) * 128]: one partial per HPB-head group, reduced over the remaining (H/G)/HPB by tasu_rope_bwd. */
+#define TASU_ATTN_DKV_HPB(rep) (((rep) % 3 == 0) ? 3 : (((rep) % 2 == 0) ? 2 : 1))
 int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t* key_mask, const void* dout, const void* dout_t,
                       const float* lse, const float* delta, float* dk_part, float* dv_part, int B, int S, int H, int G,
                       float scale, int causal, void* stream);

@@ -12,6 +12,8 @@
 // contiguous dimension with ds_read_b128 / ds_read_b64 and an XOR swizzle (no transposed LDS reads).
 //
 // Tiles: 64 queries x 64 keys per step, 256 threads = 4 waves, each wave owns 16 of the 64 rows.
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/tasu_hip.h"
 
@@ -330,33 +332,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   }
 }
 
-// =============================================================================== backward: dK, dV (per q head)
-// One block per (64 keys, query head h, batch).  Writes fp32 partials dk_part / dv_part [M, H*128]; the 6
-// query heads of a kv head are summed (and K un-rotated) by tasu_gqa_reduce_rope_bwd.
+// =============================================================================== backward: dK, dV
+// One block per (64 keys, group of HPB query heads that share a kv head, batch): K / V fragments stay in registers,
+// dK^T / dV^T accumulate in registers over the HPB heads x the (causal) query tiles, and only H/HPB fp32 partials
+// per kv head go to memory (HPB = TASU_ATTN_DKV_HPB(H/G): 3 for Qwen2.5-1.5B -> 2 partials per kv head; writing one
+// partial per QUERY head cost 50 MB of fp32 stores per call and dominated the kernel).  tasu_rope_bwd sums them.
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ qt_g,
                                                               const uint8_t* __restrict__ kmask,
                                                               const bf16* __restrict__ dout,
                                                               const bf16* __restrict__ dout_t,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               float* __restrict__ dk_part, float* __restrict__ dv_part, int S,
-                                                              int Spad, int H, int G, float scale, int causal) {
+                                                              int Spad, int H, int G, int hpb, float scale, int causal) {
   __shared__ __attribute__((aligned(16))) char smem[2 * ROW_TILE_BYTES + 2 * TR_TILE_BYTES];
   char* sQ = smem;
   char* sdO = smem + ROW_TILE_BYTES;
   char* sQt = smem + 2 * ROW_TILE_BYTES;
   char* sdOt = smem + 2 * ROW_TILE_BYTES + TR_TILE_BYTES;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ktile = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int g = h / (H / G);
+  const int ktile = blockIdx.x, hg = blockIdx.y, b = blockIdx.z;      // hg: index of the HPB-head group
+  const int h0 = hg * hpb;
+  const int g = h0 / (H / G);
   const int LD = (H + 2 * G) * HD;
-  const bf16* qbase = qkv + (size_t)b * S * LD + h * HD;
   const bf16* kbase = qkv + (size_t)b * S * LD + (H + g) * HD;
   const bf16* vbase = qkv + (size_t)b * S * LD + (H + G + g) * HD;
-  const bf16* dobase = dout + (size_t)b * S * (H * HD) + h * HD;
-  const bf16* qtbase = qt_g + ((size_t)b * H + h) * HD * Spad;
-  const bf16* dotbase = dout_t + ((size_t)b * H + h) * HD * Spad;
-  const float* lrow = lse + ((size_t)b * H + h) * Spad;
-  const float* drow = delta + ((size_t)b * H + h) * Spad;
   const int kpos = ktile * 64 + wave * 16 + (lane & 15);
   const int kc = min(kpos, S - 1);
   const int qp = lane >> 4;
@@ -373,26 +372,30 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16* __rest
   }
   const int nqt = (S + 63) >> 6;
   const int q_first = causal ? ktile : 0;
+  const int per_head = nqt - q_first;
+  const int n_it = per_head * hpb;                       // flattened (head, query tile) iteration space
+  auto fetch = [&](TileRegs& rQ, TileRegs& rdO, TileRegs& rQt, TileRegs& rdOt, int it) {
+    const int h = h0 + it / per_head, qtile = q_first + it % per_head;
+    fetch_row_tile(rQ, qkv + (size_t)b * S * LD + h * HD, LD, qtile * 64, S);
+    fetch_row_tile(rdO, dout + (size_t)b * S * (H * HD) + h * HD, H * HD, qtile * 64, S);
+    fetch_tr_tile(rQt, qt_g + ((size_t)b * H + h) * HD * Spad, Spad, qtile * 64);
+    fetch_tr_tile(rdOt, dout_t + ((size_t)b * H + h) * HD * Spad, Spad, qtile * 64);
+  };
   TileRegs rQ, rdO, rQt, rdOt;
-  fetch_row_tile(rQ, qbase, LD, q_first * 64, S);
-  fetch_row_tile(rdO, dobase, H * HD, q_first * 64, S);
-  fetch_tr_tile(rQt, qtbase, Spad, q_first * 64);
-  fetch_tr_tile(rdOt, dotbase, Spad, q_first * 64);
-  for (int qtile = q_first; qtile < nqt; ++qtile) {
+  if (n_it > 0) fetch(rQ, rdO, rQt, rdOt, 0);
+  for (int it = 0; it < n_it; ++it) {
+    const int h = h0 + it / per_head, qtile = q_first + it % per_head;
+    const float* lrow = lse + ((size_t)b * H + h) * Spad;
+    const float* drow = delta + ((size_t)b * H + h) * Spad;
     __syncthreads();
     commit_row_tile(sQ, rQ);
     commit_row_tile(sdO, rdO);
     commit_tr_tile(sQt, rQt);
     commit_tr_tile(sdOt, rdOt);
     __syncthreads();
-    if (qtile + 1 < nqt) {
-      fetch_row_tile(rQ, qbase, LD, (qtile + 1) * 64, S);
-      fetch_row_tile(rdO, dobase, H * HD, (qtile + 1) * 64, S);
-      fetch_tr_tile(rQt, qtbase, Spad, (qtile + 1) * 64);
-      fetch_tr_tile(rdOt, dotbase, Spad, (qtile + 1) * 64);
-    }
+    if (it + 1 < n_it) fetch(rQ, rdO, rQt, rdOt, it + 1);
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {  // 32 query rows at a time keeps the live set under 256 VGPRs
+    for (int qb = 0; qb < 2; ++qb) {  // 32 query rows at a time keeps the live set small
       f32x4 pv[2], ds[2];
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
@@ -426,8 +429,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16* __rest
     }
   }
   if (kpos < S) {
-    float* dkr = dk_part + ((size_t)b * S + kpos) * (H * HD) + h * HD;
-    float* dvr = dv_part + ((size_t)b * S + kpos) * (H * HD) + h * HD;
+    const int np = H / hpb;                              // partials per token row
+    float* dkr = dk_part + ((size_t)b * S + kpos) * (np * HD) + hg * HD;
+    float* dvr = dv_part + ((size_t)b * S + kpos) * (np * HD) + hg * HD;
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
       *(f32x4*)(dkr + nt * 16 + 4 * qp) = dk[nt] * scale;
@@ -474,9 +478,10 @@ extern "C" int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t*
                                  float* dv_part, int B, int S, int H, int G, float scale, int causal, void* stream) {
   if (!qkv || !qt || !key_mask || !dout || !dout_t || !lse || !delta || !dk_part || !dv_part || bad_geo(B, S, H, G))
     return TASU_ERR_ARG;
-  dim3 grid((S + 63) / 64, H, B);
+  const int hpb = TASU_ATTN_DKV_HPB(H / G);
+  dim3 grid((S + 63) / 64, H / hpb, B);
   TASU_LAUNCH(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)qt,
                      key_mask, (const bf16*)dout, (const bf16*)dout_t, lse, delta, dk_part, dv_part, S, spad_of(S), H, G,
-                     scale, causal);
+                     hpb, scale, causal);
   return TASU_OK;
 }

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(64) void rope_bwd_kernel(bf16* __restrict__ dqkv, c
                                                       const float* __restrict__ st, int H, int G) {
   const int m = blockIdx.x, hh = blockIdx.y, i = threadIdx.x;
   const int LD = (H + 2 * G) * HD;
-  const int rep = H / G;
+  const int np_g = (H / G) / TASU_ATTN_DKV_HPB(H / G);   // fp32 partials per kv head written by tasu_attn_bwd_dkv
+  const int np = H / TASU_ATTN_DKV_HPB(H / G);
   bf16* row = dqkv + (size_t)m * LD + hh * HD;
   float y1, y2;
   if (hh < H) {
@@ -108,10 +109,10 @@ __global__ __launch_bounds__(64) void rope_bwd_kernel(bf16* __restrict__ dqkv, c
   } else {
     const bool isk = hh < H + G;
     const int g = isk ? hh - H : hh - H - G;
-    const float* src = (isk ? dk_part : dv_part) + (size_t)m * (H * HD) + (size_t)g * rep * HD;
+    const float* src = (isk ? dk_part : dv_part) + (size_t)m * (np * HD) + (size_t)g * np_g * HD;
     y1 = 0.f;
     y2 = 0.f;
-    for (int r = 0; r < rep; ++r) {
+    for (int r = 0; r < np_g; ++r) {
       y1 += src[r * HD + i];
       y2 += src[r * HD + i + 64];
     }

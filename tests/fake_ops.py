@@ -118,8 +118,10 @@ class FakeOps:
         v = dqkv.view(B, S, H + 2 * G, HD)
         c, s = cos.view(B, S, 1, 64), sin.view(B, S, 1, 64)
         rep = H // G
-        dk = dk_part.view(B, S, G, rep, HD).sum(3)
-        dv = dv_part.view(B, S, G, rep, HD).sum(3)
+        hpb = 3 if rep % 3 == 0 else (2 if rep % 2 == 0 else 1)
+        npg, M = rep // hpb, B * S
+        dk = dk_part.reshape(-1)[: M * G * npg * HD].view(B, S, G, npg, HD).sum(3)
+        dv = dv_part.reshape(-1)[: M * G * npg * HD].view(B, S, G, npg, HD).sum(3)
         v[:, :, :H] = _bf(self._rot(v[:, :, :H].float(), c, s, inverse=True))
         v[:, :, H:H + G] = _bf(self._rot(dk, c, s, inverse=True))
         v[:, :, H + G:] = _bf(dv)
@@ -186,8 +188,14 @@ class FakeOps:
         q, k, v, do, p, ds = self._bwd_common(qkv, key_mask, dout, lse, delta, B, S, H, G, scale, causal)
         dv = _bf(p).float().transpose(-1, -2) @ do
         dk = (_bf(ds).float().transpose(-1, -2) @ q) * scale
-        dk_part.view(B, S, H, HD).copy_(dk.permute(0, 2, 1, 3))
-        dv_part.view(B, S, H, HD).copy_(dv.permute(0, 2, 1, 3))
+        rep = H // G
+        hpb = 3 if rep % 3 == 0 else (2 if rep % 2 == 0 else 1)
+        M = B * S
+        # partial layout of tasu_attn_bwd_dkv: [M, (H/hpb) * 128], heads summed in groups of hpb
+        dk_part.reshape(-1)[: M * (H // hpb) * HD].view(B, S, H // hpb, HD).copy_(
+            dk.permute(0, 2, 1, 3).reshape(B, S, H // hpb, hpb, HD).sum(3))
+        dv_part.reshape(-1)[: M * (H // hpb) * HD].view(B, S, H // hpb, HD).copy_(
+            dv.permute(0, 2, 1, 3).reshape(B, S, H // hpb, hpb, HD).sum(3))
 
     # ---------------------------------------------------------------- activations
     def swiglu_fwd(self, gu, act, M, I):

@@ -167,7 +167,9 @@ def test_rope(hip, fake, B, S, H, G):
     for c, g in zip(*outs):
         assert rel_err(g, c) < 1e-2
     dqkv = randn(M, LD, dtype=BF, seed=2)
-    dkp, dvp = randn(M, H * HD, seed=3), randn(M, H * HD, seed=4)
+    rep = H // G
+    hpb = 3 if rep % 3 == 0 else (2 if rep % 2 == 0 else 1)
+    dkp, dvp = randn(M, (H // hpb) * HD, seed=3), randn(M, (H // hpb) * HD, seed=4)
     (c,), (g,) = run_pair(hip, fake, "rope_bwd", [dqkv, dkp, dvp, cc, sc, B, S, H, G], [0])
     assert rel_err(g, c) < 1e-2
 
@@ -204,7 +206,11 @@ def test_attention_fwd_bwd(hip, fake, B, S, H, G, mask_kind, causal):
     dkp, dvp = torch.zeros(M, H * HD), torch.zeros(M, H * HD)
     (kc, vc), (kg, vg) = run_pair(hip, fake, "attn_bwd_dkv", [qkv, qt, km, dout, tc, lc, dc, dkp, dvp, B, S, H, G, scale, causal],
                                   [7, 8])
-    assert rel_err(kg, kc) < 2e-2 and rel_err(vg, vc) < 2e-2
+    rep = H // G
+    hpb = 3 if rep % 3 == 0 else (2 if rep % 2 == 0 else 1)
+    n_used = M * (H // hpb) * HD
+    assert rel_err(kg.reshape(-1)[:n_used], kc.reshape(-1)[:n_used]) < 2e-2
+    assert rel_err(vg.reshape(-1)[:n_used], vc.reshape(-1)[:n_used]) < 2e-2
 
 
 def test_attention_online_softmax_rescale(hip, fake):
