@@ -133,16 +133,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 
   const int nkt = causal ? (qt + 1) : ((S + 63) >> 6);
   TileRegs rK, rVt;
+  uint32_t mk_next[4], mkw[4];                    // key-mask words of the tile, prefetched with it (no load -> use stall)
   fetch_row_tile(rK, kbase, LD, 0, S);
   fetch_tr_tile(rVt, vtbase, Spad, 0);
+#pragma unroll
+  for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + st * 16 + 4 * qp);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     commit_row_tile(sK, rK);
     commit_tr_tile(sVt, rVt);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) mkw[st] = mk_next[st];
     __syncthreads();
     if (kt + 1 < nkt) {
       fetch_row_tile(rK, kbase, LD, (kt + 1) * 64, S);
       fetch_tr_tile(rVt, vtbase, Spad, (kt + 1) * 64);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + (kt + 1) * 64 + st * 16 + 4 * qp);
     }
 
     f32x4 s[4];
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) a = mfma16(frag_row(sK, st, ks, lane), qf[ks], a);
       const int key0 = kt * 64 + st * 16 + 4 * qp;
-      const uint32_t mk = *(const uint32_t*)(mrow + key0);
+      const uint32_t mk = mkw[st];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = key0 + r;
@@ -280,19 +287,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 
   const int nkt = causal ? (qt + 1) : ((S + 63) >> 6);
   TileRegs rK, rV, rKt;
+  uint32_t mk_next[4], mkw[4];
   fetch_row_tile(rK, kbase, LD, 0, S);
   fetch_row_tile(rV, vbase, LD, 0, S);
   fetch_tr_tile(rKt, ktbase, Spad, 0);
+#pragma unroll
+  for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + st * 16 + 4 * qp);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     commit_row_tile(sK, rK);
     commit_row_tile(sV, rV);
     commit_tr_tile(sKt, rKt);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) mkw[st] = mk_next[st];
     __syncthreads();
     if (kt + 1 < nkt) {
       fetch_row_tile(rK, kbase, LD, (kt + 1) * 64, S);
       fetch_row_tile(rV, vbase, LD, (kt + 1) * 64, S);
       fetch_tr_tile(rKt, ktbase, Spad, (kt + 1) * 64);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + (kt + 1) * 64 + st * 16 + 4 * qp);
     }
     f32x4 ds[4];
 #pragma unroll
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
         dp = mfma16(frag_row(sV, st, ks, lane), dof[ks], dp);
       }
       const int key0 = kt * 64 + st * 16 + 4 * qp;
-      const uint32_t mk = *(const uint32_t*)(mrow + key0);
+      const uint32_t mk = mkw[st];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = key0 + r;
@@ -344,11 +358,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16* __rest
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               float* __restrict__ dk_part, float* __restrict__ dv_part, int S,
                                                               int Spad, int H, int G, int hpb, float scale, int causal) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * ROW_TILE_BYTES + 2 * TR_TILE_BYTES];
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 tiles + lse[64] + delta[64]
   char* sQ = smem;
   char* sdO = smem + ROW_TILE_BYTES;
   char* sQt = smem + 2 * ROW_TILE_BYTES;
   char* sdOt = smem + 2 * ROW_TILE_BYTES + TR_TILE_BYTES;
+  float* s_ld = (float*)(smem + 2 * ROW_TILE_BYTES + 2 * TR_TILE_BYTES);   // [0,64) lse, [64,128) delta of the q tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ktile = blockIdx.x, hg = blockIdx.y, b = blockIdx.z;      // hg: index of the HPB-head group
   const int h0 = hg * hpb;
@@ -374,24 +389,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16* __rest
   const int q_first = causal ? ktile : 0;
   const int per_head = nqt - q_first;
   const int n_it = per_head * hpb;                       // flattened (head, query tile) iteration space
+  float r_ld = 0.f;                                      // threads 0..63: lse[q], 64..127: delta[q] of the fetched tile
   auto fetch = [&](TileRegs& rQ, TileRegs& rdO, TileRegs& rQt, TileRegs& rdOt, int it) {
     const int h = h0 + it / per_head, qtile = q_first + it % per_head;
     fetch_row_tile(rQ, qkv + (size_t)b * S * LD + h * HD, LD, qtile * 64, S);
     fetch_row_tile(rdO, dout + (size_t)b * S * (H * HD) + h * HD, H * HD, qtile * 64, S);
     fetch_tr_tile(rQt, qt_g + ((size_t)b * H + h) * HD * Spad, Spad, qtile * 64);
     fetch_tr_tile(rdOt, dout_t + ((size_t)b * H + h) * HD * Spad, Spad, qtile * 64);
+    if (threadIdx.x < 128)
+      r_ld = (threadIdx.x < 64 ? lse : delta)[((size_t)b * H + h) * Spad + qtile * 64 + (threadIdx.x & 63)];
   };
   TileRegs rQ, rdO, rQt, rdOt;
   if (n_it > 0) fetch(rQ, rdO, rQt, rdOt, 0);
   for (int it = 0; it < n_it; ++it) {
-    const int h = h0 + it / per_head, qtile = q_first + it % per_head;
-    const float* lrow = lse + ((size_t)b * H + h) * Spad;
-    const float* drow = delta + ((size_t)b * H + h) * Spad;
+    const int qtile = q_first + it % per_head;
     __syncthreads();
     commit_row_tile(sQ, rQ);
     commit_row_tile(sdO, rdO);
     commit_tr_tile(sQt, rQt);
     commit_tr_tile(sdOt, rdOt);
+    if (threadIdx.x < 128) s_ld[threadIdx.x] = r_ld;
     __syncthreads();
     if (it + 1 < n_it) fetch(rQ, rdO, rQt, rdOt, it + 1);
 #pragma unroll
@@ -408,8 +425,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16* __rest
           dp = mfma16(frag_row(sdO, qs, ks, lane), vf[ks], dp);
         }
         const int q0 = qtile * 64 + qs * 16 + 4 * qp;  // < Spad
-        const f32x4 l4 = *(const f32x4*)(lrow + q0);
-        const f32x4 d4 = *(const f32x4*)(drow + q0);
+        const f32x4 l4 = *(const f32x4*)(s_ld + qs * 16 + 4 * qp);
+        const f32x4 d4 = *(const f32x4*)(s_ld + 64 + qs * 16 + 4 * qp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = q0 + r;
@@ -480,7 +497,13 @@ extern "C" int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t*
     return TASU_ERR_ARG;
   const int hpb = TASU_ATTN_DKV_HPB(H / G);
   dim3 grid((S + 63) / 64, H / hpb, B);
-  TASU_LAUNCH(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)qt,
+  constexpr int DKV_LDS = 2 * ROW_TILE_BYTES + 2 * TR_TILE_BYTES + 128 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    attr_set = true;
+  }
+  TASU_LAUNCH(attn_bwd_dkv_kernel, grid, dim3(256), DKV_LDS, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)qt,
                      key_mask, (const bf16*)dout, (const bf16*)dout_t, lse, delta, dk_part, dv_part, S, spad_of(S), H, G,
                      hpb, scale, causal);
   return TASU_OK;
