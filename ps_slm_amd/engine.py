@@ -83,7 +83,7 @@ class TasuEngine:
         st = self._last_state
         if st is None:
             raise RuntimeError("backward() called before a forward pass")
-        self.core.backward(st)
+        self.core.run_backward(st)
         self.micro_steps += 1
         if self.world > 1:
             g = self.core.proj.g

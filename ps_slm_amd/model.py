@@ -234,6 +234,12 @@ class TasuModel:
         self.keep_logits = keep_logits
         self._ws = {}
         self.training = True
+        # hipGraph replay of the (shape-static) forward / backward launch sequences: ~700 launches per step collapse
+        # into two graph launches.  Keyed by the shapes baked into kernel arguments; the first call of a key runs
+        # eagerly (allocates the workspace), the second is captured, later ones replay.
+        self.use_graphs = False
+        self._graphs = {}
+        self._graph_seen = {}
 
     # ------------------------------------------------------------------------------------------ weights
     def load_reference_state_dict(self, sd):
@@ -526,6 +532,40 @@ class TasuModel:
         rows[: st.Ra] = st.plan.audio_rows
         st.dev["audio_rows_pad"] = self._upload("audio_rows_pad", rows)
         return st.dev["audio_rows_pad"]
+
+    # ------------------------------------------------------------------------------------------ hipGraph replay
+    def _graphed(self, key, fn):
+        if not (self.use_graphs and self.device.type == "cuda"):
+            return fn()
+        g = self._graphs.get(key)
+        if g is not None:
+            g.replay()
+            return
+        seen = self._graph_seen.get(key, 0)
+        self._graph_seen[key] = seen + 1
+        if seen < 1:
+            return fn()                              # eager warm-up: buffer allocation, lazy kernel attributes
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        self._graphs[key] = g
+        g.replay()
+
+    def _shape_key(self, st, tag):
+        return (tag, st.B, st.S, st.Ra, st.Rap, self.keep_logits)
+
+    def run_forward_text(self, st, compute_loss=True, need_backward=True):
+        """forward_projector_text + forward_llm, graph-replayed when enabled."""
+        def fn():
+            self.forward_projector_text(st)
+            self.forward_llm(st, compute_loss=compute_loss, need_backward=need_backward)
+        self._graphed(self._shape_key(st, ("fwd_text", compute_loss, need_backward)), fn)
+
+    def run_backward(self, st):
+        if "audio_rows_pad" not in st.dev:
+            self._pad_rows(st)                       # H2D upload stays outside the captured region
+        self._graphed(self._shape_key(st, "bwd"), lambda: self.backward(st))
 
     # ------------------------------------------------------------------------------------------ results
     def logits_view(self, st):

@@ -257,11 +257,11 @@ class slam_model_asr:
             if self.gt_emb_noise:
                 alphas, keeps = self.draw_noise(ids_list)
             st = core.prepare_text(input_ids, attention_mask, labels, ids_list, alphas, keeps)
-            core.forward_projector_text(st)
+            core.run_forward_text(st, compute_loss=labels is not None, need_backward=self.training)
         else:
             st = core.prepare_audio(input_ids, attention_mask, labels, input_features, input_feature_length,
                                     do_psd=self.do_psd)
-        core.forward_llm(st, compute_loss=labels is not None, need_backward=self.training)
+            core.forward_llm(st, compute_loss=labels is not None, need_backward=self.training)
         self.last_state = st
         if labels is None:
             return CausalLMOutput(None, core.logits_view(st)), -1

@@ -186,3 +186,26 @@ def test_generate_beam4_on_gpu():
         g, c, r = outs["gpu_" + path], outs["cpu_" + path], z[key]
         assert ((g == c).cumprod(1).sum(1) >= 8).all(), (path, g, c)
         assert ((g == r).cumprod(1).sum(1) >= 8).all(), (path, g, r)
+
+
+def test_graph_replay_matches_eager(setup):
+    """hipGraph capture/replay of the forward and backward launch sequences gives bit-identical results."""
+    geo, sd, gm, _ = setup
+    batch = synthetic_text_batch(geo, 3, seed=77, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12,
+                                 noise=False)
+    def one(model):
+        st = model.prepare_text(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["post_ids"], None, None)
+        model.run_forward_text(st)
+        model.run_backward(st)
+        torch.cuda.synchronize()
+        return st.dev["loss_out"].clone(), model.proj.g.clone()
+    gm.use_graphs = False
+    l0, g0 = one(gm)
+    gm.use_graphs = True
+    outs = [one(gm) for _ in range(4)]          # eager warm-up, capture + replay, replay, replay
+    gm.use_graphs = False
+    assert len(gm._graphs) == 2
+    for l, g in outs:
+        assert torch.equal(l, l0) and torch.equal(g, g0)
+    gm._graphs.clear()
+    gm._graph_seen.clear()
