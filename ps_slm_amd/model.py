@@ -534,23 +534,26 @@ class TasuModel:
         return st.dev["audio_rows_pad"]
 
     # ------------------------------------------------------------------------------------------ hipGraph replay
-    def _graphed(self, key, fn):
+    def _graphed(self, key, fn, st):
         if not (self.use_graphs and self.device.type == "cuda"):
             return fn()
         g = self._graphs.get(key)
         if g is not None:
-            g.replay()
+            g[0].replay()
+            for k, v in g[1].items():                 # the views the captured code published into st.dev
+                st.dev.setdefault(k, v)
             return
         seen = self._graph_seen.get(key, 0)
         self._graph_seen[key] = seen + 1
         if seen < 1:
             return fn()                              # eager warm-up: buffer allocation, lazy kernel attributes
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        graph = torch.cuda.CUDAGraph()
+        before = set(st.dev)
+        with torch.cuda.graph(graph):
             fn()
-        self._graphs[key] = g
-        g.replay()
+        self._graphs[key] = (graph, {k: v for k, v in st.dev.items() if k not in before})
+        graph.replay()
 
     def _shape_key(self, st, tag):
         return (tag, st.B, st.S, st.Ra, st.Rap, self.keep_logits)
@@ -560,12 +563,12 @@ class TasuModel:
         def fn():
             self.forward_projector_text(st)
             self.forward_llm(st, compute_loss=compute_loss, need_backward=need_backward)
-        self._graphed(self._shape_key(st, ("fwd_text", compute_loss, need_backward)), fn)
+        self._graphed(self._shape_key(st, ("fwd_text", compute_loss, need_backward)), fn, st)
 
     def run_backward(self, st):
         if "audio_rows_pad" not in st.dev:
             self._pad_rows(st)                       # H2D upload stays outside the captured region
-        self._graphed(self._shape_key(st, "bwd"), lambda: self.backward(st))
+        self._graphed(self._shape_key(st, "bwd"), lambda: self.backward(st), st)
 
     # ------------------------------------------------------------------------------------------ results
     def logits_view(self, st):
