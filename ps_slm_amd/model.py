@@ -182,6 +182,7 @@ class LLMWeights:
 
     def load_reference_state_dict(self, sd, pre="llm."):
         geo = self.geo
+        self.layers = []
         for l in range(geo.llm_layers):
             p = f"{pre}model.layers.{l}."
             self.add_layer(sd[p + "input_layernorm.weight"],
@@ -198,6 +199,7 @@ class LLMWeights:
         """Seeded N(0, 0.02) linears/embedding, ones norms (HF default init), generated ON DEVICE tensor by tensor
         (no pretrained weights exist on the benchmark box)."""
         geo, dev = self.geo, self.device
+        self.layers = []
         g = torch.Generator(device=dev).manual_seed(seed)
         D, I, H, G = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads
 
