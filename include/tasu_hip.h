@@ -40,6 +40,16 @@ int tasu_abi_version(void);
 int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                       const float* resid, int M, int N, int K, int out_mode, void* stream);
 
+/* Same GEMM with a caller-owned device workspace that lets small grids split the K range over several blocks per tile
+ * (256 x 192 tiles; the last-arriving block of a tile sums the fp32 partials in split order: deterministic).
+ * Workspace layout: TASU_GEMM_WS_COUNTERS int32 arrival counters, which the caller zeroes ONCE (every launch leaves
+ * them zero), followed by the partial tiles; 64 MiB + 16 KiB covers every shape of the path.  Launches that share a
+ * workspace must be ordered on one stream.  workspace may be NULL (identical to tasu_gemm_nt_bf16).                  */
+#define TASU_GEMM_WS_COUNTERS 4096
+int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                         const float* resid, int M, int N, int K, int out_mode, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
 /* Weight-streaming variant for M <= 64 rows (the decode step, M = batch x beams): HBM-bound, split-K over the grid
  * with a deterministic fp32 slab reduction.  workspace: >= ksplit*64*round_up(N,64) floats (16 x 64 x round_up(N,64)
  * always suffices); may be NULL (no K split).  Same operand rules and out_mode as tasu_gemm_nt_bf16.             */
@@ -205,6 +215,11 @@ int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k, const int
                       float* out_val, int32_t* out_idx, void* stream);
 /* x[m,:] = table[ids[m],:] (fp32 embedding rows of the last generated tokens). */
 int tasu_embed_rows(const float* table, const int32_t* ids, float* x, int M, int D, void* stream);
+
+/* MI355X-specific helper with no counterpart in the reference: reads [p, p + bytes) and drops the data, so that the
+ * bytes sit in the 256 MB Infinity Cache when the next GEMM (launched on ANOTHER stream) asks for them.  `blocks`
+ * one-wave workgroups (256..1024 is plenty); policy 0 = default cache policy, 1 = `nt` loads.  p 16-byte aligned. */
+int tasu_cache_prefetch(const void* p, int64_t bytes, int blocks, int policy, void* stream);
 
 #ifdef __cplusplus
 }

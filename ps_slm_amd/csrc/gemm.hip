@@ -30,6 +30,9 @@ struct GemmArgs {
   int M, N, K;
   int lda, ldb, ldc;
   int tiles_m, tiles_n;
+  int ksplit;           // > 1: blockIdx covers tiles x ksplit, every block reduces K-steps [ks*per, (ks+1)*per)
+  float* partial;       // [tiles][ksplit][BM*BN] fp32 partial tiles (register-image order)
+  int* counters;        // [tiles] arrival counters, zero between launches (the last arriver resets its tile's)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -41,7 +44,13 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // 256 x 256 / 8 waves (2 x 4, wave tile 128 x 64, one block per CU) halves the L2 -> LDS bytes per FLOP of the 128-wide
 // tiles ((BM+BN)/(BM*BN): 1/128 vs 1/64); the 128-wide tiles run at roughly the chip's L2 bandwidth (2 x 32 KB per
 // K-step per CU), which is what caps them near 1 PFLOP/s.
-template <int BM, int BN, int NWM, int NWN, int OUT_MODE, bool HAS_BIAS, int SCHED>
+//
+// SPLITK: grids that cannot fill the chip with whole tiles (M = 4096 x N = 1536 is 128 tiles of 256 x 192) split the K
+// range over `ksplit` blocks per tile.  Every block writes its fp32 partial tile to the workspace, fences at agent
+// scope (the 8 XCD L2s are not coherent with each other without it) and takes a ticket from the tile's arrival counter;
+// the LAST arriver adds the partials in split order (ksplit == 2: own + other, which is order-independent) and runs the
+// normal epilogue.  No spinning, so no co-residency requirement; bitwise deterministic.
+template <int BM, int BN, int NWM, int NWN, int OUT_MODE, bool HAS_BIAS, int SCHED, bool SPLITK = false>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(GemmArgs p) {
   constexpr int NW = NWM * NWN, NT = 64 * NW;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -59,7 +68,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(GemmArgs p) 
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  int ks = 0;
+  if (SPLITK) {
+    ks = logical % p.ksplit;
+    logical /= p.ksplit;
+  }
+  const int tile_id = logical;
   constexpr int GROUP_M = 8;
   const int per_group = GROUP_M * p.tiles_n;
   const int gid = logical / per_group;
@@ -112,11 +127,16 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(GemmArgs p) 
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
-  stage(0, 0);
+  int kbeg = 0, nk = p.K / BK;
+  if (SPLITK) {
+    const int per = (nk + p.ksplit - 1) / p.ksplit;
+    kbeg = ks * per;
+    nk = min(nk, kbeg + per);
+  }
+  if (kbeg < nk) stage(0, kbeg);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = kbeg; kt < nk; ++kt) {
+    const int cur = (kt - kbeg) & 1;
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
     const char* sa = smem + cur * STAGE_BYTES + (wr * WM) * 128;
     const char* sb = smem + cur * STAGE_BYTES + A_BYTES + (wc * WN) * 128;
@@ -148,6 +168,40 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(GemmArgs p) 
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * MI * NI - 2 * (MI + NI), 0);
     }
     __syncthreads();
+  }
+
+  if (SPLITK) {
+    constexpr int TILE_F = BM * BN;
+    float* mine = p.partial + ((size_t)tile_id * p.ksplit + ks) * TILE_F;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) *(f32x4*)(mine + ((i * NI + j) * NT + tid) * 4) = acc[i][j];
+    __threadfence();                       // release: partial tile visible device-wide before the ticket
+    __syncthreads();
+    int* flag = (int*)smem;
+    if (tid == 0) flag[0] = atomicAdd(p.counters + tile_id, 1);
+    __syncthreads();
+    if (flag[0] != p.ksplit - 1) return;   // not the last arriver of this tile
+    __threadfence();                       // acquire: the other blocks' partials
+    if (tid == 0) p.counters[tile_id] = 0; // leave the counter ready for the next launch
+    const float* base = p.partial + (size_t)tile_id * p.ksplit * TILE_F;
+    if (p.ksplit == 2) {
+      const float* other = base + (size_t)(1 - ks) * TILE_F;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] += *(const f32x4*)(other + ((i * NI + j) * NT + tid) * 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          f32x4 s = *(const f32x4*)(base + ((i * NI + j) * NT + tid) * 4);
+          for (int k2 = 1; k2 < p.ksplit; ++k2) s += *(const f32x4*)(base + (size_t)k2 * TILE_F + ((i * NI + j) * NT + tid) * 4);
+          acc[i][j] = s;
+        }
+    }
   }
 
   // ---- epilogue.  acc[i][j][r] = C[m][n], m = row0 + wr*WM + i*16 + (lane&15),
@@ -204,19 +258,19 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(GemmArgs p) 
   }
 }
 
-template <int BM, int BN, int NWM, int NWN, int OUT_MODE, bool HAS_BIAS, int SCHED>
+template <int BM, int BN, int NWM, int NWN, int OUT_MODE, bool HAS_BIAS, int SCHED, bool SPLITK = false>
 int launch(GemmArgs a, hipStream_t st) {
   constexpr int LDS = 2 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, NWM, NWN, OUT_MODE, HAS_BIAS, SCHED>,
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, NWM, NWN, OUT_MODE, HAS_BIAS, SCHED, SPLITK>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  TASU_LAUNCH((gemm_nt_kernel<BM, BN, NWM, NWN, OUT_MODE, HAS_BIAS, SCHED>), dim3(a.tiles_m * a.tiles_n),
-              dim3(64 * NWM * NWN), LDS, st, a);
+  TASU_LAUNCH((gemm_nt_kernel<BM, BN, NWM, NWN, OUT_MODE, HAS_BIAS, SCHED, SPLITK>),
+              dim3(a.tiles_m * a.tiles_n * (SPLITK ? a.ksplit : 1)), dim3(64 * NWM * NWN), LDS, st, a);
   return TASU_OK;
 }
 
@@ -231,6 +285,9 @@ int sched_variant() {
 template <int OUT_MODE, bool HAS_BIAS>
 int launch_tiled(const GemmArgs& a, int bn, hipStream_t st) {
   if (bn == 256) return launch<256, 256, 2, 4, OUT_MODE, HAS_BIAS, 1>(a, st);
+  if (bn == 192)
+    return a.ksplit > 1 ? launch<256, 192, 2, 4, OUT_MODE, HAS_BIAS, 1, true>(a, st)
+                        : launch<256, 192, 2, 4, OUT_MODE, HAS_BIAS, 1>(a, st);
   if (sched_variant() == 1)
     return bn == 96 ? launch<128, 96, 2, 2, OUT_MODE, HAS_BIAS, 1>(a, st) : launch<128, 128, 2, 2, OUT_MODE, HAS_BIAS, 1>(a, st);
   return bn == 96 ? launch<128, 96, 2, 2, OUT_MODE, HAS_BIAS, 0>(a, st) : launch<128, 128, 2, 2, OUT_MODE, HAS_BIAS, 0>(a, st);
@@ -240,15 +297,20 @@ int launch_tiled(const GemmArgs& a, int bn, hipStream_t st) {
 // blocks, the tail efficiency tiles / (waves * 512) decides (N = 1536 at M = 4096: 384 tiles of 128x128 fill 75 % of
 // the slots, 512 tiles of 128x96 fill all of them: measured +11...+17 %); larger grids keep the wider tile, whose MFMA
 // per LDS read ratio is better (measured: N = 8960 loses 10 % with the narrow tile).
-int pick_bn(int M, int N) {
+int pick_bn(int M, int N, int K, size_t ws_bytes) {
   static const int forced = [] {
     const char* e = getenv("TASU_GEMM_BN");
     return e ? atoi(e) : 0;
   }();
-  if (forced == 96 || forced == 128 || forced == 256) return forced;
+  if (forced == 96 || forced == 128 || forced == 192 || forced == 256) return forced;
   // 256 x 256 (one block per CU): worth it when the grid is many rounds of 256 blocks, or (almost) exactly one round
   // (measured on MI355X, M = 4096 / 8192: gate_up +15 %, lm_head +8 %, M = 8192 x N = 1536..2048 +10...18 %;
   //  560- and 784-tile grids lose 2...3 % against the 128-wide tiles and stay there).
+  // very deep, small-grid problems (lm_head dgrad: K = 151,936; projector Linear1: K = 25,088): 256 x 192 tiles with the K
+  // range split over up to 8 blocks per tile (measured cold: d_lm_head 884 -> 995, proj1 497 -> 570 TFLOP/s)
+  const long t192 = (long)((M + 255) / 256) * ((N + 191) / 192);
+  if (K >= 24576 && t192 <= 128 && ws_bytes >= TASU_GEMM_WS_COUNTERS * sizeof(int) + (size_t)t192 * 2 * 256 * 192 * 4)
+    return 192;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   if (t256 >= 1024 || (t256 >= 192 && t256 <= 256)) return 256;
   const long slots = 512;
@@ -269,16 +331,43 @@ int kernel_choice() {
   return v;
 }
 
+int pipe96_auto() {
+  static const int v = [] {
+    const char* e = getenv("TASU_GEMM_PIPE96");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
 }  // namespace
 
 int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                             const float* resid, int M, int N, int K, int out_mode, int bn, hipStream_t st);
 
-extern "C" int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
-                                 const float* resid, int M, int N, int K, int out_mode, void* stream) {
+// Split-K plan for the 256 x 192 tile: ksplit blocks per tile so that tiles * ksplit is (close to) one round of 256
+// blocks, every split keeping >= 16 K-steps.  Returns 1 when the workspace is missing or too small.
+static int plan_ksplit(int M, int N, int K, size_t ws_bytes) {
+  static const int forced = [] {
+    const char* e = getenv("TASU_GEMM_KSPLIT");
+    return e ? atoi(e) : 0;
+  }();
+  const long tiles = (long)((M + 255) / 256) * ((N + 191) / 192);
+  int ks = forced > 0 ? forced : (int)(256 / tiles);
+  const int nk = K / BK;
+  if (ks > nk / 16) ks = nk / 16;
+  if (ks > 8) ks = 8;
+  if (ks < 1) ks = 1;
+  if (tiles > TASU_GEMM_WS_COUNTERS) return 1;
+  while (ks > 1 && TASU_GEMM_WS_COUNTERS * sizeof(int) + (size_t)tiles * ks * 256 * 192 * 4 > ws_bytes) --ks;
+  return ks;
+}
+
+extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                                    const float* resid, int M, int N, int K, int out_mode, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return TASU_ERR_ARG;
   if (K % BK != 0 || lda % 8 != 0 || ldb % 8 != 0) return TASU_ERR_ARG;
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return TASU_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)workspace & 15)) return TASU_ERR_ARG;
   if (out_mode == TASU_GEMM_OUT_F32_RESID_BF16R && !resid) return TASU_ERR_ARG;
   GemmArgs a;
   a.A = (const bf16*)A;
@@ -293,6 +382,9 @@ extern "C" int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
   a.ldb = ldb;
   a.ldc = ldc;
   a.tiles_m = a.tiles_n = 0;
+  a.ksplit = 1;
+  a.partial = nullptr;
+  a.counters = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const bool hb = bias != nullptr;
   if (kernel_choice() == 2) {
@@ -310,7 +402,24 @@ extern "C" int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     }
     return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, bn, st);
   }
-  const int bn = pick_bn(M, N);
+  const size_t ws_bytes = workspace ? (size_t)workspace_bytes : 0;
+  const int bn = pick_bn(M, N, K, ws_bytes);
+  if (bn == 96 && kernel_choice() == 0 && pipe96_auto()) {
+    // N = 1536 at M = 4096: 256 tiles of 256 x 96 = one block per CU; the 3-stage ring of gemm_pipe.hip keeps two
+    // K-steps in flight and is the faster kernel when the weight operand comes cold from HBM, which is the case inside
+    // the training step (measured cold: down 770 -> 826, d_gate_up 797 -> 884, d_qkv 661 -> 728 TFLOP/s).
+    const long t = (long)((M + 255) / 256) * ((N + 95) / 96);
+    const long rounds = (t + 255) / 256;
+    if ((double)t / (double)(rounds * 256) >= 0.85)
+      return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, 96, st);
+  }
+  if (bn == 192) {
+    a.ksplit = plan_ksplit(M, N, K, ws_bytes);
+    if (a.ksplit > 1) {
+      a.counters = (int*)workspace;
+      a.partial = (float*)((char*)workspace + TASU_GEMM_WS_COUNTERS * sizeof(int));
+    }
+  }
   switch (out_mode) {
     case TASU_GEMM_OUT_BF16:
       return hb ? launch_tiled<TASU_GEMM_OUT_BF16, true>(a, bn, st) : launch_tiled<TASU_GEMM_OUT_BF16, false>(a, bn, st);
@@ -322,4 +431,9 @@ extern "C" int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     default:
       return TASU_ERR_ARG;
   }
+}
+
+extern "C" int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                                 const float* resid, int M, int N, int K, int out_mode, void* stream) {
+  return tasu_gemm_nt_bf16_ws(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, nullptr, 0, stream);
 }

@@ -10,6 +10,7 @@ import torch
 from . import _lib
 
 GEMM_BF16, GEMM_F32, GEMM_RESID = 0, 1, 2
+GEMM_WS_BYTES = (64 << 20) + 4096 * 4          # tasu_gemm_nt_bf16_ws workspace: counters + split-K partial tiles
 LN_BWD_SPLIT = 16
 
 
@@ -28,6 +29,9 @@ class HipOps:
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise TasuOpError("HipOps needs a ROCm device (torch.cuda.is_available() is False)")
+        # split-K workspace of tasu_gemm_nt_bf16_ws: zeroed arrival counters + fp32 partial tiles (include/tasu_hip.h).
+        # Allocated up front (never inside a hipGraph capture); all GEMMs of one HipOps run on one stream.
+        self.gemm_ws = torch.zeros(GEMM_WS_BYTES, dtype=torch.uint8, device="cuda")
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -45,8 +49,13 @@ class HipOps:
         lda = a.stride(0) if lda is None else lda
         ldb = b.stride(0) if ldb is None else ldb
         ldc = c.stride(0) if ldc is None else ldc
-        self._chk(self.lib.tasu_gemm_nt_bf16(_p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), _p(resid), M, N, K, mode,
-                                             self._stream()), "tasu_gemm_nt_bf16")
+        self._chk(self.lib.tasu_gemm_nt_bf16_ws(_p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), _p(resid), M, N, K, mode,
+                                                _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()), "tasu_gemm_nt_bf16_ws")
+
+    def cache_prefetch(self, t, stream, blocks=512, policy=0):
+        """Pull tensor t through the Infinity Cache on `stream` (a torch.cuda.Stream other than the compute stream)."""
+        self._chk(self.lib.tasu_cache_prefetch(_p(t), t.numel() * t.element_size(), blocks, policy, stream.cuda_stream),
+                  "tasu_cache_prefetch")
 
     def gemm_skinny(self, a, b, c, M, N, K, ws, bias=None, resid=None, mode=GEMM_BF16):
         """M <= 64 weight-streaming GEMM (decode step); ws: fp32 workspace tensor."""

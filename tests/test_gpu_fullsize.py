@@ -1,0 +1,156 @@
+"""Parity at BASELINE.json's FULL sizes (Qwen2.5-1.5B geometry, CTC vocabulary 25,055, S = 256), where the CPU oracle
+would take minutes per step: size-independent properties of the path instead of a second implementation.
+
+  * every decoder / lm_head / projector GEMM shape of the benchmark step against rocBLAS (torch.matmul) on the same bits;
+  * the fused CE kernel at V = 151,936 against fp32 log-softmax of the very logits it consumed (loss, accuracy, dlogits);
+  * run-to-run determinism of loss and gradients (bitwise);
+  * the analytic projector gradient against a central finite difference of the loss along the gradient direction;
+  * batch-permutation invariance and padding invariance of loss and gradients (ragged batch vs each utterance alone).
+
+Random-init weights of the real architecture (no checkpoint exists on the GPU box); inputs are seeded.
+"""
+import math
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from ps_slm_amd.model import Geometry, TasuModel
+from ps_slm_amd.synthetic import synthetic_text_batch
+
+pytestmark = pytest.mark.gpu
+BF, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def full():
+    from ps_slm_amd.ops import HipOps
+    geo = Geometry.qwen25_1p5b()
+    m = TasuModel(geo, HipOps(), "cuda", keep_logits=True)
+    m.init_random(seed=4321)
+    return geo, m
+
+
+def step(m, batch, backward=True):
+    st = m.prepare_text(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["post_ids"],
+                        batch.get("alphas"), batch.get("keeps"))
+    m.forward_projector_text(st)
+    m.forward_llm(st, need_backward=backward)
+    if backward:
+        m.backward(st)
+    torch.cuda.synchronize()
+    return st
+
+
+def take(batch, rows):
+    """Sub-batch of utterances `rows`, trimmed to its own longest utterance (what the collator would have produced)."""
+    am = batch["attention_mask"][rows]
+    n = int(am.sum(1).max())
+    out = dict(input_ids=batch["input_ids"][rows][:, :n], attention_mask=am[:, :n], labels=batch["labels"][rows][:, :n],
+               post_ids=[batch["post_ids"][r] for r in rows])
+    if "alphas" in batch:
+        out["alphas"] = [batch["alphas"][r] for r in rows]
+        out["keeps"] = [batch["keeps"][r] for r in rows]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ GEMM shapes
+M_TOK = 4096
+FULL_SHAPES = [("qkv", M_TOK, 2048, 1536), ("o", M_TOK, 1536, 1536), ("gate_up", M_TOK, 17920, 1536),
+               ("down", M_TOK, 1536, 8960), ("d_down", M_TOK, 8960, 1536), ("d_gate_up", M_TOK, 1536, 17920),
+               ("d_qkv", M_TOK, 1536, 2048), ("lm_head", M_TOK, 151936, 1536), ("d_lm_head", M_TOK, 1536, 151936),
+               ("proj1", 1664, 2048, 25088), ("proj2", 1664, 1536, 2048), ("wgrad1", 2048, 25088, 1664),
+               ("wgrad2", 1536, 2048, 1664), ("d_proj1", 1664, 25088, 2048)]
+
+
+@pytest.mark.parametrize("name,M,N,K", FULL_SHAPES, ids=[s[0] for s in FULL_SHAPES])
+def test_benchmark_gemm_shapes_vs_rocblas(full, name, M, N, K):
+    _, m = full
+    g = torch.Generator(device="cuda").manual_seed(zlib.crc32(name.encode()) % 1000)
+    a = torch.randn(M, K, generator=g, device="cuda").to(BF)
+    b = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(BF)
+    c = torch.empty(M, N, device="cuda", dtype=BF)
+    m.ops.gemm(a, b, c, M, N, K)
+    ref = torch.matmul(a, b.t())                       # rocBLAS bf16, fp32 accumulation
+    torch.cuda.synchronize()
+    diff = (c.float() - ref.float())
+    scale = ref.float().abs().max()
+    # both sides round an fp32 sum to bf16; the sums differ only by accumulation order -> at most one bf16 ulp apart
+    assert float(diff.abs().max() / scale) < 2 ** -7
+    assert float(diff.norm() / ref.float().norm()) < 2e-3
+    c2 = torch.empty_like(c)
+    m.ops.gemm(a, b, c2, M, N, K)
+    torch.cuda.synchronize()
+    assert torch.equal(c, c2)
+
+
+# ------------------------------------------------------------------------------------------------ whole step
+def test_full_size_step_properties(full):
+    geo, m = full
+    batch = synthetic_text_batch(geo, 4, seed=99, noise=True, drop_prob=0.1, ragged=True)
+    st = step(m, batch)
+    loss = st.dev["loss_out"].clone()
+    g = m.proj.g.clone()
+    assert torch.isfinite(loss).all() and torch.isfinite(g).all()
+    assert abs(float(loss[0]) - math.log(geo.llm_vocab)) < 1.0      # random init: CE near ln(V)
+
+    # ---- fused CE at V = 151,936 against fp32 log-softmax of the same bf16 logits
+    V = geo.llm_vocab
+    logits = st.dev["logits"][:, :V].float()
+    labels = st.dev["shift_labels"].long()
+    sel = labels >= 0
+    lp = torch.log_softmax(logits[sel], dim=-1)
+    ref_loss = -lp.gather(1, labels[sel][:, None]).mean()
+    assert abs(float(loss[0]) - float(ref_loss)) < 2e-5 * float(ref_loss) + 1e-5
+    ref_hits = int((logits[sel].argmax(-1) == labels[sel]).sum())
+    assert abs(float(loss[1]) * int(sel.sum()) - ref_hits) < 0.5
+    assert int(loss[2]) == int(sel.sum())
+    dl = st.dev["dlogits"][:, :V].float()
+    ref_dl = torch.zeros_like(dl)
+    p = lp.exp()
+    p[torch.arange(p.shape[0], device="cuda"), labels[sel]] -= 1.0
+    ref_dl[sel] = p / float(sel.sum())
+    assert float((dl - ref_dl).norm() / ref_dl.norm()) < 4e-3        # bf16 storage of dlogits
+    assert float(dl[~sel].abs().max()) == 0.0
+    del logits, lp, p, dl, ref_dl
+
+    # ---- determinism
+    st2 = step(m, batch)
+    assert torch.equal(st2.dev["loss_out"], loss) and torch.equal(m.proj.g, g)
+
+    # ---- analytic gradient vs central finite difference along the gradient direction
+    p0 = m.proj.p.clone()
+    gn = float(g.norm())
+    d = g / gn
+    eps = 0.04 / gn                                    # predicted |dL| = 0.04 per side
+    vals = []
+    for sgn in (+1.0, -1.0):
+        m.proj.p.copy_(p0 + sgn * eps * d)
+        m.sync_projector_copies()
+        vals.append(float(step(m, batch, backward=False).dev["loss_out"][0]))
+    m.proj.p.copy_(p0)
+    m.sync_projector_copies()
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - gn) < 0.15 * gn, (fd, gn, vals)
+
+    # ---- batch permutation: same loss and gradient up to summation order
+    perm = [2, 0, 3, 1]
+    stp = step(m, take(batch, perm))
+    assert abs(float(stp.dev["loss_out"][0]) - float(loss[0])) < 2e-5
+    gp = m.proj.g
+    assert float((gp - g).norm() / g.norm()) < 2e-3
+
+    # ---- padding invariance: the ragged batch against every utterance alone (no padding at all)
+    tot_loss, tot_cnt, gsum = 0.0, 0, torch.zeros_like(g)
+    for r in range(4):
+        s1 = step(m, take(batch, [r]))
+        cnt = int(s1.dev["loss_out"][2])
+        tot_loss += float(s1.dev["loss_out"][0]) * cnt
+        tot_cnt += cnt
+        gsum += m.proj.g * cnt
+    assert tot_cnt == int(loss[2])
+    assert abs(tot_loss / tot_cnt - float(loss[0])) < 1e-3
+    gsum /= tot_cnt
+    cos = float(torch.nn.functional.cosine_similarity(gsum.flatten(), g.flatten(), dim=0))
+    assert cos > 0.999 and float((gsum - g).norm() / g.norm()) < 3e-2

@@ -70,6 +70,27 @@ def test_gemm(hip, fake, M, N, K, mode, bias):
     assert torch.equal(gc.cpu()[:, N:], cc[:, N:]), "columns beyond N must be untouched"
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 384, 32768), (300, 200, 24576), (1664, 2048, 25088), (1024, 1536, 28672)])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_gemm_split_k(hip, fake, M, N, K, mode):
+    """Deep, small-grid problems take the 256 x 192 split-K path (last-arriver reduction through the workspace): same
+    result as the double, bitwise repeatable, and the arrival counters are left zero."""
+    ldc = (N + 63) // 64 * 64
+    a = randn(M, K, dtype=BF, seed=1)
+    b = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
+    c = torch.zeros(M, ldc, dtype=BF if mode == 0 else F32)
+    r = randn(M, ldc, seed=4) if mode == 2 else None
+    cc, g1, g2 = c.clone(), c.cuda(), c.cuda()
+    fake.gemm(a, b, cc, M, N, K, resid=r, mode=mode)
+    ad, bd, rd = a.cuda(), b.cuda(), dev(r)
+    hip.gemm(ad, bd, g1, M, N, K, resid=rd, mode=mode)
+    hip.gemm(ad, bd, g2, M, N, K, resid=rd, mode=mode)
+    torch.cuda.synchronize()
+    assert rel_err(g1, cc) < 1e-2
+    assert torch.equal(g1, g2)
+    assert int(hip.gemm_ws[:4096 * 4].view(torch.int32).abs().sum()) == 0
+
+
 def test_gemm_exact_integers(hip):
     """A = I (padded), asymmetric B: catches row/col swaps and k-permutation errors exactly."""
     M = N = K = 128

@@ -1,33 +1,55 @@
-"""Micro-benchmark of tasu_gemm_nt_bf16 on the decoder's shapes (random data; HIP events on the launch stream)."""
-import sys, os, json
+"""Micro-benchmark of tasu_gemm_nt_bf16_ws on the decoder's shapes (random data; HIP events on the launch stream).
+
+  python tools/bench_gemm.py [M] [--cold] [--iters N] [--only name,name]
+
+--cold rotates over enough distinct operand sets (>= 1.5 GB in total) that no launch finds its operands in the 256 MB
+Infinity Cache -- the situation inside the training step, where every layer streams its own weights.
+"""
+import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ps_slm_amd.ops import HipOps
 
+ap = argparse.ArgumentParser()
+ap.add_argument("M", nargs="?", type=int, default=4096)
+ap.add_argument("--cold", action="store_true")
+ap.add_argument("--iters", type=int, default=40)
+ap.add_argument("--only", default="")
+args = ap.parse_args()
 ops = HipOps()
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+M = args.M
 shapes = [("qkv", M, 2048, 1536), ("o", M, 1536, 1536), ("gate_up", M, 17920, 1536), ("down", M, 1536, 8960),
-          ("d_down", M, 8960, 1536), ("d_gate_up", M, 1536, 17920), ("lm_head", M, 151936, 1536),
+          ("d_down", M, 8960, 1536), ("d_gate_up", M, 1536, 17920), ("d_qkv", M, 1536, 2048), ("lm_head", M, 151936, 1536),
           ("d_lm_head", M, 1536, 151936), ("proj1", 1664, 2048, 25088), ("wgrad1", 2048, 25088, 1664),
           ("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192)]
+only = set(filter(None, args.only.split(",")))
 res = []
 for name, m, n, k in shapes:
-    a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
-    b = (torch.randn(n, k, device="cuda") * k ** -0.5).to(torch.bfloat16)
-    c = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
-    for _ in range(3):
+    if only and name not in only:
+        continue
+    per_set = 2 * (m * k + n * k + m * n)
+    nsets = max(2, min(16, -(-(3 << 29) // per_set))) if args.cold else 1
+    a0 = torch.randn(m, k, device="cuda").to(torch.bfloat16)
+    b0 = (torch.randn(n, k, device="cuda") * k ** -0.5).to(torch.bfloat16)
+    sets = [(a0, b0, torch.empty(m, n, device="cuda", dtype=torch.bfloat16))]
+    for _ in range(nsets - 1):
+        sets.append((a0.clone(), b0.clone(), torch.empty(m, n, device="cuda", dtype=torch.bfloat16)))
+    for i in range(max(3, nsets)):
+        a, b, c = sets[i % nsets]
         ops.gemm(a, b, c, m, n, k)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    iters = 20
+    iters = args.iters
     e0.record()
-    for _ in range(iters):
+    for i in range(iters):
+        a, b, c = sets[i % nsets]
         ops.gemm(a, b, c, m, n, k)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     tf = 2.0 * m * n * k / ms / 1e9
-    res.append(dict(name=name, M=m, N=n, K=k, ms=round(ms, 4), tflops=round(tf, 1)))
-    print(f"{name:10s} M={m:5d} N={n:6d} K={k:6d}  {ms:8.3f} ms  {tf:7.1f} TF/s", flush=True)
-    del a, b, c
+    res.append(dict(name=name, M=m, N=n, K=k, ms=round(ms, 4), tflops=round(tf, 1), sets=nsets))
+    print(f"{name:10s} M={m:5d} N={n:6d} K={k:6d}  {ms:8.3f} ms  {tf:7.1f} TF/s  ({nsets} sets)", flush=True)
+    del sets, a0, b0, a, b, c
+    torch.cuda.empty_cache()
 print(json.dumps(res))
