@@ -297,7 +297,7 @@ int launch_tiled(const GemmArgs& a, int bn, hipStream_t st) {
 // blocks, the tail efficiency tiles / (waves * 512) decides (N = 1536 at M = 4096: 384 tiles of 128x128 fill 75 % of
 // the slots, 512 tiles of 128x96 fill all of them: measured +11...+17 %); larger grids keep the wider tile, whose MFMA
 // per LDS read ratio is better (measured: N = 8960 loses 10 % with the narrow tile).
-int pick_bn(int M, int N, int K, size_t ws_bytes) {
+int pick_bn(int M, int N) {
   static const int forced = [] {
     const char* e = getenv("TASU_GEMM_BN");
     return e ? atoi(e) : 0;
@@ -306,11 +306,6 @@ int pick_bn(int M, int N, int K, size_t ws_bytes) {
   // 256 x 256 (one block per CU): worth it when the grid is many rounds of 256 blocks, or (almost) exactly one round
   // (measured on MI355X, M = 4096 / 8192: gate_up +15 %, lm_head +8 %, M = 8192 x N = 1536..2048 +10...18 %;
   //  560- and 784-tile grids lose 2...3 % against the 128-wide tiles and stay there).
-  // very deep, small-grid problems (lm_head dgrad: K = 151,936; projector Linear1: K = 25,088): 256 x 192 tiles with the K
-  // range split over up to 8 blocks per tile (measured cold: d_lm_head 884 -> 995, proj1 497 -> 570 TFLOP/s)
-  const long t192 = (long)((M + 255) / 256) * ((N + 191) / 192);
-  if (K >= 24576 && t192 <= 128 && ws_bytes >= TASU_GEMM_WS_COUNTERS * sizeof(int) + (size_t)t192 * 2 * 256 * 192 * 4)
-    return 192;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   if (t256 >= 1024 || (t256 >= 192 && t256 <= 256)) return 256;
   const long slots = 512;
@@ -327,14 +322,6 @@ int kernel_choice() {
     const char* e = getenv("TASU_GEMM_KERNEL");
     if (!e) return 0;
     return e[0] == 'p' ? 2 : (e[0] == 'v' ? 1 : 0);
-  }();
-  return v;
-}
-
-int pipe96_auto() {
-  static const int v = [] {
-    const char* e = getenv("TASU_GEMM_PIPE96");
-    return e ? atoi(e) : 1;
   }();
   return v;
 }
@@ -387,31 +374,43 @@ extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int l
   a.counters = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const bool hb = bias != nullptr;
-  if (kernel_choice() == 2) {
-    static const int pbn = [] {
-      const char* e = getenv("TASU_GEMM_BN");
-      return e ? atoi(e) : 0;
-    }();
-    int bn = pbn;
-    if (bn != 96 && bn != 128) {
-      // one block per CU: prefer the width whose tile count fills whole rounds of 256 blocks
-      const long t128 = (long)((M + 255) / 256) * ((N + 127) / 128), t96 = (long)((M + 255) / 256) * ((N + 95) / 96);
-      const long w128 = (t128 + 255) / 256, w96 = (t96 + 255) / 256;
-      const double e128 = (double)t128 / (double)(w128 * 256), e96 = (double)t96 / (double)(w96 * 256) / 1.06;
-      bn = (w128 <= 3 && e96 > e128) ? 96 : 128;
-    }
-    return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, bn, st);
-  }
   const size_t ws_bytes = workspace ? (size_t)workspace_bytes : 0;
-  const int bn = pick_bn(M, N, K, ws_bytes);
-  if (bn == 96 && kernel_choice() == 0 && pipe96_auto()) {
-    // N = 1536 at M = 4096: 256 tiles of 256 x 96 = one block per CU; the 3-stage ring of gemm_pipe.hip keeps two
-    // K-steps in flight and is the faster kernel when the weight operand comes cold from HBM, which is the case inside
-    // the training step (measured cold: down 770 -> 826, d_gate_up 797 -> 884, d_qkv 661 -> 728 TFLOP/s).
-    const long t = (long)((M + 255) / 256) * ((N + 95) / 96);
-    const long rounds = (t + 255) / 256;
-    if ((double)t / (double)(rounds * 256) >= 0.85)
-      return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, 96, st);
+  static const int forced_bn = [] {
+    const char* e = getenv("TASU_GEMM_BN");
+    return e ? atoi(e) : 0;
+  }();
+  // ---- kernel / tile policy (MI355X, cold weight operands as inside the training step; tools/bench_gemm.py --cold):
+  //  * the pipelined 256 x {128, 96} kernel with loader waves (gemm_pipe.hip) is the fastest on every decoder, lm_head
+  //    and projector shape (qkv 700 -> 822, gate_up 780 -> 837, d_down 690 -> 772, d_lm_head 975 -> 1065 TFLOP/s ...);
+  //    the width is the one that fills whole rounds of 256 one-per-CU blocks better, the narrow tile paying ~11 % for
+  //    its lower FLOP per staged byte;
+  //  * grids that cover less than half of the CUs but are deep (K >= 8192) split K over 256 x 192 tiles instead;
+  //  * problems of at most 128 rows keep the 128-row tiles of this file (a 256-row tile would be half empty).
+  int use_pipe_bn = 0;
+  if (kernel_choice() == 2) {
+    use_pipe_bn = (forced_bn == 96 || forced_bn == 128) ? forced_bn : -1;
+  } else if (kernel_choice() == 0 && forced_bn == 0 && M > 128) {
+    use_pipe_bn = -1;
+  }
+  if (use_pipe_bn != 0) {
+    const long tm = (M + 255) / 256;
+    const long t128 = tm * ((N + 127) / 128), t96 = tm * ((N + 95) / 96);
+    if (kernel_choice() == 0 && t96 < 128 && K >= 8192 && plan_ksplit(M, N, K, ws_bytes) > 1) {
+      use_pipe_bn = 0;                              // falls through to the split-K tile below
+    } else {
+      if (use_pipe_bn < 0) {
+        const long w128 = (t128 + 255) / 256, w96 = (t96 + 255) / 256;
+        const double e128 = (double)t128 / (double)(w128 * 256), e96 = 0.89 * (double)t96 / (double)(w96 * 256);
+        use_pipe_bn = e96 > e128 ? 96 : 128;
+      }
+      return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, use_pipe_bn, st);
+    }
+  }
+  int bn;
+  if (kernel_choice() == 0 && forced_bn == 0 && M > 128) {
+    bn = 192;                                       // the deep small-grid case above
+  } else {
+    bn = pick_bn(M, N);
   }
   if (bn == 192) {
     a.ksplit = plan_ksplit(M, N, K, ws_bytes);

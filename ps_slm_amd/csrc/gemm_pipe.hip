@@ -9,6 +9,8 @@
 // phases; tile t+1 is awaited with a COUNTED s_waitcnt vmcnt(12) that leaves tile t+2 in flight (a __syncthreads would
 // drain it).  Ring safety: buffer (t+2)%3 == (t-1)%3 is refilled only after barrier(t-1), before which every wave
 // waited for its last reads of tile t-1 (lgkmcnt(0)).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -32,8 +34,14 @@ struct Args {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int BN, int OUT_MODE, bool HAS_BIAS>
-__global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(Args p) {
+// DBG (timing experiments only, wrong results): 1 = no LDS-DMA in the steady state, 2 = no fragment reads, 3 = neither.
+//
+// LOADERS: the block gets four more waves (4..7) that do nothing but issue the LDS-DMA of the ring and wait for it; the
+// four MFMA waves then carry fragment reads and MFMAs only.  Measured on this kernel (8192^3, warm): MFMA + barrier alone
+// 1.94 PFLOP/s, + fragment reads 1.60, + LDS-DMA issue 1.10 -- a global_load_lds costs its issuing wave ~100 cycles of
+// address processing during which that wave's MFMA queue drains, so the issue is moved to waves that have none.
+template <int BN, int OUT_MODE, bool HAS_BIAS, int DBG = 0, bool LOADERS = false>
+__global__ __launch_bounds__(LOADERS ? 512 : 256, LOADERS ? 1 : 2) void gemm_pipe_kernel(Args p) {
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int WM = 128, WN = BN / 2, MI = WM / 16, NI = WN / 16;
   constexpr int PA = BM / 32, PB = BN / 32;       // LDS-DMA pieces per wave per tile: 8 + 4 (or 3)
@@ -41,7 +49,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(Args p) {
   constexpr int NR = MI + NI;                      // fragment reads per phase
   constexpr int NM = MI * NI;                      // MFMAs per phase
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
+  const bool is_loader = LOADERS && wave_id >= 4;
+  const int wave = wave_id & 3;                    // staging share (loader) / tile quadrant (MFMA wave)
   const int wr = wave >> 1, wc = wave & 1;
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -82,6 +92,32 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(Args p) {
                                        0);
   };
 
+  const int nk = p.K / BK;
+  if (LOADERS && is_loader) {
+    stage(0, 0);
+    if (nk > 1) {
+      stage(1, 1);
+      if (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int slot2 = 2;                                 // ring slot of tile t+2
+    for (int t = 0; t < nk; ++t) {
+      if (t + 2 < nk) {
+        stage(slot2, t + 2);
+        if (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                // tile t+1 is in LDS; every MFMA wave is done with tile t-1... (see below)
+      slot2 = slot2 == 2 ? 0 : slot2 + 1;
+    }
+    return;
+  }
+
   const int sw = (lane >> 1) & 7;
   int roff[2];
 #pragma unroll
@@ -109,16 +145,17 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(Args p) {
       for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
   };
 
-  const int nk = p.K / BK;
   bf16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
   // ---- prologue: tiles 0 and 1 in flight, wait for tile 0, first fragments
-  stage(0, 0);
-  if (nk > 1) stage(1, 1);
-  if (nk > 1) {
-    if (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!LOADERS) {
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 1) {
+      if (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -131,18 +168,18 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(Args p) {
     const int nxt = cur == 2 ? 0 : cur + 1;      // slot of tile t+1
     const int nx2 = nxt == 2 ? 0 : nxt + 1;      // slot of tile t+2 (== slot of tile t-1)
     // ---------------- phase 1: MFMA(t, k-half 0)  ||  reads (t, k-half 1)  ||  LDS-DMA of tile t+2
-    if constexpr (MORE2) stage(nx2, t + 2);
-    read_frags(fa1, fb1, cur, 1);
+    if constexpr (MORE2 && !(DBG & 1) && !LOADERS) stage(nx2, t + 2);
+    if constexpr (!(DBG & 2)) read_frags(fa1, fb1, cur, 1);
     mma(fa0, fb0);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                     // 2 MFMA
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     // 1 DS read
-      if constexpr (MORE2) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM (LDS-DMA issue)
+      if constexpr (MORE2 && !(DBG & 1) && !LOADERS) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM (LDS-DMA issue)
     }
     __builtin_amdgcn_sched_group_barrier(0x008, NM - 2 * NR, 0);
     // ---------------- hand-over: my reads of tile t are done; tile t+1 has landed (tile t+2 may stay in flight)
-    if constexpr (MORE1) {
+    if constexpr (MORE1 && !LOADERS) {
       if constexpr (MORE2) {
         if constexpr (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
@@ -154,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(Args p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // ---------------- phase 2: MFMA(t, k-half 1)  ||  reads (t+1, k-half 0)
-    if constexpr (MORE1) read_frags(fa0, fb0, nxt, 0);
+    if constexpr (MORE1 && !(DBG & 2)) read_frags(fa0, fb0, nxt, 0);
     mma(fa1, fb1);
     if constexpr (MORE1) {
 #pragma unroll
@@ -230,23 +267,52 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(Args p) {
   }
 }
 
-template <int BN, int OUT_MODE, bool HAS_BIAS>
-int launch(Args a, hipStream_t st) {
+int loaders_enabled() {
+  static const int v = [] {
+    const char* e = getenv("TASU_PIPE_LOADERS");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
+template <int BN, int OUT_MODE, bool HAS_BIAS, bool LOADERS>
+int launch_v(Args a, hipStream_t st) {
   constexpr int LDS = 3 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS>,
+    (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS, 0, LOADERS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  TASU_LAUNCH((gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS>), dim3(a.tiles_m * a.tiles_n), dim3(256), LDS, st, a);
+  TASU_LAUNCH((gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS, 0, LOADERS>), dim3(a.tiles_m * a.tiles_n),
+              dim3(LOADERS ? 512 : 256), LDS, st, a);
+  return TASU_OK;
+}
+
+template <int BN, int OUT_MODE, bool HAS_BIAS>
+int launch(Args a, hipStream_t st) {
+  return loaders_enabled() ? launch_v<BN, OUT_MODE, HAS_BIAS, true>(a, st) : launch_v<BN, OUT_MODE, HAS_BIAS, false>(a, st);
+}
+
+template <int BN, int DBG>
+int launch_dbg(Args a, hipStream_t st) {
+  constexpr int LDS = 3 * (BM + BN) * BK * 2;
+  (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<BN, 0, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  TASU_LAUNCH((gemm_pipe_kernel<BN, 0, false, DBG>), dim3(a.tiles_m * a.tiles_n), dim3(256), LDS, st, a);
   return TASU_OK;
 }
 
 template <int OUT_MODE, bool HAS_BIAS>
 int launch_bn(const Args& a, int bn, hipStream_t st) {
+  static const int dbg = [] {
+    const char* e = getenv("TASU_PIPE_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  if (dbg && bn == 128) return dbg == 1 ? launch_dbg<128, 1>(a, st) : dbg == 2 ? launch_dbg<128, 2>(a, st) : launch_dbg<128, 3>(a, st);
   return bn == 96 ? launch<96, OUT_MODE, HAS_BIAS>(a, st) : launch<128, OUT_MODE, HAS_BIAS>(a, st);
 }
 
