@@ -216,10 +216,6 @@ int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k, const int
 /* x[m,:] = table[ids[m],:] (fp32 embedding rows of the last generated tokens). */
 int tasu_embed_rows(const float* table, const int32_t* ids, float* x, int M, int D, void* stream);
 
-/* MI355X-specific helper with no counterpart in the reference: reads [p, p + bytes) and drops the data, so that the
- * bytes sit in the 256 MB Infinity Cache when the next GEMM (launched on ANOTHER stream) asks for them.  `blocks`
- * one-wave workgroups (256..1024 is plenty); policy 0 = default cache policy, 1 = `nt` loads.  p 16-byte aligned. */
-int tasu_cache_prefetch(const void* p, int64_t bytes, int blocks, int policy, void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,13 +34,12 @@ struct Args {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-// DBG (timing experiments only, wrong results): 1 = no LDS-DMA in the steady state, 2 = no fragment reads, 3 = neither.
 //
 // LOADERS: the block gets four more waves (4..7) that do nothing but issue the LDS-DMA of the ring and wait for it; the
 // four MFMA waves then carry fragment reads and MFMAs only.  Measured on this kernel (8192^3, warm): MFMA + barrier alone
 // 1.94 PFLOP/s, + fragment reads 1.60, + LDS-DMA issue 1.10 -- a global_load_lds costs its issuing wave ~100 cycles of
 // address processing during which that wave's MFMA queue drains, so the issue is moved to waves that have none.
-template <int BN, int OUT_MODE, bool HAS_BIAS, int DBG = 0, bool LOADERS = false>
+template <int BN, int OUT_MODE, bool HAS_BIAS, bool LOADERS>
 __global__ __launch_bounds__(LOADERS ? 512 : 256, LOADERS ? 1 : 2) void gemm_pipe_kernel(Args p) {
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int WM = 128, WN = BN / 2, MI = WM / 16, NI = WN / 16;
@@ -80,16 +79,42 @@ __global__ __launch_bounds__(LOADERS ? 512 : 256, LOADERS ? 1 : 2) void gemm_pip
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     gb[i] = p.B + (size_t)min(col0 + r, p.N - 1) * p.ldb + c * 8;
   }
+  // Loader waves address through buffer descriptors (base = the block's first A / B row, per-lane 32-bit byte offset
+  // fixed for the whole K loop, the K offset in an SGPR): no per-K-step address VALU and a cheaper issue than the
+  // 64-bit-pointer global form (buffer_load_dwordx4 ... offen lds).
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer builtins exist in the device pass only
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)row0 * p.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (size_t)col0 * p.ldb), 0, 0x7fffffff, 0x00020000);
+#endif
+  int voa[PA], vob[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) voa[i] = (int)((ga[i] - (p.A + (size_t)row0 * p.lda)) * 2);
+#pragma unroll
+  for (int i = 0; i < PB; ++i) vob[i] = (int)((gb[i] - (p.B + (size_t)col0 * p.ldb)) * 2);
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE;
     const int koff = kt * BK;
+    if constexpr (LOADERS) {
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int i = 0; i < PA; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(base + (wave * PA + i) * 1024), 16, 0, 0);
+      for (int i = 0; i < PA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (wave * PA + i) * 1024), 16, voa[i], koff * 2, 0, 0);
 #pragma unroll
-    for (int i = 0; i < PB; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(base + A_BYTES + (wave * PB + i) * 1024), 16, 0,
-                                       0);
+      for (int i = 0; i < PB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (wave * PB + i) * 1024), 16, vob[i],
+                                                 koff * 2, 0, 0);
+#endif
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(base + (wave * PA + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < PB; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(base + A_BYTES + (wave * PB + i) * 1024), 16,
+                                         0, 0);
+    }
   };
 
   const int nk = p.K / BK;
@@ -168,14 +193,14 @@ __global__ __launch_bounds__(LOADERS ? 512 : 256, LOADERS ? 1 : 2) void gemm_pip
     const int nxt = cur == 2 ? 0 : cur + 1;      // slot of tile t+1
     const int nx2 = nxt == 2 ? 0 : nxt + 1;      // slot of tile t+2 (== slot of tile t-1)
     // ---------------- phase 1: MFMA(t, k-half 0)  ||  reads (t, k-half 1)  ||  LDS-DMA of tile t+2
-    if constexpr (MORE2 && !(DBG & 1) && !LOADERS) stage(nx2, t + 2);
-    if constexpr (!(DBG & 2)) read_frags(fa1, fb1, cur, 1);
+    if constexpr (MORE2 && !LOADERS) stage(nx2, t + 2);
+    read_frags(fa1, fb1, cur, 1);
     mma(fa0, fb0);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                     // 2 MFMA
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     // 1 DS read
-      if constexpr (MORE2 && !(DBG & 1) && !LOADERS) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM (LDS-DMA issue)
+      if constexpr (MORE2 && !LOADERS) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM (LDS-DMA issue)
     }
     __builtin_amdgcn_sched_group_barrier(0x008, NM - 2 * NR, 0);
     // ---------------- hand-over: my reads of tile t are done; tile t+1 has landed (tile t+2 may stay in flight)
@@ -191,7 +216,7 @@ __global__ __launch_bounds__(LOADERS ? 512 : 256, LOADERS ? 1 : 2) void gemm_pip
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // ---------------- phase 2: MFMA(t, k-half 1)  ||  reads (t+1, k-half 0)
-    if constexpr (MORE1 && !(DBG & 2)) read_frags(fa0, fb0, nxt, 0);
+    if constexpr (MORE1) read_frags(fa0, fb0, nxt, 0);
     mma(fa1, fb1);
     if constexpr (MORE1) {
 #pragma unroll
@@ -280,13 +305,13 @@ int launch_v(Args a, hipStream_t st) {
   constexpr int LDS = 3 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS, 0, LOADERS>,
+    (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS, LOADERS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  TASU_LAUNCH((gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS, 0, LOADERS>), dim3(a.tiles_m * a.tiles_n),
+  TASU_LAUNCH((gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS, LOADERS>), dim3(a.tiles_m * a.tiles_n),
               dim3(LOADERS ? 512 : 256), LDS, st, a);
   return TASU_OK;
 }
@@ -296,23 +321,8 @@ int launch(Args a, hipStream_t st) {
   return loaders_enabled() ? launch_v<BN, OUT_MODE, HAS_BIAS, true>(a, st) : launch_v<BN, OUT_MODE, HAS_BIAS, false>(a, st);
 }
 
-template <int BN, int DBG>
-int launch_dbg(Args a, hipStream_t st) {
-  constexpr int LDS = 3 * (BM + BN) * BK * 2;
-  (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<BN, 0, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  a.tiles_m = (a.M + BM - 1) / BM;
-  a.tiles_n = (a.N + BN - 1) / BN;
-  TASU_LAUNCH((gemm_pipe_kernel<BN, 0, false, DBG>), dim3(a.tiles_m * a.tiles_n), dim3(256), LDS, st, a);
-  return TASU_OK;
-}
-
 template <int OUT_MODE, bool HAS_BIAS>
 int launch_bn(const Args& a, int bn, hipStream_t st) {
-  static const int dbg = [] {
-    const char* e = getenv("TASU_PIPE_DBG");
-    return e ? atoi(e) : 0;
-  }();
-  if (dbg && bn == 128) return dbg == 1 ? launch_dbg<128, 1>(a, st) : dbg == 2 ? launch_dbg<128, 2>(a, st) : launch_dbg<128, 3>(a, st);
   return bn == 96 ? launch<96, OUT_MODE, HAS_BIAS>(a, st) : launch<128, OUT_MODE, HAS_BIAS>(a, st);
 }
 

@@ -80,41 +80,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
-// Streams [p, p + bytes) through the memory-side Infinity Cache (256 MB) with loads whose data is dropped: launched on
-// a side stream while a GEMM runs, it turns the NEXT GEMM's cold HBM weight reads into cache hits (measured on the
-// decoder shapes: 700-780 TFLOP/s on cold operands vs 890-1020 TFLOP/s on cache-resident ones).  One wave per block,
-// 8 x 16 B loads in flight per lane; policy 1 adds the `nt` (streaming) hint so the lines do not linger in the XCD L2s.
-template <int NT>
-__global__ __launch_bounds__(64) void cache_prefetch_kernel(const u32x4* p, size_t n16, unsigned* sink) {
-  const size_t stride = (size_t)gridDim.x * 64;
-  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-  u32x4 acc = u32x4{0u, 0u, 0u, 0u};
-  for (; i < n16; i += stride * 8) {
-    u32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const size_t j = i + (size_t)u * stride;
-      const u32x4* q = p + (j < n16 ? j : i);
-      v[u] = NT ? __builtin_nontemporal_load(q) : *q;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc ^= v[u];
-  }
-  // never true (n16 is a real size); keeps the loads alive without a store
-  if (n16 == ~(size_t)0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = acc.x;
-}
-
-extern "C" int tasu_cache_prefetch(const void* p, int64_t bytes, int blocks, int policy, void* stream) {
-  if (!p || bytes <= 0 || ((uintptr_t)p & 15) || blocks <= 0) return TASU_ERR_ARG;
-  const size_t n16 = (size_t)bytes / 16;
-  if (n16 == 0) return TASU_OK;
-  if (policy == 1)
-    TASU_LAUNCH(cache_prefetch_kernel<1>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, (const u32x4*)p, n16, (unsigned*)nullptr);
-  else
-    TASU_LAUNCH(cache_prefetch_kernel<0>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, (const u32x4*)p, n16, (unsigned*)nullptr);
-  return TASU_OK;
-}
-
 extern "C" int tasu_abi_version(void) { return TASU_ABI_VERSION; }
 
 extern "C" int tasu_posterior_build(const int32_t* ids, const float* alpha, float* out, int ld, int R, int V,

@@ -22,7 +22,6 @@ HBM layout (sized for 288 GB: everything stays resident, nothing is recomputed):
   * per layer saved for backward: x_in, x_mid (fp32), rstd1/2, rotated qkv, Q^T/K^T, attention out, lse, gate|up.
 """
 import math
-import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -243,31 +242,6 @@ class TasuModel:
         self.use_graphs = False
         self._graphs = {}
         self._graph_seen = {}
-        # Weight prefetch (MI355X-specific): the frozen decoder streams 6.2 GB of weights per step, each GEMM finding its
-        # weight operand cold in HBM (measured: 700-800 TFLOP/s cold vs 900-1020 with the weight in the 256 MB Infinity
-        # Cache).  A side stream pulls the NEXT GEMM's weights through the cache while kernels with little memory traffic
-        # run (attention, norms, the small GEMMs).  Level 0 = off, 1 = only in such quiet windows, 2 = also beside the
-        # HBM-bound SwiGLU kernels (for the weights whose use follows those).
-        self.prefetch = int(os.environ.get("TASU_PREFETCH", "0")) if self.device.type == "cuda" else 0
-        self.pf_blocks = int(os.environ.get("TASU_PREFETCH_BLOCKS", "512"))
-        self.pf_stream = torch.cuda.Stream(device=self.device) if self.prefetch else None
-        self._pf_forked = False
-
-    # ------------------------------------------------------------------------------------------ weight prefetch
-    def _pf(self, level, *tensors):
-        """Fork: from the point reached on the compute stream, stream `tensors` through the Infinity Cache on the side
-        stream (it starts when the kernels launched so far have finished and runs beside the ones launched next)."""
-        if self.prefetch < level:
-            return
-        self.pf_stream.wait_stream(torch.cuda.current_stream())
-        for t in tensors:
-            self.ops.cache_prefetch(t, self.pf_stream, self.pf_blocks)
-        self._pf_forked = True
-
-    def _pf_join(self):
-        if self._pf_forked:
-            torch.cuda.current_stream().wait_stream(self.pf_stream)
-            self._pf_forked = False
 
     # ------------------------------------------------------------------------------------------ weights
     def load_reference_state_dict(self, sd):
@@ -455,18 +429,13 @@ class TasuModel:
             x_in, x_mid, x_out = xs[2 * l], xs[2 * l + 1], xs[2 * l + 2]
             ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], geo.rms_eps)
             ops.gemm(xn, w["wqkv"], qkv[l], M, LDQ, D, bias=w["bqkv"])
-            self._pf(1, w["wo"], w["wgu"])                      # lands beside RoPE / attention / the o projection
             ops.rope_fwd(qkv[l], cos, sin, qt[l], kt[l], vt, B, S, H, G)
             ops.attn_fwd(qkv[l], vt, d["key_mask"], ao[l], lse[l], B, S, H, G, scale, True)
             ops.gemm(ao[l], w["wo"], x_mid, M, D, H * HD, resid=x_in, mode=GEMM_RESID)
             ops.rmsnorm_fwd(x_mid, w["ln2"], xn, rstd[2 * l + 1], geo.rms_eps)
             ops.gemm(xn, w["wgu"], gu[l], M, 2 * I, D)
-            self._pf(2, w["wd"])                                # beside SwiGLU (HBM-bound itself)
             ops.swiglu_fwd(gu[l], act, M, I)
-            if l + 1 < L:
-                self._pf(1, llm.layers[l + 1]["wqkv"])          # beside the down projection
             ops.gemm(act, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
-        self._pf_join()
         d.update(xs=xs, cos=cos, sin=sin, rstd=rstd, qkv=qkv, qt=qt, kt=kt, ao=ao, lse=lse, gu=gu)
         if logits_rows == "none":                              # decode prefill: the caller projects the last rows only
             return
@@ -515,17 +484,13 @@ class TasuModel:
         dvp = self._buf("dvp", (M, H * HD), f32)
         # lm_head dgrad (K = Vpad: dlogits pad columns are zero) and final norm
         ops.gemm(d["dlogits"], llm.head_t, dn, M, D, Vp)
-        self._pf(1, llm.layers[L - 1]["wd_t"])
         ops.rmsnorm_bwd(dn, xs[2 * L], llm.norm, rstd[2 * L], dx, dxb, False)
         for l in range(L - 1, -1, -1):
             w = llm.layers[l]
             x_in, x_mid = xs[2 * l], xs[2 * l + 1]
             ops.gemm(dxb, w["wd_t"], dact, M, I, D)
-            self._pf(2, w["wgu_t"])                             # beside swiglu_bwd (HBM-bound itself)
             ops.swiglu_bwd(dact, d["gu"][l], dgu, M, I)
             ops.gemm(dgu, w["wgu_t"], dn, M, D, 2 * I)
-            # beside the norm / o-projection / attention backward kernels: this layer's small weights, the next layer's wd^T
-            self._pf(1, w["wo_t"], w["wqkv_t"], *([llm.layers[l - 1]["wd_t"]] if l > 0 else []))
             ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
             ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)
             ops.attn_bwd_prep(dao, d["ao"][l], delta, dao_t, B, S, H)
@@ -535,7 +500,6 @@ class TasuModel:
             ops.rope_bwd(dqkv, dkp, dvp, cos, sin, B, S, H, G)
             ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)
             ops.rmsnorm_bwd(dn, x_in, w["ln1"], rstd[2 * l], dx, dxb, True)
-        self._pf_join()
         # merge backward: gradient rows that hold audio -> projector output gradient
         Rap, K, Kp, Hb, Do = st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
         audio_rows = d["audio_rows_pad"] if "audio_rows_pad" in d else self._pad_rows(st)

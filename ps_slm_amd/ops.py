@@ -52,11 +52,6 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_nt_bf16_ws(_p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), _p(resid), M, N, K, mode,
                                                 _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()), "tasu_gemm_nt_bf16_ws")
 
-    def cache_prefetch(self, t, stream, blocks=512, policy=0):
-        """Pull tensor t through the Infinity Cache on `stream` (a torch.cuda.Stream other than the compute stream)."""
-        self._chk(self.lib.tasu_cache_prefetch(_p(t), t.numel() * t.element_size(), blocks, policy, stream.cuda_stream),
-                  "tasu_cache_prefetch")
-
     def gemm_skinny(self, a, b, c, M, N, K, ws, bias=None, resid=None, mode=GEMM_BF16):
         """M <= 64 weight-streaming GEMM (decode step); ws: fp32 workspace tensor."""
         self._chk(self.lib.tasu_gemm_skinny_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(bias),
