@@ -1,16 +1,26 @@
-// Software-pipelined bf16 NT GEMM for gfx950: 256 x BN block tile (BN = 128 or 96), BK = 64, 4 waves (2 x 2), wave tile
-// 128 x BN/2, ONE wave per SIMD (1 block per CU), 3-stage LDS ring filled by global_load_lds_dwordx4.
+// Persistent, software-pipelined bf16 NT GEMM for gfx950.
 //
-// Why a second kernel next to gemm.hip: with 64x64 wave tiles the 128x128 kernel spends an LDS read for every two
-// MFMAs and hides latency only through the second wave of each SIMD.  Here a wave owns 128 x 64 (2.7 MFMAs per read,
-// a third less LDS traffic per FLOP) and hides its OWN latencies: each K-step is two phases of 32 MFMAs, and every
-// phase carries the 12 fragment reads of the NEXT phase and (first phase) the 12 LDS-DMA issues of the tile two steps
-// ahead, interleaved between the MFMAs with sched_group_barrier.  One raw s_barrier per K-step sits between the two
-// phases; tile t+1 is awaited with a COUNTED s_waitcnt vmcnt(12) that leaves tile t+2 in flight (a __syncthreads would
-// drain it).  Ring safety: buffer (t+2)%3 == (t-1)%3 is refilled only after barrier(t-1), before which every wave
-// waited for its last reads of tile t-1 (lgkmcnt(0)).
-#include <stdlib.h>
-
+// One 512-thread workgroup per CU walks a static list of 256 x BN output tiles (BN = 128 or 96, BK = 64):
+//   * waves 0..3 ("MFMA waves", one per SIMD, 2 x 2 over the tile, wave tile 128 x BN/2) carry fragment reads and MFMAs
+//     only.  Each K-step is two phases of 32 (24) MFMAs; every phase carries the 12 (11) ds_read_b128 of the NEXT phase,
+//     interleaved with sched_group_barrier, so a wave hides its own LDS latency; one raw s_barrier per K-step sits
+//     between the phases.
+//   * waves 4..7 ("loader waves") do nothing but fill a 3-slot LDS ring two K-steps ahead with
+//     buffer_load_dwordx4 ... lds (base = the tile's first A / B row in a buffer descriptor, per-lane 32-bit offset fixed
+//     per tile, K offset in an SGPR) and wait for it with a counted vmcnt that leaves the newest slot in flight.
+//     Why separate waves: an LDS-DMA costs its issuing wave ~100 cycles of address processing during which that wave's
+//     MFMA queue drains.  Measured on the 4-wave predecessor of this kernel (8192^3, warm): MFMA + barrier alone
+//     1.94 PFLOP/s, + fragment reads 1.60, + LDS-DMA issue 1.10; with loader waves 1.30, with descriptor addressing 1.37.
+//   * the ring does not stop at tile boundaries: while the MFMA waves convert and store a finished tile, the first two
+//     K-steps of the workgroup's next tile are already landing, and the stores drain under the next tile's MFMAs
+//     (the MFMA waves never wait on vmcnt).  Measured against the same kernel launched one tile per workgroup: equal within
+//     noise on the decoder shapes (the per-tile cost that remains, ~4 us of a 25-us K = 1536 tile, is the epilogue's own
+//     issue time plus the write of C itself: time = 35 us + K * 0.115 us for 4096 x 17920, i.e. 1.27 PFLOP/s asymptotic).
+//
+// Ring safety: slot (q+2)%3 == (q-1)%3 is refilled after barrier(q-1), before which every MFMA wave waited for its last
+// reads of step q-1 (lgkmcnt(0)); step q+1 is complete in LDS before barrier(q) because every loader waited for its own
+// share first.  The LDS image is lane-linear per 1-KiB piece (8 rows x 128 B), so the bank swizzle (16-B chunk c of row r
+// at chunk c ^ ((r>>1)&7)) is applied on the per-lane SOURCE offset and again on the ds_read_b128 address.
 #include <type_traits>
 
 #include "common.h"
@@ -32,117 +42,109 @@ struct Args {
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
 
-//
-// LOADERS: the block gets four more waves (4..7) that do nothing but issue the LDS-DMA of the ring and wait for it; the
-// four MFMA waves then carry fragment reads and MFMAs only.  Measured on this kernel (8192^3, warm): MFMA + barrier alone
-// 1.94 PFLOP/s, + fragment reads 1.60, + LDS-DMA issue 1.10 -- a global_load_lds costs its issuing wave ~100 cycles of
-// address processing during which that wave's MFMA queue drains, so the issue is moved to waves that have none.
-template <int BN, int OUT_MODE, bool HAS_BIAS, bool LOADERS>
-__global__ __launch_bounds__(LOADERS ? 512 : 256, LOADERS ? 1 : 2) void gemm_pipe_kernel(Args p) {
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int WM = 128, WN = BN / 2, MI = WM / 16, NI = WN / 16;
-  constexpr int PA = BM / 32, PB = BN / 32;       // LDS-DMA pieces per wave per tile: 8 + 4 (or 3)
-  constexpr int NG = PA + PB;                      // vmcnt units per tile per wave
-  constexpr int NR = MI + NI;                      // fragment reads per phase
-  constexpr int NM = MI * NI;                      // MFMAs per phase
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
-  const bool is_loader = LOADERS && wave_id >= 4;
-  const int wave = wave_id & 3;                    // staging share (loader) / tile quadrant (MFMA wave)
-  const int wr = wave >> 1, wc = wave & 1;
-
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+// tile s of the virtual one-tile-per-block grid -> (tm, tn): XCD-aware (block b and tile s = b + r*gridDim share b % 8,
+// i.e. the XCD, because gridDim is a multiple of 8), bijective, then a 4-row-group raster for L2 reuse of the B panel.
+__device__ __forceinline__ void tile_coords(const Args& p, int s, int ntiles, int& tm, int& tn) {
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = s & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (s >> 3);
   constexpr int GROUP_M = 4;
   const int per_group = GROUP_M * p.tiles_n;
   const int gid = logical / per_group;
   const int first_m = gid * GROUP_M;
   const int gsz = min(p.tiles_m - first_m, GROUP_M);
   const int in_g = logical - gid * per_group;
-  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
-  const int row0 = tm * BM, col0 = tn * BN;
+  tm = first_m + in_g % gsz;
+  tn = in_g / gsz;
+}
 
-  const bf16* ga[PA];
-  const bf16* gb[PB];
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const int r = (wave * PA + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    ga[i] = p.A + (size_t)min(row0 + r, p.M - 1) * p.lda + c * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < PB; ++i) {
-    const int r = (wave * PB + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    gb[i] = p.B + (size_t)min(col0 + r, p.N - 1) * p.ldb + c * 8;
-  }
-  // Loader waves address through buffer descriptors (base = the block's first A / B row, per-lane 32-bit byte offset
-  // fixed for the whole K loop, the K offset in an SGPR): no per-K-step address VALU and a cheaper issue than the
-  // 64-bit-pointer global form (buffer_load_dwordx4 ... offen lds).
-#if defined(__HIP_DEVICE_COMPILE__)   // the buffer builtins exist in the device pass only
-  const __amdgpu_buffer_rsrc_t rsA =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)row0 * p.lda), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (size_t)col0 * p.ldb), 0, 0x7fffffff, 0x00020000);
-#endif
-  int voa[PA], vob[PB];
-#pragma unroll
-  for (int i = 0; i < PA; ++i) voa[i] = (int)((ga[i] - (p.A + (size_t)row0 * p.lda)) * 2);
-#pragma unroll
-  for (int i = 0; i < PB; ++i) vob[i] = (int)((gb[i] - (p.B + (size_t)col0 * p.ldb)) * 2);
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * STAGE;
-    const int koff = kt * BK;
-    if constexpr (LOADERS) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-      for (int i = 0; i < PA; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (wave * PA + i) * 1024), 16, voa[i], koff * 2, 0, 0);
-#pragma unroll
-      for (int i = 0; i < PB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (wave * PB + i) * 1024), 16, vob[i],
-                                                 koff * 2, 0, 0);
-#endif
-    } else {
-#pragma unroll
-      for (int i = 0; i < PA; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(base + (wave * PA + i) * 1024), 16, 0, 0);
-#pragma unroll
-      for (int i = 0; i < PB; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(base + A_BYTES + (wave * PB + i) * 1024), 16,
-                                         0, 0);
-    }
-  };
-
+template <int BN, int OUT_MODE, bool HAS_BIAS>
+__global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int WM = 128, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+  constexpr int PA = BM / 32, PB = BN / 32;       // LDS-DMA pieces per loader wave per K-step: 8 + 4 (or 3)
+  constexpr int NG = PA + PB;                      // vmcnt units per K-step per loader wave
+  constexpr int NR = MI + NI;                      // fragment reads per phase
+  constexpr int NM = MI * NI;                      // MFMAs per phase
+  static_assert(NG == 12 || NG == 11, "the counted vmcnt immediates below assume 12 or 11 pieces per K-step");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
+  const int wave = wave_id & 3;                    // staging share (loader) / tile quadrant (MFMA wave)
   const int nk = p.K / BK;
-  if (LOADERS && is_loader) {
-    stage(0, 0);
-    if (nk > 1) {
-      stage(1, 1);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  [[maybe_unused]] const int total = my_tiles * nk;  // K-steps this workgroup walks, across all its tiles
+
+  if (wave_id >= 4) {
+    // ================================================================ loader waves
+#if defined(__HIP_DEVICE_COMPILE__)                 // the buffer builtins exist in the device pass only
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    int voa[PA], vob[PB];
+    int ld_tile = blockIdx.x, ld_k = 0;            // load cursor (runs two K-steps ahead of the MFMA waves)
+    auto setup = [&](int s) {
+      int tm, tn;
+      tile_coords(p, s, ntiles, tm, tn);
+      const int row0 = tm * BM, col0 = tn * BN;
+      rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)row0 * p.lda), 0, 0x7fffffff, 0x00020000);
+      rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (size_t)col0 * p.ldb), 0, 0x7fffffff, 0x00020000);
+      // piece pc = 8 tile rows x 128 B; lane l -> tile row pc*8 + (l>>3), LDS chunk l&7 <- global chunk (l&7)^((row>>1)&7)
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int r = (wave * PA + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        voa[i] = (min(row0 + r, p.M - 1) - row0) * p.lda * 2 + c * 16;
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int r = (wave * PB + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        vob[i] = (min(col0 + r, p.N - 1) - col0) * p.ldb * 2 + c * 16;
+      }
+    };
+    auto issue = [&](int slot) {
+      char* base = smem + slot * STAGE;
+      const int koff = ld_k * (BK * 2);
+#pragma unroll
+      for (int i = 0; i < PA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (wave * PA + i) * 1024), 16, voa[i], koff, 0, 0);
+#pragma unroll
+      for (int i = 0; i < PB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (wave * PB + i) * 1024), 16, vob[i], koff,
+                                                 0, 0);
+      if (++ld_k == nk) {
+        ld_k = 0;
+        ld_tile += gridDim.x;
+        if (ld_tile < ntiles) setup(ld_tile);
+      }
+    };
+    setup(ld_tile);
+    issue(0);
+    if (total > 1) {
+      issue(1);
       if (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    int slot2 = 2;                                 // ring slot of tile t+2
-    for (int t = 0; t < nk; ++t) {
-      if (t + 2 < nk) {
-        stage(slot2, t + 2);
+    int slot2 = 2;                                 // ring slot of step q+2
+    for (int q = 0; q < total; ++q) {
+      if (q + 2 < total) {
+        issue(slot2);
         if (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __builtin_amdgcn_s_barrier();                // tile t+1 is in LDS; every MFMA wave is done with tile t-1... (see below)
+      __builtin_amdgcn_s_barrier();                // step q+1 is in LDS; slot (q-1)%3 is free (see "Ring safety" above)
       slot2 = slot2 == 2 ? 0 : slot2 + 1;
     }
+#endif
     return;
   }
 
+  // ================================================================== MFMA waves
+  const int wr = wave >> 1, wc = wave & 1;
   const int sw = (lane >> 1) & 7;
   int roff[2];
 #pragma unroll
@@ -159,10 +161,12 @@ __global__ __launch_bounds__(LOADERS ? 512 : 256, LOADERS ? 1 : 2) void gemm_pip
   };
 
   f32x4 acc[MI][NI];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
   auto mma = [&](bf16x8 (&fa)[MI], bf16x8 (&fb)[NI]) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -171,54 +175,33 @@ __global__ __launch_bounds__(LOADERS ? 512 : 256, LOADERS ? 1 : 2) void gemm_pip
   };
 
   bf16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
-  // ---- prologue: tiles 0 and 1 in flight, wait for tile 0, first fragments
-  if (!LOADERS) {
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    if (nk > 1) {
-      if (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __builtin_amdgcn_s_barrier();
+  zero_acc();
+  __builtin_amdgcn_s_barrier();                    // step 0 is in LDS
   asm volatile("" ::: "memory");
   read_frags(fa0, fb0, 0, 0);
 
-  // One K-step.  MORE2: tile t+2 exists (its LDS-DMA is issued here); MORE1: tile t+1 exists (awaited + first reads).
+  // One K-step.  MORE: a next step exists (possibly the first of the next tile): its first fragments are read in phase 2.
   // Straight-line code (no branches inside) so that sched_group_barrier can interleave across the whole phase.
-  auto kstep = [&](auto more2_tag, auto more1_tag, int t, int cur) {
-    constexpr bool MORE2 = decltype(more2_tag)::value, MORE1 = decltype(more1_tag)::value;
-    const int nxt = cur == 2 ? 0 : cur + 1;      // slot of tile t+1
-    const int nx2 = nxt == 2 ? 0 : nxt + 1;      // slot of tile t+2 (== slot of tile t-1)
-    // ---------------- phase 1: MFMA(t, k-half 0)  ||  reads (t, k-half 1)  ||  LDS-DMA of tile t+2
-    if constexpr (MORE2 && !LOADERS) stage(nx2, t + 2);
+  auto kstep = [&](auto more_tag, int cur) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const int nxt = cur == 2 ? 0 : cur + 1;
+    // ---------------- phase 1: MFMA(q, k-half 0)  ||  reads (q, k-half 1)
     read_frags(fa1, fb1, cur, 1);
     mma(fa0, fb0);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                     // 2 MFMA
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     // 1 DS read
-      if constexpr (MORE2 && !LOADERS) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM (LDS-DMA issue)
     }
     __builtin_amdgcn_sched_group_barrier(0x008, NM - 2 * NR, 0);
-    // ---------------- hand-over: my reads of tile t are done; tile t+1 has landed (tile t+2 may stay in flight)
-    if constexpr (MORE1 && !LOADERS) {
-      if constexpr (MORE2) {
-        if constexpr (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
+    // ---------------- hand-over: my reads of step q are done (slot reusable); step q+1 has landed (loaders waited)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // ---------------- phase 2: MFMA(t, k-half 1)  ||  reads (t+1, k-half 0)
-    if constexpr (MORE1) read_frags(fa0, fb0, nxt, 0);
+    // ---------------- phase 2: MFMA(q, k-half 1)  ||  reads (q+1, k-half 0)
+    if constexpr (MORE) read_frags(fa0, fb0, nxt, 0);
     mma(fa1, fb1);
-    if constexpr (MORE1) {
+    if constexpr (MORE) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
@@ -228,97 +211,107 @@ __global__ __launch_bounds__(LOADERS ? 512 : 256, LOADERS ? 1 : 2) void gemm_pip
     }
     return nxt;
   };
-  using T = std::true_type;
-  using F = std::false_type;
-  int cur = 0;                                   // ring slot of tile t
-  int t = 0;
-  for (; t + 2 < nk; ++t) cur = kstep(T{}, T{}, t, cur);
-  if (t + 1 < nk) {
-    cur = kstep(F{}, T{}, t, cur);
-    ++t;
-  }
-  kstep(F{}, F{}, t, cur);
 
-  // ---- epilogue: acc[i][j][r] = C[m][n], m = row0 + wr*128 + i*16 + (lane&15), n = col0 + wc*WN + j*16 + (lane>>4)*4 + r
+  // acc[i][j][r] = C[m][n], m = row0 + wr*128 + i*16 + (lane&15), n = col0 + wc*WN + j*16 + (lane>>4)*4 + r
+  auto store_tile = [&](int row0, int col0) {
+    // opaque copies of the lane coordinates: keeps the 32 per-fragment output addresses from being hoisted out of the
+    // tile loop into registers that the K loop needs (the kernel sits at the 256-VGPR limit of two waves per SIMD)
+    int l15 = lane & 15, l4 = (lane >> 4) * 4;
+    asm volatile("" : "+v"(l15), "+v"(l4));
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = row0 + wr * WM + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
+    for (int i = 0; i < MI; ++i) {
+      asm volatile("" ::: "memory");               // one row block at a time: bounds the loads the scheduler batches
+      const int m = row0 + wr * WM + i * 16 + l15;
+      if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = col0 + wc * WN + j * 16 + (lane >> 4) * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if (HAS_BIAS) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) v[r] += (float)p.bias[n + r];
-      }
-      const size_t off = (size_t)m * p.ldc + n;
-      const bool full = (n + 4 <= p.N) && ((off & 3) == 0);
-      if (OUT_MODE == TASU_GEMM_OUT_BF16) {
-        bf16* c = (bf16*)p.C + off;
-        const bf16x4 o = __builtin_convertvector(v, bf16x4);
-        if (full) {
-          *(bf16x4*)c = o;
-        } else {
+      for (int j = 0; j < NI; ++j) {
+        const int n = col0 + wc * WN + j * 16 + l4;
+        if (n >= p.N) continue;
+        f32x4 v = acc[i][j];
+        if (HAS_BIAS) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) c[r] = o[r];
+            if (n + r < p.N) v[r] += (float)p.bias[n + r];
         }
-      } else if (OUT_MODE == TASU_GEMM_OUT_F32) {
-        float* c = (float*)p.C + off;
-        if (full) {
-          *(f32x4*)c = v;
-        } else {
+        const size_t off = (size_t)m * p.ldc + n;
+        const bool full = (n + 4 <= p.N) && ((off & 3) == 0);
+        if (OUT_MODE == TASU_GEMM_OUT_BF16) {
+          bf16* c = (bf16*)p.C + off;
+          const bf16x4 o = __builtin_convertvector(v, bf16x4);
+          if (full) {
+            *(bf16x4*)c = o;
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) c[r] = v[r];
-        }
-      } else {
-        float* c = (float*)p.C + off;
-        const float* rs = p.R + off;
-        const f32x4 rr = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
-        if (full) {
-          const f32x4 old = *(const f32x4*)rs;
-          *(f32x4*)c = old + rr;
-        } else {
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) c[r] = o[r];
+          }
+        } else if (OUT_MODE == TASU_GEMM_OUT_F32) {
+          float* c = (float*)p.C + off;
+          if (full) {
+            *(f32x4*)c = v;
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) c[r] = rs[r] + rr[r];
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) c[r] = v[r];
+          }
+        } else {  // TASU_GEMM_OUT_F32_RESID_BF16R: C(fp32) = R(fp32) + bf16_round(result)
+          float* c = (float*)p.C + off;
+          const float* rs = p.R + off;
+          const f32x4 rr = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
+          if (full) {
+            const f32x4 old = *(const f32x4*)rs;
+            *(f32x4*)c = old + rr;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) c[r] = rs[r] + rr[r];
+          }
         }
       }
     }
+  };
+
+  using T = std::true_type;
+  using F = std::false_type;
+  int cur = 0;                                     // ring slot of the current step
+  for (int s = blockIdx.x; s < ntiles; s += gridDim.x) {
+    int tm, tn;
+    tile_coords(p, s, ntiles, tm, tn);
+    for (int kt = 0; kt + 1 < nk; ++kt) cur = kstep(T{}, cur);
+    cur = kstep(F{}, cur);                         // no read-ahead into the next tile: the fragment registers are free
+    store_tile(tm * BM, tn * BN);                  // for the epilogue, whose stores then drain under the next tile
+    zero_acc();
+    if (s + (int)gridDim.x < ntiles) read_frags(fa0, fb0, cur, 0);   // landed before the barrier of the step just done
   }
 }
 
-int loaders_enabled() {
-  static const int v = [] {
-    const char* e = getenv("TASU_PIPE_LOADERS");
-    return e ? atoi(e) : 1;
+int cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    return cus >= 8 ? (cus & ~7) : 8;              // a multiple of 8 keeps a workgroup's tiles on one XCD
   }();
-  return v;
+  return n;
 }
 
-template <int BN, int OUT_MODE, bool HAS_BIAS, bool LOADERS>
-int launch_v(Args a, hipStream_t st) {
+template <int BN, int OUT_MODE, bool HAS_BIAS>
+int launch(Args a, hipStream_t st) {
   constexpr int LDS = 3 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS, LOADERS>,
+    (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  TASU_LAUNCH((gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS, LOADERS>), dim3(a.tiles_m * a.tiles_n),
-              dim3(LOADERS ? 512 : 256), LDS, st, a);
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int grid = ntiles < cu_count() ? ntiles : cu_count();
+  TASU_LAUNCH((gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS>), dim3(grid), dim3(512), LDS, st, a);
   return TASU_OK;
-}
-
-template <int BN, int OUT_MODE, bool HAS_BIAS>
-int launch(Args a, hipStream_t st) {
-  return loaders_enabled() ? launch_v<BN, OUT_MODE, HAS_BIAS, true>(a, st) : launch_v<BN, OUT_MODE, HAS_BIAS, false>(a, st);
 }
 
 template <int OUT_MODE, bool HAS_BIAS>

@@ -15,6 +15,7 @@ ap.add_argument("M", nargs="?", type=int, default=4096)
 ap.add_argument("--cold", action="store_true")
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--only", default="")
+ap.add_argument("--shape", action="append", default=[], help="extra M,N,K (repeatable); implies --only custom")
 args = ap.parse_args()
 ops = HipOps()
 M = args.M
@@ -23,6 +24,9 @@ shapes = [("qkv", M, 2048, 1536), ("o", M, 1536, 1536), ("gate_up", M, 17920, 15
           ("d_lm_head", M, 1536, 151936), ("proj1", 1664, 2048, 25088), ("wgrad1", 2048, 25088, 1664),
           ("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192)]
 only = set(filter(None, args.only.split(",")))
+if args.shape:
+    shapes = [("custom", *map(int, sh.split(","))) for sh in args.shape]
+    only = set()
 res = []
 for name, m, n, k in shapes:
     if only and name not in only:
