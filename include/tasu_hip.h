@@ -50,12 +50,16 @@ int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C
                          const float* resid, int M, int N, int K, int out_mode, void* workspace,
                          int64_t workspace_bytes, void* stream);
 
-/* Weight-streaming variant for M <= 64 rows (the decode step, M = batch x beams): HBM-bound, split-K over the grid
- * with a deterministic fp32 slab reduction.  workspace: >= ksplit*64*round_up(N,64) floats (16 x 64 x round_up(N,64)
- * always suffices); may be NULL (no K split).  Same operand rules and out_mode as tasu_gemm_nt_bf16.             */
+/* Weight-streaming GEMM for M <= 64 rows (the decode step; transformers modeling_qwen2.py linears at one token per beam).
+ * workspace: fp32 split-K slabs, 32 * 64 * round_up(N, 96) floats always suffice; may be NULL (no K split).  Launches
+ * sharing a workspace must be ordered on one stream.  Operand rules and out_mode as tasu_gemm_nt_bf16.              */
 int tasu_gemm_skinny_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                           const float* resid, int M, int N, int K, int out_mode, float* workspace,
                           int64_t workspace_floats, void* stream);
+/* Qwen2MLP gate|up projection + activation in one launch (modeling_qwen2.py Qwen2MLP.forward, M <= 64):
+ * act[M, I] = bf16( bf16(silu(g)) * u ),  g | u = bf16(A[M,K] . Wgu[2I,K]^T)  (gate rows first, then up rows).        */
+int tasu_gemm_skinny_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,
+                            float* workspace, int64_t workspace_floats, void* stream);
 
 /* Tiled transpose out[c][r] = in[r][c], bf16 (used to feed wgrad through the NT GEMM). rows<=R and
  * cols<=C outside [R,C) of `out` up to (Cpad, Rpad) are written as zero so K-padding stays exact.       */
@@ -195,24 +199,34 @@ int tasu_psd_gather(const float* post, int ldp, const int32_t* seg_start, const 
 /* ------------------------------------------------------------------------------------------- decode loop
  * ps-slm.py:660-675 -> HF GenerationMixin beam search (num_beams 4, max_new_tokens 200, greedy-beam) with a KV cache.
  * Cache layout: k/v cache [M = B*n_beams, ctx, G*128] bf16 (row = beam, position-major so that appending one token
- * is one contiguous write).
- * kv_fill: copy the rotated K and V of a prefill qkv activation [B*S, (H+2G)*128] into every beam row of the cache. */
+ * is one contiguous write) plus a ROW INDEX [M, ctx] int32: index[m, i] = the cache row that physically holds position
+ * i of beam m.  The prompt is stored once per utterance (row of its first beam); a beam reorder
+ * (Cache.reorder_cache) permutes index rows -- 4 bytes per position for all layers -- instead of copying K/V.
+ * kv_fill: copy the rotated K and V of a prefill qkv activation [B*S, (H+2G)*128] into cache row b*n_beams. */
 int tasu_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int S, int H, int G, int n_beams, int ctx,
                  void* stream);
-/* kv_append: cache[row, pos[row]] = k|v of the single-token qkv activation [M, (H+2G)*128]. */
+/* kv_append: cache[row, pos[row]] = k|v of the single-token qkv activation [M, (H+2G)*128] (a beam appends to ITS row). */
 int tasu_kv_append(const void* qkv, void* kcache, void* vcache, const int32_t* pos, int M, int H, int G, int ctx,
                    void* stream);
-/* kv_gather: dst[row, :lens[row]] = src[src_row[row], :lens[row]] -- beam reorder (Cache.reorder_cache). */
-int tasu_kv_gather(const void* src_k, const void* src_v, void* dst_k, void* dst_v, const int32_t* src_row,
-                   const int32_t* lens, int M, int G, int ctx, void* stream);
-/* Single-token GQA attention over the cache: keys [kstart[row], lens[row]) visible (left padding / current length);
- * out [M, H*128] bf16.  ctx <= 2048, (H/G)*64 <= 1024. */
-int tasu_attn_decode(const void* qkv, const void* kcache, const void* vcache, const int32_t* kstart,
-                     const int32_t* lens, void* out, int M, int H, int G, int ctx, float scale, void* stream);
-/* log_softmax + top-k per row of bf16 logits [M, ld]: out_val[M,k] (descending log-probs), out_idx[M,k] (token ids);
- * the n_banned ids in `banned` (device) score -inf after the softmax (MinLengthLogitsProcessor). k in {1,2,4,6,8,16}. */
+/* rope_append (decode step): rotate q and k of the single-token qkv activation [M, (H+2G)*128] in place (tables
+ * [M, 64] from tasu_rope_table) and write the rotated k and v to cache[row, pos[row]] -- tasu_rope_fwd + kv_append. */
+int tasu_rope_append(void* qkv, const float* cos_tab, const float* sin_tab, void* kcache, void* vcache, const int32_t* pos,
+                     int M, int H, int G, int ctx, void* stream);
+/* index[m, i] = (m / n_beams) * n_beams for i < S (shared prompt), m for i >= S. */
+int tasu_kv_index_init(int32_t* index, int B, int n_beams, int S, int ctx, void* stream);
+/* dst[m, :lens[m]] = src[src_row[m], :lens[m]] (src_row NULL = identity); dst != src; entries >= lens[m] untouched. */
+int tasu_kv_index_reorder(const int32_t* src_index, int32_t* dst_index, const int32_t* src_row, const int32_t* lens, int M,
+                          int ctx, void* stream);
+/* Single-token GQA attention over the cache: keys [kstart[row], lens[row]) visible (left padding / current length),
+ * key i read from cache row row_index[row, i] (row_index NULL: the row itself); out [M, H*128] bf16.  ctx <= 2048. */
+int tasu_attn_decode(const void* qkv, const void* kcache, const void* vcache, const int32_t* row_index,
+                     const int32_t* kstart, const int32_t* lens, void* out, int M, int H, int G, int ctx, float scale,
+                     void* stream);
+/* log_softmax + top-k per row of bf16 logits [M, ld]: out_val[M,k] (descending log-probs), out_idx[M,k] (token ids;
+ * ties: smaller id first); the n_banned ids in `banned` (device) score -inf after the softmax
+ * (MinLengthLogitsProcessor).  k in {1,2,4,6,8,16}.  workspace: M * 16 * (2 + 2k) floats (column-part partials).     */
 int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned,
-                      float* out_val, int32_t* out_idx, void* stream);
+                      float* out_val, int32_t* out_idx, float* workspace, int64_t workspace_floats, void* stream);
 /* x[m,:] = table[ids[m],:] (fp32 embedding rows of the last generated tokens). */
 int tasu_embed_rows(const float* table, const int32_t* ids, float* x, int M, int D, void* stream);
 

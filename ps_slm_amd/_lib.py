@@ -51,9 +51,12 @@ PROTOTYPES = {
     "tasu_psd_gather": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tasu_kv_fill": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tasu_kv_append": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    "tasu_kv_gather": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    "tasu_attn_decode": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
-    "tasu_logprob_topk": [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp],
+    "tasu_gemm_skinny_swiglu": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i64, vp],
+    "tasu_rope_append": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "tasu_kv_index_init": [vp, i32, i32, i32, i32, vp],
+    "tasu_kv_index_reorder": [vp, vp, vp, vp, i32, i32, vp],
+    "tasu_attn_decode": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "tasu_logprob_topk": [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i64, vp],
     "tasu_embed_rows": [vp, vp, vp, i32, i32, vp],
 }
 

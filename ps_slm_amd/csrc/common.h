@@ -69,3 +69,5 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 __device__ __forceinline__ float bf16_round(float x) { return (float)(bf16)x; }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }

@@ -7,7 +7,8 @@
 namespace {
 constexpr int HD = 128;
 
-// cache[(b*nb + j), s, :] = k|v block of qkv[(b*S + s), :]   for every beam j.   grid (S, B), block 256
+// cache[b*nb, s, :] = k|v block of qkv[(b*S + s), :]: the prompt is stored ONCE per utterance, in the cache row of its
+// first beam; the other beams reach it through the row index (kv_index_*).   grid (S, B), block 256
 __global__ __launch_bounds__(256) void kv_fill_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kc, bf16* __restrict__ vc,
                                                       int S, int H, int G, int nb, int ctx) {
   const int s = blockIdx.x, b = blockIdx.y;
@@ -17,8 +18,61 @@ __global__ __launch_bounds__(256) void kv_fill_kernel(const bf16* __restrict__ q
     const bf16x8 v = *(const bf16x8*)(src + c);
     bf16* base = c < W ? kc : vc;
     const int cc = c < W ? c : c - W;
-    for (int j = 0; j < nb; ++j) *(bf16x8*)(base + (((size_t)(b * nb + j)) * ctx + s) * W + cc) = v;
+    *(bf16x8*)(base + (((size_t)b * nb) * ctx + s) * W + cc) = v;
   }
+}
+
+// Decode-step RoPE + cache append: one block per row; thread t rotates 8-element chunk pairs (x[d], x[d+64]) of the H query
+// and G key heads in place and copies the rotated keys and the values into cache[row, pos[row]].
+__global__ __launch_bounds__(256) void rope_append_kernel(bf16* __restrict__ qkv, const float* __restrict__ ct,
+                                                          const float* __restrict__ st, bf16* __restrict__ kc,
+                                                          bf16* __restrict__ vc, const int32_t* __restrict__ pos, int H, int G,
+                                                          int ctx) {
+  const int row = blockIdx.x;
+  const int LD = (H + 2 * G) * HD, W = G * HD;
+  bf16* x = qkv + (size_t)row * LD;
+  const size_t slot = ((size_t)row * ctx + pos[row]) * W;
+  const float* cr = ct + (size_t)row * 64;
+  const float* sr = st + (size_t)row * 64;
+  for (int u = threadIdx.x; u < (H + G) * 8; u += 256) {       // unit = (head, 8-wide chunk of the low half)
+    const int hh = u >> 3, c = (u & 7) * 8;
+    bf16* hp = x + hh * HD;
+    bf16x8 lo = *(const bf16x8*)(hp + c), hi = *(const bf16x8*)(hp + 64 + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float cs = cr[c + j], sn = sr[c + j];
+      const float x1 = (float)lo[j], x2 = (float)hi[j];
+      lo[j] = (bf16)(x1 * cs - x2 * sn);
+      hi[j] = (bf16)(x2 * cs + x1 * sn);
+    }
+    *(bf16x8*)(hp + c) = lo;
+    *(bf16x8*)(hp + 64 + c) = hi;
+    if (hh >= H) {
+      bf16* kd = kc + slot + (hh - H) * HD;
+      *(bf16x8*)(kd + c) = lo;
+      *(bf16x8*)(kd + 64 + c) = hi;
+    }
+  }
+  for (int c = threadIdx.x * 8; c < W; c += 256 * 8) *(bf16x8*)(vc + slot + c) = *(const bf16x8*)(x + (H + G) * HD + c);
+}
+
+// Row index of the beam-shared cache: index[m, i] = physical cache row that holds position i of logical row (beam) m.
+// init: prompt positions point at the utterance's first beam, generated positions at the row itself.
+__global__ __launch_bounds__(256) void kv_index_init_kernel(int32_t* __restrict__ index, int nb, int S, int ctx, int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int m = e / ctx, i = e - m * ctx;
+  index[e] = i < S ? (m / nb) * nb : m;
+}
+// beam reorder (HF Cache.reorder_cache) on the index instead of on the cache: dst[m, :lens[m]] = src[src_row[m], :lens[m]];
+// positions >= lens[m] keep their value (the identity written by init: a row always appends into itself).  grid (M)
+__global__ __launch_bounds__(256) void kv_index_reorder_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst,
+                                                               const int32_t* __restrict__ src_row,
+                                                               const int32_t* __restrict__ lens, int ctx) {
+  const int m = blockIdx.x;
+  const int n = lens[m];
+  const int32_t* s = src + (size_t)(src_row ? src_row[m] : m) * ctx;
+  for (int i = threadIdx.x; i < n; i += 256) dst[(size_t)m * ctx + i] = s[i];
 }
 
 // cache[row, pos[row], :] = k|v block of qkv[row, :]     grid (M), block 128
@@ -37,29 +91,16 @@ __global__ __launch_bounds__(128) void kv_append_kernel(const bf16* __restrict__
   }
 }
 
-// dst[row, 0:len[row], :] = src[src_row[row], 0:len[row], :]  (beam reorder; ping-pong buffers)   grid (ctx_blocks, M)
-__global__ __launch_bounds__(256) void kv_gather_kernel(const bf16* __restrict__ sk, const bf16* __restrict__ sv, bf16* __restrict__ dk,
-                                                        bf16* __restrict__ dv, const int32_t* __restrict__ src_row,
-                                                        const int32_t* __restrict__ lens, int W, int ctx) {
-  const int row = blockIdx.y;
-  const int n = lens[row];
-  const int sr = src_row[row];
-  const int per = (W / 8);                     // 16-byte chunks per position
-  const size_t total = (size_t)n * per;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t off = i * 8;
-    *(bf16x8*)(dk + (size_t)row * ctx * W + off) = *(const bf16x8*)(sk + (size_t)sr * ctx * W + off);
-    *(bf16x8*)(dv + (size_t)row * ctx * W + off) = *(const bf16x8*)(sv + (size_t)sr * ctx * W + off);
-  }
-}
-
-// Single-token GQA attention over the cache, flash-decoding style inside one block per (row, kv group):
-// the 8 waves split the KEYS (not the heads), so every K / V row is read once for all REP query heads of the group
-// and the serial chain per wave is nk/8 keys long.
-//   phase 1  scores: 16 lanes per key (one 16-byte load each: a wave instruction reads 4 whole 256-B K rows), REP dot
-//            products per key from q kept in registers, xor-shuffle reduction, scores -> LDS [REP][ctx]
+// Single-token GQA attention over the cache: one 8-wave block per (row, kv group); memory-bound (every K / V byte of the
+// row's cache is read once for all REP query heads of the group), so the design goal is wide loads and many of them in
+// flight, not arithmetic:
+//   phase 1  scores on the matrix cores: a wave takes 16 keys at a time; lane l loads 16 B of key (l & 15) for each of the
+//            four 32-wide slices of the head dimension, which is exactly the B operand of mfma_f32_16x16x32_bf16
+//            (B[k][n] = K[key n][dim k]); the A operand holds the REP query heads in rows 0..REP-1 (rows >= REP zero).
+//            4 MFMAs per 16 keys, no shuffles; scaled scores -> LDS [REP][ctx]
 //   phase 1b softmax statistics per head (wave h), probabilities (bf16-rounded like the prefill kernel) back to LDS
-//   phase 2  P.V: lane owns dims 2*lane, 2*lane+1 of its wave's key range for all REP heads; partials -> LDS
+//   phase 2  P.V: lane owns 8 dims (one 16-B load covers them, 16 lanes a whole 256-B V row, a wave instruction 4 keys)
+//            for all REP heads; 4 loads in flight; key quarters folded with two xor-shuffles, waves through LDS
 //   phase 3  cross-wave sum, 1/l, bf16 store
 // keys in [kstart[row], lens[row]) are visible.  ctx <= MAX_CTX.
 constexpr int MAX_CTX = 2048;
@@ -67,53 +108,52 @@ constexpr int DEC_NW = 8;
 template <int REP>
 __global__ __launch_bounds__(64 * DEC_NW) void attn_decode_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ kc,
                                                                   const bf16* __restrict__ vc,
+                                                                  const int32_t* __restrict__ row_index,
                                                                   const int32_t* __restrict__ kstart,
                                                                   const int32_t* __restrict__ lens, bf16* __restrict__ out,
                                                                   int H, int G, int ctx, float scale) {
-  extern __shared__ float sp[];                         // [REP][ctx] scores | [DEC_NW][REP][128] partial outputs | [REP] 1/l
+  // [REP][ctx] scores | [DEC_NW][REP][128] partial outputs | [REP] 1/l | [ctx] physical cache row of every visible key
+  extern __shared__ float sp[];
   float* sc = sp;
   float* part = sp + (size_t)REP * ctx;
   float* linv = part + DEC_NW * REP * HD;
+  int* prow = (int*)(linv + REP + (REP & 1));
   const int row = blockIdx.x, g = blockIdx.y;
   const int W = G * HD, LD = (H + 2 * G) * HD;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int k0 = kstart[row], nk = lens[row] - k0;
-  const int chunk = ((nk + DEC_NW - 1) / DEC_NW + 3) & ~3;     // keys per wave, multiple of 4
-  const int kb = wave * chunk, ke = min(nk, kb + chunk);
-  const int sub = lane & 15, kq = lane >> 4;
-  float q[REP][8];
+  const int l15 = lane & 15, lq = lane >> 4;
+  for (int i = threadIdx.x; i < nk; i += 64 * DEC_NW) prow[i] = row_index ? row_index[(size_t)row * ctx + k0 + i] : row;
+  __syncthreads();
+  // ---- phase 1: scores
+  bf16x8 qf[4];
 #pragma unroll
-  for (int h = 0; h < REP; ++h) {
-    const bf16x8 v = *(const bf16x8*)(qkv + (size_t)row * LD + (g * REP + h) * HD + sub * 8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) q[h][j] = (float)v[j] * scale;
+  for (int s4 = 0; s4 < 4; ++s4) {
+    qf[s4] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (l15 < REP) qf[s4] = *(const bf16x8*)(qkv + (size_t)row * LD + (g * REP + l15) * HD + s4 * 32 + lq * 8);
   }
-  const bf16* kbase = kc + ((size_t)row * ctx + k0) * W + g * HD + sub * 8;
-  for (int i0 = kb; i0 < ke; i0 += 4) {
-    const int i = i0 + kq;
-    float kf[8];
-    if (i < ke) {
-      const bf16x8 v = *(const bf16x8*)(kbase + (size_t)i * W);
+  const bf16* kbase = kc + (size_t)k0 * W + g * HD + lq * 8;
+  const int nchunk = (nk + 15) >> 4;
+  for (int c = wave; c < nchunk; c += DEC_NW) {
+    const int key = c * 16 + l15;
+    const int kcl = min(key, nk - 1);
+    const bf16* kp = kbase + ((size_t)prow[kcl] * ctx + kcl) * W;
+    bf16x8 kf[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) kf[j] = (float)v[j];
-    } else {
+    for (int s4 = 0; s4 < 4; ++s4) kf[s4] = *(const bf16x8*)(kp + s4 * 32);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) kf[j] = 0.f;
-    }
+    for (int s4 = 0; s4 < 4; ++s4) acc = mfma16(qf[s4], kf[s4], acc);
+    // acc[r] = score(head lq*4 + r, key c*16 + l15)
+    if (key < nk) {
 #pragma unroll
-    for (int h = 0; h < REP; ++h) {
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += q[h][j] * kf[j];
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      s += __shfl_xor(s, 8, 64);
-      if (sub == 0 && i < ke) sc[h * ctx + i] = s;
+      for (int r = 0; r < 4; ++r)
+        if (lq * 4 + r < REP) sc[(lq * 4 + r) * ctx + key] = acc[r] * scale;
     }
   }
   __syncthreads();
-  for (int h = wave; h < REP; h += DEC_NW) {               // softmax statistics of head h
+  // ---- phase 1b: softmax statistics of head h
+  for (int h = wave; h < REP; h += DEC_NW) {
     float m = -__builtin_inff();
     for (int i = lane; i < nk; i += 64) m = fmaxf(m, sc[h * ctx + i]);
     m = wave_max(m);
@@ -127,35 +167,52 @@ __global__ __launch_bounds__(64 * DEC_NW) void attn_decode_kernel(const bf16* __
     if (lane == 0) linv[h] = l > 0.f ? 1.f / l : 0.f;
   }
   __syncthreads();
-  const bf16* vbase = vc + ((size_t)row * ctx + k0) * W + g * HD + 2 * lane;
-  float o[REP][2];
+  // ---- phase 2: P.V   (lane: dims 8*l15 .. +7, key quarter lq; wave: keys wave*4 + lq, stride 32)
+  const bf16* vbase = vc + (size_t)k0 * W + g * HD + l15 * 8;
+  float o[REP][8];
 #pragma unroll
-  for (int h = 0; h < REP; ++h) o[h][0] = o[h][1] = 0.f;
-  int i = kb;
-  for (; i + 4 <= ke; i += 4) {
-    bf16x2 v[4];
+  for (int h = 0; h < REP; ++h)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *(const bf16x2*)(vbase + (size_t)(i + u) * W);
+    for (int j = 0; j < 8; ++j) o[h][j] = 0.f;
+  constexpr int UN = 4;
+  for (int i0 = wave * 4; i0 < nk; i0 += DEC_NW * 4 * UN) {
+    bf16x8 v[UN];
+    int key[UN];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < UN; ++u) {
+      key[u] = i0 + u * DEC_NW * 4 + lq;
+      const int kcl = min(key[u], nk - 1);
+      v[u] = *(const bf16x8*)(vbase + ((size_t)prow[kcl] * ctx + kcl) * W);
+    }
 #pragma unroll
-      for (int h = 0; h < REP; ++h) {
-        const float p = sc[h * ctx + i + u];
-        o[h][0] += p * (float)v[u][0];
-        o[h][1] += p * (float)v[u][1];
+    for (int u = 0; u < UN; ++u) {
+      if (key[u] < nk) {
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+          const float p = sc[h * ctx + key[u]];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[h][j] += p * (float)v[u][j];
+        }
       }
-  }
-  for (; i < ke; ++i) {
-    const bf16x2 v = *(const bf16x2*)(vbase + (size_t)i * W);
-#pragma unroll
-    for (int h = 0; h < REP; ++h) {
-      const float p = sc[h * ctx + i];
-      o[h][0] += p * (float)v[0];
-      o[h][1] += p * (float)v[1];
     }
   }
 #pragma unroll
-  for (int h = 0; h < REP; ++h) *(f32x2*)(part + ((wave * REP + h) * HD) + 2 * lane) = f32x2{o[h][0], o[h][1]};
+  for (int h = 0; h < REP; ++h)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = o[h][j];
+      x += __shfl_xor(x, 16, 64);
+      x += __shfl_xor(x, 32, 64);
+      o[h][j] = x;
+    }
+  if (lq == 0) {
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      float* dst = part + ((wave * REP + h) * HD) + l15 * 8;
+      *(f32x4*)dst = f32x4{o[h][0], o[h][1], o[h][2], o[h][3]};
+      *(f32x4*)(dst + 4) = f32x4{o[h][4], o[h][5], o[h][6], o[h][7]};
+    }
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < REP * HD; e += 64 * DEC_NW) {
     const int h = e / HD, d = e - h * HD;
@@ -169,16 +226,21 @@ __global__ __launch_bounds__(64 * DEC_NW) void attn_decode_kernel(const bf16* __
 // per row: lse over V columns, then the k best log-probs (value = logit - lse) with their column ids, descending;
 // columns listed in `banned` (n_banned ids, e.g. EOS while cur_len < min_length) score -inf.   k <= 16.
 constexpr int TOPK_MAX = 16;
+constexpr int TOPK_PARTS = 16;       // column parts per row: 64 rows x 16 parts = 1024 blocks for the 152k-column vocabulary
+// Stage 1, grid (M, TOPK_PARTS): block (row, part) scans its share of the row's columns with 16-byte loads and leaves
+//   pm/ps = max and sum exp(x - max) over its columns, pv/pi = its K largest logits (descending; ties: smaller column).
+// Stage 2, grid (M): merges the parts (lse = log sum exp over all columns; K rounds of argmax over the P sorted lists).
 template <int K>
-__global__ __launch_bounds__(256) void logprob_topk_kernel(const bf16* __restrict__ logits, int ld, int V,
-                                                           const int32_t* __restrict__ banned, int n_banned,
-                                                           float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+__global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__ logits, int ld, int V,
+                                                        const int32_t* __restrict__ banned, int n_banned,
+                                                        float* __restrict__ pm, float* __restrict__ ps,
+                                                        float* __restrict__ pv, int32_t* __restrict__ pi) {
   __shared__ float red[4];
   __shared__ float cv[256 * K];
   __shared__ int ci[256 * K];
   __shared__ float bestv[4];
   __shared__ int besti[4], bestslot[4];
-  const int row = blockIdx.x;
+  const int row = blockIdx.x, part = blockIdx.y;
   const bf16* lr = logits + (size_t)row * ld;
   float tv[K];
   int ti[K];
@@ -187,10 +249,12 @@ __global__ __launch_bounds__(256) void logprob_topk_kernel(const bf16* __restric
     tv[j] = -__builtin_inff();
     ti[j] = 0x7fffffff;
   }
-  // 16-byte loads (ld % 8 == 0, checked by the host entry); columns >= V are skipped
+  // this part's 8-column chunks [v0, v1) (ld % 8 == 0, checked by the host entry); columns >= V are skipped
   const int nv = (V + 7) / 8;
+  const int per = (nv + TOPK_PARTS - 1) / TOPK_PARTS;
+  const int v0 = part * per, v1 = min(nv, v0 + per);
   float m = -__builtin_inff();
-  for (int cv8 = threadIdx.x; cv8 < nv; cv8 += 256) {
+  for (int cv8 = v0 + threadIdx.x; cv8 < v1; cv8 += 256) {
     const bf16x8 x = *(const bf16x8*)(lr + cv8 * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -198,7 +262,7 @@ __global__ __launch_bounds__(256) void logprob_topk_kernel(const bf16* __restric
   }
   m = block_max<4>(m, red);
   float s = 0.f;
-  for (int cv8 = threadIdx.x; cv8 < nv; cv8 += 256) {
+  for (int cv8 = v0 + threadIdx.x; cv8 < v1; cv8 += 256) {
     const bf16x8 x = *(const bf16x8*)(lr + cv8 * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -228,7 +292,11 @@ __global__ __launch_bounds__(256) void logprob_topk_kernel(const bf16* __restric
     }
   }
   s = block_sum<4>(s, red);
-  const float lse = m + __logf(s);
+  const size_t slot0 = (size_t)row * TOPK_PARTS + part;
+  if (threadIdx.x == 0) {
+    pm[slot0] = m;
+    ps[slot0] = s;
+  }
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     cv[threadIdx.x * K + j] = tv[j];
@@ -268,10 +336,46 @@ __global__ __launch_bounds__(256) void logprob_topk_kernel(const bf16* __restric
       }
     if (threadIdx.x == bs) ++head;
     if (threadIdx.x == 0) {
-      out_val[(size_t)row * K + r] = bv - lse;
-      out_idx[(size_t)row * K + r] = bi;
+      pv[slot0 * K + r] = bv;
+      pi[slot0 * K + r] = bi;
     }
     __syncthreads();
+  }
+}
+
+// one wave per row: lane p < TOPK_PARTS owns part p's sorted list
+template <int K>
+__global__ __launch_bounds__(64) void topk_merge_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
+                                                        const float* __restrict__ pv, const int32_t* __restrict__ pi,
+                                                        float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const bool live = lane < TOPK_PARTS;
+  const size_t slot0 = (size_t)row * TOPK_PARTS + (live ? lane : 0);
+  const float mp = live ? pm[slot0] : -__builtin_inff();
+  const float m = wave_max(mp);
+  const float s = wave_sum(live && mp > -__builtin_inff() ? ps[slot0] * __expf(mp - m) : 0.f);
+  const float lse = m + __logf(s);
+  int head = 0;
+  for (int r = 0; r < K; ++r) {
+    float v = live && head < K ? pv[slot0 * K + head] : -__builtin_inff();
+    int id = live && head < K ? pi[slot0 * K + head] : 0x7fffffff;
+    int owner = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(id, o, 64);
+      const int oo = __shfl_xor(owner, o, 64);
+      if (ov > v || (ov == v && oi < id)) {
+        v = ov;
+        id = oi;
+        owner = oo;
+      }
+    }
+    if (lane == owner) ++head;
+    if (lane == 0) {
+      out_val[(size_t)row * K + r] = v - lse;
+      out_idx[(size_t)row * K + r] = id;
+    }
   }
 }
 
@@ -301,20 +405,33 @@ extern "C" int tasu_kv_append(const void* qkv, void* kcache, void* vcache, const
               H, G, ctx);
   return TASU_OK;
 }
-extern "C" int tasu_kv_gather(const void* src_k, const void* src_v, void* dst_k, void* dst_v, const int32_t* src_row,
-                              const int32_t* lens, int M, int G, int ctx, void* stream) {
-  if (!src_k || !src_v || !dst_k || !dst_v || !src_row || !lens || M <= 0 || G <= 0 || ctx <= 0) return TASU_ERR_ARG;
-  TASU_LAUNCH(kv_gather_kernel, dim3(8, M), dim3(256), 0, (hipStream_t)stream, (const bf16*)src_k, (const bf16*)src_v,
-              (bf16*)dst_k, (bf16*)dst_v, src_row, lens, G * HD, ctx);
+extern "C" int tasu_rope_append(void* qkv, const float* cos_tab, const float* sin_tab, void* kcache, void* vcache,
+                                const int32_t* pos, int M, int H, int G, int ctx, void* stream) {
+  if (!qkv || !cos_tab || !sin_tab || !kcache || !vcache || !pos || M <= 0 || H <= 0 || G <= 0 || ctx <= 0) return TASU_ERR_ARG;
+  TASU_LAUNCH(rope_append_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (bf16*)qkv, cos_tab, sin_tab, (bf16*)kcache,
+              (bf16*)vcache, pos, H, G, ctx);
   return TASU_OK;
 }
-extern "C" int tasu_attn_decode(const void* qkv, const void* kcache, const void* vcache, const int32_t* kstart,
-                                const int32_t* lens, void* out, int M, int H, int G, int ctx, float scale, void* stream) {
+extern "C" int tasu_kv_index_init(int32_t* index, int B, int n_beams, int S, int ctx, void* stream) {
+  if (!index || B <= 0 || n_beams <= 0 || S <= 0 || ctx < S) return TASU_ERR_ARG;
+  const int total = B * n_beams * ctx;
+  TASU_LAUNCH(kv_index_init_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, index, n_beams, S, ctx, total);
+  return TASU_OK;
+}
+extern "C" int tasu_kv_index_reorder(const int32_t* src_index, int32_t* dst_index, const int32_t* src_row, const int32_t* lens,
+                                     int M, int ctx, void* stream) {
+  if (!src_index || !dst_index || src_index == dst_index || !lens || M <= 0 || ctx <= 0) return TASU_ERR_ARG;
+  TASU_LAUNCH(kv_index_reorder_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, src_index, dst_index, src_row, lens, ctx);
+  return TASU_OK;
+}
+extern "C" int tasu_attn_decode(const void* qkv, const void* kcache, const void* vcache, const int32_t* row_index,
+                                const int32_t* kstart, const int32_t* lens, void* out, int M, int H, int G, int ctx, float scale,
+                                void* stream) {
   if (!qkv || !kcache || !vcache || !kstart || !lens || !out || M <= 0 || H <= 0 || G <= 0 || H % G || ctx <= 0 ||
       ctx > MAX_CTX)
     return TASU_ERR_ARG;
   const int rep = H / G;
-  const size_t lds = ((size_t)rep * ctx + DEC_NW * rep * HD + rep) * sizeof(float);
+  const size_t lds = ((size_t)rep * ctx + DEC_NW * rep * HD + rep + (rep & 1) + ctx) * sizeof(float);
   if (lds > 160 * 1024) return TASU_ERR_ARG;
 #define DEC_CASE(R)                                                                                                   \
   case R: {                                                                                                           \
@@ -325,7 +442,7 @@ extern "C" int tasu_attn_decode(const void* qkv, const void* kcache, const void*
       attr_set = true;                                                                                                \
     }                                                                                                                 \
     TASU_LAUNCH(attn_decode_kernel<R>, dim3(M, G), dim3(64 * DEC_NW), lds, (hipStream_t)stream, (const bf16*)qkv,      \
-                (const bf16*)kcache, (const bf16*)vcache, kstart, lens, (bf16*)out, H, G, ctx, scale);                 \
+                (const bf16*)kcache, (const bf16*)vcache, row_index, kstart, lens, (bf16*)out, H, G, ctx, scale);                 \
     return TASU_OK;                                                                                                   \
   }
   switch (rep) {
@@ -336,14 +453,21 @@ extern "C" int tasu_attn_decode(const void* qkv, const void* kcache, const void*
 #undef DEC_CASE
 }
 extern "C" int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned,
-                                 float* out_val, int32_t* out_idx, void* stream) {
-  if (!logits || !out_val || !out_idx || M <= 0 || V <= 0 || ld < V || ld % 8 || k <= 0 || k > TOPK_MAX || n_banned < 0 ||
-      (n_banned > 0 && !banned))
+                                 float* out_val, int32_t* out_idx, float* workspace, int64_t workspace_floats, void* stream) {
+  if (!logits || !out_val || !out_idx || !workspace || M <= 0 || V <= 0 || ld < V || ld % 8 || k <= 0 || k > TOPK_MAX ||
+      n_banned < 0 || (n_banned > 0 && !banned))
     return TASU_ERR_ARG;
+  const size_t slots = (size_t)M * TOPK_PARTS;
+  if ((size_t)workspace_floats < slots * (2 + 2 * (size_t)k)) return TASU_ERR_ARG;
+  float* pm = workspace;
+  float* ps = pm + slots;
+  float* pv = ps + slots;
+  int32_t* pi = (int32_t*)(pv + slots * k);
 #define TOPK_CASE(KK)                                                                                                \
   case KK:                                                                                                           \
-    TASU_LAUNCH(logprob_topk_kernel<KK>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ld, V, banned, \
-                n_banned, out_val, out_idx);                                                                         \
+    TASU_LAUNCH(topk_part_kernel<KK>, dim3(M, TOPK_PARTS), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ld, V, \
+                banned, n_banned, pm, ps, pv, pi);                                                                   \
+    TASU_LAUNCH(topk_merge_kernel<KK>, dim3(M), dim3(64), 0, (hipStream_t)stream, pm, ps, pv, pi, out_val, out_idx);  \
     return TASU_OK;
   switch (k) {
     TOPK_CASE(1) TOPK_CASE(2) TOPK_CASE(4) TOPK_CASE(6) TOPK_CASE(8) TOPK_CASE(16)

@@ -5,8 +5,6 @@
 
 namespace {
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
 inline int grid_for(int64_t nvec) {
   int64_t b = (nvec + 255) / 256;

@@ -1,11 +1,19 @@
 // Weight-streaming bf16 NT GEMM for M <= 64 rows (the decode step: M = batch x beams): C[M,N] = A[M,K] . B[N,K]^T.
-// HBM-bound (every weight byte is read once per step), so the design goal is bytes in flight, not MFMA rate:
-//   * grid = (N / 64 column tiles) x (K splits), sized to cover the 256 CUs even for N = 1536;
+// HBM-bound (every weight byte is read once per step), and a decode step is ~300 such small launches, so the design goals
+// are bytes in flight, whole rounds of one-block-per-CU grids, and as few launches as possible:
+//   * grid = (N / BN column tiles) x (K splits); BN in {64, 96} and the split count are chosen so that the blocks fill one
+//     round of the CUs as fully as possible (a 280-block grid on 256 CUs takes two rounds);
 //   * a block is 4 INDEPENDENT waves: wave w owns the K-steps  w, w+4, ...  of the block's K range and a PRIVATE
 //     double-buffered LDS region filled by its own global_load_lds_dwordx4 -- no block barrier in the main loop, only
 //     the wave's counted s_waitcnt vmcnt (data a wave DMA'd itself needs no barrier);
-//   * the 4 waves' 64x64 fp32 partials are summed through LDS once, and the K splits through fp32 slabs + a small
-//     reduce/epilogue kernel (bias, bf16 rounding, residual add): deterministic, no atomics.
+//   * the 4 waves' 64 x BN fp32 partials are summed through LDS once, and the K splits through fp32 slabs + a small
+//     reduce/epilogue kernel (bias, bf16 rounding, residual add): deterministic, no atomics.  (Tried: the last-arriving
+//     block of a tile reduces in place, hand-off through sc1 stores/loads and an arrival counter -- 15-30 % SLOWER than
+//     the second launch, because one block per tile then sums all slabs serially while the other CUs idle.)
+//   * SWIGLU: the block's BN weight rows are BN/2 gate rows and the BN/2 up rows of the same columns, and the epilogue
+//     writes act = bf16(bf16(silu(g)) * u) -- the Qwen2 MLP's gate|up projection and activation in one launch.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -13,10 +21,8 @@
 
 namespace tasu_skinny {
 
-constexpr int BM = 64, BN = 64, BK = 64;
-constexpr int TILE_BYTES = 64 * BK * 2;              // one 64 x 64 bf16 operand tile = 8 KiB = 8 LDS-DMA pieces
-constexpr int WAVE_STAGE = 2 * TILE_BYTES;           // A + B
-constexpr int WAVE_LDS = 2 * WAVE_STAGE;             // double buffered: 32 KiB per wave, 128 KiB per block
+constexpr int BM = 64, BK = 64;
+constexpr int A_BYTES = BM * BK * 2;                 // 8 KiB = 8 LDS-DMA pieces
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -24,12 +30,13 @@ typedef const __attribute__((address_space(1))) void glb_void;
 struct Args {
   const bf16* A;
   const bf16* B;
-  float* slab;          // [ksplit][64][ldn] fp32 partials (ksplit > 1) ...
-  void* C;              // ... or the final output (ksplit == 1)
+  float* slab;          // [ksplit][tile][64 * BN] fp32 partials (ksplit > 1)
+  void* C;
   const float* R;
   const bf16* bias;
-  int M, N, K, lda, ldb, ldc, ldn;
+  int M, N, K, lda, ldb, ldc;
   int ksplit, out_mode;
+  int up_row0;          // SWIGLU: first "up" row of B (= I); N = I
 };
 
 __device__ __forceinline__ void store_out(const Args& p, int m, int n, f32x4 v) {
@@ -52,25 +59,38 @@ __device__ __forceinline__ void store_out(const Args& p, int m, int n, f32x4 v) 
   }
 }
 
+template <int BN, bool SWIGLU>
 __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(Args p) {
+  constexpr int NI = BN / 16, PB = BN / 8;            // B fragments per wave row, B pieces per K-step
+  constexpr int B_BYTES = BN * BK * 2, WAVE_STAGE = A_BYTES + B_BYTES, WAVE_LDS = 2 * WAVE_STAGE;
+  static_assert(64 * BN * 4 <= WAVE_LDS, "the cross-wave reduction reuses a wave's staging region");
+  constexpr int HALF = BN / 2;                         // SWIGLU: gate rows [0, HALF), up rows [HALF, BN) of the tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tn = blockIdx.x, ks = blockIdx.y;
-  const int col0 = tn * BN;
+  const int col0 = tn * (SWIGLU ? HALF : BN);          // first output column of the tile
   const int nk = p.K / BK;
   const int per = (nk + p.ksplit - 1) / p.ksplit;
   const int kbeg = ks * per, kend = min(nk, kbeg + per);
   char* my = smem + wave * WAVE_LDS;
 
-  // per-lane source pointers of the 8 + 8 pieces of one K-step (swizzled like gemm.hip: chunk c of row r at c ^ ((r>>1)&7))
+  // per-lane source pointers of the 8 + PB pieces of one K-step (swizzled like gemm.hip: chunk c of row r at c ^ ((r>>1)&7))
   const bf16* ga[8];
-  const bf16* gb[8];
+  const bf16* gb[PB];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int r = i * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     ga[i] = p.A + (size_t)min(r, p.M - 1) * p.lda + c * 8;
-    gb[i] = p.B + (size_t)min(col0 + r, p.N - 1) * p.ldb + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int r = i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int brow;
+    if (SWIGLU) brow = r < HALF ? min(col0 + r, p.N - 1) : p.up_row0 + min(col0 + r - HALF, p.N - 1);
+    else brow = min(col0 + r, p.N - 1);
+    gb[i] = p.B + (size_t)brow * p.ldb + c * 8;
   }
   auto stage = [&](int buf, int kt) {
     char* base = my + buf * WAVE_STAGE;
@@ -79,19 +99,19 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(Args p) {
     for (int i = 0; i < 8; ++i)
       __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(base + i * 1024), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(base + TILE_BYTES + i * 1024), 16, 0, 0);
+    for (int i = 0; i < PB; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(base + A_BYTES + i * 1024), 16, 0, 0);
   };
   const int sw = (lane >> 1) & 7;
   int roff[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) roff[kk] = (lane & 15) * 128 + (((kk * 4 + (lane >> 4)) ^ sw) << 4);
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NI];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int kt = kbeg + wave;
   int buf = 0;
@@ -100,77 +120,183 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(Args p) {
     const bool more = kt + 4 < kend;
     if (more) {
       stage(buf ^ 1, kt + 4);
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // current tile landed, next stays in flight
+      // current tile landed, next (8 + PB pieces) stays in flight
+      if (PB == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     const char* sa = my + buf * WAVE_STAGE;
-    const char* sb = sa + TILE_BYTES;
+    const char* sb = sa + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
+      bf16x8 fa[4], fb[NI];
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(sa + i * 16 * 128 + roff[kk]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(sb + j * 16 * 128 + roff[kk]);
+      for (int j = 0; j < NI; ++j) fb[j] = *(const bf16x8*)(sb + j * 16 * 128 + roff[kk]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
     }
     // the LDS reads above must have returned before this buffer is DMA'd again by the next iteration's stage()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     buf ^= 1;
   }
-  // ---- sum the 4 waves' partials through LDS (each wave's private region is free again: 16 KiB of fp32 per wave)
+  // ---- sum the 4 waves' partials through LDS (each wave's private region is free again)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  float* red = (float*)(smem + wave * WAVE_LDS);              // [64 m][64 n] fp32, lane-linear chunks
+  float* red = (float*)(smem + wave * WAVE_LDS);              // [4 x NI fragments][64 lanes] f32x4, lane-linear
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *(f32x4*)(red + ((i * 4 + j) * 64 + lane) * 4) = acc[i][j];
+    for (int j = 0; j < NI; ++j) *(f32x4*)(red + ((i * NI + j) * 64 + lane) * 4) = acc[i][j];
   __syncthreads();
-  // wave w finalises the (i = w) row block: acc[i][j] summed over the 4 regions
-  f32x4 sum[4];
+  // wave w finalises the (i = w) row block: acc[w][j] summed over the 4 regions.
+  // sum[j][r] = C[m = wave*16 + (lane&15)][tile column j*16 + (lane>>4)*4 + r]
+  f32x4 sum[NI];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NI; ++j) {
     sum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w2 = 0; w2 < 4; ++w2)
-      sum[j] += *(const f32x4*)((const float*)(smem + w2 * WAVE_LDS) + ((wave * 4 + j) * 64 + lane) * 4);
+      sum[j] += *(const f32x4*)((const float*)(smem + w2 * WAVE_LDS) + ((wave * NI + j) * 64 + lane) * 4);
+  }
+  if (p.ksplit > 1) {
+    // partial tile -> slab [ks][tile] in fragment-image order; skinny_reduce_kernel finishes
+    float* mine = p.slab + ((size_t)ks * gridDim.x + tn) * (64 * BN);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) *(f32x4*)(mine + ((wave * NI + j) * 64 + lane) * 4) = sum[j];
+    return;
   }
   const int m = wave * 16 + (lane & 15);
+  if (SWIGLU) {
+    // fragments j < NI/2 hold gate columns, j + NI/2 the up values of the same columns
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = col0 + j * 16 + (lane >> 4) * 4;
-    if (p.ksplit == 1) {
-      store_out(p, m, n, sum[j]);
-    } else if (n < p.ldn) {
-      *(f32x4*)(p.slab + ((size_t)ks * BM + m) * p.ldn + n) = sum[j];
+    for (int j = 0; j < NI / 2; ++j) {
+      const int n = col0 + j * 16 + (lane >> 4) * 4;
+      if (m < p.M && n < p.N) {
+        bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= p.N) break;
+          const float g = bf16_round(sum[j][r]), u = bf16_round(sum[j + NI / 2][r]);
+          dst[r] = (bf16)(bf16_round(silu_f(g)) * u);
+        }
+      }
     }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) store_out(p, m, col0 + j * 16 + (lane >> 4) * 4, sum[j]);
   }
 }
 
-// out = epilogue(sum over splits of slab)      grid = ceil(M * ldn/4 / 256)
-__global__ __launch_bounds__(256) void skinny_reduce_kernel(Args p) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int n4 = p.ldn / 4;
-  if (idx >= p.M * n4) return;
-  const int m = idx / n4, n = (idx - m * n4) * 4;
+// out = epilogue(sum over splits of the slabs).  One thread per f32x4 of the fragment image: grid = tiles * 64 * BN / 4 / 256.
+template <int BN, bool SWIGLU>
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(Args p, int tiles) {
+  constexpr int NI = BN / 16, TILE_F = 64 * BN;
+  const int idx = blockIdx.x * 256 + threadIdx.x;       // f32x4 index over [tile][wave][j][lane]
+  if (idx >= tiles * (TILE_F / 4)) return;
+  const int tn = idx / (TILE_F / 4), e = idx - tn * (TILE_F / 4);
+  const int lane = e & 63, j = (e >> 6) % NI, wave = (e >> 6) / NI;
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < p.ksplit; ++k) s += *(const f32x4*)(p.slab + ((size_t)k * BM + m) * p.ldn + n);
-  store_out(p, m, n, s);
+  for (int k = 0; k < p.ksplit; ++k) s += *(const f32x4*)(p.slab + ((size_t)k * tiles + tn) * TILE_F + e * 4);
+  const int m = wave * 16 + (lane & 15);
+  if (SWIGLU) {
+    // the thread that owns gate fragment j also reads the matching up fragment j + NI/2
+    if (j >= NI / 2) return;
+    f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.ksplit; ++k)
+      u += *(const f32x4*)(p.slab + ((size_t)k * tiles + tn) * TILE_F + (e + (NI / 2) * 64) * 4);
+    const int n = tn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+    if (m < p.M && n < p.N) {
+      bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n + r >= p.N) break;
+        dst[r] = (bf16)(bf16_round(silu_f(bf16_round(s[r]))) * bf16_round(u[r]));
+      }
+    }
+  } else {
+    store_out(p, m, tn * BN + j * 16 + (lane >> 4) * 4, s);
+  }
+}
+
+int cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    return cus;
+  }();
+  return n;
+}
+
+template <int BN, bool SWIGLU>
+int launch(Args a, int tiles, hipStream_t st) {
+  constexpr int LDS = 4 * 2 * (A_BYTES + BN * BK * 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<BN, SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  TASU_LAUNCH((gemm_skinny_kernel<BN, SWIGLU>), dim3(tiles, a.ksplit), dim3(256), LDS, st, a);
+  if (a.ksplit > 1)
+    TASU_LAUNCH((skinny_reduce_kernel<BN, SWIGLU>), dim3((tiles * 16 * BN + 255) / 256), dim3(256), 0, st, a, tiles);
+  return TASU_OK;
+}
+
+// Tile width and K split (one block per CU: 128-160 KiB of LDS).  Measured on MI355X, M = 64, cold weights, graph replay
+// (tools/bench_skinny.py): a launch costs ~8.5 us however small, so splits only pay when the column tiles alone leave
+// most CUs idle --
+//   enough tiles (>= 60 % of the CUs): no split; the width that needs fewer rounds x rows
+//       (gate|up 2 x 8960 x 1536: 96 -> 187 blocks, 18.4 us = 3.0 TB/s; 64 -> 280 blocks = two rounds, 23.2 us);
+//   few tiles: 64-wide, K split to about one block per CU, at most 4 ways when K is short
+//       (down 1536 x 8960: 24 tiles x 10 = 15.0 us vs 45.3 us unsplit; qkv / o, K = 1536: 8.5-9 us at any split).
+template <bool SWIGLU>
+int plan_and_launch(Args a, float* ws, size_t ws_floats, hipStream_t st) {
+  const int cus = cu_count();
+  const int nk = a.K / BK;
+  static const int force_bn = [] { const char* e = getenv("TASU_SKINNY_BN"); return e ? atoi(e) : 0; }();
+  static const int force_ks = [] { const char* e = getenv("TASU_SKINNY_KS"); return e ? atoi(e) : 0; }();
+  auto tiles_of = [&](int bn) { const int cols = SWIGLU ? bn / 2 : bn; return (a.N + cols - 1) / cols; };
+  int best_bn = 64, best_ks = 1;
+  const int t64 = tiles_of(64), t96 = tiles_of(96);
+  if (t96 * 10 >= cus * 6) {
+    const long r64 = (t64 + cus - 1) / cus, r96 = (t96 + cus - 1) / cus;
+    best_bn = r96 * 96 < r64 * 64 ? 96 : 64;
+  } else if (ws) {
+    int ks = cus / t64;
+    const int max_ks = nk <= 32 ? 4 : 32;
+    if (ks > max_ks) ks = max_ks;
+    if (ks > nk / 4) ks = nk / 4;                             // keep >= 1 K-step per wave
+    while (ks > 1 && (size_t)t64 * ks * 64 * 64 > ws_floats) --ks;
+    best_ks = ks > 1 ? ks : 1;
+  }
+  if (force_bn == 64 || force_bn == 96) best_bn = force_bn;
+  if (force_ks > 0 && ws) {
+    best_ks = force_ks <= nk / 4 ? force_ks : (nk / 4 > 0 ? nk / 4 : 1);
+    while (best_ks > 1 && (size_t)tiles_of(best_bn) * best_ks * 64 * best_bn > ws_floats) --best_ks;
+  }
+  const int cols = SWIGLU ? best_bn / 2 : best_bn;
+  const int tiles = (a.N + cols - 1) / cols;
+  a.ksplit = best_ks;
+  a.slab = ws;
+  return best_bn == 96 ? launch<96, SWIGLU>(a, tiles, st) : launch<64, SWIGLU>(a, tiles, st);
 }
 
 }  // namespace tasu_skinny
 
-// workspace: ksplit * 64 * round_up(N, 64) floats.  Returns TASU_ERR_ARG when the shape is not a skinny one.
-static int tasu_gemm_skinny_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
-                              const float* resid, int M, int N, int K, int out_mode, float* ws, size_t ws_floats,
-                              hipStream_t st) {
+extern "C" int tasu_gemm_skinny_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                                     const float* resid, int M, int N, int K, int out_mode, float* workspace,
+                                     int64_t workspace_floats, void* stream) {
   using namespace tasu_skinny;
-  if (M > BM) return TASU_ERR_ARG;
+  if (!A || !B || !C || M <= 0 || M > 64 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldb % 8) return TASU_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)workspace & 15)) return TASU_ERR_ARG;
+  if (out_mode < 0 || out_mode > 2 || (out_mode == TASU_GEMM_OUT_F32_RESID_BF16R && !resid)) return TASU_ERR_ARG;
   Args a;
   a.A = (const bf16*)A;
   a.B = (const bf16*)B;
@@ -183,35 +309,29 @@ static int tasu_gemm_skinny_dispatch(const void* A, int lda, const void* B, int 
   a.lda = lda;
   a.ldb = ldb;
   a.ldc = ldc;
-  a.ldn = (N + 63) / 64 * 64;
   a.out_mode = out_mode;
-  const int tiles = (N + BN - 1) / BN, nk = K / BK;
-  int ks = 1;
-  if (tiles < 256) {
-    ks = (320 + tiles - 1) / tiles;            // aim at >= 320 blocks ...
-    if (ks > nk / 4) ks = nk / 4 > 0 ? nk / 4 : 1;   // ... but keep >= 1 K-step per wave
-    if (ks < 1) ks = 1;
-  }
-  while (ks > 1 && (size_t)ks * BM * a.ldn > ws_floats) --ks;
-  if (ks > 1 && !ws) ks = 1;
-  a.ksplit = ks;
-  a.slab = ws;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WAVE_LDS);
-    attr_set = true;
-  }
-  TASU_LAUNCH(gemm_skinny_kernel, dim3(tiles, ks), dim3(256), 4 * WAVE_LDS, st, a);
-  if (ks > 1) TASU_LAUNCH(skinny_reduce_kernel, dim3((M * (a.ldn / 4) + 255) / 256), dim3(256), 0, st, a);
-  return TASU_OK;
+  a.up_row0 = 0;
+  return plan_and_launch<false>(a, workspace, workspace ? (size_t)workspace_floats : 0, (hipStream_t)stream);
 }
 
-extern "C" int tasu_gemm_skinny_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
-                                     const float* resid, int M, int N, int K, int out_mode, float* workspace,
-                                     int64_t workspace_floats, void* stream) {
-  if (!A || !B || !C || M <= 0 || M > 64 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldb % 8) return TASU_ERR_ARG;
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return TASU_ERR_ARG;
-  if (out_mode < 0 || out_mode > 2 || (out_mode == TASU_GEMM_OUT_F32_RESID_BF16R && !resid)) return TASU_ERR_ARG;
-  return tasu_gemm_skinny_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, workspace,
-                                   workspace ? (size_t)workspace_floats : 0, (hipStream_t)stream);
+extern "C" int tasu_gemm_skinny_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I,
+                                       int K, float* workspace, int64_t workspace_floats, void* stream) {
+  using namespace tasu_skinny;
+  if (!A || !Wgu || !act || M <= 0 || M > 64 || I <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8) return TASU_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)Wgu & 15) || ((uintptr_t)workspace & 15)) return TASU_ERR_ARG;
+  Args a;
+  a.A = (const bf16*)A;
+  a.B = (const bf16*)Wgu;
+  a.C = act;
+  a.R = nullptr;
+  a.bias = nullptr;
+  a.M = M;
+  a.N = I;
+  a.K = K;
+  a.lda = lda;
+  a.ldb = ldw;
+  a.ldc = ldact;
+  a.out_mode = TASU_GEMM_OUT_BF16;
+  a.up_row0 = I;
+  return plan_and_launch<true>(a, workspace, workspace ? (size_t)workspace_floats : 0, (hipStream_t)stream);
 }

@@ -7,7 +7,8 @@ continuations -- and the host does the (tiny) selection, finished-beam heap and 
 
 Device per step (M = B*nb rows): embedding rows -> 28 x [RMSNorm, qkv GEMM, RoPE, KV append, cache attention, o GEMM +
 residual, RMSNorm, gate|up GEMM, SwiGLU, down GEMM + residual] -> RMSNorm -> lm_head GEMM -> log-softmax top-k ->
-beam reorder of the KV cache (ping-pong gather).  HBM-bound: every step streams the bf16 weights once.
+beam reorder of the cache's row index.  HBM-bound: every step streams the bf16 weights once; the ~430 launches of a step
+are replayed as one hipGraph when ``model.use_graphs`` is set.
 """
 import numpy as np
 import torch
@@ -102,10 +103,16 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     # ---- prefill with the training-forward kernels (no loss)
     model.forward_llm(st, compute_loss=False, need_backward=False, logits_rows="none")
     d = st.dev
-    kc = buf("dec_kc", (2, L, M * ctx * W), bf)
-    vc = buf("dec_vc", (2, L, M * ctx * W), bf)
+    # KV cache [L][M, ctx, W] + the beam row index (include/tasu_hip.h): the prompt is stored once per utterance and a
+    # beam reorder permutes 4-byte index entries once per step instead of copying K/V in every layer
+    kc = buf("dec_kc", (L, M * ctx * W), bf)
+    vc = buf("dec_vc", (L, M * ctx * W), bf)
+    index = buf("dec_index", (M, ctx), i32)
+    index_tmp = buf("dec_index_tmp", (M, ctx), i32)
+    ops.kv_index_init(index, B, nb, S, ctx)
+    ops.kv_index_init(index_tmp, B, nb, S, ctx)
     for l in range(L):
-        ops.kv_fill(d["qkv"][l], kc[0, l], vc[0, l], B, S, H, G, nb, ctx)
+        ops.kv_fill(d["qkv"][l], kc[l], vc[l], B, S, H, G, nb, ctx)
     valid = st.plan.key_mask[:, :S].sum(1).astype(np.int64)               # real tokens per prompt
     kstart_h = np.repeat(S - valid, nb).astype(np.int32)                   # left padding is at the front
     kstart = model._upload("dec_kstart", kstart_h)
@@ -126,7 +133,7 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     vals = np.full((B, nb, K), NEG, dtype=np.float32)                      # beams 1.. start at -1e9 (HF init)
     idx = np.zeros((B, nb, K), dtype=np.int64)
     vals[:, 0], idx[:, 0] = v0, i0
-    tok, parent = state.update(vals, idx)                                  # all parents are beam 0: no reorder needed
+    tok, parent = state.update(vals, idx)
     x = buf("dec_x", (M, D), f32)
     x2 = buf("dec_x2", (M, D), f32)
     qkv = buf("dec_qkv", (M, LDQ), bf)
@@ -135,8 +142,13 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     act = buf("dec_act", (M, I), bf)
     cos = buf("dec_cos", (M, HD // 2), f32)
     sin = buf("dec_sin", (M, HD // 2), f32)
-    cur_buf = 0
-    ws = buf("dec_gemm_ws", (16 * 64 * rup(max(V, 2 * I), 64),), f32)
+    ws = buf("dec_gemm_ws", (32 * 64 * rup(max(V, 2 * I), 96),), f32)          # tasu_gemm_skinny_bf16 split-K slabs
+    # per-step device inputs live in fixed buffers so that the step can be replayed as a hipGraph
+    ids_d = buf("in_dec_ids", (M,), i32)
+    pos_d = buf("in_dec_pos", (M,), i32)
+    slot_d = buf("in_dec_slot", (M,), i32)
+    lens_d = buf("in_dec_lens", (M,), i32)
+    src_d = buf("in_dec_src", (M,), i32)
 
     def gemm(a, b, c, m, n, k, **kw):
         if m <= 64:
@@ -144,37 +156,63 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
         else:
             ops.gemm(a, b, c, m, n, k, **kw)
 
-    while not state.done:
-        t = state.cur                                                       # tokens generated so far (>= 1)
-        ids = model._upload("dec_ids", tok.reshape(-1).astype(np.int32))
-        pos = model._upload("dec_pos", np.repeat(valid + t - 1, nb).astype(np.int32))      # position id of the new token
-        slot = model._upload("dec_slot", np.full(M, S + t - 1, dtype=np.int32))            # its cache slot
-        lens = model._upload("dec_lens", np.full(M, S + t, dtype=np.int32))
-        ops.embed_rows(llm.embed, ids, x, M, D)
-        ops.rope_table(pos, cos, sin, HD, geo.rope_theta)
+    def device_step(ban):
+        """One generated position for all M beams: beam reorder of the row index (parents of the previous step), then the
+        28-layer single-token pass over the cache, lm_head and the per-row top-k."""
+        ops.kv_index_reorder(index, index_tmp, src_d, slot_d, M, ctx)
+        ops.kv_index_reorder(index_tmp, index, None, slot_d, M, ctx)
+        ops.embed_rows(llm.embed, ids_d, x, M, D)
+        ops.rope_table(pos_d, cos, sin, HD, geo.rope_theta)
         for l, w in enumerate(llm.layers):
             ops.rmsnorm_fwd(x, w["ln1"], xn, None, geo.rms_eps)
             gemm(xn, w["wqkv"], qkv, M, LDQ, D, bias=w["bqkv"])
-            ops.rope_fwd(qkv, cos, sin, None, None, None, M, 1, H, G)
-            ops.kv_append(qkv, kc[cur_buf, l], vc[cur_buf, l], slot, M, H, G, ctx)
-            ops.attn_decode(qkv, kc[cur_buf, l], vc[cur_buf, l], kstart, lens, ao, M, H, G, ctx, scale)
+            ops.rope_append(qkv, cos, sin, kc[l], vc[l], slot_d, M, H, G, ctx)
+            ops.attn_decode(qkv, kc[l], vc[l], index, kstart, lens_d, ao, M, H, G, ctx, scale)
             gemm(ao, w["wo"], x2, M, D, H * HD, resid=x, mode=GEMM_RESID)
             ops.rmsnorm_fwd(x2, w["ln2"], xn, None, geo.rms_eps)
-            gemm(xn, w["wgu"], gu, M, 2 * I, D)
-            ops.swiglu_fwd(gu, act, M, I)
+            if M <= 64:
+                ops.gemm_skinny_swiglu(xn, w["wgu"], act, M, I, D, ws)
+            else:
+                ops.gemm(xn, w["wgu"], gu, M, 2 * I, D)
+                ops.swiglu_fwd(gu, act, M, I)
             gemm(act, w["wd"], x, M, D, I, resid=x2, mode=GEMM_RESID)
         ops.rmsnorm_fwd(x, llm.norm, xn, None, geo.rms_eps)
         gemm(xn, llm.head, logits, M, V, D)
-        ops.logprob_topk(logits, M, V, K, banned, 1 if state.ban_eos() else 0, tv, ti)
+        ops.logprob_topk(logits, M, V, K, banned, ban, tv, ti)
+
+    # hipGraph replay of device_step (~430 launches): the first step of a shape runs eagerly, the second is captured.
+    # A graph is only valid for the buffers it was captured on, so the key carries their addresses.
+    use_graphs = model.decode_graphs and model.device.type == "cuda"
+    graphs = model._graphs
+
+    def run_step(ban):
+        if not use_graphs:
+            return device_step(ban)
+        key = ("decode", B, S, nb, ctx, ban, kc.data_ptr(), vc.data_ptr(), index.data_ptr(), logits.data_ptr(), ws.data_ptr())
+        g = graphs.get(key)
+        if g is not None:
+            return g.replay()
+        seen = model._graph_seen.get(key, 0)
+        model._graph_seen[key] = seen + 1
+        if seen < 1:
+            return device_step(ban)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            device_step(ban)
+        graphs[key] = g
+        g.replay()
+
+    while not state.done:
+        t = state.cur                                                       # tokens generated so far (>= 1)
+        src = (np.arange(B)[:, None] * nb + parent).reshape(-1).astype(np.int32)
+        ids_d.copy_(torch.from_numpy(tok.reshape(-1).astype(np.int32)), non_blocking=True)
+        pos_d.copy_(torch.from_numpy(np.repeat(valid + t - 1, nb).astype(np.int32)), non_blocking=True)   # position id of the new token
+        slot_d.copy_(torch.from_numpy(np.full(M, S + t - 1, dtype=np.int32)), non_blocking=True)           # its cache slot
+        lens_d.copy_(torch.from_numpy(np.full(M, S + t, dtype=np.int32)), non_blocking=True)
+        src_d.copy_(torch.from_numpy(src), non_blocking=True)                                              # parents of the last update
+        run_step(1 if state.ban_eos() else 0)
         vals = tv.cpu().numpy().reshape(B, nb, K)                           # one small D2H sync per step
         idx = ti.cpu().numpy().reshape(B, nb, K).astype(np.int64)
         tok, parent = state.update(vals, idx)
-        if state.done:
-            break
-        src = (np.arange(B)[:, None] * nb + parent).reshape(-1).astype(np.int32)
-        if not np.array_equal(src, np.arange(M, dtype=np.int32)):
-            src_d = model._upload("dec_src", src)
-            for l in range(L):
-                ops.kv_gather(kc[cur_buf, l], vc[cur_buf, l], kc[1 - cur_buf, l], vc[1 - cur_buf, l], src_d, lens, M, G, ctx)
-            cur_buf = 1 - cur_buf
     return torch.from_numpy(state.result())

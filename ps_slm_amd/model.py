@@ -240,6 +240,7 @@ class TasuModel:
         # into two graph launches.  Keyed by the shapes baked into kernel arguments; the first call of a key runs
         # eagerly (allocates the workspace), the second is captured, later ones replay.
         self.use_graphs = False
+        self.decode_graphs = True      # the decode step (ps_slm_amd/decode.py) is always replayed as a graph on the GPU
         self._graphs = {}
         self._graph_seen = {}
 

@@ -32,6 +32,7 @@ class HipOps:
         # split-K workspace of tasu_gemm_nt_bf16_ws: zeroed arrival counters + fp32 partial tiles (include/tasu_hip.h).
         # Allocated up front (never inside a hipGraph capture); all GEMMs of one HipOps run on one stream.
         self.gemm_ws = torch.zeros(GEMM_WS_BYTES, dtype=torch.uint8, device="cuda")
+        self.topk_ws = torch.empty(1024 * 16 * 34, dtype=torch.float32, device="cuda")   # tasu_logprob_topk partials, M <= 1024
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -192,17 +193,34 @@ class HipOps:
     def kv_append(self, qkv, kc, vc, pos, M, H, G, ctx):
         self._chk(self.lib.tasu_kv_append(_p(qkv), _p(kc), _p(vc), _p(pos), M, H, G, ctx, self._stream()), "tasu_kv_append")
 
-    def kv_gather(self, sk, sv, dk, dv, src_row, lens, M, G, ctx):
-        self._chk(self.lib.tasu_kv_gather(_p(sk), _p(sv), _p(dk), _p(dv), _p(src_row), _p(lens), M, G, ctx, self._stream()),
-                  "tasu_kv_gather")
+    def gemm_skinny_swiglu(self, a, wgu, act, M, I, K, ws):
+        """act[M, I] = swiglu(a[M,K] @ wgu[2I,K]^T) in one launch (decode step)."""
+        self._chk(self.lib.tasu_gemm_skinny_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), M, I, K,
+                                                   _p(ws), 0 if ws is None else ws.numel(), self._stream()),
+                  "tasu_gemm_skinny_swiglu")
 
-    def attn_decode(self, qkv, kc, vc, kstart, lens, out, M, H, G, ctx, scale):
-        self._chk(self.lib.tasu_attn_decode(_p(qkv), _p(kc), _p(vc), _p(kstart), _p(lens), _p(out), M, H, G, ctx, scale,
+    def rope_append(self, qkv, cos, sin, kc, vc, pos, M, H, G, ctx):
+        self._chk(self.lib.tasu_rope_append(_p(qkv), _p(cos), _p(sin), _p(kc), _p(vc), _p(pos), M, H, G, ctx, self._stream()),
+                  "tasu_rope_append")
+
+    def kv_index_init(self, index, B, nb, S, ctx):
+        self._chk(self.lib.tasu_kv_index_init(_p(index), B, nb, S, ctx, self._stream()), "tasu_kv_index_init")
+
+    def kv_index_reorder(self, src, dst, src_row, lens, M, ctx):
+        self._chk(self.lib.tasu_kv_index_reorder(_p(src), _p(dst), _p(src_row), _p(lens), M, ctx, self._stream()),
+                  "tasu_kv_index_reorder")
+
+    def attn_decode(self, qkv, kc, vc, index, kstart, lens, out, M, H, G, ctx, scale):
+        self._chk(self.lib.tasu_attn_decode(_p(qkv), _p(kc), _p(vc), _p(index), _p(kstart), _p(lens), _p(out), M, H, G, ctx, scale,
                                             self._stream()), "tasu_attn_decode")
 
     def logprob_topk(self, logits, M, V, k, banned, n_banned, out_val, out_idx):
+        need = M * 16 * (2 + 2 * k)
+        if self.topk_ws.numel() < need:
+            raise TasuOpError(f"logprob_topk: M={M}, k={k} exceeds the preallocated workspace")
         self._chk(self.lib.tasu_logprob_topk(_p(logits), logits.stride(0), M, V, k, _p(banned), n_banned, _p(out_val),
-                                             _p(out_idx), self._stream()), "tasu_logprob_topk")
+                                             _p(out_idx), _p(self.topk_ws), self.topk_ws.numel(), self._stream()),
+                  "tasu_logprob_topk")
 
     def embed_rows(self, table, ids, x, M, D):
         self._chk(self.lib.tasu_embed_rows(_p(table), _p(ids), _p(x), M, D, self._stream()), "tasu_embed_rows")

@@ -353,8 +353,8 @@ class FakeOps:
         W = G * HD
         v = qkv.view(B, S, (H + 2 * G) * HD)
         k4, v4 = kc.view(B, nb, ctx, W), vc.view(B, nb, ctx, W)
-        k4[:, :, :S] = v[:, None, :, H * HD:H * HD + W]
-        v4[:, :, :S] = v[:, None, :, H * HD + W:]
+        k4[:, 0, :S] = v[:, :, H * HD:H * HD + W]          # the prompt lives in the first beam's row only
+        v4[:, 0, :S] = v[:, :, H * HD + W:]
 
     def kv_append(self, qkv, kc, vc, pos, M, H, G, ctx):
         W = G * HD
@@ -363,26 +363,42 @@ class FakeOps:
         k3[r, pos.long()] = qkv[:M, H * HD:H * HD + W]
         v3[r, pos.long()] = qkv[:M, H * HD + W:]
 
-    def kv_gather(self, sk, sv, dk, dv, src_row, lens, M, G, ctx):
-        W = G * HD
-        for src, dst in ((sk, dk), (sv, dv)):
-            s3, d3 = src.view(M, ctx, W), dst.view(M, ctx, W)
-            for r in range(M):
-                n = int(lens[r])
-                d3[r, :n] = s3[int(src_row[r]), :n]
+    def gemm_skinny_swiglu(self, a, wgu, act, M, I, K, ws):
+        gu = torch.empty(M, 2 * I, dtype=torch.bfloat16)
+        self.gemm(a, wgu, gu, M, 2 * I, K)
+        self.swiglu_fwd(gu, act, M, I)
 
-    def attn_decode(self, qkv, kc, vc, kstart, lens, out, M, H, G, ctx, scale):
+    def rope_append(self, qkv, cos, sin, kc, vc, pos, M, H, G, ctx):
+        self.rope_fwd(qkv, cos, sin, None, None, None, M, 1, H, G)
+        self.kv_append(qkv, kc, vc, pos, M, H, G, ctx)
+
+    def kv_index_init(self, index, B, nb, S, ctx):
+        ix = index.view(B * nb, ctx)
+        m = torch.arange(B * nb, dtype=ix.dtype)
+        ix[:] = m[:, None]
+        ix[:, :S] = ((m // nb) * nb)[:, None]
+
+    def kv_index_reorder(self, src, dst, src_row, lens, M, ctx):
+        s2, d2 = src.view(M, ctx), dst.view(M, ctx)
+        for r in range(M):
+            n = int(lens[r])
+            d2[r, :n] = s2[r if src_row is None else int(src_row[r]), :n]
+
+    def attn_decode(self, qkv, kc, vc, index, kstart, lens, out, M, H, G, ctx, scale):
         W, rep = G * HD, H // G
         q = qkv[:M, :H * HD].float().view(M, H, HD)
         k3, v3 = kc.view(M, ctx, G, HD).float(), vc.view(M, ctx, G, HD).float()
         o = torch.zeros(M, H, HD)
         for r in range(M):
             a, b = int(kstart[r]), int(lens[r])
+            pos = torch.arange(a, b)
+            rows = torch.full((b - a,), r, dtype=torch.long) if index is None else index.view(M, ctx)[r, a:b].long()
+            kr, vr = k3[rows, pos], v3[rows, pos]                    # [n, G, HD] gathered through the row index
             for h in range(H):
                 g = h // rep
-                s = (k3[r, a:b, g] @ (q[r, h] * scale))
+                s = (kr[:, g] @ (q[r, h] * scale))
                 p = torch.exp(s - s.max())
-                o[r, h] = (_bf(p).float() @ v3[r, a:b, g]) / p.sum()
+                o[r, h] = (_bf(p).float() @ vr[:, g]) / p.sum()
         out.view(M, H, HD).copy_(_bf(o))
 
     def logprob_topk(self, logits, M, V, k, banned, n_banned, out_val, out_idx):

@@ -375,13 +375,15 @@ def test_decode_kernels(hip, fake):
     assert torch.equal(kc2, kg) and torch.equal(vc2, vg)
     kstart = torch.tensor([0, 0, 0, 5, 5, 5], dtype=I32)
     lens = torch.full((M,), S + 1, dtype=I32)
-    (oc,), (og,) = run_pair(hip, fake, "attn_decode", [qkv, kc2, vc2, kstart, lens, torch.zeros(M, H * HD, dtype=BF), M, H, G, ctx,
-                                                       HD ** -0.5], [5])
-    assert rel_err(og, oc) < 2e-2
+    (ix0,), (ixg,) = run_pair(hip, fake, "kv_index_init", [torch.zeros(M * ctx, dtype=I32), B, nb, S, ctx], [0])
+    assert torch.equal(ix0, ixg) and int(ix0.view(M, ctx)[4, 0]) == 3 and int(ix0.view(M, ctx)[4, S]) == 4
     src = torch.tensor([1, 0, 0, 5, 3, 3], dtype=I32)
-    (dk, dv), (gk, gv) = run_pair(hip, fake, "kv_gather", [kc2, vc2, torch.zeros_like(kc2), torch.zeros_like(vc2), src, lens, M, G, ctx],
-                                  [2, 3])
-    assert torch.equal(dk, gk) and torch.equal(dv, gv)
+    (ix1,), (ixg,) = run_pair(hip, fake, "kv_index_reorder", [ix0, ix0.clone(), src, lens, M, ctx], [1])
+    assert torch.equal(ix1, ixg) and int(ix1.view(M, ctx)[0, S]) == 1 and int(ix1.view(M, ctx)[0, S + 1]) == 0
+    for ix in (ix0, ix1, None):
+        (oc,), (og,) = run_pair(hip, fake, "attn_decode", [qkv, kc2, vc2, ix, kstart, lens, torch.zeros(M, H * HD, dtype=BF), M, H, G,
+                                                           ctx, HD ** -0.5], [6])
+        assert rel_err(og, oc) < 2e-2
     V, ld = 1000, 1024
     lg = torch.zeros(M, ld, dtype=BF)
     lg[:, :V] = randn(M, V, dtype=BF, seed=3, scale=3.0)
@@ -415,9 +417,38 @@ def test_gemm_skinny(hip, fake, M, N, K, mode, bias):
     c = torch.zeros(M, ldc, dtype=BF if mode == 0 else F32)
     r = randn(M, ldc, seed=4) if mode == 2 else None
     cc, gc = c.clone(), c.cuda()
-    ws = torch.zeros(16 * 64 * ldc).cuda()
+    ws = torch.zeros(32 * 64 * ((N + 95) // 96 * 96)).cuda()
     fake.gemm_skinny(a, b, cc, M, N, K, None, bias=bv, resid=r, mode=mode)
-    hip.gemm_skinny(a.cuda(), b.cuda(), gc, M, N, K, ws, bias=dev(bv), resid=dev(r), mode=mode)
+    ad, bd = a.cuda(), b.cuda()
+    hip.gemm_skinny(ad, bd, gc, M, N, K, ws, bias=dev(bv), resid=dev(r), mode=mode)
+    g2 = c.cuda()
+    hip.gemm_skinny(ad, bd, g2, M, N, K, ws, bias=dev(bv), resid=dev(r), mode=mode)
     torch.cuda.synchronize()
     assert rel_err(gc, cc) < (1e-2 if mode != 1 else 2e-5 * math.sqrt(K))
     assert torch.equal(gc.cpu()[:, N:], cc[:, N:])
+    assert torch.equal(gc, g2)
+
+
+@pytest.mark.parametrize("M,I,K", [(64, 8960, 1536), (40, 200, 128), (64, 96, 4096)])
+def test_gemm_skinny_swiglu(hip, fake, M, I, K):
+    a = randn(M, K, dtype=BF, seed=1)
+    w = randn(2 * I, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
+    ca, ga = torch.zeros(M, I, dtype=BF), torch.zeros(M, I, dtype=BF).cuda()
+    ws = torch.zeros(32 * 64 * ((2 * I + 95) // 96 * 96)).cuda()
+    fake.gemm_skinny_swiglu(a, w, ca, M, I, K, None)
+    hip.gemm_skinny_swiglu(a.cuda(), w.cuda(), ga, M, I, K, ws)
+    torch.cuda.synchronize()
+    assert rel_err(ga, ca) < 2e-2
+
+
+def test_rope_append(hip, fake):
+    M, H, G, ctx = 6, 4, 2, 16
+    LD, W = (H + 2 * G) * HD, G * HD
+    qkv = randn(M, LD, dtype=BF, seed=1)
+    ang = randn(M, 64, seed=2)
+    cos, sin = torch.cos(ang), torch.sin(ang)
+    pos = torch.tensor([3, 0, 15, 7, 7, 1], dtype=I32)
+    kc, vc = torch.zeros(M * ctx * W, dtype=BF), torch.zeros(M * ctx * W, dtype=BF)
+    (qc, kc1, vc1), (qg, kg, vg) = run_pair(hip, fake, "rope_append", [qkv, cos, sin, kc, vc, pos, M, H, G, ctx], [0, 3, 4])
+    assert rel_err(qg, qc) < 1e-2 and rel_err(kg, kc1) < 1e-2 and torch.equal(vg, vc1)
+    assert torch.equal(kg != 0, kc1 != 0)
