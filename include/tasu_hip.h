@@ -56,6 +56,11 @@ int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C
 int tasu_gemm_skinny_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                           const float* resid, int M, int N, int K, int out_mode, float* workspace,
                           int64_t workspace_floats, void* stream);
+/* Projection + residual add + the NEXT RMSNorm in one call (o / down projection of a Qwen2DecoderLayer at M <= 64):
+ * C[M,N] fp32 (row stride N) = resid + bf16(A[M,K] . B[N,K]^T);  y[M,N] bf16 = norm_w * (C * rsqrt(mean(C^2) + eps)).   */
+int tasu_gemm_skinny_norm(const void* A, int lda, const void* B, int ldb, float* C, const float* resid, int M, int N, int K,
+                          const float* norm_w, void* y, float eps, float* workspace, int64_t workspace_floats,
+                          void* stream);
 /* Qwen2MLP gate|up projection + activation in one launch (modeling_qwen2.py Qwen2MLP.forward, M <= 64):
  * act[M, I] = bf16( bf16(silu(g)) * u ),  g | u = bf16(A[M,K] . Wgu[2I,K]^T)  (gate rows first, then up rows).        */
 int tasu_gemm_skinny_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,

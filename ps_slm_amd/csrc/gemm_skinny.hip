@@ -223,6 +223,45 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(Args p, int tiles) {
   }
 }
 
+// Row-wise finish of a split GEMM whose result feeds an RMSNorm (o / down projection of the decode step): block = row m;
+// C[m, :] = R[m, :] + bf16(sum of the slabs), then y[m, :] = bf16(w * (C[m, :] * rstd)) -- tasu_rmsnorm_fwd's arithmetic --
+// in the same launch (one launch less per norm: ~5 us of the ~9-us floor these small kernels run at).  N % 4 == 0.
+template <int BN>
+__global__ __launch_bounds__(256) void skinny_reduce_norm_kernel(Args p, int tiles, const float* __restrict__ nw,
+                                                                 bf16* __restrict__ y, float eps) {
+  constexpr int NI = BN / 16, TILE_F = 64 * BN;
+  __shared__ float red[4];
+  const int m = blockIdx.x;
+  const int wave_r = m >> 4, l15 = m & 15;
+  const int ngroups = p.N / 4;
+  float* crow = (float*)p.C + (size_t)m * p.ldc;
+  const float* rrow = p.R + (size_t)m * p.ldc;
+  float ss = 0.f;
+  for (int g = threadIdx.x; g < ngroups; g += 256) {
+    const int n = g * 4, tn = n / BN, nin = n - tn * BN;
+    const int e = ((wave_r * NI + (nin >> 4)) * 64 + ((nin & 15) >> 2) * 16 + l15) * 4;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.ksplit; ++k) s += *(const f32x4*)(p.slab + ((size_t)k * tiles + tn) * TILE_F + e);
+    const f32x4 r = *(const f32x4*)(rrow + n);
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = r[q] + bf16_round(s[q]);
+    *(f32x4*)(crow + n) = v;
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  ss = block_sum<4>(ss, red);
+  const float rs = rsqrtf(ss / (float)p.N + eps);
+  for (int g = threadIdx.x; g < ngroups; g += 256) {
+    const int n = g * 4;
+    const f32x4 v = *(const f32x4*)(crow + n);     // this thread's own store above
+    const f32x4 w = *(const f32x4*)(nw + n);
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = w[q] * (v[q] * rs);
+    *(bf16x4*)(y + (size_t)m * p.N + n) = __builtin_convertvector(o, bf16x4);
+  }
+}
+
 int cu_count() {
   static const int n = [] {
     int dev = 0, cus = 256;
@@ -235,8 +274,14 @@ int cu_count() {
   return n;
 }
 
+struct NormArgs {
+  const float* w = nullptr;   // RMSNorm weight [N]; null = no fused norm
+  bf16* y = nullptr;          // normalized bf16 output [M, N]
+  float eps = 0.f;
+};
+
 template <int BN, bool SWIGLU>
-int launch(Args a, int tiles, hipStream_t st) {
+int launch(Args a, int tiles, hipStream_t st, NormArgs na = NormArgs()) {
   constexpr int LDS = 4 * 2 * (A_BYTES + BN * BK * 2);
   static bool attr_set = false;
   if (!attr_set) {
@@ -244,8 +289,14 @@ int launch(Args a, int tiles, hipStream_t st) {
     attr_set = true;
   }
   TASU_LAUNCH((gemm_skinny_kernel<BN, SWIGLU>), dim3(tiles, a.ksplit), dim3(256), LDS, st, a);
-  if (a.ksplit > 1)
-    TASU_LAUNCH((skinny_reduce_kernel<BN, SWIGLU>), dim3((tiles * 16 * BN + 255) / 256), dim3(256), 0, st, a, tiles);
+  if (a.ksplit > 1) {
+    if (na.w)
+      TASU_LAUNCH((skinny_reduce_norm_kernel<BN>), dim3(a.M), dim3(256), 0, st, a, tiles, na.w, na.y, na.eps);
+    else
+      TASU_LAUNCH((skinny_reduce_kernel<BN, SWIGLU>), dim3((tiles * 16 * BN + 255) / 256), dim3(256), 0, st, a, tiles);
+  } else if (na.w) {
+    return tasu_rmsnorm_fwd((const float*)a.C, na.w, na.y, nullptr, a.M, a.N, na.eps, st);   // unsplit: C is final
+  }
   return TASU_OK;
 }
 
@@ -257,7 +308,7 @@ int launch(Args a, int tiles, hipStream_t st) {
 //   few tiles: 64-wide, K split to about one block per CU, at most 4 ways when K is short
 //       (down 1536 x 8960: 24 tiles x 10 = 15.0 us vs 45.3 us unsplit; qkv / o, K = 1536: 8.5-9 us at any split).
 template <bool SWIGLU>
-int plan_and_launch(Args a, float* ws, size_t ws_floats, hipStream_t st) {
+int plan_and_launch(Args a, float* ws, size_t ws_floats, hipStream_t st, NormArgs na = NormArgs()) {
   const int cus = cu_count();
   const int nk = a.K / BK;
   static const int force_bn = [] { const char* e = getenv("TASU_SKINNY_BN"); return e ? atoi(e) : 0; }();
@@ -285,7 +336,7 @@ int plan_and_launch(Args a, float* ws, size_t ws_floats, hipStream_t st) {
   const int tiles = (a.N + cols - 1) / cols;
   a.ksplit = best_ks;
   a.slab = ws;
-  return best_bn == 96 ? launch<96, SWIGLU>(a, tiles, st) : launch<64, SWIGLU>(a, tiles, st);
+  return best_bn == 96 ? launch<96, SWIGLU>(a, tiles, st, na) : launch<64, SWIGLU>(a, tiles, st, na);
 }
 
 }  // namespace tasu_skinny
@@ -334,4 +385,32 @@ extern "C" int tasu_gemm_skinny_swiglu(const void* A, int lda, const void* Wgu, 
   a.out_mode = TASU_GEMM_OUT_BF16;
   a.up_row0 = I;
   return plan_and_launch<true>(a, workspace, workspace ? (size_t)workspace_floats : 0, (hipStream_t)stream);
+}
+
+extern "C" int tasu_gemm_skinny_norm(const void* A, int lda, const void* B, int ldb, float* C, const float* resid, int M, int N,
+                                     int K, const float* norm_w, void* y, float eps, float* workspace,
+                                     int64_t workspace_floats, void* stream) {
+  using namespace tasu_skinny;
+  if (!A || !B || !C || !resid || !norm_w || !y || M <= 0 || M > 64 || N <= 0 || N % 4 || K <= 0 || K % 64 || lda % 8 || ldb % 8)
+    return TASU_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)workspace & 15)) return TASU_ERR_ARG;
+  Args a;
+  a.A = (const bf16*)A;
+  a.B = (const bf16*)B;
+  a.C = C;
+  a.R = resid;
+  a.bias = nullptr;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.lda = lda;
+  a.ldb = ldb;
+  a.ldc = N;
+  a.out_mode = TASU_GEMM_OUT_F32_RESID_BF16R;
+  a.up_row0 = 0;
+  NormArgs na;
+  na.w = norm_w;
+  na.y = (bf16*)y;
+  na.eps = eps;
+  return plan_and_launch<false>(a, workspace, workspace ? (size_t)workspace_floats : 0, (hipStream_t)stream, na);
 }

@@ -163,20 +163,23 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
         ops.kv_index_reorder(index_tmp, index, None, slot_d, M, ctx)
         ops.embed_rows(llm.embed, ids_d, x, M, D)
         ops.rope_table(pos_d, cos, sin, HD, geo.rope_theta)
+        ops.rmsnorm_fwd(x, llm.layers[0]["ln1"], xn, None, geo.rms_eps)
         for l, w in enumerate(llm.layers):
-            ops.rmsnorm_fwd(x, w["ln1"], xn, None, geo.rms_eps)
+            next_norm = llm.layers[l + 1]["ln1"] if l + 1 < L else llm.norm      # the norm that consumes this layer's output
             gemm(xn, w["wqkv"], qkv, M, LDQ, D, bias=w["bqkv"])
             ops.rope_append(qkv, cos, sin, kc[l], vc[l], slot_d, M, H, G, ctx)
             ops.attn_decode(qkv, kc[l], vc[l], index, kstart, lens_d, ao, M, H, G, ctx, scale)
-            gemm(ao, w["wo"], x2, M, D, H * HD, resid=x, mode=GEMM_RESID)
-            ops.rmsnorm_fwd(x2, w["ln2"], xn, None, geo.rms_eps)
-            if M <= 64:
+            if M <= 64:                                                          # projection + residual + next norm fused
+                ops.gemm_skinny_norm(ao, w["wo"], x2, x, M, D, H * HD, w["ln2"], xn, geo.rms_eps, ws)
                 ops.gemm_skinny_swiglu(xn, w["wgu"], act, M, I, D, ws)
+                ops.gemm_skinny_norm(act, w["wd"], x, x2, M, D, I, next_norm, xn, geo.rms_eps, ws)
             else:
+                ops.gemm(ao, w["wo"], x2, M, D, H * HD, resid=x, mode=GEMM_RESID)
+                ops.rmsnorm_fwd(x2, w["ln2"], xn, None, geo.rms_eps)
                 ops.gemm(xn, w["wgu"], gu, M, 2 * I, D)
                 ops.swiglu_fwd(gu, act, M, I)
-            gemm(act, w["wd"], x, M, D, I, resid=x2, mode=GEMM_RESID)
-        ops.rmsnorm_fwd(x, llm.norm, xn, None, geo.rms_eps)
+                ops.gemm(act, w["wd"], x, M, D, I, resid=x2, mode=GEMM_RESID)
+                ops.rmsnorm_fwd(x, next_norm, xn, None, geo.rms_eps)
         gemm(xn, llm.head, logits, M, V, D)
         ops.logprob_topk(logits, M, V, K, banned, ban, tv, ti)
 

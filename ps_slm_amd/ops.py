@@ -193,6 +193,12 @@ class HipOps:
     def kv_append(self, qkv, kc, vc, pos, M, H, G, ctx):
         self._chk(self.lib.tasu_kv_append(_p(qkv), _p(kc), _p(vc), _p(pos), M, H, G, ctx, self._stream()), "tasu_kv_append")
 
+    def gemm_skinny_norm(self, a, b, c, resid, M, N, K, norm_w, y, eps, ws):
+        """c (fp32) = resid + bf16(a @ b^T); y = rmsnorm(c, norm_w) -- decode-step projection with the next norm fused."""
+        self._chk(self.lib.tasu_gemm_skinny_norm(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), _p(resid), M, N, K, _p(norm_w),
+                                                 _p(y), eps, _p(ws), 0 if ws is None else ws.numel(), self._stream()),
+                  "tasu_gemm_skinny_norm")
+
     def gemm_skinny_swiglu(self, a, wgu, act, M, I, K, ws):
         """act[M, I] = swiglu(a[M,K] @ wgu[2I,K]^T) in one launch (decode step)."""
         self._chk(self.lib.tasu_gemm_skinny_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), M, I, K,

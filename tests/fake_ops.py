@@ -363,6 +363,10 @@ class FakeOps:
         k3[r, pos.long()] = qkv[:M, H * HD:H * HD + W]
         v3[r, pos.long()] = qkv[:M, H * HD + W:]
 
+    def gemm_skinny_norm(self, a, b, c, resid, M, N, K, norm_w, y, eps, ws):
+        self.gemm(a, b, c, M, N, K, resid=resid, mode=2)
+        self.rmsnorm_fwd(c[:M], norm_w, y[:M], None, eps)
+
     def gemm_skinny_swiglu(self, a, wgu, act, M, I, K, ws):
         gu = torch.empty(M, 2 * I, dtype=torch.bfloat16)
         self.gemm(a, wgu, gu, M, 2 * I, K)

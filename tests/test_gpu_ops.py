@@ -441,6 +441,18 @@ def test_gemm_skinny_swiglu(hip, fake, M, I, K):
     assert rel_err(ga, ca) < 2e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 1536, 8960), (64, 1536, 1536), (33, 256, 512), (64, 17920, 128)])
+def test_gemm_skinny_norm(hip, fake, M, N, K):
+    a = randn(M, K, dtype=BF, seed=1)
+    b = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
+    r = randn(M, N, seed=3)
+    w = randn(N, seed=4).abs() + 0.5
+    ws = torch.zeros(32 * 64 * ((N + 95) // 96 * 96)).cuda()
+    (cc, yc), (cg, yg) = run_pair(hip, fake, "gemm_skinny_norm", [a, b, torch.zeros(M, N), r, M, N, K, w, torch.zeros(M, N, dtype=BF),
+                                                                  1e-6, ws], [2, 8])
+    assert rel_err(cg, cc) < 1e-2 and rel_err(yg, yc) < 2e-2
+
+
 def test_rope_append(hip, fake):
     M, H, G, ctx = 6, 4, 2, 16
     LD, W = (H + 2 * G) * HD, G * HD
