@@ -166,6 +166,36 @@ def cpu_baseline(timeout_s=240):
                           f"(8 cores): 0.14 utterances/s"}
 
 
+def decode_leg(core, raw, B, new_tokens=200, beams=4):
+    """Second half of BASELINE.json's metric ("...; decode tok/s"): beam-4 generate of the same model on rank 0, prompt of
+    24 ids + <speech> -> 128 merged positions, exactly `new_tokens` generated positions per utterance (an EOS id that never
+    matches keeps every run the same length).  Timed region = prefill + the whole decode loop, second run."""
+    from ps_slm_amd.decode import beam_search_generate
+    ids = raw["input_ids"][:, :25]
+    am = torch.ones_like(ids, dtype=torch.bool)
+
+    def run():
+        st = core.prepare_text(ids, am, None, raw["post_ids"], None, None)
+        core.forward_projector_text(st)
+        return beam_search_generate(core, st, num_beams=beams, max_new_tokens=new_tokens, eos_token_id=-1, pad_token_id=0)
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_new = int(out.shape[1])
+    weight_bytes = 2 * sum(int(w[k].numel()) for w in core.llm.layers for k in ("wqkv", "wo", "wgu", "wd")) \
+        + 2 * int(core.llm.head.numel())
+    return {"metric": "decode tokens/sec (beam 4, emitted tokens)", "value": round(B * n_new / dt, 1), "unit": "tokens/s",
+            "beam_tokens_per_s": round(beams * B * n_new / dt, 1), "ms_per_step": round(dt / n_new * 1e3, 3),
+            "config": {"utterances": B, "beams": beams, "prefill_len": 128, "new_tokens": n_new},
+            "roofline": {"bound": "hbm", "achieved": round(weight_bytes / (dt / n_new) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(weight_bytes / (dt / n_new) / 8e12, 4),
+                         "note": "bf16 weight bytes streamed once per generated position / wall time per position"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +207,7 @@ def main():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--drop-prob", type=float, default=0.0, help="CPS token drop (0 keeps S fixed at 256)")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of hipGraph replay")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode tok/s leg (second half of BASELINE.json's metric)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker()
@@ -272,7 +303,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
         if os.path.isfile(pmc) and args.model == "qwen2.5-1.5b" and B == 16:
             # measured offline with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction);
-            # bytes per gemm_nt_kernel launch, averaged over the same launches `achieved` averages over
+            # bytes per GEMM launch, averaged over the same launches `achieved` averages over
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         line = {
             "metric": "train utterances/sec (Qwen2.5-1.5B align)", "value": round(utt_per_s, 2), "unit": "utterances/s",
@@ -284,12 +315,14 @@ def main():
                        "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "gemm_nt_kernel (tasu_gemm_nt_bf16)", "launches_per_step": n_launch // max(args.steps, 1),
+                         "kernel": "tasu_pipe::gemm_pipe_kernel (tasu_gemm_nt_bf16_ws)", "launches_per_step": n_launch // max(args.steps, 1),
                          "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
                          "algorithmic_gflop_per_launch": round(gemm_flops_step * args.steps / max(n_launch, 1) / 1e9, 2),
                          "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4), "launch": "hipGraph replay" if core.use_graphs else "eager",
                          "whole_step_tflops": round(total_flops_per_utt(geo, S, n_audio) * B * args.steps / dt / 1e12, 1)},
         }
+        if world == 1 and not args.no_decode:
+            line["decode"] = decode_leg(core, raw, B)
         if world == 1 and not args.no_cpu_baseline and args.model == "qwen2.5-1.5b":
             del engine, model, core
             torch.cuda.empty_cache()
