@@ -123,6 +123,11 @@ int tasu_attn_bwd_dq(const void* qkv, const void* kt, const uint8_t* key_mask, c
 int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t* key_mask, const void* dout, const void* dout_t,
                       const float* lse, const float* delta, float* dk_part, float* dv_part, int B, int S, int H, int G,
                       float scale, int causal, void* stream);
+/* tasu_attn_bwd_dq + tasu_attn_bwd_dkv in ONE launch (same arguments, same results): the dQ and dK/dV blocks share the
+ * grid, so neither kernel's tail leaves CUs idle. */
+int tasu_attn_bwd(const void* qkv, const void* qt, const void* kt, const uint8_t* key_mask, const void* dout,
+                  const void* dout_t, const float* lse, const float* delta, void* dqkv, float* dk_part, float* dv_part, int B,
+                  int S, int H, int G, float scale, int causal, void* stream);
 
 /* -------------------------------------------------------------------------------------------- SwiGLU
  * act = bf16(bf16(silu(gate)) * up) on the fused [M, 2I] gate|up activation (modeling_qwen2.py:46-48),

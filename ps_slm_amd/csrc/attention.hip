@@ -254,17 +254,17 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16* __restri
 }
 
 // =============================================================================== backward: dQ
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ kt_g,
-                                                             const uint8_t* __restrict__ kmask,
-                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                             const float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                             int S, int Spad, int H, int G, float scale, int causal) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * ROW_TILE_BYTES + TR_TILE_BYTES];
+constexpr int DQ_LDS = 2 * ROW_TILE_BYTES + TR_TILE_BYTES;
+__device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, const bf16* __restrict__ kt_g,
+                                                 const uint8_t* __restrict__ kmask, const bf16* __restrict__ dout,
+                                                 const float* __restrict__ lse, const float* __restrict__ delta,
+                                                 bf16* __restrict__ dqkv, int S, int Spad, int H, int G, float scale,
+                                                 int causal, int bx, int by, int bz, char* smem) {
   char* sK = smem;
   char* sV = smem + ROW_TILE_BYTES;
   char* sKt = smem + 2 * ROW_TILE_BYTES;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int qt = bx, h = by, b = bz;
   const int g = h / (H / G);
   const int LD = (H + 2 * G) * HD;
   const bf16* qbase = qkv + (size_t)b * S * LD + h * HD;
@@ -351,21 +351,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 // dK^T / dV^T accumulate in registers over the HPB heads x the (causal) query tiles, and only H/HPB fp32 partials
 // per kv head go to memory (HPB = TASU_ATTN_DKV_HPB(H/G): 3 for Qwen2.5-1.5B -> 2 partials per kv head; writing one
 // partial per QUERY head cost 50 MB of fp32 stores per call and dominated the kernel).  tasu_rope_bwd sums them.
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ qt_g,
-                                                              const uint8_t* __restrict__ kmask,
-                                                              const bf16* __restrict__ dout,
-                                                              const bf16* __restrict__ dout_t,
-                                                              const float* __restrict__ lse, const float* __restrict__ delta,
-                                                              float* __restrict__ dk_part, float* __restrict__ dv_part, int S,
-                                                              int Spad, int H, int G, int hpb, float scale, int causal) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 tiles + lse[64] + delta[64]
+constexpr int DKV_LDS = 2 * ROW_TILE_BYTES + 2 * TR_TILE_BYTES + 128 * 4;   // 4 tiles + lse[64] + delta[64]
+__device__ __forceinline__ void attn_bwd_dkv_body(const bf16* __restrict__ qkv, const bf16* __restrict__ qt_g,
+                                                  const uint8_t* __restrict__ kmask, const bf16* __restrict__ dout,
+                                                  const bf16* __restrict__ dout_t, const float* __restrict__ lse,
+                                                  const float* __restrict__ delta, float* __restrict__ dk_part,
+                                                  float* __restrict__ dv_part, int S, int Spad, int H, int G, int hpb,
+                                                  float scale, int causal, int bx, int by, int bz, char* smem) {
   char* sQ = smem;
   char* sdO = smem + ROW_TILE_BYTES;
   char* sQt = smem + 2 * ROW_TILE_BYTES;
   char* sdOt = smem + 2 * ROW_TILE_BYTES + TR_TILE_BYTES;
   float* s_ld = (float*)(smem + 2 * ROW_TILE_BYTES + 2 * TR_TILE_BYTES);   // [0,64) lse, [64,128) delta of the q tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ktile = blockIdx.x, hg = blockIdx.y, b = blockIdx.z;      // hg: index of the HPB-head group
+  const int ktile = bx, hg = by, b = bz;      // hg: index of the HPB-head group
   const int h0 = hg * hpb;
   const int g = h0 / (H / G);
   const int LD = (H + 2 * G) * HD;
@@ -457,6 +456,52 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16* __rest
   }
 }
 
+// ---- launchable forms.  attn_bwd_kernel runs BOTH halves of the attention backward in one grid: blocks [0, n_dkv) are
+// dK/dV blocks (one per CU-slot, ~50 us each), the rest dQ blocks (three short rounds); launched one after the other the
+// two kernels leave half of the chip idle in their tails (dQ: 768 blocks on 512 slots; dK/dV: 256 blocks, one round).
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ kt_g,
+                                                             const uint8_t* __restrict__ kmask,
+                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                             int S, int Spad, int H, int G, float scale, int causal) {
+  __shared__ __attribute__((aligned(16))) char smem[DQ_LDS];
+  attn_bwd_dq_body(qkv, kt_g, kmask, dout, lse, delta, dqkv, S, Spad, H, G, scale, causal, blockIdx.x, blockIdx.y, blockIdx.z,
+                   smem);
+}
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ qt_g,
+                                                              const uint8_t* __restrict__ kmask,
+                                                              const bf16* __restrict__ dout,
+                                                              const bf16* __restrict__ dout_t,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              float* __restrict__ dk_part, float* __restrict__ dv_part, int S,
+                                                              int Spad, int H, int G, int hpb, float scale, int causal) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_bwd_dkv_body(qkv, qt_g, kmask, dout, dout_t, lse, delta, dk_part, dv_part, S, Spad, H, G, hpb, scale, causal, blockIdx.x,
+                    blockIdx.y, blockIdx.z, smem);
+}
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ qt_g,
+                                                          const bf16* __restrict__ kt_g, const uint8_t* __restrict__ kmask,
+                                                          const bf16* __restrict__ dout, const bf16* __restrict__ dout_t,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          bf16* __restrict__ dqkv, float* __restrict__ dk_part,
+                                                          float* __restrict__ dv_part, int S, int Spad, int H, int G, int hpb,
+                                                          float scale, int causal, int B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nt = (S + 63) >> 6;
+  const int n_dkv = nt * (H / hpb) * B;
+  int id = blockIdx.x;
+  if (id < n_dkv) {
+    // longest blocks first: under the causal mask key tile 0 meets every query tile, the last key tile only one
+    const int bx = id % nt, by = (id / nt) % (H / hpb), bz = id / (nt * (H / hpb));
+    attn_bwd_dkv_body(qkv, qt_g, kmask, dout, dout_t, lse, delta, dk_part, dv_part, S, Spad, H, G, hpb, scale, causal, bx, by, bz,
+                      smem);
+  } else {
+    id -= n_dkv;
+    const int bx = nt - 1 - id % nt, by = (id / nt) % H, bz = id / (nt * H);      // long (late) query tiles first
+    attn_bwd_dq_body(qkv, kt_g, kmask, dout, lse, delta, dqkv, S, Spad, H, G, scale, causal, bx, by, bz, smem);
+  }
+}
+
 }  // namespace
 
 static inline bool bad_geo(int B, int S, int H, int G) { return B <= 0 || S <= 0 || H <= 0 || G <= 0 || H % G != 0; }
@@ -497,7 +542,6 @@ extern "C" int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t*
     return TASU_ERR_ARG;
   const int hpb = TASU_ATTN_DKV_HPB(H / G);
   dim3 grid((S + 63) / 64, H / hpb, B);
-  constexpr int DKV_LDS = 2 * ROW_TILE_BYTES + 2 * TR_TILE_BYTES + 128 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
@@ -506,5 +550,24 @@ extern "C" int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t*
   TASU_LAUNCH(attn_bwd_dkv_kernel, grid, dim3(256), DKV_LDS, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)qt,
                      key_mask, (const bf16*)dout, (const bf16*)dout_t, lse, delta, dk_part, dv_part, S, spad_of(S), H, G,
                      hpb, scale, causal);
+  return TASU_OK;
+}
+
+extern "C" int tasu_attn_bwd(const void* qkv, const void* qt, const void* kt, const uint8_t* key_mask, const void* dout,
+                             const void* dout_t, const float* lse, const float* delta, void* dqkv, float* dk_part,
+                             float* dv_part, int B, int S, int H, int G, float scale, int causal, void* stream) {
+  if (!qkv || !qt || !kt || !key_mask || !dout || !dout_t || !lse || !delta || !dqkv || !dk_part || !dv_part ||
+      bad_geo(B, S, H, G))
+    return TASU_ERR_ARG;
+  const int hpb = TASU_ATTN_DKV_HPB(H / G);
+  const int nt = (S + 63) / 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    attr_set = true;
+  }
+  TASU_LAUNCH(attn_bwd_kernel, dim3(nt * (H / hpb) * B + nt * H * B), dim3(256), DKV_LDS, (hipStream_t)stream, (const bf16*)qkv,
+              (const bf16*)qt, (const bf16*)kt, key_mask, (const bf16*)dout, (const bf16*)dout_t, lse, delta, (bf16*)dqkv, dk_part,
+              dv_part, S, spad_of(S), H, G, hpb, scale, causal, B);
   return TASU_OK;
 }

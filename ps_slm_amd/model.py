@@ -495,9 +495,8 @@ class TasuModel:
             ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
             ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)
             ops.attn_bwd_prep(dao, d["ao"][l], delta, dao_t, B, S, H)
-            ops.attn_bwd_dq(d["qkv"][l], d["kt"][l], d["key_mask"], dao, d["lse"][l], delta, dqkv, B, S, H, G, scale, True)
-            ops.attn_bwd_dkv(d["qkv"][l], d["qt"][l], d["key_mask"], dao, dao_t, d["lse"][l], delta, dkp, dvp, B, S, H, G,
-                             scale, True)
+            ops.attn_bwd(d["qkv"][l], d["qt"][l], d["kt"][l], d["key_mask"], dao, dao_t, d["lse"][l], delta, dqkv, dkp, dvp,
+                         B, S, H, G, scale, True)                       # dQ and dK/dV blocks share one grid
             ops.rope_bwd(dqkv, dkp, dvp, cos, sin, B, S, H, G)
             ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)
             ops.rmsnorm_bwd(dn, x_in, w["ln1"], rstd[2 * l], dx, dxb, True)

@@ -119,6 +119,12 @@ class HipOps:
                                              _p(dk_part), _p(dv_part), B, S, H, G, scale, int(causal), self._stream()),
                   "tasu_attn_bwd_dkv")
 
+    def attn_bwd(self, qkv, qt, kt, key_mask, dout, dout_t, lse, delta, dqkv, dk_part, dv_part, B, S, H, G, scale, causal):
+        """attn_bwd_dq + attn_bwd_dkv in one launch."""
+        self._chk(self.lib.tasu_attn_bwd(_p(qkv), _p(qt), _p(kt), _p(key_mask), _p(dout), _p(dout_t), _p(lse), _p(delta),
+                                         _p(dqkv), _p(dk_part), _p(dv_part), B, S, H, G, scale, int(causal), self._stream()),
+                  "tasu_attn_bwd")
+
     # ------------------------------------------------------------------ activations
     def swiglu_fwd(self, gu, act, M, I):
         self._chk(self.lib.tasu_swiglu_fwd(_p(gu), _p(act), M, I, self._stream()), "tasu_swiglu_fwd")

@@ -198,6 +198,10 @@ class FakeOps:
             dv.permute(0, 2, 1, 3).reshape(B, S, H // hpb, hpb, HD).sum(3))
 
     # ---------------------------------------------------------------- activations
+    def attn_bwd(self, qkv, qt, kt, key_mask, dout, dout_t, lse, delta, dqkv, dk_part, dv_part, B, S, H, G, scale, causal):
+        self.attn_bwd_dq(qkv, kt, key_mask, dout, lse, delta, dqkv, B, S, H, G, scale, causal)
+        self.attn_bwd_dkv(qkv, qt, key_mask, dout, dout_t, lse, delta, dk_part, dv_part, B, S, H, G, scale, causal)
+
     def swiglu_fwd(self, gu, act, M, I):
         g, u = gu[:, :I].float(), gu[:, I:].float()
         act.copy_(_bf(_bf(F.silu(g)).float() * u))

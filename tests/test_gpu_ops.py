@@ -232,6 +232,14 @@ def test_attention_fwd_bwd(hip, fake, B, S, H, G, mask_kind, causal):
     n_used = M * (H // hpb) * HD
     assert rel_err(kg.reshape(-1)[:n_used], kc.reshape(-1)[:n_used]) < 2e-2
     assert rel_err(vg.reshape(-1)[:n_used], vc.reshape(-1)[:n_used]) < 2e-2
+    # the single-launch form gives the same bits as the two launches
+    q2, k2, v2 = torch.zeros(M, LD, dtype=BF).cuda(), torch.zeros(M, H * HD).cuda(), torch.zeros(M, H * HD).cuda()
+    hip.attn_bwd(qkv.cuda(), qt.cuda(), kt.cuda(), km.cuda(), dout.cuda(), tc.cuda(), lc.cuda(), dc.cuda(), q2, k2, v2, B, S, H, G,
+                 scale, causal)
+    torch.cuda.synchronize()
+    assert torch.equal(q2.cpu().view(B, S, -1)[:, :, :H * HD], qg.view(B, S, -1)[:, :, :H * HD])
+    assert torch.equal(k2.cpu().reshape(-1)[:n_used], kg.reshape(-1)[:n_used])
+    assert torch.equal(v2.cpu().reshape(-1)[:n_used], vg.reshape(-1)[:n_used])
 
 
 def test_attention_online_softmax_rescale(hip, fake):
