@@ -113,7 +113,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   char* sK = smem;
   char* sVt = smem + ROW_TILE_BYTES;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // grid (H, B, query tiles): the late query tiles, which meet the most key tiles under the causal mask, are dispatched
+  // first, so the 1.5-round grid (768 blocks on 512 slots at 16 x 12 x 256) ends on the short ones
+  const int qt = (int)gridDim.z - 1 - (int)blockIdx.z, h = blockIdx.x, b = blockIdx.y;
   const int g = h / (H / G);
   const int LD = (H + 2 * G) * HD;
   const bf16* qbase = qkv + (size_t)b * S * LD + h * HD;
@@ -510,7 +512,7 @@ static inline int spad_of(int S) { return (S + 63) & ~63; }
 extern "C" int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key_mask, void* out, float* lse, int B,
                              int S, int H, int G, float scale, int causal, void* stream) {
   if (!qkv || !vt || !key_mask || !out || !lse || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
-  dim3 grid((S + 63) / 64, H, B);
+  dim3 grid(H, B, (S + 63) / 64);
   TASU_LAUNCH(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)vt,
                      key_mask, (bf16*)out, lse, S, spad_of(S), H, G, scale, causal);
   return TASU_OK;

@@ -448,7 +448,9 @@ class TasuModel:
             return
         row_loss = self._buf("row_loss", (M,), f32)
         row_hit = self._buf("row_hit", (M,), torch.int32)
-        row_arg = self._buf("row_arg", (M,), torch.int32)
+        # per-row argmax (the reference's `preds`, ps-slm.py:533) only matters at labelled rows for the accuracy; the kernel
+        # skips the scan of ignored rows when no argmax buffer is passed, which the training step does
+        row_arg = None if need_backward else self._buf("row_arg", (M,), torch.int32)
         if need_backward and not self.keep_logits:
             dlogits = logits                                   # overwrite in place (throughput mode)
         elif need_backward:
