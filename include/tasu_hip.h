@@ -50,6 +50,12 @@ int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C
                          const float* resid, int M, int N, int K, int out_mode, void* workspace,
                          int64_t workspace_bytes, void* stream);
 
+/* Qwen2MLP gate|up projection with the activation in its epilogue (modeling_qwen2.py Qwen2MLP.forward), training step:
+ * gu[M, 2I] = bf16(A[M,K] . Wgu[2I,K]^T) (gate columns first; saved for the backward) and
+ * act[M, I] = bf16( bf16(silu(g)) * u ) -- bit-identical to tasu_gemm_nt_bf16 + tasu_swiglu_fwd.  I % 4 == 0.        */
+int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K,
+                             void* stream);
+
 /* Weight-streaming GEMM for M <= 64 rows (the decode step; transformers modeling_qwen2.py linears at one token per beam).
  * workspace: fp32 split-K slabs, 32 * 64 * round_up(N, 96) floats always suffice; may be NULL (no K split).  Launches
  * sharing a workspace must be ordered on one stream.  Operand rules and out_mode as tasu_gemm_nt_bf16.              */

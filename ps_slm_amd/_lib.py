@@ -17,6 +17,7 @@ PROTOTYPES = {
     "tasu_abi_version": [],
     "tasu_gemm_nt_bf16": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
     "tasu_gemm_nt_bf16_ws": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
+    "tasu_gemm_gate_up_swiglu": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp],
     "tasu_gemm_skinny_bf16": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "tasu_transpose_bf16": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "tasu_cast_f32_bf16": [vp, vp, i64, vp],

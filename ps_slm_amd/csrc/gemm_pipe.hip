@@ -29,6 +29,7 @@
 namespace tasu_pipe {
 
 constexpr int BM = 256, BK = 64;
+constexpr int OUT_GU_SWIGLU = 3;    // internal epilogue of tasu_gemm_gate_up_swiglu (after the three TASU_GEMM_OUT_* modes)
 
 struct Args {
   const bf16* A;
@@ -39,6 +40,7 @@ struct Args {
   int M, N, K;
   int lda, ldb, ldc;
   int tiles_m, tiles_n;
+  bf16* act;            // OUT_GU_SWIGLU: act[M, N] (N = I); C = gate|up [M, 2N]; B = Wgu [2N, K], gate rows first
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -86,7 +88,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
       tile_coords(p, s, ntiles, tm, tn);
       const int row0 = tm * BM, col0 = tn * BN;
       rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)row0 * p.lda), 0, 0x7fffffff, 0x00020000);
-      rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (size_t)col0 * p.ldb), 0, 0x7fffffff, 0x00020000);
+      // OUT_GU_SWIGLU: the tile's 128 weight rows are, per 64-row half (= one MFMA wave column), 32 gate rows and the 32 up
+      // rows of the same output columns; the descriptor then starts at the weight matrix itself
+      const int brow0 = OUT_MODE == OUT_GU_SWIGLU ? 0 : col0;
+      rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (size_t)brow0 * p.ldb), 0, 0x7fffffff, 0x00020000);
       // piece pc = 8 tile rows x 128 B; lane l -> tile row pc*8 + (l>>3), LDS chunk l&7 <- global chunk (l&7)^((row>>1)&7)
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
@@ -98,7 +103,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
       for (int i = 0; i < PB; ++i) {
         const int r = (wave * PB + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        vob[i] = (min(col0 + r, p.N - 1) - col0) * p.ldb * 2 + c * 16;
+        if (OUT_MODE == OUT_GU_SWIGLU) {
+          const int half = r >> 6, rr = r & 63;                       // wave column, row inside it
+          const int ocol = min(tn * 64 + half * 32 + (rr & 31), p.N - 1);   // output (act) column
+          vob[i] = (ocol + (rr >= 32 ? p.N : 0)) * p.ldb * 2 + c * 16;
+        } else {
+          vob[i] = (min(col0 + r, p.N - 1) - col0) * p.ldb * 2 + c * 16;
+        }
       }
     };
     auto issue = [&](int slot) {
@@ -213,6 +224,31 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   };
 
   // acc[i][j][r] = C[m][n], m = row0 + wr*128 + i*16 + (lane&15), n = col0 + wc*WN + j*16 + (lane>>4)*4 + r
+  // OUT_GU_SWIGLU epilogue: fragments j = 0, 1 of a wave are gate columns, j = 2, 3 the up values of the same columns
+  auto store_gu_swiglu = [&](int row0, int tn) {
+    int l15 = lane & 15, l4 = (lane >> 4) * 4;
+    asm volatile("" : "+v"(l15), "+v"(l4));
+    bf16* gu = (bf16*)p.C;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      asm volatile("" ::: "memory");
+      const int m = row0 + wr * WM + i * 16 + l15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NI / 2; ++j) {
+        const int n = tn * 64 + wc * 32 + j * 16 + l4;              // act column; N % 4 == 0
+        if (n >= p.N) continue;
+        const bf16x4 g4 = __builtin_convertvector(acc[i][j], bf16x4), u4 = __builtin_convertvector(acc[i][j + NI / 2], bf16x4);
+        bf16x4 a4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a4[r] = (bf16)(bf16_round(silu_f((float)g4[r])) * (float)u4[r]);
+        *(bf16x4*)(gu + (size_t)m * (2 * (size_t)p.N) + n) = g4;
+        *(bf16x4*)(gu + (size_t)m * (2 * (size_t)p.N) + p.N + n) = u4;
+        *(bf16x4*)(p.act + (size_t)m * p.N + n) = a4;
+      }
+    }
+  };
+
   auto store_tile = [&](int row0, int col0) {
     // opaque copies of the lane coordinates: keeps the 32 per-fragment output addresses from being hoisted out of the
     // tile loop into registers that the K loop needs (the kernel sits at the 256-VGPR limit of two waves per SIMD)
@@ -279,7 +315,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
     tile_coords(p, s, ntiles, tm, tn);
     for (int kt = 0; kt + 1 < nk; ++kt) cur = kstep(T{}, cur);
     cur = kstep(F{}, cur);                         // no read-ahead into the next tile: the fragment registers are free
-    store_tile(tm * BM, tn * BN);                  // for the epilogue, whose stores then drain under the next tile
+    if constexpr (OUT_MODE == OUT_GU_SWIGLU) store_gu_swiglu(tm * BM, tn);
+    else store_tile(tm * BM, tn * BN);             // for the epilogue, whose stores then drain under the next tile
     zero_acc();
     if (s + (int)gridDim.x < ntiles) read_frags(fa0, fb0, cur, 0);   // landed before the barrier of the step just done
   }
@@ -307,7 +344,7 @@ int launch(Args a, hipStream_t st) {
     attr_set = true;
   }
   a.tiles_m = (a.M + BM - 1) / BM;
-  a.tiles_n = (a.N + BN - 1) / BN;
+  a.tiles_n = OUT_MODE == OUT_GU_SWIGLU ? (a.N + 63) / 64 : (a.N + BN - 1) / BN;
   const int ntiles = a.tiles_m * a.tiles_n;
   const int grid = ntiles < cu_count() ? ntiles : cu_count();
   TASU_LAUNCH((gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS>), dim3(grid), dim3(512), LDS, st, a);
@@ -338,6 +375,7 @@ int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void
   a.ldb = ldb;
   a.ldc = ldc;
   a.tiles_m = a.tiles_n = 0;
+  a.act = nullptr;
   const bool hb = bias != nullptr;
   switch (out_mode) {
     case TASU_GEMM_OUT_BF16:
@@ -350,4 +388,26 @@ int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void
     default:
       return TASU_ERR_ARG;
   }
+}
+
+extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I,
+                                        int K, void* stream) {
+  using namespace tasu_pipe;
+  if (!A || !Wgu || !gu || !act || M <= 0 || I <= 0 || I % 4 || K <= 0 || K % BK || lda % 8 || ldw % 8) return TASU_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)Wgu & 15) || ((uintptr_t)gu & 7) || ((uintptr_t)act & 7)) return TASU_ERR_ARG;
+  Args a;
+  a.A = (const bf16*)A;
+  a.B = (const bf16*)Wgu;
+  a.C = gu;
+  a.R = nullptr;
+  a.bias = nullptr;
+  a.M = M;
+  a.N = I;
+  a.K = K;
+  a.lda = lda;
+  a.ldb = ldw;
+  a.ldc = 2 * I;
+  a.tiles_m = a.tiles_n = 0;
+  a.act = (bf16*)act;
+  return launch<128, OUT_GU_SWIGLU, false>(a, (hipStream_t)stream);
 }

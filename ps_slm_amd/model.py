@@ -434,8 +434,7 @@ class TasuModel:
             ops.attn_fwd(qkv[l], vt, d["key_mask"], ao[l], lse[l], B, S, H, G, scale, True)
             ops.gemm(ao[l], w["wo"], x_mid, M, D, H * HD, resid=x_in, mode=GEMM_RESID)
             ops.rmsnorm_fwd(x_mid, w["ln2"], xn, rstd[2 * l + 1], geo.rms_eps)
-            ops.gemm(xn, w["wgu"], gu[l], M, 2 * I, D)
-            ops.swiglu_fwd(gu[l], act, M, I)
+            ops.gemm_gate_up_swiglu(xn, w["wgu"], gu[l], act, M, I, D)          # gate|up projection + SwiGLU epilogue
             ops.gemm(act, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
         d.update(xs=xs, cos=cos, sin=sin, rstd=rstd, qkv=qkv, qt=qt, kt=kt, ao=ao, lse=lse, gu=gu)
         if logits_rows == "none":                              # decode prefill: the caller projects the last rows only

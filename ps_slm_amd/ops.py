@@ -53,6 +53,11 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_nt_bf16_ws(_p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), _p(resid), M, N, K, mode,
                                                 _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()), "tasu_gemm_nt_bf16_ws")
 
+    def gemm_gate_up_swiglu(self, a, wgu, gu, act, M, I, K):
+        """gu[M,2I] = a @ wgu^T and act[M,I] = swiglu(gu) in one launch (training step)."""
+        self._chk(self.lib.tasu_gemm_gate_up_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), M, I, K,
+                                                    self._stream()), "tasu_gemm_gate_up_swiglu")
+
     def gemm_skinny(self, a, b, c, M, N, K, ws, bias=None, resid=None, mode=GEMM_BF16):
         """M <= 64 weight-streaming GEMM (decode step); ws: fp32 workspace tensor."""
         self._chk(self.lib.tasu_gemm_skinny_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(bias),

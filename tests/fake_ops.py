@@ -367,6 +367,10 @@ class FakeOps:
         k3[r, pos.long()] = qkv[:M, H * HD:H * HD + W]
         v3[r, pos.long()] = qkv[:M, H * HD + W:]
 
+    def gemm_gate_up_swiglu(self, a, wgu, gu, act, M, I, K):
+        self.gemm(a, wgu, gu, M, 2 * I, K)
+        self.swiglu_fwd(gu, act, M, I)
+
     def gemm_skinny_norm(self, a, b, c, resid, M, N, K, norm_w, y, eps, ws):
         self.gemm(a, b, c, M, N, K, resid=resid, mode=2)
         self.rmsnorm_fwd(c[:M], norm_w, y[:M], None, eps)
