@@ -380,15 +380,14 @@ extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int l
     return e ? atoi(e) : 0;
   }();
   // ---- kernel / tile policy (MI355X, cold weight operands as inside the training step; tools/bench_gemm.py --cold):
-  //  * the pipelined 256 x {128, 96} kernel with loader waves (gemm_pipe.hip) is the fastest on every decoder, lm_head
-  //    and projector shape (qkv 700 -> 822, gate_up 780 -> 837, d_down 690 -> 772, d_lm_head 975 -> 1065 TFLOP/s ...);
-  //    the width is the one that fills whole rounds of 256 one-per-CU blocks better, the narrow tile paying ~11 % for
-  //    its lower FLOP per staged byte;
+  //  * the pipelined kernel with loader waves (gemm_pipe.hip; tiles 256 x 128, 128 x 192, 256 x 96) is the fastest on
+  //    every decoder, lm_head and projector shape (qkv 700 -> 822, gate_up 780 -> 837, d_down 690 -> 772, d_lm_head
+  //    975 -> 1149 TFLOP/s ...); the tile is the one that fills whole rounds of 256 one-per-CU blocks at the least cost;
   //  * grids that cover less than half of the CUs but are deep (K >= 8192) split K over 256 x 192 tiles instead;
   //  * problems of at most 128 rows keep the 128-row tiles of this file (a 256-row tile would be half empty).
   int use_pipe_bn = 0;
   if (kernel_choice() == 2) {
-    use_pipe_bn = (forced_bn == 96 || forced_bn == 128) ? forced_bn : -1;
+    use_pipe_bn = (forced_bn == 96 || forced_bn == 128 || forced_bn == 192) ? forced_bn : -1;
   } else if (kernel_choice() == 0 && forced_bn == 0 && M > 128) {
     use_pipe_bn = -1;
   }
@@ -399,9 +398,13 @@ extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int l
       use_pipe_bn = 0;                              // falls through to the split-K tile below
     } else {
       if (use_pipe_bn < 0) {
-        const long w128 = (t128 + 255) / 256, w96 = (t96 + 255) / 256;
-        const double e128 = (double)t128 / (double)(w128 * 256), e96 = 0.89 * (double)t96 / (double)(w96 * 256);
-        use_pipe_bn = e96 > e128 ? 96 : 128;
+        // time ~ rounds of one-block-per-CU grids x tile area / per-FLOP efficiency of the tile (8192^3, cold: 256 x 128
+        // 1300, 128 x 192 1123, 256 x 96 ~1040 TFLOP/s).  N = 1536 at M = 4096 -> 256 tiles of 128 x 192 (+7 % over
+        // 256 x 96: fewer staged bytes and fragment reads per FLOP); wide grids -> 256 x 128.
+        auto cost = [&](long tiles, double area, double eff) { return (double)((tiles + 255) / 256) * area / eff; };
+        const long t192 = (long)((M + 127) / 128) * ((N + 191) / 192);
+        const double c128 = cost(t128, 256.0 * 128, 1.00), c192 = cost(t192, 128.0 * 192, 0.86), c96 = cost(t96, 256.0 * 96, 0.80);
+        use_pipe_bn = c128 <= c192 && c128 <= c96 ? 128 : (c192 <= c96 ? 192 : 96);
       }
       return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, use_pipe_bn, st);
     }

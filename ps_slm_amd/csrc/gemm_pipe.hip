@@ -1,7 +1,7 @@
 // Persistent, software-pipelined bf16 NT GEMM for gfx950.
 //
-// One 512-thread workgroup per CU walks a static list of 256 x BN output tiles (BN = 128 or 96, BK = 64):
-//   * waves 0..3 ("MFMA waves", one per SIMD, 2 x 2 over the tile, wave tile 128 x BN/2) carry fragment reads and MFMAs
+// One 512-thread workgroup per CU walks a static list of output tiles (256 x 128, 256 x 96 or 128 x 192; BK = 64):
+//   * waves 0..3 ("MFMA waves", one per SIMD, 2 x 2 over the tile, wave tile BM/2 x BN/2) carry fragment reads and MFMAs
 //     only.  Each K-step is two phases of 32 (24) MFMAs; every phase carries the 12 (11) ds_read_b128 of the NEXT phase,
 //     interleaved with sched_group_barrier, so a wave hides its own LDS latency; one raw s_barrier per K-step sits
 //     between the phases.
@@ -28,7 +28,7 @@
 
 namespace tasu_pipe {
 
-constexpr int BM = 256, BK = 64;
+constexpr int BK = 64;
 constexpr int OUT_GU_SWIGLU = 3;    // internal epilogue of tasu_gemm_gate_up_swiglu (after the three TASU_GEMM_OUT_* modes)
 
 struct Args {
@@ -60,15 +60,15 @@ __device__ __forceinline__ void tile_coords(const Args& p, int s, int ntiles, in
   tn = in_g / gsz;
 }
 
-template <int BN, int OUT_MODE, bool HAS_BIAS>
+template <int BM, int BN, int OUT_MODE, bool HAS_BIAS>
 __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int WM = 128, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
   constexpr int PA = BM / 32, PB = BN / 32;       // LDS-DMA pieces per loader wave per K-step: 8 + 4 (or 3)
   constexpr int NG = PA + PB;                      // vmcnt units per K-step per loader wave
   constexpr int NR = MI + NI;                      // fragment reads per phase
   constexpr int NM = MI * NI;                      // MFMAs per phase
-  static_assert(NG == 12 || NG == 11, "the counted vmcnt immediates below assume 12 or 11 pieces per K-step");
+  static_assert(NG >= 10 && NG <= 12, "the counted vmcnt immediates below cover 10, 11 or 12 pieces per K-step");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
   const int wave = wave_id & 3;                    // staging share (loader) / tile quadrant (MFMA wave)
@@ -128,12 +128,16 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
         if (ld_tile < ntiles) setup(ld_tile);
       }
     };
+    auto wait_keep_one_step = [&]() {              // all but the newest K-step's pieces have landed
+      if constexpr (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if constexpr (NG == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    };
     setup(ld_tile);
     issue(0);
     if (total > 1) {
       issue(1);
-      if (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      wait_keep_one_step();
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -142,8 +146,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
     for (int q = 0; q < total; ++q) {
       if (q + 2 < total) {
         issue(slot2);
-        if (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        wait_keep_one_step();
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
     return nxt;
   };
 
-  // acc[i][j][r] = C[m][n], m = row0 + wr*128 + i*16 + (lane&15), n = col0 + wc*WN + j*16 + (lane>>4)*4 + r
+  // acc[i][j][r] = C[m][n], m = row0 + wr*WM + i*16 + (lane&15), n = col0 + wc*WN + j*16 + (lane>>4)*4 + r
   // OUT_GU_SWIGLU epilogue: fragments j = 0, 1 of a wave are gate columns, j = 2, 3 the up values of the same columns
   auto store_gu_swiglu = [&](int row0, int tn) {
     int l15 = lane & 15, l4 = (lane >> 4) * 4;
@@ -334,12 +337,12 @@ int cu_count() {
   return n;
 }
 
-template <int BN, int OUT_MODE, bool HAS_BIAS>
+template <int BM, int BN, int OUT_MODE, bool HAS_BIAS>
 int launch(Args a, hipStream_t st) {
   constexpr int LDS = 3 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS>,
+    (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<BM, BN, OUT_MODE, HAS_BIAS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
@@ -347,13 +350,15 @@ int launch(Args a, hipStream_t st) {
   a.tiles_n = OUT_MODE == OUT_GU_SWIGLU ? (a.N + 63) / 64 : (a.N + BN - 1) / BN;
   const int ntiles = a.tiles_m * a.tiles_n;
   const int grid = ntiles < cu_count() ? ntiles : cu_count();
-  TASU_LAUNCH((gemm_pipe_kernel<BN, OUT_MODE, HAS_BIAS>), dim3(grid), dim3(512), LDS, st, a);
+  TASU_LAUNCH((gemm_pipe_kernel<BM, BN, OUT_MODE, HAS_BIAS>), dim3(grid), dim3(512), LDS, st, a);
   return TASU_OK;
 }
 
+// tile = 256 x 128, 256 x 96, or (bn == 192) 128 x 192
 template <int OUT_MODE, bool HAS_BIAS>
 int launch_bn(const Args& a, int bn, hipStream_t st) {
-  return bn == 96 ? launch<96, OUT_MODE, HAS_BIAS>(a, st) : launch<128, OUT_MODE, HAS_BIAS>(a, st);
+  if (bn == 192) return launch<128, 192, OUT_MODE, HAS_BIAS>(a, st);
+  return bn == 96 ? launch<256, 96, OUT_MODE, HAS_BIAS>(a, st) : launch<256, 128, OUT_MODE, HAS_BIAS>(a, st);
 }
 
 }  // namespace tasu_pipe
@@ -409,5 +414,5 @@ extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu,
   a.ldc = 2 * I;
   a.tiles_m = a.tiles_n = 0;
   a.act = (bf16*)act;
-  return launch<128, OUT_GU_SWIGLU, false>(a, (hipStream_t)stream);
+  return launch<256, 128, OUT_GU_SWIGLU, false>(a, (hipStream_t)stream);
 }
