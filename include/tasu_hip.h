@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 1
+#define TASU_ABI_VERSION 2
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM

@@ -63,7 +63,7 @@ PROTOTYPES = {
     "tasu_embed_rows": [vp, vp, vp, i32, i32, vp],
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 
