@@ -67,6 +67,11 @@ int tasu_gemm_skinny_bf16(const void* A, int lda, const void* B, int ldb, void* 
 int tasu_gemm_skinny_norm(const void* A, int lda, const void* B, int ldb, float* C, const float* resid, int M, int N, int K,
                           const float* norm_w, void* y, float eps, float* workspace, int64_t workspace_floats,
                           void* stream);
+/* q|k|v projection (+ bias) of a decode step with RoPE and the cache append behind it (Qwen2Attention.forward at one token
+ * per beam): qkv[M, (H+2G)*128] bf16 rotated in place semantics of tasu_rope_append; k, v -> cache[row, pos[row]].     */
+int tasu_gemm_skinny_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw, const void* bias, void* qkv, int M, int H,
+                              int G, int K, const float* cos_tab, const float* sin_tab, void* kcache, void* vcache,
+                              const int32_t* pos, int ctx, float* workspace, int64_t workspace_floats, void* stream);
 /* Qwen2MLP gate|up projection + activation in one launch (modeling_qwen2.py Qwen2MLP.forward, M <= 64):
  * act[M, I] = bf16( bf16(silu(g)) * u ),  g | u = bf16(A[M,K] . Wgu[2I,K]^T)  (gate rows first, then up rows).        */
 int tasu_gemm_skinny_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,

@@ -262,6 +262,87 @@ __global__ __launch_bounds__(256) void skinny_reduce_norm_kernel(Args p, int til
   }
 }
 
+// Row-wise finish of the split qkv projection of a decode step: block = row m; q|k|v[m, :] = bf16(sum of the slabs + bias),
+// RoPE on the H query and G key heads (tables [M, 64]), rotated row written to qkv[m, :] and its k and v appended to
+// cache[m, pos[m]] -- skinny_reduce + tasu_rope_append in one launch, same arithmetic and rounding points.
+template <int BN>
+__global__ __launch_bounds__(256) void skinny_reduce_rope_kernel(Args p, int tiles, const float* __restrict__ ct,
+                                                                 const float* __restrict__ st, bf16* __restrict__ kc,
+                                                                 bf16* __restrict__ vc, const int32_t* __restrict__ pos, int H,
+                                                                 int G, int ctx) {
+  constexpr int NI = BN / 16, TILE_F = 64 * BN, HD = 128;
+  const int m = blockIdx.x;
+  const int wave_r = m >> 4, l15 = m & 15;
+  const int W = G * HD;
+  // bf16-rounded (sum over the slabs + bias) of four 4-column groups of row m at once: 4 independent loads in flight per split
+  auto cols4x4 = [&](const int (&n)[4], bf16x4 (&o)[4]) {
+    size_t off[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int tn = n[g] / BN, nin = n[g] - tn * BN;
+      off[g] = (size_t)tn * TILE_F + ((wave_r * NI + (nin >> 4)) * 64 + ((nin & 15) >> 2) * 16 + l15) * 4;
+    }
+    f32x4 s[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) s[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int k = 0; k < p.ksplit; ++k) {
+      const float* base = p.slab + (size_t)k * tiles * TILE_F;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) s[g] += *(const f32x4*)(base + off[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[g][q] = (bf16)(s[g][q] + (p.bias ? (float)p.bias[n[g] + q] : 0.f));
+  };
+  bf16* out = (bf16*)p.C + (size_t)m * p.ldc;
+  const size_t slot = ((size_t)m * ctx + pos[m]) * W;
+  const int nrot = (H + G) * 8;                               // rotation units: (head, 8-wide chunk of the low half)
+  for (int u = threadIdx.x; u < nrot + G * 8; u += 256) {
+    bf16x4 v[4];
+    if (u < nrot) {
+      const int hh = u >> 3, c = (u & 7) * 8;
+      const int n[4] = {hh * HD + c, hh * HD + c + 4, hh * HD + 64 + c, hh * HD + 64 + c + 4};
+      cols4x4(n, v);
+      const f32x4 c0 = *(const f32x4*)(ct + (size_t)m * 64 + c), c1 = *(const f32x4*)(ct + (size_t)m * 64 + c + 4);
+      const f32x4 s0 = *(const f32x4*)(st + (size_t)m * 64 + c), s1 = *(const f32x4*)(st + (size_t)m * 64 + c + 4);
+      bf16x8 lo, hi;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float cs = j < 4 ? c0[j] : c1[j - 4], sn = j < 4 ? s0[j] : s1[j - 4];
+        const float x1 = (float)(j < 4 ? v[0][j] : v[1][j - 4]), x2 = (float)(j < 4 ? v[2][j] : v[3][j - 4]);
+        lo[j] = (bf16)(x1 * cs - x2 * sn);
+        hi[j] = (bf16)(x2 * cs + x1 * sn);
+      }
+      *(bf16x8*)(out + hh * HD + c) = lo;
+      *(bf16x8*)(out + hh * HD + 64 + c) = hi;
+      if (hh >= H) {
+        bf16* kd = kc + slot + (hh - H) * HD;
+        *(bf16x8*)(kd + c) = lo;
+        *(bf16x8*)(kd + 64 + c) = hi;
+      }
+    } else {                                                   // V: 16-element units
+      const int c = (u - nrot) * 16;
+      const int nb = (H + G) * HD + c;
+      const int n[4] = {nb, nb + 4, nb + 8, nb + 12};
+      cols4x4(n, v);
+      bf16x8 v0, v1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v0[j] = v[0][j];
+        v0[4 + j] = v[1][j];
+        v1[j] = v[2][j];
+        v1[4 + j] = v[3][j];
+      }
+      *(bf16x8*)(out + nb) = v0;
+      *(bf16x8*)(out + nb + 8) = v1;
+      *(bf16x8*)(vc + slot + c) = v0;
+      *(bf16x8*)(vc + slot + c + 8) = v1;
+    }
+  }
+}
+
 int cu_count() {
   static const int n = [] {
     int dev = 0, cus = 256;
@@ -278,6 +359,13 @@ struct NormArgs {
   const float* w = nullptr;   // RMSNorm weight [N]; null = no fused norm
   bf16* y = nullptr;          // normalized bf16 output [M, N]
   float eps = 0.f;
+  // qkv finish (RoPE + cache append) instead of a norm: cos != nullptr
+  const float* cos = nullptr;
+  const float* sin = nullptr;
+  bf16* kc = nullptr;
+  bf16* vc = nullptr;
+  const int32_t* pos = nullptr;
+  int H = 0, G = 0, ctx = 0;
 };
 
 template <int BN, bool SWIGLU>
@@ -292,10 +380,15 @@ int launch(Args a, int tiles, hipStream_t st, NormArgs na = NormArgs()) {
   if (a.ksplit > 1) {
     if (na.w)
       TASU_LAUNCH((skinny_reduce_norm_kernel<BN>), dim3(a.M), dim3(256), 0, st, a, tiles, na.w, na.y, na.eps);
+    else if (na.cos)
+      TASU_LAUNCH((skinny_reduce_rope_kernel<BN>), dim3(a.M), dim3(256), 0, st, a, tiles, na.cos, na.sin, na.kc, na.vc, na.pos,
+                  na.H, na.G, na.ctx);
     else
       TASU_LAUNCH((skinny_reduce_kernel<BN, SWIGLU>), dim3((tiles * 16 * BN + 255) / 256), dim3(256), 0, st, a, tiles);
   } else if (na.w) {
     return tasu_rmsnorm_fwd((const float*)a.C, na.w, na.y, nullptr, a.M, a.N, na.eps, st);   // unsplit: C is final
+  } else if (na.cos) {
+    return tasu_rope_append(a.C, na.cos, na.sin, na.kc, na.vc, na.pos, a.M, na.H, na.G, na.ctx, st);
   }
   return TASU_OK;
 }
@@ -412,5 +505,40 @@ extern "C" int tasu_gemm_skinny_norm(const void* A, int lda, const void* B, int 
   na.w = norm_w;
   na.y = (bf16*)y;
   na.eps = eps;
+  return plan_and_launch<false>(a, workspace, workspace ? (size_t)workspace_floats : 0, (hipStream_t)stream, na);
+}
+
+extern "C" int tasu_gemm_skinny_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw, const void* bias, void* qkv, int M,
+                                         int H, int G, int K, const float* cos_tab, const float* sin_tab, void* kcache,
+                                         void* vcache, const int32_t* pos, int ctx, float* workspace, int64_t workspace_floats,
+                                         void* stream) {
+  using namespace tasu_skinny;
+  if (!A || !Wqkv || !qkv || !cos_tab || !sin_tab || !kcache || !vcache || !pos || M <= 0 || M > 64 || H <= 0 || G <= 0 || K <= 0 ||
+      K % 64 || lda % 8 || ldw % 8 || ctx <= 0)
+    return TASU_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)Wqkv & 15) || ((uintptr_t)workspace & 15) || ((uintptr_t)qkv & 15)) return TASU_ERR_ARG;
+  Args a;
+  a.A = (const bf16*)A;
+  a.B = (const bf16*)Wqkv;
+  a.C = qkv;
+  a.R = nullptr;
+  a.bias = (const bf16*)bias;
+  a.M = M;
+  a.N = (H + 2 * G) * 128;
+  a.K = K;
+  a.lda = lda;
+  a.ldb = ldw;
+  a.ldc = a.N;
+  a.out_mode = TASU_GEMM_OUT_BF16;
+  a.up_row0 = 0;
+  NormArgs na;
+  na.cos = cos_tab;
+  na.sin = sin_tab;
+  na.kc = (bf16*)kcache;
+  na.vc = (bf16*)vcache;
+  na.pos = pos;
+  na.H = H;
+  na.G = G;
+  na.ctx = ctx;
   return plan_and_launch<false>(a, workspace, workspace ? (size_t)workspace_floats : 0, (hipStream_t)stream, na);
 }

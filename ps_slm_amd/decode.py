@@ -166,8 +166,11 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
         ops.rmsnorm_fwd(x, llm.layers[0]["ln1"], xn, None, geo.rms_eps)
         for l, w in enumerate(llm.layers):
             next_norm = llm.layers[l + 1]["ln1"] if l + 1 < L else llm.norm      # the norm that consumes this layer's output
-            gemm(xn, w["wqkv"], qkv, M, LDQ, D, bias=w["bqkv"])
-            ops.rope_append(qkv, cos, sin, kc[l], vc[l], slot_d, M, H, G, ctx)
+            if M <= 64:
+                ops.gemm_skinny_qkv_rope(xn, w["wqkv"], w["bqkv"], qkv, M, H, G, D, cos, sin, kc[l], vc[l], slot_d, ctx, ws)
+            else:
+                ops.gemm(xn, w["wqkv"], qkv, M, LDQ, D, bias=w["bqkv"])
+                ops.rope_append(qkv, cos, sin, kc[l], vc[l], slot_d, M, H, G, ctx)
             ops.attn_decode(qkv, kc[l], vc[l], index, kstart, lens_d, ao, M, H, G, ctx, scale)
             if M <= 64:                                                          # projection + residual + next norm fused
                 ops.gemm_skinny_norm(ao, w["wo"], x2, x, M, D, H * HD, w["ln2"], xn, geo.rms_eps, ws)

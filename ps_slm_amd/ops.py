@@ -210,6 +210,13 @@ class HipOps:
                                                  _p(y), eps, _p(ws), 0 if ws is None else ws.numel(), self._stream()),
                   "tasu_gemm_skinny_norm")
 
+    def gemm_skinny_qkv_rope(self, a, wqkv, bias, qkv, M, H, G, K, cos, sin, kc, vc, pos, ctx, ws):
+        """qkv = rope(a @ wqkv^T + bias); k, v appended to the cache at pos -- one call per decode-step layer."""
+        self._chk(self.lib.tasu_gemm_skinny_qkv_rope(_p(a), a.stride(0), _p(wqkv), wqkv.stride(0), _p(bias), _p(qkv), M, H, G, K,
+                                                     _p(cos), _p(sin), _p(kc), _p(vc), _p(pos), ctx, _p(ws),
+                                                     0 if ws is None else ws.numel(), self._stream()),
+                  "tasu_gemm_skinny_qkv_rope")
+
     def gemm_skinny_swiglu(self, a, wgu, act, M, I, K, ws):
         """act[M, I] = swiglu(a[M,K] @ wgu[2I,K]^T) in one launch (decode step)."""
         self._chk(self.lib.tasu_gemm_skinny_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), M, I, K,

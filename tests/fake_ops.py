@@ -375,6 +375,10 @@ class FakeOps:
         self.gemm(a, b, c, M, N, K, resid=resid, mode=2)
         self.rmsnorm_fwd(c[:M], norm_w, y[:M], None, eps)
 
+    def gemm_skinny_qkv_rope(self, a, wqkv, bias, qkv, M, H, G, K, cos, sin, kc, vc, pos, ctx, ws):
+        self.gemm(a, wqkv, qkv, M, (H + 2 * G) * HD, K, bias=bias)
+        self.rope_append(qkv, cos, sin, kc, vc, pos, M, H, G, ctx)
+
     def gemm_skinny_swiglu(self, a, wgu, act, M, I, K, ws):
         gu = torch.empty(M, 2 * I, dtype=torch.bfloat16)
         self.gemm(a, wgu, gu, M, 2 * I, K)

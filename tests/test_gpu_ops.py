@@ -480,6 +480,24 @@ def test_gemm_skinny_norm(hip, fake, M, N, K):
     assert rel_err(cg, cc) < 1e-2 and rel_err(yg, yc) < 2e-2
 
 
+@pytest.mark.parametrize("M,H,G,K", [(64, 12, 2, 1536), (10, 4, 2, 256), (33, 2, 1, 128)])
+def test_gemm_skinny_qkv_rope(hip, fake, M, H, G, K):
+    ctx, LD, W = 16, (H + 2 * G) * HD, G * HD
+    a = randn(M, K, dtype=BF, seed=1)
+    w = randn(LD, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
+    bias = randn(LD, dtype=BF, seed=3)
+    ang = randn(M, 64, seed=4)
+    cos, sin = torch.cos(ang), torch.sin(ang)
+    pos = (torch.arange(M) % ctx).to(I32)
+    ws = torch.zeros(32 * 64 * ((LD + 95) // 96 * 96)).cuda()
+    (qc, kc1, vc1), (qg, kg, vg) = run_pair(hip, fake, "gemm_skinny_qkv_rope",
+                                            [a, w, bias, torch.zeros(M, LD, dtype=BF), M, H, G, K, cos, sin,
+                                             torch.zeros(M * ctx * W, dtype=BF), torch.zeros(M * ctx * W, dtype=BF), pos, ctx, ws],
+                                            [3, 10, 11])
+    assert rel_err(qg, qc) < 2e-2 and rel_err(kg, kc1) < 2e-2 and rel_err(vg, vc1) < 2e-2
+    assert torch.equal(kg != 0, kc1 != 0) or float(((kg != 0) != (kc1 != 0)).float().mean()) < 1e-3
+
+
 def test_rope_append(hip, fake):
     M, H, G, ctx = 6, 4, 2, 16
     LD, W = (H + 2 * G) * HD, G * HD
