@@ -201,12 +201,14 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(Args p, int tiles) {
   const int tn = idx / (TILE_F / 4), e = idx - tn * (TILE_F / 4);
   const int lane = e & 63, j = (e >> 6) % NI, wave = (e >> 6) / NI;
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
   for (int k = 0; k < p.ksplit; ++k) s += *(const f32x4*)(p.slab + ((size_t)k * tiles + tn) * TILE_F + e * 4);
   const int m = wave * 16 + (lane & 15);
   if (SWIGLU) {
     // the thread that owns gate fragment j also reads the matching up fragment j + NI/2
     if (j >= NI / 2) return;
     f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int k = 0; k < p.ksplit; ++k)
       u += *(const f32x4*)(p.slab + ((size_t)k * tiles + tn) * TILE_F + (e + (NI / 2) * 64) * 4);
     const int n = tn * (BN / 2) + j * 16 + (lane >> 4) * 4;
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(256) void skinny_reduce_norm_kernel(Args p, int til
     const int n = g * 4, tn = n / BN, nin = n - tn * BN;
     const int e = ((wave_r * NI + (nin >> 4)) * 64 + ((nin & 15) >> 2) * 16 + l15) * 4;
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int k = 0; k < p.ksplit; ++k) s += *(const f32x4*)(p.slab + ((size_t)k * tiles + tn) * TILE_F + e);
     const f32x4 r = *(const f32x4*)(rrow + n);
     f32x4 v;
