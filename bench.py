@@ -47,7 +47,8 @@ def total_flops_per_utt(geo, S, n_audio):
 
 
 class TimedOps:
-    """Wraps HipOps.gemm with HIP event pairs recorded on the launch stream (torch's current stream)."""
+    """Wraps the GEMM launches of HipOps (gemm and the gate|up GEMM with the SwiGLU epilogue: every launch whose FLOPs
+    gemm_flops_per_utt counts) with HIP event pairs recorded on the launch stream (torch's current stream)."""
 
     def __init__(self, ops):
         self._ops = ops
@@ -57,14 +58,20 @@ class TimedOps:
     def __getattr__(self, name):
         return getattr(self._ops, name)
 
-    def gemm(self, *a, **k):
+    def _timed(self, fn, a, k):
         if not self.enabled:
-            return self._ops.gemm(*a, **k)
+            return fn(*a, **k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        self._ops.gemm(*a, **k)
+        fn(*a, **k)
         e1.record()
         self.events.append((e0, e1))
+
+    def gemm(self, *a, **k):
+        return self._timed(self._ops.gemm, a, k)
+
+    def gemm_gate_up_swiglu(self, *a, **k):
+        return self._timed(self._ops.gemm_gate_up_swiglu, a, k)
 
     def total_ms(self):
         return sum(a.elapsed_time(b) for a, b in self.events)
@@ -315,7 +322,7 @@ def main():
                        "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "tasu_pipe::gemm_pipe_kernel (tasu_gemm_nt_bf16_ws)", "launches_per_step": n_launch // max(args.steps, 1),
+                         "kernel": "tasu_pipe::gemm_pipe_kernel (tasu_gemm_nt_bf16_ws, tasu_gemm_gate_up_swiglu)", "launches_per_step": n_launch // max(args.steps, 1),
                          "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
                          "algorithmic_gflop_per_launch": round(gemm_flops_step * args.steps / max(n_launch, 1) / 1e9, 2),
                          "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4), "launch": "hipGraph replay" if core.use_graphs else "eager",
