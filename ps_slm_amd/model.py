@@ -225,6 +225,7 @@ class StepState:
     Rap: int = 0       # padded to 64
     dev: dict = field(default_factory=dict)
     out: object = None
+    path: str = "text"   # "text" (pseudo-posterior) or "audio" (encoder + PSD): part of the graph keys, the buffers differ
 
 
 class TasuModel:
@@ -350,6 +351,7 @@ class TasuModel:
         rows, new_lens, Lmax = psd_on_device(self, post, B, T, Te, fl_dev, do_psd)
         st = self._finish_prepare(input_ids, attention_mask, labels, new_lens, Lmax)
         st.Ra, st.Rap = B * Lmax, rup(B * Lmax, 64)
+        st.path = "audio"
         st.dev["post"] = rows
         st.dev["psd_lens"] = new_lens
         self._projector_from_posterior(st)
@@ -559,7 +561,7 @@ class TasuModel:
         graph.replay()
 
     def _shape_key(self, st, tag):
-        return (tag, st.B, st.S, st.Ra, st.Rap, self.keep_logits)
+        return (tag, st.path, st.B, st.S, st.Ra, st.Rap, self.keep_logits)
 
     def run_forward_text(self, st, compute_loss=True, need_backward=True):
         """forward_projector_text + forward_llm, graph-replayed when enabled."""
@@ -567,6 +569,11 @@ class TasuModel:
             self.forward_projector_text(st)
             self.forward_llm(st, compute_loss=compute_loss, need_backward=need_backward)
         self._graphed(self._shape_key(st, ("fwd_text", compute_loss, need_backward)), fn, st)
+
+    def run_forward_llm(self, st, compute_loss=True, need_backward=True):
+        """forward_llm alone (audio branch: the projector has already run eagerly behind the host-side PSD plan)."""
+        self._graphed(self._shape_key(st, ("fwd_llm", compute_loss, need_backward)),
+                      lambda: self.forward_llm(st, compute_loss=compute_loss, need_backward=need_backward), st)
 
     def run_backward(self, st):
         if "audio_rows_pad" not in st.dev:

@@ -261,7 +261,7 @@ class slam_model_asr:
         else:
             st = core.prepare_audio(input_ids, attention_mask, labels, input_features, input_feature_length,
                                     do_psd=self.do_psd)
-            core.forward_llm(st, compute_loss=labels is not None, need_backward=self.training)
+            core.run_forward_llm(st, compute_loss=labels is not None, need_backward=self.training)
         self.last_state = st
         if labels is None:
             return CausalLMOutput(None, core.logits_view(st)), -1

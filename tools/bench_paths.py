@@ -39,6 +39,7 @@ if what == "decode":
                       "beam_tok_per_s": round(4 * B * out.shape[1] / dt, 1), "ms_per_step": round(dt / out.shape[1] * 1e3, 3),
                       "weights_bytes_per_step": 2 * 1543714304}))
 else:
+    core.use_graphs = True
     eng = TasuEngine(model, load_ds_config(DEFAULT_DS_CONFIG))
     eng.train()
     batch = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
@@ -48,7 +49,7 @@ else:
         eng.backward(out.loss)
         eng.step()
         return out
-    for _ in range(2):
+    for _ in range(3):
         step()
     torch.cuda.synchronize()
     n = 5
