@@ -33,6 +33,74 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
   }
 }
 
+// Register-resident forms for D = NG * 256 (1536 -> 6, 3584 -> 14): the row is loaded once, all loads in flight together;
+// same arithmetic and summation order as the generic kernels.
+template <int NG>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              bf16* __restrict__ y, float* __restrict__ rstd, int M, float eps) {
+  constexpr int D = NG * 256;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * D + lane * 4;
+  f32x4 v[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) v[g] = *(const f32x4*)(xr + g * 256);
+  float ss = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) ss += v[g][0] * v[g][0] + v[g][1] * v[g][1] + v[g][2] * v[g][2] + v[g][3] * v[g][3];
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)D + eps);
+  if (lane == 0 && rstd) rstd[row] = r;
+  bf16* yr = y + (size_t)row * D + lane * 4;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const f32x4 gw = *(const f32x4*)(w + lane * 4 + g * 256);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = gw[j] * (v[g][j] * r);
+    *(bf16x4*)(yr + g * 256) = __builtin_convertvector(o, bf16x4);
+  }
+}
+
+template <int NG>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_reg_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ w, const float* __restrict__ rstd,
+                                                              float* __restrict__ dx, bf16* __restrict__ dxb, int accumulate,
+                                                              int M) {
+  constexpr int D = NG * 256;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const size_t base = (size_t)row * D + lane * 4;
+  f32x4 v[NG], d[NG], o[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    v[g] = *(const f32x4*)(x + base + g * 256);
+    d[g] = __builtin_convertvector(*(const bf16x4*)(dy + base + g * 256), f32x4);
+    o[g] = accumulate ? *(const f32x4*)(dx + base + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float r = rstd[row];
+  float dot = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const f32x4 gw = *(const f32x4*)(w + lane * 4 + g * 256);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      d[g][j] *= gw[j];                          // w * dy, reused below
+      dot += d[g][j] * v[g][j] * r;
+    }
+  }
+  dot = wave_sum(dot) / (float)D;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[g][j] += r * (d[g][j] - v[g][j] * r * dot);
+    *(f32x4*)(dx + base + g * 256) = o[g];
+    if (dxb) *(bf16x4*)(dxb + base + g * 256) = __builtin_convertvector(o[g], bf16x4);
+  }
+}
+
 // dx += rstd * (w*dy - xhat * mean(w*dy*xhat)),  xhat = x * rstd
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ rstd,
@@ -177,15 +245,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
 extern "C" int tasu_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, int M, int D, float eps,
                                 void* stream) {
   if (!x || !w || !y || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
-  TASU_LAUNCH(rmsnorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)y, rstd, M, D,
-                     eps);
+  const dim3 grid((M + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 1536) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<6>, grid, dim3(256), 0, st, x, w, (bf16*)y, rstd, M, eps);
+  else if (D == 3584) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<14>, grid, dim3(256), 0, st, x, w, (bf16*)y, rstd, M, eps);
+  else if (D == 256) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<1>, grid, dim3(256), 0, st, x, w, (bf16*)y, rstd, M, eps);
+  else TASU_LAUNCH(rmsnorm_fwd_kernel, grid, dim3(256), 0, st, x, w, (bf16*)y, rstd, M, D, eps);
   return TASU_OK;
 }
 extern "C" int tasu_rmsnorm_bwd(const void* dy, const float* x, const float* w, const float* rstd, float* dx, void* dx_bf16,
                                 int accumulate, int M, int D, void* stream) {
   if (!dy || !x || !w || !rstd || !dx || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
-  TASU_LAUNCH(rmsnorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, x, w, rstd,
-                     dx, (bf16*)dx_bf16, accumulate, M, D);
+  const dim3 grid((M + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16* d = (const bf16*)dy;
+  bf16* db = (bf16*)dx_bf16;
+  if (D == 1536) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<6>, grid, dim3(256), 0, st, d, x, w, rstd, dx, db, accumulate, M);
+  else if (D == 3584) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<14>, grid, dim3(256), 0, st, d, x, w, rstd, dx, db, accumulate, M);
+  else if (D == 256) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<1>, grid, dim3(256), 0, st, d, x, w, rstd, dx, db, accumulate, M);
+  else TASU_LAUNCH(rmsnorm_bwd_kernel, grid, dim3(256), 0, st, d, x, w, rstd, dx, db, accumulate, M, D);
   return TASU_OK;
 }
 extern "C" int tasu_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,

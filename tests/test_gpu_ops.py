@@ -140,7 +140,7 @@ def test_transpose_cast(hip, fake):
 
 
 # ------------------------------------------------------------------------------------------------ norms
-@pytest.mark.parametrize("M,D", [(37, 256), (512, 1536)])
+@pytest.mark.parametrize("M,D", [(37, 256), (512, 1536), (70, 3584), (33, 320)])
 def test_rmsnorm(hip, fake, M, D):
     x, w = randn(M, D, seed=1), 1 + 0.1 * randn(D, seed=2)
     (yc, rc), (yg, rg) = run_pair(hip, fake, "rmsnorm_fwd", [x, w, torch.zeros(M, D, dtype=BF), torch.zeros(M), 1e-6],

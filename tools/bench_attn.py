@@ -21,6 +21,7 @@ calls = {"fwd": lambda: ops.attn_fwd(qkv, vt, km, out, lse, B, S, H, G, sc, True
          "prep": lambda: ops.attn_bwd_prep(dout, out, delta, dout_t, B, S, H),
          "dq": lambda: ops.attn_bwd_dq(qkv, kt, km, dout, lse, delta, dqkv, B, S, H, G, sc, True),
          "dkv": lambda: ops.attn_bwd_dkv(qkv, qt, km, dout, dout_t, lse, delta, dkp, dvp, B, S, H, G, sc, True),
+         "bwd (dq+dkv, one launch)": lambda: ops.attn_bwd(qkv, qt, kt, km, dout, dout_t, lse, delta, dqkv, dkp, dvp, B, S, H, G, sc, True),
          "rope_bwd": lambda: ops.rope_bwd(dqkv, dkp, dvp, cos, sin, B, S, H, G)}
 for name, fn in calls.items():
     for _ in range(3): fn()
@@ -29,4 +30,4 @@ for name, fn in calls.items():
     e0.record()
     for _ in range(20): fn()
     e1.record(); torch.cuda.synchronize()
-    print(f"{name:9s} {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us", flush=True)
+    print(f"{name:26s} {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us", flush=True)
