@@ -134,6 +134,11 @@ def test_transpose_cast(hip, fake):
     dst = torch.full((256, 128), 7.0, dtype=BF)
     (c,), (g,) = run_pair(hip, fake, "transpose", [src, dst, 100, 203, 128, 256], [1])
     assert torch.equal(c, g)
+    # 16-byte aligned leading dimensions: interior tiles take the vectorised path, edge tiles the element-wise one
+    src = randn(200, 328, dtype=BF, seed=7)
+    dst = torch.full((384, 256), 7.0, dtype=BF)
+    (c,), (g,) = run_pair(hip, fake, "transpose", [src, dst, 200, 328, 256, 384], [1])
+    assert torch.equal(c, g)
     x = randn(1000 * 37 + 3, seed=6)
     (c,), (g,) = run_pair(hip, fake, "cast_bf16", [x, torch.zeros_like(x, dtype=BF)], [1])
     assert torch.equal(c, g)
