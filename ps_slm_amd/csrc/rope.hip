@@ -93,39 +93,74 @@ __global__ __launch_bounds__(256) void rope_fwd_kernel(bf16* __restrict__ qkv, c
 
 // Backward: q block of dqkv holds dQ (rotated space, bf16) -> un-rotate in place.  k/v blocks are produced from
 // the per-query-head fp32 partials: sum over the H/G heads of the group, un-rotate K, round to bf16.
-// grid (M, H + 2G), block 64 (one lane per rotation pair).
-__global__ __launch_bounds__(64) void rope_bwd_kernel(bf16* __restrict__ dqkv, const float* __restrict__ dk_part,
+// grid (ceil(M / TOK)), block 256: (H + 2G) * 8 threads per token, each owning the 8-wide chunk pair (x[c..c+7],
+// x[64+c..64+c+7]) of one head: 16-byte accesses throughout (one lane per rotation pair and one 64-thread block per head
+// moved 50 MB at 2.9 TB/s).
+__global__ __launch_bounds__(256) void rope_bwd_kernel(bf16* __restrict__ dqkv, const float* __restrict__ dk_part,
                                                       const float* __restrict__ dv_part, const float* __restrict__ ct,
-                                                      const float* __restrict__ st, int H, int G) {
-  const int m = blockIdx.x, hh = blockIdx.y, i = threadIdx.x;
+                                                      const float* __restrict__ st, int M, int H, int G) {
+  const int upt = (H + 2 * G) * 8;                       // units per token
+  const int tpb = upt <= 128 ? 256 / upt : 1;            // tokens per block
+  const int tpt = 256 / tpb;                             // threads per token
+  const int tl = threadIdx.x / tpt;
+  const int m = blockIdx.x * tpb + tl;
+  if (tl >= tpb || m >= M) return;
   const int LD = (H + 2 * G) * HD;
   const int np_g = (H / G) / TASU_ATTN_DKV_HPB(H / G);   // fp32 partials per kv head written by tasu_attn_bwd_dkv
   const int np = H / TASU_ATTN_DKV_HPB(H / G);
+  for (int u = threadIdx.x - tl * tpt; u < upt; u += tpt) {
+  const int hh = u >> 3, c = (u & 7) * 8;
   bf16* row = dqkv + (size_t)m * LD + hh * HD;
-  float y1, y2;
+  float y1[8], y2[8];
   if (hh < H) {
-    y1 = (float)row[i];
-    y2 = (float)row[i + 64];
+    const bf16x8 lo = *(const bf16x8*)(row + c), hi = *(const bf16x8*)(row + 64 + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      y1[j] = (float)lo[j];
+      y2[j] = (float)hi[j];
+    }
   } else {
     const bool isk = hh < H + G;
     const int g = isk ? hh - H : hh - H - G;
     const float* src = (isk ? dk_part : dv_part) + (size_t)m * (np * HD) + (size_t)g * np_g * HD;
-    y1 = 0.f;
-    y2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y1[j] = y2[j] = 0.f;
     for (int r = 0; r < np_g; ++r) {
-      y1 += src[r * HD + i];
-      y2 += src[r * HD + i + 64];
+      const f32x4 a0 = *(const f32x4*)(src + r * HD + c), a1 = *(const f32x4*)(src + r * HD + c + 4);
+      const f32x4 b0 = *(const f32x4*)(src + r * HD + 64 + c), b1 = *(const f32x4*)(src + r * HD + 64 + c + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y1[j] += a0[j];
+        y1[4 + j] += a1[j];
+        y2[j] += b0[j];
+        y2[4 + j] += b1[j];
+      }
     }
     if (!isk) {
-      row[i] = (bf16)y1;
-      row[i + 64] = (bf16)y2;
-      return;
+      bf16x8 lo, hi;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        lo[j] = (bf16)y1[j];
+        hi[j] = (bf16)y2[j];
+      }
+      *(bf16x8*)(row + c) = lo;
+      *(bf16x8*)(row + 64 + c) = hi;
+      continue;
     }
   }
-  const float c = ct[(size_t)m * 64 + i], s = st[(size_t)m * 64 + i];
+  const f32x4 c0 = *(const f32x4*)(ct + (size_t)m * 64 + c), c1 = *(const f32x4*)(ct + (size_t)m * 64 + c + 4);
+  const f32x4 s0 = *(const f32x4*)(st + (size_t)m * 64 + c), s1 = *(const f32x4*)(st + (size_t)m * 64 + c + 4);
   // forward: y1 = x1 c - x2 s ; y2 = x2 c + x1 s   =>   dx1 = dy1 c + dy2 s ; dx2 = dy2 c - dy1 s
-  row[i] = (bf16)(y1 * c + y2 * s);
-  row[i + 64] = (bf16)(y2 * c - y1 * s);
+  bf16x8 lo, hi;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float cs = j < 4 ? c0[j] : c1[j - 4], sn = j < 4 ? s0[j] : s1[j - 4];
+    lo[j] = (bf16)(y1[j] * cs + y2[j] * sn);
+    hi[j] = (bf16)(y2[j] * cs - y1[j] * sn);
+  }
+  *(bf16x8*)(row + c) = lo;
+  *(bf16x8*)(row + 64 + c) = hi;
+  }
 }
 }  // namespace
 
@@ -151,8 +186,9 @@ extern "C" int tasu_rope_bwd(void* dqkv, const float* dk_part, const float* dv_p
                              const float* sin_tab, int B, int S, int H, int G, void* stream) {
   if (!dqkv || !dk_part || !dv_part || !cos_tab || !sin_tab || B <= 0 || S <= 0 || H <= 0 || G <= 0 || H % G)
     return TASU_ERR_ARG;
-  dim3 grid(B * S, H + 2 * G);
-  TASU_LAUNCH(rope_bwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, (bf16*)dqkv, dk_part, dv_part, cos_tab,
-                     sin_tab, H, G);
+  const int upt = (H + 2 * G) * 8;
+  const int tpb = upt <= 128 ? 256 / upt : 1, M = B * S;
+  TASU_LAUNCH(rope_bwd_kernel, dim3((M + tpb - 1) / tpb), dim3(256), 0, (hipStream_t)stream, (bf16*)dqkv, dk_part, dv_part,
+              cos_tab, sin_tab, M, H, G);
   return TASU_OK;
 }

@@ -200,7 +200,7 @@ def make_mask(B, S, kind):
     return m
 
 
-@pytest.mark.parametrize("B,S,H,G", [(2, 100, 4, 2), (2, 256, 12, 2), (1, 64, 2, 1)])
+@pytest.mark.parametrize("B,S,H,G", [(2, 100, 4, 2), (2, 256, 12, 2), (1, 64, 2, 1), (1, 70, 28, 4)])
 def test_rope(hip, fake, B, S, H, G):
     M, LD, Spad = B * S, (H + 2 * G) * HD, (S + 63) // 64 * 64
     pos = torch.randint(0, S, (M,), dtype=I32)
