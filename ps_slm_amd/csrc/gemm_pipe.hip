@@ -257,6 +257,16 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
     // tile loop into registers that the K loop needs (the kernel sits at the 256-VGPR limit of two waves per SIMD)
     int l15 = lane & 15, l4 = (lane >> 4) * 4;
     asm volatile("" : "+v"(l15), "+v"(l4));
+    // the bias depends on the column only: NI x 4 values per lane, loaded once per tile (not once per row block)
+    [[maybe_unused]] float bv[NI][4];
+    if (HAS_BIAS) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = col0 + wc * WN + j * 16 + l4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[j][r] = n + r < p.N ? (float)p.bias[n + r] : 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       asm volatile("" ::: "memory");               // one row block at a time: bounds the loads the scheduler batches
@@ -269,8 +279,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
         f32x4 v = acc[i][j];
         if (HAS_BIAS) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) v[r] += (float)p.bias[n + r];
+          for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
         }
         const size_t off = (size_t)m * p.ldc + n;
         const bool full = (n + 4 <= p.N) && ((off & 3) == 0);
