@@ -267,6 +267,45 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
         for (int r = 0; r < 4; ++r) bv[j][r] = n + r < p.N ? (float)p.bias[n + r] : 0.f;
       }
     }
+    if constexpr (OUT_MODE == TASU_GEMM_OUT_F32_RESID_BF16R && BM == 128) {
+      // residual add: the fp32 residual rows of IB row blocks are fetched together (clamped addresses, no branches)
+      // before the first use -- one memory round trip per IB row blocks instead of one per fragment; with one tile per CU
+      // (N = 1536: o and down projections) nothing else hides this latency
+      if ((p.ldc & 3) == 0 && (p.N & 3) == 0 && (((uintptr_t)p.R | (uintptr_t)p.C) & 15) == 0) {
+        constexpr int IB = 2;                       // (the 256-row tiles have no registers to spare: fragment-wise path below)
+        static_assert(MI % IB == 0, "row blocks are processed in groups of IB");
+#pragma unroll
+        for (int i0 = 0; i0 < MI; i0 += IB) {
+          asm volatile("" ::: "memory");
+          f32x4 old[IB][NI];
+#pragma unroll
+          for (int ii = 0; ii < IB; ++ii) {
+            const int m = min(row0 + wr * WM + (i0 + ii) * 16 + l15, p.M - 1);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+              const int n = min(col0 + wc * WN + j * 16 + l4, p.N - 4);
+              old[ii][j] = *(const f32x4*)(p.R + (size_t)m * p.ldc + n);
+            }
+          }
+#pragma unroll
+          for (int ii = 0; ii < IB; ++ii) {
+            const int m = row0 + wr * WM + (i0 + ii) * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+              const int n = col0 + wc * WN + j * 16 + l4;
+              f32x4 v = acc[i0 + ii][j];
+              if (HAS_BIAS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
+              }
+              const f32x4 rr = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
+              if (m < p.M && n < p.N) *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = old[ii][j] + rr;
+            }
+          }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       asm volatile("" ::: "memory");               // one row block at a time: bounds the loads the scheduler batches
