@@ -65,6 +65,17 @@ def get_custom_model_factory(model_config):
         raise
 
 
+def _id_word(i):
+    """id -> lower-case word (base-26 digits a..z), e.g. 27 -> 'bb'."""
+    w = ""
+    i = int(i)
+    while True:
+        w = chr(ord("a") + i % 26) + w
+        i //= 26
+        if i == 0:
+            return w
+
+
 class SyntheticDataset:
     """Pre-batched iterable with a ``collator`` (the contract of MultiTaskDynamicBatchDataset,
     Multitask/dataset/speech_dataset_large.py:307-330) that yields the SURVEY 8d synthetic utterances."""
@@ -85,7 +96,9 @@ class SyntheticDataset:
                  input_feature_length=raw["input_feature_length"], GT=[" ".join(map(str, p)) for p in raw["post_ids"]])
         if self.inference:
             b["keys"] = [f"utt{i}" for i in range(len(b["GT"]))]
-            b["targets"] = b["GT"]
+            # generate() cleans the transcripts with the reference's regex (letters and .,!? only, ps-slm.py:592-596), so
+            # the synthetic transcripts are letter-words (one per pseudo-posterior row), not digit strings
+            b["targets"] = [" ".join(_id_word(i) for i in p) for p in raw["post_ids"]]
             n = 25
             b["input_ids"], b["attention_mask"] = b["input_ids"][:, :n], b["attention_mask"][:, :n]
         else:

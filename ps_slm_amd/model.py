@@ -327,6 +327,9 @@ class TasuModel:
             kept.append(ids)
         lens = np.array([len(k) for k in kept], dtype=np.int64)
         Lmax = int(lens.max())
+        if Lmax == 0:
+            raise ValueError("text branch: every utterance has an empty pseudo-posterior (no sentencepiece ids left after "
+                             "cleaning / CPS drops); the projector needs at least one row")
         Ra = B * Lmax
         Rap = rup(Ra, 64)
         pid = np.full(Rap, -1, dtype=np.int32)

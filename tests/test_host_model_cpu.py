@@ -252,3 +252,18 @@ def test_beam_state_matches_oracle_on_random_scores():
     ref = fin_seq[:, 0, : int(fin_len[:, 0].max())].numpy()
     assert np.array_equal(mine, ref), (mine, ref)
     assert (mine == eos).any(), "the stream must exercise the EOS / finished-beam path"
+
+
+def test_synthetic_inference_transcripts_survive_reference_cleaning():
+    """The synthetic test split must give generate() transcripts that are non-empty after the reference's regex
+    (ps-slm.py:592-596) -- digit strings are wiped by it."""
+    import re
+    from ps_slm_amd.finetune_deepspeed import SyntheticDataset
+    from ps_slm_amd.ps_slm import SyntheticSentencePiece
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    ds = SyntheticDataset(geo, 2, 1, 0, inference=True)
+    b = ds.collator(next(iter(ds)))
+    sp = SyntheticSentencePiece(geo.ctc_vocab)
+    for t in b["targets"]:
+        cleaned = re.sub(r"[^A-Za-z\s.,!?]+", "", t).lower().strip()
+        assert cleaned == t and len(sp.encode(cleaned)) == len(t.split()) > 0
