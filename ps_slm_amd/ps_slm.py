@@ -115,7 +115,7 @@ def geometry_from_config(model_config) -> Geometry:
             raise ValueError(f"unknown synthetic geometry {name!r}")
     else:
         raise FileNotFoundError(f"model_config.llm_path={path!r}: no config.json there and not a 'synthetic:<name>' spec")
-    if model_config.get("encoder_dim", None) not in (None, geo.ctc_vocab) and not path.endswith("mid"):
+    if model_config.get("encoder_dim", None) not in (None, geo.ctc_vocab) and path.lower() != "synthetic:mid":
         geo.ctc_vocab = int(model_config.encoder_dim)
     if model_config.get("llm_dim", None) not in (None, geo.llm_dim):
         raise ValueError(f"model_config.llm_dim={model_config.llm_dim} does not match the LLM hidden size {geo.llm_dim}")

@@ -267,3 +267,41 @@ def test_synthetic_inference_transcripts_survive_reference_cleaning():
     for t in b["targets"]:
         cleaned = re.sub(r"[^A-Za-z\s.,!?]+", "", t).lower().strip()
         assert cleaned == t and len(sp.encode(cleaned)) == len(t.split()) > 0
+
+
+def test_model_factory_from_hf_directory(tmp_path):
+    """llm_path pointing at a HF-style directory (config.json + *.safetensors, no tokenizer files): geometry from the
+    config, weights through load_hf_llm_state_dict, projector checkpoint through ckpt_path -- same loss as the model built
+    directly from the same tensors."""
+    import json
+    from safetensors.torch import save_file
+    from ps_slm_amd.config import ModelConfig, TrainConfig
+    from ps_slm_amd.ps_slm import model_factory
+    # the projector bottleneck is not an HF config field: the reference hard-codes 2048 (projector.py:141), the default
+    geo = Geometry.from_dict(dict(MID_GEOMETRY, bottleneck=Geometry().bottleneck))
+    sd = random_state_dict(geo, 77, with_encoder=False)
+    hf = tmp_path / "qwen_mid"
+    hf.mkdir()
+    json.dump(dict(vocab_size=geo.llm_vocab, hidden_size=geo.llm_dim, intermediate_size=geo.llm_inter,
+                   num_hidden_layers=geo.llm_layers, num_attention_heads=geo.llm_heads, num_key_value_heads=geo.llm_kv_heads,
+                   head_dim=128, rope_theta=geo.rope_theta, rms_norm_eps=geo.rms_eps, tie_word_embeddings=True),
+              open(hf / "config.json", "w"))
+    save_file({k[4:]: v.contiguous() for k, v in sd.items() if k.startswith("llm.")}, str(hf / "model.safetensors"))
+    ckpt = tmp_path / "projector.pt"
+    torch.save({k: v for k, v in sd.items() if k.startswith("encoder_projector.")}, ckpt)
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True)
+    mc = ModelConfig(llm_path=str(hf), llm_dim=geo.llm_dim, encoder_projector="linear-silu", encoder_dim=geo.ctc_vocab)
+    model, tok = model_factory(tc, mc, ops=FakeOps(), device="cpu", ckpt_path=str(ckpt))
+    # without tokenizer files the special ids are the defaults of the real Qwen vocabulary; a real run takes them from the
+    # tokenizer (model_factory).  Point them into the 1000-word test vocabulary.
+    model.core.geo.speech_id, model.core.geo.eos_id = geo.speech_id, geo.eos_id
+    ref = TasuModel(geo, FakeOps(), "cpu")
+    ref.load_reference_state_dict(sd)
+    batch = synthetic_text_batch(geo, 2, seed=5, prompt_len=9, n_audio=13, target_len=11, speech_pos=4, feat_frames=12, noise=False)
+    def loss_of(core):
+        st = core.prepare_text(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["post_ids"], None, None)
+        core.forward_projector_text(st)
+        core.forward_llm(st, need_backward=False)
+        return float(st.dev["loss_out"][0])
+    assert model.core.geo.llm_layers == geo.llm_layers and model.core.geo.llm_vocab == geo.llm_vocab
+    assert abs(loss_of(model.core) - loss_of(ref)) < 1e-6
