@@ -115,11 +115,32 @@ def geometry_from_config(model_config) -> Geometry:
             raise ValueError(f"unknown synthetic geometry {name!r}")
     else:
         raise FileNotFoundError(f"model_config.llm_path={path!r}: no config.json there and not a 'synthetic:<name>' spec")
+    apply_encoder_config(geo, model_config.get("encoder_path", None))
     if model_config.get("encoder_dim", None) not in (None, geo.ctc_vocab) and path.lower() != "synthetic:mid":
         geo.ctc_vocab = int(model_config.encoder_dim)
     if model_config.get("llm_dim", None) not in (None, geo.llm_dim):
         raise ValueError(f"model_config.llm_dim={model_config.llm_dim} does not match the LLM hidden size {geo.llm_dim}")
     return geo
+
+
+def apply_encoder_config(geo: Geometry, encoder_path):
+    """funasr ships the encoder geometry in ``<encoder_path>/config.yaml`` (``input_size`` + ``encoder_conf``: the file
+    funasr's AutoModel builds SenseVoiceSmall from, Multitask/model/ps-slm.py:91-106); absent file = the published
+    SenseVoiceSmall values already in ``Geometry``."""
+    cfg_file = os.path.join(str(encoder_path or ""), "config.yaml")
+    if not os.path.isfile(cfg_file):
+        return
+    import yaml
+    c = yaml.safe_load(open(cfg_file)) or {}
+    ec = c.get("encoder_conf", {}) or {}
+    for key, field in (("output_size", "enc_dim"), ("attention_heads", "enc_heads"), ("linear_units", "enc_ffn"),
+                       ("num_blocks", "enc_blocks"), ("tp_blocks", "enc_tp_blocks"), ("kernel_size", "enc_kernel")):
+        if key in ec:
+            setattr(geo, field, int(ec[key]))
+    if "input_size" in c:
+        geo.feat_dim = int(c["input_size"])
+    if int(ec.get("sanm_shfit", 0)) != 0:
+        raise NotImplementedError("sanm_shfit != 0 is not what SenseVoiceSmall ships (SenseVoice.py:209-228 path only)")
 
 
 def load_hf_llm_state_dict(path):

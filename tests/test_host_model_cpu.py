@@ -305,3 +305,46 @@ def test_model_factory_from_hf_directory(tmp_path):
         return float(st.dev["loss_out"][0])
     assert model.core.geo.llm_layers == geo.llm_layers and model.core.geo.llm_vocab == geo.llm_vocab
     assert abs(loss_of(model.core) - loss_of(ref)) < 1e-6
+
+
+def test_model_factory_audio_branch_from_checkpoints(tmp_path):
+    """Audio recipe through model_factory: HF LLM directory + funasr-style encoder directory (config.yaml + model.pt).
+    Same loss as the model loaded directly from the reference-named state dict."""
+    import json
+    import yaml
+    from safetensors.torch import save_file
+    from ps_slm_amd.config import ModelConfig, TrainConfig
+    from ps_slm_amd.ps_slm import model_factory
+    geo = Geometry.from_dict(dict(MID_GEOMETRY, bottleneck=Geometry().bottleneck))
+    sd = random_state_dict(geo, 78, with_encoder=True)
+    hf, enc = tmp_path / "llm", tmp_path / "sensevoice"
+    hf.mkdir()
+    enc.mkdir()
+    json.dump(dict(vocab_size=geo.llm_vocab, hidden_size=geo.llm_dim, intermediate_size=geo.llm_inter,
+                   num_hidden_layers=geo.llm_layers, num_attention_heads=geo.llm_heads, num_key_value_heads=geo.llm_kv_heads,
+                   head_dim=128, rope_theta=geo.rope_theta, rms_norm_eps=geo.rms_eps, tie_word_embeddings=True),
+              open(hf / "config.json", "w"))
+    save_file({k[4:]: v.contiguous() for k, v in sd.items() if k.startswith("llm.")}, str(hf / "model.safetensors"))
+    yaml.safe_dump(dict(input_size=geo.feat_dim,
+                        encoder_conf=dict(output_size=geo.enc_dim, attention_heads=geo.enc_heads, linear_units=geo.enc_ffn,
+                                          num_blocks=geo.enc_blocks, tp_blocks=geo.enc_tp_blocks, kernel_size=geo.enc_kernel,
+                                          sanm_shfit=0)), open(enc / "config.yaml", "w"))
+    torch.save({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, enc / "model.pt")
+    ckpt = tmp_path / "projector.pt"
+    torch.save({k: v for k, v in sd.items() if k.startswith("encoder_projector.")}, ckpt)
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=False, ctc_posterior=True, do_psd=True)
+    mc = ModelConfig(llm_path=str(hf), llm_dim=geo.llm_dim, encoder_path=str(enc), encoder_projector="linear-silu",
+                     encoder_dim=geo.ctc_vocab)
+    model, _ = model_factory(tc, mc, ops=FakeOps(), device="cpu", ckpt_path=str(ckpt))
+    model.core.geo.speech_id, model.core.geo.eos_id = geo.speech_id, geo.eos_id
+    assert dataclasses.asdict(model.core.geo) == dataclasses.asdict(geo)
+    ref = TasuModel(geo, FakeOps(), "cpu")
+    ref.load_reference_state_dict(sd)
+    batch = synthetic_text_batch(geo, 2, seed=6, prompt_len=9, n_audio=13, target_len=11, speech_pos=4, feat_frames=24, noise=False)
+
+    def loss_of(core):
+        st = core.prepare_audio(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["input_features"],
+                                batch["input_feature_length"], do_psd=True)
+        core.forward_llm(st, need_backward=False)
+        return float(st.dev["loss_out"][0])
+    assert abs(loss_of(model.core) - loss_of(ref)) < 1e-6
