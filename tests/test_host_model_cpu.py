@@ -287,14 +287,23 @@ def test_model_factory_from_hf_directory(tmp_path):
                    head_dim=128, rope_theta=geo.rope_theta, rms_norm_eps=geo.rms_eps, tie_word_embeddings=True),
               open(hf / "config.json", "w"))
     save_file({k[4:]: v.contiguous() for k, v in sd.items() if k.startswith("llm.")}, str(hf / "model.safetensors"))
+    # a real tokenizer directory: 900 words + <eos>; model_factory adds <speech> (-> id 901) like ps-slm.py:133-140 and
+    # takes the special ids from the tokenizer
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {f"w{i}": i for i in range(900)}
+    vocab["<eos>"] = 900
+    t = Tokenizer(models.WordLevel(vocab, unk_token="w0"))
+    t.pre_tokenizer = pre_tokenizers.Whitespace()
+    PreTrainedTokenizerFast(tokenizer_object=t, eos_token="<eos>").save_pretrained(str(hf))
     ckpt = tmp_path / "projector.pt"
     torch.save({k: v for k, v in sd.items() if k.startswith("encoder_projector.")}, ckpt)
     tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True)
     mc = ModelConfig(llm_path=str(hf), llm_dim=geo.llm_dim, encoder_projector="linear-silu", encoder_dim=geo.ctc_vocab)
     model, tok = model_factory(tc, mc, ops=FakeOps(), device="cpu", ckpt_path=str(ckpt))
-    # without tokenizer files the special ids are the defaults of the real Qwen vocabulary; a real run takes them from the
-    # tokenizer (model_factory).  Point them into the 1000-word test vocabulary.
-    model.core.geo.speech_id, model.core.geo.eos_id = geo.speech_id, geo.eos_id
+    assert tok.default_speech_token == 901 and tok.pad_token_id == tok.eos_token_id == 900
+    assert (model.core.geo.speech_id, model.core.geo.eos_id) == (901, 900)
+    geo.speech_id, geo.eos_id = 901, 900
     ref = TasuModel(geo, FakeOps(), "cpu")
     ref.load_reference_state_dict(sd)
     batch = synthetic_text_batch(geo, 2, seed=5, prompt_len=9, n_audio=13, target_len=11, speech_pos=4, feat_frames=12, noise=False)
@@ -348,3 +357,19 @@ def test_model_factory_audio_branch_from_checkpoints(tmp_path):
         core.forward_llm(st, need_backward=False)
         return float(st.dev["loss_out"][0])
     assert abs(loss_of(model.core) - loss_of(ref)) < 1e-6
+
+
+def test_encoder_tokenizer_from_sentencepiece_model(tmp_path):
+    """setup_encoder_tokenizer picks up funasr's BPE model file (Multitask/model/tokenizer.py) when it is there."""
+    import sentencepiece as spm
+    from ps_slm_amd.config import ModelConfig
+    from ps_slm_amd.ps_slm import setup_encoder_tokenizer
+    corpus = tmp_path / "corpus.txt"
+    corpus.write_text("\n".join(f"hello world this is sentence number {i} of the tiny corpus" for i in range(200)))
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "chn_jpn_yue_eng_ko_spectok.bpe"),
+                                   vocab_size=60, model_type="bpe", minloglevel=2)
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    tok = setup_encoder_tokenizer(ModelConfig(encoder_path=str(tmp_path)), geo)
+    ids = tok.encode("hello tiny world")
+    assert tok.vocab_size == 60 and len(ids) > 0 and all(isinstance(i, int) and 0 <= i < 60 for i in ids)
+    assert setup_encoder_tokenizer(ModelConfig(encoder_path=str(tmp_path / "nope")), geo).vocab_size == geo.ctc_vocab
