@@ -53,6 +53,11 @@ class TasuEngine:
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pending = None
         self._last_state = None
+        # gradient accumulation (ds_config "gradient_accumulation_steps", DeepSpeed semantics: every micro-step's gradient
+        # enters with weight 1/k, the optimizer and the scheduler step on every k-th call of step()); k = 1 in the shipped
+        # config, in which case no accumulation buffer exists and nothing below costs anything
+        self.ga = max(1, int(ds_config.get("gradient_accumulation_steps", 1)))
+        self._g_acc = torch.zeros_like(self.core.proj.g) if self.ga > 1 else None
 
     # ---- nn.Module-like surface the reference's train() uses (deepspeed_utils.py:136-246)
     def train(self):
@@ -85,8 +90,12 @@ class TasuEngine:
             raise RuntimeError("backward() called before a forward pass")
         self.core.run_backward(st)
         self.micro_steps += 1
+        if self.ga > 1:
+            self._g_acc.add_(self.core.proj.g, alpha=1.0 / self.ga)
+            if self.micro_steps % self.ga != 0:
+                return                                  # not a boundary: no exchange yet
         if self.world > 1:
-            g = self.core.proj.g
+            g = self._g_acc if self.ga > 1 else self.core.proj.g
             if self.comm_stream is not None:
                 self.comm_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.comm_stream):
@@ -94,7 +103,12 @@ class TasuEngine:
             else:
                 self._pending = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
+    def is_gradient_accumulation_boundary(self):
+        return self.micro_steps % self.ga == 0
+
     def step(self):
+        if self.ga > 1 and not self.is_gradient_accumulation_boundary():
+            return                                      # DeepSpeed: step() between boundaries is a no-op
         if self._pending is not None:
             self._pending.wait()
             if self.comm_stream is not None:
@@ -104,8 +118,11 @@ class TasuEngine:
         self.global_steps += 1
         self._lr_host[0] = self.get_lr()[0]
         self.lr_dev.copy_(self._lr_host, non_blocking=True)
-        self.core.ops.adamw(pr.p, pr.g, pr.m, pr.v, pr.pb, self.lr_dev, c["betas"][0], c["betas"][1], c["eps"],
+        g = self._g_acc if self.ga > 1 else pr.g
+        self.core.ops.adamw(pr.p, g, pr.m, pr.v, pr.pb, self.lr_dev, c["betas"][0], c["betas"][1], c["eps"],
                             c["weight_decay"], self.global_steps, 1.0 / self.world)
+        if self.ga > 1:
+            self._g_acc.zero_()
         pr.refresh_working_copies(self.core.ops)
         self.sched_iter += 1           # lr_scheduler.step() follows optimizer.step() in the DeepSpeed engine
 

@@ -135,6 +135,42 @@ def test_engine_steps_match_oracle_adamw_and_schedule():
         assert float(da.norm() / db.norm()) == pytest.approx(1.0, abs=0.05), k
 
 
+def test_gradient_accumulation_matches_deepspeed_semantics():
+    """gradient_accumulation_steps = 2: step() is a no-op off the boundary; on it the update equals ONE AdamW step on the
+    mean of the two micro-batch gradients (DeepSpeed scales each micro loss by 1/k), and the scheduler advances once."""
+    def build(ga):
+        tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True)
+        mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+        model, _ = model_factory(tc, mc, device="cpu", ops=FakeOps(), init_seed=1234)
+        cfg = load_ds_config(DEFAULT_DS_CONFIG)
+        cfg.update(lr=1e-3, gradient_accumulation_steps=ga)
+        eng = TasuEngine(model, cfg)
+        eng.sched_iter = 10                  # past the zero-lr warm-up steps
+        return model, eng
+    geo = build(1)[0].core.geo
+    raws = [synthetic_text_batch(geo, 2, seed=40 + i, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8,
+                                 noise=False) for i in range(2)]
+    m2, e2 = build(2)
+    p0 = m2.core.proj.p.clone()
+    grads = []
+    for i, raw in enumerate(raws):
+        out, _ = e2(**to_call(raw))
+        e2.backward(out.loss)
+        grads.append(m2.core.proj.g.clone())
+        e2.step()
+        if i == 0:
+            assert torch.equal(m2.core.proj.p, p0) and e2.global_steps == 0 and not e2.is_gradient_accumulation_boundary()
+    assert e2.global_steps == 1 and e2.sched_iter == 11
+    # reference update: one engine step with the averaged gradient planted in the bucket
+    m1, e1 = build(1)
+    out, _ = e1(**to_call(raws[0]))
+    e1.backward(out.loss)
+    m1.core.proj.g.copy_(0.5 * (grads[0] + grads[1]))
+    e1.step()
+    torch.testing.assert_close(m2.core.proj.p, m1.core.proj.p, rtol=0, atol=1e-7)
+    assert float((m2.core.proj.p - p0).abs().max()) > 0
+
+
 def _dp_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     dist.init_process_group("gloo", rank=rank, world_size=world)
