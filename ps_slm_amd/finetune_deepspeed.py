@@ -118,10 +118,40 @@ def get_dataset(dataset_config, tokenizer, split, geo, rank, steps=20, batch_siz
     return getattr(load_module_from_py_file(module_path), func_name)(dataset_config, tokenizer, split)
 
 
-def train(engine, dataset, train_config, log_config, rank, world):
-    """Loop body of Multitask/utils/deepspeed_utils.py:190-246 (uneven-data join, forward, backward, step, logging)."""
+def evaluation(engine, train_config, eval_dataset, rank, world):
+    """Multitask/utils/deepspeed_utils.py:394-498: forward only, loss and accuracy summed over the batches and over ranks,
+    ``eval_epoch_loss = (sum / num_steps) / world`` -- including the reference's step count under dynamic batching
+    (``tot_step + 1`` = number of batches + 1, :479-481).  The reference also arg-maxes and batch-decodes every eval
+    batch into a list it never reads (:457-463); that dead host work is not reproduced."""
+    import math
+    engine.eval()
+    dev = engine.core.device
+    tot = torch.zeros(2, dtype=torch.float32, device=dev)
+    n = 0
+    for raw in eval_dataset:
+        batch = eval_dataset.collator(raw)
+        outputs, acc = engine(**batch)
+        tot[0] += outputs.loss.detach().float()
+        tot[1] += acc if isinstance(acc, torch.Tensor) else float(acc)
+        n += 1
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    num_steps = n if train_config.batching_strategy != "dynamic" else n + 1
+    loss, acc = (tot / max(num_steps, 1) / world).tolist()
+    ppl = math.exp(loss)
+    if rank == 0:
+        logger.info(" eval_ppl=%s eval_epoch_loss=%s eval_epoch_acc=%s", ppl, loss, acc)
+    engine.train()
+    return ppl, loss, acc
+
+
+def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=None):
+    """Loop body of Multitask/utils/deepspeed_utils.py:190-246 (uneven-data join, forward, backward, step, logging) and
+    the validation / save-on-improvement block behind it (:248-290)."""
     results = {}
     total_loss, total_acc, steps, utts = 0.0, 0.0, 0, 0
+    best_val_loss, best_val_acc = float("inf"), 0.0
+    val_loss, val_ppl, val_acc = [], [], []
     t0 = time.perf_counter()
     for epoch in range(train_config.num_epochs):
         engine.train()
@@ -137,6 +167,19 @@ def train(engine, dataset, train_config, log_config, rank, world):
             engine.step()
             steps += 1
             utts += batch["input_ids"].shape[0]
+            if eval_dataset is not None and train_config.run_validation and steps % train_config.validation_interval == 0:
+                ppl, el, ea = evaluation(engine, train_config, eval_dataset, rank, world)
+                if train_config.save_model and (el < best_val_loss or ea > best_val_acc) and \
+                        not str(train_config.output_dir).startswith("PATH/"):
+                    # checkpoint_handler.py:169-182 naming: <output_dir>/<model_name>_epoch_E_step_S/
+                    d = os.path.join(train_config.output_dir, f"{train_config.model_name}_epoch_{epoch + 1}_step_{steps}")
+                    if rank == 0:
+                        os.makedirs(d, exist_ok=True)
+                    engine.save_checkpoint(os.path.join(d, "pytorch_model.bin"))
+                best_val_loss, best_val_acc = min(best_val_loss, el), max(best_val_acc, ea)
+                val_loss.append(el)
+                val_ppl.append(ppl)
+                val_acc.append(ea)
             if steps % max(1, log_config.log_interval) == 0:
                 l, a = float(loss), float(acc)                 # the only host sync of the loop, every log_interval steps
                 total_loss, total_acc = total_loss + l, total_acc + a
@@ -147,6 +190,10 @@ def train(engine, dataset, train_config, log_config, rank, world):
     sl, sa = engine.reduce_scalars(total_loss / n_logged, total_acc / n_logged)
     results["avg_train_loss"], results["avg_train_acc"] = sl / world, sa / world
     results["steps"], results["utterances_per_s"] = steps, world * utts / max(time.perf_counter() - t0, 1e-9)
+    if val_loss:
+        results["avg_eval_prep"] = sum(val_ppl) / len(val_ppl)
+        results["avg_eval_loss"] = sum(val_loss) / len(val_loss)
+        results["avg_eval_acc"] = sum(val_acc) / len(val_acc)
     return results
 
 
@@ -170,7 +217,11 @@ def main(argv=None):
     engine = TasuEngine(model, ds_cfg)
     dataset = get_dataset(dataset_config, tokenizer, "train", model.core.geo, rank,
                           steps=int(cfg.get("synthetic_steps", 20)), batch_size=int(cfg.get("synthetic_batch", 16)))
-    results = train(engine, dataset, train_config, log_config, rank, world)
+    eval_dataset = None
+    if train_config.run_validation:
+        eval_dataset = get_dataset(dataset_config, tokenizer, "val", model.core.geo, rank,
+                                   steps=int(cfg.get("synthetic_eval_steps", 2)), batch_size=int(cfg.get("synthetic_batch", 16)))
+    results = train(engine, dataset, train_config, log_config, rank, world, eval_dataset)
     if rank == 0:
         for k, v in results.items():
             logger.info("Key: %s, Value: %s", k, v)

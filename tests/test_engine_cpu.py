@@ -1,6 +1,7 @@
 """Host logic on CPU (FakeOps double): plugin surface, config overrides, engine semantics (AdamW + DeepSpeed-style
 WarmupCosineLR ordering), CPS noise RNG parity with the reference, and the N > 1 data-parallel path over gloo."""
 import dataclasses
+import math
 import os
 
 import numpy as np
@@ -233,10 +234,16 @@ def test_train_loop_and_checkpoint_roundtrip(tmp_path):
     syn.synthetic_text_batch = lambda geo, B, seed, noise=False: real(geo, B, seed=seed, prompt_len=9, n_audio=21, target_len=17,
                                                                        speech_pos=4, feat_frames=8, noise=noise)
     try:
-        res = train(eng, ds, TrainConfig(num_epochs=1), LogConfig(log_interval=1), 0, 1)
+        # validation every 2 steps on a 2-batch eval split; improvement -> <output_dir>/<model_name>_epoch_1_step_2/
+        tcfg = TrainConfig(num_epochs=1, run_validation=True, validation_interval=2, save_model=True,
+                           output_dir=str(tmp_path / "out"), batching_strategy="dynamic")
+        res = train(eng, ds, tcfg, LogConfig(log_interval=1), 0, 1, eval_dataset=SyntheticDataset(core.geo, 2, 2, 0))
     finally:
         syn.synthetic_text_batch = real
     assert res["steps"] == 3 and res["avg_train_loss"] > 0
+    assert res["avg_eval_loss"] > 0 and res["avg_eval_prep"] == pytest.approx(math.exp(res["avg_eval_loss"]), rel=1e-6)
+    assert os.path.isfile(tmp_path / "out" / "asr_model_epoch_1_step_2" / "pytorch_model.bin")
+    assert eng.module.training
     path = str(tmp_path / "pytorch_model.bin")
     eng.save_checkpoint(path)
     sd = torch.load(path)
