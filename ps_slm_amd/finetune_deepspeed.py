@@ -156,6 +156,7 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
     for epoch in range(train_config.num_epochs):
         engine.train()
         it = iter(dataset)
+        epoch_step = 0                                         # the reference's `step + 1` (per epoch, :190, :248)
         while True:
             raw = next(it, None)
             if not engine.all_have_data(raw is not None):      # replaces deepspeed_join's gloo monitored_barrier
@@ -166,13 +167,14 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
             engine.backward(loss)
             engine.step()
             steps += 1
+            epoch_step += 1
             utts += batch["input_ids"].shape[0]
-            if eval_dataset is not None and train_config.run_validation and steps % train_config.validation_interval == 0:
+            if eval_dataset is not None and train_config.run_validation and epoch_step % train_config.validation_interval == 0:
                 ppl, el, ea = evaluation(engine, train_config, eval_dataset, rank, world)
                 if train_config.save_model and (el < best_val_loss or ea > best_val_acc) and \
                         not str(train_config.output_dir).startswith("PATH/"):
                     # checkpoint_handler.py:169-182 naming: <output_dir>/<model_name>_epoch_E_step_S/
-                    d = os.path.join(train_config.output_dir, f"{train_config.model_name}_epoch_{epoch + 1}_step_{steps}")
+                    d = os.path.join(train_config.output_dir, f"{train_config.model_name}_epoch_{epoch + 1}_step_{epoch_step}")
                     if rank == 0:
                         os.makedirs(d, exist_ok=True)
                     engine.save_checkpoint(os.path.join(d, "pytorch_model.bin"))
