@@ -164,6 +164,11 @@ def model_factory(train_config, model_config, **kwargs):
     if train_config.get("use_peft", False) or not train_config.get("freeze_llm", True):
         raise NotImplementedError("the MI355X path trains the projector only (freeze_llm=true, use_peft=false: "
                                   "Multitask/scripts/finetune_deespeed_sensevoice.sh:28,84)")
+    if not train_config.get("use_fp16", False):
+        # the reference computes in fp32 unless use_fp16 wraps the step in bf16 autocast (deepspeed_utils.py:160,205) and
+        # decodes in fp32 (inference_batch.py:113-117); this path has ONE arithmetic: bf16 autocast semantics
+        logger.warning("train_config.use_fp16 is false: the MI355X path still computes with bf16-autocast semantics "
+                       "(bf16 GEMM operands, fp32 accumulation / residual stream / norms / loss)")
     geo = geometry_from_config(model_config)
     tokenizer = setup_tokenizer(train_config, model_config, geo, **kwargs)
     if not isinstance(tokenizer, SyntheticLLMTokenizer):
