@@ -8,7 +8,7 @@ continuations -- and the host does the (tiny) selection, finished-beam heap and 
 Device per step (M = B*nb rows): embedding rows -> 28 x [RMSNorm, qkv GEMM, RoPE, KV append, cache attention, o GEMM +
 residual, RMSNorm, gate|up GEMM, SwiGLU, down GEMM + residual] -> RMSNorm -> lm_head GEMM -> log-softmax top-k ->
 beam reorder of the cache's row index.  HBM-bound: every step streams the bf16 weights once; the ~430 launches of a step
-are replayed as one hipGraph when ``model.use_graphs`` is set.
+are replayed as one hipGraph (``model.decode_graphs``, on by default on the GPU).
 """
 import numpy as np
 import torch
@@ -189,17 +189,19 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     # hipGraph replay of device_step (~430 launches): the first step of a shape runs eagerly, the second is captured.
     # A graph is only valid for the buffers it was captured on, so the key carries their addresses.
     use_graphs = model.decode_graphs and model.device.type == "cuda"
-    graphs = model._graphs
+    graphs, seen_cnt = model._dec_graphs, model._dec_seen
 
     def run_step(ban):
         if not use_graphs:
             return device_step(ban)
-        key = ("decode", B, S, nb, ctx, ban, kc.data_ptr(), vc.data_ptr(), index.data_ptr(), logits.data_ptr(), ws.data_ptr())
+        key = ("decode", B, S, nb, ctx, ban, model._buf_gen)    # buffers are grow-only: same generation = same addresses
+        for old in [k for k in graphs if k[-1] != model._buf_gen]:
+            del graphs[old]                                      # captured on addresses that have since been freed
         g = graphs.get(key)
         if g is not None:
             return g.replay()
-        seen = model._graph_seen.get(key, 0)
-        model._graph_seen[key] = seen + 1
+        seen = seen_cnt.get(key, 0)
+        seen_cnt[key] = seen + 1
         if seen < 1:
             return device_step(ban)
         torch.cuda.synchronize()

@@ -217,10 +217,9 @@ def main(argv=None):
                                      device=f"cuda:{local_rank}", keep_logits=False)
     ds_cfg = load_ds_config(cfg.deepspeed_config) if cfg.deepspeed_config else load_ds_config(DEFAULT_DS_CONFIG)
     engine = TasuEngine(model, ds_cfg)
-    # hipGraph replay of the forward/backward launch sequences pays when batch shapes repeat (fixed-length data); with
-    # the reference's dynamic batching every batch has its own shape, so it is off unless asked for (++use_graphs=true)
-    synthetic = dataset_config.get("file", "synthetic") in ("synthetic", None)
-    model.core.use_graphs = str(cfg.get("use_graphs", synthetic)).lower() in ("1", "true", "yes")
+    # hipGraph replay of the forward/backward launch sequences pays when batch shapes repeat (fixed-length data, no CPS
+    # drops); with dynamic batching or CPS drops every batch has its own shape, so it is off unless asked for
+    model.core.use_graphs = str(cfg.get("use_graphs", False)).lower() in ("1", "true", "yes")
     dataset = get_dataset(dataset_config, tokenizer, "train", model.core.geo, rank,
                           steps=int(cfg.get("synthetic_steps", 20)), batch_size=int(cfg.get("synthetic_batch", 16)))
     eval_dataset = None

@@ -244,6 +244,8 @@ class TasuModel:
         self.decode_graphs = True      # the decode step (ps_slm_amd/decode.py) is always replayed as a graph on the GPU
         self._graphs = {}
         self._graph_seen = {}
+        self._buf_gen = 0              # bumped whenever a named workspace buffer is re-allocated (grown)
+        self._dec_graphs, self._dec_seen = {}, {}   # decode-step graphs (ps_slm_amd/decode.py), keyed by shape + _buf_gen
 
     # ------------------------------------------------------------------------------------------ weights
     def load_reference_state_dict(self, sd):
@@ -309,6 +311,8 @@ class TasuModel:
         n = int(np.prod(shape))
         t = self._ws.get(name)
         if t is None or t.numel() < n or t.dtype != dtype:
+            if t is not None:
+                self._buf_gen += 1                # a buffer moved: graphs captured on the old address are dead
             t = torch.empty(n, dtype=dtype, device=self.device)
             self._ws[name] = t
         return t[:n].view(*shape)
@@ -546,6 +550,12 @@ class TasuModel:
         if not (self.use_graphs and self.device.type == "cuda"):
             return fn()
         g = self._graphs.get(key)
+        if g is not None and g[2] != self._buf_gen:
+            # a workspace buffer has grown since the capture (a larger batch shape came by): the graph holds freed
+            # addresses.  Drop every graph of that generation and start over for this key.
+            self._graphs = {k: v for k, v in self._graphs.items() if v[2] == self._buf_gen}
+            self._graph_seen.pop(key, None)
+            g = None
         if g is not None:
             g[0].replay()
             for k, v in g[1].items():                 # the views the captured code published into st.dev
@@ -558,9 +568,12 @@ class TasuModel:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         before = set(st.dev)
+        gen = self._buf_gen
         with torch.cuda.graph(graph):
             fn()
-        self._graphs[key] = (graph, {k: v for k, v in st.dev.items() if k not in before})
+        if gen != self._buf_gen:                      # a buffer grew DURING the capture: do not keep the graph
+            return
+        self._graphs[key] = (graph, {k: v for k, v in st.dev.items() if k not in before}, gen)
         graph.replay()
 
     def _shape_key(self, st, tag):

@@ -203,9 +203,18 @@ def test_graph_replay_matches_eager(setup):
     l0, g0 = one(gm)
     gm.use_graphs = True
     outs = [one(gm) for _ in range(4)]          # eager warm-up, capture + replay, replay, replay
-    gm.use_graphs = False
     assert len(gm._graphs) == 2
     for l, g in outs:
+        assert torch.equal(l, l0) and torch.equal(g, g0)
+    # a LARGER batch grows the named workspace buffers: the graphs above hold freed addresses and must not be replayed
+    big = synthetic_text_batch(geo, 7, seed=78, prompt_len=9, n_audio=40, target_len=30, speech_pos=4, feat_frames=12, noise=False)
+    stb = gm.prepare_text(big["input_ids"], big["attention_mask"], big["labels"], big["post_ids"], None, None)
+    gm.run_forward_text(stb)
+    gm.run_backward(stb)
+    torch.cuda.synchronize()
+    again = [one(gm) for _ in range(3)]          # eager, re-capture, replay -- all on the new buffers
+    gm.use_graphs = False
+    for l, g in again:
         assert torch.equal(l, l0) and torch.equal(g, g0)
     gm._graphs.clear()
     gm._graph_seen.clear()
