@@ -64,6 +64,20 @@ def test_step_vs_double_and_oracle(setup, ragged, noise, drop):
         assert cosine(gg[k], g) > 0.999, k
 
 
+def test_long_sequence_step_vs_double(setup):
+    """S ~ 1000 (16 key tiles per query tile, ragged lengths): loss, logits and projector gradients against the CPU double."""
+    geo, sd, gm, cm = setup
+    batch = synthetic_text_batch(geo, 2, seed=41, prompt_len=30, n_audio=400, target_len=570, speech_pos=7, feat_frames=12,
+                                 noise=True, drop_prob=0.05, ragged=True)
+    sg, sc = run_text(gm, batch), run_text(cm, batch)
+    assert sg.S == sc.S and sg.S > 900
+    lg, lc = sg.dev["loss_out"].cpu(), sc.dev["loss_out"]
+    assert abs(float(lg[0]) - float(lc[0])) < 2e-3 and abs(float(lg[1]) - float(lc[1])) <= 1.0 / sc.plan.count + 1e-6
+    gg, gc = gm.projector_grads(), cm.projector_grads()
+    for k in gc:
+        assert cosine(gg[k], gc[k]) > 0.999, k
+
+
 def test_step_vs_reference_golden(setup):
     """Golden = the real reference in fp32 (tests/golden/mid_text_clean.npz).  Stated bf16 tolerances:
     |loss - ref| <= 2e-2, logits max-abs error <= 3% of the logit range, projector grads cosine >= 0.995."""
