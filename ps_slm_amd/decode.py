@@ -14,7 +14,6 @@ import numpy as np
 import torch
 
 from .model import HD, StepState, rup
-from .ops import GEMM_RESID
 
 NEG = -1.0e9
 
@@ -138,7 +137,6 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     x2 = buf("dec_x2", (M, D), f32)
     qkv = buf("dec_qkv", (M, LDQ), bf)
     ao = buf("dec_ao", (M, H * HD), bf)
-    gu = buf("dec_gu", (M, 2 * I), bf)
     act = buf("dec_act", (M, I), bf)
     cos = buf("dec_cos", (M, HD // 2), f32)
     sin = buf("dec_sin", (M, HD // 2), f32)
@@ -150,11 +148,10 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     lens_d = buf("in_dec_lens", (M,), i32)
     src_d = buf("in_dec_src", (M,), i32)
 
-    def gemm(a, b, c, m, n, k, **kw):
-        if m <= 64:
-            ops.gemm_skinny(a, b, c, m, n, k, ws, **kw)
-        else:
-            ops.gemm(a, b, c, m, n, k, **kw)
+    # The weight-streaming kernels take at most 64 rows: more beams than that (B > 16 at 4 beams) run them in row chunks
+    # (the weights are then streamed once per chunk; K/V, attention and top-k are not chunked).
+    chunks = [(m0, min(64, M - m0)) for m0 in range(0, M, 64)]
+    kcv, vcv = kc.view(L, M, ctx * W), vc.view(L, M, ctx * W)
 
     def device_step(ban):
         """One generated position for all M beams: beam reorder of the row index (parents of the previous step), then the
@@ -166,24 +163,18 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
         ops.rmsnorm_fwd(x, llm.layers[0]["ln1"], xn, None, geo.rms_eps)
         for l, w in enumerate(llm.layers):
             next_norm = llm.layers[l + 1]["ln1"] if l + 1 < L else llm.norm      # the norm that consumes this layer's output
-            if M <= 64:
-                ops.gemm_skinny_qkv_rope(xn, w["wqkv"], w["bqkv"], qkv, M, H, G, D, cos, sin, kc[l], vc[l], slot_d, ctx, ws)
-            else:
-                ops.gemm(xn, w["wqkv"], qkv, M, LDQ, D, bias=w["bqkv"])
-                ops.rope_append(qkv, cos, sin, kc[l], vc[l], slot_d, M, H, G, ctx)
+            for m0, mc in chunks:                                                # qkv projection + bias + RoPE + cache append
+                r = slice(m0, m0 + mc)
+                ops.gemm_skinny_qkv_rope(xn[r], w["wqkv"], w["bqkv"], qkv[r], mc, H, G, D, cos[r], sin[r], kcv[l, r], vcv[l, r],
+                                         slot_d[r], ctx, ws)
             ops.attn_decode(qkv, kc[l], vc[l], index, kstart, lens_d, ao, M, H, G, ctx, scale)
-            if M <= 64:                                                          # projection + residual + next norm fused
-                ops.gemm_skinny_norm(ao, w["wo"], x2, x, M, D, H * HD, w["ln2"], xn, geo.rms_eps, ws)
-                ops.gemm_skinny_swiglu(xn, w["wgu"], act, M, I, D, ws)
-                ops.gemm_skinny_norm(act, w["wd"], x, x2, M, D, I, next_norm, xn, geo.rms_eps, ws)
-            else:
-                ops.gemm(ao, w["wo"], x2, M, D, H * HD, resid=x, mode=GEMM_RESID)
-                ops.rmsnorm_fwd(x2, w["ln2"], xn, None, geo.rms_eps)
-                ops.gemm(xn, w["wgu"], gu, M, 2 * I, D)
-                ops.swiglu_fwd(gu, act, M, I)
-                ops.gemm(act, w["wd"], x, M, D, I, resid=x2, mode=GEMM_RESID)
-                ops.rmsnorm_fwd(x, next_norm, xn, None, geo.rms_eps)
-        gemm(xn, llm.head, logits, M, V, D)
+            for m0, mc in chunks:                                                # projections with residual + next norm fused
+                r = slice(m0, m0 + mc)
+                ops.gemm_skinny_norm(ao[r], w["wo"], x2[r], x[r], mc, D, H * HD, w["ln2"], xn[r], geo.rms_eps, ws)
+                ops.gemm_skinny_swiglu(xn[r], w["wgu"], act[r], mc, I, D, ws)
+                ops.gemm_skinny_norm(act[r], w["wd"], x[r], x2[r], mc, D, I, next_norm, xn[r], geo.rms_eps, ws)
+        for m0, mc in chunks:
+            ops.gemm_skinny(xn[m0:m0 + mc], llm.head, logits[m0:m0 + mc], mc, V, D, ws)
         ops.logprob_topk(logits, M, V, K, banned, ban, tv, ti)
 
     # hipGraph replay of device_step (~430 launches): the first step of a shape runs eagerly, the second is captured.
