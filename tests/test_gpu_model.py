@@ -202,6 +202,28 @@ def test_generate_beam4_on_gpu():
         assert ((g == r).cumprod(1).sum(1) >= 8).all(), (path, g, r)
 
 
+def test_generate_more_than_64_beams_rows(setup):
+    """20 utterances x 4 beams = 80 rows: the weight-streaming kernels run in two row chunks (64 + 16).  Row arithmetic does
+    not depend on the batch a row sits in, so the tokens must be EXACTLY those of the same utterances decoded ten at a time
+    (one chunk); against the CPU double most rows agree (a random-init model is full of near-ties that bf16 flips)."""
+    from ps_slm_amd.decode import beam_search_generate
+    geo, sd, gm, cm = setup
+    batch = synthetic_text_batch(geo, 20, seed=91, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12, noise=False)
+    ids, am = batch["input_ids"][:, :9], batch["attention_mask"][:, :9]
+
+    def decode(m, rows):
+        st = m.prepare_text(ids[rows], am[rows], None, [batch["post_ids"][r] for r in rows], None, None)
+        m.forward_projector_text(st)
+        return beam_search_generate(m, st, max_new_tokens=12).numpy()
+    g_all = decode(gm, list(range(20)))
+    g_lo, g_hi = decode(gm, list(range(10))), decode(gm, list(range(10, 20)))
+    n = min(g_all.shape[1], g_lo.shape[1], g_hi.shape[1])
+    assert np.array_equal(g_all[:10, :n], g_lo[:, :n]) and np.array_equal(g_all[10:, :n], g_hi[:, :n])
+    c = decode(cm, list(range(20)))
+    n = min(n, c.shape[1])
+    assert ((g_all[:, :n] == c[:, :n]).cumprod(1).sum(1) >= 8).mean() >= 0.7
+
+
 def test_graph_replay_matches_eager(setup):
     """hipGraph capture/replay of the forward and backward launch sequences gives bit-identical results."""
     geo, sd, gm, _ = setup
