@@ -191,10 +191,11 @@ def test_generate_beam4_text_and_audio_vs_reference_tokens():
     assert (common >= 8).all(), (toks, z["tokens_audio"])
 
 
-def test_beam_state_matches_oracle_on_random_scores():
+@pytest.mark.parametrize("nb", [1, 2, 3, 4])
+def test_beam_state_matches_oracle_on_random_scores(nb):
     """Host beam bookkeeping vs the oracle's tensor formulation on a synthetic score stream with EOS events."""
     from ps_slm_amd.decode import BeamState
-    B, nb, V, T, eos = 3, 4, 50, 12, 7
+    B, V, T, eos = 3, 50, 12, 7
     g = torch.Generator().manual_seed(0)
     table = torch.randn(64, V, generator=g) * 2.0
     table[:, eos] += 1.5                                      # make EOS competitive so beams really finish
@@ -373,3 +374,25 @@ def test_encoder_tokenizer_from_sentencepiece_model(tmp_path):
     ids = tok.encode("hello tiny world")
     assert tok.vocab_size == 60 and len(ids) > 0 and all(isinstance(i, int) and 0 <= i < 60 for i in ids)
     assert setup_encoder_tokenizer(ModelConfig(encoder_path=str(tmp_path / "nope")), geo).vocab_size == geo.ctc_vocab
+
+
+@pytest.mark.parametrize("nb", [1, 2, 3])
+def test_generate_other_beam_counts_match_bf16_oracle(nb):
+    """num_beams 1 (greedy), 2 and 3 (top-k widths 2, 4, 6): product decode loop through the CPU double against the bf16
+    oracle.  The bookkeeping itself is compared exactly in test_beam_state_matches_oracle_on_random_scores; here the two
+    bf16 emulations (KV-cache loop vs full re-run) may part at a near-tie of this random-init model, so a common prefix
+    of 3 tokens is required for every utterance and exact equality for most."""
+    from ps_slm_amd.decode import beam_search_generate
+    geo, sd, batch, z, word_ids = gen_case()
+    gd = dataclasses.asdict(geo)
+    ids, am = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    model = build(geo, sd)
+    st = model.prepare_text(ids, am, None, word_ids, None, None)
+    model.forward_projector_text(st)
+    toks = beam_search_generate(model, st, num_beams=nb, max_new_tokens=12).numpy()
+    post, plen = O.pseudo_posterior(word_ids, geo.ctc_vocab)
+    emb, mask, _, _ = O.merge(O.projector(sd, post, "bf16"), plen, sd["llm.model.embed_tokens.weight"][ids], ids, am, None, geo.speech_id)
+    ref16 = O.beam_search_generate(sd, emb.detach(), mask, gd, num_beams=nb, max_new_tokens=12, mode="bf16").numpy()
+    n = min(toks.shape[1], ref16.shape[1])
+    common = (toks[:, :n] == ref16[:, :n]).cumprod(1).sum(1)
+    assert (common >= 3).all() and (common == n).any(), (toks, ref16)
