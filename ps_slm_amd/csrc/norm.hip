@@ -175,6 +175,59 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+// Short rows (D <= 1024, D % 4 == 0: the SANM encoder's 512- and 560-wide norms): one wave per row, the row in registers,
+// four rows per block.  Same two-pass statistics as above (the block-per-row kernel spends most of its 16 us per launch in
+// barriers for 2 KB of data).
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void layernorm_fwd_wave_kernel(const float* __restrict__ x, int ldx,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 void* __restrict__ y, int ldy, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd, int R, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* xr = x + (size_t)row * ldx;
+  f32x4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = lane * 4 + g * 256;
+    v[g] = c < D ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += v[g][0] + v[g][1] + v[g][2] + v[g][3];
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (lane * 4 + g * 256 < D) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q += (v[g][j] - mu) * (v[g][j] - mu);
+    }
+  }
+  const float r = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = r;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = lane * 4 + g * 256;
+    if (c < D) {
+      const f32x4 ga = *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[g][j] - mu) * r * ga[j] + be[j];
+      if (OUT_F32) *(f32x4*)((float*)y + (size_t)row * ldy + c) = o;
+      else *(bf16x4*)((bf16*)y + (size_t)row * ldy + c) = __builtin_convertvector(o, bf16x4);
+    }
+  }
+  // pad columns [D, ldy) are zero like in the block-per-row kernel
+  for (int c = D + lane; c < ldy; c += 64) {
+    if (OUT_F32) ((float*)y)[(size_t)row * ldy + c] = 0.f;
+    else ((bf16*)y)[(size_t)row * ldy + c] = (bf16)0.f;
+  }
+}
+
 // dgamma/dbeta partials: grid (ceil(D/256), RSPLIT); thread = one column; rows r = split, split+RSPLIT, ...
 // ws layout: [RSPLIT][2][Dws] fp32.
 __global__ __launch_bounds__(256) void layernorm_bwd_partial_kernel(const bf16* __restrict__ dy, int lddy,
@@ -269,6 +322,17 @@ extern "C" int tasu_rmsnorm_bwd(const void* dy, const float* x, const float* w, 
 extern "C" int tasu_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
                                   int y_is_f32, float* mean, float* rstd, int R, int D, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || R <= 0 || D <= 0 || ldx < D || ldy < D) return TASU_ERR_ARG;
+  const bool wave_ok = D <= 1024 && D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
+                       !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15);
+  if (wave_ok) {
+    if (y_is_f32)
+      TASU_LAUNCH(layernorm_fwd_wave_kernel<true>, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
+                  y, ldy, mean, rstd, R, D, eps);
+    else
+      TASU_LAUNCH(layernorm_fwd_wave_kernel<false>, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
+                  y, ldy, mean, rstd, R, D, eps);
+    return TASU_OK;
+  }
   if (y_is_f32)
     TASU_LAUNCH(layernorm_fwd_kernel<true>, dim3(R), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy,
                        mean, rstd, D, eps);

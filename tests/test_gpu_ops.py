@@ -159,7 +159,7 @@ def test_rmsnorm(hip, fake, M, D):
         assert rel_err(dg, dc) < 1e-4 and rel_err(bg, bc) < 1e-2
 
 
-@pytest.mark.parametrize("R,D,Dp,out_dtype", [(20, 203, 256, BF), (8, 25055, 25088, BF), (16, 560, 560, F32)])
+@pytest.mark.parametrize("R,D,Dp,out_dtype", [(20, 203, 256, BF), (8, 25055, 25088, BF), (16, 560, 560, F32), (70, 512, 512, BF), (9, 256, 320, BF)])
 def test_layernorm(hip, fake, R, D, Dp, out_dtype):
     x = torch.zeros(R, Dp)
     x[:, :D] = randn(R, D, seed=1).abs() * 0.01
@@ -360,6 +360,16 @@ def test_encoder_aux(hip, fake):
     g = torch.zeros(B * T, E).cuda()
     hip.fsmn_fwd(gq[:, 2 * E:], 3 * E, w.cuda(), lens.cuda(), g, B, T, E, ks, False)
     assert rel_err(g, c) < 1e-5
+    fake.fsmn_fwd(vcol, 3 * E, w, lens, c, B, T, E, ks, True)              # accumulate on top (vector path)
+    hip.fsmn_fwd(gq[:, 2 * E:], 3 * E, w.cuda(), lens.cuda(), g, B, T, E, ks, True)
+    assert rel_err(g, c) < 1e-5
+    E2 = 84                                                                 # not a multiple of 8: element-wise path
+    q2 = randn(B * T, E2, dtype=BF, seed=5)
+    w2 = randn(E2, ks, seed=6, scale=0.2)
+    c2, g2 = torch.zeros(B * T, E2), torch.zeros(B * T, E2).cuda()
+    fake.fsmn_fwd(q2, E2, w2, lens, c2, B, T, E2, ks, False)
+    hip.fsmn_fwd(q2.cuda(), E2, w2.cuda(), lens.cuda(), g2, B, T, E2, ks, False)
+    assert rel_err(g2, c2) < 1e-5
     R, V, ld = 30, 203, 256
     lg = randn(R, ld, seed=4, scale=3.0)
     (c,), (g,) = run_pair(hip, fake, "softmax_rows", [lg, torch.ones(R, ld), R, V], [1])
