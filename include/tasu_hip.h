@@ -252,6 +252,18 @@ int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k, const int
 int tasu_embed_rows(const float* table, const int32_t* ids, float* x, int M, int D, void* stream);
 
 
+/* ------------------------------------------------------------------------------------------- audio front end
+ * funasr WavFrontend (speech_dataset_large.py:133-146; third-party algorithm, see oracle/fbank_oracle.py): Kaldi log-mel
+ * filterbank of a device waveform.  frames = 1 + (n_samples - win) / shift (snip_edges); every frame: x * scale, DC removal,
+ * pre-emphasis, `window` [win], zero-pad to 512, power spectrum, `mel` [n_mels, 257] (dense, fp32), log(max(., FLT_EPSILON)).
+ * out [frames, n_mels] fp32.  win <= 512. */
+int tasu_fbank(const float* wave, int64_t n_samples, float scale, int win, int shift, const float* window, const float* mel,
+               int n_mels, float preemph, float* out, void* stream);
+/* Low-frame-rate stacking + CMVN: out[i, m*D + k] = (fb[clamp(i*lfr_n + m - (lfr_m-1)/2, 0, T-1), k] + means[m*D+k]) *
+ * scales[m*D+k] for i < ceil(T / lfr_n); means may be NULL (no CMVN). */
+int tasu_lfr_cmvn(const float* fb, int T, int D, int lfr_m, int lfr_n, const float* means, const float* scales, float* out,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

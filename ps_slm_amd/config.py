@@ -99,6 +99,7 @@ class DataConfig(_Section):
     dev_scp_file_path: str = ""
     test_scp_file_path: str = ""
     inference_mode: bool = False
+    text_only: bool = False          # ps_slm_amd/dataset.py: read audio lengths only (text-only alignment recipe)
 
 
 @dataclass

@@ -113,9 +113,17 @@ def get_dataset(dataset_config, tokenizer, split, geo, rank, steps=20, batch_siz
     module_path, func_name = f.split(":") if ":" in f else (f, "get_custom_dataset")
     if not module_path.endswith(".py"):
         raise ValueError(f"Dataset file {module_path} is not a .py file.")
-    if not Path(module_path).is_file():
-        raise FileNotFoundError(f"Dataset py file {module_path} does not exist or is not a file.")
-    return getattr(load_module_from_py_file(module_path), func_name)(dataset_config, tokenizer, split)
+    p = Path(module_path)
+    if not p.is_file():
+        alt = Path(__file__).resolve().parent.parent / module_path          # relative to the repository root
+        if not alt.is_file():
+            raise FileNotFoundError(f"Dataset py file {module_path} does not exist or is not a file.")
+        p = alt
+    if p.resolve() == (Path(__file__).resolve().parent / "dataset.py"):
+        from . import dataset as module                                     # keep package-relative imports working
+    else:
+        module = load_module_from_py_file(p.as_posix())
+    return getattr(module, func_name)(dataset_config, tokenizer, split)
 
 
 def evaluation(engine, train_config, eval_dataset, rank, world):

@@ -246,5 +246,14 @@ class HipOps:
                                              _p(out_idx), _p(self.topk_ws), self.topk_ws.numel(), self._stream()),
                   "tasu_logprob_topk")
 
+    # ------------------------------------------------------------------ audio front end
+    def fbank(self, wave, n_samples, scale, win, shift, window, mel, n_mels, preemph, out):
+        self._chk(self.lib.tasu_fbank(_p(wave), n_samples, scale, win, shift, _p(window), _p(mel), n_mels, preemph, _p(out),
+                                      self._stream()), "tasu_fbank")
+
+    def lfr_cmvn(self, fb, T, D, lfr_m, lfr_n, means, scales, out):
+        self._chk(self.lib.tasu_lfr_cmvn(_p(fb), T, D, lfr_m, lfr_n, _p(means), _p(scales), _p(out), self._stream()),
+                  "tasu_lfr_cmvn")
+
     def embed_rows(self, table, ids, x, M, D):
         self._chk(self.lib.tasu_embed_rows(_p(table), _p(ids), _p(x), M, D, self._stream()), "tasu_embed_rows")

@@ -285,6 +285,9 @@ class slam_model_asr:
             st = core.prepare_text(input_ids, attention_mask, labels, ids_list, alphas, keeps)
             core.run_forward_text(st, compute_loss=labels is not None, need_backward=self.training)
         else:
+            if input_features is None:
+                raise ValueError("the audio branch needs input_features: dataset_config.text_only=true is only valid with "
+                                 "train_config.gt_emb=true (text pseudo-posterior instead of the encoder)")
             st = core.prepare_audio(input_ids, attention_mask, labels, input_features, input_feature_length,
                                     do_psd=self.do_psd)
             core.run_forward_llm(st, compute_loss=labels is not None, need_backward=self.training)

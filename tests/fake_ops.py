@@ -427,5 +427,25 @@ class FakeOps:
         out_val[:M] = v[:, :k]
         out_idx[:M] = i[:, :k].to(out_idx.dtype)
 
+    def fbank(self, wave, n_samples, scale, win, shift, window, mel, n_mels, preemph, out):
+        T = 0 if n_samples < win else 1 + (n_samples - win) // shift
+        if T == 0:
+            return
+        idx = torch.arange(win)[None, :] + shift * torch.arange(T)[:, None]
+        fr = wave[:n_samples].float()[idx] * scale
+        fr = fr - fr.mean(1, keepdim=True)
+        fr = (fr - preemph * torch.cat([fr[:, :1], fr[:, :-1]], 1)) * window[None, :]
+        spec = torch.fft.rfft(fr.double(), n=512, dim=1)
+        power = (spec.real ** 2 + spec.imag ** 2).float()
+        out[:T] = torch.log(torch.clamp(power @ mel.t(), min=1.1920928955078125e-07))
+
+    def lfr_cmvn(self, fb, T, D, lfr_m, lfr_n, means, scales, out):
+        T_lfr = (T + lfr_n - 1) // lfr_n
+        f = torch.arange(T_lfr)[:, None] * lfr_n + torch.arange(lfr_m)[None, :] - (lfr_m - 1) // 2
+        v = fb[:T][f.clamp(0, T - 1)].reshape(T_lfr, lfr_m * D)
+        if means is not None:
+            v = (v + means[None, :]) * scales[None, :]
+        out[:T_lfr] = v
+
     def embed_rows(self, table, ids, x, M, D):
         x[:M] = table[ids[:M].long()]
