@@ -60,6 +60,15 @@ __device__ __forceinline__ void tile_coords(const Args& p, int s, int ntiles, in
   tn = in_g / gsz;
 }
 
+// a: lanes 16-31 / 48-63 receive b of lanes 0-15 / 32-47; b: lanes 0-15 / 32-47 receive a of lanes 16-31 / 48-63
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+#endif
+}
+
 template <int BM, int BN, int OUT_MODE, bool HAS_BIAS>
 __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -232,6 +241,44 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
     int l15 = lane & 15, l4 = (lane >> 4) * 4;
     asm volatile("" : "+v"(l15), "+v"(l4));
     bf16* gu = (bf16*)p.C;
+    if constexpr (NI == 4) {
+      // paired 16-byte stores (see store_tile): gate fragments (0, 1) and up fragments (2, 3) each form one pair
+      if ((p.N & 7) == 0 && (((uintptr_t)gu | (uintptr_t)p.act) & 15) == 0) {
+        int cpair = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;
+        asm volatile("" : "+v"(cpair));
+        auto rows = [&](auto interior_tag) {
+          constexpr bool INTERIOR = decltype(interior_tag)::value;     // whole tile inside the matrix: no per-lane tests
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            asm volatile("" ::: "memory");
+            const int m = row0 + wr * WM + i * 16 + l15;
+            union { bf16x4 h; unsigned u[2]; } g0, g1, u0, u1, a0, a1;
+            g0.h = __builtin_convertvector(acc[i][0], bf16x4), g1.h = __builtin_convertvector(acc[i][1], bf16x4);
+            u0.h = __builtin_convertvector(acc[i][2], bf16x4), u1.h = __builtin_convertvector(acc[i][3], bf16x4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              a0.h[r] = (bf16)(bf16_round(silu_f((float)g0.h[r])) * (float)u0.h[r]);
+              a1.h[r] = (bf16)(bf16_round(silu_f((float)g1.h[r])) * (float)u1.h[r]);
+            }
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              swap16(g0.u[d], g1.u[d]);
+              swap16(u0.u[d], u1.u[d]);
+              swap16(a0.u[d], a1.u[d]);
+            }
+            const int n = tn * 64 + wc * 32 + cpair;                  // act column of this lane's 8 values
+            if (INTERIOR || (m < p.M && n < p.N)) {                   // N % 8 == 0: all eight or none
+              *(u32x4*)(gu + (size_t)m * (2 * (size_t)p.N) + n) = u32x4{g0.u[0], g0.u[1], g1.u[0], g1.u[1]};
+              *(u32x4*)(gu + (size_t)m * (2 * (size_t)p.N) + p.N + n) = u32x4{u0.u[0], u0.u[1], u1.u[0], u1.u[1]};
+              *(u32x4*)(p.act + (size_t)m * p.N + n) = u32x4{a0.u[0], a0.u[1], a1.u[0], a1.u[1]};
+            }
+          }
+        };
+        if (row0 + BM <= p.M && tn * 64 + 64 <= p.N) rows(std::true_type{});
+        else rows(std::false_type{});
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       asm volatile("" ::: "memory");
@@ -267,6 +314,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
         for (int r = 0; r < 4; ++r) bv[j][r] = n + r < p.N ? (float)p.bias[n + r] : 0.f;
       }
     }
+    const bool interior = row0 + BM <= p.M && col0 + BN <= p.N;     // wave-uniform: the whole tile lies inside the matrix
     if constexpr (OUT_MODE == TASU_GEMM_OUT_F32_RESID_BF16R && BM == 128) {
       // residual add: the fp32 residual rows of IB row blocks are fetched together (clamped addresses, no branches)
       // before the first use -- one memory round trip per IB row blocks instead of one per fragment; with one tile per CU
@@ -299,8 +347,84 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
                 for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
               }
               const f32x4 rr = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
-              if (m < p.M && n < p.N) *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = old[ii][j] + rr;
+              if (interior || (m < p.M && n < p.N)) *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = old[ii][j] + rr;
             }
+          }
+        }
+        return;
+      }
+    }
+    if constexpr (OUT_MODE == TASU_GEMM_OUT_BF16 && NI % 2 == 0) {
+      // bf16 output: the epilogue is store-ISSUE bound (16 rows x 32 B per dwordx2 instruction).  Fragment pairs (j, j+1)
+      // trade halves between lanes l and l+16 (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows
+      // of the second), after which every lane holds 8 consecutive columns: one 16-byte store per pair, 64 B per row.
+      if ((p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0) {
+        int cpair = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;       // first of this lane's 8 columns inside the pair
+        asm volatile("" : "+v"(cpair));
+        auto rows = [&](auto interior_tag) {
+          constexpr bool INTERIOR = decltype(interior_tag)::value;   // straight-line code: no per-lane edge tests
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            asm volatile("" ::: "memory");
+            const int m = row0 + wr * WM + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < NI; j += 2) {
+              f32x4 v0 = acc[i][j], v1 = acc[i][j + 1];
+              if (HAS_BIAS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v0[r] += bv[j][r], v1[r] += bv[j + 1][r];
+              }
+              union { bf16x4 h; unsigned u[2]; } a, b;
+              a.h = __builtin_convertvector(v0, bf16x4);
+              b.h = __builtin_convertvector(v1, bf16x4);
+              union { u32x4 q; bf16 h[8]; } o;
+              swap16(a.u[0], b.u[0]);
+              swap16(a.u[1], b.u[1]);
+              o.q = u32x4{a.u[0], a.u[1], b.u[0], b.u[1]};
+              const int n = col0 + wc * WN + j * 16 + cpair;
+              bf16* c = (bf16*)p.C + (size_t)m * p.ldc + n;
+              if constexpr (INTERIOR) {
+                *(u32x4*)c = o.q;
+              } else if (m < p.M) {
+                if (n + 8 <= p.N) {
+                  *(u32x4*)c = o.q;
+                } else {
+#pragma unroll
+                  for (int r = 0; r < 8; ++r)
+                    if (n + r < p.N) c[r] = o.h[r];
+                }
+              }
+            }
+          }
+        };
+        if (interior) rows(std::true_type{});
+        else rows(std::false_type{});
+        return;
+      }
+    }
+    if constexpr (OUT_MODE != TASU_GEMM_OUT_BF16) {
+      // fp32 outputs, interior tile, 16-byte aligned rows: straight-line code (the general loop below tests every fragment)
+      if (interior && (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0 &&
+          (OUT_MODE != TASU_GEMM_OUT_F32_RESID_BF16R || ((uintptr_t)p.R & 15) == 0)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          asm volatile("" ::: "memory");
+          const size_t rowoff = (size_t)(row0 + wr * WM + i * 16 + l15) * p.ldc + (col0 + wc * WN + l4);
+          [[maybe_unused]] f32x4 old[NI];
+          if constexpr (OUT_MODE == TASU_GEMM_OUT_F32_RESID_BF16R) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) old[j] = *(const f32x4*)(p.R + rowoff + j * 16);
+          }
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            f32x4 v = acc[i][j];
+            if (HAS_BIAS) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
+            }
+            if constexpr (OUT_MODE == TASU_GEMM_OUT_F32_RESID_BF16R)
+              v = old[j] + __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
+            *(f32x4*)((float*)p.C + rowoff + j * 16) = v;
           }
         }
         return;

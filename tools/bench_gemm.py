@@ -15,6 +15,7 @@ ap.add_argument("M", nargs="?", type=int, default=4096)
 ap.add_argument("--cold", action="store_true")
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--only", default="")
+ap.add_argument("--check", action="store_true", help="compare against torch.matmul (rocBLAS) on the same bits")
 ap.add_argument("--shape", action="append", default=[], help="extra M,N,K (repeatable); implies --only custom")
 args = ap.parse_args()
 ops = HipOps()
@@ -42,6 +43,11 @@ for name, m, n, k in shapes:
         a, b, c = sets[i % nsets]
         ops.gemm(a, b, c, m, n, k)
     torch.cuda.synchronize()
+    if args.check:
+        ref = (a0.float() @ b0.float().t())
+        err = float((sets[0][2].float() - ref).abs().max() / ref.abs().max())
+        print(f"  check {name}: rel err {err:.2e}" + ("" if err < 1e-2 else "  <-- MISMATCH"), flush=True)
+        del ref
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     iters = args.iters
     e0.record()
