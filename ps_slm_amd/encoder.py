@@ -107,6 +107,22 @@ def encoder_posterior(model, feats, feat_lens):
     for b in range(B):
         km[b, : int(lens_h[b])] = 1
     key_mask = model._upload("enc_key_mask", km)
+    # everything below is a fixed launch sequence for a given (B, T): ~12 launches x 70 blocks, replayed as one hipGraph
+    # when the model runs with graphs (the uploads above stay outside the captured region)
+    out = {}
+    model.graphed_region(("encoder", B, T), lambda: out.update(post=_encoder_body(model, x0, lens, key_mask, B, T)))
+    return model._buf("enc_post", (M, Kp), f32), Te, lens
+
+
+def _encoder_body(model, x0, lens, key_mask, B, T):
+    ops, geo, enc = model.ops, model.geo, model.encoder
+    Fd = geo.feat_dim
+    E, Hh, Ff, V = geo.enc_dim, geo.enc_heads, geo.enc_ffn, geo.ctc_vocab
+    Te, Kp = T + 4, rup(V, 64)
+    M = B * Te
+    Spad = rup(Te, 64)
+    f32, bf = torch.float32, torch.bfloat16
+    buf = model._buf
     x = buf("enc_x", (M, Fd), f32)
     ops.sinusoid_pe(x0.view(M, Fd), x, B, Te, Fd, float(E) ** 0.5)
     ident_c = buf("enc_cos1", (M, HD // 2), f32)
@@ -156,7 +172,7 @@ def encoder_posterior(model, feats, feat_lens):
     ops.gemm(encb, enc.ctc_w, logits, M, V, E, bias=enc.ctc_b)
     post = buf("enc_post", (M, Kp), f32)
     ops.softmax_rows(logits, post, M, V)
-    return post, Te, lens
+    return post
 
 
 def psd_on_device(model, post, B, T, Te, feat_lens_dev, do_psd=True):

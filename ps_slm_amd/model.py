@@ -576,6 +576,13 @@ class TasuModel:
         self._graphs[key] = (graph, {k: v for k, v in st.dev.items() if k not in before}, gen)
         graph.replay()
 
+    def graphed_region(self, key, fn):
+        """Runs ``fn`` (a launch sequence that depends only on ``key`` and on the contents of persistent workspace
+        buffers) eagerly or, with graphs enabled, as a captured hipGraph keyed by ``key`` (+ the workspace generation)."""
+        class _NoState:
+            dev = {}
+        self._graphed(("region",) + tuple(key), fn, _NoState())
+
     def _shape_key(self, st, tag):
         return (tag, st.path, st.B, st.S, st.Ra, st.Rap, self.keep_logits)
 

@@ -254,3 +254,37 @@ def test_graph_replay_matches_eager(setup):
         assert torch.equal(l, l0) and torch.equal(g, g0)
     gm._graphs.clear()
     gm._graph_seen.clear()
+
+
+def test_encoder_graph_replay_matches_eager():
+    """The SANM encoder's launch sequence replayed as a hipGraph: bit-identical CTC posterior, PSD lengths and loss for
+    inputs that CHANGE between the capture and the replays (the uploads stay outside the captured region)."""
+    from conftest import mid_audio_psd_case
+    from ps_slm_amd.ops import HipOps
+    geo, sd, batch, _ = mid_audio_psd_case()
+    gm = TasuModel(geo, HipOps(), "cuda")
+    gm.load_reference_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    variants = [dict(batch, input_features=batch["input_features"] + 0.3 * i * torch.randn(batch["input_features"].shape, generator=g))
+                for i in range(4)]
+
+    def one(b):
+        st = gm.prepare_audio(b["input_ids"], b["attention_mask"], b["labels"], b["input_features"], b["input_feature_length"])
+        gm.run_forward_llm(st)
+        gm.run_backward(st)
+        torch.cuda.synchronize()
+        Te = b["input_features"].shape[1] + 4
+        post = gm._buf("enc_post", (b["input_features"].shape[0] * Te, rup64(geo.ctc_vocab)), torch.float32).clone()
+        return post, np.array(st.dev["psd_lens"]).copy(), st.dev["loss_out"].clone()
+
+    def rup64(v):
+        return (v + 63) // 64 * 64
+
+    gm.use_graphs = False
+    want = [one(b) for b in variants]
+    gm.use_graphs = True
+    got = [one(b) for b in variants]                  # eager warm-up, capture + replay, replay, replay
+    assert any(k[0] == "region" and k[1] == "encoder" for k in gm._graphs)
+    for (p0, n0, l0), (p1, n1, l1) in zip(want, got):
+        assert torch.equal(p0, p1) and np.array_equal(n0, n1) and torch.equal(l0, l1)
+    assert not torch.equal(want[0][0], want[3][0])     # the variants really differ
