@@ -15,6 +15,7 @@ ap.add_argument("M", nargs="?", type=int, default=4096)
 ap.add_argument("--cold", action="store_true")
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--only", default="")
+ap.add_argument("--vendor", action="store_true", help="also time torch.matmul (rocBLAS / hipBLASLt) on the same operand sets")
 ap.add_argument("--check", action="store_true", help="compare against torch.matmul (rocBLAS) on the same bits")
 ap.add_argument("--shape", action="append", default=[], help="extra M,N,K (repeatable); implies --only custom")
 args = ap.parse_args()
@@ -58,8 +59,24 @@ for name, m, n, k in shapes:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     tf = 2.0 * m * n * k / ms / 1e9
-    res.append(dict(name=name, M=m, N=n, K=k, ms=round(ms, 4), tflops=round(tf, 1), sets=nsets))
-    print(f"{name:10s} M={m:5d} N={n:6d} K={k:6d}  {ms:8.3f} ms  {tf:7.1f} TF/s  ({nsets} sets)", flush=True)
+    extra = ""
+    rec = dict(name=name, M=m, N=n, K=k, ms=round(ms, 4), tflops=round(tf, 1), sets=nsets)
+    if args.vendor:
+        for i in range(max(3, nsets)):
+            a, b, c = sets[i % nsets]
+            torch.matmul(a, b.t(), out=c)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(iters):
+            a, b, c = sets[i % nsets]
+            torch.matmul(a, b.t(), out=c)
+        e1.record()
+        torch.cuda.synchronize()
+        vms = e0.elapsed_time(e1) / iters
+        rec.update(vendor_ms=round(vms, 4), vendor_tflops=round(2.0 * m * n * k / vms / 1e9, 1))
+        extra = f"   vendor {vms:8.3f} ms {rec['vendor_tflops']:7.1f} TF/s  ({vms / ms:.2f}x)"
+    res.append(rec)
+    print(f"{name:10s} M={m:5d} N={n:6d} K={k:6d}  {ms:8.3f} ms  {tf:7.1f} TF/s  ({nsets} sets){extra}", flush=True)
     del sets, a0, b0, a, b, c
     torch.cuda.empty_cache()
 print(json.dumps(res))
