@@ -16,6 +16,9 @@
 
 #include <type_traits>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "../../include/tasu_hip.h"
 
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(Args p) {
   for (int i = 0; i < 8; ++i) {
     const int r = i * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    ga[i] = p.A + (size_t)min(r, p.M - 1) * p.lda + c * 8;
+    ga[i] = p.A + (size_t)min(r, p.M - 1) * p.lda + c * 8 - (i & 3) * 512;   // - the immediate offset of stage()
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
@@ -90,17 +93,24 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(Args p) {
     int brow;
     if (SWIGLU) brow = r < HALF ? min(col0 + r, p.N - 1) : p.up_row0 + min(col0 + r - HALF, p.N - 1);
     else brow = min(col0 + r, p.N - 1);
-    gb[i] = p.B + (size_t)brow * p.ldb + c * 8;
+    gb[i] = p.B + (size_t)brow * p.ldb + c * 8 - (i & 3) * 512;
   }
   auto stage = [&](int buf, int kt) {
     char* base = my + buf * WAVE_STAGE;
     const int koff = kt * BK;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(base + i * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < PB; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(base + A_BYTES + i * 1024), 16, 0, 0);
+    // one M0 (LDS base) per four pieces: the immediate offset (i & 3) KiB moves the LDS address and the global address
+    // alike; the per-lane pointers were lowered by the same amount (writing M0 per piece costs ~40 issue cycles each)
+    auto one_a = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(base + (i & ~3) * 1024), 16, (i & 3) * 1024, 0);
+    };
+    auto one_b = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(base + A_BYTES + (i & ~3) * 1024), 16,
+                                       (i & 3) * 1024, 0);
+    };
+    [&]<int... I>(std::integer_sequence<int, I...>) { (one_a(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, 8>{});
+    [&]<int... I>(std::integer_sequence<int, I...>) { (one_b(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, PB>{});
   };
   const int sw = (lane >> 1) & 7;
   int roff[2];
