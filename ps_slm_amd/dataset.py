@@ -16,7 +16,6 @@ with the standard library; the features come from ``ps_slm_amd.frontend`` (HIP f
 ``dataset_config.text_only = true`` (the text-only alignment recipe: the model never looks at ``input_features``) only the
 audio LENGTH is read -- it decides the batch composition through ``window_class`` -- and no features are computed.
 """
-import copy
 import io
 import json
 import os
@@ -77,159 +76,169 @@ def audio_num_samples(path):
 
 
 # ------------------------------------------------------------------------------------------------ dataset
+_SPLIT_FIELD = {"train": "train_scp_file_path", "val": "dev_scp_file_path", "test": "test_scp_file_path"}
+_TARGET_JUNK = re.compile(r"[^A-Za-z\s.,!?']+")          # what the reference strips from training targets (:164)
+
+
+def _prompt_table(path):
+    """multiprompt.jsonl -> {task: [prompt, ...]} in file order (the order matters: prompts are drawn by index)."""
+    table = {}
+    with open(path) as f:
+        for row in map(json.loads, filter(None, (ln.strip() for ln in f))):
+            table.setdefault(row["task"], []).append(row["prompt"])
+    return table
+
+
+def _unescape(text):
+    """The jsonl ``GT`` field carries backslash escapes (speech_dataset_large.py:96-102); undecodable text stays as is."""
+    try:
+        return text.encode("utf-8").decode("unicode_escape")
+    except Exception:
+        return text
+
+
 class MultiTaskDataset(IterableDataset):
+    """One sample per ``multitask.jsonl`` line of this rank's (and DataLoader worker's) share."""
+
     def __init__(self, dataset_config, tokenizer=None, split="train", frontend=None):
         super().__init__()
-        self.multitask_prompt_list = {}
-        self.append_info_tasks = dataset_config.append_info_tasks
-        with open(dataset_config.multitask_prompt_path) as f_prompt:
-            for line in f_prompt:
-                item = json.loads(line.strip())
-                self.multitask_prompt_list.setdefault(item["task"], []).append(item["prompt"])
-        if split == "train":
-            self.data_path = dataset_config.train_scp_file_path
-        elif split == "val":
-            self.data_path = dataset_config.dev_scp_file_path
-        elif split == "test":
-            self.data_path = dataset_config.test_scp_file_path
-        else:
+        if split not in _SPLIT_FIELD:
             raise ValueError("Split must be train val test")
-        self.prompt_template = dataset_config.get("prompt_style", "{}")
-        self.dataset_config = dataset_config
-        self.tokenizer = tokenizer
-        self.split = split
-        self.max_audio_length = dataset_config.get("max_audio_length", 30)
-        self.inference_mode = dataset_config.get("inference_mode", False)
+        cfg = dataset_config
+        self.dataset_config, self.tokenizer, self.split = cfg, tokenizer, split
+        self.data_path = getattr(cfg, _SPLIT_FIELD[split])
+        self.multitask_prompt_list = _prompt_table(cfg.multitask_prompt_path)
+        self.append_info_tasks = cfg.append_info_tasks
+        self.prompt_template = cfg.get("prompt_style", "{}")
+        self.inference_mode = bool(cfg.get("inference_mode", False))
+        self.text_only = bool(cfg.get("text_only", False))
+        self.max_audio_length = cfg.get("max_audio_length", 30)
         self.sample_rate = SAMPLE_RATE
-        self.text_only = bool(dataset_config.get("text_only", False))
         self.frontend = frontend                    # callable(waveform float32) -> (features [T, D] tensor, T)
-        if self.frontend is None:
+        if frontend is None:
             from .frontend import WavFrontend
-            self.frontend = WavFrontend.from_encoder_path(dataset_config.get("encoder_path", None))
+            self.frontend = WavFrontend.from_encoder_path(cfg.get("encoder_path", None))
+
+    @property
+    def _jsonl(self):
+        return os.path.join(self.data_path, "multitask.jsonl")
 
     def __len__(self):
-        with open(os.path.join(self.data_path, "multitask.jsonl"), "r", encoding="utf-8") as f:
+        with open(self._jsonl, "r", encoding="utf-8") as f:
             return sum(1 for _ in f)
 
+    def _share(self):
+        """(stride, phase): line n belongs to this iterator when n % stride == phase -- ranks outermost, DataLoader workers
+        inside a rank (speech_dataset_large.py:72-91)."""
+        info = torch.utils.data.get_worker_info()
+        n_work, w = (info.num_workers, info.id) if info is not None else (1, 0)
+        distributed = dist.is_available() and dist.is_initialized()
+        n_rank, r = (dist.get_world_size(), dist.get_rank()) if distributed else (1, 0)
+        return n_work * n_rank, r * n_work + w
+
+    def _audio(self, path):
+        if self.text_only:
+            return None, self.frontend.output_length(audio_num_samples(path))
+        return self.frontend(read_audio(path)[1])
+
+    def _sample(self, item):
+        task, target = item["task"], item["target"]
+        feats, n_frames = self._audio(item["path"])
+        # the prompt is drawn from the task's list with the GLOBAL random stream, after the audio has been read
+        text = self.prompt_template.format(random.choice(self.multitask_prompt_list[task]))
+        if task in self.append_info_tasks:
+            text = text.format(item[task])
+        head = self.tokenizer.encode(text)
+        ids = list(head)
+        if not self.inference_mode:
+            target = _TARGET_JUNK.sub("", target).lower().strip()
+            ids += self.tokenizer.encode(target) + [self.tokenizer.eos_token_id]
+        ids = torch.tensor(ids)
+        sample = dict(input_ids=ids, attention_mask=ids.ge(-1), input_features=feats, input_feature_length=n_frames,
+                      key=item["key"], target=target, GT=_unescape(item.get("GT", "")))
+        if not self.inference_mode:
+            lab = ids.clone()
+            lab[: len(head)] = self.tokenizer.default_ignore_token
+            sample["labels"] = lab
+        return sample
+
     def __iter__(self):
-        worker_info = torch.utils.data.get_worker_info()
-        num_workers, worker_id = (1, 0) if worker_info is None else (worker_info.num_workers, worker_info.id)
-        if dist.is_available() and dist.is_initialized():
-            world_size, rank = dist.get_world_size(), dist.get_rank()
-        else:
-            world_size, rank = 1, 0
-        total_num_workers = num_workers * world_size
-        worker_rank = rank * num_workers + worker_id
-        with open(os.path.join(self.data_path, "multitask.jsonl")) as f_task:
-            for data_index, line in enumerate(f_task):
-                if (data_index % total_num_workers) != worker_rank:
-                    continue
-                item = json.loads(line.strip())
-                ark_path, key, target, task = item["path"], item["key"], item["target"], item["task"]
-                raw = item.get("GT", "")
-                try:
-                    GT = raw.encode("utf-8").decode("unicode_escape")
-                except Exception:
-                    GT = raw
-                if self.text_only:
-                    input_features = None
-                    input_feature_length = self.frontend.output_length(audio_num_samples(ark_path))
-                else:
-                    _, audio_raw = read_audio(ark_path)
-                    input_features, input_feature_length = self.frontend(audio_raw)
-                prompt = random.choice(self.multitask_prompt_list[task])
-                prompt = self.prompt_template.format(prompt)
-                if task in self.append_info_tasks:
-                    prompt = prompt.format(item[task])
-                prompt_ids = self.tokenizer.encode(prompt)
-                prompt_length = len(prompt_ids)
-                prompt_ids = torch.tensor(prompt_ids)
-                if not self.inference_mode:
-                    target = re.sub(r"[^A-Za-z\s.,!?']+", "", target).lower().strip()
-                    target_ids = self.tokenizer.encode(target)
-                    target_ids.append(self.tokenizer.eos_token_id)
-                    input_ids = torch.cat([prompt_ids, torch.tensor(target_ids)])
-                else:
-                    input_ids = prompt_ids
-                result = {"input_ids": input_ids, "attention_mask": input_ids.ge(-1), "input_features": input_features,
-                          "input_feature_length": input_feature_length, "key": key, "target": target, "GT": GT}
-                if not self.inference_mode:
-                    labels = copy.deepcopy(input_ids)
-                    labels[:prompt_length] = self.tokenizer.default_ignore_token
-                    result["labels"] = labels
-                yield result
+        stride, phase = self._share()
+        with open(self._jsonl) as f:
+            for n, line in enumerate(f):
+                if n % stride == phase:
+                    yield self._sample(json.loads(line.strip()))
 
     @staticmethod
     def pad(sequence, max_length, padding_idx=0, padding_style="right"):
+        """Tensor padded (or cut) to ``max_length`` along dim 0, filler on the given side."""
         if not isinstance(sequence, torch.Tensor):
             raise TypeError("Type mismatch during padding!")
-        if len(sequence) >= max_length:
+        missing = max_length - len(sequence)
+        if missing <= 0:
             return sequence[:max_length]
-        fill = torch.full([max_length - len(sequence)] + list(sequence.size())[1:], padding_idx, dtype=sequence.dtype)
-        return torch.cat((sequence, fill)) if padding_style == "right" else torch.cat((fill, sequence))
+        filler = sequence.new_full((missing,) + tuple(sequence.shape[1:]), padding_idx)
+        return torch.cat((filler, sequence) if padding_style == "left" else (sequence, filler))
 
     def collator(self, samples):
+        """Batch schema of speech_dataset_large.py:240-305: ids / mask / labels padded to the longest sequence (left in
+        inference mode, right in training), features zero-padded along time, GT / keys / targets as lists."""
         assert samples is not None
-        padding_style = "left" if self.inference_mode else "right"
-        L = max(s["input_ids"].shape[0] for s in samples)
-        result = {
-            "input_ids": torch.stack([self.pad(s["input_ids"], L, self.tokenizer.pad_token_id, padding_style) for s in samples]),
-            "attention_mask": torch.stack([self.pad(s["attention_mask"], L, False, padding_style) for s in samples]),
-            "input_feature_length": torch.tensor([s["input_feature_length"] for s in samples], dtype=torch.long),
-        }
-        if self.text_only:
-            result["input_features"] = None
-        else:
-            T = max(s["input_features"].size(0) for s in samples)
-            result["input_features"] = torch.stack([
-                torch.nn.functional.pad(s["input_features"], (0, 0, 0, T - s["input_features"].size(0)), value=0.0)
-                for s in samples])
-        result["GT"] = [s["GT"] for s in samples]
+        side = "left" if self.inference_mode else "right"
+        width = max(len(s["input_ids"]) for s in samples)
+        tok = self.tokenizer
+        stack = lambda key, fill: torch.stack([self.pad(s[key], width, fill, side) for s in samples])
+        batch = {"input_ids": stack("input_ids", tok.pad_token_id), "attention_mask": stack("attention_mask", False)}
+        batch["input_features"] = None
+        if not self.text_only:
+            frames = max(s["input_features"].size(0) for s in samples)
+            batch["input_features"] = torch.stack(
+                [torch.nn.functional.pad(s["input_features"], (0, 0, 0, frames - s["input_features"].size(0))) for s in samples])
+        batch["input_feature_length"] = torch.tensor([s["input_feature_length"] for s in samples], dtype=torch.long)
+        batch["GT"] = [s["GT"] for s in samples]
         if self.inference_mode:
-            result["keys"] = [s["key"] for s in samples]
-            result["targets"] = [s["target"] for s in samples]
+            batch["keys"], batch["targets"] = [s["key"] for s in samples], [s["target"] for s in samples]
         else:
-            result["labels"] = torch.stack([self.pad(s["labels"], L, self.tokenizer.default_ignore_token, padding_style)
-                                            for s in samples])
-        return result
+            batch["labels"] = stack("labels", tok.default_ignore_token)
+        return batch
 
 
 class MultiTaskDynamicBatchDataset(IterableDataset):
-    """Pre-batched iterable: elements are appended until ``window_class`` says the next one would overflow the budget."""
+    """Pre-batched iterable over ``dataset``: yields lists of samples; ``window_class(sample, pending)`` decides whether
+    ``sample`` still fits the pending list (False) or opens a new one (True) -- speech_dataset_large.py:307-330."""
 
     def __init__(self, dataset, window_class):
         super().__init__()
-        assert window_class is not None
+        if window_class is None:
+            raise AssertionError("window_class is required")
         self.dp, self.window_class, self.collator = dataset, window_class, dataset.collator
-        self._buffer = []
 
     def __iter__(self):
-        for elem in self.dp:
-            if not self.window_class(elem, self._buffer):
-                self._buffer.append(elem)
-            else:
-                if len(self._buffer) > 0:
-                    yield self._buffer
-                self._buffer = [elem]
-        if len(self._buffer) > 0:
-            yield self._buffer
-        self._buffer = []
+        pending = []
+        for sample in self.dp:
+            if self.window_class(sample, pending):
+                if pending:
+                    yield pending
+                pending = []
+            pending.append(sample)
+        if pending:
+            yield pending
 
     def __len__(self):
         return len(self.dp)
 
 
 def window_class(elem, buffer, max_frame_length, ds_rate):
-    """speech_dataset_large.py:333-338 -- NOTE the empty-buffer case returns True, so the very first element is routed
-    through the 'flush' branch of the batcher (which has nothing to flush) exactly as in the reference."""
-    if len(buffer) == 0:
+    """True when ``elem`` must open a new batch: an empty buffer (the reference routes the very first element through the
+    flush branch as well, :333-335) or batch size x longest merged length over the frame budget (:336-338)."""
+    if not buffer:
         return True
-    frames = lambda e: len(e["input_ids"]) + (e["input_feature_length"] // ds_rate) - 1
-    max_frame = max(frames(elem), max(frames(b) for b in buffer))
-    return (len(buffer) + 1) * max_frame > max_frame_length
+    merged = lambda e: len(e["input_ids"]) + e["input_feature_length"] // ds_rate - 1
+    longest = max(merged(e) for e in [elem, *buffer])
+    return (len(buffer) + 1) * longest > max_frame_length
 
 
 def get_speech_dataset(dataset_config, tokenizer, split, frontend=None):
-    dataset = MultiTaskDataset(dataset_config, tokenizer, split, frontend=frontend)
     budget = dataset_config.train_max_frame_length if split == "train" else dataset_config.eval_max_frame_length
-    return MultiTaskDynamicBatchDataset(dataset, partial(window_class, max_frame_length=budget, ds_rate=dataset_config.ds_rate))
+    fits = partial(window_class, max_frame_length=budget, ds_rate=dataset_config.ds_rate)
+    return MultiTaskDynamicBatchDataset(MultiTaskDataset(dataset_config, tokenizer, split, frontend=frontend), fits)
