@@ -286,11 +286,12 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if core.use_graphs and rank == 0 and world == 1:
+    if core.use_graphs:
+        # every rank takes part (the step contains the gradient all-reduce); only rank 0 records the event pairs
         core.use_graphs = False
         step()
         torch.cuda.synchronize()
-        timed.enabled = True
+        timed.enabled = rank == 0
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
