@@ -70,6 +70,22 @@ def test_gemm(hip, fake, M, N, K, mode, bias):
     assert torch.equal(gc.cpu()[:, N:], cc[:, N:]), "columns beyond N must be untouched"
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gemm_unaligned_output_rows(hip, fake, mode):
+    """ldc = N = 203: rows of C are neither 16- nor 8-byte aligned, so the kernels take their element-wise epilogues."""
+    M, N, K = 300, 203, 128
+    a = randn(M, K, dtype=BF, seed=1)
+    b = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
+    bv = randn(N, dtype=BF, seed=3)
+    c = torch.zeros(M, N, dtype=BF if mode == 0 else F32)
+    r = randn(M, N, seed=4) if mode == 2 else None
+    cc, gc = c.clone(), c.cuda()
+    fake.gemm(a, b, cc, M, N, K, bias=bv, resid=r, mode=mode)
+    hip.gemm(a.cuda(), b.cuda(), gc, M, N, K, bias=dev(bv), resid=dev(r), mode=mode)
+    torch.cuda.synchronize()
+    assert rel_err(gc, cc) < (1e-2 if mode != 1 else 2e-5 * math.sqrt(K))
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 384, 32768), (300, 200, 24576), (1664, 2048, 25088), (1024, 1536, 28672)])
 @pytest.mark.parametrize("mode", [0, 2])
 def test_gemm_split_k(hip, fake, M, N, K, mode):
