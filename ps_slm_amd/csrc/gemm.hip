@@ -14,6 +14,9 @@
 // stores).  blockIdx is remapped so that each XCD (private L2) works on a contiguous band of tiles.
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "../../include/tasu_hip.h"
 
@@ -94,25 +97,32 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_nt_kernel(GemmArgs p) 
   for (int i = 0; i < PA; ++i) {
     const int r = (wave * PA + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    ga[i] = p.A + (size_t)min(row0 + r, p.M - 1) * p.lda + c * 8;
+    ga[i] = p.A + (size_t)min(row0 + r, p.M - 1) * p.lda + c * 8 - (i & 3) * 512;   // - the immediate offset of stage()
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int r = (wave * PB + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    gb[i] = p.B + (size_t)min(col0 + r, p.N - 1) * p.ldb + c * 8;
+    gb[i] = p.B + (size_t)min(col0 + r, p.N - 1) * p.ldb + c * 8 - (i & 3) * 512;
   }
 
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE_BYTES;
     const int koff = kt * BK;
-#pragma unroll
-    for (int i = 0; i < PA; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(base + (wave * PA + i) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < PB; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(base + A_BYTES + (wave * PB + i) * 1024), 16, 0,
-                                       0);
+    // one M0 (LDS base) per four pieces: the immediate offset (i & 3) KiB moves the LDS address and the global address
+    // alike, and the per-lane pointers were lowered by the same amount (see gemm_pipe.hip)
+    auto one_a = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(base + (wave * PA + (i & ~3)) * 1024), 16,
+                                       (i & 3) * 1024, 0);
+    };
+    auto one_b = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(base + A_BYTES + (wave * PB + (i & ~3)) * 1024), 16,
+                                       (i & 3) * 1024, 0);
+    };
+    [&]<int... I>(std::integer_sequence<int, I...>) { (one_a(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, PA>{});
+    [&]<int... I>(std::integer_sequence<int, I...>) { (one_b(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, PB>{});
   };
 
   // ---- per-lane LDS read offsets (bytes) for the two 32-deep k sub-steps.
