@@ -227,3 +227,34 @@ def test_generate_beam4_text_and_audio(geo, tiny_weights):
     emb, mask, _, _ = O.merge(proj, pl, W["llm.model.embed_tokens.weight"][ids], ids, am, None, geo["speech_id"])
     toks = O.beam_search_generate(W, emb, mask, geo, max_new_tokens=12)
     assert np.array_equal(toks.numpy(), z["tokens"]), (toks, z["tokens"])
+
+
+def test_merge_plan_random_batches_vs_reference(geo):
+    """48 random ragged batches (right / left padding, with and without labels, 1-5 rows) through the REAL reference's
+    _merge_input_ids_with_audio_features (oracle/make_golden_merge.py): the product's host plan (ps_slm_amd.merge) and the
+    oracle's restatement must place every token, audio frame and pad exactly where the reference did."""
+    from conftest import load_npz
+    from ps_slm_amd.merge import build_merge_plan
+    z = load_npz("merge_random")
+    for n in range(int(z["n_cases"])):
+        ids, am, na = z[f"c{n}_input_ids"], z[f"c{n}_attention_mask"], z[f"c{n}_num_audio"]
+        labels = z.get(f"c{n}_labels")
+        Lmax = int(na.max())
+        plan = build_merge_plan(ids, am, labels, na, geo["speech_id"], Lmax)
+        B, S = plan.B, plan.S
+        tag, mask, pos = z[f"c{n}_source_tag"], z[f"c{n}_mask"].astype(bool), z[f"c{n}_position_ids"]
+        assert tag.shape == (B, S), n
+        kind, idx = plan.src_kind.reshape(B, S), plan.src_idx.reshape(B, S)
+        # decode the reference's tags: token t -> -(t + 1); audio frame (b, j) -> 1000 (b + 1) + j; pad -> 0
+        want_kind = np.where(tag < 0, 1, np.where(tag > 0, 2, 0))
+        assert np.array_equal(kind, want_kind), n
+        assert np.array_equal(idx[kind == 1], (-tag[kind == 1] - 1).astype(np.int64)), n
+        bb, jj = np.divmod(tag[kind == 2].astype(np.int64), 1000)
+        assert np.array_equal(idx[kind == 2], (bb - 1) * Lmax + jj), n
+        assert np.array_equal(np.nonzero(kind == 2)[0], bb - 1), n            # audio rows stay in their own utterance
+        assert np.array_equal(plan.key_mask[:, :S].astype(bool), mask), n
+        assert np.array_equal(plan.position_ids.reshape(B, S), pos), n
+        if labels is not None:
+            assert np.array_equal(plan.labels, z[f"c{n}_merged_labels"]), n
+        op = O.merge_plan(torch.from_numpy(ids), torch.from_numpy(am), torch.from_numpy(na), geo["speech_id"])
+        assert np.array_equal(op["mask"].numpy(), mask) and np.array_equal(op["position_ids"].numpy(), pos), n
