@@ -419,6 +419,33 @@ def test_psd_kernels(hip, fake):
     torch.testing.assert_close(og.view(B, Tout, ld)[:, :, :V], ref, rtol=1e-5, atol=1e-7)
 
 
+def test_psd_kernels_random_batches_vs_reference(hip):
+    """The three PSD kernels on the 32 random batches of tests/golden/psd_random.npz (outputs of the REAL reference's psd()):
+    lengths exact, merged rows within fp32 rounding of the reference's running means."""
+    from conftest import load_npz
+    z = load_npz("psd_random")
+    for c in range(int(z["n_cases"])):
+        post = torch.from_numpy(z[f"c{c}_posterior"])
+        B, T, V = post.shape
+        ld = 64
+        p2 = torch.zeros(B * T, ld)
+        p2[:, :V] = post.reshape(B * T, V)
+        p2, lens = p2.cuda(), torch.from_numpy(z[f"c{c}_lens"]).to(I32).cuda()
+        fid, fbl = torch.zeros(B * T, dtype=I32, device="cuda"), torch.zeros(B * T, device="cuda")
+        ss, sl = torch.zeros(B * T, dtype=I32, device="cuda"), torch.zeros(B * T, dtype=I32, device="cuda")
+        nl = torch.zeros(B, dtype=I32, device="cuda")
+        hip.psd_frame_stats(p2, lens, fid, fbl, B, T, T, V, 0)
+        hip.psd_plan(fid, fbl, lens, ss, sl, nl, B, T, 0, 0.9)
+        want_lens = z[f"c{c}_new_lens"]
+        assert np.array_equal(nl.cpu().numpy(), want_lens), c
+        Tout = int(want_lens.max())
+        if Tout == 0:
+            continue
+        rows = torch.ones(B * Tout, ld, device="cuda")
+        hip.psd_gather(p2, ss, sl, nl, rows, B, T, T, Tout, V)
+        torch.testing.assert_close(rows.view(B, Tout, ld)[:, :, :V].cpu(), torch.from_numpy(z[f"c{c}_out"]), rtol=1e-5, atol=1e-7)
+
+
 # ------------------------------------------------------------------------------------------------ decode loop
 def test_decode_kernels(hip, fake):
     B, S, H, G, nb, ctx = 2, 40, 4, 2, 3, 64

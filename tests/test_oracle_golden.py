@@ -258,3 +258,14 @@ def test_merge_plan_random_batches_vs_reference(geo):
             assert np.array_equal(plan.labels, z[f"c{n}_merged_labels"]), n
         op = O.merge_plan(torch.from_numpy(ids), torch.from_numpy(am), torch.from_numpy(na), geo["speech_id"])
         assert np.array_equal(op["mask"].numpy(), mask) and np.array_equal(op["position_ids"].numpy(), pos), n
+
+
+def test_psd_random_batches_vs_reference():
+    """32 random batches of peaky posteriors through the REAL reference's psd() (oracle/make_golden_psd.py)."""
+    z = load_npz("psd_random")
+    for n in range(int(z["n_cases"])):
+        post, lens = torch.from_numpy(z[f"c{n}_posterior"]), torch.from_numpy(z[f"c{n}_lens"])
+        out, nl = O.psd(post, lens, post, 0)
+        assert np.array_equal(nl.numpy(), z[f"c{n}_new_lens"]), n
+        assert tuple(out.shape) == z[f"c{n}_out"].shape, n
+        close(out, z[f"c{n}_out"], rtol=1e-6, atol=1e-7)
