@@ -191,9 +191,12 @@ def test_generate_beam4_text_and_audio_vs_reference_tokens():
     assert (common >= 8).all(), (toks, z["tokens_audio"])
 
 
+@pytest.mark.parametrize("lpw,min_len", [(1.0, 1), (2.0, 1), (0.5, 4), (1.0, 6)])
 @pytest.mark.parametrize("nb", [1, 2, 3, 4])
-def test_beam_state_matches_oracle_on_random_scores(nb):
-    """Host beam bookkeeping vs the oracle's tensor formulation on a synthetic score stream with EOS events."""
+def test_beam_state_matches_oracle_on_random_scores(nb, lpw, min_len):
+    """Host beam bookkeeping vs the oracle's tensor formulation (the loop of oracle/tasu_oracle.py::beam_search_generate, which
+    tests/test_oracle_golden.py pins against the reference's generate() for these beam counts, length penalties and minimum
+    lengths) on a synthetic score stream with EOS events."""
     from ps_slm_amd.decode import BeamState
     B, V, T, eos = 3, 50, 12, 7
     g = torch.Generator().manual_seed(0)
@@ -206,7 +209,7 @@ def test_beam_state_matches_oracle_on_random_scores(nb):
     def logits_for(tokens, t):
         last = tokens[:, t - 1] if t > 0 else torch.zeros(tokens.shape[0], dtype=torch.long)
         return table[(last * 7 + t) % 64]
-    state = BeamState(B, nb, T, eos, eos, 1.0, 1)
+    state = BeamState(B, nb, T, eos, eos, lpw, min_len)
     while not state.done:
         t = state.cur
         seqs = torch.from_numpy(state.run_seq).view(B * nb, -1)
@@ -226,7 +229,7 @@ def test_beam_state_matches_oracle_on_random_scores(nb):
     cur = 0
     while True:
         lp = torch.log_softmax(logits_for(run_seq.view(B * nb, -1), cur), -1)
-        if cur < 1:
+        if cur < min_len:
             lp[:, eos] = float("-inf")
         acc = (lp.view(B, nb, V) + run_sc[:, :, None]).view(B, nb * V)
         top_lp, top_ix = torch.topk(acc, 2 * nb)
@@ -239,7 +242,7 @@ def test_beam_state_matches_oracle_on_random_scores(nb):
         run_seq = torch.gather(cand, 1, nxt[:, :, None].expand(-1, -1, T))
         run_sc = torch.gather(run_lp, 1, nxt)
         just = stop & (torch.arange(2 * nb) < nb)[None]
-        sc = top_lp / (cur + 1) + (~unsat).float() * NEG + (~just).float() * NEG
+        sc = top_lp / ((cur + 1) ** lpw) + (~unsat).float() * NEG + (~just).float() * NEG
         keep = torch.topk(torch.cat([fin_sc, sc], 1), nb)[1]
         fin_seq = torch.gather(torch.cat([fin_seq, cand], 1), 1, keep[:, :, None].expand(-1, -1, T))
         fin_len = torch.gather(torch.cat([fin_len, torch.full((B, 2 * nb), cur + 1)], 1), 1, keep)
@@ -247,7 +250,7 @@ def test_beam_state_matches_oracle_on_random_scores(nb):
         fin_sc = torch.gather(torch.cat([fin_sc, sc], 1), 1, keep)
         cur += 1
         worst = torch.where(is_fin, fin_sc.min(1, keepdim=True)[0], torch.full_like(fin_sc, NEG))
-        unsat = unsat & (run_sc[:, :1] / cur > worst).any(-1, keepdim=True)
+        unsat = unsat & (run_sc[:, :1] / (cur ** lpw) > worst).any(-1, keepdim=True)
         if not (bool(unsat.any()) and not bool(stop.all())):
             break
     ref = fin_seq[:, 0, : int(fin_len[:, 0].max())].numpy()

@@ -269,3 +269,20 @@ def test_psd_random_batches_vs_reference():
         assert np.array_equal(nl.numpy(), z[f"c{n}_new_lens"]), n
         assert tuple(out.shape) == z[f"c{n}_out"].shape, n
         close(out, z[f"c{n}_out"], rtol=1e-6, atol=1e-7)
+
+
+def test_generate_random_cases_vs_reference(geo, tiny_weights):
+    """14 decode cases of the REAL reference's generate() (oracle/make_golden_generate.py): 1-3 left-padded utterances,
+    1-4 beams, several max_new_tokens / min_length / length_penalty settings -- token ids must be identical."""
+    from conftest import split_flat
+    z = load_npz("generate_random")
+    for n in range(int(z["n_cases"])):
+        ids, am = torch.from_numpy(z[f"c{n}_input_ids"]), torch.from_numpy(z[f"c{n}_attention_mask"])
+        post_ids = split_flat(z[f"c{n}_post_ids_flat"], z[f"c{n}_post_lens"])
+        nb, new, min_len = (int(v) for v in z[f"c{n}_kw"])
+        post, plen = O.pseudo_posterior(post_ids, geo["ctc_vocab"])
+        proj = O.projector(tiny_weights, post)
+        emb, mask, _, _ = O.merge(proj, plen, tiny_weights["llm.model.embed_tokens.weight"][ids], ids, am, None, geo["speech_id"])
+        toks = O.beam_search_generate(tiny_weights, emb, mask, geo, num_beams=nb, max_new_tokens=new, min_length=min_len,
+                                      length_penalty=float(z[f"c{n}_length_penalty"]))
+        assert np.array_equal(toks.numpy(), z[f"c{n}_tokens"]), (n, toks, z[f"c{n}_tokens"])
