@@ -399,3 +399,39 @@ def test_generate_other_beam_counts_match_bf16_oracle(nb):
     n = min(toks.shape[1], ref16.shape[1])
     common = (toks[:, :n] == ref16[:, :n]).cumprod(1).sum(1)
     assert (common >= 3).all() and (common == n).any(), (toks, ref16)
+
+
+def test_cps_noise_draws_and_posterior_vs_reference():
+    """12 seeded calls of the REAL reference's ctc_pseudo_posterior_noise (oracle/make_golden_noise.py): from the same torch
+    seed the plugin's draw_noise must make the same draws in the same order, and the posterior built from them (oracle
+    arithmetic and the product's posterior kernel through the CPU double) must equal the reference's."""
+    from conftest import load_npz, split_flat
+    from ps_slm_amd.config import ModelConfig, TrainConfig
+    from ps_slm_amd.ps_slm import model_factory
+    z = load_npz("cps_noise_random")
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=True, ctc_posterior=True, do_psd=True)
+    mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+    model, _ = model_factory(tc, mc, device="cpu", ops=FakeOps(), init_seed=3)
+    core, V = model.core, int(load_npz("geometry")["ctc_vocab"])
+    for n in range(int(z["n_cases"])):
+        ids = [list(map(int, p)) for p in split_flat(z[f"c{n}_ids_flat"], z[f"c{n}_ids_lens"])]
+        model.drop_prob, model.smooth_low, model.smooth_high = (float(v) for v in z[f"c{n}_params"])
+        torch.manual_seed(int(z[f"c{n}_seed"]))
+        alphas, keeps = model.draw_noise(ids)
+        post, lens = O.pseudo_posterior(ids, V, alphas, keeps)
+        assert np.array_equal(lens.numpy(), z[f"c{n}_lens"]), n
+        torch.testing.assert_close(post, torch.from_numpy(z[f"c{n}_posterior"]), rtol=1e-6, atol=1e-8)
+        # the product's posterior rows (kernel semantics through the CPU double) at the mid geometry's vocabulary: same ids
+        # (all < 203), same draws -> the same rows up to the 1 / V smoothing floor, checked through the argmax and the peak
+        B, Lmax = len(ids), int(lens.max())
+        tok = torch.full((B, 3), 5, dtype=torch.long)
+        tok[:, 1] = core.geo.speech_id
+        st = core.prepare_text(tok, torch.ones(B, 3, dtype=torch.bool), None, ids, alphas, keeps)
+        core.forward_projector_text(st)
+        rows = st.dev["post"][: B * Lmax].view(B, Lmax, -1)[:, :, : core.geo.ctc_vocab].float()
+        ref = torch.from_numpy(z[f"c{n}_posterior"])
+        live = torch.arange(Lmax)[None, :] < lens[:, None]
+        assert torch.equal(rows.argmax(-1)[live], ref.argmax(-1)[live]), n
+        a = torch.tensor(alphas)[:, None].expand(-1, Lmax)[live]
+        torch.testing.assert_close(rows.max(-1).values[live], (1 - a) + a / core.geo.ctc_vocab, rtol=1e-6, atol=1e-7)
+        assert float(rows[~live].abs().max()) == 0.0 if (~live).any() else True
