@@ -202,6 +202,27 @@ def test_generate_beam4_on_gpu():
         assert ((g == r).cumprod(1).sum(1) >= 8).all(), (path, g, r)
 
 
+@pytest.mark.parametrize("nb,min_len,lpw", [(2, 6, 2.0), (3, 4, 0.5), (1, 1, 1.0)])
+def test_generate_other_settings_on_gpu(setup, nb, min_len, lpw):
+    """Other beam counts, a minimum length (EOS banned in the log-prob/top-k kernel for the first positions) and length
+    penalties: GPU decode vs the same host code on the CPU double (common prefix >= 6 on every row, equal on most)."""
+    from ps_slm_amd.decode import beam_search_generate
+    geo, sd, gm, cm = setup
+    batch = synthetic_text_batch(geo, 4, seed=17, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12, noise=False)
+    ids, am = batch["input_ids"][:, :9], batch["attention_mask"][:, :9]
+    outs = []
+    for m in (gm, cm):
+        st = m.prepare_text(ids, am, None, batch["post_ids"], None, None)
+        m.forward_projector_text(st)
+        outs.append(beam_search_generate(m, st, num_beams=nb, max_new_tokens=12, min_length=min_len, length_penalty=lpw).numpy())
+    g, c = outs
+    n = min(g.shape[1], c.shape[1])
+    assert n >= min_len
+    common = (g[:, :n] == c[:, :n]).cumprod(1).sum(1)
+    assert (common >= min(6, n)).all() and (common == n).mean() >= 0.5, (g, c)
+    assert not (g[:, : min_len - 1] == geo.eos_id).any()          # EOS cannot appear before min_length
+
+
 def test_generate_more_than_64_beams_rows(setup):
     """20 utterances x 4 beams = 80 rows: the weight-streaming kernels run in two row chunks (64 + 16).  Row arithmetic does
     not depend on the batch a row sits in, so the tokens must be EXACTLY those of the same utterances decoded ten at a time
