@@ -77,6 +77,21 @@ def test_encoder_ragged(geo, tiny_weights):
     close(post, z["ctc_posterior"], **FP32_TOL)
 
 
+def test_encoder_random_batches_vs_reference(geo, tiny_weights):
+    """8 random ragged batches through the REAL reference's SANM encoder + CTC head (oracle/make_golden_encoder.py): frame counts
+    below, at and above the FSMN kernel width.  Rows beyond an utterance's length are padding in both and are not compared."""
+    z = load_npz("encoder_random")
+    for n in range(int(z["n_cases"])):
+        speech, slen = torch.from_numpy(z[f"c{n}_speech"]), torch.from_numpy(z[f"c{n}_speech_lengths"])
+        enc, olens = O.sensevoice_encoder(tiny_weights, speech, slen, geo["enc_heads"], geo["enc_kernel"])
+        assert np.array_equal(olens.numpy(), z[f"c{n}_olens"]), n
+        post = torch.softmax(O.linear(enc, tiny_weights["encoder.ctc.ctc_lo.weight"], tiny_weights["encoder.ctc.ctc_lo.bias"], "fp32"), -1)
+        for b in range(speech.shape[0]):
+            L = int(olens[b])
+            close(enc[b, :L], z[f"c{n}_enc_out"][b, :L], **FP32_TOL)
+            close(post[b, :L], z[f"c{n}_ctc_posterior"][b, :L], **FP32_TOL)
+
+
 def test_psd_crafted():
     z = load_npz("psd_crafted")
     post = torch.from_numpy(z["posterior"])
