@@ -28,6 +28,22 @@ def test_text_forward_backward_fp32(case, geo, tiny_weights):
         close(g, z["grad." + k[len("encoder_projector."):]], rtol=2e-4, atol=1e-6)
 
 
+def test_text_forward_backward_random_batches_vs_reference(geo, tiny_weights):
+    """8 random text-only batches through the REAL reference's forward + backward (oracle/make_golden_text_random.py)."""
+    from conftest import split_flat
+    z = load_npz("text_random")
+    for n in range(int(z["n_cases"])):
+        b = {k: torch.from_numpy(z[f"c{n}_{k}"]) for k in ("input_ids", "attention_mask", "labels")}
+        b["post_ids"] = split_flat(z[f"c{n}_post_ids_flat"], z[f"c{n}_post_lens"])
+        out, grads = O.loss_and_projector_grads(tiny_weights, b, geo, "fp32")
+        close(out["loss"], z[f"c{n}_loss"], rtol=1e-5, atol=1e-6)
+        close(out["acc"], z[f"c{n}_acc"], rtol=0, atol=1e-7)
+        valid = out["mask"]
+        close(out["logits"][valid], torch.from_numpy(z[f"c{n}_logits"])[valid], **FP32_TOL)
+        for k, g in grads.items():
+            close(g, z[f"c{n}_grad." + k[len("encoder_projector."):]], rtol=2e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("case", ["text_clean_right", "text_clean_left"])
 def test_merge_plan(case, geo, tiny_weights):
     b, z = golden_batch(case)
