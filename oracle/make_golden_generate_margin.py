@@ -1,0 +1,123 @@
+"""TEST INFRASTRUCTURE ONLY -- tests/golden/mid_generate_margin.npz: 14 decode cases at the kernel-compatible "mid"
+geometry whose beam-search decisions do not hinge on rounding noise, so that token ids can be compared EXACTLY between the
+REAL reference's ``generate`` (fp32), the bf16-mode oracle, the CPU double and the HIP decode path.
+
+A seeded random-init decoder is full of near-ties (its bf16 logits carry 8 significant bits), which any two bf16 evaluations
+of the same network resolve differently; comparing tokens over such a case tests luck, not arithmetic.  This generator
+draws prompts until a case is STABLE, i.e.
+  * the REAL reference's fp32 tokens equal the bf16-mode oracle's (rounding every operand to bf16 moved no decision),
+  * the tokens survive N_JITTER runs of the bf16 oracle with random one-ulp flips on 15 % of every step's logits
+    (oracle.tasu_oracle.bf16_ulp_jitter: the kind of difference a different accumulation order produces, several times
+    more frequent), and
+  * the product's host code on the CPU double (KV cache, per-row top-k, beam bookkeeping; tests/fake_ops.py) agrees.
+Only prompts and the reference's tokens are stored; the weights are regenerated from the seed by the tests
+(ps_slm_amd.synthetic.decode_fixture_state_dict).  The 14 settings are those of oracle/make_golden_generate.py (1-4 beams,
+max_new_tokens, min_length, length_penalty).  Run in the build container only:
+    python oracle/make_golden_generate_margin.py"""
+import dataclasses
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import tasu_oracle as O  # noqa: E402
+from oracle.make_golden import quiet  # noqa: E402
+from oracle.ref_import import build_reference_model  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "mid_generate_margin.npz")
+SEED_W = 4242
+N_JITTER = 6
+PLANS = [dict(num_beams=4, max_new_tokens=12), dict(num_beams=4, max_new_tokens=5), dict(num_beams=2, max_new_tokens=9),
+         dict(num_beams=3, max_new_tokens=7, length_penalty=2.0), dict(num_beams=1, max_new_tokens=8),
+         dict(num_beams=4, max_new_tokens=10, min_length=6), dict(num_beams=4, max_new_tokens=6, length_penalty=0.5)]
+
+
+def make_case(geo, rng):
+    sp, eos = geo.speech_id, geo.eos_id
+    B = int(rng.integers(1, 4))
+    rows = [rng.integers(0, 900, int(rng.integers(2, 9))).tolist() + [sp] + rng.integers(0, 900, int(rng.integers(0, 4))).tolist()
+            for _ in range(B)]
+    L = max(len(r) for r in rows)
+    ids = torch.tensor([[eos] * (L - len(r)) + r for r in rows])
+    am = torch.tensor([[0] * (L - len(r)) + [1] * len(r) for r in rows]).bool()
+    letters = list("abcdefghijklmnopqrstuvwxyz")
+    targets = [" ".join("".join(rng.choice(letters, int(rng.integers(1, 5)))) for _ in range(int(rng.integers(2, 12))))
+               for _ in range(B)]
+    return ids, am, targets
+
+
+def main():
+    from fake_ops import FakeOps
+    from ps_slm_amd.decode import beam_search_generate
+    from ps_slm_amd.model import Geometry, TasuModel
+    from ps_slm_amd.synthetic import MID_GEOMETRY, decode_fixture_state_dict
+
+    torch.set_num_threads(4)
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    gd = dataclasses.asdict(geo)
+    sd = decode_fixture_state_dict(geo, SEED_W)
+    model = build_reference_model(gd, 0, dict(gt_emb=True, gt_emb_noise=False))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    # the frozen encoder keeps its own init: the text branch never reads it (ps-slm.py:590-598)
+    assert not unexpected and all(k.startswith("encoder.") or k == "llm.lm_head.weight" for k in missing), (missing, unexpected)
+    model.eval()
+    double = TasuModel(geo, FakeOps(), "cpu")
+    double.load_reference_state_dict(sd)
+    arrs, n, tried = {}, 0, 0
+    for case in range(14):
+        kw = PLANS[case % len(PLANS)]
+        nb, new = kw.get("num_beams", 4), kw["max_new_tokens"]
+        okw = dict(num_beams=nb, max_new_tokens=new, min_length=kw.get("min_length", 1),
+                   length_penalty=kw.get("length_penalty", 1.0))
+        seed = 1000 * case
+        while True:
+            seed += 1
+            tried += 1
+            rng = np.random.default_rng(seed)
+            ids, am, targets = make_case(geo, rng)
+            post_ids = [model.encoder_tokenizer.encode(t) for t in targets]      # lower-case letters pass ps-slm.py:592-596
+            post, plen = O.pseudo_posterior(post_ids, geo.ctc_vocab)
+            emb, mask, _, _ = O.merge(O.projector(sd, post, "bf16"), plen, sd["llm.model.embed_tokens.weight"][ids], ids, am,
+                                      None, geo.speech_id)
+            emb = emb.detach()
+            t16 = O.beam_search_generate(sd, emb, mask, gd, mode="bf16", **okw)
+            if case % 2 == 1 and not (t16 == geo.eos_id).any():
+                continue                                                     # every other case must see a beam finish early
+            with torch.no_grad():
+                toks = quiet(model.generate, input_ids=ids, input_features=torch.zeros(len(post_ids), 8, geo.feat_dim),
+                             attention_mask=am, input_feature_length=torch.full((len(post_ids),), 8), targets=targets, **kw)
+            if toks.shape != t16.shape or not torch.equal(toks, t16):
+                continue
+            stable = True
+            for j in range(N_JITTER):
+                tj = O.beam_search_generate(sd, emb, mask, gd, mode="bf16", logit_jitter=O.bf16_ulp_jitter(100 * seed + j), **okw)
+                if tj.shape != t16.shape or not torch.equal(tj, t16):
+                    stable = False
+                    break
+            if not stable:
+                continue
+            st = double.prepare_text(ids, am, None, post_ids, None, None)
+            double.forward_projector_text(st)
+            tc = beam_search_generate(double, st, eos_token_id=geo.eos_id, pad_token_id=geo.eos_id, **okw)
+            if tc.shape != t16.shape or not torch.equal(tc, t16):
+                continue
+            break
+        arrs.update({f"c{n}_input_ids": ids.numpy(), f"c{n}_attention_mask": am.numpy(), f"c{n}_tokens": toks.numpy(),
+                     f"c{n}_post_ids_flat": np.concatenate([np.asarray(p) for p in post_ids]),
+                     f"c{n}_post_lens": np.asarray([len(p) for p in post_ids]),
+                     f"c{n}_kw": np.asarray([nb, new, kw.get("min_length", 1)]),
+                     f"c{n}_length_penalty": np.asarray(kw.get("length_penalty", 1.0)), f"c{n}_seed": np.asarray(seed)})
+        print(f"case {n}: seed {seed} B={ids.shape[0]} nb={nb} new={new} tokens {toks.tolist()}", flush=True)
+        n += 1
+    arrs["n_cases"] = np.asarray(n)
+    arrs["seed_w"] = np.asarray(SEED_W)
+    np.savez_compressed(OUT, **arrs)
+    print(n, "cases,", tried, "prompts tried;", f"{os.path.getsize(OUT) / 1024:.1f} KB")
+
+
+if __name__ == "__main__":
+    main()

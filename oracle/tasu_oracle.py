@@ -436,15 +436,32 @@ def lr_for_optimizer_step(k, base_lr, **kw):
 
 
 # ----------------------------------------------------------------------------- decode: beam search
+def bf16_ulp_jitter(seed, prob=0.15):
+    """Returns a ``logit_jitter`` for beam_search_generate: each logit moves by +-1 bf16 ulp with probability ``prob`` (two
+    bf16 evaluations of one network differ like this wherever an fp32 sum sits next to a rounding boundary, at a few
+    per cent of the logits)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def jitter(logits):
+        ulp = torch.exp2(torch.floor(torch.log2(logits.abs().clamp_min(1e-30))) - 7)
+        flip = (torch.rand(logits.shape, generator=g) < prob).float() * (torch.randint(0, 2, logits.shape, generator=g) * 2 - 1)
+        return logits + flip * ulp
+    return jitter
+
+
 def beam_search_generate(W, emb, mask, geo, num_beams=4, max_new_tokens=200, min_length=1, length_penalty=1.0,
-                         eos_token_id=None, pad_token_id=None, mode="fp32"):
+                         eos_token_id=None, pad_token_id=None, mode="fp32", logit_jitter=None):
     """slam_model_asr.generate's decode loop (Multitask/model/ps-slm.py:660-675): HF ``generate(inputs_embeds=...,
     num_beams=4, do_sample=False, early_stopping=False)`` restated (transformers generation/utils.py ``_beam_search``,
     un-vendored dependency): every step keeps the 2*num_beams best continuations, the first num_beams non-finished
     ones keep running, finished ones (EOS or max length) among the top num_beams compete for the num_beams result
     slots with score / (generated_length ** length_penalty); the loop ends when no running beam can beat the worst
     kept result (heuristic on the current length) or every continuation hit a stopping criterion.  No KV cache here:
-    the whole sequence is re-run every step (CPU oracle, tiny sizes).  Returns new tokens only, [B, n_new]."""
+    the whole sequence is re-run every step (CPU oracle, tiny sizes).  Returns new tokens only, [B, n_new].
+
+    ``logit_jitter`` (optional callable logits -> logits) perturbs every step's logits; the fixture generator
+    oracle/make_golden_generate_margin.py uses it to keep only decode cases whose tokens survive random one-ulp flips of the
+    bf16 logits (``bf16_ulp_jitter``), i.e. cases without near-ties."""
     B, S, D = emb.shape
     nb, V = num_beams, lm_head_weight(W).shape[0]
     eos = geo["eos_id"] if eos_token_id is None else eos_token_id
@@ -471,6 +488,8 @@ def beam_search_generate(W, emb, mask, geo, num_beams=4, max_new_tokens=200, min
         pos = (m.long().cumsum(-1) - 1).masked_fill(~m, 1)
         hid = qwen2_hidden(W, x, m, pos, geo["llm_heads"], geo["llm_kv_heads"], geo.get("rope_theta", 1e6), mode)
         logits = linear(hid[:, -1], lm_head_weight(W), None, mode).float()
+        if logit_jitter is not None:
+            logits = logit_jitter(logits)
         logp = torch.log_softmax(logits, -1)
         if cur < min_length:
             logp[:, eos] = float("-inf")

@@ -29,10 +29,12 @@ __device__ __forceinline__ Stat combine(Stat a, Stat b) {
   return o;
 }
 
-__global__ __launch_bounds__(256) void ce_kernel(const bf16* __restrict__ logits, int ldv,
+// logits and dlogits may be the SAME buffer (include/tasu_hip.h; the training step overwrites the logits in place), so
+// neither is __restrict__ and every read of a row element that pass 2 may overwrite happens before the block barrier.
+__global__ __launch_bounds__(256) void ce_kernel(const bf16* logits, int ldv,
                                                  const int32_t* __restrict__ labels, int V, float* __restrict__ row_loss,
                                                  int32_t* __restrict__ row_hit, int32_t* __restrict__ row_argmax,
-                                                 bf16* __restrict__ dlogits, const float* __restrict__ inv_count) {
+                                                 bf16* dlogits, const float* __restrict__ inv_count) {
   __shared__ Stat red[4];
   const int row = blockIdx.x;
   const int label = labels[row];
@@ -91,6 +93,9 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16* __restrict__ logits
     other.arg = __shfl_xor(st.arg, o, 64);
     st = combine(st, other);
   }
+  // the label's logit is read BEFORE the barrier: with dlogits aliasing logits, other waves start overwriting the row
+  // (pass 2) as soon as they have passed it
+  const float label_logit = (threadIdx.x == 0 && !ignored) ? (float)lr[label] : 0.f;
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = st;
   __syncthreads();
   st = combine(combine(red[0], red[1]), combine(red[2], red[3]));
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16* __restrict__ logits
       row_loss[row] = 0.f;
       row_hit[row] = 0;
     } else {
-      row_loss[row] = lse - (float)lr[label];
+      row_loss[row] = lse - label_logit;
       row_hit[row] = st.arg == label ? 1 : 0;
     }
   }

@@ -84,6 +84,17 @@ def random_state_dict(geo: Geometry, seed: int, with_encoder=True, scale=0.05):
     return sd
 
 
+def decode_fixture_state_dict(geo: Geometry, seed: int, eos_boost=2.5):
+    """Weights of the decode fixtures whose token ids are compared exactly (oracle/make_golden_generate_margin.py,
+    tests/golden/mid_generate_margin.npz): ``random_state_dict`` without the encoder, with the EOS row of the embedding /
+    lm_head table scaled up so that beams do finish inside a dozen positions (a random-init head almost never emits EOS)."""
+    sd = random_state_dict(geo, seed, with_encoder=False)
+    for key in ("llm.model.embed_tokens.weight", "llm.lm_head.weight"):
+        if key in sd:
+            sd[key][geo.eos_id] *= eos_boost
+    return sd
+
+
 def synthetic_text_batch(geo: Geometry, B, seed, prompt_len=25, n_audio=104, target_len=128, speech_pos=12,
                          feat_frames=500, noise=True, drop_prob=0.0, ragged=False):
     """One fixed-length (or ragged, for tests) text-only batch in the collator's schema

@@ -70,3 +70,23 @@ def mid_audio_psd_case():
     batch["input_features"] = torch.from_numpy(z["input_features"]).float()
     batch["input_feature_length"] = torch.from_numpy(z["input_feature_length"])
     return geo, sd, batch, z
+
+
+def decode_margin_cases():
+    """(geo, state dict, cases) of tests/golden/mid_generate_margin.npz (oracle/make_golden_generate_margin.py): decode cases
+    whose beam-search decisions are stable under bf16 rounding noise, so token ids are compared EXACTLY.  Each case:
+    dict(ids, am, post_ids, kw, tokens) with kw = generate() keyword arguments and tokens = the REAL reference's output."""
+    from ps_slm_amd.model import Geometry
+    from ps_slm_amd.synthetic import MID_GEOMETRY, decode_fixture_state_dict
+
+    z = load_npz("mid_generate_margin")
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    sd = decode_fixture_state_dict(geo, int(z["seed_w"]))
+    cases = []
+    for n in range(int(z["n_cases"])):
+        nb, new, min_len = (int(v) for v in z[f"c{n}_kw"])
+        cases.append(dict(ids=torch.from_numpy(z[f"c{n}_input_ids"]), am=torch.from_numpy(z[f"c{n}_attention_mask"]),
+                          post_ids=split_flat(z[f"c{n}_post_ids_flat"], z[f"c{n}_post_lens"]), tokens=z[f"c{n}_tokens"],
+                          kw=dict(num_beams=nb, max_new_tokens=new, min_length=min_len,
+                                  length_penalty=float(z[f"c{n}_length_penalty"]))))
+    return geo, sd, cases

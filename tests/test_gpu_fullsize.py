@@ -1,11 +1,14 @@
-"""Parity at BASELINE.json's FULL sizes (Qwen2.5-1.5B geometry, CTC vocabulary 25,055, S = 256), where the CPU oracle
-would take minutes per step: size-independent properties of the path instead of a second implementation.
+"""Parity at BASELINE.json's FULL sizes (Qwen2.5-1.5B geometry of configs 2-4 and Qwen2.5-7B geometry of config 5, CTC
+vocabulary 25,055, S = 256; the full 50 + 20-layer SenseVoiceSmall encoder at 504 frames), where the CPU oracle would take
+minutes per step: size-independent properties of the path instead of a second implementation.
 
   * every decoder / lm_head / projector GEMM shape of the benchmark step against rocBLAS (torch.matmul) on the same bits;
   * the fused CE kernel at V = 151,936 against fp32 log-softmax of the very logits it consumed (loss, accuracy, dlogits);
   * run-to-run determinism of loss and gradients (bitwise);
   * the analytic projector gradient against a central finite difference of the loss along the gradient direction;
   * batch-permutation invariance and padding invariance of loss and gradients (ragged batch vs each utterance alone).
+
+  * the full-size SANM encoder: a ragged batch equals every utterance alone, PSD lengths are exact.
 
 Random-init weights of the real architecture (no checkpoint exists on the GPU box); inputs are seeded.
 """
@@ -23,13 +26,25 @@ pytestmark = pytest.mark.gpu
 BF, F32 = torch.bfloat16, torch.float32
 
 
+_MODELS = {}
+
+
+def full_model(name):
+    """One full-geometry model at a time on the device (the 7B one holds 2 x 15 GB of bf16 weights)."""
+    from ps_slm_amd.ops import HipOps
+    if name not in _MODELS:
+        _MODELS.clear()
+        torch.cuda.empty_cache()
+        geo = Geometry.qwen25_1p5b() if name == "1.5b" else Geometry.qwen25_7b()
+        m = TasuModel(geo, HipOps(), "cuda", keep_logits=True)
+        m.init_random(seed=4321)
+        _MODELS[name] = (geo, m)
+    return _MODELS[name]
+
+
 @pytest.fixture(scope="module")
 def full():
-    from ps_slm_amd.ops import HipOps
-    geo = Geometry.qwen25_1p5b()
-    m = TasuModel(geo, HipOps(), "cuda", keep_logits=True)
-    m.init_random(seed=4321)
-    return geo, m
+    return full_model("1.5b")
 
 
 def step(m, batch, backward=True):
@@ -64,7 +79,14 @@ FULL_SHAPES = [("qkv", M_TOK, 2048, 1536), ("o", M_TOK, 1536, 1536), ("gate_up",
                ("wgrad2", 1536, 2048, 1664), ("d_proj1", 1664, 25088, 2048)]
 
 
-@pytest.mark.parametrize("name,M,N,K", FULL_SHAPES, ids=[s[0] for s in FULL_SHAPES])
+# Qwen2.5-7B (config 5): hidden 3584, 28 q / 4 kv heads, intermediate 18944, untied lm_head over 152064 ids
+SHAPES_7B = [("7b_qkv", M_TOK, 4608, 3584), ("7b_o", M_TOK, 3584, 3584), ("7b_gate_up", M_TOK, 37888, 3584),
+             ("7b_down", M_TOK, 3584, 18944), ("7b_d_down", M_TOK, 18944, 3584), ("7b_d_gate_up", M_TOK, 3584, 37888),
+             ("7b_d_qkv", M_TOK, 3584, 4608), ("7b_lm_head", M_TOK, 152064, 3584), ("7b_d_lm_head", M_TOK, 3584, 152064),
+             ("7b_proj2", 1664, 3584, 2048), ("7b_wgrad2", 3584, 2048, 1664), ("7b_d_proj2", 1664, 2048, 3584)]
+
+
+@pytest.mark.parametrize("name,M,N,K", FULL_SHAPES + SHAPES_7B, ids=[s[0] for s in FULL_SHAPES + SHAPES_7B])
 def test_benchmark_gemm_shapes_vs_rocblas(full, name, M, N, K):
     _, m = full
     g = torch.Generator(device="cuda").manual_seed(zlib.crc32(name.encode()) % 1000)
@@ -86,8 +108,9 @@ def test_benchmark_gemm_shapes_vs_rocblas(full, name, M, N, K):
 
 
 # ------------------------------------------------------------------------------------------------ whole step
-def test_full_size_step_properties(full):
-    geo, m = full
+@pytest.mark.parametrize("size", ["1.5b", "7b"])
+def test_full_size_step_properties(size):
+    geo, m = full_model(size)
     batch = synthetic_text_batch(geo, 4, seed=99, noise=True, drop_prob=0.1, ragged=True)
     st = step(m, batch)
     loss = st.dev["loss_out"].clone()
@@ -155,3 +178,59 @@ def test_full_size_step_properties(full):
     cos = float(torch.nn.functional.cosine_similarity(gsum.flatten(), g.flatten(), dim=0))
     # two bf16 evaluations of the same gradient through 28 layers differ by ~3 % (rounding of dlogits / count differs)
     assert cos > 0.998 and float((gsum - g).norm() / g.norm()) < 5e-2
+
+
+# ------------------------------------------------------------------------------------------------ full-size encoder
+def test_full_size_encoder_batch_equals_single_utterances():
+    """SenseVoiceSmall at its published geometry (50 + 20 SANM layers, 4 x 128 heads, FSMN kernel 11, CTC vocabulary 25,055),
+    500 + 4 frames, ragged lengths: every utterance's CTC posterior inside the padded batch must equal the posterior of that
+    utterance run alone (key-padding mask, FSMN masking and row-independent GEMMs leave no cross-utterance path), rows are
+    probability vectors, and the PSD lengths of the device kernels equal the oracle's PSD of the same posterior exactly."""
+    from oracle import tasu_oracle as O
+    from ps_slm_amd.encoder import encoder_posterior, psd_on_device
+    from ps_slm_amd.ops import HipOps
+    _MODELS.clear()
+    torch.cuda.empty_cache()
+    geo = Geometry.qwen25_1p5b()
+    geo.llm_layers = 0                                   # encoder-only test: no decoder weights
+    m = TasuModel(geo, HipOps(), "cuda")
+    from ps_slm_amd.encoder import EncoderWeights
+    from ps_slm_amd.synthetic import random_state_dict
+    sd = {k: v for k, v in random_state_dict(geo, 77, with_encoder=True).items() if k.startswith("encoder.")}
+    # a peaky head with a strong blank, so that PSD merges runs and drops blank frames (a flat random posterior keeps all)
+    g = torch.Generator().manual_seed(3)
+    sd["encoder.ctc.ctc_lo.weight"] = sd["encoder.ctc.ctc_lo.weight"] * 6.0
+    bias = torch.zeros(geo.ctc_vocab)
+    bias[geo.blank_id] = 4.0
+    sd["encoder.ctc.ctc_lo.bias"] = bias
+    m.encoder = EncoderWeights(geo, m.device)
+    m.encoder.load_reference_state_dict(sd)
+    T, lens = 500, [500, 377, 123]
+    feats = torch.randn(3, T, geo.feat_dim, generator=g).half().float()
+    for b, n in enumerate(lens):
+        feats[b, n:] = 0
+    V, Te = geo.ctc_vocab, T + 4
+    post, _, _ = encoder_posterior(m, feats, torch.tensor(lens))
+    torch.cuda.synchronize()
+    post = post.view(3, Te, -1)[:, :, :V].clone()
+    fl_dev = m._upload("feat_lens", np.asarray(lens, dtype=np.int32))
+    _, new_lens, _ = psd_on_device(m, m._buf("enc_post", (3 * Te, (V + 63) // 64 * 64), F32), 3, T, Te, fl_dev, True)
+    # rows are probability vectors
+    for b, n in enumerate(lens):
+        rows = post[b, : n + 4]
+        assert torch.isfinite(rows).all() and float(rows.min()) >= 0.0
+        assert float((rows.sum(-1) - 1).abs().max()) < 1e-4
+    # PSD lengths: device kernels vs the oracle's PSD (restates ps-slm.py:237-317) on the same posterior
+    body = post[:, 4:].cpu()
+    _, want_lens = O.psd(body, torch.tensor(lens), body)
+    assert np.array_equal(new_lens, want_lens.numpy()), (new_lens, want_lens)
+    assert (new_lens < np.asarray(lens)).all() and (new_lens > 0).all()      # merging / blank filtering really happened
+    # each utterance alone (no padding, own T) gives the same rows
+    for b, n in enumerate(lens):
+        alone, _, _ = encoder_posterior(m, feats[b:b + 1, :n], torch.tensor([n]))
+        torch.cuda.synchronize()
+        alone = alone.view(1, n + 4, -1)[0, :, :V]
+        diff = float((alone - post[b, : n + 4]).abs().max())
+        assert diff < 2e-3, (b, diff)                                        # probabilities; bf16 activations inside
+        same_arg = (alone.argmax(-1) == post[b, : n + 4].argmax(-1)).float().mean()
+        assert float(same_arg) > 0.995, (b, float(same_arg))

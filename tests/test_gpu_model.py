@@ -202,6 +202,27 @@ def test_generate_beam4_on_gpu():
         assert ((g == r).cumprod(1).sum(1) >= 8).all(), (path, g, r)
 
 
+def test_generate_margin_cases_exact_on_gpu():
+    """Token ids are index work: on the 14 rounding-stable decode cases of tests/golden/mid_generate_margin.npz (1-4 beams,
+    min_length, length penalties, left padding, EOS events; oracle/make_golden_generate_margin.py) the HIP decode path must
+    EQUAL the REAL reference's generate() tokens -- which the bf16 oracle and the CPU double also reproduce exactly
+    (tests/test_oracle_golden.py, tests/test_host_model_cpu.py)."""
+    from conftest import decode_margin_cases
+    from ps_slm_amd.decode import beam_search_generate
+    from ps_slm_amd.ops import HipOps
+    geo, sd, cases = decode_margin_cases()
+    gm = TasuModel(geo, HipOps(), "cuda")
+    gm.load_reference_state_dict(sd)
+    bad = []
+    for n, c in enumerate(cases):
+        st = gm.prepare_text(c["ids"], c["am"], None, c["post_ids"], None, None)
+        gm.forward_projector_text(st)
+        toks = beam_search_generate(gm, st, eos_token_id=geo.eos_id, pad_token_id=geo.eos_id, **c["kw"]).numpy()
+        if toks.shape != c["tokens"].shape or not np.array_equal(toks, c["tokens"]):
+            bad.append((n, toks.tolist(), c["tokens"].tolist()))
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("nb,min_len,lpw", [(2, 6, 2.0), (3, 4, 0.5), (1, 1, 1.0)])
 def test_generate_other_settings_on_gpu(setup, nb, min_len, lpw):
     """Other beam counts, a minimum length (EOS banned in the log-prob/top-k kernel for the first positions) and length

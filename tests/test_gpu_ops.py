@@ -334,6 +334,28 @@ def test_cross_entropy(hip, fake, M, V, ldv):
     assert rel_err(og, oc) < 1e-5
 
 
+def test_cross_entropy_in_place(hip, fake):
+    """dlogits aliasing logits (what the training step does with keep_logits=False, ps_slm_amd/model.py): row_loss must still be
+    lse - logit[label] -- the label's logit is read before any wave overwrites the row -- and the gradient must equal the
+    two-buffer result.  4096 rows x 5 launches so that a lost race would show."""
+    M, V, ldv = 4096, 1000, 1024
+    lg = torch.zeros(M, ldv, dtype=BF)
+    lg[:, :V] = randn(M, V, dtype=BF, seed=11, scale=3.0)
+    lab = torch.randint(V - 64, V, (M,), dtype=I32)             # labels in the LAST chunk of the row: pass 2 reaches them late,
+    lab[::2] = torch.randint(0, 64, (M // 2,), dtype=I32)        # and in the first chunk: pass 2 rewrites them first
+    lab[::5] = -100
+    inv = torch.tensor([1.0 / float((lab >= 0).sum())])
+    want_l, want_h, want_d = torch.zeros(M), torch.zeros(M, dtype=I32), torch.zeros(M, ldv, dtype=BF)
+    fake.ce_fwd_bwd(lg.clone(), lab, M, V, want_l, want_h, None, want_d, inv)
+    for _ in range(5):
+        buf, rl, rh = lg.cuda(), torch.zeros(M, device="cuda"), torch.zeros(M, dtype=I32, device="cuda")
+        hip.ce_fwd_bwd(buf, lab.cuda(), M, V, rl, rh, None, buf, inv.cuda())
+        torch.cuda.synchronize()
+        assert float((rl.cpu() - want_l).abs().max()) < 1e-3 * float(want_l.abs().max())
+        assert torch.equal(rh.cpu(), want_h)
+        assert rel_err(buf, want_d) < 1e-2
+
+
 # ------------------------------------------------------------------------------------------------ front end
 def test_posterior_merge_adamw(hip, fake):
     R, V, ld = 40, 203, 256

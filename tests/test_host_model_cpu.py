@@ -435,3 +435,17 @@ def test_cps_noise_draws_and_posterior_vs_reference():
         a = torch.tensor(alphas)[:, None].expand(-1, Lmax)[live]
         torch.testing.assert_close(rows.max(-1).values[live], (1 - a) + a / core.geo.ctc_vocab, rtol=1e-6, atol=1e-7)
         assert float(rows[~live].abs().max()) == 0.0 if (~live).any() else True
+
+
+def test_generate_margin_cases_exact_on_the_double():
+    """Product decode loop (prefill, KV cache + row index, per-row top-k, beam bookkeeping) on the CPU double against the REAL
+    reference's tokens on the 14 rounding-stable cases of tests/golden/mid_generate_margin.npz: exact equality."""
+    from conftest import decode_margin_cases
+    from ps_slm_amd.decode import beam_search_generate
+    geo, sd, cases = decode_margin_cases()
+    model = build(geo, sd)
+    for n, c in enumerate(cases):
+        st = model.prepare_text(c["ids"], c["am"], None, c["post_ids"], None, None)
+        model.forward_projector_text(st)
+        toks = beam_search_generate(model, st, eos_token_id=geo.eos_id, pad_token_id=geo.eos_id, **c["kw"]).numpy()
+        assert np.array_equal(toks, c["tokens"]), (n, toks, c["tokens"])

@@ -317,3 +317,21 @@ def test_generate_random_cases_vs_reference(geo, tiny_weights):
         toks = O.beam_search_generate(tiny_weights, emb, mask, geo, num_beams=nb, max_new_tokens=new, min_length=min_len,
                                       length_penalty=float(z[f"c{n}_length_penalty"]))
         assert np.array_equal(toks.numpy(), z[f"c{n}_tokens"]), (n, toks, z[f"c{n}_tokens"])
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_generate_margin_cases_vs_reference(mode):
+    """14 rounding-stable decode cases at the mid geometry (oracle/make_golden_generate_margin.py): the oracle's beam search
+    must reproduce the REAL reference's generate() token ids exactly, in fp32 and in bf16-emulation mode (these are the cases
+    the HIP decode path is compared with token by token in tests/test_gpu_model.py)."""
+    import dataclasses
+
+    from conftest import decode_margin_cases
+    geo, sd, cases = decode_margin_cases()
+    gd = dataclasses.asdict(geo)
+    for n, c in enumerate(cases):
+        post, plen = O.pseudo_posterior(c["post_ids"], geo.ctc_vocab)
+        emb, mask, _, _ = O.merge(O.projector(sd, post, mode), plen, sd["llm.model.embed_tokens.weight"][c["ids"]], c["ids"],
+                                  c["am"], None, geo.speech_id)
+        toks = O.beam_search_generate(sd, emb.detach(), mask, gd, mode=mode, **c["kw"])
+        assert np.array_equal(toks.numpy(), c["tokens"]), (n, toks, c["tokens"])
