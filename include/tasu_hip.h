@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 2
+#define TASU_ABI_VERSION 3
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -192,8 +192,9 @@ int tasu_merge_bwd(const float* dx, const int32_t* audio_rows, void* dproj_bf16,
 /* --------------------------------------------------------------------------------------------- AdamW
  * DeepSpeed FusedAdam(adam_w_mode) of Multitask/conf/ds_config.json:4-11 over one flat fp32 buffer:
  * g' = g*grad_scale; m,v update; p = p*(1-lr*wd) - lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps).  Optionally writes
- * the bf16 working copy of p.  lr is read from DEVICE memory (*lr) so a captured graph can be replayed.   */
-int tasu_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* lr, float beta1,
+ * the bf16 working copy of p.  Elementwise, so a bucket may be updated in several calls over disjoint ranges
+ * (the engine updates each all-reduced chunk as it arrives); lr is passed by value per call.               */
+int tasu_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
                float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
 /* -------------------------------------------------------------------------- SenseVoice encoder pieces

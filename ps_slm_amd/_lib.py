@@ -44,7 +44,7 @@ PROTOTYPES = {
     "tasu_posterior_build": [vp, vp, vp, i32, i32, i32, vp],
     "tasu_embed_merge_fwd": [vp, vp, vp, vp, vp, i32, i32, vp],
     "tasu_merge_bwd": [vp, vp, vp, i32, i32, vp],
-    "tasu_adamw": [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, i32, f32, vp],
+    "tasu_adamw": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
     "tasu_sinusoid_pe": [vp, vp, i32, i32, i32, f32, vp],
     "tasu_fsmn_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "tasu_softmax_rows": [vp, i32, i32, vp, i32, i32, i32, vp],
@@ -66,7 +66,7 @@ PROTOTYPES = {
     "tasu_embed_rows": [vp, vp, vp, i32, i32, vp],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

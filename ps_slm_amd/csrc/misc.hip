@@ -54,9 +54,8 @@ __global__ __launch_bounds__(256) void merge_bwd_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ pb, int64_t n,
-                                                    const float* __restrict__ lr_ptr, float b1, float b2, float eps, float wd,
+                                                    float lr, float b1, float b2, float eps, float wd,
                                                     float inv_bc1, float inv_sqrt_bc2, float gscale) {
-  const float lr = *lr_ptr;
   const int64_t nv = n / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
     f32x4 pp = *(const f32x4*)(p + i * 4);
@@ -104,10 +103,10 @@ extern "C" int tasu_merge_bwd(const float* dx, const int32_t* audio_rows, void* 
   return TASU_OK;
 }
 
-extern "C" int tasu_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* lr,
+extern "C" int tasu_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                           float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                           void* stream) {
-  if (!p || !g || !m || !v || !lr || n <= 0 || n % 4 || step < 1) return TASU_ERR_ARG;
+  if (!p || !g || !m || !v || n <= 0 || n % 4 || step < 1) return TASU_ERR_ARG;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   int64_t blocks = (n / 4 + 255) / 256;

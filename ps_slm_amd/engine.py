@@ -5,13 +5,18 @@ at Multitask/utils/deepspeed_utils.py:235-236; config Multitask/conf/ds_config.j
 Semantics reproduced: every rank computes the mean CE over ITS OWN non-ignored tokens; gradients are averaged
 over ranks (DeepSpeed's post-divide by world size); AdamW (decoupled decay, bias correction, fp32 state) on the
 trainable parameters only; WarmupCosineLR stepped after every optimizer step.  ZeRO-2 partitioning is dropped:
-with 54.5 M trainable parameters it would save 0.6 GB per GPU of 288 GB, and replicated DP with one all-reduce
+with 54.5 M trainable parameters it would save 0.6 GB per GPU of 288 GB, and replicated DP with all-reduce
 is the same update.
 
-Data parallelism: one process per GPU, ``torch.distributed`` (backend "nccl" == RCCL over xGMI); ONE flat fp32
-gradient bucket (the projector's flat buffer, 218 MB) is all-reduced on a side HIP stream that is event-chained
-behind the wgrad kernels; ``step()`` makes the compute stream wait for it and folds the 1/world_size into the
-fused AdamW kernel.  No data-path collective exists besides this one.
+Data parallelism (``overlap_comm`` of ds_config.json:15-21, rebuilt for this step): one process per GPU,
+``torch.distributed`` (backend "nccl" == RCCL over xGMI).  The flat fp32 gradient bucket (218 MB) is exchanged in the
+ranges the backward completes them in (TasuModel.grad_ranges): the Linear2 / bias tail, then N row blocks of the
+Linear1 weight gradient (94 % of the bytes), then the LayerNorm parameters.  Each range's all-reduce is issued on a side
+HIP stream behind an event recorded right after its wgrad kernel, so it runs under the remaining backward kernels
+(later row blocks, the dxn GEMM, the LayerNorm-parameter reduction); ``step()`` then walks the ranges in the same order:
+wait for range i, fused AdamW on range i (1/world folded in) -- which runs while range i+1 is still on the wire.  The
+projector is the FIRST layer of the network, so its gradients are the LAST thing backward produces: what cannot be
+hidden is the all-reduce of the final row block.  No other data-path collective exists.
 """
 import math
 
@@ -35,27 +40,31 @@ def warmup_cosine_ratio(it, warmup_num_steps=200, total_num_steps=15000, warmup_
 
 
 class TasuEngine:
-    def __init__(self, module, ds_config, process_group=None):
+    def __init__(self, module, ds_config, process_group=None, w1_chunks=None, force_exchange=False):
         """module: ps_slm_amd.ps_slm.slam_model_asr (exposes .core = TasuModel).  ds_config: dict from
-        ps_slm_amd.config.load_ds_config."""
+        ps_slm_amd.config.load_ds_config.  ``w1_chunks``: row blocks the Linear1 wgrad is exchanged in (default 4 when
+        gradients are exchanged, 1 otherwise).  ``force_exchange``: run the collectives even at world size 1 (tests)."""
         self.module = module
         self.core = module.core
         self.cfg = ds_config
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
+        self.w1_chunks = int(w1_chunks) if w1_chunks else (4 if self.exchange else 1)
         self.global_steps = 0          # optimizer steps taken
         self.sched_iter = -1           # WarmupCosineLR.last_batch_iteration (scheduler steps AFTER the optimizer)
         self.micro_steps = 0
         dev = self.core.device
-        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(1)
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self._pending = None
+        self._pending = []             # [(lo, hi, work)] in issue order
         self._last_state = None
-        # gradient accumulation (ds_config "gradient_accumulation_steps", DeepSpeed semantics: every micro-step's gradient
-        # enters with weight 1/k, the optimizer and the scheduler step on every k-th call of step()); k = 1 in the shipped
-        # config, in which case no accumulation buffer exists and nothing below costs anything
+        self.time_exchange = False     # bench.py: record event pairs around every wait of step()
+        self.exposed_events = []
+        # gradient accumulation (ds_config "gradient_accumulation_steps"; 1 in the shipped config, in which case no
+        # accumulation buffer exists and nothing below costs anything).  Reference semantics: the loop divides the loss by k
+        # (deepspeed_utils.py:210) and DeepSpeed's backward scales by 1/k again, so each micro-batch gradient enters with
+        # weight 1/k^2; the optimizer and the scheduler step on every k-th call of step().
         self.ga = max(1, int(ds_config.get("gradient_accumulation_steps", 1)))
         self._g_acc = torch.zeros_like(self.core.proj.g) if self.ga > 1 else None
 
@@ -82,26 +91,37 @@ class TasuEngine:
                                                      self.cfg["cos_min_ratio"], self.cfg["warmup_type"])]
 
     # ---- backward + gradient exchange
+    def _issue(self, g, lo, hi):
+        """All-reduce of bucket range [lo, hi) on the side stream, ordered behind everything the compute stream has been
+        given so far (= the kernels that wrote the range)."""
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                work = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        else:
+            work = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._pending.append((lo, hi, work))
+
     def backward(self, loss=None):
-        """Hand-scheduled backward of the last forward, then the DP all-reduce of the flat gradient bucket on the
-        side stream (asynchronous w.r.t. the compute stream until step())."""
+        """Hand-scheduled backward of the last forward; with N > 1 the bucket ranges are all-reduced on the side stream as
+        the wgrad kernels complete them (asynchronous w.r.t. the compute stream until step())."""
         st = self._last_state
         if st is None:
             raise RuntimeError("backward() called before a forward pass")
-        self.core.run_backward(st)
         self.micro_steps += 1
         if self.ga > 1:
-            self._g_acc.add_(self.core.proj.g, alpha=1.0 / self.ga)
-            if self.micro_steps % self.ga != 0:
-                return                                  # not a boundary: no exchange yet
-        if self.world > 1:
-            g = self._g_acc if self.ga > 1 else self.core.proj.g
-            if self.comm_stream is not None:
-                self.comm_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self.comm_stream):
-                    self._pending = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            else:
-                self._pending = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self.core.run_backward(st)
+            self._g_acc.add_(self.core.proj.g, alpha=1.0 / (self.ga * self.ga))
+            if self.micro_steps % self.ga == 0 and self.exchange:
+                self._issue(self._g_acc, 0, self._g_acc.numel())
+            return
+        if self.exchange:
+            g = self.core.proj.g
+            self.core.run_backward(st, on_ready=lambda lo, hi: self._issue(g, lo, hi), w1_chunks=self.w1_chunks)
+        else:
+            self.core.run_backward(st)
 
     def is_gradient_accumulation_boundary(self):
         return self.micro_steps % self.ga == 0
@@ -109,22 +129,36 @@ class TasuEngine:
     def step(self):
         if self.ga > 1 and not self.is_gradient_accumulation_boundary():
             return                                      # DeepSpeed: step() between boundaries is a no-op
-        if self._pending is not None:
-            self._pending.wait()
-            if self.comm_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.comm_stream)
-            self._pending = None
         c, pr = self.cfg, self.core.proj
         self.global_steps += 1
-        self._lr_host[0] = self.get_lr()[0]
-        self.lr_dev.copy_(self._lr_host, non_blocking=True)
+        lr = self.get_lr()[0]
         g = self._g_acc if self.ga > 1 else pr.g
-        self.core.ops.adamw(pr.p, g, pr.m, pr.v, pr.pb, self.lr_dev, c["betas"][0], c["betas"][1], c["eps"],
-                            c["weight_decay"], self.global_steps, 1.0 / self.world)
+        ranges = self._pending if self._pending else [(0, pr.numel, None)]
+        for lo, hi, work in ranges:
+            if work is not None:
+                timed = self.time_exchange and self.comm_stream is not None
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                work.wait()                             # NCCL: the compute STREAM waits (no host block); gloo: host wait
+                if self.comm_stream is not None:
+                    torch.cuda.current_stream().wait_stream(self.comm_stream)
+                if timed:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self.exposed_events.append((e0, e1))
+            self.core.ops.adamw(pr.p[lo:hi], g[lo:hi], pr.m[lo:hi], pr.v[lo:hi], pr.pb[lo:hi], lr, c["betas"][0], c["betas"][1],
+                                c["eps"], c["weight_decay"], self.global_steps, 1.0 / self.world)
+        self._pending = []
         if self.ga > 1:
             self._g_acc.zero_()
         pr.refresh_working_copies(self.core.ops)
         self.sched_iter += 1           # lr_scheduler.step() follows optimizer.step() in the DeepSpeed engine
+
+    def exposed_ms(self):
+        """Sum of the intervals the compute stream spent waiting for gradient ranges since ``exposed_events`` was cleared
+        (needs ``time_exchange``; call after a device synchronize)."""
+        return sum(a.elapsed_time(b) for a, b in self.exposed_events)
 
     # ---- uneven-data join (replaces the per-step gloo monitored_barrier of deepspeed_utils.py:102-123,191)
     def all_have_data(self, has_batch: bool) -> bool:

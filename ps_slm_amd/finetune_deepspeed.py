@@ -177,7 +177,14 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
             steps += 1
             epoch_step += 1
             utts += batch["input_ids"].shape[0]
-            if eval_dataset is not None and train_config.run_validation and epoch_step % train_config.validation_interval == 0:
+            log_now = steps % max(1, log_config.log_interval) == 0
+            val_now = eval_dataset is not None and train_config.run_validation and \
+                epoch_step % train_config.validation_interval == 0
+            if log_now and val_now:
+                # loss / acc are views into the step's result buffer, which the validation forwards below overwrite:
+                # read them first
+                loss, acc = float(loss), float(acc)
+            if val_now:
                 ppl, el, ea = evaluation(engine, train_config, eval_dataset, rank, world)
                 if train_config.save_model and (el < best_val_loss or ea > best_val_acc) and \
                         not str(train_config.output_dir).startswith("PATH/"):
@@ -190,7 +197,7 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
                 val_loss.append(el)
                 val_ppl.append(ppl)
                 val_acc.append(ea)
-            if steps % max(1, log_config.log_interval) == 0:
+            if log_now:
                 l, a = float(loss), float(acc)                 # the only host sync of the loop, every log_interval steps
                 total_loss, total_acc = total_loss + l, total_acc + a
                 if rank == 0:

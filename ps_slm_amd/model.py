@@ -471,9 +471,15 @@ class TasuModel:
         d.update(dlogits=dlogits, loss_out=res, row_arg=row_arg)
 
     # ------------------------------------------------------------------------------------------ backward
-    def backward(self, st: StepState):
+    def backward(self, st: StepState, on_ready=None, w1_chunks=1):
         """dgrad-only through the frozen decoder, then wgrad of the projector into the flat grad buffer."""
-        ops, geo, llm, pr = self.ops, self.geo, self.llm, self.proj
+        self.backward_llm(st)
+        self.backward_projector(st, on_ready, w1_chunks)
+
+    def backward_llm(self, st: StepState):
+        """lm_head dgrad, final norm, 28 decoder layers (dgrad only: the LLM is frozen).  Leaves d(loss)/d(inputs_embeds)
+        in the fp32 workspace buffer ``dx``."""
+        ops, geo, llm = self.ops, self.geo, self.llm
         B, S, M = st.B, st.S, st.M
         D, I, H, G, V = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_vocab
         Spad, Vp, LDQ = st.plan.Spad, rup(V, 64), (H + 2 * G) * HD
@@ -510,11 +516,31 @@ class TasuModel:
             ops.rope_bwd(dqkv, dkp, dvp, cos, sin, B, S, H, G)
             ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)
             ops.rmsnorm_bwd(dn, x_in, w["ln1"], rstd[2 * l], dx, dxb, True)
+        d["dx"] = dx
+
+    def grad_ranges(self, w1_chunks=1):
+        """The flat gradient bucket as the ranges backward_projector completes, in completion order:
+        [ffn.0.bias | ffn.2.weight | ffn.2.bias] (one contiguous tail), then ``w1_chunks`` row blocks of ffn.0.weight,
+        then [norm.weight | norm.bias].  The ranges tile [0, numel) exactly."""
+        pr = self.proj
+        o_w1, o_b1 = pr.offsets["ffn.0.weight"][0], pr.offsets["ffn.0.bias"][0]
+        rows = [pr.Hb * i // w1_chunks for i in range(w1_chunks + 1)]
+        return [(o_b1, pr.numel)] + [(o_w1 + r0 * pr.Kp, o_w1 + r1 * pr.Kp) for r0, r1 in zip(rows[:-1], rows[1:])] + [(0, o_w1)]
+
+    def backward_projector(self, st: StepState, on_ready=None, w1_chunks=1):
+        """Merge backward + projector backward (projector.py:149-151 reversed): wgrads land in the flat fp32 bucket.
+        ``on_ready(lo, hi)`` (the engine's gradient exchange) is called as soon as the kernels that complete the bucket range
+        [lo, hi) have been launched, in the order of ``grad_ranges(w1_chunks)``; with ``w1_chunks`` > 1 the ffn.0.weight
+        wgrad -- 94 % of the bucket -- runs as that many row-block GEMMs so that its all-reduce starts before the
+        projector's input-side work (dxn, LayerNorm parameter gradients) has run."""
+        ops, pr, d = self.ops, self.proj, st.dev
+        bf, f32 = torch.bfloat16, torch.float32
+        ranges = self.grad_ranges(w1_chunks)
         # merge backward: gradient rows that hold audio -> projector output gradient
         Rap, K, Kp, Hb, Do = st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
         audio_rows = d["audio_rows_pad"] if "audio_rows_pad" in d else self._pad_rows(st)
         dy2 = self._buf("dy2", (Rap, Do), bf)
-        ops.merge_bwd(dx, audio_rows, dy2, Rap, Do)
+        ops.merge_bwd(d["dx"], audio_rows, dy2, Rap, Do)
         # Linear2: db2, dW2 = dy2^T a1, da1 = dy2 W2
         ops.colsum(dy2, pr.view(pr.g, "ffn.2.bias"), Rap, Do)
         dy2_t = self._buf("dy2_t", (Do, Rap), bf)
@@ -528,16 +554,25 @@ class TasuModel:
         ops.silu_bwd(da1, d["h1"], dh1)
         # Linear1: db1, dW1 = dh1^T xn, dxn = dh1 W1
         ops.colsum(dh1, pr.view(pr.g, "ffn.0.bias"), Rap, Hb)
+        if on_ready is not None:
+            on_ready(*ranges[0])
         dh1_t = self._buf("dh1_t", (Hb, Rap), bf)
         xn_t = self._buf("xn_t", (Kp, Rap), bf)
         ops.transpose(dh1, dh1_t, Rap, Hb, Rap, Hb)
         ops.transpose(d["xn"], xn_t, Rap, Kp, Rap, Kp)
-        ops.gemm(dh1_t, xn_t, pr.view(pr.g, "ffn.0.weight"), Hb, Kp, Rap, mode=GEMM_F32)
+        gw1 = pr.view(pr.g, "ffn.0.weight")
+        rows = [Hb * i // w1_chunks for i in range(w1_chunks + 1)]
+        for i, (r0, r1) in enumerate(zip(rows[:-1], rows[1:])):
+            ops.gemm(dh1_t[r0:r1], xn_t, gw1[r0:r1], r1 - r0, Kp, Rap, mode=GEMM_F32)
+            if on_ready is not None:
+                on_ready(*ranges[1 + i])
         dxn = self._buf("dxn", (Rap, Kp), bf)
         ops.gemm(dh1, pr.w1b_t, dxn, Rap, Kp, Hb)
         ws = self._buf("ln_ws", (2 * LN_BWD_SPLIT * K,), f32)
         ops.layernorm_bwd_params(dxn, d["post"], d["ln_mean"], d["ln_rstd"], pr.view(pr.g, "norm.weight"),
                                  pr.view(pr.g, "norm.bias"), ws, Rap, K)
+        if on_ready is not None:
+            on_ready(*ranges[-1])
 
     def _pad_rows(self, st):
         rows = np.full(st.Rap, -1, dtype=np.int32)
@@ -598,10 +633,17 @@ class TasuModel:
         self._graphed(self._shape_key(st, ("fwd_llm", compute_loss, need_backward)),
                       lambda: self.forward_llm(st, compute_loss=compute_loss, need_backward=need_backward), st)
 
-    def run_backward(self, st):
+    def run_backward(self, st, on_ready=None, w1_chunks=1):
+        """Backward of the last forward, graph-replayed when enabled.  With a gradient-exchange hook (``on_ready``, N > 1) only
+        the decoder part is replayed as a graph; the projector tail (~20 launches) is launched eagerly so that the hook can
+        chain its collectives between the wgrad kernels."""
         if "audio_rows_pad" not in st.dev:
             self._pad_rows(st)                       # H2D upload stays outside the captured region
-        self._graphed(self._shape_key(st, "bwd"), lambda: self.backward(st), st)
+        if on_ready is None:
+            self._graphed(self._shape_key(st, "bwd"), lambda: self.backward(st), st)
+        else:
+            self._graphed(self._shape_key(st, "bwd_llm"), lambda: self.backward_llm(st), st)
+            self.backward_projector(st, on_ready, w1_chunks)
 
     # ------------------------------------------------------------------------------------------ results
     def logits_view(self, st):

@@ -169,8 +169,8 @@ class HipOps:
         self._chk(self.lib.tasu_merge_bwd(_p(dx), _p(audio_rows), _p(dproj), n, D, self._stream()), "tasu_merge_bwd")
 
     # ------------------------------------------------------------------ optimizer
-    def adamw(self, p, g, m, v, p_bf16, lr_dev, beta1, beta2, eps, wd, step, grad_scale):
-        self._chk(self.lib.tasu_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(lr_dev), beta1, beta2, eps, wd,
+    def adamw(self, p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale):
+        self._chk(self.lib.tasu_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), float(lr), beta1, beta2, eps, wd,
                                       step, grad_scale, self._stream()), "tasu_adamw")
 
     # ------------------------------------------------------------------ encoder / PSD

@@ -275,8 +275,8 @@ class FakeOps:
         dproj[ok] = _bf(dx[r[ok]])
 
     # ---------------------------------------------------------------- optimizer
-    def adamw(self, p, g, m, v, p_bf16, lr_dev, beta1, beta2, eps, wd, step, grad_scale):
-        lr = float(lr_dev[0])
+    def adamw(self, p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale):
+        lr = float(torch.tensor(lr, dtype=torch.float32))        # the kernel takes lr as a C float
         gr = g * grad_scale
         m.mul_(beta1).add_(gr, alpha=1 - beta1)
         v.mul_(beta2).addcmul_(gr, gr, value=1 - beta2)

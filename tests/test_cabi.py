@@ -37,7 +37,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     lib = _lib.load()
     assert lib.tasu_gemm_nt_bf16(None, 64, None, 64, None, 64, None, None, 64, 64, 64, 0, None) == 1
     assert lib.tasu_rmsnorm_fwd(None, None, None, None, 4, 6, 1e-6, None) == 1
-    assert lib.tasu_adamw(None, None, None, None, None, 0, None, 0.9, 0.999, 1e-6, 0.0, 1, 1.0, None) == 1
+    assert lib.tasu_adamw(None, None, None, None, None, 0, 5e-5, 0.9, 0.999, 1e-6, 0.0, 1, 1.0, None) == 1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

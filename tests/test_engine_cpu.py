@@ -137,8 +137,9 @@ def test_engine_steps_match_oracle_adamw_and_schedule():
 
 
 def test_gradient_accumulation_matches_deepspeed_semantics():
-    """gradient_accumulation_steps = 2: step() is a no-op off the boundary; on it the update equals ONE AdamW step on the
-    mean of the two micro-batch gradients (DeepSpeed scales each micro loss by 1/k), and the scheduler advances once."""
+    """gradient_accumulation_steps = 2: step() is a no-op off the boundary; on it the update equals ONE AdamW step on
+    sum(g_i) / k^2 -- the reference's loop divides the loss by k (deepspeed_utils.py:210) and DeepSpeed's backward scales by
+    1/k again -- and the scheduler advances once."""
     def build(ga):
         tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True)
         mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
@@ -166,7 +167,7 @@ def test_gradient_accumulation_matches_deepspeed_semantics():
     m1, e1 = build(1)
     out, _ = e1(**to_call(raws[0]))
     e1.backward(out.loss)
-    m1.core.proj.g.copy_(0.5 * (grads[0] + grads[1]))
+    m1.core.proj.g.copy_(0.25 * (grads[0] + grads[1]))
     e1.step()
     torch.testing.assert_close(m2.core.proj.p, m1.core.proj.p, rtol=0, atol=1e-7)
     assert float((m2.core.proj.p - p0).abs().max()) > 0
@@ -180,9 +181,18 @@ def _dp_worker(rank, world, port, ret):
     eng.sched_iter = 10                      # skip the zero-lr warm-up steps
     raw = synthetic_text_batch(model.core.geo, 2, seed=100 + rank, prompt_len=9, n_audio=21, target_len=17, speech_pos=4,
                                feat_frames=8, noise=False)
+    # the rank's own gradient: one backward with the exchange switched off (the asynchronous all-reduces of the real
+    # backward below rewrite the bucket in place, range by range)
     out, _ = eng(**to_call(raw))
+    eng.exchange = False
     eng.backward(out.loss)
     g_local = model.core.proj.g.clone()
+    eng.exchange, eng.micro_steps = True, 0
+    out, _ = eng(**to_call(raw))
+    eng.backward(out.loss)
+    assert len(eng._pending) == eng.w1_chunks + 2 and eng.w1_chunks == 4      # tail, 4 row blocks of dW1, LayerNorm params
+    assert sorted((lo, hi) for lo, hi, _ in eng._pending)[0][0] == 0
+    assert sum(hi - lo for lo, hi, _ in eng._pending) == model.core.proj.numel   # the ranges tile the bucket
     eng.step()
     ret[rank] = dict(loss=float(out.loss), grad=g_local, param=model.core.proj.p.clone(),
                      reduced=eng.reduce_scalars(float(out.loss)), joined=eng.all_have_data(rank == 0))

@@ -1,0 +1,72 @@
+"""The engine's gradient exchange on hardware: a 1-rank ``nccl`` (= RCCL) process group on the MI355X, so that the side-stream
+event chaining, the per-range RCCL all-reduces, the stream waits of step() and the chunked AdamW all execute on the GPU
+(the N > 1 semantics -- rank-averaged gradients, identical replicas -- are covered over gloo in tests/test_engine_cpu.py;
+a one-GPU box cannot host a second RCCL rank)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from ps_slm_amd.config import DEFAULT_DS_CONFIG, ModelConfig, TrainConfig, load_ds_config
+from ps_slm_amd.engine import TasuEngine
+from ps_slm_amd.ps_slm import model_factory
+from ps_slm_amd.synthetic import synthetic_text_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_group():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    yield
+    dist.destroy_process_group()
+
+
+def build(force, chunks, graphs):
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True,
+                     use_fp16=True)
+    mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+    model, _ = model_factory(tc, mc, device="cuda:0", init_seed=1234, keep_logits=False)
+    model.core.use_graphs = graphs
+    cfg = load_ds_config(DEFAULT_DS_CONFIG)
+    cfg["lr"] = 1e-3
+    eng = TasuEngine(model, cfg, force_exchange=force, w1_chunks=chunks)
+    eng.sched_iter = 10                                   # past DeepSpeed's two zero-lr steps
+    return model, eng
+
+
+def run_steps(model, eng, n=4):
+    raw = synthetic_text_batch(model.core.geo, 3, seed=5, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8,
+                               noise=False, ragged=True)
+    call = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"], input_features=None,
+                input_feature_length=None, GT=[" ".join(map(str, p)) for p in raw["post_ids"]])
+    losses = []
+    for _ in range(n):
+        out, _ = eng(**call)
+        eng.backward(out.loss)
+        eng.step()
+        losses.append(out.loss.clone())
+    torch.cuda.synchronize()
+    return torch.stack(losses).cpu(), model.core.proj.p.clone(), model.core.proj.m.clone()
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_chunked_rccl_exchange_is_bit_identical_to_the_single_bucket_step(nccl_group, graphs):
+    """Four optimizer steps with the exchange forced on (6 RCCL all-reduces per step: tail, 4 row blocks of the Linear1
+    wgrad, LayerNorm parameters; AdamW per range) against the plain single-bucket step: losses, parameters and Adam moments
+    must be bit-identical (a 1-rank sum is the identity, AdamW is elementwise, the row-block GEMMs keep every element's
+    K order).  With graphs the decoder backward is replayed as a hipGraph and the projector tail stays eager."""
+    m0, e0 = build(False, None, graphs)
+    want = run_steps(m0, e0)
+    m1, e1 = build(True, 4, graphs)
+    assert e1.exchange and e1.w1_chunks == 4 and e1.comm_stream is not None
+    e1.time_exchange = True
+    got = run_steps(m1, e1)
+    assert len(e1.exposed_events) == 4 * 6 and e1.exposed_ms() >= 0.0
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert float(want[0][-1]) < float(want[0][0])         # and the steps do train

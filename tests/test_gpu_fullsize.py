@@ -173,7 +173,7 @@ def test_full_size_step_properties(size):
         tot_cnt += cnt
         gsum += m.proj.g * cnt
     assert tot_cnt == int(loss[2])
-    assert abs(tot_loss / tot_cnt - float(loss[0])) < 1e-3
+    assert abs(tot_loss / tot_cnt - float(loss[0])) < (1e-3 if size == "1.5b" else 3e-3)   # 7B: K = 18944 sums, other tile paths
     gsum /= tot_cnt
     cos = float(torch.nn.functional.cosine_similarity(gsum.flatten(), g.flatten(), dim=0))
     # two bf16 evaluations of the same gradient through 28 layers differ by ~3 % (rounding of dlogits / count differs)

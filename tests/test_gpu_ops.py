@@ -375,7 +375,7 @@ def test_posterior_merge_adamw(hip, fake):
     assert torch.equal(c, g)
     n = 4096 + 64
     p, gr, m, v = randn(n, seed=4), randn(n, seed=5), randn(n, seed=6).abs() * 0.1, randn(n, seed=7).abs() * 0.01
-    lr = torch.tensor([5e-5])
+    lr = 5e-5
     outs = run_pair(hip, fake, "adamw", [p, gr, m, v, torch.zeros(n, dtype=BF), lr, 0.9, 0.999, 1e-6, 0.01, 3, 0.125], [0, 2, 3, 4])
     for c, g in zip(*outs):
         assert rel_err(g, c) < 1e-5 if c.dtype == F32 else rel_err(g, c) < 1e-2
