@@ -94,6 +94,15 @@ int tasu_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, float* rstd, 
  * gradient the next dgrad GEMM consumes.                                                                */
 int tasu_rmsnorm_bwd(const void* dy_bf16, const float* x, const float* w, const float* rstd, float* dx,
                      void* dx_bf16, int accumulate, int M, int D, void* stream);
+/* Row-indexed forms for the training step's lm_head, which projects only the positions that carry a label
+ * (transformers loss_utils.py:49-71 ignores the others; ps_slm_amd/model.py "labelled rows"):
+ * fwd: y[i,:] = rmsnorm(x[src_rows[i],:]) for i < n_rows, a zero row (rstd 0) where src_rows[i] < 0;
+ * bwd: dy / rstd are compact [n_rows]; for every m < M: s = slot[m]; dx[m,:] = dgrad(dy[s], x[m], rstd[s]) if
+ * s >= 0 else 0 (no accumulation), dx_bf16 likewise.                                                        */
+int tasu_rmsnorm_fwd_rows(const float* x, const int32_t* src_rows, const float* w, void* y, float* rstd, int n_rows, int D,
+                          float eps, void* stream);
+int tasu_rmsnorm_bwd_rows(const void* dy_compact, const float* x, const float* w, const float* rstd_compact,
+                          const int32_t* slot, float* dx, void* dx_bf16, int M, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- RoPE
  * cos/sin tables from position ids (modeling_qwen2.py:91-102): tab[m][i] = cos/sin(pos[m] * theta^(-2i/hd)),

@@ -7,13 +7,21 @@
 namespace {
 
 // one wave per row, 4 rows per 256-thread block.  D % 4 == 0.
-__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          bf16* __restrict__ y, float* __restrict__ rstd, int M, int D,
-                                                          float eps) {
+// ``src`` (optional): output row i is the norm of input row src[i]; src[i] < 0 gives a zero row and rstd 0 (the lm_head of
+// the training step only projects the rows that carry a label).
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ src,
+                                                          const float* __restrict__ w, bf16* __restrict__ y,
+                                                          float* __restrict__ rstd, int M, int D, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
-  const float* xr = x + (size_t)row * D;
+  const int srow = src ? src[row] : row;
+  if (srow < 0) {
+    for (int c = lane * 4; c < D; c += 256) *(bf16x4*)(y + (size_t)row * D + c) = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    if (lane == 0 && rstd) rstd[row] = 0.f;
+    return;
+  }
+  const float* xr = x + (size_t)srow * D;
   float ss = 0.f;
   for (int c = lane * 4; c < D; c += 256) {
     const f32x4 v = *(const f32x4*)(xr + c);
@@ -36,13 +44,22 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 // Register-resident forms for D = NG * 256 (1536 -> 6, 3584 -> 14): the row is loaded once, all loads in flight together;
 // same arithmetic and summation order as the generic kernels.
 template <int NG>
-__global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              bf16* __restrict__ y, float* __restrict__ rstd, int M, float eps) {
+__global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __restrict__ x, const int32_t* __restrict__ src,
+                                                              const float* __restrict__ w, bf16* __restrict__ y,
+                                                              float* __restrict__ rstd, int M, float eps) {
   constexpr int D = NG * 256;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
-  const float* xr = x + (size_t)row * D + lane * 4;
+  const int srow = src ? src[row] : row;
+  if (srow < 0) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      *(bf16x4*)(y + (size_t)row * D + lane * 4 + g * 256) = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    if (lane == 0 && rstd) rstd[row] = 0.f;
+    return;
+  }
+  const float* xr = x + (size_t)srow * D + lane * 4;
   f32x4 v[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) v[g] = *(const f32x4*)(xr + g * 256);
@@ -64,23 +81,35 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __res
 }
 
 template <int NG>
+// ``slot`` (optional): dy and rstd are COMPACT (one row per labelled position); slot[row] is row's compact index, or < 0
+// for a row whose output gradient is zero (then dx = dxb = 0; accumulate must be 0 with a slot map).
 __global__ __launch_bounds__(256) void rmsnorm_bwd_reg_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                               const float* __restrict__ w, const float* __restrict__ rstd,
-                                                              float* __restrict__ dx, bf16* __restrict__ dxb, int accumulate,
-                                                              int M) {
+                                                              const int32_t* __restrict__ slot, float* __restrict__ dx,
+                                                              bf16* __restrict__ dxb, int accumulate, int M) {
   constexpr int D = NG * 256;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
   const size_t base = (size_t)row * D + lane * 4;
+  const int crow = slot ? slot[row] : row;
+  if (crow < 0) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      *(f32x4*)(dx + base + g * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (dxb) *(bf16x4*)(dxb + base + g * 256) = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    }
+    return;
+  }
+  const size_t cbase = (size_t)crow * D + lane * 4;
   f32x4 v[NG], d[NG], o[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     v[g] = *(const f32x4*)(x + base + g * 256);
-    d[g] = __builtin_convertvector(*(const bf16x4*)(dy + base + g * 256), f32x4);
+    d[g] = __builtin_convertvector(*(const bf16x4*)(dy + cbase + g * 256), f32x4);
     o[g] = accumulate ? *(const f32x4*)(dx + base + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const float r = rstd[row];
+  const float r = rstd[crow];
   float dot = 0.f;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -104,14 +133,22 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_reg_kernel(const bf16* __rest
 // dx += rstd * (w*dy - xhat * mean(w*dy*xhat)),  xhat = x * rstd
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ rstd,
-                                                          float* __restrict__ dx, bf16* __restrict__ dxb, int accumulate,
-                                                          int M, int D) {
+                                                          const int32_t* __restrict__ slot, float* __restrict__ dx,
+                                                          bf16* __restrict__ dxb, int accumulate, int M, int D) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
+  const int crow = slot ? slot[row] : row;
+  if (crow < 0) {
+    for (int c = lane * 4; c < D; c += 256) {
+      *(f32x4*)(dx + (size_t)row * D + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (dxb) *(bf16x4*)(dxb + (size_t)row * D + c) = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    }
+    return;
+  }
   const float* xr = x + (size_t)row * D;
-  const bf16* dr = dy + (size_t)row * D;
-  const float r = rstd[row];
+  const bf16* dr = dy + (size_t)crow * D;
+  const float r = rstd[crow];
   float dot = 0.f;
   for (int c = lane * 4; c < D; c += 256) {
     const f32x4 v = *(const f32x4*)(xr + c);
@@ -295,29 +332,47 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
 
 }  // namespace
 
-extern "C" int tasu_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, int M, int D, float eps,
-                                void* stream) {
+static int rmsnorm_fwd_any(const float* x, const int32_t* src, const float* w, void* y, float* rstd, int M, int D, float eps,
+                           void* stream) {
   if (!x || !w || !y || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
   const dim3 grid((M + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
-  if (D == 1536) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<6>, grid, dim3(256), 0, st, x, w, (bf16*)y, rstd, M, eps);
-  else if (D == 3584) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<14>, grid, dim3(256), 0, st, x, w, (bf16*)y, rstd, M, eps);
-  else if (D == 256) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<1>, grid, dim3(256), 0, st, x, w, (bf16*)y, rstd, M, eps);
-  else TASU_LAUNCH(rmsnorm_fwd_kernel, grid, dim3(256), 0, st, x, w, (bf16*)y, rstd, M, D, eps);
+  if (D == 1536) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<6>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps);
+  else if (D == 3584) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<14>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps);
+  else if (D == 256) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<1>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps);
+  else TASU_LAUNCH(rmsnorm_fwd_kernel, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, D, eps);
   return TASU_OK;
 }
-extern "C" int tasu_rmsnorm_bwd(const void* dy, const float* x, const float* w, const float* rstd, float* dx, void* dx_bf16,
-                                int accumulate, int M, int D, void* stream) {
-  if (!dy || !x || !w || !rstd || !dx || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
+static int rmsnorm_bwd_any(const void* dy, const float* x, const float* w, const float* rstd, const int32_t* slot, float* dx,
+                           void* dx_bf16, int accumulate, int M, int D, void* stream) {
+  if (!dy || !x || !w || !rstd || !dx || M <= 0 || D <= 0 || D % 4 || (slot && accumulate)) return TASU_ERR_ARG;
   const dim3 grid((M + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
   const bf16* d = (const bf16*)dy;
   bf16* db = (bf16*)dx_bf16;
-  if (D == 1536) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<6>, grid, dim3(256), 0, st, d, x, w, rstd, dx, db, accumulate, M);
-  else if (D == 3584) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<14>, grid, dim3(256), 0, st, d, x, w, rstd, dx, db, accumulate, M);
-  else if (D == 256) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<1>, grid, dim3(256), 0, st, d, x, w, rstd, dx, db, accumulate, M);
-  else TASU_LAUNCH(rmsnorm_bwd_kernel, grid, dim3(256), 0, st, d, x, w, rstd, dx, db, accumulate, M, D);
+  if (D == 1536) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<6>, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M);
+  else if (D == 3584) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<14>, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M);
+  else if (D == 256) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<1>, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M);
+  else TASU_LAUNCH(rmsnorm_bwd_kernel, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M, D);
   return TASU_OK;
+}
+extern "C" int tasu_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, int M, int D, float eps,
+                                void* stream) {
+  return rmsnorm_fwd_any(x, nullptr, w, y, rstd, M, D, eps, stream);
+}
+extern "C" int tasu_rmsnorm_bwd(const void* dy, const float* x, const float* w, const float* rstd, float* dx, void* dx_bf16,
+                                int accumulate, int M, int D, void* stream) {
+  return rmsnorm_bwd_any(dy, x, w, rstd, nullptr, dx, dx_bf16, accumulate, M, D, stream);
+}
+extern "C" int tasu_rmsnorm_fwd_rows(const float* x, const int32_t* src_rows, const float* w, void* y, float* rstd, int n_rows,
+                                     int D, float eps, void* stream) {
+  if (!src_rows) return TASU_ERR_ARG;
+  return rmsnorm_fwd_any(x, src_rows, w, y, rstd, n_rows, D, eps, stream);
+}
+extern "C" int tasu_rmsnorm_bwd_rows(const void* dy_compact, const float* x, const float* w, const float* rstd_compact,
+                                     const int32_t* slot, float* dx, void* dx_bf16, int M, int D, void* stream) {
+  if (!slot) return TASU_ERR_ARG;
+  return rmsnorm_bwd_any(dy_compact, x, w, rstd_compact, slot, dx, dx_bf16, 0, M, D, stream);
 }
 extern "C" int tasu_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
                                   int y_is_f32, float* mean, float* rstd, int R, int D, float eps, void* stream) {

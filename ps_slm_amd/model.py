@@ -223,6 +223,8 @@ class StepState:
     M: int = 0
     Ra: int = 0        # projector rows (B * Lmax)
     Rap: int = 0       # padded to 64
+    nL: int = 0        # positions that carry a label (shift_labels >= 0)
+    nLp: int = 0       # padded to 64
     dev: dict = field(default_factory=dict)
     out: object = None
     path: str = "text"   # "text" (pseudo-posterior) or "audio" (encoder + PSD): part of the graph keys, the buffers differ
@@ -382,6 +384,21 @@ class TasuModel:
         st.dev["shift_labels"] = self._upload("shift_labels", plan.shift_labels)
         st.dev["audio_rows"] = self._upload("audio_rows", plan.audio_rows)
         st.dev["inv_count"] = self._upload("inv_count", np.array([1.0 / max(plan.count, 1)], dtype=np.float32))
+        if labels is not None:
+            # compact index of the labelled positions: the training step's lm_head, CE and lm_head dgrad only run over these
+            # rows (forward_llm, "labelled rows"); rows -> positions, slot = the inverse map, labels in compact order
+            sl = np.asarray(plan.shift_labels).reshape(-1)
+            rows = np.nonzero(sl >= 0)[0].astype(np.int32)
+            st.nL, st.nLp = len(rows), rup(max(len(rows), 1), 64)
+            lab_rows = np.full(st.nLp, -1, dtype=np.int32)
+            lab_rows[: st.nL] = rows
+            lab_c = np.full(st.nLp, -100, dtype=np.int32)
+            lab_c[: st.nL] = sl[rows]
+            slot = np.full(st.M, -1, dtype=np.int32)
+            slot[rows] = np.arange(st.nL, dtype=np.int32)
+            st.dev["lab_rows"] = self._upload("lab_rows", lab_rows)
+            st.dev["lab_compact"] = self._upload("lab_compact", lab_c)
+            st.dev["lab_slot"] = self._upload("lab_slot", slot)
         return st
 
     # ------------------------------------------------------------------------------------------ forward
@@ -448,6 +465,8 @@ class TasuModel:
         d.update(xs=xs, cos=cos, sin=sin, rstd=rstd, qkv=qkv, qt=qt, kt=kt, ao=ao, lse=lse, gu=gu)
         if logits_rows == "none":                              # decode prefill: the caller projects the last rows only
             return
+        if compute_loss and need_backward and not self.keep_logits:
+            return self._loss_on_labelled_rows(st)
         ops.rmsnorm_fwd(xs[2 * L], llm.norm, xn, rstd[2 * L], geo.rms_eps)
         logits = self._buf("logits", (M, Vp), bf)
         ops.gemm(xn, llm.head, logits, M, V, D)
@@ -469,6 +488,29 @@ class TasuModel:
         res = self._buf("loss_out", (4,), f32)
         ops.ce_reduce(row_loss, row_hit, d["shift_labels"], M, res)
         d.update(dlogits=dlogits, loss_out=res, row_arg=row_arg)
+
+    def _loss_on_labelled_rows(self, st: StepState):
+        """Throughput form of the loss head (training step, ``keep_logits=False``): the shifted CE ignores every position
+        without a label (loss_utils.py:49-71, ignore_index -100), so final norm -> lm_head -> CE -> dlogits run over the
+        labelled rows only, gathered into a compact [nLp, D] operand (half of the 4096 rows of the benchmark batch, whose
+        prompt and audio positions carry no label).  Loss, accuracy and every gradient equal the full-materialisation path's
+        (rows without a label have dlogits == 0 there); ``outputs.logits`` does not exist in this mode."""
+        ops, geo, llm, d = self.ops, self.geo, self.llm, st.dev
+        D, V, L = geo.llm_dim, geo.llm_vocab, geo.llm_layers
+        Vp, n = rup(V, 64), st.nLp
+        bf, f32 = torch.bfloat16, torch.float32
+        xn_c = self._buf("xn_lab", (n, D), bf)
+        rstd_c = self._buf("rstd_lab", (n,), f32)
+        ops.rmsnorm_fwd_rows(d["xs"][2 * L], d["lab_rows"], llm.norm, xn_c, rstd_c, geo.rms_eps)
+        logits = self._buf("logits", (n, Vp), bf)
+        ops.gemm(xn_c, llm.head, logits, n, V, D)
+        row_loss = self._buf("row_loss", (n,), f32)
+        row_hit = self._buf("row_hit", (n,), torch.int32)
+        ops.ce_fwd_bwd(logits, d["lab_compact"], n, V, row_loss, row_hit, None, logits, d["inv_count"])   # dlogits in place
+        res = self._buf("loss_out", (4,), f32)
+        ops.ce_reduce(row_loss, row_hit, d["lab_compact"], n, res)
+        d.update(dlogits=logits, loss_out=res, row_arg=None, rstd_lab=rstd_c, labelled_only=True)
+        d.pop("logits", None)
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, st: StepState, on_ready=None, w1_chunks=1):
@@ -500,8 +542,13 @@ class TasuModel:
         dkp = self._buf("dkp", (M, H * HD), f32)
         dvp = self._buf("dvp", (M, H * HD), f32)
         # lm_head dgrad (K = Vpad: dlogits pad columns are zero) and final norm
-        ops.gemm(d["dlogits"], llm.head_t, dn, M, D, Vp)
-        ops.rmsnorm_bwd(dn, xs[2 * L], llm.norm, rstd[2 * L], dx, dxb, False)
+        if d.get("labelled_only"):
+            dn_c = self._buf("dn_lab", (st.nLp, D), bf)
+            ops.gemm(d["dlogits"], llm.head_t, dn_c, st.nLp, D, Vp)
+            ops.rmsnorm_bwd_rows(dn_c, xs[2 * L], llm.norm, d["rstd_lab"], d["lab_slot"], dx, dxb)
+        else:
+            ops.gemm(d["dlogits"], llm.head_t, dn, M, D, Vp)
+            ops.rmsnorm_bwd(dn, xs[2 * L], llm.norm, rstd[2 * L], dx, dxb, False)
         for l in range(L - 1, -1, -1):
             w = llm.layers[l]
             x_in, x_mid = xs[2 * l], xs[2 * l + 1]
@@ -619,7 +666,7 @@ class TasuModel:
         self._graphed(("region",) + tuple(key), fn, _NoState())
 
     def _shape_key(self, st, tag):
-        return (tag, st.path, st.B, st.S, st.Ra, st.Rap, self.keep_logits)
+        return (tag, st.path, st.B, st.S, st.Ra, st.Rap, st.nLp, self.keep_logits)
 
     def run_forward_text(self, st, compute_loss=True, need_backward=True):
         """forward_projector_text + forward_llm, graph-replayed when enabled."""
@@ -647,6 +694,9 @@ class TasuModel:
 
     # ------------------------------------------------------------------------------------------ results
     def logits_view(self, st):
-        """[B, S, V] view of the bf16 logits buffer (valid until the next forward)."""
+        """[B, S, V] view of the bf16 logits buffer (valid until the next forward); None in the throughput mode of the
+        training step (``keep_logits=False``), which only projects the labelled rows."""
+        if "logits" not in st.dev:
+            return None
         V = self.geo.llm_vocab
         return st.dev["logits"].view(st.B, st.S, -1)[:, :, :V]

@@ -81,6 +81,18 @@ class HipOps:
         self._chk(self.lib.tasu_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dx), _p(dx_bf16), int(accumulate), M, D,
                                             self._stream()), "tasu_rmsnorm_bwd")
 
+    def rmsnorm_fwd_rows(self, x, src_rows, w, y, rstd, eps):
+        """y[i] = rmsnorm(x[src_rows[i]]) (zero row where src_rows[i] < 0); y / rstd are compact."""
+        n, D = y.shape
+        self._chk(self.lib.tasu_rmsnorm_fwd_rows(_p(x), _p(src_rows), _p(w), _p(y), _p(rstd), n, D, eps, self._stream()),
+                  "tasu_rmsnorm_fwd_rows")
+
+    def rmsnorm_bwd_rows(self, dy, x, w, rstd, slot, dx, dx_bf16):
+        """dx[m] = rmsnorm dgrad of compact row slot[m] (dy, rstd compact) or 0 where slot[m] < 0."""
+        M, D = x.shape
+        self._chk(self.lib.tasu_rmsnorm_bwd_rows(_p(dy), _p(x), _p(w), _p(rstd), _p(slot), _p(dx), _p(dx_bf16), M, D,
+                                                 self._stream()), "tasu_rmsnorm_bwd_rows")
+
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, R, D, eps):
         self._chk(self.lib.tasu_layernorm_fwd(_p(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0),
                                               int(y.dtype == torch.float32), _p(mean), _p(rstd), R, D, eps,

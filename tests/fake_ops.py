@@ -67,6 +67,26 @@ class FakeOps:
         if dx_bf16 is not None:
             dx_bf16.copy_(_bf(dx))
 
+    def rmsnorm_fwd_rows(self, x, src_rows, w, y, rstd, eps):
+        src = src_rows[: y.shape[0]].long()
+        ok = src >= 0
+        xs = x[src.clamp_min(0)]
+        r = torch.rsqrt(xs.pow(2).mean(-1) + eps) * ok
+        rstd[: y.shape[0]].copy_(r)
+        y.copy_(_bf(w * (xs * r[:, None])))
+
+    def rmsnorm_bwd_rows(self, dy, x, w, rstd, slot, dx, dx_bf16):
+        M, D = x.shape
+        s = slot[:M].long()
+        ok = (s >= 0)[:, None]
+        d = dy.float()[s.clamp_min(0)]
+        r = rstd[s.clamp_min(0)][:, None]
+        xh = x * r
+        dot = (w * d * xh).sum(-1, keepdim=True) / D
+        dx.copy_(torch.where(ok, r * (w * d - xh * dot), torch.zeros_like(x)))
+        if dx_bf16 is not None:
+            dx_bf16.copy_(_bf(dx))
+
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, R, D, eps):
         xr = x[:R, :D]
         mu = xr.mean(-1)

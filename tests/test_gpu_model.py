@@ -202,6 +202,25 @@ def test_generate_beam4_on_gpu():
         assert ((g == r).cumprod(1).sum(1) >= 8).all(), (path, g, r)
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_labelled_rows_loss_head_on_gpu(setup, ragged):
+    """The training step's throughput mode (keep_logits=False: lm_head / CE / lm_head dgrad over the labelled rows only, CE
+    writing dlogits over the logits) against full materialisation on the GPU: loss and accuracy equal to fp32 rounding of the
+    row sums, count exact, projector gradients equal up to the accumulation order of the two GEMM row layouts."""
+    from ps_slm_amd.ops import HipOps
+    geo, sd, gm, _ = setup
+    lean = TasuModel(geo, HipOps(), "cuda", keep_logits=False)
+    lean.load_reference_state_dict(sd)
+    batch = synthetic_text_batch(geo, 3, seed=9, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12,
+                                 noise=True, drop_prob=0.1, ragged=ragged)
+    sf, sl = run_text(gm, batch), run_text(lean, batch)
+    lf, ll = sf.dev["loss_out"].cpu(), sl.dev["loss_out"].cpu()
+    assert float(lf[2]) == float(ll[2]) and float(lf[1]) == float(ll[1])
+    assert abs(float(lf[0]) - float(ll[0])) < 1e-5 * float(lf[0])
+    assert float((gm.proj.g - lean.proj.g).norm() / gm.proj.g.norm()) < 5e-3
+    assert cosine(gm.proj.g, lean.proj.g) > 0.9999
+
+
 def test_generate_margin_cases_exact_on_gpu():
     """Token ids are index work: on the 14 rounding-stable decode cases of tests/golden/mid_generate_margin.npz (1-4 beams,
     min_length, length penalties, left padding, EOS events; oracle/make_golden_generate_margin.py) the HIP decode path must

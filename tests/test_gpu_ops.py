@@ -297,6 +297,41 @@ def test_attention_online_softmax_rescale(hip, fake):
     assert rel_err(og, oc) < 2e-2 and float((lg - lc).abs().max()) < 2e-3
 
 
+@pytest.mark.parametrize("D", [256, 1536, 3584, 512])
+def test_rmsnorm_row_indexed(hip, fake, D):
+    """Gathered forward / scattered backward over the labelled rows (tasu_rmsnorm_fwd_rows / _bwd_rows): the gathered rows must
+    be BIT-identical to the plain kernels on the same rows (same arithmetic and summation order), unlabelled rows exact zeros."""
+    M, n = 150, 64
+    x = randn(M, D, seed=1)
+    w = 1 + 0.1 * randn(D, seed=2)
+    g = torch.Generator().manual_seed(3)
+    rows = torch.randperm(M, generator=g)[:50].sort().values.to(I32)
+    src = torch.full((n,), -1, dtype=I32)
+    src[:50] = rows
+    slot = torch.full((M,), -1, dtype=I32)
+    slot[rows.long()] = torch.arange(50, dtype=I32)
+    (yc, rc), (yg, rg) = run_pair(hip, fake, "rmsnorm_fwd_rows", [x, src, w, torch.ones(n, D, dtype=BF), torch.ones(n), 1e-6], [3, 4])
+    assert rel_err(yg, yc) < 1e-2 and rel_err(rg, rc) < 1e-5
+    assert float(yg[50:].float().abs().max()) == 0.0 and float(rg[50:].abs().max()) == 0.0
+    y_full, r_full = torch.zeros(M, D, dtype=BF, device="cuda"), torch.zeros(M, device="cuda")
+    hip.rmsnorm_fwd(x.cuda(), w.cuda(), y_full, r_full, 1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(y_full.cpu()[rows.long()], yg[:50]) and torch.equal(r_full.cpu()[rows.long()], rg[:50])
+    dy = randn(n, D, dtype=BF, seed=4)
+    (dc, dbc), (dg, dbg) = run_pair(hip, fake, "rmsnorm_bwd_rows", [dy, x, w, rc, slot, torch.ones(M, D), torch.ones(M, D, dtype=BF)], [5, 6])
+    assert rel_err(dg, dc) < 1e-4 and rel_err(dbg, dbc) < 1e-2
+    mask = torch.ones(M, dtype=torch.bool)
+    mask[rows.long()] = False
+    assert float(dg[mask].abs().max()) == 0.0 and float(dbg[mask].float().abs().max()) == 0.0
+    dy_full = torch.zeros(M, D, dtype=BF)
+    dy_full[rows.long()] = dy[:50]
+    dx_full, dx_rows = torch.zeros(M, D, device="cuda"), torch.ones(M, D, device="cuda")
+    hip.rmsnorm_bwd(dy_full.cuda(), x.cuda(), w.cuda(), r_full, dx_full, None, False)
+    hip.rmsnorm_bwd_rows(dy.cuda(), x.cuda(), w.cuda(), rg.cuda(), slot.cuda(), dx_rows, None)      # the GPU's own rstd
+    torch.cuda.synchronize()
+    assert torch.equal(dx_full.cpu()[rows.long()], dx_rows.cpu()[rows.long()])
+
+
 # ------------------------------------------------------------------------------------------------ activations
 def test_swiglu_silu_relu(hip, fake):
     M, I = 77, 512

@@ -449,3 +449,19 @@ def test_generate_margin_cases_exact_on_the_double():
         model.forward_projector_text(st)
         toks = beam_search_generate(model, st, eos_token_id=geo.eos_id, pad_token_id=geo.eos_id, **c["kw"]).numpy()
         assert np.array_equal(toks, c["tokens"]), (n, toks, c["tokens"])
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_labelled_rows_loss_head_equals_full_materialisation(mid, ragged):
+    """keep_logits=False (the training step's throughput mode: final norm, lm_head, CE and lm_head dgrad over the labelled
+    positions only) against keep_logits=True (logits for every position): same loss, accuracy and count (up to the order the row
+    losses are summed in) and the same projector gradients up to fp32 summation order of the differently shaped GEMMs."""
+    geo, sd = mid
+    batch = synthetic_text_batch(geo, 3, seed=9, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12,
+                                 noise=True, drop_prob=0.1, ragged=ragged)
+    full, lean = build(geo, sd), build(geo, sd)
+    lean.keep_logits = False
+    sf, sl = run_text(full, batch), run_text(lean, batch)
+    assert sl.nL == int((sf.plan.shift_labels >= 0).sum()) and sl.nLp % 64 == 0 and lean.logits_view(sl) is None
+    torch.testing.assert_close(sf.dev["loss_out"], sl.dev["loss_out"], rtol=1e-6, atol=0)
+    assert float((full.proj.g - lean.proj.g).norm() / full.proj.g.norm()) < 5e-3     # bf16 roundings move with the summation order
