@@ -177,7 +177,7 @@ def test_full_size_step_properties(size):
     gsum /= tot_cnt
     cos = float(torch.nn.functional.cosine_similarity(gsum.flatten(), g.flatten(), dim=0))
     # two bf16 evaluations of the same gradient through 28 layers differ by ~3 % (rounding of dlogits / count differs)
-    assert cos > 0.998 and float((gsum - g).norm() / g.norm()) < 5e-2
+    assert cos > 0.998 and float((gsum - g).norm() / g.norm()) < (5e-2 if size == "1.5b" else 8e-2)
 
 
 # ------------------------------------------------------------------------------------------------ full-size encoder
