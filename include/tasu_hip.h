@@ -55,6 +55,13 @@ int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C
  * act[M, I] = bf16( bf16(silu(g)) * u ) -- bit-identical to tasu_gemm_nt_bf16 + tasu_swiglu_fwd.  I % 4 == 0.        */
 int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K,
                              void* stream);
+/* Split-K form of the NT GEMM for outputs too small to fill the chip behind a very long K (the lm_head dgrad over
+ * the labelled rows: [n_rows, 1536] outputs, K = padded vocabulary): partials[s] [M, ldc] fp32 = A[:, Ks] . B[:, Ks]^T
+ * for the ksplit contiguous K ranges (K % (64 * ksplit) == 0), written as ksplit consecutive [M, ldc] matrices;
+ * tasu_sum_slabs_bf16 adds them in slab order and rounds ONCE to bf16 (the rounding point of the unsplit GEMM). */
+int tasu_gemm_nt_bf16_splitk(const void* A, int lda, const void* B, int ldb, float* partials, int ldc, int M, int N, int K,
+                             int ksplit, void* stream);
+int tasu_sum_slabs_bf16(const float* slabs, int n_slabs, int64_t slab_stride, void* out_bf16, int64_t n, void* stream);
 
 /* Weight-streaming GEMM for M <= 64 rows (the decode step; transformers modeling_qwen2.py linears at one token per beam).
  * workspace: fp32 split-K slabs, 32 * 64 * round_up(N, 96) floats always suffice; may be NULL (no K split).  Launches
@@ -258,6 +265,24 @@ int tasu_attn_decode(const void* qkv, const void* kcache, const void* vcache, co
  * (MinLengthLogitsProcessor).  k in {1,2,4,6,8,16}.  workspace: M * 16 * (2 + 2k) floats (column-part partials).     */
 int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned,
                       float* out_val, int32_t* out_idx, float* workspace, int64_t workspace_floats, void* stream);
+/* One generated position of the beam search behind slam_model_asr.generate (ps-slm.py:660-675 -> HF
+ * GenerationMixin._beam_search, num_beams = n_beams, do_sample = False, early_stopping = False), entirely on the
+ * device: candidates = per-row top-2*n_beams log-probs (tasu_logprob_topk) + running scores; selection, finished-
+ * hypothesis heap (score / len^penalty via len_pow[t] = float32(t ** length_penalty)), HF's early-stop heuristic.
+ * State [B, n_beams]: run_scores, fin_scores, fin_len, fin_par, fin_tok, is_fin; unsat [B]; back-pointers
+ * bp_tok / bp_par [max_new, B, n_beams] (token and parent slot of every running beam per step; a finished
+ * hypothesis is (fin_len, fin_par, fin_tok) + the walk up the back-pointers).  ctl[0] = positions generated,
+ * ctl[1] = done (the call is then a no-op); done_host (optional, pinned host word) receives ctl[0] when done.
+ * Also writes the next step's inputs: token ids, cache source rows (beam reorder), position ids (valid[b] +
+ * t), cache slots S + t, lengths, and banned[0] = eos while the next position is below min_length else -1.
+ * first = 1: vals / idx hold B rows (the prompt's last position); beams >= 1 do not exist yet.  B <= 256,
+ * n_beams <= 5.                                                                                              */
+int tasu_beam_update(const float* vals, const int32_t* idx, float* run_scores, float* fin_scores, int32_t* fin_len,
+                     int32_t* fin_par, int32_t* fin_tok, int32_t* is_fin, int32_t* unsat, int32_t* bp_tok,
+                     int32_t* bp_par, const float* len_pow, int32_t* ctl, int32_t* done_host, const int32_t* valid,
+                     int32_t* next_ids, int32_t* next_src, int32_t* next_pos, int32_t* next_slot, int32_t* next_lens,
+                     int32_t* banned, int B, int n_beams, int max_new, int eos, int min_length, int S, int first,
+                     void* stream);
 /* x[m,:] = table[ids[m],:] (fp32 embedding rows of the last generated tokens). */
 int tasu_embed_rows(const float* table, const int32_t* ids, float* x, int M, int D, void* stream);
 

@@ -379,6 +379,193 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------- beam bookkeeping
+// One generated position of HF ``generate(num_beams = nb, do_sample = False, early_stopping = False)`` (transformers
+// generation/utils.py ``_beam_search``; restated in oracle/tasu_oracle.py::beam_search_generate and, vectorised, in
+// ps_slm_amd/decode.py::BeamState, which this kernel reproduces decision for decision): thread b owns utterance b.
+//   candidates  = per-row top-K log-probs (K = 2 nb) + the running score of their beam;
+//   top K       by (score desc, beam asc, token asc) -- the order of a flattened [nb * V] top-k;
+//   running     = the first nb candidates that neither are EOS nor reach max_new (their score otherwise + NEG);
+//   finished    = candidates among the first nb that stop compete with the kept ones on score / len^penalty;
+//   done        = no utterance can still improve (HF's heuristic on the best running score) or every candidate stopped.
+// Sequences are not copied: every step records (token, parent slot) of the running beams in bp_tok / bp_par
+// [step][b][slot], a finished hypothesis keeps (last step, parent slot, last token), and the host walks the back-pointers
+// once at the end.  The kernel also writes the NEXT step's device inputs (token ids, cache source rows for the beam
+// reorder, position ids, cache slots, lengths, the EOS ban while cur < min_length), so the whole decode step replays as one
+// hipGraph with no host round trip; ctl[0] = positions generated so far, ctl[1] = done (then the kernel is a no-op).
+constexpr float BEAM_NEG = -1.0e9f;
+constexpr int BEAM_MAX_NB = 5;          // nb * 2 nb candidates must fit the 64-bit `used` mask below
+struct BeamArgs {
+  const float* vals;          // [B * nb, K] (first call: [B, K], beams >= 1 absent)
+  const int32_t* idx;
+  float* run_scores;          // [B, nb]
+  float* fin_scores;          // [B, nb]
+  int32_t* fin_len;           // [B, nb]
+  int32_t* fin_par;           // [B, nb]   parent slot (running set of the previous step) of a kept finished hypothesis
+  int32_t* fin_tok;           // [B, nb]   its last token
+  int32_t* is_fin;            // [B, nb]
+  int32_t* unsat;             // [B]
+  int32_t* bp_tok;            // [max_new, B, nb]
+  int32_t* bp_par;            // [max_new, B, nb]
+  const float* len_pow;       // [max_new + 2]: float32(t ** length_penalty)
+  int32_t* ctl;               // [0] cur, [1] done
+  int32_t* done_host;         // optional pinned host word mirroring ctl[1]
+  const int32_t* valid;       // [B] real (unpadded) prompt length
+  int32_t* next_ids;          // [B * nb]
+  int32_t* next_src;
+  int32_t* next_pos;
+  int32_t* next_slot;
+  int32_t* next_lens;
+  int32_t* banned;            // [1]: eos while the next position is still below min_length, else -1
+  int B, nb, max_new, eos, min_length, S, first;
+};
+
+__global__ __launch_bounds__(256) void beam_update_kernel(BeamArgs p) {
+  __shared__ int s_unsat_any, s_stop_all;
+  const int b = threadIdx.x;
+  const int nb = p.nb, K = 2 * nb;
+  const int cur = p.ctl[0];
+  if (p.ctl[1]) return;                                   // finished earlier: leave every output as it is
+  if (threadIdx.x == 0) {
+    s_unsat_any = 0;
+    s_stop_all = 1;
+  }
+  __syncthreads();
+  if (b < p.B) {
+    // ---- candidates
+    float cs[2 * BEAM_MAX_NB * BEAM_MAX_NB];
+    int ct[2 * BEAM_MAX_NB * BEAM_MAX_NB];
+    for (int j = 0; j < nb; ++j) {
+      const float rs = p.run_scores[b * nb + j];
+      for (int k = 0; k < K; ++k) {
+        float v = BEAM_NEG;
+        int t = 0;
+        if (!p.first || j == 0) {
+          const size_t row = p.first ? (size_t)b : (size_t)b * nb + j;
+          v = p.vals[row * K + k];
+          t = p.idx[row * K + k];
+        }
+        cs[j * K + k] = v + rs;
+        ct[j * K + k] = t;
+      }
+    }
+    // ---- top K by (score desc, beam asc, token asc)
+    float top_lp[2 * BEAM_MAX_NB];
+    int tok[2 * BEAM_MAX_NB], beam[2 * BEAM_MAX_NB];
+    unsigned long long used = 0ull;
+    for (int r = 0; r < K; ++r) {
+      int best = -1;
+      for (int c = 0; c < nb * K; ++c) {
+        if ((used >> c) & 1ull) continue;
+        if (best < 0) {
+          best = c;
+          continue;
+        }
+        const int bj = best / K, cj = c / K;
+        if (cs[c] > cs[best] || (cs[c] == cs[best] && (cj < bj || (cj == bj && ct[c] < ct[best])))) best = c;
+      }
+      used |= 1ull << best;
+      top_lp[r] = cs[best];
+      tok[r] = ct[best];
+      beam[r] = best / K;
+    }
+    // ---- running beams of the next step: stable top nb of run_lp
+    bool stop[2 * BEAM_MAX_NB];
+    float run_lp[2 * BEAM_MAX_NB];
+    bool all_stop = true;
+    for (int i = 0; i < K; ++i) {
+      stop[i] = tok[i] == p.eos || cur + 1 >= p.max_new;
+      all_stop = all_stop && stop[i];
+      run_lp[i] = top_lp[i] + (stop[i] ? BEAM_NEG : 0.f);
+    }
+    unsigned taken = 0u;
+    float new_rs[BEAM_MAX_NB];
+    for (int n = 0; n < nb; ++n) {
+      int best = -1;
+      for (int i = 0; i < K; ++i) {
+        if ((taken >> i) & 1u) continue;
+        if (best < 0 || run_lp[i] > run_lp[best]) best = i;          // strict >: the earlier index wins ties (stable)
+      }
+      taken |= 1u << best;
+      new_rs[n] = run_lp[best];
+      const size_t o = ((size_t)cur * p.B + b) * nb + n;
+      p.bp_tok[o] = tok[best];
+      p.bp_par[o] = beam[best];
+      const int m = b * nb + n;
+      p.next_ids[m] = tok[best];
+      p.next_src[m] = b * nb + beam[best];
+      p.next_pos[m] = p.valid[b] + cur;
+      p.next_slot[m] = p.S + cur;
+      p.next_lens[m] = p.S + cur + 1;
+    }
+    // ---- finished hypotheses: stable top nb of [kept | new]
+    const bool unsat = p.unsat[b] != 0;
+    float m_sc[3 * BEAM_MAX_NB];
+    int m_len[3 * BEAM_MAX_NB], m_par[3 * BEAM_MAX_NB], m_tok[3 * BEAM_MAX_NB], m_fin[3 * BEAM_MAX_NB];
+    for (int j = 0; j < nb; ++j) {
+      m_sc[j] = p.fin_scores[b * nb + j];
+      m_len[j] = p.fin_len[b * nb + j];
+      m_par[j] = p.fin_par[b * nb + j];
+      m_tok[j] = p.fin_tok[b * nb + j];
+      m_fin[j] = p.is_fin[b * nb + j];
+    }
+    const float lp_now = p.len_pow[cur + 1];
+    for (int i = 0; i < K; ++i) {
+      const bool just = stop[i] && i < nb;
+      float sc = top_lp[i] / lp_now;
+      sc = sc + (unsat ? 0.f : BEAM_NEG);
+      sc = sc + (just ? 0.f : BEAM_NEG);
+      m_sc[nb + i] = sc;
+      m_len[nb + i] = cur + 1;
+      m_par[nb + i] = beam[i];
+      m_tok[nb + i] = tok[i];
+      m_fin[nb + i] = just ? 1 : 0;
+    }
+    unsigned kept = 0u;
+    float f_sc[BEAM_MAX_NB];
+    int f_fin[BEAM_MAX_NB];
+    int order[BEAM_MAX_NB];
+    for (int n = 0; n < nb; ++n) {
+      int best = -1;
+      for (int i = 0; i < nb + K; ++i) {
+        if ((kept >> i) & 1u) continue;
+        if (best < 0 || m_sc[i] > m_sc[best]) best = i;
+      }
+      kept |= 1u << best;
+      order[n] = best;
+      f_sc[n] = m_sc[best];
+      f_fin[n] = m_fin[best];
+    }
+    float min_fin = f_sc[0];
+    for (int n = 0; n < nb; ++n) {
+      const int i = order[n];
+      p.fin_scores[b * nb + n] = m_sc[i];
+      p.fin_len[b * nb + n] = m_len[i];
+      p.fin_par[b * nb + n] = m_par[i];
+      p.fin_tok[b * nb + n] = m_tok[i];
+      p.is_fin[b * nb + n] = m_fin[i];
+      p.run_scores[b * nb + n] = new_rs[n];
+      min_fin = fminf(min_fin, f_sc[n]);
+    }
+    // ---- can a running beam still beat the worst kept hypothesis?
+    const float best_run = new_rs[0] / lp_now;           // the new cur is cur + 1: the same power
+    bool improve = false;
+    for (int n = 0; n < nb; ++n) improve = improve || best_run > (f_fin[n] ? min_fin : BEAM_NEG);
+    const bool still = unsat && improve;
+    p.unsat[b] = still ? 1 : 0;
+    if (still) atomicOr(&s_unsat_any, 1);
+    if (!all_stop) atomicAnd(&s_stop_all, 0);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int done = !(s_unsat_any && !s_stop_all);
+    p.ctl[0] = cur + 1;
+    p.ctl[1] = done;
+    p.banned[0] = (cur + 1 < p.min_length) ? p.eos : -1;
+    if (p.done_host) __hip_atomic_store(p.done_host, done ? cur + 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // x[m,:] = table[ids[m], :]  (fp32 embedding rows for the decode step)
 __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
                                                          float* __restrict__ x, int M, int D) {
@@ -479,5 +666,22 @@ extern "C" int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k
 extern "C" int tasu_embed_rows(const float* table, const int32_t* ids, float* x, int M, int D, void* stream) {
   if (!table || !ids || !x || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
   TASU_LAUNCH(embed_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ids, x, M, D);
+  return TASU_OK;
+}
+
+extern "C" int tasu_beam_update(const float* vals, const int32_t* idx, float* run_scores, float* fin_scores, int32_t* fin_len,
+                                int32_t* fin_par, int32_t* fin_tok, int32_t* is_fin, int32_t* unsat, int32_t* bp_tok,
+                                int32_t* bp_par, const float* len_pow, int32_t* ctl, int32_t* done_host, const int32_t* valid,
+                                int32_t* next_ids, int32_t* next_src, int32_t* next_pos, int32_t* next_slot, int32_t* next_lens,
+                                int32_t* banned, int B, int n_beams, int max_new, int eos, int min_length, int S, int first,
+                                void* stream) {
+  if (!vals || !idx || !run_scores || !fin_scores || !fin_len || !fin_par || !fin_tok || !is_fin || !unsat || !bp_tok || !bp_par ||
+      !len_pow || !ctl || !valid || !next_ids || !next_src || !next_pos || !next_slot || !next_lens || !banned)
+    return TASU_ERR_ARG;
+  if (B <= 0 || B > 256 || n_beams <= 0 || n_beams > BEAM_MAX_NB || max_new <= 0 || S <= 0) return TASU_ERR_ARG;
+  BeamArgs a{vals, idx, run_scores, fin_scores, fin_len, fin_par, fin_tok, is_fin, unsat, bp_tok, bp_par, len_pow, ctl,
+             done_host, valid, next_ids, next_src, next_pos, next_slot, next_lens, banned, B, n_beams, max_new, eos,
+             min_length, S, first};
+  TASU_LAUNCH(beam_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   return TASU_OK;
 }

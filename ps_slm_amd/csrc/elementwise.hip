@@ -110,6 +110,16 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restri
   }
 }
 
+// y = bf16(slab_0 + slab_1 + ... ) in slab order (the finish of a split-K GEMM: fp32 partial sums, ONE rounding).  n % 4 == 0.
+__global__ void sum_slabs_bf16_kernel(const float* __restrict__ slabs, int n_slabs, int64_t stride, bf16* __restrict__ y, int64_t n) {
+  const int64_t nv = n / 4;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 a = *(const f32x4*)(slabs + v * 4);
+    for (int s = 1; s < n_slabs; ++s) a += *(const f32x4*)(slabs + (size_t)s * stride + v * 4);
+    *(bf16x4*)(y + v * 4) = __builtin_convertvector(a, bf16x4);
+  }
+}
+
 // out[c][r] = in[r][c] for r < R, c < C; zero for the padding region up to (Cpad rows, Rpad cols) of out.
 // 64x64 tiles through LDS; grid (ceil(Rpad/64), ceil(Cpad/64)).
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ in, int ld_in, bf16* __restrict__ out,
@@ -204,5 +214,11 @@ extern "C" int tasu_transpose_bf16(const void* in, int ld_in, void* out, int ld_
   dim3 grid((Rpad + 63) / 64, (Cpad + 63) / 64);
   TASU_LAUNCH(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)in, ld_in, (bf16*)out,
                      ld_out, R, C, Rpad, Cpad);
+  return TASU_OK;
+}
+extern "C" int tasu_sum_slabs_bf16(const float* slabs, int n_slabs, int64_t slab_stride, void* out, int64_t n, void* stream) {
+  if (!slabs || !out || n_slabs < 1 || n <= 0 || n % 4 || slab_stride < n || slab_stride % 4) return TASU_ERR_ARG;
+  TASU_LAUNCH(sum_slabs_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, slab_stride,
+              (bf16*)out, n);
   return TASU_OK;
 }

@@ -42,6 +42,10 @@ struct Args {
   int lda, ldb, ldc;
   int tiles_m, tiles_n;
   bf16* act;            // OUT_GU_SWIGLU: act[M, N] (N = I); C = gate|up [M, 2N]; B = Wgu [2N, K], gate rows first
+  // split-K (TASU_GEMM_OUT_F32 only): work item s covers K range [ks * K/ksplit, +K/ksplit) of output tile s % (tiles_m *
+  // tiles_n), ks = s / (tiles_m * tiles_n), and writes its fp32 partial tile into slab ks (C + ks * split_stride floats)
+  int ksplit;
+  long long split_stride;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -82,8 +86,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
   const int wave = wave_id & 3;                    // staging share (loader) / tile quadrant (MFMA wave)
-  const int nk = p.K / BK;
-  const int ntiles = p.tiles_m * p.tiles_n;
+  const int nk = p.K / BK / p.ksplit;              // K-steps per work item
+  const int base_tiles = p.tiles_m * p.tiles_n;
+  const int ntiles = base_tiles * p.ksplit;
   const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   [[maybe_unused]] const int total = my_tiles * nk;  // K-steps this workgroup walks, across all its tiles
 
@@ -95,15 +100,17 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
     int ld_tile = blockIdx.x, ld_k = 0;            // load cursor (runs two K-steps ahead of the MFMA waves)
     auto setup = [&](int s) {
       int tm, tn;
-      tile_coords(p, s, ntiles, tm, tn);
+      const int ks = s / base_tiles;
+      tile_coords(p, s - ks * base_tiles, base_tiles, tm, tn);
       const int row0 = tm * BM, col0 = tn * BN;
+      const size_t kbase = (size_t)ks * nk * BK;    // first K element of this work item
       // both descriptors start 3 KiB below the tile: the per-lane offsets carry +3 KiB minus the immediate offset of their
       // piece (issue()), which keeps every register offset non-negative
-      rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(p.A + (size_t)row0 * p.lda) - 3072), 0, 0x7fffffff, 0x00020000);
+      rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(p.A + (size_t)row0 * p.lda + kbase) - 3072), 0, 0x7fffffff, 0x00020000);
       // OUT_GU_SWIGLU: the tile's 128 weight rows are, per 64-row half (= one MFMA wave column), 32 gate rows and the 32 up
       // rows of the same output columns; the descriptor then starts at the weight matrix itself
       const int brow0 = OUT_MODE == OUT_GU_SWIGLU ? 0 : col0;
-      rsB = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(p.B + (size_t)brow0 * p.ldb) - 3072), 0, 0x7fffffff, 0x00020000);
+      rsB = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(p.B + (size_t)brow0 * p.ldb + kbase) - 3072), 0, 0x7fffffff, 0x00020000);
       // piece pc = 8 tile rows x 128 B; lane l -> tile row pc*8 + (l>>3), LDS chunk l&7 <- global chunk (l&7)^((row>>1)&7)
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
@@ -497,9 +504,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   using T = std::true_type;
   using F = std::false_type;
   int cur = 0;                                     // ring slot of the current step
+  void* const c_first = p.C;
   for (int s = blockIdx.x; s < ntiles; s += gridDim.x) {
     int tm, tn;
-    tile_coords(p, s, ntiles, tm, tn);
+    const int ks = s / base_tiles;
+    tile_coords(p, s - ks * base_tiles, base_tiles, tm, tn);
+    if constexpr (OUT_MODE == TASU_GEMM_OUT_F32) p.C = (float*)c_first + (size_t)ks * p.split_stride;   // slab of this K range
     for (int kt = 0; kt + 1 < nk; ++kt) cur = kstep(T{}, cur);
     cur = kstep(F{}, cur);                         // no read-ahead into the next tile: the fragment registers are free
     if constexpr (OUT_MODE == OUT_GU_SWIGLU) store_gu_swiglu(tm * BM, tn);
@@ -532,7 +542,7 @@ int launch(Args a, hipStream_t st) {
   }
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = OUT_MODE == OUT_GU_SWIGLU ? (a.N + 63) / 64 : (a.N + BN - 1) / BN;
-  const int ntiles = a.tiles_m * a.tiles_n;
+  const int ntiles = a.tiles_m * a.tiles_n * a.ksplit;
   const int grid = ntiles < cu_count() ? ntiles : cu_count();
   TASU_LAUNCH((gemm_pipe_kernel<BM, BN, OUT_MODE, HAS_BIAS>), dim3(grid), dim3(512), LDS, st, a);
   return TASU_OK;
@@ -565,6 +575,8 @@ int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void
   a.ldc = ldc;
   a.tiles_m = a.tiles_n = 0;
   a.act = nullptr;
+  a.ksplit = 1;
+  a.split_stride = 0;
   const bool hb = bias != nullptr;
   switch (out_mode) {
     case TASU_GEMM_OUT_BF16:
@@ -598,5 +610,36 @@ extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu,
   a.ldc = 2 * I;
   a.tiles_m = a.tiles_n = 0;
   a.act = (bf16*)act;
+  a.ksplit = 1;
+  a.split_stride = 0;
   return launch<256, 128, OUT_GU_SWIGLU, false>(a, (hipStream_t)stream);
+}
+
+// ---- split-K form for grids that would leave most CUs idle behind a very long K (the lm_head dgrad over the labelled rows
+// of a batch: 2048 x 1536 outputs, K = 151,936): ksplit fp32 partial matrices, summed by tasu_sum_slabs_bf16.
+extern "C" int tasu_gemm_nt_bf16_splitk(const void* A, int lda, const void* B, int ldb, float* partials, int ldc, int M, int N,
+                                        int K, int ksplit, void* stream) {
+  using namespace tasu_pipe;
+  if (!A || !B || !partials || M <= 0 || N <= 0 || K <= 0 || ksplit < 1 || ksplit > 16 || K % (BK * ksplit) || lda % 8 || ldb % 8 ||
+      ldc < N)
+    return TASU_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)partials & 15)) return TASU_ERR_ARG;
+  if ((((size_t)K / ksplit) * 2) % 16) return TASU_ERR_ARG;     // every K range starts 16-byte aligned
+  Args a;
+  a.A = (const bf16*)A;
+  a.B = (const bf16*)B;
+  a.C = partials;
+  a.R = nullptr;
+  a.bias = nullptr;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.lda = lda;
+  a.ldb = ldb;
+  a.ldc = ldc;
+  a.tiles_m = a.tiles_n = 0;
+  a.act = nullptr;
+  a.ksplit = ksplit;
+  a.split_stride = (long long)M * ldc;
+  return launch<128, 192, TASU_GEMM_OUT_F32, false>(a, (hipStream_t)stream);
 }

@@ -1,21 +1,25 @@
 """Decode loop of ``slam_model_asr.generate`` (Multitask/model/ps-slm.py:539-677) on the gfx950 kernels: prefill with
 the training forward kernels, then one single-token step per generated position with a per-beam KV cache.  The beam
 bookkeeping of HF ``generate(num_beams=4, do_sample=False, early_stopping=False)`` (transformers generation/utils.py
-``_beam_search``; dependency not in the reference tree) is restated on the host in numpy: per step the device returns,
-for each of the B*nb live rows, its 2*nb best log-probs (tasu_logprob_topk) -- a superset of the batch's 2*nb best
-continuations -- and the host does the (tiny) selection, finished-beam heap and early-stop heuristic.
+``_beam_search``; dependency not in the reference tree) runs ON THE DEVICE (``tasu_beam_update``: selection among the
+rows' 2*nb best log-probs, finished-hypothesis heap, early-stop heuristic, and the next step's token ids / cache rows /
+positions), so a generated position is ONE hipGraph replay with no host round trip; the host only polls a pinned
+"done" word a couple of steps behind the device and walks the back-pointers once at the end.  ``BeamState`` is the
+vectorised host restatement of the same bookkeeping (tests pin it against the oracle's loop, and the kernel against it).
 
-Device per step (M = B*nb rows): embedding rows -> 28 x [RMSNorm, qkv GEMM, RoPE, KV append, cache attention, o GEMM +
-residual, RMSNorm, gate|up GEMM, SwiGLU, down GEMM + residual] -> RMSNorm -> lm_head GEMM -> log-softmax top-k ->
-beam reorder of the cache's row index.  HBM-bound: every step streams the bf16 weights once; the ~430 launches of a step
-are replayed as one hipGraph (``model.decode_graphs``, on by default on the GPU).
+Device per step (M = B*nb rows): beam reorder of the cache's row index -> embedding rows -> 28 x [RMSNorm, qkv GEMM, RoPE,
+KV append, cache attention, o GEMM + residual, RMSNorm, gate|up GEMM, SwiGLU, down GEMM + residual] -> RMSNorm -> lm_head
+GEMM -> log-softmax top-k -> beam update.  HBM-bound: every step streams the bf16 weights once.
 """
+import collections
+
 import numpy as np
 import torch
 
 from .model import HD, StepState, rup
 
 NEG = -1.0e9
+DECODE_GRAPH_CACHE = 8   # decode-step graphs kept per model (LRU)
 
 
 class BeamState:
@@ -85,6 +89,61 @@ class BeamState:
         return self.fin_seq[:, 0, :n]
 
 
+class DeviceBeam:
+    """Device-resident beam-search state + the next step's inputs (the arguments of ``tasu_beam_update``)."""
+
+    def __init__(self, model, B, nb, max_new, eos, length_penalty, min_length, S, valid):
+        self.B, self.nb, self.max_new, self.eos, self.min_length, self.S = B, nb, max_new, int(eos), int(min_length), S
+        up, buf = model._upload, model._buf
+        M = B * nb
+        i32 = torch.int32
+        rs = np.zeros((B, nb), dtype=np.float32)
+        rs[:, 1:] = NEG
+        self.run_scores = up("bm_run", rs)
+        self.fin_scores = up("bm_fin", np.full((B, nb), NEG, dtype=np.float32))
+        zeros = np.zeros((B, nb), dtype=np.int32)
+        self.fin_len, self.fin_par = up("bm_flen", zeros), up("bm_fpar", zeros)
+        self.fin_tok, self.is_fin = up("bm_ftok", zeros), up("bm_isfin", zeros)
+        self.unsat = up("bm_unsat", np.ones(B, dtype=np.int32))
+        self.bp_tok = buf("bm_bptok", (max_new, B, nb), i32)
+        self.bp_par = buf("bm_bppar", (max_new, B, nb), i32)
+        # float32(t ** length_penalty) exactly as the host restatement computes it (python float power, then one rounding)
+        self.len_pow = up("bm_lenpow", np.array([np.float32(float(t) ** float(length_penalty)) for t in range(max_new + 2)],
+                                                dtype=np.float32))
+        self.ctl = up("bm_ctl", np.zeros(2, dtype=np.int32))
+        self.valid = up("bm_valid", np.asarray(valid, dtype=np.int32))
+        self.next_ids, self.next_src = buf("in_dec_ids", (M,), i32), buf("in_dec_src", (M,), i32)
+        self.next_pos, self.next_slot, self.next_lens = buf("in_dec_pos", (M,), i32), buf("in_dec_slot", (M,), i32), buf("in_dec_lens", (M,), i32)
+        self.banned = up("dec_banned", np.array([eos if min_length > 0 else -1], dtype=np.int32))
+        self.done_host = None
+        if model.device.type == "cuda":
+            if getattr(model, "_done_host", None) is None:
+                model._done_host = torch.zeros(1, dtype=i32).pin_memory()
+            self.done_host = model._done_host
+            self.done_host.zero_()
+
+    def result(self, pad):
+        """Walks the back-pointers of every utterance's best finished hypothesis -> LongTensor [B, n_new] (CPU)."""
+        flen = self.fin_len.cpu().numpy()[:, 0]
+        fpar, ftok = self.fin_par.cpu().numpy()[:, 0], self.fin_tok.cpu().numpy()[:, 0]
+        bpt, bpp = self.bp_tok.cpu().numpy(), self.bp_par.cpu().numpy()
+        n = int(flen.max())
+        out = np.full((self.B, n), pad, dtype=np.int64)
+        for b in range(self.B):
+            t = int(flen[b]) - 1
+            if t < 0:
+                continue
+            out[b, t] = ftok[b]
+            slot = int(fpar[b])
+            for u in range(t - 1, -1, -1):
+                out[b, u] = bpt[u, b, slot]
+                slot = int(bpp[u, b, slot])
+        return torch.from_numpy(out)
+
+
+DONE_POLL_DEPTH = 2      # generated positions the device may run ahead of the host's look at the "done" word
+
+
 def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, min_length=1, length_penalty=1.0,
                          eos_token_id=None, pad_token_id=None):
     """st: a prepared state whose projector output (st.dev['y2']) is ready.  Returns LongTensor [B, n_new] (CPU)."""
@@ -125,14 +184,9 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     ops.gemm(xn, llm.head, logits, B, V, D)
     tv = buf("dec_topv", (M, K), f32)
     ti = buf("dec_topi", (M, K), i32)
-    banned = model._upload("dec_banned", np.array([eos], dtype=np.int32))
-    state = BeamState(B, nb, max_new_tokens, eos, pad, length_penalty, min_length)
-    ops.logprob_topk(logits, B, V, K, banned, 1 if state.ban_eos() else 0, tv, ti)
-    v0, i0 = tv[:B].cpu().numpy(), ti[:B].cpu().numpy()
-    vals = np.full((B, nb, K), NEG, dtype=np.float32)                      # beams 1.. start at -1e9 (HF init)
-    idx = np.zeros((B, nb, K), dtype=np.int64)
-    vals[:, 0], idx[:, 0] = v0, i0
-    tok, parent = state.update(vals, idx)
+    bs = DeviceBeam(model, B, nb, max_new_tokens, eos, length_penalty, min_length, S, valid)
+    ops.logprob_topk(logits, B, V, K, bs.banned, 1, tv, ti)
+    ops.beam_update(tv, ti, bs, True)                                      # first position: only beam 0 exists
     x = buf("dec_x", (M, D), f32)
     x2 = buf("dec_x2", (M, D), f32)
     qkv = buf("dec_qkv", (M, LDQ), bf)
@@ -141,21 +195,17 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     cos = buf("dec_cos", (M, HD // 2), f32)
     sin = buf("dec_sin", (M, HD // 2), f32)
     ws = buf("dec_gemm_ws", (32 * 64 * rup(max(V, 2 * I), 96),), f32)          # tasu_gemm_skinny_bf16 split-K slabs
-    # per-step device inputs live in fixed buffers so that the step can be replayed as a hipGraph
-    ids_d = buf("in_dec_ids", (M,), i32)
-    pos_d = buf("in_dec_pos", (M,), i32)
-    slot_d = buf("in_dec_slot", (M,), i32)
-    lens_d = buf("in_dec_lens", (M,), i32)
-    src_d = buf("in_dec_src", (M,), i32)
+    # per-step device inputs live in fixed buffers (written by tasu_beam_update) so that the step replays as a hipGraph
+    ids_d, pos_d, slot_d, lens_d, src_d = bs.next_ids, bs.next_pos, bs.next_slot, bs.next_lens, bs.next_src
 
     # The weight-streaming kernels take at most 64 rows: more beams than that (B > 16 at 4 beams) run them in row chunks
     # (the weights are then streamed once per chunk; K/V, attention and top-k are not chunked).
     chunks = [(m0, min(64, M - m0)) for m0 in range(0, M, 64)]
     kcv, vcv = kc.view(L, M, ctx * W), vc.view(L, M, ctx * W)
 
-    def device_step(ban):
+    def device_step():
         """One generated position for all M beams: beam reorder of the row index (parents of the previous step), then the
-        28-layer single-token pass over the cache, lm_head and the per-row top-k."""
+        28-layer single-token pass over the cache, lm_head, the per-row top-k and the beam update."""
         ops.kv_index_reorder(index, index_tmp, src_d, slot_d, M, ctx)
         ops.kv_index_reorder(index_tmp, index, None, slot_d, M, ctx)
         ops.embed_rows(llm.embed, ids_d, x, M, D)
@@ -175,43 +225,56 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
                 ops.gemm_skinny_norm(act[r], w["wd"], x[r], x2[r], mc, D, I, next_norm, xn[r], geo.rms_eps, ws)
         for m0, mc in chunks:
             ops.gemm_skinny(xn[m0:m0 + mc], llm.head, logits[m0:m0 + mc], mc, V, D, ws)
-        ops.logprob_topk(logits, M, V, K, banned, ban, tv, ti)
+        ops.logprob_topk(logits, M, V, K, bs.banned, 1, tv, ti)
+        ops.beam_update(tv, ti, bs, False)
 
     # hipGraph replay of device_step (~430 launches): the first step of a shape runs eagerly, the second is captured.
-    # A graph is only valid for the buffers it was captured on, so the key carries their addresses.
+    # A graph is only valid for the buffers it was captured on (grow-only workspace: same generation = same addresses) and
+    # for the scalars baked into its kernel arguments; a small LRU bounds the cache (real data gives almost every batch its
+    # own prompt length).
     use_graphs = model.decode_graphs and model.device.type == "cuda"
     graphs, seen_cnt = model._dec_graphs, model._dec_seen
+    key = ("decode", B, S, nb, ctx, max_new_tokens, int(eos), int(min_length), model._buf_gen)
 
-    def run_step(ban):
+    def run_step():
         if not use_graphs:
-            return device_step(ban)
-        key = ("decode", B, S, nb, ctx, ban, model._buf_gen)    # buffers are grow-only: same generation = same addresses
+            return device_step()
         for old in [k for k in graphs if k[-1] != model._buf_gen]:
             del graphs[old]                                      # captured on addresses that have since been freed
+            seen_cnt.pop(old, None)
         g = graphs.get(key)
         if g is not None:
+            graphs.move_to_end(key)
             return g.replay()
         seen = seen_cnt.get(key, 0)
         seen_cnt[key] = seen + 1
         if seen < 1:
-            return device_step(ban)
+            return device_step()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            device_step(ban)
+            device_step()
         graphs[key] = g
+        while len(graphs) > DECODE_GRAPH_CACHE:
+            old, _ = graphs.popitem(last=False)
+            seen_cnt.pop(old, None)
         g.replay()
 
-    while not state.done:
-        t = state.cur                                                       # tokens generated so far (>= 1)
-        src = (np.arange(B)[:, None] * nb + parent).reshape(-1).astype(np.int32)
-        ids_d.copy_(torch.from_numpy(tok.reshape(-1).astype(np.int32)), non_blocking=True)
-        pos_d.copy_(torch.from_numpy(np.repeat(valid + t - 1, nb).astype(np.int32)), non_blocking=True)   # position id of the new token
-        slot_d.copy_(torch.from_numpy(np.full(M, S + t - 1, dtype=np.int32)), non_blocking=True)           # its cache slot
-        lens_d.copy_(torch.from_numpy(np.full(M, S + t, dtype=np.int32)), non_blocking=True)
-        src_d.copy_(torch.from_numpy(src), non_blocking=True)                                              # parents of the last update
-        run_step(1 if state.ban_eos() else 0)
-        vals = tv.cpu().numpy().reshape(B, nb, K)                           # one small D2H sync per step
-        idx = ti.cpu().numpy().reshape(B, nb, K).astype(np.int64)
-        tok, parent = state.update(vals, idx)
-    return torch.from_numpy(state.result())
+    if model.device.type == "cuda":
+        # the host issues positions ahead of the device and looks at the pinned "done" word DONE_POLL_DEPTH positions late
+        # (an event per position); positions issued after the device finished are no-ops for the beam state
+        inflight = collections.deque()
+        for _ in range(max_new_tokens - 1):
+            run_step()
+            ev = torch.cuda.Event()
+            ev.record()
+            inflight.append(ev)
+            if len(inflight) > DONE_POLL_DEPTH:
+                inflight.popleft().synchronize()
+                if int(bs.done_host[0]):
+                    break
+        torch.cuda.synchronize()
+    else:
+        while not int(bs.ctl[1]):
+            run_step()
+    return bs.result(pad)

@@ -21,6 +21,7 @@ HBM layout (sized for 288 GB: everything stays resident, nothing is recomputed):
     dimension is padded to a multiple of 64 with zeros (pad columns provably stay zero under AdamW).
   * per layer saved for backward: x_in, x_mid (fp32), rstd1/2, rotated qkv, Q^T/K^T, attention out, lse, gate|up.
 """
+import collections
 import math
 from dataclasses import dataclass, field
 
@@ -247,7 +248,8 @@ class TasuModel:
         self._graphs = {}
         self._graph_seen = {}
         self._buf_gen = 0              # bumped whenever a named workspace buffer is re-allocated (grown)
-        self._dec_graphs, self._dec_seen = {}, {}   # decode-step graphs (ps_slm_amd/decode.py), keyed by shape + _buf_gen
+        self._dec_graphs, self._dec_seen = collections.OrderedDict(), {}   # decode-step graphs (ps_slm_amd/decode.py): small LRU
+        self._done_host = None         # pinned "decode finished" word the beam-update kernel writes
 
     # ------------------------------------------------------------------------------------------ weights
     def load_reference_state_dict(self, sd):
@@ -544,7 +546,17 @@ class TasuModel:
         # lm_head dgrad (K = Vpad: dlogits pad columns are zero) and final norm
         if d.get("labelled_only"):
             dn_c = self._buf("dn_lab", (st.nLp, D), bf)
-            ops.gemm(d["dlogits"], llm.head_t, dn_c, st.nLp, D, Vp)
+            # [nLp, D] outputs in 128 x 192 tiles behind K = Vp: when they cover at most half of the 256 CUs the K range is
+            # split so that every CU works (2048 labelled rows x 1536: 128 tiles x 2 ranges)
+            tiles = ((st.nLp + 127) // 128) * ((D + 191) // 192)
+            ksplit = max(1, min(256 // tiles, 8))
+            while ksplit > 1 and Vp % (64 * ksplit):
+                ksplit -= 1
+            if ksplit > 1 and D % 4 == 0:
+                ws = self._buf("dn_lab_slabs", (ksplit, st.nLp, D), f32)
+                ops.gemm_splitk(d["dlogits"], llm.head_t, dn_c, st.nLp, D, Vp, ksplit, ws)
+            else:
+                ops.gemm(d["dlogits"], llm.head_t, dn_c, st.nLp, D, Vp)
             ops.rmsnorm_bwd_rows(dn_c, xs[2 * L], llm.norm, d["rstd_lab"], d["lab_slot"], dx, dxb)
         else:
             ops.gemm(d["dlogits"], llm.head_t, dn, M, D, Vp)

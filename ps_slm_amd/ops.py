@@ -53,6 +53,13 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_nt_bf16_ws(_p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), _p(resid), M, N, K, mode,
                                                 _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()), "tasu_gemm_nt_bf16_ws")
 
+    def gemm_splitk(self, a, b, c, M, N, K, ksplit, ws):
+        """c[M,N] (bf16) = a[M,K] @ b[N,K]^T with the K range cut into ``ksplit`` work items per output tile (fp32 partial
+        matrices in ``ws``, summed in order, one bf16 rounding): for outputs that cannot fill the chip behind a very long K."""
+        self._chk(self.lib.tasu_gemm_nt_bf16_splitk(_p(a), a.stride(0), _p(b), b.stride(0), _p(ws), N, M, N, K, ksplit,
+                                                    self._stream()), "tasu_gemm_nt_bf16_splitk")
+        self._chk(self.lib.tasu_sum_slabs_bf16(_p(ws), ksplit, M * N, _p(c), M * N, self._stream()), "tasu_sum_slabs_bf16")
+
     def gemm_gate_up_swiglu(self, a, wgu, gu, act, M, I, K):
         """gu[M,2I] = a @ wgu^T and act[M,I] = swiglu(gu) in one launch (training step)."""
         self._chk(self.lib.tasu_gemm_gate_up_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), M, I, K,
@@ -257,6 +264,15 @@ class HipOps:
         self._chk(self.lib.tasu_logprob_topk(_p(logits), logits.stride(0), M, V, k, _p(banned), n_banned, _p(out_val),
                                              _p(out_idx), _p(self.topk_ws), self.topk_ws.numel(), self._stream()),
                   "tasu_logprob_topk")
+
+    def beam_update(self, vals, idx, bs, first):
+        """One position of the device-side beam search (tasu_beam_update); ``bs``: ps_slm_amd.decode.DeviceBeam."""
+        self._chk(self.lib.tasu_beam_update(_p(vals), _p(idx), _p(bs.run_scores), _p(bs.fin_scores), _p(bs.fin_len), _p(bs.fin_par),
+                                            _p(bs.fin_tok), _p(bs.is_fin), _p(bs.unsat), _p(bs.bp_tok), _p(bs.bp_par),
+                                            _p(bs.len_pow), _p(bs.ctl), _p(bs.done_host), _p(bs.valid), _p(bs.next_ids),
+                                            _p(bs.next_src), _p(bs.next_pos), _p(bs.next_slot), _p(bs.next_lens), _p(bs.banned),
+                                            bs.B, bs.nb, bs.max_new, bs.eos, bs.min_length, bs.S, int(first), self._stream()),
+                  "tasu_beam_update")
 
     # ------------------------------------------------------------------ audio front end
     def fbank(self, wave, n_samples, scale, win, shift, window, mel, n_mels, preemph, out):

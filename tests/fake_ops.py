@@ -5,6 +5,8 @@ schedule, engine, DP) end to end and compare it with the oracle, so that the onl
 the GPU is the kernels themselves (tests/test_gpu_*.py compare HipOps with this double op by op)."""
 import math
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -294,6 +296,63 @@ class FakeOps:
         ok = torch.nonzero(r >= 0)[:, 0]
         dproj[ok] = _bf(dx[r[ok]])
 
+    def beam_update(self, vals, idx, bs, first):
+        """Scalar restatement of csrc/decode.hip::beam_update_kernel (float32 arithmetic in the same order)."""
+        f32 = np.float32
+        NEG = f32(-1.0e9)
+        if int(bs.ctl[1]):
+            return
+        B, nb, K, cur = bs.B, bs.nb, 2 * bs.nb, int(bs.ctl[0])
+        V, I = vals.numpy(), idx.numpy()
+        unsat_any, stop_all = False, True
+        lp_now = f32(bs.len_pow[cur + 1])
+        for b in range(B):
+            cand = []                                            # (score, beam, token)
+            for j in range(nb):
+                rs = f32(bs.run_scores[b, j])
+                for k in range(K):
+                    if first and j > 0:
+                        v, t = NEG, 0
+                    else:
+                        row = b if first else b * nb + j
+                        v, t = f32(V[row, k]), int(I[row, k])
+                    cand.append((f32(v + rs), j, t))
+            cand.sort(key=lambda c: (-c[0], c[1], c[2]))
+            top = cand[:K]
+            stop = [t == bs.eos or cur + 1 >= bs.max_new for _, _, t in top]
+            stop_all = stop_all and all(stop)
+            run_lp = [f32(s + (NEG if st else f32(0))) for (s, _, _), st in zip(top, stop)]
+            nxt = sorted(range(K), key=lambda i: (-run_lp[i], i))[:nb]
+            for n, i in enumerate(nxt):
+                bs.bp_tok[cur, b, n], bs.bp_par[cur, b, n] = top[i][2], top[i][1]
+                m = b * nb + n
+                bs.next_ids[m], bs.next_src[m] = top[i][2], b * nb + top[i][1]
+                bs.next_pos[m], bs.next_slot[m], bs.next_lens[m] = int(bs.valid[b]) + cur, bs.S + cur, bs.S + cur + 1
+            unsat = bool(bs.unsat[b])
+            merged = [(f32(bs.fin_scores[b, j]), int(bs.fin_len[b, j]), int(bs.fin_par[b, j]), int(bs.fin_tok[b, j]),
+                       int(bs.is_fin[b, j])) for j in range(nb)]
+            for i, (s, bm, t) in enumerate(top):
+                just = stop[i] and i < nb
+                sc = f32(s / lp_now)
+                sc = f32(sc + (f32(0) if unsat else NEG))
+                sc = f32(sc + (f32(0) if just else NEG))
+                merged.append((sc, cur + 1, bm, t, int(just)))
+            keep = sorted(range(nb + K), key=lambda i: (-merged[i][0], i))[:nb]
+            for n, i in enumerate(keep):
+                bs.fin_scores[b, n] = float(merged[i][0])
+                bs.fin_len[b, n], bs.fin_par[b, n], bs.fin_tok[b, n], bs.is_fin[b, n] = merged[i][1:]
+                bs.run_scores[b, n] = float(run_lp[nxt[n]])
+            best_run = f32(run_lp[nxt[0]] / lp_now)
+            min_fin = min(merged[i][0] for i in keep)
+            improve = any(best_run > (min_fin if merged[i][4] else NEG) for i in keep)
+            bs.unsat[b] = int(unsat and improve)
+            unsat_any = unsat_any or bool(bs.unsat[b])
+        done = not (unsat_any and not stop_all)
+        bs.ctl[0], bs.ctl[1] = cur + 1, int(done)
+        bs.banned[0] = bs.eos if cur + 1 < bs.min_length else -1
+        if bs.done_host is not None:
+            bs.done_host[0] = cur + 1 if done else 0
+
     # ---------------------------------------------------------------- optimizer
     def adamw(self, p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale):
         lr = float(torch.tensor(lr, dtype=torch.float32))        # the kernel takes lr as a C float
@@ -387,6 +446,13 @@ class FakeOps:
         k3[r, pos.long()] = qkv[:M, H * HD:H * HD + W]
         v3[r, pos.long()] = qkv[:M, H * HD + W:]
 
+    def gemm_splitk(self, a, b, c, M, N, K, ksplit, ws):
+        per = K // ksplit
+        acc = torch.zeros(M, N)
+        for s in range(ksplit):
+            acc += a[:M, s * per:(s + 1) * per].float() @ b[:N, s * per:(s + 1) * per].float().t()
+        c[:M, :N] = _bf(acc)
+
     def gemm_gate_up_swiglu(self, a, wgu, gu, act, M, I, K):
         self.gemm(a, wgu, gu, M, 2 * I, K)
         self.swiglu_fwd(gu, act, M, I)
@@ -441,7 +507,8 @@ class FakeOps:
         lg = logits[:M, :V].float()
         lp = lg - torch.logsumexp(lg, -1, keepdim=True)
         if n_banned:
-            lp[:, banned[:n_banned].long()] = float("-inf")
+            ban = banned[:n_banned].long()
+            lp[:, ban[ban >= 0]] = float("-inf")               # an entry of -1 bans nothing (tasu_beam_update lifts the EOS ban so)
         # descending by value, ties by smaller column (torch.sort is stable on the negated, index-ordered input)
         v, i = torch.sort(lp, dim=-1, descending=True, stable=True)
         out_val[:M] = v[:, :k]

@@ -107,6 +107,28 @@ def test_benchmark_gemm_shapes_vs_rocblas(full, name, M, N, K):
     assert torch.equal(c, c2)
 
 
+@pytest.mark.parametrize("M,N,K,ksplit", [(2048, 1536, 151936, 2), (2048, 3584, 152064, 2), (1024, 1536, 151936, 4), (200, 256, 1024, 8)])
+def test_splitk_gemm_vs_rocblas(full, M, N, K, ksplit):
+    """The lm_head dgrad over the labelled rows (K = padded vocabulary) as ksplit K ranges per output tile + ordered fp32 sum +
+    one bf16 rounding, against rocBLAS on the same bits; deterministic."""
+    _, m = full
+    g = torch.Generator(device="cuda").manual_seed(M + ksplit)
+    a = (torch.randn(M, K, generator=g, device="cuda") * 0.05).to(BF)
+    b = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(BF)
+    ws = torch.empty(ksplit, M, N, device="cuda", dtype=F32)
+    c = torch.empty(M, N, device="cuda", dtype=BF)
+    m.ops.gemm_splitk(a, b, c, M, N, K, ksplit, ws)
+    ref = torch.matmul(a, b.t())
+    torch.cuda.synchronize()
+    diff = c.float() - ref.float()
+    assert float(diff.abs().max() / ref.float().abs().max()) < 2 ** -7
+    assert float(diff.norm() / ref.float().norm()) < 2e-3
+    c2 = torch.empty_like(c)
+    m.ops.gemm_splitk(a, b, c2, M, N, K, ksplit, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(c, c2)
+
+
 # ------------------------------------------------------------------------------------------------ whole step
 @pytest.mark.parametrize("size", ["1.5b", "7b"])
 def test_full_size_step_properties(size):

@@ -624,3 +624,20 @@ def test_rope_append(hip, fake):
     (qc, kc1, vc1), (qg, kg, vg) = run_pair(hip, fake, "rope_append", [qkv, cos, sin, kc, vc, pos, M, H, G, ctx], [0, 3, 4])
     assert rel_err(qg, qc) < 1e-2 and rel_err(kg, kc1) < 1e-2 and torch.equal(vg, vc1)
     assert torch.equal(kg != 0, kc1 != 0)
+
+
+# ------------------------------------------------------------------------------------------------ device beam search
+@pytest.mark.parametrize("quantise", [False, True])
+@pytest.mark.parametrize("nb,lpw,min_len", [(4, 1.0, 1), (4, 2.0, 1), (3, 0.5, 4), (2, 1.0, 6), (1, 1.0, 1), (5, 1.0, 2)])
+def test_beam_update_kernel_is_exact(hip, nb, lpw, min_len, quantise):
+    """tasu_beam_update (selection, finished-hypothesis heap, early stop, back-pointers, next-step inputs) against the host
+    BeamState on synthetic score streams -- 16 utterances, EOS events, exact ties when quantised: identical tokens, the same
+    number of steps, and no state change from calls issued after it reported done."""
+    from beam_stream import make_table, run_device, run_host
+    B, V, T, eos = 16, 50, 14, 7
+    table = make_table(3, V, eos, quantise)
+    want = run_host(table, B, nb, T, eos, lpw, min_len)
+    got, calls = run_device(hip, "cuda", table, B, nb, T, eos, lpw, min_len, extra_steps=3)
+    fake, calls_f = run_device(FakeOps(), "cpu", table, B, nb, T, eos, lpw, min_len)
+    assert np.array_equal(got, want), (got, want)
+    assert np.array_equal(got, fake) and calls == calls_f

@@ -465,3 +465,19 @@ def test_labelled_rows_loss_head_equals_full_materialisation(mid, ragged):
     assert sl.nL == int((sf.plan.shift_labels >= 0).sum()) and sl.nLp % 64 == 0 and lean.logits_view(sl) is None
     torch.testing.assert_close(sf.dev["loss_out"], sl.dev["loss_out"], rtol=1e-6, atol=0)
     assert float((full.proj.g - lean.proj.g).norm() / full.proj.g.norm()) < 5e-3     # bf16 roundings move with the summation order
+
+
+@pytest.mark.parametrize("quantise", [False, True])
+@pytest.mark.parametrize("lpw,min_len", [(1.0, 1), (2.0, 1), (0.5, 4), (1.0, 6)])
+@pytest.mark.parametrize("nb", [1, 2, 3, 4])
+def test_device_beam_update_restatement_matches_host_beam_state(nb, lpw, min_len, quantise):
+    """The scalar restatement of the device beam-update kernel (tests/fake_ops.py::beam_update over back-pointers, the double
+    the HIP kernel is compared with bit for bit) against the vectorised BeamState (pinned against the oracle's loop above):
+    identical tokens on synthetic score streams with EOS events and, quantised, exact score ties."""
+    from beam_stream import make_table, run_device, run_host
+    B, V, T, eos = 3, 50, 12, 7
+    table = make_table(0, V, eos, quantise)
+    want = run_host(table, B, nb, T, eos, lpw, min_len)
+    got, _ = run_device(FakeOps(), "cpu", table, B, nb, T, eos, lpw, min_len, extra_steps=2)
+    assert np.array_equal(got, want), (got, want)
+    assert (got == eos).any()
