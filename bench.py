@@ -75,6 +75,9 @@ class TimedOps:
     def gemm_gate_up_swiglu(self, *a, **k):
         return self._timed(self._ops.gemm_gate_up_swiglu, a, k)
 
+    def gemm_splitk(self, *a, **k):
+        return self._timed(self._ops.gemm_splitk, a, k)
+
     def total_ms(self):
         return sum(a.elapsed_time(b) for a, b in self.events)
 
@@ -123,9 +126,10 @@ def pooled_state_dict(geo, seed=1234):
     return sd
 
 
-def cpu_baseline_worker():
+def cpu_baseline_worker(kind):
     """Runs in a CHILD process (no GPU): the oracle (CPU port of the reference path, oracle/tasu_oracle.py) at FULL
-    geometry, fp32, B = 1 synthetic utterance, fwd + bwd + AdamW; encoder pass skipped like the GPU leg."""
+    geometry, fp32, on a BOUNDED sample of the GPU workload (training at B = 1 and B = 16, decode at
+    B = 1 and B = 16).  kind: train1 | train16 | decode1 | decode16.  Encoder pass skipped like the GPU leg."""
     import dataclasses
 
     from oracle import tasu_oracle as O
@@ -137,42 +141,59 @@ def cpu_baseline_worker():
     torch.set_num_threads(threads)
     geo = Geometry.qwen25_1p5b()
     sd = pooled_state_dict(geo)
-    batch = synthetic_text_batch(geo, 1, seed=1234)
     gd = dataclasses.asdict(geo)
-    m = {k: torch.zeros_like(sd[k]) for k in O.PROJ_KEYS}
-    v = {k: torch.zeros_like(sd[k]) for k in O.PROJ_KEYS}
-    times = []
-    t_start = time.perf_counter()
-    for step in range(1, 5):
+    host = f"torch {torch.__version__}, {threads} threads ({cores} usable cores), encoder pass skipped"
+    if kind.startswith("train"):
+        B = int(kind[5:])
+        batch = synthetic_text_batch(geo, B, seed=1234)
+        m = {k: torch.zeros_like(sd[k]) for k in O.PROJ_KEYS}
+        v = {k: torch.zeros_like(sd[k]) for k in O.PROJ_KEYS}
+        times, t_start = [], time.perf_counter()
+        budget = 25.0 if B == 1 else 60.0
+        for step in range(1, 5):
+            t0 = time.perf_counter()
+            out, grads = O.loss_and_projector_grads(sd, batch, gd, "fp32")
+            for k in O.PROJ_KEYS:
+                O.adamw_step(sd[k], grads[k], m[k], v[k], step, 5e-5)
+            times.append(time.perf_counter() - t0)
+            if step >= (2 if B == 1 else 1) and time.perf_counter() - t_start > budget:
+                break
+        timed = times[1:] if len(times) > 1 else times           # B = 16: a single iteration may already fill the budget
+        print(json.dumps({"value": round(B / (sum(timed) / len(timed)), 4), "unit": "utterances/s", "cores": threads, "kind": "port",
+                          "sample": f"oracle/tasu_oracle.py fp32, B={B} utterance(s) (S=256, 104 audio tokens), fwd+bwd+AdamW, "
+                                    f"{len(timed)} timed iteration(s) after {len(times) - len(timed)} warm-up, {host}"}), flush=True)
+        return
+    B = int(kind[6:])
+    new = 6 if B == 1 else 2                                     # bounded: the oracle re-runs the whole sequence per position
+    batch = synthetic_text_batch(geo, B, seed=1234, noise=False)
+    ids = batch["input_ids"][:, :25]
+    am = torch.ones_like(ids, dtype=torch.bool)
+    post, plen = O.pseudo_posterior(batch["post_ids"], geo.ctc_vocab)
+    with torch.no_grad():
+        emb, mask, _, _ = O.merge(O.projector(sd, post, "fp32"), plen, sd["llm.model.embed_tokens.weight"][ids], ids, am, None,
+                                  geo.speech_id)
         t0 = time.perf_counter()
-        out, grads = O.loss_and_projector_grads(sd, batch, gd, "fp32")
-        for k in O.PROJ_KEYS:
-            O.adamw_step(sd[k], grads[k], m[k], v[k], step, 5e-5)
-        times.append(time.perf_counter() - t0)
-        if step >= 2 and time.perf_counter() - t_start > 25.0:
-            break
-    timed = times[1:]
-    print(json.dumps({"value": round(1.0 / (sum(timed) / len(timed)), 4), "unit": "utterances/s", "cores": threads,
-                      "kind": "port",
-                      "sample": f"oracle/tasu_oracle.py fp32, B=1 utterance (S=256, 104 audio tokens), fwd+bwd+AdamW, "
-                                f"{len(timed)} timed iterations after 1 warm-up, torch {torch.__version__}, {threads} threads "
-                                f"({cores} usable cores), encoder pass skipped"}), flush=True)
+        toks = O.beam_search_generate(sd, emb, mask, gd, num_beams=4, max_new_tokens=new, eos_token_id=-1, pad_token_id=0)
+        dt = time.perf_counter() - t0
+    print(json.dumps({"value": round(B * toks.shape[1] / dt, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
+                      "sample": f"oracle beam search fp32 (no KV cache: the whole sequence is re-run per position), B={B}, beam 4, "
+                                f"prefill 128, {toks.shape[1]} generated positions, {host}"}), flush=True)
 
 
-def cpu_baseline(timeout_s=240):
+def cpu_baseline(kind="train1", timeout_s=240):
     import subprocess
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    unit = "utterances/s" if kind.startswith("train") else "tokens/s"
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", kind], capture_output=True,
                            text=True, timeout=timeout_s, env=env, cwd=ROOT)
         for ln in reversed(r.stdout.strip().splitlines()):
             if ln.startswith("{"):
                 return json.loads(ln)
-        return {"value": None, "unit": "utterances/s", "cores": 0, "kind": "port", "sample": "worker failed: " + r.stderr[-300:]}
+        return {"value": None, "unit": unit, "cores": 0, "kind": "port", "sample": f"{kind} worker failed: " + r.stderr[-300:]}
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "utterances/s", "cores": 0, "kind": "port",
-                "sample": f"worker exceeded {timeout_s}s on this host; indicative figure measured in the build container "
-                          f"(8 cores): 0.14 utterances/s"}
+        return {"value": None, "unit": unit, "cores": 0, "kind": "port",
+                "sample": f"{kind} worker exceeded {timeout_s}s on this host"}
 
 
 def decode_leg(core, raw, B, new_tokens=200, beams=4):
@@ -195,14 +216,169 @@ def decode_leg(core, raw, B, new_tokens=200, beams=4):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n_new = int(out.shape[1])
+    geo = core.geo
     weight_bytes = 2 * sum(int(w[k].numel()) for w in core.llm.layers for k in ("wqkv", "wo", "wgu", "wd")) \
         + 2 * int(core.llm.head.numel())
+    # K/V bytes a position reads: every beam row attends over its whole context (28,672 B x context x rows at 1.5B);
+    # averaged over the generated positions (context 128 .. 128 + n_new - 1)
+    kv_row_pos = geo.llm_layers * 2 * geo.llm_kv_heads * 128 * 2
+    kv_bytes = kv_row_pos * (128 + (n_new - 1) / 2.0) * B * beams
+    per_pos = dt / n_new
     return {"metric": "decode tokens/sec (beam 4, emitted tokens)", "value": round(B * n_new / dt, 1), "unit": "tokens/s",
-            "beam_tokens_per_s": round(beams * B * n_new / dt, 1), "ms_per_step": round(dt / n_new * 1e3, 3),
+            "beam_tokens_per_s": round(beams * B * n_new / dt, 1), "ms_per_step": round(per_pos * 1e3, 3),
             "config": {"utterances": B, "beams": beams, "prefill_len": 128, "new_tokens": n_new},
-            "roofline": {"bound": "hbm", "achieved": round(weight_bytes / (dt / n_new) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(weight_bytes / (dt / n_new) / 8e12, 4),
-                         "note": "bf16 weight bytes streamed once per generated position / wall time per position"}}
+            "roofline": {"bound": "hbm", "achieved": round((weight_bytes + kv_bytes) / per_pos / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round((weight_bytes + kv_bytes) / per_pos / 8e12, 4),
+                         "weight_bytes_per_position": weight_bytes, "kv_bytes_per_position_avg": int(kv_bytes),
+                         "note": "(bf16 weight bytes streamed once + K/V bytes read by the 64 beam rows) per generated position / "
+                                 "wall time per position (prefill included in the wall time)"}}
+
+
+def encoder_gemm_flops_per_utt(geo, frames):
+    """GEMM FLOPs of the frozen SANM encoder + CTC head per utterance (forward only; SURVEY 8d: 2 x 3,145,728 per frame-layer
+    for the 512-wide layers, layer 0 reads 560 features, CTC head 2 x 512 x 25055 per frame; attention not counted here)."""
+    E, Ff, Fd, V = geo.enc_dim, geo.enc_ffn, geo.feat_dim, geo.ctc_vocab
+    layers = geo.enc_blocks + geo.enc_tp_blocks
+    per_layer = 3 * E * E + E * E + 2 * E * Ff
+    first = 3 * E * Fd + E * E + 2 * E * Ff
+    return 2 * frames * ((layers - 1) * per_layer + first + E * V)
+
+
+def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank, want_decode):
+    """One training workload (path: "text" = the text-only CPS recipe of configs 2/3/5, "audio" = config 4: 500 feature frames
+    through the SenseVoice encoder, CTC posterior, PSD, projector, LLM).  Returns the fields of a bench record."""
+    import torch.distributed as dist
+
+    from ps_slm_amd.config import DEFAULT_DS_CONFIG, ModelConfig, TrainConfig, load_ds_config
+    from ps_slm_amd.engine import TasuEngine
+    from ps_slm_amd.ps_slm import model_factory
+    from ps_slm_amd.synthetic import synthetic_text_batch
+
+    audio = path == "audio"
+    train_config = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=not audio, gt_emb_noise=not audio, ctc_posterior=True,
+                               do_psd=True, use_fp16=True, batching_strategy="dynamic")
+    model_config = ModelConfig(llm_path=f"synthetic:{model_name}", encoder_projector="linear-silu", encoder_dim=25055,
+                               llm_dim={"qwen2.5-1.5b": 1536, "qwen2.5-7b": 3584, "mid": 256}[model_name])
+    model, _ = model_factory(train_config, model_config, device=f"cuda:{local_rank}", init_seed=1234, keep_logits=False,
+                             with_encoder=audio)
+    model.drop_prob = args.drop_prob
+    core = model.core
+    core.use_graphs = not args.no_graphs
+    timed = TimedOps(core.ops)
+    core.ops = timed
+    engine = TasuEngine(model, load_ds_config(DEFAULT_DS_CONFIG))
+    engine.train()
+    geo = core.geo
+    raw = synthetic_text_batch(geo, B, seed=1234 + rank, noise=False)
+    if audio:
+        batch = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
+                     input_features=raw["input_features"], input_feature_length=raw["input_feature_length"], GT=None)
+    else:
+        GT = [" ".join(map(str, p)) for p in raw["post_ids"]]
+        batch = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
+                     input_features=None, input_feature_length=None, GT=GT)
+    torch.manual_seed(1234 + rank)          # CPS alpha / keep draws come from the global CPU RNG, like the reference
+
+    def step():
+        out, acc = engine(**batch)
+        engine.backward(out.loss)
+        engine.step()
+        return out
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    # hipGraph replay cannot carry per-launch event pairs, so with graphs the GEMM launches are timed in a second,
+    # eager pass over the same number of steps right after the timed region (same kernels, same shapes, same data).
+    timed.enabled = rank == 0 and not core.use_graphs
+    engine.time_exchange = world > 1
+    engine.exposed_events = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timed.enabled = False
+    exposed_ms = engine.exposed_ms() / max(steps, 1) if world > 1 else 0.0
+    engine.time_exchange = False
+    if world > 1:
+        t = torch.tensor([dt, exposed_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, exposed_ms = float(t[0].item()), float(t[1].item())
+    if core.use_graphs:
+        # every rank takes part (the step contains the gradient all-reduce); only rank 0 records the event pairs
+        core.use_graphs = False
+        step()
+        torch.cuda.synchronize()
+        timed.enabled = rank == 0
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        timed.enabled = False
+        core.use_graphs = True
+    loss = float(out.loss)
+    rec = None
+    if rank == 0:
+        st = engine._last_state
+        S = st.S
+        n_audio = st.Ra / B                             # projector rows per utterance (audio: PSD output, padded to the batch max)
+        n_head = st.nLp / B                             # lm_head rows executed per utterance (labelled positions, padded to 64)
+        enc = encoder_gemm_flops_per_utt(geo, raw["input_features"].shape[1] + 4) if audio else 0
+        gemm_flops_step = (gemm_flops_per_utt(geo, S, n_audio, n_head) + enc) * B
+        executed_step = (total_flops_per_utt(geo, S, n_audio, n_head) + enc) * B
+        survey_step = (total_flops_per_utt(geo, S, n_audio) + enc) * B
+        gemm_ms = timed.total_ms()
+        n_launch = len(timed.events)
+        achieved = gemm_flops_step * steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
+        if os.path.isfile(pmc) and model_name == "qwen2.5-1.5b" and B == 16 and not audio:
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+            traffic_src = ("OFFLINE figure read from profiles/r01_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                           "tools/pmc_gemm.py, gfx950 x2 fetch correction), not measured by this run")
+        what = ("audio-SFT step (500 feature frames -> SANM encoder -> CTC posterior -> PSD -> projector -> LLM fwd+dgrad bwd+"
+                "projector wgrad+AdamW)" if audio else
+                "text-only CPS alignment step (fwd+dgrad bwd+projector wgrad+AdamW), frozen encoder pass skipped")
+        rec = {
+            "value": round(world * B * steps / dt, 2), "unit": "utterances/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "config": {"workload": f"{what}, {model_name}, {B} utterances/GPU x S={S} "
+                                   f"({n_audio:.0f} audio tokens/utterance), lm_head + CE on the {st.nL} labelled positions of the "
+                                   f"batch only (the other rows' loss and gradient are identically zero)",
+                       "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "kernel": "tasu_pipe::gemm_pipe_kernel (tasu_gemm_nt_bf16_ws, tasu_gemm_gate_up_swiglu, tasu_gemm_nt_bf16_splitk)",
+                         "launches_per_step": n_launch // max(steps, 1),
+                         "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
+                         "algorithmic_gflop_per_launch": round(gemm_flops_step * steps / max(n_launch, 1) / 1e9, 2),
+                         "gemm_ms_per_step_eager_pass": round(gemm_ms / max(steps, 1), 3),
+                         "launch": "hipGraph replay" if core.use_graphs else "eager",
+                         "passes_note": ("value / ms_per_step: hipGraph replay of the timed steps; achieved / avg_launch_us: HIP event "
+                                         "pairs around every GEMM launch in a second, EAGER pass of the same steps (graphs cannot carry "
+                                         "per-launch events)") if core.use_graphs else "one eager pass",
+                         "whole_step_tflops": round(executed_step * steps / dt / 1e12 / world * world, 1),
+                         "whole_step_frac": round(executed_step * steps / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                         "whole_step_frac_at_survey_flops": round(survey_step * steps / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                         "flops_note": "achieved / whole_step_frac count EXECUTED FLOPs per GPU (lm_head rows without a label are "
+                                       "not computed and not counted); whole_step_frac_at_survey_flops prices the same "
+                                       "utterances/s at SURVEY 8d's algorithmic FLOPs, which count them"},
+        }
+        if world > 1:
+            rec["allreduce_exposed_ms"] = round(exposed_ms, 3)
+            rec["allreduce_note"] = (f"per step, max over ranks: time the compute stream waited for gradient ranges in step() "
+                                     f"(event pairs around every wait); bucket exchanged in {engine.w1_chunks + 2} ranges")
+        if want_decode:
+            rec["decode"] = decode_leg(core, raw, B)
+    del engine, model, core, timed
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
@@ -212,21 +388,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
     ap.add_argument("--model", default="qwen2.5-1.5b", choices=["qwen2.5-1.5b", "qwen2.5-7b", "mid"])
+    ap.add_argument("--path", default="text", choices=["text", "audio"], help="headline workload: text-only CPS or audio-SFT")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--drop-prob", type=float, default=0.0, help="CPS token drop (0 keeps S fixed at 256)")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of hipGraph replay")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode tok/s leg (second half of BASELINE.json's metric)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-4 (audio-SFT) and config-5 (Qwen2.5-7B) sub-records")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
-        return cpu_baseline_worker()
+        return cpu_baseline_worker(args.cpu_baseline_worker)
 
     import torch.distributed as dist
-
-    from ps_slm_amd.config import DEFAULT_DS_CONFIG, ModelConfig, TrainConfig, load_ds_config
-    from ps_slm_amd.engine import TasuEngine
-    from ps_slm_amd.ps_slm import model_factory
-    from ps_slm_amd.synthetic import synthetic_text_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -239,113 +412,27 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
-    train_config = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=True, ctc_posterior=True,
-                               do_psd=True, use_fp16=True, batching_strategy="dynamic")
-    model_config = ModelConfig(llm_path=f"synthetic:{args.model}", encoder_projector="linear-silu", encoder_dim=25055,
-                               llm_dim={"qwen2.5-1.5b": 1536, "qwen2.5-7b": 3584, "mid": 256}[args.model])
-    model, _ = model_factory(train_config, model_config, device=f"cuda:{local_rank}", init_seed=1234, keep_logits=False)
-    model.drop_prob = args.drop_prob
-    core = model.core
-    core.use_graphs = not args.no_graphs
-    timed = TimedOps(core.ops)
-    core.ops = timed
-    engine = TasuEngine(model, load_ds_config(DEFAULT_DS_CONFIG))
-    engine.train()
-    geo = core.geo
-
-    B = args.batch
-    raw = synthetic_text_batch(geo, B, seed=1234 + rank, noise=False)
-    GT = [" ".join(map(str, p)) for p in raw["post_ids"]]
-    batch = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
-                 input_features=None, input_feature_length=None, GT=GT)
-    torch.manual_seed(1234 + rank)          # CPS alpha / keep draws come from the global CPU RNG, like the reference
-
-    def step():
-        out, acc = engine(**batch)
-        engine.backward(out.loss)
-        engine.step()
-        return out
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # hipGraph replay cannot carry per-launch event pairs, so with graphs the GEMM launches are timed in a second,
-    # eager pass over the same number of steps right after the timed region (same kernels, same shapes, same data).
-    timed.enabled = rank == 0 and not core.use_graphs
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timed.enabled = False
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if core.use_graphs:
-        # every rank takes part (the step contains the gradient all-reduce); only rank 0 records the event pairs
-        core.use_graphs = False
-        step()
-        torch.cuda.synchronize()
-        timed.enabled = rank == 0
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        timed.enabled = False
-        core.use_graphs = True
-    loss = float(out.loss)
-
+    main_rec = train_leg(args, args.model, args.path, args.batch, args.steps, args.warmup, world, rank, local_rank,
+                         want_decode=world == 1 and not args.no_decode and args.path == "text")
+    extras = {}
+    headline = args.model == "qwen2.5-1.5b" and args.path == "text"
+    if world == 1 and headline and not args.no_extra:
+        # BASELINE.json configs 4 and 5 as sub-records of the same line (shorter runs: their steps are 3-4x longer)
+        extras["audio_sft"] = train_leg(args, "qwen2.5-1.5b", "audio", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank, False)
+        extras["qwen2.5-7b"] = train_leg(args, "qwen2.5-7b", "text", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank, False)
     if rank == 0:
-        S = engine._last_state.S
-        n_audio = len(raw["post_ids"][0])
-        utt_per_s = world * B * args.steps / dt
-        gemm_ms = timed.total_ms()
-        n_launch = len(timed.events)
-        n_head = engine._last_state.nLp / B            # lm_head rows executed per utterance (labelled positions, padded to 64)
-        gemm_flops_step = gemm_flops_per_utt(geo, S, n_audio, n_head) * B
-        executed_step = total_flops_per_utt(geo, S, n_audio, n_head) * B
-        survey_step = total_flops_per_utt(geo, S, n_audio) * B
-        achieved = gemm_flops_step * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
-        if os.path.isfile(pmc) and args.model == "qwen2.5-1.5b" and B == 16:
-            # measured offline with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction);
-            # bytes per GEMM launch, averaged over the same launches `achieved` averages over
-            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-        line = {
-            "metric": "train utterances/sec (Qwen2.5-1.5B align)", "value": round(utt_per_s, 2), "unit": "utterances/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"text-only CPS alignment step (fwd+dgrad bwd+projector wgrad+AdamW), {args.model}, "
-                                   f"{B} utterances/GPU x S={S} (25 prompt + {n_audio} audio + 128 target tokens), "
-                                   f"frozen encoder pass skipped, lm_head + CE on the {engine._last_state.nL} labelled positions "
-                                   f"of the batch only (the other rows' loss and gradient are identically zero)",
-                       "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "tasu_pipe::gemm_pipe_kernel (tasu_gemm_nt_bf16_ws, tasu_gemm_gate_up_swiglu)", "launches_per_step": n_launch // max(args.steps, 1),
-                         "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
-                         "algorithmic_gflop_per_launch": round(gemm_flops_step * args.steps / max(n_launch, 1) / 1e9, 2),
-                         "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4), "launch": "hipGraph replay" if core.use_graphs else "eager",
-                         "whole_step_tflops": round(executed_step * args.steps / dt / 1e12, 1),
-                         "whole_step_frac": round(executed_step * args.steps / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
-                         "whole_step_frac_at_survey_flops": round(survey_step * args.steps / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
-                         "flops_note": "achieved / whole_step_frac count EXECUTED FLOPs (lm_head rows without a label are "
-                                       "not computed and not counted); whole_step_frac_at_survey_flops prices the same "
-                                       "utterances/s at SURVEY 8d's 1.634 TFLOP/utterance, which counts them"},
-        }
-        if world == 1 and not args.no_decode:
-            line["decode"] = decode_leg(core, raw, B)
-        if world == 1 and not args.no_cpu_baseline and args.model == "qwen2.5-1.5b":
-            del engine, model, core
-            torch.cuda.empty_cache()
-            line["cpu_baseline"] = cpu_baseline()
+        line = {"metric": "train utterances/sec (Qwen2.5-1.5B align)" if args.model != "qwen2.5-7b" else "train utterances/sec (Qwen2.5-7B align)",
+                "value": main_rec["value"], "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": main_rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16", "data": "synthetic"}
+        line.update({k: v for k, v in main_rec.items() if k not in ("value", "unit", "ms_per_step")})
+        for name, rec in extras.items():
+            rec["metric"] = "train utterances/sec" + (" (audio-SFT, config 4)" if name == "audio_sft" else " (Qwen2.5-7B align, config 5)")
+            line[name] = rec
+        if world == 1 and not args.no_cpu_baseline and headline:
+            line["cpu_baseline"] = cpu_baseline("train1")
+            line["cpu_baselines"] = {"train_B16": cpu_baseline("train16", 300), "decode_B1": cpu_baseline("decode1", 240),
+                                     "decode_B16": cpu_baseline("decode16", 300)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
