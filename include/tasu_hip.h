@@ -79,6 +79,30 @@ int tasu_gemm_skinny_norm(const void* A, int lda, const void* B, int ldb, float*
 int tasu_gemm_skinny_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw, const void* bias, void* qkv, int M, int H,
                               int G, int K, const float* cos_tab, const float* sin_tab, void* kcache, void* vcache,
                               const int32_t* pos, int ctx, float* workspace, int64_t workspace_floats, void* stream);
+
+/* Second-generation decode-step GEMMs (csrc/gemm_stream.hip): activations in registers, weights global -> registers,
+ * persistent column tiles, the consuming op's epilogue in the SAME launch (no split-K finish launch).  M <= 64;
+ * K (per K range) in {256, 512, 1536, 1792} -- tasu_stream_supported(K, ksplit) says whether a shape is served; other
+ * shapes stay on the tasu_gemm_skinny_* entry points, whose arithmetic and rounding points these reproduce:
+ *   tasu_gemm_stream_bf16      C = bf16(A W^T + bias)  (out_mode TASU_GEMM_OUT_BF16; lm_head) or
+ *                              C(fp32) = resid + bf16(A W^T)  (TASU_GEMM_OUT_F32_RESID_BF16R; o projection + residual)
+ *   tasu_gemm_stream_swiglu    act = bf16(bf16(silu(g)) * u), g | u = A Wgu^T   (modeling_qwen2.py:41-48)
+ *   tasu_gemm_stream_qkv_rope  qkv = rope(A Wqkv^T + bias), k and v appended to the cache at pos[m]  (:189-208, :91-135)
+ *   tasu_gemm_stream_slabs     K split over workgroups (K = ksplit * {256..1792}: the down projection, 8960 = 5 x 1792):
+ *                              fp32 partial tiles; tasu_stream_finish_norm adds them in order, then
+ *                              C(fp32) = resid + bf16(sum) and y = rmsnorm(C, norm_w) for the next layer             */
+int tasu_stream_supported(int K, int ksplit);
+int tasu_gemm_stream_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias,
+                          const float* resid, int M, int N, int K, int out_mode, void* stream);
+int tasu_gemm_stream_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,
+                            void* stream);
+int tasu_gemm_stream_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw, const void* bias, void* qkv, int M, int H,
+                              int G, int K, const float* cos_tab, const float* sin_tab, void* kcache, void* vcache,
+                              const int32_t* pos, int ctx, void* stream);
+int tasu_gemm_stream_slabs(const void* A, int lda, const void* W, int ldw, float* slabs, int64_t slab_floats, int M, int N,
+                           int K, int ksplit, void* stream);
+int tasu_stream_finish_norm(const float* slabs, int ksplit, float* C, const float* resid, int M, int N, const float* norm_w,
+                            void* y, float eps, void* stream);
 /* Qwen2MLP gate|up projection + activation in one launch (modeling_qwen2.py Qwen2MLP.forward, M <= 64):
  * act[M, I] = bf16( bf16(silu(g)) * u ),  g | u = bf16(A[M,K] . Wgu[2I,K]^T)  (gate rows first, then up rows).        */
 int tasu_gemm_skinny_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,

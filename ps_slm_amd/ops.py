@@ -5,6 +5,8 @@ caller-allocated).  There is no eager/PyTorch fallback: construction fails if th
 The method set is the operator interface of the model code (ps_slm_amd/model.py); tests exercise the same
 model code on CPU by injecting tests/fake_ops.py, a torch-CPU double with identical signatures.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -33,6 +35,9 @@ class HipOps:
         # Allocated up front (never inside a hipGraph capture); all GEMMs of one HipOps run on one stream.
         self.gemm_ws = torch.zeros(GEMM_WS_BYTES, dtype=torch.uint8, device="cuda")
         self.topk_ws = torch.empty(1024 * 16 * 34, dtype=torch.float32, device="cuda")   # tasu_logprob_topk partials, M <= 1024
+        # decode-step GEMMs: the single-launch weight-streaming kernels (csrc/gemm_stream.hip) where they serve the shape,
+        # the split-K + finish kernels (csrc/gemm_skinny.hip) otherwise.  TASU_DECODE_STREAM=0 forces the latter (A/B runs).
+        self.use_stream = os.environ.get("TASU_DECODE_STREAM", "1") != "0"
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -65,8 +70,20 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_gate_up_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), M, I, K,
                                                     self._stream()), "tasu_gemm_gate_up_swiglu")
 
+    def _stream_split(self, K):
+        """K ranges the streaming kernels can take this K in (0 = not served)."""
+        if not self.use_stream:
+            return 0
+        for ks in (1, 5, 7, 2, 3, 4, 6, 8):
+            if K % ks == 0 and self.lib.tasu_stream_supported(K, ks):
+                return ks
+        return 0
+
     def gemm_skinny(self, a, b, c, M, N, K, ws, bias=None, resid=None, mode=GEMM_BF16):
         """M <= 64 weight-streaming GEMM (decode step); ws: fp32 workspace tensor."""
+        if mode == GEMM_BF16 and resid is None and self._stream_split(K) == 1 and c.stride(0) % 4 == 0:
+            return self._chk(self.lib.tasu_gemm_stream_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(bias),
+                                                            None, M, N, K, mode, self._stream()), "tasu_gemm_stream_bf16")
         self._chk(self.lib.tasu_gemm_skinny_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(bias),
                                                  _p(resid), M, N, K, mode, _p(ws), 0 if ws is None else ws.numel(),
                                                  self._stream()), "tasu_gemm_skinny_bf16")
@@ -225,12 +242,27 @@ class HipOps:
 
     def gemm_skinny_norm(self, a, b, c, resid, M, N, K, norm_w, y, eps, ws):
         """c (fp32) = resid + bf16(a @ b^T); y = rmsnorm(c, norm_w) -- decode-step projection with the next norm fused."""
+        ks = self._stream_split(K) if N % 16 == 0 else 0
+        if ks == 1:
+            # one launch for the projection + residual add, one for the norm (the sum of squares needs the whole row)
+            self._chk(self.lib.tasu_gemm_stream_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), N, None, _p(resid), M, N, K,
+                                                     GEMM_RESID, self._stream()), "tasu_gemm_stream_bf16")
+            return self._chk(self.lib.tasu_rmsnorm_fwd(_p(c), _p(norm_w), _p(y), None, M, N, eps, self._stream()), "tasu_rmsnorm_fwd")
+        if ks > 1 and ws is not None and ws.numel() >= ks * (N // 16) * 1024:
+            self._chk(self.lib.tasu_gemm_stream_slabs(_p(a), a.stride(0), _p(b), b.stride(0), _p(ws), ws.numel(), M, N, K, ks,
+                                                      self._stream()), "tasu_gemm_stream_slabs")
+            return self._chk(self.lib.tasu_stream_finish_norm(_p(ws), ks, _p(c), _p(resid), M, N, _p(norm_w), _p(y), eps,
+                                                              self._stream()), "tasu_stream_finish_norm")
         self._chk(self.lib.tasu_gemm_skinny_norm(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), _p(resid), M, N, K, _p(norm_w),
                                                  _p(y), eps, _p(ws), 0 if ws is None else ws.numel(), self._stream()),
                   "tasu_gemm_skinny_norm")
 
     def gemm_skinny_qkv_rope(self, a, wqkv, bias, qkv, M, H, G, K, cos, sin, kc, vc, pos, ctx, ws):
         """qkv = rope(a @ wqkv^T + bias); k, v appended to the cache at pos -- one call per decode-step layer."""
+        if self._stream_split(K) == 1:
+            return self._chk(self.lib.tasu_gemm_stream_qkv_rope(_p(a), a.stride(0), _p(wqkv), wqkv.stride(0), _p(bias), _p(qkv), M, H,
+                                                                G, K, _p(cos), _p(sin), _p(kc), _p(vc), _p(pos), ctx, self._stream()),
+                             "tasu_gemm_stream_qkv_rope")
         self._chk(self.lib.tasu_gemm_skinny_qkv_rope(_p(a), a.stride(0), _p(wqkv), wqkv.stride(0), _p(bias), _p(qkv), M, H, G, K,
                                                      _p(cos), _p(sin), _p(kc), _p(vc), _p(pos), ctx, _p(ws),
                                                      0 if ws is None else ws.numel(), self._stream()),
@@ -238,6 +270,9 @@ class HipOps:
 
     def gemm_skinny_swiglu(self, a, wgu, act, M, I, K, ws):
         """act[M, I] = swiglu(a[M,K] @ wgu[2I,K]^T) in one launch (decode step)."""
+        if self._stream_split(K) == 1 and I % 8 == 0 and act.stride(0) % 4 == 0:
+            return self._chk(self.lib.tasu_gemm_stream_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), M, I,
+                                                              K, self._stream()), "tasu_gemm_stream_swiglu")
         self._chk(self.lib.tasu_gemm_skinny_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), M, I, K,
                                                    _p(ws), 0 if ws is None else ws.numel(), self._stream()),
                   "tasu_gemm_skinny_swiglu")

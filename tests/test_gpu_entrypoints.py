@@ -1,0 +1,108 @@
+"""SURVEY 8f rows 2 and 3 on the MI355X: checkpoint compatibility (HF safetensors LLM directory, funasr encoder directory,
+projector state dict -> the HIP model through ``model_factory``) and the validation loop / best-checkpoint policy of the
+training entrypoint (``evaluation()``, Multitask/utils/deepspeed_utils.py:394-498, :256-281) -- both against the same host
+code on the CPU double."""
+import dataclasses
+import math
+import os
+
+import pytest
+import torch
+
+from ckpt_fixtures import write_checkpoint_dirs
+from fake_ops import FakeOps
+from ps_slm_amd.config import DEFAULT_DS_CONFIG, LogConfig, ModelConfig, TrainConfig, load_ds_config
+from ps_slm_amd.engine import TasuEngine
+from ps_slm_amd.model import Geometry, TasuModel
+from ps_slm_amd.ps_slm import model_factory
+from ps_slm_amd.synthetic import MID_GEOMETRY, random_state_dict, synthetic_text_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_checkpoint_directories_load_into_the_hip_model(tmp_path):
+    """llm_path = HF directory, encoder_path = funasr directory, ckpt_path = projector state dict: the model built by
+    model_factory on the GPU gives bit-identical audio-branch loss and projector gradients to the HIP model loaded directly
+    from the reference-named state dict, matches the CPU double within bf16 tolerance, and its projector checkpoint
+    round-trips through engine.save_checkpoint / load_state_dict."""
+    from ps_slm_amd.ops import HipOps
+    geo = Geometry.from_dict(dict(MID_GEOMETRY, bottleneck=Geometry().bottleneck))
+    sd = random_state_dict(geo, 78, with_encoder=True)
+    hf, enc, ckpt = write_checkpoint_dirs(tmp_path, geo, sd)
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=False, ctc_posterior=True, do_psd=True, use_fp16=True)
+    mc = ModelConfig(llm_path=str(hf), llm_dim=geo.llm_dim, encoder_path=str(enc), encoder_projector="linear-silu",
+                     encoder_dim=geo.ctc_vocab)
+    model, _ = model_factory(tc, mc, device="cuda:0", ckpt_path=str(ckpt))
+    model.core.geo.speech_id, model.core.geo.eos_id = geo.speech_id, geo.eos_id
+    assert dataclasses.asdict(model.core.geo) == dataclasses.asdict(geo)
+    direct = TasuModel(geo, HipOps(), "cuda")
+    direct.load_reference_state_dict(sd)
+    double = TasuModel(geo, FakeOps(), "cpu")
+    double.load_reference_state_dict(sd)
+    batch = synthetic_text_batch(geo, 2, seed=6, prompt_len=9, n_audio=13, target_len=11, speech_pos=4, feat_frames=24, noise=False)
+
+    def step(core):
+        st = core.prepare_audio(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["input_features"],
+                                batch["input_feature_length"], do_psd=True)
+        core.forward_llm(st)
+        core.backward(st)
+        if core.device.type == "cuda":
+            torch.cuda.synchronize()
+        return st.dev["loss_out"].cpu().clone(), core.proj.g.cpu().clone()
+    l_f, g_f = step(model.core)
+    l_d, g_d = step(direct)
+    l_c, g_c = step(double)
+    assert torch.equal(l_f, l_d) and torch.equal(g_f, g_d)
+    assert abs(float(l_f[0]) - float(l_c[0])) < 5e-3
+    assert float(torch.nn.functional.cosine_similarity(g_f.flatten(), g_c.flatten(), dim=0)) > 0.999
+    # projector checkpoint round trip (reference key names, unpadded shapes)
+    eng = TasuEngine(model, load_ds_config(DEFAULT_DS_CONFIG))
+    out = tmp_path / "out.bin"
+    eng.save_checkpoint(str(out))
+    saved = torch.load(out)
+    assert sorted(saved) == sorted(k for k in sd if k.startswith("encoder_projector."))
+    for k, v in saved.items():
+        assert v.shape == sd[k].shape and torch.equal(v, sd[k])
+
+
+def test_validation_loop_and_best_checkpoint_on_gpu(tmp_path):
+    """train() with run_validation on the GPU: evaluation() every 2 steps over a 2-batch eval split, checkpoint written on
+    improvement with the reference's directory naming, model back in train mode; eval loss / accuracy / perplexity agree with
+    the same loop on the CPU double (same seeds, same synthetic data)."""
+    import ps_slm_amd.synthetic as syn
+    from ps_slm_amd.finetune_deepspeed import SyntheticDataset, train
+
+    def run(device, ops, out_dir):
+        tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True,
+                         use_fp16=True)
+        mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+        model, _ = model_factory(tc, mc, device=device, ops=ops, init_seed=1234, keep_logits=False)
+        cfg = load_ds_config(DEFAULT_DS_CONFIG)
+        cfg["lr"] = 1e-3
+        eng = TasuEngine(model, cfg)
+        eng.sched_iter = 10
+        geo = model.core.geo
+        tcfg = TrainConfig(num_epochs=1, run_validation=True, validation_interval=2, save_model=True, output_dir=str(out_dir),
+                           batching_strategy="dynamic")
+        res = train(eng, SyntheticDataset(geo, 2, 4, 0), tcfg, LogConfig(log_interval=1), 0, 1,
+                    eval_dataset=SyntheticDataset(geo, 2, 2, 0))
+        return res, eng
+
+    real = syn.synthetic_text_batch
+    syn.synthetic_text_batch = lambda geo, B, seed, noise=False: real(geo, B, seed=seed, prompt_len=9, n_audio=21, target_len=17,
+                                                                       speech_pos=4, feat_frames=8, noise=noise)
+    try:
+        res_g, eng_g = run("cuda:0", None, tmp_path / "gpu")
+        res_c, _ = run("cpu", FakeOps(), tmp_path / "cpu")
+    finally:
+        syn.synthetic_text_batch = real
+    assert res_g["steps"] == 4 and eng_g.module.training
+    assert res_g["avg_eval_prep"] == pytest.approx(
+        sum(math.exp(l) for l in [res_g["avg_eval_loss"]]) , rel=0.2)           # ppl is exp(loss) per evaluation, averaged
+    for k in ("avg_train_loss", "avg_eval_loss"):
+        assert abs(res_g[k] - res_c[k]) < 1e-2, (k, res_g[k], res_c[k])
+    for k in ("avg_train_acc", "avg_eval_acc"):
+        assert abs(res_g[k] - res_c[k]) < 0.05, (k, res_g[k], res_c[k])
+    assert os.path.isfile(tmp_path / "gpu" / "asr_model_epoch_1_step_2" / "pytorch_model.bin")
+    sd = torch.load(tmp_path / "gpu" / "asr_model_epoch_1_step_2" / "pytorch_model.bin")
+    assert sd["encoder_projector.ffn.0.weight"].shape == (128, 203)

@@ -20,6 +20,15 @@ def hip():
     return HipOps()
 
 
+@pytest.fixture(params=["stream", "skinny"])
+def hip_both(hip, request):
+    """The decode-step GEMM ops on both kernel families: the single-launch streaming kernels (csrc/gemm_stream.hip, where they
+    serve the shape) and the split-K + finish kernels (csrc/gemm_skinny.hip)."""
+    hip.use_stream = request.param == "stream"
+    yield hip
+    hip.use_stream = True
+
+
 @pytest.fixture(scope="module")
 def fake():
     return FakeOps()
@@ -551,7 +560,8 @@ def test_logprob_topk_full_vocab(hip, fake):
 
 @pytest.mark.parametrize("M,N,K,mode,bias", [(64, 1536, 8960, 2, False), (64, 2048, 1536, 0, True), (40, 17920, 1536, 0, False),
                                              (64, 1000, 256, 1, True), (4, 151936, 1536, 0, False), (64, 1536, 1536, 2, False)])
-def test_gemm_skinny(hip, fake, M, N, K, mode, bias):
+def test_gemm_skinny(hip_both, fake, M, N, K, mode, bias):
+    hip = hip_both
     ldc = (N + 63) // 64 * 64
     a = randn(M, K, dtype=BF, seed=1)
     b = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
@@ -572,7 +582,8 @@ def test_gemm_skinny(hip, fake, M, N, K, mode, bias):
 
 
 @pytest.mark.parametrize("M,I,K", [(64, 8960, 1536), (40, 200, 128), (64, 96, 4096)])
-def test_gemm_skinny_swiglu(hip, fake, M, I, K):
+def test_gemm_skinny_swiglu(hip_both, fake, M, I, K):
+    hip = hip_both
     a = randn(M, K, dtype=BF, seed=1)
     w = randn(2 * I, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
     ca, ga = torch.zeros(M, I, dtype=BF), torch.zeros(M, I, dtype=BF).cuda()
@@ -584,7 +595,8 @@ def test_gemm_skinny_swiglu(hip, fake, M, I, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 1536, 8960), (64, 1536, 1536), (33, 256, 512), (64, 17920, 128)])
-def test_gemm_skinny_norm(hip, fake, M, N, K):
+def test_gemm_skinny_norm(hip_both, fake, M, N, K):
+    hip = hip_both
     a = randn(M, K, dtype=BF, seed=1)
     b = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
     r = randn(M, N, seed=3)
@@ -596,7 +608,8 @@ def test_gemm_skinny_norm(hip, fake, M, N, K):
 
 
 @pytest.mark.parametrize("M,H,G,K", [(64, 12, 2, 1536), (10, 4, 2, 256), (33, 2, 1, 128)])
-def test_gemm_skinny_qkv_rope(hip, fake, M, H, G, K):
+def test_gemm_skinny_qkv_rope(hip_both, fake, M, H, G, K):
+    hip = hip_both
     ctx, LD, W = 16, (H + 2 * G) * HD, G * HD
     a = randn(M, K, dtype=BF, seed=1)
     w = randn(LD, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
