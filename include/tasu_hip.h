@@ -92,17 +92,25 @@ int tasu_gemm_skinny_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw,
  *                              fp32 partial tiles; tasu_stream_finish_norm adds them in order, then
  *                              C(fp32) = resid + bf16(sum) and y = rmsnorm(C, norm_w) for the next layer             */
 int tasu_stream_supported(int K, int ksplit);
+/* a_frag / w_frag / out_frag / y_frag = 1: that operand is in FRAGMENT ORDER (the order mfma_f32_16x16x32_bf16 consumes it
+ * in, so that every wave instruction reads 1 KiB contiguous instead of 16 rows x 64 B):
+ *   activations [<= 64, K]:  X_f[K / 32][4 row tiles][64 lanes][8],  lane = 16 * ((k % 32) / 8) + row % 16, element k % 8
+ *   weights: per 16-row column tile, in the row order of the tile's epilogue: tasu_to_fragment_order(kind = 0 plain,
+ *   2 SwiGLU (8 gate + 8 up rows), 3 q|k|v (paired RoPE columns); N = output columns) -> [tile][K / 32][64][8].           */
 int tasu_gemm_stream_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias,
-                          const float* resid, int M, int N, int K, int out_mode, void* stream);
+                          const float* resid, int M, int N, int K, int out_mode, int a_frag, int w_frag, void* stream);
 int tasu_gemm_stream_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,
-                            void* stream);
+                            int a_frag, int w_frag, int out_frag, void* stream);
 int tasu_gemm_stream_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw, const void* bias, void* qkv, int M, int H,
                               int G, int K, const float* cos_tab, const float* sin_tab, void* kcache, void* vcache,
-                              const int32_t* pos, int ctx, void* stream);
+                              const int32_t* pos, int ctx, int a_frag, int w_frag, void* stream);
 int tasu_gemm_stream_slabs(const void* A, int lda, const void* W, int ldw, float* slabs, int64_t slab_floats, int M, int N,
-                           int K, int ksplit, void* stream);
+                           int K, int ksplit, int a_frag, int w_frag, void* stream);
 int tasu_stream_finish_norm(const float* slabs, int ksplit, float* C, const float* resid, int M, int N, const float* norm_w,
-                            void* y, float eps, void* stream);
+                            void* y, float eps, int y_frag, void* stream);
+/* y_f = rmsnorm(x, w) written in fragment order (M <= 64, D % 32 == 0): the decode step's first / post-attention norm. */
+int tasu_rmsnorm_fwd_frag(const float* x, const float* w, void* y_frag, int M, int D, float eps, void* stream);
+int tasu_to_fragment_order(const void* W, int ldw, void* out, int kind, int N, int K, int H, int G, void* stream);
 /* Qwen2MLP gate|up projection + activation in one launch (modeling_qwen2.py Qwen2MLP.forward, M <= 64):
  * act[M, I] = bf16( bf16(silu(g)) * u ),  g | u = bf16(A[M,K] . Wgu[2I,K]^T)  (gate rows first, then up rows).        */
 int tasu_gemm_skinny_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,
@@ -282,7 +290,7 @@ int tasu_kv_index_reorder(const int32_t* src_index, int32_t* dst_index, const in
 /* Single-token GQA attention over the cache: keys [kstart[row], lens[row]) visible (left padding / current length),
  * key i read from cache row row_index[row, i] (row_index NULL: the row itself); out [M, H*128] bf16.  ctx <= 2048. */
 int tasu_attn_decode(const void* qkv, const void* kcache, const void* vcache, const int32_t* row_index,
-                     const int32_t* kstart, const int32_t* lens, void* out, int M, int H, int G, int ctx, float scale,
+                     const int32_t* kstart, const int32_t* lens, void* out, int M, int H, int G, int ctx, float scale, int out_frag,
                      void* stream);
 /* log_softmax + top-k per row of bf16 logits [M, ld]: out_val[M,k] (descending log-probs), out_idx[M,k] (token ids;
  * ties: smaller id first); the n_banned ids in `banned` (device) score -inf after the softmax

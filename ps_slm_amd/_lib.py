@@ -61,14 +61,16 @@ PROTOTYPES = {
     "tasu_rope_append": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "tasu_kv_index_init": [vp, i32, i32, i32, i32, vp],
     "tasu_kv_index_reorder": [vp, vp, vp, vp, i32, i32, vp],
-    "tasu_attn_decode": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "tasu_attn_decode": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "tasu_logprob_topk": [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i64, vp],
     "tasu_stream_supported": [i32, i32],
-    "tasu_gemm_stream_bf16": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
-    "tasu_gemm_stream_swiglu": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],
-    "tasu_gemm_stream_qkv_rope": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp],
-    "tasu_gemm_stream_slabs": [vp, i32, vp, i32, vp, i64, i32, i32, i32, i32, vp],
-    "tasu_stream_finish_norm": [vp, i32, vp, vp, i32, i32, vp, vp, f32, vp],
+    "tasu_gemm_stream_bf16": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tasu_gemm_stream_swiglu": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tasu_gemm_stream_qkv_rope": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "tasu_gemm_stream_slabs": [vp, i32, vp, i32, vp, i64, i32, i32, i32, i32, i32, i32, vp],
+    "tasu_stream_finish_norm": [vp, i32, vp, vp, i32, i32, vp, vp, f32, i32, vp],
+    "tasu_rmsnorm_fwd_frag": [vp, vp, vp, i32, i32, f32, vp],
+    "tasu_to_fragment_order": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "tasu_gemm_nt_bf16_splitk": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "tasu_sum_slabs_bf16": [vp, i32, i64, vp, i64, vp],
     "tasu_beam_update": [vp] * 21 + [i32] * 7 + [vp],

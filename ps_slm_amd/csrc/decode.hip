@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64 * DEC_NW) void attn_decode_kernel(const bf16* __
                                                                   const int32_t* __restrict__ row_index,
                                                                   const int32_t* __restrict__ kstart,
                                                                   const int32_t* __restrict__ lens, bf16* __restrict__ out,
-                                                                  int H, int G, int ctx, float scale) {
+                                                                  int H, int G, int ctx, float scale, int out_frag) {
   // [REP][ctx] scores | [DEC_NW][REP][128] partial outputs | [REP] 1/l | [ctx] physical cache row of every visible key
   extern __shared__ float sp[];
   float* sc = sp;
@@ -219,7 +219,12 @@ __global__ __launch_bounds__(64 * DEC_NW) void attn_decode_kernel(const bf16* __
     float s = 0.f;
 #pragma unroll
     for (int w2 = 0; w2 < DEC_NW; ++w2) s += part[(w2 * REP + h) * HD + d];
-    out[(size_t)row * (H * HD) + (g * REP + h) * HD + d] = (bf16)(s * linv[h]);
+    const int n = (g * REP + h) * HD + d;                  // column of the [M, H * 128] attention output
+    // out_frag: the o projection's A operand in fragment order (csrc/gemm_stream.hip); row = row % 64 of its 64-row chunk
+    const size_t o = out_frag ? ((size_t)(row >> 6) * 64 * (H * HD)) +
+                                    ((((size_t)(n >> 5) * 4 + ((row & 63) >> 4)) * 64 + ((n & 31) >> 3) * 16 + (row & 15)) << 3) + (n & 7)
+                              : (size_t)row * (H * HD) + n;
+    out[o] = (bf16)(s * linv[h]);
   }
 }
 
@@ -613,7 +618,7 @@ extern "C" int tasu_kv_index_reorder(const int32_t* src_index, int32_t* dst_inde
 }
 extern "C" int tasu_attn_decode(const void* qkv, const void* kcache, const void* vcache, const int32_t* row_index,
                                 const int32_t* kstart, const int32_t* lens, void* out, int M, int H, int G, int ctx, float scale,
-                                void* stream) {
+                                int out_frag, void* stream) {
   if (!qkv || !kcache || !vcache || !kstart || !lens || !out || M <= 0 || H <= 0 || G <= 0 || H % G || ctx <= 0 ||
       ctx > MAX_CTX)
     return TASU_ERR_ARG;
@@ -629,7 +634,7 @@ extern "C" int tasu_attn_decode(const void* qkv, const void* kcache, const void*
       attr_set = true;                                                                                                \
     }                                                                                                                 \
     TASU_LAUNCH(attn_decode_kernel<R>, dim3(M, G), dim3(64 * DEC_NW), lds, (hipStream_t)stream, (const bf16*)qkv,      \
-                (const bf16*)kcache, (const bf16*)vcache, row_index, kstart, lens, (bf16*)out, H, G, ctx, scale);                 \
+                (const bf16*)kcache, (const bf16*)vcache, row_index, kstart, lens, (bf16*)out, H, G, ctx, scale, out_frag);       \
     return TASU_OK;                                                                                                   \
   }
   switch (rep) {

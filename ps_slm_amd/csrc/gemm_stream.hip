@@ -21,6 +21,18 @@
 //                  projection, K = 8960 = 5 x 1792; skinny_reduce_norm finishes it together with residual and next norm)
 //     -- the same arithmetic and rounding points as gemm_skinny.hip's kernels + finish kernels.
 // K range per workgroup = 8 waves x KS x 32 (KS = 1, 2, 6, 7: 256, 512, 1536, 1792); anything else stays on gemm_skinny.
+//
+// FRAGMENT-ORDER OPERANDS.  A lane's MFMA operand is 8 k-values of ONE matrix row, and the 16 lanes of a lane group hold 16
+// different rows: read straight from a row-major matrix, one wave instruction touches 16 rows x 64 B -- half-used cache lines,
+// 16 of them per 16-lane group (measured: the q|k|v projection spent ~10 of its 13 us loading its 196 KB of activations this
+// way).  Both operands therefore also exist in the order the MFMA consumes them, in which every wave instruction reads 1 KiB
+// contiguous:   X_f[k-step c = k / 32][row tile t][lane = 16 * ((k % 32) / 8) + row % 16][k % 8]
+//   * weights are static: tasu_to_fragment_order re-lays them out once at load time, per column tile in the row order of the
+//     tile's epilogue (w_frag = 1: W points at [tile][K / 32][64 lanes][8]);
+//   * activations [<= 64, K] are written in this order by their producers -- the SwiGLU epilogue here (out_frag), the norm
+//     kernels (tasu_rmsnorm_fwd_frag, tasu_stream_finish_norm) and the cache attention (tasu_attn_decode_frag) -- and read
+//     with a_frag = 1: [K / 32][4 row tiles][64 lanes][8].
+// Row-major operands (a_frag = w_frag = 0) remain supported (tests, first use before the layouts are registered).
 #include "common.h"
 #include "../../include/tasu_hip.h"
 
@@ -38,6 +50,8 @@ struct Args {
   int M, N, K, lda, ldw, ldc;
   int tiles;              // column tiles per K range
   int I;                  // E_SWIGLU: first "up" row of W
+  int a_frag, w_frag;     // operands in fragment order (see the header comment)
+  int out_frag;           // E_SWIGLU: act is written in fragment order (K of its consumer = N)
   // E_QKV
   int H, G, ctx;
   const float* cos_t;
@@ -70,19 +84,34 @@ __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_kernel(Args p) {
 
   // ---- activations: this wave's K slice of all 64 rows, as MFMA B operands (rows beyond M are clamped; masked at the store)
   bf16x8 a[4][KS];
+  const int cg0 = ((int)blockIdx.y * NW + wave) * KS;                   // this wave's first global k-step
+  if (p.a_frag) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const bf16* ar = p.A + (size_t)min(t * 16 + l15, p.M - 1) * p.lda + k0;
+    for (int c = 0; c < KS; ++c)
 #pragma unroll
-    for (int c = 0; c < KS; ++c) a[t][c] = *(const bf16x8*)(ar + c * 32);
+      for (int t = 0; t < 4; ++t) a[t][c] = *(const bf16x8*)(p.A + (((size_t)(cg0 + c) * 4 + t) * 64 + lane) * 8);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16* ar = p.A + (size_t)min(t * 16 + l15, p.M - 1) * p.lda + k0;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) a[t][c] = *(const bf16x8*)(ar + c * 32);
+    }
   }
 
   const int ntl = (p.tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles this workgroup walks
   auto tile_of = [&](int i) { return (int)blockIdx.x + min(i, ntl - 1) * (int)gridDim.x; };   // clamped: loads past the end re-read
+  const int ksteps_all = p.K >> 5;
   auto load_w = [&](bf16x8 (&w)[KS], int i) {
-    const bf16* wr = p.W + (size_t)min(weight_row<EPI>(p, tile_of(i), l15), (EPI == E_SWIGLU ? 2 * p.I : p.N) - 1) * p.ldw + k0;
+    if (p.w_frag) {
+      const bf16* wr = p.W + (((size_t)tile_of(i) * ksteps_all + cg0) * 64 + lane) * 8;
 #pragma unroll
-    for (int c = 0; c < KS; ++c) w[c] = __builtin_nontemporal_load((const bf16x8*)(wr + c * 32));
+      for (int c = 0; c < KS; ++c) w[c] = __builtin_nontemporal_load((const bf16x8*)(wr + c * 512));
+    } else {
+      const bf16* wr = p.W + (size_t)min(weight_row<EPI>(p, tile_of(i), l15), (EPI == E_SWIGLU ? 2 * p.I : p.N) - 1) * p.ldw + k0;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) w[c] = __builtin_nontemporal_load((const bf16x8*)(wr + c * 32));
+    }
   };
 
   auto finish = [&](int i) {
@@ -104,18 +133,23 @@ __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_kernel(Args p) {
       f32x4 u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) u[r] = __shfl_xor(s[r], 32, 64);
-      if (lq < 2 && m < p.M) {
+      if (lq < 2 && (m < p.M || p.out_frag)) {
         const int n = t * 8 + 4 * lq;
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (bf16)(bf16_round(silu_f(bf16_round(s[r]))) * bf16_round(u[r]));
-        bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n;
-        if (n + 4 <= p.N) {
-          *(bf16x4*)dst = o;
+        if (p.out_frag) {
+          // element (m, n .. n+3) of the consumer's A operand: k-step n / 32, lane group (n % 32) / 8, row tile = wave
+          *(bf16x4*)((bf16*)p.C + ((((size_t)(n >> 5) * 4 + wave) * 64 + ((n & 31) >> 3) * 16 + l15) << 3) + (n & 7)) = o;
         } else {
+          bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n;
+          if (n + 4 <= p.N) {
+            *(bf16x4*)dst = o;
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) dst[r] = o[r];
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) dst[r] = o[r];
+          }
         }
       }
       return;
@@ -272,7 +306,7 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" int tasu_stream_supported(int K, int ksplit) { return tasu_stream::k_supported(K, ksplit) ? 1 : 0; }
 
 extern "C" int tasu_gemm_stream_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias,
-                                     const float* resid, int M, int N, int K, int out_mode, void* stream) {
+                                     const float* resid, int M, int N, int K, int out_mode, int a_frag, int w_frag, void* stream) {
   using namespace tasu_stream;
   if (!A || !W || !C || M <= 0 || M > 64 || N <= 0 || !k_supported(K, 1) || lda % 8 || ldw % 8) return TASU_ERR_ARG;
   if (!aligned16(A) || !aligned16(W)) return TASU_ERR_ARG;
@@ -287,11 +321,12 @@ extern "C" int tasu_gemm_stream_bf16(const void* A, int lda, const void* W, int 
   a.bias = (const bf16*)bias;
   a.M = M, a.N = N, a.K = K, a.lda = lda, a.ldw = ldw, a.ldc = ldc;
   a.tiles = (N + 15) / 16;
+  a.a_frag = a_frag, a.w_frag = w_frag;
   return out_mode == TASU_GEMM_OUT_BF16 ? launch<E_BF16>(a, 1, (hipStream_t)stream) : launch<E_RESID>(a, 1, (hipStream_t)stream);
 }
 
 extern "C" int tasu_gemm_stream_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,
-                                       void* stream) {
+                                       int a_frag, int w_frag, int out_frag, void* stream) {
   using namespace tasu_stream;
   if (!A || !Wgu || !act || M <= 0 || M > 64 || I <= 0 || I % 8 || !k_supported(K, 1) || lda % 8 || ldw % 8 || ldact % 4)
     return TASU_ERR_ARG;
@@ -303,12 +338,14 @@ extern "C" int tasu_gemm_stream_swiglu(const void* A, int lda, const void* Wgu, 
   a.M = M, a.N = I, a.K = K, a.lda = lda, a.ldw = ldw, a.ldc = ldact;
   a.I = I;
   a.tiles = I / 8;
+  a.a_frag = a_frag, a.w_frag = w_frag, a.out_frag = out_frag;
+  if (out_frag && I % 32) return TASU_ERR_ARG;
   return launch<E_SWIGLU>(a, 1, (hipStream_t)stream);
 }
 
 extern "C" int tasu_gemm_stream_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw, const void* bias, void* qkv, int M,
                                          int H, int G, int K, const float* cos_tab, const float* sin_tab, void* kcache,
-                                         void* vcache, const int32_t* pos, int ctx, void* stream) {
+                                         void* vcache, const int32_t* pos, int ctx, int a_frag, int w_frag, void* stream) {
   using namespace tasu_stream;
   if (!A || !Wqkv || !qkv || !cos_tab || !sin_tab || !kcache || !vcache || !pos || M <= 0 || M > 64 || H <= 0 || G <= 0 ||
       !k_supported(K, 1) || lda % 8 || ldw % 8 || ctx <= 0)
@@ -326,13 +363,14 @@ extern "C" int tasu_gemm_stream_qkv_rope(const void* A, int lda, const void* Wqk
   a.cos_t = cos_tab, a.sin_t = sin_tab;
   a.kc = (bf16*)kcache, a.vc = (bf16*)vcache, a.pos = pos;
   a.tiles = (H + 2 * G) * 8;
+  a.a_frag = a_frag, a.w_frag = w_frag;
   return launch<E_QKV>(a, 1, (hipStream_t)stream);
 }
 
 // K split over workgroups: fp32 partial tiles [ksplit][N/16][16 x 64] in `slabs` (fragment order: element ((w * 64 + l) * 4 + r)
 // of a tile = C[m = 16 w + (l & 15)][column 4 (l >> 4) + r]); tasu_stream_finish_norm sums them.
 extern "C" int tasu_gemm_stream_slabs(const void* A, int lda, const void* W, int ldw, float* slabs, int64_t slab_floats, int M,
-                                      int N, int K, int ksplit, void* stream) {
+                                      int N, int K, int ksplit, int a_frag, int w_frag, void* stream) {
   using namespace tasu_stream;
   if (!A || !W || !slabs || M <= 0 || M > 64 || N <= 0 || N % 16 || !k_supported(K, ksplit) || lda % 8 || ldw % 8) return TASU_ERR_ARG;
   if (!aligned16(A) || !aligned16(W) || !aligned16(slabs)) return TASU_ERR_ARG;
@@ -343,6 +381,7 @@ extern "C" int tasu_gemm_stream_slabs(const void* A, int lda, const void* W, int
   a.C = slabs;
   a.M = M, a.N = N, a.K = K, a.lda = lda, a.ldw = ldw, a.ldc = N;
   a.tiles = N / 16;
+  a.a_frag = a_frag, a.w_frag = w_frag;
   return launch<E_SLAB>(a, ksplit, (hipStream_t)stream);
 }
 
@@ -352,7 +391,8 @@ namespace tasu_stream {
 // arithmetic of gemm_skinny.hip's skinny_reduce_norm_kernel on this kernel's slab layout.  N % 16 == 0.
 __global__ __launch_bounds__(256) void stream_finish_norm_kernel(const float* __restrict__ slabs, int ksplit, int tiles,
                                                                  float* __restrict__ C, const float* __restrict__ R, int N,
-                                                                 const float* __restrict__ nw, bf16* __restrict__ y, float eps) {
+                                                                 const float* __restrict__ nw, bf16* __restrict__ y, float eps,
+                                                                 int y_frag) {
   __shared__ float red[4];
   const int m = blockIdx.x;
   const int row_tile = m >> 4, l15 = m & 15;
@@ -381,15 +421,88 @@ __global__ __launch_bounds__(256) void stream_finish_norm_kernel(const float* __
     f32x4 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = w[q] * (v[q] * rs);
-    *(bf16x4*)(y + (size_t)m * N + n) = __builtin_convertvector(o, bf16x4);
+    bf16* dst = y_frag ? y + ((((size_t)(n >> 5) * 4 + row_tile) * 64 + ((n & 31) >> 3) * 16 + l15) << 3) + (n & 7)
+                       : y + (size_t)m * N + n;
+    *(bf16x4*)dst = __builtin_convertvector(o, bf16x4);
+  }
+}
+
+// y_f = rmsnorm(x) in fragment order (tasu_rmsnorm_fwd's arithmetic: one wave per row, same summation order).  D % 32 == 0.
+__global__ __launch_bounds__(256) void rmsnorm_fwd_frag_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               bf16* __restrict__ y, int M, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * D;
+  float ss = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 v = *(const f32x4*)(xr + c);
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)D + eps);
+  const int row_tile = row >> 4, l15 = row & 15;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 v = *(const f32x4*)(xr + c);
+    const f32x4 g = *(const f32x4*)(w + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[j] * r);
+    *(bf16x4*)(y + ((((size_t)(c >> 5) * 4 + row_tile) * 64 + ((c & 31) >> 3) * 16 + l15) << 3) + (c & 7)) =
+        __builtin_convertvector(o, bf16x4);
+  }
+}
+
+// Re-lays a row-major weight matrix out in fragment order, one 16-row column tile at a time in the row order of the tile's
+// epilogue (kind: E_BF16 plain, E_SWIGLU 8 gate + 8 up rows, E_QKV paired RoPE columns).  Load-time work.
+template <int EPI>
+__global__ __launch_bounds__(256) void to_fragment_order_kernel(Args p, bf16* __restrict__ out) {
+  const int t = blockIdx.x;
+  const int ksteps = p.K >> 5;
+  const int limit = (EPI == E_SWIGLU ? 2 * p.I : p.N) - 1;
+  for (int e = threadIdx.x; e < ksteps * 64; e += 256) {
+    const int c = e >> 6, lane = e & 63;
+    const int row = min(weight_row<EPI>(p, t, lane & 15), limit);
+    *(bf16x8*)(out + (((size_t)t * ksteps + c) * 64 + lane) * 8) = *(const bf16x8*)(p.W + (size_t)row * p.ldw + c * 32 + (lane >> 4) * 8);
   }
 }
 }  // namespace tasu_stream
 
 extern "C" int tasu_stream_finish_norm(const float* slabs, int ksplit, float* C, const float* resid, int M, int N,
-                                       const float* norm_w, void* y, float eps, void* stream) {
-  if (!slabs || !C || !resid || !norm_w || !y || ksplit < 1 || M <= 0 || M > 64 || N <= 0 || N % 16) return TASU_ERR_ARG;
+                                       const float* norm_w, void* y, float eps, int y_frag, void* stream) {
+  if (!slabs || !C || !resid || !norm_w || !y || ksplit < 1 || M <= 0 || M > 64 || N <= 0 || N % 16 || (y_frag && N % 32))
+    return TASU_ERR_ARG;
   TASU_LAUNCH(tasu_stream::stream_finish_norm_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, slabs, ksplit, N / 16, C, resid, N,
-              norm_w, (bf16*)y, eps);
+              norm_w, (bf16*)y, eps, y_frag);
+  return TASU_OK;
+}
+
+extern "C" int tasu_rmsnorm_fwd_frag(const float* x, const float* w, void* y_frag, int M, int D, float eps, void* stream) {
+  if (!x || !w || !y_frag || M <= 0 || M > 64 || D <= 0 || D % 32) return TASU_ERR_ARG;
+  TASU_LAUNCH(tasu_stream::rmsnorm_fwd_frag_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)y_frag, M, D, eps);
+  return TASU_OK;
+}
+
+extern "C" int tasu_to_fragment_order(const void* W, int ldw, void* out, int kind, int N, int K, int H, int G, void* stream) {
+  using namespace tasu_stream;
+  if (!W || !out || N <= 0 || K <= 0 || K % 32 || ldw % 8 || !aligned16(W) || !aligned16(out)) return TASU_ERR_ARG;
+  Args a{};
+  a.W = (const bf16*)W;
+  a.K = K, a.ldw = ldw;
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == E_BF16) {
+    a.N = N;
+    TASU_LAUNCH(to_fragment_order_kernel<E_BF16>, dim3((N + 15) / 16), dim3(256), 0, st, a, (bf16*)out);
+  } else if (kind == E_SWIGLU) {                         // N = I (output columns); W holds 2 I rows
+    if (N % 8) return TASU_ERR_ARG;
+    a.N = N, a.I = N;
+    TASU_LAUNCH(to_fragment_order_kernel<E_SWIGLU>, dim3(N / 8), dim3(256), 0, st, a, (bf16*)out);
+  } else if (kind == E_QKV) {
+    if (H <= 0 || G <= 0 || N != (H + 2 * G) * 128) return TASU_ERR_ARG;
+    a.N = N, a.H = H, a.G = G;
+    TASU_LAUNCH(to_fragment_order_kernel<E_QKV>, dim3((H + 2 * G) * 8), dim3(256), 0, st, a, (bf16*)out);
+  } else {
+    return TASU_ERR_ARG;
+  }
   return TASU_OK;
 }

@@ -160,6 +160,27 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     buf = model._buf
     # ---- prefill with the training-forward kernels (no loss)
     model.forward_llm(st, compute_loss=False, need_backward=False, logits_rows="none")
+    # decode-step weights in the order the streaming kernels consume them (built once per model), and the decision whether the
+    # step's bf16 activations travel between its kernels in that order too (ops.begin_decode)
+    llm.prepare_decode(ops)
+    ops.begin_decode(D, H * HD, I)
+    try:
+        return _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_penalty, eos, pad)
+    finally:
+        ops.end_decode()
+
+
+def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_penalty, eos, pad):
+    ops, geo, llm = model.ops, model.geo, model.llm
+    B, S = st.B, st.S
+    M, K = B * nb, 2 * nb
+    Mp = rup(M, 64)                                                         # fragment-order buffers hold whole 64-row chunks
+    D, I, H, G, V, L = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_vocab, geo.llm_layers
+    Vp, LDQ, W = rup(V, 64), (H + 2 * G) * HD, G * HD
+    ctx = S + max_new_tokens
+    scale = HD ** -0.5
+    bf, f32, i32 = torch.bfloat16, torch.float32, torch.int32
+    buf = model._buf
     d = st.dev
     # KV cache [L][M, ctx, W] + the beam row index (include/tasu_hip.h): the prompt is stored once per utterance and a
     # beam reorder permutes 4-byte index entries once per step instead of copying K/V in every layer
@@ -178,7 +199,7 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     last_rows = model._upload("dec_last_rows", (np.arange(B, dtype=np.int32) + 1) * S - 1)
     xl = buf("dec_xlast", (B, D), f32)
     ops.embed_rows(d["xs"][2 * L], last_rows, xl, B, D)                    # row gather out of the residual stream
-    xn = buf("dec_xn", (M, D), bf)
+    xn = buf("dec_xn", (Mp, D), bf)
     logits = buf("dec_logits", (M, Vp), bf)
     ops.rmsnorm_fwd(xl, llm.norm, xn[:B], None, geo.rms_eps)
     ops.gemm(xn, llm.head, logits, B, V, D)
@@ -190,8 +211,8 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     x = buf("dec_x", (M, D), f32)
     x2 = buf("dec_x2", (M, D), f32)
     qkv = buf("dec_qkv", (M, LDQ), bf)
-    ao = buf("dec_ao", (M, H * HD), bf)
-    act = buf("dec_act", (M, I), bf)
+    ao = buf("dec_ao", (Mp, H * HD), bf)
+    act = buf("dec_act", (Mp, I), bf)
     cos = buf("dec_cos", (M, HD // 2), f32)
     sin = buf("dec_sin", (M, HD // 2), f32)
     ws = buf("dec_gemm_ws", (32 * 64 * rup(max(V, 2 * I), 96),), f32)          # tasu_gemm_skinny_bf16 split-K slabs
@@ -210,7 +231,8 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
         ops.kv_index_reorder(index_tmp, index, None, slot_d, M, ctx)
         ops.embed_rows(llm.embed, ids_d, x, M, D)
         ops.rope_table(pos_d, cos, sin, HD, geo.rope_theta)
-        ops.rmsnorm_fwd(x, llm.layers[0]["ln1"], xn, None, geo.rms_eps)
+        for m0, mc in chunks:
+            ops.dec_rmsnorm(x[m0:m0 + mc], llm.layers[0]["ln1"], xn[m0:m0 + mc], geo.rms_eps)
         for l, w in enumerate(llm.layers):
             next_norm = llm.layers[l + 1]["ln1"] if l + 1 < L else llm.norm      # the norm that consumes this layer's output
             for m0, mc in chunks:                                                # qkv projection + bias + RoPE + cache append

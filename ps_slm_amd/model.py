@@ -152,6 +152,7 @@ class LLMWeights:
         self.head = None       # bf16 [V, D]
         self.head_t = None     # bf16 [D, Vpad]
         self.norm = None       # fp32 [D]
+        self._decode_ready = False
 
     @staticmethod
     def _pair(w, device):
@@ -181,8 +182,23 @@ class LLMWeights:
         self.head_t[:, :V].copy_(hb.t())
         self.norm = norm.to(dev, torch.float32).contiguous()
 
+    def prepare_decode(self, ops):
+        """Decode-step copies of the frozen weights in the order the weight-streaming kernels consume them
+        (ops.register_decode_weight; once per model, +1x the decoder's bf16 bytes)."""
+        if self._decode_ready:
+            return
+        geo = self.geo
+        for w in self.layers:
+            ops.register_decode_weight(w["wqkv"], "qkv", w["wqkv"].shape[0], geo.llm_heads, geo.llm_kv_heads)
+            ops.register_decode_weight(w["wo"], "plain", w["wo"].shape[0])
+            ops.register_decode_weight(w["wgu"], "swiglu", geo.llm_inter)
+            ops.register_decode_weight(w["wd"], "plain", w["wd"].shape[0])
+        ops.register_decode_weight(self.head, "plain", self.head.shape[0])
+        self._decode_ready = True
+
     def load_reference_state_dict(self, sd, pre="llm."):
         geo = self.geo
+        self._decode_ready = False
         self.layers = []
         for l in range(geo.llm_layers):
             p = f"{pre}model.layers.{l}."
@@ -201,6 +217,7 @@ class LLMWeights:
         (no pretrained weights exist on the benchmark box)."""
         geo, dev = self.geo, self.device
         self.layers = []
+        self._decode_ready = False
         g = torch.Generator(device=dev).manual_seed(seed)
         D, I, H, G = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads
 

@@ -38,6 +38,8 @@ class HipOps:
         # decode-step GEMMs: the single-launch weight-streaming kernels (csrc/gemm_stream.hip) where they serve the shape,
         # the split-K + finish kernels (csrc/gemm_skinny.hip) otherwise.  TASU_DECODE_STREAM=0 forces the latter (A/B runs).
         self.use_stream = os.environ.get("TASU_DECODE_STREAM", "1") != "0"
+        self.dec_frag = False          # set by begin_decode(): decode activations travel in fragment order
+        self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -70,6 +72,7 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_gate_up_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), M, I, K,
                                                     self._stream()), "tasu_gemm_gate_up_swiglu")
 
+    # ------------------------------------------------------------------ decode-step GEMMs
     def _stream_split(self, K):
         """K ranges the streaming kernels can take this K in (0 = not served)."""
         if not self.use_stream:
@@ -79,11 +82,46 @@ class HipOps:
                 return ks
         return 0
 
+    def begin_decode(self, D, HHD, I):
+        """Called once per generate(): decides whether the decode step's bf16 activations (normed hidden state, attention
+        output, MLP activation) travel between its kernels in FRAGMENT ORDER (include/tasu_hip.h) -- possible when the
+        streaming kernels serve every GEMM of the layer.  Returns that decision."""
+        self.dec_frag = bool(self._stream_split(D) == 1 and self._stream_split(HHD) == 1 and self._stream_split(I) > 0
+                             and D % 32 == 0 and HHD % 32 == 0 and I % 32 == 0)
+        return self.dec_frag
+
+    def end_decode(self):
+        self.dec_frag = False
+
+    def register_decode_weight(self, w, kind, N, H=0, G=0):
+        """Load-time: a fragment-order copy of a decode-step weight (kind: 'plain' | 'swiglu' | 'qkv'), looked up by the
+        row-major tensor's address when a streaming GEMM is called with it."""
+        if not self.use_stream or w.data_ptr() in self._frag or self._stream_split(w.shape[1]) == 0:
+            return
+        out = torch.empty(w.numel() if kind != "plain" else ((N + 15) // 16) * 16 * w.shape[1], dtype=torch.bfloat16, device=w.device)
+        code = {"plain": 0, "swiglu": 2, "qkv": 3}[kind]
+        self._chk(self.lib.tasu_to_fragment_order(_p(w), w.stride(0), _p(out), code, N, w.shape[1], H, G, self._stream()),
+                  "tasu_to_fragment_order")
+        self._frag[w.data_ptr()] = (out, w)          # keeps the row-major tensor alive: its address is the key
+
+    def _wf(self, w):
+        f = self._frag.get(w.data_ptr())
+        return (f[0], 1) if f is not None else (w, 0)
+
+    def dec_rmsnorm(self, x, w, y, eps):
+        """y = rmsnorm(x) for the decode step: fragment order when the layer runs on the streaming kernels."""
+        M, D = x.shape
+        if self.dec_frag:
+            return self._chk(self.lib.tasu_rmsnorm_fwd_frag(_p(x), _p(w), _p(y), M, D, eps, self._stream()), "tasu_rmsnorm_fwd_frag")
+        self._chk(self.lib.tasu_rmsnorm_fwd(_p(x), _p(w), _p(y), None, M, D, eps, self._stream()), "tasu_rmsnorm_fwd")
+
     def gemm_skinny(self, a, b, c, M, N, K, ws, bias=None, resid=None, mode=GEMM_BF16):
         """M <= 64 weight-streaming GEMM (decode step); ws: fp32 workspace tensor."""
         if mode == GEMM_BF16 and resid is None and self._stream_split(K) == 1 and c.stride(0) % 4 == 0:
-            return self._chk(self.lib.tasu_gemm_stream_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(bias),
-                                                            None, M, N, K, mode, self._stream()), "tasu_gemm_stream_bf16")
+            wf, wflag = self._wf(b)
+            return self._chk(self.lib.tasu_gemm_stream_bf16(_p(a), a.stride(0), _p(wf), b.stride(0), _p(c), c.stride(0), _p(bias),
+                                                            None, M, N, K, mode, int(self.dec_frag), wflag, self._stream()),
+                             "tasu_gemm_stream_bf16")
         self._chk(self.lib.tasu_gemm_skinny_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(bias),
                                                  _p(resid), M, N, K, mode, _p(ws), 0 if ws is None else ws.numel(),
                                                  self._stream()), "tasu_gemm_skinny_bf16")
@@ -243,15 +281,17 @@ class HipOps:
     def gemm_skinny_norm(self, a, b, c, resid, M, N, K, norm_w, y, eps, ws):
         """c (fp32) = resid + bf16(a @ b^T); y = rmsnorm(c, norm_w) -- decode-step projection with the next norm fused."""
         ks = self._stream_split(K) if N % 16 == 0 else 0
+        frag = int(self.dec_frag)
+        wf, wflag = self._wf(b)
         if ks == 1:
             # one launch for the projection + residual add, one for the norm (the sum of squares needs the whole row)
-            self._chk(self.lib.tasu_gemm_stream_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), N, None, _p(resid), M, N, K,
-                                                     GEMM_RESID, self._stream()), "tasu_gemm_stream_bf16")
-            return self._chk(self.lib.tasu_rmsnorm_fwd(_p(c), _p(norm_w), _p(y), None, M, N, eps, self._stream()), "tasu_rmsnorm_fwd")
+            self._chk(self.lib.tasu_gemm_stream_bf16(_p(a), a.stride(0), _p(wf), b.stride(0), _p(c), N, None, _p(resid), M, N, K,
+                                                     GEMM_RESID, frag, wflag, self._stream()), "tasu_gemm_stream_bf16")
+            return self.dec_rmsnorm(c[:M], norm_w, y, eps)
         if ks > 1 and ws is not None and ws.numel() >= ks * (N // 16) * 1024:
-            self._chk(self.lib.tasu_gemm_stream_slabs(_p(a), a.stride(0), _p(b), b.stride(0), _p(ws), ws.numel(), M, N, K, ks,
-                                                      self._stream()), "tasu_gemm_stream_slabs")
-            return self._chk(self.lib.tasu_stream_finish_norm(_p(ws), ks, _p(c), _p(resid), M, N, _p(norm_w), _p(y), eps,
+            self._chk(self.lib.tasu_gemm_stream_slabs(_p(a), a.stride(0), _p(wf), b.stride(0), _p(ws), ws.numel(), M, N, K, ks,
+                                                      frag, wflag, self._stream()), "tasu_gemm_stream_slabs")
+            return self._chk(self.lib.tasu_stream_finish_norm(_p(ws), ks, _p(c), _p(resid), M, N, _p(norm_w), _p(y), eps, frag,
                                                               self._stream()), "tasu_stream_finish_norm")
         self._chk(self.lib.tasu_gemm_skinny_norm(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), _p(resid), M, N, K, _p(norm_w),
                                                  _p(y), eps, _p(ws), 0 if ws is None else ws.numel(), self._stream()),
@@ -260,8 +300,10 @@ class HipOps:
     def gemm_skinny_qkv_rope(self, a, wqkv, bias, qkv, M, H, G, K, cos, sin, kc, vc, pos, ctx, ws):
         """qkv = rope(a @ wqkv^T + bias); k, v appended to the cache at pos -- one call per decode-step layer."""
         if self._stream_split(K) == 1:
-            return self._chk(self.lib.tasu_gemm_stream_qkv_rope(_p(a), a.stride(0), _p(wqkv), wqkv.stride(0), _p(bias), _p(qkv), M, H,
-                                                                G, K, _p(cos), _p(sin), _p(kc), _p(vc), _p(pos), ctx, self._stream()),
+            wf, wflag = self._wf(wqkv)
+            return self._chk(self.lib.tasu_gemm_stream_qkv_rope(_p(a), a.stride(0), _p(wf), wqkv.stride(0), _p(bias), _p(qkv), M, H,
+                                                                G, K, _p(cos), _p(sin), _p(kc), _p(vc), _p(pos), ctx,
+                                                                int(self.dec_frag), wflag, self._stream()),
                              "tasu_gemm_stream_qkv_rope")
         self._chk(self.lib.tasu_gemm_skinny_qkv_rope(_p(a), a.stride(0), _p(wqkv), wqkv.stride(0), _p(bias), _p(qkv), M, H, G, K,
                                                      _p(cos), _p(sin), _p(kc), _p(vc), _p(pos), ctx, _p(ws),
@@ -271,8 +313,10 @@ class HipOps:
     def gemm_skinny_swiglu(self, a, wgu, act, M, I, K, ws):
         """act[M, I] = swiglu(a[M,K] @ wgu[2I,K]^T) in one launch (decode step)."""
         if self._stream_split(K) == 1 and I % 8 == 0 and act.stride(0) % 4 == 0:
-            return self._chk(self.lib.tasu_gemm_stream_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), M, I,
-                                                              K, self._stream()), "tasu_gemm_stream_swiglu")
+            wf, wflag = self._wf(wgu)
+            frag = int(self.dec_frag)
+            return self._chk(self.lib.tasu_gemm_stream_swiglu(_p(a), a.stride(0), _p(wf), wgu.stride(0), _p(act), act.stride(0), M, I,
+                                                              K, frag, wflag, frag, self._stream()), "tasu_gemm_stream_swiglu")
         self._chk(self.lib.tasu_gemm_skinny_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), M, I, K,
                                                    _p(ws), 0 if ws is None else ws.numel(), self._stream()),
                   "tasu_gemm_skinny_swiglu")
@@ -290,7 +334,7 @@ class HipOps:
 
     def attn_decode(self, qkv, kc, vc, index, kstart, lens, out, M, H, G, ctx, scale):
         self._chk(self.lib.tasu_attn_decode(_p(qkv), _p(kc), _p(vc), _p(index), _p(kstart), _p(lens), _p(out), M, H, G, ctx, scale,
-                                            self._stream()), "tasu_attn_decode")
+                                            int(self.dec_frag), self._stream()), "tasu_attn_decode")
 
     def logprob_topk(self, logits, M, V, k, banned, n_banned, out_val, out_idx):
         need = M * 16 * (2 + 2 * k)

@@ -457,6 +457,18 @@ class FakeOps:
         self.gemm(a, wgu, gu, M, 2 * I, K)
         self.swiglu_fwd(gu, act, M, I)
 
+    def begin_decode(self, D, HHD, I):
+        return False
+
+    def end_decode(self):
+        pass
+
+    def register_decode_weight(self, w, kind, N, H=0, G=0):
+        pass
+
+    def dec_rmsnorm(self, x, w, y, eps):
+        self.rmsnorm_fwd(x, w, y[: x.shape[0]], None, eps)
+
     def gemm_skinny_norm(self, a, b, c, resid, M, N, K, norm_w, y, eps, ws):
         self.gemm(a, b, c, M, N, K, resid=resid, mode=2)
         self.rmsnorm_fwd(c[:M], norm_w, y[:M], None, eps)
@@ -501,7 +513,7 @@ class FakeOps:
                 s = (kr[:, g] @ (q[r, h] * scale))
                 p = torch.exp(s - s.max())
                 o[r, h] = (_bf(p).float() @ vr[:, g]) / p.sum()
-        out.view(M, H, HD).copy_(_bf(o))
+        out[:M].view(M, H, HD).copy_(_bf(o))            # out may be padded to whole 64-row chunks
 
     def logprob_topk(self, logits, M, V, k, banned, n_banned, out_val, out_idx):
         lg = logits[:M, :V].float()

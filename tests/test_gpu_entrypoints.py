@@ -77,6 +77,8 @@ def test_validation_loop_and_best_checkpoint_on_gpu(tmp_path):
                          use_fp16=True)
         mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
         model, _ = model_factory(tc, mc, device=device, ops=ops, init_seed=1234, keep_logits=False)
+        # the factory's synthetic init draws on the model's own device: give both runs the same (CPU-drawn) weights
+        model.core.load_reference_state_dict(random_state_dict(model.core.geo, 11, with_encoder=False))
         cfg = load_ds_config(DEFAULT_DS_CONFIG)
         cfg["lr"] = 1e-3
         eng = TasuEngine(model, cfg)

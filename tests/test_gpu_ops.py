@@ -654,3 +654,62 @@ def test_beam_update_kernel_is_exact(hip, nb, lpw, min_len, quantise):
     fake, calls_f = run_device(FakeOps(), "cpu", table, B, nb, T, eos, lpw, min_len)
     assert np.array_equal(got, want), (got, want)
     assert np.array_equal(got, fake) and calls == calls_f
+
+
+@pytest.mark.parametrize("M,D,I,H,G,V", [(64, 1536, 8960, 12, 2, 4000), (40, 256, 512, 2, 1, 1000), (64, 512, 1792, 4, 2, 520)])
+def test_decode_layer_chain_in_fragment_order(hip, fake, M, D, I, H, G, V):
+    """One decode layer + lm_head on the streaming kernels with every operand in FRAGMENT ORDER (weights re-laid out by
+    tasu_to_fragment_order, activations written in that order by the norm / attention / SwiGLU producers) against the same
+    kernels on row-major operands: the layouts only change where bytes live, so every output must be BIT-identical; and both
+    agree with the CPU double within bf16 tolerance."""
+    ctx, LD, W, HHD = 24, (H + 2 * G) * HD, G * HD, H * HD
+    g = torch.Generator().manual_seed(D + I)
+    rn = lambda *sh, k=1.0: (torch.randn(*sh, generator=g) * k)
+    wqkv, bq = rn(LD, D, k=D ** -0.5).to(BF), rn(LD).to(BF)
+    wo, wgu, wd = rn(D, HHD, k=HHD ** -0.5).to(BF), rn(2 * I, D, k=D ** -0.5).to(BF), rn(D, I, k=I ** -0.5).to(BF)
+    head = rn(V, D, k=D ** -0.5).to(BF)
+    ln1, ln2, ln3 = 1 + 0.1 * rn(D), 1 + 0.1 * rn(D), 1 + 0.1 * rn(D)
+    x0 = rn(M, D)
+    ang = rn(M, 64)
+    cos, sin = torch.cos(ang), torch.sin(ang)
+    pos = (3 + torch.arange(M) % 5).to(I32)
+    kc0, vc0 = rn(M * ctx * W).to(BF), rn(M * ctx * W).to(BF)
+    kstart, lens = torch.zeros(M, dtype=I32), (pos + 1).to(I32)
+
+    def chain(ops, dev_, frag):
+        t = lambda a: a.to(dev_)
+        w = dict(wqkv=t(wqkv), wo=t(wo), wgu=t(wgu), wd=t(wd), head=t(head))
+        if frag:
+            ops.register_decode_weight(w["wqkv"], "qkv", LD, H, G)
+            ops.register_decode_weight(w["wo"], "plain", D)
+            ops.register_decode_weight(w["wgu"], "swiglu", I)
+            ops.register_decode_weight(w["wd"], "plain", D)
+            ops.register_decode_weight(w["head"], "plain", V)
+            assert ops.begin_decode(D, HHD, I)
+        Mp = 64
+        x, x2 = t(x0.clone()), torch.zeros(M, D, device=dev_)
+        xn, ao, act = (torch.zeros(Mp, n, dtype=BF, device=dev_) for n in (D, HHD, I))
+        qkv = torch.zeros(M, LD, dtype=BF, device=dev_)
+        kc, vc = t(kc0.clone()), t(vc0.clone())
+        ws = torch.zeros(32 * 64 * ((max(V, 2 * I) + 95) // 96 * 96), device=dev_) if dev_ != "cpu" else None
+        logits = torch.zeros(M, (V + 63) // 64 * 64, dtype=BF, device=dev_)
+        ops.dec_rmsnorm(x, t(ln1), xn, 1e-6)
+        ops.gemm_skinny_qkv_rope(xn, w["wqkv"], t(bq), qkv, M, H, G, D, t(cos), t(sin), kc, vc, t(pos), ctx, ws)
+        ops.attn_decode(qkv, kc, vc, None, t(kstart), t(lens), ao, M, H, G, ctx, HD ** -0.5)
+        ops.gemm_skinny_norm(ao, w["wo"], x2, x, M, D, HHD, t(ln2), xn, 1e-6, ws)
+        ops.gemm_skinny_swiglu(xn, w["wgu"], act, M, I, D, ws)
+        ops.gemm_skinny_norm(act, w["wd"], x, x2, M, D, I, t(ln3), xn, 1e-6, ws)
+        ops.gemm_skinny(xn, w["head"], logits, M, V, D, ws)
+        if dev_ != "cpu":
+            torch.cuda.synchronize()
+        if frag:
+            ops.end_decode()
+        return [a.cpu() for a in (qkv, kc, vc, x2, x, logits[:, :V])]
+
+    hip.use_stream = True
+    row = chain(hip, "cuda", False)
+    frg = chain(hip, "cuda", True)
+    cpu = chain(fake, "cpu", False)
+    for name, a, b, c in zip(("qkv", "kc", "vc", "x_mid", "x_out", "logits"), row, frg, cpu):
+        assert torch.equal(a, b), name
+        assert rel_err(a, c) < 3e-2, name
