@@ -73,27 +73,33 @@ __device__ __forceinline__ int weight_row(const Args& p, int t, int r) {
   return t * 16 + r;
 }
 
-template <int KS, int EPI>
+// MT = 16-row tiles of the activations a workgroup owns (4 = all 64 rows; 2 / 1: the rows are split over blockIdx.z, for GEMMs
+// with too few column tiles to occupy the chip -- a workgroup's traffic is its (MT * 16 + columns) x K operand bytes, and with
+// 1-2 column tiles per workgroup the 64 activation rows dominate it).
+// FRAG: both operands in fragment order (compile-time: a run-time layout test inside the load lambdas splits the ring loop
+// into branches across which the compiler drains vmcnt).
+template <int KS, int EPI, int MT, bool FRAG>
 __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_kernel(Args p) {
-  // partial tiles: [2 buffers][NW waves][4 row tiles][64 lanes] f32x4 = 2 x 32 KiB
-  __shared__ __attribute__((aligned(16))) float red[2][NW][4][64][4];
+  // partial tiles: [2 buffers][NW waves][MT row tiles][64 lanes] f32x4
+  __shared__ __attribute__((aligned(16))) float red[2][NW][MT][64][4];
+  const int mt0 = (int)blockIdx.z * MT;                 // first row tile of this workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
   const int krange = NW * KS * 32;
   const int k0 = blockIdx.y * krange + wave * (KS * 32) + lq * 8;      // this lane's first k of step 0
 
   // ---- activations: this wave's K slice of all 64 rows, as MFMA B operands (rows beyond M are clamped; masked at the store)
-  bf16x8 a[4][KS];
+  bf16x8 a[MT][KS];
   const int cg0 = ((int)blockIdx.y * NW + wave) * KS;                   // this wave's first global k-step
-  if (p.a_frag) {
+  if (FRAG) {
 #pragma unroll
     for (int c = 0; c < KS; ++c)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) a[t][c] = *(const bf16x8*)(p.A + (((size_t)(cg0 + c) * 4 + t) * 64 + lane) * 8);
+      for (int t = 0; t < MT; ++t) a[t][c] = *(const bf16x8*)(p.A + (((size_t)(cg0 + c) * 4 + mt0 + t) * 64 + lane) * 8);
   } else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bf16* ar = p.A + (size_t)min(t * 16 + l15, p.M - 1) * p.lda + k0;
+    for (int t = 0; t < MT; ++t) {
+      const bf16* ar = p.A + (size_t)min((mt0 + t) * 16 + l15, p.M - 1) * p.lda + k0;
 #pragma unroll
       for (int c = 0; c < KS; ++c) a[t][c] = *(const bf16x8*)(ar + c * 32);
     }
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_kernel(Args p) {
   auto tile_of = [&](int i) { return (int)blockIdx.x + min(i, ntl - 1) * (int)gridDim.x; };   // clamped: loads past the end re-read
   const int ksteps_all = p.K >> 5;
   auto load_w = [&](bf16x8 (&w)[KS], int i) {
-    if (p.w_frag) {
+    if (FRAG) {
       const bf16* wr = p.W + (((size_t)tile_of(i) * ksteps_all + cg0) * 64 + lane) * 8;
 #pragma unroll
       for (int c = 0; c < KS; ++c) w[c] = __builtin_nontemporal_load((const bf16x8*)(wr + c * 512));
@@ -115,17 +121,18 @@ __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_kernel(Args p) {
   };
 
   auto finish = [&](int i) {
-    // ---- cross-wave sum + epilogue of tile i (waves 0..3: row tile = wave); called after the barrier of tile i
-    if (wave >= 4) return;
+    // ---- cross-wave sum + epilogue of tile i (waves 0..MT-1: row tile = mt0 + wave); called after the barrier of tile i
+    if (wave >= MT || i >= ntl) return;
     const int buf = i & 1, t = tile_of(i);
     f32x4 s = *(const f32x4*)red[buf][0][wave][lane];
 #pragma unroll
     for (int w2 = 1; w2 < NW; ++w2) s += *(const f32x4*)red[buf][w2][wave][lane];
-    const int m = wave * 16 + l15;
+    const int rt = mt0 + wave;                           // row tile (0..3) of this wave's results
+    const int m = rt * 16 + l15;
     // s[r] = C[m][tile column 4 * lq + r]
     if (EPI == E_SLAB) {
       float* slab = (float*)p.C + ((size_t)blockIdx.y * p.tiles + t) * 1024;     // [16 columns][64 rows]: fragment order
-      *(f32x4*)(slab + (wave * 64 + lane) * 4) = s;
+      *(f32x4*)(slab + (rt * 64 + lane) * 4) = s;
       return;
     }
     if (EPI == E_SWIGLU) {
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_kernel(Args p) {
         for (int r = 0; r < 4; ++r) o[r] = (bf16)(bf16_round(silu_f(bf16_round(s[r]))) * bf16_round(u[r]));
         if (p.out_frag) {
           // element (m, n .. n+3) of the consumer's A operand: k-step n / 32, lane group (n % 32) / 8, row tile = wave
-          *(bf16x4*)((bf16*)p.C + ((((size_t)(n >> 5) * 4 + wave) * 64 + ((n & 31) >> 3) * 16 + l15) << 3) + (n & 7)) = o;
+          *(bf16x4*)((bf16*)p.C + ((((size_t)(n >> 5) * 4 + rt) * 64 + ((n & 31) >> 3) * 16 + l15) << 3) + (n & 7)) = o;
         } else {
           bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n;
           if (n + 4 <= p.N) {
@@ -227,16 +234,16 @@ __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_kernel(Args p) {
   };
 
   auto compute = [&](const bf16x8 (&w)[KS], int i) {
-    f32x4 acc[4];
+    f32x4 acc[MT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KS; ++c)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = mfma16(w[c], a[t][c], acc[t]);
+      for (int t = 0; t < MT; ++t) acc[t] = mfma16(w[c], a[t][c], acc[t]);
     const int buf = i & 1;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) *(f32x4*)red[buf][wave][t][lane] = acc[t];
+    for (int t = 0; t < MT; ++t) *(f32x4*)red[buf][wave][t][lane] = acc[t];
     // my partial tile is in LDS; everybody's is after the barrier.  Raw s_barrier: the weight loads of the next tiles stay
     // in flight across it (a __syncthreads() would drain vmcnt).  Buffer (i & 1) is written again at tile i + 2, which every
     // wave reaches only after the barrier of tile i + 1, i.e. after all reads of tile i.
@@ -248,18 +255,24 @@ __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_kernel(Args p) {
 
   bf16x8 w0[KS], w1[KS], w2[KS];
   load_w(w0, 0);
+  if (ntl <= 2) {
+    // one or two tiles (the q|k|v, o and down projections): no ring, nothing loaded twice
+    if (ntl == 2) load_w(w1, 1);
+    compute(w0, 0);
+    if (ntl == 2) compute(w1, 1);
+    return;
+  }
+  // three tiles in flight per wave.  The body is branch-free (the trip count is rounded up to a multiple of three: the spare
+  // bodies re-read the last tile and skip their epilogue), so that the compiler's vmcnt bookkeeping sees one straight ring
+  // and waits for the oldest tile only.
   load_w(w1, 1);
   for (int i = 0; i < ntl; i += 3) {
     load_w(w2, i + 2);
     compute(w0, i);
-    if (i + 1 < ntl) {
-      load_w(w0, i + 3);
-      compute(w1, i + 1);
-    }
-    if (i + 2 < ntl) {
-      load_w(w1, i + 4);
-      compute(w2, i + 2);
-    }
+    load_w(w0, i + 3);
+    compute(w1, i + 1);
+    load_w(w1, i + 4);
+    compute(w2, i + 2);
   }
 }
 
@@ -275,20 +288,35 @@ int cu_count() {
   return n;
 }
 
-template <int EPI>
-int launch(const Args& a, int ksplit, hipStream_t st) {
-  const int krange = a.K / ksplit;
-  const int ks = krange / (NW * 32);
-  // one workgroup per CU when the tiles allow it (two fit: 64 KiB of LDS, <= 128 VGPRs at KS <= 2 only)
-  const int per_split = cu_count() / ksplit > 0 ? cu_count() / ksplit : 1;
-  const dim3 grid(a.tiles < per_split ? a.tiles : per_split, ksplit);
+template <int EPI, int MT, bool FRAG>
+int launch_ks(const Args& a, int ksplit, dim3 grid, hipStream_t st) {
+  const int ks = a.K / ksplit / (NW * 32);
   switch (ks) {
-    case 1: TASU_LAUNCH((stream_gemm_kernel<1, EPI>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
-    case 2: TASU_LAUNCH((stream_gemm_kernel<2, EPI>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
-    case 6: TASU_LAUNCH((stream_gemm_kernel<6, EPI>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
-    case 7: TASU_LAUNCH((stream_gemm_kernel<7, EPI>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
+    case 1: TASU_LAUNCH((stream_gemm_kernel<1, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
+    case 2: TASU_LAUNCH((stream_gemm_kernel<2, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
+    case 6: TASU_LAUNCH((stream_gemm_kernel<6, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
+    case 7: TASU_LAUNCH((stream_gemm_kernel<7, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
     default: return TASU_ERR_ARG;
   }
+}
+template <int EPI, int MT>
+int launch_mt(const Args& a, int ksplit, dim3 grid, hipStream_t st) {
+  if (a.a_frag != a.w_frag) return TASU_ERR_ARG;         // the operands travel in fragment order together or not at all
+  return a.a_frag ? launch_ks<EPI, MT, true>(a, ksplit, grid, st) : launch_ks<EPI, MT, false>(a, ksplit, grid, st);
+}
+
+template <int EPI>
+int launch(const Args& a, int ksplit, hipStream_t st) {
+  // Rows per workgroup: all 64 when the column tiles alone give every CU work; otherwise the row tiles are split over
+  // blockIdx.z (2 x 32 rows) so that twice as many workgroups each load half of the activations.
+  const int cus = cu_count();
+  const int row_tiles = (a.M + 15) / 16;
+  // (K-range slabs: always -- 7 k-steps x 4 row tiles of activations per wave would not leave registers for the weight ring)
+  const bool split_rows = row_tiles > 2 && (EPI == E_SLAB || a.tiles * ksplit * 2 <= cus + cus / 4);
+  const int zs = split_rows ? 2 : 1;
+  const int per_split = cus / (ksplit * zs) > 0 ? cus / (ksplit * zs) : 1;
+  const dim3 grid(a.tiles < per_split ? a.tiles : per_split, ksplit, zs);
+  return split_rows ? launch_mt<EPI, 2>(a, ksplit, grid, st) : launch_mt<EPI, 4>(a, ksplit, grid, st);
 }
 
 bool k_supported(int K, int ksplit) {
@@ -427,32 +455,6 @@ __global__ __launch_bounds__(256) void stream_finish_norm_kernel(const float* __
   }
 }
 
-// y_f = rmsnorm(x) in fragment order (tasu_rmsnorm_fwd's arithmetic: one wave per row, same summation order).  D % 32 == 0.
-__global__ __launch_bounds__(256) void rmsnorm_fwd_frag_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                               bf16* __restrict__ y, int M, int D, float eps) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const float* xr = x + (size_t)row * D;
-  float ss = 0.f;
-  for (int c = lane * 4; c < D; c += 256) {
-    const f32x4 v = *(const f32x4*)(xr + c);
-    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-  }
-  ss = wave_sum(ss);
-  const float r = rsqrtf(ss / (float)D + eps);
-  const int row_tile = row >> 4, l15 = row & 15;
-  for (int c = lane * 4; c < D; c += 256) {
-    const f32x4 v = *(const f32x4*)(xr + c);
-    const f32x4 g = *(const f32x4*)(w + c);
-    f32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[j] * r);
-    *(bf16x4*)(y + ((((size_t)(c >> 5) * 4 + row_tile) * 64 + ((c & 31) >> 3) * 16 + l15) << 3) + (c & 7)) =
-        __builtin_convertvector(o, bf16x4);
-  }
-}
-
 // Re-lays a row-major weight matrix out in fragment order, one 16-row column tile at a time in the row order of the tile's
 // epilogue (kind: E_BF16 plain, E_SWIGLU 8 gate + 8 up rows, E_QKV paired RoPE columns).  Load-time work.
 template <int EPI>
@@ -474,12 +476,6 @@ extern "C" int tasu_stream_finish_norm(const float* slabs, int ksplit, float* C,
     return TASU_ERR_ARG;
   TASU_LAUNCH(tasu_stream::stream_finish_norm_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, slabs, ksplit, N / 16, C, resid, N,
               norm_w, (bf16*)y, eps, y_frag);
-  return TASU_OK;
-}
-
-extern "C" int tasu_rmsnorm_fwd_frag(const float* x, const float* w, void* y_frag, int M, int D, float eps, void* stream) {
-  if (!x || !w || !y_frag || M <= 0 || M > 64 || D <= 0 || D % 32) return TASU_ERR_ARG;
-  TASU_LAUNCH(tasu_stream::rmsnorm_fwd_frag_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)y_frag, M, D, eps);
   return TASU_OK;
 }
 

@@ -9,9 +9,14 @@ namespace {
 // one wave per row, 4 rows per 256-thread block.  D % 4 == 0.
 // ``src`` (optional): output row i is the norm of input row src[i]; src[i] < 0 gives a zero row and rstd 0 (the lm_head of
 // the training step only projects the rows that carry a label).
+// ``frag``: y is written in the MFMA fragment order of the decode step's streaming GEMMs (csrc/gemm_stream.hip: element
+// (row, c) at [c / 32][row / 16][16 * ((c % 32) / 8) + row % 16][c % 8], rows < 64) instead of row-major -- same arithmetic.
+__device__ __forceinline__ size_t frag_offset(int row, int c) {
+  return ((((size_t)(c >> 5) * 4 + (row >> 4)) * 64 + ((c & 31) >> 3) * 16 + (row & 15)) << 3) + (c & 7);
+}
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ src,
                                                           const float* __restrict__ w, bf16* __restrict__ y,
-                                                          float* __restrict__ rstd, int M, int D, float eps) {
+                                                          float* __restrict__ rstd, int M, int D, float eps, int frag) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
@@ -37,7 +42,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[j] * r);
-    *(bf16x4*)(yr + c) = __builtin_convertvector(o, bf16x4);
+    *(bf16x4*)(frag ? y + frag_offset(row, c) : yr + c) = __builtin_convertvector(o, bf16x4);
   }
 }
 
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 template <int NG>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __restrict__ x, const int32_t* __restrict__ src,
                                                               const float* __restrict__ w, bf16* __restrict__ y,
-                                                              float* __restrict__ rstd, int M, float eps) {
+                                                              float* __restrict__ rstd, int M, float eps, int frag) {
   constexpr int D = NG * 256;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __res
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = gw[j] * (v[g][j] * r);
-    *(bf16x4*)(yr + g * 256) = __builtin_convertvector(o, bf16x4);
+    *(bf16x4*)(frag ? y + frag_offset(row, lane * 4 + g * 256) : yr + g * 256) = __builtin_convertvector(o, bf16x4);
   }
 }
 
@@ -333,15 +338,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
 }  // namespace
 
 static int rmsnorm_fwd_any(const float* x, const int32_t* src, const float* w, void* y, float* rstd, int M, int D, float eps,
-                           void* stream) {
+                           void* stream, int frag = 0) {
   if (!x || !w || !y || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
   const dim3 grid((M + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
-  if (D == 1536) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<6>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps);
-  else if (D == 3584) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<14>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps);
-  else if (D == 256) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<1>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps);
-  else TASU_LAUNCH(rmsnorm_fwd_kernel, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, D, eps);
+  if (D == 1536) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<6>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag);
+  else if (D == 3584) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<14>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag);
+  else if (D == 256) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<1>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag);
+  else TASU_LAUNCH(rmsnorm_fwd_kernel, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, D, eps, frag);
   return TASU_OK;
+}
+extern "C" int tasu_rmsnorm_fwd_frag(const float* x, const float* w, void* y_frag, int M, int D, float eps, void* stream) {
+  if (M > 64 || D % 32) return TASU_ERR_ARG;
+  return rmsnorm_fwd_any(x, nullptr, w, y_frag, nullptr, M, D, eps, stream, 1);
 }
 static int rmsnorm_bwd_any(const void* dy, const float* x, const float* w, const float* rstd, const int32_t* slot, float* dx,
                            void* dx_bf16, int accumulate, int M, int D, void* stream) {

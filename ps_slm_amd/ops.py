@@ -105,7 +105,9 @@ class HipOps:
         self._frag[w.data_ptr()] = (out, w)          # keeps the row-major tensor alive: its address is the key
 
     def _wf(self, w):
-        f = self._frag.get(w.data_ptr())
+        """(weight pointer, layout flag): the fragment-order copy while a decode runs in fragment order (the activations and
+        the weights of a streaming GEMM change layout together), else the row-major tensor."""
+        f = self._frag.get(w.data_ptr()) if self.dec_frag else None
         return (f[0], 1) if f is not None else (w, 0)
 
     def dec_rmsnorm(self, x, w, y, eps):

@@ -693,13 +693,14 @@ def test_decode_layer_chain_in_fragment_order(hip, fake, M, D, I, H, G, V):
         kc, vc = t(kc0.clone()), t(vc0.clone())
         ws = torch.zeros(32 * 64 * ((max(V, 2 * I) + 95) // 96 * 96), device=dev_) if dev_ != "cpu" else None
         logits = torch.zeros(M, (V + 63) // 64 * 64, dtype=BF, device=dev_)
-        ops.dec_rmsnorm(x, t(ln1), xn, 1e-6)
-        ops.gemm_skinny_qkv_rope(xn, w["wqkv"], t(bq), qkv, M, H, G, D, t(cos), t(sin), kc, vc, t(pos), ctx, ws)
+        # like ps_slm_amd/decode.py: row slices of buffers that hold a whole 64-row chunk (the base address is what counts)
+        ops.dec_rmsnorm(x, t(ln1), xn[:M], 1e-6)
+        ops.gemm_skinny_qkv_rope(xn[:M], w["wqkv"], t(bq), qkv, M, H, G, D, t(cos), t(sin), kc, vc, t(pos), ctx, ws)
         ops.attn_decode(qkv, kc, vc, None, t(kstart), t(lens), ao, M, H, G, ctx, HD ** -0.5)
-        ops.gemm_skinny_norm(ao, w["wo"], x2, x, M, D, HHD, t(ln2), xn, 1e-6, ws)
-        ops.gemm_skinny_swiglu(xn, w["wgu"], act, M, I, D, ws)
-        ops.gemm_skinny_norm(act, w["wd"], x, x2, M, D, I, t(ln3), xn, 1e-6, ws)
-        ops.gemm_skinny(xn, w["head"], logits, M, V, D, ws)
+        ops.gemm_skinny_norm(ao[:M], w["wo"], x2, x, M, D, HHD, t(ln2), xn[:M], 1e-6, ws)
+        ops.gemm_skinny_swiglu(xn[:M], w["wgu"], act[:M], M, I, D, ws)
+        ops.gemm_skinny_norm(act[:M], w["wd"], x, x2, M, D, I, t(ln3), xn[:M], 1e-6, ws)
+        ops.gemm_skinny(xn[:M], w["head"], logits, M, V, D, ws)
         if dev_ != "cpu":
             torch.cuda.synchronize()
         if frag:

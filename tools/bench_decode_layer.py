@@ -1,6 +1,6 @@
 """Micro-benchmark of the decode step's per-layer ops at Qwen2.5-1.5B geometry (M = 64 beam rows) over 28 distinct weight sets
 (cold, like the layer loop), hipGraph-replayed: the split-K + finish kernels (csrc/gemm_skinny.hip) against the single-launch
-streaming kernels (csrc/gemm_stream.hip).  Usage: python tools/bench_decode_layer.py [stream|skinny|both]"""
+streaming kernels (csrc/gemm_stream.hip).  Usage: python tools/bench_decode_layer.py [frag|stream|skinny|both]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -51,8 +51,19 @@ def timed(name, fn, n, nbytes):
     return us
 
 
-for mode in (["stream", "skinny"] if which == "both" else [which]):
-    ops.use_stream = mode == "stream"
+for mode in (["frag", "stream", "skinny"] if which == "both" else [which]):
+    ops.use_stream = mode != "skinny"
+    if mode == "frag":                 # weights re-laid out in MFMA order + activations travelling in it
+        for i in range(L):
+            ops.register_decode_weight(wqkv[i], "qkv", LD, H, G)
+            ops.register_decode_weight(wo[i], "plain", D)
+            ops.register_decode_weight(wgu[i], "swiglu", I)
+            ops.register_decode_weight(wd[i], "plain", D)
+        ops.register_decode_weight(head, "plain", V)
+        assert ops.begin_decode(D, D, I)
+    else:
+        ops.end_decode()
+        ops._frag = {}
     print(mode)
     tot = 0.0
     tot += timed("qkv + bias + rope + append", lambda: [ops.gemm_skinny_qkv_rope(xn, wqkv[i], bq, qkv, M, H, G, D, cos, sin, kc, vc, pos, ctx, ws) for i in range(L)], L, LD * D * 2)
