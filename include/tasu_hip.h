@@ -72,7 +72,7 @@ int tasu_gemm_skinny_bf16(const void* A, int lda, const void* B, int ldb, void* 
 /* Projection + residual add + the NEXT RMSNorm in one call (o / down projection of a Qwen2DecoderLayer at M <= 64):
  * C[M,N] fp32 (row stride N) = resid + bf16(A[M,K] . B[N,K]^T);  y[M,N] bf16 = norm_w * (C * rsqrt(mean(C^2) + eps)).   */
 int tasu_gemm_skinny_norm(const void* A, int lda, const void* B, int ldb, float* C, const float* resid, int M, int N, int K,
-                          const float* norm_w, void* y, float eps, float* workspace, int64_t workspace_floats,
+                          const float* norm_w, void* y, float eps, int y_frag, float* workspace, int64_t workspace_floats,
                           void* stream);
 /* q|k|v projection (+ bias) of a decode step with RoPE and the cache append behind it (Qwen2Attention.forward at one token
  * per beam): qkv[M, (H+2G)*128] bf16 rotated in place semantics of tasu_rope_append; k, v -> cache[row, pos[row]].     */

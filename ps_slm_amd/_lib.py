@@ -55,7 +55,7 @@ PROTOTYPES = {
     "tasu_psd_gather": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tasu_kv_fill": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tasu_kv_append": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    "tasu_gemm_skinny_norm": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, f32, vp, i64, vp],
+    "tasu_gemm_skinny_norm": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, f32, i32, vp, i64, vp],
     "tasu_gemm_skinny_qkv_rope": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i64, vp],
     "tasu_gemm_skinny_swiglu": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i64, vp],
     "tasu_rope_append": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(Args p, int tiles) {
 // in the same launch (one launch less per norm: ~5 us of the ~9-us floor these small kernels run at).  N % 4 == 0.
 template <int BN>
 __global__ __launch_bounds__(256) void skinny_reduce_norm_kernel(Args p, int tiles, const float* __restrict__ nw,
-                                                                 bf16* __restrict__ y, float eps) {
+                                                                 bf16* __restrict__ y, float eps, int y_frag) {
   constexpr int NI = BN / 16, TILE_F = 64 * BN;
   __shared__ float red[4];
   const int m = blockIdx.x;
@@ -271,7 +271,10 @@ __global__ __launch_bounds__(256) void skinny_reduce_norm_kernel(Args p, int til
     f32x4 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = w[q] * (v[q] * rs);
-    *(bf16x4*)(y + (size_t)m * p.N + n) = __builtin_convertvector(o, bf16x4);
+    // y_frag: the MFMA fragment order of csrc/gemm_stream.hip's activations ([n / 32][m / 16][16 * ((n % 32) / 8) + m % 16][n % 8])
+    bf16* dst = y_frag ? y + ((((size_t)(n >> 5) * 4 + (m >> 4)) * 64 + ((n & 31) >> 3) * 16 + (m & 15)) << 3) + (n & 7)
+                       : y + (size_t)m * p.N + n;
+    *(bf16x4*)dst = __builtin_convertvector(o, bf16x4);
   }
 }
 
@@ -372,6 +375,7 @@ struct NormArgs {
   const float* w = nullptr;   // RMSNorm weight [N]; null = no fused norm
   bf16* y = nullptr;          // normalized bf16 output [M, N]
   float eps = 0.f;
+  int y_frag = 0;             // y in fragment order (needs N % 32 == 0)
   // qkv finish (RoPE + cache append) instead of a norm: cos != nullptr
   const float* cos = nullptr;
   const float* sin = nullptr;
@@ -392,14 +396,15 @@ int launch(Args a, int tiles, hipStream_t st, NormArgs na = NormArgs()) {
   TASU_LAUNCH((gemm_skinny_kernel<BN, SWIGLU>), dim3(tiles, a.ksplit), dim3(256), LDS, st, a);
   if (a.ksplit > 1) {
     if (na.w)
-      TASU_LAUNCH((skinny_reduce_norm_kernel<BN>), dim3(a.M), dim3(256), 0, st, a, tiles, na.w, na.y, na.eps);
+      TASU_LAUNCH((skinny_reduce_norm_kernel<BN>), dim3(a.M), dim3(256), 0, st, a, tiles, na.w, na.y, na.eps, na.y_frag);
     else if (na.cos)
       TASU_LAUNCH((skinny_reduce_rope_kernel<BN>), dim3(a.M), dim3(256), 0, st, a, tiles, na.cos, na.sin, na.kc, na.vc, na.pos,
                   na.H, na.G, na.ctx);
     else
       TASU_LAUNCH((skinny_reduce_kernel<BN, SWIGLU>), dim3((tiles * 16 * BN + 255) / 256), dim3(256), 0, st, a, tiles);
   } else if (na.w) {
-    return tasu_rmsnorm_fwd((const float*)a.C, na.w, na.y, nullptr, a.M, a.N, na.eps, st);   // unsplit: C is final
+    return na.y_frag ? tasu_rmsnorm_fwd_frag((const float*)a.C, na.w, na.y, a.M, a.N, na.eps, st)
+                     : tasu_rmsnorm_fwd((const float*)a.C, na.w, na.y, nullptr, a.M, a.N, na.eps, st);   // unsplit: C is final
   } else if (na.cos) {
     return tasu_rope_append(a.C, na.cos, na.sin, na.kc, na.vc, na.pos, a.M, na.H, na.G, na.ctx, st);
   }
@@ -494,10 +499,11 @@ extern "C" int tasu_gemm_skinny_swiglu(const void* A, int lda, const void* Wgu, 
 }
 
 extern "C" int tasu_gemm_skinny_norm(const void* A, int lda, const void* B, int ldb, float* C, const float* resid, int M, int N,
-                                     int K, const float* norm_w, void* y, float eps, float* workspace,
+                                     int K, const float* norm_w, void* y, float eps, int y_frag, float* workspace,
                                      int64_t workspace_floats, void* stream) {
   using namespace tasu_skinny;
-  if (!A || !B || !C || !resid || !norm_w || !y || M <= 0 || M > 64 || N <= 0 || N % 4 || K <= 0 || K % 64 || lda % 8 || ldb % 8)
+  if (!A || !B || !C || !resid || !norm_w || !y || M <= 0 || M > 64 || N <= 0 || N % 4 || K <= 0 || K % 64 || lda % 8 || ldb % 8 ||
+      (y_frag && N % 32))
     return TASU_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)workspace & 15)) return TASU_ERR_ARG;
   Args a;
@@ -518,6 +524,7 @@ extern "C" int tasu_gemm_skinny_norm(const void* A, int lda, const void* B, int 
   na.w = norm_w;
   na.y = (bf16*)y;
   na.eps = eps;
+  na.y_frag = y_frag;
   return plan_and_launch<false>(a, workspace, workspace ? (size_t)workspace_floats : 0, (hipStream_t)stream, na);
 }
 

@@ -39,6 +39,8 @@ class HipOps:
         # the split-K + finish kernels (csrc/gemm_skinny.hip) otherwise.  TASU_DECODE_STREAM=0 forces the latter (A/B runs).
         self.use_stream = os.environ.get("TASU_DECODE_STREAM", "1") != "0"
         self.dec_frag = False          # set by begin_decode(): decode activations travel in fragment order
+        self.dec_frag_act = False      # ... including the MLP activation that feeds the down projection
+        self.dec_down_slabs = False
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
 
     # ------------------------------------------------------------------ plumbing
@@ -86,12 +88,18 @@ class HipOps:
         """Called once per generate(): decides whether the decode step's bf16 activations (normed hidden state, attention
         output, MLP activation) travel between its kernels in FRAGMENT ORDER (include/tasu_hip.h) -- possible when the
         streaming kernels serve every GEMM of the layer.  Returns that decision."""
-        self.dec_frag = bool(self._stream_split(D) == 1 and self._stream_split(HHD) == 1 and self._stream_split(I) > 0
-                             and D % 32 == 0 and HHD % 32 == 0 and I % 32 == 0)
+        self.dec_frag = bool(self._stream_split(D) == 1 and self._stream_split(HHD) == 1 and D % 32 == 0 and HHD % 32 == 0)
+        # the MLP activation (the down projection's input): fragment order only when the down projection itself runs on the
+        # streaming kernels in ONE K range.  A K too long for that (8960 = 5 x 1792) stays on the split-K kernels of
+        # gemm_skinny.hip, whose 64 x 64 x K/10 blocks move fewer operand bytes per CU than 5 K-range slabs do
+        # (measured at 1.5B: 18.8 us against 23.0 us per layer); TASU_DECODE_DOWN_SLABS=1 forces the slabs (A/B runs).
+        self.dec_down_slabs = os.environ.get("TASU_DECODE_DOWN_SLABS", "0") == "1"
+        ks_down = self._stream_split(I)
+        self.dec_frag_act = bool(self.dec_frag and I % 32 == 0 and (ks_down == 1 or (ks_down > 1 and self.dec_down_slabs)))
         return self.dec_frag
 
     def end_decode(self):
-        self.dec_frag = False
+        self.dec_frag = self.dec_frag_act = False
 
     def register_decode_weight(self, w, kind, N, H=0, G=0):
         """Load-time: a fragment-order copy of a decode-step weight (kind: 'plain' | 'swiglu' | 'qkv'), looked up by the
@@ -283,20 +291,25 @@ class HipOps:
     def gemm_skinny_norm(self, a, b, c, resid, M, N, K, norm_w, y, eps, ws):
         """c (fp32) = resid + bf16(a @ b^T); y = rmsnorm(c, norm_w) -- decode-step projection with the next norm fused."""
         ks = self._stream_split(K) if N % 16 == 0 else 0
-        frag = int(self.dec_frag)
-        wf, wflag = self._wf(b)
+        # layout of the INPUT: a one-range K reads a buffer written in the layer's activation order (dec_frag); a longer K is
+        # the down projection, whose input layout is dec_frag_act
+        a_frag = int(self.dec_frag if ks == 1 else self.dec_frag_act)
+        y_frag = int(self.dec_frag)
+        if ks > 1 and not (self.dec_down_slabs or a_frag):
+            ks = 0                                          # split-K kernels of gemm_skinny.hip (see begin_decode)
+        wf, wflag = (self._wf(b) if a_frag else (b, 0))
         if ks == 1:
             # one launch for the projection + residual add, one for the norm (the sum of squares needs the whole row)
             self._chk(self.lib.tasu_gemm_stream_bf16(_p(a), a.stride(0), _p(wf), b.stride(0), _p(c), N, None, _p(resid), M, N, K,
-                                                     GEMM_RESID, frag, wflag, self._stream()), "tasu_gemm_stream_bf16")
+                                                     GEMM_RESID, a_frag, wflag, self._stream()), "tasu_gemm_stream_bf16")
             return self.dec_rmsnorm(c[:M], norm_w, y, eps)
         if ks > 1 and ws is not None and ws.numel() >= ks * (N // 16) * 1024:
             self._chk(self.lib.tasu_gemm_stream_slabs(_p(a), a.stride(0), _p(wf), b.stride(0), _p(ws), ws.numel(), M, N, K, ks,
-                                                      frag, wflag, self._stream()), "tasu_gemm_stream_slabs")
-            return self._chk(self.lib.tasu_stream_finish_norm(_p(ws), ks, _p(c), _p(resid), M, N, _p(norm_w), _p(y), eps, frag,
+                                                      a_frag, wflag, self._stream()), "tasu_gemm_stream_slabs")
+            return self._chk(self.lib.tasu_stream_finish_norm(_p(ws), ks, _p(c), _p(resid), M, N, _p(norm_w), _p(y), eps, y_frag,
                                                               self._stream()), "tasu_stream_finish_norm")
         self._chk(self.lib.tasu_gemm_skinny_norm(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), _p(resid), M, N, K, _p(norm_w),
-                                                 _p(y), eps, _p(ws), 0 if ws is None else ws.numel(), self._stream()),
+                                                 _p(y), eps, y_frag, _p(ws), 0 if ws is None else ws.numel(), self._stream()),
                   "tasu_gemm_skinny_norm")
 
     def gemm_skinny_qkv_rope(self, a, wqkv, bias, qkv, M, H, G, K, cos, sin, kc, vc, pos, ctx, ws):
@@ -316,9 +329,9 @@ class HipOps:
         """act[M, I] = swiglu(a[M,K] @ wgu[2I,K]^T) in one launch (decode step)."""
         if self._stream_split(K) == 1 and I % 8 == 0 and act.stride(0) % 4 == 0:
             wf, wflag = self._wf(wgu)
-            frag = int(self.dec_frag)
             return self._chk(self.lib.tasu_gemm_stream_swiglu(_p(a), a.stride(0), _p(wf), wgu.stride(0), _p(act), act.stride(0), M, I,
-                                                              K, frag, wflag, frag, self._stream()), "tasu_gemm_stream_swiglu")
+                                                              K, int(self.dec_frag), wflag, int(self.dec_frag_act), self._stream()),
+                             "tasu_gemm_stream_swiglu")
         self._chk(self.lib.tasu_gemm_skinny_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), M, I, K,
                                                    _p(ws), 0 if ws is None else ws.numel(), self._stream()),
                   "tasu_gemm_skinny_swiglu")
