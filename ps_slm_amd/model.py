@@ -339,9 +339,11 @@ class TasuModel:
         return t[:n].view(*shape)
 
     # ------------------------------------------------------------------------------------------ host prep
-    def prepare_text(self, input_ids, attention_mask, labels, post_ids, alphas=None, keeps=None) -> StepState:
+    def prepare_text(self, input_ids, attention_mask, labels, post_ids, alphas=None, keeps=None, row_alphas=None) -> StepState:
         """Host side of the text-only branch (ps-slm.py:459-468): apply the CPS draws (drop mask, alpha) to the
-        sentencepiece ids, build the merge plan, and upload all integer inputs in one staging copy."""
+        sentencepiece ids, build the merge plan, and upload all integer inputs in one staging copy.  ``row_alphas`` (one list
+        per utterance, same lengths as ``post_ids``): per-ROW smoothing instead of one alpha per utterance -- the form CPS
+        insertions need (an inserted blank row is an exact one-hot, ps-slm.py:396-398); excludes alphas / keeps."""
         geo = self.geo
         B = len(post_ids)
         kept = []
@@ -361,7 +363,9 @@ class TasuModel:
         pal = np.zeros(Rap, dtype=np.float32)
         for u, ids in enumerate(kept):
             pid[u * Lmax: u * Lmax + len(ids)] = ids
-            if alphas is not None:
+            if row_alphas is not None:
+                pal[u * Lmax: u * Lmax + len(ids)] = np.asarray(row_alphas[u], dtype=np.float32)
+            elif alphas is not None:
                 pal[u * Lmax: u * Lmax + len(ids)] = float(alphas[u])
         st = self._finish_prepare(input_ids, attention_mask, labels, lens, Lmax)
         st.dev["post_ids"] = self._upload("post_ids", pid)

@@ -263,15 +263,36 @@ class slam_model_asr:
         self.core.sync_projector_copies()
         return missing, [k for k in sd if not k.startswith("encoder_projector.")]
 
-    # ---- CPS noise draws: same calls in the same order on the global CPU RNG as ps-slm.py:380-388
+    # ---- CPS noise draws: same calls in the same order on the global CPU RNG as ps-slm.py:380-399
     def draw_noise(self, ids_list):
+        """insert_prob == 0 (the shipped recipe): per utterance one uniform alpha, then one rand(len) keep mask."""
         if self.insert_prob != 0.0:
-            raise NotImplementedError("insert_prob != 0 (ps-slm.py:390-399) is not used by the shipped recipe")
+            raise ValueError("insert_prob != 0: use draw_noise_rows (insertions change the row sequence)")
         alphas, keeps = [], []
         for ids in ids_list:
             alphas.append(torch.empty(()).uniform_(self.smooth_low, self.smooth_high).item())
             keeps.append((torch.rand(len(ids)) > self.drop_prob).numpy())
         return alphas, keeps
+
+    def draw_noise_rows(self, ids_list, blank_id=0):
+        """The full CPS noise of ps-slm.py:360-409 as row descriptions: per utterance the final sequence of (id, alpha) after
+        smoothing, drops and -- ``insert_prob`` > 0 -- int(len * insert_prob) insertions, each at randint(0, len + 1), each with
+        probability 1/2 a copy of the row before it (same id, same alpha) and otherwise an exact one-hot blank row (alpha 0).
+        Same calls in the same order on the global CPU RNG as the reference.  Returns (ids per utterance, alphas per row)."""
+        out_ids, out_alpha = [], []
+        for ids in ids_list:
+            alpha = torch.empty(()).uniform_(self.smooth_low, self.smooth_high).item()
+            keep = (torch.rand(len(ids)) > self.drop_prob).numpy()
+            rows = [(int(i), alpha) for i, k in zip(ids, keep) if k]
+            for _ in range(int(len(rows) * self.insert_prob)):
+                pos = torch.randint(0, len(rows) + 1, (1,)).item()
+                if bool(torch.rand(1) < 0.5) and len(rows) > 0:
+                    rows.insert(pos, rows[pos - 1] if pos > 0 else rows[0])
+                else:
+                    rows.insert(pos, (int(blank_id), 0.0))
+            out_ids.append([r[0] for r in rows])
+            out_alpha.append([r[1] for r in rows])
+        return out_ids, out_alpha
 
     # ---- forward (ps-slm.py:411-537)
     def forward(self, input_ids=None, input_features=None, attention_mask=None, input_feature_length=None, GT=None,
@@ -279,10 +300,12 @@ class slam_model_asr:
         core = self.core
         if self.gt_emb:
             ids_list = [self.encoder_tokenizer.encode(t) for t in GT]
-            alphas = keeps = None
-            if self.gt_emb_noise:
+            alphas = keeps = row_alphas = None
+            if self.gt_emb_noise and self.insert_prob != 0.0:
+                ids_list, row_alphas = self.draw_noise_rows(ids_list, core.geo.blank_id)
+            elif self.gt_emb_noise:
                 alphas, keeps = self.draw_noise(ids_list)
-            st = core.prepare_text(input_ids, attention_mask, labels, ids_list, alphas, keeps)
+            st = core.prepare_text(input_ids, attention_mask, labels, ids_list, alphas, keeps, row_alphas=row_alphas)
             core.run_forward_text(st, compute_loss=labels is not None, need_backward=self.training)
         else:
             if input_features is None:

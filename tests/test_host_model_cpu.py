@@ -402,9 +402,10 @@ def test_generate_other_beam_counts_match_bf16_oracle(nb):
 
 
 def test_cps_noise_draws_and_posterior_vs_reference():
-    """12 seeded calls of the REAL reference's ctc_pseudo_posterior_noise (oracle/make_golden_noise.py): from the same torch
-    seed the plugin's draw_noise must make the same draws in the same order, and the posterior built from them (oracle
-    arithmetic and the product's posterior kernel through the CPU double) must equal the reference's."""
+    """20 seeded calls of the REAL reference's ctc_pseudo_posterior_noise (oracle/make_golden_noise.py; the last 8 with
+    insert_prob > 0): from the same torch seed the plugin's draw_noise / draw_noise_rows must make the same draws in the same
+    order, and the posterior built from them (oracle arithmetic and the product's posterior kernel through the CPU double) must
+    equal the reference's."""
     from conftest import load_npz, split_flat
     from ps_slm_amd.config import ModelConfig, TrainConfig
     from ps_slm_amd.ps_slm import model_factory
@@ -413,28 +414,53 @@ def test_cps_noise_draws_and_posterior_vs_reference():
     mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
     model, _ = model_factory(tc, mc, device="cpu", ops=FakeOps(), init_seed=3)
     core, V = model.core, int(load_npz("geometry")["ctc_vocab"])
+    n_insert_cases = 0
     for n in range(int(z["n_cases"])):
         ids = [list(map(int, p)) for p in split_flat(z[f"c{n}_ids_flat"], z[f"c{n}_ids_lens"])]
         model.drop_prob, model.smooth_low, model.smooth_high = (float(v) for v in z[f"c{n}_params"])
+        model.insert_prob = float(z[f"c{n}_insert_prob"])
         torch.manual_seed(int(z[f"c{n}_seed"]))
-        alphas, keeps = model.draw_noise(ids)
-        post, lens = O.pseudo_posterior(ids, V, alphas, keeps)
+        ref = torch.from_numpy(z[f"c{n}_posterior"])
+        if model.insert_prob == 0.0:
+            alphas, keeps = model.draw_noise(ids)
+            post, lens = O.pseudo_posterior(ids, V, alphas, keeps)
+            row_ids = [[i for i, k in zip(u, kk) if k] for u, kk in zip(ids, keeps)]
+            row_alphas = [[a] * len(r) for a, r in zip(alphas, row_ids)]
+        else:
+            n_insert_cases += 1
+            row_ids, row_alphas = model.draw_noise_rows(ids, blank_id=0)
+            lens = torch.tensor([len(r) for r in row_ids])
+            post = torch.zeros(len(ids), int(lens.max()), V)
+            for b, (r, al) in enumerate(zip(row_ids, row_alphas)):
+                for i, (tok_id, a) in enumerate(zip(r, al)):
+                    post[b, i] = a / V
+                    post[b, i, tok_id] += 1 - a
         assert np.array_equal(lens.numpy(), z[f"c{n}_lens"]), n
-        torch.testing.assert_close(post, torch.from_numpy(z[f"c{n}_posterior"]), rtol=1e-6, atol=1e-8)
+        torch.testing.assert_close(post, ref, rtol=1e-6, atol=1e-8)
         # the product's posterior rows (kernel semantics through the CPU double) at the mid geometry's vocabulary: same ids
         # (all < 203), same draws -> the same rows up to the 1 / V smoothing floor, checked through the argmax and the peak
         B, Lmax = len(ids), int(lens.max())
         tok = torch.full((B, 3), 5, dtype=torch.long)
         tok[:, 1] = core.geo.speech_id
-        st = core.prepare_text(tok, torch.ones(B, 3, dtype=torch.bool), None, ids, alphas, keeps)
+        st = core.prepare_text(tok, torch.ones(B, 3, dtype=torch.bool), None, row_ids, None, None, row_alphas=row_alphas)
         core.forward_projector_text(st)
         rows = st.dev["post"][: B * Lmax].view(B, Lmax, -1)[:, :, : core.geo.ctc_vocab].float()
-        ref = torch.from_numpy(z[f"c{n}_posterior"])
         live = torch.arange(Lmax)[None, :] < lens[:, None]
         assert torch.equal(rows.argmax(-1)[live], ref.argmax(-1)[live]), n
-        a = torch.tensor(alphas)[:, None].expand(-1, Lmax)[live]
+        a = torch.zeros(B, Lmax)
+        for b, al in enumerate(row_alphas):
+            a[b, : len(al)] = torch.tensor(al)
+        a = a[live]
         torch.testing.assert_close(rows.max(-1).values[live], (1 - a) + a / core.geo.ctc_vocab, rtol=1e-6, atol=1e-7)
         assert float(rows[~live].abs().max()) == 0.0 if (~live).any() else True
+    assert n_insert_cases == 8
+    # the forward of the plugin takes the insertion path when insert_prob is set
+    model.insert_prob, model.drop_prob = 0.5, 0.1
+    raw = synthetic_text_batch(core.geo, 2, seed=3, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8, noise=False)
+    torch.manual_seed(5)
+    out, _ = model(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
+                   GT=[" ".join(map(str, p)) for p in raw["post_ids"]])
+    assert torch.isfinite(out.loss) and model.last_state.Ra > 2 * 21 * 0.9
 
 
 def test_generate_margin_cases_exact_on_the_double():
