@@ -1,0 +1,31 @@
+"""Per-shape memory-side bytes of the training step's GEMMs from two rocprofv3 --pmc passes of tools/gemm_shapes_run.py
+(FETCH_SIZE, WRITE_SIZE; gfx950 corrections of MI355X_MICROARCH.md: FETCH_SIZE x2 for 16-B/lane streaming reads, WRITE_SIZE exact;
+both in KB) -> JSON with measured / algorithmic bytes per shape."""
+import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gemm_shapes_run import REPS, SHAPES
+
+
+def per_dispatch(dirname, counter):
+    f = glob.glob(dirname + "/*/*counter_collection.csv")[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "gemm_pipe_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return [float(r["Counter_Value"]) for r in rows]
+
+
+fetch, write = per_dispatch(sys.argv[1], "FETCH_SIZE"), per_dispatch(sys.argv[2], "WRITE_SIZE")
+assert len(fetch) == len(write) == REPS * len(SHAPES), (len(fetch), len(write))
+out = {"command": "rocprofv3 --pmc FETCH_SIZE (resp. WRITE_SIZE) --kernel-trace --output-format csv -- python3 tools/gemm_shapes_run.py "
+                  "(two separate passes; cold, rotating operand sets; the last of 3 launches per shape is reported)",
+       "correction": "gfx950: FETCH_SIZE x2 (16-B/lane streaming reads are tallied at half), WRITE_SIZE exact; fabric-side L2 misses, "
+                     "Infinity-Cache hits included", "shapes": {}}
+for i, (name, m, n, k, mode, sw) in enumerate(SHAPES):
+    j = i * REPS + REPS - 1
+    rows = 2 * n if sw else n
+    out_bytes = m * rows * (2 if mode == 0 else 4) + (m * n * 2 if sw else 0) + (m * n * 4 if mode == 2 else 0)
+    algo = (m * k + rows * k) * 2 + out_bytes + (m * n * 4 if mode == 2 else 0)
+    meas_f, meas_w = 2 * fetch[j] * 1024, write[j] * 1024
+    out["shapes"][name] = {"M": m, "N": rows, "K": k, "fetch_bytes": int(meas_f), "write_bytes": int(meas_w),
+                           "algorithmic_bytes": int(algo), "ratio": round((meas_f + meas_w) / algo, 2)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
