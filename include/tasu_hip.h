@@ -197,6 +197,8 @@ int tasu_swiglu_bwd(const void* dact, const void* gu, void* dgu, int M, int I, v
 int tasu_silu_fwd(const void* x, void* y, int64_t n, void* stream);
 int tasu_silu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
 int tasu_relu_fwd(const void* x, void* y, int64_t n, void* stream);
+/* ReLU backward (EncoderProjectorConcat, projector.py:35): dx = dy where x > 0 else 0.                     */
+int tasu_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------- cross entropy + token accuracy
  * transformers loss_utils.py:49-71 (shift, ignore_index -100, mean) + ps-slm.py:533-535 / utils/metric.py

@@ -131,8 +131,9 @@ class FakeLLMTokenizer:
         self.bos_token_id = None
 
 
-def build_reference_model(geo, seed, train_flags):
-    """Seeded random-init reference ``slam_model_asr`` at geometry ``geo`` (dict)."""
+def build_reference_model(geo, seed, train_flags, projector="linear-silu", ds_rate=1):
+    """Seeded random-init reference ``slam_model_asr`` at geometry ``geo`` (dict); ``projector``: "linear-silu"
+    (EncoderProjectorLinearSiLU) or "linear" (EncoderProjectorConcat with encoder_projector_ds_rate = ds_rate)."""
     import transformers
 
     ps, sv, proj = load_reference()
@@ -157,9 +158,12 @@ def build_reference_model(geo, seed, train_flags):
     for p in llm.parameters():
         p.requires_grad = False
     llm.eval()
-    model_config = Cfg(encoder_projector="linear-silu", encoder_path="/nonexistent",
+    model_config = Cfg(encoder_projector=projector, encoder_path="/nonexistent", encoder_projector_ds_rate=ds_rate,
                        encoder_dim=geo["ctc_vocab"], llm_dim=geo["llm_dim"])
-    projector = proj.EncoderProjectorLinearSiLU(model_config, bottleneck=geo["bottleneck"])
+    if projector == "linear":
+        projector = proj.EncoderProjectorConcat(model_config)      # bottleneck fixed at 2048 by the reference class
+    else:
+        projector = proj.EncoderProjectorLinearSiLU(model_config, bottleneck=geo["bottleneck"])
     train_config = Cfg(ctc_posterior=True, do_psd=True, voca_trans=False, gt_emb=True, gt_emb_noise=False,
                        top1_emb=False)
     train_config.update(train_flags)

@@ -206,7 +206,14 @@ def pseudo_posterior(ids_list, V, alphas=None, keeps=None):
 
 # ----------------------------------------------------------------------------- projector
 def projector(W, x, mode="fp32", pre="encoder_projector."):
-    """EncoderProjectorLinearSiLU.forward, Multitask/model/projector.py:139-151."""
+    """EncoderProjectorLinearSiLU.forward, Multitask/model/projector.py:139-151; with ``linear1.*`` keys instead:
+    EncoderProjectorConcat.forward, :38-49 (k = in_features / feature width frames concatenated, ReLU, no norm)."""
+    if pre + "linear1.weight" in W:
+        k = W[pre + "linear1.weight"].shape[1] // x.shape[-1]
+        B, T, Dm = x.shape
+        x = x[:, : (T // k) * k].reshape(B, T // k, Dm * k)
+        h = rbf(F.relu(linear(x, W[pre + "linear1.weight"], W[pre + "linear1.bias"], mode)), mode)
+        return linear(h, W[pre + "linear2.weight"], W[pre + "linear2.bias"], mode)
     h = layer_norm(x, W[pre + "norm.weight"], W[pre + "norm.bias"], 1e-5)
     h = linear(h, W[pre + "ffn.0.weight"], W[pre + "ffn.0.bias"], mode)
     h = rbf(F.silu(h), mode)
@@ -372,6 +379,8 @@ def forward_audio(W, batch, geo, mode="fp32"):
 
 def forward_from_posterior(W, batch, post, plen, geo, mode="fp32"):
     proj = projector(W, post, mode)
+    if "encoder_projector.linear1.weight" in W:            # k frames per projector row: len // k rows (ps-slm.py:482)
+        plen = plen // (W["encoder_projector.linear1.weight"].shape[1] // post.shape[-1])
     tok = W["llm.model.embed_tokens.weight"][batch["input_ids"]]
     emb, mask, lab, pos = merge(proj, plen, tok, batch["input_ids"], batch["attention_mask"],
                                 batch.get("labels"), geo["speech_id"])
@@ -389,12 +398,13 @@ PROJ_KEYS = tuple("encoder_projector." + k for k in
 
 
 def loss_and_projector_grads(W, batch, geo, mode="fp32", audio=False):
+    keys = tuple(k for k in W if k.startswith("encoder_projector."))      # either projector kind
     Wg = dict(W)
-    for k in PROJ_KEYS:
+    for k in keys:
         Wg[k] = W[k].detach().clone().requires_grad_(True)
     out = (forward_audio if audio else forward_text)(Wg, batch, geo, mode)
-    grads = torch.autograd.grad(out["loss"], [Wg[k] for k in PROJ_KEYS])
-    return out, dict(zip(PROJ_KEYS, grads))
+    grads = torch.autograd.grad(out["loss"], [Wg[k] for k in keys])
+    return out, dict(zip(keys, grads))
 
 
 # ----------------------------------------------------------------------------- optimizer / schedule

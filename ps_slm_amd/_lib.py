@@ -37,6 +37,7 @@ PROTOTYPES = {
     "tasu_swiglu_bwd": [vp, vp, vp, i32, i32, vp],
     "tasu_silu_fwd": [vp, vp, i64, vp],
     "tasu_silu_bwd": [vp, vp, vp, i64, vp],
+    "tasu_relu_bwd": [vp, vp, vp, i64, vp],
     "tasu_relu_fwd": [vp, vp, i64, vp],
     "tasu_ce_fwd_bwd": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp],
     "tasu_ce_reduce": [vp, vp, vp, i32, vp, vp],

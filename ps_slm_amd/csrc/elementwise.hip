@@ -98,6 +98,23 @@ __global__ void silu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restr
   }
 }
 
+// dx = dy where x > 0 else 0 (ReLU of EncoderProjectorConcat, projector.py:35)
+__global__ void relu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, bf16* __restrict__ dx, int64_t n) {
+  const int64_t nv = n / 8;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
+    const bf16x8 a = *(const bf16x8*)(x + v * 8);
+    const bf16x8 d = *(const bf16x8*)(dy + v * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)a[j] > 0.f ? d[j] : (bf16)0.f;
+    *(bf16x8*)(dx + v * 8) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const int64_t i = nv * 8 + threadIdx.x;
+    dx[i] = (float)x[i] > 0.f ? dy[i] : (bf16)0.f;
+  }
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, int64_t n) {
   const int64_t nv = n / 4;
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
@@ -200,6 +217,11 @@ extern "C" int tasu_silu_bwd(const void* dy, const void* x, void* dx, int64_t n,
   if (!dy || !x || !dx || n <= 0) return TASU_ERR_ARG;
   TASU_LAUNCH(silu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy,
                      (const bf16*)x, (bf16*)dx, n);
+  return TASU_OK;
+}
+extern "C" int tasu_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream) {
+  if (!dy || !x || !dx || n <= 0) return TASU_ERR_ARG;
+  TASU_LAUNCH(relu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)x, (bf16*)dx, n);
   return TASU_OK;
 }
 extern "C" int tasu_cast_f32_bf16(const void* in, void* out, int64_t n, void* stream) {

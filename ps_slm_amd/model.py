@@ -54,6 +54,9 @@ class Geometry:
     ctc_vocab: int = 25055
     bottleneck: int = 2048
     ln_eps: float = 1e-5
+    projector: str = "linear-silu"   # "linear-silu" (EncoderProjectorLinearSiLU, projector.py:129-151: the shipped recipe) or
+                                     # "linear" (EncoderProjectorConcat, projector.py:28-49: k frames concatenated, ReLU, no norm)
+    projector_ds_rate: int = 1       # k of the "linear" projector (model_config.encoder_projector_ds_rate)
     # SenseVoiceSmall encoder
     feat_dim: int = 560
     enc_dim: int = 512
@@ -83,20 +86,36 @@ class Geometry:
 
 
 PROJ_NAMES = ("norm.weight", "norm.bias", "ffn.0.weight", "ffn.0.bias", "ffn.2.weight", "ffn.2.bias")
+PROJ_NAMES_LINEAR = ("linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias")
 
 
 class ProjectorParams:
-    """The only trainable tensors (54,512,062 parameters at full geometry) in one flat, padded buffer."""
+    """The only trainable tensors (54,512,062 parameters at full geometry) in one flat, padded buffer.  Two projector kinds
+    share the layout [optional LayerNorm | W1 | b1 | W2 | b2]: the first Linear reads k frames of the CTC vocabulary, each
+    frame's K columns padded to Kp = a multiple of 64 (the pad columns of W1 stay zero: their inputs are zero)."""
 
     def __init__(self, geo: Geometry, device):
         K, Kp, Hb, Do = geo.ctc_vocab, rup(geo.ctc_vocab, 64), geo.bottleneck, geo.llm_dim
+        self.kind = geo.projector
+        if self.kind not in ("linear-silu", "linear"):
+            raise NotImplementedError(f"encoder_projector {self.kind!r}")
+        self.k = int(geo.projector_ds_rate) if self.kind == "linear" else 1
+        self.has_norm = self.kind == "linear-silu"
+        k = self.k
         self.K, self.Kp, self.Hb, self.Do = K, Kp, Hb, Do
-        shapes = {"norm.weight": (Kp,), "norm.bias": (Kp,), "ffn.0.weight": (Hb, Kp), "ffn.0.bias": (Hb,),
-                  "ffn.2.weight": (Do, Hb), "ffn.2.bias": (Do,)}
-        self.real = {"norm.weight": (K,), "norm.bias": (K,), "ffn.0.weight": (Hb, K), "ffn.0.bias": (Hb,),
-                     "ffn.2.weight": (Do, Hb), "ffn.2.bias": (Do,)}
+        if self.has_norm:
+            self.names = PROJ_NAMES
+            self.n_w1, self.n_b1, self.n_w2, self.n_b2 = "ffn.0.weight", "ffn.0.bias", "ffn.2.weight", "ffn.2.bias"
+            shapes = {"norm.weight": (Kp,), "norm.bias": (Kp,)}
+            self.real = {"norm.weight": (K,), "norm.bias": (K,)}
+        else:
+            self.names = PROJ_NAMES_LINEAR
+            self.n_w1, self.n_b1, self.n_w2, self.n_b2 = PROJ_NAMES_LINEAR
+            shapes, self.real = {}, {}
+        shapes.update({self.n_w1: (Hb, k * Kp), self.n_b1: (Hb,), self.n_w2: (Do, Hb), self.n_b2: (Do,)})
+        self.real.update({self.n_w1: (Hb, k * K), self.n_b1: (Hb,), self.n_w2: (Do, Hb), self.n_b2: (Do,)})
         self.offsets, off = {}, 0
-        for n in PROJ_NAMES:
+        for n in self.names:
             self.offsets[n] = (off, shapes[n])
             off += rup(int(np.prod(shapes[n])), 64)
         self.numel = off
@@ -106,8 +125,8 @@ class ProjectorParams:
         self.m = torch.zeros(off, **f32)
         self.v = torch.zeros(off, **f32)
         self.pb = torch.zeros(off, dtype=torch.bfloat16, device=device)
-        self.w1b_t = torch.zeros(Kp, Hb, dtype=torch.bfloat16, device=device)   # ffn.0.weight^T for dgrad
-        self.w2b_t = torch.zeros(Hb, Do, dtype=torch.bfloat16, device=device)   # ffn.2.weight^T for dgrad
+        self.w1b_t = torch.zeros(k * Kp, Hb, dtype=torch.bfloat16, device=device)   # W1^T for dgrad
+        self.w2b_t = torch.zeros(Hb, Do, dtype=torch.bfloat16, device=device)       # W2^T for dgrad
 
     def view(self, flat, name):
         off, shp = self.offsets[name]
@@ -116,29 +135,42 @@ class ProjectorParams:
     def num_parameters(self):
         return sum(int(np.prod(s)) for s in self.real.values())
 
+    def _blocks(self, t2d):
+        """[rows, k * Kp] padded view -> [rows, k, Kp] (frame blocks)."""
+        return t2d.view(t2d.shape[0], self.k, self.Kp)
+
     def load(self, name, t):
         """t: fp32 tensor with the REFERENCE shape (unpadded)."""
         dst = self.view(self.p, name)
         dst.zero_()
         if dst.dim() == 1:
             dst[: t.shape[0]].copy_(t)
+        elif name == self.n_w1:
+            self._blocks(dst)[:, :, : self.K].copy_(t.reshape(t.shape[0], self.k, self.K))
         else:
             dst[:, : t.shape[1]].copy_(t)
 
-    def export(self, name):
-        src = self.view(self.p, name)
+    def _export(self, flat, name):
+        src = self.view(flat, name)
         r = self.real[name]
-        return (src[: r[0]] if src.dim() == 1 else src[:, : r[1]]).detach().clone()
+        if src.dim() == 1:
+            return src[: r[0]].detach().clone()
+        if name == self.n_w1:
+            return self._blocks(src)[:, :, : self.K].reshape(r[0], r[1]).detach().clone()
+        return src[:, : r[1]].detach().clone()
+
+    def export(self, name):
+        return self._export(self.p, name)
 
     def export_grad(self, name):
-        src = self.view(self.g, name)
-        r = self.real[name]
-        return (src[: r[0]] if src.dim() == 1 else src[:, : r[1]]).detach().clone()
+        return self._export(self.g, name)
 
     def refresh_working_copies(self, ops):
         """bf16 working copy (skipped when AdamW already wrote it) + the transposed copies for dgrad."""
-        ops.transpose(self.view(self.pb, "ffn.0.weight"), self.w1b_t, self.Hb, self.Kp, self.Hb, self.Kp)
-        ops.transpose(self.view(self.pb, "ffn.2.weight"), self.w2b_t, self.Do, self.Hb, self.Do, self.Hb)
+        kKp = self.k * self.Kp
+        if self.has_norm:       # the "linear" projector's input carries no parameters: its W1^T (input gradient) is never needed
+            ops.transpose(self.view(self.pb, self.n_w1), self.w1b_t, self.Hb, kKp, self.Hb, kKp)
+        ops.transpose(self.view(self.pb, self.n_w2), self.w2b_t, self.Do, self.Hb, self.Do, self.Hb)
 
 
 class LLMWeights:
@@ -241,6 +273,7 @@ class StepState:
     M: int = 0
     Ra: int = 0        # projector rows (B * Lmax)
     Rap: int = 0       # padded to 64
+    Fap: int = 0       # posterior FRAME rows, padded (= Rap * k: the "linear" projector concatenates k frames per row)
     nL: int = 0        # positions that carry a label (shift_labels >= 0)
     nLp: int = 0       # padded to 64
     dev: dict = field(default_factory=dict)
@@ -272,7 +305,7 @@ class TasuModel:
     def load_reference_state_dict(self, sd):
         """sd: reference-named tensors (``llm.*``, ``encoder_projector.*``, optionally ``encoder.*``)."""
         self.llm.load_reference_state_dict(sd)
-        for n in PROJ_NAMES:
+        for n in self.proj.names:
             self.proj.load(n, sd["encoder_projector." + n].to(self.device, torch.float32))
         self.sync_projector_copies()
         if any(k.startswith("encoder.") for k in sd):
@@ -289,22 +322,24 @@ class TasuModel:
             self.encoder.init_random(seed + 2)
 
     def init_projector_default(self, seed=42):
-        """Default nn.Module init of EncoderProjectorLinearSiLU (projector.py:137-147) when training starts from
-        pretrained LLM/encoder weights and no projector checkpoint."""
-        geo, dev = self.geo, self.device
+        """Default nn.Module init of the projector (EncoderProjectorLinearSiLU, projector.py:137-147, which zeroes its last
+        bias; EncoderProjectorConcat, :28-37, plain nn.Linear init) when training starts from pretrained LLM/encoder weights and
+        no projector checkpoint."""
+        geo, dev, pr = self.geo, self.device, self.proj
         g = torch.Generator(device=dev).manual_seed(seed)
-        K, Hb, Do = geo.ctc_vocab, geo.bottleneck, geo.llm_dim
+        K, Hb, Do = geo.ctc_vocab * pr.k, geo.bottleneck, geo.llm_dim
 
         def un(shape, fan_in):
             b = 1.0 / math.sqrt(fan_in)
             return (torch.rand(*shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1) * b
 
-        self.proj.load("norm.weight", torch.ones(K, device=dev))
-        self.proj.load("norm.bias", torch.zeros(K, device=dev))
-        self.proj.load("ffn.0.weight", un((Hb, K), K))
-        self.proj.load("ffn.0.bias", un((Hb,), K))
-        self.proj.load("ffn.2.weight", un((Do, Hb), Hb))
-        self.proj.load("ffn.2.bias", torch.zeros(Do, device=dev))
+        if pr.has_norm:
+            pr.load("norm.weight", torch.ones(K, device=dev))
+            pr.load("norm.bias", torch.zeros(K, device=dev))
+        pr.load(pr.n_w1, un((Hb, K), K))
+        pr.load(pr.n_b1, un((Hb,), K))
+        pr.load(pr.n_w2, un((Do, Hb), Hb))
+        pr.load(pr.n_b2, torch.zeros(Do, device=dev) if pr.has_norm else un((Do,), Hb))
         self.sync_projector_copies()
 
     def load_encoder_checkpoint(self, path):
@@ -321,10 +356,10 @@ class TasuModel:
         self.proj.refresh_working_copies(self.ops)
 
     def projector_state_dict(self):
-        return {"encoder_projector." + n: self.proj.export(n) for n in PROJ_NAMES}
+        return {"encoder_projector." + n: self.proj.export(n) for n in self.proj.names}
 
     def projector_grads(self):
-        return {"encoder_projector." + n: self.proj.export_grad(n) for n in PROJ_NAMES}
+        return {"encoder_projector." + n: self.proj.export_grad(n) for n in self.proj.names}
 
     # ------------------------------------------------------------------------------------------ workspace
     def _buf(self, name, shape, dtype):
@@ -353,24 +388,28 @@ class TasuModel:
                 ids = ids[np.asarray(keeps[u], dtype=bool)]
             kept.append(ids)
         lens = np.array([len(k) for k in kept], dtype=np.int64)
-        Lmax = int(lens.max())
+        kk = self.proj.k
+        # the "linear" projector concatenates k frames per row and drops the batch tensor's trailing seq_len % k frames
+        # (projector.py:41-45); every utterance then owns len // k projector rows (ps-slm.py:482)
+        Lmax = (int(lens.max()) // kk) * kk
         if Lmax == 0:
             raise ValueError("text branch: every utterance has an empty pseudo-posterior (no sentencepiece ids left after "
                              "cleaning / CPS drops); the projector needs at least one row")
-        Ra = B * Lmax
-        Rap = rup(Ra, 64)
-        pid = np.full(Rap, -1, dtype=np.int32)
-        pal = np.zeros(Rap, dtype=np.float32)
+        Fa = B * Lmax
+        Fap = rup(Fa, 64 * kk)
+        pid = np.full(Fap, -1, dtype=np.int32)
+        pal = np.zeros(Fap, dtype=np.float32)
         for u, ids in enumerate(kept):
-            pid[u * Lmax: u * Lmax + len(ids)] = ids
+            n = min(len(ids), Lmax)
+            pid[u * Lmax: u * Lmax + n] = ids[:n]
             if row_alphas is not None:
-                pal[u * Lmax: u * Lmax + len(ids)] = np.asarray(row_alphas[u], dtype=np.float32)
+                pal[u * Lmax: u * Lmax + n] = np.asarray(row_alphas[u], dtype=np.float32)[:n]
             elif alphas is not None:
-                pal[u * Lmax: u * Lmax + len(ids)] = float(alphas[u])
-        st = self._finish_prepare(input_ids, attention_mask, labels, lens, Lmax)
+                pal[u * Lmax: u * Lmax + n] = float(alphas[u])
+        st = self._finish_prepare(input_ids, attention_mask, labels, lens // kk, Lmax // kk)
         st.dev["post_ids"] = self._upload("post_ids", pid)
         st.dev["post_alpha"] = self._upload("post_alpha", pal)
-        st.Ra, st.Rap = Ra, Rap
+        st.Ra, st.Rap, st.Fap = Fa // kk, Fap // kk, Fap
         return st
 
     def prepare_audio(self, input_ids, attention_mask, labels, input_features, input_feature_length, do_psd=True) -> StepState:
@@ -381,8 +420,12 @@ class TasuModel:
         fl = np.asarray(input_feature_length.cpu() if isinstance(input_feature_length, torch.Tensor) else input_feature_length)
         fl_dev = self._upload("feat_lens", fl.astype(np.int32))
         rows, new_lens, Lmax = psd_on_device(self, post, B, T, Te, fl_dev, do_psd)
+        if self.proj.k != 1:
+            raise NotImplementedError("the 'linear' projector with encoder_projector_ds_rate > 1 is served on the text branch only "
+                                      "(the shipped recipes run ds_rate = 1)")
         st = self._finish_prepare(input_ids, attention_mask, labels, new_lens, Lmax)
         st.Ra, st.Rap = B * Lmax, rup(B * Lmax, 64)
+        st.Fap = st.Rap
         st.path = "audio"
         st.dev["post"] = rows
         st.dev["psd_lens"] = new_lens
@@ -426,29 +469,34 @@ class TasuModel:
 
     # ------------------------------------------------------------------------------------------ forward
     def forward_projector_text(self, st: StepState):
-        """pseudo-posterior rows -> LayerNorm(25055) -> Linear -> SiLU -> Linear   (projector.py:149-151)."""
+        """pseudo-posterior rows -> projector (projector.py:149-151 / :38-49)."""
         ops, pr = self.ops, self.proj
-        Rap, K, Kp, Hb, Do = st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
-        post = self._buf("post", (Rap, Kp), torch.float32)
-        ops.posterior_build(st.dev["post_ids"], st.dev["post_alpha"], post, Rap, K)
+        post = self._buf("post", (st.Fap, pr.Kp), torch.float32)
+        ops.posterior_build(st.dev["post_ids"], st.dev["post_alpha"], post, st.Fap, pr.K)
         st.dev["post"] = post
         self._projector_from_posterior(st)
 
     def _projector_from_posterior(self, st):
+        """linear-silu: LayerNorm(25055) -> Linear -> SiLU -> Linear;  linear: [k frames concatenated] Linear -> ReLU -> Linear."""
         ops, pr = self.ops, self.proj
-        Rap, K, Kp, Hb, Do = st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
+        Fap, Rap, K, Kp, Hb, Do = st.Fap, st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
         post = st.dev["post"]
-        xn = self._buf("xn", (Rap, Kp), torch.bfloat16)
-        mean = self._buf("ln_mean", (Rap,), torch.float32)
-        rstd = self._buf("ln_rstd", (Rap,), torch.float32)
-        ops.layernorm_fwd(post, pr.view(pr.p, "norm.weight"), pr.view(pr.p, "norm.bias"), xn, mean, rstd, Rap, K,
-                          self.geo.ln_eps)
+        xn = self._buf("xn", (Fap, Kp), torch.bfloat16)
+        mean = rstd = None
+        if pr.has_norm:
+            mean = self._buf("ln_mean", (Fap,), torch.float32)
+            rstd = self._buf("ln_rstd", (Fap,), torch.float32)
+            ops.layernorm_fwd(post, pr.view(pr.p, "norm.weight"), pr.view(pr.p, "norm.bias"), xn, mean, rstd, Fap, K,
+                              self.geo.ln_eps)
+        else:
+            ops.cast_bf16(post, xn)                            # autocast: the Linear rounds its input to bf16
+        xrows = xn.view(Rap, pr.k * Kp)                        # k consecutive frames = one projector row
         h1 = self._buf("h1", (Rap, Hb), torch.bfloat16)
-        ops.gemm(xn, pr.view(pr.pb, "ffn.0.weight"), h1, Rap, Hb, Kp, bias=pr.view(pr.pb, "ffn.0.bias"))
+        ops.gemm(xrows, pr.view(pr.pb, pr.n_w1), h1, Rap, Hb, pr.k * Kp, bias=pr.view(pr.pb, pr.n_b1))
         a1 = self._buf("a1", (Rap, Hb), torch.bfloat16)
-        ops.silu_fwd(h1, a1)
+        (ops.silu_fwd if pr.has_norm else ops.relu_fwd)(h1, a1)
         y2 = self._buf("y2", (Rap, Do), torch.bfloat16)
-        ops.gemm(a1, pr.view(pr.pb, "ffn.2.weight"), y2, Rap, Do, Hb, bias=pr.view(pr.pb, "ffn.2.bias"))
+        ops.gemm(a1, pr.view(pr.pb, pr.n_w2), y2, Rap, Do, Hb, bias=pr.view(pr.pb, pr.n_b2))
         st.dev.update(xn=xn, ln_mean=mean, ln_rstd=rstd, h1=h1, a1=a1, y2=y2)
 
     def forward_llm(self, st: StepState, compute_loss=True, need_backward=True, logits_rows="all"):
@@ -600,52 +648,58 @@ class TasuModel:
 
     def grad_ranges(self, w1_chunks=1):
         """The flat gradient bucket as the ranges backward_projector completes, in completion order:
-        [ffn.0.bias | ffn.2.weight | ffn.2.bias] (one contiguous tail), then ``w1_chunks`` row blocks of ffn.0.weight,
-        then [norm.weight | norm.bias].  The ranges tile [0, numel) exactly."""
+        [b1 | W2 | b2] (one contiguous tail), then ``w1_chunks`` row blocks of W1, then -- linear-silu only --
+        [norm.weight | norm.bias].  The ranges tile [0, numel) exactly."""
         pr = self.proj
-        o_w1, o_b1 = pr.offsets["ffn.0.weight"][0], pr.offsets["ffn.0.bias"][0]
+        o_w1, o_b1 = pr.offsets[pr.n_w1][0], pr.offsets[pr.n_b1][0]
+        ld = pr.k * pr.Kp
         rows = [pr.Hb * i // w1_chunks for i in range(w1_chunks + 1)]
-        return [(o_b1, pr.numel)] + [(o_w1 + r0 * pr.Kp, o_w1 + r1 * pr.Kp) for r0, r1 in zip(rows[:-1], rows[1:])] + [(0, o_w1)]
+        out = [(o_b1, pr.numel)] + [(o_w1 + r0 * ld, o_w1 + r1 * ld) for r0, r1 in zip(rows[:-1], rows[1:])]
+        return out + ([(0, o_w1)] if o_w1 > 0 else [])
 
     def backward_projector(self, st: StepState, on_ready=None, w1_chunks=1):
-        """Merge backward + projector backward (projector.py:149-151 reversed): wgrads land in the flat fp32 bucket.
+        """Merge backward + projector backward (projector.py:149-151 / :38-49 reversed): wgrads land in the flat fp32 bucket.
         ``on_ready(lo, hi)`` (the engine's gradient exchange) is called as soon as the kernels that complete the bucket range
-        [lo, hi) have been launched, in the order of ``grad_ranges(w1_chunks)``; with ``w1_chunks`` > 1 the ffn.0.weight
-        wgrad -- 94 % of the bucket -- runs as that many row-block GEMMs so that its all-reduce starts before the
-        projector's input-side work (dxn, LayerNorm parameter gradients) has run."""
+        [lo, hi) have been launched, in the order of ``grad_ranges(w1_chunks)``; with ``w1_chunks`` > 1 the W1 wgrad -- 94 % of
+        the bucket -- runs as that many row-block GEMMs so that its all-reduce starts before the projector's input-side work
+        (dxn, LayerNorm parameter gradients) has run."""
         ops, pr, d = self.ops, self.proj, st.dev
         bf, f32 = torch.bfloat16, torch.float32
         ranges = self.grad_ranges(w1_chunks)
         # merge backward: gradient rows that hold audio -> projector output gradient
         Rap, K, Kp, Hb, Do = st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
+        kKp = pr.k * Kp
         audio_rows = d["audio_rows_pad"] if "audio_rows_pad" in d else self._pad_rows(st)
         dy2 = self._buf("dy2", (Rap, Do), bf)
         ops.merge_bwd(d["dx"], audio_rows, dy2, Rap, Do)
         # Linear2: db2, dW2 = dy2^T a1, da1 = dy2 W2
-        ops.colsum(dy2, pr.view(pr.g, "ffn.2.bias"), Rap, Do)
+        ops.colsum(dy2, pr.view(pr.g, pr.n_b2), Rap, Do)
         dy2_t = self._buf("dy2_t", (Do, Rap), bf)
         a1_t = self._buf("a1_t", (Hb, Rap), bf)
         ops.transpose(dy2, dy2_t, Rap, Do, Rap, Do)
         ops.transpose(d["a1"], a1_t, Rap, Hb, Rap, Hb)
-        ops.gemm(dy2_t, a1_t, pr.view(pr.g, "ffn.2.weight"), Do, Hb, Rap, mode=GEMM_F32)
+        ops.gemm(dy2_t, a1_t, pr.view(pr.g, pr.n_w2), Do, Hb, Rap, mode=GEMM_F32)
         da1 = self._buf("da1", (Rap, Hb), bf)
         ops.gemm(dy2, pr.w2b_t, da1, Rap, Hb, Do)
         dh1 = self._buf("dh1", (Rap, Hb), bf)
-        ops.silu_bwd(da1, d["h1"], dh1)
+        (ops.silu_bwd if pr.has_norm else ops.relu_bwd)(da1, d["h1"], dh1)
         # Linear1: db1, dW1 = dh1^T xn, dxn = dh1 W1
-        ops.colsum(dh1, pr.view(pr.g, "ffn.0.bias"), Rap, Hb)
+        ops.colsum(dh1, pr.view(pr.g, pr.n_b1), Rap, Hb)
         if on_ready is not None:
             on_ready(*ranges[0])
         dh1_t = self._buf("dh1_t", (Hb, Rap), bf)
-        xn_t = self._buf("xn_t", (Kp, Rap), bf)
+        xn_t = self._buf("xn_t", (kKp, Rap), bf)
+        xrows = d["xn"].view(Rap, kKp)
         ops.transpose(dh1, dh1_t, Rap, Hb, Rap, Hb)
-        ops.transpose(d["xn"], xn_t, Rap, Kp, Rap, Kp)
-        gw1 = pr.view(pr.g, "ffn.0.weight")
+        ops.transpose(xrows, xn_t, Rap, kKp, Rap, kKp)
+        gw1 = pr.view(pr.g, pr.n_w1)
         rows = [Hb * i // w1_chunks for i in range(w1_chunks + 1)]
         for i, (r0, r1) in enumerate(zip(rows[:-1], rows[1:])):
-            ops.gemm(dh1_t[r0:r1], xn_t, gw1[r0:r1], r1 - r0, Kp, Rap, mode=GEMM_F32)
+            ops.gemm(dh1_t[r0:r1], xn_t, gw1[r0:r1], r1 - r0, kKp, Rap, mode=GEMM_F32)
             if on_ready is not None:
                 on_ready(*ranges[1 + i])
+        if not pr.has_norm:
+            return                                     # the posterior carries no parameters: nothing upstream of W1
         dxn = self._buf("dxn", (Rap, Kp), bf)
         ops.gemm(dh1, pr.w1b_t, dxn, Rap, Kp, Hb)
         ws = self._buf("ln_ws", (2 * LN_BWD_SPLIT * K,), f32)
@@ -699,7 +753,7 @@ class TasuModel:
         self._graphed(("region",) + tuple(key), fn, _NoState())
 
     def _shape_key(self, st, tag):
-        return (tag, st.path, st.B, st.S, st.Ra, st.Rap, st.nLp, self.keep_logits)
+        return (tag, st.path, st.B, st.S, st.Ra, st.Rap, st.Fap, st.nLp, self.keep_logits)
 
     def run_forward_text(self, st, compute_loss=True, need_backward=True):
         """forward_projector_text + forward_llm, graph-replayed when enabled."""

@@ -227,6 +227,9 @@ class HipOps:
     def silu_bwd(self, dy, x, dx):
         self._chk(self.lib.tasu_silu_bwd(_p(dy), _p(x), _p(dx), x.numel(), self._stream()), "tasu_silu_bwd")
 
+    def relu_bwd(self, dy, x, dx):
+        self._chk(self.lib.tasu_relu_bwd(_p(dy), _p(x), _p(dx), x.numel(), self._stream()), "tasu_relu_bwd")
+
     def relu_fwd(self, x, y):
         self._chk(self.lib.tasu_relu_fwd(_p(x), _p(y), x.numel(), self._stream()), "tasu_relu_fwd")
 

@@ -158,9 +158,12 @@ def load_hf_llm_state_dict(path):
 
 def model_factory(train_config, model_config, **kwargs):
     """Same contract as Multitask/model/ps-slm.py:130-181: returns (model, tokenizer)."""
-    if model_config.get("encoder_projector", "linear-silu") != "linear-silu":
-        raise NotImplementedError("only the shipped recipe's projector ('linear-silu', "
-                                  "Multitask/scripts/finetune_deespeed_sensevoice.sh:25) is on the MI355X hot path")
+    projector = model_config.get("encoder_projector", "linear-silu")
+    if projector not in ("linear-silu", "linear"):
+        raise NotImplementedError(f"encoder_projector={projector!r}: the MI355X path serves 'linear-silu' (the shipped recipe, "
+                                  "Multitask/scripts/finetune_deespeed_sensevoice.sh:25) and 'linear' (EncoderProjectorConcat, "
+                                  "Multitask/model/projector.py:28-49); cov1d-linear / q-former / cross-attention / "
+                                  "simple_linear are not built")
     if train_config.get("use_peft", False) or not train_config.get("freeze_llm", True):
         raise NotImplementedError("the MI355X path trains the projector only (freeze_llm=true, use_peft=false: "
                                   "Multitask/scripts/finetune_deespeed_sensevoice.sh:28,84)")
@@ -170,6 +173,8 @@ def model_factory(train_config, model_config, **kwargs):
         logger.warning("train_config.use_fp16 is false: the MI355X path still computes with bf16-autocast semantics "
                        "(bf16 GEMM operands, fp32 accumulation / residual stream / norms / loss)")
     geo = geometry_from_config(model_config)
+    geo.projector = projector
+    geo.projector_ds_rate = int(model_config.get("encoder_projector_ds_rate", 1) or 1) if projector == "linear" else 1
     tokenizer = setup_tokenizer(train_config, model_config, geo, **kwargs)
     if not isinstance(tokenizer, SyntheticLLMTokenizer):
         geo.speech_id, geo.eos_id = tokenizer.default_speech_token, tokenizer.eos_token_id
@@ -250,9 +255,8 @@ class slam_model_asr:
         return self.core.projector_state_dict()
 
     def load_state_dict(self, sd, strict=False):
-        from .model import PROJ_NAMES
         missing = []
-        for n in PROJ_NAMES:
+        for n in self.core.proj.names:
             k = "encoder_projector." + n
             if k in sd:
                 self.core.proj.load(n, sd[k].to(self.core.device, torch.float32))

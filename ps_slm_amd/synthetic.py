@@ -50,12 +50,19 @@ def random_state_dict(geo: Geometry, seed: int, with_encoder=True, scale=0.05):
     if not geo.tied:
         sd["llm.lm_head.weight"] = rn(V, D)
     K, Hb = geo.ctc_vocab, geo.bottleneck
-    sd["encoder_projector.norm.weight"] = near_one(K)
-    sd["encoder_projector.norm.bias"] = rn(K)
-    sd["encoder_projector.ffn.0.weight"] = rn(Hb, K, s=1.0 / math.sqrt(K))
-    sd["encoder_projector.ffn.0.bias"] = rn(Hb)
-    sd["encoder_projector.ffn.2.weight"] = rn(D, Hb, s=1.0 / math.sqrt(Hb))
-    sd["encoder_projector.ffn.2.bias"] = rn(D)
+    if geo.projector == "linear":                       # EncoderProjectorConcat: k frames concatenated, no norm
+        Kin = K * geo.projector_ds_rate
+        sd["encoder_projector.linear1.weight"] = rn(Hb, Kin, s=1.0 / math.sqrt(K))
+        sd["encoder_projector.linear1.bias"] = rn(Hb)
+        sd["encoder_projector.linear2.weight"] = rn(D, Hb, s=1.0 / math.sqrt(Hb))
+        sd["encoder_projector.linear2.bias"] = rn(D)
+    else:
+        sd["encoder_projector.norm.weight"] = near_one(K)
+        sd["encoder_projector.norm.bias"] = rn(K)
+        sd["encoder_projector.ffn.0.weight"] = rn(Hb, K, s=1.0 / math.sqrt(K))
+        sd["encoder_projector.ffn.0.bias"] = rn(Hb)
+        sd["encoder_projector.ffn.2.weight"] = rn(D, Hb, s=1.0 / math.sqrt(Hb))
+        sd["encoder_projector.ffn.2.bias"] = rn(D)
     if with_encoder:
         E, Fd, Ff, ks = geo.enc_dim, geo.feat_dim, geo.enc_ffn, geo.enc_kernel
         sd["encoder.embed.weight"] = rn(16, Fd, s=1.0)

@@ -245,6 +245,9 @@ class FakeOps:
     def relu_fwd(self, x, y):
         y.copy_(torch.relu(x))
 
+    def relu_bwd(self, dy, x, dx):
+        dx.copy_(torch.where(x.float() > 0, dy, torch.zeros_like(dy)))
+
     # ---------------------------------------------------------------- loss
     def ce_fwd_bwd(self, logits, shift_labels, M, V, row_loss, row_hit, row_argmax, dlogits, inv_count):
         lg = logits[:M, :V].float()

@@ -507,3 +507,30 @@ def test_device_beam_update_restatement_matches_host_beam_state(nb, lpw, min_len
     got, _ = run_device(FakeOps(), "cpu", table, B, nb, T, eos, lpw, min_len, extra_steps=2)
     assert np.array_equal(got, want), (got, want)
     assert (got == eos).any()
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_linear_projector_step_matches_oracle_and_reference(k):
+    """The alternate projector (``encoder_projector="linear"``: k frames concatenated -> Linear -> ReLU -> Linear, no norm; flat
+    bucket [W1 | b1 | W2 | b2]) through the product's host code on the CPU double: loss / gradients against the bf16 oracle,
+    loss against the REAL reference's fp32 golden, state-dict round trip under the reference's key names, and the gradient
+    exchange ranges tiling the bucket."""
+    from conftest import linear_projector_case
+    geo, sd, batch, z = linear_projector_case(k)
+    model = build(geo, sd)
+    assert model.proj.names == ("linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias") and model.proj.k == k
+    st = run_text(model, batch)
+    out, grads = O.loss_and_projector_grads(sd, batch, dataclasses.asdict(geo), "bf16")
+    assert abs(float(st.dev["loss_out"][0]) - float(out["loss"])) < 2e-3
+    assert abs(float(st.dev["loss_out"][0]) - float(z["loss"])) < 2e-2
+    mine = model.projector_grads()
+    assert sorted(mine) == sorted(grads)
+    for name, g in grads.items():
+        assert mine[name].shape == g.shape, name
+        assert float(torch.nn.functional.cosine_similarity(mine[name].flatten(), g.flatten(), dim=0)) > 0.999, name
+    for name, v in model.projector_state_dict().items():
+        assert torch.equal(v, sd[name]), name
+    for chunks in (1, 4):
+        ranges = sorted(model.grad_ranges(chunks))
+        assert ranges[0][0] == 0 and ranges[-1][1] == model.proj.numel and len(ranges) == chunks + 1
+        assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))

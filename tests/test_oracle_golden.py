@@ -335,3 +335,22 @@ def test_generate_margin_cases_vs_reference(mode):
                                   c["am"], None, geo.speech_id)
         toks = O.beam_search_generate(sd, emb.detach(), mask, gd, mode=mode, **c["kw"])
         assert np.array_equal(toks.numpy(), c["tokens"]), (n, toks, c["tokens"])
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_linear_projector_vs_reference(k):
+    """encoder_projector="linear" (EncoderProjectorConcat, projector.py:28-49), ds_rate 1 and 2, through the REAL reference at
+    the mid geometry: the oracle's restatement reproduces loss, accuracy, logits and projector gradients."""
+    import dataclasses
+
+    from conftest import linear_projector_case
+    geo, sd, batch, z = linear_projector_case(k)
+    out, grads = O.loss_and_projector_grads(sd, batch, dataclasses.asdict(geo), "fp32")
+    close(out["loss"], z["loss"])
+    close(out["acc"], z["acc"])
+    cols = torch.from_numpy(z["cols"])
+    close(out["logits"][:, :, cols], z["logits_cols"], rtol=2e-4, atol=2e-5)
+    close(grads["encoder_projector.linear1.bias"], z["grad.linear1.bias"], rtol=2e-4, atol=1e-7)
+    close(grads["encoder_projector.linear2.bias"], z["grad.linear2.bias"], rtol=2e-4, atol=1e-7)
+    close(grads["encoder_projector.linear2.weight"][::16], z["grad.linear2.weight.rows16"], rtol=2e-4, atol=1e-7)
+    close(grads["encoder_projector.linear1.weight"][::64], z["grad.linear1.weight.rows64"], rtol=2e-4, atol=1e-7)
