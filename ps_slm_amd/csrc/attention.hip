@@ -105,6 +105,11 @@ __device__ __forceinline__ void load_row_frags(bf16x8 f[4], const bf16* g, int l
 constexpr float NEG_INF = -__builtin_inff();
 
 // ======================================================================================= forward
+// QW = 16-query sub-tiles per wave (block = 4 waves = 64 * QW queries).  The loop is LDS-read bound, not MFMA bound: with one
+// sub-tile per wave every K / V^T fragment read from LDS feeds ONE MFMA (1 KiB of LDS per 16 MFMA cycles, four waves on a
+// 128 B/clk LDS: twice the MFMA time).  With QW = 2 each fragment feeds two MFMAs (the wave's two query sub-tiles), halving
+// the LDS traffic per FLOP.
+template <int QW>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
                                                           const uint8_t* __restrict__ kmask, bf16* __restrict__ out,
                                                           float* __restrict__ lse, int S, int Spad, int H, int G,
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   char* sVt = smem + ROW_TILE_BYTES;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // grid (H, B, query tiles): the late query tiles, which meet the most key tiles under the causal mask, are dispatched
-  // first, so the 1.5-round grid (768 blocks on 512 slots at 16 x 12 x 256) ends on the short ones
+  // first, so that a multi-round grid ends on the short ones
   const int qt = (int)gridDim.z - 1 - (int)blockIdx.z, h = blockIdx.x, b = blockIdx.y;
   const int g = h / (H / G);
   const int LD = (H + 2 * G) * HD;
@@ -123,17 +128,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   const bf16* vtbase = vt + ((size_t)b * G + g) * HD * Spad;
   const uint8_t* mrow = kmask + (size_t)b * Spad;
 
-  const int qpos = qt * 64 + wave * 16 + (lane & 15);
+  const int q0 = qt * 64 * QW + wave * 16 * QW;        // first query of this wave
   const int qp = lane >> 4;
-  bf16x8 qf[4];
-  load_row_frags(qf, qbase, LD, min(qpos, S - 1), lane);
-
-  f32x4 o[8];
+  int qpos[QW];
+  bf16x8 qf[QW][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = NEG_INF, l_run = 0.f;
+  for (int u = 0; u < QW; ++u) {
+    qpos[u] = q0 + u * 16 + (lane & 15);
+    load_row_frags(qf[u], qbase, LD, min(qpos[u], S - 1), lane);
+  }
 
-  const int nkt = causal ? (qt + 1) : ((S + 63) >> 6);
+  f32x4 o[QW][8];
+  float m_run[QW], l_run[QW];
+#pragma unroll
+  for (int u = 0; u < QW; ++u) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m_run[u] = NEG_INF;
+    l_run[u] = 0.f;
+  }
+
+  const int nkt_all = (S + 63) >> 6;
+  const int nkt = causal ? min(nkt_all, (qt + 1) * QW) : nkt_all;
   TileRegs rK, rVt;
   uint32_t mk_next[4], mkw[4];                    // key-mask words of the tile, prefetched with it (no load -> use stall)
   fetch_row_tile(rK, kbase, LD, 0, S);
@@ -154,61 +170,83 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
       for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + (kt + 1) * 64 + st * 16 + 4 * qp);
     }
 
-    f32x4 s[4];
-    float tmax = NEG_INF;
+    f32x4 s[QW][4];
+    float tmax[QW];
+#pragma unroll
+    for (int u = 0; u < QW; ++u) tmax[u] = NEG_INF;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 a[QW];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a = mfma16(frag_row(sK, st, ks, lane), qf[ks], a);
+      for (int u = 0; u < QW; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kfrag = frag_row(sK, st, ks, lane);          // one LDS read, QW MFMAs
+#pragma unroll
+        for (int u = 0; u < QW; ++u) a[u] = mfma16(kfrag, qf[u][ks], a[u]);
+      }
       const int key0 = kt * 64 + st * 16 + 4 * qp;
       const uint32_t mk = mkw[st];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + r;
-        const bool ok = ((mk >> (8 * r)) & 0xff) && (!causal || key <= qpos);
-        a[r] = ok ? a[r] * scale : NEG_INF;
-        tmax = fmaxf(tmax, a[r]);
+      for (int u = 0; u < QW; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + r;
+          const bool ok = ((mk >> (8 * r)) & 0xff) && (!causal || key <= qpos[u]);
+          a[u][r] = ok ? a[u][r] * scale : NEG_INF;
+          tmax[u] = fmaxf(tmax[u], a[u][r]);
+        }
+        s[u][st] = a[u];
       }
-      s[st] = a;
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_use);  // m_run = -inf -> 0
-    float psum = 0.f;
+    bf16x8 pf0[QW], pf1[QW];
 #pragma unroll
-    for (int st = 0; st < 4; ++st)
+    for (int u = 0; u < QW; ++u) {
+      float tm = fmaxf(tmax[u], __shfl_xor(tmax[u], 16, 64));
+      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+      const float m_new = fmaxf(m_run[u], tm);
+      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+      const float alpha = __expf(m_run[u] - m_use);  // m_run = -inf -> 0
+      float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __expf(s[st][r] - m_use);
-        s[st][r] = p;
-        psum += p;
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+      for (int st = 0; st < 4; ++st)
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) o[nt] *= alpha;
-    const bf16x8 pf0 = pack_pair(s[0], s[1]);
-    const bf16x8 pf1 = pack_pair(s[2], s[3]);
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[u][st][r] - m_use);
+          s[u][st][r] = p;
+          psum += p;
+        }
+      l_run[u] = l_run[u] * alpha + psum;
+      m_run[u] = m_new;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) o[u][nt] *= alpha;
+      pf0[u] = pack_pair(s[u][0], s[u][1]);
+      pf1[u] = pack_pair(s[u][2], s[u][3]);
+    }
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      o[nt] = mfma16(frag_tr(sVt, nt, 0, lane), pf0, o[nt]);
-      o[nt] = mfma16(frag_tr(sVt, nt, 1, lane), pf1, o[nt]);
+      const bf16x8 v0 = frag_tr(sVt, nt, 0, lane), v1 = frag_tr(sVt, nt, 1, lane);   // read once, used by QW sub-tiles
+#pragma unroll
+      for (int u = 0; u < QW; ++u) {
+        o[u][nt] = mfma16(v0, pf0[u], o[u][nt]);
+        o[u][nt] = mfma16(v1, pf1[u], o[u][nt]);
+      }
     }
   }
-  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
-  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-  if (qpos < S) {
-    bf16* orow = out + ((size_t)b * S + qpos) * (H * HD) + h * HD;
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) {
-      const f32x4 v = o[nt] * inv;
-      *(bf16x4*)(orow + nt * 16 + 4 * qp) = __builtin_convertvector(v, bf16x4);
+  for (int u = 0; u < QW; ++u) {
+    float l_tot = l_run[u] + __shfl_xor(l_run[u], 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (qpos[u] < S) {
+      bf16* orow = out + ((size_t)b * S + qpos[u]) * (H * HD) + h * HD;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const f32x4 v = o[u][nt] * inv;
+        *(bf16x4*)(orow + nt * 16 + 4 * qp) = __builtin_convertvector(v, bf16x4);
+      }
+      if (qp == 0) lse[((size_t)b * H + h) * Spad + qpos[u]] = l_tot > 0.f ? m_run[u] + __logf(l_tot) : 0.f;
     }
-    if (qp == 0) lse[((size_t)b * H + h) * Spad + qpos] = l_tot > 0.f ? m_run + __logf(l_tot) : 0.f;
   }
 }
 
@@ -512,9 +550,20 @@ static inline int spad_of(int S) { return (S + 63) & ~63; }
 extern "C" int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key_mask, void* out, float* lse, int B,
                              int S, int H, int G, float scale, int causal, void* stream) {
   if (!qkv || !vt || !key_mask || !out || !lse || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
-  dim3 grid(H, B, (S + 63) / 64);
-  TASU_LAUNCH(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)vt,
-                     key_mask, (bf16*)out, lse, S, spad_of(S), H, G, scale, causal);
+  static const int qw2_from = [] { const char* e = getenv("TASU_ATTN_QW2_FROM"); return e ? atoi(e) : 1 << 30; }();
+  if (S >= qw2_from) {
+    // two query sub-tiles per wave (128-query blocks): half the LDS traffic per FLOP of the one-sub-tile form.  Measured at the
+    // training shape (S = 256, causal): 20.7 us against 20.5 us -- these launches are bound by the latency of the per-tile
+    // staging (1-4 key tiles per block), not by LDS bandwidth -- so the form is opt-in (TASU_ATTN_QW2_FROM=<S>) for long
+    // non-causal sequences.
+    dim3 grid(H, B, (S + 127) / 128);
+    TASU_LAUNCH(attn_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)vt, key_mask,
+                (bf16*)out, lse, S, spad_of(S), H, G, scale, causal);
+  } else {
+    dim3 grid(H, B, 1);
+    TASU_LAUNCH(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)vt, key_mask,
+                (bf16*)out, lse, S, spad_of(S), H, G, scale, causal);
+  }
   return TASU_OK;
 }
 

@@ -227,9 +227,16 @@ class slam_model_asr:
         self.voca_trans = train_config.get("voca_trans", False)
         self.gt_emb = train_config.get("gt_emb", False)
         self.gt_emb_noise = train_config.get("gt_emb_noise", False)
-        if not self.ctc_posterior or self.voca_trans or train_config.get("top1_emb", False):
-            raise NotImplementedError("only ctc_posterior=true, voca_trans=false, top1_emb=false (the shipped TASU "
-                                      "recipe, Multitask/scripts/finetune_deespeed_sensevoice.sh:31-35) is supported")
+        if self.voca_trans or train_config.get("top1_emb", False):
+            # FINDING: the reference's own voca_trans branch cannot run -- forward (ps-slm.py:485-514) and generate (:614-640) read
+            # `encoder_outs`, which is only assigned in the voca_trans == False branch (:457-471, :590-603), and raise
+            # UnboundLocalError (reproduced with the imported reference); top1_emb lives inside that branch.  There is nothing to
+            # pin an implementation against.
+            raise NotImplementedError("voca_trans / top1_emb: the reference's branch (Multitask/model/ps-slm.py:485-514) reads an "
+                                      "unassigned `encoder_outs` and raises UnboundLocalError as shipped; not built")
+        if not self.ctc_posterior:
+            raise NotImplementedError("ctc_posterior=false (raw encoder features into the projector, ps-slm.py:515-523) is not the "
+                                      "TASU recipe (Multitask/scripts/finetune_deespeed_sensevoice.sh:31-35); not built")
         # knobs of ctc_pseudo_posterior_noise (ps-slm.py:372-375), overridable as attributes like in the reference
         self.drop_prob, self.insert_prob, self.smooth_low, self.smooth_high = 0.05, 0.0, 0.0, 0.1
         self.training = True
