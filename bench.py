@@ -337,11 +337,12 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         n_launch = len(timed.events)
         achieved = gemm_flops_step * steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")
         if os.path.isfile(pmc) and model_name == "qwen2.5-1.5b" and B == 16 and not audio:
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-            traffic_src = ("OFFLINE figure read from profiles/r01_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                           "tools/pmc_gemm.py, gfx950 x2 fetch correction), not measured by this run")
+            traffic_src = ("OFFLINE figure read from profiles/r02_gemm_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                           "over tools/gemm_shapes_run.py, gfx950 x2 fetch correction; launch-count-weighted mean of the per-shape "
+                           "figures), not measured by this run")
         what = ("audio-SFT step (500 feature frames -> SANM encoder -> CTC posterior -> PSD -> projector -> LLM fwd+dgrad bwd+"
                 "projector wgrad+AdamW)" if audio else
                 "text-only CPS alignment step (fwd+dgrad bwd+projector wgrad+AdamW), frozen encoder pass skipped")

@@ -27,5 +27,9 @@ for i, (name, m, n, k, mode, sw) in enumerate(SHAPES):
     meas_f, meas_w = 2 * fetch[j] * 1024, write[j] * 1024
     out["shapes"][name] = {"M": m, "N": rows, "K": k, "fetch_bytes": int(meas_f), "write_bytes": int(meas_w),
                            "algorithmic_bytes": int(algo), "ratio": round((meas_f + meas_w) / algo, 2)}
+per_layer = {"qkv", "o", "gate_up+swiglu", "down", "d_down", "d_gate_up", "d_o", "d_qkv"}
+tot = sum((28 if k in per_layer else 1) * (v["fetch_bytes"] + v["write_bytes"]) for k, v in out["shapes"].items())
+cnt = sum(28 if k in per_layer else 1 for k in out["shapes"])
+out["traffic_bytes_per_launch"] = int(tot / cnt)       # bench.py's roofline.traffic: launch-count-weighted mean of one step's GEMMs
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
