@@ -125,6 +125,19 @@ __global__ __launch_bounds__(64 * DEC_NW) void attn_decode_kernel(const bf16* __
   const int l15 = lane & 15, lq = lane >> 4;
   for (int i = threadIdx.x; i < nk; i += 64 * DEC_NW) prow[i] = row_index ? row_index[(size_t)row * ctx + k0 + i] : row;
   __syncthreads();
+  // ---- V prefetch: the first PRE_IT x UN value rows of this thread's phase-2 walk are requested NOW, so that their latency
+  // runs under phase 1 (K loads, score MFMAs) and the softmax instead of behind them (the phases are otherwise two dependent
+  // memory round trips); contexts up to PRE_IT * 128 keys are covered entirely
+  constexpr int UN = 4, PRE_IT = 3;
+  const bf16* vbase = vc + (size_t)k0 * W + g * HD + l15 * 8;
+  bf16x8 vpre[PRE_IT][UN];
+#pragma unroll
+  for (int it = 0; it < PRE_IT; ++it)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int kcl = min(wave * 4 + it * (DEC_NW * 4 * UN) + u * DEC_NW * 4 + lq, nk - 1);
+      vpre[it][u] = *(const bf16x8*)(vbase + ((size_t)prow[kcl] * ctx + kcl) * W);
+    }
   // ---- phase 1: scores
   bf16x8 qf[4];
 #pragma unroll
@@ -168,33 +181,36 @@ __global__ __launch_bounds__(64 * DEC_NW) void attn_decode_kernel(const bf16* __
   }
   __syncthreads();
   // ---- phase 2: P.V   (lane: dims 8*l15 .. +7, key quarter lq; wave: keys wave*4 + lq, stride 32)
-  const bf16* vbase = vc + (size_t)k0 * W + g * HD + l15 * 8;
   float o[REP][8];
 #pragma unroll
   for (int h = 0; h < REP; ++h)
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[h][j] = 0.f;
-  constexpr int UN = 4;
-  for (int i0 = wave * 4; i0 < nk; i0 += DEC_NW * 4 * UN) {
-    bf16x8 v[UN];
-    int key[UN];
+  auto accumulate = [&](const bf16x8 (&v)[UN], int i0) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      key[u] = i0 + u * DEC_NW * 4 + lq;
-      const int kcl = min(key[u], nk - 1);
-      v[u] = *(const bf16x8*)(vbase + ((size_t)prow[kcl] * ctx + kcl) * W);
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      if (key[u] < nk) {
+      const int key = i0 + u * DEC_NW * 4 + lq;
+      if (key < nk) {
 #pragma unroll
         for (int h = 0; h < REP; ++h) {
-          const float p = sc[h * ctx + key[u]];
+          const float p = sc[h * ctx + key];
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[h][j] += p * (float)v[u][j];
         }
       }
     }
+  };
+#pragma unroll
+  for (int it = 0; it < PRE_IT; ++it)
+    if (wave * 4 + it * (DEC_NW * 4 * UN) < nk) accumulate(vpre[it], wave * 4 + it * (DEC_NW * 4 * UN));
+  for (int i0 = wave * 4 + PRE_IT * (DEC_NW * 4 * UN); i0 < nk; i0 += DEC_NW * 4 * UN) {
+    bf16x8 v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int kcl = min(i0 + u * DEC_NW * 4 + lq, nk - 1);
+      v[u] = *(const bf16x8*)(vbase + ((size_t)prow[kcl] * ctx + kcl) * W);
+    }
+    accumulate(v, i0);
   }
 #pragma unroll
   for (int h = 0; h < REP; ++h)

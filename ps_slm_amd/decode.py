@@ -274,7 +274,7 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
             return device_step()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             device_step()
         graphs[key] = g
         while len(graphs) > DECODE_GRAPH_CACHE:

@@ -738,7 +738,7 @@ class TasuModel:
         graph = torch.cuda.CUDAGraph()
         before = set(st.dev)
         gen = self._buf_gen
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may call into HIP
             fn()
         if gen != self._buf_gen:                      # a buffer grew DURING the capture: do not keep the graph
             return
