@@ -560,7 +560,7 @@ extern "C" int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key
     TASU_LAUNCH(attn_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)vt, key_mask,
                 (bf16*)out, lse, S, spad_of(S), H, G, scale, causal);
   } else {
-    dim3 grid(H, B, 1);
+    dim3 grid(H, B, (S + 63) / 64);
     TASU_LAUNCH(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)vt, key_mask,
                 (bf16*)out, lse, S, spad_of(S), H, G, scale, causal);
   }
