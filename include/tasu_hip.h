@@ -333,6 +333,16 @@ int tasu_fbank(const float* wave, int64_t n_samples, float scale, int win, int s
 int tasu_lfr_cmvn(const float* fb, int T, int D, int lfr_m, int lfr_n, const float* means, const float* scales, float* out,
                   void* stream);
 
+/* ------------------------------------------------------------------------------------------ FLAC (host)
+ * The reference reads ``.flac`` entries with torchaudio.load (speech_dataset_large.py:123-127: [C, T] float
+ * in [-1, 1), channel mean).  HOST functions (no device work, no stream): tasu_flac_info parses STREAMINFO
+ * (rate_channels_bps[3], total samples per channel); tasu_flac_decode decodes the whole stream into
+ * mono_out[capacity] = mean over channels of sample / 2^(bps-1), verifying every frame's CRC-8 / CRC-16 and the
+ * STREAMINFO MD5 of the decoded PCM.  Returns 0, 1 (bad argument / capacity too small) or 3 (corrupt or
+ * unsupported stream).  Restated from the published format; parity unpinned against libFLAC (absent).      */
+int tasu_flac_info(const uint8_t* data, int64_t n_bytes, int32_t* rate_channels_bps, int64_t* total_samples);
+int tasu_flac_decode(const uint8_t* data, int64_t n_bytes, float* mono_out, int64_t capacity, int64_t* n_decoded);
+
 #ifdef __cplusplus
 }
 #endif

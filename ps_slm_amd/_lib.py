@@ -74,6 +74,8 @@ PROTOTYPES = {
     "tasu_to_fragment_order": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "tasu_gemm_nt_bf16_splitk": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "tasu_sum_slabs_bf16": [vp, i32, i64, vp, i64, vp],
+    "tasu_flac_info": [vp, i64, vp, vp],
+    "tasu_flac_decode": [vp, i64, vp, i64, vp],
     "tasu_beam_update": [vp] * 21 + [i32] * 7 + [vp],
     "tasu_fbank": [vp, i64, f32, i32, i32, vp, vp, i32, f32, vp, vp],
     "tasu_lfr_cmvn": [vp, i32, i32, i32, i32, vp, vp, vp, vp],

@@ -72,8 +72,13 @@ def test_read_audio_wav_and_ark(tmp_path):
         w.writeframes(np.stack([fx.waveform_i16(1), fx.waveform_i16(1)], 1).tobytes())
     rate, y = ds_mod.read_audio(p)
     assert len(y) == fx.N_SAMPLES[1] and ds_mod.audio_num_samples(p) == fx.N_SAMPLES[1]
-    with pytest.raises(NotImplementedError):
-        ds_mod.read_audio("x.flac")
+    # .flac entries go through the native decoder (tests/test_flac_cpu.py); here: same samples as the wav of the same waveform
+    from flac_fixtures import write_flac
+    pf = tmp_path / "u1.flac"
+    pf.write_bytes(write_flac(fx.waveform_i16(1).astype(np.int64), rate=16000, bps=16, blocksize=1024))
+    rate, z = ds_mod.read_audio(str(pf))
+    assert rate == 16000 and np.array_equal(z, fx.waveform_i16(1).astype(np.float32) / 32768.0)
+    assert ds_mod.audio_num_samples(str(pf)) == fx.N_SAMPLES[1]
 
 
 def test_window_class_first_element_and_budget():
