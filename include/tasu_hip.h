@@ -149,9 +149,10 @@ int tasu_rmsnorm_bwd_rows(const void* dy_compact, const float* x, const float* w
 int tasu_rope_table(const int32_t* pos, float* cos_tab, float* sin_tab, int M, int head_dim, float theta,
                     void* stream);
 /* Rotate q and k heads of the fused qkv activation IN PLACE (rotate-half convention, modeling_qwen2.py:
- * 113-135, fp32 math, bf16 result) and emit the transposed copies the attention kernels stream:
+ * 113-135, fp32 math, bf16 result):
  *   qkv    [M, (H+2G)*128] bf16 : q heads | k heads | v heads
- *   qt     [B, H, 128, S], kt [B, G, 128, S], vt [B, G, 128, S]  (any of them may be NULL)                */
+ *   qt     [B, H, 128, S], kt [B, G, 128, S], vt [B, G, 128, S]: OPTIONAL transposed copies (NULL = not written; the
+ *   attention kernels no longer read them: since round 2 they transpose in LDS with ds_read_b64_tr_b16)       */
 int tasu_rope_fwd(void* qkv, const float* cos_tab, const float* sin_tab, void* qt, void* kt, void* vt,
                   int B, int S, int H, int G, void* stream);
 /* Autograd of the above on dqkv [M,(H+2G)*128]: the q block (dQ in rotated space, written by tasu_attn_bwd_dq)
@@ -168,7 +169,9 @@ int tasu_rope_bwd(void* dqkv, const float* dk_part, const float* dv_part, const 
  * causal = 0 gives the bidirectional SANM attention of the encoder (SenseVoice.py:171-207).              */
 int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key_mask, void* out, float* lse, int B, int S,
                   int H, int G, float scale, int causal, void* stream);
-/* Backward.  prep: delta[b,h,s] = sum_d dO.O and dOt [B,H,128,Spad];  dq: dQ (rotated space) into the q block
+/* The vt / kt / qt / dout_t arguments of the attention entry points are UNUSED since round 2 (pass NULL): the kernels read
+ * V^T, K^T, Q^T and dO^T out of the token-major tiles in LDS with the hardware transpose read.
+ * Backward.  prep: delta[b,h,s] = sum_d dO.O (and, only if dout_t != NULL, dOt [B,H,128,Spad]);  dq: dQ (rotated space) into the q block
  * of dqkv;  dkv: fp32 partials dk_part / dv_part [M, (H/HPB)*128] (no atomics; see TASU_ATTN_DKV_HPB).  Spad = S rounded up to 64; key_mask is [B, Spad] (pad = 0); lse/delta are
  * [B, H, Spad]; qt/kt/vt/dOt are [B, heads, 128, Spad] with zero token padding.                           */
 int tasu_attn_bwd_prep(const void* dout, const void* out, float* delta, void* dout_t, int B, int S, int H,

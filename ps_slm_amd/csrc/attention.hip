@@ -7,9 +7,11 @@
 // index of the NEXT product is what the accumulator registers enumerate.  A 16x16 score tile then feeds the
 // following MFMA as a register operand with no LDS round trip: the two 16-wide score tiles of a 32-deep
 // k-step are packed as k-slots {4q'+r | 16+4q'+r}, and the other operand is read from LDS in that same
-// permuted order (two 8-byte reads).  Operands whose reduced index is the token index are streamed from
-// pre-transposed [128, S] copies written by the RoPE / prep kernels, so every LDS tile is read along its
-// contiguous dimension with ds_read_b128 / ds_read_b64 and an XOR swizzle (no transposed LDS reads).
+// permuted order.  Operands whose reduced index is the TOKEN index (V^T for P.V, K^T for dQ, Q^T / dO^T for dK / dV)
+// come out of the SAME token-major LDS tile the row reads use, through gfx950's hardware transpose read
+// (ds_read_b64_tr_b16: a 16-lane group reads a 4-token x 16-d block and every lane receives one d column of it) --
+// round 1 streamed pre-transposed [128, S] global copies of Q, K, V and dO into extra LDS tiles instead, which doubled the
+// bytes a dK/dV block stages per step (64 KB) in a loop that is bound by exactly that staging latency.
 //
 // Tiles: 64 queries x 64 keys per step, 256 threads = 4 waves, each wave owns 16 of the 64 rows.
 #include <stdlib.h>
@@ -23,9 +25,7 @@ constexpr int HD = 128;
 
 // ---- LDS tile images ---------------------------------------------------------------------------------
 // "row" image : [64 tokens][128 d] bf16, 256-B rows, 16-B chunk c of row r stored at c ^ (r & 15)
-// "tr"  image : [128 d][64 tokens] bf16, 128-B rows, 16-B chunk c of row r stored at c ^ ((r >> 1) & 7)
 constexpr int ROW_TILE_BYTES = 64 * 256;
-constexpr int TR_TILE_BYTES = 128 * 128;
 
 // Tile staging is split (issue-early / write-late): fetch_* issues the 4 global loads of a tile into registers, the
 // MFMA work of the previous tile runs while they are in flight, and commit_* writes them to LDS after the barrier.
@@ -51,45 +51,30 @@ __device__ __forceinline__ void commit_row_tile(char* lds, const TileRegs& t) {
     *(bf16x8*)(lds + r * 256 + ((c ^ (r & 15)) << 4)) = t.v[i];
   }
 }
-// [128][64] tile (rows d, columns tokens tok0..tok0+63) of a [128, Spad] matrix -> "tr" image.
-__device__ __forceinline__ void fetch_tr_tile(TileRegs& t, const bf16* g, int spad, int tok0) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = i * 256 + threadIdx.x;
-    const int r = idx >> 3, c = idx & 7;
-    t.v[i] = *(const bf16x8*)(g + (size_t)r * spad + tok0 + c * 8);
-  }
-}
-__device__ __forceinline__ void commit_tr_tile(char* lds, const TileRegs& t) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = i * 256 + threadIdx.x;
-    const int r = idx >> 3, c = idx & 7;
-    *(bf16x8*)(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = t.v[i];
-  }
-}
 // MFMA operand (16 rows = tile rows sub*16 + (lane&15), k = d in [32ks + 8q', +8)) from a "row" image.
 __device__ __forceinline__ bf16x8 frag_row(const char* lds, int sub, int ks, int lane) {
   const int r = sub * 16 + (lane & 15);
   const int c = ks * 4 + (lane >> 4);
   return *(const bf16x8*)(lds + r * 256 + ((c ^ (lane & 15)) << 4));
 }
-// MFMA operand (16 rows = d in nt*16 + (lane&15), k-slots of token block tb (32 tokens):
-// element j <-> token tb*32 + (j<4 ? 4q'+j : 16+4q'+j-4)) from a "tr" image.
-__device__ __forceinline__ bf16x8 frag_tr(const char* lds, int nt, int tb, int lane) {
-  const int r = nt * 16 + (lane & 15);
-  const int qp = lane >> 4;
-  const int sw = (r >> 1) & 7;
-  const int t0 = tb * 32 + 4 * qp;  // first 4 tokens
-  const int t1 = t0 + 16;           // second 4 tokens
-  const bf16x4 lo = *(const bf16x4*)(lds + r * 128 + (((t0 >> 3) ^ sw) << 4) + (t0 & 7) * 2);
-  const bf16x4 hi = *(const bf16x4*)(lds + r * 128 + (((t1 >> 3) ^ sw) << 4) + (t1 & 7) * 2);
-  bf16x8 o;
-  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-  return o;
+// MFMA operand (16 rows = d in nt*16 + (lane&15), k-slots of token block tb (32 tokens): element j <-> token tb*32 + (j<4 ? 4q'+j :
+// 16+4q'+j-4), q' = lane>>4) read out of a token-major "row" image with two hardware transpose reads.  A 16-lane group g reads
+// the 4-token x 16-d block (tokens T0 + 4g .. +3, d = nt*16 .. +15): lane 4q+p of the group supplies the address of token
+// T0 + 4g + q, columns nt*16 + 4p .. +3, and lane i receives column nt*16 + i of the four tokens.  EXEC must be all ones.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 frag_tr_row(const char* lds, int nt, int tb, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int r0 = tb * 32 + 4 * g + q, r1 = r0 + 16;                 // this lane's address rows for the two reads
+  const int ch = nt * 2 + (p >> 1), inner = (p & 1) * 8;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + r0 * 256 + ((ch ^ (r0 & 15)) << 4) + inner));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + r1 * 256 + ((ch ^ (r1 & 15)) << 4) + inner));
+  union { s16x4 s[2]; bf16x8 b; } u;
+  u.s[0] = lo;
+  u.s[1] = hi;
+  return u.b;
 }
-// pack two 16-wide score tiles (fp32 accumulators) into the k-slot order frag_tr uses.
+// pack two 16-wide score tiles (fp32 accumulators) into the k-slot order frag_tr / frag_tr_row use.
 __device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
   bf16x8 o;
   o[0] = (bf16)a[0]; o[1] = (bf16)a[1]; o[2] = (bf16)a[2]; o[3] = (bf16)a[3];
@@ -114,9 +99,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
                                                           const uint8_t* __restrict__ kmask, bf16* __restrict__ out,
                                                           float* __restrict__ lse, int S, int Spad, int H, int G,
                                                           float scale, int causal) {
-  __shared__ __attribute__((aligned(16))) char smem[ROW_TILE_BYTES + TR_TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[2 * ROW_TILE_BYTES];
   char* sK = smem;
-  char* sVt = smem + ROW_TILE_BYTES;
+  char* sV = smem + ROW_TILE_BYTES;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // grid (H, B, query tiles): the late query tiles, which meet the most key tiles under the causal mask, are dispatched
   // first, so that a multi-round grid ends on the short ones
@@ -125,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   const int LD = (H + 2 * G) * HD;
   const bf16* qbase = qkv + (size_t)b * S * LD + h * HD;
   const bf16* kbase = qkv + (size_t)b * S * LD + (H + g) * HD;
-  const bf16* vtbase = vt + ((size_t)b * G + g) * HD * Spad;
+  const bf16* vbase = qkv + (size_t)b * S * LD + (H + G + g) * HD;
   const uint8_t* mrow = kmask + (size_t)b * Spad;
 
   const int q0 = qt * 64 * QW + wave * 16 * QW;        // first query of this wave
@@ -153,19 +138,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   TileRegs rK, rVt;
   uint32_t mk_next[4], mkw[4];                    // key-mask words of the tile, prefetched with it (no load -> use stall)
   fetch_row_tile(rK, kbase, LD, 0, S);
-  fetch_tr_tile(rVt, vtbase, Spad, 0);
+  fetch_row_tile(rVt, vbase, LD, 0, S);
 #pragma unroll
   for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + st * 16 + 4 * qp);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     commit_row_tile(sK, rK);
-    commit_tr_tile(sVt, rVt);
+    commit_row_tile(sV, rVt);
 #pragma unroll
     for (int st = 0; st < 4; ++st) mkw[st] = mk_next[st];
     __syncthreads();
     if (kt + 1 < nkt) {
       fetch_row_tile(rK, kbase, LD, (kt + 1) * 64, S);
-      fetch_tr_tile(rVt, vtbase, Spad, (kt + 1) * 64);
+      fetch_row_tile(rVt, vbase, LD, (kt + 1) * 64, S);
 #pragma unroll
       for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + (kt + 1) * 64 + st * 16 + 4 * qp);
     }
@@ -225,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     }
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      const bf16x8 v0 = frag_tr(sVt, nt, 0, lane), v1 = frag_tr(sVt, nt, 1, lane);   // read once, used by QW sub-tiles
+      const bf16x8 v0 = frag_tr_row(sV, nt, 0, lane), v1 = frag_tr_row(sV, nt, 1, lane);   // read once, used by QW sub-tiles
 #pragma unroll
       for (int u = 0; u < QW; ++u) {
         o[u][nt] = mfma16(v0, pf0[u], o[u][nt]);
@@ -280,6 +265,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16* __restri
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
   if (part == 0 && tok < S) delta[((size_t)b * H + h) * Spad + tok] = acc;
+  if (!dout_t) return;                                   // the backward kernels transpose in LDS (frag_tr_row): delta only
   __syncthreads();
   // transposed write: thread -> d = tid>>1, 32 tokens
   const int d = threadIdx.x >> 1, half = threadIdx.x & 1;
@@ -294,7 +280,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16* __restri
 }
 
 // =============================================================================== backward: dQ
-constexpr int DQ_LDS = 2 * ROW_TILE_BYTES + TR_TILE_BYTES;
+constexpr int DQ_LDS = 2 * ROW_TILE_BYTES;
 __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, const bf16* __restrict__ kt_g,
                                                  const uint8_t* __restrict__ kmask, const bf16* __restrict__ dout,
                                                  const float* __restrict__ lse, const float* __restrict__ delta,
@@ -302,7 +288,6 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, c
                                                  int causal, int bx, int by, int bz, char* smem) {
   char* sK = smem;
   char* sV = smem + ROW_TILE_BYTES;
-  char* sKt = smem + 2 * ROW_TILE_BYTES;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qt = bx, h = by, b = bz;
   const int g = h / (H / G);
@@ -310,7 +295,6 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, c
   const bf16* qbase = qkv + (size_t)b * S * LD + h * HD;
   const bf16* kbase = qkv + (size_t)b * S * LD + (H + g) * HD;
   const bf16* vbase = qkv + (size_t)b * S * LD + (H + G + g) * HD;
-  const bf16* ktbase = kt_g + ((size_t)b * G + g) * HD * Spad;
   const uint8_t* mrow = kmask + (size_t)b * Spad;
   const int qpos = qt * 64 + wave * 16 + (lane & 15);
   const int qc = min(qpos, S - 1);
@@ -326,25 +310,22 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, c
   for (int i = 0; i < 8; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = causal ? (qt + 1) : ((S + 63) >> 6);
-  TileRegs rK, rV, rKt;
+  TileRegs rK, rV;
   uint32_t mk_next[4], mkw[4];
   fetch_row_tile(rK, kbase, LD, 0, S);
   fetch_row_tile(rV, vbase, LD, 0, S);
-  fetch_tr_tile(rKt, ktbase, Spad, 0);
 #pragma unroll
   for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + st * 16 + 4 * qp);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     commit_row_tile(sK, rK);
     commit_row_tile(sV, rV);
-    commit_tr_tile(sKt, rKt);
 #pragma unroll
     for (int st = 0; st < 4; ++st) mkw[st] = mk_next[st];
     __syncthreads();
     if (kt + 1 < nkt) {
       fetch_row_tile(rK, kbase, LD, (kt + 1) * 64, S);
       fetch_row_tile(rV, vbase, LD, (kt + 1) * 64, S);
-      fetch_tr_tile(rKt, ktbase, Spad, (kt + 1) * 64);
 #pragma unroll
       for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + (kt + 1) * 64 + st * 16 + 4 * qp);
     }
@@ -372,8 +353,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, c
     const bf16x8 f1 = pack_pair(ds[2], ds[3]);
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      dq[nt] = mfma16(frag_tr(sKt, nt, 0, lane), f0, dq[nt]);
-      dq[nt] = mfma16(frag_tr(sKt, nt, 1, lane), f1, dq[nt]);
+      dq[nt] = mfma16(frag_tr_row(sK, nt, 0, lane), f0, dq[nt]);      // K^T out of the token-major K tile
+      dq[nt] = mfma16(frag_tr_row(sK, nt, 1, lane), f1, dq[nt]);
     }
   }
   if (qpos < S) {
@@ -391,7 +372,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, c
 // dK^T / dV^T accumulate in registers over the HPB heads x the (causal) query tiles, and only H/HPB fp32 partials
 // per kv head go to memory (HPB = TASU_ATTN_DKV_HPB(H/G): 3 for Qwen2.5-1.5B -> 2 partials per kv head; writing one
 // partial per QUERY head cost 50 MB of fp32 stores per call and dominated the kernel).  tasu_rope_bwd sums them.
-constexpr int DKV_LDS = 2 * ROW_TILE_BYTES + 2 * TR_TILE_BYTES + 128 * 4;   // 4 tiles + lse[64] + delta[64]
+constexpr int DKV_LDS = 2 * ROW_TILE_BYTES + 128 * 4;   // Q and dO tiles + lse[64] + delta[64]
 __device__ __forceinline__ void attn_bwd_dkv_body(const bf16* __restrict__ qkv, const bf16* __restrict__ qt_g,
                                                   const uint8_t* __restrict__ kmask, const bf16* __restrict__ dout,
                                                   const bf16* __restrict__ dout_t, const float* __restrict__ lse,
@@ -400,9 +381,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16* __restrict__ qkv, 
                                                   float scale, int causal, int bx, int by, int bz, char* smem) {
   char* sQ = smem;
   char* sdO = smem + ROW_TILE_BYTES;
-  char* sQt = smem + 2 * ROW_TILE_BYTES;
-  char* sdOt = smem + 2 * ROW_TILE_BYTES + TR_TILE_BYTES;
-  float* s_ld = (float*)(smem + 2 * ROW_TILE_BYTES + 2 * TR_TILE_BYTES);   // [0,64) lse, [64,128) delta of the q tile
+  float* s_ld = (float*)(smem + 2 * ROW_TILE_BYTES);   // [0,64) lse, [64,128) delta of the q tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ktile = bx, hg = by, b = bz;      // hg: index of the HPB-head group
   const int h0 = hg * hpb;
@@ -429,27 +408,23 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16* __restrict__ qkv, 
   const int per_head = nqt - q_first;
   const int n_it = per_head * hpb;                       // flattened (head, query tile) iteration space
   float r_ld = 0.f;                                      // threads 0..63: lse[q], 64..127: delta[q] of the fetched tile
-  auto fetch = [&](TileRegs& rQ, TileRegs& rdO, TileRegs& rQt, TileRegs& rdOt, int it) {
+  auto fetch = [&](TileRegs& rQ, TileRegs& rdO, int it) {
     const int h = h0 + it / per_head, qtile = q_first + it % per_head;
     fetch_row_tile(rQ, qkv + (size_t)b * S * LD + h * HD, LD, qtile * 64, S);
     fetch_row_tile(rdO, dout + (size_t)b * S * (H * HD) + h * HD, H * HD, qtile * 64, S);
-    fetch_tr_tile(rQt, qt_g + ((size_t)b * H + h) * HD * Spad, Spad, qtile * 64);
-    fetch_tr_tile(rdOt, dout_t + ((size_t)b * H + h) * HD * Spad, Spad, qtile * 64);
     if (threadIdx.x < 128)
       r_ld = (threadIdx.x < 64 ? lse : delta)[((size_t)b * H + h) * Spad + qtile * 64 + (threadIdx.x & 63)];
   };
-  TileRegs rQ, rdO, rQt, rdOt;
-  if (n_it > 0) fetch(rQ, rdO, rQt, rdOt, 0);
+  TileRegs rQ, rdO;
+  if (n_it > 0) fetch(rQ, rdO, 0);
   for (int it = 0; it < n_it; ++it) {
     const int qtile = q_first + it % per_head;
     __syncthreads();
     commit_row_tile(sQ, rQ);
     commit_row_tile(sdO, rdO);
-    commit_tr_tile(sQt, rQt);
-    commit_tr_tile(sdOt, rdOt);
     if (threadIdx.x < 128) s_ld[threadIdx.x] = r_ld;
     __syncthreads();
-    if (it + 1 < n_it) fetch(rQ, rdO, rQt, rdOt, it + 1);
+    if (it + 1 < n_it) fetch(rQ, rdO, it + 1);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {  // 32 query rows at a time keeps the live set small
       f32x4 pv[2], ds[2];
@@ -479,8 +454,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16* __restrict__ qkv, 
       const bf16x8 sf = pack_pair(ds[0], ds[1]);
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
-        dv[nt] = mfma16(frag_tr(sdOt, nt, qb, lane), pf, dv[nt]);
-        dk[nt] = mfma16(frag_tr(sQt, nt, qb, lane), sf, dk[nt]);
+        dv[nt] = mfma16(frag_tr_row(sdO, nt, qb, lane), pf, dv[nt]);     // dO^T, Q^T out of the token-major tiles
+        dk[nt] = mfma16(frag_tr_row(sQ, nt, qb, lane), sf, dk[nt]);
       }
     }
   }
@@ -549,7 +524,8 @@ static inline int spad_of(int S) { return (S + 63) & ~63; }
 
 extern "C" int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key_mask, void* out, float* lse, int B,
                              int S, int H, int G, float scale, int causal, void* stream) {
-  if (!qkv || !vt || !key_mask || !out || !lse || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
+  (void)vt;                                              // unused since round 2: V^T is read out of the V tile in LDS
+  if (!qkv || !key_mask || !out || !lse || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
   static const int qw2_from = [] { const char* e = getenv("TASU_ATTN_QW2_FROM"); return e ? atoi(e) : 1 << 30; }();
   if (S >= qw2_from) {
     // two query sub-tiles per wave (128-query blocks): half the LDS traffic per FLOP of the one-sub-tile form.  Measured at the
@@ -569,7 +545,7 @@ extern "C" int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key
 
 extern "C" int tasu_attn_bwd_prep(const void* dout, const void* out, float* delta, void* dout_t, int B, int S, int H,
                                   void* stream) {
-  if (!dout || !out || !delta || !dout_t || B <= 0 || S <= 0 || H <= 0) return TASU_ERR_ARG;
+  if (!dout || !out || !delta || B <= 0 || S <= 0 || H <= 0) return TASU_ERR_ARG;
   dim3 grid((S + 63) / 64, H, B);
   TASU_LAUNCH(attn_bwd_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dout,
                      (const bf16*)out, delta, (bf16*)dout_t, S, spad_of(S), H);
@@ -579,7 +555,7 @@ extern "C" int tasu_attn_bwd_prep(const void* dout, const void* out, float* delt
 extern "C" int tasu_attn_bwd_dq(const void* qkv, const void* kt, const uint8_t* key_mask, const void* dout,
                                 const float* lse, const float* delta, void* dqkv, int B, int S, int H, int G,
                                 float scale, int causal, void* stream) {
-  if (!qkv || !kt || !key_mask || !dout || !lse || !delta || !dqkv || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
+  if (!qkv || !key_mask || !dout || !lse || !delta || !dqkv || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
   dim3 grid((S + 63) / 64, H, B);
   TASU_LAUNCH(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)kt,
                      key_mask, (const bf16*)dout, lse, delta, (bf16*)dqkv, S, spad_of(S), H, G, scale, causal);
@@ -589,8 +565,7 @@ extern "C" int tasu_attn_bwd_dq(const void* qkv, const void* kt, const uint8_t* 
 extern "C" int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t* key_mask, const void* dout,
                                  const void* dout_t, const float* lse, const float* delta, float* dk_part,
                                  float* dv_part, int B, int S, int H, int G, float scale, int causal, void* stream) {
-  if (!qkv || !qt || !key_mask || !dout || !dout_t || !lse || !delta || !dk_part || !dv_part || bad_geo(B, S, H, G))
-    return TASU_ERR_ARG;
+  if (!qkv || !key_mask || !dout || !lse || !delta || !dk_part || !dv_part || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
   const int hpb = TASU_ATTN_DKV_HPB(H / G);
   dim3 grid((S + 63) / 64, H / hpb, B);
   static bool attr_set = false;
@@ -607,9 +582,7 @@ extern "C" int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t*
 extern "C" int tasu_attn_bwd(const void* qkv, const void* qt, const void* kt, const uint8_t* key_mask, const void* dout,
                              const void* dout_t, const float* lse, const float* delta, void* dqkv, float* dk_part,
                              float* dv_part, int B, int S, int H, int G, float scale, int causal, void* stream) {
-  if (!qkv || !qt || !kt || !key_mask || !dout || !dout_t || !lse || !delta || !dqkv || !dk_part || !dv_part ||
-      bad_geo(B, S, H, G))
-    return TASU_ERR_ARG;
+  if (!qkv || !key_mask || !dout || !lse || !delta || !dqkv || !dk_part || !dv_part || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
   const int hpb = TASU_ATTN_DKV_HPB(H / G);
   const int nt = (S + 63) / 64;
   static bool attr_set = false;

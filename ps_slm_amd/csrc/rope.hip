@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void rope_fwd_kernel(bf16* __restrict__ qkv, c
       *(bf16x8*)(row + 64 + part * 16) = b0;
       *(bf16x8*)(row + 64 + part * 16 + 8) = b1;
     }
+    if (!qt && !kt && !vt) return;                       // in-place rotation only (the attention kernels transpose in LDS)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       tile[tl][part * 16 + j] = a0[j];
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void rope_fwd_kernel(bf16* __restrict__ qkv, c
       tile[tl][64 + part * 16 + 8 + j] = b1[j];
     }
   } else {
+    if (!qt && !kt && !vt) return;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       tile[tl][part * 16 + j] = (bf16)0.f;
@@ -176,7 +178,8 @@ extern "C" int tasu_rope_table(const int32_t* pos, float* cos_tab, float* sin_ta
 extern "C" int tasu_rope_fwd(void* qkv, const float* cos_tab, const float* sin_tab, void* qt, void* kt, void* vt, int B,
                              int S, int H, int G, void* stream) {
   if (!qkv || !cos_tab || !sin_tab || B <= 0 || S <= 0 || H <= 0 || G <= 0) return TASU_ERR_ARG;
-  dim3 grid((S + 63) / 64, H + 2 * G, B);
+  // without transposed copies only the q and k heads have work (the v heads are not rotated)
+  dim3 grid((S + 63) / 64, (qt || kt || vt) ? H + 2 * G : H + G, B);
   TASU_LAUNCH(rope_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (bf16*)qkv, cos_tab, sin_tab, (bf16*)qt,
                      (bf16*)kt, (bf16*)vt, S, (S + 63) & ~63, H, G);
   return TASU_OK;

@@ -4,8 +4,7 @@ x*sqrt(d)+sinusoidal PE, 1 + 49 layers, after_norm, 20 tp layers, tp_norm) -> CT
 -> PSD (ps-slm.py:237-317).  Forward only (the encoder is frozen and its input needs no gradient).
 
 Per layer (SenseVoice.py:324-400, pre-norm, eval): LayerNorm fp32 -> fused q|k|v GEMM (bf16, K padded 560->576 for
-layer 0) -> bidirectional 4-head attention with key padding (tasu_attn_fwd, causal=0; V^T from tasu_rope_fwd with an
-identity rotation) -> linear_out GEMM fused with the residual add -> + FSMN memory (depthwise conv over time on
+layer 0) -> bidirectional 4-head attention with key padding (tasu_attn_fwd, causal=0) -> linear_out GEMM fused with the residual add -> + FSMN memory (depthwise conv over time on
 masked v, tasu_fsmn_fwd) -> LayerNorm -> FFN GEMM / ReLU / GEMM fused with the residual add.
 """
 import math
@@ -125,14 +124,9 @@ def _encoder_body(model, x0, lens, key_mask, B, T):
     buf = model._buf
     x = buf("enc_x", (M, Fd), f32)
     ops.sinusoid_pe(x0.view(M, Fd), x, B, Te, Fd, float(E) ** 0.5)
-    ident_c = buf("enc_cos1", (M, HD // 2), f32)
-    ident_s = buf("enc_sin0", (M, HD // 2), f32)
-    ident_c.fill_(1.0)
-    ident_s.zero_()
     zero_res = buf("enc_zero", (M, E), f32)
     zero_res.zero_()
     qkv = buf("enc_qkv", (M, 3 * E), bf)
-    vt = buf("enc_vt", (B * Hh * HD * Spad,), bf)
     ao = buf("enc_ao", (M, E), bf)
     lse = buf("enc_lse", (B * Hh * Spad,), f32)
     xa = buf("enc_xa", (M, E), f32)
@@ -149,8 +143,7 @@ def _encoder_body(model, x0, lens, key_mask, B, T):
         xn = buf("enc_xn", (M, w["kp"]), bf)
         ops.layernorm_fwd(cur, w["n1"][0], w["n1"][1], xn, None, None, M, w["in_dim"], 1e-5)
         ops.gemm(xn, w["wqkv"], qkv, M, 3 * E, w["kp"], bias=w["bqkv"])
-        ops.rope_fwd(qkv, ident_c, ident_s, None, None, vt, B, Te, Hh, Hh)      # identity rotation: only V^T is used
-        ops.attn_fwd(qkv, vt, key_mask, ao, lse, B, Te, Hh, Hh, scale, False)
+        ops.attn_fwd(qkv, None, key_mask, ao, lse, B, Te, Hh, Hh, scale, False)
         mid = xa if cur is not xa else xb
         resid = cur if w["in_dim"] == E else zero_res                           # no residual on layer 0 (:372-389)
         ops.gemm(ao, w["wout"], mid, M, E, E, bias=w["bout"], resid=resid, mode=GEMM_RESID)

@@ -19,7 +19,7 @@ HBM layout (sized for 288 GB: everything stays resident, nothing is recomputed):
   * embedding table fp32 (gather) + bf16 lm_head copies [V,D] and [D,Vpad].
   * projector parameters in ONE flat fp32 buffer (+ flat grad / m / v / bf16 working copy); the 25055-wide K
     dimension is padded to a multiple of 64 with zeros (pad columns provably stay zero under AdamW).
-  * per layer saved for backward: x_in, x_mid (fp32), rstd1/2, rotated qkv, Q^T/K^T, attention out, lse, gate|up.
+  * per layer saved for backward: x_in, x_mid (fp32), rstd1/2, rotated qkv, attention out, lse, gate|up.
 """
 import collections
 import math
@@ -515,9 +515,6 @@ class TasuModel:
         ops.rope_table(d["pos"], cos, sin, HD, geo.rope_theta)
         rstd = self._buf("rstd", (2 * L + 1, M), f32)
         qkv = self._buf("qkv", (L, M, LDQ), bf)
-        qt = self._buf("qt", (L, B * H * HD * Spad), bf)
-        kt = self._buf("kt", (L, B * G * HD * Spad), bf)
-        vt = self._buf("vt", (B * G * HD * Spad,), bf)
         ao = self._buf("ao", (L, M, H * HD), bf)
         lse = self._buf("lse", (L, B * H * Spad), f32)
         gu = self._buf("gu", (L, M, 2 * I), bf)
@@ -527,13 +524,13 @@ class TasuModel:
             x_in, x_mid, x_out = xs[2 * l], xs[2 * l + 1], xs[2 * l + 2]
             ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], geo.rms_eps)
             ops.gemm(xn, w["wqkv"], qkv[l], M, LDQ, D, bias=w["bqkv"])
-            ops.rope_fwd(qkv[l], cos, sin, qt[l], kt[l], vt, B, S, H, G)
-            ops.attn_fwd(qkv[l], vt, d["key_mask"], ao[l], lse[l], B, S, H, G, scale, True)
+            ops.rope_fwd(qkv[l], cos, sin, None, None, None, B, S, H, G)          # in place; no transposed copies (attention.hip)
+            ops.attn_fwd(qkv[l], None, d["key_mask"], ao[l], lse[l], B, S, H, G, scale, True)
             ops.gemm(ao[l], w["wo"], x_mid, M, D, H * HD, resid=x_in, mode=GEMM_RESID)
             ops.rmsnorm_fwd(x_mid, w["ln2"], xn, rstd[2 * l + 1], geo.rms_eps)
             ops.gemm_gate_up_swiglu(xn, w["wgu"], gu[l], act, M, I, D)          # gate|up projection + SwiGLU epilogue
             ops.gemm(act, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
-        d.update(xs=xs, cos=cos, sin=sin, rstd=rstd, qkv=qkv, qt=qt, kt=kt, ao=ao, lse=lse, gu=gu)
+        d.update(xs=xs, cos=cos, sin=sin, rstd=rstd, qkv=qkv, ao=ao, lse=lse, gu=gu)
         if logits_rows == "none":                              # decode prefill: the caller projects the last rows only
             return
         if compute_loss and need_backward and not self.keep_logits:
@@ -607,7 +604,6 @@ class TasuModel:
         dact = self._buf("dact", (M, I), bf)
         dgu = self._buf("dgu", (M, 2 * I), bf)
         dao = self._buf("dao", (M, H * HD), bf)
-        dao_t = self._buf("dao_t", (B * H * HD * Spad,), bf)
         delta = self._buf("delta", (B * H * Spad,), f32)
         dqkv = self._buf("dqkv", (M, LDQ), bf)
         dkp = self._buf("dkp", (M, H * HD), f32)
@@ -638,8 +634,8 @@ class TasuModel:
             ops.gemm(dgu, w["wgu_t"], dn, M, D, 2 * I)
             ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
             ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)
-            ops.attn_bwd_prep(dao, d["ao"][l], delta, dao_t, B, S, H)
-            ops.attn_bwd(d["qkv"][l], d["qt"][l], d["kt"][l], d["key_mask"], dao, dao_t, d["lse"][l], delta, dqkv, dkp, dvp,
+            ops.attn_bwd_prep(dao, d["ao"][l], delta, None, B, S, H)
+            ops.attn_bwd(d["qkv"][l], None, None, d["key_mask"], dao, None, d["lse"][l], delta, dqkv, dkp, dvp,
                          B, S, H, G, scale, True)                       # dQ and dK/dV blocks share one grid
             ops.rope_bwd(dqkv, dkp, dvp, cos, sin, B, S, H, G)
             ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)

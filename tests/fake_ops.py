@@ -184,9 +184,10 @@ class FakeOps:
         Spad = (S + 63) // 64 * 64
         d = dout.view(B, S, H, HD)
         delta.view(B, H, Spad)[..., :S] = (d.float() * out.view(B, S, H, HD).float()).sum(-1).permute(0, 2, 1)
-        t = dout_t.view(B, H, HD, Spad)
-        t.zero_()
-        t[..., :S] = d.permute(0, 2, 3, 1)
+        if dout_t is not None:
+            t = dout_t.view(B, H, HD, Spad)
+            t.zero_()
+            t[..., :S] = d.permute(0, 2, 3, 1)
 
     def _bwd_common(self, qkv, key_mask, dout, lse, delta, B, S, H, G, scale, causal):
         Spad = (S + 63) // 64 * 64
