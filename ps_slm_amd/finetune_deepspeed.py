@@ -235,6 +235,10 @@ def main(argv=None):
     # hipGraph replay of the forward/backward launch sequences pays when batch shapes repeat (fixed-length data, no CPS
     # drops); with dynamic batching or CPS drops every batch has its own shape, so it is off unless asked for
     model.core.use_graphs = str(cfg.get("use_graphs", False)).lower() in ("1", "true", "yes")
+    if model.core.use_graphs and str(cfg.get("graph_buckets", "16,8,256")).lower() not in ("", "none", "0"):
+        # shapes of real batches rarely repeat exactly: pad them to buckets (token columns, posterior rows, labelled rows) so that
+        # the LRU of captured step graphs gets hits (TasuModel.shape_buckets)
+        model.core.shape_buckets = tuple(int(v) for v in str(cfg.get("graph_buckets", "16,8,256")).split(","))
     dataset = get_dataset(dataset_config, tokenizer, "train", model.core.geo, rank,
                           steps=int(cfg.get("synthetic_steps", 20)), batch_size=int(cfg.get("synthetic_batch", 16)))
     eval_dataset = None

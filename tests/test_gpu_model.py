@@ -344,6 +344,35 @@ def test_graph_replay_matches_eager(setup):
     gm._graph_seen.clear()
 
 
+def test_bucketed_shapes_reuse_graphs(setup):
+    """Real data gives every batch its own shape; with TasuModel.shape_buckets three batches of different raw shapes fall into
+    one bucket, so the graphs captured on the second are replayed for the third -- and every bucketed, graph-replayed step
+    matches the eager step on the unpadded batch (loss to summation order, gradients to bf16 rounding of the padded GEMMs)."""
+    from ps_slm_amd.ops import HipOps
+    geo, sd, gm, _ = setup
+    bm = TasuModel(geo, HipOps(), "cuda")
+    bm.load_reference_state_dict(sd)
+    bm.use_graphs, bm.shape_buckets = True, (16, 8, 256)
+    gm.use_graphs = False
+    shapes = ((3, 21, 17), (4, 19, 17), (5, 20, 18), (6, 21, 16))
+    for i, (seed, n_audio, tl) in enumerate(shapes):
+        batch = synthetic_text_batch(geo, 3, seed=seed, prompt_len=9, n_audio=n_audio, target_len=tl, speech_pos=4, feat_frames=12,
+                                     noise=True, drop_prob=0.0, ragged=True)
+        outs = []
+        for m in (gm, bm):
+            st = m.prepare_text(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["post_ids"],
+                                batch.get("alphas"), batch.get("keeps"))
+            m.run_forward_text(st)
+            m.run_backward(st)
+            torch.cuda.synchronize()
+            outs.append((st.dev["loss_out"].clone(), m.proj.g.clone(), st.S))
+        (l0, g0, s0), (l1, g1, s1) = outs
+        assert s1 % 16 == 0 and 0 <= s1 - s0 < 16
+        assert abs(float(l0[0]) - float(l1[0])) < 1e-5 * float(l0[0]) + 1e-6 and float(l0[2]) == float(l1[2])
+        assert float((g0 - g1).norm() / g0.norm()) < 5e-3
+        assert len(bm._graphs) == (0 if i == 0 else 2)          # eager, captured, then replayed: one forward + one backward graph
+
+
 def test_encoder_graph_replay_matches_eager():
     """The SANM encoder's launch sequence replayed as a hipGraph: bit-identical CTC posterior, PSD lengths and loss for
     inputs that CHANGE between the capture and the replays (the uploads stay outside the captured region)."""

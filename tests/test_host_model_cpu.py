@@ -534,3 +534,22 @@ def test_linear_projector_step_matches_oracle_and_reference(k):
         ranges = sorted(model.grad_ranges(chunks))
         assert ranges[0][0] == 0 and ranges[-1][1] == model.proj.numel and len(ranges) == chunks + 1
         assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+
+
+def test_shape_buckets_pad_without_changing_the_step(mid):
+    """TasuModel.shape_buckets (graph reuse for real data): the batch is padded to the next multiple of (token columns, posterior
+    rows, labelled rows) with masked columns / zero rows / ignored labels; loss, accuracy, count and gradients are those of the
+    unpadded batch, and different raw shapes inside one bucket give the same step shapes."""
+    geo, sd = mid
+    plain, bucketed = build(geo, sd), build(geo, sd)
+    bucketed.shape_buckets = (16, 8, 256)
+    keys = set()
+    for seed, n_audio, tl in ((3, 21, 17), (4, 19, 17), (5, 20, 18)):
+        batch = synthetic_text_batch(geo, 3, seed=seed, prompt_len=9, n_audio=n_audio, target_len=tl, speech_pos=4, feat_frames=12,
+                                     noise=True, drop_prob=0.0, ragged=True)
+        sp, sb = run_text(plain, batch), run_text(bucketed, batch)
+        assert sb.S % 16 == 0 and sb.Ra % (3 * 8) == 0 and sb.nLp % 256 == 0 and sb.S >= sp.S and sb.S - sp.S < 16
+        keys.add(bucketed._shape_key(sb, "fwd"))
+        torch.testing.assert_close(sp.dev["loss_out"][:3], sb.dev["loss_out"][:3], rtol=1e-6, atol=1e-7)
+        assert float((plain.proj.g - bucketed.proj.g).norm() / plain.proj.g.norm()) < 5e-3
+    assert len(keys) == 1, keys
