@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 3
+#define TASU_ABI_VERSION 4
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -89,8 +89,9 @@ int tasu_gemm_skinny_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw,
  *   tasu_gemm_stream_swiglu    act = bf16(bf16(silu(g)) * u), g | u = A Wgu^T   (modeling_qwen2.py:41-48)
  *   tasu_gemm_stream_qkv_rope  qkv = rope(A Wqkv^T + bias), k and v appended to the cache at pos[m]  (:189-208, :91-135)
  *   tasu_gemm_stream_slabs     K split over workgroups (K = ksplit * {256..1792}: the down projection, 8960 = 5 x 1792):
- *                              fp32 partial tiles; tasu_stream_finish_norm adds them in order, then
- *                              C(fp32) = resid + bf16(sum) and y = rmsnorm(C, norm_w) for the next layer             */
+ *                              fp32 partial results, row-major [ksplit][64][N] (slab_floats >= ksplit * 64 * N);
+ *                              tasu_stream_finish_norm (N a multiple of 256, N / 256 in {1, 2, 6, 7}) adds them in order,
+ *                              then C(fp32) = resid + bf16(sum) and y = rmsnorm(C, norm_w) for the next layer       */
 int tasu_stream_supported(int K, int ksplit);
 /* a_frag / w_frag / out_frag / y_frag = 1: that operand is in FRAGMENT ORDER (the order mfma_f32_16x16x32_bf16 consumes it
  * in, so that every wave instruction reads 1 KiB contiguous instead of 16 rows x 64 B):
@@ -335,6 +336,50 @@ int tasu_fbank(const float* wave, int64_t n_samples, float scale, int win, int s
  * scales[m*D+k] for i < ceil(T / lfr_n); means may be NULL (no CMVN). */
 int tasu_lfr_cmvn(const float* fb, int T, int D, int lfr_m, int lfr_n, const float* means, const float* scales, float* out,
                   void* stream);
+
+/* ------------------------------------------------------------------------------------------ decode: the layer loop in one launch
+ * Replaces, for one generated position of <= 64 beam rows, the per-layer launch sequence of the decode step
+ * (reference: Multitask/model/ps-slm.py:660-675 -> HF GenerationMixin.beam_search -> Qwen2ForCausalLM.forward with
+ * past_key_values: q|k|v projection + RoPE + cache update, attention over the cache, o projection, post-attention
+ * RMSNorm, SwiGLU MLP, for each of the L decoder layers, then the final RMSNorm) by ONE persistent kernel: one workgroup
+ * per CU, the dependent steps of a layer separated by grid barriers (csrc/decode_mega.hip).  Same arithmetic, rounding
+ * points and summation orders as tasu_gemm_stream_qkv_rope / tasu_attn_decode / tasu_gemm_stream_bf16 (residual) /
+ * tasu_rmsnorm_fwd_frag / tasu_gemm_stream_swiglu / tasu_gemm_stream_slabs + tasu_stream_finish_norm launched one by one.
+ *
+ * layers: DEVICE array [L] of tasu_decode_layer; the bf16 weights in FRAGMENT ORDER (tasu_to_fragment_order: wqkv kind 3,
+ *   wo / wd kind 0, wgu kind 2), bqkv [(H + 2G) * 128] bf16 or NULL, ln1 / ln2 fp32 [D], kcache / vcache [M, ctx, G * 128].
+ * x0 [M, D] fp32: the embeddings of this position's tokens; final_norm [D] fp32.
+ * xn_out: fragment-order bf16 [D / 32][4][64][8] = the final-normed hidden state, lm_head's A operand (256-byte aligned).
+ * ws: tasu_decode_layers_ws_bytes(L, D, H, G, I) bytes, 256-byte aligned (a slice per layer: every intermediate is written
+ *   once per launch).  sync: tasu_decode_layers_sync_words() uint32 words, zeroed by the caller once (and again after an
+ *   error); sync[1] counts barrier time-outs (a workgroup of the grid was not resident): non-zero = the results of that
+ *   launch and all later ones are invalid.
+ * cos_tab / sin_tab [M, 64], slot [M] (cache position appended at), row_index [M, ctx] or NULL, kstart / lens [M]: as in
+ *   tasu_gemm_stream_qkv_rope and tasu_attn_decode.
+ * Supported (tasu_decode_layers_supported): M <= 64, H * 128 == D, (D, H / G, I) = (1536, 6, multiple of 1792 up to 8 x)
+ *   [Qwen2.5-1.5B] or (256, 2, multiple of 512) [the test geometry]; ctx <= 2048.  Other geometries keep the per-GEMM
+ *   launches. */
+typedef struct {
+  const void* wqkv;
+  const void* bqkv;
+  const void* wo;
+  const void* wgu;
+  const void* wd;
+  const float* ln1;
+  const float* ln2;
+  void* kcache;
+  void* vcache;
+} tasu_decode_layer;
+int tasu_decode_layers_supported(int M, int D, int H, int G, int I, int ctx);
+int64_t tasu_decode_layers_ws_bytes(int L, int D, int H, int G, int I);
+int tasu_decode_layers_sync_words(void);
+/* Debug: while a device buffer is set, every tasu_decode_layers launch records per workgroup the 100-MHz wall-clock tick at which
+ * it entered and left each grid barrier: [barrier][workgroup (CU count)][2] uint64, for as many barriers as fit. NULL clears. */
+int tasu_decode_layers_set_trace(uint64_t* device_buf, int64_t words);
+int tasu_decode_layers(const tasu_decode_layer* layers, int L, const float* x0, const float* final_norm, void* xn_out, void* ws,
+                       int64_t ws_bytes, uint32_t* sync, int M, int D, int H, int G, int I, const float* cos_tab,
+                       const float* sin_tab, const int32_t* slot, const int32_t* row_index, const int32_t* kstart,
+                       const int32_t* lens, int ctx, float eps, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------ FLAC (host)
  * The reference reads ``.flac`` entries with torchaudio.load (speech_dataset_large.py:123-127: [C, T] float

@@ -8,7 +8,7 @@ import os
 import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtasu_hip.so")
+LIB_PATH = os.environ.get("TASU_LIB_PATH") or os.path.join(_HERE, "libtasu_hip.so")     # (override: instrumented debug builds)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -80,9 +80,15 @@ PROTOTYPES = {
     "tasu_fbank": [vp, i64, f32, i32, i32, vp, vp, i32, f32, vp, vp],
     "tasu_lfr_cmvn": [vp, i32, i32, i32, i32, vp, vp, vp, vp],
     "tasu_embed_rows": [vp, vp, vp, i32, i32, vp],
+    "tasu_decode_layers_supported": [i32] * 6,
+    "tasu_decode_layers_ws_bytes": [i32] * 5,
+    "tasu_decode_layers_sync_words": [],
+    "tasu_decode_layers_set_trace": [vp, i64],
+    "tasu_decode_layers": [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp],
 }
+RESTYPE_I64 = {"tasu_decode_layers_ws_bytes"}
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 
@@ -105,7 +111,7 @@ def load():
         except AttributeError as e:
             raise TasuLibraryError(f"{LIB_PATH} does not export {name} (stale build?)") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name in RESTYPE_I64 else C.c_int
     if lib.tasu_abi_version() != ABI_VERSION:
         raise TasuLibraryError(f"ABI version mismatch: library {lib.tasu_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

@@ -2,6 +2,7 @@
 // fill / append / beam reorder, single-token GQA attention over the cache, and the per-row log-softmax + top-k that
 // feeds the beam bookkeeping.  All HBM-bound (weights and KV are read once per step).
 #include "common.h"
+#include "attn_decode_body.h"
 #include "../../include/tasu_hip.h"
 
 namespace {
@@ -91,20 +92,9 @@ __global__ __launch_bounds__(128) void kv_append_kernel(const bf16* __restrict__
   }
 }
 
-// Single-token GQA attention over the cache: one 8-wave block per (row, kv group); memory-bound (every K / V byte of the
-// row's cache is read once for all REP query heads of the group), so the design goal is wide loads and many of them in
-// flight, not arithmetic:
-//   phase 1  scores on the matrix cores: a wave takes 16 keys at a time; lane l loads 16 B of key (l & 15) for each of the
-//            four 32-wide slices of the head dimension, which is exactly the B operand of mfma_f32_16x16x32_bf16
-//            (B[k][n] = K[key n][dim k]); the A operand holds the REP query heads in rows 0..REP-1 (rows >= REP zero).
-//            4 MFMAs per 16 keys, no shuffles; scaled scores -> LDS [REP][ctx]
-//   phase 1b softmax statistics per head (wave h), probabilities (bf16-rounded like the prefill kernel) back to LDS
-//   phase 2  P.V: lane owns 8 dims (one 16-B load covers them, 16 lanes a whole 256-B V row, a wave instruction 4 keys)
-//            for all REP heads; 4 loads in flight; key quarters folded with two xor-shuffles, waves through LDS
-//   phase 3  cross-wave sum, 1/l, bf16 store
-// keys in [kstart[row], lens[row]) are visible.  ctx <= MAX_CTX.
-constexpr int MAX_CTX = 2048;
-constexpr int DEC_NW = 8;
+using tasu_attn_dec::DEC_NW;
+using tasu_attn_dec::MAX_CTX;
+// Single-token GQA attention over the cache: one 8-wave block per (row, kv group); body and design notes: attn_decode_body.h
 template <int REP>
 __global__ __launch_bounds__(64 * DEC_NW) void attn_decode_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ kc,
                                                                   const bf16* __restrict__ vc,
@@ -112,136 +102,9 @@ __global__ __launch_bounds__(64 * DEC_NW) void attn_decode_kernel(const bf16* __
                                                                   const int32_t* __restrict__ kstart,
                                                                   const int32_t* __restrict__ lens, bf16* __restrict__ out,
                                                                   int H, int G, int ctx, float scale, int out_frag) {
-  // [REP][ctx] scores | [DEC_NW][REP][128] partial outputs | [REP] 1/l | [ctx] physical cache row of every visible key
   extern __shared__ float sp[];
-  float* sc = sp;
-  float* part = sp + (size_t)REP * ctx;
-  float* linv = part + DEC_NW * REP * HD;
-  int* prow = (int*)(linv + REP + (REP & 1));
-  const int row = blockIdx.x, g = blockIdx.y;
-  const int W = G * HD, LD = (H + 2 * G) * HD;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k0 = kstart[row], nk = lens[row] - k0;
-  const int l15 = lane & 15, lq = lane >> 4;
-  for (int i = threadIdx.x; i < nk; i += 64 * DEC_NW) prow[i] = row_index ? row_index[(size_t)row * ctx + k0 + i] : row;
-  __syncthreads();
-  // ---- V prefetch: the first PRE_IT x UN value rows of this thread's phase-2 walk are requested NOW, so that their latency
-  // runs under phase 1 (K loads, score MFMAs) and the softmax instead of behind them (the phases are otherwise two dependent
-  // memory round trips); contexts up to PRE_IT * 128 keys are covered entirely
-  constexpr int UN = 4, PRE_IT = 3;
-  const bf16* vbase = vc + (size_t)k0 * W + g * HD + l15 * 8;
-  bf16x8 vpre[PRE_IT][UN];
-#pragma unroll
-  for (int it = 0; it < PRE_IT; ++it)
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int kcl = min(wave * 4 + it * (DEC_NW * 4 * UN) + u * DEC_NW * 4 + lq, nk - 1);
-      vpre[it][u] = *(const bf16x8*)(vbase + ((size_t)prow[kcl] * ctx + kcl) * W);
-    }
-  // ---- phase 1: scores
-  bf16x8 qf[4];
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) {
-    qf[s4] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (l15 < REP) qf[s4] = *(const bf16x8*)(qkv + (size_t)row * LD + (g * REP + l15) * HD + s4 * 32 + lq * 8);
-  }
-  const bf16* kbase = kc + (size_t)k0 * W + g * HD + lq * 8;
-  const int nchunk = (nk + 15) >> 4;
-  for (int c = wave; c < nchunk; c += DEC_NW) {
-    const int key = c * 16 + l15;
-    const int kcl = min(key, nk - 1);
-    const bf16* kp = kbase + ((size_t)prow[kcl] * ctx + kcl) * W;
-    bf16x8 kf[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) kf[s4] = *(const bf16x8*)(kp + s4 * 32);
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) acc = mfma16(qf[s4], kf[s4], acc);
-    // acc[r] = score(head lq*4 + r, key c*16 + l15)
-    if (key < nk) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (lq * 4 + r < REP) sc[(lq * 4 + r) * ctx + key] = acc[r] * scale;
-    }
-  }
-  __syncthreads();
-  // ---- phase 1b: softmax statistics of head h
-  for (int h = wave; h < REP; h += DEC_NW) {
-    float m = -__builtin_inff();
-    for (int i = lane; i < nk; i += 64) m = fmaxf(m, sc[h * ctx + i]);
-    m = wave_max(m);
-    float l = 0.f;
-    for (int i = lane; i < nk; i += 64) {
-      const float p = __expf(sc[h * ctx + i] - m);
-      sc[h * ctx + i] = (float)(bf16)p;
-      l += p;
-    }
-    l = wave_sum(l);
-    if (lane == 0) linv[h] = l > 0.f ? 1.f / l : 0.f;
-  }
-  __syncthreads();
-  // ---- phase 2: P.V   (lane: dims 8*l15 .. +7, key quarter lq; wave: keys wave*4 + lq, stride 32)
-  float o[REP][8];
-#pragma unroll
-  for (int h = 0; h < REP; ++h)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[h][j] = 0.f;
-  auto accumulate = [&](const bf16x8 (&v)[UN], int i0) {
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int key = i0 + u * DEC_NW * 4 + lq;
-      if (key < nk) {
-#pragma unroll
-        for (int h = 0; h < REP; ++h) {
-          const float p = sc[h * ctx + key];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[h][j] += p * (float)v[u][j];
-        }
-      }
-    }
-  };
-#pragma unroll
-  for (int it = 0; it < PRE_IT; ++it)
-    if (wave * 4 + it * (DEC_NW * 4 * UN) < nk) accumulate(vpre[it], wave * 4 + it * (DEC_NW * 4 * UN));
-  for (int i0 = wave * 4 + PRE_IT * (DEC_NW * 4 * UN); i0 < nk; i0 += DEC_NW * 4 * UN) {
-    bf16x8 v[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int kcl = min(i0 + u * DEC_NW * 4 + lq, nk - 1);
-      v[u] = *(const bf16x8*)(vbase + ((size_t)prow[kcl] * ctx + kcl) * W);
-    }
-    accumulate(v, i0);
-  }
-#pragma unroll
-  for (int h = 0; h < REP; ++h)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float x = o[h][j];
-      x += __shfl_xor(x, 16, 64);
-      x += __shfl_xor(x, 32, 64);
-      o[h][j] = x;
-    }
-  if (lq == 0) {
-#pragma unroll
-    for (int h = 0; h < REP; ++h) {
-      float* dst = part + ((wave * REP + h) * HD) + l15 * 8;
-      *(f32x4*)dst = f32x4{o[h][0], o[h][1], o[h][2], o[h][3]};
-      *(f32x4*)(dst + 4) = f32x4{o[h][4], o[h][5], o[h][6], o[h][7]};
-    }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < REP * HD; e += 64 * DEC_NW) {
-    const int h = e / HD, d = e - h * HD;
-    float s = 0.f;
-#pragma unroll
-    for (int w2 = 0; w2 < DEC_NW; ++w2) s += part[(w2 * REP + h) * HD + d];
-    const int n = (g * REP + h) * HD + d;                  // column of the [M, H * 128] attention output
-    // out_frag: the o projection's A operand in fragment order (csrc/gemm_stream.hip); row = row % 64 of its 64-row chunk
-    const size_t o = out_frag ? ((size_t)(row >> 6) * 64 * (H * HD)) +
-                                    ((((size_t)(n >> 5) * 4 + ((row & 63) >> 4)) * 64 + ((n & 31) >> 3) * 16 + (row & 15)) << 3) + (n & 7)
-                              : (size_t)row * (H * HD) + n;
-    out[o] = (bf16)(s * linv[h]);
-  }
+  tasu_attn_dec::attn_decode_body<REP, false>(sp, blockIdx.x, blockIdx.y, qkv, kc, vc, row_index, kstart, lens, out, H, G, ctx, scale,
+                                              out_frag);
 }
 
 // per row: lse over V columns, then the k best log-probs (value = logit - lse) with their column ids, descending;
@@ -403,7 +266,7 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------- beam bookkeeping
 // One generated position of HF ``generate(num_beams = nb, do_sample = False, early_stopping = False)`` (transformers
 // generation/utils.py ``_beam_search``; restated in oracle/tasu_oracle.py::beam_search_generate and, vectorised, in
-// ps_slm_amd/decode.py::BeamState, which this kernel reproduces decision for decision): thread b owns utterance b.
+// ps_slm_amd/decode.py::BeamState, which this kernel reproduces decision for decision): one wave per utterance.
 //   candidates  = per-row top-K log-probs (K = 2 nb) + the running score of their beam;
 //   top K       by (score desc, beam asc, token asc) -- the order of a flattened [nb * V] top-k;
 //   running     = the first nb candidates that neither are EOS nor reach max_new (their score otherwise + NEG);
@@ -441,10 +304,16 @@ struct BeamArgs {
   int B, nb, max_new, eos, min_length, S, first;
 };
 
-__global__ __launch_bounds__(256) void beam_update_kernel(BeamArgs p) {
+// One WAVE per utterance (16 utterances per pass of a 1024-thread block): lane c < nb * K holds candidate (beam c / K, k-th best
+// of that beam); every selection is a rank computed with wave shuffles -- rank = number of candidates that precede this one in
+// the (score desc, beam asc, token asc, index asc) order -- so there are no per-thread arrays and no serial scans (the first,
+// thread-per-utterance form of this kernel spent 88 us per position in scratch-memory loops).
+__global__ __launch_bounds__(1024) void beam_update_kernel(BeamArgs p) {
   __shared__ int s_unsat_any, s_stop_all;
-  const int b = threadIdx.x;
-  const int nb = p.nb, K = 2 * nb;
+  __shared__ float s_top_lp[16][2 * BEAM_MAX_NB];
+  __shared__ int s_top_tok[16][2 * BEAM_MAX_NB], s_top_beam[16][2 * BEAM_MAX_NB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = p.nb, K = 2 * nb, NC = nb * K;
   const int cur = p.ctl[0];
   if (p.ctl[1]) return;                                   // finished earlier: leave every output as it is
   if (threadIdx.x == 0) {
@@ -452,130 +321,119 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamArgs p) {
     s_stop_all = 1;
   }
   __syncthreads();
-  if (b < p.B) {
+  const float lp_now = p.len_pow[cur + 1];
+  for (int b = wave; b < p.B; b += 16) {                  // wave-uniform loop
     // ---- candidates
-    float cs[2 * BEAM_MAX_NB * BEAM_MAX_NB];
-    int ct[2 * BEAM_MAX_NB * BEAM_MAX_NB];
-    for (int j = 0; j < nb; ++j) {
-      const float rs = p.run_scores[b * nb + j];
-      for (int k = 0; k < K; ++k) {
-        float v = BEAM_NEG;
-        int t = 0;
-        if (!p.first || j == 0) {
-          const size_t row = p.first ? (size_t)b : (size_t)b * nb + j;
-          v = p.vals[row * K + k];
-          t = p.idx[row * K + k];
-        }
-        cs[j * K + k] = v + rs;
-        ct[j * K + k] = t;
+    const int j = lane / K, k = lane - j * K;
+    float cs = -__builtin_inff();
+    int ct = 0;
+    if (lane < NC) {
+      float v = BEAM_NEG;
+      if (!p.first || j == 0) {
+        const size_t row = p.first ? (size_t)b : (size_t)b * nb + j;
+        v = p.vals[row * K + k];
+        ct = p.idx[row * K + k];
       }
+      cs = v + p.run_scores[b * nb + j];
     }
-    // ---- top K by (score desc, beam asc, token asc)
-    float top_lp[2 * BEAM_MAX_NB];
-    int tok[2 * BEAM_MAX_NB], beam[2 * BEAM_MAX_NB];
-    unsigned long long used = 0ull;
-    for (int r = 0; r < K; ++r) {
-      int best = -1;
-      for (int c = 0; c < nb * K; ++c) {
-        if ((used >> c) & 1ull) continue;
-        if (best < 0) {
-          best = c;
-          continue;
-        }
-        const int bj = best / K, cj = c / K;
-        if (cs[c] > cs[best] || (cs[c] == cs[best] && (cj < bj || (cj == bj && ct[c] < ct[best])))) best = c;
-      }
-      used |= 1ull << best;
-      top_lp[r] = cs[best];
-      tok[r] = ct[best];
-      beam[r] = best / K;
+    // ---- top K by (score desc, beam asc, token asc, candidate index asc)
+    int rank = 0;
+    for (int d = 0; d < NC; ++d) {
+      const float sd = __shfl(cs, d, 64);
+      const int td = __shfl(ct, d, 64);
+      const int jd = d / K;
+      const bool before = sd > cs || (sd == cs && (jd < j || (jd == j && (td < ct || (td == ct && d < lane)))));
+      rank += before ? 1 : 0;
     }
-    // ---- running beams of the next step: stable top nb of run_lp
-    bool stop[2 * BEAM_MAX_NB];
-    float run_lp[2 * BEAM_MAX_NB];
-    bool all_stop = true;
-    for (int i = 0; i < K; ++i) {
-      stop[i] = tok[i] == p.eos || cur + 1 >= p.max_new;
-      all_stop = all_stop && stop[i];
-      run_lp[i] = top_lp[i] + (stop[i] ? BEAM_NEG : 0.f);
+    if (lane < NC && rank < K) {
+      s_top_lp[wave][rank] = cs;
+      s_top_tok[wave][rank] = ct;
+      s_top_beam[wave][rank] = j;
     }
-    unsigned taken = 0u;
-    float new_rs[BEAM_MAX_NB];
-    for (int n = 0; n < nb; ++n) {
-      int best = -1;
-      for (int i = 0; i < K; ++i) {
-        if ((taken >> i) & 1u) continue;
-        if (best < 0 || run_lp[i] > run_lp[best]) best = i;          // strict >: the earlier index wins ties (stable)
-      }
-      taken |= 1u << best;
-      new_rs[n] = run_lp[best];
-      const size_t o = ((size_t)cur * p.B + b) * nb + n;
-      p.bp_tok[o] = tok[best];
-      p.bp_par[o] = beam[best];
-      const int m = b * nb + n;
-      p.next_ids[m] = tok[best];
-      p.next_src[m] = b * nb + beam[best];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- lanes i < K: the K best in order
+    const bool is_top = lane < K;
+    const float top_lp = is_top ? s_top_lp[wave][lane] : 0.f;
+    const int tok = is_top ? s_top_tok[wave][lane] : 0, beam = is_top ? s_top_beam[wave][lane] : 0;
+    const bool stop = is_top && (tok == p.eos || cur + 1 >= p.max_new);
+    const float run_lp = is_top ? top_lp + (stop ? BEAM_NEG : 0.f) : -__builtin_inff();
+    const bool all_stop = __all(!is_top || stop);
+    // running beams of the next step: stable top nb of run_lp
+    int r_run = 0;
+    for (int d = 0; d < K; ++d) {
+      const float sd = __shfl(run_lp, d, 64);
+      r_run += (sd > run_lp || (sd == run_lp && d < lane)) ? 1 : 0;
+    }
+    const bool runs = is_top && r_run < nb;
+    if (runs) {
+      const size_t o = ((size_t)cur * p.B + b) * nb + r_run;
+      p.bp_tok[o] = tok;
+      p.bp_par[o] = beam;
+      const int m = b * nb + r_run;
+      p.next_ids[m] = tok;
+      p.next_src[m] = b * nb + beam;
       p.next_pos[m] = p.valid[b] + cur;
       p.next_slot[m] = p.S + cur;
       p.next_lens[m] = p.S + cur + 1;
     }
-    // ---- finished hypotheses: stable top nb of [kept | new]
+    const float best_run_lp = __shfl(run_lp, __ffsll((long long)__ballot(runs && r_run == 0)) - 1, 64);   // new running score of slot 0
+    // ---- finished hypotheses: stable top nb of [kept (lanes 0..nb-1) | new (lanes nb..nb+K-1)]
     const bool unsat = p.unsat[b] != 0;
-    float m_sc[3 * BEAM_MAX_NB];
-    int m_len[3 * BEAM_MAX_NB], m_par[3 * BEAM_MAX_NB], m_tok[3 * BEAM_MAX_NB], m_fin[3 * BEAM_MAX_NB];
-    for (int j = 0; j < nb; ++j) {
-      m_sc[j] = p.fin_scores[b * nb + j];
-      m_len[j] = p.fin_len[b * nb + j];
-      m_par[j] = p.fin_par[b * nb + j];
-      m_tok[j] = p.fin_tok[b * nb + j];
-      m_fin[j] = p.is_fin[b * nb + j];
-    }
-    const float lp_now = p.len_pow[cur + 1];
-    for (int i = 0; i < K; ++i) {
-      const bool just = stop[i] && i < nb;
-      float sc = top_lp[i] / lp_now;
-      sc = sc + (unsat ? 0.f : BEAM_NEG);
-      sc = sc + (just ? 0.f : BEAM_NEG);
-      m_sc[nb + i] = sc;
-      m_len[nb + i] = cur + 1;
-      m_par[nb + i] = beam[i];
-      m_tok[nb + i] = tok[i];
-      m_fin[nb + i] = just ? 1 : 0;
-    }
-    unsigned kept = 0u;
-    float f_sc[BEAM_MAX_NB];
-    int f_fin[BEAM_MAX_NB];
-    int order[BEAM_MAX_NB];
-    for (int n = 0; n < nb; ++n) {
-      int best = -1;
-      for (int i = 0; i < nb + K; ++i) {
-        if ((kept >> i) & 1u) continue;
-        if (best < 0 || m_sc[i] > m_sc[best]) best = i;
+    const bool is_old = lane < nb, is_new = lane >= nb && lane < nb + K;
+    const int src = lane - nb;                             // index into the K best for the new entries
+    float m_sc = -__builtin_inff();
+    int m_len = 0, m_par = 0, m_tok = 0, m_fin = 0;
+    {
+      // new entries read the top list through shuffles (lane src holds entry src)
+      const float t_lp = __shfl(top_lp, src < 0 ? 0 : src, 64);
+      const int t_tok = __shfl(tok, src < 0 ? 0 : src, 64), t_beam = __shfl(beam, src < 0 ? 0 : src, 64);
+      const int t_stop = __shfl((int)stop, src < 0 ? 0 : src, 64);
+      if (is_old) {
+        m_sc = p.fin_scores[b * nb + lane];
+        m_len = p.fin_len[b * nb + lane];
+        m_par = p.fin_par[b * nb + lane];
+        m_tok = p.fin_tok[b * nb + lane];
+        m_fin = p.is_fin[b * nb + lane];
+      } else if (is_new) {
+        const bool just = t_stop && src < nb;
+        float sc = t_lp / lp_now;
+        sc = sc + (unsat ? 0.f : BEAM_NEG);
+        sc = sc + (just ? 0.f : BEAM_NEG);
+        m_sc = sc;
+        m_len = cur + 1;
+        m_par = t_beam;
+        m_tok = t_tok;
+        m_fin = just ? 1 : 0;
       }
-      kept |= 1u << best;
-      order[n] = best;
-      f_sc[n] = m_sc[best];
-      f_fin[n] = m_fin[best];
     }
-    float min_fin = f_sc[0];
-    for (int n = 0; n < nb; ++n) {
-      const int i = order[n];
-      p.fin_scores[b * nb + n] = m_sc[i];
-      p.fin_len[b * nb + n] = m_len[i];
-      p.fin_par[b * nb + n] = m_par[i];
-      p.fin_tok[b * nb + n] = m_tok[i];
-      p.is_fin[b * nb + n] = m_fin[i];
-      p.run_scores[b * nb + n] = new_rs[n];
-      min_fin = fminf(min_fin, f_sc[n]);
+    int r_fin = 0;
+    for (int d = 0; d < nb + K; ++d) {
+      const float sd = __shfl(m_sc, d, 64);
+      r_fin += (sd > m_sc || (sd == m_sc && d < lane)) ? 1 : 0;
     }
+    const bool kept = (is_old || is_new) && r_fin < nb;
+    // every lane has read its old entry: the wave is converged here, so the writes below cannot overtake those reads
+    if (kept) {
+      p.fin_scores[b * nb + r_fin] = m_sc;
+      p.fin_len[b * nb + r_fin] = m_len;
+      p.fin_par[b * nb + r_fin] = m_par;
+      p.fin_tok[b * nb + r_fin] = m_tok;
+      p.is_fin[b * nb + r_fin] = m_fin;
+    }
+    if (runs) p.run_scores[b * nb + r_run] = run_lp;
     // ---- can a running beam still beat the worst kept hypothesis?
-    const float best_run = new_rs[0] / lp_now;           // the new cur is cur + 1: the same power
-    bool improve = false;
-    for (int n = 0; n < nb; ++n) improve = improve || best_run > (f_fin[n] ? min_fin : BEAM_NEG);
+    float min_fin = kept ? m_sc : __builtin_inff();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) min_fin = fminf(min_fin, __shfl_xor(min_fin, o, 64));
+    const float best_run = best_run_lp / lp_now;           // the new cur is cur + 1: the same power
+    const bool improve = __any(kept && best_run > (m_fin ? min_fin : BEAM_NEG));
     const bool still = unsat && improve;
-    p.unsat[b] = still ? 1 : 0;
-    if (still) atomicOr(&s_unsat_any, 1);
-    if (!all_stop) atomicAnd(&s_stop_all, 0);
+    if (lane == 0) {
+      p.unsat[b] = still ? 1 : 0;
+      if (still) atomicOr(&s_unsat_any, 1);
+      if (!all_stop) atomicAnd(&s_stop_all, 0);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -660,6 +518,11 @@ extern "C" int tasu_attn_decode(const void* qkv, const void* kcache, const void*
   }
 #undef DEC_CASE
 }
+#ifdef TASU_ATTN_TRACE
+extern "C" int tasu_attn_trace_read(uint64_t* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tasu_attn_dec::g_attn_trace), 16 * sizeof(uint64_t)) == hipSuccess ? 0 : 2;
+}
+#endif
 extern "C" int tasu_logprob_topk(const void* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned,
                                  float* out_val, int32_t* out_idx, float* workspace, int64_t workspace_floats, void* stream) {
   if (!logits || !out_val || !out_idx || !workspace || M <= 0 || V <= 0 || ld < V || ld % 8 || k <= 0 || k > TOPK_MAX ||
@@ -703,6 +566,6 @@ extern "C" int tasu_beam_update(const float* vals, const int32_t* idx, float* ru
   BeamArgs a{vals, idx, run_scores, fin_scores, fin_len, fin_par, fin_tok, is_fin, unsat, bp_tok, bp_par, len_pow, ctl,
              done_host, valid, next_ids, next_src, next_pos, next_slot, next_lens, banned, B, n_beams, max_new, eos,
              min_length, S, first};
-  TASU_LAUNCH(beam_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  TASU_LAUNCH(beam_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return TASU_OK;
 }

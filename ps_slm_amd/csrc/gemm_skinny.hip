@@ -278,6 +278,72 @@ __global__ __launch_bounds__(256) void skinny_reduce_norm_kernel(Args p, int til
   }
 }
 
+// The same finish with the row in registers (N <= 4096): every slab load of a thread is issued before the first sum (the loop
+// above waits for its loads four at a time: three dependent round trips at ksplit = 10), the norm weight and the residual
+// travel with them, and the second pass uses the registers instead of re-reading the thread's own store -- two memory round
+// trips instead of six (9.3 -> ~5.5 us per decode layer).  Same sums in the same order.
+template <int BN>
+__global__ __launch_bounds__(256) void skinny_reduce_norm_reg_kernel(Args p, int tiles, const float* __restrict__ nw,
+                                                                     bf16* __restrict__ y, float eps, int y_frag) {
+  constexpr int NI = BN / 16, TILE_F = 64 * BN, MAXG = 4, KC = 8;
+  __shared__ float red[4];
+  const int m = blockIdx.x;
+  const int wave_r = m >> 4, l15 = m & 15;
+  const int ngroups = p.N / 4;
+  float* crow = (float*)p.C + (size_t)m * p.ldc;
+  const float* rrow = p.R + (size_t)m * p.ldc;
+  f32x4 v[MAXG], w[MAXG], s[MAXG];
+  size_t e[MAXG];
+  bool on[MAXG];
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int g = threadIdx.x + i * 256;
+    on[i] = g < ngroups;
+    const int n = (on[i] ? g : 0) * 4, tn = n / BN, nin = n - tn * BN;
+    e[i] = (size_t)tn * TILE_F + ((wave_r * NI + (nin >> 4)) * 64 + ((nin & 15) >> 2) * 16 + l15) * 4;
+    s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    v[i] = on[i] ? *(const f32x4*)(rrow + n) : s[i];
+    w[i] = on[i] ? *(const f32x4*)(nw + n) : s[i];
+  }
+  for (int k0 = 0; k0 < p.ksplit; k0 += KC) {
+    f32x4 t[MAXG][KC];
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i)
+#pragma unroll
+      for (int j = 0; j < KC; ++j)
+        t[i][j] = on[i] && k0 + j < p.ksplit ? *(const f32x4*)(p.slab + (size_t)(k0 + j) * tiles * TILE_F + e[i])
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i)
+#pragma unroll
+      for (int j = 0; j < KC; ++j) s[i] += t[i][j];
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    if (on[i]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[i][q] = v[i][q] + bf16_round(s[i][q]);
+      *(f32x4*)(crow + (threadIdx.x + i * 256) * 4) = v[i];
+      ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+  }
+  ss = block_sum<4>(ss, red);
+  const float rs = rsqrtf(ss / (float)p.N + eps);
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    if (on[i]) {
+      const int n = (threadIdx.x + i * 256) * 4;
+      f32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = w[i][q] * (v[i][q] * rs);
+      bf16* dst = y_frag ? y + ((((size_t)(n >> 5) * 4 + (m >> 4)) * 64 + ((n & 31) >> 3) * 16 + (m & 15)) << 3) + (n & 7)
+                         : y + (size_t)m * p.N + n;
+      *(bf16x4*)dst = __builtin_convertvector(o, bf16x4);
+    }
+  }
+}
+
 // Row-wise finish of the split qkv projection of a decode step: block = row m; q|k|v[m, :] = bf16(sum of the slabs + bias),
 // RoPE on the H query and G key heads (tables [M, 64]), rotated row written to qkv[m, :] and its k and v appended to
 // cache[m, pos[m]] -- skinny_reduce + tasu_rope_append in one launch, same arithmetic and rounding points.
@@ -395,7 +461,9 @@ int launch(Args a, int tiles, hipStream_t st, NormArgs na = NormArgs()) {
   }
   TASU_LAUNCH((gemm_skinny_kernel<BN, SWIGLU>), dim3(tiles, a.ksplit), dim3(256), LDS, st, a);
   if (a.ksplit > 1) {
-    if (na.w)
+    if (na.w && a.N <= 4096)
+      TASU_LAUNCH((skinny_reduce_norm_reg_kernel<BN>), dim3(a.M), dim3(256), 0, st, a, tiles, na.w, na.y, na.eps, na.y_frag);
+    else if (na.w)
       TASU_LAUNCH((skinny_reduce_norm_kernel<BN>), dim3(a.M), dim3(256), 0, st, a, tiles, na.w, na.y, na.eps, na.y_frag);
     else if (na.cos)
       TASU_LAUNCH((skinny_reduce_rope_kernel<BN>), dim3(a.M), dim3(256), 0, st, a, tiles, na.cos, na.sin, na.kc, na.vc, na.pos,

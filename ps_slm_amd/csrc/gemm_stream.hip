@@ -33,247 +33,17 @@
 //     kernels (tasu_rmsnorm_fwd_frag, tasu_stream_finish_norm) and the cache attention (tasu_attn_decode_frag) -- and read
 //     with a_frag = 1: [K / 32][4 row tiles][64 lanes][8].
 // Row-major operands (a_frag = w_frag = 0) remain supported (tests, first use before the layouts are registered).
-#include "common.h"
+#include "stream_body.h"
 #include "../../include/tasu_hip.h"
 
 namespace tasu_stream {
 
-enum { E_BF16 = 0, E_RESID = 1, E_SWIGLU = 2, E_QKV = 3, E_SLAB = 4 };
-constexpr int NW = 8;                      // waves per workgroup
-
-struct Args {
-  const bf16* A;          // [M, lda] activations
-  const bf16* W;          // [*, ldw] weights, K contiguous
-  void* C;                // output (bf16 or fp32, see epilogues); E_SLAB: fp32 slabs [ksplit][tiles][16 x 64]
-  const float* R;         // E_RESID: residual [M, ldc] fp32
-  const bf16* bias;       // [N] or null
-  int M, N, K, lda, ldw, ldc;
-  int tiles;              // column tiles per K range
-  int I;                  // E_SWIGLU: first "up" row of W
-  int a_frag, w_frag;     // operands in fragment order (see the header comment)
-  int out_frag;           // E_SWIGLU: act is written in fragment order (K of its consumer = N)
-  // E_QKV
-  int H, G, ctx;
-  const float* cos_t;
-  const float* sin_t;
-  bf16* kc;
-  bf16* vc;
-  const int32_t* pos;
-};
-
-// first weight row (of 16) that lane group row r = l & 15 of tile t reads
-template <int EPI>
-__device__ __forceinline__ int weight_row(const Args& p, int t, int r) {
-  if (EPI == E_SWIGLU) return (r < 8 ? 0 : p.I) + t * 8 + (r & 7);
-  if (EPI == E_QKV) {
-    const int rot_tiles = (p.H + p.G) * 8;                 // q and k heads: 8 tiles of (8 + 8) paired columns each
-    if (t < rot_tiles) return (t >> 3) * 128 + (t & 7) * 8 + (r & 7) + (r >= 8 ? 64 : 0);
-    return (p.H + p.G) * 128 + (t - rot_tiles) * 16 + r;   // v heads: 16 plain columns
-  }
-  return t * 16 + r;
-}
-
-// MT = 16-row tiles of the activations a workgroup owns (4 = all 64 rows; 2 / 1: the rows are split over blockIdx.z, for GEMMs
-// with too few column tiles to occupy the chip -- a workgroup's traffic is its (MT * 16 + columns) x K operand bytes, and with
-// 1-2 column tiles per workgroup the 64 activation rows dominate it).
-// FRAG: both operands in fragment order (compile-time: a run-time layout test inside the load lambdas splits the ring loop
-// into branches across which the compiler drains vmcnt).
 template <int KS, int EPI, int MT, bool FRAG>
 __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_kernel(Args p) {
-  // partial tiles: [2 buffers][NW waves][MT row tiles][64 lanes] f32x4
-  __shared__ __attribute__((aligned(16))) float red[2][NW][MT][64][4];
-  const int mt0 = (int)blockIdx.z * MT;                 // first row tile of this workgroup
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l15 = lane & 15, lq = lane >> 4;
-  const int krange = NW * KS * 32;
-  const int k0 = blockIdx.y * krange + wave * (KS * 32) + lq * 8;      // this lane's first k of step 0
-
-  // ---- activations: this wave's K slice of all 64 rows, as MFMA B operands (rows beyond M are clamped; masked at the store)
-  bf16x8 a[MT][KS];
-  const int cg0 = ((int)blockIdx.y * NW + wave) * KS;                   // this wave's first global k-step
-  if (FRAG) {
-#pragma unroll
-    for (int c = 0; c < KS; ++c)
-#pragma unroll
-      for (int t = 0; t < MT; ++t) a[t][c] = *(const bf16x8*)(p.A + (((size_t)(cg0 + c) * 4 + mt0 + t) * 64 + lane) * 8);
-  } else {
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const bf16* ar = p.A + (size_t)min((mt0 + t) * 16 + l15, p.M - 1) * p.lda + k0;
-#pragma unroll
-      for (int c = 0; c < KS; ++c) a[t][c] = *(const bf16x8*)(ar + c * 32);
-    }
-  }
-
-  const int ntl = (p.tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles this workgroup walks
-  auto tile_of = [&](int i) { return (int)blockIdx.x + min(i, ntl - 1) * (int)gridDim.x; };   // clamped: loads past the end re-read
-  const int ksteps_all = p.K >> 5;
-  auto load_w = [&](bf16x8 (&w)[KS], int i) {
-    if (FRAG) {
-      const bf16* wr = p.W + (((size_t)tile_of(i) * ksteps_all + cg0) * 64 + lane) * 8;
-#pragma unroll
-      for (int c = 0; c < KS; ++c) w[c] = __builtin_nontemporal_load((const bf16x8*)(wr + c * 512));
-    } else {
-      const bf16* wr = p.W + (size_t)min(weight_row<EPI>(p, tile_of(i), l15), (EPI == E_SWIGLU ? 2 * p.I : p.N) - 1) * p.ldw + k0;
-#pragma unroll
-      for (int c = 0; c < KS; ++c) w[c] = __builtin_nontemporal_load((const bf16x8*)(wr + c * 32));
-    }
-  };
-
-  auto finish = [&](int i) {
-    // ---- cross-wave sum + epilogue of tile i (waves 0..MT-1: row tile = mt0 + wave); called after the barrier of tile i
-    if (wave >= MT || i >= ntl) return;
-    const int buf = i & 1, t = tile_of(i);
-    f32x4 s = *(const f32x4*)red[buf][0][wave][lane];
-#pragma unroll
-    for (int w2 = 1; w2 < NW; ++w2) s += *(const f32x4*)red[buf][w2][wave][lane];
-    const int rt = mt0 + wave;                           // row tile (0..3) of this wave's results
-    const int m = rt * 16 + l15;
-    // s[r] = C[m][tile column 4 * lq + r]
-    if (EPI == E_SLAB) {
-      float* slab = (float*)p.C + ((size_t)blockIdx.y * p.tiles + t) * 1024;     // [16 columns][64 rows]: fragment order
-      *(f32x4*)(slab + (rt * 64 + lane) * 4) = s;
-      return;
-    }
-    if (EPI == E_SWIGLU) {
-      // lanes lq < 2 hold gate columns t*8 + 4*lq + r, lanes lq + 2 the up values of the same columns
-      f32x4 u;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) u[r] = __shfl_xor(s[r], 32, 64);
-      if (lq < 2 && (m < p.M || p.out_frag)) {
-        const int n = t * 8 + 4 * lq;
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16)(bf16_round(silu_f(bf16_round(s[r]))) * bf16_round(u[r]));
-        if (p.out_frag) {
-          // element (m, n .. n+3) of the consumer's A operand: k-step n / 32, lane group (n % 32) / 8, row tile = wave
-          *(bf16x4*)((bf16*)p.C + ((((size_t)(n >> 5) * 4 + rt) * 64 + ((n & 31) >> 3) * 16 + l15) << 3) + (n & 7)) = o;
-        } else {
-          bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n;
-          if (n + 4 <= p.N) {
-            *(bf16x4*)dst = o;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < p.N) dst[r] = o[r];
-          }
-        }
-      }
-      return;
-    }
-    if (EPI == E_QKV) {
-      const int rot_tiles = (p.H + p.G) * 8;
-      const int W = p.G * 128;
-      bf16* out = (bf16*)p.C + (size_t)m * p.ldc;
-      if (t < rot_tiles) {
-        // lanes lq < 2: low-half columns c0 + 4*lq + r of head hh; lanes lq + 2: their partners (+64)
-        const int hh = t >> 3, c0 = (t & 7) * 8 + 4 * (lq & 1);
-        const int col = hh * 128 + c0 + (lq >= 2 ? 64 : 0);
-        bf16x4 mine;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mine[r] = (bf16)(s[r] + (p.bias ? (float)p.bias[col + r] : 0.f));
-        f32x4 x1, x2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float other = __shfl_xor((float)mine[r], 32, 64);
-          x1[r] = lq < 2 ? (float)mine[r] : other;       // low half
-          x2[r] = lq < 2 ? other : (float)mine[r];       // high half
-        }
-        if (m < p.M) {
-          const f32x4 cs = *(const f32x4*)(p.cos_t + (size_t)m * 64 + c0), sn = *(const f32x4*)(p.sin_t + (size_t)m * 64 + c0);
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16)(lq < 2 ? x1[r] * cs[r] - x2[r] * sn[r] : x2[r] * cs[r] + x1[r] * sn[r]);
-          *(bf16x4*)(out + col) = o;
-          if (hh >= p.H) {
-            const size_t slot = ((size_t)m * p.ctx + p.pos[m]) * W;
-            *(bf16x4*)(p.kc + slot + (hh - p.H) * 128 + c0 + (lq >= 2 ? 64 : 0)) = o;
-          }
-        }
-      } else if (m < p.M) {
-        const int c = (t - rot_tiles) * 16 + 4 * lq;           // column inside the v block
-        const int col = (p.H + p.G) * 128 + c;
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16)(s[r] + (p.bias ? (float)p.bias[col + r] : 0.f));
-        *(bf16x4*)(out + col) = o;
-        *(bf16x4*)(p.vc + ((size_t)m * p.ctx + p.pos[m]) * W + c) = o;
-      }
-      return;
-    }
-    // E_BF16 / E_RESID
-    const int n = t * 16 + 4 * lq;
-    if (m >= p.M || n >= p.N) return;
-    if (EPI == E_RESID) {
-      float* dst = (float*)p.C + (size_t)m * p.ldc + n;
-      const float* rs = p.R + (size_t)m * p.ldc + n;
-      if (n + 4 <= p.N) {
-        const f32x4 old = *(const f32x4*)rs;
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = old[r] + bf16_round(s[r]);
-        *(f32x4*)dst = o;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) dst[r] = rs[r] + bf16_round(s[r]);
-      }
-    } else {
-      bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n;
-      bf16x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (bf16)(s[r] + (p.bias && n + r < p.N ? (float)p.bias[n + r] : 0.f));
-      if (n + 4 <= p.N) {
-        *(bf16x4*)dst = o;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) dst[r] = o[r];
-      }
-    }
-  };
-
-  auto compute = [&](const bf16x8 (&w)[KS], int i) {
-    f32x4 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < KS; ++c)
-#pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t] = mfma16(w[c], a[t][c], acc[t]);
-    const int buf = i & 1;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) *(f32x4*)red[buf][wave][t][lane] = acc[t];
-    // my partial tile is in LDS; everybody's is after the barrier.  Raw s_barrier: the weight loads of the next tiles stay
-    // in flight across it (a __syncthreads() would drain vmcnt).  Buffer (i & 1) is written again at tile i + 2, which every
-    // wave reaches only after the barrier of tile i + 1, i.e. after all reads of tile i.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    finish(i);
-  };
-
-  bf16x8 w0[KS], w1[KS], w2[KS];
-  load_w(w0, 0);
-  if (ntl <= 2) {
-    // one or two tiles (the q|k|v, o and down projections): no ring, nothing loaded twice
-    if (ntl == 2) load_w(w1, 1);
-    compute(w0, 0);
-    if (ntl == 2) compute(w1, 1);
-    return;
-  }
-  // three tiles in flight per wave.  The body is branch-free (the trip count is rounded up to a multiple of three: the spare
-  // bodies re-read the last tile and skip their epilogue), so that the compiler's vmcnt bookkeeping sees one straight ring
-  // and waits for the oldest tile only.
-  load_w(w1, 1);
-  for (int i = 0; i < ntl; i += 3) {
-    load_w(w2, i + 2);
-    compute(w0, i);
-    load_w(w0, i + 3);
-    compute(w1, i + 1);
-    load_w(w1, i + 4);
-    compute(w2, i + 2);
-  }
+  __shared__ __attribute__((aligned(16))) float red[2 * NW * MT * 256];
+  int bx, by, bz;
+  if (!grid_position((int)blockIdx.x, p.gx, p.gy, p.gz, bx, by, bz)) return;
+  stream_gemm_body<KS, EPI, MT, FRAG, false>(p, red, bx, p.gx, by, bz);
 }
 
 int cu_count() {
@@ -289,7 +59,10 @@ int cu_count() {
 }
 
 template <int EPI, int MT, bool FRAG>
-int launch_ks(const Args& a, int ksplit, dim3 grid, hipStream_t st) {
+int launch_ks(Args a, int ksplit, dim3 grid3, hipStream_t st) {
+  a.gx = grid3.x, a.gy = grid3.y, a.gz = grid3.z;
+  const int per = 8 * a.gz;                              // whole groups of (8 XCDs x row splits): grid_position
+  const dim3 grid((a.gx * a.gy * a.gz + per - 1) / per * per);
   const int ks = a.K / ksplit / (NW * 32);
   switch (ks) {
     case 1: TASU_LAUNCH((stream_gemm_kernel<1, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
@@ -395,8 +168,8 @@ extern "C" int tasu_gemm_stream_qkv_rope(const void* A, int lda, const void* Wqk
   return launch<E_QKV>(a, 1, (hipStream_t)stream);
 }
 
-// K split over workgroups: fp32 partial tiles [ksplit][N/16][16 x 64] in `slabs` (fragment order: element ((w * 64 + l) * 4 + r)
-// of a tile = C[m = 16 w + (l & 15)][column 4 (l >> 4) + r]); tasu_stream_finish_norm sums them.
+// K split over workgroups: fp32 partial results, row-major [ksplit][64 rows][N] in `slabs` (rows >= M: unspecified);
+// tasu_stream_finish_norm sums them.
 extern "C" int tasu_gemm_stream_slabs(const void* A, int lda, const void* W, int ldw, float* slabs, int64_t slab_floats, int M,
                                       int N, int K, int ksplit, int a_frag, int w_frag, void* stream) {
   using namespace tasu_stream;
@@ -414,45 +187,13 @@ extern "C" int tasu_gemm_stream_slabs(const void* A, int lda, const void* W, int
 }
 
 namespace tasu_stream {
-// Row-wise finish of tasu_gemm_stream_slabs for a projection that feeds an RMSNorm (the down projection of a decode layer):
-// block = row m;  C[m, :] = R[m, :] + bf16(sum of the slabs in slab order);  y[m, :] = bf16(w * (C[m, :] * rstd)) -- the
-// arithmetic of gemm_skinny.hip's skinny_reduce_norm_kernel on this kernel's slab layout.  N % 16 == 0.
-__global__ __launch_bounds__(256) void stream_finish_norm_kernel(const float* __restrict__ slabs, int ksplit, int tiles,
-                                                                 float* __restrict__ C, const float* __restrict__ R, int N,
-                                                                 const float* __restrict__ nw, bf16* __restrict__ y, float eps,
-                                                                 int y_frag) {
-  __shared__ float red[4];
-  const int m = blockIdx.x;
-  const int row_tile = m >> 4, l15 = m & 15;
-  float* crow = C + (size_t)m * N;
-  const float* rrow = R + (size_t)m * N;
-  float ss = 0.f;
-  for (int g = threadIdx.x; g < N / 4; g += 256) {
-    const int n = g * 4, t = n >> 4, lq = (n & 15) >> 2;
-    const size_t e = (size_t)t * 1024 + ((row_tile * 64 + lq * 16 + l15) << 2);
-    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k = 0; k < ksplit; ++k) s += *(const f32x4*)(slabs + (size_t)k * tiles * 1024 + e);
-    const f32x4 r = *(const f32x4*)(rrow + n);
-    f32x4 v;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = r[q] + bf16_round(s[q]);
-    *(f32x4*)(crow + n) = v;
-    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-  }
-  ss = block_sum<4>(ss, red);
-  const float rs = rsqrtf(ss / (float)N + eps);
-  for (int g = threadIdx.x; g < N / 4; g += 256) {
-    const int n = g * 4;
-    const f32x4 v = *(const f32x4*)(crow + n);     // this thread's own store above
-    const f32x4 w = *(const f32x4*)(nw + n);
-    f32x4 o;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = w[q] * (v[q] * rs);
-    bf16* dst = y_frag ? y + ((((size_t)(n >> 5) * 4 + row_tile) * 64 + ((n & 31) >> 3) * 16 + l15) << 3) + (n & 7)
-                       : y + (size_t)m * N + n;
-    *(bf16x4*)dst = __builtin_convertvector(o, bf16x4);
-  }
+// Row-wise finish of tasu_gemm_stream_slabs (finish_norm_row, stream_body.h): one wave per row, 4 rows per block.
+template <int NG>
+__global__ __launch_bounds__(256) void stream_finish_norm_kernel(const float* __restrict__ slabs, int ksplit, float* __restrict__ C,
+                                                                 const float* __restrict__ R, int M, const float* __restrict__ nw,
+                                                                 bf16* __restrict__ y, float eps, int y_frag) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m < M) finish_norm_row<NG, false>(slabs, ksplit, C, R, nw, y, eps, y_frag, m);
 }
 
 // Re-lays a row-major weight matrix out in fragment order, one 16-row column tile at a time in the row order of the tile's
@@ -472,11 +213,19 @@ __global__ __launch_bounds__(256) void to_fragment_order_kernel(Args p, bf16* __
 
 extern "C" int tasu_stream_finish_norm(const float* slabs, int ksplit, float* C, const float* resid, int M, int N,
                                        const float* norm_w, void* y, float eps, int y_frag, void* stream) {
-  if (!slabs || !C || !resid || !norm_w || !y || ksplit < 1 || M <= 0 || M > 64 || N <= 0 || N % 16 || (y_frag && N % 32))
-    return TASU_ERR_ARG;
-  TASU_LAUNCH(tasu_stream::stream_finish_norm_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, slabs, ksplit, N / 16, C, resid, N,
-              norm_w, (bf16*)y, eps, y_frag);
-  return TASU_OK;
+  if (!slabs || !C || !resid || !norm_w || !y || ksplit < 1 || M <= 0 || M > 64 || N <= 0 || N % 256) return TASU_ERR_ARG;
+  const dim3 grid((M + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+#define TASU_FIN(NG)                                                                                                              \
+  case NG:                                                                                                                        \
+    TASU_LAUNCH(tasu_stream::stream_finish_norm_kernel<NG>, grid, dim3(256), 0, st, slabs, ksplit, C, resid, M, norm_w, (bf16*)y, \
+                eps, y_frag);                                                                                                     \
+    return TASU_OK;
+  switch (N / 256) {
+    TASU_FIN(1) TASU_FIN(2) TASU_FIN(6) TASU_FIN(7)
+    default: return TASU_ERR_ARG;
+  }
+#undef TASU_FIN
 }
 
 extern "C" int tasu_to_fragment_order(const void* W, int ldw, void* out, int kind, int N, int K, int H, int G, void* stream) {

@@ -65,9 +65,11 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __res
     return;
   }
   const float* xr = x + (size_t)srow * D + lane * 4;
-  f32x4 v[NG];
+  f32x4 v[NG], gw[NG];                // the norm weights travel with the row: one memory round trip before the stores
 #pragma unroll
   for (int g = 0; g < NG; ++g) v[g] = *(const f32x4*)(xr + g * 256);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) gw[g] = *(const f32x4*)(w + lane * 4 + g * 256);
   float ss = 0.f;
 #pragma unroll
   for (int g = 0; g < NG; ++g) ss += v[g][0] * v[g][0] + v[g][1] * v[g][1] + v[g][2] * v[g][2] + v[g][3] * v[g][3];
@@ -77,10 +79,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __res
   bf16* yr = y + (size_t)row * D + lane * 4;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    const f32x4 gw = *(const f32x4*)(w + lane * 4 + g * 256);
     f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = gw[j] * (v[g][j] * r);
+    for (int j = 0; j < 4; ++j) o[j] = gw[g][j] * (v[g][j] * r);
     *(bf16x4*)(frag ? y + frag_offset(row, lane * 4 + g * 256) : yr + g * 256) = __builtin_convertvector(o, bf16x4);
   }
 }

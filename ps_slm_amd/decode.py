@@ -170,6 +170,33 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
         ops.end_decode()
 
 
+def layers_per_gemm(ops, geo, layers, final_norm, x, x2, xn, qkv, ao, act, cos, sin, kc, vc, index, kstart, slot, lens, M, ctx, ws):
+    """One generated position through the decoder layers with one launch per GEMM (6-7 launches per layer): the path for more
+    than 64 beam rows and for geometries csrc/decode_mega.hip does not serve, and what the one-launch path is tested against.
+    In: x [M, D] fp32 (token embeddings); out: xn = the final-normed hidden state; K/V appended at ``slot``."""
+    D, I, H, G, L = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, len(layers)
+    W = G * HD
+    scale = HD ** -0.5
+    # the weight-streaming kernels take at most 64 rows: more beams than that (B > 16 at 4 beams) run them in row chunks
+    # (the weights are then streamed once per chunk; K/V, attention and top-k are not chunked)
+    chunks = [(m0, min(64, M - m0)) for m0 in range(0, M, 64)]
+    kcv, vcv = kc.view(L, M, ctx * W), vc.view(L, M, ctx * W)
+    for m0, mc in chunks:
+        ops.dec_rmsnorm(x[m0:m0 + mc], layers[0]["ln1"], xn[m0:m0 + mc], geo.rms_eps)
+    for l, w in enumerate(layers):
+        next_norm = layers[l + 1]["ln1"] if l + 1 < L else final_norm            # the norm that consumes this layer's output
+        for m0, mc in chunks:                                                    # qkv projection + bias + RoPE + cache append
+            r = slice(m0, m0 + mc)
+            ops.gemm_skinny_qkv_rope(xn[r], w["wqkv"], w["bqkv"], qkv[r], mc, H, G, D, cos[r], sin[r], kcv[l, r], vcv[l, r],
+                                     slot[r], ctx, ws)
+        ops.attn_decode(qkv, kc[l], vc[l], index, kstart, lens, ao, M, H, G, ctx, scale)
+        for m0, mc in chunks:                                                    # projections with residual + next norm fused
+            r = slice(m0, m0 + mc)
+            ops.gemm_skinny_norm(ao[r], w["wo"], x2[r], x[r], mc, D, H * HD, w["ln2"], xn[r], geo.rms_eps, ws)
+            ops.gemm_skinny_swiglu(xn[r], w["wgu"], act[r], mc, I, D, ws)
+            ops.gemm_skinny_norm(act[r], w["wd"], x[r], x2[r], mc, D, I, next_norm, xn[r], geo.rms_eps, ws)
+
+
 def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_penalty, eos, pad):
     ops, geo, llm = model.ops, model.geo, model.llm
     B, S = st.B, st.S
@@ -223,6 +250,16 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
     # (the weights are then streamed once per chunk; K/V, attention and top-k are not chunked).
     chunks = [(m0, min(64, M - m0)) for m0 in range(0, M, 64)]
     kcv, vcv = kc.view(L, M, ctx * W), vc.view(L, M, ctx * W)
+    # <= 64 rows at a geometry csrc/decode_mega.hip serves: the whole layer loop is ONE persistent launch per position
+    mega = bool(getattr(ops, "decode_layers_supported", None) and ops.decode_layers_supported(M, D, H, G, I, ctx))
+    if mega:
+        mega_ws = buf("dec_mega_ws", (ops.decode_layers_ws_bytes(L, D, H, G, I) + 256,), torch.uint8)
+        mega_ws = mega_ws[(-mega_ws.data_ptr()) % 256:]
+        table_key = (kc.data_ptr(), vc.data_ptr(), M, ctx, model._buf_gen)
+        if getattr(model, "_dec_table_key", None) != table_key:
+            model._dec_table = ops.decode_layer_table(llm.layers, kc, vc)
+            model._dec_table_key = table_key
+        table = model._dec_table
 
     def device_step():
         """One generated position for all M beams: beam reorder of the row index (parents of the previous step), then the
@@ -231,24 +268,19 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
         ops.kv_index_reorder(index_tmp, index, None, slot_d, M, ctx)
         ops.embed_rows(llm.embed, ids_d, x, M, D)
         ops.rope_table(pos_d, cos, sin, HD, geo.rope_theta)
-        for m0, mc in chunks:
-            ops.dec_rmsnorm(x[m0:m0 + mc], llm.layers[0]["ln1"], xn[m0:m0 + mc], geo.rms_eps)
-        for l, w in enumerate(llm.layers):
-            next_norm = llm.layers[l + 1]["ln1"] if l + 1 < L else llm.norm      # the norm that consumes this layer's output
-            for m0, mc in chunks:                                                # qkv projection + bias + RoPE + cache append
-                r = slice(m0, m0 + mc)
-                ops.gemm_skinny_qkv_rope(xn[r], w["wqkv"], w["bqkv"], qkv[r], mc, H, G, D, cos[r], sin[r], kcv[l, r], vcv[l, r],
-                                         slot_d[r], ctx, ws)
-            ops.attn_decode(qkv, kc[l], vc[l], index, kstart, lens_d, ao, M, H, G, ctx, scale)
-            for m0, mc in chunks:                                                # projections with residual + next norm fused
-                r = slice(m0, m0 + mc)
-                ops.gemm_skinny_norm(ao[r], w["wo"], x2[r], x[r], mc, D, H * HD, w["ln2"], xn[r], geo.rms_eps, ws)
-                ops.gemm_skinny_swiglu(xn[r], w["wgu"], act[r], mc, I, D, ws)
-                ops.gemm_skinny_norm(act[r], w["wd"], x[r], x2[r], mc, D, I, next_norm, xn[r], geo.rms_eps, ws)
+        if mega:
+            ops.decode_layers(table, L, x, llm.norm, xn, mega_ws, M, D, H, G, I, cos, sin, slot_d, index, kstart, lens_d, ctx,
+                              geo.rms_eps, scale)
+        else:
+            per_gemm_layers()
         for m0, mc in chunks:
             ops.gemm_skinny(xn[m0:m0 + mc], llm.head, logits[m0:m0 + mc], mc, V, D, ws)
         ops.logprob_topk(logits, M, V, K, bs.banned, 1, tv, ti)
         ops.beam_update(tv, ti, bs, False)
+
+    def per_gemm_layers():
+        layers_per_gemm(ops, geo, llm.layers, llm.norm, x, x2, xn, qkv, ao, act, cos, sin, kc, vc, index, kstart, slot_d, lens_d,
+                        M, ctx, ws)
 
     # hipGraph replay of device_step (~430 launches): the first step of a shape runs eagerly, the second is captured.
     # A graph is only valid for the buffers it was captured on (grow-only workspace: same generation = same addresses) and
@@ -256,7 +288,7 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
     # own prompt length).
     use_graphs = model.decode_graphs and model.device.type == "cuda"
     graphs, seen_cnt = model._dec_graphs, model._dec_seen
-    key = ("decode", B, S, nb, ctx, max_new_tokens, int(eos), int(min_length), model._buf_gen)
+    key = ("decode", B, S, nb, ctx, max_new_tokens, int(eos), int(min_length), mega, model._buf_gen)
 
     def run_step():
         if not use_graphs:
@@ -296,6 +328,8 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
                 if int(bs.done_host[0]):
                     break
         torch.cuda.synchronize()
+        if mega:
+            ops.decode_layers_check()
     else:
         while not int(bs.ctl[1]):
             run_step()

@@ -42,6 +42,12 @@ class HipOps:
         self.dec_frag_act = False      # ... including the MLP activation that feeds the down projection
         self.dec_down_slabs = False
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
+        # the decode step's layer loop as one persistent launch (csrc/decode_mega.hip).  EXPERIMENTAL, off by default: parity-green
+        # (bit-identical to the per-GEMM launches, tests/test_gpu_decode_mega.py) but slower on MI355X -- 2.7 vs 2.0 ms per
+        # position at 1.5B: a phase costs the same memory round trips as the kernel it replaces and the 1.5-us grid barrier
+        # buys nothing over a hipGraph launch.  TASU_DECODE_MEGA=1 selects it (A/B runs).
+        self.use_mega = os.environ.get("TASU_DECODE_MEGA", "0") == "1"
+        self._mega_sync = None
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -89,11 +95,11 @@ class HipOps:
         output, MLP activation) travel between its kernels in FRAGMENT ORDER (include/tasu_hip.h) -- possible when the
         streaming kernels serve every GEMM of the layer.  Returns that decision."""
         self.dec_frag = bool(self._stream_split(D) == 1 and self._stream_split(HHD) == 1 and D % 32 == 0 and HHD % 32 == 0)
-        # the MLP activation (the down projection's input): fragment order only when the down projection itself runs on the
-        # streaming kernels in ONE K range.  A K too long for that (8960 = 5 x 1792) stays on the split-K kernels of
-        # gemm_skinny.hip, whose 64 x 64 x K/10 blocks move fewer operand bytes per CU than 5 K-range slabs do
-        # (measured at 1.5B: 18.8 us against 23.0 us per layer); TASU_DECODE_DOWN_SLABS=1 forces the slabs (A/B runs).
-        self.dec_down_slabs = os.environ.get("TASU_DECODE_DOWN_SLABS", "0") == "1"
+        # the MLP activation (the down projection's input): fragment order when the down projection runs on the streaming
+        # kernels -- in one K range, or (K = 8960 = 5 x 1792) as K-range slabs + tasu_stream_finish_norm.  The slabs are the
+        # default since the two row halves of a K range share an XCD's L2 and the slabs are row-major (1.89 vs 2.0 ms per
+        # position at 1.5B against the split-K kernels of gemm_skinny.hip); TASU_DECODE_DOWN_SLABS=0 selects the latter (A/B).
+        self.dec_down_slabs = os.environ.get("TASU_DECODE_DOWN_SLABS", "1") != "0"
         ks_down = self._stream_split(I)
         self.dec_frag_act = bool(self.dec_frag and I % 32 == 0 and (ks_down == 1 or (ks_down > 1 and self.dec_down_slabs)))
         return self.dec_frag
@@ -338,6 +344,45 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_skinny_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), M, I, K,
                                                    _p(ws), 0 if ws is None else ws.numel(), self._stream()),
                   "tasu_gemm_skinny_swiglu")
+
+    # ------------------------------------------------------------------ decode: the layer loop in one launch
+    def decode_layers_supported(self, M, D, H, G, I, ctx):
+        """True when tasu_decode_layers serves this decode (and the fragment-order weights it needs are registered)."""
+        return bool(self.use_mega and self.use_stream and self.dec_frag
+                    and self.lib.tasu_decode_layers_supported(M, D, H, G, I, ctx))
+
+    def decode_layers_ws_bytes(self, L, D, H, G, I):
+        return int(self.lib.tasu_decode_layers_ws_bytes(L, D, H, G, I))
+
+    def decode_layer_table(self, layers, kc, vc):
+        """Device array of tasu_decode_layer (include/tasu_hip.h) for the L decoder layers: fragment-order weight copies
+        (register_decode_weight), norms, and the layer's K / V cache."""
+        rows = []
+        for l, w in enumerate(layers):
+            frag = [self._frag[w[k].data_ptr()][0].data_ptr() for k in ("wqkv", "wo", "wgu", "wd")]
+            rows.append([frag[0], w["bqkv"].data_ptr(), frag[1], frag[2], frag[3], w["ln1"].data_ptr(), w["ln2"].data_ptr(),
+                         kc[l].data_ptr(), vc[l].data_ptr()])
+        return torch.tensor(rows, dtype=torch.int64).cuda()
+
+    def decode_layers(self, table, L, x0, final_norm, xn_out, ws, M, D, H, G, I, cos, sin, slot, index, kstart, lens, ctx, eps,
+                      scale):
+        """One generated position through all L decoder layers + the final norm in ONE launch (tasu_decode_layers)."""
+        if self._mega_sync is None:
+            self._mega_sync = torch.zeros(self.lib.tasu_decode_layers_sync_words(), dtype=torch.int32, device="cuda")
+        self._chk(self.lib.tasu_decode_layers(_p(table), L, _p(x0), _p(final_norm), _p(xn_out), _p(ws), ws.numel() * ws.element_size(),
+                                              _p(self._mega_sync), M, D, H, G, I, _p(cos), _p(sin), _p(slot), _p(index), _p(kstart),
+                                              _p(lens), ctx, eps, scale, self._stream()), "tasu_decode_layers")
+
+    def decode_layers_check(self):
+        """Raises if a grid barrier of tasu_decode_layers timed out since the last check (its results are then invalid); the
+        barrier state is reset.  Synchronises: call after a generate(), not per position."""
+        if self._mega_sync is None:
+            return
+        n = int(self._mega_sync[1])
+        if n:
+            self._mega_sync.zero_()
+            raise TasuOpError(f"tasu_decode_layers: {n} grid-barrier time-outs (a workgroup of the persistent grid was not "
+                              f"resident); the decode results are invalid.  TASU_DECODE_MEGA=0 selects the per-GEMM launches.")
 
     def rope_append(self, qkv, cos, sin, kc, vc, pos, M, H, G, ctx):
         self._chk(self.lib.tasu_rope_append(_p(qkv), _p(cos), _p(sin), _p(kc), _p(vc), _p(pos), M, H, G, ctx, self._stream()),

@@ -10,7 +10,7 @@ from conftest import ROOT
 def header_functions():
     txt = open(os.path.join(ROOT, "include", "tasu_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return {m.group(1): m.group(2) for m in re.finditer(r"\bint\s+(tasu_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S)}
+    return {m.group(1): m.group(2) for m in re.finditer(r"\bint(?:64_t)?\s+(tasu_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S)}
 
 
 def test_every_declared_symbol_is_exported_and_bound():

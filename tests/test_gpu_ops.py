@@ -24,9 +24,9 @@ def hip():
 def hip_both(hip, request):
     """The decode-step GEMM ops on both kernel families: the single-launch streaming kernels (csrc/gemm_stream.hip, where they
     serve the shape) and the split-K + finish kernels (csrc/gemm_skinny.hip)."""
-    hip.use_stream = hip.dec_down_slabs = request.param == "stream"     # K-range slabs for K = 8960 too (off by default)
+    hip.use_stream = hip.dec_down_slabs = request.param == "stream"     # K-range slabs for K = 8960 / the split-K kernels
     yield hip
-    hip.use_stream, hip.dec_down_slabs = True, False
+    hip.use_stream, hip.dec_down_slabs = True, True
 
 
 @pytest.fixture(scope="module")
