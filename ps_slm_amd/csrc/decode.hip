@@ -120,10 +120,8 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
                                                         float* __restrict__ pm, float* __restrict__ ps,
                                                         float* __restrict__ pv, int32_t* __restrict__ pi) {
   __shared__ float red[4];
-  __shared__ float cv[256 * K];
-  __shared__ int ci[256 * K];
-  __shared__ float bestv[4];
-  __shared__ int besti[4], bestslot[4];
+  __shared__ float cv[4 * K];
+  __shared__ int ci[4 * K];
   const int row = blockIdx.x, part = blockIdx.y;
   const bf16* lr = logits + (size_t)row * ld;
   float tv[K];
@@ -137,8 +135,27 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
   const int nv = (V + 7) / 8;
   const int per = (nv + TOPK_PARTS - 1) / TOPK_PARTS;
   const int v0 = part * per, v1 = min(nv, v0 + per);
+  // a thread's chunks are loaded ONCE, all loads in flight together (two dependent passes over global memory, five
+  // sequential loads each, were most of this kernel's time); parts longer than 256 * MAXC chunks take the loop below too
+  constexpr int MAXC = 6;
+  bf16x8 xs[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cv8 = v0 + threadIdx.x + i * 256;
+    xs[i] = cv8 < v1 ? *(const bf16x8*)(lr + cv8 * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  const int vreg = min(v1, v0 + 256 * MAXC);      // chunks [v0, vreg) live in registers
   float m = -__builtin_inff();
-  for (int cv8 = v0 + threadIdx.x; cv8 < v1; cv8 += 256) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cv8 = v0 + threadIdx.x + i * 256;
+    if (cv8 < vreg) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (cv8 * 8 + j < V) m = fmaxf(m, (float)xs[i][j]);
+    }
+  }
+  for (int cv8 = vreg + threadIdx.x; cv8 < v1; cv8 += 256) {
     const bf16x8 x = *(const bf16x8*)(lr + cv8 * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -146,8 +163,7 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
   }
   m = block_max<4>(m, red);
   float s = 0.f;
-  for (int cv8 = v0 + threadIdx.x; cv8 < v1; cv8 += 256) {
-    const bf16x8 x = *(const bf16x8*)(lr + cv8 * 8);
+  auto visit = [&](const bf16x8& x, int cv8) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = cv8 * 8 + j;
@@ -174,56 +190,68 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
         }
       }
     }
+  };
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cv8 = v0 + threadIdx.x + i * 256;
+    if (cv8 < vreg) visit(xs[i], cv8);
   }
+  for (int cv8 = vreg + threadIdx.x; cv8 < v1; cv8 += 256) visit(*(const bf16x8*)(lr + cv8 * 8), cv8);
   s = block_sum<4>(s, red);
   const size_t slot0 = (size_t)row * TOPK_PARTS + part;
   if (threadIdx.x == 0) {
     pm[slot0] = m;
     ps[slot0] = s;
   }
+  // Selection without block-wide rounds (K rounds of block argmax with two barriers each were 30 of this kernel's 38 us):
+  //   each WAVE merges its 64 sorted lists by K rounds of wave argmax over the list heads (shuffles only; the winner shifts
+  //   its register list up), leaving the wave's K best, sorted; the four waves' 4 K candidates then meet in LDS and wave 0
+  //   ranks them (rank = number of candidates ahead in the (value desc, column asc) order).
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
-    cv[threadIdx.x * K + j] = tv[j];
-    ci[threadIdx.x * K + j] = ti[j];
-  }
-  __syncthreads();
-  // K rounds of block-wide argmax over the 256 list heads (each list is sorted, so only heads compete)
-  int head = 0;                                   // this thread's next unconsumed entry
   for (int r = 0; r < K; ++r) {
-    float v = head < K ? cv[threadIdx.x * K + head] : -__builtin_inff();
-    int id = head < K ? ci[threadIdx.x * K + head] : 0x7fffffff;
-    int slot = threadIdx.x;
+    float v = tv[0];
+    int id = ti[0];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(v, o, 64);
       const int oi = __shfl_xor(id, o, 64);
-      const int os = __shfl_xor(slot, o, 64);
       if (ov > v || (ov == v && oi < id)) {
         v = ov;
         id = oi;
-        slot = os;
       }
     }
-    if ((threadIdx.x & 63) == 0) {
-      bestv[threadIdx.x >> 6] = v;
-      besti[threadIdx.x >> 6] = id;
-      bestslot[threadIdx.x >> 6] = slot;
-    }
-    __syncthreads();
-    float bv = bestv[0];
-    int bi = besti[0], bs = bestslot[0];
-    for (int w = 1; w < 4; ++w)
-      if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) {
-        bv = bestv[w];
-        bi = besti[w];
-        bs = bestslot[w];
+    if (id == ti[0] && v == tv[0]) {                // this lane's head won (columns are unique; exhausted lists hold 0x7fffffff)
+#pragma unroll
+      for (int j = 0; j + 1 < K; ++j) {
+        tv[j] = tv[j + 1];
+        ti[j] = ti[j + 1];
       }
-    if (threadIdx.x == bs) ++head;
-    if (threadIdx.x == 0) {
-      pv[slot0 * K + r] = bv;
-      pi[slot0 * K + r] = bi;
+      tv[K - 1] = -__builtin_inff();
+      ti[K - 1] = 0x7fffffff;
     }
-    __syncthreads();
+    if (lane == 0) {
+      cv[wave * K + r] = v;
+      ci[wave * K + r] = id;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    static_assert(4 * K <= 64, "the four waves' candidates fit one wave");
+    const bool live = lane < 4 * K;
+    const float v = live ? cv[lane] : -__builtin_inff();
+    const int id = live ? ci[lane] : 0x7fffffff;
+    int rank = 0;
+#pragma unroll
+    for (int d = 0; d < 4 * K; ++d) {
+      const float dv = __shfl(v, d, 64);
+      const int di = __shfl(id, d, 64);
+      rank += (dv > v || (dv == v && (di < id || (di == id && d < lane)))) ? 1 : 0;
+    }
+    if (live && rank < K) {
+      pv[slot0 * K + rank] = v;
+      pi[slot0 * K + rank] = id;
+    }
   }
 }
 
@@ -497,7 +525,7 @@ extern "C" int tasu_attn_decode(const void* qkv, const void* kcache, const void*
       ctx > MAX_CTX)
     return TASU_ERR_ARG;
   const int rep = H / G;
-  const size_t lds = ((size_t)rep * ctx + DEC_NW * rep * HD + rep + (rep & 1) + ctx) * sizeof(float);
+  const size_t lds = (size_t)tasu_attn_dec::attn_decode_lds_floats(rep, ctx) * sizeof(float);
   if (lds > 160 * 1024) return TASU_ERR_ARG;
 #define DEC_CASE(R)                                                                                                   \
   case R: {                                                                                                           \
