@@ -104,6 +104,11 @@ using tasu_stream::Args;
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+#ifdef TASU_STREAM_TRACE
+extern "C" int tasu_stream_trace_read(uint64_t* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tasu_stream::g_stream_trace), 32 * sizeof(uint64_t)) == hipSuccess ? 0 : 2;
+}
+#endif
 extern "C" int tasu_stream_supported(int K, int ksplit) { return tasu_stream::k_supported(K, ksplit) ? 1 : 0; }
 
 extern "C" int tasu_gemm_stream_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias,

@@ -7,6 +7,13 @@ namespace tasu_stream {
 
 enum { E_BF16 = 0, E_RESID = 1, E_SWIGLU = 2, E_QKV = 3, E_SLAB = 4 };
 constexpr int NW = 8;                      // waves per workgroup
+#ifdef TASU_STREAM_TRACE
+// debug build (make trace; tools/stream_trace.py): wall-clock stamps of workgroup 0's first thread after every tile
+__device__ unsigned long long g_stream_trace[32];
+#define TASU_STREAM_STAMP(k) do { if (threadIdx.x == 0 && bx == 0 && by == 0 && bz == 0 && (k) < 32) g_stream_trace[k] = wall_clock64(); } while (0)
+#else
+#define TASU_STREAM_STAMP(k) do { } while (0)
+#endif
 int cu_count();                            // compute units of the current device (gemm_stream.hip)
 
 struct Args {
@@ -293,26 +300,34 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
   };
 
   bf16x8 w0[KS], w1[KS], w2[KS];
+  TASU_STREAM_STAMP(0);
   load_w(w0, 0);
   if (ntl <= 2) {
     // one or two tiles (the q|k|v, o and down projections): no ring, nothing loaded twice
     if (ntl == 2) load_w(w1, 1);
     const Epi e0 = load_epi(0), e1 = load_epi(1);
+    TASU_STREAM_STAMP(1);
     compute(w0, 0, &e0);
+    TASU_STREAM_STAMP(2);
     if (ntl == 2) compute(w1, 1, &e1);
+    TASU_STREAM_STAMP(3);
     return;
   }
   // three tiles in flight per wave.  The body is branch-free (the trip count is rounded up to a multiple of three: the spare
   // bodies re-read the last tile and skip their epilogue), so that the compiler's vmcnt bookkeeping sees one straight ring
   // and waits for the oldest tile only.
   load_w(w1, 1);
+  TASU_STREAM_STAMP(1);
   for (int i = 0; i < ntl; i += 3) {
     load_w(w2, i + 2);
     compute(w0, i, nullptr);
+    TASU_STREAM_STAMP(2 + i);
     load_w(w0, i + 3);
     compute(w1, i + 1, nullptr);
+    TASU_STREAM_STAMP(3 + i);
     load_w(w1, i + 4);
     compute(w2, i + 2, nullptr);
+    TASU_STREAM_STAMP(4 + i);
   }
 }
 

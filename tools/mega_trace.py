@@ -21,7 +21,8 @@ for w in c["layers"]:
     ops.register_decode_weight(w["wgu"], "swiglu", I)
     ops.register_decode_weight(w["wd"], "plain", D)
 assert ops.begin_decode(D, H * HD, I)
-table = ops.decode_layer_table(c["layers"], c["kc"], c["vc"])
+same = os.environ.get("MEGA_TRACE_SAME_WEIGHTS") == "1"      # every layer reads layer 0's weights: Infinity-Cache-warm upper bound
+table = ops.decode_layer_table([c["layers"][0]] * L if same else c["layers"], c["kc"], c["vc"])
 ws = torch.empty(ops.decode_layers_ws_bytes(L, D, H, G, I), dtype=torch.uint8, device="cuda")
 xn = torch.zeros(64, D, dtype=torch.bfloat16, device="cuda")
 ncu = torch.cuda.get_device_properties(0).multi_processor_count
