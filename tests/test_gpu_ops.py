@@ -714,3 +714,33 @@ def test_decode_layer_chain_in_fragment_order(hip, fake, M, D, I, H, G, V):
     for name, a, b, c in zip(("qkv", "kc", "vc", "x_mid", "x_out", "logits"), row, frg, cpu):
         assert torch.equal(a, b), name
         assert rel_err(a, c) < 3e-2, name
+
+
+@pytest.mark.parametrize("H,G,ctx,frag", [(12, 2, 1100, 1), (2, 1, 700, 0), (28, 4, 530, 0), (12, 2, 40, 1)])
+def test_attn_decode_long_ragged_contexts(hip, fake, H, G, ctx, frag):
+    """Cache attention beyond what a wave prefetches (3 K chunks / 2 V blocks per wave = 384 / 512 keys): ragged visible ranges
+    from 1 key to the whole context, random physical rows behind the index, 6 / 2 / 7 query heads per kv group, row-major and
+    fragment-order outputs.  bf16 output: <= 2 % of the tensor's scale against the fp32 double."""
+    M, W, LD = 9, G * HD, (H + 2 * G) * HD
+    rs = np.random.RandomState(ctx)
+    qkv = randn(M, LD, dtype=BF, seed=11)
+    kc, vc = randn(M * ctx * W, dtype=BF, seed=12, scale=0.7), randn(M * ctx * W, dtype=BF, seed=13, scale=0.7)
+    lens = np.array([1, 2, 17, ctx, ctx - 1, ctx // 2, 385, min(513, ctx), 33][:M], dtype=np.int32).clip(1, ctx)
+    kstart = np.minimum(rs.randint(0, 9, size=M), lens - 1).astype(np.int32)
+    index = torch.from_numpy(rs.randint(0, M, size=(M, ctx)).astype(np.int32))
+    want = torch.zeros(M, H * HD, dtype=BF)
+    fake.attn_decode(qkv, kc, vc, index, torch.from_numpy(kstart), torch.from_numpy(lens), want, M, H, G, ctx, HD ** -0.5)
+    out = torch.zeros(64, H * HD, dtype=BF, device="cuda")
+    hip.dec_frag = bool(frag)
+    try:
+        hip.attn_decode(dev(qkv), dev(kc), dev(vc), dev(index), dev(torch.from_numpy(kstart)), dev(torch.from_numpy(lens)), out, M, H, G,
+                        ctx, HD ** -0.5)
+    finally:
+        hip.dec_frag = False
+    torch.cuda.synchronize()
+    got = out.cpu()
+    if frag:
+        K = H * HD
+        got = got.view(K // 32, 4, 4, 16, 8).permute(1, 3, 0, 2, 4).reshape(64, K)
+    assert torch.isfinite(got[:M].float()).all()
+    assert rel_err(want, got[:M]) < 2e-2
