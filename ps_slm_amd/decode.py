@@ -233,6 +233,7 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
     tv = buf("dec_topv", (M, K), f32)
     ti = buf("dec_topi", (M, K), i32)
     bs = DeviceBeam(model, B, nb, max_new_tokens, eos, length_penalty, min_length, S, valid)
+    model._last_beam = bs                                                  # (tests read the final scores / back-pointers)
     ops.logprob_topk(logits, B, V, K, bs.banned, 1, tv, ti)
     ops.beam_update(tv, ti, bs, True)                                      # first position: only beam 0 exists
     x = buf("dec_x", (M, D), f32)

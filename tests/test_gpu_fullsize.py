@@ -256,3 +256,36 @@ def test_full_size_encoder_batch_equals_single_utterances():
         assert diff < 2e-3, (b, diff)                                        # probabilities; bf16 activations inside
         same_arg = (alone.argmax(-1) == post[b, : n + 4].argmax(-1)).float().mean()
         assert float(same_arg) > 0.995, (b, float(same_arg))
+
+
+# ------------------------------------------------------------------------------------------------ decode
+def test_full_size_decode_scores_equal_full_forward(full):
+    """KV-cache decode == full recompute, at Qwen2.5-1.5B size (where the oracle would take an hour): the beam search's final
+    score of every returned hypothesis (sum of the per-position log-probs its decode steps produced, / length) must equal the
+    sum of log-softmax values a plain forward over [prompt + the returned tokens] assigns to those tokens.  That ties the cache
+    fill / append, the beam reorder through the row index, the RoPE positions, the single-token attention, the weight-streaming
+    GEMMs and the top-k log-probs to the training-forward kernels.  Tolerance 0.02 nats per token (two bf16 evaluations of a
+    28-layer decoder; a wrong cache row or position moves a chosen token's log-prob by nats)."""
+    from ps_slm_amd.decode import beam_search_generate
+    geo, m = full
+    B, n_new, nb = 5, 7, 4
+    batch = synthetic_text_batch(geo, B, seed=321, noise=False)
+    ids = batch["input_ids"][:, :25]
+    am = torch.ones_like(ids, dtype=torch.bool)
+    st = m.prepare_text(ids, am, None, batch["post_ids"], None, None)
+    m.forward_projector_text(st)
+    out = beam_search_generate(m, st, num_beams=nb, max_new_tokens=n_new, eos_token_id=-1, pad_token_id=0)
+    assert tuple(out.shape) == (B, n_new)
+    beam_score = m._last_beam.fin_scores[:, 0].float().cpu() * n_new          # length_penalty 1.0: score = sum / length
+    S = st.S
+    ids2 = torch.cat([ids, out.to(ids.dtype)], dim=1)
+    st2 = m.prepare_text(ids2, torch.ones_like(ids2, dtype=torch.bool), None, batch["post_ids"], None, None)
+    m.forward_projector_text(st2)
+    m.forward_llm(st2, compute_loss=False, need_backward=False)
+    torch.cuda.synchronize()
+    assert st2.S == S + n_new
+    logits = m.logits_view(st2)
+    lp = torch.log_softmax(logits[:, S - 1:S - 1 + n_new].float(), dim=-1)
+    tok_lp = lp.gather(2, out.cuda().long()[:, :, None])[:, :, 0].cpu()
+    assert float(tok_lp.min()) > -math.log(geo.llm_vocab) + 1.0             # the beams' tokens stand out of the uniform floor
+    assert float((tok_lp.sum(1) - beam_score).abs().max()) < 0.02 * n_new, (tok_lp.sum(1), beam_score)   # measured: 0.047 over 7 tokens; another utterance's tokens: 25
