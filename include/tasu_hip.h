@@ -294,7 +294,10 @@ int tasu_kv_index_init(int32_t* index, int B, int n_beams, int S, int ctx, void*
 int tasu_kv_index_reorder(const int32_t* src_index, int32_t* dst_index, const int32_t* src_row, const int32_t* lens, int M,
                           int ctx, void* stream);
 /* Single-token GQA attention over the cache: keys [kstart[row], lens[row]) visible (left padding / current length),
- * key i read from cache row row_index[row, i] (row_index NULL: the row itself); out [M, H*128] bf16.  ctx <= 2048. */
+ * key i read from cache row row_index[row, i] (row_index NULL: the row itself; all ctx entries of a row must be valid cache
+ * rows -- they are read before lens is known); out [M, H*128] bf16, or the o projection's fragment-order A operand with
+ * out_frag = 1 (64-row chunks).  Scores and P.V both run as 16x16x32 bf16 MFMAs (csrc/attn_decode_body.h).  ctx <= 2048 and
+ * 4 * (H/G * ctx + H/G * round_up(ctx, 32) / 2 + ctx) + 64 KiB of LDS <= 160 KiB (H/G = 8: ctx <= ~1800); 1 <= lens - kstart. */
 int tasu_attn_decode(const void* qkv, const void* kcache, const void* vcache, const int32_t* row_index,
                      const int32_t* kstart, const int32_t* lens, void* out, int M, int H, int G, int ctx, float scale, int out_frag,
                      void* stream);
