@@ -9,7 +9,7 @@ constexpr int HD = 128;
 #ifdef TASU_ATTN_TRACE
 // debug build (tools/attn_trace.py): wall-clock stamps of workgroup (0, 0) at the body's phase boundaries
 __device__ unsigned long long g_attn_trace[16];
-#define TASU_ATTN_STAMP(k) do { if (threadIdx.x == 0 && row == 0 && g == 0) g_attn_trace[k] = wall_clock64(); } while (0)
+#define TASU_ATTN_STAMP(k) do { if (threadIdx.x == 0 && row == 0 && g == 0) tasu_attn_dec::g_attn_trace[k] = wall_clock64(); } while (0)
 #else
 #define TASU_ATTN_STAMP(k) do { } while (0)
 #endif

@@ -123,6 +123,8 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
   __shared__ float cv[4 * K];
   __shared__ int ci[4 * K];
   const int row = blockIdx.x, part = blockIdx.y;
+  [[maybe_unused]] const int g = part;                   // (TASU_ATTN_STAMP's workgroup test: row == 0 && g == 0)
+  TASU_ATTN_STAMP(9);
   const bf16* lr = logits + (size_t)row * ld;
   float tv[K];
   int ti[K];
@@ -161,8 +163,11 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
     for (int j = 0; j < 8; ++j)
       if (cv8 * 8 + j < V) m = fmaxf(m, (float)x[j]);
   }
+  TASU_ATTN_STAMP(10);
   m = block_max<4>(m, red);
+  TASU_ATTN_STAMP(11);
   float s = 0.f;
+  const int ban0 = n_banned > 0 ? banned[0] : -1, ban1 = n_banned > 1 ? banned[1] : -1;    // the usual case: EOS below min_length
   auto visit = [&](const bf16x8& x, int cv8) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -172,8 +177,8 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
       s += __expf(f - m);
       // thread-local sorted list (descending; on ties the smaller column, seen first, stays ahead)
       if (f > tv[K - 1]) {
-        bool ban = false;
-        for (int b = 0; b < n_banned; ++b) ban |= (banned[b] == c);
+        bool ban = c == ban0 || c == ban1;             // (a global load per candidate here cost ~0.5 us each, ~20 per thread)
+        for (int b = 2; b < n_banned; ++b) ban |= (banned[b] == c);
         if (ban) continue;
         tv[K - 1] = f;
         ti[K - 1] = c;
@@ -197,6 +202,7 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
     if (cv8 < vreg) visit(xs[i], cv8);
   }
   for (int cv8 = vreg + threadIdx.x; cv8 < v1; cv8 += 256) visit(*(const bf16x8*)(lr + cv8 * 8), cv8);
+  TASU_ATTN_STAMP(12);
   s = block_sum<4>(s, red);
   const size_t slot0 = (size_t)row * TOPK_PARTS + part;
   if (threadIdx.x == 0) {
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
       ci[wave * K + r] = id;
     }
   }
+  TASU_ATTN_STAMP(13);
   __syncthreads();
   if (wave == 0) {
     static_assert(4 * K <= 64, "the four waves' candidates fit one wave");
@@ -253,6 +260,7 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
       pi[slot0 * K + rank] = id;
     }
   }
+  TASU_ATTN_STAMP(14);
 }
 
 // one wave per row: lane p < TOPK_PARTS owns part p's sorted list
