@@ -115,16 +115,16 @@ constexpr int TOPK_PARTS = 16;       // column parts per row: 64 rows x 16 parts
 //   pm/ps = max and sum exp(x - max) over its columns, pv/pi = its K largest logits (descending; ties: smaller column).
 // Stage 2, grid (M): merges the parts (lse = log sum exp over all columns; K rounds of argmax over the P sorted lists).
 template <int K>
-__global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__ logits, int ld, int V,
+__device__ void topk_part_lists(const bf16* __restrict__ logits, int ld, int V,
                                                         const int32_t* __restrict__ banned, int n_banned,
                                                         float* __restrict__ pm, float* __restrict__ ps,
                                                         float* __restrict__ pv, int32_t* __restrict__ pi) {
+  // The general form: per-thread sorted lists merged per wave and per block.  Used by topk_part_kernel when more than CAND_CAP
+  // columns tie with or exceed its selection threshold (it re-does the whole part, the statistics included).
   __shared__ float red[4];
   __shared__ float cv[4 * K];
   __shared__ int ci[4 * K];
   const int row = blockIdx.x, part = blockIdx.y;
-  [[maybe_unused]] const int g = part;                   // (TASU_ATTN_STAMP's workgroup test: row == 0 && g == 0)
-  TASU_ATTN_STAMP(9);
   const bf16* lr = logits + (size_t)row * ld;
   float tv[K];
   int ti[K];
@@ -163,9 +163,7 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
     for (int j = 0; j < 8; ++j)
       if (cv8 * 8 + j < V) m = fmaxf(m, (float)x[j]);
   }
-  TASU_ATTN_STAMP(10);
   m = block_max<4>(m, red);
-  TASU_ATTN_STAMP(11);
   float s = 0.f;
   const int ban0 = n_banned > 0 ? banned[0] : -1, ban1 = n_banned > 1 ? banned[1] : -1;    // the usual case: EOS below min_length
   auto visit = [&](const bf16x8& x, int cv8) {
@@ -202,7 +200,6 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
     if (cv8 < vreg) visit(xs[i], cv8);
   }
   for (int cv8 = vreg + threadIdx.x; cv8 < v1; cv8 += 256) visit(*(const bf16x8*)(lr + cv8 * 8), cv8);
-  TASU_ATTN_STAMP(12);
   s = block_sum<4>(s, red);
   const size_t slot0 = (size_t)row * TOPK_PARTS + part;
   if (threadIdx.x == 0) {
@@ -241,7 +238,6 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
       ci[wave * K + r] = id;
     }
   }
-  TASU_ATTN_STAMP(13);
   __syncthreads();
   if (wave == 0) {
     static_assert(4 * K <= 64, "the four waves' candidates fit one wave");
@@ -260,6 +256,137 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__
       pi[slot0 * K + rank] = id;
     }
   }
+}
+
+// Threshold form (the common case; the per-thread insertion lists of topk_part_lists are instruction-bound: in a wave some lane
+// inserts at almost every element, so every element pays the whole insertion -- 10 of the kernel's 21 us):
+//   tau = the largest, over the four waves, of the wave's K-th largest per-thread maximum (banned columns excluded): at least K
+//   columns are >= tau, so the part's K best all are; a second scan over the register-resident chunks collects the columns
+//   >= tau (a handful) into LDS, and one wave ranks them by (value desc, column asc).  More than CAND_CAP such columns
+//   (massive ties): the general form takes over.
+constexpr int CAND_CAP = 64;
+template <int K>
+__global__ __launch_bounds__(256) void topk_part_kernel(const bf16* __restrict__ logits, int ld, int V,
+                                                        const int32_t* __restrict__ banned, int n_banned,
+                                                        float* __restrict__ pm, float* __restrict__ ps,
+                                                        float* __restrict__ pv, int32_t* __restrict__ pi) {
+  __shared__ float red[4];
+  __shared__ float wtau[4];
+  __shared__ float cand_v[CAND_CAP];
+  __shared__ int cand_i[CAND_CAP];
+  __shared__ int cand_n;
+  const int row = blockIdx.x, part = blockIdx.y;
+  [[maybe_unused]] const int g = part;                   // (TASU_ATTN_STAMP's workgroup test: row == 0 && g == 0)
+  TASU_ATTN_STAMP(9);
+  const bf16* lr = logits + (size_t)row * ld;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = (V + 7) / 8;
+  const int per = (nv + TOPK_PARTS - 1) / TOPK_PARTS;
+  const int v0 = part * per, v1 = min(nv, v0 + per);
+  constexpr int MAXC = 6;
+  if (v1 - v0 > 256 * MAXC) {                              // a part longer than the register window: general form
+    topk_part_lists<K>(logits, ld, V, banned, n_banned, pm, ps, pv, pi);
+    return;
+  }
+  if (threadIdx.x == 0) cand_n = 0;
+  bf16x8 xs[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cv8 = v0 + threadIdx.x + i * 256;
+    xs[i] = cv8 < v1 ? *(const bf16x8*)(lr + cv8 * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  const int ban0 = n_banned > 0 ? banned[0] : -1, ban1 = n_banned > 1 ? banned[1] : -1;
+  auto is_banned = [&](int c) {
+    bool ban = c == ban0 || c == ban1;
+    for (int b = 2; b < n_banned; ++b) ban |= (banned[b] == c);
+    return ban;
+  };
+  // pass 1: the part's maximum (softmax statistics: all columns) and this thread's best selectable column value
+  float m = -__builtin_inff(), msel = -__builtin_inff();
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cv8 = v0 + threadIdx.x + i * 256;
+    if (cv8 < v1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cv8 * 8 + j;
+        if (c < V) {
+          const float f = (float)xs[i][j];
+          m = fmaxf(m, f);
+          if (f > msel && !is_banned(c)) msel = f;
+        }
+      }
+    }
+  }
+  TASU_ATTN_STAMP(10);
+  m = block_max<4>(m, red);
+  TASU_ATTN_STAMP(11);
+  // the wave's K-th largest per-thread best: K rounds of (wave max, retire one lane that holds it)
+  float mine = msel, kth = -__builtin_inff();
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    kth = wave_max(mine);
+    const unsigned long long holders = __ballot(mine == kth);
+    if (lane == __ffsll((long long)holders) - 1) mine = -__builtin_inff();
+  }
+  if (lane == 0) wtau[wave] = kth;
+  __syncthreads();
+  const float tau = fmaxf(fmaxf(wtau[0], wtau[1]), fmaxf(wtau[2], wtau[3]));
+  // pass 2: sum of exp, and the columns >= tau
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cv8 = v0 + threadIdx.x + i * 256;
+    if (cv8 < v1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cv8 * 8 + j;
+        if (c < V) {
+          const float f = (float)xs[i][j];
+          s += __expf(f - m);
+          if (f >= tau && f > -__builtin_inff() && !is_banned(c)) {
+            const int slot = atomicAdd(&cand_n, 1);
+            if (slot < CAND_CAP) {
+              cand_v[slot] = f;
+              cand_i[slot] = c;
+            }
+          }
+        }
+      }
+    }
+  }
+  TASU_ATTN_STAMP(12);
+  s = block_sum<4>(s, red);                              // (its barriers also publish the candidates)
+  const int n_cand = cand_n;
+  if (n_cand > CAND_CAP) {                                 // block-uniform
+    topk_part_lists<K>(logits, ld, V, banned, n_banned, pm, ps, pv, pi);
+    return;
+  }
+  const size_t slot0 = (size_t)row * TOPK_PARTS + part;
+  if (threadIdx.x == 0) {
+    pm[slot0] = m;
+    ps[slot0] = s;
+  }
+  TASU_ATTN_STAMP(13);
+  if (wave == 0) {
+    const bool live = lane < n_cand;
+    const float v = live ? cand_v[lane] : -__builtin_inff();
+    const int id = live ? cand_i[lane] : 0x7fffffff;
+    int rank = 0;
+    for (int d = 0; d < n_cand; ++d) {
+      const float dv = __shfl(v, d, 64);
+      const int di = __shfl(id, d, 64);
+      rank += (dv > v || (dv == v && di < id)) ? 1 : 0;
+    }
+    if (live && rank < K) {
+      pv[slot0 * K + rank] = v;
+      pi[slot0 * K + rank] = id;
+    }
+    if (lane >= n_cand && lane < K) {                     // fewer than K selectable columns in this part
+      pv[slot0 * K + lane] = -__builtin_inff();
+      pi[slot0 * K + lane] = 0x7fffffff;
+    }
+  }
   TASU_ATTN_STAMP(14);
 }
 
@@ -275,23 +402,37 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float* __restrict_
   const float m = wave_max(mp);
   const float s = wave_sum(live && mp > -__builtin_inff() ? ps[slot0] * __expf(mp - m) : 0.f);
   const float lse = m + __logf(s);
-  int head = 0;
+  // the part's sorted list in registers (one round trip; a load per round made the K rounds K dependent round trips);
+  // the winner of a round shifts its list up
+  float lv[K];
+  int li[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    lv[j] = live ? pv[slot0 * K + j] : -__builtin_inff();
+    li[j] = live ? pi[slot0 * K + j] : 0x7fffffff;
+  }
+#pragma unroll
   for (int r = 0; r < K; ++r) {
-    float v = live && head < K ? pv[slot0 * K + head] : -__builtin_inff();
-    int id = live && head < K ? pi[slot0 * K + head] : 0x7fffffff;
-    int owner = lane;
+    float v = lv[0];
+    int id = li[0];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(v, o, 64);
       const int oi = __shfl_xor(id, o, 64);
-      const int oo = __shfl_xor(owner, o, 64);
       if (ov > v || (ov == v && oi < id)) {
         v = ov;
         id = oi;
-        owner = oo;
       }
     }
-    if (lane == owner) ++head;
+    if (id == li[0] && v == lv[0]) {                // this part's head won (columns are unique; exhausted lists hold 0x7fffffff)
+#pragma unroll
+      for (int j = 0; j + 1 < K; ++j) {
+        lv[j] = lv[j + 1];
+        li[j] = li[j + 1];
+      }
+      lv[K - 1] = -__builtin_inff();
+      li[K - 1] = 0x7fffffff;
+    }
     if (lane == 0) {
       out_val[(size_t)row * K + r] = v - lse;
       out_idx[(size_t)row * K + r] = id;

@@ -744,3 +744,24 @@ def test_attn_decode_long_ragged_contexts(hip, fake, H, G, ctx, frag):
         got = got.view(K // 32, 4, 4, 16, 8).permute(1, 3, 0, 2, 4).reshape(64, K)
     assert torch.isfinite(got[:M].float()).all()
     assert rel_err(want, got[:M]) < 2e-2
+
+
+@pytest.mark.parametrize("V,levels,k,nban", [(151936, 0, 8, 1), (151936, 5, 8, 2), (151936, 40, 16, 0), (5000, 2, 4, 3), (70, 0, 8, 1),
+                                              (40000, 1, 6, 1)])
+def test_logprob_topk_ties_and_full_vocabulary(hip, fake, V, levels, k, nban):
+    """Token ids are index work: exact against the double, with the tie rule (smaller column first).  ``levels`` > 0 quantises
+    the logits to that many distinct values, so that hundreds of columns tie at the selection threshold (the kernel's
+    general path), 0 keeps random bf16 logits (its threshold path); banned ids include the row's best column."""
+    M = 7
+    ld = (V + 63) // 64 * 64
+    g = torch.Generator().manual_seed(V + levels)
+    x = torch.randn(M, V, generator=g) * 2.5
+    if levels:
+        x = torch.round(x.clamp(-3, 3) / 6 * levels) * (6 / max(levels, 1))
+    lg = torch.zeros(M, ld, dtype=BF)
+    lg[:, :V] = x.to(BF)
+    banned = torch.tensor([int(lg[0, :V].float().argmax()), 3, -1][:max(nban, 1)], dtype=I32)
+    (vc_, ic_), (vg_, ig_) = run_pair(hip, fake, "logprob_topk", [lg, M, V, k, banned, nban, torch.zeros(M, k), torch.zeros(M, k, dtype=I32)],
+                                      [6, 7])
+    assert torch.equal(ic_, ig_), (ic_, ig_)
+    torch.testing.assert_close(vg_, vc_, rtol=0, atol=2e-4)
