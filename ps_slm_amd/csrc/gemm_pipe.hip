@@ -149,7 +149,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
                                                  vob[i], koff, (i & 3) * 1024, 0);
       };
       [&]<int... I>(std::integer_sequence<int, I...>) { (one_a(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, PA>{});
+#if !defined(TASU_EXP_NO_B_DMA)                    // (timing experiment, wrong results: the B tile never reaches LDS)
       [&]<int... I>(std::integer_sequence<int, I...>) { (one_b(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, PB>{});
+#else
+      (void)one_b;
+#endif
       if (++ld_k == nk) {
         ld_k = 0;
         ld_tile += gridDim.x;
@@ -157,6 +161,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
       }
     };
     auto wait_keep_one_step = [&]() {              // all but the newest K-step's pieces have landed
+#if defined(TASU_EXP_NO_B_DMA)
+      if constexpr (PA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      return;
+#endif
       if constexpr (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else if constexpr (NG == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -196,8 +205,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   auto read_frags = [&](bf16x8 (&fa)[MI], bf16x8 (&fb)[NI], int buf, int kk) {
     const char* sa = smem + buf * STAGE + a_base + roff[kk];
     const char* sb = smem + buf * STAGE + b_base + roff[kk];
+#if !defined(TASU_EXP_NO_B_READS)                  // (timing experiment, wrong results: the B fragments are never refreshed)
 #pragma unroll
     for (int j = 0; j < NI; ++j) fb[j] = *(const bf16x8*)(sb + j * 16 * 128);
+#else
+    (void)sb;
+#endif
 #pragma unroll
     for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(sa + i * 16 * 128);
   };
@@ -217,6 +230,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   };
 
   bf16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+#if defined(TASU_EXP_NO_B_READS)
+#pragma unroll
+  for (int j = 0; j < NI; ++j) fb0[j] = fb1[j] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1};
+#endif
   zero_acc();
   __builtin_amdgcn_s_barrier();                    // step 0 is in LDS
   asm volatile("" ::: "memory");
