@@ -340,6 +340,16 @@ int tasu_fbank(const float* wave, int64_t n_samples, float scale, int win, int s
 int tasu_lfr_cmvn(const float* fb, int T, int D, int lfr_m, int lfr_n, const float* means, const float* scales, float* out,
                   void* stream);
 
+/* Everything a generated position needs before its first decoder layer, in one launch (each piece also exists as its own
+ * entry point: tasu_embed_rows, tasu_rmsnorm_fwd_frag, tasu_rope_table, tasu_kv_index_reorder; bit-identical results):
+ *   x[m, :] = table[ids[m], :];  xn_frag = RMSNorm(x, norm_w) in fragment order (64-row chunks);  cos / sin [M, 64] of pos[m]
+ *   (HD = 128);  and the beam reorder of the cache row index IN PLACE: index[m, :lens[m]] = index_before[src_row[m], :lens[m]],
+ *   which requires src_row[m] to be a row of m's own utterance (rows (m / n_beams) * n_beams .. + n_beams - 1; HF beam search
+ *   reorders within a batch item).  D % 256 == 0 (D / 256 in {1, 2, 6, 7, 14}), n_beams <= 5, ctx <= 2048. */
+int tasu_decode_step_prologue(const float* table, const int32_t* ids, float* x, const float* norm_w, void* xn_frag, float eps,
+                              const int32_t* pos, float* cos_tab, float* sin_tab, float theta, int32_t* index,
+                              const int32_t* src_row, const int32_t* lens, int n_beams, int M, int D, int ctx, void* stream);
+
 /* ------------------------------------------------------------------------------------------ decode: the layer loop in one launch
  * Replaces, for one generated position of <= 64 beam rows, the per-layer launch sequence of the decode step
  * (reference: Multitask/model/ps-slm.py:660-675 -> HF GenerationMixin.beam_search -> Qwen2ForCausalLM.forward with

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "tasu_fbank": [vp, i64, f32, i32, i32, vp, vp, i32, f32, vp, vp],
     "tasu_lfr_cmvn": [vp, i32, i32, i32, i32, vp, vp, vp, vp],
     "tasu_embed_rows": [vp, vp, vp, i32, i32, vp],
+    "tasu_decode_step_prologue": [vp, vp, vp, vp, vp, f32, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp],
     "tasu_decode_layers_supported": [i32] * 6,
     "tasu_decode_layers_ws_bytes": [i32] * 5,
     "tasu_decode_layers_sync_words": [],

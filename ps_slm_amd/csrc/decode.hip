@@ -632,7 +632,71 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
   for (int c = lane * 4; c < D; c += 256) *(f32x4*)(x + (size_t)m * D + c) = *(const f32x4*)(src + c);
 }
 
+// Everything a generated position needs before its first layer, in ONE launch (block = beam row m; each piece used to be a
+// launch of ~5 us that does microseconds of work):
+//   wave 0  x[m, :] = table[ids[m], :] (fp32 embedding row) and xn = RMSNorm(x[m], norm_w) in fragment order (stream_body.h's
+//           norm_row_frag: the arithmetic of tasu_rmsnorm_fwd_frag), 64-row chunks;
+//   wave 1  RoPE factors cos / sin [m, 64] of position pos[m] (rope.hip's rope_table_kernel arithmetic);
+//   all     if m is the first row of its utterance (m % nb == 0): the beam reorder of the utterance's nb rows of the cache row
+//           index, IN PLACE -- dst[r, :lens[r]] = src[src_row[r], :lens[r]] -- staged through LDS; a beam's parent is always a
+//           row of the same utterance (HF beam search reorders within a batch item), which is what makes one workgroup enough.
+template <int NG>
+__global__ __launch_bounds__(256) void decode_step_prologue_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                                                   float* __restrict__ x, const float* __restrict__ norm_w,
+                                                                   bf16* __restrict__ xn, float eps, const int32_t* __restrict__ pos,
+                                                                   float* __restrict__ ct, float* __restrict__ st, float theta,
+                                                                   int32_t* __restrict__ index, const int32_t* __restrict__ src_row,
+                                                                   const int32_t* __restrict__ lens, int nb, int M, int ctx) {
+  extern __shared__ int stage[];                          // [nb][ctx]
+  constexpr int D = NG * 256;
+  const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave == 0) {
+    const float* src = table + (size_t)ids[m] * D;
+    for (int c = lane * 4; c < D; c += 256) *(f32x4*)(x + (size_t)m * D + c) = *(const f32x4*)(src + c);
+    tasu_stream::norm_row_frag_ptr<NG, false>(src, norm_w, xn + (size_t)(m >> 6) * 64 * D, m & 63, eps);
+  } else if (wave == 1) {
+    const int half = HD / 2, i = lane;
+    const float inv = 1.0f / powf(theta, (float)(2 * i) / (float)(2 * half));
+    const float ang = (float)pos[m] * inv;
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    ct[m * half + i] = cs;
+    st[m * half + i] = sn;
+  }
+  if (m % nb) return;
+  const int rows = min(nb, M - m);
+  for (int r = 0; r < rows; ++r) {
+    const int n = lens[m + r];
+    const int32_t* s = index + (size_t)src_row[m + r] * ctx;
+    for (int i = threadIdx.x; i < n; i += 256) stage[r * ctx + i] = s[i];
+  }
+  __syncthreads();
+  for (int r = 0; r < rows; ++r) {
+    const int n = lens[m + r];
+    for (int i = threadIdx.x; i < n; i += 256) index[(size_t)(m + r) * ctx + i] = stage[r * ctx + i];
+  }
+}
+
 }  // namespace
+
+extern "C" int tasu_decode_step_prologue(const float* table, const int32_t* ids, float* x, const float* norm_w, void* xn_frag,
+                                         float eps, const int32_t* pos, float* cos_tab, float* sin_tab, float theta, int32_t* index,
+                                         const int32_t* src_row, const int32_t* lens, int n_beams, int M, int D, int ctx,
+                                         void* stream) {
+  if (!table || !ids || !x || !norm_w || !xn_frag || !pos || !cos_tab || !sin_tab || !index || !src_row || !lens) return TASU_ERR_ARG;
+  if (M <= 0 || n_beams <= 0 || n_beams > BEAM_MAX_NB || ctx <= 0 || ctx > MAX_CTX || D % 256) return TASU_ERR_ARG;
+  const size_t lds = (size_t)n_beams * ctx * sizeof(int);
+#define TASU_PRO(NG)                                                                                                              \
+  case NG:                                                                                                                        \
+    TASU_LAUNCH(decode_step_prologue_kernel<NG>, dim3(M), dim3(256), lds, (hipStream_t)stream, table, ids, x, norm_w, (bf16*)xn_frag, \
+                eps, pos, cos_tab, sin_tab, theta, index, src_row, lens, n_beams, M, ctx);                                       \
+    return TASU_OK;
+  switch (D / 256) {
+    TASU_PRO(1) TASU_PRO(2) TASU_PRO(6) TASU_PRO(7) TASU_PRO(14)
+    default: return TASU_ERR_ARG;
+  }
+#undef TASU_PRO
+}
 
 extern "C" int tasu_kv_fill(const void* qkv, void* kcache, void* vcache, int B, int S, int H, int G, int n_beams, int ctx,
                             void* stream) {

@@ -339,11 +339,12 @@ __device__ __forceinline__ size_t frag_index(int row, int c) {
 // One WAVE: y[row, :] = bf16(w * (x[row, :] * rstd)) in fragment order, D = NG * 256 -- the arithmetic and summation order of
 // norm.hip's rmsnorm_fwd_reg_kernel (lane owns columns 4 * lane + 256 * g).
 template <int NG, bool WT>
-__device__ __forceinline__ void norm_row_frag(const float* __restrict__ x, const float* __restrict__ w, bf16* __restrict__ y, int row,
-                                              float eps) {
+__device__ __forceinline__ void norm_row_frag_ptr(const float* __restrict__ xrow, const float* __restrict__ w, bf16* __restrict__ y,
+                                                  int row, float eps) {
+  // xrow: the row's D fp32 values; row (< 64): its position in the fragment-order output
   constexpr int D = NG * 256;
   const int lane = threadIdx.x & 63;
-  const float* xr = x + (size_t)row * D + lane * 4;
+  const float* xr = xrow + lane * 4;
   f32x4 v[NG], gw[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) v[g] = *(const f32x4*)(xr + g * 256);
@@ -361,6 +362,12 @@ __device__ __forceinline__ void norm_row_frag(const float* __restrict__ x, const
     for (int j = 0; j < 4; ++j) o[j] = gw[g][j] * (v[g][j] * r);
     st_out<WT>((bf16x4*)(y + frag_index(row, lane * 4 + g * 256)), __builtin_convertvector(o, bf16x4));
   }
+}
+
+template <int NG, bool WT>
+__device__ __forceinline__ void norm_row_frag(const float* __restrict__ x, const float* __restrict__ w, bf16* __restrict__ y, int row,
+                                              float eps) {
+  norm_row_frag_ptr<NG, WT>(x + (size_t)row * (NG * 256), w, y, row, eps);
 }
 
 // One WAVE: row-wise finish of the E_SLAB partial tiles for a projection that feeds an RMSNorm (the down projection of a decode

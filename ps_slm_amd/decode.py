@@ -170,10 +170,12 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
         ops.end_decode()
 
 
-def layers_per_gemm(ops, geo, layers, final_norm, x, x2, xn, qkv, ao, act, cos, sin, kc, vc, index, kstart, slot, lens, M, ctx, ws):
+def layers_per_gemm(ops, geo, layers, final_norm, x, x2, xn, qkv, ao, act, cos, sin, kc, vc, index, kstart, slot, lens, M, ctx, ws,
+                    normed=False):
     """One generated position through the decoder layers with one launch per GEMM (6-7 launches per layer): the path for more
     than 64 beam rows and for geometries csrc/decode_mega.hip does not serve, and what the one-launch path is tested against.
-    In: x [M, D] fp32 (token embeddings); out: xn = the final-normed hidden state; K/V appended at ``slot``."""
+    In: x [M, D] fp32 (token embeddings; ``normed``: xn already holds layer 0's input norm of it); out: xn = the final-normed
+    hidden state; K/V appended at ``slot``."""
     D, I, H, G, L = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, len(layers)
     W = G * HD
     scale = HD ** -0.5
@@ -181,8 +183,9 @@ def layers_per_gemm(ops, geo, layers, final_norm, x, x2, xn, qkv, ao, act, cos, 
     # (the weights are then streamed once per chunk; K/V, attention and top-k are not chunked)
     chunks = [(m0, min(64, M - m0)) for m0 in range(0, M, 64)]
     kcv, vcv = kc.view(L, M, ctx * W), vc.view(L, M, ctx * W)
-    for m0, mc in chunks:
-        ops.dec_rmsnorm(x[m0:m0 + mc], layers[0]["ln1"], xn[m0:m0 + mc], geo.rms_eps)
+    if not normed:                                                               # (the step prologue has done it already)
+        for m0, mc in chunks:
+            ops.dec_rmsnorm(x[m0:m0 + mc], layers[0]["ln1"], xn[m0:m0 + mc], geo.rms_eps)
     for l, w in enumerate(layers):
         next_norm = layers[l + 1]["ln1"] if l + 1 < L else final_norm            # the norm that consumes this layer's output
         for m0, mc in chunks:                                                    # qkv projection + bias + RoPE + cache append
@@ -265,10 +268,8 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
     def device_step():
         """One generated position for all M beams: beam reorder of the row index (parents of the previous step), then the
         28-layer single-token pass over the cache, lm_head, the per-row top-k and the beam update."""
-        ops.kv_index_reorder(index, index_tmp, src_d, slot_d, M, ctx)
-        ops.kv_index_reorder(index_tmp, index, None, slot_d, M, ctx)
-        ops.embed_rows(llm.embed, ids_d, x, M, D)
-        ops.rope_table(pos_d, cos, sin, HD, geo.rope_theta)
+        ops.decode_step_prologue(llm.embed, ids_d, x, llm.layers[0]["ln1"], xn, geo.rms_eps, pos_d, cos, sin, HD, geo.rope_theta, index,
+                                 index_tmp, src_d, slot_d, nb, M, D, ctx)
         if mega:
             ops.decode_layers(table, L, x, llm.norm, xn, mega_ws, M, D, H, G, I, cos, sin, slot_d, index, kstart, lens_d, ctx,
                               geo.rms_eps, scale)
@@ -281,7 +282,7 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
 
     def per_gemm_layers():
         layers_per_gemm(ops, geo, llm.layers, llm.norm, x, x2, xn, qkv, ao, act, cos, sin, kc, vc, index, kstart, slot_d, lens_d,
-                        M, ctx, ws)
+                        M, ctx, ws, normed=True)
 
     # hipGraph replay of device_step (~430 launches): the first step of a shape runs eagerly, the second is captured.
     # A graph is only valid for the buffers it was captured on (grow-only workspace: same generation = same addresses) and

@@ -47,6 +47,7 @@ class HipOps:
         # position at 1.5B: a phase costs the same memory round trips as the kernel it replaces and the 1.5-us grid barrier
         # buys nothing over a hipGraph launch.  TASU_DECODE_MEGA=1 selects it (A/B runs).
         self.use_mega = os.environ.get("TASU_DECODE_MEGA", "0") == "1"
+        self.dec_prologue = os.environ.get("TASU_DECODE_PROLOGUE", "1") != "0"    # the position's five set-up launches as one
         self._mega_sync = None
 
     # ------------------------------------------------------------------ plumbing
@@ -344,6 +345,21 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_skinny_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), M, I, K,
                                                    _p(ws), 0 if ws is None else ws.numel(), self._stream()),
                   "tasu_gemm_skinny_swiglu")
+
+    def decode_step_prologue(self, table, ids, x, norm_w, xn, eps, pos, cos, sin, head_dim, theta, index, index_tmp, src_row, lens,
+                             n_beams, M, D, ctx):
+        """Start of a generated position: embedding rows, the first layer's input norm, the RoPE factors and the beam reorder of
+        the cache row index -- one launch in fragment-order decodes (tasu_decode_step_prologue), else the five separate ones."""
+        if self.dec_frag and self.dec_prologue and D % 256 == 0 and D // 256 in (1, 2, 6, 7, 14) and head_dim == 128 and n_beams <= 5:
+            return self._chk(self.lib.tasu_decode_step_prologue(_p(table), _p(ids), _p(x), _p(norm_w), _p(xn), eps, _p(pos), _p(cos),
+                                                                _p(sin), theta, _p(index), _p(src_row), _p(lens), n_beams, M, D, ctx,
+                                                                self._stream()), "tasu_decode_step_prologue")
+        self.kv_index_reorder(index, index_tmp, src_row, lens, M, ctx)
+        self.kv_index_reorder(index_tmp, index, None, lens, M, ctx)
+        self.embed_rows(table, ids, x, M, D)
+        self.rope_table(pos, cos, sin, head_dim, theta)
+        for m0 in range(0, M, 64):
+            self.dec_rmsnorm(x[m0:m0 + 64], norm_w, xn[m0:m0 + 64], eps)
 
     # ------------------------------------------------------------------ decode: the layer loop in one launch
     def decode_layers_supported(self, M, D, H, G, I, ctx):

@@ -550,5 +550,13 @@ class FakeOps:
             v = (v + means[None, :]) * scales[None, :]
         out[:T_lfr] = v
 
+    def decode_step_prologue(self, table, ids, x, norm_w, xn, eps, pos, cos, sin, head_dim, theta, index, index_tmp, src_row, lens,
+                             n_beams, M, D, ctx):
+        self.kv_index_reorder(index, index_tmp, src_row, lens, M, ctx)
+        self.kv_index_reorder(index_tmp, index, None, lens, M, ctx)
+        self.embed_rows(table, ids, x, M, D)
+        self.rope_table(pos, cos, sin, head_dim, theta)
+        self.dec_rmsnorm(x[:M], norm_w, xn, eps)
+
     def embed_rows(self, table, ids, x, M, D):
         x[:M] = table[ids[:M].long()]

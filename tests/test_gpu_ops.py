@@ -765,3 +765,41 @@ def test_logprob_topk_ties_and_full_vocabulary(hip, fake, V, levels, k, nban):
                                       [6, 7])
     assert torch.equal(ic_, ig_), (ic_, ig_)
     torch.testing.assert_close(vg_, vc_, rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("D,M,nb,ctx", [(1536, 64, 4, 328), (256, 12, 3, 70), (1536, 100, 4, 200), (3584, 10, 5, 64)])
+def test_decode_step_prologue_equals_its_five_launches(hip, D, M, nb, ctx):
+    """Embedding rows + first input norm (fragment order) + RoPE factors + in-place beam reorder of the cache row index in one
+    launch (tasu_decode_step_prologue) against tasu_embed_rows / tasu_rmsnorm_fwd_frag / tasu_rope_table / 2 x
+    tasu_kv_index_reorder: bit for bit."""
+    rs = np.random.RandomState(D + M)
+    V = 500
+    table = dev(randn(V, D, seed=1))
+    ids = dev(torch.from_numpy(rs.randint(0, V, size=M).astype(np.int32)))
+    w = dev(1 + randn(D, seed=2, scale=0.1))
+    pos = dev(torch.from_numpy(rs.randint(0, 3000, size=M).astype(np.int32)))
+    lens = dev(torch.from_numpy(rs.randint(1, ctx + 1, size=M).astype(np.int32)))
+    groups = (np.arange(M) // nb) * nb
+    src = dev(torch.from_numpy((groups + rs.randint(0, nb, size=M)).clip(max=M - 1).astype(np.int32)))     # a parent of the same utterance
+    index0 = torch.from_numpy(rs.randint(0, M, size=(M, ctx)).astype(np.int32))
+    Mp = (M + 63) // 64 * 64
+    outs = []
+    hip.dec_frag = True
+    try:
+        for fused in (False, True):
+            hip.dec_prologue = fused
+            x, xn = torch.zeros(M, D, device="cuda"), torch.zeros(Mp, D, dtype=BF, device="cuda")
+            cos, sin = torch.zeros(M, 64, device="cuda"), torch.zeros(M, 64, device="cuda")
+            index, tmp = dev(index0.clone()), dev(index0.clone())
+            hip.decode_step_prologue(table, ids, x, w, xn, 1e-6, pos, cos, sin, HD, 1e6, index, tmp, src, lens, nb, M, D, ctx)
+            torch.cuda.synchronize()
+            outs.append((x, xn.view(torch.int16), cos, sin, index))
+    finally:
+        hip.dec_frag, hip.dec_prologue = False, True
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    want = index0.clone()
+    for m in range(M):
+        n = int(lens[m])
+        want[m, :n] = index0[int(src[m]), :n]
+    assert torch.equal(outs[1][4].cpu(), want)
