@@ -305,8 +305,9 @@ class HipOps:
         # the down projection, whose input layout is dec_frag_act
         a_frag = int(self.dec_frag if ks == 1 else self.dec_frag_act)
         y_frag = int(self.dec_frag)
-        if ks > 1 and not (self.dec_down_slabs or a_frag):
-            ks = 0                                          # split-K kernels of gemm_skinny.hip (see begin_decode)
+        if ks > 1 and (not (self.dec_down_slabs or a_frag) or N % 256 or N // 256 not in (1, 2, 6, 7)):
+            ks = 0                                          # split-K kernels of gemm_skinny.hip (see begin_decode; the slab
+                                                            # finish serves N = 256 * {1, 2, 6, 7} -- not the 7B's 3584)
         wf, wflag = (self._wf(b) if a_frag else (b, 0))
         if ks == 1:
             # one launch for the projection + residual add, one for the norm (the sum of squares needs the whole row)

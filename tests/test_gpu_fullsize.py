@@ -259,15 +259,16 @@ def test_full_size_encoder_batch_equals_single_utterances():
 
 
 # ------------------------------------------------------------------------------------------------ decode
-def test_full_size_decode_scores_equal_full_forward(full):
+@pytest.mark.parametrize("size", ["1.5b", "7b"])
+def test_full_size_decode_scores_equal_full_forward(size):
     """KV-cache decode == full recompute, at Qwen2.5-1.5B size (where the oracle would take an hour): the beam search's final
     score of every returned hypothesis (sum of the per-position log-probs its decode steps produced, / length) must equal the
     sum of log-softmax values a plain forward over [prompt + the returned tokens] assigns to those tokens.  That ties the cache
     fill / append, the beam reorder through the row index, the RoPE positions, the single-token attention, the weight-streaming
-    GEMMs and the top-k log-probs to the training-forward kernels.  Tolerance 0.02 nats per token (two bf16 evaluations of a
-    28-layer decoder; a wrong cache row or position moves a chosen token's log-prob by nats)."""
+    GEMMs and the top-k log-probs to the training-forward kernels.  Tolerance 0.02 (1.5B) / 0.05 (7B) nats per token (two bf16
+    evaluations of a 28-layer decoder; a wrong cache row or position moves a chosen token's log-prob by nats)."""
     from ps_slm_amd.decode import beam_search_generate
-    geo, m = full
+    geo, m = full_model(size)          # 7B: no streaming kernels for K = 3584 -> the split-K decode GEMMs, 7 query heads per kv group
     B, n_new, nb = 5, 7, 4
     batch = synthetic_text_batch(geo, B, seed=321, noise=False)
     ids = batch["input_ids"][:, :25]
@@ -288,4 +289,7 @@ def test_full_size_decode_scores_equal_full_forward(full):
     lp = torch.log_softmax(logits[:, S - 1:S - 1 + n_new].float(), dim=-1)
     tok_lp = lp.gather(2, out.cuda().long()[:, :, None])[:, :, 0].cpu()
     assert float(tok_lp.min()) > -math.log(geo.llm_vocab) + 1.0             # the beams' tokens stand out of the uniform floor
-    assert float((tok_lp.sum(1) - beam_score).abs().max()) < 0.02 * n_new, (tok_lp.sum(1), beam_score)   # measured: 0.047 over 7 tokens; another utterance's tokens: 25
+    # measured: 1.5B 0.047 over the 7 tokens, 7B 0.22 (its chosen logits are 8-16, where a bf16 ulp is 0.06); another utterance's
+    # tokens through the same forward: 25
+    tol = (0.02 if size == "1.5b" else 0.05) * n_new
+    assert float((tok_lp.sum(1) - beam_score).abs().max()) < tol, (tok_lp.sum(1), beam_score)
