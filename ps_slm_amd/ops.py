@@ -43,7 +43,7 @@ class HipOps:
         self.dec_down_slabs = False
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
         # the decode step's layer loop as one persistent launch (csrc/decode_mega.hip).  EXPERIMENTAL, off by default: parity-green
-        # (bit-identical to the per-GEMM launches, tests/test_gpu_decode_mega.py) but slower on MI355X -- 2.7 vs 2.0 ms per
+        # (bit-identical to the per-GEMM launches, tests/test_gpu_decode_mega.py) but slower on MI355X -- 2.03 vs 1.77 ms per
         # position at 1.5B: a phase costs the same memory round trips as the kernel it replaces and the 1.5-us grid barrier
         # buys nothing over a hipGraph launch.  TASU_DECODE_MEGA=1 selects it (A/B runs).
         self.use_mega = os.environ.get("TASU_DECODE_MEGA", "0") == "1"
