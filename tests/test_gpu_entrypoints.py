@@ -108,3 +108,29 @@ def test_validation_loop_and_best_checkpoint_on_gpu(tmp_path):
     assert os.path.isfile(tmp_path / "gpu" / "asr_model_epoch_1_step_2" / "pytorch_model.bin")
     sd = torch.load(tmp_path / "gpu" / "asr_model_epoch_1_step_2" / "pytorch_model.bin")
     assert sd["encoder_projector.ffn.0.weight"].shape == (128, 203)
+
+
+def test_training_entrypoint_with_graph_replay_on_a_corpus(tmp_path):
+    """finetune_deepspeed.main on a generated wav-in-ark corpus (audio path: fbank -> encoder -> PSD -> projector -> LLM; full
+    Qwen2.5-1.5B / SenseVoiceSmall geometry because the front end produces 560-wide features), 2 epochs:
+    ``++use_graphs=true ++graph_buckets=16,8,256`` (real batches share bucketed shapes, so the second epoch replays hipGraphs)
+    must give the eager run's loss and accuracy -- bucket padding carries no label and no key."""
+    import json
+    import dataset_fixtures as fx
+    from ps_slm_amd.finetune_deepspeed import main
+    dirs = fx.write_corpus(str(tmp_path), split_sizes=(("train", 9),))
+    with open(tmp_path / "multiprompt.jsonl", "w") as f:
+        for task, prompt in (("ASR", "11 12 13"), ("ST", "21 22"), ("hotword", "31 32 33 34")):
+            f.write(json.dumps({"task": task, "prompt": prompt}) + "\n")
+    base = ["++model_config.file=ps_slm_amd/ps_slm.py:model_factory", "++model_config.llm_path=synthetic:qwen2.5-1.5b", "++model_config.llm_dim=1536",
+            "++model_config.encoder_dim=25055", "++model_config.encoder_projector=linear-silu", "++train_config.freeze_llm=true",
+            "++train_config.freeze_encoder=true", "++train_config.gt_emb=false", "++train_config.ctc_posterior=true",
+            "++train_config.do_psd=true", "++train_config.num_epochs=2", "++dataset_config.file=ps_slm_amd/dataset.py:get_speech_dataset",
+            f"++dataset_config.train_scp_file_path={dirs['train']}", f"++dataset_config.multitask_prompt_path={tmp_path}/multiprompt.jsonl",
+            "++dataset_config.prompt_style={} 151665", "++dataset_config.train_max_frame_length=40", "++dataset_config.ds_rate=8",
+            "++metric=acc", "++log_config.log_interval=1"]
+    eager = main(base)
+    graphs = main(base + ["++use_graphs=true", "++graph_buckets=16,8,256"])
+    assert eager["steps"] == graphs["steps"] and eager["steps"] >= 4
+    assert abs(eager["avg_train_loss"] - graphs["avg_train_loss"]) < 2e-3, (eager, graphs)
+    assert abs(eager["avg_train_acc"] - graphs["avg_train_acc"]) < 0.02, (eager, graphs)
