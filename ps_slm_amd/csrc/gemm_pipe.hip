@@ -27,6 +27,11 @@
 #include "common.h"
 #include "../../include/tasu_hip.h"
 
+#if defined(TASU_EXP_B_DIRECT)                      // prototype (tools/bench_gemm_bdirect.py): B = fragment-order weights, global -> registers
+#define TASU_EXP_NO_B_READS
+#define TASU_EXP_NO_B_DMA
+#endif
+
 namespace tasu_pipe {
 
 constexpr int BK = 64;
@@ -234,6 +239,21 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
 #pragma unroll
   for (int j = 0; j < NI; ++j) fb0[j] = fb1[j] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1};
 #endif
+#if defined(TASU_EXP_B_DIRECT)
+  // B comes from a fragment-order copy [tile_n][wave column][K-step][k-half][j][64 lanes][8] (p.B), one K-step ahead:
+  // gbn0 / gbn1 = the next step's fragments, requested at the top of a K-step and moved into fb0 / fb1 at its end
+  bf16x8 gbn0[NI], gbn1[NI];
+  constexpr size_t BSTEP = (size_t)2 * NI * 512;
+  auto b_tile = [&](int tn) { return p.B + (size_t)(tn * 2 + wc) * (p.K / BK) * BSTEP + lane * 8; };
+  auto load_b = [&](bf16x8 (&g0)[NI], bf16x8 (&g1)[NI], const bf16* src) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      g0[j] = *(const bf16x8*)(src + j * 512);
+      g1[j] = *(const bf16x8*)(src + (NI + j) * 512);
+    }
+  };
+  const bf16* bnext = nullptr;
+#endif
   zero_acc();
   __builtin_amdgcn_s_barrier();                    // step 0 is in LDS
   asm volatile("" ::: "memory");
@@ -244,6 +264,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   auto kstep = [&](auto more_tag, int cur) {
     constexpr bool MORE = decltype(more_tag)::value;
     const int nxt = cur == 2 ? 0 : cur + 1;
+#if defined(TASU_EXP_B_DIRECT)
+    load_b(gbn0, gbn1, bnext);
+#endif
     // ---------------- phase 1: MFMA(q, k-half 0)  ||  reads (q, k-half 1)
     read_frags(fa1, fb1, cur, 1);
     mma(fa0, fb0);
@@ -268,6 +291,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
       }
       __builtin_amdgcn_sched_group_barrier(0x008, NM - 2 * NR, 1);
     }
+#if defined(TASU_EXP_B_DIRECT)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      fb0[j] = gbn0[j];
+      fb1[j] = gbn1[j];
+    }
+#endif
     return nxt;
   };
 
@@ -527,8 +557,24 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
     const int ks = s / base_tiles;
     tile_coords(p, s - ks * base_tiles, base_tiles, tm, tn);
     if constexpr (OUT_MODE == TASU_GEMM_OUT_F32) p.C = (float*)c_first + (size_t)ks * p.split_stride;   // slab of this K range
+#if defined(TASU_EXP_B_DIRECT)
+    const bf16* btile = b_tile(tn);
+    if (s == (int)blockIdx.x) load_b(fb0, fb1, btile);            // the workgroup's first tile: step 0 synchronously
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      bnext = btile + (size_t)(kt + 1) * BSTEP;
+      cur = kstep(T{}, cur);
+    }
+    bnext = btile;                                 // (no next tile: a harmless re-read)
+    if (s + (int)gridDim.x < ntiles) {
+      int tm2, tn2;
+      tile_coords(p, s + (int)gridDim.x, base_tiles, tm2, tn2);
+      bnext = b_tile(tn2);
+    }
+    cur = kstep(F{}, cur);
+#else
     for (int kt = 0; kt + 1 < nk; ++kt) cur = kstep(T{}, cur);
     cur = kstep(F{}, cur);                         // no read-ahead into the next tile: the fragment registers are free
+#endif
     if constexpr (OUT_MODE == OUT_GU_SWIGLU) store_gu_swiglu(tm * BM, tn);
     else store_tile(tm * BM, tn * BN);             // for the epilogue, whose stores then drain under the next tile
     zero_acc();
