@@ -40,7 +40,7 @@ class HipOps:
         self.use_stream = os.environ.get("TASU_DECODE_STREAM", "1") != "0"
         self.dec_frag = False          # set by begin_decode(): decode activations travel in fragment order
         self.dec_frag_act = False      # ... including the MLP activation that feeds the down projection
-        self.dec_down_slabs = False
+        self.dec_down_slabs = os.environ.get("TASU_DECODE_DOWN_SLABS", "1") != "0"    # (begin_decode re-reads it)
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
         # the decode step's layer loop as one persistent launch (csrc/decode_mega.hip).  EXPERIMENTAL, off by default: parity-green
         # (bit-identical to the per-GEMM launches, tests/test_gpu_decode_mega.py) but slower on MI355X -- 2.03 vs 1.77 ms per

@@ -656,7 +656,8 @@ def test_beam_update_kernel_is_exact(hip, nb, lpw, min_len, quantise):
     assert np.array_equal(got, fake) and calls == calls_f
 
 
-@pytest.mark.parametrize("M,D,I,H,G,V", [(64, 1536, 8960, 12, 2, 4000), (40, 256, 512, 2, 1, 1000), (64, 512, 1792, 4, 2, 520)])
+@pytest.mark.parametrize("M,D,I,H,G,V", [(64, 1536, 8960, 12, 2, 4000), (40, 256, 512, 2, 1, 1000), (64, 512, 1792, 4, 2, 520),
+                                         (1, 1536, 8960, 12, 2, 4000), (17, 1536, 8960, 12, 2, 700)])
 def test_decode_layer_chain_in_fragment_order(hip, fake, M, D, I, H, G, V):
     """One decode layer + lm_head on the streaming kernels with every operand in FRAGMENT ORDER (weights re-laid out by
     tasu_to_fragment_order, activations written in that order by the norm / attention / SwiGLU producers) against the same
@@ -707,7 +708,7 @@ def test_decode_layer_chain_in_fragment_order(hip, fake, M, D, I, H, G, V):
             ops.end_decode()
         return [a.cpu() for a in (qkv, kc, vc, x2, x, logits[:, :V])]
 
-    hip.use_stream = True
+    hip.use_stream = hip.dec_down_slabs = True             # both layouts sum the same K-range slabs (bit-identical results)
     row = chain(hip, "cuda", False)
     frg = chain(hip, "cuda", True)
     cpu = chain(fake, "cpu", False)
