@@ -364,7 +364,7 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                          "passes_note": ("value / ms_per_step: hipGraph replay of the timed steps; achieved / avg_launch_us: HIP event "
                                          "pairs around every GEMM launch in a second, EAGER pass of the same steps (graphs cannot carry "
                                          "per-launch events)") if core.use_graphs else "one eager pass",
-                         "whole_step_tflops": round(executed_step * steps / dt / 1e12 / world * world, 1),
+                         "whole_step_tflops": round(executed_step * steps / dt / 1e12, 1),     # per GPU (executed_step counts one rank's batch)
                          "whole_step_frac": round(executed_step * steps / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                          "whole_step_frac_at_survey_flops": round(survey_step * steps / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                          "flops_note": "achieved / whole_step_frac count EXECUTED FLOPs per GPU (lm_head rows without a label are "

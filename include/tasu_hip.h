@@ -50,6 +50,18 @@ int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C
                          const float* resid, int M, int N, int K, int out_mode, void* workspace,
                          int64_t workspace_bytes, void* stream);
 
+/* tasu_gemm_nt_bf16 on a NAMED kernel, regardless of the tile policy of tasu_gemm_nt_bf16_ws (tests compare the kernels with
+ * each other bit for bit -- they accumulate every output element in the same K order -- and tuning runs time them side by side):
+ *   PP256    256 x 256 tiles, eight MFMA waves in two groups one barrier apart, every wave stages its own share of the
+ *            operands by LDS-DMA (csrc/gemm_pp.hip); needs K % 128 == 0, K >= 256
+ *   PIPE128 / PIPE192 / PIPE96   256 x 128 / 128 x 192 / 256 x 96 tiles, four MFMA waves + four loader waves (csrc/gemm_pipe.hip) */
+#define TASU_GEMM_KERNEL_PP256 1
+#define TASU_GEMM_KERNEL_PIPE128 2
+#define TASU_GEMM_KERNEL_PIPE192 3
+#define TASU_GEMM_KERNEL_PIPE96 4
+int tasu_gemm_nt_bf16_kernel(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                             const float* resid, int M, int N, int K, int out_mode, int kernel, void* stream);
+
 /* Qwen2MLP gate|up projection with the activation in its epilogue (modeling_qwen2.py Qwen2MLP.forward), training step:
  * gu[M, 2I] = bf16(A[M,K] . Wgu[2I,K]^T) (gate columns first; saved for the backward) and
  * act[M, I] = bf16( bf16(silu(g)) * u ) -- bit-identical to tasu_gemm_nt_bf16 + tasu_swiglu_fwd.  I % 4 == 0.        */
@@ -349,50 +361,6 @@ int tasu_lfr_cmvn(const float* fb, int T, int D, int lfr_m, int lfr_n, const flo
 int tasu_decode_step_prologue(const float* table, const int32_t* ids, float* x, const float* norm_w, void* xn_frag, float eps,
                               const int32_t* pos, float* cos_tab, float* sin_tab, float theta, int32_t* index,
                               const int32_t* src_row, const int32_t* lens, int n_beams, int M, int D, int ctx, void* stream);
-
-/* ------------------------------------------------------------------------------------------ decode: the layer loop in one launch
- * Replaces, for one generated position of <= 64 beam rows, the per-layer launch sequence of the decode step
- * (reference: Multitask/model/ps-slm.py:660-675 -> HF GenerationMixin.beam_search -> Qwen2ForCausalLM.forward with
- * past_key_values: q|k|v projection + RoPE + cache update, attention over the cache, o projection, post-attention
- * RMSNorm, SwiGLU MLP, for each of the L decoder layers, then the final RMSNorm) by ONE persistent kernel: one workgroup
- * per CU, the dependent steps of a layer separated by grid barriers (csrc/decode_mega.hip).  Same arithmetic, rounding
- * points and summation orders as tasu_gemm_stream_qkv_rope / tasu_attn_decode / tasu_gemm_stream_bf16 (residual) /
- * tasu_rmsnorm_fwd_frag / tasu_gemm_stream_swiglu / tasu_gemm_stream_slabs + tasu_stream_finish_norm launched one by one.
- *
- * layers: DEVICE array [L] of tasu_decode_layer; the bf16 weights in FRAGMENT ORDER (tasu_to_fragment_order: wqkv kind 3,
- *   wo / wd kind 0, wgu kind 2), bqkv [(H + 2G) * 128] bf16 or NULL, ln1 / ln2 fp32 [D], kcache / vcache [M, ctx, G * 128].
- * x0 [M, D] fp32: the embeddings of this position's tokens; final_norm [D] fp32.
- * xn_out: fragment-order bf16 [D / 32][4][64][8] = the final-normed hidden state, lm_head's A operand (256-byte aligned).
- * ws: tasu_decode_layers_ws_bytes(L, D, H, G, I) bytes, 256-byte aligned (a slice per layer: every intermediate is written
- *   once per launch).  sync: tasu_decode_layers_sync_words() uint32 words, zeroed by the caller once (and again after an
- *   error); sync[1] counts barrier time-outs (a workgroup of the grid was not resident): non-zero = the results of that
- *   launch and all later ones are invalid.
- * cos_tab / sin_tab [M, 64], slot [M] (cache position appended at), row_index [M, ctx] or NULL, kstart / lens [M]: as in
- *   tasu_gemm_stream_qkv_rope and tasu_attn_decode.
- * Supported (tasu_decode_layers_supported): M <= 64, H * 128 == D, (D, H / G, I) = (1536, 6, multiple of 1792 up to 8 x)
- *   [Qwen2.5-1.5B] or (256, 2, multiple of 512) [the test geometry]; ctx <= 2048.  Other geometries keep the per-GEMM
- *   launches. */
-typedef struct {
-  const void* wqkv;
-  const void* bqkv;
-  const void* wo;
-  const void* wgu;
-  const void* wd;
-  const float* ln1;
-  const float* ln2;
-  void* kcache;
-  void* vcache;
-} tasu_decode_layer;
-int tasu_decode_layers_supported(int M, int D, int H, int G, int I, int ctx);
-int64_t tasu_decode_layers_ws_bytes(int L, int D, int H, int G, int I);
-int tasu_decode_layers_sync_words(void);
-/* Debug: while a device buffer is set, every tasu_decode_layers launch records per workgroup the 100-MHz wall-clock tick at which
- * it entered and left each grid barrier: [barrier][workgroup (CU count)][2] uint64, for as many barriers as fit. NULL clears. */
-int tasu_decode_layers_set_trace(uint64_t* device_buf, int64_t words);
-int tasu_decode_layers(const tasu_decode_layer* layers, int L, const float* x0, const float* final_norm, void* xn_out, void* ws,
-                       int64_t ws_bytes, uint32_t* sync, int M, int D, int H, int G, int I, const float* cos_tab,
-                       const float* sin_tab, const int32_t* slot, const int32_t* row_index, const int32_t* kstart,
-                       const int32_t* lens, int ctx, float eps, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------ FLAC (host)
  * The reference reads ``.flac`` entries with torchaudio.load (speech_dataset_large.py:123-127: [C, T] float

@@ -460,7 +460,8 @@ def bf16_ulp_jitter(seed, prob=0.15):
 
 
 def beam_search_generate(W, emb, mask, geo, num_beams=4, max_new_tokens=200, min_length=1, length_penalty=1.0,
-                         eos_token_id=None, pad_token_id=None, mode="fp32", logit_jitter=None):
+                         eos_token_id=None, pad_token_id=None, mode="fp32", logit_jitter=None, logits_trace=None,
+                         logits_replay=None):
     """slam_model_asr.generate's decode loop (Multitask/model/ps-slm.py:660-675): HF ``generate(inputs_embeds=...,
     num_beams=4, do_sample=False, early_stopping=False)`` restated (transformers generation/utils.py ``_beam_search``,
     un-vendored dependency): every step keeps the 2*num_beams best continuations, the first num_beams non-finished
@@ -471,7 +472,11 @@ def beam_search_generate(W, emb, mask, geo, num_beams=4, max_new_tokens=200, min
 
     ``logit_jitter`` (optional callable logits -> logits) perturbs every step's logits; the fixture generator
     oracle/make_golden_generate_margin.py uses it to keep only decode cases whose tokens survive random one-ulp flips of the
-    bf16 logits (``bf16_ulp_jitter``), i.e. cases without near-ties."""
+    bf16 logits (``bf16_ulp_jitter``), i.e. cases without near-ties.  ``logits_trace`` (a list) receives every step's
+    (logits, running prefixes); ``logits_replay`` (such a list) replaces the network: a step whose running prefixes equal the
+    recorded ones reuses the recorded logits (the network is a function of the prefixes), any other step ends the call with
+    ``None`` -- a jittered run over a recorded trajectory therefore costs only the bookkeeping, and a run that leaves the
+    trajectory has already shown the case to be unstable."""
     B, S, D = emb.shape
     nb, V = num_beams, lm_head_weight(W).shape[0]
     eos = geo["eos_id"] if eos_token_id is None else eos_token_id
@@ -493,11 +498,18 @@ def beam_search_generate(W, emb, mask, geo, num_beams=4, max_new_tokens=200, min
     cur = 0
     while True:
         toks = run_seq.view(B * nb, -1)[:, :cur]
-        x = torch.cat([emb_b, table[toks]], 1)
-        m = torch.cat([mask_b.bool(), torch.ones(B * nb, cur, dtype=torch.bool)], 1)
-        pos = (m.long().cumsum(-1) - 1).masked_fill(~m, 1)
-        hid = qwen2_hidden(W, x, m, pos, geo["llm_heads"], geo["llm_kv_heads"], geo.get("rope_theta", 1e6), mode)
-        logits = linear(hid[:, -1], lm_head_weight(W), None, mode).float()
+        if logits_replay is not None:
+            if cur >= len(logits_replay) or not torch.equal(logits_replay[cur][1], toks):
+                return None
+            logits = logits_replay[cur][0].clone()
+        else:
+            x = torch.cat([emb_b, table[toks]], 1)
+            m = torch.cat([mask_b.bool(), torch.ones(B * nb, cur, dtype=torch.bool)], 1)
+            pos = (m.long().cumsum(-1) - 1).masked_fill(~m, 1)
+            hid = qwen2_hidden(W, x, m, pos, geo["llm_heads"], geo["llm_kv_heads"], geo.get("rope_theta", 1e6), mode)
+            logits = linear(hid[:, -1], lm_head_weight(W), None, mode).float()
+        if logits_trace is not None:
+            logits_trace.append((logits.clone(), toks.clone()))
         if logit_jitter is not None:
             logits = logit_jitter(logits)
         logp = torch.log_softmax(logits, -1)

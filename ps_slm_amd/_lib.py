@@ -18,6 +18,7 @@ PROTOTYPES = {
     "tasu_gemm_nt_bf16": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
     "tasu_gemm_nt_bf16_ws": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "tasu_gemm_gate_up_swiglu": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp],
+    "tasu_gemm_nt_bf16_kernel": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "tasu_gemm_skinny_bf16": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "tasu_transpose_bf16": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "tasu_cast_f32_bf16": [vp, vp, i64, vp],
@@ -81,13 +82,8 @@ PROTOTYPES = {
     "tasu_lfr_cmvn": [vp, i32, i32, i32, i32, vp, vp, vp, vp],
     "tasu_embed_rows": [vp, vp, vp, i32, i32, vp],
     "tasu_decode_step_prologue": [vp, vp, vp, vp, vp, f32, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp],
-    "tasu_decode_layers_supported": [i32] * 6,
-    "tasu_decode_layers_ws_bytes": [i32] * 5,
-    "tasu_decode_layers_sync_words": [],
-    "tasu_decode_layers_set_trace": [vp, i64],
-    "tasu_decode_layers": [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp],
 }
-RESTYPE_I64 = {"tasu_decode_layers_ws_bytes"}
+RESTYPE_I64 = set()
 
 ABI_VERSION = 4
 _lib = None

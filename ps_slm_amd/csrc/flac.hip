@@ -251,7 +251,11 @@ int decode_stream(const uint8_t* d, int64_t n, const Info& in, Sink&& sink) {
   int64_t done = 0;
   while ((br.pos >> 3) + 2 <= n && (in.total == 0 || done < in.total)) {
     const int64_t start = br.pos >> 3;
-    if (br.bits(14) != 0x3ffe) return ERR_STREAM;
+    if (br.bits(14) != 0x3ffe) {
+      // STREAMINFO without a total: the stream ends where the frames end (trailing bytes such as an ID3v1 tag are not frames)
+      if (in.total == 0 && done > 0) break;
+      return ERR_STREAM;
+    }
     br.bits(1);
     br.bits(1);                                    // blocking strategy: the coded number is not needed for sequential decode
     const int bs_code = (int)br.bits(4), sr_code = (int)br.bits(4), ca = (int)br.bits(4), ss_code = (int)br.bits(3);
@@ -280,8 +284,10 @@ int decode_stream(const uint8_t* d, int64_t n, const Info& in, Sink&& sink) {
     const int64_t hdr_end = br.pos >> 3;
     const uint8_t want8 = (uint8_t)br.bits(8);
     if (br.fail || crc8(d + start, hdr_end - start) != want8) return ERR_STREAM;
+    if (ca > 10) return ERR_STREAM;                 // channel assignments 11-15 are reserved
     const int nch = ca < 8 ? ca + 1 : 2;
     if (nch != in.channels) return ERR_STREAM;
+    if (ca >= 8 && bps + 1 > 32) return ERR_STREAM; // a 33-bit side channel is beyond the 32-bit reads of BitReader
     for (int c = 0; c < nch; ++c) {
       ch[c].assign(blocksize, 0);
       const bool side = (ca == 8 && c == 1) || (ca == 9 && c == 0) || (ca == 10 && c == 1);

@@ -1,0 +1,306 @@
+// Epilogues shared by the bf16 NT GEMM kernels of gemm_pipe.hip (4 MFMA waves + 4 loader waves) and gemm_pp.hip (8 MFMA waves):
+// a wave owns MI x NI accumulator fragments of 16 x 16,
+//   acc[i][j][r] = C[m][n],  m = row0 + wrow + i*16 + (lane & 15),  n = col0 + wcol + j*16 + (lane >> 4)*4 + r
+// (the weight fragment is the MFMA's first operand, so a lane holds 4 CONSECUTIVE output columns of one row).
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "../../include/tasu_hip.h"
+
+namespace tasu_gemm {
+
+constexpr int OUT_GU_SWIGLU = 3;    // internal epilogue of tasu_gemm_gate_up_swiglu (after the three TASU_GEMM_OUT_* modes)
+
+struct Args {
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  const float* R;
+  const bf16* bias;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int tiles_m, tiles_n;
+  bf16* act;            // OUT_GU_SWIGLU: act[M, N] (N = I); C = gate|up [M, 2N]; B = Wgu [2N, K], gate rows first
+  // split-K (TASU_GEMM_OUT_F32 only): work item s covers K range [ks * K/ksplit, +K/ksplit) of output tile s % (tiles_m *
+  // tiles_n), ks = s / (tiles_m * tiles_n), and writes its fp32 partial tile into slab ks (C + ks * split_stride floats)
+  int ksplit;
+  long long split_stride;
+};
+
+// tile s of the virtual one-tile-per-block grid -> (tm, tn): XCD-aware (block b and tile s = b + r*gridDim share b % 8,
+// i.e. the XCD, because gridDim is a multiple of 8), bijective, then a GROUP_M-row-group raster for L2 reuse of the B panel.
+template <int GROUP_M = 4>
+__device__ __forceinline__ void tile_coords(const Args& p, int s, int ntiles, int& tm, int& tn) {
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = s & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (s >> 3);
+  const int per_group = GROUP_M * p.tiles_n;
+  const int gid = logical / per_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_g = logical - gid * per_group;
+  tm = first_m + in_g % gsz;
+  tn = in_g / gsz;
+}
+
+// a: lanes 16-31 / 48-63 receive b of lanes 0-15 / 32-47; b: lanes 0-15 / 32-47 receive a of lanes 16-31 / 48-63
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+#endif
+}
+
+// OUT_GU_SWIGLU epilogue: fragments j < NI/2 of a wave are gate columns, j >= NI/2 the up values of the SAME act columns
+// acol0 .. acol0 + 8*NI - 1 (the weight rows of a wave column are laid out that way by the loader): writes gate|up and
+// act = bf16(bf16(silu(gate)) * up).
+template <int MI, int NI, int BM>
+__device__ __forceinline__ void store_gu_swiglu(const Args& p, f32x4 (&acc)[MI][NI], int row0, int acol0, int wrow, int lane) {
+  int l15 = lane & 15, l4 = (lane >> 4) * 4;
+  asm volatile("" : "+v"(l15), "+v"(l4));
+  bf16* gu = (bf16*)p.C;
+  if constexpr (NI == 4) {
+    // paired 16-byte stores (see store_tile): gate fragments (0, 1) and up fragments (2, 3) each form one pair
+    if ((p.N & 7) == 0 && (((uintptr_t)gu | (uintptr_t)p.act) & 15) == 0) {
+      int cpair = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;
+      asm volatile("" : "+v"(cpair));
+      auto rows = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;     // whole tile inside the matrix: no per-lane tests
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          asm volatile("" ::: "memory");
+          const int m = row0 + wrow + i * 16 + l15;
+          union { bf16x4 h; unsigned u[2]; } g0, g1, u0, u1, a0, a1;
+          g0.h = __builtin_convertvector(acc[i][0], bf16x4), g1.h = __builtin_convertvector(acc[i][1], bf16x4);
+          u0.h = __builtin_convertvector(acc[i][2], bf16x4), u1.h = __builtin_convertvector(acc[i][3], bf16x4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            a0.h[r] = (bf16)(bf16_round(silu_f((float)g0.h[r])) * (float)u0.h[r]);
+            a1.h[r] = (bf16)(bf16_round(silu_f((float)g1.h[r])) * (float)u1.h[r]);
+          }
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            swap16(g0.u[d], g1.u[d]);
+            swap16(u0.u[d], u1.u[d]);
+            swap16(a0.u[d], a1.u[d]);
+          }
+          const int n = acol0 + cpair;                  // act column of this lane's 8 values
+          if (INTERIOR || (m < p.M && n < p.N)) {                   // N % 8 == 0: all eight or none
+            *(u32x4*)(gu + (size_t)m * (2 * (size_t)p.N) + n) = u32x4{g0.u[0], g0.u[1], g1.u[0], g1.u[1]};
+            *(u32x4*)(gu + (size_t)m * (2 * (size_t)p.N) + p.N + n) = u32x4{u0.u[0], u0.u[1], u1.u[0], u1.u[1]};
+            *(u32x4*)(p.act + (size_t)m * p.N + n) = u32x4{a0.u[0], a0.u[1], a1.u[0], a1.u[1]};
+          }
+        }
+      };
+      if (row0 + BM <= p.M && acol0 + 32 <= p.N) rows(std::true_type{});
+      else rows(std::false_type{});
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    asm volatile("" ::: "memory");
+    const int m = row0 + wrow + i * 16 + l15;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NI / 2; ++j) {
+      const int n = acol0 + j * 16 + l4;              // act column; N % 4 == 0
+      if (n >= p.N) continue;
+      const bf16x4 g4 = __builtin_convertvector(acc[i][j], bf16x4), u4 = __builtin_convertvector(acc[i][j + NI / 2], bf16x4);
+      bf16x4 a4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a4[r] = (bf16)(bf16_round(silu_f((float)g4[r])) * (float)u4[r]);
+      *(bf16x4*)(gu + (size_t)m * (2 * (size_t)p.N) + n) = g4;
+      *(bf16x4*)(gu + (size_t)m * (2 * (size_t)p.N) + p.N + n) = u4;
+      *(bf16x4*)(p.act + (size_t)m * p.N + n) = a4;
+    }
+  }
+}
+
+template <int MI, int NI, int OUT_MODE, bool HAS_BIAS, int BM, int BN, bool WIDE_RESID>
+__device__ __forceinline__ void store_tile(const Args& p, f32x4 (&acc)[MI][NI], int row0, int col0, int wrow, int wcol, int lane) {
+  // opaque copies of the lane coordinates: keeps the 32 per-fragment output addresses from being hoisted out of the
+  // tile loop into registers that the K loop needs (the kernel sits at the 256-VGPR limit of two waves per SIMD)
+  int l15 = lane & 15, l4 = (lane >> 4) * 4;
+  asm volatile("" : "+v"(l15), "+v"(l4));
+  // the bias depends on the column only: NI x 4 values per lane, loaded once per tile (not once per row block)
+  [[maybe_unused]] float bv[NI][4];
+  if (HAS_BIAS) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = col0 + wcol + j * 16 + l4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[j][r] = n + r < p.N ? (float)p.bias[n + r] : 0.f;
+    }
+  }
+  const bool interior = row0 + BM <= p.M && col0 + BN <= p.N;     // wave-uniform: the whole tile lies inside the matrix
+  if constexpr (OUT_MODE == TASU_GEMM_OUT_F32_RESID_BF16R && WIDE_RESID) {
+    // residual add: the fp32 residual rows of IB row blocks are fetched together (clamped addresses, no branches)
+    // before the first use -- one memory round trip per IB row blocks instead of one per fragment; with one tile per CU
+    // (N = 1536: o and down projections) nothing else hides this latency
+    if ((p.ldc & 3) == 0 && (p.N & 3) == 0 && (((uintptr_t)p.R | (uintptr_t)p.C) & 15) == 0) {
+      constexpr int IB = 2;                       // (the 256-row tiles have no registers to spare: fragment-wise path below)
+      static_assert(MI % IB == 0, "row blocks are processed in groups of IB");
+#pragma unroll
+      for (int i0 = 0; i0 < MI; i0 += IB) {
+        asm volatile("" ::: "memory");
+        f32x4 old[IB][NI];
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+          const int m = min(row0 + wrow + (i0 + ii) * 16 + l15, p.M - 1);
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const int n = min(col0 + wcol + j * 16 + l4, p.N - 4);
+            old[ii][j] = *(const f32x4*)(p.R + (size_t)m * p.ldc + n);
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+          const int m = row0 + wrow + (i0 + ii) * 16 + l15;
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const int n = col0 + wcol + j * 16 + l4;
+            f32x4 v = acc[i0 + ii][j];
+            if (HAS_BIAS) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
+            }
+            const f32x4 rr = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
+            if (interior || (m < p.M && n < p.N)) *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = old[ii][j] + rr;
+          }
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (OUT_MODE == TASU_GEMM_OUT_BF16 && NI % 2 == 0) {
+    // bf16 output: the epilogue is store-ISSUE bound (16 rows x 32 B per dwordx2 instruction).  Fragment pairs (j, j+1)
+    // trade halves between lanes l and l+16 (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows
+    // of the second), after which every lane holds 8 consecutive columns: one 16-byte store per pair, 64 B per row.
+    if ((p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0) {
+      int cpair = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;       // first of this lane's 8 columns inside the pair
+      asm volatile("" : "+v"(cpair));
+      auto rows = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;   // straight-line code: no per-lane edge tests
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          asm volatile("" ::: "memory");
+          const int m = row0 + wrow + i * 16 + l15;
+#pragma unroll
+          for (int j = 0; j < NI; j += 2) {
+            f32x4 v0 = acc[i][j], v1 = acc[i][j + 1];
+            if (HAS_BIAS) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v0[r] += bv[j][r], v1[r] += bv[j + 1][r];
+            }
+            union { bf16x4 h; unsigned u[2]; } a, b;
+            a.h = __builtin_convertvector(v0, bf16x4);
+            b.h = __builtin_convertvector(v1, bf16x4);
+            union { u32x4 q; bf16 h[8]; } o;
+            swap16(a.u[0], b.u[0]);
+            swap16(a.u[1], b.u[1]);
+            o.q = u32x4{a.u[0], a.u[1], b.u[0], b.u[1]};
+            const int n = col0 + wcol + j * 16 + cpair;
+            bf16* c = (bf16*)p.C + (size_t)m * p.ldc + n;
+            if constexpr (INTERIOR) {
+              *(u32x4*)c = o.q;
+            } else if (m < p.M) {
+              if (n + 8 <= p.N) {
+                *(u32x4*)c = o.q;
+              } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                  if (n + r < p.N) c[r] = o.h[r];
+              }
+            }
+          }
+        }
+      };
+      if (interior) rows(std::true_type{});
+      else rows(std::false_type{});
+      return;
+    }
+  }
+  if constexpr (OUT_MODE != TASU_GEMM_OUT_BF16) {
+    // fp32 outputs, interior tile, 16-byte aligned rows: straight-line code (the general loop below tests every fragment)
+    if (interior && (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0 &&
+        (OUT_MODE != TASU_GEMM_OUT_F32_RESID_BF16R || ((uintptr_t)p.R & 15) == 0)) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        asm volatile("" ::: "memory");
+        const size_t rowoff = (size_t)(row0 + wrow + i * 16 + l15) * p.ldc + (col0 + wcol + l4);
+        [[maybe_unused]] f32x4 old[NI];
+        if constexpr (OUT_MODE == TASU_GEMM_OUT_F32_RESID_BF16R) {
+#pragma unroll
+          for (int j = 0; j < NI; ++j) old[j] = *(const f32x4*)(p.R + rowoff + j * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          f32x4 v = acc[i][j];
+          if (HAS_BIAS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
+          }
+          if constexpr (OUT_MODE == TASU_GEMM_OUT_F32_RESID_BF16R)
+            v = old[j] + __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
+          *(f32x4*)((float*)p.C + rowoff + j * 16) = v;
+        }
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    asm volatile("" ::: "memory");               // one row block at a time: bounds the loads the scheduler batches
+    const int m = row0 + wrow + i * 16 + l15;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = col0 + wcol + j * 16 + l4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (HAS_BIAS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
+      }
+      const size_t off = (size_t)m * p.ldc + n;
+      const bool full = (n + 4 <= p.N) && ((off & 3) == 0);
+      if (OUT_MODE == TASU_GEMM_OUT_BF16) {
+        bf16* c = (bf16*)p.C + off;
+        const bf16x4 o = __builtin_convertvector(v, bf16x4);
+        if (full) {
+          *(bf16x4*)c = o;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) c[r] = o[r];
+        }
+      } else if (OUT_MODE == TASU_GEMM_OUT_F32) {
+        float* c = (float*)p.C + off;
+        if (full) {
+          *(f32x4*)c = v;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) c[r] = v[r];
+        }
+      } else {  // TASU_GEMM_OUT_F32_RESID_BF16R: C(fp32) = R(fp32) + bf16_round(result)
+        float* c = (float*)p.C + off;
+        const float* rs = p.R + off;
+        const f32x4 rr = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
+        if (full) {
+          const f32x4 old = *(const f32x4*)rs;
+          *(f32x4*)c = old + rr;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) c[r] = rs[r] + rr[r];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace tasu_gemm

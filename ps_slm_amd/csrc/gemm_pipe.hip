@@ -21,63 +21,17 @@
 // reads of step q-1 (lgkmcnt(0)); step q+1 is complete in LDS before barrier(q) because every loader waited for its own
 // share first.  The LDS image is lane-linear per 1-KiB piece (8 rows x 128 B), so the bank swizzle (16-B chunk c of row r
 // at chunk c ^ ((r>>1)&7)) is applied on the per-lane SOURCE offset and again on the ds_read_b128 address.
-#include <type_traits>
-#include <utility>
+#include <stdlib.h>
 
-#include "common.h"
-#include "../../include/tasu_hip.h"
-
-#if defined(TASU_EXP_B_DIRECT)                      // prototype (tools/bench_gemm_bdirect.py): B = fragment-order weights, global -> registers
-#define TASU_EXP_NO_B_READS
-#define TASU_EXP_NO_B_DMA
-#endif
+#include "gemm_epilogue.h"
 
 namespace tasu_pipe {
 
-constexpr int BK = 64;
-constexpr int OUT_GU_SWIGLU = 3;    // internal epilogue of tasu_gemm_gate_up_swiglu (after the three TASU_GEMM_OUT_* modes)
+using namespace tasu_gemm;
 
-struct Args {
-  const bf16* A;
-  const bf16* B;
-  void* C;
-  const float* R;
-  const bf16* bias;
-  int M, N, K;
-  int lda, ldb, ldc;
-  int tiles_m, tiles_n;
-  bf16* act;            // OUT_GU_SWIGLU: act[M, N] (N = I); C = gate|up [M, 2N]; B = Wgu [2N, K], gate rows first
-  // split-K (TASU_GEMM_OUT_F32 only): work item s covers K range [ks * K/ksplit, +K/ksplit) of output tile s % (tiles_m *
-  // tiles_n), ks = s / (tiles_m * tiles_n), and writes its fp32 partial tile into slab ks (C + ks * split_stride floats)
-  int ksplit;
-  long long split_stride;
-};
+constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) void lds_void;
-
-// tile s of the virtual one-tile-per-block grid -> (tm, tn): XCD-aware (block b and tile s = b + r*gridDim share b % 8,
-// i.e. the XCD, because gridDim is a multiple of 8), bijective, then a 4-row-group raster for L2 reuse of the B panel.
-__device__ __forceinline__ void tile_coords(const Args& p, int s, int ntiles, int& tm, int& tn) {
-  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = s & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (s >> 3);
-  constexpr int GROUP_M = 4;
-  const int per_group = GROUP_M * p.tiles_n;
-  const int gid = logical / per_group;
-  const int first_m = gid * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int in_g = logical - gid * per_group;
-  tm = first_m + in_g % gsz;
-  tn = in_g / gsz;
-}
-
-// a: lanes 16-31 / 48-63 receive b of lanes 0-15 / 32-47; b: lanes 0-15 / 32-47 receive a of lanes 16-31 / 48-63
-__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-  a = r[0];
-  b = r[1];
-#endif
-}
 
 template <int BM, int BN, int OUT_MODE, bool HAS_BIAS>
 __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
@@ -154,11 +108,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
                                                  vob[i], koff, (i & 3) * 1024, 0);
       };
       [&]<int... I>(std::integer_sequence<int, I...>) { (one_a(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, PA>{});
-#if !defined(TASU_EXP_NO_B_DMA)                    // (timing experiment, wrong results: the B tile never reaches LDS)
       [&]<int... I>(std::integer_sequence<int, I...>) { (one_b(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, PB>{});
-#else
-      (void)one_b;
-#endif
       if (++ld_k == nk) {
         ld_k = 0;
         ld_tile += gridDim.x;
@@ -166,11 +116,6 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
       }
     };
     auto wait_keep_one_step = [&]() {              // all but the newest K-step's pieces have landed
-#if defined(TASU_EXP_NO_B_DMA)
-      if constexpr (PA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      return;
-#endif
       if constexpr (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else if constexpr (NG == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -210,12 +155,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   auto read_frags = [&](bf16x8 (&fa)[MI], bf16x8 (&fb)[NI], int buf, int kk) {
     const char* sa = smem + buf * STAGE + a_base + roff[kk];
     const char* sb = smem + buf * STAGE + b_base + roff[kk];
-#if !defined(TASU_EXP_NO_B_READS)                  // (timing experiment, wrong results: the B fragments are never refreshed)
 #pragma unroll
     for (int j = 0; j < NI; ++j) fb[j] = *(const bf16x8*)(sb + j * 16 * 128);
-#else
-    (void)sb;
-#endif
 #pragma unroll
     for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(sa + i * 16 * 128);
   };
@@ -235,25 +176,6 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   };
 
   bf16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
-#if defined(TASU_EXP_NO_B_READS)
-#pragma unroll
-  for (int j = 0; j < NI; ++j) fb0[j] = fb1[j] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1};
-#endif
-#if defined(TASU_EXP_B_DIRECT)
-  // B comes from a fragment-order copy [tile_n][wave column][K-step][k-half][j][64 lanes][8] (p.B), one K-step ahead:
-  // gbn0 / gbn1 = the next step's fragments, requested at the top of a K-step and moved into fb0 / fb1 at its end
-  bf16x8 gbn0[NI], gbn1[NI];
-  constexpr size_t BSTEP = (size_t)2 * NI * 512;
-  auto b_tile = [&](int tn) { return p.B + (size_t)(tn * 2 + wc) * (p.K / BK) * BSTEP + lane * 8; };
-  auto load_b = [&](bf16x8 (&g0)[NI], bf16x8 (&g1)[NI], const bf16* src) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      g0[j] = *(const bf16x8*)(src + j * 512);
-      g1[j] = *(const bf16x8*)(src + (NI + j) * 512);
-    }
-  };
-  const bf16* bnext = nullptr;
-#endif
   zero_acc();
   __builtin_amdgcn_s_barrier();                    // step 0 is in LDS
   asm volatile("" ::: "memory");
@@ -264,9 +186,6 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   auto kstep = [&](auto more_tag, int cur) {
     constexpr bool MORE = decltype(more_tag)::value;
     const int nxt = cur == 2 ? 0 : cur + 1;
-#if defined(TASU_EXP_B_DIRECT)
-    load_b(gbn0, gbn1, bnext);
-#endif
     // ---------------- phase 1: MFMA(q, k-half 0)  ||  reads (q, k-half 1)
     read_frags(fa1, fb1, cur, 1);
     mma(fa0, fb0);
@@ -291,261 +210,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
       }
       __builtin_amdgcn_sched_group_barrier(0x008, NM - 2 * NR, 1);
     }
-#if defined(TASU_EXP_B_DIRECT)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      fb0[j] = gbn0[j];
-      fb1[j] = gbn1[j];
-    }
-#endif
     return nxt;
   };
 
-  // acc[i][j][r] = C[m][n], m = row0 + wr*WM + i*16 + (lane&15), n = col0 + wc*WN + j*16 + (lane>>4)*4 + r
-  // OUT_GU_SWIGLU epilogue: fragments j = 0, 1 of a wave are gate columns, j = 2, 3 the up values of the same columns
-  auto store_gu_swiglu = [&](int row0, int tn) {
-    int l15 = lane & 15, l4 = (lane >> 4) * 4;
-    asm volatile("" : "+v"(l15), "+v"(l4));
-    bf16* gu = (bf16*)p.C;
-    if constexpr (NI == 4) {
-      // paired 16-byte stores (see store_tile): gate fragments (0, 1) and up fragments (2, 3) each form one pair
-      if ((p.N & 7) == 0 && (((uintptr_t)gu | (uintptr_t)p.act) & 15) == 0) {
-        int cpair = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;
-        asm volatile("" : "+v"(cpair));
-        auto rows = [&](auto interior_tag) {
-          constexpr bool INTERIOR = decltype(interior_tag)::value;     // whole tile inside the matrix: no per-lane tests
-#pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            asm volatile("" ::: "memory");
-            const int m = row0 + wr * WM + i * 16 + l15;
-            union { bf16x4 h; unsigned u[2]; } g0, g1, u0, u1, a0, a1;
-            g0.h = __builtin_convertvector(acc[i][0], bf16x4), g1.h = __builtin_convertvector(acc[i][1], bf16x4);
-            u0.h = __builtin_convertvector(acc[i][2], bf16x4), u1.h = __builtin_convertvector(acc[i][3], bf16x4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              a0.h[r] = (bf16)(bf16_round(silu_f((float)g0.h[r])) * (float)u0.h[r]);
-              a1.h[r] = (bf16)(bf16_round(silu_f((float)g1.h[r])) * (float)u1.h[r]);
-            }
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-              swap16(g0.u[d], g1.u[d]);
-              swap16(u0.u[d], u1.u[d]);
-              swap16(a0.u[d], a1.u[d]);
-            }
-            const int n = tn * 64 + wc * 32 + cpair;                  // act column of this lane's 8 values
-            if (INTERIOR || (m < p.M && n < p.N)) {                   // N % 8 == 0: all eight or none
-              *(u32x4*)(gu + (size_t)m * (2 * (size_t)p.N) + n) = u32x4{g0.u[0], g0.u[1], g1.u[0], g1.u[1]};
-              *(u32x4*)(gu + (size_t)m * (2 * (size_t)p.N) + p.N + n) = u32x4{u0.u[0], u0.u[1], u1.u[0], u1.u[1]};
-              *(u32x4*)(p.act + (size_t)m * p.N + n) = u32x4{a0.u[0], a0.u[1], a1.u[0], a1.u[1]};
-            }
-          }
-        };
-        if (row0 + BM <= p.M && tn * 64 + 64 <= p.N) rows(std::true_type{});
-        else rows(std::false_type{});
-        return;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      asm volatile("" ::: "memory");
-      const int m = row0 + wr * WM + i * 16 + l15;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < NI / 2; ++j) {
-        const int n = tn * 64 + wc * 32 + j * 16 + l4;              // act column; N % 4 == 0
-        if (n >= p.N) continue;
-        const bf16x4 g4 = __builtin_convertvector(acc[i][j], bf16x4), u4 = __builtin_convertvector(acc[i][j + NI / 2], bf16x4);
-        bf16x4 a4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a4[r] = (bf16)(bf16_round(silu_f((float)g4[r])) * (float)u4[r]);
-        *(bf16x4*)(gu + (size_t)m * (2 * (size_t)p.N) + n) = g4;
-        *(bf16x4*)(gu + (size_t)m * (2 * (size_t)p.N) + p.N + n) = u4;
-        *(bf16x4*)(p.act + (size_t)m * p.N + n) = a4;
-      }
-    }
-  };
-
-  auto store_tile = [&](int row0, int col0) {
-    // opaque copies of the lane coordinates: keeps the 32 per-fragment output addresses from being hoisted out of the
-    // tile loop into registers that the K loop needs (the kernel sits at the 256-VGPR limit of two waves per SIMD)
-    int l15 = lane & 15, l4 = (lane >> 4) * 4;
-    asm volatile("" : "+v"(l15), "+v"(l4));
-    // the bias depends on the column only: NI x 4 values per lane, loaded once per tile (not once per row block)
-    [[maybe_unused]] float bv[NI][4];
-    if (HAS_BIAS) {
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = col0 + wc * WN + j * 16 + l4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[j][r] = n + r < p.N ? (float)p.bias[n + r] : 0.f;
-      }
-    }
-    const bool interior = row0 + BM <= p.M && col0 + BN <= p.N;     // wave-uniform: the whole tile lies inside the matrix
-    if constexpr (OUT_MODE == TASU_GEMM_OUT_F32_RESID_BF16R && BM == 128) {
-      // residual add: the fp32 residual rows of IB row blocks are fetched together (clamped addresses, no branches)
-      // before the first use -- one memory round trip per IB row blocks instead of one per fragment; with one tile per CU
-      // (N = 1536: o and down projections) nothing else hides this latency
-      if ((p.ldc & 3) == 0 && (p.N & 3) == 0 && (((uintptr_t)p.R | (uintptr_t)p.C) & 15) == 0) {
-        constexpr int IB = 2;                       // (the 256-row tiles have no registers to spare: fragment-wise path below)
-        static_assert(MI % IB == 0, "row blocks are processed in groups of IB");
-#pragma unroll
-        for (int i0 = 0; i0 < MI; i0 += IB) {
-          asm volatile("" ::: "memory");
-          f32x4 old[IB][NI];
-#pragma unroll
-          for (int ii = 0; ii < IB; ++ii) {
-            const int m = min(row0 + wr * WM + (i0 + ii) * 16 + l15, p.M - 1);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-              const int n = min(col0 + wc * WN + j * 16 + l4, p.N - 4);
-              old[ii][j] = *(const f32x4*)(p.R + (size_t)m * p.ldc + n);
-            }
-          }
-#pragma unroll
-          for (int ii = 0; ii < IB; ++ii) {
-            const int m = row0 + wr * WM + (i0 + ii) * 16 + l15;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-              const int n = col0 + wc * WN + j * 16 + l4;
-              f32x4 v = acc[i0 + ii][j];
-              if (HAS_BIAS) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
-              }
-              const f32x4 rr = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
-              if (interior || (m < p.M && n < p.N)) *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = old[ii][j] + rr;
-            }
-          }
-        }
-        return;
-      }
-    }
-    if constexpr (OUT_MODE == TASU_GEMM_OUT_BF16 && NI % 2 == 0) {
-      // bf16 output: the epilogue is store-ISSUE bound (16 rows x 32 B per dwordx2 instruction).  Fragment pairs (j, j+1)
-      // trade halves between lanes l and l+16 (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows
-      // of the second), after which every lane holds 8 consecutive columns: one 16-byte store per pair, 64 B per row.
-      if ((p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0) {
-        int cpair = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;       // first of this lane's 8 columns inside the pair
-        asm volatile("" : "+v"(cpair));
-        auto rows = [&](auto interior_tag) {
-          constexpr bool INTERIOR = decltype(interior_tag)::value;   // straight-line code: no per-lane edge tests
-#pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            asm volatile("" ::: "memory");
-            const int m = row0 + wr * WM + i * 16 + l15;
-#pragma unroll
-            for (int j = 0; j < NI; j += 2) {
-              f32x4 v0 = acc[i][j], v1 = acc[i][j + 1];
-              if (HAS_BIAS) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v0[r] += bv[j][r], v1[r] += bv[j + 1][r];
-              }
-              union { bf16x4 h; unsigned u[2]; } a, b;
-              a.h = __builtin_convertvector(v0, bf16x4);
-              b.h = __builtin_convertvector(v1, bf16x4);
-              union { u32x4 q; bf16 h[8]; } o;
-              swap16(a.u[0], b.u[0]);
-              swap16(a.u[1], b.u[1]);
-              o.q = u32x4{a.u[0], a.u[1], b.u[0], b.u[1]};
-              const int n = col0 + wc * WN + j * 16 + cpair;
-              bf16* c = (bf16*)p.C + (size_t)m * p.ldc + n;
-              if constexpr (INTERIOR) {
-                *(u32x4*)c = o.q;
-              } else if (m < p.M) {
-                if (n + 8 <= p.N) {
-                  *(u32x4*)c = o.q;
-                } else {
-#pragma unroll
-                  for (int r = 0; r < 8; ++r)
-                    if (n + r < p.N) c[r] = o.h[r];
-                }
-              }
-            }
-          }
-        };
-        if (interior) rows(std::true_type{});
-        else rows(std::false_type{});
-        return;
-      }
-    }
-    if constexpr (OUT_MODE != TASU_GEMM_OUT_BF16) {
-      // fp32 outputs, interior tile, 16-byte aligned rows: straight-line code (the general loop below tests every fragment)
-      if (interior && (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0 &&
-          (OUT_MODE != TASU_GEMM_OUT_F32_RESID_BF16R || ((uintptr_t)p.R & 15) == 0)) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          asm volatile("" ::: "memory");
-          const size_t rowoff = (size_t)(row0 + wr * WM + i * 16 + l15) * p.ldc + (col0 + wc * WN + l4);
-          [[maybe_unused]] f32x4 old[NI];
-          if constexpr (OUT_MODE == TASU_GEMM_OUT_F32_RESID_BF16R) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) old[j] = *(const f32x4*)(p.R + rowoff + j * 16);
-          }
-#pragma unroll
-          for (int j = 0; j < NI; ++j) {
-            f32x4 v = acc[i][j];
-            if (HAS_BIAS) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
-            }
-            if constexpr (OUT_MODE == TASU_GEMM_OUT_F32_RESID_BF16R)
-              v = old[j] + __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
-            *(f32x4*)((float*)p.C + rowoff + j * 16) = v;
-          }
-        }
-        return;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      asm volatile("" ::: "memory");               // one row block at a time: bounds the loads the scheduler batches
-      const int m = row0 + wr * WM + i * 16 + l15;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = col0 + wc * WN + j * 16 + l4;
-        if (n >= p.N) continue;
-        f32x4 v = acc[i][j];
-        if (HAS_BIAS) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
-        }
-        const size_t off = (size_t)m * p.ldc + n;
-        const bool full = (n + 4 <= p.N) && ((off & 3) == 0);
-        if (OUT_MODE == TASU_GEMM_OUT_BF16) {
-          bf16* c = (bf16*)p.C + off;
-          const bf16x4 o = __builtin_convertvector(v, bf16x4);
-          if (full) {
-            *(bf16x4*)c = o;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < p.N) c[r] = o[r];
-          }
-        } else if (OUT_MODE == TASU_GEMM_OUT_F32) {
-          float* c = (float*)p.C + off;
-          if (full) {
-            *(f32x4*)c = v;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < p.N) c[r] = v[r];
-          }
-        } else {  // TASU_GEMM_OUT_F32_RESID_BF16R: C(fp32) = R(fp32) + bf16_round(result)
-          float* c = (float*)p.C + off;
-          const float* rs = p.R + off;
-          const f32x4 rr = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
-          if (full) {
-            const f32x4 old = *(const f32x4*)rs;
-            *(f32x4*)c = old + rr;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < p.N) c[r] = rs[r] + rr[r];
-          }
-        }
-      }
-    }
+  // epilogues: gemm_epilogue.h (acc[i][j][r] = C[m][n], m = row0 + wr*WM + i*16 + (lane&15), n = col0 + wc*WN + j*16 + (lane>>4)*4 + r)
+  auto store_gu = [&](int row0, int tn) { store_gu_swiglu<MI, NI, BM>(p, acc, row0, tn * 64 + wc * 32, wr * WM, lane); };
+  auto store_c = [&](int row0, int col0) {
+    store_tile<MI, NI, OUT_MODE, HAS_BIAS, BM, BN, BM == 128>(p, acc, row0, col0, wr * WM, wc * WN, lane);
   };
 
   using T = std::true_type;
@@ -557,26 +228,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
     const int ks = s / base_tiles;
     tile_coords(p, s - ks * base_tiles, base_tiles, tm, tn);
     if constexpr (OUT_MODE == TASU_GEMM_OUT_F32) p.C = (float*)c_first + (size_t)ks * p.split_stride;   // slab of this K range
-#if defined(TASU_EXP_B_DIRECT)
-    const bf16* btile = b_tile(tn);
-    if (s == (int)blockIdx.x) load_b(fb0, fb1, btile);            // the workgroup's first tile: step 0 synchronously
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-      bnext = btile + (size_t)(kt + 1) * BSTEP;
-      cur = kstep(T{}, cur);
-    }
-    bnext = btile;                                 // (no next tile: a harmless re-read)
-    if (s + (int)gridDim.x < ntiles) {
-      int tm2, tn2;
-      tile_coords(p, s + (int)gridDim.x, base_tiles, tm2, tn2);
-      bnext = b_tile(tn2);
-    }
-    cur = kstep(F{}, cur);
-#else
     for (int kt = 0; kt + 1 < nk; ++kt) cur = kstep(T{}, cur);
     cur = kstep(F{}, cur);                         // no read-ahead into the next tile: the fragment registers are free
-#endif
-    if constexpr (OUT_MODE == OUT_GU_SWIGLU) store_gu_swiglu(tm * BM, tn);
-    else store_tile(tm * BM, tn * BN);             // for the epilogue, whose stores then drain under the next tile
+    if constexpr (OUT_MODE == OUT_GU_SWIGLU) store_gu(tm * BM, tn);
+    else store_c(tm * BM, tn * BN);             // for the epilogue, whose stores then drain under the next tile
     zero_acc();
     if (s + (int)gridDim.x < ntiles) read_frags(fa0, fb0, cur, 0);   // landed before the barrier of the step just done
   }
@@ -654,11 +309,32 @@ int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void
   }
 }
 
+int tasu_gemm_pp_gu_dispatch(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K, hipStream_t st);
+
 extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I,
                                         int K, void* stream) {
   using namespace tasu_pipe;
   if (!A || !Wgu || !gu || !act || M <= 0 || I <= 0 || I % 4 || K <= 0 || K % BK || lda % 8 || ldw % 8) return TASU_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)Wgu & 15) || ((uintptr_t)gu & 7) || ((uintptr_t)act & 7)) return TASU_ERR_ARG;
+  static const int forced = [] {                  // TASU_GEMM_GU_KERNEL=pipe|pp: A/B runs and tests of either kernel
+    const char* e = getenv("TASU_GEMM_GU_KERNEL");
+    return !e ? 0 : (e[0] == 'p' && e[1] == 'p' ? 2 : 1);
+  }();
+  if (forced == 2 && I % 128 == 0 && K >= 256 && K % 128 == 0)
+    return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream);
+  if (forced == 0) {
+    // tile policy as in tasu_gemm_nt_bf16_ws (gemm.hip): 256 x 256 tiles (128 act columns, gemm_pp.hip) where their coarser
+    // rounds cost less than the 1.19 x per-FLOP efficiency they bring (4096 x 17920 x 1536: 257 -> 218 us)
+    static const bool pp_on = [] {
+      const char* e = getenv("TASU_GEMM_PP");
+      return !(e && e[0] == '0');
+    }();
+    const long tm = (M + 255) / 256, cus = cu_count();
+    const double c128 = (double)((tm * ((I + 63) / 64) + cus - 1) / cus) * 0.5;
+    const double c256 = (double)((tm * ((I + 127) / 128) + cus - 1) / cus) / 1.19;
+    if (pp_on && I % 128 == 0 && K >= 256 && K % 128 == 0 && c256 < c128)
+      return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream);
+  }
   Args a;
   a.A = (const bf16*)A;
   a.B = (const bf16*)Wgu;

@@ -22,6 +22,7 @@ import os
 import random
 import re
 import struct
+import sys
 import wave
 from functools import partial
 
@@ -29,6 +30,11 @@ import numpy as np
 import torch
 import torch.distributed as dist
 from torch.utils.data import IterableDataset
+
+# loaded by the reference's SourceFileLoader outside any package (Multitask/utils/dataset_utils.py:14-25): no relative imports
+_PKG_PARENT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _PKG_PARENT not in sys.path:
+    sys.path.insert(0, _PKG_PARENT)
 
 SAMPLE_RATE = 16000
 
@@ -51,7 +57,7 @@ def read_flac(path):
     libtasu_hip.so (csrc/flac.hip: host code; every frame CRC and the STREAMINFO MD5 are verified)."""
     import ctypes
 
-    from . import _lib
+    from ps_slm_amd import _lib
     lib = _lib.load()
     blob = np.fromfile(path, dtype=np.uint8)
     info = (ctypes.c_int32 * 3)()
@@ -93,7 +99,7 @@ def audio_num_samples(path):
     if os.path.splitext(path)[1].lower() == ".flac":
         import ctypes
 
-        from . import _lib
+        from ps_slm_amd import _lib
         blob = np.fromfile(path, dtype=np.uint8, count=1 << 16)           # STREAMINFO sits at the front
         info, total = (ctypes.c_int32 * 3)(), ctypes.c_int64(0)
         if _lib.load().tasu_flac_info(blob.ctypes.data, blob.size, info, ctypes.byref(total)) == 0 and total.value:
@@ -146,7 +152,7 @@ class MultiTaskDataset(IterableDataset):
         self.sample_rate = SAMPLE_RATE
         self.frontend = frontend                    # callable(waveform float32) -> (features [T, D] tensor, T)
         if frontend is None:
-            from .frontend import WavFrontend
+            from ps_slm_amd.frontend import WavFrontend
             self.frontend = WavFrontend.from_encoder_path(cfg.get("encoder_path", None))
 
     @property

@@ -20,6 +20,7 @@ from .model import HD, StepState, rup
 
 NEG = -1.0e9
 DECODE_GRAPH_CACHE = 8   # decode-step graphs kept per model (LRU)
+BEAM_MAX_NB, BEAM_MAX_B, DECODE_MAX_CTX = 5, 256, 2048   # limits of tasu_beam_update / tasu_decode_step_prologue / tasu_attn_decode
 
 
 class BeamState:
@@ -108,7 +109,8 @@ class DeviceBeam:
         self.bp_tok = buf("bm_bptok", (max_new, B, nb), i32)
         self.bp_par = buf("bm_bppar", (max_new, B, nb), i32)
         # float32(t ** length_penalty) exactly as the host restatement computes it (python float power, then one rounding)
-        self.len_pow = up("bm_lenpow", np.array([np.float32(float(t) ** float(length_penalty)) for t in range(max_new + 2)],
+        # (index 0 is never read: a hypothesis has at least one token; 0 ** negative penalty would raise)
+        self.len_pow = up("bm_lenpow", np.array([1.0] + [np.float32(float(t) ** float(length_penalty)) for t in range(1, max_new + 2)],
                                                 dtype=np.float32))
         self.ctl = up("bm_ctl", np.zeros(2, dtype=np.int32))
         self.valid = up("bm_valid", np.asarray(valid, dtype=np.int32))
@@ -149,6 +151,15 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
     """st: a prepared state whose projector output (st.dev['y2']) is ready.  Returns LongTensor [B, n_new] (CPU)."""
     ops, geo, llm = model.ops, model.geo, model.llm
     B, S, nb = st.B, st.S, num_beams
+    # limits of the device beam search (tasu_beam_update, tasu_decode_step_prologue: include/tasu_hip.h), checked BEFORE the prefill
+    if not 1 <= nb <= BEAM_MAX_NB:
+        raise ValueError(f"num_beams={nb}: the device beam search serves 1..{BEAM_MAX_NB} beams")
+    if B > BEAM_MAX_B:
+        raise ValueError(f"{B} utterances per generate() call: the device beam search serves at most {BEAM_MAX_B}")
+    if S + max_new_tokens > DECODE_MAX_CTX:
+        raise ValueError(f"prompt {S} + max_new_tokens {max_new_tokens} exceeds the cache attention's context limit {DECODE_MAX_CTX}")
+    if max_new_tokens < 1:
+        raise ValueError("max_new_tokens must be >= 1")
     M, K = B * nb, 2 * nb
     D, I, H, G, V, L = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_vocab, geo.llm_layers
     Vp, LDQ, W = rup(V, 64), (H + 2 * G) * HD, G * HD
@@ -173,7 +184,7 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
 def layers_per_gemm(ops, geo, layers, final_norm, x, x2, xn, qkv, ao, act, cos, sin, kc, vc, index, kstart, slot, lens, M, ctx, ws,
                     normed=False):
     """One generated position through the decoder layers with one launch per GEMM (6-7 launches per layer): the path for more
-    than 64 beam rows and for geometries csrc/decode_mega.hip does not serve, and what the one-launch path is tested against.
+    than 64 beam rows as well (64-row chunks).
     In: x [M, D] fp32 (token embeddings; ``normed``: xn already holds layer 0's input norm of it); out: xn = the final-normed
     hidden state; K/V appended at ``slot``."""
     D, I, H, G, L = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, len(layers)
@@ -254,27 +265,12 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
     # (the weights are then streamed once per chunk; K/V, attention and top-k are not chunked).
     chunks = [(m0, min(64, M - m0)) for m0 in range(0, M, 64)]
     kcv, vcv = kc.view(L, M, ctx * W), vc.view(L, M, ctx * W)
-    # <= 64 rows at a geometry csrc/decode_mega.hip serves: the whole layer loop is ONE persistent launch per position
-    mega = bool(getattr(ops, "decode_layers_supported", None) and ops.decode_layers_supported(M, D, H, G, I, ctx))
-    if mega:
-        mega_ws = buf("dec_mega_ws", (ops.decode_layers_ws_bytes(L, D, H, G, I) + 256,), torch.uint8)
-        mega_ws = mega_ws[(-mega_ws.data_ptr()) % 256:]
-        table_key = (kc.data_ptr(), vc.data_ptr(), M, ctx, model._buf_gen)
-        if getattr(model, "_dec_table_key", None) != table_key:
-            model._dec_table = ops.decode_layer_table(llm.layers, kc, vc)
-            model._dec_table_key = table_key
-        table = model._dec_table
-
     def device_step():
         """One generated position for all M beams: beam reorder of the row index (parents of the previous step), then the
         28-layer single-token pass over the cache, lm_head, the per-row top-k and the beam update."""
         ops.decode_step_prologue(llm.embed, ids_d, x, llm.layers[0]["ln1"], xn, geo.rms_eps, pos_d, cos, sin, HD, geo.rope_theta, index,
                                  index_tmp, src_d, slot_d, nb, M, D, ctx)
-        if mega:
-            ops.decode_layers(table, L, x, llm.norm, xn, mega_ws, M, D, H, G, I, cos, sin, slot_d, index, kstart, lens_d, ctx,
-                              geo.rms_eps, scale)
-        else:
-            per_gemm_layers()
+        per_gemm_layers()
         for m0, mc in chunks:
             ops.gemm_skinny(xn[m0:m0 + mc], llm.head, logits[m0:m0 + mc], mc, V, D, ws)
         ops.logprob_topk(logits, M, V, K, bs.banned, 1, tv, ti)
@@ -290,7 +286,10 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
     # own prompt length).
     use_graphs = model.decode_graphs and model.device.type == "cuda"
     graphs, seen_cnt = model._dec_graphs, model._dec_seen
-    key = ("decode", B, S, nb, ctx, max_new_tokens, int(eos), int(min_length), mega, model._buf_gen)
+    # the launch / layout switches decide which kernels device_step issues: a graph captured under one setting must not be
+    # replayed under another (in-process A/B runs)
+    switches = tuple(bool(getattr(ops, n, False)) for n in ("use_stream", "dec_frag", "dec_frag_act", "dec_down_slabs", "dec_prologue"))
+    key = ("decode", B, S, nb, ctx, max_new_tokens, int(eos), int(min_length), switches, model._buf_gen)
 
     def run_step():
         if not use_graphs:
@@ -330,8 +329,6 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
                 if int(bs.done_host[0]):
                     break
         torch.cuda.synchronize()
-        if mega:
-            ops.decode_layers_check()
     else:
         while not int(bs.ctl[1]):
             run_step()

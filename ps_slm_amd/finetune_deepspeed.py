@@ -54,10 +54,7 @@ def get_custom_model_factory(model_config):
         if not alt.is_file():
             raise FileNotFoundError(f"Dataset py file {p.as_posix()} does not exist or is not a file.")
         p = alt
-    if p.resolve() == (Path(__file__).resolve().parent / "ps_slm.py"):
-        from . import ps_slm as module                                      # keep package-relative imports working
-    else:
-        module = load_module_from_py_file(p.as_posix())
+    module = load_module_from_py_file(p.as_posix())
     try:
         return getattr(module, func_name)
     except AttributeError:
@@ -119,10 +116,7 @@ def get_dataset(dataset_config, tokenizer, split, geo, rank, steps=20, batch_siz
         if not alt.is_file():
             raise FileNotFoundError(f"Dataset py file {module_path} does not exist or is not a file.")
         p = alt
-    if p.resolve() == (Path(__file__).resolve().parent / "dataset.py"):
-        from . import dataset as module                                     # keep package-relative imports working
-    else:
-        module = load_module_from_py_file(p.as_posix())
+    module = load_module_from_py_file(p.as_posix())
     return getattr(module, func_name)(dataset_config, tokenizer, split)
 
 

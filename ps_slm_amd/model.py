@@ -185,6 +185,16 @@ class LLMWeights:
         self.head_t = None     # bf16 [D, Vpad]
         self.norm = None       # fp32 [D]
         self._decode_ready = False
+        self._stale_ptrs = []  # row-major weight addresses whose fragment-order copies (ops._frag) belong to replaced weights
+
+    def _drop_weights(self):
+        """Before a reload: remember which registered decode copies die with the old tensors."""
+        for w in self.layers:
+            self._stale_ptrs += [w[k].data_ptr() for k in ("wqkv", "wo", "wgu", "wd")]
+        if self.head is not None:
+            self._stale_ptrs.append(self.head.data_ptr())
+        self.layers = []
+        self._decode_ready = False
 
     @staticmethod
     def _pair(w, device):
@@ -220,18 +230,24 @@ class LLMWeights:
         if self._decode_ready:
             return
         geo = self.geo
+        if self._stale_ptrs and hasattr(ops, "forget_decode_weights"):
+            ops.forget_decode_weights(self._stale_ptrs)           # copies of the weights this model held before a reload
+        self._stale_ptrs = []
+        self._decode_ready = True
+        # fragment-order copies are read only when the whole layer runs in fragment order (ops.begin_decode): at Qwen2.5-7B
+        # (D = 3584 streams as 7 x 512) it does not, and ~10 GB of copies would never be used
+        if hasattr(ops, "decode_frag_possible") and not ops.decode_frag_possible(geo.llm_dim, geo.llm_heads * HD):
+            return
         for w in self.layers:
             ops.register_decode_weight(w["wqkv"], "qkv", w["wqkv"].shape[0], geo.llm_heads, geo.llm_kv_heads)
             ops.register_decode_weight(w["wo"], "plain", w["wo"].shape[0])
             ops.register_decode_weight(w["wgu"], "swiglu", geo.llm_inter)
-            ops.register_decode_weight(w["wd"], "plain", w["wd"].shape[0])
+            ops.register_decode_weight(w["wd"], "plain", w["wd"].shape[0], slabs_ok=True)
         ops.register_decode_weight(self.head, "plain", self.head.shape[0])
-        self._decode_ready = True
 
     def load_reference_state_dict(self, sd, pre="llm."):
         geo = self.geo
-        self._decode_ready = False
-        self.layers = []
+        self._drop_weights()
         for l in range(geo.llm_layers):
             p = f"{pre}model.layers.{l}."
             self.add_layer(sd[p + "input_layernorm.weight"],
@@ -248,8 +264,7 @@ class LLMWeights:
         """Seeded N(0, 0.02) linears/embedding, ones norms (HF default init), generated ON DEVICE tensor by tensor
         (no pretrained weights exist on the benchmark box)."""
         geo, dev = self.geo, self.device
-        self.layers = []
-        self._decode_ready = False
+        self._drop_weights()
         g = torch.Generator(device=dev).manual_seed(seed)
         D, I, H, G = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads
 

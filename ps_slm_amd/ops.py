@@ -42,13 +42,7 @@ class HipOps:
         self.dec_frag_act = False      # ... including the MLP activation that feeds the down projection
         self.dec_down_slabs = os.environ.get("TASU_DECODE_DOWN_SLABS", "1") != "0"    # (begin_decode re-reads it)
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
-        # the decode step's layer loop as one persistent launch (csrc/decode_mega.hip).  EXPERIMENTAL, off by default: parity-green
-        # (bit-identical to the per-GEMM launches, tests/test_gpu_decode_mega.py) but slower on MI355X -- 2.03 vs 1.77 ms per
-        # position at 1.5B: a phase costs the same memory round trips as the kernel it replaces and the 1.5-us grid barrier
-        # buys nothing over a hipGraph launch.  TASU_DECODE_MEGA=1 selects it (A/B runs).
-        self.use_mega = os.environ.get("TASU_DECODE_MEGA", "0") == "1"
         self.dec_prologue = os.environ.get("TASU_DECODE_PROLOGUE", "1") != "0"    # the position's five set-up launches as one
-        self._mega_sync = None
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -68,6 +62,13 @@ class HipOps:
         ldc = c.stride(0) if ldc is None else ldc
         self._chk(self.lib.tasu_gemm_nt_bf16_ws(_p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), _p(resid), M, N, K, mode,
                                                 _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()), "tasu_gemm_nt_bf16_ws")
+
+    GEMM_KERNELS = {"pp256": 1, "pipe128": 2, "pipe192": 3, "pipe96": 4}
+
+    def gemm_on(self, kernel, a, b, c, M, N, K, bias=None, resid=None, mode=GEMM_BF16):
+        """gemm() on a NAMED kernel (tasu_gemm_nt_bf16_kernel), regardless of the dispatcher's tile policy: tests and tuning."""
+        self._chk(self.lib.tasu_gemm_nt_bf16_kernel(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(bias), _p(resid),
+                                                    M, N, K, mode, self.GEMM_KERNELS[kernel], self._stream()), "tasu_gemm_nt_bf16_kernel")
 
     def gemm_splitk(self, a, b, c, M, N, K, ksplit, ws):
         """c[M,N] (bf16) = a[M,K] @ b[N,K]^T with the K range cut into ``ksplit`` work items per output tile (fp32 partial
@@ -108,10 +109,21 @@ class HipOps:
     def end_decode(self):
         self.dec_frag = self.dec_frag_act = False
 
-    def register_decode_weight(self, w, kind, N, H=0, G=0):
+    def decode_frag_possible(self, D, HHD):
+        """The predicate begin_decode() uses for fragment-order operands: only then is a fragment-order weight copy ever read."""
+        return bool(self._stream_split(D) == 1 and self._stream_split(HHD) == 1 and D % 32 == 0 and HHD % 32 == 0)
+
+    def forget_decode_weights(self, ptrs):
+        """Drops the fragment-order copies registered for these row-major weight addresses (a model reloading its weights)."""
+        for p in ptrs:
+            self._frag.pop(p, None)
+
+    def register_decode_weight(self, w, kind, N, H=0, G=0, slabs_ok=False):
         """Load-time: a fragment-order copy of a decode-step weight (kind: 'plain' | 'swiglu' | 'qkv'), looked up by the
-        row-major tensor's address when a streaming GEMM is called with it."""
-        if not self.use_stream or w.data_ptr() in self._frag or self._stream_split(w.shape[1]) == 0:
+        row-major tensor's address when a streaming GEMM is called with it.  Only for a K the streaming kernels take in ONE
+        range -- or, ``slabs_ok`` (the down projection), in K-range slabs: no other copy is ever handed out by _wf()."""
+        ks = self._stream_split(w.shape[1])
+        if not self.use_stream or w.data_ptr() in self._frag or ks == 0 or (ks > 1 and not slabs_ok):
             return
         out = torch.empty(w.numel() if kind != "plain" else ((N + 15) // 16) * 16 * w.shape[1], dtype=torch.bfloat16, device=w.device)
         code = {"plain": 0, "swiglu": 2, "qkv": 3}[kind]
@@ -361,45 +373,6 @@ class HipOps:
         self.rope_table(pos, cos, sin, head_dim, theta)
         for m0 in range(0, M, 64):
             self.dec_rmsnorm(x[m0:m0 + 64], norm_w, xn[m0:m0 + 64], eps)
-
-    # ------------------------------------------------------------------ decode: the layer loop in one launch
-    def decode_layers_supported(self, M, D, H, G, I, ctx):
-        """True when tasu_decode_layers serves this decode (and the fragment-order weights it needs are registered)."""
-        return bool(self.use_mega and self.use_stream and self.dec_frag
-                    and self.lib.tasu_decode_layers_supported(M, D, H, G, I, ctx))
-
-    def decode_layers_ws_bytes(self, L, D, H, G, I):
-        return int(self.lib.tasu_decode_layers_ws_bytes(L, D, H, G, I))
-
-    def decode_layer_table(self, layers, kc, vc):
-        """Device array of tasu_decode_layer (include/tasu_hip.h) for the L decoder layers: fragment-order weight copies
-        (register_decode_weight), norms, and the layer's K / V cache."""
-        rows = []
-        for l, w in enumerate(layers):
-            frag = [self._frag[w[k].data_ptr()][0].data_ptr() for k in ("wqkv", "wo", "wgu", "wd")]
-            rows.append([frag[0], w["bqkv"].data_ptr(), frag[1], frag[2], frag[3], w["ln1"].data_ptr(), w["ln2"].data_ptr(),
-                         kc[l].data_ptr(), vc[l].data_ptr()])
-        return torch.tensor(rows, dtype=torch.int64).cuda()
-
-    def decode_layers(self, table, L, x0, final_norm, xn_out, ws, M, D, H, G, I, cos, sin, slot, index, kstart, lens, ctx, eps,
-                      scale):
-        """One generated position through all L decoder layers + the final norm in ONE launch (tasu_decode_layers)."""
-        if self._mega_sync is None:
-            self._mega_sync = torch.zeros(self.lib.tasu_decode_layers_sync_words(), dtype=torch.int32, device="cuda")
-        self._chk(self.lib.tasu_decode_layers(_p(table), L, _p(x0), _p(final_norm), _p(xn_out), _p(ws), ws.numel() * ws.element_size(),
-                                              _p(self._mega_sync), M, D, H, G, I, _p(cos), _p(sin), _p(slot), _p(index), _p(kstart),
-                                              _p(lens), ctx, eps, scale, self._stream()), "tasu_decode_layers")
-
-    def decode_layers_check(self):
-        """Raises if a grid barrier of tasu_decode_layers timed out since the last check (its results are then invalid); the
-        barrier state is reset.  Synchronises: call after a generate(), not per position."""
-        if self._mega_sync is None:
-            return
-        n = int(self._mega_sync[1])
-        if n:
-            self._mega_sync.zero_()
-            raise TasuOpError(f"tasu_decode_layers: {n} grid-barrier time-outs (a workgroup of the persistent grid was not "
-                              f"resident); the decode results are invalid.  TASU_DECODE_MEGA=0 selects the per-GEMM launches.")
 
     def rope_append(self, qkv, cos, sin, kc, vc, pos, M, H, G, ctx):
         self._chk(self.lib.tasu_rope_append(_p(qkv), _p(cos), _p(sin), _p(kc), _p(vc), _p(pos), M, H, G, ctx, self._stream()),

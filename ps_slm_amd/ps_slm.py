@@ -13,12 +13,20 @@ import json
 import logging
 import os
 import re
+import sys
 from types import SimpleNamespace
 
 import numpy as np
 import torch
 
-from .model import Geometry, TasuModel
+# The reference loads a plugin with SourceFileLoader under the module name "<file name>", outside any package
+# (Multitask/utils/dataset_utils.py:14-25), so this file cannot use package-relative imports: make the package importable
+# by its absolute name from wherever the file lies, then import it like any other client would.
+_PKG_PARENT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _PKG_PARENT not in sys.path:
+    sys.path.insert(0, _PKG_PARENT)
+
+from ps_slm_amd.model import Geometry, TasuModel  # noqa: E402
 
 logger = logging.getLogger(__name__)
 
@@ -109,7 +117,7 @@ def geometry_from_config(model_config) -> Geometry:
         elif name in ("qwen2.5-7b", "7b"):
             geo = Geometry.qwen25_7b()
         elif name == "mid":
-            from .synthetic import MID_GEOMETRY
+            from ps_slm_amd.synthetic import MID_GEOMETRY
             geo = Geometry.from_dict(MID_GEOMETRY)
         else:
             raise ValueError(f"unknown synthetic geometry {name!r}")
@@ -183,7 +191,7 @@ def model_factory(train_config, model_config, **kwargs):
         device = f"cuda:{int(os.environ.get('LOCAL_RANK', train_config.get('device', 0) or 0))}"
     ops = kwargs.get("ops", None)
     if ops is None:
-        from .ops import HipOps     # raises if libtasu_hip.so is missing or there is no GPU: no fallback
+        from ps_slm_amd.ops import HipOps     # raises if libtasu_hip.so is missing or there is no GPU: no fallback
         ops = HipOps()
     core = TasuModel(geo, ops, device, keep_logits=bool(kwargs.get("keep_logits", True)))
     llm_path = str(model_config.get("llm_path", ""))
@@ -336,7 +344,7 @@ class slam_model_asr:
     @torch.no_grad()
     def generate(self, input_ids=None, input_features=None, attention_mask=None, input_feature_length=None,
                  targets=None, **kwargs):
-        from .decode import beam_search_generate
+        from ps_slm_amd.decode import beam_search_generate
         core = self.core
         if self.gt_emb:                                     # ps-slm.py:590-598
             texts = [re.sub(r"[^A-Za-z\s.,!?]+", "", t).lower().strip() for t in targets]

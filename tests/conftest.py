@@ -80,6 +80,8 @@ def decode_margin_cases():
     from ps_slm_amd.synthetic import MID_GEOMETRY, decode_fixture_state_dict
 
     z = load_npz("mid_generate_margin")
+    # the generator COUNTS stable cases its CPU double (the product's host code) got wrong instead of dropping them
+    assert int(z["double_disagreements"]) == 0
     geo = Geometry.from_dict(MID_GEOMETRY)
     sd = decode_fixture_state_dict(geo, int(z["seed_w"]))
     cases = []

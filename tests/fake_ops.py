@@ -467,7 +467,7 @@ class FakeOps:
     def end_decode(self):
         pass
 
-    def register_decode_weight(self, w, kind, N, H=0, G=0):
+    def register_decode_weight(self, w, kind, N, H=0, G=0, slabs_ok=False):
         pass
 
     def dec_rmsnorm(self, x, w, y, eps):

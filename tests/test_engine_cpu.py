@@ -227,7 +227,52 @@ def test_plugin_loader_errors_match_reference():
         get_custom_model_factory(ModelConfig(file="nope/ps_slm.py:model_factory"))
     with pytest.raises(AttributeError):
         get_custom_model_factory(ModelConfig(file="ps_slm_amd/ps_slm.py:not_there"))
-    assert get_custom_model_factory(ModelConfig(file="ps_slm_amd/ps_slm.py:model_factory")) is model_factory
+    f = get_custom_model_factory(ModelConfig(file="ps_slm_amd/ps_slm.py:model_factory"))
+    assert f.__name__ == "model_factory" and f.__module__ == "ps_slm.py"      # module name = file name, like the reference
+
+
+_REFERENCE_LOADER = """
+import importlib, importlib.machinery, importlib.util, sys
+from pathlib import Path
+
+def load_module_from_py_file(py_file):               # Multitask/utils/dataset_utils.py:14-25, restated
+    module_name = Path(py_file).name
+    loader = importlib.machinery.SourceFileLoader(module_name, py_file)
+    spec = importlib.util.spec_from_loader(module_name, loader)
+    module = importlib.util.module_from_spec(spec)
+    loader.exec_module(module)
+    return module
+
+assert not any(p.rstrip("/").endswith("repo") for p in sys.path), sys.path
+sys.path.insert(0, sys.argv[2])                      # tests/ only (fake_ops), NOT the repository root
+model_mod = load_module_from_py_file(sys.argv[1] + "/ps_slm_amd/ps_slm.py")
+data_mod = load_module_from_py_file(sys.argv[1] + "/ps_slm_amd/dataset.py")
+factory = getattr(model_mod, "model_factory")        # Multitask/utils/model_utils.py:28-29
+assert callable(getattr(data_mod, "get_speech_dataset"))
+from fake_ops import FakeOps
+from ps_slm_amd.config import ModelConfig, TrainConfig
+tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True)
+mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+model, tok = factory(tc, mc, device="cpu", ops=FakeOps(), init_seed=1)
+assert sorted(model.state_dict())[0].startswith("encoder_projector.")
+print("LOADED", type(model).__name__, model_mod.__name__, data_mod.__name__)
+"""
+
+
+def test_reference_loader_loads_the_plugins(tmp_path):
+    """The reference's own SourceFileLoader recipe (module name = file name, no package, repository root NOT on sys.path,
+    another working directory) gets ``model_factory`` and ``get_speech_dataset`` out of the two plugin files and the
+    factory builds a model."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ref_loader.py"
+    script.write_text(_REFERENCE_LOADER)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, str(script), repo, os.path.join(repo, "tests")], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "LOADED slam_model_asr ps_slm.py dataset.py" in r.stdout
 
 
 def test_train_loop_and_checkpoint_roundtrip(tmp_path):

@@ -84,14 +84,16 @@ def _two_rank_worker(rank, world, port, ret):
         call = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"], input_features=None,
                     input_feature_length=None, GT=[" ".join(map(str, p)) for p in raw["post_ids"]])
         eng.time_exchange = True
-        losses = []
-        for _ in range(4):                                   # eager, captured, replayed, replayed (decoder backward as a graph)
+        losses, p1 = [], None
+        for i in range(4):                                   # eager, captured, replayed, replayed (decoder backward as a graph)
             out, _ = eng(**call)
             eng.backward(out.loss)
             eng.step()
             losses.append(float(out.loss))
+            if i == 0:
+                p1 = model.core.proj.p.cpu().clone()         # the replica after the FIRST rank-averaged update
         torch.cuda.synchronize()
-        ret[rank] = dict(losses=losses, p=model.core.proj.p.cpu().clone(), waits=len(eng.exposed_events))
+        ret[rank] = dict(losses=losses, p=model.core.proj.p.cpu().clone(), p1=p1, waits=len(eng.exposed_events))
     finally:
         dist.destroy_process_group()
 
@@ -111,9 +113,11 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas():
     assert torch.equal(r0["p"], r1["p"]), "replicas diverged"
     assert r0["waits"] == 4 * 6 and r1["waits"] == 4 * 6
     assert r0["losses"][-1] < r0["losses"][0] and r1["losses"][-1] < r1["losses"][0]
-    # single-process replay of the FIRST step: gradients of both ranks' batches averaged by hand
+    # single-process replay of the FIRST step: both ranks' gradients computed here, averaged by hand (sum, then the 1/world
+    # the AdamW kernel applies), one AdamW step -- must EQUAL rank 0's replica after its first update, bit for bit (a two-term
+    # fp32 sum is order-independent, AdamW is elementwise, the kernels are run-to-run deterministic)
     model, eng = build(False, None, graphs=False)
-    grads = []
+    grads, losses = [], []
     for rank in range(2):
         raw = synthetic_text_batch(model.core.geo, 3, seed=50 + rank, prompt_len=9, n_audio=21, target_len=17, speech_pos=4,
                                    feat_frames=8, noise=False, ragged=True)
@@ -121,4 +125,13 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas():
                      input_feature_length=None, GT=[" ".join(map(str, p)) for p in raw["post_ids"]])
         eng.backward(out.loss)
         grads.append(model.core.proj.g.clone())
-    assert abs(float(out.loss) - r1["losses"][0]) < 1e-6
+        losses.append(float(out.loss))
+    assert abs(losses[0] - r0["losses"][0]) < 1e-6 and abs(losses[1] - r1["losses"][0]) < 1e-6
+    assert not torch.equal(grads[0], grads[1])                # the ranks really saw different batches
+    model.core.proj.g.copy_(grads[0] + grads[1])
+    eng.world = 2                                             # grad_scale = 1/world inside the AdamW kernel: 0.5 * (g0 + g1)
+    eng._last_state = None
+    eng.step()
+    torch.cuda.synchronize()
+    assert torch.equal(model.core.proj.p.cpu(), r0["p1"]), "the 2-rank update is not the AdamW step on the averaged gradient"
+    assert torch.equal(r0["p1"], r1["p1"])

@@ -134,3 +134,57 @@ def test_training_entrypoint_with_graph_replay_on_a_corpus(tmp_path):
     assert eager["steps"] == graphs["steps"] and eager["steps"] >= 4
     assert abs(eager["avg_train_loss"] - graphs["avg_train_loss"]) < 2e-3, (eager, graphs)
     assert abs(eager["avg_train_acc"] - graphs["avg_train_acc"]) < 0.02, (eager, graphs)
+
+
+def test_decode_entrypoint_on_a_corpus(tmp_path):
+    """Row a18 -- ``inference_batch.main`` (reference loop: Multitask/inference_batch.py:139-151) on a generated wav-in-ark test
+    split at full geometry (audio branch: fbank -> encoder -> PSD -> projector -> beam-4 generate): one ``key\\ttext`` line per
+    utterance in ``{decode_log}_pred`` / ``_gt``, in dataset order; the ``_gt`` text is the dataset's target; the ``_pred``
+    text is ``batch_decode(generate(**batch))`` of the same batches driven by hand (same seed, same plugin)."""
+    import json
+    import dataset_fixtures as fx
+    from ps_slm_amd.config import parse_args
+    from ps_slm_amd.finetune_deepspeed import get_custom_model_factory, get_dataset
+    from ps_slm_amd.inference_batch import main as decode_main
+    test = fx.write_corpus(str(tmp_path), split_sizes=(("test", 7),))["test"]
+    with open(tmp_path / "multiprompt.jsonl", "w") as f:
+        for task, prompt in (("ASR", "11 12 13"), ("ST", "21 22"), ("hotword", "31 32 33 34")):
+            f.write(json.dumps({"task": task, "prompt": prompt}) + "\n")
+    argv = ["++model_config.file=ps_slm_amd/ps_slm.py:model_factory", "++model_config.llm_path=synthetic:qwen2.5-1.5b",
+            "++model_config.llm_dim=1536", "++model_config.encoder_dim=25055", "++model_config.encoder_projector=linear-silu",
+            "++train_config.freeze_llm=true", "++train_config.gt_emb=false", "++train_config.ctc_posterior=true",
+            "++train_config.do_psd=true", "++dataset_config.file=ps_slm_amd/dataset.py:get_speech_dataset",
+            f"++dataset_config.test_scp_file_path={test}", f"++dataset_config.multitask_prompt_path={tmp_path}/multiprompt.jsonl",
+            "++dataset_config.prompt_style={} 151665", "++dataset_config.inference_mode=true",
+            "++dataset_config.eval_max_frame_length=20", "++dataset_config.ds_rate=8", "++max_new_tokens=10",
+            f"++decode_log={tmp_path}/out/decode_log"]
+    pred_path, gt_path = decode_main(argv)
+    assert pred_path == f"{tmp_path}/out/decode_log_pred" and gt_path == f"{tmp_path}/out/decode_log_gt"
+    pred = [l.rstrip("\n").split("\t") for l in open(pred_path)]
+    gt = [l.rstrip("\n").split("\t") for l in open(gt_path)]
+    assert len(pred) == len(gt) == 7 and all(len(p) == 2 for p in pred) and all(len(g) == 2 for g in gt)
+    assert [p[0] for p in pred] == [g[0] for g in gt]
+    # the same loop by hand
+    cfg = parse_args(argv)
+    torch.manual_seed(cfg.train_config.seed)
+    import random as _random
+    _random.seed(cfg.train_config.seed)
+    factory = get_custom_model_factory(cfg.model_config)
+    model, tok = factory(cfg.train_config, cfg.model_config, device="cuda:0", with_encoder=True)
+    model.eval()
+    ds = get_dataset(cfg.dataset_config, tok, "test", model.core.geo, 0)
+    keys, texts, targets, nb = [], [], [], 0
+    for raw in ds:
+        batch = ds.collator(raw)
+        k, t = batch.pop("keys"), batch.pop("targets")
+        batch.pop("GT", None)
+        out = model.generate(**batch, targets=t, max_new_tokens=10)
+        assert out.dtype == torch.int64 and out.shape[0] == len(k) and out.shape[1] <= 10
+        keys += k
+        targets += t
+        texts += [s.replace("\n", " ") for s in model.tokenizer.batch_decode(out, add_special_tokens=False, skip_special_tokens=True)]
+        nb += 1
+    assert nb >= 2                                                    # dynamic batching cut the split into several batches
+    assert [p[0] for p in pred] == keys and [g[1] for g in gt] == targets
+    assert [p[1] for p in pred] == texts
+    assert any(p[1] for p in pred)                                    # something was decoded

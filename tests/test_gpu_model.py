@@ -249,7 +249,7 @@ def test_linear_projector_on_gpu(k):
 
 
 def test_generate_margin_cases_exact_on_gpu():
-    """Token ids are index work: on the 14 rounding-stable decode cases of tests/golden/mid_generate_margin.npz (1-4 beams,
+    """Token ids are index work: on the 17 rounding-stable decode cases of tests/golden/mid_generate_margin.npz (14 short + 3 with 40-50 generated positions; 1-4 beams,
     min_length, length penalties, left padding, EOS events; oracle/make_golden_generate_margin.py) the HIP decode path must
     EQUAL the REAL reference's generate() tokens -- which the bf16 oracle and the CPU double also reproduce exactly
     (tests/test_oracle_golden.py, tests/test_host_model_cpu.py)."""

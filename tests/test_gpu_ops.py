@@ -79,6 +79,46 @@ def test_gemm(hip, fake, M, N, K, mode, bias):
     assert torch.equal(gc.cpu()[:, N:], cc[:, N:]), "columns beyond N must be untouched"
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (300, 520, 384), (1000, 1000, 1536), (257, 72, 256), (768, 2304, 1280)])
+@pytest.mark.parametrize("mode,bias", [(0, False), (0, True), (1, True), (2, False)])
+def test_gemm_pp256_kernel(hip, fake, M, N, K, mode, bias):
+    """The 256 x 256 eight-wave kernel (csrc/gemm_pp.hip) called by name: against the fp32 double, and BIT FOR BIT against the
+    loader-wave kernel of gemm_pipe.hip (both accumulate every output element over K in the same order).  Shapes with edge tiles
+    in both directions (rows / columns past the matrix are clipped by the buffer descriptor, not per lane), 1 to 27 tiles per
+    workgroup stream, 4 to 24 K-tiles."""
+    ldc = (N + 63) // 64 * 64
+    a = randn(M, K, dtype=BF, seed=1)
+    b = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
+    bv = randn(N, dtype=BF, seed=3) if bias else None
+    c = torch.zeros(M, ldc, dtype=BF if mode == 0 else F32)
+    r = randn(M, ldc, seed=4) if mode == 2 else None
+    cc, g_pp, g_pipe = c.clone(), c.cuda(), c.cuda()
+    fake.gemm(a, b, cc, M, N, K, bias=bv, resid=r, mode=mode)
+    ad, bd = a.cuda(), b.cuda()
+    hip.gemm_on("pp256", ad, bd, g_pp, M, N, K, bias=dev(bv), resid=dev(r), mode=mode)
+    hip.gemm_on("pipe128", ad, bd, g_pipe, M, N, K, bias=dev(bv), resid=dev(r), mode=mode)
+    torch.cuda.synchronize()
+    assert rel_err(g_pp, cc) < (1e-2 if mode != 1 else 2e-5 * math.sqrt(K))
+    assert torch.equal(g_pp.cpu()[:, N:], cc[:, N:]), "columns beyond N must be untouched"
+    assert torch.equal(g_pp, g_pipe)
+
+
+def test_gemm_pp256_many_tiles_per_workgroup(hip):
+    """4096 x 17920 x 1536 (gate|up of the benchmark: 1120 tiles, 4 or 5 per workgroup, the stream of K-tiles crosses tile
+    boundaries) and 2048 x 9000 x 256 (4 K-tiles per tile: every K-tile pair stages into the next tile): bit-identical to the
+    loader-wave kernel, run twice (bitwise repeatable: no race on the LDS ring)."""
+    for M, N, K in ((4096, 17920, 1536), (2048, 9000, 256)):
+        a = randn(M, K, dtype=BF, seed=5).cuda()
+        b = randn(N, K, dtype=BF, seed=6, scale=1.0 / math.sqrt(K)).cuda()
+        ldc = (N + 63) // 64 * 64
+        c1, c2, c3 = (torch.zeros(M, ldc, dtype=BF).cuda() for _ in range(3))
+        hip.gemm_on("pp256", a, b, c1, M, N, K)
+        hip.gemm_on("pipe128", a, b, c2, M, N, K)
+        hip.gemm_on("pp256", a, b, c3, M, N, K)
+        torch.cuda.synchronize()
+        assert torch.equal(c1, c2) and torch.equal(c1, c3)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gemm_unaligned_output_rows(hip, fake, mode):
     """ldc = N = 203: rows of C are neither 16- nor 8-byte aligned, so the kernels take their element-wise epilogues."""
@@ -116,7 +156,7 @@ def test_gemm_split_k(hip, fake, M, N, K, mode):
     assert int(hip.gemm_ws[:4096 * 4].view(torch.int32).abs().sum()) == 0
 
 
-@pytest.mark.parametrize("M,I,K", [(4096, 8960, 1536), (300, 200, 128), (257, 72, 64), (64, 96, 256)])
+@pytest.mark.parametrize("M,I,K", [(4096, 8960, 1536), (300, 200, 128), (257, 72, 64), (64, 96, 256), (4096, 8192, 256), (1100, 4480, 384)])
 def test_gemm_gate_up_swiglu(hip, fake, M, I, K):
     """Fused epilogue == GEMM followed by swiglu_fwd: same gate|up bits, same activation bits."""
     a = randn(M, K, dtype=BF, seed=1).cuda()

@@ -465,7 +465,7 @@ def test_cps_noise_draws_and_posterior_vs_reference():
 
 def test_generate_margin_cases_exact_on_the_double():
     """Product decode loop (prefill, KV cache + row index, per-row top-k, beam bookkeeping) on the CPU double against the REAL
-    reference's tokens on the 14 rounding-stable cases of tests/golden/mid_generate_margin.npz: exact equality."""
+    reference's tokens on the 17 rounding-stable cases (3 of them 40-50 positions long) of tests/golden/mid_generate_margin.npz: exact equality."""
     from conftest import decode_margin_cases
     from ps_slm_amd.decode import beam_search_generate
     geo, sd, cases = decode_margin_cases()

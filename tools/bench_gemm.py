@@ -18,6 +18,7 @@ ap.add_argument("--only", default="")
 ap.add_argument("--vendor", action="store_true", help="also time torch.matmul (rocBLAS / hipBLASLt) on the same operand sets")
 ap.add_argument("--check", action="store_true", help="compare against torch.matmul (rocBLAS) on the same bits")
 ap.add_argument("--shape", action="append", default=[], help="extra M,N,K (repeatable); implies --only custom")
+ap.add_argument("--pad", type=int, default=0, help="operand row pitch = K + pad elements (L2 channel experiment)")
 args = ap.parse_args()
 ops = HipOps()
 M = args.M
@@ -35,11 +36,12 @@ for name, m, n, k in shapes:
         continue
     per_set = 2 * (m * k + n * k + m * n)
     nsets = max(2, min(16, -(-(3 << 29) // per_set))) if args.cold else 1
-    a0 = torch.randn(m, k, device="cuda").to(torch.bfloat16)
-    b0 = (torch.randn(n, k, device="cuda") * k ** -0.5).to(torch.bfloat16)
+    ap0 = torch.randn(m, k + args.pad, device="cuda").to(torch.bfloat16)             # padded pitch; the operands are views
+    bp0 = (torch.randn(n, k + args.pad, device="cuda") * k ** -0.5).to(torch.bfloat16)
+    a0, b0 = ap0[:, :k], bp0[:, :k]
     sets = [(a0, b0, torch.empty(m, n, device="cuda", dtype=torch.bfloat16))]
     for _ in range(nsets - 1):
-        sets.append((a0.clone(), b0.clone(), torch.empty(m, n, device="cuda", dtype=torch.bfloat16)))
+        sets.append((ap0.clone()[:, :k], bp0.clone()[:, :k], torch.empty(m, n, device="cuda", dtype=torch.bfloat16)))
     for i in range(max(3, nsets)):
         a, b, c = sets[i % nsets]
         ops.gemm(a, b, c, m, n, k)
