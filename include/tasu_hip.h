@@ -74,6 +74,12 @@ int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, v
 int tasu_gemm_nt_bf16_splitk(const void* A, int lda, const void* B, int ldb, float* partials, int ldc, int M, int N, int K,
                              int ksplit, void* stream);
 int tasu_sum_slabs_bf16(const float* slabs, int n_slabs, int64_t slab_stride, void* out_bf16, int64_t n, void* stream);
+/* The same K-range slabs from the 256 x 256 eight-wave kernel (csrc/gemm_pp.hip): for outputs that fill the chip neither with
+ * 256 x 256 tiles nor (efficiently) with small ones behind a long K -- the decoder's N = 1536 projections at K = 8960 / 17920,
+ * where a CU's L2 -> LDS ingest per FLOP, not the matrix pipe, bounds the 128 x 192 one-tile-per-CU grid.
+ * K % (128 * ksplit) == 0 and K / ksplit >= 256. */
+int tasu_gemm_nt_bf16_slabs(const void* A, int lda, const void* B, int ldb, float* partials, int ldc, int M, int N, int K,
+                            int ksplit, void* stream);
 
 /* Weight-streaming GEMM for M <= 64 rows (the decode step; transformers modeling_qwen2.py linears at one token per beam).
  * workspace: fp32 split-K slabs, 32 * 64 * round_up(N, 96) floats always suffice; may be NULL (no K split).  Launches

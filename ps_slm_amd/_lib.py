@@ -74,6 +74,7 @@ PROTOTYPES = {
     "tasu_rmsnorm_fwd_frag": [vp, vp, vp, i32, i32, f32, vp],
     "tasu_to_fragment_order": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "tasu_gemm_nt_bf16_splitk": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "tasu_gemm_nt_bf16_slabs": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "tasu_sum_slabs_bf16": [vp, i32, i64, vp, i64, vp],
     "tasu_flac_info": [vp, i64, vp, vp],
     "tasu_flac_decode": [vp, i64, vp, i64, vp],

@@ -418,14 +418,19 @@ extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int l
         const double c128 = cost(t128, 256.0 * 128, 1.00), c192 = cost(t192, 128.0 * 192, 0.86), c96 = cost(t96, 256.0 * 96, 0.80);
         use_pipe_bn = c128 <= c192 && c128 <= c96 ? 128 : (c192 <= c96 ? 192 : 96);
         // the 256 x 256 eight-wave kernel (gemm_pp.hip): 2/3 of the L2 -> LDS bytes per FLOP of the 256 x 128 tile.  Measured on
-        // whole rounds at K = 1536 (4096 x 16384: 1199 vs 972 TFLOP/s) its per-FLOP efficiency is 1.19-1.23 x that tile's, so
-        // it wins wherever its coarser rounds do not eat that up (gate|up, d_down, lm_head; not the one-round N = 1536 grids)
+        // whole rounds at K = 1536 (4096 x 16384: 1232 vs 995 TFLOP/s) its per-FLOP efficiency is 1.24 x that tile's, so it wins
+        // wherever its coarser rounds do not eat that up (gate|up, lm_head; d_down's 3 rounds against 5: a tie on paper, +0.5 %
+        // on the step measured with TASU_GEMM_PP_EFF = 1.26 against 1.19 on one box; not the one-round N = 1536 grids)
         static const bool pp_on = [] {
           const char* e = getenv("TASU_GEMM_PP");
           return !(e && e[0] == '0');
         }();
         if (pp_on && kernel_choice() == 0 && K >= 256 && K % 128 == 0) {
-          const double c256 = cost(tm * ((N + 255) / 256), 256.0 * 256, 1.19);
+          static const double pp_eff = [] {            // TASU_GEMM_PP_EFF: tuning runs
+            const char* e = getenv("TASU_GEMM_PP_EFF");
+            return e ? atof(e) : 1.26;
+          }();
+          const double c256 = cost(tm * ((N + 255) / 256), 256.0 * 256, pp_eff);
           const double best = use_pipe_bn == 128 ? c128 : (use_pipe_bn == 192 ? c192 : c96);
           if (c256 < best) return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st);
         }

@@ -44,8 +44,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;          // group (tile rows wr*128 ..), wave column (tile cols wc*64 ..)
-  const int nk = p.K / BK;
-  const int ntiles = p.tiles_m * p.tiles_n;
+  // split-K (TASU_GEMM_OUT_F32 only, gemm_epilogue.h): work item s = K range s / base_tiles of output tile s % base_tiles
+  const int nk = p.K / BK / p.ksplit;                // K-tiles per work item (even, >= 4)
+  const int base_tiles = p.tiles_m * p.tiles_n;
+  const int ntiles = base_tiles * p.ksplit;
 
 #if defined(__HIP_DEVICE_COMPILE__)
   // ------------------------------------------------------------------ staging
@@ -61,14 +63,18 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
   };
   auto setup = [&](Src& d, int s) {
     int tm, tn;
-    tile_coords<4>(p, s, ntiles, tm, tn);
+    const int ks = s / base_tiles;
+    tile_coords<4>(p, s - ks * base_tiles, base_tiles, tm, tn);
     const int row0 = tm * BM;
     const int brow0 = OUT_MODE == OUT_GU_SWIGLU ? tn * 128 : tn * BN;   // OUT_GU_SWIGLU: first gate row = first act column
-    d.a = (const char*)(p.A + (size_t)row0 * p.lda) - 1024;
-    d.b = (const char*)(p.B + (size_t)brow0 * p.ldb) - 1024;
-    const size_t ra = (size_t)(p.M - row0) * p.lda * 2 + 1024;
+    const size_t k0 = (size_t)ks * nk * BK;          // first K element of this work item
+    d.a = (const char*)(p.A + (size_t)row0 * p.lda + k0) - 1024;
+    d.b = (const char*)(p.B + (size_t)brow0 * p.ldb + k0) - 1024;
+    // (the byte counts run from the descriptor base, which a K range moves into the first row: rows past the end are still
+    // past the count, and the last row's K range ends inside it)
+    const size_t ra = (size_t)(p.M - row0) * p.lda * 2 + 1024 - k0 * 2;
     // OUT_GU_SWIGLU: the up rows lie N rows behind the gate rows; the tile's 128 act columns exist (N % 128 == 0 is required)
-    const size_t rb = (size_t)(OUT_MODE == OUT_GU_SWIGLU ? 2 * p.N - brow0 : p.N - brow0) * p.ldb * 2 + 1024;
+    const size_t rb = (size_t)(OUT_MODE == OUT_GU_SWIGLU ? 2 * p.N - brow0 : p.N - brow0) * p.ldb * 2 + 1024 - k0 * 2;
     d.na = (unsigned)(ra < 0x7ffffff0ull ? ra : 0x7ffffff0ull);
     d.nb = (unsigned)(rb < 0x7ffffff0ull ? rb : 0x7ffffff0ull);
   };
@@ -254,13 +260,16 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
   read_b(fbx, Z{}, Z{});
 
   auto store_gu = [&](int row0, int tn) { store_gu_swiglu<MI, NI, BM>(p, acc, row0, tn * 128 + wc * 32, wr * 128, lane); };
-  auto store_c = [&](int row0, int col0) {
-    store_tile<MI, NI, OUT_MODE, HAS_BIAS, BM, BN, false>(p, acc, row0, col0, wr * 128, wc * 64, lane);
+  auto store_c = [&](int row0, int col0, int ks) {
+    Args q = p;
+    if constexpr (OUT_MODE == TASU_GEMM_OUT_F32) q.C = (float*)p.C + (size_t)ks * p.split_stride;   // slab of this K range
+    store_tile<MI, NI, OUT_MODE, HAS_BIAS, BM, BN, false>(q, acc, row0, col0, wr * 128, wc * 64, lane);
   };
 
   for (int s = blockIdx.x; s < ntiles; s += gridDim.x) {
     int tm, tn;
-    tile_coords<4>(p, s, ntiles, tm, tn);
+    const int ks = s / base_tiles;
+    tile_coords<4>(p, s - ks * base_tiles, base_tiles, tm, tn);
     // the workgroup's next tile; after the last one the stream re-stages this tile's first units (never read) so that the
     // DMA count behind every wait stays the same
     if (s + (int)gridDim.x < ntiles) setup(nxt, s + (int)gridDim.x);
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
       fence();
     }
     if constexpr (OUT_MODE == OUT_GU_SWIGLU) store_gu(tm * BM, tn);
-    else store_c(tm * BM, tn * BN);
+    else store_c(tm * BM, tn * BN, ks);
     zero_acc();
     cur = nxt;
   }
@@ -306,7 +315,7 @@ int launch(Args a, hipStream_t st) {
   }
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = OUT_MODE == OUT_GU_SWIGLU ? (a.N + 127) / 128 : (a.N + 255) / 256;
-  const int ntiles = a.tiles_m * a.tiles_n;
+  const int ntiles = a.tiles_m * a.tiles_n * a.ksplit;
   const int grid = ntiles < cu_count() ? ntiles : cu_count();
   TASU_LAUNCH((gemm_pp_kernel<OUT_MODE, HAS_BIAS>), dim3(grid), dim3(512), LDS, st, a);
   return TASU_OK;
@@ -369,6 +378,35 @@ int tasu_gemm_pp_gu_dispatch(const void* A, int lda, const void* Wgu, int ldw, v
   a.ksplit = 1;
   a.split_stride = 0;
   return launch<OUT_GU_SWIGLU, false>(a, st);
+}
+
+// K range slabs on 256 x 256 tiles: partials[ks][M, ldc] (fp32) = A[:, ks-th K range] . B[:, ks-th K range]^T, ks < ksplit.
+// For outputs too narrow to fill the chip with whole tiles behind a long K (N = 1536 at M = 4096: 96 tiles): the consumer sums
+// the slabs (tasu_rmsnorm_*_slabs, tasu_sum_slabs_bf16).  K % (128 * ksplit) == 0, K / ksplit >= 256.
+extern "C" int tasu_gemm_nt_bf16_slabs(const void* A, int lda, const void* B, int ldb, float* partials, int ldc, int M, int N, int K,
+                                       int ksplit, void* stream) {
+  using namespace tasu_pp;
+  if (!A || !B || !partials || M <= 0 || N <= 0 || K <= 0 || ksplit < 1 || ksplit > 16 || K % (128 * ksplit) || K / ksplit < 256 ||
+      lda % 8 || ldb % 8 || ldc < N)
+    return TASU_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)partials & 15)) return TASU_ERR_ARG;
+  Args a;
+  a.A = (const bf16*)A;
+  a.B = (const bf16*)B;
+  a.C = partials;
+  a.R = nullptr;
+  a.bias = nullptr;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.lda = lda;
+  a.ldb = ldb;
+  a.ldc = ldc;
+  a.tiles_m = a.tiles_n = 0;
+  a.act = nullptr;
+  a.ksplit = ksplit;
+  a.split_stride = (long long)M * ldc;
+  return launch<TASU_GEMM_OUT_F32, false>(a, (hipStream_t)stream);
 }
 
 int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,

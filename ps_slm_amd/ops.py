@@ -77,6 +77,12 @@ class HipOps:
                                                     self._stream()), "tasu_gemm_nt_bf16_splitk")
         self._chk(self.lib.tasu_sum_slabs_bf16(_p(ws), ksplit, M * N, _p(c), M * N, self._stream()), "tasu_sum_slabs_bf16")
 
+    def gemm_slabs(self, a, b, ws, M, N, K, ksplit):
+        """ws[ks][M, N] (fp32) = a[:, ks-th K range] @ b[:, ks-th K range]^T on 256 x 256 tiles (tasu_gemm_nt_bf16_slabs); the
+        consumer sums the slabs."""
+        self._chk(self.lib.tasu_gemm_nt_bf16_slabs(_p(a), a.stride(0), _p(b), b.stride(0), _p(ws), N, M, N, K, ksplit,
+                                                   self._stream()), "tasu_gemm_nt_bf16_slabs")
+
     def gemm_gate_up_swiglu(self, a, wgu, gu, act, M, I, K):
         """gu[M,2I] = a @ wgu^T and act[M,I] = swiglu(gu) in one launch (training step)."""
         self._chk(self.lib.tasu_gemm_gate_up_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), M, I, K,

@@ -88,6 +88,32 @@ for name, m, n, k in shapes:
     del sets, a0, b0, c_ref, c_new
     torch.cuda.empty_cache()
 
+# K-range slabs for the N = 1536 projections behind a long K
+for name, m, n, k in (("down", M, 1536, 8960), ("d_gate_up", M, 1536, 17920)):
+    if only and name not in only and "slabs" not in only:
+        continue
+    nsets = 1 if args.warm else 8
+    sets = [(torch.randn(m, k, device="cuda").to(torch.bfloat16), (torch.randn(n, k, device="cuda") * k ** -0.5).to(torch.bfloat16),
+             torch.empty(m, n, device="cuda", dtype=torch.bfloat16)) for _ in range(nsets)]
+    fl = 2.0 * m * n * k / 1e9
+    a0, b0, c0 = sets[0]
+    ref = torch.zeros(m, n, device="cuda")
+    pipe(a0, b0, ref, m, n, k, GEMM_F32, bn=192)
+    t_ref = timeit(lambda a, b, c: pipe(a, b, c, m, n, k, bn=192), sets, args.iters)
+    line = f"{name:10s} {m}x{n}x{k}: pipe192 {t_ref*1e3:7.1f} us {fl/t_ref:7.1f} TF"
+    for ks in (2, 4, 5, 7):
+        if k % (128 * ks):
+            continue
+        ws = torch.zeros(ks, m, n, device="cuda")
+        ops.gemm_slabs(a0, b0, ws, m, n, k, ks)
+        torch.cuda.synchronize()
+        err = float((ws.sum(0) - ref).abs().max() / ref.abs().max())
+        t = timeit(lambda a, b, c: ops.gemm_slabs(a, b, ws, m, n, k, ks), sets, args.iters)
+        line += f" | slabs x{ks} {t*1e3:7.1f} us {fl/t:7.1f} TF (err {err:.1e})"
+        del ws
+    print(line, flush=True)
+    del sets
+
 # gate|up with the SwiGLU epilogue: TASU_GEMM_GU_KERNEL=pipe / pp selects the kernel per process (run twice)
 if not only or "gate_up" in only:
     m, I, k = M, 8960, 1536

@@ -21,8 +21,8 @@ for r in rows:
 for s, c, ms, a in lines:
     out.append(f"| {s} | {c:.1f} | {ms:.3f} | {a:.1f} | {100 * ms / tot:.1f} |")
 out.append(f"| **total** | | **{tot:.2f}** | | |")
-g = [l for l in lines if l[0].startswith("gemm_nt") or "gemm_pipe_kernel" in l[0]]
+g = [l for l in lines if l[0].startswith("gemm_nt") or "gemm_pipe_kernel" in l[0] or "gemm_pp_kernel" in l[0]]
 if g:
-    out += ["", f"GEMM kernels of tasu_gemm_nt_bf16_ws (gemm_pipe_kernel / gemm_nt_kernel, all instantiations): {sum(l[1] for l in g):.0f} launches/step, {sum(l[2] for l in g):.2f} ms/step, "
+    out += ["", f"GEMM kernels (gemm_pp_kernel / gemm_pipe_kernel / gemm_nt_kernel, all instantiations): {sum(l[1] for l in g):.0f} launches/step, {sum(l[2] for l in g):.2f} ms/step, "
             f"average launch {1e3 * sum(l[2] for l in g) / sum(l[1] for l in g):.1f} us"]
 print("\n".join(out))
