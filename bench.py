@@ -244,9 +244,17 @@ def encoder_gemm_flops_per_utt(geo, frames):
     return 2 * frames * ((layers - 1) * per_layer + first + E * V)
 
 
-def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank, want_decode):
+def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank, want_decode, device=None, ops=None,
+              variable=False, blank_biased=False):
     """One training workload (path: "text" = the text-only CPS recipe of configs 2/3/5, "audio" = config 4: 500 feature frames
-    through the SenseVoice encoder, CTC posterior, PSD, projector, LLM).  Returns the fields of a bench record."""
+    through the SenseVoice encoder, CTC posterior, PSD, projector, LLM).  Returns the fields of a bench record.
+    ``device`` / ``ops``: tests/test_bench_cpu.py drives this function over gloo with the CPU operator double (the N > 1
+    bookkeeping -- barriers, MAX-reduce of the wall time, rank-0-only record, exposed all-reduce time -- without a GPU).
+    ``variable``: SURVEY 8d's variable-S run -- 8 distinct batches, CPS token drop 0.05 (fresh draws every step), shapes padded to
+    the training entrypoint's buckets (``++graph_buckets=16,8,256``) so that the LRU of captured step graphs gets hits: the
+    throughput of real dynamic batching, where no two steps need have the same shape.  ``blank_biased`` (audio path): the CTC
+    head's blank bias is raised until PSD keeps ~100 of the 500 frames (a trained encoder's regime; the random-init posterior
+    keeps ~476)."""
     import torch.distributed as dist
 
     from ps_slm_amd.config import DEFAULT_DS_CONFIG, ModelConfig, TrainConfig, load_ds_config
@@ -259,67 +267,94 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                                do_psd=True, use_fp16=True, batching_strategy="dynamic")
     model_config = ModelConfig(llm_path=f"synthetic:{model_name}", encoder_projector="linear-silu", encoder_dim=25055,
                                llm_dim={"qwen2.5-1.5b": 1536, "qwen2.5-7b": 3584, "mid": 256}[model_name])
-    model, _ = model_factory(train_config, model_config, device=f"cuda:{local_rank}", init_seed=1234, keep_logits=False,
-                             with_encoder=audio)
-    model.drop_prob = args.drop_prob
+    device = device or f"cuda:{local_rank}"
+    on_gpu = device.startswith("cuda")
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    model, _ = model_factory(train_config, model_config, device=device, init_seed=1234, keep_logits=False,
+                             with_encoder=audio, **({"ops": ops} if ops is not None else {}))
+    model.drop_prob = 0.05 if variable else args.drop_prob
     core = model.core
-    core.use_graphs = not args.no_graphs
+    core.use_graphs = on_gpu and not args.no_graphs
+    if variable:
+        core.shape_buckets = (16, 8, 256)
     timed = TimedOps(core.ops)
     core.ops = timed
     engine = TasuEngine(model, load_ds_config(DEFAULT_DS_CONFIG))
     engine.train()
     geo = core.geo
-    raw = synthetic_text_batch(geo, B, seed=1234 + rank, noise=False)
-    if audio:
-        batch = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
-                     input_features=raw["input_features"], input_feature_length=raw["input_feature_length"], GT=None)
-    else:
+    def make_batch(seed):
+        raw = synthetic_text_batch(geo, B, seed=seed, noise=False)
+        if audio:
+            return raw, dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
+                             input_features=raw["input_features"], input_feature_length=raw["input_feature_length"], GT=None)
         GT = [" ".join(map(str, p)) for p in raw["post_ids"]]
-        batch = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
-                     input_features=None, input_feature_length=None, GT=GT)
+        return raw, dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
+                         input_features=None, input_feature_length=None, GT=GT)
+
+    raw, batch = make_batch(1234 + rank)
+    batches = [batch] + ([make_batch(1234 + rank + 100 * i)[1] for i in range(1, 8)] if variable else [])
     torch.manual_seed(1234 + rank)          # CPS alpha / keep draws come from the global CPU RNG, like the reference
+    blank_note = None
+    if blank_biased:
+        # bisection on the blank logit's bias: forward passes only, until PSD keeps 90-110 rows per utterance
+        enc = core.encoder
+        lo_b, hi_b, bias0 = 0.0, 30.0, float(enc.ctc_b[geo.blank_id])
+        for _ in range(12):
+            mid_b = 0.5 * (lo_b + hi_b)
+            enc.ctc_b[geo.blank_id] = bias0 + mid_b
+            engine(**batch)
+            kept = engine._last_state.Ra / B
+            if 90 <= kept <= 110:
+                break
+            lo_b, hi_b = (mid_b, hi_b) if kept > 110 else (lo_b, mid_b)
+        blank_note = f"CTC blank bias raised by {mid_b:.2f}: PSD keeps {kept:.0f} rows per utterance (padded to the batch maximum)"
+    seen_shapes = set()
+    step_no = [0]
 
     def step():
-        out, acc = engine(**batch)
+        b = batches[step_no[0] % len(batches)]
+        step_no[0] += 1
+        out, acc = engine(**b)
+        seen_shapes.add((engine._last_state.S, engine._last_state.Ra))
         engine.backward(out.loss)
         engine.step()
         return out
 
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     # hipGraph replay cannot carry per-launch event pairs, so with graphs the GEMM launches are timed in a second,
     # eager pass over the same number of steps right after the timed region (same kernels, same shapes, same data).
-    timed.enabled = rank == 0 and not core.use_graphs
+    timed.enabled = on_gpu and rank == 0 and not core.use_graphs
     engine.time_exchange = world > 1
     engine.exposed_events = []
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     timed.enabled = False
     exposed_ms = engine.exposed_ms() / max(steps, 1) if world > 1 else 0.0
     engine.time_exchange = False
     if world > 1:
-        t = torch.tensor([dt, exposed_ms], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt, exposed_ms], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, exposed_ms = float(t[0].item()), float(t[1].item())
     if core.use_graphs:
         # every rank takes part (the step contains the gradient all-reduce); only rank 0 records the event pairs
         core.use_graphs = False
         step()
-        torch.cuda.synchronize()
+        sync()
         timed.enabled = rank == 0
         for _ in range(steps):
             step()
-        torch.cuda.synchronize()
+        sync()
         timed.enabled = False
         core.use_graphs = True
     loss = float(out.loss)
@@ -336,16 +371,23 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         gemm_ms = timed.total_ms()
         n_launch = len(timed.events)
         achieved = gemm_flops_step * steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # HBM-side bytes per GEMM launch are NOT measured by this run (PMC counters need their own rocprofv3 --pmc passes):
+        # the offline per-shape figures are in the cited file
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")
-        if os.path.isfile(pmc) and model_name == "qwen2.5-1.5b" and B == 16 and not audio:
-            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-            traffic_src = ("OFFLINE figure read from profiles/r02_gemm_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                           "over tools/gemm_shapes_run.py, gfx950 x2 fetch correction; launch-count-weighted mean of the per-shape "
-                           "figures), not measured by this run")
+        pmc = os.path.join(ROOT, "profiles", "r03_gemm_pmc.json")
+        if os.path.isfile(pmc) and model_name == "qwen2.5-1.5b" and B == 16 and not audio and not variable:
+            traffic_src = ("not measured by this run; offline: profiles/r03_gemm_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                           f"passes over tools/gemm_shapes_run.py, gfx950 x2 fetch correction): "
+                           f"{json.load(open(pmc)).get('traffic_bytes_per_launch')} bytes per launch, launch-count-weighted")
         what = ("audio-SFT step (500 feature frames -> SANM encoder -> CTC posterior -> PSD -> projector -> LLM fwd+dgrad bwd+"
                 "projector wgrad+AdamW)" if audio else
                 "text-only CPS alignment step (fwd+dgrad bwd+projector wgrad+AdamW), frozen encoder pass skipped")
+        if variable:
+            what += (f"; VARIABLE shapes: 8 distinct batches, CPS token drop 0.05 redrawn every step, shapes padded to buckets "
+                     f"(16 token columns, 8 posterior rows, 256 labelled rows): {len(seen_shapes)} distinct (S, posterior rows) seen, "
+                     f"{len(core._graphs)} step graphs captured; the figures below describe the LAST step's shape")
+        if blank_note:
+            what += "; " + blank_note
         rec = {
             "value": round(world * B * steps / dt, 2), "unit": "utterances/s", "ms_per_step": round(dt / steps * 1e3, 3),
             "config": {"workload": f"{what}, {model_name}, {B} utterances/GPU x S={S} "
@@ -355,7 +397,7 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "tasu_pipe::gemm_pipe_kernel (tasu_gemm_nt_bf16_ws, tasu_gemm_gate_up_swiglu, tasu_gemm_nt_bf16_splitk)",
+                         "kernel": "tasu_pp::gemm_pp_kernel + tasu_pipe::gemm_pipe_kernel (tasu_gemm_nt_bf16_ws, tasu_gemm_gate_up_swiglu, tasu_gemm_nt_bf16_splitk)",
                          "launches_per_step": n_launch // max(steps, 1),
                          "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
                          "algorithmic_gflop_per_launch": round(gemm_flops_step * steps / max(n_launch, 1) / 1e9, 2),
@@ -374,12 +416,24 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         if world > 1:
             rec["allreduce_exposed_ms"] = round(exposed_ms, 3)
             rec["allreduce_note"] = (f"per step, max over ranks: time the compute stream waited for gradient ranges in step() "
-                                     f"(event pairs around every wait); bucket exchanged in {engine.w1_chunks + 2} ranges")
+                                     f"(event pairs around every wait); bucket exchanged in {engine.w1_chunks + 2} ranges.  Expected "
+                                     f"on 8 xGMI-connected GPUs: ~0.35 ms (the last 51-MB row block of the Linear1 weight gradient at "
+                                     f"the ~300 GB/s bus bandwidth RCCL reaches; the whole 218-MB bucket would be ~1.3 ms), DESIGN.md 6")
         if want_decode:
             rec["decode"] = decode_leg(core, raw, B)
     del engine, model, core, timed
     torch.cuda.empty_cache()
     return rec
+
+
+def check_launch(world, gpus):
+    """``--gpus N`` must be launched as N processes (torch.distributed.run, one per GPU): anything else would print a line whose
+    n_gpus does not describe the run."""
+    if world != gpus:
+        if world == 1:
+            raise SystemExit(f"--gpus {gpus}: launch multi-GPU runs with torch.distributed.run (one process per GPU): python -m "
+                             f"torch.distributed.run --nnodes=1 --nproc-per-node {gpus} --master-addr 127.0.0.1 bench.py --gpus {gpus}")
+        raise SystemExit(f"--gpus {gpus} but WORLD_SIZE is {world}: the launcher's process count and --gpus must agree")
 
 
 def main():
@@ -405,9 +459,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    check_launch(world, args.gpus)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -419,7 +471,10 @@ def main():
     headline = args.model == "qwen2.5-1.5b" and args.path == "text"
     if world == 1 and headline and not args.no_extra:
         # BASELINE.json configs 4 and 5 as sub-records of the same line (shorter runs: their steps are 3-4x longer)
+        extras["variable_S"] = train_leg(args, "qwen2.5-1.5b", "text", args.batch, 16, 24, 1, 0, local_rank, False, variable=True)
         extras["audio_sft"] = train_leg(args, "qwen2.5-1.5b", "audio", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank, False)
+        extras["audio_sft_blank_biased"] = train_leg(args, "qwen2.5-1.5b", "audio", args.batch, max(5, args.steps // 2), 2, 1, 0,
+                                                     local_rank, False, blank_biased=True)
         extras["qwen2.5-7b"] = train_leg(args, "qwen2.5-7b", "text", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank, False)
     if rank == 0:
         line = {"metric": "train utterances/sec (Qwen2.5-1.5B align)" if args.model != "qwen2.5-7b" else "train utterances/sec (Qwen2.5-7B align)",
@@ -428,7 +483,9 @@ def main():
                 "dtype": "bf16", "data": "synthetic"}
         line.update({k: v for k, v in main_rec.items() if k not in ("value", "unit", "ms_per_step")})
         for name, rec in extras.items():
-            rec["metric"] = "train utterances/sec" + (" (audio-SFT, config 4)" if name == "audio_sft" else " (Qwen2.5-7B align, config 5)")
+            rec["metric"] = "train utterances/sec" + {"audio_sft": " (audio-SFT, config 4)", "qwen2.5-7b": " (Qwen2.5-7B align, config 5)",
+                                                      "variable_S": " (text-only, variable shapes: CPS drop 0.05, bucketed hipGraphs)",
+                                                      "audio_sft_blank_biased": " (audio-SFT, config 4, ~100 audio tokens per utterance)"}[name]
             line[name] = rec
         if world == 1 and not args.no_cpu_baseline and headline:
             line["cpu_baseline"] = cpu_baseline("train1")
