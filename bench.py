@@ -302,8 +302,11 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         for _ in range(12):
             mid_b = 0.5 * (lo_b + hi_b)
             enc.ctc_b[geo.blank_id] = bias0 + mid_b
-            engine(**batch)
-            kept = engine._last_state.Ra / B
+            try:
+                engine(**batch)
+                kept = engine._last_state.Ra / B
+            except ValueError:                      # "PSD removed every frame": the bias is far too high
+                kept = 0.0
             if 90 <= kept <= 110:
                 break
             lo_b, hi_b = (mid_b, hi_b) if kept > 110 else (lo_b, mid_b)

@@ -133,7 +133,8 @@ class FakeLLMTokenizer:
 
 def build_reference_model(geo, seed, train_flags, projector="linear-silu", ds_rate=1):
     """Seeded random-init reference ``slam_model_asr`` at geometry ``geo`` (dict); ``projector``: "linear-silu"
-    (EncoderProjectorLinearSiLU) or "linear" (EncoderProjectorConcat with encoder_projector_ds_rate = ds_rate)."""
+    (EncoderProjectorLinearSiLU), "linear" (EncoderProjectorConcat with encoder_projector_ds_rate = ds_rate) or "cov1d-linear"
+    (EncoderProjectorCov1d, kernel = stride = ds_rate)."""
     import transformers
 
     ps, sv, proj = load_reference()
@@ -160,7 +161,9 @@ def build_reference_model(geo, seed, train_flags, projector="linear-silu", ds_ra
     llm.eval()
     model_config = Cfg(encoder_projector=projector, encoder_path="/nonexistent", encoder_projector_ds_rate=ds_rate,
                        encoder_dim=geo["ctc_vocab"], llm_dim=geo["llm_dim"])
-    if projector == "linear":
+    if projector == "cov1d-linear":
+        projector = proj.EncoderProjectorCov1d(model_config)       # hidden width fixed at 2048 by the reference class
+    elif projector == "linear":
         projector = proj.EncoderProjectorConcat(model_config)      # bottleneck fixed at 2048 by the reference class
     else:
         projector = proj.EncoderProjectorLinearSiLU(model_config, bottleneck=geo["bottleneck"])

@@ -207,7 +207,16 @@ def pseudo_posterior(ids_list, V, alphas=None, keeps=None):
 # ----------------------------------------------------------------------------- projector
 def projector(W, x, mode="fp32", pre="encoder_projector."):
     """EncoderProjectorLinearSiLU.forward, Multitask/model/projector.py:139-151; with ``linear1.*`` keys instead:
-    EncoderProjectorConcat.forward, :38-49 (k = in_features / feature width frames concatenated, ReLU, no norm)."""
+    EncoderProjectorConcat.forward, :38-49 (k = in_features / feature width frames concatenated, ReLU, no norm); with
+    ``conv1d.*`` keys as well: EncoderProjectorCov1d.forward, :64-73 (Conv1d kernel = stride = k over time, ReLU, Linear, ReLU,
+    Linear; autocast runs the convolution in bf16 like a Linear)."""
+    if pre + "conv1d.weight" in W:
+        w = W[pre + "conv1d.weight"]                         # [out, in, k]
+        k = w.shape[2]
+        c = F.conv1d(rbf(x, mode).transpose(1, 2), rbf(w, mode), rbf(W[pre + "conv1d.bias"], mode), stride=k).transpose(1, 2)
+        h = rbf(F.relu(rbf(c, mode)), mode)
+        h = rbf(F.relu(linear(h, W[pre + "linear1.weight"], W[pre + "linear1.bias"], mode)), mode)
+        return linear(h, W[pre + "linear2.weight"], W[pre + "linear2.bias"], mode)
     if pre + "linear1.weight" in W:
         k = W[pre + "linear1.weight"].shape[1] // x.shape[-1]
         B, T, Dm = x.shape
@@ -379,7 +388,9 @@ def forward_audio(W, batch, geo, mode="fp32"):
 
 def forward_from_posterior(W, batch, post, plen, geo, mode="fp32"):
     proj = projector(W, post, mode)
-    if "encoder_projector.linear1.weight" in W:            # k frames per projector row: len // k rows (ps-slm.py:482)
+    if "encoder_projector.conv1d.weight" in W:             # Conv1d kernel = stride = k: len // k rows (ps-slm.py:482)
+        plen = plen // W["encoder_projector.conv1d.weight"].shape[2]
+    elif "encoder_projector.linear1.weight" in W:          # k frames per projector row: len // k rows (ps-slm.py:482)
         plen = plen // (W["encoder_projector.linear1.weight"].shape[1] // post.shape[-1])
     tok = W["llm.model.embed_tokens.weight"][batch["input_ids"]]
     emb, mask, lab, pos = merge(proj, plen, tok, batch["input_ids"], batch["attention_mask"],

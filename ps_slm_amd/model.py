@@ -87,21 +87,27 @@ class Geometry:
 
 PROJ_NAMES = ("norm.weight", "norm.bias", "ffn.0.weight", "ffn.0.bias", "ffn.2.weight", "ffn.2.bias")
 PROJ_NAMES_LINEAR = ("linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias")
+PROJ_NAMES_COV1D = ("conv1d.weight", "conv1d.bias") + PROJ_NAMES_LINEAR
 
 
 class ProjectorParams:
-    """The only trainable tensors (54,512,062 parameters at full geometry) in one flat, padded buffer.  Two projector kinds
-    share the layout [optional LayerNorm | W1 | b1 | W2 | b2]: the first Linear reads k frames of the CTC vocabulary, each
-    frame's K columns padded to Kp = a multiple of 64 (the pad columns of W1 stay zero: their inputs are zero)."""
+    """The only trainable tensors (54,512,062 parameters at full geometry) in one flat, padded buffer.  Three projector kinds
+    share the layout [optional input stage | W1 | b1 | W2 | b2]: the first Linear reads ``kin`` frames of the CTC vocabulary,
+    each frame's K columns padded to Kp = a multiple of 64 (the pad columns of W1 stay zero: their inputs are zero).  Input
+    stage: LayerNorm ("linear-silu"), nothing ("linear": kin = k frames concatenated), or ("cov1d-linear",
+    EncoderProjectorCov1d, projector.py:53-73) Conv1d(K, K, kernel = stride = k) + ReLU, stored as the [Kp, k * Kp] matrix of
+    the GEMM over k concatenated frames (W0[o, j * Kp + i] = conv.weight[o, i, j]) -- then kin = 1."""
 
     def __init__(self, geo: Geometry, device):
         K, Kp, Hb, Do = geo.ctc_vocab, rup(geo.ctc_vocab, 64), geo.bottleneck, geo.llm_dim
         self.kind = geo.projector
-        if self.kind not in ("linear-silu", "linear"):
+        if self.kind not in ("linear-silu", "linear", "cov1d-linear"):
             raise NotImplementedError(f"encoder_projector {self.kind!r}")
-        self.k = int(geo.projector_ds_rate) if self.kind == "linear" else 1
+        self.k = int(geo.projector_ds_rate) if self.kind in ("linear", "cov1d-linear") else 1   # frames per projector row
         self.has_norm = self.kind == "linear-silu"
-        k = self.k
+        self.has_conv = self.kind == "cov1d-linear"
+        self.kin = 1 if self.has_conv else self.k           # frames the first Linear reads
+        kc, k = self.k, self.kin
         self.K, self.Kp, self.Hb, self.Do = K, Kp, Hb, Do
         if self.has_norm:
             self.names = PROJ_NAMES
@@ -109,9 +115,12 @@ class ProjectorParams:
             shapes = {"norm.weight": (Kp,), "norm.bias": (Kp,)}
             self.real = {"norm.weight": (K,), "norm.bias": (K,)}
         else:
-            self.names = PROJ_NAMES_LINEAR
+            self.names = PROJ_NAMES_COV1D if self.has_conv else PROJ_NAMES_LINEAR
             self.n_w1, self.n_b1, self.n_w2, self.n_b2 = PROJ_NAMES_LINEAR
             shapes, self.real = {}, {}
+            if self.has_conv:
+                shapes = {"conv1d.weight": (Kp, kc * Kp), "conv1d.bias": (Kp,)}
+                self.real = {"conv1d.weight": (K, K, kc), "conv1d.bias": (K,)}
         shapes.update({self.n_w1: (Hb, k * Kp), self.n_b1: (Hb,), self.n_w2: (Do, Hb), self.n_b2: (Do,)})
         self.real.update({self.n_w1: (Hb, k * K), self.n_b1: (Hb,), self.n_w2: (Do, Hb), self.n_b2: (Do,)})
         self.offsets, off = {}, 0
@@ -125,7 +134,7 @@ class ProjectorParams:
         self.m = torch.zeros(off, **f32)
         self.v = torch.zeros(off, **f32)
         self.pb = torch.zeros(off, dtype=torch.bfloat16, device=device)
-        self.w1b_t = torch.zeros(k * Kp, Hb, dtype=torch.bfloat16, device=device)   # W1^T for dgrad
+        self.w1b_t = torch.zeros(k * Kp, Hb, dtype=torch.bfloat16, device=device)   # W1^T for dgrad (linear-silu, cov1d-linear)
         self.w2b_t = torch.zeros(Hb, Do, dtype=torch.bfloat16, device=device)       # W2^T for dgrad
 
     def view(self, flat, name):
@@ -136,8 +145,12 @@ class ProjectorParams:
         return sum(int(np.prod(s)) for s in self.real.values())
 
     def _blocks(self, t2d):
-        """[rows, k * Kp] padded view -> [rows, k, Kp] (frame blocks)."""
-        return t2d.view(t2d.shape[0], self.k, self.Kp)
+        """[rows, kin * Kp] padded view -> [rows, kin, Kp] (frame blocks)."""
+        return t2d.view(t2d.shape[0], self.kin, self.Kp)
+
+    def _conv_blocks(self, t2d):
+        """conv1d.weight as stored, [Kp, k * Kp] -> [Kp, k, Kp] (output channel, tap, input channel)."""
+        return t2d.view(self.Kp, self.k, self.Kp)
 
     def load(self, name, t):
         """t: fp32 tensor with the REFERENCE shape (unpadded)."""
@@ -145,8 +158,10 @@ class ProjectorParams:
         dst.zero_()
         if dst.dim() == 1:
             dst[: t.shape[0]].copy_(t)
+        elif name == "conv1d.weight":                      # reference layout [out, in, tap]
+            self._conv_blocks(dst)[: self.K, :, : self.K].copy_(t.permute(0, 2, 1))
         elif name == self.n_w1:
-            self._blocks(dst)[:, :, : self.K].copy_(t.reshape(t.shape[0], self.k, self.K))
+            self._blocks(dst)[:, :, : self.K].copy_(t.reshape(t.shape[0], self.kin, self.K))
         else:
             dst[:, : t.shape[1]].copy_(t)
 
@@ -155,6 +170,8 @@ class ProjectorParams:
         r = self.real[name]
         if src.dim() == 1:
             return src[: r[0]].detach().clone()
+        if name == "conv1d.weight":
+            return self._conv_blocks(src)[: self.K, :, : self.K].permute(0, 2, 1).contiguous().detach().clone()
         if name == self.n_w1:
             return self._blocks(src)[:, :, : self.K].reshape(r[0], r[1]).detach().clone()
         return src[:, : r[1]].detach().clone()
@@ -167,8 +184,8 @@ class ProjectorParams:
 
     def refresh_working_copies(self, ops):
         """bf16 working copy (skipped when AdamW already wrote it) + the transposed copies for dgrad."""
-        kKp = self.k * self.Kp
-        if self.has_norm:       # the "linear" projector's input carries no parameters: its W1^T (input gradient) is never needed
+        kKp = self.kin * self.Kp
+        if self.has_norm or self.has_conv:   # the "linear" projector's input carries no parameters: its W1^T is never needed
             ops.transpose(self.view(self.pb, self.n_w1), self.w1b_t, self.Hb, kKp, self.Hb, kKp)
         ops.transpose(self.view(self.pb, self.n_w2), self.w2b_t, self.Do, self.Hb, self.Do, self.Hb)
 
@@ -349,7 +366,7 @@ class TasuModel:
         no projector checkpoint."""
         geo, dev, pr = self.geo, self.device, self.proj
         g = torch.Generator(device=dev).manual_seed(seed)
-        K, Hb, Do = geo.ctc_vocab * pr.k, geo.bottleneck, geo.llm_dim
+        K, Hb, Do = geo.ctc_vocab * pr.kin, geo.bottleneck, geo.llm_dim
 
         def un(shape, fan_in):
             b = 1.0 / math.sqrt(fan_in)
@@ -358,6 +375,10 @@ class TasuModel:
         if pr.has_norm:
             pr.load("norm.weight", torch.ones(K, device=dev))
             pr.load("norm.bias", torch.zeros(K, device=dev))
+        if pr.has_conv:                                    # nn.Conv1d default init: fan_in = in_channels * kernel_size
+            Kc = geo.ctc_vocab
+            pr.load("conv1d.weight", un((Kc, Kc, pr.k), Kc * pr.k))
+            pr.load("conv1d.bias", un((Kc,), Kc * pr.k))
         pr.load(pr.n_w1, un((Hb, K), K))
         pr.load(pr.n_b1, un((Hb,), K))
         pr.load(pr.n_w2, un((Do, Hb), Hb))
@@ -513,7 +534,8 @@ class TasuModel:
         self._projector_from_posterior(st)
 
     def _projector_from_posterior(self, st):
-        """linear-silu: LayerNorm(25055) -> Linear -> SiLU -> Linear;  linear: [k frames concatenated] Linear -> ReLU -> Linear."""
+        """linear-silu: LayerNorm(25055) -> Linear -> SiLU -> Linear;  linear: [k frames concatenated] Linear -> ReLU -> Linear;
+        cov1d-linear: Conv1d(k, stride k) -> ReLU -> Linear -> ReLU -> Linear."""
         ops, pr = self.ops, self.proj
         Fap, Rap, K, Kp, Hb, Do = st.Fap, st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
         post = st.dev["post"]
@@ -527,13 +549,22 @@ class TasuModel:
         else:
             ops.cast_bf16(post, xn)                            # autocast: the Linear rounds its input to bf16
         xrows = xn.view(Rap, pr.k * Kp)                        # k consecutive frames = one projector row
+        c0 = a0 = None
+        if pr.has_conv:
+            # Conv1d(kernel = stride = k) over time = one GEMM over the k concatenated frames; pad output channels stay zero
+            # (zero weight rows, zero bias), then ReLU (projector.py:66-69)
+            c0 = self._buf("c0", (Rap, Kp), torch.bfloat16)
+            ops.gemm(xrows, pr.view(pr.pb, "conv1d.weight"), c0, Rap, Kp, pr.k * Kp, bias=pr.view(pr.pb, "conv1d.bias"))
+            a0 = self._buf("a0", (Rap, Kp), torch.bfloat16)
+            ops.relu_fwd(c0, a0)
+            xrows = a0
         h1 = self._buf("h1", (Rap, Hb), torch.bfloat16)
-        ops.gemm(xrows, pr.view(pr.pb, pr.n_w1), h1, Rap, Hb, pr.k * Kp, bias=pr.view(pr.pb, pr.n_b1))
+        ops.gemm(xrows, pr.view(pr.pb, pr.n_w1), h1, Rap, Hb, pr.kin * Kp, bias=pr.view(pr.pb, pr.n_b1))
         a1 = self._buf("a1", (Rap, Hb), torch.bfloat16)
         (ops.silu_fwd if pr.has_norm else ops.relu_fwd)(h1, a1)
         y2 = self._buf("y2", (Rap, Do), torch.bfloat16)
         ops.gemm(a1, pr.view(pr.pb, pr.n_w2), y2, Rap, Do, Hb, bias=pr.view(pr.pb, pr.n_b2))
-        st.dev.update(xn=xn, ln_mean=mean, ln_rstd=rstd, h1=h1, a1=a1, y2=y2)
+        st.dev.update(xn=xn, ln_mean=mean, ln_rstd=rstd, h1=h1, a1=a1, y2=y2, c0=c0, a0=a0)
 
     def forward_llm(self, st: StepState, compute_loss=True, need_backward=True, logits_rows="all"):
         ops, geo, llm = self.ops, self.geo, self.llm
@@ -680,11 +711,12 @@ class TasuModel:
 
     def grad_ranges(self, w1_chunks=1):
         """The flat gradient bucket as the ranges backward_projector completes, in completion order:
-        [b1 | W2 | b2] (one contiguous tail), then ``w1_chunks`` row blocks of W1, then -- linear-silu only --
-        [norm.weight | norm.bias].  The ranges tile [0, numel) exactly."""
+        [b1 | W2 | b2] (one contiguous tail), then ``w1_chunks`` row blocks of W1, then the input stage's parameters --
+        [norm.weight | norm.bias] (linear-silu) or [conv1d.weight | conv1d.bias] (cov1d-linear).  The ranges tile [0, numel)
+        exactly."""
         pr = self.proj
         o_w1, o_b1 = pr.offsets[pr.n_w1][0], pr.offsets[pr.n_b1][0]
-        ld = pr.k * pr.Kp
+        ld = pr.kin * pr.Kp
         rows = [pr.Hb * i // w1_chunks for i in range(w1_chunks + 1)]
         out = [(o_b1, pr.numel)] + [(o_w1 + r0 * ld, o_w1 + r1 * ld) for r0, r1 in zip(rows[:-1], rows[1:])]
         return out + ([(0, o_w1)] if o_w1 > 0 else [])
@@ -700,7 +732,7 @@ class TasuModel:
         ranges = self.grad_ranges(w1_chunks)
         # merge backward: gradient rows that hold audio -> projector output gradient
         Rap, K, Kp, Hb, Do = st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
-        kKp = pr.k * Kp
+        kKp = pr.kin * Kp                                     # input width of the first Linear
         audio_rows = d["audio_rows_pad"] if "audio_rows_pad" in d else self._pad_rows(st)
         dy2 = self._buf("dy2", (Rap, Do), bf)
         ops.merge_bwd(d["dx"], audio_rows, dy2, Rap, Do)
@@ -721,7 +753,7 @@ class TasuModel:
             on_ready(*ranges[0])
         dh1_t = self._buf("dh1_t", (Hb, Rap), bf)
         xn_t = self._buf("xn_t", (kKp, Rap), bf)
-        xrows = d["xn"].view(Rap, kKp)
+        xrows = d["a0"] if pr.has_conv else d["xn"].view(Rap, kKp)
         ops.transpose(dh1, dh1_t, Rap, Hb, Rap, Hb)
         ops.transpose(xrows, xn_t, Rap, kKp, Rap, kKp)
         gw1 = pr.view(pr.g, pr.n_w1)
@@ -730,6 +762,22 @@ class TasuModel:
             ops.gemm(dh1_t[r0:r1], xn_t, gw1[r0:r1], r1 - r0, kKp, Rap, mode=GEMM_F32)
             if on_ready is not None:
                 on_ready(*ranges[1 + i])
+        if pr.has_conv:
+            # input stage of cov1d-linear: da0 = dh1 W1, through the ReLU, then db0 and dW0 = dc0^T [k frames concatenated]
+            da0 = self._buf("dxn", (Rap, Kp), bf)
+            ops.gemm(dh1, pr.w1b_t, da0, Rap, Kp, Hb)
+            dc0 = self._buf("dc0", (Rap, Kp), bf)
+            ops.relu_bwd(da0, d["c0"], dc0)
+            ops.colsum(dc0, pr.view(pr.g, "conv1d.bias"), Rap, Kp)
+            kcKp = pr.k * Kp
+            dc0_t = self._buf("dc0_t", (Kp, Rap), bf)
+            xcat_t = self._buf("xcat_t", (kcKp, Rap), bf)
+            ops.transpose(dc0, dc0_t, Rap, Kp, Rap, Kp)
+            ops.transpose(d["xn"].view(Rap, kcKp), xcat_t, Rap, kcKp, Rap, kcKp)
+            ops.gemm(dc0_t, xcat_t, pr.view(pr.g, "conv1d.weight"), Kp, kcKp, Rap, mode=GEMM_F32)
+            if on_ready is not None:
+                on_ready(*ranges[-1])
+            return
         if not pr.has_norm:
             return                                     # the posterior carries no parameters: nothing upstream of W1
         dxn = self._buf("dxn", (Rap, Kp), bf)

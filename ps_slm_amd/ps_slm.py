@@ -167,11 +167,11 @@ def load_hf_llm_state_dict(path):
 def model_factory(train_config, model_config, **kwargs):
     """Same contract as Multitask/model/ps-slm.py:130-181: returns (model, tokenizer)."""
     projector = model_config.get("encoder_projector", "linear-silu")
-    if projector not in ("linear-silu", "linear"):
+    if projector not in ("linear-silu", "linear", "cov1d-linear"):
         raise NotImplementedError(f"encoder_projector={projector!r}: the MI355X path serves 'linear-silu' (the shipped recipe, "
-                                  "Multitask/scripts/finetune_deespeed_sensevoice.sh:25) and 'linear' (EncoderProjectorConcat, "
-                                  "Multitask/model/projector.py:28-49); cov1d-linear / q-former / cross-attention / "
-                                  "simple_linear are not built")
+                                  "Multitask/scripts/finetune_deespeed_sensevoice.sh:25), 'linear' (EncoderProjectorConcat, "
+                                  "Multitask/model/projector.py:28-49) and 'cov1d-linear' (EncoderProjectorCov1d, :53-73); "
+                                  "q-former / cross-attention / simple_linear are not built")
     if train_config.get("use_peft", False) or not train_config.get("freeze_llm", True):
         raise NotImplementedError("the MI355X path trains the projector only (freeze_llm=true, use_peft=false: "
                                   "Multitask/scripts/finetune_deespeed_sensevoice.sh:28,84)")
@@ -182,7 +182,7 @@ def model_factory(train_config, model_config, **kwargs):
                        "(bf16 GEMM operands, fp32 accumulation / residual stream / norms / loss)")
     geo = geometry_from_config(model_config)
     geo.projector = projector
-    geo.projector_ds_rate = int(model_config.get("encoder_projector_ds_rate", 1) or 1) if projector == "linear" else 1
+    geo.projector_ds_rate = int(model_config.get("encoder_projector_ds_rate", 1) or 1) if projector in ("linear", "cov1d-linear") else 1
     tokenizer = setup_tokenizer(train_config, model_config, geo, **kwargs)
     if not isinstance(tokenizer, SyntheticLLMTokenizer):
         geo.speech_id, geo.eos_id = tokenizer.default_speech_token, tokenizer.eos_token_id

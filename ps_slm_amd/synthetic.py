@@ -50,7 +50,15 @@ def random_state_dict(geo: Geometry, seed: int, with_encoder=True, scale=0.05):
     if not geo.tied:
         sd["llm.lm_head.weight"] = rn(V, D)
     K, Hb = geo.ctc_vocab, geo.bottleneck
-    if geo.projector == "linear":                       # EncoderProjectorConcat: k frames concatenated, no norm
+    if geo.projector == "cov1d-linear":                 # EncoderProjectorCov1d: Conv1d(K, K, k, stride k) -> ReLU -> Linear -> ReLU -> Linear
+        kc = geo.projector_ds_rate
+        sd["encoder_projector.conv1d.weight"] = rn(K, K, kc, s=1.0 / math.sqrt(K * kc))
+        sd["encoder_projector.conv1d.bias"] = rn(K)
+        sd["encoder_projector.linear1.weight"] = rn(Hb, K, s=1.0 / math.sqrt(K))
+        sd["encoder_projector.linear1.bias"] = rn(Hb)
+        sd["encoder_projector.linear2.weight"] = rn(D, Hb, s=1.0 / math.sqrt(Hb))
+        sd["encoder_projector.linear2.bias"] = rn(D)
+    elif geo.projector == "linear":                     # EncoderProjectorConcat: k frames concatenated, no norm
         Kin = K * geo.projector_ds_rate
         sd["encoder_projector.linear1.weight"] = rn(Hb, Kin, s=1.0 / math.sqrt(K))
         sd["encoder_projector.linear1.bias"] = rn(Hb)

@@ -94,6 +94,20 @@ def decode_margin_cases():
     return geo, sd, cases
 
 
+def cov1d_projector_case(k):
+    """(geo, state dict, batch, fixture) of tests/golden/mid_text_cov1d_k{k}.npz (oracle/make_golden_cov1d.py): the alternate
+    ``encoder_projector="cov1d-linear"`` (EncoderProjectorCov1d: Conv1d kernel = stride = k -> ReLU -> Linear -> ReLU -> Linear)."""
+    from ps_slm_amd.model import Geometry
+    from ps_slm_amd.synthetic import MID_GEOMETRY, random_state_dict, synthetic_text_batch
+
+    z = load_npz(f"mid_text_cov1d_k{k}")
+    geo = Geometry.from_dict(dict(MID_GEOMETRY, projector="cov1d-linear", projector_ds_rate=k, bottleneck=2048))
+    sd = random_state_dict(geo, int(z["seed_w"]), with_encoder=False)
+    batch = synthetic_text_batch(geo, 3, seed=int(z["seed_b"]), prompt_len=9, n_audio=22, target_len=17, speech_pos=4,
+                                 feat_frames=12, noise=False, ragged=True)
+    return geo, sd, batch, z
+
+
 def linear_projector_case(k):
     """(geo, state dict, batch, fixture) of tests/golden/mid_text_linear_k{k}.npz (oracle/make_golden_linear.py): the alternate
     ``encoder_projector="linear"`` (EncoderProjectorConcat) with k frames concatenated per projector row."""

@@ -536,6 +536,33 @@ def test_linear_projector_step_matches_oracle_and_reference(k):
         assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
 
 
+@pytest.mark.parametrize("k", [1, 2])
+def test_cov1d_projector_step_matches_oracle_and_reference(k):
+    """``encoder_projector="cov1d-linear"`` (Conv1d kernel = stride = k as one GEMM over k concatenated frames -> ReLU -> Linear ->
+    ReLU -> Linear; flat bucket [conv W | conv b | W1 | b1 | W2 | b2]) through the product's host code on the CPU double: loss /
+    gradients against the bf16 oracle, loss against the REAL reference's fp32 golden, state-dict round trip under the reference's
+    key names (conv1d.weight in its [out, in, tap] layout), and the gradient exchange ranges tiling the bucket."""
+    from conftest import cov1d_projector_case
+    geo, sd, batch, z = cov1d_projector_case(k)
+    model = build(geo, sd)
+    assert model.proj.names[:2] == ("conv1d.weight", "conv1d.bias") and model.proj.k == k and model.proj.kin == 1
+    st = run_text(model, batch)
+    out, grads = O.loss_and_projector_grads(sd, batch, dataclasses.asdict(geo), "bf16")
+    assert abs(float(st.dev["loss_out"][0]) - float(out["loss"])) < 2e-3
+    assert abs(float(st.dev["loss_out"][0]) - float(z["loss"])) < 2e-2
+    mine = model.projector_grads()
+    assert sorted(mine) == sorted(grads)
+    for name, g in grads.items():
+        assert mine[name].shape == g.shape, name
+        assert float(torch.nn.functional.cosine_similarity(mine[name].flatten(), g.flatten(), dim=0)) > 0.999, name
+    for name, v in model.projector_state_dict().items():
+        assert torch.equal(v, sd[name]), name
+    for chunks in (1, 4):
+        ranges = sorted(model.grad_ranges(chunks))
+        assert ranges[0][0] == 0 and ranges[-1][1] == model.proj.numel and len(ranges) == chunks + 2
+        assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+
+
 def test_shape_buckets_pad_without_changing_the_step(mid):
     """TasuModel.shape_buckets (graph reuse for real data): the batch is padded to the next multiple of (token columns, posterior
     rows, labelled rows) with masked columns / zero rows / ignored labels; loss, accuracy, count and gradients are those of the

@@ -354,3 +354,24 @@ def test_linear_projector_vs_reference(k):
     close(grads["encoder_projector.linear2.bias"], z["grad.linear2.bias"], rtol=2e-4, atol=1e-7)
     close(grads["encoder_projector.linear2.weight"][::16], z["grad.linear2.weight.rows16"], rtol=2e-4, atol=1e-7)
     close(grads["encoder_projector.linear1.weight"][::64], z["grad.linear1.weight.rows64"], rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_cov1d_projector_vs_reference(k):
+    """encoder_projector="cov1d-linear" (EncoderProjectorCov1d, projector.py:53-73), kernel = stride = 1 and 2, through the REAL
+    reference at the mid geometry: the oracle's restatement reproduces loss, accuracy, logits and projector gradients."""
+    import dataclasses
+
+    from conftest import cov1d_projector_case
+    geo, sd, batch, z = cov1d_projector_case(k)
+    out, grads = O.loss_and_projector_grads(sd, batch, dataclasses.asdict(geo), "fp32")
+    close(out["loss"], z["loss"])
+    close(out["acc"], z["acc"])
+    cols = torch.from_numpy(z["cols"])
+    close(out["logits"][:, :, cols], z["logits_cols"], rtol=2e-4, atol=2e-5)
+    close(grads["encoder_projector.conv1d.bias"], z["grad.conv1d.bias"], rtol=2e-4, atol=1e-7)
+    close(grads["encoder_projector.conv1d.weight"][::8], z["grad.conv1d.weight.rows8"], rtol=2e-4, atol=1e-7)
+    close(grads["encoder_projector.linear1.bias"], z["grad.linear1.bias"], rtol=2e-4, atol=1e-7)
+    close(grads["encoder_projector.linear2.bias"], z["grad.linear2.bias"], rtol=2e-4, atol=1e-7)
+    close(grads["encoder_projector.linear2.weight"][::16], z["grad.linear2.weight.rows16"], rtol=2e-4, atol=1e-7)
+    close(grads["encoder_projector.linear1.weight"][::64], z["grad.linear1.weight.rows64"], rtol=2e-4, atol=1e-7)
