@@ -368,6 +368,24 @@ int tasu_decode_step_prologue(const float* table, const int32_t* ids, float* x, 
                               const int32_t* pos, float* cos_tab, float* sin_tab, float theta, int32_t* index,
                               const int32_t* src_row, const int32_t* lens, int n_beams, int M, int D, int ctx, void* stream);
 
+/* ------------------------------------------------------------------------------------------ RCCL (one process per GPU)
+ * Replaces the gradient exchange of the DeepSpeed engine (Multitask/finetune_deepspeed.py:147-149; ZeRO-2 reduce-scatter +
+ * all-gather, Multitask/conf/ds_config.json:15-21) by what it amounts to for 54.5 M replicated parameters: an in-place SUM
+ * all-reduce of ranges of the flat fp32 gradient bucket over RCCL / xGMI, asynchronous on the given HIP stream (the engine uses
+ * a side stream chained to the wgrad kernels by events and divides by the world size inside tasu_adamw).
+ * RCCL is bound at run time (the copy already in the process, else the ROCm installation's; TASU_RCCL_PATH overrides).
+ * Bootstrap: rank 0 calls tasu_comm_unique_id, the launcher's rendezvous carries the 128 bytes to every rank (the entrypoint
+ * broadcasts them over the process group torch.distributed.run set up), every rank calls tasu_comm_init on ITS device
+ * (hipSetDevice first).  HOST calls; a communicator belongs to the thread / device that created it.
+ * tasu_allreduce_min_i32: the 1-int "every rank still has a batch" flag that replaces the reference's per-step gloo
+ * monitored_barrier (Multitask/utils/deepspeed_utils.py:102-123,191). */
+int tasu_comm_available(void);                                   /* 1 when RCCL could be bound */
+int tasu_comm_unique_id(uint8_t* id128);
+int tasu_comm_init(const uint8_t* id128, int rank, int world, void** comm);
+int tasu_comm_destroy(void* comm);
+int tasu_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
+int tasu_allreduce_min_i32(void* comm, int32_t* buf, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------------ FLAC (host)
  * The reference reads ``.flac`` entries with torchaudio.load (speech_dataset_large.py:123-127: [C, T] float
  * in [-1, 1), channel mean).  HOST functions (no device work, no stream): tasu_flac_info parses STREAMINFO

@@ -85,6 +85,14 @@ PROTOTYPES = {
     "tasu_decode_step_prologue": [vp, vp, vp, vp, vp, f32, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp],
 }
 RESTYPE_I64 = set()
+PROTOTYPES.update({
+    "tasu_comm_available": [],
+    "tasu_comm_unique_id": [vp],
+    "tasu_comm_init": [vp, i32, i32, vp],
+    "tasu_comm_destroy": [vp],
+    "tasu_allreduce_f32": [vp, vp, i64, vp],
+    "tasu_allreduce_min_i32": [vp, vp, i64, vp],
+})
 
 ABI_VERSION = 4
 _lib = None

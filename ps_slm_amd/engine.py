@@ -8,8 +8,11 @@ trainable parameters only; WarmupCosineLR stepped after every optimizer step.  Z
 with 54.5 M trainable parameters it would save 0.6 GB per GPU of 288 GB, and replicated DP with all-reduce
 is the same update.
 
-Data parallelism (``overlap_comm`` of ds_config.json:15-21, rebuilt for this step): one process per GPU,
-``torch.distributed`` (backend "nccl" == RCCL over xGMI).  The flat fp32 gradient bucket (218 MB) is exchanged in the
+Data parallelism (``overlap_comm`` of ds_config.json:15-21, rebuilt for this step): one process per GPU.  On the GPU the
+collective is RCCL over xGMI through the C-ABI (``tasu_comm_init`` / ``tasu_allreduce_f32``, include/tasu_hip.h: RcclExchange
+below); ``torch.distributed`` is the launcher's rendezvous (it carries RCCL's unique id to the ranks) and the control plane
+(logged scalars, checkpoint barrier) -- and, over gloo, the collective of the CPU test double and of the two-ranks-on-one-GPU
+test, which RCCL cannot host.  The flat fp32 gradient bucket (218 MB) is exchanged in the
 ranges the backward completes them in (TasuModel.grad_ranges): the Linear2 / bias tail, then N row blocks of the
 Linear1 weight gradient (94 % of the bytes), then the LayerNorm parameters.  Each range's all-reduce is issued on a side
 HIP stream behind an event recorded right after its wgrad kernel, so it runs under the remaining backward kernels
@@ -18,10 +21,49 @@ wait for range i, fused AdamW on range i (1/world folded in) -- which runs while
 projector is the FIRST layer of the network, so its gradients are the LAST thing backward produces: what cannot be
 hidden is the all-reduce of the final row block.  No other data-path collective exists.
 """
+import ctypes
 import math
 
 import torch
 import torch.distributed as dist
+
+
+class RcclExchange:
+    """The data-path collective on the GPU: one RCCL communicator per process behind the C-ABI (csrc/comm.hip).  The unique id
+    travels over the process group the launcher set up (control plane); the all-reduces themselves never touch
+    torch.distributed."""
+
+    def __init__(self, lib, pg, device):
+        self.lib = lib
+        if not lib.tasu_comm_available():
+            raise RuntimeError("libtasu_hip.so could not bind RCCL (librccl.so not found; TASU_RCCL_PATH overrides)")
+        rank, world = dist.get_rank(pg), dist.get_world_size(pg)
+        ident = (ctypes.c_uint8 * 128)()
+        if rank == 0 and lib.tasu_comm_unique_id(ident):
+            raise RuntimeError("tasu_comm_unique_id failed")
+        box = [bytes(ident)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
+        ident = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+        torch.cuda.set_device(device)
+        comm = ctypes.c_void_p()
+        if lib.tasu_comm_init(ident, rank, world, ctypes.byref(comm)):
+            raise RuntimeError(f"tasu_comm_init failed (rank {rank} of {world})")
+        self.comm = comm
+
+    def all_reduce_sum(self, t, stream):
+        """In-place SUM over the ranks of a contiguous fp32 tensor, asynchronous on ``stream``."""
+        if self.lib.tasu_allreduce_f32(self.comm, t.data_ptr(), t.numel(), stream.cuda_stream):
+            raise RuntimeError("tasu_allreduce_f32 failed")
+
+    def all_reduce_min_i32(self, t, stream):
+        if self.lib.tasu_allreduce_min_i32(self.comm, t.data_ptr(), t.numel(), stream.cuda_stream):
+            raise RuntimeError("tasu_allreduce_min_i32 failed")
+
+    def close(self):
+        if self.comm:
+            self.lib.tasu_comm_destroy(self.comm)
+            self.comm = None
 
 
 def warmup_cosine_ratio(it, warmup_num_steps=200, total_num_steps=15000, warmup_min_ratio=0.0, cos_min_ratio=1e-4,
@@ -57,6 +99,11 @@ class TasuEngine:
         self.micro_steps = 0
         dev = self.core.device
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # the collective: RCCL through the C-ABI when the ranks were launched with the nccl backend (one GPU per rank); a gloo
+        # group (CPU double; two ranks sharing one GPU in tests) keeps torch.distributed's all_reduce
+        self.rccl = None
+        if self.exchange and dev.type == "cuda" and dist.get_backend(process_group) == "nccl":
+            self.rccl = RcclExchange(self.core.ops.lib, process_group, dev)
         self._pending = []             # [(lo, hi, work)] in issue order
         self._last_state = None
         self.time_exchange = False     # bench.py: record event pairs around every wait of step()
@@ -98,8 +145,13 @@ class TasuEngine:
             ev = torch.cuda.Event()
             ev.record()
             self.comm_stream.wait_event(ev)
-            with torch.cuda.stream(self.comm_stream):
-                work = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if self.rccl is not None:
+                self.rccl.all_reduce_sum(g[lo:hi], self.comm_stream)
+                work = torch.cuda.Event()              # "this range has been reduced": the compute stream waits for it in step()
+                work.record(self.comm_stream)
+            else:
+                with torch.cuda.stream(self.comm_stream):
+                    work = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         else:
             work = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._pending.append((lo, hi, work))
@@ -140,9 +192,12 @@ class TasuEngine:
                 if timed:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record()
-                work.wait()                             # NCCL: the compute STREAM waits (no host block); gloo: host wait
-                if self.comm_stream is not None:
-                    torch.cuda.current_stream().wait_stream(self.comm_stream)
+                if isinstance(work, torch.cuda.Event):
+                    torch.cuda.current_stream().wait_event(work)    # RCCL: the compute STREAM waits for this range only
+                else:
+                    work.wait()                         # gloo: host wait
+                    if self.comm_stream is not None:
+                        torch.cuda.current_stream().wait_stream(self.comm_stream)
                 if timed:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
@@ -165,7 +220,10 @@ class TasuEngine:
         if self.world == 1:
             return has_batch
         flag = torch.tensor([1 if has_batch else 0], dtype=torch.int32, device=self.core.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+        if self.rccl is not None:
+            self.rccl.all_reduce_min_i32(flag, torch.cuda.current_stream())
+        else:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
         return bool(flag.item())
 
     def reduce_scalars(self, *vals):

@@ -64,12 +64,42 @@ def test_chunked_rccl_exchange_is_bit_identical_to_the_single_bucket_step(nccl_g
     want = run_steps(m0, e0)
     m1, e1 = build(True, 4, graphs)
     assert e1.exchange and e1.w1_chunks == 4 and e1.comm_stream is not None
+    assert e1.rccl is not None and e1.rccl.comm                 # the collective is RCCL through the C-ABI (tasu_allreduce_f32)
     e1.time_exchange = True
     got = run_steps(m1, e1)
     assert len(e1.exposed_events) == 4 * 6 and e1.exposed_ms() >= 0.0
     for a, b in zip(want, got):
         assert torch.equal(a, b)
     assert float(want[0][-1]) < float(want[0][0])         # and the steps do train
+
+
+def test_rccl_entry_points_of_the_c_abi():
+    """tasu_comm_unique_id / tasu_comm_init / tasu_allreduce_f32 / tasu_allreduce_min_i32 / tasu_comm_destroy called directly (one
+    rank: the sum over one rank is the identity, bit for bit), on a side stream with event chaining like the engine's."""
+    import ctypes
+    from ps_slm_amd import _lib
+    lib = _lib.load()
+    assert lib.tasu_comm_available() == 1
+    ident = (ctypes.c_uint8 * 128)()
+    assert lib.tasu_comm_unique_id(ident) == 0 and any(ident)
+    torch.cuda.set_device(0)
+    comm = ctypes.c_void_p()
+    assert lib.tasu_comm_init(ident, 0, 1, ctypes.byref(comm)) == 0 and comm.value
+    assert lib.tasu_comm_init(ident, 1, 1, ctypes.byref(ctypes.c_void_p())) != 0        # rank out of range
+    x = torch.randn(1 << 20, device="cuda")
+    want = x.clone()
+    side = torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    ev.record()
+    side.wait_event(ev)
+    assert lib.tasu_allreduce_f32(comm, x.data_ptr(), x.numel(), side.cuda_stream) == 0
+    torch.cuda.current_stream().wait_stream(side)
+    flag = torch.tensor([1], dtype=torch.int32, device="cuda")
+    assert lib.tasu_allreduce_min_i32(comm, flag.data_ptr(), 1, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(x, want) and int(flag) == 1
+    assert lib.tasu_allreduce_f32(comm, None, 4, None) != 0
+    assert lib.tasu_comm_destroy(comm) == 0
 
 
 def _two_rank_worker(rank, world, port, ret):
