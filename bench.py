@@ -282,8 +282,8 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
     engine = TasuEngine(model, load_ds_config(DEFAULT_DS_CONFIG))
     engine.train()
     geo = core.geo
-    def make_batch(seed):
-        raw = synthetic_text_batch(geo, B, seed=seed, noise=False)
+    def make_batch(seed, **shape):
+        raw = synthetic_text_batch(geo, B, seed=seed, noise=False, **shape)
         if audio:
             return raw, dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
                              input_features=raw["input_features"], input_feature_length=raw["input_feature_length"], GT=None)
@@ -292,7 +292,10 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                          input_features=None, input_feature_length=None, GT=GT)
 
     raw, batch = make_batch(1234 + rank)
-    batches = [batch] + ([make_batch(1234 + rank + 100 * i)[1] for i in range(1, 8)] if variable else [])
+    # variable shapes: 8 ragged batches of different audio / target lengths (dynamic batching gives every batch its own shape)
+    var_shapes = [(104, 128), (96, 120), (88, 101), (104, 90), (73, 128), (99, 111), (80, 84), (92, 125)]
+    batches = [batch] if not variable else [make_batch(1234 + rank + 100 * i, n_audio=na, target_len=tl, ragged=True)[1]
+                                             for i, (na, tl) in enumerate(var_shapes)]
     torch.manual_seed(1234 + rank)          # CPS alpha / keep draws come from the global CPU RNG, like the reference
     blank_note = None
     if blank_biased:
@@ -386,9 +389,10 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                 "projector wgrad+AdamW)" if audio else
                 "text-only CPS alignment step (fwd+dgrad bwd+projector wgrad+AdamW), frozen encoder pass skipped")
         if variable:
-            what += (f"; VARIABLE shapes: 8 distinct batches, CPS token drop 0.05 redrawn every step, shapes padded to buckets "
-                     f"(16 token columns, 8 posterior rows, 256 labelled rows): {len(seen_shapes)} distinct (S, posterior rows) seen, "
-                     f"{len(core._graphs)} step graphs captured; the figures below describe the LAST step's shape")
+            what += (f"; VARIABLE shapes: 8 ragged batches (73-104 audio tokens, 84-128 target tokens per utterance), CPS token drop "
+                     f"0.05 redrawn every step, shapes padded to buckets (16 token columns, 8 posterior rows, 256 labelled rows): "
+                     f"{len(seen_shapes)} distinct (S, posterior rows) seen, {len(core._graphs)} step graphs captured; value = "
+                     f"utterances / wall time over all shapes; S, FLOPs and roofline describe the LAST step's shape only")
         if blank_note:
             what += "; " + blank_note
         rec = {
@@ -474,7 +478,7 @@ def main():
     headline = args.model == "qwen2.5-1.5b" and args.path == "text"
     if world == 1 and headline and not args.no_extra:
         # BASELINE.json configs 4 and 5 as sub-records of the same line (shorter runs: their steps are 3-4x longer)
-        extras["variable_S"] = train_leg(args, "qwen2.5-1.5b", "text", args.batch, 16, 24, 1, 0, local_rank, False, variable=True)
+        extras["variable_S"] = train_leg(args, "qwen2.5-1.5b", "text", args.batch, 32, 24, 1, 0, local_rank, False, variable=True)
         extras["audio_sft"] = train_leg(args, "qwen2.5-1.5b", "audio", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank, False)
         extras["audio_sft_blank_biased"] = train_leg(args, "qwen2.5-1.5b", "audio", args.batch, max(5, args.steps // 2), 2, 1, 0,
                                                      local_rank, False, blank_biased=True)
