@@ -339,9 +339,9 @@ int kernel_choice() {
 }  // namespace
 
 int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
-                            const float* resid, int M, int N, int K, int out_mode, int bn, hipStream_t st);
+                            const float* resid, int M, int N, int K, int out_mode, int bn, hipStream_t st, int n0, int n1);
 int tasu_gemm_pp_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias, const float* resid,
-                          int M, int N, int K, int out_mode, hipStream_t st);
+                          int M, int N, int K, int out_mode, hipStream_t st, int n0, int n1);
 
 // Split-K plan for the 256 x 192 tile: ksplit blocks per tile so that tiles * ksplit is (close to) one round of 256
 // blocks, every split keeping >= 16 K-steps.  Returns 1 when the workspace is missing or too small.
@@ -432,10 +432,31 @@ extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int l
           }();
           const double c256 = cost(tm * ((N + 255) / 256), 256.0 * 256, pp_eff);
           const double best = use_pipe_bn == 128 ? c128 : (use_pipe_bn == 192 ? c192 : c96);
-          if (c256 < best) return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st);
+          if (c256 < best) {
+            // a mostly empty last round of big tiles (d_down: 560 tiles = 2.19 rounds): whole rounds on the big tiles, the
+            // remaining columns on the small tiles in a second launch (TASU_GEMM_NSPLIT=0 disables)
+            static const bool split_on = [] {
+              const char* e = getenv("TASU_GEMM_NSPLIT");
+              return !(e && e[0] == '0');
+            }();
+            const long tn = (N + 255) / 256, full = (tm * tn) / 256, tn_main = full * 256 / tm;
+            if (split_on && full >= 1 && tn_main > 0 && tn_main < tn) {
+              const int n_main = (int)tn_main * 256, n_tail = N - n_main;
+              const long u128 = tm * ((n_tail + 127) / 128), u192 = (long)((M + 127) / 128) * ((n_tail + 191) / 192);
+              const double t128 = cost(u128, 256.0 * 128, 1.00), t192 = cost(u192, 128.0 * 192, 0.86);
+              const double c_split = (double)full * 256.0 * 256 / pp_eff + (t128 < t192 ? t128 : t192) + 0.05 * 256.0 * 256;
+              if (c_split < c256) {
+                const int rc = tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, n_main);
+                if (rc) return rc;
+                return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, t128 < t192 ? 128 : 192, st,
+                                               n_main, 0);
+              }
+            }
+            return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, 0);
+          }
         }
       }
-      return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, use_pipe_bn, st);
+      return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, use_pipe_bn, st, 0, 0);
     }
   }
   int bn;

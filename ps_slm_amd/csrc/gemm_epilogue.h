@@ -27,6 +27,10 @@ struct Args {
   // tiles_n), ks = s / (tiles_m * tiles_n), and writes its fp32 partial tile into slab ks (C + ks * split_stride floats)
   int ksplit;
   long long split_stride;
+  // column range of this launch: output columns [n0, N) (OUT_GU_SWIGLU: act columns) -- the dispatcher covers a problem whose
+  // 256 x 256 tiles would end in a mostly empty round with two launches, whole rounds of big tiles + the rest on small ones
+  int n0 = 0;
+  int n1 = 0;           // host side only: the launch's tiles cover columns [n0, n1) (0 = N); n1 is tile-aligned or N
 };
 
 // tile s of the virtual one-tile-per-block grid -> (tm, tn): XCD-aware (block b and tile s = b + r*gridDim share b % 8,

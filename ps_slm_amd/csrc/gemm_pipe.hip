@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
       int tm, tn;
       const int ks = s / base_tiles;
       tile_coords(p, s - ks * base_tiles, base_tiles, tm, tn);
-      const int row0 = tm * BM, col0 = tn * BN;
+      const int row0 = tm * BM, col0 = p.n0 + tn * BN;
       const size_t kbase = (size_t)ks * nk * BK;    // first K element of this work item
       // both descriptors start 3 KiB below the tile: the per-lane offsets carry +3 KiB minus the immediate offset of their
       // piece (issue()), which keeps every register offset non-negative
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         if (OUT_MODE == OUT_GU_SWIGLU) {
           const int half = r >> 6, rr = r & 63;                       // wave column, row inside it
-          const int ocol = min(tn * 64 + half * 32 + (rr & 31), p.N - 1);   // output (act) column
+          const int ocol = min(p.n0 + tn * 64 + half * 32 + (rr & 31), p.N - 1);   // output (act) column
           vob[i] = (ocol + (rr >= 32 ? p.N : 0)) * p.ldb * 2 + c * 16 + (3 - (i & 3)) * 1024;
         } else {
           vob[i] = (min(col0 + r, p.N - 1) - col0) * p.ldb * 2 + c * 16 + (3 - (i & 3)) * 1024;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   };
 
   // epilogues: gemm_epilogue.h (acc[i][j][r] = C[m][n], m = row0 + wr*WM + i*16 + (lane&15), n = col0 + wc*WN + j*16 + (lane>>4)*4 + r)
-  auto store_gu = [&](int row0, int tn) { store_gu_swiglu<MI, NI, BM>(p, acc, row0, tn * 64 + wc * 32, wr * WM, lane); };
+  auto store_gu = [&](int row0, int tn) { store_gu_swiglu<MI, NI, BM>(p, acc, row0, p.n0 + tn * 64 + wc * 32, wr * WM, lane); };
   auto store_c = [&](int row0, int col0) {
     store_tile<MI, NI, OUT_MODE, HAS_BIAS, BM, BN, BM == 128>(p, acc, row0, col0, wr * WM, wc * WN, lane);
   };
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
     for (int kt = 0; kt + 1 < nk; ++kt) cur = kstep(T{}, cur);
     cur = kstep(F{}, cur);                         // no read-ahead into the next tile: the fragment registers are free
     if constexpr (OUT_MODE == OUT_GU_SWIGLU) store_gu(tm * BM, tn);
-    else store_c(tm * BM, tn * BN);             // for the epilogue, whose stores then drain under the next tile
+    else store_c(tm * BM, p.n0 + tn * BN);      // for the epilogue, whose stores then drain under the next tile
     zero_acc();
     if (s + (int)gridDim.x < ntiles) read_frags(fa0, fb0, cur, 0);   // landed before the barrier of the step just done
   }
@@ -259,7 +259,8 @@ int launch(Args a, hipStream_t st) {
     attr_set = true;
   }
   a.tiles_m = (a.M + BM - 1) / BM;
-  a.tiles_n = OUT_MODE == OUT_GU_SWIGLU ? (a.N + 63) / 64 : (a.N + BN - 1) / BN;
+  const int n_end = a.n1 > 0 ? a.n1 : a.N;
+  a.tiles_n = OUT_MODE == OUT_GU_SWIGLU ? (n_end - a.n0 + 63) / 64 : (n_end - a.n0 + BN - 1) / BN;
   const int ntiles = a.tiles_m * a.tiles_n * a.ksplit;
   const int grid = ntiles < cu_count() ? ntiles : cu_count();
   TASU_LAUNCH((gemm_pipe_kernel<BM, BN, OUT_MODE, HAS_BIAS>), dim3(grid), dim3(512), LDS, st, a);
@@ -277,9 +278,11 @@ int launch_bn(const Args& a, int bn, hipStream_t st) {
 
 // called from gemm.hip's dispatcher
 int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
-                            const float* resid, int M, int N, int K, int out_mode, int bn, hipStream_t st) {
+                            const float* resid, int M, int N, int K, int out_mode, int bn, hipStream_t st, int n0, int n1) {
   using namespace tasu_pipe;
   Args a;
+  a.n0 = n0;
+  a.n1 = n1;
   a.A = (const bf16*)A;
   a.B = (const bf16*)B;
   a.C = C;
@@ -309,7 +312,8 @@ int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void
   }
 }
 
-int tasu_gemm_pp_gu_dispatch(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K, hipStream_t st);
+int tasu_gemm_pp_gu_dispatch(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K, hipStream_t st,
+                             int n0, int n1);
 
 extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I,
                                         int K, void* stream) {
@@ -320,38 +324,59 @@ extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu,
     const char* e = getenv("TASU_GEMM_GU_KERNEL");
     return !e ? 0 : (e[0] == 'p' && e[1] == 'p' ? 2 : 1);
   }();
-  if (forced == 2 && I % 128 == 0 && K >= 256 && K % 128 == 0)
-    return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream);
-  if (forced == 0) {
+  auto pipe_range = [&](int n0) {                 // 256 x 128 tiles (64 act columns) of this file over act columns [n0, I)
+    Args a;
+    a.A = (const bf16*)A;
+    a.B = (const bf16*)Wgu;
+    a.C = gu;
+    a.R = nullptr;
+    a.bias = nullptr;
+    a.M = M;
+    a.N = I;
+    a.K = K;
+    a.lda = lda;
+    a.ldb = ldw;
+    a.ldc = 2 * I;
+    a.tiles_m = a.tiles_n = 0;
+    a.act = (bf16*)act;
+    a.ksplit = 1;
+    a.split_stride = 0;
+    a.n0 = n0;
+    return launch<256, 128, OUT_GU_SWIGLU, false>(a, (hipStream_t)stream);
+  };
+  const bool pp_ok = I % 128 == 0 && K >= 256 && K % 128 == 0;
+  if (forced == 2 && pp_ok) return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, 0);
+  if (forced == 0 && pp_ok) {
     // tile policy as in tasu_gemm_nt_bf16_ws (gemm.hip): 256 x 256 tiles (128 act columns, gemm_pp.hip) where their coarser
-    // rounds cost less than the 1.19 x per-FLOP efficiency they bring (4096 x 17920 x 1536: 257 -> 218 us)
+    // rounds cost less than the per-FLOP efficiency they bring (4096 x 17920 x 1536: 257 -> 218 us); and when the last round
+    // of big tiles would be mostly empty (1120 tiles on 256 CUs: 4.375 rounds), whole rounds on the big tiles + the remaining
+    // columns on the small ones in a second launch (4 rounds + 192 tiles of 256 x 128)
     static const bool pp_on = [] {
       const char* e = getenv("TASU_GEMM_PP");
       return !(e && e[0] == '0');
     }();
-    const long tm = (M + 255) / 256, cus = cu_count();
-    const double c128 = (double)((tm * ((I + 63) / 64) + cus - 1) / cus) * 0.5;
-    const double c256 = (double)((tm * ((I + 127) / 128) + cus - 1) / cus) / 1.19;
-    if (pp_on && I % 128 == 0 && K >= 256 && K % 128 == 0 && c256 < c128)
-      return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream);
+    static const bool split_on = [] {
+      const char* e = getenv("TASU_GEMM_NSPLIT");
+      return !(e && e[0] == '0');
+    }();
+    const long tm = (M + 255) / 256, cus = cu_count(), tn = (I + 127) / 128;
+    auto rounds = [&](long tiles) { return (double)((tiles + cus - 1) / cus); };
+    const double c128 = rounds(tm * ((I + 63) / 64)) * 0.5;
+    const double c256 = rounds(tm * tn) / 1.26;
+    if (pp_on && c256 < c128) {
+      const long full = (tm * tn) / cus;                          // whole rounds of big tiles
+      const long tn_main = full * cus / tm;                       // column tiles they cover
+      if (split_on && full >= 1 && tn_main < tn && tn_main > 0) {
+        const double c_split = (double)full / 1.26 + rounds(tm * (tn - tn_main) * 2) * 0.5 + 0.05;   // + the second launch's ramp
+        if (c_split < c256) {
+          const int rc = tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, (int)tn_main * 128);
+          return rc ? rc : pipe_range((int)tn_main * 128);
+        }
+      }
+      return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, 0);
+    }
   }
-  Args a;
-  a.A = (const bf16*)A;
-  a.B = (const bf16*)Wgu;
-  a.C = gu;
-  a.R = nullptr;
-  a.bias = nullptr;
-  a.M = M;
-  a.N = I;
-  a.K = K;
-  a.lda = lda;
-  a.ldb = ldw;
-  a.ldc = 2 * I;
-  a.tiles_m = a.tiles_n = 0;
-  a.act = (bf16*)act;
-  a.ksplit = 1;
-  a.split_stride = 0;
-  return launch<256, 128, OUT_GU_SWIGLU, false>(a, (hipStream_t)stream);
+  return pipe_range(0);
 }
 
 // ---- split-K form for grids that would leave most CUs idle behind a very long K (the lm_head dgrad over the labelled rows

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
     const int ks = s / base_tiles;
     tile_coords<4>(p, s - ks * base_tiles, base_tiles, tm, tn);
     const int row0 = tm * BM;
-    const int brow0 = OUT_MODE == OUT_GU_SWIGLU ? tn * 128 : tn * BN;   // OUT_GU_SWIGLU: first gate row = first act column
+    const int brow0 = p.n0 + (OUT_MODE == OUT_GU_SWIGLU ? tn * 128 : tn * BN);   // OUT_GU_SWIGLU: first gate row = first act column
     const size_t k0 = (size_t)ks * nk * BK;          // first K element of this work item
     d.a = (const char*)(p.A + (size_t)row0 * p.lda + k0) - 1024;
     d.b = (const char*)(p.B + (size_t)brow0 * p.ldb + k0) - 1024;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
   fence();
   read_b(fbx, Z{}, Z{});
 
-  auto store_gu = [&](int row0, int tn) { store_gu_swiglu<MI, NI, BM>(p, acc, row0, tn * 128 + wc * 32, wr * 128, lane); };
+  auto store_gu = [&](int row0, int tn) { store_gu_swiglu<MI, NI, BM>(p, acc, row0, p.n0 + tn * 128 + wc * 32, wr * 128, lane); };
   auto store_c = [&](int row0, int col0, int ks) {
     Args q = p;
     if constexpr (OUT_MODE == TASU_GEMM_OUT_F32) q.C = (float*)p.C + (size_t)ks * p.split_stride;   // slab of this K range
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
       fence();
     }
     if constexpr (OUT_MODE == OUT_GU_SWIGLU) store_gu(tm * BM, tn);
-    else store_c(tm * BM, tn * BN, ks);
+    else store_c(tm * BM, p.n0 + tn * BN, ks);
     zero_acc();
     cur = nxt;
   }
@@ -314,7 +314,8 @@ int launch(Args a, hipStream_t st) {
     attr_set = true;
   }
   a.tiles_m = (a.M + BM - 1) / BM;
-  a.tiles_n = OUT_MODE == OUT_GU_SWIGLU ? (a.N + 127) / 128 : (a.N + 255) / 256;
+  const int n_end = a.n1 > 0 ? a.n1 : a.N;
+  a.tiles_n = OUT_MODE == OUT_GU_SWIGLU ? (n_end - a.n0 + 127) / 128 : (n_end - a.n0 + 255) / 256;
   const int ntiles = a.tiles_m * a.tiles_n * a.ksplit;
   const int grid = ntiles < cu_count() ? ntiles : cu_count();
   TASU_LAUNCH((gemm_pp_kernel<OUT_MODE, HAS_BIAS>), dim3(grid), dim3(512), LDS, st, a);
@@ -326,9 +327,11 @@ int launch(Args a, hipStream_t st) {
 // C[M,N] = A[M,K] . B[N,K]^T (+ bias) with the 256 x 256 ping-pong kernel; same contract as tasu_gemm_nt_bf16_ws
 // (K % 64 == 0, lda / ldb % 8 == 0, 16-byte aligned operands).  Called from gemm.hip's dispatcher.
 int tasu_gemm_pp_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias, const float* resid,
-                          int M, int N, int K, int out_mode, hipStream_t st) {
+                          int M, int N, int K, int out_mode, hipStream_t st, int n0, int n1) {
   using namespace tasu_pp;
   Args a;
+  a.n0 = n0;
+  a.n1 = n1;
   a.A = (const bf16*)A;
   a.B = (const bf16*)B;
   a.C = C;
@@ -358,10 +361,13 @@ int tasu_gemm_pp_dispatch(const void* A, int lda, const void* B, int ldb, void* 
 }
 
 // gate|up projection + SwiGLU epilogue on 256 x 256 tiles (128 act columns); called from tasu_gemm_gate_up_swiglu (gemm_pipe.hip)
-int tasu_gemm_pp_gu_dispatch(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K, hipStream_t st) {
+int tasu_gemm_pp_gu_dispatch(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K, hipStream_t st,
+                             int n0, int n1) {
   using namespace tasu_pp;
   if (I % 128 || K < 256 || K % 128) return TASU_ERR_ARG;
   Args a;
+  a.n0 = n0;
+  a.n1 = n1;
   a.A = (const bf16*)A;
   a.B = (const bf16*)Wgu;
   a.C = gu;
@@ -410,7 +416,7 @@ extern "C" int tasu_gemm_nt_bf16_slabs(const void* A, int lda, const void* B, in
 }
 
 int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
-                            const float* resid, int M, int N, int K, int out_mode, int bn, hipStream_t st);
+                            const float* resid, int M, int N, int K, int out_mode, int bn, hipStream_t st, int n0, int n1);
 
 // tasu_gemm_nt_bf16 on a NAMED kernel, regardless of the dispatcher's tile policy (tests, tuning runs; include/tasu_hip.h)
 extern "C" int tasu_gemm_nt_bf16_kernel(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
@@ -421,13 +427,13 @@ extern "C" int tasu_gemm_nt_bf16_kernel(const void* A, int lda, const void* B, i
   switch (kernel) {
     case TASU_GEMM_KERNEL_PP256:
       if (K < 256 || K % 128) return TASU_ERR_ARG;            // an even number (>= 4) of 64-deep K-tiles
-      return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, (hipStream_t)stream);
+      return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, (hipStream_t)stream, 0, 0);
     case TASU_GEMM_KERNEL_PIPE128:
-      return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, 128, (hipStream_t)stream);
+      return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, 128, (hipStream_t)stream, 0, 0);
     case TASU_GEMM_KERNEL_PIPE192:
-      return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, 192, (hipStream_t)stream);
+      return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, 192, (hipStream_t)stream, 0, 0);
     case TASU_GEMM_KERNEL_PIPE96:
-      return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, 96, (hipStream_t)stream);
+      return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, 96, (hipStream_t)stream, 0, 0);
     default:
       return TASU_ERR_ARG;
   }

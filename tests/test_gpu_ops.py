@@ -119,6 +119,24 @@ def test_gemm_pp256_many_tiles_per_workgroup(hip):
         assert torch.equal(c1, c2) and torch.equal(c1, c3)
 
 
+@pytest.mark.parametrize("mode", [0, 2])
+def test_gemm_policy_splits_the_columns_over_two_kernels(hip, mode):
+    """4096 x 8960 (560 tiles of 256 x 256 = 2.19 rounds of 256 CUs) and 4096 x 17920: the dispatcher runs whole rounds on the
+    256 x 256 kernel and the remaining columns on the loader-wave kernel in a second launch; every output element still sees
+    its K range in the same order, so the result equals one kernel's, bit for bit."""
+    for M, N, K in ((4096, 8960, 256), (4096, 17920, 384), (3000, 9100, 256)):
+        a = randn(M, K, dtype=BF, seed=7).cuda()
+        b = randn(N, K, dtype=BF, seed=8, scale=1.0 / math.sqrt(K)).cuda()
+        ldc = (N + 63) // 64 * 64
+        r = randn(M, ldc, seed=9).cuda() if mode == 2 else None
+        c1 = torch.zeros(M, ldc, dtype=BF if mode == 0 else F32).cuda()
+        c2 = torch.zeros_like(c1)
+        hip.gemm(a, b, c1, M, N, K, resid=r, mode=mode)
+        hip.gemm_on("pipe128", a, b, c2, M, N, K, resid=r, mode=mode)
+        torch.cuda.synchronize()
+        assert torch.equal(c1, c2), (M, N, K)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gemm_unaligned_output_rows(hip, fake, mode):
     """ldc = N = 203: rows of C are neither 16- nor 8-byte aligned, so the kernels take their element-wise epilogues."""
