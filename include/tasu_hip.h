@@ -161,6 +161,12 @@ int tasu_rmsnorm_fwd_rows(const float* x, const int32_t* src_rows, const float* 
                           float eps, void* stream);
 int tasu_rmsnorm_bwd_rows(const void* dy_compact, const float* x, const float* w, const float* rstd_compact,
                           const int32_t* slot, float* dx, void* dx_bf16, int M, int D, void* stream);
+/* ... and with the rows' residual-stream gradient given COMPACT as well (the last decoder layer's MLP runs on the labelled rows
+ * only: positions without a label feed nothing there): dx[m,:] = resid[s,:] + dgrad(dy[s], x[m], rstd[s]) if s = slot[m] >= 0
+ * else 0 -- the scatter back to all M rows, for the layer's attention backward. */
+int tasu_rmsnorm_bwd_rows_resid(const void* dy_compact, const float* x, const float* w, const float* rstd_compact,
+                                const int32_t* slot, const float* resid_compact, float* dx, void* dx_bf16, int M, int D,
+                                void* stream);
 
 /* ---------------------------------------------------------------------------------------------- RoPE
  * cos/sin tables from position ids (modeling_qwen2.py:91-102): tab[m][i] = cos/sin(pos[m] * theta^(-2i/hd)),

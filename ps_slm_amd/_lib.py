@@ -26,6 +26,7 @@ PROTOTYPES = {
     "tasu_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "tasu_rmsnorm_fwd_rows": [vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "tasu_rmsnorm_bwd_rows": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "tasu_rmsnorm_bwd_rows_resid": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "tasu_rope_table": [vp, vp, vp, i32, i32, f32, vp],
     "tasu_rope_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "tasu_rope_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

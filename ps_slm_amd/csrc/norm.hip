@@ -92,7 +92,8 @@ template <int NG>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_reg_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                               const float* __restrict__ w, const float* __restrict__ rstd,
                                                               const int32_t* __restrict__ slot, float* __restrict__ dx,
-                                                              bf16* __restrict__ dxb, int accumulate, int M) {
+                                                              bf16* __restrict__ dxb, int accumulate, int M,
+                                                              const float* __restrict__ resid_c) {
   constexpr int D = NG * 256;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -113,7 +114,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_reg_kernel(const bf16* __rest
   for (int g = 0; g < NG; ++g) {
     v[g] = *(const f32x4*)(x + base + g * 256);
     d[g] = __builtin_convertvector(*(const bf16x4*)(dy + cbase + g * 256), f32x4);
-    o[g] = accumulate ? *(const f32x4*)(dx + base + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // resid_c (with a slot map): the COMPACT residual-stream gradient of the row, which this row's output starts from
+    o[g] = accumulate ? *(const f32x4*)(dx + base + g * 256)
+                      : (resid_c ? *(const f32x4*)(resid_c + cbase + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f});
   }
   const float r = rstd[crow];
   float dot = 0.f;
@@ -140,7 +143,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_reg_kernel(const bf16* __rest
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ rstd,
                                                           const int32_t* __restrict__ slot, float* __restrict__ dx,
-                                                          bf16* __restrict__ dxb, int accumulate, int M, int D) {
+                                                          bf16* __restrict__ dxb, int accumulate, int M, int D,
+                                                          const float* __restrict__ resid_c) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
     const f32x4 d = __builtin_convertvector(*(const bf16x4*)(dr + c), f32x4);
     f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
     if (accumulate) o = *(const f32x4*)(dxr + c);
+    else if (resid_c) o = *(const f32x4*)(resid_c + (size_t)crow * D + c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] += r * (g[j] * d[j] - v[j] * r * dot);
     *(f32x4*)(dxr + c) = o;
@@ -354,16 +359,16 @@ extern "C" int tasu_rmsnorm_fwd_frag(const float* x, const float* w, void* y_fra
   return rmsnorm_fwd_any(x, nullptr, w, y_frag, nullptr, M, D, eps, stream, 1);
 }
 static int rmsnorm_bwd_any(const void* dy, const float* x, const float* w, const float* rstd, const int32_t* slot, float* dx,
-                           void* dx_bf16, int accumulate, int M, int D, void* stream) {
-  if (!dy || !x || !w || !rstd || !dx || M <= 0 || D <= 0 || D % 4 || (slot && accumulate)) return TASU_ERR_ARG;
+                           void* dx_bf16, int accumulate, int M, int D, void* stream, const float* resid_c = nullptr) {
+  if (!dy || !x || !w || !rstd || !dx || M <= 0 || D <= 0 || D % 4 || (slot && accumulate) || (resid_c && !slot)) return TASU_ERR_ARG;
   const dim3 grid((M + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
   const bf16* d = (const bf16*)dy;
   bf16* db = (bf16*)dx_bf16;
-  if (D == 1536) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<6>, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M);
-  else if (D == 3584) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<14>, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M);
-  else if (D == 256) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<1>, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M);
-  else TASU_LAUNCH(rmsnorm_bwd_kernel, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M, D);
+  if (D == 1536) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<6>, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M, resid_c);
+  else if (D == 3584) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<14>, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M, resid_c);
+  else if (D == 256) TASU_LAUNCH(rmsnorm_bwd_reg_kernel<1>, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M, resid_c);
+  else TASU_LAUNCH(rmsnorm_bwd_kernel, grid, dim3(256), 0, st, d, x, w, rstd, slot, dx, db, accumulate, M, D, resid_c);
   return TASU_OK;
 }
 extern "C" int tasu_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, int M, int D, float eps,
@@ -383,6 +388,12 @@ extern "C" int tasu_rmsnorm_bwd_rows(const void* dy_compact, const float* x, con
                                      const int32_t* slot, float* dx, void* dx_bf16, int M, int D, void* stream) {
   if (!slot) return TASU_ERR_ARG;
   return rmsnorm_bwd_any(dy_compact, x, w, rstd_compact, slot, dx, dx_bf16, 0, M, D, stream);
+}
+extern "C" int tasu_rmsnorm_bwd_rows_resid(const void* dy_compact, const float* x, const float* w, const float* rstd_compact,
+                                           const int32_t* slot, const float* resid_compact, float* dx, void* dx_bf16, int M, int D,
+                                           void* stream) {
+  if (!slot || !resid_compact) return TASU_ERR_ARG;
+  return rmsnorm_bwd_any(dy_compact, x, w, rstd_compact, slot, dx, dx_bf16, 0, M, D, stream, resid_compact);
 }
 extern "C" int tasu_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
                                   int y_is_f32, float* mean, float* rstd, int R, int D, float eps, void* stream) {

@@ -23,6 +23,7 @@ HBM layout (sized for 288 GB: everything stays resident, nothing is recomputed):
 """
 import collections
 import math
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -332,6 +333,10 @@ class TasuModel:
         # ignored label rows: exactly the padding the collator itself produces for a longer batch, so loss and gradients do not
         # change -- and the step's graphs are kept in a small LRU, so that shapes recur.
         self.shape_buckets = None
+        # training step: the LAST decoder layer's MLP (and everything after it) runs on the labelled rows only -- the hidden state
+        # of a position without a label feeds nothing after that layer's attention (its K / V, which all rows still produce) --
+        # like the loss head (_loss_on_labelled_rows).  Same loss and gradients; TASU_TAIL_ROWS=0 switches it off (A/B runs).
+        self.tail_rows = os.environ.get("TASU_TAIL_ROWS", "1") != "0"
         self.graph_cache_size = 64
         self.decode_graphs = True      # the decode step (ps_slm_amd/decode.py) is always replayed as a graph on the GPU
         self._graphs = {}
@@ -520,6 +525,7 @@ class TasuModel:
             slot = np.full(st.M, -1, dtype=np.int32)
             slot[rows] = np.arange(st.nL, dtype=np.int32)
             st.dev["lab_rows"] = self._upload("lab_rows", lab_rows)
+            st.dev["lab_rows0"] = self._upload("lab_rows0", np.maximum(lab_rows, 0))      # padding slots read row 0 (their results are ignored)
             st.dev["lab_compact"] = self._upload("lab_compact", lab_c)
             st.dev["lab_slot"] = self._upload("lab_slot", slot)
         return st
@@ -587,6 +593,8 @@ class TasuModel:
         gu = self._buf("gu", (L, M, 2 * I), bf)
         xn = self._buf("xn_llm", (M, D), bf)
         act = self._buf("act", (M, I), bf)
+        tail = bool(self.tail_rows and compute_loss and need_backward and not self.keep_logits and logits_rows != "none"
+                    and "lab_rows" in d and st.nLp > 0)
         for l, w in enumerate(llm.layers):
             x_in, x_mid, x_out = xs[2 * l], xs[2 * l + 1], xs[2 * l + 2]
             ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], geo.rms_eps)
@@ -594,6 +602,21 @@ class TasuModel:
             ops.rope_fwd(qkv[l], cos, sin, None, None, None, B, S, H, G)          # in place; no transposed copies (attention.hip)
             ops.attn_fwd(qkv[l], None, d["key_mask"], ao[l], lse[l], B, S, H, G, scale, True)
             ops.gemm(ao[l], w["wo"], x_mid, M, D, H * HD, resid=x_in, mode=GEMM_RESID)
+            if tail and l == L - 1:
+                # the last layer's MLP on the nLp labelled rows (compact operands; row gathers by the plan's index)
+                n = st.nLp
+                xn_t = self._buf("xn_tail", (n, D), bf)
+                rstd_t = self._buf("rstd_tail", (n,), f32)
+                ops.rmsnorm_fwd_rows(x_mid, d["lab_rows"], w["ln2"], xn_t, rstd_t, geo.rms_eps)
+                gu_t = self._buf("gu_tail", (n, 2 * I), bf)
+                act_t = self._buf("act_tail", (n, I), bf)
+                ops.gemm_gate_up_swiglu(xn_t, w["wgu"], gu_t, act_t, n, I, D)
+                xmid_t = self._buf("xmid_tail", (n, D), f32)
+                ops.embed_rows(x_mid, d["lab_rows0"], xmid_t, n, D)
+                xout_t = self._buf("xout_tail", (n, D), f32)
+                ops.gemm(act_t, w["wd"], xout_t, n, D, I, resid=xmid_t, mode=GEMM_RESID)
+                d.update(rstd_tail=rstd_t, gu_tail=gu_t, xout_tail=xout_t)
+                continue
             ops.rmsnorm_fwd(x_mid, w["ln2"], xn, rstd[2 * l + 1], geo.rms_eps)
             ops.gemm_gate_up_swiglu(xn, w["wgu"], gu[l], act, M, I, D)          # gate|up projection + SwiGLU epilogue
             ops.gemm(act, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
@@ -636,7 +659,10 @@ class TasuModel:
         bf, f32 = torch.bfloat16, torch.float32
         xn_c = self._buf("xn_lab", (n, D), bf)
         rstd_c = self._buf("rstd_lab", (n,), f32)
-        ops.rmsnorm_fwd_rows(d["xs"][2 * L], d["lab_rows"], llm.norm, xn_c, rstd_c, geo.rms_eps)
+        if "xout_tail" in d:                                 # the last layer already produced the labelled rows compact
+            ops.rmsnorm_fwd(d["xout_tail"], llm.norm, xn_c, rstd_c, geo.rms_eps)
+        else:
+            ops.rmsnorm_fwd_rows(d["xs"][2 * L], d["lab_rows"], llm.norm, xn_c, rstd_c, geo.rms_eps)
         logits = self._buf("logits", (n, Vp), bf)
         ops.gemm(xn_c, llm.head, logits, n, V, D)
         row_loss = self._buf("row_loss", (n,), f32)
@@ -689,17 +715,32 @@ class TasuModel:
                 ops.gemm_splitk(d["dlogits"], llm.head_t, dn_c, st.nLp, D, Vp, ksplit, ws)
             else:
                 ops.gemm(d["dlogits"], llm.head_t, dn_c, st.nLp, D, Vp)
-            ops.rmsnorm_bwd_rows(dn_c, xs[2 * L], llm.norm, d["rstd_lab"], d["lab_slot"], dx, dxb)
+            if "xout_tail" in d:
+                # final norm and the last layer's MLP on the compact rows; the post-attention norm's backward scatters the result
+                # (+ the rows' residual gradient) back to all M rows for that layer's attention backward
+                n, w = st.nLp, llm.layers[L - 1]
+                dx_t = self._buf("dx_tail", (n, D), f32)
+                dxb_t = self._buf("dxb_tail", (n, D), bf)
+                ops.rmsnorm_bwd(dn_c, d["xout_tail"], llm.norm, d["rstd_lab"], dx_t, dxb_t, False)
+                dact_t = self._buf("dact_tail", (n, I), bf)
+                dgu_t = self._buf("dgu_tail", (n, 2 * I), bf)
+                ops.gemm(dxb_t, w["wd_t"], dact_t, n, I, D)
+                ops.swiglu_bwd(dact_t, d["gu_tail"], dgu_t, n, I)
+                ops.gemm(dgu_t, w["wgu_t"], dn_c, n, D, 2 * I)
+                ops.rmsnorm_bwd_rows_resid(dn_c, xs[2 * L - 1], w["ln2"], d["rstd_tail"], d["lab_slot"], dx_t, dx, dxb)
+            else:
+                ops.rmsnorm_bwd_rows(dn_c, xs[2 * L], llm.norm, d["rstd_lab"], d["lab_slot"], dx, dxb)
         else:
             ops.gemm(d["dlogits"], llm.head_t, dn, M, D, Vp)
             ops.rmsnorm_bwd(dn, xs[2 * L], llm.norm, rstd[2 * L], dx, dxb, False)
         for l in range(L - 1, -1, -1):
             w = llm.layers[l]
             x_in, x_mid = xs[2 * l], xs[2 * l + 1]
-            ops.gemm(dxb, w["wd_t"], dact, M, I, D)
-            ops.swiglu_bwd(dact, d["gu"][l], dgu, M, I)
-            ops.gemm(dgu, w["wgu_t"], dn, M, D, 2 * I)
-            ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
+            if not (l == L - 1 and "xout_tail" in d):          # (the compact tail above has done the last layer's MLP)
+                ops.gemm(dxb, w["wd_t"], dact, M, I, D)
+                ops.swiglu_bwd(dact, d["gu"][l], dgu, M, I)
+                ops.gemm(dgu, w["wgu_t"], dn, M, D, 2 * I)
+                ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
             ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)
             ops.attn_bwd_prep(dao, d["ao"][l], delta, None, B, S, H)
             ops.attn_bwd(d["qkv"][l], None, None, d["key_mask"], dao, None, d["lse"][l], delta, dqkv, dkp, dvp,

@@ -190,6 +190,12 @@ class HipOps:
         self._chk(self.lib.tasu_rmsnorm_bwd_rows(_p(dy), _p(x), _p(w), _p(rstd), _p(slot), _p(dx), _p(dx_bf16), M, D,
                                                  self._stream()), "tasu_rmsnorm_bwd_rows")
 
+    def rmsnorm_bwd_rows_resid(self, dy, x, w, rstd, slot, resid, dx, dx_bf16):
+        """dx[m] = resid[slot[m]] + rmsnorm dgrad of compact row slot[m] (dy, rstd, resid compact) or 0 where slot[m] < 0."""
+        M, D = x.shape
+        self._chk(self.lib.tasu_rmsnorm_bwd_rows_resid(_p(dy), _p(x), _p(w), _p(rstd), _p(slot), _p(resid), _p(dx), _p(dx_bf16), M, D,
+                                                       self._stream()), "tasu_rmsnorm_bwd_rows_resid")
+
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, R, D, eps):
         self._chk(self.lib.tasu_layernorm_fwd(_p(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0),
                                               int(y.dtype == torch.float32), _p(mean), _p(rstd), R, D, eps,

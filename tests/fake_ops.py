@@ -89,6 +89,18 @@ class FakeOps:
         if dx_bf16 is not None:
             dx_bf16.copy_(_bf(dx))
 
+    def rmsnorm_bwd_rows_resid(self, dy, x, w, rstd, slot, resid, dx, dx_bf16):
+        M, D = x.shape
+        s = slot[:M].long()
+        ok = (s >= 0)[:, None]
+        d = dy.float()[s.clamp_min(0)]
+        r = rstd[s.clamp_min(0)][:, None]
+        xh = x * r
+        dot = (w * d * xh).sum(-1, keepdim=True) / D
+        dx.copy_(torch.where(ok, resid[s.clamp_min(0)] + r * (w * d - xh * dot), torch.zeros_like(x)))
+        if dx_bf16 is not None:
+            dx_bf16.copy_(_bf(dx))
+
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, R, D, eps):
         xr = x[:R, :D]
         mu = xr.mean(-1)

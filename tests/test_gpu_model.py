@@ -221,6 +221,25 @@ def test_labelled_rows_loss_head_on_gpu(setup, ragged):
     assert cosine(gm.proj.g, lean.proj.g) > 0.9999
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_tail_layer_on_labelled_rows_on_gpu(setup, ragged):
+    """TasuModel.tail_rows on the HIP kernels against the all-rows schedule: same loss, accuracy and count, and projector
+    gradients equal bit for bit (every output element of the compact GEMMs sees its K range in the same order; the row gathers /
+    scatters move values only)."""
+    from ps_slm_amd.ops import HipOps
+    geo, sd, _, _ = setup
+    a, b = TasuModel(geo, HipOps(), "cuda", keep_logits=False), TasuModel(geo, HipOps(), "cuda", keep_logits=False)
+    a.load_reference_state_dict(sd)
+    b.load_reference_state_dict(sd)
+    a.tail_rows, b.tail_rows = True, False
+    batch = synthetic_text_batch(geo, 3, seed=11, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12,
+                                 noise=True, drop_prob=0.1, ragged=ragged)
+    sa, sb = run_text(a, batch), run_text(b, batch)
+    assert "xout_tail" in sa.dev and "xout_tail" not in sb.dev
+    assert torch.equal(sa.dev["loss_out"], sb.dev["loss_out"])
+    assert torch.equal(a.proj.g, b.proj.g)
+
+
 @pytest.mark.parametrize("k", [1, 2])
 def test_linear_projector_on_gpu(k):
     """``encoder_projector="linear"`` (EncoderProjectorConcat, k frames per projector row) on the HIP kernels: against the REAL

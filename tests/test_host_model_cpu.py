@@ -493,6 +493,25 @@ def test_labelled_rows_loss_head_equals_full_materialisation(mid, ragged):
     assert float((full.proj.g - lean.proj.g).norm() / full.proj.g.norm()) < 5e-3     # bf16 roundings move with the summation order
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_tail_layer_on_labelled_rows_changes_nothing(mid, ragged):
+    """TasuModel.tail_rows (the last decoder layer's MLP, the final norm and the loss head on the labelled rows only): every row
+    is computed independently of the others after that layer's attention, so loss, accuracy, count AND the projector gradients
+    equal the all-rows schedule's (on the double up to the summation order of torch's differently shaped CPU matmuls, which moves a
+    few bf16 roundings; the HIP kernels, whose K order does not depend on the row count, are compared bit for bit in
+    tests/test_gpu_model.py)."""
+    geo, sd = mid
+    batch = synthetic_text_batch(geo, 3, seed=11, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12,
+                                 noise=True, drop_prob=0.1, ragged=ragged)
+    a, b = build(geo, sd), build(geo, sd)
+    a.keep_logits = b.keep_logits = False
+    a.tail_rows, b.tail_rows = True, False
+    sa, sb = run_text(a, batch), run_text(b, batch)
+    assert "xout_tail" in sa.dev and "xout_tail" not in sb.dev
+    torch.testing.assert_close(sa.dev["loss_out"], sb.dev["loss_out"], rtol=1e-6, atol=0)
+    assert float((a.proj.g - b.proj.g).norm() / b.proj.g.norm()) < 5e-3
+
+
 @pytest.mark.parametrize("quantise", [False, True])
 @pytest.mark.parametrize("lpw,min_len", [(1.0, 1), (2.0, 1), (0.5, 4), (1.0, 6)])
 @pytest.mark.parametrize("nb", [1, 2, 3, 4])
