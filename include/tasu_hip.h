@@ -374,6 +374,16 @@ int tasu_decode_step_prologue(const float* table, const int32_t* ids, float* x, 
                               const int32_t* pos, float* cos_tab, float* sin_tab, float theta, int32_t* index,
                               const int32_t* src_row, const int32_t* lens, int n_beams, int M, int D, int ctx, void* stream);
 
+/* ------------------------------------------------------------------------------------------ cross-attention projector
+ * EncoderProjectorCTCCA (Multitask/model/projector.py:104-126; model_config.encoder_projector = "cross-attention",
+ * ps-slm.py:475-480): Q = W_q(posterior) (tasu_gemm_nt_bf16), then per head h of 8 (width d = llm_dim / 8, a multiple of 64):
+ * scores = Q_h . E_h^T (tasu_gemm_nt_bf16 over the V2 rows of the LLM's embedding table, K = d), P below, z_h = P . E_h
+ * (tasu_gemm_nt_bf16 against the transposed table, K = ld).  The row kernels between the two contractions:
+ *   tasu_scale_softmax_rows_bf16   P[r, :V] = bf16(softmax(bf16(S[r, :V] * scale))), P[r, V:ld] = 0   (S, P bf16 [R, ld])
+ *   tasu_softmax_bwd_rows_bf16     dS[r, :V] = bf16(bf16(P o (dP - sum_c P o dP)) * scale), dS[r, V:ld] = 0 */
+int tasu_scale_softmax_rows_bf16(const void* s, void* p, int R, int V, int ld, float scale, void* stream);
+int tasu_softmax_bwd_rows_bf16(const void* p, const void* dp, void* ds, int R, int V, int ld, float scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------ RCCL (one process per GPU)
  * Replaces the gradient exchange of the DeepSpeed engine (Multitask/finetune_deepspeed.py:147-149; ZeRO-2 reduce-scatter +
  * all-gather, Multitask/conf/ds_config.json:15-21) by what it amounts to for 54.5 M replicated parameters: an in-place SUM

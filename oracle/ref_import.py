@@ -134,7 +134,7 @@ class FakeLLMTokenizer:
 def build_reference_model(geo, seed, train_flags, projector="linear-silu", ds_rate=1):
     """Seeded random-init reference ``slam_model_asr`` at geometry ``geo`` (dict); ``projector``: "linear-silu"
     (EncoderProjectorLinearSiLU), "linear" (EncoderProjectorConcat with encoder_projector_ds_rate = ds_rate) or "cov1d-linear"
-    (EncoderProjectorCov1d, kernel = stride = ds_rate)."""
+    (EncoderProjectorCov1d, kernel = stride = ds_rate) or "cross-attention" (EncoderProjectorCTCCA)."""
     import transformers
 
     ps, sv, proj = load_reference()
@@ -161,7 +161,9 @@ def build_reference_model(geo, seed, train_flags, projector="linear-silu", ds_ra
     llm.eval()
     model_config = Cfg(encoder_projector=projector, encoder_path="/nonexistent", encoder_projector_ds_rate=ds_rate,
                        encoder_dim=geo["ctc_vocab"], llm_dim=geo["llm_dim"])
-    if projector == "cov1d-linear":
+    if projector == "cross-attention":
+        projector = proj.EncoderProjectorCTCCA(model_config)       # one matrix W_q; 8 heads over the LLM's embedding table
+    elif projector == "cov1d-linear":
         projector = proj.EncoderProjectorCov1d(model_config)       # hidden width fixed at 2048 by the reference class
     elif projector == "linear":
         projector = proj.EncoderProjectorConcat(model_config)      # bottleneck fixed at 2048 by the reference class

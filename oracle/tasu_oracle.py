@@ -210,6 +210,20 @@ def projector(W, x, mode="fp32", pre="encoder_projector."):
     EncoderProjectorConcat.forward, :38-49 (k = in_features / feature width frames concatenated, ReLU, no norm); with
     ``conv1d.*`` keys as well: EncoderProjectorCov1d.forward, :64-73 (Conv1d kernel = stride = k over time, ReLU, Linear, ReLU,
     Linear; autocast runs the convolution in bf16 like a Linear)."""
+    if pre + "W_q.weight" in W:
+        # EncoderProjectorCTCCA.forward, projector.py:111-126 (called with the detached input-embedding table, ps-slm.py:475-479);
+        # under autocast: Linear and both einsums in bf16, the scale on the bf16 scores, softmax in fp32
+        E = W["llm.model.embed_tokens.weight"].detach()
+        B, T, _ = x.shape
+        Q = linear(x, W[pre + "W_q.weight"], None, mode)
+        h = 8
+        d = Q.shape[-1] // h
+        q = Q.view(B, T, h, d)
+        k = rbf(E, mode).view(-1, h, d)
+        scores = rbf(rbf(torch.einsum("bthd,vhd->bthv", rbf(q, mode), k), mode) / d ** 0.5, mode)
+        attn = scores.softmax(dim=-1)
+        z = rbf(torch.einsum("bthv,vhd->bthd", rbf(attn, mode), k), mode)
+        return z.reshape(B, T, -1)
     if pre + "conv1d.weight" in W:
         w = W[pre + "conv1d.weight"]                         # [out, in, k]
         k = w.shape[2]

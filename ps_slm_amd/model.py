@@ -57,7 +57,8 @@ class Geometry:
     ln_eps: float = 1e-5
     projector: str = "linear-silu"   # "linear-silu" (EncoderProjectorLinearSiLU, projector.py:129-151: the shipped recipe) or
                                      # "linear" (EncoderProjectorConcat, projector.py:28-49: k frames concatenated, ReLU, no norm)
-    projector_ds_rate: int = 1       # k of the "linear" projector (model_config.encoder_projector_ds_rate)
+    projector_ds_rate: int = 1       # k of the "linear" / "cov1d-linear" projectors (model_config.encoder_projector_ds_rate)
+    ca_heads: int = 8                # heads of the "cross-attention" projector (EncoderProjectorCTCCA, projector.py:105: n_heads=8)
     # SenseVoiceSmall encoder
     feat_dim: int = 560
     enc_dim: int = 512
@@ -89,6 +90,7 @@ class Geometry:
 PROJ_NAMES = ("norm.weight", "norm.bias", "ffn.0.weight", "ffn.0.bias", "ffn.2.weight", "ffn.2.bias")
 PROJ_NAMES_LINEAR = ("linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias")
 PROJ_NAMES_COV1D = ("conv1d.weight", "conv1d.bias") + PROJ_NAMES_LINEAR
+PROJ_NAMES_CA = ("W_q.weight",)
 
 
 class ProjectorParams:
@@ -102,8 +104,25 @@ class ProjectorParams:
     def __init__(self, geo: Geometry, device):
         K, Kp, Hb, Do = geo.ctc_vocab, rup(geo.ctc_vocab, 64), geo.bottleneck, geo.llm_dim
         self.kind = geo.projector
-        if self.kind not in ("linear-silu", "linear", "cov1d-linear"):
+        if self.kind not in ("linear-silu", "linear", "cov1d-linear", "cross-attention"):
             raise NotImplementedError(f"encoder_projector {self.kind!r}")
+        self.is_ca = self.kind == "cross-attention"
+        if self.is_ca:
+            # EncoderProjectorCTCCA (projector.py:104-126): ONE trainable matrix, W_q [llm_dim, K] (no bias); keys and values are
+            # the LLM's embedding table.  Laid out like a first Linear with kin = 1 whose "bottleneck" is llm_dim.
+            self.k = self.kin = 1
+            self.has_norm = self.has_conv = False
+            self.K, self.Kp, self.Hb, self.Do = K, Kp, Do, Do
+            self.names = PROJ_NAMES_CA
+            self.n_w1, self.n_b1, self.n_w2, self.n_b2 = "W_q.weight", None, None, None
+            self.real = {"W_q.weight": (Do, K)}
+            self.offsets = {"W_q.weight": (0, (Do, Kp))}
+            self.numel = off = rup(Do * Kp, 64)
+            f32 = dict(dtype=torch.float32, device=device)
+            self.p, self.g, self.m, self.v = (torch.zeros(off, **f32) for _ in range(4))
+            self.pb = torch.zeros(off, dtype=torch.bfloat16, device=device)
+            self.w1b_t = self.w2b_t = None
+            return
         self.k = int(geo.projector_ds_rate) if self.kind in ("linear", "cov1d-linear") else 1   # frames per projector row
         self.has_norm = self.kind == "linear-silu"
         self.has_conv = self.kind == "cov1d-linear"
@@ -185,6 +204,8 @@ class ProjectorParams:
 
     def refresh_working_copies(self, ops):
         """bf16 working copy (skipped when AdamW already wrote it) + the transposed copies for dgrad."""
+        if self.is_ca:
+            return                                         # nothing upstream of W_q needs a gradient
         kKp = self.kin * self.Kp
         if self.has_norm or self.has_conv:   # the "linear" projector's input carries no parameters: its W1^T is never needed
             ops.transpose(self.view(self.pb, self.n_w1), self.w1b_t, self.Hb, kKp, self.Hb, kKp)
@@ -377,6 +398,10 @@ class TasuModel:
             b = 1.0 / math.sqrt(fan_in)
             return (torch.rand(*shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1) * b
 
+        if pr.is_ca:
+            pr.load("W_q.weight", un((Do, K), K))
+            self.sync_projector_copies()
+            return
         if pr.has_norm:
             pr.load("norm.weight", torch.ones(K, device=dev))
             pr.load("norm.bias", torch.zeros(K, device=dev))
@@ -543,6 +568,8 @@ class TasuModel:
         """linear-silu: LayerNorm(25055) -> Linear -> SiLU -> Linear;  linear: [k frames concatenated] Linear -> ReLU -> Linear;
         cov1d-linear: Conv1d(k, stride k) -> ReLU -> Linear -> ReLU -> Linear."""
         ops, pr = self.ops, self.proj
+        if pr.is_ca:
+            return self._forward_cross_attention(st)
         Fap, Rap, K, Kp, Hb, Do = st.Fap, st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
         post = st.dev["post"]
         xn = self._buf("xn", (Fap, Kp), torch.bfloat16)
@@ -571,6 +598,74 @@ class TasuModel:
         y2 = self._buf("y2", (Rap, Do), torch.bfloat16)
         ops.gemm(a1, pr.view(pr.pb, pr.n_w2), y2, Rap, Do, Hb, bias=pr.view(pr.pb, pr.n_b2))
         st.dev.update(xn=xn, ln_mean=mean, ln_rstd=rstd, h1=h1, a1=a1, y2=y2, c0=c0, a0=a0)
+
+    # ---- cross-attention projector (EncoderProjectorCTCCA, projector.py:104-126; ps-slm.py:475-480)
+    def _ca_tables(self):
+        """(E [V, D], E^T [D, Vpad]) in bf16: the LLM's input embedding table, which is keys AND values of the projector (detached:
+        ps-slm.py:476-478).  With tied embeddings these are the lm_head copies the decoder already holds."""
+        llm, geo = self.llm, self.geo
+        if geo.tied:
+            return llm.head, llm.head_t
+        if getattr(llm, "_ca_e", None) is None:
+            V, D, Vp = geo.llm_vocab, geo.llm_dim, rup(geo.llm_vocab, 64)
+            e = llm.embed.to(torch.bfloat16).contiguous()
+            et = torch.zeros(D, Vp, dtype=torch.bfloat16, device=self.device)
+            et[:, :V].copy_(e.t())
+            llm._ca_e, llm._ca_et = e, et
+        return llm._ca_e, llm._ca_et
+
+    def _forward_cross_attention(self, st):
+        """Q = W_q(posterior rows); per head: P = softmax(Q_h E_h^T / sqrt(d)) over the V2 embedding rows, z_h = P E_h; the
+        projector output is the heads side by side.  P is kept for the backward (8 x [rows, V2] bf16)."""
+        ops, pr, geo, d = self.ops, self.proj, self.geo, st.dev
+        bf = torch.bfloat16
+        Fap, Rap, Kp, D = st.Fap, st.Rap, pr.Kp, pr.Do
+        V, Vp, H = geo.llm_vocab, rup(geo.llm_vocab, 64), geo.ca_heads
+        dh = D // H
+        if D % H or dh % 64:
+            raise NotImplementedError(f"cross-attention projector: head width llm_dim / {H} = {D / H:g} must be a multiple of 64 "
+                                      "(the K dimension of the score GEMMs)")
+        scale = dh ** -0.5
+        xn = self._buf("xn", (Fap, Kp), bf)
+        ops.cast_bf16(d["post"], xn)                           # autocast: the Linear rounds its input to bf16
+        q = self._buf("ca_q", (Rap, D), bf)
+        ops.gemm(xn, pr.view(pr.pb, "W_q.weight"), q, Rap, D, Kp)
+        E, ET = self._ca_tables()
+        sc = self._buf("ca_s", (Rap, Vp), bf)
+        P = self._buf("ca_p", (H, Rap, Vp), bf)
+        y2 = self._buf("y2", (Rap, D), bf)
+        for h in range(H):
+            hs = slice(h * dh, (h + 1) * dh)
+            ops.gemm(q[:, hs], E[:, hs], sc, Rap, V, dh)       # scores of head h against every embedding row
+            ops.scale_softmax_rows(sc, P[h], Rap, V, scale)
+            ops.gemm(P[h], ET[hs], y2[:, hs], Rap, dh, Vp)
+        d.update(xn=xn, ca_q=q, ca_p=P, y2=y2)
+
+    def _backward_cross_attention(self, st, on_ready):
+        ops, pr, geo, d = self.ops, self.proj, self.geo, st.dev
+        bf, f32 = torch.bfloat16, torch.float32
+        Rap, Kp, D = st.Rap, pr.Kp, pr.Do
+        V, Vp, H = geo.llm_vocab, rup(geo.llm_vocab, 64), geo.ca_heads
+        dh, scale = D // H, (D // H) ** -0.5
+        audio_rows = d["audio_rows_pad"] if "audio_rows_pad" in d else self._pad_rows(st)
+        dy2 = self._buf("dy2", (Rap, D), bf)
+        ops.merge_bwd(d["dx"], audio_rows, dy2, Rap, D)
+        E, ET = self._ca_tables()
+        dp = self._buf("ca_s", (Rap, Vp), bf)
+        ds = self._buf("ca_ds", (Rap, Vp), bf)
+        dq = self._buf("ca_dq", (Rap, D), bf)
+        for h in range(H):
+            hs = slice(h * dh, (h + 1) * dh)
+            ops.gemm(dy2[:, hs], E[:, hs], dp, Rap, V, dh)     # dP = dz_h E_h^T
+            ops.softmax_bwd_rows(d["ca_p"][h], dp, ds, Rap, V, scale)
+            ops.gemm(ds, ET[hs], dq[:, hs], Rap, dh, Vp)       # dQ_h = dS E_h
+        dq_t = self._buf("ca_dq_t", (D, Rap), bf)
+        xn_t = self._buf("xn_t", (Kp, Rap), bf)
+        ops.transpose(dq, dq_t, Rap, D, Rap, D)
+        ops.transpose(d["xn"].view(Rap, Kp), xn_t, Rap, Kp, Rap, Kp)
+        ops.gemm(dq_t, xn_t, pr.view(pr.g, "W_q.weight"), D, Kp, Rap, mode=GEMM_F32)
+        if on_ready is not None:
+            on_ready(0, pr.numel)
 
     def forward_llm(self, st: StepState, compute_loss=True, need_backward=True, logits_rows="all"):
         ops, geo, llm = self.ops, self.geo, self.llm
@@ -756,6 +851,8 @@ class TasuModel:
         [norm.weight | norm.bias] (linear-silu) or [conv1d.weight | conv1d.bias] (cov1d-linear).  The ranges tile [0, numel)
         exactly."""
         pr = self.proj
+        if pr.is_ca:
+            return [(0, pr.numel)]
         o_w1, o_b1 = pr.offsets[pr.n_w1][0], pr.offsets[pr.n_b1][0]
         ld = pr.kin * pr.Kp
         rows = [pr.Hb * i // w1_chunks for i in range(w1_chunks + 1)]
@@ -769,6 +866,8 @@ class TasuModel:
         the bucket -- runs as that many row-block GEMMs so that its all-reduce starts before the projector's input-side work
         (dxn, LayerNorm parameter gradients) has run."""
         ops, pr, d = self.ops, self.proj, st.dev
+        if pr.is_ca:
+            return self._backward_cross_attention(st, on_ready)
         bf, f32 = torch.bfloat16, torch.float32
         ranges = self.grad_ranges(w1_chunks)
         # merge backward: gradient rows that hold audio -> projector output gradient

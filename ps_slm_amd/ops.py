@@ -196,6 +196,15 @@ class HipOps:
         self._chk(self.lib.tasu_rmsnorm_bwd_rows_resid(_p(dy), _p(x), _p(w), _p(rstd), _p(slot), _p(resid), _p(dx), _p(dx_bf16), M, D,
                                                        self._stream()), "tasu_rmsnorm_bwd_rows_resid")
 
+    def scale_softmax_rows(self, s, p, R, V, scale):
+        """p[r, :V] = bf16(softmax(bf16(s[r, :V] * scale))), pad columns zero (cross-attention projector)."""
+        self._chk(self.lib.tasu_scale_softmax_rows_bf16(_p(s), _p(p), R, V, s.stride(0), scale, self._stream()),
+                  "tasu_scale_softmax_rows_bf16")
+
+    def softmax_bwd_rows(self, p, dp, ds, R, V, scale):
+        self._chk(self.lib.tasu_softmax_bwd_rows_bf16(_p(p), _p(dp), _p(ds), R, V, p.stride(0), scale, self._stream()),
+                  "tasu_softmax_bwd_rows_bf16")
+
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, R, D, eps):
         self._chk(self.lib.tasu_layernorm_fwd(_p(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0),
                                               int(y.dtype == torch.float32), _p(mean), _p(rstd), R, D, eps,

@@ -167,11 +167,11 @@ def load_hf_llm_state_dict(path):
 def model_factory(train_config, model_config, **kwargs):
     """Same contract as Multitask/model/ps-slm.py:130-181: returns (model, tokenizer)."""
     projector = model_config.get("encoder_projector", "linear-silu")
-    if projector not in ("linear-silu", "linear", "cov1d-linear"):
+    if projector not in ("linear-silu", "linear", "cov1d-linear", "cross-attention"):
         raise NotImplementedError(f"encoder_projector={projector!r}: the MI355X path serves 'linear-silu' (the shipped recipe, "
                                   "Multitask/scripts/finetune_deespeed_sensevoice.sh:25), 'linear' (EncoderProjectorConcat, "
-                                  "Multitask/model/projector.py:28-49) and 'cov1d-linear' (EncoderProjectorCov1d, :53-73); "
-                                  "q-former / cross-attention / simple_linear are not built")
+                                  "Multitask/model/projector.py:28-49), 'cov1d-linear' (EncoderProjectorCov1d, :53-73) and "
+                                  "'cross-attention' (EncoderProjectorCTCCA, :104-126); q-former / simple_linear are not built")
     if train_config.get("use_peft", False) or not train_config.get("freeze_llm", True):
         raise NotImplementedError("the MI355X path trains the projector only (freeze_llm=true, use_peft=false: "
                                   "Multitask/scripts/finetune_deespeed_sensevoice.sh:28,84)")

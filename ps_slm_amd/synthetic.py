@@ -50,7 +50,9 @@ def random_state_dict(geo: Geometry, seed: int, with_encoder=True, scale=0.05):
     if not geo.tied:
         sd["llm.lm_head.weight"] = rn(V, D)
     K, Hb = geo.ctc_vocab, geo.bottleneck
-    if geo.projector == "cov1d-linear":                 # EncoderProjectorCov1d: Conv1d(K, K, k, stride k) -> ReLU -> Linear -> ReLU -> Linear
+    if geo.projector == "cross-attention":              # EncoderProjectorCTCCA: one matrix, W_q [llm_dim, K], no bias
+        sd["encoder_projector.W_q.weight"] = rn(D, K, s=1.0 / math.sqrt(K))
+    elif geo.projector == "cov1d-linear":                 # EncoderProjectorCov1d: Conv1d(K, K, k, stride k) -> ReLU -> Linear -> ReLU -> Linear
         kc = geo.projector_ds_rate
         sd["encoder_projector.conv1d.weight"] = rn(K, K, kc, s=1.0 / math.sqrt(K * kc))
         sd["encoder_projector.conv1d.bias"] = rn(K)

@@ -94,6 +94,20 @@ def decode_margin_cases():
     return geo, sd, cases
 
 
+def ca_projector_case():
+    """(geo, state dict, batch, fixture) of tests/golden/mid512_text_ca.npz (oracle/make_golden_ca.py): the alternate
+    ``encoder_projector="cross-attention"`` (EncoderProjectorCTCCA) at llm_dim 512 (8 heads of 64)."""
+    from ps_slm_amd.model import Geometry
+    from ps_slm_amd.synthetic import MID_GEOMETRY, random_state_dict, synthetic_text_batch
+
+    z = load_npz("mid512_text_ca")
+    geo = Geometry.from_dict(dict(MID_GEOMETRY, projector="cross-attention", llm_dim=512, llm_heads=4, llm_kv_heads=2, llm_inter=1024))
+    sd = random_state_dict(geo, int(z["seed_w"]), with_encoder=False)
+    batch = synthetic_text_batch(geo, 3, seed=int(z["seed_b"]), prompt_len=9, n_audio=22, target_len=17, speech_pos=4,
+                                 feat_frames=12, noise=False, ragged=True)
+    return geo, sd, batch, z
+
+
 def cov1d_projector_case(k):
     """(geo, state dict, batch, fixture) of tests/golden/mid_text_cov1d_k{k}.npz (oracle/make_golden_cov1d.py): the alternate
     ``encoder_projector="cov1d-linear"`` (EncoderProjectorCov1d: Conv1d kernel = stride = k -> ReLU -> Linear -> ReLU -> Linear)."""

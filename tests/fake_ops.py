@@ -101,6 +101,16 @@ class FakeOps:
         if dx_bf16 is not None:
             dx_bf16.copy_(_bf(dx))
 
+    def scale_softmax_rows(self, s, p, R, V, scale):
+        z = _bf(s[:R, :V].float() * scale)
+        p.zero_()
+        p[:R, :V] = _bf(torch.softmax(z, -1))
+
+    def softmax_bwd_rows(self, p, dp, ds, R, V, scale):
+        P, dP = p[:R, :V].float(), dp[:R, :V].float()
+        ds.zero_()
+        ds[:R, :V] = _bf(_bf(P * (dP - (P * dP).sum(-1, keepdim=True))) * scale)
+
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, R, D, eps):
         xr = x[:R, :D]
         mu = xr.mean(-1)

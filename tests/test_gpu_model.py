@@ -295,6 +295,30 @@ def test_cov1d_projector_on_gpu(k):
     assert cosine(gg["encoder_projector.linear1.weight"][::64], torch.from_numpy(z["grad.linear1.weight.rows64"])) > 0.995
 
 
+def test_cross_attention_projector_on_gpu():
+    """``encoder_projector="cross-attention"`` (EncoderProjectorCTCCA) on the HIP kernels (score / value GEMMs per head against
+    the embedding table, tasu_scale_softmax_rows_bf16 / tasu_softmax_bwd_rows_bf16 between them): against the REAL reference's
+    fp32 golden (|loss - ref| <= 2e-2, logits <= 3 % of their range, W_q gradient cosine >= 0.99) and against the same host
+    code on the CPU double (loss 2e-3, gradient cosine 0.999)."""
+    from conftest import ca_projector_case
+    from ps_slm_amd.ops import HipOps
+    geo, sd, batch, z = ca_projector_case()
+    gm = TasuModel(geo, HipOps(), "cuda")
+    gm.load_reference_state_dict(sd)
+    cm = TasuModel(geo, FakeOps(), "cpu")
+    cm.load_reference_state_dict(sd)
+    sg, sc = run_text(gm, batch), run_text(cm, batch)
+    lg = float(sg.dev["loss_out"][0])
+    assert abs(lg - float(z["loss"])) < 2e-2 and abs(lg - float(sc.dev["loss_out"][0])) < 2e-3
+    valid = torch.from_numpy(sg.plan.key_mask[:, : sg.S].astype(bool))
+    cols = torch.from_numpy(z["cols"])
+    ref = torch.from_numpy(z["logits_cols"])
+    assert float((gm.logits_view(sg).float().cpu()[:, :, cols] - ref)[valid].abs().max() / ref[valid].abs().max()) < 3e-2
+    gg, gc = gm.projector_grads(), cm.projector_grads()
+    assert cosine(gg["encoder_projector.W_q.weight"], gc["encoder_projector.W_q.weight"]) > 0.999
+    assert cosine(gg["encoder_projector.W_q.weight"], torch.from_numpy(z["grad.W_q.weight"])) > 0.99
+
+
 def test_generate_margin_cases_exact_on_gpu():
     """Token ids are index work: on the 17 rounding-stable decode cases of tests/golden/mid_generate_margin.npz (14 short + 3 with 40-50 generated positions; 1-4 beams,
     min_length, length penalties, left padding, EOS events; oracle/make_golden_generate_margin.py) the HIP decode path must

@@ -582,6 +582,26 @@ def test_cov1d_projector_step_matches_oracle_and_reference(k):
         assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
 
 
+def test_cross_attention_projector_step_matches_oracle_and_reference():
+    """``encoder_projector="cross-attention"`` (W_q, then per head two GEMMs against the LLM's embedding table around the
+    scale + softmax row kernel) through the product's host code on the CPU double: loss / W_q gradient against the bf16 oracle,
+    loss against the REAL reference's fp32 golden, state-dict round trip, one exchange range."""
+    from conftest import ca_projector_case
+    geo, sd, batch, z = ca_projector_case()
+    model = build(geo, sd)
+    assert model.proj.names == ("W_q.weight",) and model.proj.is_ca
+    st = run_text(model, batch)
+    out, grads = O.loss_and_projector_grads(sd, batch, dataclasses.asdict(geo), "bf16")
+    assert abs(float(st.dev["loss_out"][0]) - float(out["loss"])) < 2e-3
+    assert abs(float(st.dev["loss_out"][0]) - float(z["loss"])) < 2e-2
+    mine = model.projector_grads()
+    assert sorted(mine) == sorted(grads) == ["encoder_projector.W_q.weight"]
+    g, m = grads["encoder_projector.W_q.weight"], mine["encoder_projector.W_q.weight"]
+    assert m.shape == g.shape and float(torch.nn.functional.cosine_similarity(m.flatten(), g.flatten(), dim=0)) > 0.995
+    assert torch.equal(model.projector_state_dict()["encoder_projector.W_q.weight"], sd["encoder_projector.W_q.weight"])
+    assert model.grad_ranges(4) == [(0, model.proj.numel)]
+
+
 def test_shape_buckets_pad_without_changing_the_step(mid):
     """TasuModel.shape_buckets (graph reuse for real data): the batch is padded to the next multiple of (token columns, posterior
     rows, labelled rows) with masked columns / zero rows / ignored labels; loss, accuracy, count and gradients are those of the

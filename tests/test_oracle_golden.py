@@ -375,3 +375,18 @@ def test_cov1d_projector_vs_reference(k):
     close(grads["encoder_projector.linear2.bias"], z["grad.linear2.bias"], rtol=2e-4, atol=1e-7)
     close(grads["encoder_projector.linear2.weight"][::16], z["grad.linear2.weight.rows16"], rtol=2e-4, atol=1e-7)
     close(grads["encoder_projector.linear1.weight"][::64], z["grad.linear1.weight.rows64"], rtol=2e-4, atol=1e-7)
+
+
+def test_cross_attention_projector_vs_reference():
+    """encoder_projector="cross-attention" (EncoderProjectorCTCCA, projector.py:104-126: 8 heads over the LLM's embedding table)
+    through the REAL reference at llm_dim 512: the oracle's restatement reproduces loss, accuracy, logits and the W_q gradient."""
+    import dataclasses
+
+    from conftest import ca_projector_case
+    geo, sd, batch, z = ca_projector_case()
+    out, grads = O.loss_and_projector_grads(sd, batch, dataclasses.asdict(geo), "fp32")
+    close(out["loss"], z["loss"])
+    close(out["acc"], z["acc"])
+    cols = torch.from_numpy(z["cols"])
+    close(out["logits"][:, :, cols], z["logits_cols"], rtol=2e-4, atol=2e-5)
+    close(grads["encoder_projector.W_q.weight"], z["grad.W_q.weight"], rtol=5e-4, atol=1e-8)
