@@ -1,8 +1,9 @@
 """The profiled program of the per-shape GEMM traffic measurement: launches every GEMM shape of the 1.5B benchmark step REPS
-times in a fixed order on rotating (cold) operand sets, so that dispatch k of gemm_pipe_kernel belongs to shape k // REPS.
+times in a fixed order on rotating (cold) operand sets; a tiny marker launch (cast_f32_bf16_kernel) follows every GEMM call, so
+that the GEMM dispatches between two markers are one call (the column-split policy makes two launches out of some calls).
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir1> -- python3 tools/gemm_shapes_run.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dir2> -- python3 tools/gemm_shapes_run.py
-    python tools/pmc_shapes.py <dir1> <dir2> profiles/r02_gemm_pmc.json"""
+    python tools/pmc_shapes.py <dir1> <dir2> profiles/r03_gemm_pmc.json"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,12 +27,14 @@ if __name__ == "__main__":
         c = torch.empty(m, rows, device="cuda", dtype=torch.float32 if mode != GEMM_BF16 else bf)
         r = torch.zeros(m, n, device="cuda") if mode == GEMM_RESID else None
         act = torch.empty(m, n, device="cuda", dtype=bf) if sw else None
+        mk_in, mk_out = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda", dtype=bf)
         torch.cuda.synchronize()
         for i in range(REPS):
             if sw:
                 ops.gemm_gate_up_swiglu(a[i], b[i], c, act, m, n, k)
             else:
                 ops.gemm(a[i], b[i], c, m, n, k, resid=r, mode=mode)
+            ops.cast_bf16(mk_in, mk_out)                   # marker: end of this call's dispatches
         torch.cuda.synchronize()
         del a, b, c
         torch.cuda.empty_cache()
