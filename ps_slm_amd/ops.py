@@ -83,6 +83,9 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_nt_bf16_slabs(_p(a), a.stride(0), _p(b), b.stride(0), _p(ws), N, M, N, K, ksplit,
                                                    self._stream()), "tasu_gemm_nt_bf16_slabs")
 
+    def sum_slabs(self, ws, n_slabs, out, n):
+        self._chk(self.lib.tasu_sum_slabs_bf16(_p(ws), n_slabs, n, _p(out), n, self._stream()), "tasu_sum_slabs_bf16")
+
     def gemm_gate_up_swiglu(self, a, wgu, gu, act, M, I, K):
         """gu[M,2I] = a @ wgu^T and act[M,I] = swiglu(gu) in one launch (training step)."""
         self._chk(self.lib.tasu_gemm_gate_up_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), M, I, K,
