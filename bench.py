@@ -459,7 +459,7 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                                      f"on 8 xGMI-connected GPUs: ~0.35 ms (the last 51-MB row block of the Linear1 weight gradient at "
                                      f"the ~300 GB/s bus bandwidth RCCL reaches; the whole 218-MB bucket would be ~1.3 ms), DESIGN.md 6")
         if want_decode:
-            rec["decode"] = decode_leg(core, raw, B)
+            rec["decode"] = decode_leg(core, raw, B, new_tokens=200 if model_name != "qwen2.5-7b" else 64)
     del engine, model, core, timed
     torch.cuda.empty_cache()
     return rec
@@ -514,7 +514,9 @@ def main():
         extras["audio_sft"] = train_leg(args, "qwen2.5-1.5b", "audio", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank, False)
         extras["audio_sft_blank_biased"] = train_leg(args, "qwen2.5-1.5b", "audio", args.batch, max(5, args.steps // 2), 2, 1, 0,
                                                      local_rank, False, blank_biased=True)
-        extras["qwen2.5-7b"] = train_leg(args, "qwen2.5-7b", "text", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank, False)
+        extras["qwen2.5-7b"] = train_leg(args, "qwen2.5-7b", "text", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank,
+                                          want_decode=not args.no_decode)     # + the 7B decode leg (split-K GEMV kernels: no streaming
+                                                                              # kernels exist for K = 3584 / 18944 yet)
     if rank == 0:
         line = {"metric": "train utterances/sec (Qwen2.5-1.5B align)" if args.model != "qwen2.5-7b" else "train utterances/sec (Qwen2.5-7B align)",
                 "value": main_rec["value"], "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
