@@ -742,7 +742,7 @@ def test_decode_layer_chain_in_fragment_order(hip, fake, M, D, I, H, G, V):
             ops.register_decode_weight(w["wqkv"], "qkv", LD, H, G)
             ops.register_decode_weight(w["wo"], "plain", D)
             ops.register_decode_weight(w["wgu"], "swiglu", I)
-            ops.register_decode_weight(w["wd"], "plain", D)
+            ops.register_decode_weight(w["wd"], "plain", D, slabs_ok=True)      # K = 8960: five K-range slabs
             ops.register_decode_weight(w["head"], "plain", V)
             assert ops.begin_decode(D, HHD, I)
         Mp = 64
@@ -753,17 +753,19 @@ def test_decode_layer_chain_in_fragment_order(hip, fake, M, D, I, H, G, V):
         ws = torch.zeros(32 * 64 * ((max(V, 2 * I) + 95) // 96 * 96), device=dev_) if dev_ != "cpu" else None
         logits = torch.zeros(M, (V + 63) // 64 * 64, dtype=BF, device=dev_)
         # like ps_slm_amd/decode.py: row slices of buffers that hold a whole 64-row chunk (the base address is what counts)
-        ops.dec_rmsnorm(x, t(ln1), xn[:M], 1e-6)
-        ops.gemm_skinny_qkv_rope(xn[:M], w["wqkv"], t(bq), qkv, M, H, G, D, t(cos), t(sin), kc, vc, t(pos), ctx, ws)
-        ops.attn_decode(qkv, kc, vc, None, t(kstart), t(lens), ao, M, H, G, ctx, HD ** -0.5)
-        ops.gemm_skinny_norm(ao[:M], w["wo"], x2, x, M, D, HHD, t(ln2), xn[:M], 1e-6, ws)
-        ops.gemm_skinny_swiglu(xn[:M], w["wgu"], act[:M], M, I, D, ws)
-        ops.gemm_skinny_norm(act[:M], w["wd"], x, x2, M, D, I, t(ln3), xn[:M], 1e-6, ws)
-        ops.gemm_skinny(xn[:M], w["head"], logits, M, V, D, ws)
-        if dev_ != "cpu":
-            torch.cuda.synchronize()
-        if frag:
-            ops.end_decode()
+        try:
+            ops.dec_rmsnorm(x, t(ln1), xn[:M], 1e-6)
+            ops.gemm_skinny_qkv_rope(xn[:M], w["wqkv"], t(bq), qkv, M, H, G, D, t(cos), t(sin), kc, vc, t(pos), ctx, ws)
+            ops.attn_decode(qkv, kc, vc, None, t(kstart), t(lens), ao, M, H, G, ctx, HD ** -0.5)
+            ops.gemm_skinny_norm(ao[:M], w["wo"], x2, x, M, D, HHD, t(ln2), xn[:M], 1e-6, ws)
+            ops.gemm_skinny_swiglu(xn[:M], w["wgu"], act[:M], M, I, D, ws)
+            ops.gemm_skinny_norm(act[:M], w["wd"], x, x2, M, D, I, t(ln3), xn[:M], 1e-6, ws)
+            ops.gemm_skinny(xn[:M], w["head"], logits, M, V, D, ws)
+            if dev_ != "cpu":
+                torch.cuda.synchronize()
+        finally:
+            if frag:
+                ops.end_decode()             # a failing call must not leave the next test in fragment order
         return [a.cpu() for a in (qkv, kc, vc, x2, x, logits[:, :V])]
 
     hip.use_stream = hip.dec_down_slabs = True             # both layouts sum the same K-range slabs (bit-identical results)

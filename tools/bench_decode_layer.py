@@ -58,7 +58,7 @@ for mode in (["frag", "stream", "skinny"] if which == "both" else [which]):
             ops.register_decode_weight(wqkv[i], "qkv", LD, H, G)
             ops.register_decode_weight(wo[i], "plain", D)
             ops.register_decode_weight(wgu[i], "swiglu", I)
-            ops.register_decode_weight(wd[i], "plain", D)
+            ops.register_decode_weight(wd[i], "plain", D, slabs_ok=True)
         ops.register_decode_weight(head, "plain", V)
         assert ops.begin_decode(D, D, I)
     else:

@@ -14,7 +14,7 @@ wgu = [rn(2 * I, D, k=D ** -0.5) for _ in range(L)]
 wd = [rn(D, I, k=I ** -0.5) for _ in range(L)]
 for i in range(L):
     ops.register_decode_weight(wgu[i], "swiglu", I)
-    ops.register_decode_weight(wd[i], "plain", D)
+    ops.register_decode_weight(wd[i], "plain", D, slabs_ok=True)
 assert ops.begin_decode(D, D, I)
 xn, act = rn(M, D), rn(M, I)
 ws = torch.zeros(32 * 64 * 17920, device="cuda")

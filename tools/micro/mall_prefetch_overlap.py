@@ -21,7 +21,7 @@ for i in range(L):
     ops.register_decode_weight(wqkv[i], "qkv", LD, H, G)
     ops.register_decode_weight(wo[i], "plain", D)
     ops.register_decode_weight(wgu[i], "swiglu", I)
-    ops.register_decode_weight(wd[i], "plain", D)
+    ops.register_decode_weight(wd[i], "plain", D, slabs_ok=True)
 assert ops.begin_decode(D, D, I)
 frag = lambda w: ops._frag[w.data_ptr()][0]
 xn, ao, act = (torch.zeros(64, n, dtype=bf, device="cuda") for n in (D, D, I))

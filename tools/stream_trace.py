@@ -14,7 +14,7 @@ wd = [rn(D, I, k=I ** -0.5) for _ in range(L)]
 wo = [rn(D, D, k=D ** -0.5) for _ in range(L)]
 for i in range(L):
     ops.register_decode_weight(wgu[i], "swiglu", I)
-    ops.register_decode_weight(wd[i], "plain", D)
+    ops.register_decode_weight(wd[i], "plain", D, slabs_ok=True)
     ops.register_decode_weight(wo[i], "plain", D)
 assert ops.begin_decode(D, D, I)
 xn, act, ao = rn(M, D), rn(M, I), rn(M, D)
