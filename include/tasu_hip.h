@@ -67,6 +67,21 @@ int tasu_gemm_nt_bf16_kernel(const void* A, int lda, const void* B, int ldb, voi
  * act[M, I] = bf16( bf16(silu(g)) * u ) -- bit-identical to tasu_gemm_nt_bf16 + tasu_swiglu_fwd.  I % 4 == 0.        */
 int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K,
                              void* stream);
+/* ... with the workspace of tasu_gemm_nt_bf16_ws (or NULL): the 256 x 256 kernel may then cut its last rounds of tiles along K
+ * (stream-K, below).  gu / act are bit-identical to the call without a workspace only where no tile is cut. */
+int tasu_gemm_gate_up_swiglu_ws(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K,
+                                void* workspace, int64_t workspace_bytes, void* stream);
+/* tasu_gemm_nt_bf16_ws on the 256 x 256 eight-wave kernel with the STREAM-K schedule wherever the output tiles do not fill
+ * whole rounds of workgroups (one per CU), whatever tile the dispatcher's policy would pick: the trailing tiles are cut along K
+ * into one contiguous range of K-tile pairs per workgroup; a range that does not begin its tile leaves an fp32 partial tile in
+ * the workspace, and the workgroup that holds the tile's first K-tiles adds the partials IN K ORDER and runs the epilogue -- the
+ * result is bitwise repeatable, and differs from the unsplit kernel's only in the association of the fp32 sum over K.
+ * tasu_gemm_nt_bf16_ws takes this path by itself for the K-deep N = 1536 projections (96 tiles on 256 CUs) and for shapes
+ * whose last round of tiles would be mostly empty.  K % 128 == 0, K >= 256; workspace >= 64 MiB + 16 KiB, zero-initialised
+ * once (every launch leaves its flag words at zero); launches sharing a workspace must be ordered on one stream. */
+int tasu_gemm_nt_bf16_streamk(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                              const float* resid, int M, int N, int K, int out_mode, void* workspace, int64_t workspace_bytes,
+                              void* stream);
 /* Split-K form of the NT GEMM for outputs too small to fill the chip behind a very long K (the lm_head dgrad over
  * the labelled rows: [n_rows, 1536] outputs, K = padded vocabulary): partials[s] [M, ldc] fp32 = A[:, Ks] . B[:, Ks]^T
  * for the ksplit contiguous K ranges (K % (64 * ksplit) == 0), written as ksplit consecutive [M, ldc] matrices;

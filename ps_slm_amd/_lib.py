@@ -89,6 +89,8 @@ RESTYPE_I64 = set()
 PROTOTYPES.update({
     "tasu_scale_softmax_rows_bf16": [vp, vp, i32, i32, i32, f32, vp],
     "tasu_softmax_bwd_rows_bf16": [vp, vp, vp, i32, i32, i32, f32, vp],
+    "tasu_gemm_gate_up_swiglu_ws": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, i64, vp],
+    "tasu_gemm_nt_bf16_streamk": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "tasu_comm_available": [],
     "tasu_comm_unique_id": [vp],
     "tasu_comm_init": [vp, i32, i32, vp],

@@ -18,6 +18,7 @@
 #include <utility>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "../../include/tasu_hip.h"
 
 namespace {
@@ -341,7 +342,11 @@ int kernel_choice() {
 int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                             const float* resid, int M, int N, int K, int out_mode, int bn, hipStream_t st, int n0, int n1);
 int tasu_gemm_pp_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias, const float* resid,
-                          int M, int N, int K, int out_mode, hipStream_t st, int n0, int n1);
+                          int M, int N, int K, int out_mode, hipStream_t st, int n0, int n1, void* ws, size_t ws_bytes, double sk_rem);
+namespace tasu_pp {
+double sk_max_rem();
+int cu_count();
+}
 
 // Split-K plan for the 256 x 192 tile: ksplit blocks per tile so that tiles * ksplit is (close to) one round of 256
 // blocks, every split keeping >= 16 K-steps.  Returns 1 when the workspace is missing or too small.
@@ -430,9 +435,18 @@ extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int l
             const char* e = getenv("TASU_GEMM_PP_EFF");
             return e ? atof(e) : 1.26;
           }();
-          const double c256 = cost(tm * ((N + 255) / 256), 256.0 * 256, pp_eff);
+          // stream-K (gemm_pp.hip; needs the workspace): the 256 x 256 tiles fill FRACTIONAL rounds -- every workgroup gets the
+          // same number of K-tile pairs -- for the price of the partial tiles' round trip (~35 us per launch whatever K is:
+          // 1e8 / K in the units of this model).  That serves d_gate_up (96 tiles on 256 CUs, K = 17920: 203 -> 181 us); at
+          // K = 8960 (down) the 128 x 192 one-round grid still wins (100 vs 108 us).
+          const long t256 = tm * ((N + 255) / 256);
+          const int cus = tasu_pp::cu_count();
+          const bool sk = tasu_gemm::sk_plan(t256, K / 128, cus, ws_bytes >= TASU_GEMM_WS_COUNTERS * sizeof(int) + (size_t)cus * 262144,
+                                             tasu_pp::sk_max_rem()) > 0;
+          const double c256 = sk ? (double)t256 / cus * 256.0 * 256 / pp_eff + 1.0e8 / K : cost(t256, 256.0 * 256, pp_eff);
           const double best = use_pipe_bn == 128 ? c128 : (use_pipe_bn == 192 ? c192 : c96);
           if (c256 < best) {
+            if (sk) return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, 0, workspace, ws_bytes, -2.0);
             // a mostly empty last round of big tiles (d_down: 560 tiles = 2.19 rounds): whole rounds on the big tiles, the
             // remaining columns on the small tiles in a second launch (TASU_GEMM_NSPLIT=0 disables)
             static const bool split_on = [] {
@@ -446,13 +460,13 @@ extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int l
               const double t128 = cost(u128, 256.0 * 128, 1.00), t192 = cost(u192, 128.0 * 192, 0.86);
               const double c_split = (double)full * 256.0 * 256 / pp_eff + (t128 < t192 ? t128 : t192) + 0.05 * 256.0 * 256;
               if (c_split < c256) {
-                const int rc = tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, n_main);
+                const int rc = tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, n_main, nullptr, 0, -2.0);
                 if (rc) return rc;
                 return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, t128 < t192 ? 128 : 192, st,
                                                n_main, 0);
               }
             }
-            return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, 0);
+            return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, 0, nullptr, 0, -2.0);
           }
         }
       }

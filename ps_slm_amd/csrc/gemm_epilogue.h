@@ -31,7 +31,25 @@ struct Args {
   // 256 x 256 tiles would end in a mostly empty round with two launches, whole rounds of big tiles + the rest on small ones
   int n0 = 0;
   int n1 = 0;           // host side only: the launch's tiles cover columns [n0, n1) (0 = N); n1 is tile-aligned or N
+  // stream-K (gemm_pp.hip): the LAST sk_tiles output tiles are cut along K into one contiguous range of K-tile pairs per
+  // workgroup; a range that does not begin with its tile's first pair leaves an fp32 partial tile in sk_partial[workgroup]
+  // (256 KiB each, accumulator order) and raises sk_flags[workgroup]; the workgroup holding the tile's first pairs adds the
+  // partials in K order and stores the tile.  0 = every tile whole (the flags are left at 0 by every launch).
+  int sk_tiles = 0;
+  float* sk_partial = nullptr;
+  int* sk_flags = nullptr;
+  double sk_rem = -2.0;  // host side only: sk_plan's max_rem for this launch (-2 = the library default / TASU_GEMM_SK*)
 };
+
+// Stream-K plan of the 256 x 256 kernel for T output tiles of P K-tile pairs on G workgroups: how many (trailing) tiles are
+// cut along K.  0 = none: whole rounds, no workspace, ranges shorter than 8 pairs, or a last round that is nearly full.
+inline int sk_plan(long T, int P, int G, bool have_ws, double max_rem) {
+  if (!have_ws || max_rem < 0 || T <= 0 || T % G == 0) return 0;
+  if (T < G) return T * P / G >= 8 ? (int)T : 0;
+  const long rem = T % G;
+  if (max_rem <= 0 || (double)rem > max_rem * G || P < 8) return 0;
+  return (int)(rem + G);                       // the remainder and one whole round: 1 to 2 tiles per workgroup
+}
 
 // tile s of the virtual one-tile-per-block grid -> (tm, tn): XCD-aware (block b and tile s = b + r*gridDim share b % 8,
 // i.e. the XCD, because gridDim is a multiple of 8), bijective, then a GROUP_M-row-group raster for L2 reuse of the B panel.

@@ -313,11 +313,18 @@ int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void
 }
 
 int tasu_gemm_pp_gu_dispatch(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K, hipStream_t st,
-                             int n0, int n1);
+                             int n0, int n1, void* ws, size_t ws_bytes);
+namespace tasu_pp {
+double sk_max_rem();
+}
 
-extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I,
-                                        int K, void* stream) {
+// workspace (that of tasu_gemm_nt_bf16_ws) or nullptr: with it the 256 x 256 kernel may cut its last rounds along K (stream-K)
+extern "C" int tasu_gemm_gate_up_swiglu_ws(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I,
+                                           int K, void* workspace, int64_t workspace_bytes, void* stream) {
   using namespace tasu_pipe;
+  if (((uintptr_t)workspace & 15) || workspace_bytes < 0) return TASU_ERR_ARG;
+  void* const ws = workspace;
+  const size_t ws_bytes = workspace ? (size_t)workspace_bytes : 0;
   if (!A || !Wgu || !gu || !act || M <= 0 || I <= 0 || I % 4 || K <= 0 || K % BK || lda % 8 || ldw % 8) return TASU_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)Wgu & 15) || ((uintptr_t)gu & 7) || ((uintptr_t)act & 7)) return TASU_ERR_ARG;
   static const int forced = [] {                  // TASU_GEMM_GU_KERNEL=pipe|pp: A/B runs and tests of either kernel
@@ -345,7 +352,7 @@ extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu,
     return launch<256, 128, OUT_GU_SWIGLU, false>(a, (hipStream_t)stream);
   };
   const bool pp_ok = I % 128 == 0 && K >= 256 && K % 128 == 0;
-  if (forced == 2 && pp_ok) return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, 0);
+  if (forced == 2 && pp_ok) return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, 0, ws, ws_bytes);
   if (forced == 0 && pp_ok) {
     // tile policy as in tasu_gemm_nt_bf16_ws (gemm.hip): 256 x 256 tiles (128 act columns, gemm_pp.hip) where their coarser
     // rounds cost less than the per-FLOP efficiency they bring (4096 x 17920 x 1536: 257 -> 218 us); and when the last round
@@ -362,21 +369,30 @@ extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu,
     const long tm = (M + 255) / 256, cus = cu_count(), tn = (I + 127) / 128;
     auto rounds = [&](long tiles) { return (double)((tiles + cus - 1) / cus); };
     const double c128 = rounds(tm * ((I + 63) / 64)) * 0.5;
-    const double c256 = rounds(tm * tn) / 1.26;
+    // stream-K (workspace given): the big tiles fill fractional rounds, for the price of the partial tiles' round trip (~35 us)
+    const bool sk = tasu_gemm::sk_plan(tm * tn, K / 128, (int)cus, ws_bytes >= TASU_GEMM_WS_COUNTERS * sizeof(int) + (size_t)cus * 262144,
+                                       tasu_pp::sk_max_rem()) > 0;
+    const double c256 = sk ? ((double)(tm * tn) / cus) / 1.26 + 1.0e8 / K / 52012.0 : rounds(tm * tn) / 1.26;
     if (pp_on && c256 < c128) {
+      if (sk) return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, 0, ws, ws_bytes);
       const long full = (tm * tn) / cus;                          // whole rounds of big tiles
       const long tn_main = full * cus / tm;                       // column tiles they cover
       if (split_on && full >= 1 && tn_main < tn && tn_main > 0) {
         const double c_split = (double)full / 1.26 + rounds(tm * (tn - tn_main) * 2) * 0.5 + 0.05;   // + the second launch's ramp
         if (c_split < c256) {
-          const int rc = tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, (int)tn_main * 128);
+          const int rc = tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, (int)tn_main * 128, nullptr, 0);
           return rc ? rc : pipe_range((int)tn_main * 128);
         }
       }
-      return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, 0);
+      return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, 0, nullptr, 0);
     }
   }
   return pipe_range(0);
+}
+
+extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I,
+                                        int K, void* stream) {
+  return tasu_gemm_gate_up_swiglu_ws(A, lda, Wgu, ldw, gu, act, M, I, K, nullptr, 0, stream);
 }
 
 // ---- split-K form for grids that would leave most CUs idle behind a very long K (the lm_head dgrad over the labelled rows

@@ -45,29 +45,61 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;          // group (tile rows wr*128 ..), wave column (tile cols wc*64 ..)
   // split-K (TASU_GEMM_OUT_F32 only, gemm_epilogue.h): work item s = K range s / base_tiles of output tile s % base_tiles
-  const int nk = p.K / BK / p.ksplit;                // K-tiles per work item (even, >= 4)
+  const int nk = p.K / BK / p.ksplit;                // K-tiles per whole work item (even)
   const int base_tiles = p.tiles_m * p.tiles_n;
-  const int ntiles = base_tiles * p.ksplit;
+  // ---- the workgroup's list of work items.  Whole tiles (and K-range slabs) are dealt round-robin: item s = blockIdx + i *
+  // gridDim.  The last p.sk_tiles tiles are cut along K instead (stream-K): sk_tiles * P K-tile pairs, one contiguous range
+  // [ub(w), ub(w+1)) per workgroup, visited BEFORE its whole tiles, so that a partial tile is in memory long before the
+  // workgroup that completes the tile asks for it.  Range ends within 4 pairs of a tile boundary snap to it.
+  enum { FULL = 0, PART = 1, HEAD = 2 };
+  struct Item {
+    int tile, ks, k0t, nkt, kind;                    // output tile, slab, first K-tile, K-tiles (even), role
+  };
+  const int G = (int)gridDim.x, wg = (int)blockIdx.x;
+  const int P = p.K / (2 * BK);
+  const int dp_tiles = base_tiles * p.ksplit - p.sk_tiles;
+  const unsigned sk_units = (unsigned)p.sk_tiles * P;   // (the host keeps sk_units * gridDim below 2^31)
+  auto ub = [&](int w) -> int {
+    unsigned b = (unsigned)w * sk_units / (unsigned)G;
+    const unsigned r = b % (unsigned)P;
+    if (r && r < 4) b -= r;
+    else if (r && P - r < 4) b += P - r;
+    return (int)b;
+  };
+  const int u0 = p.sk_tiles ? ub(wg) : 0, u1 = p.sk_tiles ? ub(wg + 1) : 0;
+  const int nsk = u1 > u0 ? (u1 - 1) / P - u0 / P + 1 : 0;
+  auto get_item = [&](int idx, Item& it) -> bool {
+    if (idx < nsk) {
+      const int t = u0 / P + idx;
+      const int a = idx == 0 ? u0 : t * P, b = min(u1, (t + 1) * P);
+      it.tile = dp_tiles + t, it.ks = 0, it.k0t = (a - t * P) * 2, it.nkt = (b - a) * 2;
+      it.kind = a != t * P ? PART : (b != (t + 1) * P ? HEAD : FULL);
+      return true;
+    }
+    const int s = wg + (idx - nsk) * G;
+    if (s >= dp_tiles) return false;
+    it.ks = s / base_tiles, it.tile = s - it.ks * base_tiles, it.k0t = it.ks * nk, it.nkt = nk, it.kind = FULL;
+    return true;
+  };
 
 #if defined(__HIP_DEVICE_COMPILE__)
   // ------------------------------------------------------------------ staging
-  // Per tile only wave-uniform values change: the operand origins (1 KiB below the tile's first A / B row: piece 1 of a
-  // pair is addressed with immediate offset 1 KiB, which moves the LDS address and the global address alike, and a per-lane
-  // offset lowered by the same amount) and the byte counts up to the end of the matrices.  Rows past the end of a matrix
-  // (edge tiles) are beyond the descriptor's range: the hardware returns zeros for them, nothing is clamped per lane, and
-  // the per-lane offsets below are the same for every tile.
+  // Per work item only wave-uniform values change: the operand origins (1 KiB below the first A / B row of the tile at the
+  // item's first K element: piece 1 of a pair is addressed with immediate offset 1 KiB, which moves the LDS address and the
+  // global address alike, and a per-lane offset lowered by the same amount) and the byte counts up to the end of the matrices.
+  // Rows past the end of a matrix (edge tiles) are beyond the descriptor's range: the hardware returns zeros for them, nothing
+  // is clamped per lane, and the per-lane offsets below are the same for every item.
   struct Src {
     const char* a;
     const char* b;
     unsigned na, nb;
   };
-  auto setup = [&](Src& d, int s) {
+  auto setup = [&](Src& d, const Item& it) {
     int tm, tn;
-    const int ks = s / base_tiles;
-    tile_coords<4>(p, s - ks * base_tiles, base_tiles, tm, tn);
+    tile_coords<4>(p, it.tile, base_tiles, tm, tn);
     const int row0 = tm * BM;
     const int brow0 = p.n0 + (OUT_MODE == OUT_GU_SWIGLU ? tn * 128 : tn * BN);   // OUT_GU_SWIGLU: first gate row = first act column
-    const size_t k0 = (size_t)ks * nk * BK;          // first K element of this work item
+    const size_t k0 = (size_t)it.k0t * BK;           // first K element of this work item
     d.a = (const char*)(p.A + (size_t)row0 * p.lda + k0) - 1024;
     d.b = (const char*)(p.B + (size_t)brow0 * p.ldb + k0) - 1024;
     // (the byte counts run from the descriptor base, which a K range moves into the first row: rows past the end are still
@@ -189,10 +221,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
   };
 
   Src cur, nxt;
+  int nk_cur = 0;                                    // K-tiles of the current work item
   // Two K-tiles kt, kt + 1 of the current tile (stream parities 0 and 1 = buffers 0 and 1; the cols-0-31 fragments of the first
-  // are in fbx).  What is staged two K-tiles ahead belongs to the workgroup's next tile once kt + 2 == nk (nk is even).
+  // are in fbx).  What is staged two K-tiles ahead belongs to the workgroup's next work item once kt + 2 == nk_cur (even).
   auto kpair = [&](int kt) {
-    const bool wrap = kt + 2 >= nk;
+    const bool wrap = kt + 2 >= nk_cur;
     Src ahead;
     ahead.a = wrap ? nxt.a : cur.a;
     ahead.b = wrap ? nxt.b : cur.b;
@@ -244,7 +277,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
   };
 
   // ------------------------------------------------------------------ prologue: the DMA sequence up to phase 0 of K-tile 0
-  setup(cur, blockIdx.x);
+  Item ci, ni;
+  if (!get_item(0, ci)) return;
+  setup(cur, ci);
   nxt = cur;
   stage(cur, U0{}, Z{}, 0);
   stage(cur, U1{}, Z{}, 0);
@@ -259,35 +294,126 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
   fence();
   read_b(fbx, Z{}, Z{});
 
-  auto store_gu = [&](int row0, int tn) { store_gu_swiglu<MI, NI, BM>(p, acc, row0, p.n0 + tn * 128 + wc * 32, wr * 128, lane); };
-  auto store_c = [&](int row0, int col0, int ks) {
+  auto store_gu = [&](int row0, int tn, bool off) {
     Args q = p;
+    if (off) q.M = 0;
+    store_gu_swiglu<MI, NI, BM>(q, acc, row0, p.n0 + tn * 128 + wc * 32, wr * 128, lane);
+  };
+  auto store_c = [&](int row0, int col0, int ks, bool off) {
+    Args q = p;
+    if (off) q.M = 0;
     if constexpr (OUT_MODE == TASU_GEMM_OUT_F32) q.C = (float*)p.C + (size_t)ks * p.split_stride;   // slab of this K range
     store_tile<MI, NI, OUT_MODE, HAS_BIAS, BM, BN, false>(q, acc, row0, col0, wr * 128, wc * 64, lane);
   };
+  // stream-K partial tiles (256 KiB per workgroup): fragment f = i * NI + j of wave w at float4 index (w * 32 + f) * 64 + lane,
+  // i.e. a wave's fragments are 1 KiB apart (immediate offsets from one address per accumulator row)
+  auto part_row = [&](int w, int i) {
+    int slot = wave * (32 * 64) + lane;              // opaque: recomputed where it is used, not kept in a register (or in
+    asm volatile("" : "+v"(slot));                   // scratch) across the K loop
+    return (f32x4*)(p.sk_partial + (size_t)w * (BM * BN)) + (slot + i * NI * 64);
+  };
 
-  for (int s = blockIdx.x; s < ntiles; s += gridDim.x) {
-    int tm, tn;
-    const int ks = s / base_tiles;
-    tile_coords<4>(p, s - ks * base_tiles, base_tiles, tm, tn);
-    // the workgroup's next tile; after the last one the stream re-stages this tile's first units (never read) so that the
-    // DMA count behind every wait stays the same
-    if (s + (int)gridDim.x < ntiles) setup(nxt, s + (int)gridDim.x);
+  for (int idx = 0;; ++idx) {
+    // the workgroup's next work item; after the last one the stream re-stages this item's first units (never read) so that
+    // the DMA count behind every wait stays the same
+    const bool more = get_item(idx + 1, ni);
+    if (more) setup(nxt, ni);
+    nk_cur = ci.nkt;
     if (wr == 1) {                                   // group 1 runs one barrier behind group 0 through the K loop
       fence();
       __builtin_amdgcn_s_barrier();
       fence();
     }
-    for (int kt = 0; kt < nk; kt += 2) kpair(kt);
+    for (int kt = 0; kt < nk_cur; kt += 2) kpair(kt);
     if (wr == 0) {                                   // ... and both run the epilogue together (a group that stored alone would
       fence();                                       // hold its partners at their next barrier for the whole epilogue, twice)
       __builtin_amdgcn_s_barrier();
       fence();
     }
-    if constexpr (OUT_MODE == OUT_GU_SWIGLU) store_gu(tm * BM, tn);
-    else store_c(tm * BM, p.n0 + tn * BN, ks);
+    {
+      // a K range that does not begin its tile (PART): the accumulators go to this workgroup's partial tile, then the flag.
+      // The stores are issued for EVERY item, through a buffer descriptor that is empty unless the item is such a range (the
+      // hardware drops them): no branch around code that reads all 128 accumulator registers.  The partial tiles are written
+      // and read with device-scope (sc1) accesses, which are coherent between the XCDs' L2s by themselves: no cache-wide
+      // write-back / invalidate (a release / acquire FENCE would flush the operand panels the other workgroups of the XCD
+      // are sharing through that L2).
+      const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sk_partial + (size_t)wg * (BM * BN)), 0,
+                                                                           ci.kind == PART ? BM * BN * 4 : 0, 0x00020000);
+      int slot = (wave * (32 * 64) + lane) * 16;
+      asm volatile("" : "+v"(slot));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          union { f32x4 f; u32x4 u; } v;
+          v.f = acc[i][j];
+          __builtin_amdgcn_raw_buffer_store_b128(v.u, prs, slot + (i * NI + j) * 1024, 0, /*sc1*/ 16);
+        }
+    }
+    if (ci.kind == PART) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (threadIdx.x == 0) __hip_atomic_store(p.sk_flags + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (ci.kind == HEAD) {
+      // the tile's first pairs: the later ranges belong to the next workgroups (each one's FIRST item, done long ago);
+      // their partial tiles are added in K order, so the sum does not depend on who finished when
+      const int tile_end = (ci.tile - dp_tiles + 1) * P;
+#pragma nounroll
+      for (int j = wg + 1; j < G && ub(j) < tile_end; ++j) {
+        if (threadIdx.x == 0) {
+          while (__hip_atomic_load(p.sk_flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+          __hip_atomic_store(p.sk_flags + j, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left at 0 for the next launch
+        }
+        __builtin_amdgcn_s_barrier();
+        // 32 KiB per wave, read one accumulator row (4 loads) at a time with the next row already in flight: the round trip
+        // to the memory side (sc1: past the L2) is paid once per partial tile, not once per row
+        f32x4 ta[NI], tb[NI];
+        auto issue = [&](f32x4 (&t)[NI], int i) {
+          const f32x4* q = part_row(j, i);
+          asm volatile(
+              "global_load_dwordx4 %0, %4, off sc1\n"
+              "global_load_dwordx4 %1, %4, off offset:1024 sc1\n"
+              "global_load_dwordx4 %2, %4, off offset:2048 sc1\n"
+              "global_load_dwordx4 %3, %4, off offset:3072 sc1"
+              : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+              : "v"(q)
+              : "memory");
+        };
+        auto add = [&](f32x4 (&t)[NI], int i, auto left_tag) {     // waits until all but the `left` youngest loads are back
+          constexpr int LEFT = decltype(left_tag)::value;
+          if constexpr (LEFT == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])::"memory");
+          else asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])::"memory");
+#pragma unroll
+          for (int jj = 0; jj < NI; ++jj) acc[i][jj] += t[jj];
+        };
+        using W4 = std::integral_constant<int, 4>;
+        using W0 = std::integral_constant<int, 0>;
+        issue(ta, 0);
+#pragma unroll
+        for (int i = 0; i < MI; i += 2) {
+          issue(tb, i + 1);
+          add(ta, i, W4{});
+          if (i + 2 < MI) {
+            issue(ta, i + 2);
+            add(tb, i + 1, W4{});
+          } else {
+            add(tb, i + 1, W0{});
+          }
+        }
+      }
+    }
+    {
+      // the tile's epilogue -- for EVERY item, PART ones with an empty matrix (every store predicated off): see above
+      int tm, tn;
+      tile_coords<4>(p, ci.tile, base_tiles, tm, tn);
+      if constexpr (OUT_MODE == OUT_GU_SWIGLU) store_gu(tm * BM, tn, ci.kind == PART);
+      else store_c(tm * BM, p.n0 + tn * BN, ci.ks, ci.kind == PART);
+    }
     zero_acc();
+    if (!more) break;
     cur = nxt;
+    ci = ni;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-staged units: no DMA may be in flight into a released LDS
 #endif
@@ -305,6 +431,20 @@ int cu_count() {
   return n;
 }
 
+// Library default of sk_plan's max_rem.  Measured (profiles/r03_gemm_streamk.txt): the round trip of the partial tiles costs
+// ~35 us per launch; it pays for fewer tiles than CUs behind a long K (d_gate_up: 96 tiles, K = 17920: 203 -> 181 us), not for
+// shapes that only lose a fraction of their last round (d_down 2.19 rounds, gate|up 4.4, lm_head 18.6: slower by 5-25 us) --
+// so those keep whole tiles unless TASU_GEMM_SK_MAXREM says otherwise.  TASU_GEMM_SK=0 disables the schedule altogether.
+double sk_max_rem() {
+  static const double v = [] {
+    const char* off = getenv("TASU_GEMM_SK");
+    if (off && off[0] == '0') return -1.0;
+    const char* e = getenv("TASU_GEMM_SK_MAXREM");
+    return e ? atof(e) : 0.0;
+  }();
+  return v;
+}
+
 template <int OUT_MODE, bool HAS_BIAS>
 int launch(Args a, hipStream_t st) {
   constexpr int LDS = 2 * BUF;
@@ -317,9 +457,22 @@ int launch(Args a, hipStream_t st) {
   const int n_end = a.n1 > 0 ? a.n1 : a.N;
   a.tiles_n = OUT_MODE == OUT_GU_SWIGLU ? (n_end - a.n0 + 127) / 128 : (n_end - a.n0 + 255) / 256;
   const int ntiles = a.tiles_m * a.tiles_n * a.ksplit;
-  const int grid = ntiles < cu_count() ? ntiles : cu_count();
+  const int G = cu_count();
+  // stream-K over the last (partial + one whole) round when the workspace is there (sk_plan, gemm_epilogue.h)
+  a.sk_tiles = a.ksplit == 1 && (long long)ntiles * (a.K / 128) < (1 << 22) ? sk_plan(ntiles, a.K / 128, G, a.sk_flags && a.sk_partial, a.sk_rem > -1.5 ? a.sk_rem : sk_max_rem()) : 0;
+  if (!a.sk_tiles) a.sk_flags = nullptr, a.sk_partial = nullptr;
+  const int grid = a.sk_tiles || ntiles >= G ? G : ntiles;
   TASU_LAUNCH((gemm_pp_kernel<OUT_MODE, HAS_BIAS>), dim3(grid), dim3(512), LDS, st, a);
   return TASU_OK;
+}
+
+// workspace of tasu_gemm_nt_bf16_ws: TASU_GEMM_WS_COUNTERS ints (all zero between launches: the flags), then the partial tiles
+void set_sk_workspace(Args& a, void* ws, size_t ws_bytes, double sk_rem) {
+  const size_t need = TASU_GEMM_WS_COUNTERS * sizeof(int) + (size_t)cu_count() * BM * 256 * sizeof(float);
+  a.sk_rem = sk_rem;
+  if (!ws || ws_bytes < need || cu_count() > TASU_GEMM_WS_COUNTERS) return;
+  a.sk_flags = (int*)ws;
+  a.sk_partial = (float*)((char*)ws + TASU_GEMM_WS_COUNTERS * sizeof(int));
 }
 
 }  // namespace tasu_pp
@@ -327,9 +480,10 @@ int launch(Args a, hipStream_t st) {
 // C[M,N] = A[M,K] . B[N,K]^T (+ bias) with the 256 x 256 ping-pong kernel; same contract as tasu_gemm_nt_bf16_ws
 // (K % 64 == 0, lda / ldb % 8 == 0, 16-byte aligned operands).  Called from gemm.hip's dispatcher.
 int tasu_gemm_pp_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias, const float* resid,
-                          int M, int N, int K, int out_mode, hipStream_t st, int n0, int n1) {
+                          int M, int N, int K, int out_mode, hipStream_t st, int n0, int n1, void* ws, size_t ws_bytes, double sk_rem) {
   using namespace tasu_pp;
   Args a;
+  set_sk_workspace(a, ws, ws_bytes, sk_rem);
   a.n0 = n0;
   a.n1 = n1;
   a.A = (const bf16*)A;
@@ -362,10 +516,11 @@ int tasu_gemm_pp_dispatch(const void* A, int lda, const void* B, int ldb, void* 
 
 // gate|up projection + SwiGLU epilogue on 256 x 256 tiles (128 act columns); called from tasu_gemm_gate_up_swiglu (gemm_pipe.hip)
 int tasu_gemm_pp_gu_dispatch(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K, hipStream_t st,
-                             int n0, int n1) {
+                             int n0, int n1, void* ws, size_t ws_bytes) {
   using namespace tasu_pp;
   if (I % 128 || K < 256 || K % 128) return TASU_ERR_ARG;
   Args a;
+  set_sk_workspace(a, ws, ws_bytes, -2.0);
   a.n0 = n0;
   a.n1 = n1;
   a.A = (const bf16*)A;
@@ -418,6 +573,18 @@ extern "C" int tasu_gemm_nt_bf16_slabs(const void* A, int lda, const void* B, in
 int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                             const float* resid, int M, int N, int K, int out_mode, int bn, hipStream_t st, int n0, int n1);
 
+// tasu_gemm_nt_bf16_ws on the 256 x 256 kernel with the stream-K schedule wherever the tiles do not fill whole rounds of
+// workgroups, whatever the dispatcher's policy would choose (tests, tuning runs).  Same contract; K % 128 == 0, K >= 256.
+extern "C" int tasu_gemm_nt_bf16_streamk(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                                         const float* resid, int M, int N, int K, int out_mode, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+  if (!A || !B || !C || !workspace || M <= 0 || N <= 0 || K < 256 || K % 128 || lda % 8 || ldb % 8) return TASU_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)workspace & 15)) return TASU_ERR_ARG;
+  if (out_mode == TASU_GEMM_OUT_F32_RESID_BF16R && !resid) return TASU_ERR_ARG;
+  return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, (hipStream_t)stream, 0, 0, workspace,
+                               (size_t)workspace_bytes, 1.0);
+}
+
 // tasu_gemm_nt_bf16 on a NAMED kernel, regardless of the dispatcher's tile policy (tests, tuning runs; include/tasu_hip.h)
 extern "C" int tasu_gemm_nt_bf16_kernel(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                                         const float* resid, int M, int N, int K, int out_mode, int kernel, void* stream) {
@@ -427,7 +594,7 @@ extern "C" int tasu_gemm_nt_bf16_kernel(const void* A, int lda, const void* B, i
   switch (kernel) {
     case TASU_GEMM_KERNEL_PP256:
       if (K < 256 || K % 128) return TASU_ERR_ARG;            // an even number (>= 4) of 64-deep K-tiles
-      return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, (hipStream_t)stream, 0, 0);
+      return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, (hipStream_t)stream, 0, 0, nullptr, 0, -2.0);
     case TASU_GEMM_KERNEL_PIPE128:
       return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, 128, (hipStream_t)stream, 0, 0);
     case TASU_GEMM_KERNEL_PIPE192:

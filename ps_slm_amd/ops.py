@@ -70,6 +70,12 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_nt_bf16_kernel(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(bias), _p(resid),
                                                     M, N, K, mode, self.GEMM_KERNELS[kernel], self._stream()), "tasu_gemm_nt_bf16_kernel")
 
+    def gemm_streamk(self, a, b, c, M, N, K, bias=None, resid=None, mode=GEMM_BF16):
+        """gemm() on the 256 x 256 kernel with the stream-K schedule (tasu_gemm_nt_bf16_streamk): tests and tuning."""
+        self._chk(self.lib.tasu_gemm_nt_bf16_streamk(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(bias), _p(resid),
+                                                     M, N, K, mode, _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()),
+                  "tasu_gemm_nt_bf16_streamk")
+
     def gemm_splitk(self, a, b, c, M, N, K, ksplit, ws):
         """c[M,N] (bf16) = a[M,K] @ b[N,K]^T with the K range cut into ``ksplit`` work items per output tile (fp32 partial
         matrices in ``ws``, summed in order, one bf16 rounding): for outputs that cannot fill the chip behind a very long K."""
@@ -88,8 +94,9 @@ class HipOps:
 
     def gemm_gate_up_swiglu(self, a, wgu, gu, act, M, I, K):
         """gu[M,2I] = a @ wgu^T and act[M,I] = swiglu(gu) in one launch (training step)."""
-        self._chk(self.lib.tasu_gemm_gate_up_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), M, I, K,
-                                                    self._stream()), "tasu_gemm_gate_up_swiglu")
+        self._chk(self.lib.tasu_gemm_gate_up_swiglu_ws(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), M, I, K,
+                                                       _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()),
+                  "tasu_gemm_gate_up_swiglu_ws")
 
     # ------------------------------------------------------------------ decode-step GEMMs
     def _stream_split(self, K):

@@ -174,6 +174,69 @@ def test_gemm_split_k(hip, fake, M, N, K, mode):
     assert int(hip.gemm_ws[:4096 * 4].view(torch.int32).abs().sum()) == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 1536, 8960), (2048, 1536, 17920), (3000, 1500, 8192), (4096, 4608, 1024), (1000, 1000, 4096),
+                                   (2304, 1280, 6144)])
+@pytest.mark.parametrize("mode,bias", [(0, False), (1, True), (2, False)])
+def test_gemm_streamk(hip, fake, M, N, K, mode, bias):
+    """The stream-K schedule of the 256 x 256 kernel (tasu_gemm_nt_bf16_streamk): 96 / 48 / 72 tiles on 256 workgroups (every
+    tile cut into 2 to 6 K ranges, edge tiles in both directions), 288 tiles (one whole round + 32 tiles: the last 288 tiles cut
+    into 9-pair ranges), 16 tiles of 32 pairs (ranges too short: whole tiles) and 45 tiles of 48 pairs (8-pair ranges, a
+    boundary within 4 pairs of a tile end snaps to it).  Against the fp32 double; BITWISE repeatable (the partial tiles are added in K order,
+    whoever finishes first); the flag words of the workspace are left at zero; columns beyond N untouched."""
+    ldc = (N + 63) // 64 * 64
+    a = randn(M, K, dtype=BF, seed=1)
+    b = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
+    bv = randn(N, dtype=BF, seed=3) if bias else None
+    c = torch.zeros(M, ldc, dtype=BF if mode == 0 else F32)
+    r = randn(M, ldc, seed=4) if mode == 2 else None
+    cc, g1, g2 = c.clone(), c.cuda(), c.cuda()
+    fake.gemm(a, b, cc, M, N, K, bias=bv, resid=r, mode=mode)
+    ad, bd = a.cuda(), b.cuda()
+    hip.gemm_streamk(ad, bd, g1, M, N, K, bias=dev(bv), resid=dev(r), mode=mode)
+    hip.gemm_streamk(ad, bd, g2, M, N, K, bias=dev(bv), resid=dev(r), mode=mode)
+    torch.cuda.synchronize()
+    assert rel_err(g1, cc) < (1e-2 if mode != 1 else 2e-5 * math.sqrt(K))
+    assert torch.equal(g1, g2)
+    assert torch.equal(g1.cpu()[:, N:], cc[:, N:]), "columns beyond N must be untouched"
+    assert int(hip.gemm_ws[:4096 * 4].view(torch.int32).abs().sum()) == 0
+
+
+def test_gemm_policy_takes_streamk_for_d_gate_up(hip):
+    """4096 x 1536 x 17920 (the MLP's input gradient: 96 tiles of 256 x 256 on 256 CUs behind 280 K-tiles): the dispatcher's
+    choice is the stream-K schedule -- its result is the named entry point's, bit for bit, and NOT the one-round 128 x 192
+    grid's (a different association of the fp32 sums), which it matches to fp32 rounding."""
+    M, N, K = 4096, 1536, 17920
+    a = randn(M, K, dtype=BF, seed=5).cuda()
+    b = randn(N, K, dtype=BF, seed=6, scale=1.0 / math.sqrt(K)).cuda()
+    c1, c2, c3 = (torch.zeros(M, N, dtype=F32).cuda() for _ in range(3))
+    hip.gemm(a, b, c1, M, N, K, mode=1)
+    hip.gemm_streamk(a, b, c2, M, N, K, mode=1)
+    hip.gemm_on("pipe192", a, b, c3, M, N, K, mode=1)
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2)
+    assert not torch.equal(c1, c3) and rel_err(c1, c3) < 1e-5
+
+
+def test_gemm_gate_up_swiglu_streamk(hip, fake):
+    """gate|up + SwiGLU on 96 tiles behind K = 16384 (2048 rows, I = 1536): with the workspace the policy cuts the tiles along K;
+    gate|up and the activation agree with the unfused double, bitwise repeatable."""
+    M, I, K = 2048, 1536, 16384
+    a = randn(M, K, dtype=BF, seed=1)
+    w = randn(2 * I, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K))
+    gu_c, act_c = torch.zeros(M, 2 * I, dtype=BF), torch.zeros(M, I, dtype=BF)
+    fake.gemm_gate_up_swiglu(a, w, gu_c, act_c, M, I, K)
+    ad, wd = a.cuda(), w.cuda()
+    outs = []
+    for _ in range(2):
+        gu, act = torch.zeros(M, 2 * I, dtype=BF).cuda(), torch.zeros(M, I, dtype=BF).cuda()
+        hip.gemm_gate_up_swiglu(ad, wd, gu, act, M, I, K)
+        outs.append((gu, act))
+    torch.cuda.synchronize()
+    assert rel_err(outs[0][0], gu_c) < 1e-2 and rel_err(outs[0][1], act_c) < 2e-2
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert int(hip.gemm_ws[:4096 * 4].view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize("M,I,K", [(4096, 8960, 1536), (300, 200, 128), (257, 72, 64), (64, 96, 256), (4096, 8192, 256), (1100, 4480, 384)])
 def test_gemm_gate_up_swiglu(hip, fake, M, I, K):
     """Fused epilogue == GEMM followed by swiglu_fwd: same gate|up bits, same activation bits."""
