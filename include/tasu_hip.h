@@ -67,6 +67,16 @@ int tasu_gemm_nt_bf16_kernel(const void* A, int lda, const void* B, int ldb, voi
  * act[M, I] = bf16( bf16(silu(g)) * u ) -- bit-identical to tasu_gemm_nt_bf16 + tasu_swiglu_fwd.  I % 4 == 0.        */
 int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K,
                              void* stream);
+/* Qwen2MLP backward, first half, in one call (the training step's d_down + SwiGLU backward):
+ *   dact[M, I] = bf16(dy[M, K] . WdT[I, K]^T)   (WdT = down_proj.weight transposed once at load time: [I, K = hidden])
+ *   dgu[m, n]     = bf16(d * u * sig(g) * (1 + g * (1 - sig(g)))),  dgu[m, I + n] = bf16(d * g * sig(g)),
+ *   g = gu[m, n], u = gu[m, I + n] (the gate|up matrix tasu_gemm_gate_up_swiglu saved), d = dact[m, n]
+ * -- bit-identical to tasu_gemm_nt_bf16 (bf16 output) followed by tasu_swiglu_bwd, which is what runs by default, through
+ * dact_ws (bf16 [M, I]).  With TASU_GEMM_DSWIGLU=1 and M > 128 the SwiGLU backward runs in the GEMM kernels' epilogue and dact
+ * never reaches memory (same bits; measured worth 0.3 % of the step: DESIGN.md 8).  I % 8 == 0, K % 64 == 0, 16-byte
+ * aligned operands; workspace as for tasu_gemm_nt_bf16_ws (may be NULL). */
+int tasu_gemm_dswiglu(const void* dy, int lddy, const void* WdT, int ldw, const void* gu, void* dgu, void* dact_ws, int M, int I,
+                      int K, void* workspace, int64_t workspace_bytes, void* stream);
 /* ... with the workspace of tasu_gemm_nt_bf16_ws (or NULL): the 256 x 256 kernel may then cut its last rounds of tiles along K
  * (stream-K, below).  gu / act are bit-identical to the call without a workspace only where no tile is cut. */
 int tasu_gemm_gate_up_swiglu_ws(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K,

@@ -71,3 +71,9 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 __device__ __forceinline__ float bf16_round(float x) { return (float)(bf16)x; }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+// SwiGLU backward of one element (tasu_swiglu_bwd and the tasu_gemm_dswiglu epilogue share this text: the same bits)
+__device__ __forceinline__ void swiglu_bwd_f(float gf, float uf, float df, float& dg, float& du) {
+  const float sg = sigmoid_f(gf);
+  dg = df * uf * sg * (1.f + gf * (1.f - sg));
+  du = df * gf * sg;
+}

@@ -46,10 +46,10 @@ __global__ void swiglu_bwd_kernel(const bf16* __restrict__ dact, const bf16* __r
     bf16x8 dg, du;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float gf = (float)g[j], uf = (float)u[j], df = (float)d[j];
-      const float sg = sigmoid_f(gf);
-      dg[j] = (bf16)(df * uf * sg * (1.f + gf * (1.f - sg)));
-      du[j] = (bf16)(df * gf * sg);
+      float dgf, duf;
+      swiglu_bwd_f((float)g[j], (float)u[j], (float)d[j], dgf, duf);
+      dg[j] = (bf16)dgf;
+      du[j] = (bf16)duf;
     }
     *(bf16x8*)(dgu + m * 2 * I + c * 8) = dg;
     *(bf16x8*)(dgu + m * 2 * I + I + c * 8) = du;

@@ -366,9 +366,12 @@ static int plan_ksplit(int M, int N, int K, size_t ws_bytes) {
   return ks;
 }
 
-extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
-                                    const float* resid, int M, int N, int K, int out_mode, void* workspace,
-                                    int64_t workspace_bytes, void* stream) {
+// out_mode: TASU_GEMM_OUT_* or tasu_gemm::OUT_DSWIGLU (`resid` is then the saved gate|up matrix, bf16 [M, 2N], C = dgu [M, 2N]:
+// served by the gemm_pipe / gemm_pp kernels only -- kUnsupported otherwise, and tasu_gemm_dswiglu runs the two-kernel form)
+constexpr int kUnsupported = -1000;
+static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias, const float* resid, int M,
+                       int N, int K, int out_mode, void* workspace, int64_t workspace_bytes, void* stream) {
+  const bool dsw = out_mode == tasu_gemm::OUT_DSWIGLU;
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return TASU_ERR_ARG;
   if (K % BK != 0 || lda % 8 != 0 || ldb % 8 != 0) return TASU_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)workspace & 15)) return TASU_ERR_ARG;
@@ -411,7 +414,7 @@ extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int l
   if (use_pipe_bn != 0) {
     const long tm = (M + 255) / 256;
     const long t128 = tm * ((N + 127) / 128), t96 = tm * ((N + 95) / 96);
-    if (kernel_choice() == 0 && t96 < 128 && K >= 8192 && plan_ksplit(M, N, K, ws_bytes) > 1) {
+    if (!dsw && kernel_choice() == 0 && t96 < 128 && K >= 8192 && plan_ksplit(M, N, K, ws_bytes) > 1) {
       use_pipe_bn = 0;                              // falls through to the split-K tile below
     } else {
       if (use_pipe_bn < 0) {
@@ -473,6 +476,7 @@ extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int l
       return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, use_pipe_bn, st, 0, 0);
     }
   }
+  if (dsw) return kUnsupported;
   int bn;
   if (kernel_choice() == 0 && forced_bn == 0 && M > 128) {
     bn = 192;                                       // the deep small-grid case above
@@ -497,6 +501,37 @@ extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int l
     default:
       return TASU_ERR_ARG;
   }
+}
+
+extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                                    const float* resid, int M, int N, int K, int out_mode, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+  if (out_mode != TASU_GEMM_OUT_BF16 && out_mode != TASU_GEMM_OUT_F32 && out_mode != TASU_GEMM_OUT_F32_RESID_BF16R) return TASU_ERR_ARG;
+  return gemm_policy(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tasu_swiglu_bwd(const void* dact, const void* gu, void* dgu, int M, int I, void* stream);
+
+// Down projection's input gradient with the SwiGLU backward in the GEMM's epilogue (include/tasu_hip.h)
+extern "C" int tasu_gemm_dswiglu(const void* dy, int lddy, const void* WdT, int ldw, const void* gu, void* dgu, void* dact_ws, int M,
+                                 int I, int K, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!dy || !WdT || !gu || !dgu || M <= 0 || I <= 0 || I % 8 || K <= 0 || K % BK || lddy % 8 || ldw % 8) return TASU_ERR_ARG;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)WdT & 15) || ((uintptr_t)gu & 15) || ((uintptr_t)dgu & 15)) return TASU_ERR_ARG;
+  // TASU_GEMM_DSWIGLU=1 selects the fused epilogue.  Off by default: measured in the step (one box, alternating runs) it is
+  // worth 0.09 ms of 29 -- the epilogue's gate|up reads and dgu writes (294 MB per call) run while the CU's MFMA pipes idle,
+  // with every CU in its epilogue at the same time, so the GEMM grows by what the separate kernel took (55 us at 6.6 TB/s)
+  // although dact's 147 MB round trip is gone.  It pays once tile boundaries of different workgroups stop coinciding.
+  const char* const fused_env = getenv("TASU_GEMM_DSWIGLU");   // (read per call: the tests run both forms in one process)
+  const bool fused_on = fused_env && fused_env[0] == '1';
+  if (fused_on) {
+    const int rc = gemm_policy(dy, lddy, WdT, ldw, dgu, 2 * I, nullptr, (const float*)gu, M, I, K, tasu_gemm::OUT_DSWIGLU, workspace,
+                               workspace_bytes, stream);
+    if (rc != kUnsupported) return rc;
+  }
+  if (!dact_ws || ((uintptr_t)dact_ws & 15)) return TASU_ERR_ARG;
+  const int rc = gemm_policy(dy, lddy, WdT, ldw, dact_ws, I, nullptr, nullptr, M, I, K, TASU_GEMM_OUT_BF16, workspace, workspace_bytes,
+                             stream);
+  return rc ? rc : tasu_swiglu_bwd(dact_ws, gu, dgu, M, I, stream);
 }
 
 extern "C" int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,

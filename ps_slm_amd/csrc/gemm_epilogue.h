@@ -12,6 +12,7 @@
 namespace tasu_gemm {
 
 constexpr int OUT_GU_SWIGLU = 3;    // internal epilogue of tasu_gemm_gate_up_swiglu (after the three TASU_GEMM_OUT_* modes)
+constexpr int OUT_DSWIGLU = 4;      // internal epilogue of tasu_gemm_dswiglu: the SwiGLU backward of the down projection's dgrad
 
 struct Args {
   const bf16* A;
@@ -141,12 +142,90 @@ __device__ __forceinline__ void store_gu_swiglu(const Args& p, f32x4 (&acc)[MI][
   }
 }
 
+// OUT_DSWIGLU epilogue (Qwen2MLP backward, modeling_qwen2.py Qwen2MLP.forward differentiated): the tile is
+// dact[M, I] = dy . Wd (the down projection's input gradient); with the saved gate|up [M, 2I] (p.act) it writes
+//   dgu[m, n]     = bf16(d * u * sig(g) * (1 + g * (1 - sig(g))))      (gate gradient)
+//   dgu[m, I + n] = bf16(d * g * sig(g))                               (up gradient),   d = bf16(dact[m, n])
+// into p.C [M, 2I] -- bit-identical to the GEMM with bf16 output followed by tasu_swiglu_bwd, without dact's round trip.
+// Fragment pairs trade halves as in store_tile's bf16 path, so a lane owns 8 consecutive columns of a row: 16-byte loads
+// of g and u, 16-byte stores of dg and du; the next row block's g / u are in flight while this one is computed.
+template <int MI, int NI, int BM, int BN>
+__device__ __forceinline__ void store_dswiglu(const Args& p, f32x4 (&acc)[MI][NI], int row0, int col0, int wrow, int wcol, int lane) {
+  if constexpr (NI % 2 == 0) {
+    constexpr int NP = NI / 2;
+    int l15 = lane & 15;
+    int cpair = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;         // first of this lane's 8 columns inside a fragment pair
+    asm volatile("" : "+v"(l15), "+v"(cpair));
+    const int I = p.N;
+    const bf16* gu = p.act;
+    bf16* dgu = (bf16*)p.C;
+    const bool interior = row0 + BM <= p.M && col0 + BN <= p.N;
+    auto rows = [&](auto interior_tag) {
+      constexpr bool INTERIOR = decltype(interior_tag)::value;
+      u32x4 gq[2][NP], uq[2][NP];
+      auto fetch = [&](int i, int buf) {
+        // clamped addresses (rows / columns past the matrix read a valid element; their results are not stored)
+        const int m = INTERIOR ? row0 + wrow + i * 16 + l15 : min(row0 + wrow + i * 16 + l15, p.M - 1);
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          int n = col0 + wcol + jp * 32 + cpair;
+          if (!INTERIOR) n = min(n, I - 8);
+          const bf16* q = gu + (size_t)m * (2 * (size_t)I) + n;
+          gq[buf][jp] = *(const u32x4*)q;
+          uq[buf][jp] = *(const u32x4*)(q + I);
+        }
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        asm volatile("" ::: "memory");
+        if (i + 1 < MI) fetch(i + 1, (i + 1) & 1);
+        const int m = row0 + wrow + i * 16 + l15;
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          union { bf16x4 h; unsigned u[2]; } a, b;
+          a.h = __builtin_convertvector(acc[i][2 * jp], bf16x4);
+          b.h = __builtin_convertvector(acc[i][2 * jp + 1], bf16x4);
+          swap16(a.u[0], b.u[0]);
+          swap16(a.u[1], b.u[1]);
+          union { u32x4 q; bf16 h[8]; } d, g, u, dg, du;
+          d.q = u32x4{a.u[0], a.u[1], b.u[0], b.u[1]};
+          g.q = gq[i & 1][jp];
+          u.q = uq[i & 1][jp];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            float dgf, duf;
+            swiglu_bwd_f((float)g.h[r], (float)u.h[r], (float)d.h[r], dgf, duf);
+            dg.h[r] = (bf16)dgf;
+            du.h[r] = (bf16)duf;
+          }
+          const int n = col0 + wcol + jp * 32 + cpair;
+          bf16* c = dgu + (size_t)m * (2 * (size_t)I) + n;
+          if constexpr (INTERIOR) {
+            *(u32x4*)c = dg.q;
+            *(u32x4*)(c + I) = du.q;
+          } else if (m < p.M && n + 8 <= I) {
+            *(u32x4*)c = dg.q;
+            *(u32x4*)(c + I) = du.q;
+          }
+        }
+      }
+    };
+    if (interior) rows(std::true_type{});
+    else rows(std::false_type{});
+  }
+}
+
 template <int MI, int NI, int OUT_MODE, bool HAS_BIAS, int BM, int BN, bool WIDE_RESID>
 __device__ __forceinline__ void store_tile(const Args& p, f32x4 (&acc)[MI][NI], int row0, int col0, int wrow, int wcol, int lane) {
   // opaque copies of the lane coordinates: keeps the 32 per-fragment output addresses from being hoisted out of the
   // tile loop into registers that the K loop needs (the kernel sits at the 256-VGPR limit of two waves per SIMD)
   int l15 = lane & 15, l4 = (lane >> 4) * 4;
   asm volatile("" : "+v"(l15), "+v"(l4));
+  if constexpr (OUT_MODE == OUT_DSWIGLU) {
+    store_dswiglu<MI, NI, BM, BN>(p, acc, row0, col0, wrow, wcol, lane);
+    return;
+  }
   // the bias depends on the column only: NI x 4 values per lane, loaded once per tile (not once per row block)
   [[maybe_unused]] float bv[NI][4];
   if (HAS_BIAS) {

@@ -307,6 +307,11 @@ int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void
     case TASU_GEMM_OUT_F32_RESID_BF16R:
       return hb ? launch_bn<TASU_GEMM_OUT_F32_RESID_BF16R, true>(a, bn, st)
                 : launch_bn<TASU_GEMM_OUT_F32_RESID_BF16R, false>(a, bn, st);
+    case OUT_DSWIGLU:                                // `resid` = the saved gate|up matrix (bf16 [M, 2N]); C = dgu [M, 2N]
+      if (hb || !resid || N % 8 || ldc != 2 * N || bn == 96) return TASU_ERR_ARG;
+      a.act = (bf16*)resid;
+      a.R = nullptr;
+      return launch_bn<OUT_DSWIGLU, false>(a, bn, st);
     default:
       return TASU_ERR_ARG;
   }

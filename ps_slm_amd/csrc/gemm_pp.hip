@@ -33,13 +33,14 @@ namespace tasu_pp {
 
 using namespace tasu_gemm;
 
-constexpr int BK = 64, BM = 256;
+[[maybe_unused]] constexpr int BK = 64, BM = 256;
 constexpr int UNIT = 16384, BUF = 4 * UNIT;        // LDS: [buffer][A0 | A1 | B0 | B1], 128 KiB
 
 typedef __attribute__((address_space(3))) void lds_void;
 
 template <int OUT_MODE, bool HAS_BIAS>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BN = 256, MI = 8, NI = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,7 +83,6 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
     return true;
   };
 
-#if defined(__HIP_DEVICE_COMPILE__)
   // ------------------------------------------------------------------ staging
   // Per work item only wave-uniform values change: the operand origins (1 KiB below the first A / B row of the tile at the
   // item's first K element: piece 1 of a pair is addressed with immediate offset 1 KiB, which moves the LDS address and the
@@ -509,6 +509,11 @@ int tasu_gemm_pp_dispatch(const void* A, int lda, const void* B, int ldb, void* 
       return hb ? launch<TASU_GEMM_OUT_F32, true>(a, st) : launch<TASU_GEMM_OUT_F32, false>(a, st);
     case TASU_GEMM_OUT_F32_RESID_BF16R:
       return hb ? launch<TASU_GEMM_OUT_F32_RESID_BF16R, true>(a, st) : launch<TASU_GEMM_OUT_F32_RESID_BF16R, false>(a, st);
+    case OUT_DSWIGLU:                                // `resid` = the saved gate|up matrix (bf16 [M, 2N]); C = dgu [M, 2N]
+      if (hb || !resid || N % 8 || ldc != 2 * N) return TASU_ERR_ARG;
+      a.act = (bf16*)resid;
+      a.R = nullptr;
+      return launch<OUT_DSWIGLU, false>(a, st);
     default:
       return TASU_ERR_ARG;
   }

@@ -819,8 +819,7 @@ class TasuModel:
                 ops.rmsnorm_bwd(dn_c, d["xout_tail"], llm.norm, d["rstd_lab"], dx_t, dxb_t, False)
                 dact_t = self._buf("dact_tail", (n, I), bf)
                 dgu_t = self._buf("dgu_tail", (n, 2 * I), bf)
-                ops.gemm(dxb_t, w["wd_t"], dact_t, n, I, D)
-                ops.swiglu_bwd(dact_t, d["gu_tail"], dgu_t, n, I)
+                ops.gemm_dswiglu(dxb_t, w["wd_t"], d["gu_tail"], dgu_t, dact_t, n, I, D)
                 ops.gemm(dgu_t, w["wgu_t"], dn_c, n, D, 2 * I)
                 ops.rmsnorm_bwd_rows_resid(dn_c, xs[2 * L - 1], w["ln2"], d["rstd_tail"], d["lab_slot"], dx_t, dx, dxb)
             else:
@@ -832,8 +831,7 @@ class TasuModel:
             w = llm.layers[l]
             x_in, x_mid = xs[2 * l], xs[2 * l + 1]
             if not (l == L - 1 and "xout_tail" in d):          # (the compact tail above has done the last layer's MLP)
-                ops.gemm(dxb, w["wd_t"], dact, M, I, D)
-                ops.swiglu_bwd(dact, d["gu"][l], dgu, M, I)
+                ops.gemm_dswiglu(dxb, w["wd_t"], d["gu"][l], dgu, dact, M, I, D)
                 ops.gemm(dgu, w["wgu_t"], dn, M, D, 2 * I)
                 ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
             ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)

@@ -98,6 +98,12 @@ class HipOps:
                                                        _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()),
                   "tasu_gemm_gate_up_swiglu_ws")
 
+    def gemm_dswiglu(self, dy, wd_t, gu, dgu, dact_ws, M, I, K):
+        """dgu[M,2I] = swiglu_bwd(dy @ wd_t^T, gu): the down projection's input gradient with the SwiGLU backward in the GEMM's
+        epilogue (tasu_gemm_dswiglu); dact_ws: bf16 [M, I] scratch for the shapes the fused epilogue does not serve."""
+        self._chk(self.lib.tasu_gemm_dswiglu(_p(dy), dy.stride(0), _p(wd_t), wd_t.stride(0), _p(gu), _p(dgu), _p(dact_ws), M, I, K,
+                                             _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()), "tasu_gemm_dswiglu")
+
     # ------------------------------------------------------------------ decode-step GEMMs
     def _stream_split(self, K):
         """K ranges the streaming kernels can take this K in (0 = not served)."""

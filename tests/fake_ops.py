@@ -251,6 +251,11 @@ class FakeOps:
         g, u = gu[:, :I].float(), gu[:, I:].float()
         act.copy_(_bf(_bf(F.silu(g)).float() * u))
 
+    def gemm_dswiglu(self, dy, wd_t, gu, dgu, dact_ws, M, I, K):
+        dact = torch.zeros(M, I, dtype=torch.bfloat16) if dact_ws is None else dact_ws
+        self.gemm(dy, wd_t, dact, M, I, K)
+        self.swiglu_bwd(dact, gu, dgu, M, I)
+
     def swiglu_bwd(self, dact, gu, dgu, M, I):
         g, u, d = gu[:, :I].float(), gu[:, I:].float(), dact.float()
         sg = torch.sigmoid(g)

@@ -217,6 +217,32 @@ def test_gemm_policy_takes_streamk_for_d_gate_up(hip):
     assert not torch.equal(c1, c3) and rel_err(c1, c3) < 1e-5
 
 
+@pytest.mark.parametrize("M,I,K", [(4096, 8960, 1536), (2048, 8960, 1536), (300, 200, 128), (1100, 4480, 384), (1000, 1000, 256),
+                                   (64, 96, 256), (4096, 1024, 256)])
+def test_gemm_dswiglu(hip, fake, M, I, K, monkeypatch):
+    """Down projection's input gradient + SwiGLU backward behind one entry point (tasu_gemm_dswiglu), both forms: the two kernels
+    through the dact scratch (default) and, TASU_GEMM_DSWIGLU=1, the SwiGLU backward in the GEMM epilogue (no scratch needed
+    for M > 128) -- the same bits as the GEMM with bf16 output followed by tasu_swiglu_bwd, on the 256 x 256 kernel + column
+    tail (4096 / 2048 x 8960), the loader-wave tiles with edge tiles in both directions, and 64 rows."""
+    dy = randn(M, K, dtype=BF, seed=1).cuda()
+    wd_t = randn(I, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K)).cuda()
+    gu = randn(M, 2 * I, dtype=BF, seed=3).cuda()
+    dact = torch.zeros(M, I, dtype=BF).cuda()
+    want = torch.zeros(M, 2 * I, dtype=BF).cuda()
+    hip.gemm(dy, wd_t, dact, M, I, K)
+    hip.swiglu_bwd(dact, gu, want, M, I)
+    for fused in ("0", "1"):
+        monkeypatch.setenv("TASU_GEMM_DSWIGLU", fused)
+        got = torch.full((M, 2 * I), 7.0, dtype=BF).cuda()
+        scratch = None if fused == "1" and M > 128 else torch.zeros(M, I, dtype=BF).cuda()
+        hip.gemm_dswiglu(dy, wd_t, gu, got, scratch, M, I, K)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), fused
+    cc = torch.zeros(M, 2 * I, dtype=BF)
+    fake.gemm_dswiglu(dy.cpu(), wd_t.cpu(), gu.cpu(), cc, None, M, I, K)
+    assert rel_err(want, cc) < 2e-2
+
+
 def test_gemm_gate_up_swiglu_streamk(hip, fake):
     """gate|up + SwiGLU on 96 tiles behind K = 16384 (2048 rows, I = 1536): with the workspace the policy cuts the tiles along K;
     gate|up and the activation agree with the unfused double, bitwise repeatable."""
