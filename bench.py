@@ -83,6 +83,9 @@ class TimedOps:
     def gemm_splitk(self, *a, **k):
         return self._timed(self._ops.gemm_splitk, a, k)
 
+    def gemm_qkv_rope(self, *a, **k):
+        return self._timed(self._ops.gemm_qkv_rope, a, k)
+
     def gemm_dswiglu(self, dy, wd_t, gu, dgu, dact_ws, M, I, K):
         if os.environ.get("TASU_GEMM_DSWIGLU", "0") == "1":            # the SwiGLU backward in the GEMM's epilogue: one launch
             return self._timed(self._ops.gemm_dswiglu, (dy, wd_t, gu, dgu, dact_ws, M, I, K), {})
@@ -440,7 +443,7 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "tasu_pp::gemm_pp_kernel + tasu_pipe::gemm_pipe_kernel (tasu_gemm_nt_bf16_ws, tasu_gemm_gate_up_swiglu, tasu_gemm_dswiglu, tasu_gemm_nt_bf16_splitk)",
+                         "kernel": "tasu_pp::gemm_pp_kernel + tasu_pipe::gemm_pipe_kernel (tasu_gemm_nt_bf16_ws, tasu_gemm_gate_up_swiglu, tasu_gemm_qkv_rope, tasu_gemm_dswiglu, tasu_gemm_nt_bf16_splitk)",
                          "launches_per_step": n_launch // max(steps, 1),
                          "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
                          "algorithmic_gflop_per_launch": round(gemm_flops_step * steps / max(n_launch, 1) / 1e9, 2),

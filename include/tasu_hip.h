@@ -67,6 +67,15 @@ int tasu_gemm_nt_bf16_kernel(const void* A, int lda, const void* B, int ldb, voi
  * act[M, I] = bf16( bf16(silu(g)) * u ) -- bit-identical to tasu_gemm_nt_bf16 + tasu_swiglu_fwd.  I % 4 == 0.        */
 int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I, int K,
                              void* stream);
+/* Qwen2Attention's q|k|v projection with bias and the rotary embedding of the q and k heads in one launch (training step and
+ * prefill; transformers modeling_qwen2.py:91-135, 150-172):
+ *   qkv[M, (H + 2G) * 128] = bf16(A[M, K] . Wqkv^T + bias), then for every q / k head and d < 64
+ *   out[d] = bf16(x[d] * cos[m][d] - x[d+64] * sin[m][d]),  out[d+64] = bf16(x[d+64] * cos[m][d] + x[d] * sin[m][d])
+ * (cos / sin: fp32 [M, 64] from tasu_rope_table) -- bit-identical to tasu_gemm_nt_bf16 + tasu_rope_fwd, which is what runs with
+ * TASU_GEMM_QKV_ROPE=0.  The kernel's loader hands each MFMA wave both members of its rotation pairs, so the rotation costs
+ * no exchange and qkv keeps its layout.  K % 64 == 0, head_dim 128, 16-byte aligned operands; bias may be NULL. */
+int tasu_gemm_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw, const void* bias, void* qkv, const float* cos_tab,
+                       const float* sin_tab, int M, int H, int G, int K, void* workspace, int64_t workspace_bytes, void* stream);
 /* Qwen2MLP backward, first half, in one call (the training step's d_down + SwiGLU backward):
  *   dact[M, I] = bf16(dy[M, K] . WdT[I, K]^T)   (WdT = down_proj.weight transposed once at load time: [I, K = hidden])
  *   dgu[m, n]     = bf16(d * u * sig(g) * (1 + g * (1 - sig(g)))),  dgu[m, I + n] = bf16(d * g * sig(g)),

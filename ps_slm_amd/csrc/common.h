@@ -71,6 +71,13 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 __device__ __forceinline__ float bf16_round(float x) { return (float)(bf16)x; }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+// rotate-half RoPE of one pair (x1 = x[i], x2 = x[i + 64]): tasu_rope_fwd and the tasu_gemm_qkv_rope epilogue share this text
+__device__ __forceinline__ void rope_pair_f(float x1, float x2, float c, float s, float& y1, float& y2) {
+  // explicit FMAs: -ffp-contract=fast may otherwise fuse either product of a * b - c * d, differently at different call sites
+  const float t1 = x2 * s, t2 = x1 * s;
+  y1 = __builtin_fmaf(x1, c, -t1);
+  y2 = __builtin_fmaf(x2, c, t2);
+}
 // SwiGLU backward of one element (tasu_swiglu_bwd and the tasu_gemm_dswiglu epilogue share this text: the same bits)
 __device__ __forceinline__ void swiglu_bwd_f(float gf, float uf, float df, float& dg, float& du) {
   const float sg = sigmoid_f(gf);

@@ -12,6 +12,7 @@
 namespace tasu_gemm {
 
 constexpr int OUT_GU_SWIGLU = 3;    // internal epilogue of tasu_gemm_gate_up_swiglu (after the three TASU_GEMM_OUT_* modes)
+constexpr int OUT_QKV_ROPE = 5;     // internal epilogue of tasu_gemm_qkv_rope: bias + rotary embedding of the q and k heads
 constexpr int OUT_DSWIGLU = 4;      // internal epilogue of tasu_gemm_dswiglu: the SwiGLU backward of the down projection's dgrad
 
 struct Args {
@@ -138,6 +139,65 @@ __device__ __forceinline__ void store_gu_swiglu(const Args& p, f32x4 (&acc)[MI][
       *(bf16x4*)(gu + (size_t)m * (2 * (size_t)p.N) + n) = g4;
       *(bf16x4*)(gu + (size_t)m * (2 * (size_t)p.N) + p.N + n) = u4;
       *(bf16x4*)(p.act + (size_t)m * p.N + n) = a4;
+    }
+  }
+}
+
+// OUT_QKV_ROPE epilogue (Qwen2Attention.forward: q/k/v projections with bias, then apply_rotary_pos_emb on q and k;
+// transformers modeling_qwen2.py:91-135, 150-172).  The tile is one 128-wide head; the loader hands wave column wc the weight
+// rows of head dims wc*32 .. +31 (fragments 0, 1) AND 64 + wc*32 .. +31 (fragments 2, 3), so that both members of every
+// rotation pair (d, d + 64) sit in the same lane and register index of fragments j and j + 2:
+//   q = bf16(acc + bias);  out[d] = bf16(q[d] * cos[m][d] - q[d+64] * sin[m][d]),  out[d+64] = bf16(q[d+64] * cos[m][d] + q[d] * sin[m][d])
+// -- bit-identical to tasu_gemm_nt_bf16 (bf16 output, bias) followed by tasu_rope_fwd.  Heads at columns >= p.split_stride
+// (the v heads) are stored unrotated.  p.R = cos [M, 64], p.act = sin [M, 64] (fp32), p.bias may be NULL.
+template <int MI, int NI, int BM>
+__device__ __forceinline__ void store_qkv_rope(const Args& p, f32x4 (&acc)[MI][NI], int row0, int col0, int wrow, int wc, int lane) {
+  if constexpr (NI == 4) {
+    int l15 = lane & 15, l4 = (lane >> 4) * 4;
+    asm volatile("" : "+v"(l15), "+v"(l4));
+    const float* ct = p.R;
+    const float* st = (const float*)p.act;
+    bf16* out = (bf16*)p.C;
+    const bool rotate = col0 < (int)p.split_stride;             // wave-uniform
+    bf16x4 blo[2], bhi[2];                                       // (kept packed: 8 registers across the row loop, not 16)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int d = col0 + wc * 32 + jj * 16 + l4;
+      blo[jj] = p.bias ? *(const bf16x4*)(p.bias + d) : bf16x4{0, 0, 0, 0};
+      bhi[jj] = p.bias ? *(const bf16x4*)(p.bias + d + 64) : bf16x4{0, 0, 0, 0};
+    }
+    f32x4 cq[2], sq[2];                                          // the next (row block, jj) step's factors are in flight
+    auto fetch = [&](int step) {
+      const int i = step >> 1, jj = step & 1;
+      const int m = min(row0 + wrow + i * 16 + l15, p.M - 1);
+      cq[step & 1] = *(const f32x4*)(ct + (size_t)m * 64 + wc * 32 + jj * 16 + l4);
+      sq[step & 1] = *(const f32x4*)(st + (size_t)m * 64 + wc * 32 + jj * 16 + l4);
+    };
+    if (rotate) fetch(0);
+#pragma unroll
+    for (int step = 0; step < 2 * MI; ++step) {
+      asm volatile("" ::: "memory");
+      if (rotate && step + 1 < 2 * MI) fetch(step + 1);
+      const int i = step >> 1, jj = step & 1;
+      const int m = row0 + wrow + i * 16 + l15;
+      f32x4 lo = acc[i][jj], hi = acc[i][jj + 2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lo[r] += (float)blo[jj][r], hi[r] += (float)bhi[jj][r];
+      bf16x4 lob = __builtin_convertvector(lo, bf16x4), hib = __builtin_convertvector(hi, bf16x4);
+      if (rotate) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float y1, y2;
+          rope_pair_f((float)lob[r], (float)hib[r], cq[step & 1][r], sq[step & 1][r], y1, y2);
+          lob[r] = (bf16)y1;
+          hib[r] = (bf16)y2;
+        }
+      }
+      if (m < p.M) {
+        bf16* c = out + (size_t)m * p.ldc + col0 + wc * 32 + jj * 16 + l4;
+        *(bf16x4*)c = lob;
+        *(bf16x4*)(c + 64) = hib;
+      }
     }
   }
 }

@@ -85,6 +85,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
           const int half = r >> 6, rr = r & 63;                       // wave column, row inside it
           const int ocol = min(p.n0 + tn * 64 + half * 32 + (rr & 31), p.N - 1);   // output (act) column
           vob[i] = (ocol + (rr >= 32 ? p.N : 0)) * p.ldb * 2 + c * 16 + (3 - (i & 3)) * 1024;
+        } else if (OUT_MODE == OUT_QKV_ROPE) {
+          // one head per tile; wave column `half` gets head dims half*32 .. +31 and 64 + half*32 .. +31 (store_qkv_rope)
+          const int half = r >> 6, rr = r & 63;
+          const int d = half * 32 + (rr & 31) + (rr >= 32 ? 64 : 0);
+          vob[i] = d * p.ldb * 2 + c * 16 + (3 - (i & 3)) * 1024;
         } else {
           vob[i] = (min(col0 + r, p.N - 1) - col0) * p.ldb * 2 + c * 16 + (3 - (i & 3)) * 1024;
         }
@@ -231,6 +236,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
     for (int kt = 0; kt + 1 < nk; ++kt) cur = kstep(T{}, cur);
     cur = kstep(F{}, cur);                         // no read-ahead into the next tile: the fragment registers are free
     if constexpr (OUT_MODE == OUT_GU_SWIGLU) store_gu(tm * BM, tn);
+    else if constexpr (OUT_MODE == OUT_QKV_ROPE) store_qkv_rope<MI, NI, BM>(p, acc, tm * BM, p.n0 + tn * BN, wr * WM, wc, lane);
     else store_c(tm * BM, p.n0 + tn * BN);      // for the epilogue, whose stores then drain under the next tile
     zero_acc();
     if (s + (int)gridDim.x < ntiles) read_frags(fa0, fb0, cur, 0);   // landed before the barrier of the step just done
@@ -398,6 +404,47 @@ extern "C" int tasu_gemm_gate_up_swiglu_ws(const void* A, int lda, const void* W
 extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I,
                                         int K, void* stream) {
   return tasu_gemm_gate_up_swiglu_ws(A, lda, Wgu, ldw, gu, act, M, I, K, nullptr, 0, stream);
+}
+
+// q|k|v projection + bias + rotary embedding of the q and k heads in one launch (include/tasu_hip.h): 256 x 128 tiles, one
+// head per tile column.  TASU_GEMM_QKV_ROPE=0 (read per call) selects the two-kernel form.
+extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
+                                    const float* resid, int M, int N, int K, int out_mode, void* workspace,
+                                    int64_t workspace_bytes, void* stream);
+extern "C" int tasu_rope_fwd(void* qkv, const float* cos_tab, const float* sin_tab, void* qt, void* kt, void* vt, int B, int S, int H,
+                             int G, void* stream);
+extern "C" int tasu_gemm_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw, const void* bias, void* qkv, const float* cos_tab,
+                                  const float* sin_tab, int M, int H, int G, int K, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+  using namespace tasu_pipe;
+  if (!A || !Wqkv || !qkv || !cos_tab || !sin_tab || M <= 0 || H <= 0 || G <= 0 || K <= 0 || K % BK || lda % 8 || ldw % 8)
+    return TASU_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)Wqkv & 15) || ((uintptr_t)qkv & 15) || ((uintptr_t)cos_tab & 15) || ((uintptr_t)sin_tab & 15))
+    return TASU_ERR_ARG;
+  const int N = (H + 2 * G) * 128;
+  const char* const e = getenv("TASU_GEMM_QKV_ROPE");
+  if (e && e[0] == '0') {
+    const int rc = tasu_gemm_nt_bf16_ws(A, lda, Wqkv, ldw, qkv, N, bias, nullptr, M, N, K, TASU_GEMM_OUT_BF16, workspace, workspace_bytes,
+                                        stream);
+    return rc ? rc : tasu_rope_fwd(qkv, cos_tab, sin_tab, nullptr, nullptr, nullptr, 1, M, H, G, stream);
+  }
+  Args a;
+  a.A = (const bf16*)A;
+  a.B = (const bf16*)Wqkv;
+  a.C = qkv;
+  a.R = cos_tab;
+  a.bias = (const bf16*)bias;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.lda = lda;
+  a.ldb = ldw;
+  a.ldc = N;
+  a.tiles_m = a.tiles_n = 0;
+  a.act = (bf16*)sin_tab;
+  a.ksplit = 1;
+  a.split_stride = (long long)(H + G) * 128;       // first column that is not rotated (the v heads)
+  return launch<256, 128, OUT_QKV_ROPE, false>(a, (hipStream_t)stream);
 }
 
 // ---- split-K form for grids that would leave most CUs idle behind a very long K (the lm_head dgrad over the labelled rows

@@ -42,12 +42,13 @@ __global__ __launch_bounds__(256) void rope_fwd_kernel(bf16* __restrict__ qkv, c
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float c0 = cr[j], s0 = sr[j], c1 = cr[8 + j], s1 = sr[8 + j];
-        const float x1 = (float)a0[j], x2 = (float)b0[j];
-        const float y1 = (float)a1[j], y2 = (float)b1[j];
-        a0[j] = (bf16)(x1 * c0 - x2 * s0);
-        b0[j] = (bf16)(x2 * c0 + x1 * s0);
-        a1[j] = (bf16)(y1 * c1 - y2 * s1);
-        b1[j] = (bf16)(y2 * c1 + y1 * s1);
+        float r1, r2, r3, r4;
+        rope_pair_f((float)a0[j], (float)b0[j], c0, s0, r1, r2);
+        rope_pair_f((float)a1[j], (float)b1[j], c1, s1, r3, r4);
+        a0[j] = (bf16)r1;
+        b0[j] = (bf16)r2;
+        a1[j] = (bf16)r3;
+        b1[j] = (bf16)r4;
       }
       *(bf16x8*)(row + part * 16) = a0;
       *(bf16x8*)(row + part * 16 + 8) = a1;

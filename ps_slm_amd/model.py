@@ -693,8 +693,7 @@ class TasuModel:
         for l, w in enumerate(llm.layers):
             x_in, x_mid, x_out = xs[2 * l], xs[2 * l + 1], xs[2 * l + 2]
             ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], geo.rms_eps)
-            ops.gemm(xn, w["wqkv"], qkv[l], M, LDQ, D, bias=w["bqkv"])
-            ops.rope_fwd(qkv[l], cos, sin, None, None, None, B, S, H, G)          # in place; no transposed copies (attention.hip)
+            ops.gemm_qkv_rope(xn, w["wqkv"], w["bqkv"], qkv[l], cos, sin, M, H, G, D)      # bias + RoPE in the GEMM's epilogue
             ops.attn_fwd(qkv[l], None, d["key_mask"], ao[l], lse[l], B, S, H, G, scale, True)
             ops.gemm(ao[l], w["wo"], x_mid, M, D, H * HD, resid=x_in, mode=GEMM_RESID)
             if tail and l == L - 1:

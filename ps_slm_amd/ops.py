@@ -98,6 +98,12 @@ class HipOps:
                                                        _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()),
                   "tasu_gemm_gate_up_swiglu_ws")
 
+    def gemm_qkv_rope(self, a, wqkv, bias, qkv, cos, sin, M, H, G, K):
+        """qkv[M, (H+2G)*128] = rope(a @ wqkv^T + bias) in one launch (tasu_gemm_qkv_rope): the training step's / prefill's
+        q|k|v projection with the rotary embedding of the q and k heads in the GEMM's epilogue."""
+        self._chk(self.lib.tasu_gemm_qkv_rope(_p(a), a.stride(0), _p(wqkv), wqkv.stride(0), _p(bias), _p(qkv), _p(cos), _p(sin), M, H, G,
+                                              K, _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()), "tasu_gemm_qkv_rope")
+
     def gemm_dswiglu(self, dy, wd_t, gu, dgu, dact_ws, M, I, K):
         """dgu[M,2I] = swiglu_bwd(dy @ wd_t^T, gu): the down projection's input gradient with the SwiGLU backward in the GEMM's
         epilogue (tasu_gemm_dswiglu); dact_ws: bf16 [M, I] scratch for the shapes the fused epilogue does not serve."""

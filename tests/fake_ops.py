@@ -251,6 +251,10 @@ class FakeOps:
         g, u = gu[:, :I].float(), gu[:, I:].float()
         act.copy_(_bf(_bf(F.silu(g)).float() * u))
 
+    def gemm_qkv_rope(self, a, wqkv, bias, qkv, cos, sin, M, H, G, K):
+        self.gemm(a, wqkv, qkv, M, (H + 2 * G) * 128, K, bias=bias)
+        self.rope_fwd(qkv, cos, sin, None, None, None, 1, M, H, G)
+
     def gemm_dswiglu(self, dy, wd_t, gu, dgu, dact_ws, M, I, K):
         dact = torch.zeros(M, I, dtype=torch.bfloat16) if dact_ws is None else dact_ws
         self.gemm(dy, wd_t, dact, M, I, K)

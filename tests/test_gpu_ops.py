@@ -243,6 +243,34 @@ def test_gemm_dswiglu(hip, fake, M, I, K, monkeypatch):
     assert rel_err(want, cc) < 2e-2
 
 
+@pytest.mark.parametrize("M,H,G,K,bias", [(4096, 12, 2, 1536, True), (1000, 4, 2, 256, True), (300, 2, 1, 128, False), (4096, 28, 4, 3584, True),
+                                          (64, 12, 2, 1536, True)])
+def test_gemm_qkv_rope(hip, fake, M, H, G, K, bias, monkeypatch):
+    """q|k|v projection + bias + RoPE of the q and k heads in the GEMM's epilogue (tasu_gemm_qkv_rope): the same bits as the GEMM
+    with bf16 output followed by tasu_rope_fwd (which TASU_GEMM_QKV_ROPE=0 runs behind the same entry point) -- 1.5B and 7B head
+    counts, a last row tile of 232 / 44 / 64 rows, no bias; the v heads come out unrotated."""
+    N = (H + 2 * G) * HD
+    a = randn(M, K, dtype=BF, seed=1).cuda()
+    w = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K)).cuda()
+    bv = randn(N, dtype=BF, seed=3).cuda() if bias else None
+    ang = randn(M, 64, seed=4)
+    cos, sin = torch.cos(ang).cuda(), torch.sin(ang).cuda()
+    want = torch.zeros(M, N, dtype=BF).cuda()
+    hip.gemm(a, w, want, M, N, K, bias=bv)
+    plain = want.clone()
+    hip.rope_fwd(want, cos, sin, None, None, None, 1, M, H, G)
+    for fused in ("1", "0"):
+        monkeypatch.setenv("TASU_GEMM_QKV_ROPE", fused)
+        got = torch.full((M, N), 7.0, dtype=BF).cuda()
+        hip.gemm_qkv_rope(a, w, bv, got, cos, sin, M, H, G, K)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), fused
+    assert torch.equal(want[:, (H + G) * HD:], plain[:, (H + G) * HD:]) and not torch.equal(want[:, :HD], plain[:, :HD])
+    cc = torch.zeros(M, N, dtype=BF)
+    fake.gemm_qkv_rope(a.cpu(), w.cpu(), None if bv is None else bv.cpu(), cc, cos.cpu(), sin.cpu(), M, H, G, K)
+    assert rel_err(want, cc) < 2e-2
+
+
 def test_gemm_gate_up_swiglu_streamk(hip, fake):
     """gate|up + SwiGLU on 96 tiles behind K = 16384 (2048 rows, I = 1536): with the workspace the policy cuts the tiles along K;
     gate|up and the activation agree with the unfused double, bitwise repeatable."""
