@@ -446,10 +446,13 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
           const int cus = tasu_pp::cu_count();
           const bool sk = tasu_gemm::sk_plan(t256, K / 128, cus, ws_bytes >= TASU_GEMM_WS_COUNTERS * sizeof(int) + (size_t)cus * 262144,
                                              tasu_pp::sk_max_rem()) > 0;
-          const double c256 = sk ? (double)t256 / cus * 256.0 * 256 / pp_eff + 1.0e8 / K : cost(t256, 256.0 * 256, pp_eff);
+          const double c256_whole = cost(t256, 256.0 * 256, pp_eff);
+          const double c256_sk = sk ? (double)t256 / cus * 256.0 * 256 / pp_eff + 1.0e8 / K : 1e30;
+          const double c256 = c256_sk < c256_whole ? c256_sk : c256_whole;
           const double best = use_pipe_bn == 128 ? c128 : (use_pipe_bn == 192 ? c192 : c96);
           if (c256 < best) {
-            if (sk) return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, 0, workspace, ws_bytes, -2.0);
+            if (c256_sk < c256_whole)
+              return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, 0, workspace, ws_bytes, -2.0);
             // a mostly empty last round of big tiles (d_down: 560 tiles = 2.19 rounds): whole rounds on the big tiles, the
             // remaining columns on the small tiles in a second launch (TASU_GEMM_NSPLIT=0 disables)
             static const bool split_on = [] {

@@ -47,7 +47,9 @@ struct Args {
 // cut along K.  0 = none: whole rounds, no workspace, ranges shorter than 8 pairs, or a last round that is nearly full.
 inline int sk_plan(long T, int P, int G, bool have_ws, double max_rem) {
   if (!have_ws || max_rem < 0 || T <= 0 || T % G == 0) return 0;
-  if (T < G) return T * P / G >= 8 ? (int)T : 0;
+  // (more than 3/4 of a round: whole tiles on T CUs run faster per CU -- 1.13-1.2 us per K-tile against 1.45 with all 256
+  // streaming, the chip-wide ceiling -- than the cut saves: 4096 x 3584 x 18944, 224 tiles: 394 us whole, 435 us cut)
+  if (T < G) return T * P / G >= 8 && (max_rem >= 1.0 || 4 * T <= 3 * (long)G) ? (int)T : 0;
   const long rem = T % G;
   if (max_rem <= 0 || (double)rem > max_rem * G || P < 8) return 0;
   return (int)(rem + G);                       // the remainder and one whole round: 1 to 2 tiles per workgroup

@@ -383,9 +383,12 @@ extern "C" int tasu_gemm_gate_up_swiglu_ws(const void* A, int lda, const void* W
     // stream-K (workspace given): the big tiles fill fractional rounds, for the price of the partial tiles' round trip (~35 us)
     const bool sk = tasu_gemm::sk_plan(tm * tn, K / 128, (int)cus, ws_bytes >= TASU_GEMM_WS_COUNTERS * sizeof(int) + (size_t)cus * 262144,
                                        tasu_pp::sk_max_rem()) > 0;
-    const double c256 = sk ? ((double)(tm * tn) / cus) / 1.26 + 1.0e8 / K / 52012.0 : rounds(tm * tn) / 1.26;
+    const double c256_whole = rounds(tm * tn) / 1.26;
+    const double c256_sk = sk ? ((double)(tm * tn) / cus) / 1.26 + 1.0e8 / K / 52012.0 : 1e30;
+    const double c256 = c256_sk < c256_whole ? c256_sk : c256_whole;
     if (pp_on && c256 < c128) {
-      if (sk) return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, 0, ws, ws_bytes);
+      if (c256_sk < c256_whole)
+        return tasu_gemm_pp_gu_dispatch(A, lda, Wgu, ldw, gu, act, M, I, K, (hipStream_t)stream, 0, 0, ws, ws_bytes);
       const long full = (tm * tn) / cus;                          // whole rounds of big tiles
       const long tn_main = full * cus / tm;                       // column tiles they cover
       if (split_on && full >= 1 && tn_main < tn && tn_main > 0) {
