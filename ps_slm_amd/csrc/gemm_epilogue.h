@@ -49,7 +49,10 @@ inline int sk_plan(long T, int P, int G, bool have_ws, double max_rem) {
   if (!have_ws || max_rem < 0 || T <= 0 || T % G == 0) return 0;
   // (more than 3/4 of a round: whole tiles on T CUs run faster per CU -- 1.13-1.2 us per K-tile against 1.45 with all 256
   // streaming, the chip-wide ceiling -- than the cut saves: 4096 x 3584 x 18944, 224 tiles: 394 us whole, 435 us cut)
-  if (T < G) return T * P / G >= 8 && (max_rem >= 1.0 || 4 * T <= 3 * (long)G) ? (int)T : 0;
+  // ... and only when the ranges' K offsets fall into at most two classes per XCD (16 T / G whole: workgroups w, w + 8, ... --
+  // one XCD -- then stream the SAME K position of tiles that share operand panels, through that XCD's L2): 96 tiles 181 us and
+  // 48 tiles 110 us at K = 17920, but 72 tiles 189 us and 84 tiles 222 us (more work in less time with 96)
+  if (T < G) return T * P / G >= 8 && (max_rem >= 1.0 || (4 * T <= 3 * (long)G && (16 * T) % G == 0)) ? (int)T : 0;
   const long rem = T % G;
   if (max_rem <= 0 || (double)rem > max_rem * G || P < 8) return 0;
   return (int)(rem + G);                       // the remainder and one whole round: 1 to 2 tiles per workgroup
