@@ -186,6 +186,12 @@ int tasu_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, float* rstd, 
  * gradient the next dgrad GEMM consumes.                                                                */
 int tasu_rmsnorm_bwd(const void* dy_bf16, const float* x, const float* w, const float* rstd, float* dx,
                      void* dx_bf16, int accumulate, int M, int D, void* stream);
+/* Residual add + RMSNorm in one pass (Qwen2DecoderLayer: hidden = residual + sublayer(...), then the next norm;
+ * modeling_qwen2.py:247-252, 289-312): x_out[M, D] (fp32) = x_prev + float(delta) with delta the sublayer's bf16 output (o or
+ * down projection, tasu_gemm_nt_bf16 with bf16 output), y (bf16) = rmsnorm(x_out) * w, rstd optional.  The same bits as the
+ * projection with TASU_GEMM_OUT_F32_RESID_BF16R followed by tasu_rmsnorm_fwd.  x_out may alias x_prev.  D % 4 == 0. */
+int tasu_rmsnorm_fwd_add(const void* delta, const float* x_prev, const float* w, float* x_out, void* y, float* rstd, int M, int D,
+                         float eps, void* stream);
 /* Row-indexed forms for the training step's lm_head, which projects only the positions that carry a label
  * (transformers loss_utils.py:49-71 ignores the others; ps_slm_amd/model.py "labelled rows"):
  * fwd: y[i,:] = rmsnorm(x[src_rows[i],:]) for i < n_rows, a zero row (rstd 0) where src_rows[i] < 0;

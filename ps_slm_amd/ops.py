@@ -195,6 +195,13 @@ class HipOps:
         M, D = x.shape
         self._chk(self.lib.tasu_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), M, D, eps, self._stream()), "tasu_rmsnorm_fwd")
 
+    def rmsnorm_fwd_add(self, delta, x_prev, w, x_out, y, rstd, eps):
+        """x_out = x_prev + delta (delta: a projection's bf16 output), y = rmsnorm(x_out): the residual add of a decoder layer
+        folded into the next norm (tasu_rmsnorm_fwd_add)."""
+        M, D = x_prev.shape
+        self._chk(self.lib.tasu_rmsnorm_fwd_add(_p(delta), _p(x_prev), _p(w), _p(x_out), _p(y), _p(rstd), M, D, eps, self._stream()),
+                  "tasu_rmsnorm_fwd_add")
+
     def rmsnorm_bwd(self, dy, x, w, rstd, dx, dx_bf16, accumulate):
         M, D = x.shape
         self._chk(self.lib.tasu_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dx), _p(dx_bf16), int(accumulate), M, D,

@@ -271,6 +271,31 @@ def test_gemm_qkv_rope(hip, fake, M, H, G, K, bias, monkeypatch):
     assert rel_err(want, cc) < 2e-2
 
 
+@pytest.mark.parametrize("M,D,K", [(4096, 1536, 1536), (300, 256, 128), (1000, 3584, 256), (77, 192, 64)])
+def test_rmsnorm_fwd_add_equals_residual_epilogue(hip, fake, M, D, K):
+    """Residual add folded into the next RMSNorm (tasu_rmsnorm_fwd_add on the projection's bf16 output) against the projection
+    in residual mode followed by tasu_rmsnorm_fwd: the same fp32 stream, normed rows and rstd, bit for bit; the register
+    forms (D = 1536 / 3584 / 256) and the generic one; x_out aliasing x_prev."""
+    a = randn(M, K, dtype=BF, seed=1).cuda()
+    w = randn(D, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K)).cuda()
+    x_prev = randn(M, D, seed=3).cuda()
+    g = (randn(D, seed=4).abs() + 0.5).cuda()
+    x1, y1, r1 = torch.zeros(M, D).cuda(), torch.zeros(M, D, dtype=BF).cuda(), torch.zeros(M).cuda()
+    hip.gemm(a, w, x1, M, D, K, resid=x_prev, mode=2)
+    hip.rmsnorm_fwd(x1, g, y1, r1, 1e-6)
+    delta = torch.zeros(M, D, dtype=BF).cuda()
+    x2, y2, r2 = torch.zeros(M, D).cuda(), torch.zeros(M, D, dtype=BF).cuda(), torch.zeros(M).cuda()
+    hip.gemm(a, w, delta, M, D, K)
+    hip.rmsnorm_fwd_add(delta, x_prev, g, x2, y2, r2, 1e-6)
+    x3 = x_prev.clone()
+    hip.rmsnorm_fwd_add(delta, x3, g, x3, y2.clone(), None, 1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x2) and torch.equal(y1, y2) and torch.equal(r1, r2) and torch.equal(x3, x1)
+    xc, yc, rc = torch.zeros(M, D), torch.zeros(M, D, dtype=BF), torch.zeros(M)
+    fake.rmsnorm_fwd_add(delta.cpu(), x_prev.cpu(), g.cpu(), xc, yc, rc, 1e-6)
+    assert rel_err(x2, xc) < 1e-6 and rel_err(y2, yc) < 1e-2 and rel_err(r2, rc) < 1e-5
+
+
 def test_gemm_gate_up_swiglu_streamk(hip, fake):
     """gate|up + SwiGLU on 96 tiles behind K = 16384 (2048 rows, I = 1536): with the workspace the policy cuts the tiles along K;
     gate|up and the activation agree with the unfused double, bitwise repeatable."""

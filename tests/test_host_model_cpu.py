@@ -512,6 +512,20 @@ def test_tail_layer_on_labelled_rows_changes_nothing(mid, ragged):
     assert float((a.proj.g - b.proj.g).norm() / b.proj.g.norm()) < 5e-3
 
 
+def test_residual_adds_in_the_norm_kernels_change_nothing(mid):
+    """TasuModel.resid_in_norm on the CPU double: o / down write bf16, the next norm adds them to the fp32 stream -- the same
+    rounding points as the projections' residual mode, hence the same loss and gradients exactly."""
+    geo, sd = mid
+    batch = synthetic_text_batch(geo, 3, seed=12, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12,
+                                 noise=True, drop_prob=0.1, ragged=True)
+    a, b = build(geo, sd), build(geo, sd)
+    a.keep_logits = b.keep_logits = False
+    a.resid_in_norm, b.resid_in_norm = True, False
+    sa, sb = run_text(a, batch), run_text(b, batch)
+    assert torch.equal(sa.dev["loss_out"], sb.dev["loss_out"])
+    assert torch.equal(a.proj.g, b.proj.g)
+
+
 @pytest.mark.parametrize("quantise", [False, True])
 @pytest.mark.parametrize("lpw,min_len", [(1.0, 1), (2.0, 1), (0.5, 4), (1.0, 6)])
 @pytest.mark.parametrize("nb", [1, 2, 3, 4])
