@@ -403,18 +403,29 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
   //  * the pipelined kernel with loader waves (gemm_pipe.hip; tiles 256 x 128, 128 x 192, 256 x 96) is the fastest on
   //    every decoder, lm_head and projector shape (qkv 700 -> 822, gate_up 780 -> 837, d_down 690 -> 772, d_lm_head
   //    975 -> 1149 TFLOP/s ...); the tile is the one that fills whole rounds of 256 one-per-CU blocks at the least cost;
-  //  * grids that cover less than half of the CUs but are deep (K >= 8192) split K over 256 x 192 tiles instead;
-  //  * problems of at most 128 rows keep the 128-row tiles of this file (a 256-row tile would be half empty).
+  //  * grids that cover less than half of the CUs behind K >= 16384 and too few K-tile pairs per CU for the stream-K schedule
+  //    (below) split K over the 256 x 192 tiles of this file instead (256 / 512 x 1536 x 17920: 130 / 150 us against 190 on
+  //    the loader-wave tiles; at K = 8960 the loader-wave tiles win: 1024 rows 94 against 162 us);
+  //  * problems of at most 64 rows keep the 128-row tiles of this file (128 x 1536 x 8960: 73 us on 256 x 96 tiles, 122 here).
+  static const bool pp_on = [] {
+    const char* e = getenv("TASU_GEMM_PP");
+    return !(e && e[0] == '0');
+  }();
   int use_pipe_bn = 0;
   if (kernel_choice() == 2) {
     use_pipe_bn = (forced_bn == 96 || forced_bn == 128 || forced_bn == 192) ? forced_bn : -1;
-  } else if (kernel_choice() == 0 && forced_bn == 0 && M > 128) {
+  } else if (kernel_choice() == 0 && forced_bn == 0 && M > 64) {
     use_pipe_bn = -1;
   }
   if (use_pipe_bn != 0) {
     const long tm = (M + 255) / 256;
     const long t128 = tm * ((N + 127) / 128), t96 = tm * ((N + 95) / 96);
-    if (!dsw && kernel_choice() == 0 && t96 < 128 && K >= 8192 && plan_ksplit(M, N, K, ws_bytes) > 1) {
+    const long t256 = tm * ((N + 255) / 256);
+    const int cus = tasu_pp::cu_count();
+    const bool sk = pp_on && kernel_choice() == 0 && K >= 256 && K % 128 == 0 &&
+                    tasu_gemm::sk_plan(t256, K / 128, cus, ws_bytes >= TASU_GEMM_WS_COUNTERS * sizeof(int) + (size_t)cus * 262144,
+                                       tasu_pp::sk_max_rem()) > 0;
+    if (!dsw && !sk && kernel_choice() == 0 && M > 128 && t96 < 128 && K >= 16384 && plan_ksplit(M, N, K, ws_bytes) > 1) {
       use_pipe_bn = 0;                              // falls through to the split-K tile below
     } else {
       if (use_pipe_bn < 0) {
@@ -429,10 +440,6 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
         // whole rounds at K = 1536 (4096 x 16384: 1232 vs 995 TFLOP/s) its per-FLOP efficiency is 1.24 x that tile's, so it wins
         // wherever its coarser rounds do not eat that up (gate|up, lm_head; d_down's 3 rounds against 5: a tie on paper, +0.5 %
         // on the step measured with TASU_GEMM_PP_EFF = 1.26 against 1.19 on one box; not the one-round N = 1536 grids)
-        static const bool pp_on = [] {
-          const char* e = getenv("TASU_GEMM_PP");
-          return !(e && e[0] == '0');
-        }();
         if (pp_on && kernel_choice() == 0 && K >= 256 && K % 128 == 0) {
           static const double pp_eff = [] {            // TASU_GEMM_PP_EFF: tuning runs
             const char* e = getenv("TASU_GEMM_PP_EFF");
@@ -442,10 +449,6 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
           // same number of K-tile pairs -- for the price of the partial tiles' round trip (~35 us per launch whatever K is:
           // 1e8 / K in the units of this model).  That serves d_gate_up (96 tiles on 256 CUs, K = 17920: 203 -> 181 us); at
           // K = 8960 (down) the 128 x 192 one-round grid still wins (100 vs 108 us).
-          const long t256 = tm * ((N + 255) / 256);
-          const int cus = tasu_pp::cu_count();
-          const bool sk = tasu_gemm::sk_plan(t256, K / 128, cus, ws_bytes >= TASU_GEMM_WS_COUNTERS * sizeof(int) + (size_t)cus * 262144,
-                                             tasu_pp::sk_max_rem()) > 0;
           const double c256_whole = cost(t256, 256.0 * 256, pp_eff);
           const double c256_sk = sk ? (double)t256 / cus * 256.0 * 256 / pp_eff + 1.0e8 / K : 1e30;
           const double c256 = c256_sk < c256_whole ? c256_sk : c256_whole;

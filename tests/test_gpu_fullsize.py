@@ -182,12 +182,14 @@ def test_full_size_step_properties(size):
     # ---- batch permutation: same loss and gradient up to summation order
     perm = [2, 0, 3, 1]
     stp = step(m, take(batch, perm))
-    # 1.5B: every row's sums run in the same order wherever the row sits.  7B: the down projection (224 tiles of 256 x 256 behind
-    # K = 18944) takes the stream-K schedule, which cuts a tile's K range where the tile's index puts it -- a row's fp32 sums are
-    # then associated differently in another batch position, and bf16 roundings flip through the 28 layers (loss ~ 1e-4 relative)
+    # Whole-tile GEMMs sum every row in the same order wherever the row sits (1.5B forward: the loss moves by the summation order
+    # of the loss only).  The stream-K schedule (d_gate_up of both sizes at this batch's ~1000 rows; at 7B also down) cuts a tile's
+    # K range where the tile's index puts it: a row's fp32 sums are then associated differently in another batch position, and
+    # bf16 roundings flip through the 28 layers -- the same size of effect as the padding-invariance check below (7B loss ~ 1e-4
+    # relative, gradients ~ 1 %)
     assert abs(float(stp.dev["loss_out"][0]) - float(loss[0])) < (2e-5 if size == "1.5b" else 5e-3)
     gp = m.proj.g
-    assert float((gp - g).norm() / g.norm()) < (2e-3 if size == "1.5b" else 5e-2)
+    assert float((gp - g).norm() / g.norm()) < 5e-2
 
     # ---- padding invariance: the ragged batch against every utterance alone (no padding at all)
     tot_loss, tot_cnt, gsum = 0.0, 0, torch.zeros_like(g)
