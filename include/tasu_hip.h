@@ -101,6 +101,11 @@ int tasu_gemm_gate_up_swiglu_ws(const void* A, int lda, const void* Wgu, int ldw
 int tasu_gemm_nt_bf16_streamk(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                               const float* resid, int M, int N, int K, int out_mode, void* workspace, int64_t workspace_bytes,
                               void* stream);
+/* Host-side restatement of that schedule through the kernel's own code (no GPU needed; tests): the work-item lists of `grid`
+ * workgroups for `tiles` output tiles of `pairs` K-tile pairs (K = 128 * pairs).  items[w][i] = {tile, first K-tile, K-tiles,
+ * role: 0 whole tile, 1 partial-tile producer, 2 tile owner}, max_items per workgroup; counts[w] = items of workgroup w.
+ * Returns the number of (trailing) tiles cut along K, or -1 on bad arguments. */
+int tasu_streamk_schedule(int tiles, int pairs, int grid, int32_t* items, int32_t* counts, int max_items);
 /* Split-K form of the NT GEMM for outputs too small to fill the chip behind a very long K (the lm_head dgrad over
  * the labelled rows: [n_rows, 1536] outputs, K = padded vocabulary): partials[s] [M, ldc] fp32 = A[:, Ks] . B[:, Ks]^T
  * for the ksplit contiguous K ranges (K % (64 * ksplit) == 0), written as ksplit consecutive [M, ldc] matrices;

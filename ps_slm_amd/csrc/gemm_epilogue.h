@@ -43,6 +43,48 @@ struct Args {
   double sk_rem = -2.0;  // host side only: sk_plan's max_rem for this launch (-2 = the library default / TASU_GEMM_SK*)
 };
 
+// The work-item list of a workgroup of the 256 x 256 kernel (gemm_pp.hip), as one piece of host / device code so that the
+// schedule can be checked on the CPU (tasu_streamk_schedule, tests/test_cabi.py).  Whole tiles (and K-range slabs) are dealt
+// round-robin: item s = wg + i * G.  The last sk_tiles tiles are cut along K instead (stream-K): sk_tiles * P K-tile pairs, one
+// contiguous range [ub(w), ub(w+1)) per workgroup, visited BEFORE its whole tiles, so that a partial tile is in memory long
+// before the workgroup that completes the tile asks for it.  Range ends within 4 pairs of a tile boundary snap to it.
+struct PpSchedule {
+  enum { FULL = 0, PART = 1, HEAD = 2 };
+  struct Item {
+    int tile, ks, k0t, nkt, kind;                    // output tile, slab, first K-tile, K-tiles (even), role
+  };
+  int G, wg, P, nk, base_tiles, dp_tiles, sk_tiles, u0, u1, nsk;
+  unsigned sk_units;                                 // (the host keeps sk_units * G below 2^31)
+  __host__ __device__ int ub(int w) const {
+    unsigned b = (unsigned)w * sk_units / (unsigned)G;
+    const unsigned r = b % (unsigned)P;
+    if (r && r < 4) b -= r;
+    else if (r && P - r < 4) b += P - r;
+    return (int)b;
+  }
+  // K = 128 * P; nk = K-tiles (64 deep) of a whole work item = 2 * P / ksplit
+  __host__ __device__ void init(int grid, int block, int pairs, int ksplit, int tiles, int sk) {
+    G = grid, wg = block, P = pairs, nk = 2 * pairs / ksplit, base_tiles = tiles, sk_tiles = sk;
+    dp_tiles = tiles * ksplit - sk;
+    sk_units = (unsigned)sk * (unsigned)pairs;
+    u0 = sk ? ub(wg) : 0, u1 = sk ? ub(wg + 1) : 0;
+    nsk = u1 > u0 ? (u1 - 1) / P - u0 / P + 1 : 0;
+  }
+  __host__ __device__ bool item(int idx, Item& it) const {
+    if (idx < nsk) {
+      const int t = u0 / P + idx;
+      const int a = idx == 0 ? u0 : t * P, e = (t + 1) * P, b = u1 < e ? u1 : e;
+      it.tile = dp_tiles + t, it.ks = 0, it.k0t = (a - t * P) * 2, it.nkt = (b - a) * 2;
+      it.kind = a != t * P ? PART : (b != e ? HEAD : FULL);
+      return true;
+    }
+    const int s = wg + (idx - nsk) * G;
+    if (s >= dp_tiles) return false;
+    it.ks = s / base_tiles, it.tile = s - it.ks * base_tiles, it.k0t = it.ks * nk, it.nkt = nk, it.kind = FULL;
+    return true;
+  }
+};
+
 // Stream-K plan of the 256 x 256 kernel for T output tiles of P K-tile pairs on G workgroups: how many (trailing) tiles are
 // cut along K.  0 = none: whole rounds, no workspace, ranges shorter than 8 pairs, or a last round that is nearly full.
 inline int sk_plan(long T, int P, int G, bool have_ws, double max_rem) {

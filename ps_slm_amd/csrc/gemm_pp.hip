@@ -46,42 +46,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;          // group (tile rows wr*128 ..), wave column (tile cols wc*64 ..)
   // split-K (TASU_GEMM_OUT_F32 only, gemm_epilogue.h): work item s = K range s / base_tiles of output tile s % base_tiles
-  const int nk = p.K / BK / p.ksplit;                // K-tiles per whole work item (even)
   const int base_tiles = p.tiles_m * p.tiles_n;
-  // ---- the workgroup's list of work items.  Whole tiles (and K-range slabs) are dealt round-robin: item s = blockIdx + i *
-  // gridDim.  The last p.sk_tiles tiles are cut along K instead (stream-K): sk_tiles * P K-tile pairs, one contiguous range
-  // [ub(w), ub(w+1)) per workgroup, visited BEFORE its whole tiles, so that a partial tile is in memory long before the
-  // workgroup that completes the tile asks for it.  Range ends within 4 pairs of a tile boundary snap to it.
-  enum { FULL = 0, PART = 1, HEAD = 2 };
-  struct Item {
-    int tile, ks, k0t, nkt, kind;                    // output tile, slab, first K-tile, K-tiles (even), role
-  };
-  const int G = (int)gridDim.x, wg = (int)blockIdx.x;
-  const int P = p.K / (2 * BK);
-  const int dp_tiles = base_tiles * p.ksplit - p.sk_tiles;
-  const unsigned sk_units = (unsigned)p.sk_tiles * P;   // (the host keeps sk_units * gridDim below 2^31)
-  auto ub = [&](int w) -> int {
-    unsigned b = (unsigned)w * sk_units / (unsigned)G;
-    const unsigned r = b % (unsigned)P;
-    if (r && r < 4) b -= r;
-    else if (r && P - r < 4) b += P - r;
-    return (int)b;
-  };
-  const int u0 = p.sk_tiles ? ub(wg) : 0, u1 = p.sk_tiles ? ub(wg + 1) : 0;
-  const int nsk = u1 > u0 ? (u1 - 1) / P - u0 / P + 1 : 0;
-  auto get_item = [&](int idx, Item& it) -> bool {
-    if (idx < nsk) {
-      const int t = u0 / P + idx;
-      const int a = idx == 0 ? u0 : t * P, b = min(u1, (t + 1) * P);
-      it.tile = dp_tiles + t, it.ks = 0, it.k0t = (a - t * P) * 2, it.nkt = (b - a) * 2;
-      it.kind = a != t * P ? PART : (b != (t + 1) * P ? HEAD : FULL);
-      return true;
-    }
-    const int s = wg + (idx - nsk) * G;
-    if (s >= dp_tiles) return false;
-    it.ks = s / base_tiles, it.tile = s - it.ks * base_tiles, it.k0t = it.ks * nk, it.nkt = nk, it.kind = FULL;
-    return true;
-  };
+  // ---- the workgroup's list of work items (PpSchedule, gemm_epilogue.h): stream-K range pieces first, then whole tiles
+  using Item = PpSchedule::Item;
+  constexpr int PART = PpSchedule::PART, HEAD = PpSchedule::HEAD;
+  PpSchedule sched;
+  sched.init((int)gridDim.x, (int)blockIdx.x, p.K / (2 * BK), p.ksplit, base_tiles, p.sk_tiles);
+  const int G = sched.G, wg = sched.wg, P = sched.P, dp_tiles = sched.dp_tiles;
+  auto ub = [&](int w) { return sched.ub(w); };
+  auto get_item = [&](int idx, Item& it) { return sched.item(idx, it); };
 
   // ------------------------------------------------------------------ staging
   // Per work item only wave-uniform values change: the operand origins (1 KiB below the first A / B row of the tile at the
@@ -577,6 +550,29 @@ extern "C" int tasu_gemm_nt_bf16_slabs(const void* A, int lda, const void* B, in
 
 int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                             const float* resid, int M, int N, int K, int out_mode, int bn, hipStream_t st, int n0, int n1);
+
+// The stream-K work-item lists of tasu_gemm_nt_bf16_streamk for `tiles` output tiles of `pairs` K-tile pairs on `grid`
+// workgroups (host restatement through the kernel's own PpSchedule; no GPU): items[w][i] = {tile, first K-tile, K-tiles, role
+// (0 whole tile, 1 partial-tile producer, 2 tile owner)}, up to max_items per workgroup; counts[w] = items of workgroup w.
+// Returns the number of tiles the plan cuts along K (0: whole tiles only), or -1 on bad arguments.
+extern "C" int tasu_streamk_schedule(int tiles, int pairs, int grid, int32_t* items, int32_t* counts, int max_items) {
+  using namespace tasu_gemm;
+  if (tiles <= 0 || pairs <= 0 || grid <= 0 || !items || !counts || max_items <= 0) return -1;
+  const int sk = (long long)tiles * pairs < (1 << 22) ? sk_plan(tiles, pairs, grid, true, 1.0) : 0;
+  for (int w = 0; w < grid; ++w) {
+    PpSchedule s;
+    s.init(grid, w, pairs, 1, tiles, sk);
+    PpSchedule::Item it;
+    int n = 0;
+    for (; s.item(n, it); ++n) {
+      if (n >= max_items) return -1;
+      int32_t* o = items + ((size_t)w * max_items + n) * 4;
+      o[0] = it.tile, o[1] = it.k0t, o[2] = it.nkt, o[3] = it.kind;
+    }
+    counts[w] = n;
+  }
+  return sk;
+}
 
 // tasu_gemm_nt_bf16_ws on the 256 x 256 kernel with the stream-K schedule wherever the tiles do not fill whole rounds of
 // workgroups, whatever the dispatcher's policy would choose (tests, tuning runs).  Same contract; K % 128 == 0, K >= 256.

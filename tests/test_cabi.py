@@ -55,3 +55,54 @@ def test_hipops_refuses_cpu_box():
     from ps_slm_amd.ops import HipOps, TasuOpError
     with pytest.raises(TasuOpError):
         HipOps()
+
+
+@pytest.mark.parametrize("tiles,pairs,grid", [(96, 140, 256), (96, 70, 256), (48, 140, 256), (24, 140, 256), (72, 64, 256), (45, 48, 256),
+                                              (288, 8, 256), (400, 12, 256), (16, 32, 256), (256, 12, 256), (7, 1187, 256), (100, 9, 64)])
+def test_streamk_schedule_covers_every_tile_once_and_cannot_deadlock(tiles, pairs, grid):
+    """The stream-K work-item lists of the 256 x 256 GEMM, produced by the kernel's own schedule code on the host
+    (tasu_streamk_schedule): every K-tile of every output tile belongs to exactly one item; the items of a cut tile are
+    contiguous in K and belong to consecutive workgroups; a partial-tile producer piece is always its workgroup's FIRST item
+    (it never waits, so the owner that waits for it -- a lower-numbered workgroup, on its last range piece -- cannot be held up
+    by anything but time); every piece is an even number (>= 2) of K-tiles; whole tiles are dealt round-robin."""
+    import ctypes as C
+    import numpy as np
+    from ps_slm_amd import _lib
+    lib = _lib.load()
+    max_items = 16
+    items = np.full((grid, max_items, 4), -1, dtype=np.int32)
+    counts = np.zeros(grid, dtype=np.int32)
+    sk = lib.tasu_streamk_schedule(tiles, pairs, grid, items.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), max_items)
+    assert 0 <= sk <= tiles
+    cover = np.zeros((tiles, 2 * pairs), dtype=np.int32)
+    owner_of, parts_of = {}, {}
+    for w in range(grid):
+        seen_whole = False
+        for i in range(counts[w]):
+            tile, k0, nk, kind = (int(v) for v in items[w, i])
+            assert 0 <= tile < tiles and nk >= 2 and nk % 2 == 0 and k0 % 2 == 0 and k0 + nk <= 2 * pairs
+            cover[tile, k0:k0 + nk] += 1
+            if kind == 1:
+                assert i == 0, "a producer piece must be the workgroup's first item"
+                assert k0 > 0
+                parts_of.setdefault(tile, []).append((k0, w))
+            elif kind == 2:
+                assert k0 == 0 and nk < 2 * pairs and not seen_whole, "an owner piece begins its tile and precedes the whole tiles"
+                assert tile not in owner_of
+                owner_of[tile] = (w, nk)
+            else:
+                assert k0 == 0 and nk == 2 * pairs
+                seen_whole = seen_whole or tile < tiles - sk
+    assert (cover == 1).all()
+    assert set(parts_of) == set(owner_of)
+    for tile, (w, end) in owner_of.items():
+        assert tile >= tiles - sk
+        for j, (k0, pw) in enumerate(sorted(parts_of[tile])):
+            assert pw == w + 1 + j and k0 == end, "the pieces of a tile follow each other in K on consecutive workgroups"
+            end = k0 + int(items[pw, 0, 2])
+        assert end == 2 * pairs
+    if sk == 0:
+        assert not owner_of and counts.max() == -(-tiles // grid)
+    else:
+        work = np.array([sum(int(items[w, i, 2]) for i in range(counts[w])) for w in range(grid)])
+        assert work.max() - work.min() <= 2 * pairs + 16 if tiles > grid else work.max() - work.min() <= 16   # balanced up to the snapping
