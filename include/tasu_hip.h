@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 4
+#define TASU_ABI_VERSION 5
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM

@@ -103,7 +103,7 @@ PROTOTYPES.update({
     "tasu_allreduce_min_i32": [vp, vp, i64, vp],
 })
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 
