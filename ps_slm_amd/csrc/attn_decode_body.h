@@ -1,5 +1,5 @@
-// Body of the single-token cache attention, shared by tasu_attn_decode's kernel (decode.hip) and the persistent decode-layer
-// kernel (decode_mega.hip).
+// Body of the single-token cache attention of tasu_attn_decode's kernel (decode.hip).  (A header because round 2's persistent
+// decode-layer kernel shared it; that kernel was measured slower than the per-GEMM launches and removed in round 3.)
 #pragma once
 #include "common.h"
 #include "stream_body.h"

@@ -1,5 +1,5 @@
-// Body of the weight-streaming decode GEMM (see gemm_stream.hip for the design notes), shared by the one-GEMM kernels of
-// gemm_stream.hip and the persistent decode-layer kernel of decode_mega.hip.
+// Body of the weight-streaming decode GEMM (see gemm_stream.hip for the design notes) of the one-GEMM kernels of
+// gemm_stream.hip.  (A header because round 2's persistent decode-layer kernel shared it; removed in round 3)
 #pragma once
 #include "common.h"
 
@@ -86,8 +86,8 @@ __device__ __forceinline__ void st_out(T* dst, T v) {
 // 1-2 column tiles per workgroup the 64 activation rows dominate it).
 // FRAG: both operands in fragment order (compile-time: a run-time layout test inside the load lambdas splits the ring loop
 // into branches across which the compiler drains vmcnt).
-// WT: outputs are stored write-through at agent scope (st_out): a workgroup on another XCD may read them after a grid barrier of
-// the SAME launch (csrc/decode_mega.hip); the plain kernels of gemm_stream.hip pass false.
+// WT: outputs are stored write-through at agent scope (st_out), for a consumer on another XCD inside the SAME launch (round 2's
+// persistent layer-loop kernel); the kernels of gemm_stream.hip pass false.
 // bx / nbx, by, bz: the workgroup's position in the (virtual) grid [column-tile walkers][K ranges][row splits];
 // red: LDS, 2 * NW * MT * 256 floats -- partial tiles [2 buffers][NW waves][MT row tiles][64 lanes] f32x4.
 template <int KS, int EPI, int MT, bool FRAG, bool WT>
