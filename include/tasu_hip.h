@@ -101,6 +101,19 @@ int tasu_gemm_gate_up_swiglu_ws(const void* A, int lda, const void* Wgu, int ldw
 int tasu_gemm_nt_bf16_streamk(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                               const float* resid, int M, int N, int K, int out_mode, void* workspace, int64_t workspace_bytes,
                               void* stream);
+/* The dispatcher's decision for C[M,N] = A[M,K] . B[N,K]^T in tasu_gemm_nt_bf16_ws (with_workspace != 0) / tasu_gemm_nt_bf16,
+ * without launching anything (no GPU needed; tests pin the policy on the training step's shapes).  Returns one of: */
+#define TASU_GEMM_PLAN_PP256 1                /* 256 x 256 eight-wave kernel, whole tiles */
+#define TASU_GEMM_PLAN_PP256_PLUS_PIPE128 2   /* whole rounds of 256 x 256 tiles + the remaining columns on 256 x 128 tiles */
+#define TASU_GEMM_PLAN_PP256_PLUS_PIPE192 3   /* ... + the remaining columns on 128 x 192 tiles */
+#define TASU_GEMM_PLAN_PP256_STREAMK 4        /* 256 x 256 tiles cut along K, one range per workgroup */
+#define TASU_GEMM_PLAN_PIPE128 5              /* loader-wave kernel, 256 x 128 tiles */
+#define TASU_GEMM_PLAN_PIPE192 6              /* loader-wave kernel, 128 x 192 tiles */
+#define TASU_GEMM_PLAN_PIPE96 7               /* loader-wave kernel, 256 x 96 tiles */
+#define TASU_GEMM_PLAN_TILE192_SPLITK 8       /* 256 x 192 tiles of gemm.hip with split-K through the workspace */
+#define TASU_GEMM_PLAN_TILES 9                /* 128-row tiles of gemm.hip (at most 64 rows, or a forced kernel) */
+/* (-1: the arguments would be rejected) */
+int tasu_gemm_plan(int M, int N, int K, int out_mode, int with_workspace);
 /* Host-side restatement of that schedule through the kernel's own code (no GPU needed; tests): the work-item lists of `grid`
  * workgroups for `tiles` output tiles of `pairs` K-tile pairs (K = 128 * pairs).  items[w][i] = {tile, first K-tile, K-tiles,
  * role: 0 whole tile, 1 partial-tile producer, 2 tile owner}, max_items per workgroup; counts[w] = items of workgroup w.

@@ -93,6 +93,7 @@ PROTOTYPES.update({
     "tasu_gemm_gate_up_swiglu_ws": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, i64, vp],
     "tasu_gemm_qkv_rope": [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "tasu_gemm_dswiglu": [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, i64, vp],
+    "tasu_gemm_plan": [i32, i32, i32, i32, i32],
     "tasu_streamk_schedule": [i32, i32, i32, vp, vp, i32],
     "tasu_gemm_nt_bf16_streamk": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "tasu_comm_available": [],

@@ -369,8 +369,9 @@ static int plan_ksplit(int M, int N, int K, size_t ws_bytes) {
 // out_mode: TASU_GEMM_OUT_* or tasu_gemm::OUT_DSWIGLU (`resid` is then the saved gate|up matrix, bf16 [M, 2N], C = dgu [M, 2N]:
 // served by the gemm_pipe / gemm_pp kernels only -- kUnsupported otherwise, and tasu_gemm_dswiglu runs the two-kernel form)
 constexpr int kUnsupported = -1000;
+// plan (optional): the decision only -- *plan = one of TASU_GEMM_PLAN_* (include/tasu_hip.h), nothing is launched
 static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias, const float* resid, int M,
-                       int N, int K, int out_mode, void* workspace, int64_t workspace_bytes, void* stream) {
+                       int N, int K, int out_mode, void* workspace, int64_t workspace_bytes, void* stream, int* plan = nullptr) {
   const bool dsw = out_mode == tasu_gemm::OUT_DSWIGLU;
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return TASU_ERR_ARG;
   if (K % BK != 0 || lda % 8 != 0 || ldb % 8 != 0) return TASU_ERR_ARG;
@@ -454,8 +455,10 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
           const double c256 = c256_sk < c256_whole ? c256_sk : c256_whole;
           const double best = use_pipe_bn == 128 ? c128 : (use_pipe_bn == 192 ? c192 : c96);
           if (c256 < best) {
-            if (c256_sk < c256_whole)
+            if (c256_sk < c256_whole) {
+              if (plan) return *plan = TASU_GEMM_PLAN_PP256_STREAMK, TASU_OK;
               return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, 0, workspace, ws_bytes, -2.0);
+            }
             // a mostly empty last round of big tiles (d_down: 560 tiles = 2.19 rounds): whole rounds on the big tiles, the
             // remaining columns on the small tiles in a second launch (TASU_GEMM_NSPLIT=0 disables)
             static const bool split_on = [] {
@@ -469,16 +472,19 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
               const double t128 = cost(u128, 256.0 * 128, 1.00), t192 = cost(u192, 128.0 * 192, 0.86);
               const double c_split = (double)full * 256.0 * 256 / pp_eff + (t128 < t192 ? t128 : t192) + 0.05 * 256.0 * 256;
               if (c_split < c256) {
+                if (plan) return *plan = t128 < t192 ? TASU_GEMM_PLAN_PP256_PLUS_PIPE128 : TASU_GEMM_PLAN_PP256_PLUS_PIPE192, TASU_OK;
                 const int rc = tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, n_main, nullptr, 0, -2.0);
                 if (rc) return rc;
                 return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, t128 < t192 ? 128 : 192, st,
                                                n_main, 0);
               }
             }
+            if (plan) return *plan = TASU_GEMM_PLAN_PP256, TASU_OK;
             return tasu_gemm_pp_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, st, 0, 0, nullptr, 0, -2.0);
           }
         }
       }
+      if (plan) return *plan = use_pipe_bn == 128 ? TASU_GEMM_PLAN_PIPE128 : (use_pipe_bn == 192 ? TASU_GEMM_PLAN_PIPE192 : TASU_GEMM_PLAN_PIPE96), TASU_OK;
       return tasu_gemm_pipe_dispatch(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, use_pipe_bn, st, 0, 0);
     }
   }
@@ -496,6 +502,7 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
       a.partial = (float*)((char*)workspace + TASU_GEMM_WS_COUNTERS * sizeof(int));
     }
   }
+  if (plan) return *plan = a.ksplit > 1 ? TASU_GEMM_PLAN_TILE192_SPLITK : TASU_GEMM_PLAN_TILES, TASU_OK;
   switch (out_mode) {
     case TASU_GEMM_OUT_BF16:
       return hb ? launch_tiled<TASU_GEMM_OUT_BF16, true>(a, bn, st) : launch_tiled<TASU_GEMM_OUT_BF16, false>(a, bn, st);
@@ -514,6 +521,16 @@ extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int l
                                     int64_t workspace_bytes, void* stream) {
   if (out_mode != TASU_GEMM_OUT_BF16 && out_mode != TASU_GEMM_OUT_F32 && out_mode != TASU_GEMM_OUT_F32_RESID_BF16R) return TASU_ERR_ARG;
   return gemm_policy(A, lda, B, ldb, C, ldc, bias, resid, M, N, K, out_mode, workspace, workspace_bytes, stream);
+}
+
+// The dispatcher's decision for a problem, without launching anything (no GPU needed; include/tasu_hip.h)
+extern "C" int tasu_gemm_plan(int M, int N, int K, int out_mode, int with_workspace) {
+  if (out_mode != TASU_GEMM_OUT_BF16 && out_mode != TASU_GEMM_OUT_F32 && out_mode != TASU_GEMM_OUT_F32_RESID_BF16R) return -1;
+  alignas(16) static char dummy[16];
+  int plan = -1;
+  const int rc = gemm_policy(dummy, K, dummy, K, dummy, N, nullptr, (const float*)dummy, M, N, K, out_mode, with_workspace ? dummy : nullptr,
+                             with_workspace ? ((int64_t)64 << 20) + 16384 : 0, nullptr, &plan);
+  return rc == TASU_OK ? plan : -1;
 }
 
 extern "C" int tasu_swiglu_bwd(const void* dact, const void* gu, void* dgu, int M, int I, void* stream);

@@ -106,3 +106,41 @@ def test_streamk_schedule_covers_every_tile_once_and_cannot_deadlock(tiles, pair
     else:
         work = np.array([sum(int(items[w, i, 2]) for i in range(counts[w])) for w in range(grid)])
         assert work.max() - work.min() <= 2 * pairs + 16 if tiles > grid else work.max() - work.min() <= 16   # balanced up to the snapping
+
+
+def test_gemm_policy_on_the_training_step_shapes():
+    """tasu_gemm_plan: the dispatcher's choice (no launch, no GPU) for the GEMM shapes of the benchmark step and its neighbours --
+    the measured winners of profiles/r03_gemm_lab.txt / r03_gemm_streamk.txt.  A policy edit that moves one of them shows up here
+    (round 3: the stream-K option once shadowed whole 256 x 256 tiles and cost the 7B and audio-SFT steps 6-8 %)."""
+    from ps_slm_amd import _lib
+    lib = _lib.load()
+    PP, PP_P128, PP_P192, SK, P128, P192, P96, SPLITK, TILES = range(1, 10)
+    BF, F32, RES = 0, 1, 2
+    M = 4096
+    want = [
+        ((M, 2048, 1536, BF), P128),            # q|k|v (the step itself runs tasu_gemm_qkv_rope: the same 256 x 128 tiles)
+        ((M, 1536, 1536, RES), P192),           # o: one round of 128 x 192
+        ((M, 1536, 1536, BF), P192),            # d_o
+        ((M, 1536, 2048, BF), P192),            # d_qkv
+        ((M, 1536, 8960, RES), P192),           # down: the cut loses at K = 8960 (108 against 100 us)
+        ((M, 8960, 1536, BF), PP_P192),         # d_down: two whole rounds + column tail
+        ((M, 17920, 1536, BF), PP_P192),        # gate|up as a plain GEMM: four whole rounds + column tail
+        ((M, 1536, 17920, BF), SK),             # d_gate_up: 96 tiles on 256 CUs, stream-K
+        ((2048, 151936, 1536, BF), PP),         # lm_head on the labelled rows
+        ((1664, 2048, 25088, BF), SK),          # projector
+        ((M, 3584, 18944, RES), PP),            # 7B down: 224 tiles, whole (the cut loses above 3/4 of a round)
+        ((M, 3584, 37888, BF), PP),             # 7B d_gate_up
+        ((2048, 1536, 17920, BF), SK),          # batch 8: 48 tiles
+        ((2048, 1536, 8960, RES), SK),
+        ((3072, 1536, 17920, BF), P192),        # batch 12: 72 tiles, K offsets not aligned within an XCD
+        ((1024, 1536, 17920, BF), SK),          # 24 tiles: up to a quarter round the offsets do not matter
+        ((1024, 1536, 8960, BF), P192),         # ... but 6.5 K-tile pairs per CU are too few
+        ((512, 1536, 17920, BF), SPLITK),       # nothing else fills the chip
+        ((128, 1536, 8960, BF), P192),
+        ((64, 1536, 1536, BF), TILES),
+    ]
+    for (m, n, k, mode), plan in want:
+        assert lib.tasu_gemm_plan(m, n, k, mode, 1) == plan, (m, n, k, mode, lib.tasu_gemm_plan(m, n, k, mode, 1), plan)
+    # without the workspace the stream-K schedule is not available
+    assert lib.tasu_gemm_plan(M, 1536, 17920, BF, 0) == P192
+    assert lib.tasu_gemm_plan(M, 1536, 17920, 5, 1) == -1 and lib.tasu_gemm_plan(M, 1536, 100, BF, 1) == -1
