@@ -454,9 +454,8 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                                          "GEMM-only hipGraph between two HIP events, per call (a call of the column-split policy is two "
                                          "kernel launches); graphs cannot carry per-launch events, and eager event pairs also time the "
                                          "host between the two launches of a split call.  In this replay the GEMMs follow each other "
-                                         "without the kernels that produce their operands, which are therefore colder than in the step: "
-                                         "rocprofv3's sum over the same launches of an eager step is ~2 % lower "
-                                         "(profiles/r03_bench_summary.md)") if core.use_graphs else
+                                         "without the kernels that produce their operands in between; rocprofv3's sum over the same "
+                                         "launches of an eager step agrees within 2 % (profiles/r03_bench_summary.md)") if core.use_graphs else
                                         "one eager pass, HIP event pairs around every GEMM call (includes the host gap inside two-launch calls)",
                          "whole_step_tflops": round(executed_step * steps / dt / 1e12, 1),     # per GPU (executed_step counts one rank's batch)
                          "whole_step_frac": round(executed_step * steps / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
