@@ -30,22 +30,25 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
-def gemm_flops_per_utt(geo, S, n_audio, n_head_rows=None):
+def gemm_flops_per_utt(geo, S, n_audio, n_head_rows=None, tail_rows=False):
     """FLOPs that run inside the MFMA GEMM kernel per utterance (weights only, multiply-add =
     2 FLOPs): decoder linears + lm_head, forward and dgrad-only backward, projector fwd + bwd.  ``n_head_rows``: positions
     the lm_head is EXECUTED on (the training step projects only the positions that carry a label); None = all S, which
-    is SURVEY's algorithmic figure."""
+    is SURVEY's algorithmic figure.  ``tail_rows``: the step also ran the LAST decoder layer's MLP (gate|up, down and their
+    dgrads) on those rows only (TasuModel.tail_rows): the other S - n_head_rows rows of that layer's MLP are not executed and
+    not counted."""
     D, I, H, G, V, L = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_vocab, geo.llm_layers
     per_layer = D * (H + 2 * G) * 128 + H * 128 * D + 3 * D * I
     proj_tok = 2 * (geo.ctc_vocab * geo.bottleneck + geo.bottleneck * D)
     head_rows = S if n_head_rows is None else n_head_rows
-    return 2 * (2 * L * per_layer * S + 2 * V * D * head_rows) + 3 * proj_tok * n_audio
+    skipped = 2 * 2 * 3 * D * I * (S - head_rows) if tail_rows else 0
+    return 2 * (2 * L * per_layer * S + 2 * V * D * head_rows) + 3 * proj_tok * n_audio - skipped
 
 
-def total_flops_per_utt(geo, S, n_audio, n_head_rows=None):
+def total_flops_per_utt(geo, S, n_audio, n_head_rows=None, tail_rows=False):
     """SURVEY.md 8d text-only total (adds causal attention: fwd 2*S*D*L per token, bwd 2.5x)."""
     attn = geo.llm_layers * 2 * S * geo.llm_heads * 128 * S
-    return gemm_flops_per_utt(geo, S, n_audio, n_head_rows) + attn + 2.5 * attn
+    return gemm_flops_per_utt(geo, S, n_audio, n_head_rows, tail_rows) + attn + 2.5 * attn
 
 
 class TimedOps:
@@ -408,8 +411,9 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         n_audio = st.Ra / B                             # projector rows per utterance (audio: PSD output, padded to the batch max)
         n_head = st.nLp / B                             # lm_head rows executed per utterance (labelled positions, padded to 64)
         enc = encoder_gemm_flops_per_utt(geo, raw["input_features"].shape[1] + 4) if audio else 0
-        gemm_flops_step = (gemm_flops_per_utt(geo, S, n_audio, n_head) + enc) * B
-        executed_step = (total_flops_per_utt(geo, S, n_audio, n_head) + enc) * B
+        tail = "xout_tail" in st.dev                    # last layer's MLP ran on the labelled rows only (TasuModel.tail_rows)
+        gemm_flops_step = (gemm_flops_per_utt(geo, S, n_audio, n_head, tail) + enc) * B
+        executed_step = (total_flops_per_utt(geo, S, n_audio, n_head, tail) + enc) * B
         survey_step = (total_flops_per_utt(geo, S, n_audio) + enc) * B
         if timed.replay_ms is not None:
             gemm_ms, n_launch = timed.replay_ms[0] * steps, timed.replay_ms[1] * steps
@@ -460,11 +464,13 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                          "whole_step_tflops": round(executed_step * steps / dt / 1e12, 1),     # per GPU (executed_step counts one rank's batch)
                          "whole_step_frac": round(executed_step * steps / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                          "whole_step_frac_at_survey_flops": round(survey_step * steps / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
-                         "flops_note": "achieved / whole_step_frac count EXECUTED FLOPs per GPU (lm_head rows without a label are "
-                                       "not computed and not counted); whole_step_frac_at_survey_flops prices the same "
-                                       "utterances/s at SURVEY 8d's algorithmic FLOPs, which count them"},
+                         "flops_note": "achieved / whole_step_frac count EXECUTED FLOPs per GPU (lm_head rows without a label, and the "
+                                       "last decoder layer's MLP on those rows, are not computed and not counted); "
+                                       "whole_step_frac_at_survey_flops prices the same utterances/s at SURVEY 8d's algorithmic "
+                                       "FLOPs, which count them"},
         }
         if world > 1:
+            rec["collective"] = engine.comm_info()      # ranks = ncclCommCount of the communicator the exchange ran on
             rec["allreduce_exposed_ms"] = round(exposed_ms, 3)
             rec["allreduce_note"] = (f"per step, max over ranks: time the compute stream waited for gradient ranges in step() "
                                      f"(event pairs around every wait); bucket exchanged in {engine.w1_chunks + 2} ranges.  Expected "
@@ -472,8 +478,10 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                                      f"the ~300 GB/s bus bandwidth RCCL reaches; the whole 218-MB bucket would be ~1.3 ms), DESIGN.md 6")
         if want_decode:
             rec["decode"] = decode_leg(core, raw, B, new_tokens=200 if model_name != "qwen2.5-7b" else 64)
+    engine.destroy()                                    # RCCL communicator, before the process group goes
     del engine, model, core, timed
-    torch.cuda.empty_cache()
+    if on_gpu:
+        torch.cuda.empty_cache()
     return rec
 
 
@@ -544,6 +552,23 @@ def main():
             line["cpu_baseline"] = cpu_baseline("train1")
             line["cpu_baselines"] = {"train_B16": cpu_baseline("train16", 300), "decode_B1": cpu_baseline("decode1", 240),
                                      "decode_B16": cpu_baseline("decode16", 300)}
+        # LAST key of the line: the headline numbers of every sub-record in a few hundred bytes, so that a reader who keeps only
+        # the tail of a long line (the driver's record does) still sees them
+        def brief(r):
+            if not isinstance(r, dict) or r.get("value") is None:
+                return None
+            out = {"value": r["value"], "unit": r.get("unit"), "ms_per_step": r.get("ms_per_step")}
+            if isinstance(r.get("roofline"), dict):
+                out["roofline_frac"] = r["roofline"].get("frac")
+                if "whole_step_frac_at_survey_flops" in r["roofline"]:
+                    out["whole_step_frac_at_survey_flops"] = r["roofline"]["whole_step_frac_at_survey_flops"]
+            return out
+        digest = {"train_1p5b": brief(dict(main_rec, unit="utterances/s")), "decode_1p5b": brief(main_rec.get("decode"))}
+        for name, rec in extras.items():
+            digest[name] = brief(rec)
+            if isinstance(rec.get("decode"), dict):
+                digest[name + "_decode"] = brief(rec["decode"])
+        line["digest"] = digest
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

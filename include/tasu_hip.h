@@ -7,6 +7,13 @@
  * replaces the PyTorch-eager arithmetic of one span of that model's forward/backward; the span is cited on
  * every declaration.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
  *
+ * TRAINING CONTRACT.  These entry points are forward AND backward kernels called in a hand-scheduled order by
+ * ps_slm_amd.model.TasuModel; no autograd graph exists across this boundary.  The reference's loop
+ * (Multitask/finetune_deepspeed.py:127-149, Multitask/utils/deepspeed_utils.py:205-236: `deepspeed.initialize` over
+ * `model.parameters()`, `engine.backward(loss)`, `engine.step()`) therefore cannot train the plugin: the engine that does is
+ * ps_slm_amd.engine.TasuEngine (same backward / step surface; tasu_adamw + tasu_comm_* / tasu_allreduce_f32 below).  A foreign
+ * engine's first `loss.backward()` raises a RuntimeError naming TasuEngine (tests/test_engine_cpu.py).
+ *
  * Conventions
  *   - plain pointers + sizes only; every pointer is DEVICE memory unless stated; no ownership transfer;
  *     the caller allocates every output and workspace.
@@ -25,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 5
+#define TASU_ABI_VERSION 6
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -447,7 +454,10 @@ int tasu_softmax_bwd_rows_bf16(const void* p, const void* dp, void* ds, int R, i
  * all-gather, Multitask/conf/ds_config.json:15-21) by what it amounts to for 54.5 M replicated parameters: an in-place SUM
  * all-reduce of ranges of the flat fp32 gradient bucket over RCCL / xGMI, asynchronous on the given HIP stream (the engine uses
  * a side stream chained to the wgrad kernels by events and divides by the world size inside tasu_adamw).
- * RCCL is bound at run time (the copy already in the process, else the ROCm installation's; TASU_RCCL_PATH overrides).
+ * RCCL is bound at run time: the copy already mapped into the process (found with dl_iterate_phdr, whatever path the host
+ * framework loaded it from), else TASU_RCCL_PATH, else the ROCm installation's.  Two copies in one process are refused:
+ * tasu_comm_available returns 0 when more than one librccl is mapped or when TASU_RCCL_PATH names a file other than the mapped
+ * one; tasu_comm_library writes the bound file's path (return 0) or the reason (return 2) into out[n].
  * Bootstrap: rank 0 calls tasu_comm_unique_id, the launcher's rendezvous carries the 128 bytes to every rank (the entrypoint
  * broadcasts them over the process group torch.distributed.run set up), every rank calls tasu_comm_init on ITS device
  * (hipSetDevice first).  HOST calls; a communicator belongs to the thread / device that created it.
@@ -457,6 +467,8 @@ int tasu_comm_available(void);                                   /* 1 when RCCL 
 int tasu_comm_unique_id(uint8_t* id128);
 int tasu_comm_init(const uint8_t* id128, int rank, int world, void** comm);
 int tasu_comm_destroy(void* comm);
+int tasu_comm_library(char* out, int n);                         /* HOST string: bound file, or why binding failed */
+int tasu_comm_count(void* comm, int* count);                     /* ncclCommCount: ranks RCCL itself sees in the communicator */
 int tasu_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
 int tasu_allreduce_min_i32(void* comm, int32_t* buf, int64_t n, void* stream);
 

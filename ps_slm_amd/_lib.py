@@ -100,11 +100,13 @@ PROTOTYPES.update({
     "tasu_comm_unique_id": [vp],
     "tasu_comm_init": [vp, i32, i32, vp],
     "tasu_comm_destroy": [vp],
+    "tasu_comm_library": [vp, i32],
+    "tasu_comm_count": [vp, vp],
     "tasu_allreduce_f32": [vp, vp, i64, vp],
     "tasu_allreduce_min_i32": [vp, vp, i64, vp],
 })
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

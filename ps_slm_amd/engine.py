@@ -34,22 +34,44 @@ class RcclExchange:
     torch.distributed."""
 
     def __init__(self, lib, pg, device):
-        self.lib = lib
-        if not lib.tasu_comm_available():
-            raise RuntimeError("libtasu_hip.so could not bind RCCL (librccl.so not found; TASU_RCCL_PATH overrides)")
+        self.lib, self.comm = lib, None
         rank, world = dist.get_rank(pg), dist.get_world_size(pg)
+        src = dist.get_global_rank(pg, 0) if pg is not None else 0
+        # Every step of the bootstrap is agreed on by ALL ranks before the next one starts: a rank that cannot bind RCCL (or
+        # rank 0 failing to draw the unique id) must not leave the others blocked in a broadcast or inside ncclCommInitRank.
+        note = ctypes.create_string_buffer(640)
+        bound = lib.tasu_comm_library(note, len(note)) == 0
         ident = (ctypes.c_uint8 * 128)()
-        if rank == 0 and lib.tasu_comm_unique_id(ident):
-            raise RuntimeError("tasu_comm_unique_id failed")
-        box = [bytes(ident)]
+        ok = bound and (rank != 0 or lib.tasu_comm_unique_id(ident) == 0)
+        box = [(bool(ok), bytes(ident), note.value.decode(errors="replace"))]
         if world > 1:
-            dist.broadcast_object_list(box, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
-        ident = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+            gathered = [None] * world
+            dist.all_gather_object(gathered, box[0], group=pg)
+            bad = [(r, g[2]) for r, g in enumerate(gathered) if not g[0]]
+            if bad:
+                raise RuntimeError("RCCL bootstrap failed on rank(s) " + "; ".join(f"{r}: {why or 'tasu_comm_unique_id failed'}" for r, why in bad)
+                                   + " (TASU_RCCL_PATH selects the library; every rank raises this error)")
+            box = [gathered[0]]
+        elif not ok:
+            raise RuntimeError(f"RCCL bootstrap failed: {box[0][2] or 'tasu_comm_unique_id failed'}")
+        self.library = box[0][2] if rank == 0 else note.value.decode(errors="replace")
+        ident = (ctypes.c_uint8 * 128).from_buffer_copy(box[0][1])
         torch.cuda.set_device(device)
         comm = ctypes.c_void_p()
-        if lib.tasu_comm_init(ident, rank, world, ctypes.byref(comm)):
+        rc = lib.tasu_comm_init(ident, rank, world, ctypes.byref(comm))
+        if world > 1:                                  # agree again: a rank whose init failed has already left the collective
+            flags = [None] * world
+            dist.all_gather_object(flags, int(rc), group=pg)
+            if any(flags):
+                raise RuntimeError(f"tasu_comm_init failed on rank(s) {[r for r, f in enumerate(flags) if f]} of {world}")
+        elif rc:
             raise RuntimeError(f"tasu_comm_init failed (rank {rank} of {world})")
         self.comm = comm
+        n = ctypes.c_int(0)
+        if lib.tasu_comm_count(comm, ctypes.byref(n)) or n.value != world:
+            raise RuntimeError(f"RCCL sees {n.value} ranks in the communicator, the launcher {world}")
+        self.ranks = n.value
+        _OPEN.add(self)
 
     def all_reduce_sum(self, t, stream):
         """In-place SUM over the ranks of a contiguous fp32 tensor, asynchronous on ``stream``."""
@@ -61,9 +83,29 @@ class RcclExchange:
             raise RuntimeError("tasu_allreduce_min_i32 failed")
 
     def close(self):
+        """Destroys the communicator (TasuEngine.destroy(), or at interpreter exit BEFORE torch.distributed tears its own
+        process group down: a live RCCL communicator at exit can hang or warn)."""
+        _OPEN.discard(self)
         if self.comm:
+            torch.cuda.synchronize()
             self.lib.tasu_comm_destroy(self.comm)
             self.comm = None
+
+
+_OPEN = set()
+
+
+def _close_all():
+    for x in list(_OPEN):
+        try:
+            x.close()
+        except Exception:          # interpreter shutdown: nothing left to report to
+            pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(_close_all)
 
 
 def warmup_cosine_ratio(it, warmup_num_steps=200, total_num_steps=15000, warmup_min_ratio=0.0, cos_min_ratio=1e-4,
@@ -214,6 +256,18 @@ class TasuEngine:
         """Sum of the intervals the compute stream spent waiting for gradient ranges since ``exposed_events`` was cleared
         (needs ``time_exchange``; call after a device synchronize)."""
         return sum(a.elapsed_time(b) for a, b in self.exposed_events)
+
+    def destroy(self):
+        """Releases the RCCL communicator; call before ``dist.destroy_process_group()`` (the entrypoints and bench.py do)."""
+        if self.rccl is not None:
+            self.rccl.close()
+            self.rccl = None
+
+    def comm_info(self):
+        """What the data-path collective runs on: {"backend", "ranks" (RCCL's own ncclCommCount), "library"}."""
+        if self.rccl is not None:
+            return {"backend": "rccl (C-ABI)", "ranks": self.rccl.ranks, "library": self.rccl.library}
+        return {"backend": dist.get_backend(self.pg) if self.exchange else None, "ranks": self.world, "library": None}
 
     # ---- uneven-data join (replaces the per-step gloo monitored_barrier of deepspeed_utils.py:102-123,191)
     def all_have_data(self, has_batch: bool) -> bool:

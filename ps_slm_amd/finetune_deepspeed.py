@@ -247,6 +247,7 @@ def main(argv=None):
             os.makedirs(train_config.output_dir, exist_ok=True)
     if train_config.save_model and train_config.output_dir and not train_config.output_dir.startswith("PATH/"):
         engine.save_checkpoint(os.path.join(train_config.output_dir, "pytorch_model.bin"))
+    engine.destroy()                                    # the RCCL communicator goes before the process group
     if world > 1:
         dist.destroy_process_group()
     return results

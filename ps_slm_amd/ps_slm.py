@@ -4,10 +4,20 @@ Multitask/utils/model_utils.py:9-33).  Same names, argument meaning and error be
 the HIP kernels of libtasu_hip.so through ps_slm_amd.model.TasuModel.
 
 What callers get (Multitask/utils/deepspeed_utils.py:205-236, Multitask/inference_batch.py:139-151):
-  model(**batch) -> (outputs, acc)   outputs.loss (0-dim device tensor), outputs.logits [B,S,V] (bf16 view)
+  model(**batch) -> (outputs, acc)   outputs.loss (0-dim device tensor, ``EngineLoss``), outputs.logits [B,S,V] (bf16 view)
   model.generate(**batch) -> LongTensor [B, n_new]
-  model.parameters() / train() / eval() / state_dict() / load_state_dict(strict=False) with the reference's
-  checkpoint keys ``encoder_projector.{norm,ffn.0,ffn.2}.{weight,bias}`` (Multitask/utils/checkpoint_handler.py:169-182)
+  model.parameters() / named_parameters() / train() / eval() / state_dict() / load_state_dict(strict=False) with the
+  reference's checkpoint keys ``encoder_projector.{norm,ffn.0,ffn.2}.{weight,bias}`` (Multitask/utils/checkpoint_handler.py:169-182)
+
+DEVIATION from the reference contract (Multitask/finetune_deepspeed.py:127-149, Multitask/utils/deepspeed_utils.py:205-236),
+stated here, in INTEGRATION.md and in include/tasu_hip.h, and pinned by tests/test_engine_cpu.py: the model is not an
+``nn.Module`` and ``outputs.loss`` carries NO autograd graph -- the backward pass is hand-scheduled HIP
+(``TasuModel.run_backward``), so the only engine that can train this model is ``ps_slm_amd.engine.TasuEngine``
+(``backward(loss)`` / ``step()``, the DeepSpeed engine's surface).  ``parameters()`` lists the trainable projector tensors
+(views of the flat fp32 master buffer, ``requires_grad=True`` like the reference's unfrozen projector; the frozen LLM and
+encoder weights live in kernel layouts and are not listed), so a foreign engine gets as far as building its optimizer; its
+first ``loss.backward()`` / ``engine.backward(loss)`` then raises ``EngineLoss``'s RuntimeError naming TasuEngine --
+never a silent no-op step.
 """
 import json
 import logging
@@ -214,6 +224,25 @@ def model_factory(train_config, model_config, **kwargs):
 
 
 # ------------------------------------------------------------------------------------------------ the model
+ENGINE_ONLY_MSG = ("ps_slm_amd: outputs.loss carries no autograd graph -- the backward pass of the MI355X path is hand-scheduled HIP "
+                   "behind ps_slm_amd.engine.TasuEngine.backward(loss) / .step() (the surface of the DeepSpeed engine of "
+                   "Multitask/finetune_deepspeed.py:147-149); torch.autograd, DeepSpeed or any other engine cannot train this "
+                   "model.  Launch training with `python -m ps_slm_amd.finetune_deepspeed ...` (INTEGRATION.md)")
+
+
+class EngineLoss(torch.Tensor):
+    """``outputs.loss``: the 0-dim fp32 device tensor the step's CE kernel wrote.  It behaves like any tensor (``loss / k``,
+    ``.detach().float()``, ``.item()`` of Multitask/utils/deepspeed_utils.py:206-232) and results of arithmetic on it stay
+    ``EngineLoss``, but ``backward()`` raises: there is no autograd graph behind it (module docstring, DEVIATION)."""
+
+    @staticmethod
+    def __new__(cls, t):
+        return torch.Tensor._make_subclass(cls, t.detach(), False)
+
+    def backward(self, *args, **kwargs):
+        raise RuntimeError(ENGINE_ONLY_MSG)
+
+
 class CausalLMOutput:
     __slots__ = ("loss", "logits")
 
@@ -261,10 +290,24 @@ class slam_model_asr:
     def to(self, *a, **k):
         return self
 
+    def named_parameters(self):
+        """The trainable tensors under the reference's names (``encoder_projector.*``; what
+        ``filter(lambda p: p.requires_grad, model.parameters())`` of Multitask/finetune_deepspeed.py:129 keeps): leaf views
+        of the flat fp32 master buffer (K padding sliced off where that is a plain column slice), ``requires_grad=True``.
+        They are containers: gradients live in ``core.proj.g`` and are written by the wgrad kernels, ``.grad`` stays None."""
+        pr = self.core.proj
+        flat = pr.p.detach()
+        for n in pr.names:
+            v = pr.view(flat, n)
+            r = pr.real[n]
+            if v.dim() == 1:
+                v = v[: r[0]]
+            elif v.dim() == 2 and len(r) == 2 and not (n == pr.n_w1 and pr.kin > 1):
+                v = v[:, : r[1]]
+            yield "encoder_projector." + n, v.requires_grad_(True)
+
     def parameters(self):
-        p = self.core.proj.p
-        p.requires_grad_(False)
-        return iter([p])
+        return (p for _, p in self.named_parameters())
 
     def state_dict(self):
         return self.core.projector_state_dict()
@@ -337,7 +380,7 @@ class slam_model_asr:
         if labels is None:
             return CausalLMOutput(None, core.logits_view(st)), -1
         res = st.dev["loss_out"]
-        return CausalLMOutput(res[0], core.logits_view(st)), (res[1] if self.metric else -1)
+        return CausalLMOutput(EngineLoss(res[0]), core.logits_view(st)), (res[1] if self.metric else -1)
 
     __call__ = forward
 
@@ -346,6 +389,13 @@ class slam_model_asr:
                  targets=None, **kwargs):
         from ps_slm_amd.decode import beam_search_generate
         core = self.core
+        # the decode loop is HF beam search with do_sample=False (ps-slm.py:660-675 defaults): a sampling / penalty knob set to
+        # anything else would silently be ignored, so it is rejected
+        for name, default in (("do_sample", False), ("top_p", 1.0), ("repetition_penalty", 1.0), ("temperature", 1.0)):
+            if kwargs.get(name, default) != default:
+                raise NotImplementedError(f"generate({name}={kwargs[name]!r}): the MI355X decode loop implements the reference's "
+                                          f"defaults only ({name}={default!r}, Multitask/model/ps-slm.py:660-675: beam search "
+                                          "without sampling, penalties or temperature)")
         if self.gt_emb:                                     # ps-slm.py:590-598
             texts = [re.sub(r"[^A-Za-z\s.,!?]+", "", t).lower().strip() for t in targets]
             ids_list = [self.encoder_tokenizer.encode(t) for t in texts]

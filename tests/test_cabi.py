@@ -144,3 +144,31 @@ def test_gemm_policy_on_the_training_step_shapes():
     # without the workspace the stream-K schedule is not available
     assert lib.tasu_gemm_plan(M, 1536, 17920, BF, 0) == P192
     assert lib.tasu_gemm_plan(M, 1536, 17920, 5, 1) == -1 and lib.tasu_gemm_plan(M, 1536, 100, BF, 1) == -1
+
+
+def test_rccl_binding_picks_the_mapped_copy_and_refuses_a_second_one():
+    """csrc/comm.hip: the library's RCCL functions come from the copy already mapped into the process (torch ships its own under
+    torch/lib and loads it by path, so a soname lookup would miss it and bind /opt/rocm's beside it); TASU_RCCL_PATH naming
+    another file is refused with a reason instead of loading a second RCCL (host-only calls: no GPU needed)."""
+    import ctypes
+    import subprocess
+    import sys
+    code = ("import ctypes, os\nfrom ps_slm_amd import _lib\nlib = _lib.load()\nb = ctypes.create_string_buffer(640)\n"
+            "rc = lib.tasu_comm_library(b, 640)\nprint(lib.tasu_comm_available(), rc, b.value.decode())\n"
+            "print(len({l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l}))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    env.pop("TASU_RCCL_PATH", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300).stdout.split("\n")
+    avail, rc, path = out[0].split(" ", 2)
+    mapped = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l]
+    if mapped:                                             # torch maps its RCCL at import on a ROCm build
+        assert (avail, rc) == ("1", "0") and os.path.samefile(path, mapped[0]) and out[1] == "1", out
+        other = "/opt/rocm/lib/librccl.so.1"
+        if os.path.isfile(other) and not os.path.samefile(other, mapped[0]):
+            env["TASU_RCCL_PATH"] = other
+            out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300).stdout.split("\n")
+            avail, rc, why = out[0].split(" ", 2)
+            assert (avail, rc) == ("0", "2") and "second RCCL" in why and out[1] == "1", out
+    lib = _lib.load()
+    assert lib.tasu_comm_count(None, None) == 1 and lib.tasu_comm_library(None, 0) == 1

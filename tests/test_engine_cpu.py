@@ -71,6 +71,44 @@ def test_factory_surface_and_errors():
         model(**call)
 
 
+def test_foreign_engine_fails_loudly_not_silently():
+    """The stated deviation from the reference's model contract (ps_slm.py module docstring): the reference's
+    own train loop (Multitask/finetune_deepspeed.py:127-149, Multitask/utils/deepspeed_utils.py:205-236) filters
+    ``model.parameters()`` by ``requires_grad``, hands them to an optimizer and calls ``engine.backward(loss)`` -- here the
+    parameter list is the projector (non-empty, leaf tensors an optimizer accepts), the loss behaves like a tensor, and
+    the first backward raises a RuntimeError naming TasuEngine instead of stepping an optimizer over ``.grad is None``."""
+    from ps_slm_amd.ps_slm import EngineLoss
+    model, _, eng = make()
+    named = dict(model.named_parameters())
+    assert sorted(named) == sorted(model.state_dict())
+    params = list(filter(lambda p: p.requires_grad, model.parameters()))
+    assert len(params) == 6 and all(p.is_leaf for p in params)
+    assert sum(p.numel() for p in params) == model.core.proj.num_parameters()
+    for k, v in model.state_dict().items():                  # views of the master buffer, reference shapes
+        assert named[k].shape == v.shape and torch.equal(named[k].detach(), v)
+    opt = torch.optim.AdamW(params, lr=1e-3)                 # what a foreign engine would build: accepted ...
+    raw = synthetic_text_batch(model.core.geo, 2, seed=3, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8, noise=False)
+    out, acc = model(**to_call(raw))
+    loss = out.loss / 2                                      # deepspeed_utils.py:210
+    assert isinstance(out.loss, EngineLoss) and isinstance(loss, EngineLoss) and loss.dim() == 0
+    assert math.isfinite(float(loss.detach().float())) and not loss.requires_grad
+    with pytest.raises(RuntimeError, match="TasuEngine"):    # ... and the first backward says which engine trains this model
+        loss.backward()
+    with pytest.raises(RuntimeError, match="TasuEngine"):
+        out.loss.backward()
+    assert all(p.grad is None for p in params)
+    before = model.core.proj.p.clone()
+    opt.step()                                               # (a step over .grad None changes nothing: it must never get here silently)
+    assert torch.equal(before, model.core.proj.p)
+    out2, _ = eng(**to_call(raw))
+    eng.backward(out2.loss)                                  # the engine of this path takes the same loss object
+    eng.step()
+    # generate(): sampling / penalty knobs other than the reference's defaults are rejected, not ignored
+    for kw in (dict(do_sample=True), dict(top_p=0.9), dict(repetition_penalty=1.2), dict(temperature=0.7)):
+        with pytest.raises(NotImplementedError, match=next(iter(kw))):
+            model.generate(**to_call(raw), targets=["a"] * 2, **kw)
+
+
 def test_noise_draws_replay_reference_rng():
     """Same seed -> the same (alpha, keep) as the reference drew in tests/golden/text_noise_right.npz."""
     b, z = golden_batch("text_noise_right")
