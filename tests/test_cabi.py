@@ -170,5 +170,6 @@ def test_rccl_binding_picks_the_mapped_copy_and_refuses_a_second_one():
             out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300).stdout.split("\n")
             avail, rc, why = out[0].split(" ", 2)
             assert (avail, rc) == ("0", "2") and "second RCCL" in why and out[1] == "1", out
+    from ps_slm_amd import _lib
     lib = _lib.load()
     assert lib.tasu_comm_count(None, None) == 1 and lib.tasu_comm_library(None, 0) == 1
