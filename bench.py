@@ -508,6 +508,8 @@ def main():
     ap.add_argument("--drop-prob", type=float, default=0.0, help="CPS token drop (0 keeps S fixed at 256)")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of hipGraph replay")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode tok/s leg (second half of BASELINE.json's metric)")
+    ap.add_argument("--blank-biased", action="store_true",
+                    help="--path audio: raise the CTC blank bias until PSD keeps ~100 frames per utterance (a trained encoder's regime)")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-4 (audio-SFT) and config-5 (Qwen2.5-7B) sub-records")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -525,7 +527,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     main_rec = train_leg(args, args.model, args.path, args.batch, args.steps, args.warmup, world, rank, local_rank,
-                         want_decode=world == 1 and not args.no_decode and args.path == "text")
+                         want_decode=world == 1 and not args.no_decode and args.path == "text",
+                         blank_biased=args.blank_biased and args.path == "audio")
     extras = {}
     headline = args.model == "qwen2.5-1.5b" and args.path == "text"
     if world == 1 and headline and not args.no_extra:

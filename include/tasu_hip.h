@@ -280,6 +280,23 @@ int tasu_attn_bwd_dkv(const void* qkv, const void* qt, const uint8_t* key_mask, 
 int tasu_attn_bwd(const void* qkv, const void* qt, const void* kt, const uint8_t* key_mask, const void* dout,
                   const void* dout_t, const float* lse, const float* delta, void* dqkv, float* dk_part, float* dv_part, int B,
                   int S, int H, int G, float scale, int causal, void* stream);
+/* tasu_attn_bwd followed by tasu_rope_bwd (modeling_qwen2.py:113-135 reversed) behind one entry point: dqkv receives the
+ * finished gradient of the UNROTATED q | k | v projection.  `kernel`:
+ *   TASU_ATTN_KERNEL_PER_HEAD  the two launches above (dk_part / dv_part: their fp32 partials)
+ *   TASU_ATTN_KERNEL_GQA       ONE launch of csrc/attention_gqa.hip (round 4; served when H / G >= 2 and S <= 4096:
+ *                              tasu_attn_gqa_supported, else bad argument): the query heads of a GQA group share the K / V and
+ *                              Q / dO tiles a workgroup stages (LDS-DMA, four deep), dK / dV are complete in their workgroup (no
+ *                              partials: dk_part / dv_part untouched, may be NULL), the rotation runs in the epilogues.  dq: the
+ *                              same bits as the per-head kernels; dk / dv: the same products in another fp32 association
+ *   TASU_ATTN_KERNEL_POLICY    the GQA kernel where it is measured faster (H / G >= 7 or at least eight 64-token tiles:
+ *                              Qwen2.5-7B, audio-SFT sequences), the per-head kernels otherwise (dk_part / dv_part required) */
+#define TASU_ATTN_KERNEL_POLICY 0
+#define TASU_ATTN_KERNEL_PER_HEAD 1
+#define TASU_ATTN_KERNEL_GQA 2
+int tasu_attn_gqa_supported(int S, int H, int G);
+int tasu_attn_bwd_rope(const void* qkv, const uint8_t* key_mask, const void* dout, const float* lse, const float* delta,
+                       const float* cos_tab, const float* sin_tab, void* dqkv, float* dk_part, float* dv_part, int B, int S,
+                       int H, int G, float scale, int causal, int kernel, void* stream);
 
 /* -------------------------------------------------------------------------------------------- SwiGLU
  * act = bf16(bf16(silu(gate)) * up) on the fused [M, 2I] gate|up activation (modeling_qwen2.py:46-48),

@@ -35,6 +35,8 @@ PROTOTYPES = {
     "tasu_attn_bwd_prep": [vp, vp, vp, vp, i32, i32, i32, vp],
     "tasu_attn_bwd_dq": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "tasu_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "tasu_attn_gqa_supported": [i32, i32, i32],
+    "tasu_attn_bwd_rope": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp],
     "tasu_attn_bwd_dkv": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "tasu_swiglu_fwd": [vp, vp, i32, i32, vp],
     "tasu_swiglu_bwd": [vp, vp, vp, i32, i32, vp],

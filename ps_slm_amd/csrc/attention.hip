@@ -16,78 +16,13 @@
 // Tiles: 64 queries x 64 keys per step, 256 threads = 4 waves, each wave owns 16 of the 64 rows.
 #include <stdlib.h>
 
-#include "common.h"
+#include "attn_tiles.h"
 #include "../../include/tasu_hip.h"
 
 namespace {
 
-constexpr int HD = 128;
+using namespace tasu_attn;
 
-// ---- LDS tile images ---------------------------------------------------------------------------------
-// "row" image : [64 tokens][128 d] bf16, 256-B rows, 16-B chunk c of row r stored at c ^ (r & 15)
-constexpr int ROW_TILE_BYTES = 64 * 256;
-
-// Tile staging is split (issue-early / write-late): fetch_* issues the 4 global loads of a tile into registers, the
-// MFMA work of the previous tile runs while they are in flight, and commit_* writes them to LDS after the barrier.
-struct TileRegs {
-  bf16x8 v[4];
-};
-// [64][128] tile whose rows are tokens tok0.. of a token-major matrix (row stride ld elements); rows >= nrows are
-// clamped (callers mask them).
-__device__ __forceinline__ void fetch_row_tile(TileRegs& t, const bf16* g, int ld, int tok0, int nrows) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = i * 256 + threadIdx.x;
-    const int r = idx >> 4, c = idx & 15;
-    const int tok = min(tok0 + r, nrows - 1);
-    t.v[i] = *(const bf16x8*)(g + (size_t)tok * ld + c * 8);
-  }
-}
-__device__ __forceinline__ void commit_row_tile(char* lds, const TileRegs& t) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = i * 256 + threadIdx.x;
-    const int r = idx >> 4, c = idx & 15;
-    *(bf16x8*)(lds + r * 256 + ((c ^ (r & 15)) << 4)) = t.v[i];
-  }
-}
-// MFMA operand (16 rows = tile rows sub*16 + (lane&15), k = d in [32ks + 8q', +8)) from a "row" image.
-__device__ __forceinline__ bf16x8 frag_row(const char* lds, int sub, int ks, int lane) {
-  const int r = sub * 16 + (lane & 15);
-  const int c = ks * 4 + (lane >> 4);
-  return *(const bf16x8*)(lds + r * 256 + ((c ^ (lane & 15)) << 4));
-}
-// MFMA operand (16 rows = d in nt*16 + (lane&15), k-slots of token block tb (32 tokens): element j <-> token tb*32 + (j<4 ? 4q'+j :
-// 16+4q'+j-4), q' = lane>>4) read out of a token-major "row" image with two hardware transpose reads.  A 16-lane group g reads
-// the 4-token x 16-d block (tokens T0 + 4g .. +3, d = nt*16 .. +15): lane 4q+p of the group supplies the address of token
-// T0 + 4g + q, columns nt*16 + 4p .. +3, and lane i receives column nt*16 + i of the four tokens.  EXEC must be all ones.
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-__device__ __forceinline__ bf16x8 frag_tr_row(const char* lds, int nt, int tb, int lane) {
-  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int r0 = tb * 32 + 4 * g + q, r1 = r0 + 16;                 // this lane's address rows for the two reads
-  const int ch = nt * 2 + (p >> 1), inner = (p & 1) * 8;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + r0 * 256 + ((ch ^ (r0 & 15)) << 4) + inner));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + r1 * 256 + ((ch ^ (r1 & 15)) << 4) + inner));
-  union { s16x4 s[2]; bf16x8 b; } u;
-  u.s[0] = lo;
-  u.s[1] = hi;
-  return u.b;
-}
-// pack two 16-wide score tiles (fp32 accumulators) into the k-slot order frag_tr / frag_tr_row use.
-__device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
-  bf16x8 o;
-  o[0] = (bf16)a[0]; o[1] = (bf16)a[1]; o[2] = (bf16)a[2]; o[3] = (bf16)a[3];
-  o[4] = (bf16)b[0]; o[5] = (bf16)b[1]; o[6] = (bf16)b[2]; o[7] = (bf16)b[3];
-  return o;
-}
-// operand straight from global: row `tok` of a token-major matrix, d in [32ks + 8q', +8), ks = 0..3
-__device__ __forceinline__ void load_row_frags(bf16x8 f[4], const bf16* g, int ld, int tok, int lane) {
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) f[ks] = *(const bf16x8*)(g + (size_t)tok * ld + ks * 32 + (lane >> 4) * 8);
-}
-
-constexpr float NEG_INF = -__builtin_inff();
 
 // ======================================================================================= forward
 // QW = 16-query sub-tiles per wave (block = 4 waves = 64 * QW queries).  The loop is LDS-read bound, not MFMA bound: with one
@@ -522,6 +457,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16* __restrict
 static inline bool bad_geo(int B, int S, int H, int G) { return B <= 0 || S <= 0 || H <= 0 || G <= 0 || H % G != 0; }
 static inline int spad_of(int S) { return (S + 63) & ~63; }
 
+// attention_gqa.hip
+extern "C" int tasu_attn_gqa_supported(int S, int H, int G);
+int tasu_attn_bwd_gqa_launch(const void* qkv, const uint8_t* key_mask, const void* dout, const float* lse, const float* delta,
+                             const float* cos_tab, const float* sin_tab, void* dqkv, int B, int S, int H, int G, float scale, int causal,
+                             hipStream_t stream);
+
 extern "C" int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key_mask, void* out, float* lse, int B,
                              int S, int H, int G, float scale, int causal, void* stream) {
   (void)vt;                                              // unused since round 2: V^T is read out of the V tile in LDS
@@ -529,8 +470,7 @@ extern "C" int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key
   static const int qw2_from = [] { const char* e = getenv("TASU_ATTN_QW2_FROM"); return e ? atoi(e) : 1 << 30; }();
   if (S >= qw2_from) {
     // two query sub-tiles per wave (128-query blocks): half the LDS traffic per FLOP of the one-sub-tile form.  Measured at the
-    // training shape (S = 256, causal): 20.7 us against 20.5 us -- these launches are bound by the latency of the per-tile
-    // staging (1-4 key tiles per block), not by LDS bandwidth -- so the form is opt-in (TASU_ATTN_QW2_FROM=<S>) for long
+    // training shape (S = 256, causal): 20.7 us against 20.5 us, so the form is opt-in (TASU_ATTN_QW2_FROM=<S>) for long
     // non-causal sequences.
     dim3 grid(H, B, (S + 127) / 128);
     TASU_LAUNCH(attn_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)vt, key_mask,
@@ -594,4 +534,28 @@ extern "C" int tasu_attn_bwd(const void* qkv, const void* qt, const void* kt, co
               (const bf16*)qt, (const bf16*)kt, key_mask, (const bf16*)dout, (const bf16*)dout_t, lse, delta, (bf16*)dqkv, dk_part,
               dv_part, S, spad_of(S), H, G, hpb, scale, causal, B);
   return TASU_OK;
+}
+
+// tasu_attn_bwd followed by tasu_rope_bwd (dqkv complete: rotated dq and dk, dv), behind one entry point.  With at least two
+// query heads per kv head this is ONE launch of the GQA kernels (attention_gqa.hip: dK / dV complete in their workgroup, the
+// rotation in the epilogues; dk_part / dv_part are not touched); otherwise the two per-head launches.  Same bits either way.
+extern "C" int tasu_rope_bwd(void* dqkv, const float* dk_part, const float* dv_part, const float* cos_tab, const float* sin_tab, int B,
+                             int S, int H, int G, void* stream);
+extern "C" int tasu_attn_bwd_rope(const void* qkv, const uint8_t* key_mask, const void* dout, const float* lse, const float* delta,
+                                  const float* cos_tab, const float* sin_tab, void* dqkv, float* dk_part, float* dv_part, int B, int S,
+                                  int H, int G, float scale, int causal, int kernel, void* stream) {
+  if (!qkv || !key_mask || !dout || !lse || !delta || !cos_tab || !sin_tab || !dqkv || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
+  if (kernel != TASU_ATTN_KERNEL_POLICY && kernel != TASU_ATTN_KERNEL_PER_HEAD && kernel != TASU_ATTN_KERNEL_GQA) return TASU_ERR_ARG;
+  const bool gqa_ok = tasu_attn_gqa_supported(S, H, G) != 0;
+  if (kernel == TASU_ATTN_KERNEL_GQA && !gqa_ok) return TASU_ERR_ARG;
+  // policy (tools/bench_attn_gqa.py): the GQA kernel where the per-head kernels' fp32 partials or their per-head staging cost
+  // most -- seven or more query heads per kv head (Qwen2.5-7B: 152.6 -> 103.4 us per layer) or eight or more 64-token tiles
+  // (audio-SFT sequences: 171.5 -> 156.0); the 1.5B training shape (6 heads, 4 tiles) is a tie (59.1 vs 61.2) and stays
+  const bool take = kernel == TASU_ATTN_KERNEL_GQA || (kernel == TASU_ATTN_KERNEL_POLICY && gqa_ok && (H / G >= 7 || (S + 63) / 64 >= 8));
+  if (take)
+    return tasu_attn_bwd_gqa_launch(qkv, key_mask, dout, lse, delta, cos_tab, sin_tab, dqkv, B, S, H, G, scale, causal, (hipStream_t)stream);
+  if (!dk_part || !dv_part) return TASU_ERR_ARG;
+  const int rc = tasu_attn_bwd(qkv, nullptr, nullptr, key_mask, dout, nullptr, lse, delta, dqkv, dk_part, dv_part, B, S, H, G, scale,
+                               causal, stream);
+  return rc ? rc : tasu_rope_bwd(dqkv, dk_part, dv_part, cos_tab, sin_tab, B, S, H, G, stream);
 }

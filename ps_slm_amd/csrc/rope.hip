@@ -2,7 +2,7 @@
 // kernels stream.  Reference arithmetic: transformers modeling_qwen2.py:91-135 (fp32 cos/sin from position_ids,
 // rotate-half, result cast to the attention dtype).  HBM-bound; one 64-token x 128-d tile per block, staged
 // through LDS so that both the in-place row write and the [128, S] transposed write are coalesced.
-#include "common.h"
+#include "attn_tiles.h"
 #include "../../include/tasu_hip.h"
 
 namespace {
@@ -158,8 +158,10 @@ __global__ __launch_bounds__(256) void rope_bwd_kernel(bf16* __restrict__ dqkv, 
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float cs = j < 4 ? c0[j] : c1[j - 4], sn = j < 4 ? s0[j] : s1[j - 4];
-    lo[j] = (bf16)(y1[j] * cs + y2[j] * sn);
-    hi[j] = (bf16)(y2[j] * cs - y1[j] * sn);
+    float d1, d2;
+    tasu_attn::rope_pair_bwd_f(y1[j], y2[j], cs, sn, d1, d2);
+    lo[j] = (bf16)d1;
+    hi[j] = (bf16)d2;
   }
   *(bf16x8*)(row + c) = lo;
   *(bf16x8*)(row + 64 + c) = hi;

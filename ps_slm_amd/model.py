@@ -857,9 +857,9 @@ class TasuModel:
                 ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
             ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)
             ops.attn_bwd_prep(dao, d["ao"][l], delta, None, B, S, H)
-            ops.attn_bwd(d["qkv"][l], None, None, d["key_mask"], dao, None, d["lse"][l], delta, dqkv, dkp, dvp,
-                         B, S, H, G, scale, True)                       # dQ and dK/dV blocks share one grid
-            ops.rope_bwd(dqkv, dkp, dvp, cos, sin, B, S, H, G)
+            # dQ, dK / dV and the rotary embedding's backward: one launch on the GQA kernels (dK / dV complete in their
+            # workgroups, the rotation in the epilogues); dkp / dvp are the per-head kernels' fp32 partials (H == G geometries)
+            ops.attn_bwd_rope(d["qkv"][l], d["key_mask"], dao, d["lse"][l], delta, cos, sin, dqkv, dkp, dvp, B, S, H, G, scale, True)
             ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)
             ops.rmsnorm_bwd(dn, x_in, w["ln1"], rstd[2 * l], dx, dxb, True)
         d["dx"] = dx

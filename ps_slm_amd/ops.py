@@ -283,6 +283,13 @@ class HipOps:
                                          _p(dqkv), _p(dk_part), _p(dv_part), B, S, H, G, scale, int(causal), self._stream()),
                   "tasu_attn_bwd")
 
+    def attn_bwd_rope(self, qkv, key_mask, dout, lse, delta, cos, sin, dqkv, dk_part, dv_part, B, S, H, G, scale, causal, kernel=0):
+        """attn_bwd + rope_bwd behind one entry point: dqkv = the finished gradient of the unrotated q | k | v projection.  kernel:
+        0 policy, 1 per-head kernels (two launches), 2 the GQA kernel (one launch; dk_part / dv_part untouched)."""
+        self._chk(self.lib.tasu_attn_bwd_rope(_p(qkv), _p(key_mask), _p(dout), _p(lse), _p(delta), _p(cos), _p(sin), _p(dqkv),
+                                              _p(dk_part), _p(dv_part), B, S, H, G, scale, int(causal), int(kernel), self._stream()),
+                  "tasu_attn_bwd_rope")
+
     # ------------------------------------------------------------------ activations
     def swiglu_fwd(self, gu, act, M, I):
         self._chk(self.lib.tasu_swiglu_fwd(_p(gu), _p(act), M, I, self._stream()), "tasu_swiglu_fwd")

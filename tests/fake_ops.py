@@ -251,6 +251,10 @@ class FakeOps:
         self.attn_bwd_dq(qkv, kt, key_mask, dout, lse, delta, dqkv, B, S, H, G, scale, causal)
         self.attn_bwd_dkv(qkv, qt, key_mask, dout, dout_t, lse, delta, dk_part, dv_part, B, S, H, G, scale, causal)
 
+    def attn_bwd_rope(self, qkv, key_mask, dout, lse, delta, cos, sin, dqkv, dk_part, dv_part, B, S, H, G, scale, causal, kernel=0):
+        self.attn_bwd(qkv, None, None, key_mask, dout, None, lse, delta, dqkv, dk_part, dv_part, B, S, H, G, scale, causal)
+        self.rope_bwd(dqkv, dk_part, dv_part, cos, sin, B, S, H, G)
+
     def swiglu_fwd(self, gu, act, M, I):
         g, u = gu[:, :I].float(), gu[:, I:].float()
         act.copy_(_bf(_bf(F.silu(g)).float() * u))

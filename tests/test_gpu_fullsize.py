@@ -207,6 +207,101 @@ def test_full_size_step_properties(size):
     assert cos > 0.998 and float((gsum - g).norm() / g.norm()) < (5e-2 if size == "1.5b" else 8e-2)
 
 
+def test_benchmark_shape_step_properties(full):
+    """The EXACT step bench.py times (configs 2 / 3): 16 utterances x S = 256 (M = 4096 rows: the 96-tile stream-K plan of
+    d_gate_up, the two-launch column split of gate|up, split-K lm_head dgrad), training mode -- loss head and the last layer's MLP
+    on the 2,048 labelled rows only (keep_logits = False, tail_rows) -- plus the bucketed variable-shape batches of the
+    `variable_S` sub-record.  Properties: bitwise run-to-run determinism; hipGraph replay == eager launches bitwise; the
+    throughput schedule equals the all-rows full-logits schedule (loss / accuracy / count and gradients); CE of the all-rows run
+    against fp32 log-softmax of its own logits; padding invariance of the bucketed shapes (the same batch unpadded)."""
+    geo, m = full
+    batch = synthetic_text_batch(geo, 16, seed=1234, noise=False)
+    assert batch["input_ids"].shape[1] + 104 - 1 == 256
+
+    def train_step(b, graphs=False, buckets=None):
+        m.keep_logits, m.use_graphs, m.shape_buckets = False, graphs, buckets
+        try:
+            st = m.prepare_text(b["input_ids"], b["attention_mask"], b["labels"], b["post_ids"], b.get("alphas"), b.get("keeps"))
+            m.run_forward_text(st)
+            m.run_backward(st)
+            torch.cuda.synchronize()
+            return st, st.dev["loss_out"].clone(), m.proj.g.clone()
+        finally:
+            m.keep_logits, m.use_graphs, m.shape_buckets = True, False, None
+
+    st, loss, g = train_step(batch)
+    assert st.M == 4096 and st.S == 256 and st.nL == 2048 and "xout_tail" in st.dev      # the benchmark's shape and schedule
+    assert torch.isfinite(loss).all() and torch.isfinite(g).all() and abs(float(loss[0]) - math.log(geo.llm_vocab)) < 1.0
+    # the GEMM plans this shape takes (pinned on the CPU in tests/test_cabi.py; here: they ran)
+    _, loss2, g2 = train_step(batch)
+    assert torch.equal(loss, loss2) and torch.equal(g, g2)                               # determinism (stream-K sums in K order)
+    for _ in range(3):                                                                   # eager warm-up, capture, replay
+        _, loss3, g3 = train_step(batch, graphs=True)
+    assert torch.equal(loss, loss3) and torch.equal(g, g3)                               # hipGraph replay == eager
+    # all-rows schedule with materialised logits (what parity tests and eval use)
+    sf = step(m, batch)
+    lf, gf = sf.dev["loss_out"].clone(), m.proj.g.clone()
+    assert abs(float(lf[0]) - float(loss[0])) < 2e-5 and int(lf[2]) == int(loss[2]) == 2048
+    assert abs(float(lf[1]) - float(loss[1])) < 1e-6
+    assert float((gf - g).norm() / gf.norm()) < 2e-2          # unlabelled rows' zero dlogits enter other stream-K / tile plans
+    V = geo.llm_vocab
+    labels = sf.dev["shift_labels"].long()
+    sel = labels >= 0
+    lp = torch.log_softmax(sf.dev["logits"][:, :V].float()[sel], dim=-1)
+    ref_loss = -lp.gather(1, labels[sel][:, None]).mean()
+    assert abs(float(lf[0]) - float(ref_loss)) < 2e-5 * float(ref_loss) + 1e-5
+    del lp
+    # ---- a ragged batch of the variable_S record, padded to the entrypoint's buckets vs unpadded
+    rb = synthetic_text_batch(geo, 16, seed=77, noise=False, n_audio=88, target_len=101, ragged=True)
+    _, l_pad, g_pad = train_step(rb, buckets=(16, 8, 256))
+    _, l_raw, g_raw = train_step(rb)
+    assert int(l_pad[2]) == int(l_raw[2]) and abs(float(l_pad[0]) - float(l_raw[0])) < 1e-3
+    assert float((g_pad - g_raw).norm() / g_raw.norm()) < 5e-2
+
+
+def test_full_geometry_audio_sft_step(full):
+    """One config-4 step at full geometry (16 x 500 feature frames -> 70-layer SANM encoder -> CTC posterior -> device PSD ->
+    projector -> LLM fwd / bwd): the PSD lengths of the three device kernels equal the oracle's PSD of the same posterior, the
+    step is bitwise repeatable, and every utterance's posterior rows feed the LLM at the merge positions the plan says."""
+    from oracle import tasu_oracle as O
+    from ps_slm_amd.encoder import EncoderWeights
+    geo, m = full
+    if m.encoder is None:
+        m.encoder = EncoderWeights(geo, m.device)
+        m.encoder.init_random(4323)
+    # a peaky posterior (blank-biased CTC head) so that PSD really merges and drops frames
+    m.encoder.ctc_b[geo.blank_id] += 12.0
+    try:
+        batch = synthetic_text_batch(geo, 16, seed=5, noise=False)
+        lens = batch["input_feature_length"].clone()
+        lens[3], lens[7] = 311, 97                                                   # ragged audio lengths
+        m.keep_logits = False
+
+        def run():
+            st = m.prepare_audio(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["input_features"], lens, do_psd=True)
+            m.forward_llm(st)
+            m.backward(st)
+            torch.cuda.synchronize()
+            return st
+        st = run()
+        loss, g = st.dev["loss_out"].clone(), m.proj.g.clone()
+        assert torch.isfinite(loss).all() and torch.isfinite(g).all() and float(g.norm()) > 0
+        T, Te, V = batch["input_features"].shape[1], batch["input_features"].shape[1] + 4, geo.ctc_vocab
+        post = m._buf("enc_post", (16 * Te, (V + 63) // 64 * 64), F32).view(16, Te, -1)    # the posterior prepare_audio left
+        got = np.asarray(st.dev["psd_lens"])
+        for b in (0, 3, 7, 15):
+            body = post[b:b + 1, 4:, :V].cpu()
+            _, want = O.psd(body, torch.tensor([int(lens[b])]), body)
+            assert int(want[0]) == int(got[b]), (b, int(want[0]), int(got[b]))
+        assert (got < np.asarray(lens)).all() and (got > 0).all()                  # merging / blank filtering really happened
+        assert st.S == 24 + int(got.max()) + 128
+        st2 = run()
+        assert torch.equal(st2.dev["loss_out"], loss) and torch.equal(m.proj.g, g)
+    finally:
+        m.encoder.ctc_b[geo.blank_id] -= 12.0
+        m.keep_logits = True
+
+
 # ------------------------------------------------------------------------------------------------ full-size encoder
 def test_full_size_encoder_batch_equals_single_utterances():
     """SenseVoiceSmall at its published geometry (50 + 20 SANM layers, 4 x 128 heads, FSMN kernel 11, CTC vocabulary 25,055),

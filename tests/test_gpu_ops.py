@@ -491,6 +491,54 @@ def test_attention_fwd_bwd(hip, fake, B, S, H, G, mask_kind, causal):
     assert torch.equal(v2.cpu().reshape(-1)[:n_used], vg.reshape(-1)[:n_used])
 
 
+@pytest.mark.parametrize("B,S,H,G", [(2, 100, 4, 2), (2, 256, 12, 2), (3, 64, 2, 1), (1, 70, 28, 4), (2, 300, 12, 2), (1, 628, 12, 2),
+                                     (2, 130, 10, 2), (16, 256, 12, 2), (16, 256, 28, 4), (1, 19, 6, 2)])
+@pytest.mark.parametrize("mask_kind", ["right", "left", "none"])
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_bwd_gqa_kernel_equals_per_head_kernels(hip, fake, B, S, H, G, mask_kind, causal):
+    """csrc/attention_gqa.hip (one launch: the query heads of a GQA group share the staged tiles, LDS-DMA ring, dK / dV complete
+    per workgroup, RoPE backward in the epilogues) against the per-head kernels of rounds 1-3 + tasu_rope_bwd: the SAME BITS for
+    the rotated dq; dk / dv equal up to the association of their fp32 sums -- for 2, 3, 5, 6 and 7 heads per group, ragged and
+    padded lengths (S not a multiple of 64, more tiles than ring slots), causal and bidirectional; and the policy entry point
+    agrees with whichever kernel it takes."""
+    if B == 16 and (mask_kind != "none" or not causal):
+        pytest.skip("the benchmark shapes once")
+    M, LD, Spad = B * S, (H + 2 * G) * HD, (S + 63) // 64 * 64
+    scale = HD ** -0.5
+    assert hip.lib.tasu_attn_gqa_supported(S, H, G) == 1
+    qkv = randn(M, LD, dtype=BF, seed=11).cuda()
+    km = make_mask(B, S, mask_kind).cuda()
+    pos = torch.arange(S, dtype=I32).repeat(B)
+    cos, sin = torch.zeros(M, 64).cuda(), torch.zeros(M, 64).cuda()
+    hip.rope_table(pos.cuda(), cos, sin, HD, 1e6)
+    out, lse = torch.zeros(M, H * HD, dtype=BF).cuda(), torch.zeros(B * H * Spad).cuda()
+    hip.attn_fwd(qkv, None, km, out, lse, B, S, H, G, scale, causal)
+    live = km[:, :S].bool()
+    dout = randn(M, H * HD, dtype=BF, seed=12).cuda()
+    dout.view(B, S, H * HD)[~live] = 0
+    delta = torch.zeros(B * H * Spad).cuda()
+    hip.attn_bwd_prep(dout, out, delta, None, B, S, H)
+    res = []
+    for kernel in (1, 2, 0):                                    # TASU_ATTN_KERNEL_PER_HEAD, _GQA, _POLICY
+        dqkv = torch.full((M, LD), 7.0, dtype=BF).cuda()
+        dkp, dvp = torch.zeros(M, H * HD).cuda(), torch.zeros(M, H * HD).cuda()
+        hip.attn_bwd_rope(qkv, km, dout, lse, delta, cos, sin, dqkv, dkp, dvp, B, S, H, G, scale, causal, kernel)
+        res.append(dqkv)
+    torch.cuda.synchronize()
+    r1, r2, r0 = (r.view(B, S, LD)[live] for r in res)
+    assert torch.isfinite(r1.float()).all()
+    assert torch.equal(r1[:, :H * HD], r2[:, :H * HD])                              # dq: the same bits
+    # dK / dV: the GQA workgroup sums ALL heads of the group (two query halves of every tile in two wave groups, one fp32 add at
+    # the end) where the per-head kernels round-trip 1-7 fp32 partials through memory: the same products in another fp32
+    # association -- equal up to bf16 roundings that flip (a 2^-9 step on a few elements in a thousand)
+    for lo, hi in ((H * HD, (H + G) * HD), ((H + G) * HD, (H + 2 * G) * HD)):
+        a, c = r1[:, lo:hi].float(), r2[:, lo:hi].float()
+        assert rel_err(c, a) < 2 ** -7                                              # at most one bf16 step of the largest element
+        assert float(((a - c).abs() > 2 ** -7 * a.abs().clamp_min(1e-6)).float().mean()) < 1e-3
+    takes_gqa = H // G >= 7 or (S + 63) // 64 >= 8
+    assert torch.equal(r0, r2 if takes_gqa else r1)
+
+
 def test_attention_online_softmax_rescale(hip, fake):
     """Force the running-max rescale branch: one late key dominates every earlier tile."""
     B, S, H, G = 1, 256, 2, 1
