@@ -72,9 +72,9 @@ __device__ __forceinline__ void st_out(T* dst, T v) {
   if constexpr (!WT) {
     *dst = v;
   } else if constexpr (sizeof(T) == 16) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");   // (s_nop: the store reads its data registers late)
   } else if constexpr (sizeof(T) == 8) {
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
   } else {
     const unsigned bits = __builtin_bit_cast(unsigned short, v);
     asm volatile("global_store_short %0, %1, off sc1" ::"v"(dst), "v"(bits) : "memory");
