@@ -340,6 +340,8 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         # bisection on the blank logit's bias: forward passes only, until PSD keeps 90-110 rows per utterance
         enc = core.encoder
         lo_b, hi_b, bias0 = 0.0, 30.0, float(enc.ctc_b[geo.blank_id])
+        if getattr(args, "blank_bias", None) is not None:
+            lo_b = hi_b = float(args.blank_bias)
         for _ in range(12):
             mid_b = 0.5 * (lo_b + hi_b)
             enc.ctc_b[geo.blank_id] = bias0 + mid_b
@@ -510,6 +512,8 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the decode tok/s leg (second half of BASELINE.json's metric)")
     ap.add_argument("--blank-biased", action="store_true",
                     help="--path audio: raise the CTC blank bias until PSD keeps ~100 frames per utterance (a trained encoder's regime)")
+    ap.add_argument("--blank-bias", type=float, default=None,
+                    help="--path audio --blank-biased: use this bias instead of searching for it (profiled runs: no search passes in the trace)")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-4 (audio-SFT) and config-5 (Qwen2.5-7B) sub-records")
     args = ap.parse_args()
     if args.cpu_baseline_worker:

@@ -56,6 +56,11 @@ int tasu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, i
 int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                          const float* resid, int M, int N, int K, int out_mode, void* workspace,
                          int64_t workspace_bytes, void* stream);
+/* C = bf16(relu(bf16(A . B^T + bias))): PositionwiseFeedForward's w_1 followed by its ReLU (Multitask/model/SenseVoice.py:71-73) in
+ * one launch -- the ReLU runs in the GEMM kernels' epilogue (max before the single bf16 rounding: the same bits as tasu_gemm_nt_bf16
+ * + tasu_relu_fwd, which is what runs for the at-most-128-row shapes the small-tile kernels serve; those need ldc == N).  */
+int tasu_gemm_bias_relu_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias, int M, int N, int K,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 /* tasu_gemm_nt_bf16 on a NAMED kernel, regardless of the tile policy of tasu_gemm_nt_bf16_ws (tests compare the kernels with
  * each other bit for bit -- they accumulate every output element in the same K order -- and tuning runs time them side by side):

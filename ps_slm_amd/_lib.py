@@ -17,6 +17,7 @@ PROTOTYPES = {
     "tasu_abi_version": [],
     "tasu_gemm_nt_bf16": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
     "tasu_gemm_nt_bf16_ws": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
+    "tasu_gemm_bias_relu_bf16": [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, i64, vp],
     "tasu_gemm_gate_up_swiglu": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp],
     "tasu_gemm_nt_bf16_kernel": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "tasu_gemm_skinny_bf16": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],

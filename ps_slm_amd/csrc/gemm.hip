@@ -516,6 +516,31 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
   }
 }
 
+namespace tasu_gemm {
+int& relu_next() {
+  static thread_local int flag = 0;
+  return flag;
+}
+}  // namespace tasu_gemm
+
+extern "C" int tasu_relu_fwd(const void* x, void* y, int64_t n, void* stream);
+// C = bf16(relu(bf16(A . B^T + bias))): PositionwiseFeedForward's w_1 + ReLU (SenseVoice.py:71-73) in one launch -- the ReLU in
+// the GEMM kernels' epilogue (max before the one bf16 rounding: the same bits as rounding first); shapes the small-tile kernels
+// of gemm.hip serve (at most 128 rows) run the GEMM and tasu_relu_fwd in place.
+extern "C" int tasu_gemm_bias_relu_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias, int M, int N,
+                                        int K, void* workspace, int64_t workspace_bytes, void* stream) {
+  int plan = 0;
+  int rc = gemm_policy(A, lda, B, ldb, C, ldc, bias, nullptr, M, N, K, TASU_GEMM_OUT_BF16, workspace, workspace_bytes, stream, &plan);
+  if (rc) return rc;
+  const bool fused = plan != TASU_GEMM_PLAN_TILES && plan != TASU_GEMM_PLAN_TILE192_SPLITK;
+  tasu_gemm::relu_next() = fused ? 1 : 0;
+  rc = gemm_policy(A, lda, B, ldb, C, ldc, bias, nullptr, M, N, K, TASU_GEMM_OUT_BF16, workspace, workspace_bytes, stream);
+  tasu_gemm::relu_next() = 0;
+  if (rc || fused) return rc;
+  if (ldc != N) return TASU_ERR_ARG;                       // (the in-place ReLU walks a dense matrix)
+  return tasu_relu_fwd(C, C, (int64_t)M * N, stream);
+}
+
 extern "C" int tasu_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* bias,
                                     const float* resid, int M, int N, int K, int out_mode, void* workspace,
                                     int64_t workspace_bytes, void* stream) {

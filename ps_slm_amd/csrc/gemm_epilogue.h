@@ -41,7 +41,11 @@ struct Args {
   float* sk_partial = nullptr;
   int* sk_flags = nullptr;
   double sk_rem = -2.0;  // host side only: sk_plan's max_rem for this launch (-2 = the library default / TASU_GEMM_SK*)
+  int relu = 0;          // TASU_GEMM_OUT_BF16 only: C = bf16(max(acc + bias, 0)) (tasu_gemm_bias_relu_bf16: PositionwiseFeedForward w_1)
 };
+
+// set by tasu_gemm_bias_relu_bf16 around its call of the dispatcher (host; the dispatchers copy it into Args::relu)
+int& relu_next();
 
 // The work-item list of a workgroup of the 256 x 256 kernel (gemm_pp.hip), as one piece of host / device code so that the
 // schedule can be checked on the CPU (tasu_streamk_schedule, tests/test_cabi.py).  Whole tiles (and K-range slabs) are dealt
@@ -404,6 +408,10 @@ __device__ __forceinline__ void store_tile(const Args& p, f32x4 (&acc)[MI][NI], 
 #pragma unroll
               for (int r = 0; r < 4; ++r) v0[r] += bv[j][r], v1[r] += bv[j + 1][r];
             }
+            if (p.relu) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v0[r] = fmaxf(v0[r], 0.f), v1[r] = fmaxf(v1[r], 0.f);
+            }
             union { bf16x4 h; unsigned u[2]; } a, b;
             a.h = __builtin_convertvector(v0, bf16x4);
             b.h = __builtin_convertvector(v1, bf16x4);
@@ -477,6 +485,10 @@ __device__ __forceinline__ void store_tile(const Args& p, f32x4 (&acc)[MI][NI], 
       const size_t off = (size_t)m * p.ldc + n;
       const bool full = (n + 4 <= p.N) && ((off & 3) == 0);
       if (OUT_MODE == TASU_GEMM_OUT_BF16) {
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
         bf16* c = (bf16*)p.C + off;
         const bf16x4 o = __builtin_convertvector(v, bf16x4);
         if (full) {

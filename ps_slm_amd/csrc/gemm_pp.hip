@@ -464,6 +464,7 @@ int tasu_gemm_pp_dispatch(const void* A, int lda, const void* B, int ldb, void* 
   a.C = C;
   a.R = resid;
   a.bias = (const bf16*)bias;
+  a.relu = out_mode == TASU_GEMM_OUT_BF16 ? tasu_gemm::relu_next() : 0;
   a.M = M;
   a.N = N;
   a.K = K;

@@ -132,7 +132,6 @@ def _encoder_body(model, x0, lens, key_mask, B, T):
     xa = buf("enc_xa", (M, E), f32)
     xb = buf("enc_xb", (M, E), f32)
     h = buf("enc_h", (M, Ff), bf)
-    hr = buf("enc_hr", (M, Ff), bf)
     scale = HD ** -0.5
     cur = x                                     # layer input (fp32), width in_dim
     for li, w in enumerate(enc.layers):
@@ -150,10 +149,9 @@ def _encoder_body(model, x0, lens, key_mask, B, T):
         ops.fsmn_fwd(qkv[:, 2 * E:], 3 * E, w["fsmn"], lens, mid, B, Te, E, geo.enc_kernel, True)
         xn2 = buf("enc_xn2", (M, E), bf)
         ops.layernorm_fwd(mid, w["n2"][0], w["n2"][1], xn2, None, None, M, E, 1e-5)
-        ops.gemm(xn2, w["w1"], h, M, Ff, E, bias=w["b1"])
-        ops.relu_fwd(h, hr)
+        ops.gemm_bias_relu(xn2, w["w1"], h, M, Ff, E, w["b1"])                  # w_1 + ReLU: the ReLU in the GEMM's epilogue
         out = xb if mid is xa else xa
-        ops.gemm(hr, w["w2"], out, M, E, Ff, bias=w["b2"], resid=mid, mode=GEMM_RESID)
+        ops.gemm(h, w["w2"], out, M, E, Ff, bias=w["b2"], resid=mid, mode=GEMM_RESID)
         cur = out
     if len(enc.layers) == enc.n_main:           # no tp layers: after_norm still applies
         nxt = xa if cur is not xa else xb

@@ -63,6 +63,11 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_nt_bf16_ws(_p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), _p(resid), M, N, K, mode,
                                                 _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()), "tasu_gemm_nt_bf16_ws")
 
+    def gemm_bias_relu(self, a, b, c, M, N, K, bias):
+        """c = relu(a @ b^T + bias), bf16: the FFN's w_1 + ReLU of the SANM encoder in one launch (tasu_gemm_bias_relu_bf16)."""
+        self._chk(self.lib.tasu_gemm_bias_relu_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(bias), M, N, K,
+                                                    _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()), "tasu_gemm_bias_relu_bf16")
+
     GEMM_KERNELS = {"pp256": 1, "pipe128": 2, "pipe192": 3, "pipe96": 4}
 
     def gemm_on(self, kernel, a, b, c, M, N, K, bias=None, resid=None, mode=GEMM_BF16):

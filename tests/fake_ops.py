@@ -285,6 +285,10 @@ class FakeOps:
     def relu_fwd(self, x, y):
         y.copy_(torch.relu(x))
 
+    def gemm_bias_relu(self, a, b, c, M, N, K, bias):
+        self.gemm(a, b, c, M, N, K, bias=bias)
+        c.copy_(torch.relu(c))
+
     def relu_bwd(self, dy, x, dx):
         dx.copy_(torch.where(x.float() > 0, dy, torch.zeros_like(dy)))
 

@@ -269,8 +269,11 @@ def test_full_geometry_audio_sft_step(full):
     if m.encoder is None:
         m.encoder = EncoderWeights(geo, m.device)
         m.encoder.init_random(4323)
-    # a peaky posterior (blank-biased CTC head) so that PSD really merges and drops frames
-    m.encoder.ctc_b[geo.blank_id] += 12.0
+    # a peaky posterior with a strong blank (the recipe of the encoder test below), so that PSD really merges runs and drops frames
+    saved_w, saved_b = m.encoder.ctc_w.clone(), m.encoder.ctc_b.clone()
+    m.encoder.ctc_w.mul_(6.0)
+    m.encoder.ctc_b.zero_()
+    m.encoder.ctc_b[geo.blank_id] = 4.0
     try:
         batch = synthetic_text_batch(geo, 16, seed=5, noise=False)
         lens = batch["input_feature_length"].clone()
@@ -298,7 +301,8 @@ def test_full_geometry_audio_sft_step(full):
         st2 = run()
         assert torch.equal(st2.dev["loss_out"], loss) and torch.equal(m.proj.g, g)
     finally:
-        m.encoder.ctc_b[geo.blank_id] -= 12.0
+        m.encoder.ctc_w.copy_(saved_w)
+        m.encoder.ctc_b.copy_(saved_b)
         m.keep_logits = True
 
 

@@ -708,6 +708,38 @@ def test_encoder_aux(hip, fake):
     assert rel_err(g, c) < 1e-5
 
 
+def test_encoder_fsmn_and_ffn_relu_at_sensevoice_size(hip, fake):
+    """The two encoder kernels of round 4 at SenseVoiceSmall's layer shape (512 channels, kernel 11, 504-frame rows, ragged):
+    the row-blocked FSMN (4 frames x 8 channels per thread, taps in registers) against the CPU double, with and without
+    accumulation; and PositionwiseFeedForward's w_1 + ReLU in the GEMM epilogue against GEMM + tasu_relu_fwd -- the same bits --
+    on the kernels the encoder's M = 8064 takes and on the small-tile fallback (M = 100)."""
+    B, T, E, ks = 3, 504, 512, 11
+    qkv = randn(B * T, 3 * E, dtype=BF, seed=21)
+    w = randn(E, ks, seed=22, scale=0.2)
+    lens = torch.tensor([504, 333, 7], dtype=I32)
+    c = randn(B * T, E, seed=23)
+    g = c.clone().cuda()
+    fake.fsmn_fwd(qkv[:, 2 * E:], 3 * E, w, lens, c, B, T, E, ks, True)
+    gq = qkv.cuda()
+    hip.fsmn_fwd(gq[:, 2 * E:], 3 * E, w.cuda(), lens.cuda(), g, B, T, E, ks, True)
+    assert rel_err(g, c) < 1e-5
+    c0, g0 = torch.ones(B * T, E), torch.ones(B * T, E).cuda()
+    fake.fsmn_fwd(qkv[:, 2 * E:], 3 * E, w, lens, c0, B, T, E, ks, False)
+    hip.fsmn_fwd(gq[:, 2 * E:], 3 * E, w.cuda(), lens.cuda(), g0, B, T, E, ks, False)
+    assert rel_err(g0, c0) < 1e-5 and float(g0.view(B, T, E)[2, 7:].abs().max()) == 0       # frames past the length: exact zeros
+    for M, N, K in ((8064, 2048, 512), (100, 2048, 512), (4096, 1024, 256)):
+        a = randn(M, K, dtype=BF, seed=M).cuda()
+        wt = (randn(N, K, seed=M + 1) * K ** -0.5).to(BF).cuda()
+        bias = randn(N, dtype=BF, seed=M + 2).cuda()
+        ref = torch.empty(M, N, dtype=BF, device="cuda")
+        hip.gemm(a, wt, ref, M, N, K, bias=bias)
+        hip.relu_fwd(ref, ref)
+        out = torch.full((M, N), -1.0, dtype=BF, device="cuda")
+        hip.gemm_bias_relu(a, wt, out, M, N, K, bias)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref) and float(out.float().min()) == 0.0 and float((out == 0).float().mean()) > 0.2
+
+
 def test_psd_kernels(hip, fake):
     from conftest import load_npz
     z = load_npz("psd_crafted")
