@@ -3,7 +3,7 @@
 // (dQ role) and Q / dO (dK / dV role) tiles staged by LDS-DMA four deep and shared by the query heads of a GQA group.
 //
 //   * tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds), four tile pairs deep (ring of NS = 4 x 32 KiB); the bank
-//     swizzle of the "row" image (attn_tiles.h: 16-B chunk c of row r at c ^ (r & 15)) is applied on the per-lane SOURCE offset,
+//     swizzle of the "row" image (attn_tiles.h: 16-B chunk c of row r at c ^ swz(r)) is applied on the per-lane SOURCE offset,
 //     rows past the end of the sequence are clipped by the buffer descriptor (zeros);
 //   * dQ role: one workgroup = (batch, kv group, 64 queries, up to three query heads per pass), wave = (head, 16 query rows):
 //     the arithmetic, order and rounding of attention.hip's dQ kernel + tasu_rope_bwd -- the same bits;
@@ -13,13 +13,15 @@
 //     7 per kv head at Qwen2.5-7B) and no reduction pass; the same products in another fp32 association.
 //
 // MEASURED (tools/bench_attn_gqa.py, us per layer incl. tasu_attn_bwd_prep, per-head kernels + tasu_rope_bwd -> this kernel):
-// 16 x 256, 28 / 4 heads 152.6 -> 103.4; 16 x 628, 12 / 2 heads 171.5 -> 156.0; 16 x 256, 12 / 2 heads 59.1 -> 61.2.  Both
-// families are bound by the LDS port, not by staging (phase stamps of an instrumented build: an MFMA phase of 16 instructions
-// takes 4x its matrix-pipe time; every 16 x 16 x 32 MFMA consumes a fresh 1-KiB fragment from LDS, i.e. 256 B per clock per
-// CU with four SIMDs issuing): sharing the staged tiles removes the partial sums and the staging chain but not that bound, which
-// is why the per-head kernels keep the training shape of the 1.5B model (tasu_attn_bwd_rope's policy) and why a forward
-// kernel of this family (built, bit-identical, 20.5 us against 19.5) is not in the tree.  What would move both: 32 x 32 x 16
-// MFMAs with two key sub-tiles per wave (half the LDS bytes per FLOP).
+// 16 x 256, 28 / 4 heads 152.6 -> 103.4; 16 x 628, 12 / 2 heads 171.5 -> 156.0; 16 x 256, 12 / 2 heads 59.1 -> 61.2 -- a win
+// where the per-head kernels' partial sums or their staging chain weigh most, a tie at the 1.5B training shape, which the
+// per-head kernels keep (tasu_attn_bwd_rope's policy).  What bounds both families at S = 256 is neither staging nor the LDS port
+// (rocprofv3 --pmc: SQ_LDS_IDX_ACTIVE is 19 % of the kernel's CU cycles, and removing every bank conflict -- attn_tiles.h's swz,
+// SQ_LDS_BANK_CONFLICT 1.47 M -> 0 -- changed no launch time) but the dependent chain inside a wave: fragment read -> 16 MFMAs ->
+// exp / pack -> transposed reads -> 16 MFMAs, with two or three waves per SIMD to cover it (phase stamps of an instrumented
+// build: an MFMA phase takes 2 - 4x its matrix-pipe time; a key-tile step of the forward kernel 2.5 us for 0.25 us of MFMA).
+// A forward kernel of this family (built, bit-identical, 20.5 us against 19.5) is therefore not in the tree; what would move
+// both is a software-pipelined body (the next step's fragment reads issued under the current MFMAs), not another staging scheme.
 #include "attn_tiles.h"
 #include "../../include/tasu_hip.h"
 
@@ -65,12 +67,12 @@ __device__ __forceinline__ void need(const T& v) {
 }
 
 // Per-lane source offsets of a wave's four 1-KiB pieces of a [64][128] tile (row stride ld_bytes): piece p = wave * 4 + i holds
-// tile rows 4p .. 4p + 3; lane l writes LDS chunk l & 15 of row 4p + (l >> 4), which must hold global chunk (l & 15) ^ (row & 15).
+// tile rows 4p .. 4p + 3; lane l writes LDS chunk l & 15 of row 4p + (l >> 4), which must hold global chunk (l & 15) ^ swz(row).
 __device__ __forceinline__ void tile_offsets(int (&voff)[4], int ld_bytes, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (wave * 4 + i) * 4 + (lane >> 4);
-    voff[i] = r * ld_bytes + (((lane & 15) ^ (r & 15)) << 4);
+    voff[i] = r * ld_bytes + (((lane & 15) ^ swz(r)) << 4);
   }
 }
 // DMA of one tile whose first row is `origin` (wave-uniform); rows_left = valid rows from there on (<= 0: all zeros)

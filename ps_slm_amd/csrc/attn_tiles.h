@@ -8,8 +8,17 @@ namespace tasu_attn {
 constexpr int HD = 128;
 
 // ---- LDS tile images ---------------------------------------------------------------------------------
-// "row" image : [64 tokens][128 d] bf16, 256-B rows, 16-B chunk c of row r stored at c ^ (r & 15)
+// "row" image : [64 tokens][128 d] bf16, 256-B rows, 16-B chunk c of row r stored at chunk position c ^ swz(r).
+// swz (round 4): rows 0..7 -> 0, 2, .., 14, rows 8..15 -> 9, 11, 13, 15, 1, 3, 5, 7 (linear over GF(2): bit i of the row
+// contributes 2, 4, 8, 9).  Rounds 1-3 used swz(r) = r & 15, which serves the ROW reads (ds_read_b128: 16 rows x one chunk per
+// lane group) without bank conflicts but not the TRANSPOSE reads: the 32 lanes a ds_read_b64_tr_b16 is served in touch 8
+// consecutive rows x the two chunks of one 16-d block, and r -> r ^ 1 maps chunk 2n of row r onto chunk 2n + 1 of row r ^ 1 --
+// every bank pair is hit twice.  With swz(r) >> 1 distinct over 8 consecutive rows both read forms are conflict-free
+// (tools/lab/lds_swizzle_search.py: the lane groups of MI355X_MICROARCH.md's LDS table).  rocprofv3 --pmc on the training shape
+// (tools/lab/attn_lds_pmc.sh): SQ_LDS_BANK_CONFLICT 491,520 -> 0 (forward), 1,474,560 -> 0 (backward), SQ_LDS_IDX_ACTIVE
+// -24 %; launch times unchanged -- these kernels are not bound by the LDS port (attention_gqa.hip, MEASURED).
 constexpr int ROW_TILE_BYTES = 64 * 256;
+__device__ __forceinline__ int swz(int r) { return ((r & 7) << 1) ^ ((r & 8) ? 9 : 0); }
 
 // Tile staging is split (issue-early / write-late): fetch_* issues the 4 global loads of a tile into registers, the
 // MFMA work of the previous tile runs while they are in flight, and commit_* writes them to LDS after the barrier.
@@ -32,14 +41,14 @@ __device__ __forceinline__ void commit_row_tile(char* lds, const TileRegs& t) {
   for (int i = 0; i < 4; ++i) {
     const int idx = i * 256 + threadIdx.x;
     const int r = idx >> 4, c = idx & 15;
-    *(bf16x8*)(lds + r * 256 + ((c ^ (r & 15)) << 4)) = t.v[i];
+    *(bf16x8*)(lds + r * 256 + ((c ^ swz(r)) << 4)) = t.v[i];
   }
 }
 // MFMA operand (16 rows = tile rows sub*16 + (lane&15), k = d in [32ks + 8q', +8)) from a "row" image.
 __device__ __forceinline__ bf16x8 frag_row(const char* lds, int sub, int ks, int lane) {
   const int r = sub * 16 + (lane & 15);
   const int c = ks * 4 + (lane >> 4);
-  return *(const bf16x8*)(lds + r * 256 + ((c ^ (lane & 15)) << 4));
+  return *(const bf16x8*)(lds + r * 256 + ((c ^ swz(lane & 15)) << 4));
 }
 // MFMA operand (16 rows = d in nt*16 + (lane&15), k-slots of token block tb (32 tokens): element j <-> token tb*32 + (j<4 ? 4q'+j :
 // 16+4q'+j-4), q' = lane>>4) read out of a token-major "row" image with two hardware transpose reads.  A 16-lane group g reads
@@ -51,8 +60,8 @@ __device__ __forceinline__ bf16x8 frag_tr_row(const char* lds, int nt, int tb, i
   const int r0 = tb * 32 + 4 * g + q, r1 = r0 + 16;                 // this lane's address rows for the two reads
   const int ch = nt * 2 + (p >> 1), inner = (p & 1) * 8;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + r0 * 256 + ((ch ^ (r0 & 15)) << 4) + inner));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + r1 * 256 + ((ch ^ (r1 & 15)) << 4) + inner));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + r0 * 256 + ((ch ^ swz(r0)) << 4) + inner));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + r1 * 256 + ((ch ^ swz(r1)) << 4) + inner));
   union { s16x4 s[2]; bf16x8 b; } u;
   u.s[0] = lo;
   u.s[1] = hi;
