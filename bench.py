@@ -90,9 +90,7 @@ class TimedOps:
         return self._timed(self._ops.gemm_qkv_rope, a, k)
 
     def gemm_dswiglu(self, dy, wd_t, gu, dgu, dact_ws, M, I, K):
-        if os.environ.get("TASU_GEMM_DSWIGLU", "0") == "1":            # the SwiGLU backward in the GEMM's epilogue: one launch
-            return self._timed(self._ops.gemm_dswiglu, (dy, wd_t, gu, dgu, dact_ws, M, I, K), {})
-        # default form of tasu_gemm_dswiglu: the GEMM (timed) + tasu_swiglu_bwd (not a GEMM: not timed) -- the same two launches
+        # tasu_gemm_dswiglu = the GEMM (timed) + tasu_swiglu_bwd (not a GEMM: not timed) -- the same two launches
         self.gemm(dy, wd_t, dact_ws, M, I, K)
         return self._ops.swiglu_bwd(dact_ws, gu, dgu, M, I)
 

@@ -92,10 +92,10 @@ int tasu_gemm_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw, const 
  *   dact[M, I] = bf16(dy[M, K] . WdT[I, K]^T)   (WdT = down_proj.weight transposed once at load time: [I, K = hidden])
  *   dgu[m, n]     = bf16(d * u * sig(g) * (1 + g * (1 - sig(g)))),  dgu[m, I + n] = bf16(d * g * sig(g)),
  *   g = gu[m, n], u = gu[m, I + n] (the gate|up matrix tasu_gemm_gate_up_swiglu saved), d = dact[m, n]
- * -- bit-identical to tasu_gemm_nt_bf16 (bf16 output) followed by tasu_swiglu_bwd, which is what runs by default, through
- * dact_ws (bf16 [M, I]).  With TASU_GEMM_DSWIGLU=1 and M > 128 the SwiGLU backward runs in the GEMM kernels' epilogue and dact
- * never reaches memory (same bits; measured worth 0.3 % of the step: DESIGN.md 8).  I % 8 == 0, K % 64 == 0, 16-byte
- * aligned operands; workspace as for tasu_gemm_nt_bf16_ws (may be NULL). */
+ * = tasu_gemm_nt_bf16 (bf16 output) into dact_ws (bf16 [M, I], required) followed by tasu_swiglu_bwd.  (A form with the SwiGLU
+ * backward in the GEMM kernels' epilogue -- dact never reaches memory, same bits -- was measured worth 0.3 % of the step and
+ * lives in the lab build only: make -C ps_slm_amd/csrc lab.)  I % 8 == 0, K % 64 == 0, 16-byte aligned operands; workspace as
+ * for tasu_gemm_nt_bf16_ws (may be NULL). */
 int tasu_gemm_dswiglu(const void* dy, int lddy, const void* WdT, int ldw, const void* gu, void* dgu, void* dact_ws, int M, int I,
                       int K, void* workspace, int64_t workspace_bytes, void* stream);
 /* ... with the workspace of tasu_gemm_nt_bf16_ws (or NULL): the 256 x 256 kernel may then cut its last rounds of tiles along K
@@ -216,12 +216,6 @@ int tasu_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, float* rstd, 
  * gradient the next dgrad GEMM consumes.                                                                */
 int tasu_rmsnorm_bwd(const void* dy_bf16, const float* x, const float* w, const float* rstd, float* dx,
                      void* dx_bf16, int accumulate, int M, int D, void* stream);
-/* Residual add + RMSNorm in one pass (Qwen2DecoderLayer: hidden = residual + sublayer(...), then the next norm;
- * modeling_qwen2.py:247-252, 289-312): x_out[M, D] (fp32) = x_prev + float(delta) with delta the sublayer's bf16 output (o or
- * down projection, tasu_gemm_nt_bf16 with bf16 output), y (bf16) = rmsnorm(x_out) * w, rstd optional.  The same bits as the
- * projection with TASU_GEMM_OUT_F32_RESID_BF16R followed by tasu_rmsnorm_fwd.  x_out may alias x_prev.  D % 4 == 0. */
-int tasu_rmsnorm_fwd_add(const void* delta, const float* x_prev, const float* w, float* x_out, void* y, float* rstd, int M, int D,
-                         float eps, void* stream);
 /* Row-indexed forms for the training step's lm_head, which projects only the positions that carry a label
  * (transformers loss_utils.py:49-71 ignores the others; ps_slm_amd/model.py "labelled rows"):
  * fwd: y[i,:] = rmsnorm(x[src_rows[i],:]) for i < n_rows, a zero row (rstd 0) where src_rows[i] < 0;

@@ -25,7 +25,6 @@ PROTOTYPES = {
     "tasu_cast_f32_bf16": [vp, vp, i64, vp],
     "tasu_rmsnorm_fwd": [vp, vp, vp, vp, i32, i32, f32, vp],
     "tasu_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    "tasu_rmsnorm_fwd_add": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "tasu_rmsnorm_fwd_rows": [vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "tasu_rmsnorm_bwd_rows": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "tasu_rmsnorm_bwd_rows_resid": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],

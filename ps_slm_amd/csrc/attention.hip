@@ -467,7 +467,7 @@ extern "C" int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key
                              int S, int H, int G, float scale, int causal, void* stream) {
   (void)vt;                                              // unused since round 2: V^T is read out of the V tile in LDS
   if (!qkv || !key_mask || !out || !lse || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
-  static const int qw2_from = [] { const char* e = getenv("TASU_ATTN_QW2_FROM"); return e ? atoi(e) : 1 << 30; }();
+  static const int qw2_from = [] { const char* e = tasu_lab_env("TASU_ATTN_QW2_FROM"); return e ? atoi(e) : 1 << 30; }();
   if (S >= qw2_from) {
     // two query sub-tiles per wave (128-query blocks): half the LDS traffic per FLOP of the one-sub-tile form.  Measured at the
     // training shape (S = 256, causal): 20.7 us against 20.5 us, so the form is opt-in (TASU_ATTN_QW2_FROM=<S>) for long

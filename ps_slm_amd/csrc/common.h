@@ -12,6 +12,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+// Tuning / A-B switches of the dispatchers (TASU_GEMM_*, TASU_SKINNY_*, TASU_ATTN_QW2_FROM) exist in the LAB build only
+// (make -C ps_slm_amd/csrc lab -> ps_slm_amd/libtasu_hip_lab.so, loaded with TASU_LIB_PATH): the shipped library always takes
+// the measured-fastest path and reads no TASU_* variable of its own except TASU_RCCL_PATH (comm.hip).
+#include <stdlib.h>
+inline const char* tasu_lab_env(const char* name) {
+#ifdef TASU_LAB
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 #define TASU_OK 0
 #define TASU_ERR_ARG 1
 #define TASU_ERR_LAUNCH 2

@@ -287,7 +287,7 @@ int launch(GemmArgs a, hipStream_t st) {
 
 int sched_variant() {
   static const int v = [] {
-    const char* e = getenv("TASU_GEMM_SCHED");
+    const char* e = tasu_lab_env("TASU_GEMM_SCHED");
     return e ? atoi(e) : 0;
   }();
   return v;
@@ -310,7 +310,7 @@ int launch_tiled(const GemmArgs& a, int bn, hipStream_t st) {
 // per LDS read ratio is better (measured: N = 8960 loses 10 % with the narrow tile).
 int pick_bn(int M, int N) {
   static const int forced = [] {
-    const char* e = getenv("TASU_GEMM_BN");
+    const char* e = tasu_lab_env("TASU_GEMM_BN");
     return e ? atoi(e) : 0;
   }();
   if (forced == 96 || forced == 128 || forced == 192 || forced == 256) return forced;
@@ -330,7 +330,7 @@ int pick_bn(int M, int N) {
 // 0 = heuristic, 1 = always the 128-wide 2-blocks-per-CU kernel of this file, 2 = always gemm_pipe.hip
 int kernel_choice() {
   static const int v = [] {
-    const char* e = getenv("TASU_GEMM_KERNEL");
+    const char* e = tasu_lab_env("TASU_GEMM_KERNEL");
     if (!e) return 0;
     return e[0] == 'p' ? 2 : (e[0] == 'v' ? 1 : 0);
   }();
@@ -352,7 +352,7 @@ int cu_count();
 // blocks, every split keeping >= 16 K-steps.  Returns 1 when the workspace is missing or too small.
 static int plan_ksplit(int M, int N, int K, size_t ws_bytes) {
   static const int forced = [] {
-    const char* e = getenv("TASU_GEMM_KSPLIT");
+    const char* e = tasu_lab_env("TASU_GEMM_KSPLIT");
     return e ? atoi(e) : 0;
   }();
   const long tiles = (long)((M + 255) / 256) * ((N + 191) / 192);
@@ -397,7 +397,7 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
   const bool hb = bias != nullptr;
   const size_t ws_bytes = workspace ? (size_t)workspace_bytes : 0;
   static const int forced_bn = [] {
-    const char* e = getenv("TASU_GEMM_BN");
+    const char* e = tasu_lab_env("TASU_GEMM_BN");
     return e ? atoi(e) : 0;
   }();
   // ---- kernel / tile policy (MI355X, cold weight operands as inside the training step; tools/bench_gemm.py --cold):
@@ -409,7 +409,7 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
   //    the loader-wave tiles; at K = 8960 the loader-wave tiles win: 1024 rows 94 against 162 us);
   //  * problems of at most 64 rows keep the 128-row tiles of this file (128 x 1536 x 8960: 73 us on 256 x 96 tiles, 122 here).
   static const bool pp_on = [] {
-    const char* e = getenv("TASU_GEMM_PP");
+    const char* e = tasu_lab_env("TASU_GEMM_PP");
     return !(e && e[0] == '0');
   }();
   int use_pipe_bn = 0;
@@ -443,7 +443,7 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
         // on the step measured with TASU_GEMM_PP_EFF = 1.26 against 1.19 on one box; not the one-round N = 1536 grids)
         if (pp_on && kernel_choice() == 0 && K >= 256 && K % 128 == 0) {
           static const double pp_eff = [] {            // TASU_GEMM_PP_EFF: tuning runs
-            const char* e = getenv("TASU_GEMM_PP_EFF");
+            const char* e = tasu_lab_env("TASU_GEMM_PP_EFF");
             return e ? atof(e) : 1.26;
           }();
           // stream-K (gemm_pp.hip; needs the workspace): the 256 x 256 tiles fill FRACTIONAL rounds -- every workgroup gets the
@@ -462,7 +462,7 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
             // a mostly empty last round of big tiles (d_down: 560 tiles = 2.19 rounds): whole rounds on the big tiles, the
             // remaining columns on the small tiles in a second launch (TASU_GEMM_NSPLIT=0 disables)
             static const bool split_on = [] {
-              const char* e = getenv("TASU_GEMM_NSPLIT");
+              const char* e = tasu_lab_env("TASU_GEMM_NSPLIT");
               return !(e && e[0] == '0');
             }();
             const long tn = (N + 255) / 256, full = (tm * tn) / 256, tn_main = full * 256 / tm;
@@ -565,17 +565,18 @@ extern "C" int tasu_gemm_dswiglu(const void* dy, int lddy, const void* WdT, int 
                                  int I, int K, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!dy || !WdT || !gu || !dgu || M <= 0 || I <= 0 || I % 8 || K <= 0 || K % BK || lddy % 8 || ldw % 8) return TASU_ERR_ARG;
   if (((uintptr_t)dy & 15) || ((uintptr_t)WdT & 15) || ((uintptr_t)gu & 15) || ((uintptr_t)dgu & 15)) return TASU_ERR_ARG;
-  // TASU_GEMM_DSWIGLU=1 selects the fused epilogue.  Off by default: measured in the step (one box, alternating runs) it is
-  // worth 0.09 ms of 29 -- the epilogue's gate|up reads and dgu writes (294 MB per call) run while the CU's MFMA pipes idle,
-  // with every CU in its epilogue at the same time, so the GEMM grows by what the separate kernel took (55 us at 6.6 TB/s)
-  // although dact's 147 MB round trip is gone.  It pays once tile boundaries of different workgroups stop coinciding.
-  const char* const fused_env = getenv("TASU_GEMM_DSWIGLU");   // (read per call: the tests run both forms in one process)
-  const bool fused_on = fused_env && fused_env[0] == '1';
-  if (fused_on) {
+  // The form with the SwiGLU backward in the GEMM's epilogue (dact never reaches memory) exists in the LAB build only
+  // (TASU_GEMM_DSWIGLU=1 there): measured in the step it was worth 0.09 ms of 29 -- the epilogue's gate|up reads and dgu writes
+  // (294 MB per call) run while the CU's MFMA pipes idle, with every CU in its epilogue at the same time, so the GEMM grows by
+  // what the separate kernel took (55 us at 6.6 TB/s).  It pays once an epilogue runs under the next tile's K loop.
+#ifdef TASU_LAB
+  const char* const fused_env = tasu_lab_env("TASU_GEMM_DSWIGLU");   // (read per call: A/B runs in one process)
+  if (fused_env && fused_env[0] == '1') {
     const int rc = gemm_policy(dy, lddy, WdT, ldw, dgu, 2 * I, nullptr, (const float*)gu, M, I, K, tasu_gemm::OUT_DSWIGLU, workspace,
                                workspace_bytes, stream);
     if (rc != kUnsupported) return rc;
   }
+#endif
   if (!dact_ws || ((uintptr_t)dact_ws & 15)) return TASU_ERR_ARG;
   const int rc = gemm_policy(dy, lddy, WdT, ldw, dact_ws, I, nullptr, nullptr, M, I, K, TASU_GEMM_OUT_BF16, workspace, workspace_bytes,
                              stream);

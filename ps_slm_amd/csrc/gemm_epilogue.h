@@ -277,7 +277,7 @@ __device__ __forceinline__ void store_dswiglu(const Args& p, f32x4 (&acc)[MI][NI
       u32x4 gq[2][NP], uq[2][NP];
       auto fetch = [&](int i, int buf) {
         // clamped addresses (rows / columns past the matrix read a valid element; their results are not stored)
-        const int m = INTERIOR ? row0 + wrow + i * 16 + l15 : min(row0 + wrow + i * 16 + l15, p.M - 1);
+        const int m = INTERIOR ? row0 + wrow + i * 16 + l15 : max(min(row0 + wrow + i * 16 + l15, p.M - 1), 0);   // (M = 0: stream-K PART items)
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
           int n = col0 + wcol + jp * 32 + cpair;

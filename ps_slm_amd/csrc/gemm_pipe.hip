@@ -314,11 +314,13 @@ int tasu_gemm_pipe_dispatch(const void* A, int lda, const void* B, int ldb, void
     case TASU_GEMM_OUT_F32_RESID_BF16R:
       return hb ? launch_bn<TASU_GEMM_OUT_F32_RESID_BF16R, true>(a, bn, st)
                 : launch_bn<TASU_GEMM_OUT_F32_RESID_BF16R, false>(a, bn, st);
+#ifdef TASU_LAB
     case OUT_DSWIGLU:                                // `resid` = the saved gate|up matrix (bf16 [M, 2N]); C = dgu [M, 2N]
       if (hb || !resid || N % 8 || ldc != 2 * N || bn == 96) return TASU_ERR_ARG;
       a.act = (bf16*)resid;
       a.R = nullptr;
       return launch_bn<OUT_DSWIGLU, false>(a, bn, st);
+#endif
     default:
       return TASU_ERR_ARG;
   }
@@ -340,7 +342,7 @@ extern "C" int tasu_gemm_gate_up_swiglu_ws(const void* A, int lda, const void* W
   if (!A || !Wgu || !gu || !act || M <= 0 || I <= 0 || I % 4 || K <= 0 || K % BK || lda % 8 || ldw % 8) return TASU_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)Wgu & 15) || ((uintptr_t)gu & 7) || ((uintptr_t)act & 7)) return TASU_ERR_ARG;
   static const int forced = [] {                  // TASU_GEMM_GU_KERNEL=pipe|pp: A/B runs and tests of either kernel
-    const char* e = getenv("TASU_GEMM_GU_KERNEL");
+    const char* e = tasu_lab_env("TASU_GEMM_GU_KERNEL");
     return !e ? 0 : (e[0] == 'p' && e[1] == 'p' ? 2 : 1);
   }();
   auto pipe_range = [&](int n0) {                 // 256 x 128 tiles (64 act columns) of this file over act columns [n0, I)
@@ -371,11 +373,11 @@ extern "C" int tasu_gemm_gate_up_swiglu_ws(const void* A, int lda, const void* W
     // of big tiles would be mostly empty (1120 tiles on 256 CUs: 4.375 rounds), whole rounds on the big tiles + the remaining
     // columns on the small ones in a second launch (4 rounds + 192 tiles of 256 x 128)
     static const bool pp_on = [] {
-      const char* e = getenv("TASU_GEMM_PP");
+      const char* e = tasu_lab_env("TASU_GEMM_PP");
       return !(e && e[0] == '0');
     }();
     static const bool split_on = [] {
-      const char* e = getenv("TASU_GEMM_NSPLIT");
+      const char* e = tasu_lab_env("TASU_GEMM_NSPLIT");
       return !(e && e[0] == '0');
     }();
     const long tm = (M + 255) / 256, cus = cu_count(), tn = (I + 127) / 128;
@@ -426,7 +428,7 @@ extern "C" int tasu_gemm_qkv_rope(const void* A, int lda, const void* Wqkv, int 
   if (((uintptr_t)A & 15) || ((uintptr_t)Wqkv & 15) || ((uintptr_t)qkv & 15) || ((uintptr_t)cos_tab & 15) || ((uintptr_t)sin_tab & 15))
     return TASU_ERR_ARG;
   const int N = (H + 2 * G) * 128;
-  const char* const e = getenv("TASU_GEMM_QKV_ROPE");
+  const char* const e = tasu_lab_env("TASU_GEMM_QKV_ROPE");
   if (e && e[0] == '0') {
     const int rc = tasu_gemm_nt_bf16_ws(A, lda, Wqkv, ldw, qkv, N, bias, nullptr, M, N, K, TASU_GEMM_OUT_BF16, workspace, workspace_bytes,
                                         stream);

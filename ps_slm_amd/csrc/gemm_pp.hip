@@ -410,9 +410,9 @@ int cu_count() {
 // so those keep whole tiles unless TASU_GEMM_SK_MAXREM says otherwise.  TASU_GEMM_SK=0 disables the schedule altogether.
 double sk_max_rem() {
   static const double v = [] {
-    const char* off = getenv("TASU_GEMM_SK");
+    const char* off = tasu_lab_env("TASU_GEMM_SK");
     if (off && off[0] == '0') return -1.0;
-    const char* e = getenv("TASU_GEMM_SK_MAXREM");
+    const char* e = tasu_lab_env("TASU_GEMM_SK_MAXREM");
     return e ? atof(e) : 0.0;
   }();
   return v;
@@ -483,11 +483,13 @@ int tasu_gemm_pp_dispatch(const void* A, int lda, const void* B, int ldb, void* 
       return hb ? launch<TASU_GEMM_OUT_F32, true>(a, st) : launch<TASU_GEMM_OUT_F32, false>(a, st);
     case TASU_GEMM_OUT_F32_RESID_BF16R:
       return hb ? launch<TASU_GEMM_OUT_F32_RESID_BF16R, true>(a, st) : launch<TASU_GEMM_OUT_F32_RESID_BF16R, false>(a, st);
+#ifdef TASU_LAB
     case OUT_DSWIGLU:                                // `resid` = the saved gate|up matrix (bf16 [M, 2N]); C = dgu [M, 2N]
       if (hb || !resid || N % 8 || ldc != 2 * N) return TASU_ERR_ARG;
       a.act = (bf16*)resid;
       a.R = nullptr;
       return launch<OUT_DSWIGLU, false>(a, st);
+#endif
     default:
       return TASU_ERR_ARG;
   }

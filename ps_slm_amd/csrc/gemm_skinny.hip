@@ -490,8 +490,8 @@ template <bool SWIGLU>
 int plan_and_launch(Args a, float* ws, size_t ws_floats, hipStream_t st, NormArgs na = NormArgs()) {
   const int cus = cu_count();
   const int nk = a.K / BK;
-  static const int force_bn = [] { const char* e = getenv("TASU_SKINNY_BN"); return e ? atoi(e) : 0; }();
-  static const int force_ks = [] { const char* e = getenv("TASU_SKINNY_KS"); return e ? atoi(e) : 0; }();
+  static const int force_bn = [] { const char* e = tasu_lab_env("TASU_SKINNY_BN"); return e ? atoi(e) : 0; }();
+  static const int force_ks = [] { const char* e = tasu_lab_env("TASU_SKINNY_KS"); return e ? atoi(e) : 0; }();
   auto tiles_of = [&](int bn) { const int cols = SWIGLU ? bn / 2 : bn; return (a.N + cols - 1) / cols; };
   int best_bn = 64, best_ks = 1;
   const int t64 = tiles_of(64), t96 = tiles_of(96);

@@ -86,70 +86,6 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __res
   }
 }
 
-// Residual add + RMSNorm in one pass: x_out = x_prev + float(delta) (delta: the bf16 output of the o / down projection),
-// y = rmsnorm(x_out).  Same bits as the GEMM's residual epilogue (C = R + bf16_round(acc)) followed by rmsnorm_fwd; what it saves
-// is that epilogue's fp32 round trip -- 50 MB per projection that every CU moved at the same moment, at the end of a
-// one-round grid, with nothing to hide it (o: 38 -> 24 us, down: 105 -> 90 us), against 37 MB more here at the HBM rate.
-template <int NG>
-__global__ __launch_bounds__(256) void rmsnorm_fwd_add_reg_kernel(const bf16* __restrict__ delta, const float* __restrict__ xp,
-                                                                  const float* __restrict__ w, float* __restrict__ xo,
-                                                                  bf16* __restrict__ y, float* __restrict__ rstd, int M, float eps) {
-  constexpr int D = NG * 256;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const size_t off = (size_t)row * D + lane * 4;
-  f32x4 v[NG], gw[NG];
-  bf16x4 dl[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) v[g] = *(const f32x4*)(xp + off + g * 256);
-#pragma unroll
-  for (int g = 0; g < NG; ++g) dl[g] = *(const bf16x4*)(delta + off + g * 256);
-#pragma unroll
-  for (int g = 0; g < NG; ++g) gw[g] = *(const f32x4*)(w + lane * 4 + g * 256);
-  float ss = 0.f;
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    v[g] += __builtin_convertvector(dl[g], f32x4);
-    *(f32x4*)(xo + off + g * 256) = v[g];
-    ss += v[g][0] * v[g][0] + v[g][1] * v[g][1] + v[g][2] * v[g][2] + v[g][3] * v[g][3];
-  }
-  ss = wave_sum(ss);
-  const float r = rsqrtf(ss / (float)D + eps);
-  if (lane == 0 && rstd) rstd[row] = r;
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    f32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = gw[g][j] * (v[g][j] * r);
-    *(bf16x4*)(y + off + g * 256) = __builtin_convertvector(o, bf16x4);
-  }
-}
-__global__ __launch_bounds__(256) void rmsnorm_fwd_add_kernel(const bf16* __restrict__ delta, const float* __restrict__ xp,
-                                                              const float* __restrict__ w, float* __restrict__ xo,
-                                                              bf16* __restrict__ y, float* __restrict__ rstd, int M, int D, float eps) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const size_t base = (size_t)row * D;
-  float ss = 0.f;
-  for (int c = lane * 4; c < D; c += 256) {
-    const f32x4 v = *(const f32x4*)(xp + base + c) + __builtin_convertvector(*(const bf16x4*)(delta + base + c), f32x4);
-    *(f32x4*)(xo + base + c) = v;
-    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-  }
-  ss = wave_sum(ss);
-  const float r = rsqrtf(ss / (float)D + eps);
-  if (lane == 0 && rstd) rstd[row] = r;
-  for (int c = lane * 4; c < D; c += 256) {
-    const f32x4 v = *(const f32x4*)(xo + base + c);          // written by this lane above
-    const f32x4 g = *(const f32x4*)(w + c);
-    f32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[j] * r);
-    *(bf16x4*)(y + base + c) = __builtin_convertvector(o, bf16x4);
-  }
-}
 
 template <int NG>
 // ``slot`` (optional): dy and rstd are COMPACT (one row per labelled position); slot[row] is row's compact index, or < 0
@@ -417,19 +353,6 @@ static int rmsnorm_fwd_any(const float* x, const int32_t* src, const float* w, v
   else if (D == 3584) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<14>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag);
   else if (D == 256) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<1>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag);
   else TASU_LAUNCH(rmsnorm_fwd_kernel, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, D, eps, frag);
-  return TASU_OK;
-}
-extern "C" int tasu_rmsnorm_fwd_add(const void* delta, const float* x_prev, const float* w, float* x_out, void* y, float* rstd, int M,
-                                    int D, float eps, void* stream) {
-  if (!delta || !x_prev || !w || !x_out || !y || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
-  if (((uintptr_t)delta & 7) || ((uintptr_t)x_prev & 15) || ((uintptr_t)x_out & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 7)) return TASU_ERR_ARG;
-  const dim3 grid((M + 3) / 4);
-  hipStream_t st = (hipStream_t)stream;
-  const bf16* dl = (const bf16*)delta;
-  if (D == 1536) TASU_LAUNCH(rmsnorm_fwd_add_reg_kernel<6>, grid, dim3(256), 0, st, dl, x_prev, w, x_out, (bf16*)y, rstd, M, eps);
-  else if (D == 3584) TASU_LAUNCH(rmsnorm_fwd_add_reg_kernel<14>, grid, dim3(256), 0, st, dl, x_prev, w, x_out, (bf16*)y, rstd, M, eps);
-  else if (D == 256) TASU_LAUNCH(rmsnorm_fwd_add_reg_kernel<1>, grid, dim3(256), 0, st, dl, x_prev, w, x_out, (bf16*)y, rstd, M, eps);
-  else TASU_LAUNCH(rmsnorm_fwd_add_kernel, grid, dim3(256), 0, st, dl, x_prev, w, x_out, (bf16*)y, rstd, M, D, eps);
   return TASU_OK;
 }
 extern "C" int tasu_rmsnorm_fwd_frag(const float* x, const float* w, void* y_frag, int M, int D, float eps, void* stream) {

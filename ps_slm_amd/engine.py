@@ -150,6 +150,8 @@ class TasuEngine:
         self._last_state = None
         self.time_exchange = False     # bench.py: record event pairs around every wait of step()
         self.exposed_events = []
+        self.trace_exchange = False    # tests: timed events per exchanged range (issue point on the compute stream, start / end of
+        self.exchange_trace = []       # its all-reduce on the side stream): [(lo, hi, issued, started, ended)]
         # gradient accumulation (ds_config "gradient_accumulation_steps"; 1 in the shipped config, in which case no
         # accumulation buffer exists and nothing below costs anything).  Reference semantics: the loop divides the loss by k
         # (deepspeed_utils.py:210) and DeepSpeed's backward scales by 1/k again, so each micro-batch gradient enters with
@@ -184,13 +186,18 @@ class TasuEngine:
         """All-reduce of bucket range [lo, hi) on the side stream, ordered behind everything the compute stream has been
         given so far (= the kernels that wrote the range)."""
         if self.comm_stream is not None:
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.trace_exchange)
             ev.record()
             self.comm_stream.wait_event(ev)
             if self.rccl is not None:
+                if self.trace_exchange:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(self.comm_stream)
                 self.rccl.all_reduce_sum(g[lo:hi], self.comm_stream)
-                work = torch.cuda.Event()              # "this range has been reduced": the compute stream waits for it in step()
+                work = torch.cuda.Event(enable_timing=self.trace_exchange)   # "this range has been reduced": step() waits for it
                 work.record(self.comm_stream)
+                if self.trace_exchange:
+                    self.exchange_trace.append((lo, hi, ev, t0, work))
             else:
                 with torch.cuda.stream(self.comm_stream):
                     work = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)

@@ -356,11 +356,8 @@ class TasuModel:
         self.shape_buckets = None
         # training step: the LAST decoder layer's MLP (and everything after it) runs on the labelled rows only -- the hidden state
         # of a position without a label feeds nothing after that layer's attention (its K / V, which all rows still produce) --
-        # like the loss head (_loss_on_labelled_rows).  Same loss and gradients; TASU_TAIL_ROWS=0 switches it off (A/B runs).
-        self.tail_rows = os.environ.get("TASU_TAIL_ROWS", "1") != "0"
-        # residual adds in the next norm's kernel instead of the o / down projections' epilogues (forward_llm).  Same bits; measured
-        # neutral on the step (the GEMMs lose 0.37 ms of fp32 epilogue, the norms gain as much: 28.56 vs 28.53 ms) -> off by default
-        self.resid_in_norm = os.environ.get("TASU_RESID_IN_NORM", "0") == "1"
+        # like the loss head (_loss_on_labelled_rows).  Same loss and gradients (tests compare both settings of the attribute).
+        self.tail_rows = True
         self.graph_cache_size = 64
         self.decode_graphs = True      # the decode step (ps_slm_amd/decode.py) is always replayed as a graph on the GPU
         self._graphs = {}
@@ -693,26 +690,12 @@ class TasuModel:
         act = self._buf("act", (M, I), bf)
         tail = bool(self.tail_rows and compute_loss and need_backward and not self.keep_logits and logits_rows != "none"
                     and "lab_rows" in d and st.nLp > 0)
-        # TASU_RESID_IN_NORM=1: the residual adds live in the NEXT norm's kernel (rmsnorm_fwd_add), not in the projections'
-        # epilogues: o and down write their bf16 result (`delta`), the norm adds it to the fp32 stream, stores the stream and
-        # normalises -- the same bits as the GEMM's residual mode (the default), whose fp32 round trip at the end of a one-round
-        # grid it moves into an HBM-bound kernel.  The last layer keeps the residual mode (its outputs are gathered row-wise).
-        delta = self._buf("delta_llm", (M, D), bf)
-        pend = False                                               # `delta` holds the previous layer's down projection
         for l, w in enumerate(llm.layers):
             x_in, x_mid, x_out = xs[2 * l], xs[2 * l + 1], xs[2 * l + 2]
-            if pend:
-                ops.rmsnorm_fwd_add(delta, xs[2 * l - 1], w["ln1"], x_in, xn, rstd[2 * l], geo.rms_eps)
-            else:
-                ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], geo.rms_eps)
+            ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], geo.rms_eps)
             ops.gemm_qkv_rope(xn, w["wqkv"], w["bqkv"], qkv[l], cos, sin, M, H, G, D)      # bias + RoPE in the GEMM's epilogue
             ops.attn_fwd(qkv[l], None, d["key_mask"], ao[l], lse[l], B, S, H, G, scale, True)
-            in_norm = self.resid_in_norm and not (tail and l == L - 1)
-            if in_norm:
-                ops.gemm(ao[l], w["wo"], delta, M, D, H * HD)
-                ops.rmsnorm_fwd_add(delta, x_in, w["ln2"], x_mid, xn, rstd[2 * l + 1], geo.rms_eps)
-            else:
-                ops.gemm(ao[l], w["wo"], x_mid, M, D, H * HD, resid=x_in, mode=GEMM_RESID)
+            ops.gemm(ao[l], w["wo"], x_mid, M, D, H * HD, resid=x_in, mode=GEMM_RESID)
             if tail and l == L - 1:
                 # the last layer's MLP on the nLp labelled rows (compact operands; row gathers by the plan's index)
                 n = st.nLp
@@ -728,14 +711,9 @@ class TasuModel:
                 ops.gemm(act_t, w["wd"], xout_t, n, D, I, resid=xmid_t, mode=GEMM_RESID)
                 d.update(rstd_tail=rstd_t, gu_tail=gu_t, xout_tail=xout_t)
                 continue
-            if not in_norm:
-                ops.rmsnorm_fwd(x_mid, w["ln2"], xn, rstd[2 * l + 1], geo.rms_eps)
+            ops.rmsnorm_fwd(x_mid, w["ln2"], xn, rstd[2 * l + 1], geo.rms_eps)
             ops.gemm_gate_up_swiglu(xn, w["wgu"], gu[l], act, M, I, D)          # gate|up projection + SwiGLU epilogue
-            pend = self.resid_in_norm and l < L - 1
-            if pend:
-                ops.gemm(act, w["wd"], delta, M, D, I)
-            else:
-                ops.gemm(act, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
+            ops.gemm(act, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
         d.update(xs=xs, cos=cos, sin=sin, rstd=rstd, qkv=qkv, ao=ao, lse=lse, gu=gu)
         if logits_rows == "none":                              # decode prefill: the caller projects the last rows only
             return

@@ -36,13 +36,13 @@ class HipOps:
         self.gemm_ws = torch.zeros(GEMM_WS_BYTES, dtype=torch.uint8, device="cuda")
         self.topk_ws = torch.empty(1024 * 16 * 34, dtype=torch.float32, device="cuda")   # tasu_logprob_topk partials, M <= 1024
         # decode-step GEMMs: the single-launch weight-streaming kernels (csrc/gemm_stream.hip) where they serve the shape,
-        # the split-K + finish kernels (csrc/gemm_skinny.hip) otherwise.  TASU_DECODE_STREAM=0 forces the latter (A/B runs).
-        self.use_stream = os.environ.get("TASU_DECODE_STREAM", "1") != "0"
+        # the split-K + finish kernels (csrc/gemm_skinny.hip) otherwise.
+        self.use_stream = True          # (tests / tools flip the attribute for A/B runs)
         self.dec_frag = False          # set by begin_decode(): decode activations travel in fragment order
         self.dec_frag_act = False      # ... including the MLP activation that feeds the down projection
-        self.dec_down_slabs = os.environ.get("TASU_DECODE_DOWN_SLABS", "1") != "0"    # (begin_decode re-reads it)
+        self.dec_down_slabs = True     # down projection as K-range slabs + tasu_stream_finish_norm (False: split-K kernels)
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
-        self.dec_prologue = os.environ.get("TASU_DECODE_PROLOGUE", "1") != "0"    # the position's five set-up launches as one
+        self.dec_prologue = True       # the position's five set-up launches as one (tasu_decode_step_prologue)
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -133,8 +133,7 @@ class HipOps:
         # the MLP activation (the down projection's input): fragment order when the down projection runs on the streaming
         # kernels -- in one K range, or (K = 8960 = 5 x 1792) as K-range slabs + tasu_stream_finish_norm.  The slabs are the
         # default since the two row halves of a K range share an XCD's L2 and the slabs are row-major (1.89 vs 2.0 ms per
-        # position at 1.5B against the split-K kernels of gemm_skinny.hip); TASU_DECODE_DOWN_SLABS=0 selects the latter (A/B).
-        self.dec_down_slabs = os.environ.get("TASU_DECODE_DOWN_SLABS", "1") != "0"
+        # position at 1.5B against the split-K kernels of gemm_skinny.hip; the dec_down_slabs attribute selects, for A/B runs).
         ks_down = self._stream_split(I)
         self.dec_frag_act = bool(self.dec_frag and I % 32 == 0 and (ks_down == 1 or (ks_down > 1 and self.dec_down_slabs)))
         return self.dec_frag
@@ -199,13 +198,6 @@ class HipOps:
     def rmsnorm_fwd(self, x, w, y, rstd, eps):
         M, D = x.shape
         self._chk(self.lib.tasu_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), M, D, eps, self._stream()), "tasu_rmsnorm_fwd")
-
-    def rmsnorm_fwd_add(self, delta, x_prev, w, x_out, y, rstd, eps):
-        """x_out = x_prev + delta (delta: a projection's bf16 output), y = rmsnorm(x_out): the residual add of a decoder layer
-        folded into the next norm (tasu_rmsnorm_fwd_add)."""
-        M, D = x_prev.shape
-        self._chk(self.lib.tasu_rmsnorm_fwd_add(_p(delta), _p(x_prev), _p(w), _p(x_out), _p(y), _p(rstd), M, D, eps, self._stream()),
-                  "tasu_rmsnorm_fwd_add")
 
     def rmsnorm_bwd(self, dy, x, w, rstd, dx, dx_bf16, accumulate):
         M, D = x.shape

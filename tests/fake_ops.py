@@ -56,10 +56,6 @@ class FakeOps:
             rstd.copy_(r)
         y.copy_(_bf(w * (x * r[:, None])))
 
-    def rmsnorm_fwd_add(self, delta, x_prev, w, x_out, y, rstd, eps):
-        x_out.copy_(x_prev + delta.float())
-        self.rmsnorm_fwd(x_out, w, y, rstd, eps)
-
     def rmsnorm_bwd(self, dy, x, w, rstd, dx, dx_bf16, accumulate):
         D = x.shape[-1]
         d = dy.float()

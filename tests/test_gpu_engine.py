@@ -73,6 +73,55 @@ def test_chunked_rccl_exchange_is_bit_identical_to_the_single_bucket_step(nccl_g
     assert float(want[0][-1]) < float(want[0][0])         # and the steps do train
 
 
+def test_side_stream_all_reduce_runs_under_the_remaining_wgrad_blocks(nccl_group):
+    """The overlap the engine is built for, at the FULL projector (LayerNorm 25055 -> 2048 -> 1536: a 218 MB bucket, four
+    51-MB row blocks of the Linear1 weight gradient) and a 16 x 104-row batch: the RCCL all-reduce of range i is issued on the
+    side stream behind an event recorded after wgrad block i, while the compute stream goes on with block i + 1 -- persistent
+    512-thread / 128-KiB-LDS GEMM workgroups on every CU.  Event timestamps must show every row block's all-reduce STARTING
+    before the next block's GEMM has ended (the GEMM workgroups do not starve the collective's kernel), and the step must equal
+    the plain single-bucket step bit for bit.  (One rank: RCCL still launches its kernel; N > 1 is the driver's to run.)"""
+    def build_full(force):
+        tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True,
+                         use_fp16=True)
+        mc = ModelConfig(llm_path="synthetic:qwen2.5-1.5b", encoder_projector="linear-silu", llm_dim=1536, encoder_dim=25055)
+        model, _ = model_factory(tc, mc, device="cuda:0", init_seed=77, keep_logits=False)
+        cfg = load_ds_config(DEFAULT_DS_CONFIG)
+        cfg["lr"] = 1e-3
+        eng = TasuEngine(model, cfg, force_exchange=force, w1_chunks=4 if force else None)
+        eng.sched_iter = 10
+        return model, eng
+    m0, e0 = build_full(False)
+    geo = m0.core.geo
+    assert geo.ctc_vocab == 25055 and m0.core.proj.numel > 54_000_000
+    raw = synthetic_text_batch(geo, 16, seed=9, noise=False)
+    call = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"], input_features=None,
+                input_feature_length=None, GT=[" ".join(map(str, p)) for p in raw["post_ids"]])
+
+    def steps(eng, model, n=3):
+        for _ in range(n):
+            out, _ = eng(**call)
+            eng.backward(out.loss)
+            eng.step()
+        torch.cuda.synchronize()
+        return model.core.proj.p.clone()
+    want = steps(e0, m0)
+    del m0, e0
+    torch.cuda.empty_cache()
+    m1, e1 = build_full(True)
+    e1.trace_exchange = True
+    got = steps(e1, m1)
+    assert torch.equal(want, got)
+    tr = e1.exchange_trace[-6:]                                   # the last step's six ranges, in issue order
+    assert len(tr) == 6
+    blocks = tr[1:5]                                              # the four row blocks of the Linear1 weight gradient
+    assert all(hi - lo > 10_000_000 for lo, hi, *_ in blocks)     # ~12.8 M floats = 51 MB each
+    for (lo, hi, issued, started, ended), nxt in zip(blocks[:-1], blocks[1:]):
+        # nxt[2] is recorded on the compute stream right after the NEXT block's GEMM: the all-reduce of this block must have
+        # started before that point, i.e. it ran under (or before) the next block's GEMM, not after it
+        assert started.elapsed_time(nxt[2]) > 0.0, (lo, hi)
+        assert issued.elapsed_time(started) < 5.0                 # and it started within milliseconds of becoming ready
+
+
 def test_rccl_entry_points_of_the_c_abi():
     """tasu_comm_unique_id / tasu_comm_init / tasu_allreduce_f32 / tasu_allreduce_min_i32 / tasu_comm_destroy called directly (one
     rank: the sum over one rank is the identity, bit for bit), on a side stream with event chaining like the engine's."""

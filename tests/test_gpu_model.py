@@ -240,25 +240,6 @@ def test_tail_layer_on_labelled_rows_on_gpu(setup, ragged):
     assert torch.equal(a.proj.g, b.proj.g)
 
 
-@pytest.mark.parametrize("tail", [True, False])
-def test_residual_adds_in_the_norm_kernels_on_gpu(setup, tail):
-    """TasuModel.resid_in_norm (TASU_RESID_IN_NORM=1: the decoder layers' residual adds run in the next RMSNorm's kernel,
-    tasu_rmsnorm_fwd_add, instead of the o / down projections' epilogues): the same loss and projector gradients, bit for bit."""
-    from ps_slm_amd.ops import HipOps
-    geo, sd, _, _ = setup
-    a, b = TasuModel(geo, HipOps(), "cuda", keep_logits=False), TasuModel(geo, HipOps(), "cuda", keep_logits=False)
-    a.load_reference_state_dict(sd)
-    b.load_reference_state_dict(sd)
-    a.resid_in_norm, b.resid_in_norm = True, False
-    a.tail_rows = b.tail_rows = tail
-    batch = synthetic_text_batch(geo, 3, seed=12, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12,
-                                 noise=True, drop_prob=0.1, ragged=True)
-    sa, sb = run_text(a, batch), run_text(b, batch)
-    assert torch.equal(sa.dev["loss_out"], sb.dev["loss_out"])
-    assert torch.equal(a.proj.g, b.proj.g)
-    assert torch.equal(sa.dev["xs"], sb.dev["xs"]) if not tail else torch.equal(sa.dev["xs"][:-1], sb.dev["xs"][:-1])
-
-
 @pytest.mark.parametrize("k", [1, 2])
 def test_linear_projector_on_gpu(k):
     """``encoder_projector="linear"`` (EncoderProjectorConcat, k frames per projector row) on the HIP kernels: against the REAL

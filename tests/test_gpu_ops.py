@@ -219,11 +219,11 @@ def test_gemm_policy_takes_streamk_for_d_gate_up(hip):
 
 @pytest.mark.parametrize("M,I,K", [(4096, 8960, 1536), (2048, 8960, 1536), (300, 200, 128), (1100, 4480, 384), (1000, 1000, 256),
                                    (64, 96, 256), (4096, 1024, 256)])
-def test_gemm_dswiglu(hip, fake, M, I, K, monkeypatch):
-    """Down projection's input gradient + SwiGLU backward behind one entry point (tasu_gemm_dswiglu), both forms: the two kernels
-    through the dact scratch (default) and, TASU_GEMM_DSWIGLU=1, the SwiGLU backward in the GEMM epilogue (no scratch needed
-    for M > 128) -- the same bits as the GEMM with bf16 output followed by tasu_swiglu_bwd, on the 256 x 256 kernel + column
-    tail (4096 / 2048 x 8960), the loader-wave tiles with edge tiles in both directions, and 64 rows."""
+def test_gemm_dswiglu(hip, fake, M, I, K):
+    """Down projection's input gradient + SwiGLU backward behind one entry point (tasu_gemm_dswiglu: the GEMM into the dact
+    scratch + tasu_swiglu_bwd; the form with the SwiGLU backward in the GEMM epilogue lives in the lab build only) -- the same
+    bits as the GEMM with bf16 output followed by tasu_swiglu_bwd, on the 256 x 256 kernel + column tail (4096 / 2048 x 8960),
+    the loader-wave tiles with edge tiles in both directions, and 64 rows."""
     dy = randn(M, K, dtype=BF, seed=1).cuda()
     wd_t = randn(I, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K)).cuda()
     gu = randn(M, 2 * I, dtype=BF, seed=3).cuda()
@@ -231,13 +231,10 @@ def test_gemm_dswiglu(hip, fake, M, I, K, monkeypatch):
     want = torch.zeros(M, 2 * I, dtype=BF).cuda()
     hip.gemm(dy, wd_t, dact, M, I, K)
     hip.swiglu_bwd(dact, gu, want, M, I)
-    for fused in ("0", "1"):
-        monkeypatch.setenv("TASU_GEMM_DSWIGLU", fused)
-        got = torch.full((M, 2 * I), 7.0, dtype=BF).cuda()
-        scratch = None if fused == "1" and M > 128 else torch.zeros(M, I, dtype=BF).cuda()
-        hip.gemm_dswiglu(dy, wd_t, gu, got, scratch, M, I, K)
-        torch.cuda.synchronize()
-        assert torch.equal(got, want), fused
+    got = torch.full((M, 2 * I), 7.0, dtype=BF).cuda()
+    hip.gemm_dswiglu(dy, wd_t, gu, got, torch.zeros(M, I, dtype=BF).cuda(), M, I, K)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
     cc = torch.zeros(M, 2 * I, dtype=BF)
     fake.gemm_dswiglu(dy.cpu(), wd_t.cpu(), gu.cpu(), cc, None, M, I, K)
     assert rel_err(want, cc) < 2e-2
@@ -245,10 +242,10 @@ def test_gemm_dswiglu(hip, fake, M, I, K, monkeypatch):
 
 @pytest.mark.parametrize("M,H,G,K,bias", [(4096, 12, 2, 1536, True), (1000, 4, 2, 256, True), (300, 2, 1, 128, False), (4096, 28, 4, 3584, True),
                                           (64, 12, 2, 1536, True)])
-def test_gemm_qkv_rope(hip, fake, M, H, G, K, bias, monkeypatch):
+def test_gemm_qkv_rope(hip, fake, M, H, G, K, bias):
     """q|k|v projection + bias + RoPE of the q and k heads in the GEMM's epilogue (tasu_gemm_qkv_rope): the same bits as the GEMM
-    with bf16 output followed by tasu_rope_fwd (which TASU_GEMM_QKV_ROPE=0 runs behind the same entry point) -- 1.5B and 7B head
-    counts, a last row tile of 232 / 44 / 64 rows, no bias; the v heads come out unrotated."""
+    with bf16 output followed by tasu_rope_fwd -- 1.5B and 7B head counts, a last row tile of 232 / 44 / 64 rows, no bias; the
+    v heads come out unrotated."""
     N = (H + 2 * G) * HD
     a = randn(M, K, dtype=BF, seed=1).cuda()
     w = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K)).cuda()
@@ -259,41 +256,14 @@ def test_gemm_qkv_rope(hip, fake, M, H, G, K, bias, monkeypatch):
     hip.gemm(a, w, want, M, N, K, bias=bv)
     plain = want.clone()
     hip.rope_fwd(want, cos, sin, None, None, None, 1, M, H, G)
-    for fused in ("1", "0"):
-        monkeypatch.setenv("TASU_GEMM_QKV_ROPE", fused)
-        got = torch.full((M, N), 7.0, dtype=BF).cuda()
-        hip.gemm_qkv_rope(a, w, bv, got, cos, sin, M, H, G, K)
-        torch.cuda.synchronize()
-        assert torch.equal(got, want), fused
+    got = torch.full((M, N), 7.0, dtype=BF).cuda()
+    hip.gemm_qkv_rope(a, w, bv, got, cos, sin, M, H, G, K)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
     assert torch.equal(want[:, (H + G) * HD:], plain[:, (H + G) * HD:]) and not torch.equal(want[:, :HD], plain[:, :HD])
     cc = torch.zeros(M, N, dtype=BF)
     fake.gemm_qkv_rope(a.cpu(), w.cpu(), None if bv is None else bv.cpu(), cc, cos.cpu(), sin.cpu(), M, H, G, K)
     assert rel_err(want, cc) < 2e-2
-
-
-@pytest.mark.parametrize("M,D,K", [(4096, 1536, 1536), (300, 256, 128), (1000, 3584, 256), (77, 192, 64)])
-def test_rmsnorm_fwd_add_equals_residual_epilogue(hip, fake, M, D, K):
-    """Residual add folded into the next RMSNorm (tasu_rmsnorm_fwd_add on the projection's bf16 output) against the projection
-    in residual mode followed by tasu_rmsnorm_fwd: the same fp32 stream, normed rows and rstd, bit for bit; the register
-    forms (D = 1536 / 3584 / 256) and the generic one; x_out aliasing x_prev."""
-    a = randn(M, K, dtype=BF, seed=1).cuda()
-    w = randn(D, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K)).cuda()
-    x_prev = randn(M, D, seed=3).cuda()
-    g = (randn(D, seed=4).abs() + 0.5).cuda()
-    x1, y1, r1 = torch.zeros(M, D).cuda(), torch.zeros(M, D, dtype=BF).cuda(), torch.zeros(M).cuda()
-    hip.gemm(a, w, x1, M, D, K, resid=x_prev, mode=2)
-    hip.rmsnorm_fwd(x1, g, y1, r1, 1e-6)
-    delta = torch.zeros(M, D, dtype=BF).cuda()
-    x2, y2, r2 = torch.zeros(M, D).cuda(), torch.zeros(M, D, dtype=BF).cuda(), torch.zeros(M).cuda()
-    hip.gemm(a, w, delta, M, D, K)
-    hip.rmsnorm_fwd_add(delta, x_prev, g, x2, y2, r2, 1e-6)
-    x3 = x_prev.clone()
-    hip.rmsnorm_fwd_add(delta, x3, g, x3, y2.clone(), None, 1e-6)
-    torch.cuda.synchronize()
-    assert torch.equal(x1, x2) and torch.equal(y1, y2) and torch.equal(r1, r2) and torch.equal(x3, x1)
-    xc, yc, rc = torch.zeros(M, D), torch.zeros(M, D, dtype=BF), torch.zeros(M)
-    fake.rmsnorm_fwd_add(delta.cpu(), x_prev.cpu(), g.cpu(), xc, yc, rc, 1e-6)
-    assert rel_err(x2, xc) < 1e-6 and rel_err(y2, yc) < 1e-2 and rel_err(r2, rc) < 1e-5
 
 
 def test_gemm_gate_up_swiglu_streamk(hip, fake):

@@ -1,5 +1,5 @@
 """Decode leg of bench.py alone (beam 4, 16 utterances, prefill 128, 200 generated positions): python tools/bench_decode.py
-[--model qwen2.5-1.5b] [--batch 16].  TASU_DECODE_MEGA=0 / TASU_DECODE_STREAM=0 select the older launch schemes (A/B runs)."""
+[--model qwen2.5-1.5b] [--batch 16].  HipOps.use_stream = False selects the split-K launch scheme (A/B runs)."""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
