@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 6
+#define TASU_ABI_VERSION 7
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -308,6 +308,28 @@ int tasu_silu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stre
 int tasu_relu_fwd(const void* x, void* y, int64_t n, void* stream);
 /* ReLU backward (EncoderProjectorConcat, projector.py:35): dx = dy where x > 0 else 0.                     */
 int tasu_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ LoRA
+ * The use_peft=true recipe (Multitask/model/ps-slm.py:114-117; PeftConfig r / lora_alpha / lora_dropout / target_modules at
+ * Multitask/aispeech_asr_config.py:41-50).  peft 0.6.0 is not part of the reference tree; its lora.Linear.forward,
+ *     result = base(x);  result += lora_B(lora_A(dropout(x))) * scaling,
+ * is restated by the host (ps_slm_amd/lora.py) on tasu_gemm_bf16 calls; these entry points are what sits between the GEMMs.
+ * tasu_lora_add: y = bf16(y + bf16(t * s)) over n bf16 values (n % 8 == 0); with x_in / x_out (both or neither) also the
+ * decoder's residual add x_out = x_in + float(y) (fp32).  s = 1 makes it a plain bf16 accumulate (dgrad sums).
+ * tasu_scale_bf16: dst = bf16(src * s).
+ * Dropout: `rng` is int64[2] in device memory = {seed, step}; element idx of dropout stream `stream_id` is kept iff the
+ * upper 32 bits of splitmix64-finalize((seed ^ step * 0x9E3779B97F4A7C15 ^ stream_id << 44) + idx * 0xD1B54A32D192ED03) are
+ * >= p * 2^32; kept values are scaled by 1 / (1 - p) (fp32) and rounded to bf16 once.  Stateless: the backward calls
+ * tasu_lora_dropout on the gradient with the same (stream_id, step) and gets the forward's mask.  The draws are this
+ * library's own -- torch's Philox stream is not reproduced (PARITY UNPINNED for the mask; pinned for a GIVEN mask).
+ * tasu_lora_dropout_norm: the same on the fp32 RMSNorm output g * (x * rstd) recomputed from the saved row scales.
+ * tasu_rng_advance: step += 1 (a launch, so that a replayed hipGraph draws fresh masks).                                   */
+int tasu_lora_add(void* y, const void* t, float s, const float* x_in, float* x_out, int64_t n, void* stream);
+int tasu_scale_bf16(const void* src, void* dst, float s, int64_t n, void* stream);
+int tasu_lora_dropout(const void* src, void* dst, int64_t n, float p, const void* rng, int stream_id, void* stream);
+int tasu_lora_dropout_norm(const float* x, const float* w, const float* rstd, void* dst, int M, int D, float p, const void* rng,
+                           int stream_id, void* stream);
+int tasu_rng_advance(void* rng, void* stream);
 
 /* ---------------------------------------------------------------------- cross entropy + token accuracy
  * transformers loss_utils.py:49-71 (shift, ignore_index -100, mean) + ps-slm.py:533-535 / utils/metric.py

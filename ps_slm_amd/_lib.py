@@ -44,6 +44,11 @@ PROTOTYPES = {
     "tasu_silu_bwd": [vp, vp, vp, i64, vp],
     "tasu_relu_bwd": [vp, vp, vp, i64, vp],
     "tasu_relu_fwd": [vp, vp, i64, vp],
+    "tasu_lora_add": [vp, vp, f32, vp, vp, i64, vp],
+    "tasu_scale_bf16": [vp, vp, f32, i64, vp],
+    "tasu_lora_dropout": [vp, vp, i64, f32, vp, i32, vp],
+    "tasu_lora_dropout_norm": [vp, vp, vp, vp, i32, i32, f32, vp, i32, vp],
+    "tasu_rng_advance": [vp, vp],
     "tasu_ce_fwd_bwd": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp],
     "tasu_ce_reduce": [vp, vp, vp, i32, vp, vp],
     "tasu_layernorm_fwd": [vp, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, f32, vp],
@@ -108,7 +113,7 @@ PROTOTYPES.update({
     "tasu_allreduce_min_i32": [vp, vp, i64, vp],
 })
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

@@ -256,7 +256,7 @@ class TasuEngine:
         self._pending = []
         if self.ga > 1:
             self._g_acc.zero_()
-        pr.refresh_working_copies(self.core.ops)
+        self.core.refresh_working_copies()
         self.sched_iter += 1           # lr_scheduler.step() follows optimizer.step() in the DeepSpeed engine
 
     def exposed_ms(self):
@@ -294,9 +294,10 @@ class TasuEngine:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
         return t.tolist()
 
-    # ---- checkpoint (projector tensors only, reference key names: checkpoint_handler.py:169-182, ps-slm.py:163-170)
+    # ---- checkpoint (the trainable tensors -- projector, + LoRA adapters with use_peft -- under the reference's key names:
+    #      checkpoint_handler.py:169-182, ps-slm.py:163-170)
     def save_checkpoint(self, path):
         if self.rank == 0:
-            torch.save({k: v.cpu() for k, v in self.core.projector_state_dict().items()}, path)
+            torch.save({k: v.cpu() for k, v in {**self.core.projector_state_dict(), **self.core.lora_state_dict()}.items()}, path)
         if self.world > 1:
             dist.barrier(group=self.pg)

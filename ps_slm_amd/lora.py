@@ -1,0 +1,372 @@
+"""LoRA on the decoder (the reference's ``use_peft=true`` recipe: Multitask/model/ps-slm.py:114-117 wraps the HF Qwen2 in
+``get_peft_model``; PeftConfig -- r=64, lora_alpha=16, lora_dropout=0.05, the seven projection names -- at
+Multitask/aispeech_asr_config.py:41-50; ``generate_peft_config`` at Multitask/utils/config_utils.py:41-60).
+
+peft (pinned 0.6.0 by the reference's requirements) is NOT part of the reference tree.  Its ``lora.Linear.forward`` is restated
+here from the published algorithm,
+
+    result = base(x);  result += lora_B(lora_A(lora_dropout(x))) * (lora_alpha / r)
+
+with ``lora_A`` initialised kaiming-uniform(a = sqrt 5) (= U(-1/sqrt(in), 1/sqrt(in))) and ``lora_B`` zero, and pinned against
+that formula applied by hand to the reference's own HF decoder (oracle/make_golden_lora.py -> tests/golden/mid_text_lora.npz).
+
+MI355X form.  The adapters are NEVER merged into the bf16 base weights (a rank-64 update of relative size 1e-3 does not survive
+a bf16 rounding of W): every adapted Linear runs base GEMM + two low-rank GEMMs on the existing NT kernels, the rounding points
+being the reference's under autocast (u = bf16(xd A^T), v = bf16(u B^T), y = bf16(base + bf16(v * s))).  All A / B tensors live
+behind the projector in the ONE flat fp32 bucket (master, grad, Adam m / v, bf16 working copy), a layer's tensors contiguous and
+the layers in the order the backward completes them (last layer first), so that AdamW and the gradient exchange see one more
+range per layer.  Weight gradients are plain NT GEMMs on transposed operands (dB = (s dy)^T u, dA = du^T xd) written straight
+into the bucket.  Nothing of the forward is recomputed except the adapters' bf16 inputs (norm outputs, SwiGLU product), which the
+frozen recipe never stored.
+"""
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from .ops import GEMM_F32, GEMM_RESID
+
+HD = 128
+TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+_PARENT = {"q_proj": "self_attn", "k_proj": "self_attn", "v_proj": "self_attn", "o_proj": "self_attn",
+           "gate_proj": "mlp", "up_proj": "mlp", "down_proj": "mlp"}
+GROUPS = (("qkv", ("q_proj", "k_proj", "v_proj")), ("o", ("o_proj",)), ("gu", ("gate_proj", "up_proj")), ("down", ("down_proj",)))
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class LoraConfig:
+    r: int = 64
+    lora_alpha: float = 16
+    lora_dropout: float = 0.05
+    target_modules: tuple = TARGETS
+
+    @property
+    def scaling(self):
+        return float(self.lora_alpha) / float(self.r)
+
+    @classmethod
+    def from_peft_config(cls, cfg):
+        """cfg: the ``train_config.peft_config`` mapping / dataclass of the reference (aispeech_asr_config.py:41-50)."""
+        get = (lambda k, d: cfg.get(k, d)) if hasattr(cfg, "get") else (lambda k, d: getattr(cfg, k, d))
+        method = get("peft_method", "lora")
+        if method not in (None, "lora"):
+            raise NotImplementedError(f"peft_method {method!r}: only 'lora' is served (llama_adapter / prefix are not used by any reference recipe)")
+        if get("bias", "none") != "none":
+            raise NotImplementedError("LoRA with trainable biases (peft_config.bias != 'none')")
+        targets = tuple(get("target_modules", TARGETS))
+        bad = [t for t in targets if t not in TARGETS]
+        if bad:
+            raise NotImplementedError(f"LoRA target_modules {bad}: the decoder's adapted Linears are {TARGETS}")
+        r = int(get("r", 64))
+        if r <= 0 or r % 8:
+            raise NotImplementedError(f"LoRA rank {r}: must be a positive multiple of 8 (16-byte rows of the bf16 operands)")
+        return cls(r=r, lora_alpha=float(get("lora_alpha", 16)), lora_dropout=float(get("lora_dropout", 0.05)),
+                   target_modules=tuple(t for t in TARGETS if t in targets))
+
+
+def target_dims(geo):
+    D, I, H, G = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads
+    return {"q_proj": (D, H * HD), "k_proj": (D, G * HD), "v_proj": (D, G * HD), "o_proj": (H * HD, D),
+            "gate_proj": (D, I), "up_proj": (D, I), "down_proj": (I, D)}
+
+
+def target_cols(geo):
+    """Column offset of a target's output inside its group's fused activation (q | k | v, gate | up)."""
+    I, H, G = geo.llm_inter, geo.llm_heads, geo.llm_kv_heads
+    return {"q_proj": 0, "k_proj": H * HD, "v_proj": (H + G) * HD, "o_proj": 0, "gate_proj": 0, "up_proj": I, "down_proj": 0}
+
+
+def key_of(layer, target, which):
+    """Reference checkpoint key (slam_model_asr.llm = PeftModel -> LoraModel -> Qwen2ForCausalLM)."""
+    return f"llm.base_model.model.model.layers.{layer}.{_PARENT[target]}.{target}.lora_{which}.default.weight"
+
+
+class LoraParams:
+    """A / B of every adapted Linear as views of the trainable bucket's tail [base, base + numel)."""
+
+    def __init__(self, geo, cfg: LoraConfig, proj, device):
+        self.geo, self.cfg, self.proj, self.device = geo, cfg, proj, device
+        self.r, self.rp = cfg.r, rup(cfg.r, 64)
+        self.dims, self.cols = target_dims(geo), target_cols(geo)
+        for t in cfg.target_modules:
+            for n in self.dims[t]:
+                if n % 64:
+                    raise NotImplementedError(f"LoRA on {t}: dimension {n} is not a multiple of 64")
+        self.groups = [(g, tuple(t for t in ts if t in cfg.target_modules)) for g, ts in GROUPS]
+        self.groups = [(g, ts) for g, ts in self.groups if ts]
+        self.slot = {}                                     # target -> index of its rp-wide column block in the group's u / du buffers
+        for _, ts in self.groups:
+            for i, t in enumerate(ts):
+                self.slot[t] = i
+        L = geo.llm_layers
+        self.base = proj.numel
+        self.offsets, self.layer_range = {}, {}
+        off = self.base
+        for l in range(L - 1, -1, -1):                     # completion order of the backward: last layer first
+            lo = off
+            for t in cfg.target_modules:
+                i, o = self.dims[t]
+                self.offsets[(l, t, "A")] = (off, (self.r, i))
+                off += rup(self.r * i, 64)
+                self.offsets[(l, t, "B")] = (off, (o, self.r))
+                off += rup(o * self.r, 64)
+            self.layer_range[l] = (lo, off)
+        self.numel = off - self.base
+        proj.extend(self.numel)
+        bf = dict(dtype=torch.bfloat16, device=device)
+        # transposed bf16 working copies for the dgrad through the adapter: B^T [r, out], A^T [in, rp] (+ padded B when r % 64)
+        self.bt = {(l, t): torch.zeros(self.r, self.dims[t][1], **bf) for l in range(L) for t in cfg.target_modules}
+        self.at = {(l, t): torch.zeros(self.dims[t][0], self.rp, **bf) for l in range(L) for t in cfg.target_modules}
+        self.bp = {}
+        if self.rp != self.r:
+            self.bp = {(l, t): torch.zeros(self.dims[t][1], self.rp, **bf) for l in range(L) for t in cfg.target_modules}
+        self.rng = torch.zeros(2, dtype=torch.int64, device=device)          # {seed, step} of the dropout masks (csrc/lora.hip)
+
+    # ---- views
+    def view(self, flat, l, t, which):
+        off, shp = self.offsets[(l, t, which)]
+        return flat[off:off + shp[0] * shp[1]].view(*shp)
+
+    def a_bf(self, l, t):
+        return self.view(self.proj.pb, l, t, "A")          # [r, in]: the B operand of u = x A^T as stored
+
+    def b_bf(self, l, t):
+        return self.bp[(l, t)] if self.bp else self.view(self.proj.pb, l, t, "B")   # [out, rp]
+
+    def num_parameters(self):
+        return sum(int(np.prod(s)) for _, s in self.offsets.values())
+
+    def names(self):
+        for l in range(self.geo.llm_layers):
+            for t in self.cfg.target_modules:
+                for which in "AB":
+                    yield key_of(l, t, which), (l, t, which)
+
+    # ---- weights
+    def init_default(self, seed=4242):
+        """peft's reset_lora_parameters: A ~ kaiming_uniform(a = sqrt 5) = U(-1/sqrt(in), 1/sqrt(in)), B = 0."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for (l, t, which), (off, shp) in self.offsets.items():
+            v = self.view(self.proj.p, l, t, which)
+            if which == "A":
+                b = 1.0 / math.sqrt(shp[1])
+                v.copy_((torch.rand(*shp, generator=g, device=self.device, dtype=torch.float32) * 2 - 1) * b)
+            else:
+                v.zero_()
+
+    def load(self, l, t, which, tensor):
+        self.view(self.proj.p, l, t, which).copy_(tensor.to(self.device, torch.float32))
+
+    def load_state_dict(self, sd, strict=True):
+        n = 0
+        for key, (l, t, which) in self.names():
+            if key in sd:
+                self.load(l, t, which, sd[key])
+                n += 1
+            elif strict:
+                raise KeyError(key)
+        return n
+
+    def state_dict(self):
+        return {key: self.view(self.proj.p, *k).detach().clone() for key, k in self.names()}
+
+    def grads(self):
+        return {key: self.view(self.proj.g, *k).detach().clone() for key, k in self.names()}
+
+    def seed_dropout(self, seed, step=0):
+        self.rng.copy_(torch.tensor([int(seed), int(step)], dtype=torch.int64))
+
+    def refresh_working_copies(self, ops):
+        """After the bf16 copy of the bucket changed (load, AdamW): the transposed copies the dgrad reads."""
+        pb = self.proj.pb
+        for l in range(self.geo.llm_layers):
+            for t in self.cfg.target_modules:
+                i, o = self.dims[t]
+                ops.transpose(self.view(pb, l, t, "B"), self.bt[(l, t)], o, self.r, o, self.r)           # [out, r] -> [r, out]
+                ops.transpose(self.view(pb, l, t, "A"), self.at[(l, t)], self.r, i, self.rp, i)           # [r, in] -> [in, rp] (zero pad)
+                if self.bp:
+                    self.bp[(l, t)][:, : self.r].copy_(self.view(pb, l, t, "B"))
+
+
+class LoraRunner:
+    """The adapted decoder layer: forward and backward of one layer with the low-rank branches in place.  Called by
+    TasuModel.forward_llm / backward_llm when ``model.lora`` is set; uses the model's named workspace buffers."""
+
+    def __init__(self, model):
+        self.m = model
+        self.lp = model.lora
+        self._zero_gen = {}
+
+    # ---- workspace
+    def _zbuf(self, name, shape):
+        """bf16 buffer that is zero when (re)allocated: the r -> rp padding columns of u / du are never written."""
+        m = self.m
+        gen_before = m._ws.get(name)
+        t = m._buf(name, shape, torch.bfloat16)
+        now = m._ws[name]
+        if gen_before is not now:
+            now.zero_()
+        return t
+
+    def _drop_on(self, training):
+        return bool(training and self.lp.cfg.lora_dropout > 0.0)
+
+    def _sid(self, l, t):
+        return l * 8 + TARGETS.index(t)
+
+    # ---- forward of one group: y (bf16 [M, width], base result incl. bias) += s * B(A(drop(x)))
+    def group_fwd(self, l, gname, targets, xin, y, width, M, drop, xin_drop=None, x_in=None, x_out=None):
+        """xin: bf16 [M, in] (the base Linear's input).  ``xin_drop(t, dst)`` fills dst with the dropped input of target t.
+        u is kept per layer for the backward.  With x_in / x_out the residual add rides on the last accumulate."""
+        m, lp, ops = self.m, self.lp, self.m.ops
+        L, r, rp, s = m.geo.llm_layers, lp.r, lp.rp, lp.cfg.scaling
+        u_all = self._zbuf("lora_u_" + gname, (L, M, len(targets) * rp))
+        tmp = m._buf("lora_tmp", (M, max(width, 1)), torch.bfloat16)
+        inn = lp.dims[targets[0]][0]
+        for t in targets:
+            i, o = lp.dims[t]
+            xd = xin
+            if drop:
+                xd = m._buf("lora_xd", (M, inn), torch.bfloat16)
+                xin_drop(t, xd)
+            u = u_all[l][:, lp.slot[t] * rp: lp.slot[t] * rp + rp]
+            ops.gemm(xd, lp.a_bf(l, t), u, M, r, i)                               # u = bf16(xd A^T)          [M, r]
+            c0 = lp.cols[t]
+            ops.gemm(u, lp.b_bf(l, t), tmp[:, c0:c0 + o], M, o, rp)               # v = bf16(u B^T)           [M, out]
+        for t2 in dict(GROUPS)[gname]:
+            if t2 not in targets:                       # an un-adapted member of the group (e.g. q and v only): no contribution
+                c0 = lp.cols[t2]
+                tmp[:, c0:c0 + lp.dims[t2][1]].zero_()
+        ops.lora_add(y, tmp, s, x_in, x_out)                                      # y = bf16(y + bf16(v s)) [, x_out = x_in + y]
+
+    # ---- backward of one group
+    def group_bwd(self, l, gname, targets, dy, width, M, xin, dx_base, drop, xin_drop=None):
+        """dy: bf16 [M, width] gradient of the group's (fused) output; xin as in the forward (recomputed by the caller); dx_base:
+        bf16 [M, in], the base path's input gradient, to which the adapters' is added.  Writes dA / dB into the bucket."""
+        m, lp, ops = self.m, self.lp, self.m.ops
+        L, r, rp, s = m.geo.llm_layers, lp.r, lp.rp, lp.cfg.scaling
+        bf = torch.bfloat16
+        Mp = rup(M, 64)
+        inn = lp.dims[targets[0]][0]
+        nt = len(targets)
+        u_all = m._ws["lora_u_" + gname][: L * M * nt * rp].view(L, M, nt * rp)
+        dys = m._buf("lora_dys", (M, width), bf)
+        ops.scale_bf16(dy, dys, s)
+        du = self._zbuf("lora_du_" + gname, (M, nt * rp))
+        dxl = m._buf("lora_dxl", (M, inn), bf)
+        for t in targets:
+            i, o = lp.dims[t]
+            c0, k = lp.cols[t], lp.slot[t]
+            ops.gemm(dys[:, c0:c0 + o], lp.bt[(l, t)], du[:, k * rp: k * rp + rp], M, r, o)     # du = bf16((s dy) B)     [M, r]
+            ops.gemm(du[:, k * rp: k * rp + rp], lp.at[(l, t)], dxl, M, i, rp)                   # dx = bf16(du A)         [M, in]
+            if drop:
+                ops.lora_dropout(dxl, dxl, lp.cfg.lora_dropout, lp.rng, self._sid(l, t))
+            ops.lora_add(dx_base, dxl, 1.0)
+        # weight gradients: dB_t = (s dy_t)^T u_t   [out, r],   dA_t = du_t^T xd_t   [r, in]   (K = the M rows, padded to 64)
+        dys_t = m._buf("lora_dys_t", (width, Mp), bf)
+        ops.transpose(dys, dys_t, M, width, Mp, width)
+        u_t = m._buf("lora_u_t", (nt * rp, Mp), bf)
+        ops.transpose(u_all[l], u_t, M, nt * rp, Mp, nt * rp)
+        du_t = m._buf("lora_du_t", (nt * rp, Mp), bf)
+        ops.transpose(du, du_t, M, nt * rp, Mp, nt * rp)
+        xin_t = m._buf("lora_xin_t", (inn, Mp), bf)
+        if not drop:
+            ops.transpose(xin, xin_t, M, inn, Mp, inn)
+        for t in targets:
+            i, o = lp.dims[t]
+            c0, k = lp.cols[t], lp.slot[t]
+            ops.gemm(dys_t[c0:c0 + o], u_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "B"), o, r, Mp, mode=GEMM_F32)
+            if drop:
+                xd = m._buf("lora_xd", (M, inn), bf)
+                xin_drop(t, xd)
+                ops.transpose(xd, xin_t, M, inn, Mp, inn)
+            ops.gemm(du_t[k * rp: k * rp + r], xin_t, lp.view(lp.proj.g, l, t, "A"), r, i, Mp, mode=GEMM_F32)
+
+    # ---- one decoder layer, forward (modeling_qwen2.py's Qwen2DecoderLayer with every adapted Linear = base + low-rank branch)
+    def layer_fwd(self, st, l, w, bufs, drop):
+        m, lp, ops, geo = self.m, self.lp, self.m.ops, self.m.geo
+        B, S, M = st.B, st.S, st.M
+        D, I, H, G = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads
+        LDQ, scale, eps, p = (H + 2 * G) * HD, HD ** -0.5, geo.rms_eps, lp.cfg.lora_dropout
+        bf = torch.bfloat16
+        xs, rstd, qkv, ao, lse, gu, xn, act, cos, sin = (bufs[k] for k in ("xs", "rstd", "qkv", "ao", "lse", "gu", "xn", "act", "cos", "sin"))
+        x_in, x_mid, x_out = xs[2 * l], xs[2 * l + 1], xs[2 * l + 2]
+        groups = dict(lp.groups)
+        sid = lambda t: self._sid(l, t)
+        ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], eps)
+        if "qkv" in groups:
+            ops.gemm(xn, w["wqkv"], qkv[l], M, LDQ, D, bias=w["bqkv"])
+            self.group_fwd(l, "qkv", groups["qkv"], xn, qkv[l], LDQ, M, drop,
+                           lambda t, dst: ops.lora_dropout_norm(x_in, w["ln1"], rstd[2 * l], dst, M, D, p, lp.rng, sid(t)))
+            ops.rope_fwd(qkv[l], cos, sin, None, None, None, B, S, H, G)
+        else:
+            ops.gemm_qkv_rope(xn, w["wqkv"], w["bqkv"], qkv[l], cos, sin, M, H, G, D)
+        ops.attn_fwd(qkv[l], None, st.dev["key_mask"], ao[l], lse[l], B, S, H, G, scale, True)
+        if "o" in groups:
+            y = m._buf("lora_y", (M, D), bf)
+            ops.gemm(ao[l], w["wo"], y, M, D, H * HD)
+            self.group_fwd(l, "o", groups["o"], ao[l], y, D, M, drop,
+                           lambda t, dst: ops.lora_dropout(ao[l], dst, p, lp.rng, sid(t)), x_in=x_in, x_out=x_mid)
+        else:
+            ops.gemm(ao[l], w["wo"], x_mid, M, D, H * HD, resid=x_in, mode=GEMM_RESID)
+        ops.rmsnorm_fwd(x_mid, w["ln2"], xn, rstd[2 * l + 1], eps)
+        if "gu" in groups:
+            ops.gemm(xn, w["wgu"], gu[l], M, 2 * I, D)
+            self.group_fwd(l, "gu", groups["gu"], xn, gu[l], 2 * I, M, drop,
+                           lambda t, dst: ops.lora_dropout_norm(x_mid, w["ln2"], rstd[2 * l + 1], dst, M, D, p, lp.rng, sid(t)))
+            ops.swiglu_fwd(gu[l], act, M, I)
+        else:
+            ops.gemm_gate_up_swiglu(xn, w["wgu"], gu[l], act, M, I, D)
+        if "down" in groups:
+            y = m._buf("lora_y", (M, D), bf)
+            ops.gemm(act, w["wd"], y, M, D, I)
+            self.group_fwd(l, "down", groups["down"], act, y, D, M, drop,
+                           lambda t, dst: ops.lora_dropout(act, dst, p, lp.rng, sid(t)), x_in=x_mid, x_out=x_out)
+        else:
+            ops.gemm(act, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
+
+    # ---- one decoder layer, backward: the frozen recipe's dgrad chain + every adapter's dgrad and weight gradients
+    def layer_bwd(self, st, l, w, bufs, drop):
+        m, lp, ops, geo, d = self.m, self.lp, self.m.ops, self.m.geo, st.dev
+        B, S, M = st.B, st.S, st.M
+        D, I, H, G = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads
+        LDQ, scale, eps, p = (H + 2 * G) * HD, HD ** -0.5, geo.rms_eps, lp.cfg.lora_dropout
+        bf = torch.bfloat16
+        dx, dxb, dn, dact, dgu, dao, delta, dqkv, dkp, dvp = (bufs[k] for k in ("dx", "dxb", "dn", "dact", "dgu", "dao", "delta", "dqkv", "dkp", "dvp"))
+        xs, rstd, cos, sin = d["xs"], d["rstd"], d["cos"], d["sin"]
+        x_in, x_mid = xs[2 * l], xs[2 * l + 1]
+        xn = m._buf("xn_llm", (M, D), bf)                      # the forward's scratch: free again
+        act = m._buf("act", (M, I), bf)
+        groups = dict(lp.groups)
+        sid = lambda t: self._sid(l, t)
+        if "down" in groups:
+            ops.gemm(dxb, w["wd_t"], dact, M, I, D)
+            ops.swiglu_fwd(d["gu"][l], act, M, I)              # the adapter's input (the frozen recipe keeps gate|up only)
+            self.group_bwd(l, "down", groups["down"], dxb, D, M, act, dact, drop,
+                           lambda t, dst: ops.lora_dropout(act, dst, p, lp.rng, sid(t)))
+            ops.swiglu_bwd(dact, d["gu"][l], dgu, M, I)
+        else:
+            ops.gemm_dswiglu(dxb, w["wd_t"], d["gu"][l], dgu, dact, M, I, D)
+        ops.gemm(dgu, w["wgu_t"], dn, M, D, 2 * I)
+        if "gu" in groups:
+            ops.rmsnorm_fwd(x_mid, w["ln2"], xn, None, eps)
+            self.group_bwd(l, "gu", groups["gu"], dgu, 2 * I, M, xn, dn, drop,
+                           lambda t, dst: ops.lora_dropout_norm(x_mid, w["ln2"], rstd[2 * l + 1], dst, M, D, p, lp.rng, sid(t)))
+        ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
+        ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)
+        if "o" in groups:
+            self.group_bwd(l, "o", groups["o"], dxb, D, M, d["ao"][l], dao, drop,
+                           lambda t, dst: ops.lora_dropout(d["ao"][l], dst, p, lp.rng, sid(t)))
+        ops.attn_bwd_prep(dao, d["ao"][l], delta, None, B, S, H)
+        ops.attn_bwd_rope(d["qkv"][l], d["key_mask"], dao, d["lse"][l], delta, cos, sin, dqkv, dkp, dvp, B, S, H, G, scale, True)
+        ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)
+        if "qkv" in groups:
+            ops.rmsnorm_fwd(x_in, w["ln1"], xn, None, eps)
+            self.group_bwd(l, "qkv", groups["qkv"], dqkv, LDQ, M, xn, dn, drop,
+                           lambda t, dst: ops.lora_dropout_norm(x_in, w["ln1"], rstd[2 * l], dst, M, D, p, lp.rng, sid(t)))
+        ops.rmsnorm_bwd(dn, x_in, w["ln1"], rstd[2 * l], dx, dxb, True)

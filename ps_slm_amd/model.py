@@ -157,6 +157,17 @@ class ProjectorParams:
         self.w1b_t = torch.zeros(k * Kp, Hb, dtype=torch.bfloat16, device=device)   # W1^T for dgrad (linear-silu, cov1d-linear)
         self.w2b_t = torch.zeros(Hb, Do, dtype=torch.bfloat16, device=device)       # W2^T for dgrad
 
+    def extend(self, extra):
+        """Grows the flat buffers by ``extra`` elements behind the projector's tensors (the LoRA adapters: ps_slm_amd/lora.py);
+        contents are kept.  Everything that walks [0, numel) -- AdamW, the gradient exchange -- then covers the tail too."""
+        n = self.numel + int(extra)
+        for name in ("p", "g", "m", "v", "pb"):
+            old = getattr(self, name)
+            new = torch.zeros(n, dtype=old.dtype, device=old.device)
+            new[: old.numel()].copy_(old)
+            setattr(self, name, new)
+        self.numel = n
+
     def view(self, flat, name):
         off, shp = self.offsets[name]
         return flat[off:off + int(np.prod(shp))].view(*shp)
@@ -333,6 +344,7 @@ class StepState:
     dev: dict = field(default_factory=dict)
     out: object = None
     path: str = "text"   # "text" (pseudo-posterior) or "audio" (encoder + PSD): part of the graph keys, the buffers differ
+    lora_drop: bool = False   # this step's forward drew LoRA dropout masks (the backward regenerates them)
 
 
 class TasuModel:
@@ -365,6 +377,8 @@ class TasuModel:
         self._buf_gen = 0              # bumped whenever a named workspace buffer is re-allocated (grown)
         self._dec_graphs, self._dec_seen = collections.OrderedDict(), {}   # decode-step graphs (ps_slm_amd/decode.py): small LRU
         self._done_host = None         # pinned "decode finished" word the beam-update kernel writes
+        self.lora = None               # ps_slm_amd.lora.LoraParams once enable_lora() ran (use_peft=true)
+        self._lora_run = None
 
     # ------------------------------------------------------------------------------------------ weights
     def load_reference_state_dict(self, sd):
@@ -426,7 +440,32 @@ class TasuModel:
 
     def sync_projector_copies(self):
         self.ops.cast_bf16(self.proj.p, self.proj.pb)
+        self.refresh_working_copies()
+
+    def refresh_working_copies(self):
+        """After the bucket's bf16 copy changed (a load, an optimizer step): the transposed copies the dgrads read."""
         self.proj.refresh_working_copies(self.ops)
+        if self.lora is not None:
+            self.lora.refresh_working_copies(self.ops)
+
+    def enable_lora(self, cfg, seed=4242):
+        """use_peft=true (ps-slm.py:114-117): adapters on the decoder's Linears, trainable next to the projector.  Call before
+        an engine is built on the model (the trainable bucket grows)."""
+        from .lora import LoraParams, LoraRunner
+        if self.lora is not None:
+            raise RuntimeError("LoRA is already enabled on this model")
+        self.lora = LoraParams(self.geo, cfg, self.proj, self.device)
+        self.lora.init_default(seed)
+        self.lora.seed_dropout(seed)
+        self._lora_run = LoraRunner(self)
+        self._graphs, self._graph_seen = {}, {}
+        self.sync_projector_copies()
+
+    def lora_state_dict(self):
+        return {} if self.lora is None else self.lora.state_dict()
+
+    def lora_grads(self):
+        return {} if self.lora is None else self.lora.grads()
 
     def projector_state_dict(self):
         return {"encoder_projector." + n: self.proj.export(n) for n in self.proj.names}
@@ -665,7 +704,7 @@ class TasuModel:
         ops.transpose(d["xn"].view(Rap, Kp), xn_t, Rap, Kp, Rap, Kp)
         ops.gemm(dq_t, xn_t, pr.view(pr.g, "W_q.weight"), D, Kp, Rap, mode=GEMM_F32)
         if on_ready is not None:
-            on_ready(0, pr.numel)
+            on_ready(0, pr.numel if self.lora is None else self.lora.base)
 
     def forward_llm(self, st: StepState, compute_loss=True, need_backward=True, logits_rows="all"):
         ops, geo, llm = self.ops, self.geo, self.llm
@@ -688,9 +727,18 @@ class TasuModel:
         gu = self._buf("gu", (L, M, 2 * I), bf)
         xn = self._buf("xn_llm", (M, D), bf)
         act = self._buf("act", (M, I), bf)
+        lora = self._lora_run
         tail = bool(self.tail_rows and compute_loss and need_backward and not self.keep_logits and logits_rows != "none"
-                    and "lab_rows" in d and st.nLp > 0)
+                    and "lab_rows" in d and st.nLp > 0 and lora is None)
+        drop = lora is not None and lora._drop_on(self.training)
+        if drop:
+            ops.rng_advance(self.lora.rng)                     # new masks for this micro-step (a launch: graph replays advance too)
+        st.lora_drop = drop
+        fb = dict(xs=xs, rstd=rstd, qkv=qkv, ao=ao, lse=lse, gu=gu, xn=xn, act=act, cos=cos, sin=sin)
         for l, w in enumerate(llm.layers):
+            if lora is not None:
+                lora.layer_fwd(st, l, w, fb, drop)
+                continue
             x_in, x_mid, x_out = xs[2 * l], xs[2 * l + 1], xs[2 * l + 2]
             ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], geo.rms_eps)
             ops.gemm_qkv_rope(xn, w["wqkv"], w["bqkv"], qkv[l], cos, sin, M, H, G, D)      # bias + RoPE in the GEMM's epilogue
@@ -826,8 +874,13 @@ class TasuModel:
         else:
             ops.gemm(d["dlogits"], llm.head_t, dn, M, D, Vp)
             ops.rmsnorm_bwd(dn, xs[2 * L], llm.norm, rstd[2 * L], dx, dxb, False)
+        lora = self._lora_run
+        bb = dict(dx=dx, dxb=dxb, dn=dn, dact=dact, dgu=dgu, dao=dao, delta=delta, dqkv=dqkv, dkp=dkp, dvp=dvp)
         for l in range(L - 1, -1, -1):
             w = llm.layers[l]
+            if lora is not None:
+                lora.layer_bwd(st, l, w, bb, bool(getattr(st, "lora_drop", False)))
+                continue
             x_in, x_mid = xs[2 * l], xs[2 * l + 1]
             if not (l == L - 1 and "xout_tail" in d):          # (the compact tail above has done the last layer's MLP)
                 ops.gemm_dswiglu(dxb, w["wd_t"], d["gu"][l], dgu, dact, M, I, D)
@@ -848,13 +901,15 @@ class TasuModel:
         [norm.weight | norm.bias] (linear-silu) or [conv1d.weight | conv1d.bias] (cov1d-linear).  The ranges tile [0, numel)
         exactly."""
         pr = self.proj
+        end = pr.numel if self.lora is None else self.lora.base            # the projector's own tensors end here
+        head = [] if self.lora is None else [(self.lora.base, pr.numel)]   # the adapters: complete when the decoder's backward is
         if pr.is_ca:
-            return [(0, pr.numel)]
+            return head + [(0, end)]
         o_w1, o_b1 = pr.offsets[pr.n_w1][0], pr.offsets[pr.n_b1][0]
         ld = pr.kin * pr.Kp
         rows = [pr.Hb * i // w1_chunks for i in range(w1_chunks + 1)]
-        out = [(o_b1, pr.numel)] + [(o_w1 + r0 * ld, o_w1 + r1 * ld) for r0, r1 in zip(rows[:-1], rows[1:])]
-        return out + ([(0, o_w1)] if o_w1 > 0 else [])
+        out = [(o_b1, end)] + [(o_w1 + r0 * ld, o_w1 + r1 * ld) for r0, r1 in zip(rows[:-1], rows[1:])]
+        return head + out + ([(0, o_w1)] if o_w1 > 0 else [])
 
     def backward_projector(self, st: StepState, on_ready=None, w1_chunks=1):
         """Merge backward + projector backward (projector.py:149-151 / :38-49 reversed): wgrads land in the flat fp32 bucket.
@@ -867,6 +922,8 @@ class TasuModel:
             return self._backward_cross_attention(st, on_ready)
         bf, f32 = torch.bfloat16, torch.float32
         ranges = self.grad_ranges(w1_chunks)
+        if self.lora is not None:
+            ranges = ranges[1:]                        # (the adapters' range belongs to backward_llm: run_backward reports it)
         # merge backward: gradient rows that hold audio -> projector output gradient
         Rap, K, Kp, Hb, Do = st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
         kKp = pr.kin * Kp                                     # input width of the first Linear
@@ -975,7 +1032,7 @@ class TasuModel:
         self._graphed(("region",) + tuple(key), fn, _NoState())
 
     def _shape_key(self, st, tag):
-        return (tag, st.path, st.B, st.S, st.Ra, st.Rap, st.Fap, st.nLp, self.keep_logits)
+        return (tag, st.path, st.B, st.S, st.Ra, st.Rap, st.Fap, st.nLp, self.keep_logits, self.lora is not None and self.training)
 
     def run_forward_text(self, st, compute_loss=True, need_backward=True):
         """forward_projector_text + forward_llm, graph-replayed when enabled."""
@@ -999,6 +1056,8 @@ class TasuModel:
             self._graphed(self._shape_key(st, "bwd"), lambda: self.backward(st), st)
         else:
             self._graphed(self._shape_key(st, "bwd_llm"), lambda: self.backward_llm(st), st)
+            if self.lora is not None:
+                on_ready(self.lora.base, self.proj.numel)      # every adapter gradient is complete: exchanged under the projector's backward
             self.backward_projector(st, on_ready, w1_chunks)
 
     # ------------------------------------------------------------------------------------------ results

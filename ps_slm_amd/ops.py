@@ -306,6 +306,24 @@ class HipOps:
     def relu_fwd(self, x, y):
         self._chk(self.lib.tasu_relu_fwd(_p(x), _p(y), x.numel(), self._stream()), "tasu_relu_fwd")
 
+    # ------------------------------------------------------------------ LoRA (elementwise pieces between the GEMMs)
+    def lora_add(self, y, t, s=1.0, x_in=None, x_out=None):
+        """y = bf16(y + bf16(t * s)); with x_in / x_out also x_out = x_in + float(y)."""
+        self._chk(self.lib.tasu_lora_add(_p(y), _p(t), float(s), _p(x_in), _p(x_out), y.numel(), self._stream()), "tasu_lora_add")
+
+    def scale_bf16(self, src, dst, s):
+        self._chk(self.lib.tasu_scale_bf16(_p(src), _p(dst), float(s), src.numel(), self._stream()), "tasu_scale_bf16")
+
+    def lora_dropout(self, src, dst, p, rng, sid):
+        self._chk(self.lib.tasu_lora_dropout(_p(src), _p(dst), src.numel(), float(p), _p(rng), int(sid), self._stream()), "tasu_lora_dropout")
+
+    def lora_dropout_norm(self, x, w, rstd, dst, M, D, p, rng, sid):
+        self._chk(self.lib.tasu_lora_dropout_norm(_p(x), _p(w), _p(rstd), _p(dst), M, D, float(p), _p(rng), int(sid), self._stream()),
+                  "tasu_lora_dropout_norm")
+
+    def rng_advance(self, rng):
+        self._chk(self.lib.tasu_rng_advance(_p(rng), self._stream()), "tasu_rng_advance")
+
     # ------------------------------------------------------------------ loss
     def ce_fwd_bwd(self, logits, shift_labels, M, V, row_loss, row_hit, row_argmax, dlogits, inv_count):
         self._chk(self.lib.tasu_ce_fwd_bwd(_p(logits), logits.stride(0), _p(shift_labels), M, V, _p(row_loss),

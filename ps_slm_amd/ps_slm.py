@@ -182,9 +182,15 @@ def model_factory(train_config, model_config, **kwargs):
                                   "Multitask/scripts/finetune_deespeed_sensevoice.sh:25), 'linear' (EncoderProjectorConcat, "
                                   "Multitask/model/projector.py:28-49), 'cov1d-linear' (EncoderProjectorCov1d, :53-73) and "
                                   "'cross-attention' (EncoderProjectorCTCCA, :104-126); q-former / simple_linear are not built")
-    if train_config.get("use_peft", False) or not train_config.get("freeze_llm", True):
-        raise NotImplementedError("the MI355X path trains the projector only (freeze_llm=true, use_peft=false: "
-                                  "Multitask/scripts/finetune_deespeed_sensevoice.sh:28,84)")
+    if not train_config.get("freeze_llm", True):
+        raise NotImplementedError("the MI355X path keeps the decoder's own weights frozen (freeze_llm=true: Multitask/scripts/"
+                                  "finetune_deespeed_sensevoice.sh:84); with use_peft=true the LoRA adapters train, full fine-tuning of "
+                                  "the LLM is not built")
+    if train_config.get("quantization", False) or train_config.get("use_emb", False):
+        raise NotImplementedError("train_config.quantization / use_emb (ps-slm.py:101-102, :119-123) are not built")
+    if kwargs.get("peft_ckpt", None):
+        raise NotImplementedError("peft_ckpt (a peft adapter DIRECTORY, ps-slm.py:110-112): load the adapters from the training "
+                                  "checkpoint with ckpt_path instead -- it holds them under the reference's own key names")
     if not train_config.get("use_fp16", False):
         # the reference computes in fp32 unless use_fp16 wraps the step in bf16 autocast (deepspeed_utils.py:160,205) and
         # decodes in fp32 (inference_batch.py:113-117); this path has ONE arithmetic: bf16 autocast semantics
@@ -215,6 +221,11 @@ def model_factory(train_config, model_config, **kwargs):
         enc_pt = os.path.join(str(model_config.get("encoder_path", "")), "model.pt")
         if need_encoder:
             core.load_encoder_checkpoint(enc_pt)
+    if train_config.get("use_peft", False):
+        from ps_slm_amd.lora import LoraConfig
+        core.enable_lora(LoraConfig.from_peft_config(train_config.get("peft_config", {}) or {}), seed=int(train_config.get("seed", 42)) + 7)
+        logger.info("LoRA: r=%d alpha=%g dropout=%g on %s: %d adapter parameters", core.lora.cfg.r, core.lora.cfg.lora_alpha,
+                    core.lora.cfg.lora_dropout, ",".join(core.lora.cfg.target_modules), core.lora.num_parameters())
     model = slam_model_asr(core, tokenizer, setup_encoder_tokenizer(model_config, geo), train_config, model_config, **kwargs)
     ckpt_path = kwargs.get("ckpt_path", None)
     if ckpt_path is not None:
@@ -282,6 +293,7 @@ class slam_model_asr:
     # ---- nn.Module-like surface
     def train(self, mode=True):
         self.training = mode
+        self.core.training = bool(mode)                # LoRA dropout is active in training mode only
         return self
 
     def eval(self):
@@ -305,12 +317,17 @@ class slam_model_asr:
             elif v.dim() == 2 and len(r) == 2 and not (n == pr.n_w1 and pr.kin > 1):
                 v = v[:, : r[1]]
             yield "encoder_projector." + n, v.requires_grad_(True)
+        if self.core.lora is not None:                 # use_peft=true: lora_A / lora_B of every adapted Linear, peft's key names
+            for key, k in self.core.lora.names():
+                yield key, self.core.lora.view(flat, *k).requires_grad_(True)
 
     def parameters(self):
         return (p for _, p in self.named_parameters())
 
     def state_dict(self):
-        return self.core.projector_state_dict()
+        """The trainable tensors (what the reference's checkpoint keeps: checkpoint_handler.py:169-182 saves with
+        exclude_frozen_parameters): the projector and, with use_peft, the adapters."""
+        return {**self.core.projector_state_dict(), **self.core.lora_state_dict()}
 
     def load_state_dict(self, sd, strict=False):
         missing = []
@@ -320,10 +337,18 @@ class slam_model_asr:
                 self.core.proj.load(n, sd[k].to(self.core.device, torch.float32))
             else:
                 missing.append(k)
+        known = set()
+        if self.core.lora is not None:
+            for key, k in self.core.lora.names():
+                known.add(key)
+                if key in sd:
+                    self.core.lora.load(*k, sd[key])
+                else:
+                    missing.append(key)
         if strict and missing:
             raise KeyError(f"missing keys {missing}")
         self.core.sync_projector_copies()
-        return missing, [k for k in sd if not k.startswith("encoder_projector.")]
+        return missing, [k for k in sd if not k.startswith("encoder_projector.") and k not in known]
 
     # ---- CPS noise draws: same calls in the same order on the global CPU RNG as ps-slm.py:380-399
     def draw_noise(self, ids_list):

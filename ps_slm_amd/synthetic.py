@@ -147,3 +147,19 @@ def synthetic_text_batch(geo: Geometry, B, seed, prompt_len=25, n_audio=104, tar
         batch["alphas"] = alphas
         batch["keeps"] = keeps
     return batch
+
+
+def random_lora_state_dict(geo: Geometry, cfg, seed: int, b_scale=0.05):
+    """Seeded adapter tensors under the reference's checkpoint keys (ps_slm_amd.lora.key_of): A ~ U(-1/sqrt(in), 1/sqrt(in)) as
+    peft initialises it, B ~ N(0, b_scale) -- NOT peft's zero init, so that every adapter contributes to the outputs and
+    every lora_A receives a gradient in parity tests."""
+    from .lora import key_of, target_dims
+    g = torch.Generator().manual_seed(seed)
+    dims = target_dims(geo)
+    sd = {}
+    for l in range(geo.llm_layers):
+        for t in cfg.target_modules:
+            i, o = dims[t]
+            sd[key_of(l, t, "A")] = (torch.rand(cfg.r, i, generator=g) * 2 - 1) / math.sqrt(i)
+            sd[key_of(l, t, "B")] = torch.randn(o, cfg.r, generator=g) * b_scale
+    return sd

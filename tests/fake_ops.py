@@ -18,6 +18,9 @@ def _bf(x):
     return x.to(torch.bfloat16)
 
 
+from oracle.lora_oracle import lora_keep_scale  # noqa: E402  (numpy restatement of csrc/lora.hip's dropout mask)
+
+
 class FakeOps:
     name = "fake-cpu"
 
@@ -284,6 +287,24 @@ class FakeOps:
     def gemm_bias_relu(self, a, b, c, M, N, K, bias):
         self.gemm(a, b, c, M, N, K, bias=bias)
         c.copy_(torch.relu(c))
+
+    # ---------------------------------------------------------------- LoRA (csrc/lora.hip)
+    def lora_add(self, y, t, s=1.0, x_in=None, x_out=None):
+        y.copy_(_bf(y.float() + _bf(t.float() * float(s)).float()))
+        if x_in is not None:
+            x_out.copy_(x_in + y.float())
+
+    def scale_bf16(self, src, dst, s):
+        dst.copy_(_bf(src.float() * float(s)))
+
+    def lora_dropout(self, src, dst, p, rng, sid):
+        dst.copy_(_bf(src.float() * lora_keep_scale(rng, sid, src.shape, p)))
+
+    def lora_dropout_norm(self, x, w, rstd, dst, M, D, p, rng, sid):
+        dst.copy_(_bf((w * (x[:M] * rstd[:M, None])) * lora_keep_scale(rng, sid, (M, D), p)))
+
+    def rng_advance(self, rng):
+        rng[1] += 1
 
     def relu_bwd(self, dy, x, dx):
         dx.copy_(torch.where(x.float() > 0, dy, torch.zeros_like(dy)))
