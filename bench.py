@@ -280,8 +280,16 @@ def encoder_gemm_flops_per_utt(geo, frames):
     return 2 * frames * ((layers - 1) * per_layer + first + E * V)
 
 
+def lora_gemm_flops_per_utt(geo, S, cfg):
+    """The adapters' GEMM FLOPs of one utterance: per adapted Linear, forward u = x A^T and v = u B^T (2 S r (in + out)),
+    backward du, dx, dB, dA (twice that)."""
+    from ps_slm_amd.lora import target_dims
+    dims = target_dims(geo)
+    return geo.llm_layers * sum(3 * 2 * S * cfg.r * (dims[t][0] + dims[t][1]) for t in cfg.target_modules)
+
+
 def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank, want_decode, device=None, ops=None,
-              variable=False, blank_biased=False):
+              variable=False, blank_biased=False, lora=False):
     """One training workload (path: "text" = the text-only CPS recipe of configs 2/3/5, "audio" = config 4: 500 feature frames
     through the SenseVoice encoder, CTC posterior, PSD, projector, LLM).  Returns the fields of a bench record.
     ``device`` / ``ops``: tests/test_bench_cpu.py drives this function over gloo with the CPU operator double (the N > 1
@@ -301,6 +309,7 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
     audio = path == "audio"
     train_config = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=not audio, gt_emb_noise=not audio, ctc_posterior=True,
                                do_psd=True, use_fp16=True, batching_strategy="dynamic")
+    train_config.use_peft = bool(lora)                  # the reference's defaults: r = 64, alpha = 16, dropout 0.05, all 7 Linears
     model_config = ModelConfig(llm_path=f"synthetic:{model_name}", encoder_projector="linear-silu", encoder_dim=25055,
                                llm_dim={"qwen2.5-1.5b": 1536, "qwen2.5-7b": 3584, "mid": 256}[model_name])
     device = device or f"cuda:{local_rank}"
@@ -412,9 +421,10 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         n_head = st.nLp / B                             # lm_head rows executed per utterance (labelled positions, padded to 64)
         enc = encoder_gemm_flops_per_utt(geo, raw["input_features"].shape[1] + 4) if audio else 0
         tail = "xout_tail" in st.dev                    # last layer's MLP ran on the labelled rows only (TasuModel.tail_rows)
-        gemm_flops_step = (gemm_flops_per_utt(geo, S, n_audio, n_head, tail) + enc) * B
-        executed_step = (total_flops_per_utt(geo, S, n_audio, n_head, tail) + enc) * B
-        survey_step = (total_flops_per_utt(geo, S, n_audio) + enc) * B
+        lo = lora_gemm_flops_per_utt(geo, S, core.lora.cfg) if core.lora is not None else 0
+        gemm_flops_step = (gemm_flops_per_utt(geo, S, n_audio, n_head, tail) + enc + lo) * B
+        executed_step = (total_flops_per_utt(geo, S, n_audio, n_head, tail) + enc + lo) * B
+        survey_step = (total_flops_per_utt(geo, S, n_audio) + enc + lo) * B
         if timed.replay_ms is not None:
             gemm_ms, n_launch = timed.replay_ms[0] * steps, timed.replay_ms[1] * steps
         else:
@@ -438,6 +448,11 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                      f"utterances / wall time over all shapes; S, FLOPs and roofline describe the LAST step's shape only")
         if blank_note:
             what += "; " + blank_note
+        if core.lora is not None:
+            c = core.lora.cfg
+            what += (f"; LoRA recipe (use_peft=true): r={c.r}, alpha={c.lora_alpha:g}, dropout {c.lora_dropout:g} on {len(c.target_modules)} "
+                     f"Linears per layer, {core.lora.num_parameters() / 1e6:.1f} M adapter parameters trained next to the projector "
+                     f"(decoder wgrads + AdamW over the larger bucket in the step)")
         rec = {
             "value": round(world * B * steps / dt, 2), "unit": "utterances/s", "ms_per_step": round(dt / steps * 1e3, 3),
             "config": {"workload": f"{what}, {model_name}, {B} utterances/GPU x S={S} "
@@ -512,6 +527,7 @@ def main():
                     help="--path audio: raise the CTC blank bias until PSD keeps ~100 frames per utterance (a trained encoder's regime)")
     ap.add_argument("--blank-bias", type=float, default=None,
                     help="--path audio --blank-biased: use this bias instead of searching for it (profiled runs: no search passes in the trace)")
+    ap.add_argument("--lora", action="store_true", help="the use_peft=true recipe (LoRA r=64 on the decoder's 7 Linears) as the measured workload")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-4 (audio-SFT) and config-5 (Qwen2.5-7B) sub-records")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -530,15 +546,16 @@ def main():
 
     main_rec = train_leg(args, args.model, args.path, args.batch, args.steps, args.warmup, world, rank, local_rank,
                          want_decode=world == 1 and not args.no_decode and args.path == "text",
-                         blank_biased=args.blank_biased and args.path == "audio")
+                         blank_biased=args.blank_biased and args.path == "audio", lora=args.lora)
     extras = {}
-    headline = args.model == "qwen2.5-1.5b" and args.path == "text"
+    headline = args.model == "qwen2.5-1.5b" and args.path == "text" and not args.lora
     if world == 1 and headline and not args.no_extra:
         # BASELINE.json configs 4 and 5 as sub-records of the same line (shorter runs: their steps are 3-4x longer)
         extras["variable_S"] = train_leg(args, "qwen2.5-1.5b", "text", args.batch, 32, 24, 1, 0, local_rank, False, variable=True)
         extras["audio_sft"] = train_leg(args, "qwen2.5-1.5b", "audio", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank, False)
         extras["audio_sft_blank_biased"] = train_leg(args, "qwen2.5-1.5b", "audio", args.batch, max(5, args.steps // 2), 2, 1, 0,
                                                      local_rank, False, blank_biased=True)
+        extras["lora_r64"] = train_leg(args, "qwen2.5-1.5b", "text", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank, False, lora=True)
         extras["qwen2.5-7b"] = train_leg(args, "qwen2.5-7b", "text", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank,
                                           want_decode=not args.no_decode)     # + the 7B decode leg (split-K GEMV kernels: no streaming
                                                                               # kernels exist for K = 3584 / 18944 yet)
@@ -551,7 +568,8 @@ def main():
         for name, rec in extras.items():
             rec["metric"] = "train utterances/sec" + {"audio_sft": " (audio-SFT, config 4)", "qwen2.5-7b": " (Qwen2.5-7B align, config 5)",
                                                       "variable_S": " (text-only, variable shapes: CPS drop 0.05, bucketed hipGraphs)",
-                                                      "audio_sft_blank_biased": " (audio-SFT, config 4, ~100 audio tokens per utterance)"}[name]
+                                                      "audio_sft_blank_biased": " (audio-SFT, config 4, ~100 audio tokens per utterance)",
+                                                      "lora_r64": " (text-only, use_peft=true: LoRA r=64 on the decoder + projector)"}[name]
             line[name] = rec
         if world == 1 and not args.no_cpu_baseline and headline:
             line["cpu_baseline"] = cpu_baseline("train1")

@@ -64,6 +64,26 @@ def main():
         save(name, **arrs)
         print(name, "loss", float(out.loss), "acc", float(acc))
 
+    # beam-4 generate() of the adapted model on the inputs of tests/golden/mid_generate_beam4.npz (text path: the clean pseudo-posterior
+    # of the regex-cleaned targets), fp32, no dropout (eval): the decode loop with adapters in place
+    from oracle.make_golden import npify  # noqa: F401
+    zg = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "mid_generate_beam4.npz"))
+    r, alpha, targets, _, _ = CASES["mid_text_lora"]
+    cfg = LoraConfig(r=r, lora_alpha=alpha, lora_dropout=0.0, target_modules=targets)
+    model = build_reference_model(gd, 0, dict(gt_emb=True, gt_emb_noise=False))
+    model.load_state_dict(sd, strict=False)
+    apply_hand_lora(model.llm, random_lora_state_dict(geo, cfg, seed_l), targets, cfg.scaling)
+    words = ["ab cd ef gh", "x yz"]
+    feats = torch.zeros(2, 12, geo.feat_dim)
+    with torch.no_grad():
+        toks = quiet(model.generate, input_ids=torch.from_numpy(zg["input_ids"]), input_features=feats,
+                     attention_mask=torch.from_numpy(zg["attention_mask"]), input_feature_length=torch.tensor([12, 12]),
+                     max_new_tokens=16, targets=words)
+    word_ids = [model.encoder_tokenizer.encode(t) for t in words]
+    assert np.array_equal(np.concatenate([np.asarray(w) for w in word_ids]), zg["post_ids_flat"])
+    save("mid_generate_lora", seed_w=seed_w, seed_l=seed_l, r=r, alpha=alpha, targets=np.asarray(",".join(targets)), tokens_text=toks)
+    print("mid_generate_lora", toks.tolist(), "base model:", zg["tokens_text"].tolist())
+
 
 if __name__ == "__main__":
     main()

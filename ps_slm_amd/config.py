@@ -42,6 +42,19 @@ class ModelConfig(_Section):
 
 
 @dataclass
+class PeftConfig(_Section):
+    """Multitask/aispeech_asr_config.py:41-50 (read by ps_slm_amd.lora.LoraConfig.from_peft_config when use_peft=true)."""
+    peft_method: str = "lora"
+    r: int = 64
+    lora_alpha: int = 16
+    target_modules: List[str] = field(default_factory=lambda: ["q_proj", "k_proj", "v_proj", "o_proj", "up_proj", "gate_proj", "down_proj"])
+    bias: str = "none"
+    task_type: str = "CAUSAL_LM"
+    lora_dropout: float = 0.05
+    inference_mode: bool = False
+
+
+@dataclass
 class TrainConfig(_Section):
     model_name: str = "asr_model"
     enable_ddp: bool = False
@@ -67,6 +80,7 @@ class TrainConfig(_Section):
     ctc_posterior: Optional[bool] = False
     voca_trans: Optional[bool] = False
     use_peft: bool = False
+    peft_config: PeftConfig = field(default_factory=PeftConfig)
     use_emb: bool = False
     gt_emb: bool = False
     gt_emb_noise: bool = False
@@ -138,6 +152,8 @@ def _coerce(text, current):
             pass
     if isinstance(current, float):
         return float(text)
+    if isinstance(current, list):
+        return [t.strip().strip("'\"") for t in text.strip("[]").split(",") if t.strip()]
     if current is None:
         for cast in (int, float):
             try:

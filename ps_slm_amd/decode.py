@@ -149,6 +149,15 @@ DONE_POLL_DEPTH = 2      # generated positions the device may run ahead of the h
 def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, min_length=1, length_penalty=1.0,
                          eos_token_id=None, pad_token_id=None):
     """st: a prepared state whose projector output (st.dev['y2']) is ready.  Returns LongTensor [B, n_new] (CPU)."""
+    if model.lora is not None and model._lora_run is not None:
+        # use_peft: prefill and the decode loop run on the merged weights W + s B A (ps_slm_amd/lora.py: merged_llm)
+        from .lora import merged_llm
+        keep = (model.llm, model._lora_run)
+        model.llm, model._lora_run = merged_llm(model), None
+        try:
+            return beam_search_generate(model, st, num_beams, max_new_tokens, min_length, length_penalty, eos_token_id, pad_token_id)
+        finally:
+            model.llm, model._lora_run = keep
     ops, geo, llm = model.ops, model.geo, model.llm
     B, S, nb = st.B, st.S, num_beams
     # limits of the device beam search (tasu_beam_update, tasu_decode_step_prologue: include/tasu_hip.h), checked BEFORE the prefill

@@ -126,6 +126,8 @@ class LoraParams:
         if self.rp != self.r:
             self.bp = {(l, t): torch.zeros(self.dims[t][1], self.rp, **bf) for l in range(L) for t in cfg.target_modules}
         self.rng = torch.zeros(2, dtype=torch.int64, device=device)          # {seed, step} of the dropout masks (csrc/lora.hip)
+        self.version = 0                                   # bumped whenever the adapters change (load, optimizer step)
+        self._merged, self._merged_version = None, -1      # decode-time weights (merged_llm below)
 
     # ---- views
     def view(self, flat, l, t, which):
@@ -184,6 +186,7 @@ class LoraParams:
     def refresh_working_copies(self, ops):
         """After the bf16 copy of the bucket changed (load, AdamW): the transposed copies the dgrad reads."""
         pb = self.proj.pb
+        self.version += 1
         for l in range(self.geo.llm_layers):
             for t in self.cfg.target_modules:
                 i, o = self.dims[t]
@@ -191,6 +194,52 @@ class LoraParams:
                 ops.transpose(self.view(pb, l, t, "A"), self.at[(l, t)], self.r, i, self.rp, i)           # [r, in] -> [in, rp] (zero pad)
                 if self.bp:
                     self.bp[(l, t)][:, : self.r].copy_(self.view(pb, l, t, "B"))
+
+
+def merged_llm(model):
+    """Decode-time weights: generate() (prefill + the beam-search loop, ps_slm_amd/decode.py) runs on W' = bf16(W + s B A) so that
+    the weight-streaming decode kernels stay exactly the frozen recipe's.  The training step never uses these (module docstring);
+    for inference the merge costs one more bf16 rounding of each weight, the same size as the rounding W itself carries.  Built
+    from the fp32 master adapters, rebuilt (in place: captured decode graphs keep their addresses) when the adapters changed.
+    Load-time layout work in torch, not on the step path."""
+    from .model import LLMWeights
+    lp, base, geo = model.lora, model.llm, model.geo
+    if lp._merged is not None and lp._merged_version == lp.version and len(lp._merged.layers) == len(base.layers):
+        return lp._merged
+    s, H, G = lp.cfg.scaling, geo.llm_heads, geo.llm_kv_heads
+    p = lp.proj.p
+
+    def delta(l, t):
+        return s * (lp.view(p, l, t, "B") @ lp.view(p, l, t, "A"))                      # fp32 [out, in]
+
+    def merge(l, w, group):
+        out = w.float()
+        for t in group:
+            if t in lp.cfg.target_modules:
+                c0 = lp.cols[t]
+                out[c0:c0 + lp.dims[t][1]] += delta(l, t)
+        return out.to(torch.bfloat16)
+
+    first = lp._merged is None
+    m = LLMWeights(geo, model.device) if first else lp._merged
+    for l, w in enumerate(base.layers):
+        new = dict(wqkv=merge(l, w["wqkv"], ("q_proj", "k_proj", "v_proj")), wo=merge(l, w["wo"], ("o_proj",)),
+                   wgu=merge(l, w["wgu"], ("gate_proj", "up_proj")), wd=merge(l, w["wd"], ("down_proj",)))
+        if first:
+            m.layers.append(dict(ln1=w["ln1"], ln2=w["ln2"], bqkv=w["bqkv"], wqkv_t=None, wo_t=None, wgu_t=None, wd_t=None, **new))
+        else:
+            for k, v in new.items():
+                m.layers[l][k].copy_(v)
+    m.embed, m.head, m.head_t, m.norm = base.embed, base.head, base.head_t, base.norm
+    if not first and m._decode_ready:
+        # the fragment-order copies of the merged weights are stale: drop them (not the shared lm_head's) and register again
+        if hasattr(model.ops, "forget_decode_weights"):
+            model.ops.forget_decode_weights([w[k].data_ptr() for w in m.layers for k in ("wqkv", "wo", "wgu", "wd")])
+        m._decode_ready = False
+        model._dec_graphs.clear()
+        model._dec_seen.clear()
+    lp._merged, lp._merged_version = m, lp.version
+    return m
 
 
 class LoraRunner:

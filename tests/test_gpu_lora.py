@@ -83,3 +83,76 @@ def test_lora_step_hip_vs_double_and_reference_golden(ops, name):
     for k, g2 in cm.projector_grads().items():
         assert cosine(gm.projector_grads()[k], g2) > 0.9995, k
     check_against_golden(gm, sg, z)
+
+
+def test_generate_with_adapters_on_gpu(ops):
+    """Beam-4 decode of the adapted model on the HIP kernels (merged weights through the streaming decode path) against the
+    hand-LoRA reference's tokens (common prefix) and the CPU double's."""
+    from test_lora_cpu import gen_inputs, generate_text
+    geo, cfg, sd, lsd, ids, am, word_ids, ref, ref_base = gen_inputs()
+    gm = build(geo, cfg, sd, lsd, ops, "cuda")
+    cm = build(geo, cfg, sd, lsd, FakeOps(), "cpu")
+    tg, tc = generate_text(gm, ids, am, word_ids), generate_text(cm, ids, am, word_ids)
+    assert ((tg == ref).cumprod(1).sum(1) >= 8).all(), (tg, ref)
+    assert ((tg == tc).cumprod(1).sum(1) >= 8).all(), (tg, tc)
+    # the adapted training step still runs on the un-merged weights afterwards
+    assert gm._lora_run is not None and gm.llm is not gm.lora._merged
+
+
+def test_lora_step_at_benchmark_shape(ops):
+    """The use_peft=true step bench.py --lora times: Qwen2.5-1.5B geometry, 16 utterances x S = 256, r = 64 on all seven Linears,
+    dropout 0.05.  Properties: peft's zero-B start (dA == 0 exactly, dB != 0, loss = the frozen model's); with non-zero adapters
+    bitwise determinism for a fixed mask step, hipGraph replay == eager launches, new masks on every replay of the step's graph."""
+    from ps_slm_amd.lora import LoraConfig
+    from ps_slm_amd.model import Geometry, TasuModel
+    from ps_slm_amd.synthetic import random_lora_state_dict, synthetic_text_batch
+    geo = Geometry.qwen25_1p5b()
+    m = TasuModel(geo, ops, "cuda", keep_logits=False)
+    m.init_random(seed=1234)
+    cfg = LoraConfig(r=64, lora_alpha=16, lora_dropout=0.05)
+    m.enable_lora(cfg, seed=11)
+    lp = m.lora
+    batch = synthetic_text_batch(geo, 16, seed=1234, noise=False)
+
+    def train_step(graphs=False, step=None):
+        m.use_graphs = graphs
+        if step is not None:
+            lp.seed_dropout(11, step)
+        st = m.prepare_text(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["post_ids"])
+        m.run_forward_text(st)
+        m.run_backward(st)
+        torch.cuda.synchronize()
+        m.use_graphs = False
+        return st, st.dev["loss_out"].clone(), m.proj.g.clone()
+
+    st, loss0, g0 = train_step(step=0)
+    assert st.M == 4096 and st.S == 256 and torch.isfinite(loss0).all() and torch.isfinite(g0).all()
+    for key, k in lp.names():
+        gv = lp.view(g0, *k)
+        assert (float(gv.abs().max()) == 0.0) == ("lora_A" in key), key
+    m.lora, m._lora_run, keep = None, None, (m.lora, m._lora_run)
+    try:                                                       # the frozen recipe on the same weights: same loss (B = 0 adds nothing)
+        stf = m.prepare_text(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["post_ids"])
+        m.tail_rows = False
+        m.run_forward_text(stf)
+        torch.cuda.synchronize()
+        assert abs(float(stf.dev["loss_out"][0]) - float(loss0[0])) < 2e-5
+    finally:
+        m.lora, m._lora_run = keep
+        m.tail_rows = True
+    lp.load_state_dict(random_lora_state_dict(geo, cfg, 5, b_scale=0.02))
+    m.sync_projector_copies()
+    _, l1, g1 = train_step(step=3)
+    _, l2, g2 = train_step(step=3)
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)                                   # same mask step: bitwise repeatable
+    _, l3, g3 = train_step(step=4)
+    assert not torch.equal(l1, l3)                                                       # another step: other masks
+    outs = []
+    lp.seed_dropout(11, 3)
+    for i in range(4):                                                                   # eager warm-up, capture, replays
+        outs.append(train_step(graphs=True)[1:])
+    assert int(lp.rng[1]) == 7                                                           # every launch of the step advanced the mask step
+    assert torch.equal(outs[0][0], l1) and torch.equal(outs[0][1], g1)                   # eager, masks of step 4
+    assert torch.equal(outs[1][0], l3) and torch.equal(outs[1][1], g3)                   # captured + replayed, masks of step 5
+    _, l6, g6 = train_step(step=6)
+    assert torch.equal(outs[3][0], l6) and torch.equal(outs[3][1], g6)                   # a later replay == eager at the same mask step

@@ -139,3 +139,193 @@ def test_lora_zero_b_equals_base_model_and_dropout_is_training_only():
     m.training = True
     run_text(m, batch)
     assert int(m.lora.rng[1]) == 1
+
+
+# ------------------------------------------------------------------------------------------------ plugin + engine surface
+import os  # noqa: E402
+
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+from ps_slm_amd.config import DEFAULT_DS_CONFIG, ModelConfig, RunConfig, TrainConfig, apply_overrides, load_ds_config  # noqa: E402
+from ps_slm_amd.engine import TasuEngine  # noqa: E402
+from ps_slm_amd.ps_slm import model_factory  # noqa: E402
+
+
+def make_lora(seed=1234, lr=1e-3, p=0.0, r=16, targets=None, **kw):
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True, use_peft=True)
+    tc.peft_config.r, tc.peft_config.lora_alpha, tc.peft_config.lora_dropout = r, 32, p
+    if targets:
+        tc.peft_config.target_modules = list(targets)
+    mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+    model, tok = model_factory(tc, mc, device="cpu", ops=FakeOps(), init_seed=seed, **kw)
+    cfg = load_ds_config(DEFAULT_DS_CONFIG)
+    cfg["lr"] = lr
+    eng = TasuEngine(model, cfg)
+    eng.sched_iter = 10                      # past the zero-lr warm-up steps
+    return model, eng
+
+
+def to_call(raw):
+    return dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"],
+                input_features=raw["input_features"], input_feature_length=raw["input_feature_length"],
+                GT=[" ".join(map(str, p)) for p in raw["post_ids"]])
+
+
+def test_peft_config_overrides_and_rejections():
+    c = apply_overrides(RunConfig(), ["++train_config.use_peft=true", "++train_config.peft_config.r=32",
+                                      "++train_config.peft_config.target_modules=[q_proj,v_proj]",
+                                      "++train_config.peft_config.lora_dropout=0.1"])
+    cfg = LoraConfig.from_peft_config(c.train_config.peft_config)
+    assert (cfg.r, cfg.lora_alpha, cfg.lora_dropout, cfg.target_modules) == (32, 16.0, 0.1, ("q_proj", "v_proj"))
+    assert cfg.scaling == 0.5
+    # the reference's defaults (aispeech_asr_config.py:41-50)
+    d = LoraConfig.from_peft_config(TrainConfig().peft_config)
+    assert (d.r, d.lora_alpha, d.lora_dropout, len(d.target_modules)) == (64, 16.0, 0.05, 7)
+    for bad in (dict(peft_method="prefix"), dict(bias="all"), dict(target_modules=["lm_head"]), dict(r=12)):
+        with pytest.raises(NotImplementedError):
+            LoraConfig.from_peft_config(bad)
+    with pytest.raises(NotImplementedError, match="freeze_llm"):
+        model_factory(TrainConfig(freeze_llm=False, gt_emb=True, ctc_posterior=True), ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256),
+                      device="cpu", ops=FakeOps())
+
+
+def test_lora_engine_steps_and_checkpoint_roundtrip(tmp_path):
+    model, eng = make_lora(p=0.1)
+    core, lp = model.core, model.core.lora
+    named = dict(model.named_parameters())
+    assert len(named) == 6 + 2 * 7 * core.geo.llm_layers and all(p.requires_grad and p.is_leaf for p in named.values())
+    assert sorted(named) == sorted(model.state_dict())
+    assert sum(p.numel() for p in named.values()) == core.proj.num_parameters() + lp.num_parameters()
+    raw = synthetic_text_batch(core.geo, 2, seed=5, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8, noise=False)
+    a0 = {k: v.clone() for k, v in lp.state_dict().items()}
+    losses = []
+    for step in range(6):
+        out, _ = eng(**to_call(raw))
+        losses.append(float(out.loss))
+        eng.backward(out.loss)
+        eng.step()
+        now = lp.state_dict()
+        if step == 0:
+            # peft's init: B = 0, so the first step's dA is zero (A stays) while every B moves
+            assert all(torch.equal(now[k], a0[k]) for k in now if "lora_A" in k)
+            assert all(float(now[k].abs().max()) > 0 for k in now if "lora_B" in k)
+        if step == 1:
+            assert all(not torch.equal(now[k], a0[k]) for k in now if "lora_A" in k)
+    assert losses[-1] < losses[0]
+    assert int(lp.rng[1]) == 6                                # one mask draw per training forward
+    # the bf16 working copies follow the master after every step
+    assert torch.equal(core.proj.pb, core.proj.p.to(torch.bfloat16))
+    t = "down_proj"
+    assert torch.equal(lp.at[(1, t)][:, : lp.r], lp.view(core.proj.pb, 1, t, "A").t())
+    assert float(lp.at[(1, t)][:, lp.r:].abs().max()) == 0.0 and torch.equal(lp.bt[(0, t)], lp.view(core.proj.pb, 0, t, "B").t())
+    # checkpoint: the trainable tensors under the reference's names; a fresh model built with ckpt_path continues from it
+    path = str(tmp_path / "pytorch_model.bin")
+    eng.save_checkpoint(path)
+    sd = torch.load(path)
+    assert sorted(sd) == sorted(model.state_dict())
+    assert sd["llm.base_model.model.model.layers.1.mlp.gate_proj.lora_B.default.weight"].shape == (512, 16)
+    m2, e2 = make_lora(seed=1234, p=0.1, ckpt_path=path)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    model.eval(), m2.eval()
+    o1, _ = model(**to_call(raw))
+    o2, _ = m2(**to_call(raw))
+    assert float(o1.loss) == float(o2.loss)
+    # a projector-only checkpoint loads into the adapted model with the adapters reported missing (strict=False), and is refused strictly
+    proj_only = {k: v for k, v in sd.items() if k.startswith("encoder_projector.")}
+    missing, unexpected = m2.load_state_dict(proj_only)
+    assert len(missing) == 2 * 7 * core.geo.llm_layers and not unexpected
+    with pytest.raises(KeyError):
+        m2.load_state_dict(proj_only, strict=True)
+
+
+def _dp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model, eng = make_lora(targets=("q_proj", "v_proj", "down_proj"))
+    sdl = random_lora_state_dict(model.core.geo, model.core.lora.cfg, 17)      # non-zero B: every adapter tensor has a gradient
+    model.load_state_dict({**model.state_dict(), **sdl})
+    raw = synthetic_text_batch(model.core.geo, 2, seed=100 + rank, prompt_len=9, n_audio=21, target_len=17, speech_pos=4,
+                               feat_frames=8, noise=False)
+    out, _ = eng(**to_call(raw))
+    eng.exchange = False
+    eng.backward(out.loss)
+    g_local = model.core.proj.g.clone()
+    eng.exchange, eng.micro_steps = True, 0
+    out, _ = eng(**to_call(raw))
+    eng.backward(out.loss)
+    lp = model.core.lora
+    assert len(eng._pending) == eng.w1_chunks + 3                             # adapters, tail, 4 row blocks of dW1, LayerNorm params
+    assert (eng._pending[0][0], eng._pending[0][1]) == (lp.base, model.core.proj.numel)
+    assert sum(hi - lo for lo, hi, _ in eng._pending) == model.core.proj.numel
+    eng.step()
+    ret[rank] = dict(grad=g_local, param=model.core.proj.p.clone())
+    dist.destroy_process_group()
+
+
+def test_lora_data_parallel_two_ranks_gloo():
+    """The adapters' gradients travel in the same flat bucket: one more range, exchanged first; replicas stay equal and the update
+    is AdamW on the rank-averaged gradient."""
+    world, port = 2, 31000 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, port, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert torch.equal(r0["param"], r1["param"]), "replicas diverged"
+    model, eng = make_lora(targets=("q_proj", "v_proj", "down_proj"))
+    model.load_state_dict({**model.state_dict(), **random_lora_state_dict(model.core.geo, model.core.lora.cfg, 17)})
+    lp = model.core.lora
+    assert float(r0["grad"][lp.base:].abs().max()) > 0 and not torch.equal(r0["grad"][lp.base:], r1["grad"][lp.base:])
+    model.core.proj.g.copy_(r0["grad"] + r1["grad"])
+    eng.world = 2
+    eng.step()
+    torch.testing.assert_close(model.core.proj.p, r0["param"], rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------ generate() with adapters
+def gen_inputs():
+    from conftest import split_flat
+    zb, zl = load_npz("mid_generate_beam4"), load_npz("mid_generate_lora")
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    cfg = LoraConfig(r=int(zl["r"]), lora_alpha=float(zl["alpha"]), lora_dropout=0.0, target_modules=tuple(str(zl["targets"]).split(",")))
+    sd = random_state_dict(geo, int(zl["seed_w"]), with_encoder=False)
+    lsd = random_lora_state_dict(geo, cfg, int(zl["seed_l"]))
+    ids, am = torch.from_numpy(zb["input_ids"]), torch.from_numpy(zb["attention_mask"])
+    return geo, cfg, sd, lsd, ids, am, split_flat(zb["post_ids_flat"], zb["post_lens"]), zl["tokens_text"], zb["tokens_text"]
+
+
+def generate_text(model, ids, am, word_ids, **kw):
+    from ps_slm_amd.decode import beam_search_generate
+    st = model.prepare_text(ids, am, None, word_ids, None, None)
+    model.forward_projector_text(st)
+    return beam_search_generate(model, st, max_new_tokens=16, **kw).numpy()
+
+
+def test_generate_with_adapters_vs_reference_tokens():
+    """Beam-4 decode of the adapted model (prefill + loop on the merged weights W + s B A) against the tokens the reference's
+    generate() produced with the LoRA formula applied by hand (fp32): a long common prefix (bf16 may flip a late near-tie), and
+    NOT the un-adapted model's tokens.  With peft's zero-B init the merged weights are the base weights bit for bit."""
+    geo, cfg, sd, lsd, ids, am, word_ids, ref, ref_base = gen_inputs()
+    m = build(geo, cfg, sd, lsd, FakeOps(), "cpu")
+    toks = generate_text(m, ids, am, word_ids)
+    common = (toks == ref).cumprod(1).sum(1)
+    assert (common >= 8).all(), (toks, ref)
+    assert not np.array_equal(toks[:, :4], ref_base[:, :4])
+    assert m._lora_run is not None and m.llm is not m.lora._merged            # the training-step weights are back in place
+    # zero-B adapters: exactly the base model's decode
+    base = TasuModel(geo, FakeOps(), "cpu")
+    base.load_reference_state_dict(sd)
+    z = TasuModel(geo, FakeOps(), "cpu")
+    z.load_reference_state_dict(sd)
+    z.enable_lora(cfg)
+    assert np.array_equal(generate_text(z, ids, am, word_ids), generate_text(base, ids, am, word_ids))
+    # the merged weights follow the adapters: after a load they are rebuilt (in place)
+    before = z.lora._merged.layers[0]["wqkv"].clone()
+    ptr = z.lora._merged.layers[0]["wqkv"].data_ptr()
+    z.lora.load_state_dict(lsd)
+    z.sync_projector_copies()
+    toks2 = generate_text(z, ids, am, word_ids)
+    assert z.lora._merged.layers[0]["wqkv"].data_ptr() == ptr and not torch.equal(z.lora._merged.layers[0]["wqkv"], before)
+    assert np.array_equal(toks2, toks)
