@@ -324,6 +324,13 @@ int tasu_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stre
  * library's own -- torch's Philox stream is not reproduced (PARITY UNPINNED for the mask; pinned for a GIVEN mask).
  * tasu_lora_dropout_norm: the same on the fp32 RMSNorm output g * (x * rstd) recomputed from the saved row scales.
  * tasu_rng_advance: step += 1 (a launch, so that a replayed hipGraph draws fresh masks).                                   */
+/* Rank-sized GEMM (csrc/gemm_rank.hip): C[M, N] = A[M, K] . B[N, K]^T for N <= 64 -- the adapters' u = xd A^T and du = dy (sB),
+ * and their weight gradients dB = dy^T u [out, r], dA = du^T xd [r, in] on transposed operands (K = the rows of the step).
+ * 16 x 64 tiles, eight waves per workgroup split K and meet in LDS (no global partials; deterministic).  out_f32: C is fp32,
+ * else bf16; transposed: C^T [N, M] is stored (ldc = its leading dimension).  K % 64 == 0, lda / ldb % 8 == 0, A / B 16-byte
+ * aligned.                                                                                                                  */
+int tasu_gemm_nt_rank(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int out_f32,
+                      int transposed, void* stream);
 int tasu_lora_add(void* y, const void* t, float s, const float* x_in, float* x_out, int64_t n, void* stream);
 int tasu_scale_bf16(const void* src, void* dst, float s, int64_t n, void* stream);
 int tasu_lora_dropout(const void* src, void* dst, int64_t n, float p, const void* rng, int stream_id, void* stream);

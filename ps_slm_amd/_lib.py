@@ -44,6 +44,7 @@ PROTOTYPES = {
     "tasu_silu_bwd": [vp, vp, vp, i64, vp],
     "tasu_relu_bwd": [vp, vp, vp, i64, vp],
     "tasu_relu_fwd": [vp, vp, i64, vp],
+    "tasu_gemm_nt_rank": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
     "tasu_lora_add": [vp, vp, f32, vp, vp, i64, vp],
     "tasu_scale_bf16": [vp, vp, f32, i64, vp],
     "tasu_lora_dropout": [vp, vp, i64, f32, vp, i32, vp],

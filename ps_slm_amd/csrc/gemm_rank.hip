@@ -1,0 +1,130 @@
+// C[M, N] = A[M, K] . B[N, K]^T for N <= 64: the rank-sized GEMMs of the LoRA recipe (ps_slm_amd/lora.py) --
+//   u  = xd A^T          [rows, r]     K = in        (forward)
+//   du = dy (sB)         [rows, r]     K = out       (backward, through lora_B)
+//   dB = dy^T u          [out, r]      K = rows      (weight gradient, fp32; operands transposed by the caller)
+//   dA = (xd^T du)^T     [r, in]       K = rows      (weight gradient, fp32, stored transposed)
+// On the tile policy of gemm.hip these are ONE column of 128-row tiles: 32 of 256 CUs walk the whole K range at one
+// latency-bound K-step (~0.7 us) after the other -- 16-77 us.  What was tried first (measured on MI355X, kept here as the reason
+// for this design): (a) fragments straight from global memory, 16 waves splitting K: adjacent lanes hold different ROWS of an
+// MFMA operand, so every 64-lane load is 64 separate 16-byte accesses -- bound by the L1's line rate, 11-50 us; (b) the 64 x 64
+// tiles of gemm.hip with its global split-K: every splitting workgroup pays an agent-scope release fence (the XCDs' L2s are not
+// coherent), 47-93 us.
+// This kernel: 16 rows x 64 columns per workgroup, EIGHT waves that split K (64-wide chunks round-robin), each wave staging its
+// own chunk -- 2 KiB of A, 8 KiB of B -- into its private 10-KiB LDS region with LDS-DMA (whole 128-byte lines, no barriers: the
+// region is wave-private) and reading MFMA fragments back with the XOR swizzle of gemm.hip; two workgroups per CU = sixteen
+// chunks in flight per CU, which is what hides the load latency.  Partial tiles meet in LDS and are summed in wave order
+// (deterministic, no global traffic).
+#include "common.h"
+#include "../../include/tasu_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int NW = 8;
+constexpr int REGION = 10240;                           // per wave: A 16 x 128 B, then B 64 x 128 B
+
+template <bool F32OUT, bool TSTORE>
+__global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
+                                                               void* __restrict__ Cv, int ldc, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m0 = blockIdx.x * 16;
+  const int ntn = (N + 15) >> 4;
+  char* mine = smem + wave * REGION;
+  // per-lane global sources of the 1-KiB pieces (8 rows x 128 B): lane -> row pc * 8 + (lane >> 3), LDS chunk lane & 7, which
+  // must hold global chunk (lane & 7) ^ ((row >> 1) & 7)  (the LDS image of a DMA is lane-linear: the swizzle sits on the source)
+  const bf16* ga[2];
+  const bf16* gb[8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = i * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+    ga[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = i * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+    gb[i] = B + (size_t)min(r, N - 1) * ldb + c * 8;
+  }
+  const int sw = (lane >> 1) & 7;
+  int roff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) roff[kk] = (lane & 15) * 128 + (((kk * 4 + (lane >> 4)) ^ sw) << 4);
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nchunks = K >> 6;
+  for (int c = wave; c < nchunks; c += NW) {
+    const int koff = c << 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(mine + i * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i * 8 < N) __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(mine + 2048 + i * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bf16x8 fa[2], fb[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      fa[kk] = *(const bf16x8*)(mine + roff[kk]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < ntn) fb[kk][j] = *(const bf16x8*)(mine + 2048 + j * 2048 + roff[kk]);
+    }
+    // the weight-side fragment goes in as the MFMA's A operand: acc[j][r] = C[m0 + (lane & 15)][j * 16 + (lane >> 4) * 4 + r]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < ntn) acc[j] = mfma16(fb[kk][j], fa[kk], acc[j]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this chunk's fragment reads are done before the next DMA lands on them
+  }
+  // partial tiles -> LDS (own region, free now), summed by waves 0..3 (one 16-column group each) in wave order
+  f32x4* part = (f32x4*)mine;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) part[j * 64 + lane] = acc[j];
+  __syncthreads();
+  const int j = wave;
+  if (j >= 4 || j >= ntn) return;
+  f32x4 s = ((const f32x4*)smem)[j * 64 + lane];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {
+    const f32x4 v = ((const f32x4*)(smem + w * REGION))[j * 64 + lane];
+    s[0] += v[0], s[1] += v[1], s[2] += v[2], s[3] += v[3];
+  }
+  const int m = m0 + (lane & 15), n0 = j * 16 + (lane >> 4) * 4;
+  if (m >= M) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + r;
+    if (n >= N) break;
+    const size_t off = TSTORE ? (size_t)n * ldc + m : (size_t)m * ldc + n;
+    if constexpr (F32OUT) ((float*)Cv)[off] = s[r];
+    else ((bf16*)Cv)[off] = (bf16)s[r];
+  }
+}
+
+template <bool F32OUT, bool TSTORE>
+int launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, hipStream_t st) {
+  constexpr int LDS = NW * REGION;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)rank_gemm_kernel<F32OUT, TSTORE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  TASU_LAUNCH((rank_gemm_kernel<F32OUT, TSTORE>), dim3((M + 15) / 16), dim3(64 * NW), LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, C,
+              ldc, M, N, K);
+  return TASU_OK;
+}
+
+}  // namespace
+
+extern "C" int tasu_gemm_nt_rank(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int out_f32,
+                                 int transposed, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || N > 64 || K <= 0 || K % 64 || lda % 8 || ldb % 8 || lda < K || ldb < K) return TASU_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return TASU_ERR_ARG;
+  if (ldc < (transposed ? M : N)) return TASU_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_f32) return transposed ? launch<true, true>(A, lda, B, ldb, C, ldc, M, N, K, st) : launch<true, false>(A, lda, B, ldb, C, ldc, M, N, K, st);
+  return transposed ? launch<false, true>(A, lda, B, ldb, C, ldc, M, N, K, st) : launch<false, false>(A, lda, B, ldb, C, ldc, M, N, K, st);
+}

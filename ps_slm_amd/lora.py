@@ -262,6 +262,15 @@ class LoraRunner:
             now.zero_()
         return t
 
+    def rank(self, a, b, c, M, N, K, f32=False, transposed=False):
+        """A GEMM with a rank-sized (N = r) output: the dedicated kernel up to r = 64, the tile policy beyond."""
+        ops = self.m.ops
+        if N <= 64:
+            return ops.gemm_rank(a, b, c, M, N, K, f32, transposed)
+        if transposed:                                     # C^T = b a^T
+            return ops.gemm(b, a, c, N, M, K, mode=GEMM_F32 if f32 else 0)
+        return ops.gemm(a, b, c, M, N, K, mode=GEMM_F32 if f32 else 0)
+
     def _drop_on(self, training):
         return bool(training and self.lp.cfg.lora_dropout > 0.0)
 
@@ -284,7 +293,7 @@ class LoraRunner:
                 xd = m._buf("lora_xd", (M, inn), torch.bfloat16)
                 xin_drop(t, xd)
             u = u_all[l][:, lp.slot[t] * rp: lp.slot[t] * rp + rp]
-            ops.gemm(xd, lp.a_bf(l, t), u, M, r, i)                               # u = bf16(xd A^T)          [M, r]
+            self.rank(xd, lp.a_bf(l, t), u, M, r, i)                              # u = bf16(xd A^T)          [M, r]
             c0 = lp.cols[t]
             ops.gemm(u, lp.b_bf(l, t), tmp[:, c0:c0 + o], M, o, rp)               # v = bf16(u B^T)           [M, out]
         for t2 in dict(GROUPS)[gname]:
@@ -311,7 +320,7 @@ class LoraRunner:
         for t in targets:
             i, o = lp.dims[t]
             c0, k = lp.cols[t], lp.slot[t]
-            ops.gemm(dys[:, c0:c0 + o], lp.bt[(l, t)], du[:, k * rp: k * rp + rp], M, r, o)     # du = bf16((s dy) B)     [M, r]
+            self.rank(dys[:, c0:c0 + o], lp.bt[(l, t)], du[:, k * rp: k * rp + rp], M, r, o)    # du = bf16((s dy) B)     [M, r]
             ops.gemm(du[:, k * rp: k * rp + rp], lp.at[(l, t)], dxl, M, i, rp)                   # dx = bf16(du A)         [M, in]
             if drop:
                 ops.lora_dropout(dxl, dxl, lp.cfg.lora_dropout, lp.rng, self._sid(l, t))
@@ -329,12 +338,12 @@ class LoraRunner:
         for t in targets:
             i, o = lp.dims[t]
             c0, k = lp.cols[t], lp.slot[t]
-            ops.gemm(dys_t[c0:c0 + o], u_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "B"), o, r, Mp, mode=GEMM_F32)
+            self.rank(dys_t[c0:c0 + o], u_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "B"), o, r, Mp, f32=True)
             if drop:
                 xd = m._buf("lora_xd", (M, inn), bf)
                 xin_drop(t, xd)
                 ops.transpose(xd, xin_t, M, inn, Mp, inn)
-            ops.gemm(du_t[k * rp: k * rp + r], xin_t, lp.view(lp.proj.g, l, t, "A"), r, i, Mp, mode=GEMM_F32)
+            self.rank(xin_t, du_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "A"), i, r, Mp, f32=True, transposed=True)   # (xd^T du)^T
 
     # ---- one decoder layer, forward (modeling_qwen2.py's Qwen2DecoderLayer with every adapted Linear = base + low-rank branch)
     def layer_fwd(self, st, l, w, bufs, drop):

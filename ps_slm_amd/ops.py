@@ -306,7 +306,12 @@ class HipOps:
     def relu_fwd(self, x, y):
         self._chk(self.lib.tasu_relu_fwd(_p(x), _p(y), x.numel(), self._stream()), "tasu_relu_fwd")
 
-    # ------------------------------------------------------------------ LoRA (elementwise pieces between the GEMMs)
+    # ------------------------------------------------------------------ LoRA
+    def gemm_rank(self, a, b, c, M, N, K, f32=False, transposed=False):
+        """c[M, N] = a[M, K] @ b[N, K]^T for N <= 64 (csrc/gemm_rank.hip); ``transposed``: c holds C^T [N, M]."""
+        self._chk(self.lib.tasu_gemm_nt_rank(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), M, N, K, int(f32), int(transposed),
+                                             self._stream()), "tasu_gemm_nt_rank")
+
     def lora_add(self, y, t, s=1.0, x_in=None, x_out=None):
         """y = bf16(y + bf16(t * s)); with x_in / x_out also x_out = x_in + float(y)."""
         self._chk(self.lib.tasu_lora_add(_p(y), _p(t), float(s), _p(x_in), _p(x_out), y.numel(), self._stream()), "tasu_lora_add")

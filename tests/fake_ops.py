@@ -288,7 +288,16 @@ class FakeOps:
         self.gemm(a, b, c, M, N, K, bias=bias)
         c.copy_(torch.relu(c))
 
-    # ---------------------------------------------------------------- LoRA (csrc/lora.hip)
+    # ---------------------------------------------------------------- LoRA (csrc/gemm_rank.hip, csrc/lora.hip)
+    def gemm_rank(self, a, b, c, M, N, K, f32=False, transposed=False):
+        assert N <= 64 and K % 64 == 0
+        acc = a[:M, :K].float() @ b[:N, :K].float().t()
+        out = acc if f32 else _bf(acc)
+        if transposed:
+            c[:N, :M] = out.t()
+        else:
+            c[:M, :N] = out
+
     def lora_add(self, y, t, s=1.0, x_in=None, x_out=None):
         y.copy_(_bf(y.float() + _bf(t.float() * float(s)).float()))
         if x_in is not None:

@@ -156,3 +156,29 @@ def test_lora_step_at_benchmark_shape(ops):
     assert torch.equal(outs[1][0], l3) and torch.equal(outs[1][1], g3)                   # captured + replayed, masks of step 5
     _, l6, g6 = train_step(step=6)
     assert torch.equal(outs[3][0], l6) and torch.equal(outs[3][1], g6)                   # a later replay == eager at the same mask step
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 64, 1536), (4096, 64, 8960), (1536, 64, 4096), (8960, 64, 4096), (141, 16, 256), (333, 24, 192),
+                                   (64, 8, 64), (2048, 48, 512), (17, 64, 1024)])
+def test_gemm_rank_vs_fp32(ops, M, N, K):
+    """csrc/gemm_rank.hip (the adapters' rank-sized GEMMs) against an fp32 product of the same bf16 operands: bf16 / fp32 output,
+    plain / transposed store, strided operands and outputs (column slices of wider buffers), nothing written outside C."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a_full = (torch.randn(M, K + 64, generator=g) * 0.5).bfloat16().cuda()
+    b_full = (torch.randn(N, K + 8, generator=g) * 0.5).bfloat16().cuda()
+    a, b = a_full[:, 64:], b_full[:, :K]
+    ref = a.float() @ b.float().t()
+    tol = 2e-3 * float(ref.abs().max()) + 1e-6
+    c = torch.full((M, N + 16), 7.0, dtype=torch.float32, device="cuda")
+    ops.gemm_rank(a, b, c[:, 8:8 + N], M, N, K, f32=True)
+    assert float((c[:, 8:8 + N] - ref).abs().max()) < tol
+    assert float((c[:, :8] - 7).abs().max()) == 0 and float((c[:, 8 + N:] - 7).abs().max()) == 0      # nothing outside the N columns
+    cb = torch.zeros(M, N + 8, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_rank(a, b, cb, M, N, K)
+    assert torch.equal(cb[:, :N], c[:, 8:8 + N].bfloat16()) and float(cb[:, N:].abs().max()) == 0
+    ct = torch.full((N, M + 3), 7.0, dtype=torch.float32, device="cuda")
+    ops.gemm_rank(a, b, ct, M, N, K, f32=True, transposed=True)
+    assert torch.equal(ct[:, :M], c[:, 8:8 + N].t()) and float((ct[:, M:] - 7).abs().max()) == 0
+    c2 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ops.gemm_rank(a, b, c2, M, N, K, f32=True)
+    assert torch.equal(c2, c[:, 8:8 + N])                                                              # deterministic
