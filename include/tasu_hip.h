@@ -333,6 +333,13 @@ int tasu_gemm_nt_rank(const void* A, int lda, const void* B, int ldb, void* C, i
                       int transposed, void* stream);
 int tasu_lora_add(void* y, const void* t, float s, const float* x_in, float* x_out, int64_t n, void* stream);
 int tasu_scale_bf16(const void* src, void* dst, float s, int64_t n, void* stream);
+/* tasu_lora_apply: y[M, N] = bf16(y + mask . bf16(s . bf16(u[M, R] W[N, R]^T))) and, with x_in / x_out (fp32, leading dimension
+ * ldx), x_out = x_in + float(y): an adapter's rank-R GEMM with the accumulate into the base result fused (one read + one write of
+ * y instead of the GEMM's result, a mask pass and an add pass).  Forward: u = the rank-sized activations, W = lora_B; backward:
+ * u = du, W = A^T [in, R], y = the base path's input gradient and, with p > 0, mask = the dropout mask (p, rng, stream_id) the
+ * forward applied to that input (element index m * N + n).  R % 64 == 0 (zero-padded rank), N % 8 == 0, ld* % 8 == 0.           */
+int tasu_lora_apply(void* y, int ldy, const void* u, int ldu, const void* W, int ldw, int M, int N, int R, float s, float p,
+                    const void* rng, int stream_id, const float* x_in, float* x_out, int ldx, void* stream);
 int tasu_lora_dropout(const void* src, void* dst, int64_t n, float p, const void* rng, int stream_id, void* stream);
 int tasu_lora_dropout_norm(const float* x, const float* w, const float* rstd, void* dst, int M, int D, float p, const void* rng,
                            int stream_id, void* stream);

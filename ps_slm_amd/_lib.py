@@ -47,6 +47,7 @@ PROTOTYPES = {
     "tasu_gemm_nt_rank": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
     "tasu_lora_add": [vp, vp, f32, vp, vp, i64, vp],
     "tasu_scale_bf16": [vp, vp, f32, i64, vp],
+    "tasu_lora_apply": [vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, i32, vp, vp, i32, vp],
     "tasu_lora_dropout": [vp, vp, i64, f32, vp, i32, vp],
     "tasu_lora_dropout_norm": [vp, vp, vp, vp, i32, i32, f32, vp, i32, vp],
     "tasu_rng_advance": [vp, vp],

@@ -99,6 +99,99 @@ __global__ __launch_bounds__(256) void dropout_norm_kernel(const float* __restri
   }
 }
 
+// y[M, N] = bf16(y + mask . bf16(s . bf16(u[M, R] W[N, R]^T)))  [, x_out = x_in + float(y)]: an adapter's second GEMM (K = R = the
+// padded rank, 64) with the accumulate into the base result fused -- forward: u = the rank-sized activations, W = lora_B, y = the
+// base Linear's output; backward: u = du, W = A^T, y = the base path's input gradient, mask = the forward's dropout mask of that
+// input.  HBM-bound on y (read + write); everything about the kernel serves that pass: the 64 x 256 tile's low-rank product goes
+// through MFMA into an LDS image (bf16, the rounding the unfused GEMM had), then every thread handles 8 consecutive columns --
+// 16-byte loads and stores of whole 512-byte row segments.  W (256 rows x 128 B) and u (64 rows) reach LDS by LDS-DMA, XOR-swizzled
+// on the source like the GEMMs' tiles.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+constexpr int AP_BM = 64, AP_BN = 256, AP_VLD = 528;   // v image row stride in bytes (512 + 16: 8-byte writes of 16 rows spread over the banks)
+
+template <bool MASK, bool RESID>
+__global__ __launch_bounds__(256, 2) void lora_apply_kernel(bf16* __restrict__ y, int ldy, const bf16* __restrict__ u, int ldu,
+                                                            const bf16* __restrict__ W, int ldw, int M, int N, int R, float s,
+                                                            uint32_t thr, float inv, const int64_t* __restrict__ rng, int sid,
+                                                            const float* __restrict__ x_in, float* __restrict__ x_out, int ldx) {
+  __shared__ __attribute__((aligned(16))) char smem[AP_BN * 128 + AP_BM * 128];   // 40 KiB: W and u tiles, then (aliased) the v image
+  static_assert(AP_BM * AP_VLD <= AP_BN * 128 + AP_BM * 128, "the v image reuses the operand tiles' space");
+  char* wt = smem;
+  char* ut = smem + AP_BN * 128;
+  char* vt = smem;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = blockIdx.x * AP_BM, n0 = blockIdx.y * AP_BN;
+  f32x4 acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int sw = (lane >> 1) & 7;
+  for (int kc = 0; kc < R; kc += 64) {
+    // W: 32 pieces of 8 rows (8 per wave); u: 8 pieces (2 per wave)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int pc = wave * 8 + i, r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+      const bf16* src = W + (size_t)min(n0 + r, N - 1) * ldw + kc + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(wt + pc * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave * 2 + i, r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+      const bf16* src = u + (size_t)min(m0 + r, M - 1) * ldu + kc + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(ut + pc * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int roff = (lane & 15) * 128 + (((kk * 4 + (lane >> 4)) ^ sw) << 4);
+      const bf16x8 fa = *(const bf16x8*)(ut + wave * 2048 + roff);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const bf16x8 fb = *(const bf16x8*)(wt + j * 2048 + roff);
+        acc[j] = mfma16(fb, fa, acc[j]);               // acc[j][r] = v[m0 + wave*16 + (lane & 15)][n0 + j*16 + (lane >> 4)*4 + r]
+      }
+    }
+    __syncthreads();
+  }
+  {
+    char* row = vt + (wave * 16 + (lane & 15)) * AP_VLD + (lane >> 4) * 8;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) *(bf16x4*)(row + j * 32) = __builtin_convertvector(acc[j], bf16x4);
+  }
+  __syncthreads();
+  uint64_t key = 0;
+  if constexpr (MASK) key = mask_key(rng, sid);
+  const int cch = (tid & 31) * 8, n = n0 + cch;
+  if (n >= N) return;
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int r = pass * 8 + (tid >> 5), m = m0 + r;
+    if (m >= M) break;
+    bf16* yp = y + (size_t)m * ldy + n;
+    const bf16x8 yv = *(const bf16x8*)yp;
+    const bf16x8 vv = *(const bf16x8*)(vt + r * AP_VLD + cch * 2);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float d = (float)(bf16)((float)vv[e] * s);
+      if constexpr (MASK) d = (float)(bf16)(d * keep_scale(key, (int64_t)m * N + n + e, thr, inv));
+      o[e] = (bf16)((float)yv[e] + d);
+    }
+    *(bf16x8*)yp = o;
+    if constexpr (RESID) {
+      const float* xi = x_in + (size_t)m * ldx + n;
+      float* xo = x_out + (size_t)m * ldx + n;
+      const f32x4 a0 = *(const f32x4*)xi, a1 = *(const f32x4*)(xi + 4);
+      f32x4 q0, q1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q0[e] = a0[e] + (float)o[e], q1[e] = a1[e] + (float)o[4 + e];
+      *(f32x4*)xo = q0;
+      *(f32x4*)(xo + 4) = q1;
+    }
+  }
+}
+
 __global__ void rng_advance_kernel(int64_t* rng) {
   if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;
 }
@@ -150,5 +243,28 @@ extern "C" int tasu_lora_dropout_norm(const float* x, const float* w, const floa
 extern "C" int tasu_rng_advance(void* rng, void* stream) {
   if (!rng) return TASU_ERR_ARG;
   TASU_LAUNCH(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int64_t*)rng);
+  return TASU_OK;
+}
+
+extern "C" int tasu_lora_apply(void* y, int ldy, const void* u, int ldu, const void* W, int ldw, int M, int N, int R, float s, float p,
+                               const void* rng, int stream_id, const float* x_in, float* x_out, int ldx, void* stream) {
+  if (!y || !u || !W || M <= 0 || N <= 0 || N % 8 || R <= 0 || R % 64 || ldy % 8 || ldu % 8 || ldw % 8 || ldu < R || ldw < R || ldy < N)
+    return TASU_ERR_ARG;
+  if ((((uintptr_t)y | (uintptr_t)u | (uintptr_t)W) & 15) || ((x_in == nullptr) != (x_out == nullptr)) || (x_in && (ldx % 4 || ldx < N)))
+    return TASU_ERR_ARG;
+  const bool mask = p > 0.f;
+  uint32_t thr = 0;
+  float inv = 1.f;
+  if (mask && (!rng || stream_id < 0 || !drop_args(p, &thr, &inv))) return TASU_ERR_ARG;
+  if (p < 0.f) return TASU_ERR_ARG;
+  const dim3 grid((M + AP_BM - 1) / AP_BM, (N + AP_BN - 1) / AP_BN), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  bf16* yy = (bf16*)y;
+  const bf16 *uu = (const bf16*)u, *ww = (const bf16*)W;
+  const int64_t* rg = (const int64_t*)rng;
+  if (mask && x_in) TASU_LAUNCH((lora_apply_kernel<true, true>), grid, block, 0, st, yy, ldy, uu, ldu, ww, ldw, M, N, R, s, thr, inv, rg, stream_id, x_in, x_out, ldx);
+  else if (mask) TASU_LAUNCH((lora_apply_kernel<true, false>), grid, block, 0, st, yy, ldy, uu, ldu, ww, ldw, M, N, R, s, thr, inv, rg, stream_id, x_in, x_out, ldx);
+  else if (x_in) TASU_LAUNCH((lora_apply_kernel<false, true>), grid, block, 0, st, yy, ldy, uu, ldu, ww, ldw, M, N, R, s, thr, inv, rg, stream_id, x_in, x_out, ldx);
+  else TASU_LAUNCH((lora_apply_kernel<false, false>), grid, block, 0, st, yy, ldy, uu, ldu, ww, ldw, M, N, R, s, thr, inv, rg, stream_id, x_in, x_out, ldx);
   return TASU_OK;
 }

@@ -119,12 +119,18 @@ class LoraParams:
         self.numel = off - self.base
         proj.extend(self.numel)
         bf = dict(dtype=torch.bfloat16, device=device)
-        # transposed bf16 working copies for the dgrad through the adapter: B^T [r, out], A^T [in, rp] (+ padded B when r % 64)
-        self.bt = {(l, t): torch.zeros(self.r, self.dims[t][1], **bf) for l in range(L) for t in cfg.target_modules}
-        self.at = {(l, t): torch.zeros(self.dims[t][0], self.rp, **bf) for l in range(L) for t in cfg.target_modules}
-        self.bp = {}
-        if self.rp != self.r:
-            self.bp = {(l, t): torch.zeros(self.dims[t][1], self.rp, **bf) for l in range(L) for t in cfg.target_modules}
+        # bf16 working copies, rebuilt from the bucket's bf16 image after every change (refresh_working_copies).  The scaling
+        # s = alpha / r is folded into them so that no activation-sized pass ever multiplies by it (exact for the shipped
+        # s = 2^-2; one more bf16 rounding of a WEIGHT otherwise):
+        #   as_ [r, in]   = s A      forward   us = xd (sA)^T               (the scaled rank activations)
+        #   bp  [out, rp] = B        forward   y += us B^T                  (rank padded to 64 with zero columns)
+        #   bts [r, out]  = s B^T    backward  du = dy (sB)                 (d(loss)/d(xd A^T) . s)
+        #   at  [in, rp]  = A^T      backward  dxd = du A ;  dA = du^T xd,  dB = dy^T us
+        keys = [(l, t) for l in range(L) for t in cfg.target_modules]
+        self.as_ = {k: torch.zeros(self.r, self.dims[k[1]][0], **bf) for k in keys}
+        self.bts = {k: torch.zeros(self.r, self.dims[k[1]][1], **bf) for k in keys}
+        self.at = {k: torch.zeros(self.dims[k[1]][0], self.rp, **bf) for k in keys}
+        self.bp = {k: torch.zeros(self.dims[k[1]][1], self.rp, **bf) for k in keys} if self.rp != self.r else {}
         self.rng = torch.zeros(2, dtype=torch.int64, device=device)          # {seed, step} of the dropout masks (csrc/lora.hip)
         self.version = 0                                   # bumped whenever the adapters change (load, optimizer step)
         self._merged, self._merged_version = None, -1      # decode-time weights (merged_llm below)
@@ -133,9 +139,6 @@ class LoraParams:
     def view(self, flat, l, t, which):
         off, shp = self.offsets[(l, t, which)]
         return flat[off:off + shp[0] * shp[1]].view(*shp)
-
-    def a_bf(self, l, t):
-        return self.view(self.proj.pb, l, t, "A")          # [r, in]: the B operand of u = x A^T as stored
 
     def b_bf(self, l, t):
         return self.bp[(l, t)] if self.bp else self.view(self.proj.pb, l, t, "B")   # [out, rp]
@@ -184,16 +187,19 @@ class LoraParams:
         self.rng.copy_(torch.tensor([int(seed), int(step)], dtype=torch.int64))
 
     def refresh_working_copies(self, ops):
-        """After the bf16 copy of the bucket changed (load, AdamW): the transposed copies the dgrad reads."""
-        pb = self.proj.pb
+        """After the bf16 image of the bucket changed (load, AdamW): the working copies the step's kernels read."""
+        pb, sc = self.proj.pb, self.cfg.scaling
         self.version += 1
         for l in range(self.geo.llm_layers):
             for t in self.cfg.target_modules:
                 i, o = self.dims[t]
-                ops.transpose(self.view(pb, l, t, "B"), self.bt[(l, t)], o, self.r, o, self.r)           # [out, r] -> [r, out]
-                ops.transpose(self.view(pb, l, t, "A"), self.at[(l, t)], self.r, i, self.rp, i)           # [r, in] -> [in, rp] (zero pad)
+                a, b = self.view(pb, l, t, "A"), self.view(pb, l, t, "B")
+                ops.scale_bf16(a, self.as_[(l, t)], sc)                                   # s A
+                ops.transpose(b, self.bts[(l, t)], o, self.r, o, self.r)                  # [out, r] -> [r, out]
+                ops.scale_bf16(self.bts[(l, t)], self.bts[(l, t)], sc)                    # s B^T
+                ops.transpose(a, self.at[(l, t)], self.r, i, self.rp, i)                  # [r, in] -> [in, rp] (zero pad)
                 if self.bp:
-                    self.bp[(l, t)][:, : self.r].copy_(self.view(pb, l, t, "B"))
+                    self.bp[(l, t)][:, : self.r].copy_(b)
 
 
 def merged_llm(model):
@@ -244,22 +250,27 @@ def merged_llm(model):
 
 class LoraRunner:
     """The adapted decoder layer: forward and backward of one layer with the low-rank branches in place.  Called by
-    TasuModel.forward_llm / backward_llm when ``model.lora`` is set; uses the model's named workspace buffers."""
+    TasuModel.forward_llm / backward_llm when ``model.lora`` is set; uses the model's named workspace buffers.
+
+    Per adapted Linear the forward is  us = xd (sA)^T  (tasu_gemm_nt_rank) and  y = bf16(y + bf16(us B^T))  (tasu_lora_apply: the
+    rank-64 product, the accumulate and -- for o / down -- the residual add in ONE pass over y); the backward is  du = dy (sB),
+    dxd = mask . (du A) accumulated into the base path's gradient (tasu_lora_apply again), dB = dy^T us and dA = du^T xd (rank GEMMs
+    on transposed operands, fp32, straight into the bucket).  Kept from the forward for the backward, per layer: us, and the
+    adapters' bf16 inputs xd (the dropped copies per target in training mode, the plain norm / attention / SwiGLU outputs
+    otherwise) -- nothing is recomputed and no mask is regenerated except inside the backward's fused accumulate."""
 
     def __init__(self, model):
         self.m = model
         self.lp = model.lora
-        self._zero_gen = {}
 
     # ---- workspace
     def _zbuf(self, name, shape):
-        """bf16 buffer that is zero when (re)allocated: the r -> rp padding columns of u / du are never written."""
+        """bf16 buffer that is zero when (re)allocated: the r -> rp padding columns of us / du are never written."""
         m = self.m
-        gen_before = m._ws.get(name)
+        before = m._ws.get(name)
         t = m._buf(name, shape, torch.bfloat16)
-        now = m._ws[name]
-        if gen_before is not now:
-            now.zero_()
+        if before is not m._ws[name]:
+            m._ws[name].zero_()
         return t
 
     def rank(self, a, b, c, M, N, K, f32=False, transposed=False):
@@ -277,73 +288,63 @@ class LoraRunner:
     def _sid(self, l, t):
         return l * 8 + TARGETS.index(t)
 
-    # ---- forward of one group: y (bf16 [M, width], base result incl. bias) += s * B(A(drop(x)))
-    def group_fwd(self, l, gname, targets, xin, y, width, M, drop, xin_drop=None, x_in=None, x_out=None):
-        """xin: bf16 [M, in] (the base Linear's input).  ``xin_drop(t, dst)`` fills dst with the dropped input of target t.
-        u is kept per layer for the backward.  With x_in / x_out the residual add rides on the last accumulate."""
-        m, lp, ops = self.m, self.lp, self.m.ops
-        L, r, rp, s = m.geo.llm_layers, lp.r, lp.rp, lp.cfg.scaling
-        u_all = self._zbuf("lora_u_" + gname, (L, M, len(targets) * rp))
-        tmp = m._buf("lora_tmp", (M, max(width, 1)), torch.bfloat16)
-        inn = lp.dims[targets[0]][0]
+    def _us(self, gname, nt, M):
+        return self._zbuf("lora_us_" + gname, (self.m.geo.llm_layers, M, nt * self.lp.rp))
+
+    def _xin(self, name, M, width):
+        """Per-layer store of an adapter input: [L, M, width] bf16."""
+        return self.m._buf("lora_x_" + name, (self.m.geo.llm_layers, M, width), torch.bfloat16)
+
+    # ---- forward of one group: y[:, cols_t] (bf16, the base result incl. bias) += us_t B_t^T for every adapted member
+    def group_fwd(self, l, gname, targets, y, M, xd_of, x_in=None, x_out=None):
+        """xd_of(t) -> the bf16 [M, in] input of target t's adapter (stored for the backward by the caller).  With x_in / x_out
+        (single-member groups: o, down) the residual add rides on the accumulate."""
+        lp, ops = self.lp, self.m.ops
+        r, rp = lp.r, lp.rp
+        us_all = self._us(gname, len(targets), M)
         for t in targets:
             i, o = lp.dims[t]
-            xd = xin
-            if drop:
-                xd = m._buf("lora_xd", (M, inn), torch.bfloat16)
-                xin_drop(t, xd)
-            u = u_all[l][:, lp.slot[t] * rp: lp.slot[t] * rp + rp]
-            self.rank(xd, lp.a_bf(l, t), u, M, r, i)                              # u = bf16(xd A^T)          [M, r]
-            c0 = lp.cols[t]
-            ops.gemm(u, lp.b_bf(l, t), tmp[:, c0:c0 + o], M, o, rp)               # v = bf16(u B^T)           [M, out]
-        for t2 in dict(GROUPS)[gname]:
-            if t2 not in targets:                       # an un-adapted member of the group (e.g. q and v only): no contribution
-                c0 = lp.cols[t2]
-                tmp[:, c0:c0 + lp.dims[t2][1]].zero_()
-        ops.lora_add(y, tmp, s, x_in, x_out)                                      # y = bf16(y + bf16(v s)) [, x_out = x_in + y]
+            k, c0 = lp.slot[t], lp.cols[t]
+            us = us_all[l][:, k * rp: k * rp + rp]
+            self.rank(xd_of(t), lp.as_[(l, t)], us, M, r, i)                       # us = bf16(xd (sA)^T)            [M, r]
+            ops.lora_apply(y[:, c0:c0 + o], us, lp.b_bf(l, t), M, o, rp, x_in=x_in, x_out=x_out)
 
     # ---- backward of one group
-    def group_bwd(self, l, gname, targets, dy, width, M, xin, dx_base, drop, xin_drop=None):
-        """dy: bf16 [M, width] gradient of the group's (fused) output; xin as in the forward (recomputed by the caller); dx_base:
-        bf16 [M, in], the base path's input gradient, to which the adapters' is added.  Writes dA / dB into the bucket."""
+    def group_bwd(self, l, gname, targets, dy, width, M, xd_of, dx_base, drop):
+        """dy: bf16 [M, width], the gradient of the group's (fused) output; dx_base: bf16 [M, in], the base path's input
+        gradient, to which every member adds mask_t . (du_t A_t).  Writes dA / dB into the bucket."""
         m, lp, ops = self.m, self.lp, self.m.ops
-        L, r, rp, s = m.geo.llm_layers, lp.r, lp.rp, lp.cfg.scaling
+        L, r, rp, p = m.geo.llm_layers, lp.r, lp.rp, lp.cfg.lora_dropout
         bf = torch.bfloat16
         Mp = rup(M, 64)
-        inn = lp.dims[targets[0]][0]
         nt = len(targets)
-        u_all = m._ws["lora_u_" + gname][: L * M * nt * rp].view(L, M, nt * rp)
-        dys = m._buf("lora_dys", (M, width), bf)
-        ops.scale_bf16(dy, dys, s)
+        inn = lp.dims[targets[0]][0]
+        us_all = m._ws["lora_us_" + gname][: L * M * nt * rp].view(L, M, nt * rp)
         du = self._zbuf("lora_du_" + gname, (M, nt * rp))
-        dxl = m._buf("lora_dxl", (M, inn), bf)
         for t in targets:
             i, o = lp.dims[t]
             c0, k = lp.cols[t], lp.slot[t]
-            self.rank(dys[:, c0:c0 + o], lp.bt[(l, t)], du[:, k * rp: k * rp + rp], M, r, o)    # du = bf16((s dy) B)     [M, r]
-            ops.gemm(du[:, k * rp: k * rp + rp], lp.at[(l, t)], dxl, M, i, rp)                   # dx = bf16(du A)         [M, in]
-            if drop:
-                ops.lora_dropout(dxl, dxl, lp.cfg.lora_dropout, lp.rng, self._sid(l, t))
-            ops.lora_add(dx_base, dxl, 1.0)
-        # weight gradients: dB_t = (s dy_t)^T u_t   [out, r],   dA_t = du_t^T xd_t   [r, in]   (K = the M rows, padded to 64)
-        dys_t = m._buf("lora_dys_t", (width, Mp), bf)
-        ops.transpose(dys, dys_t, M, width, Mp, width)
-        u_t = m._buf("lora_u_t", (nt * rp, Mp), bf)
-        ops.transpose(u_all[l], u_t, M, nt * rp, Mp, nt * rp)
-        du_t = m._buf("lora_du_t", (nt * rp, Mp), bf)
-        ops.transpose(du, du_t, M, nt * rp, Mp, nt * rp)
-        xin_t = m._buf("lora_xin_t", (inn, Mp), bf)
-        if not drop:
-            ops.transpose(xin, xin_t, M, inn, Mp, inn)
+            du_t = du[:, k * rp: k * rp + rp]
+            self.rank(dy[:, c0:c0 + o], lp.bts[(l, t)], du_t, M, r, o)             # du = bf16(dy (sB))              [M, r]
+            ops.lora_apply(dx_base, du_t, lp.at[(l, t)], M, i, rp, p=p if drop else 0.0, rng=lp.rng, sid=self._sid(l, t))
+        # weight gradients: dB_t = dy_t^T us_t [out, r],  dA_t = du_t^T xd_t [r, in]  (K = the M rows, zero-padded to 64)
+        dy_t = m._buf("lora_dy_t", (width, Mp), bf)
+        ops.transpose(dy, dy_t, M, width, Mp, width)
+        us_t = m._buf("lora_us_t", (nt * rp, Mp), bf)
+        ops.transpose(us_all[l], us_t, M, nt * rp, Mp, nt * rp)
+        du_tr = m._buf("lora_du_t", (nt * rp, Mp), bf)
+        ops.transpose(du, du_tr, M, nt * rp, Mp, nt * rp)
+        xd_t = m._buf("lora_xd_t", (inn, Mp), bf)
+        last = None
         for t in targets:
             i, o = lp.dims[t]
             c0, k = lp.cols[t], lp.slot[t]
-            self.rank(dys_t[c0:c0 + o], u_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "B"), o, r, Mp, f32=True)
-            if drop:
-                xd = m._buf("lora_xd", (M, inn), bf)
-                xin_drop(t, xd)
-                ops.transpose(xd, xin_t, M, inn, Mp, inn)
-            self.rank(xin_t, du_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "A"), i, r, Mp, f32=True, transposed=True)   # (xd^T du)^T
+            self.rank(dy_t[c0:c0 + o], us_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "B"), o, r, Mp, f32=True)
+            xd = xd_of(t)
+            if xd is not last:                              # members of a group share their input unless dropout gave each its own
+                ops.transpose(xd, xd_t, M, i, Mp, i)
+                last = xd
+            self.rank(xd_t, du_tr[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "A"), i, r, Mp, f32=True, transposed=True)
 
     # ---- one decoder layer, forward (modeling_qwen2.py's Qwen2DecoderLayer with every adapted Linear = base + low-rank branch)
     def layer_fwd(self, st, l, w, bufs, drop):
@@ -356,75 +357,93 @@ class LoraRunner:
         x_in, x_mid, x_out = xs[2 * l], xs[2 * l + 1], xs[2 * l + 2]
         groups = dict(lp.groups)
         sid = lambda t: self._sid(l, t)
-        ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], eps)
+
+        def dropped_norm(x, wn, rs):                        # target -> its own dropped copy of the norm's fp32 output, kept per layer
+            def f(t):
+                dst = self._xin(t, M, D)[l]
+                ops.lora_dropout_norm(x, wn, rs, dst, M, D, p, lp.rng, sid(t))
+                return dst
+            return f
+
+        def dropped(src, width):
+            def f(t):
+                dst = self._xin(t, M, width)[l]
+                ops.lora_dropout(src, dst, p, lp.rng, sid(t))
+                return dst
+            return f
+
+        # ---- attention block
+        keep1 = "qkv" in groups and not drop               # the norm's output IS the adapters' input: write it into the per-layer store
+        xn1 = self._xin("qkv", M, D)[l] if keep1 else xn
+        ops.rmsnorm_fwd(x_in, w["ln1"], xn1, rstd[2 * l], eps)
         if "qkv" in groups:
-            ops.gemm(xn, w["wqkv"], qkv[l], M, LDQ, D, bias=w["bqkv"])
-            self.group_fwd(l, "qkv", groups["qkv"], xn, qkv[l], LDQ, M, drop,
-                           lambda t, dst: ops.lora_dropout_norm(x_in, w["ln1"], rstd[2 * l], dst, M, D, p, lp.rng, sid(t)))
+            ops.gemm(xn1, w["wqkv"], qkv[l], M, LDQ, D, bias=w["bqkv"])
+            self.group_fwd(l, "qkv", groups["qkv"], qkv[l], M, dropped_norm(x_in, w["ln1"], rstd[2 * l]) if drop else (lambda t: xn1))
             ops.rope_fwd(qkv[l], cos, sin, None, None, None, B, S, H, G)
         else:
-            ops.gemm_qkv_rope(xn, w["wqkv"], w["bqkv"], qkv[l], cos, sin, M, H, G, D)
+            ops.gemm_qkv_rope(xn1, w["wqkv"], w["bqkv"], qkv[l], cos, sin, M, H, G, D)
         ops.attn_fwd(qkv[l], None, st.dev["key_mask"], ao[l], lse[l], B, S, H, G, scale, True)
         if "o" in groups:
             y = m._buf("lora_y", (M, D), bf)
             ops.gemm(ao[l], w["wo"], y, M, D, H * HD)
-            self.group_fwd(l, "o", groups["o"], ao[l], y, D, M, drop,
-                           lambda t, dst: ops.lora_dropout(ao[l], dst, p, lp.rng, sid(t)), x_in=x_in, x_out=x_mid)
+            self.group_fwd(l, "o", groups["o"], y, M, dropped(ao[l], H * HD) if drop else (lambda t: ao[l]), x_in=x_in, x_out=x_mid)
         else:
             ops.gemm(ao[l], w["wo"], x_mid, M, D, H * HD, resid=x_in, mode=GEMM_RESID)
-        ops.rmsnorm_fwd(x_mid, w["ln2"], xn, rstd[2 * l + 1], eps)
+        # ---- MLP block
+        keep2 = "gu" in groups and not drop
+        xn2 = self._xin("gu", M, D)[l] if keep2 else xn
+        ops.rmsnorm_fwd(x_mid, w["ln2"], xn2, rstd[2 * l + 1], eps)
+        keep3 = "down" in groups and not drop
+        act_l = self._xin("down", M, I)[l] if keep3 else act
         if "gu" in groups:
-            ops.gemm(xn, w["wgu"], gu[l], M, 2 * I, D)
-            self.group_fwd(l, "gu", groups["gu"], xn, gu[l], 2 * I, M, drop,
-                           lambda t, dst: ops.lora_dropout_norm(x_mid, w["ln2"], rstd[2 * l + 1], dst, M, D, p, lp.rng, sid(t)))
-            ops.swiglu_fwd(gu[l], act, M, I)
+            ops.gemm(xn2, w["wgu"], gu[l], M, 2 * I, D)
+            self.group_fwd(l, "gu", groups["gu"], gu[l], M, dropped_norm(x_mid, w["ln2"], rstd[2 * l + 1]) if drop else (lambda t: xn2))
+            ops.swiglu_fwd(gu[l], act_l, M, I)
         else:
-            ops.gemm_gate_up_swiglu(xn, w["wgu"], gu[l], act, M, I, D)
+            ops.gemm_gate_up_swiglu(xn2, w["wgu"], gu[l], act_l, M, I, D)
         if "down" in groups:
             y = m._buf("lora_y", (M, D), bf)
-            ops.gemm(act, w["wd"], y, M, D, I)
-            self.group_fwd(l, "down", groups["down"], act, y, D, M, drop,
-                           lambda t, dst: ops.lora_dropout(act, dst, p, lp.rng, sid(t)), x_in=x_mid, x_out=x_out)
+            ops.gemm(act_l, w["wd"], y, M, D, I)
+            self.group_fwd(l, "down", groups["down"], y, M, dropped(act_l, I) if drop else (lambda t: act_l), x_in=x_mid, x_out=x_out)
         else:
-            ops.gemm(act, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
+            ops.gemm(act_l, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
 
     # ---- one decoder layer, backward: the frozen recipe's dgrad chain + every adapter's dgrad and weight gradients
     def layer_bwd(self, st, l, w, bufs, drop):
         m, lp, ops, geo, d = self.m, self.lp, self.m.ops, self.m.geo, st.dev
         B, S, M = st.B, st.S, st.M
         D, I, H, G = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads
-        LDQ, scale, eps, p = (H + 2 * G) * HD, HD ** -0.5, geo.rms_eps, lp.cfg.lora_dropout
-        bf = torch.bfloat16
+        LDQ, scale = (H + 2 * G) * HD, HD ** -0.5
         dx, dxb, dn, dact, dgu, dao, delta, dqkv, dkp, dvp = (bufs[k] for k in ("dx", "dxb", "dn", "dact", "dgu", "dao", "delta", "dqkv", "dkp", "dvp"))
         xs, rstd, cos, sin = d["xs"], d["rstd"], d["cos"], d["sin"]
         x_in, x_mid = xs[2 * l], xs[2 * l + 1]
-        xn = m._buf("xn_llm", (M, D), bf)                      # the forward's scratch: free again
-        act = m._buf("act", (M, I), bf)
         groups = dict(lp.groups)
-        sid = lambda t: self._sid(l, t)
+
+        def stored(gname, width, shared=None):
+            """target -> the input its adapter saw in the forward (the dropped copy per target, or the group's shared input)."""
+            if drop:
+                return lambda t: self._xin(t, M, width)[l]
+            if shared is not None:
+                return lambda t: shared
+            buf = self._xin(gname, M, width)[l]
+            return lambda t: buf
+
         if "down" in groups:
             ops.gemm(dxb, w["wd_t"], dact, M, I, D)
-            ops.swiglu_fwd(d["gu"][l], act, M, I)              # the adapter's input (the frozen recipe keeps gate|up only)
-            self.group_bwd(l, "down", groups["down"], dxb, D, M, act, dact, drop,
-                           lambda t, dst: ops.lora_dropout(act, dst, p, lp.rng, sid(t)))
+            self.group_bwd(l, "down", groups["down"], dxb, D, M, stored("down", I), dact, drop)
             ops.swiglu_bwd(dact, d["gu"][l], dgu, M, I)
         else:
             ops.gemm_dswiglu(dxb, w["wd_t"], d["gu"][l], dgu, dact, M, I, D)
         ops.gemm(dgu, w["wgu_t"], dn, M, D, 2 * I)
         if "gu" in groups:
-            ops.rmsnorm_fwd(x_mid, w["ln2"], xn, None, eps)
-            self.group_bwd(l, "gu", groups["gu"], dgu, 2 * I, M, xn, dn, drop,
-                           lambda t, dst: ops.lora_dropout_norm(x_mid, w["ln2"], rstd[2 * l + 1], dst, M, D, p, lp.rng, sid(t)))
+            self.group_bwd(l, "gu", groups["gu"], dgu, 2 * I, M, stored("gu", D), dn, drop)
         ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
         ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)
         if "o" in groups:
-            self.group_bwd(l, "o", groups["o"], dxb, D, M, d["ao"][l], dao, drop,
-                           lambda t, dst: ops.lora_dropout(d["ao"][l], dst, p, lp.rng, sid(t)))
+            self.group_bwd(l, "o", groups["o"], dxb, D, M, stored("o", H * HD, shared=d["ao"][l]), dao, drop)
         ops.attn_bwd_prep(dao, d["ao"][l], delta, None, B, S, H)
         ops.attn_bwd_rope(d["qkv"][l], d["key_mask"], dao, d["lse"][l], delta, cos, sin, dqkv, dkp, dvp, B, S, H, G, scale, True)
         ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)
         if "qkv" in groups:
-            ops.rmsnorm_fwd(x_in, w["ln1"], xn, None, eps)
-            self.group_bwd(l, "qkv", groups["qkv"], dqkv, LDQ, M, xn, dn, drop,
-                           lambda t, dst: ops.lora_dropout_norm(x_in, w["ln1"], rstd[2 * l], dst, M, D, p, lp.rng, sid(t)))
+            self.group_bwd(l, "qkv", groups["qkv"], dqkv, LDQ, M, stored("qkv", D), dn, drop)
         ops.rmsnorm_bwd(dn, x_in, w["ln1"], rstd[2 * l], dx, dxb, True)

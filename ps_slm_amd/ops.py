@@ -316,6 +316,12 @@ class HipOps:
         """y = bf16(y + bf16(t * s)); with x_in / x_out also x_out = x_in + float(y)."""
         self._chk(self.lib.tasu_lora_add(_p(y), _p(t), float(s), _p(x_in), _p(x_out), y.numel(), self._stream()), "tasu_lora_add")
 
+    def lora_apply(self, y, u, w, M, N, R, s=1.0, p=0.0, rng=None, sid=0, x_in=None, x_out=None):
+        """y[M, N] = bf16(y + mask * bf16(s * bf16(u[M, R] @ w[N, R]^T))) [, x_out = x_in + y] in one pass over y (tasu_lora_apply)."""
+        self._chk(self.lib.tasu_lora_apply(_p(y), y.stride(0), _p(u), u.stride(0), _p(w), w.stride(0), M, N, R, float(s), float(p), _p(rng),
+                                           int(sid), _p(x_in), _p(x_out), 0 if x_in is None else x_in.stride(0), self._stream()),
+                  "tasu_lora_apply")
+
     def scale_bf16(self, src, dst, s):
         self._chk(self.lib.tasu_scale_bf16(_p(src), _p(dst), float(s), src.numel(), self._stream()), "tasu_scale_bf16")
 

@@ -303,6 +303,14 @@ class FakeOps:
         if x_in is not None:
             x_out.copy_(x_in + y.float())
 
+    def lora_apply(self, y, u, w, M, N, R, s=1.0, p=0.0, rng=None, sid=0, x_in=None, x_out=None):
+        d = _bf(_bf(u[:M, :R].float() @ w[:N, :R].float().t()).float() * float(s)).float()
+        if p > 0.0:
+            d = _bf(d * lora_keep_scale(rng, sid, (M, N), p)).float()
+        y[:M, :N] = _bf(y[:M, :N].float() + d)
+        if x_in is not None:
+            x_out[:M, :N] = x_in[:M, :N] + y[:M, :N].float()
+
     def scale_bf16(self, src, dst, s):
         dst.copy_(_bf(src.float() * float(s)))
 

@@ -182,3 +182,32 @@ def test_gemm_rank_vs_fp32(ops, M, N, K):
     c2 = torch.empty(M, N, dtype=torch.float32, device="cuda")
     ops.gemm_rank(a, b, c2, M, N, K, f32=True)
     assert torch.equal(c2, c[:, 8:8 + N])                                                              # deterministic
+
+
+@pytest.mark.parametrize("M,N,R", [(4096, 1536, 64), (333, 512, 64), (64, 128, 128), (141, 256, 64), (200, 8960, 64), (70, 264, 64)])
+def test_lora_apply_bit_exact_vs_double(ops, M, N, R):
+    """tasu_lora_apply (rank-R product + scale + dropout mask + accumulate + residual add in one pass over y) against the CPU
+    double: the v image is bf16 of an fp32 MFMA sum, so the comparison allows the last-place flips of that sum's order and is
+    bit-exact everywhere else; strided y / u / W (column slices), nothing written outside [M, N]."""
+    f = FakeOps()
+    g = torch.Generator().manual_seed(M + N)
+    y_full = torch.randn(M, N + 16, generator=g).bfloat16()
+    u_full = (torch.randn(M, R + 64, generator=g) * 0.3).bfloat16()
+    w = (torch.randn(N, R, generator=g) * 0.3).bfloat16()
+    xin = torch.randn(M, N, generator=g)
+    rng = torch.tensor([99, 3], dtype=torch.int64)
+    for s, p, resid in ((1.0, 0.0, False), (0.25, 0.0, True), (1.0, 0.25, False), (2.0, 0.1, True)):
+        yc, xo = y_full.clone(), torch.zeros(M, N)
+        f.lora_apply(yc[:, 8:8 + N], u_full[:, 64:], w, M, N, R, s=s, p=p, rng=rng, sid=5, x_in=xin if resid else None, x_out=xo if resid else None)
+        yg, xg = y_full.cuda(), torch.zeros(M, N, device="cuda")
+        ops.lora_apply(yg[:, 8:8 + N], u_full.cuda()[:, 64:], w.cuda(), M, N, R, s=s, p=p, rng=rng.cuda(), sid=5,
+                       x_in=xin.cuda() if resid else None, x_out=xg if resid else None)
+        a, b = yg.cpu().float(), yc.float()
+        assert torch.equal(a[:, :8], b[:, :8]) and torch.equal(a[:, 8 + N:], b[:, 8 + N:])
+        diff = (a - b).abs()
+        assert float((diff > 0).float().mean()) < 2e-3 and float(diff.max()) <= 2.0 ** -6 * float(b.abs().max())
+        if p > 0:                                                   # the same elements are dropped
+            base = y_full[:, 8:8 + N].float()
+            assert torch.equal((a[:, 8:8 + N] == base), (b[:, 8:8 + N] == base)) or float(((a[:, 8:8 + N] == base) != (b[:, 8:8 + N] == base)).float().mean()) < 1e-4
+        if resid:
+            assert torch.equal(xg.cpu(), xin + a[:, 8:8 + N])

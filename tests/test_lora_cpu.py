@@ -218,7 +218,11 @@ def test_lora_engine_steps_and_checkpoint_roundtrip(tmp_path):
     assert torch.equal(core.proj.pb, core.proj.p.to(torch.bfloat16))
     t = "down_proj"
     assert torch.equal(lp.at[(1, t)][:, : lp.r], lp.view(core.proj.pb, 1, t, "A").t())
-    assert float(lp.at[(1, t)][:, lp.r:].abs().max()) == 0.0 and torch.equal(lp.bt[(0, t)], lp.view(core.proj.pb, 0, t, "B").t())
+    sc = lp.cfg.scaling                                       # 32 / 16 = 2: folded into the copies (exact)
+    assert float(lp.at[(1, t)][:, lp.r:].abs().max()) == 0.0
+    assert torch.equal(lp.bts[(0, t)], (lp.view(core.proj.pb, 0, t, "B").t().float() * sc).to(torch.bfloat16))
+    assert torch.equal(lp.as_[(0, t)], (lp.view(core.proj.pb, 0, t, "A").float() * sc).to(torch.bfloat16))
+    assert torch.equal(lp.bp[(1, t)][:, : lp.r], lp.view(core.proj.pb, 1, t, "B")) and float(lp.bp[(1, t)][:, lp.r:].abs().max()) == 0.0
     # checkpoint: the trainable tensors under the reference's names; a fresh model built with ckpt_path continues from it
     path = str(tmp_path / "pytorch_model.bin")
     eng.save_checkpoint(path)
