@@ -344,6 +344,11 @@ int tasu_lora_dropout(const void* src, void* dst, int64_t n, float p, const void
 int tasu_lora_dropout_norm(const float* x, const float* w, const float* rstd, void* dst, int M, int D, float p, const void* rng,
                            int stream_id, void* stream);
 int tasu_rng_advance(void* rng, void* stream);
+/* tasu_lora_refresh: every working copy of every adapter in ONE launch (after a load / an optimizer step).  `pb` is the bucket's
+ * bf16 image; `table` (device, int64 [n_entries][8]) lists 2-D copies out of it: {source offset in elements, destination address,
+ * rows, cols, destination leading dimension, transpose (0 / 1), scale (float bits in the low 32), first tile}; destination =
+ * bf16(scale * source) or its transpose.  Tiles are 64 x 64; entry e owns tiles [first_e, first_e+1); total_tiles = their sum.   */
+int tasu_lora_refresh(const void* pb, const void* table, int n_entries, int total_tiles, void* stream);
 
 /* ---------------------------------------------------------------------- cross entropy + token accuracy
  * transformers loss_utils.py:49-71 (shift, ignore_index -100, mean) + ps-slm.py:533-535 / utils/metric.py

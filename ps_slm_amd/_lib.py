@@ -51,6 +51,7 @@ PROTOTYPES = {
     "tasu_lora_dropout": [vp, vp, i64, f32, vp, i32, vp],
     "tasu_lora_dropout_norm": [vp, vp, vp, vp, i32, i32, f32, vp, i32, vp],
     "tasu_rng_advance": [vp, vp],
+    "tasu_lora_refresh": [vp, vp, i32, i32, vp],
     "tasu_ce_fwd_bwd": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp],
     "tasu_ce_reduce": [vp, vp, vp, i32, vp, vp],
     "tasu_layernorm_fwd": [vp, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, f32, vp],

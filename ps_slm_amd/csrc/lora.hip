@@ -192,6 +192,43 @@ __global__ __launch_bounds__(256, 2) void lora_apply_kernel(bf16* __restrict__ y
   }
 }
 
+// All working copies of all adapters in one launch (after every optimizer step): entry e of the device table describes one 2-D
+// copy out of the bucket's bf16 image -- dst = bf16(scale * src) or its transpose -- as eight int64: {src offset (elements),
+// dst address, rows, cols, dst leading dimension, transpose, scale (float bits), first tile}.  Work unit: a 64 x 64 tile.
+__global__ __launch_bounds__(256) void lora_refresh_kernel(const bf16* __restrict__ pb, const int64_t* __restrict__ table, int n_entries) {
+  __shared__ bf16 tile[64][64 + 2];
+  const int b = blockIdx.x;
+  int lo = 0, hi = n_entries - 1;                      // last entry whose first tile is <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 8 + 7] <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const int64_t* e = table + lo * 8;
+  const bf16* src = pb + e[0];
+  bf16* dst = (bf16*)(uintptr_t)e[1];
+  const int rows = (int)e[2], cols = (int)e[3], ld = (int)e[4], tr = (int)e[5];
+  const float scale = __int_as_float((int)e[6]);
+  const int ti = b - (int)e[7], tiles_c = (cols + 63) >> 6;
+  const int r0 = (ti / tiles_c) * 64, c0 = (ti % tiles_c) * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    bf16 v = (bf16)0.f;
+    if (r0 + r < rows && c0 + c < cols) v = (bf16)((float)src[(size_t)(r0 + r) * cols + c0 + c] * scale);
+    tile[r][c] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    if (tr) {
+      const int c = i >> 6, r = i & 63;                // consecutive threads -> consecutive rows of src = consecutive columns of dst
+      if (r0 + r < rows && c0 + c < cols) dst[(size_t)(c0 + c) * ld + r0 + r] = tile[r][c];
+    } else {
+      const int r = i >> 6, c = i & 63;
+      if (r0 + r < rows && c0 + c < cols) dst[(size_t)(r0 + r) * ld + c0 + c] = tile[r][c];
+    }
+  }
+}
+
 __global__ void rng_advance_kernel(int64_t* rng) {
   if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;
 }
@@ -266,5 +303,11 @@ extern "C" int tasu_lora_apply(void* y, int ldy, const void* u, int ldu, const v
   else if (mask) TASU_LAUNCH((lora_apply_kernel<true, false>), grid, block, 0, st, yy, ldy, uu, ldu, ww, ldw, M, N, R, s, thr, inv, rg, stream_id, x_in, x_out, ldx);
   else if (x_in) TASU_LAUNCH((lora_apply_kernel<false, true>), grid, block, 0, st, yy, ldy, uu, ldu, ww, ldw, M, N, R, s, thr, inv, rg, stream_id, x_in, x_out, ldx);
   else TASU_LAUNCH((lora_apply_kernel<false, false>), grid, block, 0, st, yy, ldy, uu, ldu, ww, ldw, M, N, R, s, thr, inv, rg, stream_id, x_in, x_out, ldx);
+  return TASU_OK;
+}
+
+extern "C" int tasu_lora_refresh(const void* pb, const void* table, int n_entries, int total_tiles, void* stream) {
+  if (!pb || !table || n_entries <= 0 || total_tiles <= 0) return TASU_ERR_ARG;
+  TASU_LAUNCH(lora_refresh_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16*)pb, (const int64_t*)table, n_entries);
   return TASU_OK;
 }

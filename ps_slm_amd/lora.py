@@ -133,6 +133,7 @@ class LoraParams:
         self.bp = {k: torch.zeros(self.dims[k[1]][1], self.rp, **bf) for k in keys} if self.rp != self.r else {}
         self.rng = torch.zeros(2, dtype=torch.int64, device=device)          # {seed, step} of the dropout masks (csrc/lora.hip)
         self.version = 0                                   # bumped whenever the adapters change (load, optimizer step)
+        self._table = None                                 # device table of tasu_lora_refresh, built on first use
         self._merged, self._merged_version = None, -1      # decode-time weights (merged_llm below)
 
     # ---- views
@@ -186,10 +187,37 @@ class LoraParams:
     def seed_dropout(self, seed, step=0):
         self.rng.copy_(torch.tensor([int(seed), int(step)], dtype=torch.int64))
 
+    def _refresh_table(self):
+        """The copies of refresh_working_copies as the device table of tasu_lora_refresh (addresses are fixed for the model's life)."""
+        import struct
+        sbits = struct.unpack("<i", struct.pack("<f", float(self.cfg.scaling)))[0]
+        one = struct.unpack("<i", struct.pack("<f", 1.0))[0]
+        rows, tiles = [], 0
+
+        def add(src_off, dst, r, c, tr, bits):
+            nonlocal tiles
+            rows.append([src_off, dst.data_ptr(), r, c, dst.stride(0), tr, bits, tiles])
+            tiles += ((r + 63) // 64) * ((c + 63) // 64)
+
+        for l in range(self.geo.llm_layers):
+            for t in self.cfg.target_modules:
+                i, o = self.dims[t]
+                oa, ob = self.offsets[(l, t, "A")][0], self.offsets[(l, t, "B")][0]
+                add(oa, self.as_[(l, t)], self.r, i, 0, sbits)                            # s A
+                add(ob, self.bts[(l, t)], o, self.r, 1, sbits)                            # s B^T  [r, out]
+                add(oa, self.at[(l, t)], self.r, i, 1, one)                               # A^T    [in, rp] (pad columns stay zero)
+                if self.bp:
+                    add(ob, self.bp[(l, t)], o, self.r, 0, one)                           # B      [out, rp]
+        return torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows), tiles
+
     def refresh_working_copies(self, ops):
-        """After the bf16 image of the bucket changed (load, AdamW): the working copies the step's kernels read."""
-        pb, sc = self.proj.pb, self.cfg.scaling
+        """After the bf16 image of the bucket changed (load, AdamW): the working copies the step's kernels read -- one launch."""
         self.version += 1
+        if hasattr(ops, "lora_refresh"):
+            if self._table is None:
+                self._table = self._refresh_table()
+            return ops.lora_refresh(self.proj.pb, *self._table)
+        pb, sc = self.proj.pb, self.cfg.scaling                    # (operator sets without the fused kernel: the same copies one by one)
         for l in range(self.geo.llm_layers):
             for t in self.cfg.target_modules:
                 i, o = self.dims[t]
@@ -262,6 +290,11 @@ class LoraRunner:
     def __init__(self, model):
         self.m = model
         self.lp = model.lora
+        # the weight-gradient chain of a group (three operand transposes + 2 rank GEMMs per member) feeds nothing of the backward's
+        # critical path: it runs on a side stream under the next kernels of the dgrad chain (also inside a captured hipGraph: a
+        # fork / join of the capturing stream).  Its workgroup counts (96-560) leave most of the chip to the main stream's GEMMs.
+        self.side = torch.cuda.Stream(device=model.device) if model.device.type == "cuda" else None
+        self._side_done = {}                               # group -> event: the side chain that read this group's buffers has finished
 
     # ---- workspace
     def _zbuf(self, name, shape):
@@ -320,6 +353,7 @@ class LoraRunner:
         nt = len(targets)
         inn = lp.dims[targets[0]][0]
         us_all = m._ws["lora_us_" + gname][: L * M * nt * rp].view(L, M, nt * rp)
+        self._wait_side(gname)
         du = self._zbuf("lora_du_" + gname, (M, nt * rp))
         for t in targets:
             i, o = lp.dims[t]
@@ -328,23 +362,48 @@ class LoraRunner:
             self.rank(dy[:, c0:c0 + o], lp.bts[(l, t)], du_t, M, r, o)             # du = bf16(dy (sB))              [M, r]
             ops.lora_apply(dx_base, du_t, lp.at[(l, t)], M, i, rp, p=p if drop else 0.0, rng=lp.rng, sid=self._sid(l, t))
         # weight gradients: dB_t = dy_t^T us_t [out, r],  dA_t = du_t^T xd_t [r, in]  (K = the M rows, zero-padded to 64)
-        dy_t = m._buf("lora_dy_t", (width, Mp), bf)
+        dy_t = m._buf("lora_dy_t_" + gname, (width, Mp), bf)        # per group: the side chain of the previous layer may still read it
         ops.transpose(dy, dy_t, M, width, Mp, width)
-        us_t = m._buf("lora_us_t", (nt * rp, Mp), bf)
-        ops.transpose(us_all[l], us_t, M, nt * rp, Mp, nt * rp)
-        du_tr = m._buf("lora_du_t", (nt * rp, Mp), bf)
-        ops.transpose(du, du_tr, M, nt * rp, Mp, nt * rp)
-        xd_t = m._buf("lora_xd_t", (inn, Mp), bf)
-        last = None
-        for t in targets:
-            i, o = lp.dims[t]
-            c0, k = lp.cols[t], lp.slot[t]
-            self.rank(dy_t[c0:c0 + o], us_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "B"), o, r, Mp, f32=True)
-            xd = xd_of(t)
-            if xd is not last:                              # members of a group share their input unless dropout gave each its own
-                ops.transpose(xd, xd_t, M, i, Mp, i)
-                last = xd
-            self.rank(xd_t, du_tr[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "A"), i, r, Mp, f32=True, transposed=True)
+
+        def wgrads():
+            us_t = m._buf("lora_us_t", (nt * rp, Mp), bf)
+            ops.transpose(us_all[l], us_t, M, nt * rp, Mp, nt * rp)
+            du_tr = m._buf("lora_du_t", (nt * rp, Mp), bf)
+            ops.transpose(du, du_tr, M, nt * rp, Mp, nt * rp)
+            xd_t = m._buf("lora_xd_t", (inn, Mp), bf)
+            last = None
+            for t in targets:
+                i, o = lp.dims[t]
+                c0, k = lp.cols[t], lp.slot[t]
+                self.rank(dy_t[c0:c0 + o], us_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "B"), o, r, Mp, f32=True)
+                xd = xd_of(t)
+                if xd is not last:                          # members of a group share their input unless dropout gave each its own
+                    ops.transpose(xd, xd_t, M, i, Mp, i)
+                    last = xd
+                self.rank(xd_t, du_tr[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "A"), i, r, Mp, f32=True, transposed=True)
+
+        if self.side is None:
+            return wgrads()
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)                                           # dy_t, du, us, xd are complete
+        self.side.wait_event(fork)
+        with torch.cuda.stream(self.side):
+            wgrads()
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self._side_done[gname] = done
+
+    def _wait_side(self, gname):
+        """Before the main stream rewrites a group's du / dy_t buffers: the side chain that read them (one layer ago) is done."""
+        ev = self._side_done.pop(gname, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def join(self):
+        """End of the decoder's backward: every weight gradient is in the bucket (and a capturing stream has its forks back)."""
+        for g in list(self._side_done):
+            self._wait_side(g)
 
     # ---- one decoder layer, forward (modeling_qwen2.py's Qwen2DecoderLayer with every adapted Linear = base + low-rank branch)
     def layer_fwd(self, st, l, w, bufs, drop):

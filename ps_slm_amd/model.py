@@ -893,6 +893,8 @@ class TasuModel:
             ops.attn_bwd_rope(d["qkv"][l], d["key_mask"], dao, d["lse"][l], delta, cos, sin, dqkv, dkp, dvp, B, S, H, G, scale, True)
             ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)
             ops.rmsnorm_bwd(dn, x_in, w["ln1"], rstd[2 * l], dx, dxb, True)
+        if lora is not None:
+            lora.join()                                        # the adapters' weight-gradient chains (side stream) are back
         d["dx"] = dx
 
     def grad_ranges(self, w1_chunks=1):

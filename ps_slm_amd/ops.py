@@ -332,6 +332,9 @@ class HipOps:
         self._chk(self.lib.tasu_lora_dropout_norm(_p(x), _p(w), _p(rstd), _p(dst), M, D, float(p), _p(rng), int(sid), self._stream()),
                   "tasu_lora_dropout_norm")
 
+    def lora_refresh(self, pb, table, n_entries, total_tiles):
+        self._chk(self.lib.tasu_lora_refresh(_p(pb), _p(table), n_entries, total_tiles, self._stream()), "tasu_lora_refresh")
+
     def rng_advance(self, rng):
         self._chk(self.lib.tasu_rng_advance(_p(rng), self._stream()), "tasu_rng_advance")
 

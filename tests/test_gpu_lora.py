@@ -211,3 +211,20 @@ def test_lora_apply_bit_exact_vs_double(ops, M, N, R):
             assert torch.equal((a[:, 8:8 + N] == base), (b[:, 8:8 + N] == base)) or float(((a[:, 8:8 + N] == base) != (b[:, 8:8 + N] == base)).float().mean()) < 1e-4
         if resid:
             assert torch.equal(xg.cpu(), xin + a[:, 8:8 + N])
+
+
+@pytest.mark.parametrize("name", ["mid_text_lora", "mid_text_lora_qv"])
+def test_lora_refresh_one_launch_equals_the_copies(ops, name):
+    """tasu_lora_refresh (all working copies of all adapters from the bucket's bf16 image in one launch) against the copies
+    built one by one: s A, s B^T, A^T (zero-padded to the 64-wide rank), and the padded B when r % 64 != 0."""
+    z, geo, cfg, sd, lsd, batch = golden_case(name)
+    gm = build(geo, cfg, sd, lsd, ops, "cuda")
+    lp, pb, sc = gm.lora, gm.proj.pb, cfg.scaling
+    for l in range(geo.llm_layers):
+        for t in cfg.target_modules:
+            a, b = lp.view(pb, l, t, "A").float(), lp.view(pb, l, t, "B").float()
+            assert torch.equal(lp.as_[(l, t)], (a * sc).bfloat16()), (l, t)
+            assert torch.equal(lp.bts[(l, t)], (b.t() * sc).bfloat16()), (l, t)
+            assert torch.equal(lp.at[(l, t)][:, : lp.r], a.t().bfloat16()) and (lp.rp == lp.r or float(lp.at[(l, t)][:, lp.r:].abs().max()) == 0)
+            if lp.bp:
+                assert torch.equal(lp.bp[(l, t)][:, : lp.r], b.bfloat16()) and float(lp.bp[(l, t)][:, lp.r:].abs().max()) == 0
