@@ -131,7 +131,7 @@ class FakeLLMTokenizer:
         self.bos_token_id = None
 
 
-def build_reference_model(geo, seed, train_flags, projector="linear-silu", ds_rate=1):
+def build_reference_model(geo, seed, train_flags, projector="linear-silu", ds_rate=1, projector_in=None):
     """Seeded random-init reference ``slam_model_asr`` at geometry ``geo`` (dict); ``projector``: "linear-silu"
     (EncoderProjectorLinearSiLU), "linear" (EncoderProjectorConcat with encoder_projector_ds_rate = ds_rate) or "cov1d-linear"
     (EncoderProjectorCov1d, kernel = stride = ds_rate) or "cross-attention" (EncoderProjectorCTCCA)."""
@@ -160,7 +160,7 @@ def build_reference_model(geo, seed, train_flags, projector="linear-silu", ds_ra
         p.requires_grad = False
     llm.eval()
     model_config = Cfg(encoder_projector=projector, encoder_path="/nonexistent", encoder_projector_ds_rate=ds_rate,
-                       encoder_dim=geo["ctc_vocab"], llm_dim=geo["llm_dim"])
+                       encoder_dim=projector_in or geo["ctc_vocab"], llm_dim=geo["llm_dim"])   # projector_in: the raw-feature branch reads encoder states
     if projector == "cross-attention":
         projector = proj.EncoderProjectorCTCCA(model_config)       # one matrix W_q; 8 heads over the LLM's embedding table
     elif projector == "cov1d-linear":

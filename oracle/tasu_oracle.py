@@ -392,12 +392,13 @@ def forward_text(W, batch, geo, mode="fp32"):
     return forward_from_posterior(W, batch, post, plen, geo, mode)
 
 
-def forward_audio(W, batch, geo, mode="fp32"):
-    """slam_model_asr.forward, audio branch (gt_emb=false, ctc_posterior, do_psd): ps-slm.py:430-454,471."""
-    post, _, lens = audio_front(W, batch["input_features"], batch["input_feature_length"], geo["enc_heads"],
-                                geo["enc_kernel"], mode)
-    post, plen = psd(post, lens, post, blank_id=0)
-    return forward_from_posterior(W, batch, post, plen, geo, mode)
+def forward_audio(W, batch, geo, mode="fp32", raw=False):
+    """slam_model_asr.forward, audio branch (gt_emb=false, do_psd): ps-slm.py:430-454,471; ``raw``: the ctc_posterior=false
+    branch (ps-slm.py:515-523): PSD's decisions from the posterior, its rows from the encoder's output states."""
+    post, enc, lens = audio_front(W, batch["input_features"], batch["input_feature_length"], geo["enc_heads"],
+                                  geo["enc_kernel"], mode)
+    x, plen = psd(enc if raw else post, lens, post, blank_id=0)
+    return forward_from_posterior(W, batch, x, plen, geo, mode)
 
 
 def forward_from_posterior(W, batch, post, plen, geo, mode="fp32"):
@@ -422,12 +423,12 @@ PROJ_KEYS = tuple("encoder_projector." + k for k in
                   ("norm.weight", "norm.bias", "ffn.0.weight", "ffn.0.bias", "ffn.2.weight", "ffn.2.bias"))
 
 
-def loss_and_projector_grads(W, batch, geo, mode="fp32", audio=False):
+def loss_and_projector_grads(W, batch, geo, mode="fp32", audio=False, raw=False):
     keys = tuple(k for k in W if k.startswith("encoder_projector."))      # either projector kind
     Wg = dict(W)
     for k in keys:
         Wg[k] = W[k].detach().clone().requires_grad_(True)
-    out = (forward_audio if audio else forward_text)(Wg, batch, geo, mode)
+    out = forward_audio(Wg, batch, geo, mode, raw=raw) if audio else forward_text(Wg, batch, geo, mode)
     grads = torch.autograd.grad(out["loss"], [Wg[k] for k in keys])
     return out, dict(zip(keys, grads))
 

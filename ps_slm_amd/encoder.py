@@ -158,7 +158,13 @@ def _encoder_body(model, x0, lens, key_mask, B, T):
         ops.layernorm_fwd(cur, enc.after_norm[0], enc.after_norm[1], nxt, None, None, M, E, 1e-5)
         cur = nxt
     encb = buf("enc_outb", (M, E), bf)
-    ops.layernorm_fwd(cur, enc.tp_norm[0], enc.tp_norm[1], encb, None, None, M, E, 1e-5)     # tp_norm, bf16 for the CTC GEMM
+    if getattr(model, "raw_features", False):
+        # the raw-feature branch keeps the encoder's output states (fp32, as LayerNorm leaves them under autocast) for PSD
+        encf = buf("enc_outf", (M, E), f32)
+        ops.layernorm_fwd(cur, enc.tp_norm[0], enc.tp_norm[1], encf, None, None, M, E, 1e-5)
+        ops.cast_bf16(encf, encb)
+    else:
+        ops.layernorm_fwd(cur, enc.tp_norm[0], enc.tp_norm[1], encb, None, None, M, E, 1e-5)     # tp_norm, bf16 for the CTC GEMM
     logits = buf("enc_ctc_logits", (M, Kp), bf)
     ops.gemm(encb, enc.ctc_w, logits, M, V, E, bias=enc.ctc_b)
     post = buf("enc_post", (M, Kp), f32)
@@ -166,10 +172,13 @@ def _encoder_body(model, x0, lens, key_mask, B, T):
     return post
 
 
-def psd_on_device(model, post, B, T, Te, feat_lens_dev, do_psd=True):
-    """PSD over frames 4.. of every utterance.  Returns (rows fp32 [Rap, Kp], new_lens host int64 [B], Lmax)."""
+def psd_on_device(model, post, B, T, Te, feat_lens_dev, do_psd=True, k=1, feats=None):
+    """PSD over frames 4.. of every utterance.  The decisions (run merging, blank filter) come from the posterior; the rows that
+    are kept / averaged are the posterior's (``feats`` None) or those of ``feats`` (fp32 [B * Te, width]: the raw-feature
+    branch).  ``k``: frames per projector row -- the batch tensor's trailing Lmax % k frames are dropped (projector.py:41-45).
+    Returns (rows fp32 [rup(B * Lmax, 64 k), width padded to 64], new_lens host int64 [B] (untruncated), Lmax)."""
     ops, geo = model.ops, model.geo
-    V, Kp = geo.ctc_vocab, rup(geo.ctc_vocab, 64)
+    V = geo.ctc_vocab
     buf = model._buf
     body = post[4:]                                  # row (b, t) = b*Te + t of this view
     fid = buf("psd_fid", (B * T,), torch.int32)
@@ -182,12 +191,15 @@ def psd_on_device(model, post, B, T, Te, feat_lens_dev, do_psd=True):
     blank = geo.blank_id if do_psd else -2           # ... and merges nothing
     ops.psd_plan(fid, fbl, feat_lens_dev, ss, sl, nl, B, T, blank, thr)
     new_lens = nl.cpu().numpy().astype(np.int64)     # one small D2H sync per batch (the reference syncs per frame)
-    Lmax = int(new_lens.max()) if B else 0
+    Lmax = (int(new_lens.max()) // k) * k if B else 0
     if Lmax == 0:
-        raise ValueError("PSD removed every frame of every utterance (all-blank batch)")
-    Rap = rup(B * Lmax, 64)
-    rows = buf("post", (Rap, Kp), torch.float32)
-    if Rap > B * Lmax:
+        raise ValueError("PSD removed every frame of every utterance (all-blank batch)" if k == 1 else
+                         f"PSD left fewer than {k} frames in every utterance: no projector row")
+    src, W = (body, V) if feats is None else (feats[4:], feats.shape[1])
+    Wp = rup(W, 64)
+    Fap = rup(B * Lmax, 64 * k)
+    rows = buf("post", (Fap, Wp), torch.float32)
+    if Fap > B * Lmax:
         rows[B * Lmax:].zero_()
-    ops.psd_gather(body, ss, sl, nl, rows, B, T, Te, Lmax, V)
+    ops.psd_gather(src, ss, sl, nl, rows, B, T, Te, Lmax, W)
     return rows, new_lens, Lmax

@@ -59,6 +59,8 @@ class Geometry:
                                      # "linear" (EncoderProjectorConcat, projector.py:28-49: k frames concatenated, ReLU, no norm)
     projector_ds_rate: int = 1       # k of the "linear" / "cov1d-linear" projectors (model_config.encoder_projector_ds_rate)
     ca_heads: int = 8                # heads of the "cross-attention" projector (EncoderProjectorCTCCA, projector.py:105: n_heads=8)
+    proj_in: int = 0                 # width of a projector input frame; 0 = ctc_vocab (the CTC posterior, train_config.ctc_posterior=true);
+                                     # enc_dim for the raw-feature branch (ctc_posterior=false, ps-slm.py:515-523: encoder states)
     # SenseVoiceSmall encoder
     feat_dim: int = 560
     enc_dim: int = 512
@@ -71,6 +73,10 @@ class Geometry:
     # tokens
     speech_id: int = 151665
     eos_id: int = 151643
+
+    @property
+    def pin(self):
+        return self.proj_in or self.ctc_vocab
 
     @classmethod
     def qwen25_1p5b(cls):
@@ -102,7 +108,7 @@ class ProjectorParams:
     the GEMM over k concatenated frames (W0[o, j * Kp + i] = conv.weight[o, i, j]) -- then kin = 1."""
 
     def __init__(self, geo: Geometry, device):
-        K, Kp, Hb, Do = geo.ctc_vocab, rup(geo.ctc_vocab, 64), geo.bottleneck, geo.llm_dim
+        K, Kp, Hb, Do = geo.pin, rup(geo.pin, 64), geo.bottleneck, geo.llm_dim
         self.kind = geo.projector
         if self.kind not in ("linear-silu", "linear", "cov1d-linear", "cross-attention"):
             raise NotImplementedError(f"encoder_projector {self.kind!r}")
@@ -378,6 +384,7 @@ class TasuModel:
         self._dec_graphs, self._dec_seen = collections.OrderedDict(), {}   # decode-step graphs (ps_slm_amd/decode.py): small LRU
         self._done_host = None         # pinned "decode finished" word the beam-update kernel writes
         self.lora = None               # ps_slm_amd.lora.LoraParams once enable_lora() ran (use_peft=true)
+        self.raw_features = geo.proj_in not in (0, geo.ctc_vocab)   # ctc_posterior=false: the projector reads encoder states
         self._lora_run = None
 
     # ------------------------------------------------------------------------------------------ weights
@@ -406,7 +413,7 @@ class TasuModel:
         no projector checkpoint."""
         geo, dev, pr = self.geo, self.device, self.proj
         g = torch.Generator(device=dev).manual_seed(seed)
-        K, Hb, Do = geo.ctc_vocab * pr.kin, geo.bottleneck, geo.llm_dim
+        K, Hb, Do = geo.pin * pr.kin, geo.bottleneck, geo.llm_dim
 
         def un(shape, fan_in):
             b = 1.0 / math.sqrt(fan_in)
@@ -420,7 +427,7 @@ class TasuModel:
             pr.load("norm.weight", torch.ones(K, device=dev))
             pr.load("norm.bias", torch.zeros(K, device=dev))
         if pr.has_conv:                                    # nn.Conv1d default init: fan_in = in_channels * kernel_size
-            Kc = geo.ctc_vocab
+            Kc = geo.pin
             pr.load("conv1d.weight", un((Kc, Kc, pr.k), Kc * pr.k))
             pr.load("conv1d.bias", un((Kc,), Kc * pr.k))
         pr.load(pr.n_w1, un((Hb, K), K))
@@ -527,19 +534,22 @@ class TasuModel:
         return st
 
     def prepare_audio(self, input_ids, attention_mask, labels, input_features, input_feature_length, do_psd=True) -> StepState:
-        """Audio branch (ps-slm.py:430-454, :469-473, :482): encoder -> CTC posterior -> PSD -> projector."""
+        """Audio branch (ps-slm.py:430-454, :469-473, :482): encoder -> CTC posterior -> PSD -> projector; with ``raw_features``
+        (train_config.ctc_posterior=false, ps-slm.py:515-523) PSD's decisions still come from the posterior but the rows it keeps /
+        averages are the encoder's output states, and those feed the projector.  A projector that concatenates k frames per row
+        (``linear`` / ``cov1d-linear`` with encoder_projector_ds_rate = k) drops the batch tensor's trailing Lmax % k frames and
+        gives every utterance len // k rows (projector.py:41-45, ps-slm.py:482)."""
         from .encoder import encoder_posterior, psd_on_device
         B, T, _ = input_features.shape
         post, Te, _ = encoder_posterior(self, input_features, input_feature_length)
         fl = np.asarray(input_feature_length.cpu() if isinstance(input_feature_length, torch.Tensor) else input_feature_length)
         fl_dev = self._upload("feat_lens", fl.astype(np.int32))
-        rows, new_lens, Lmax = psd_on_device(self, post, B, T, Te, fl_dev, do_psd)
-        if self.proj.k != 1:
-            raise NotImplementedError("the 'linear' projector with encoder_projector_ds_rate > 1 is served on the text branch only "
-                                      "(the shipped recipes run ds_rate = 1)")
-        st = self._finish_prepare(input_ids, attention_mask, labels, new_lens, Lmax)
-        st.Ra, st.Rap = B * Lmax, rup(B * Lmax, 64)
-        st.Fap = st.Rap
+        kk = self.proj.k
+        src = self._ws["enc_outf"][: post.shape[0] * self.geo.enc_dim].view(post.shape[0], self.geo.enc_dim) if self.raw_features else None
+        rows, new_lens, Lmax = psd_on_device(self, post, B, T, Te, fl_dev, do_psd, k=kk, feats=src)
+        st = self._finish_prepare(input_ids, attention_mask, labels, np.minimum(new_lens, Lmax) // kk, Lmax // kk)
+        st.Fap = rows.shape[0]
+        st.Ra, st.Rap = B * Lmax // kk, st.Fap // kk
         st.path = "audio"
         st.dev["post"] = rows
         st.dev["psd_lens"] = new_lens

@@ -106,7 +106,7 @@ def setup_encoder_tokenizer(model_config, geo):
 
 
 # ------------------------------------------------------------------------------------------------ geometry / weights
-def geometry_from_config(model_config) -> Geometry:
+def geometry_from_config(model_config, raw_features=False) -> Geometry:
     """HF config.json under llm_path when present; otherwise a named synthetic geometry
     (``llm_path = synthetic:qwen2.5-1.5b | synthetic:qwen2.5-7b | synthetic:mid``)."""
     path = str(model_config.get("llm_path", "") or "")
@@ -134,7 +134,14 @@ def geometry_from_config(model_config) -> Geometry:
     else:
         raise FileNotFoundError(f"model_config.llm_path={path!r}: no config.json there and not a 'synthetic:<name>' spec")
     apply_encoder_config(geo, model_config.get("encoder_path", None))
-    if model_config.get("encoder_dim", None) not in (None, geo.ctc_vocab) and path.lower() != "synthetic:mid":
+    if raw_features:
+        # train_config.ctc_posterior=false (ps-slm.py:515-523): model_config.encoder_dim is the width of the encoder states the
+        # projector reads; the CTC vocabulary (PSD still decides on the posterior) stays the encoder's own
+        ed = model_config.get("encoder_dim", None)
+        if ed not in (None, geo.enc_dim) and path.lower() != "synthetic:mid":
+            raise ValueError(f"ctc_posterior=false: model_config.encoder_dim={ed} must be the encoder's output size {geo.enc_dim}")
+        geo.proj_in = geo.enc_dim
+    elif model_config.get("encoder_dim", None) not in (None, geo.ctc_vocab) and path.lower() != "synthetic:mid":
         geo.ctc_vocab = int(model_config.encoder_dim)
     if model_config.get("llm_dim", None) not in (None, geo.llm_dim):
         raise ValueError(f"model_config.llm_dim={model_config.llm_dim} does not match the LLM hidden size {geo.llm_dim}")
@@ -177,6 +184,15 @@ def load_hf_llm_state_dict(path):
 def model_factory(train_config, model_config, **kwargs):
     """Same contract as Multitask/model/ps-slm.py:130-181: returns (model, tokenizer)."""
     projector = model_config.get("encoder_projector", "linear-silu")
+    if projector == "q-former":
+        # FINDING: the reference cannot run its q-former either.  EncoderProjectorQFormer.forward(x, atts) (projector.py:91-100)
+        # takes the attention mask as a second argument and has no `.k`, but every call site of slam_model_asr passes one argument
+        # and divides the lengths by `.k` (ps-slm.py:482,488,505,522, :612-651) -- TypeError "missing 1 required positional
+        # argument: 'atts'"; with cross_attn=true the embedding table lands in `atts` and the merge fails on the 64 query rows
+        # (reproduced with the imported reference: tests/test_oracle_golden.py::test_reference_cannot_run_its_q_former).
+        raise NotImplementedError("encoder_projector='q-former': the reference's slam_model_asr cannot call EncoderProjectorQFormer "
+                                  "(Multitask/model/projector.py:91 needs `atts`, ps-slm.py:482 passes one argument and reads `.k`); "
+                                  "there is no behaviour to reproduce")
     if projector not in ("linear-silu", "linear", "cov1d-linear", "cross-attention"):
         raise NotImplementedError(f"encoder_projector={projector!r}: the MI355X path serves 'linear-silu' (the shipped recipe, "
                                   "Multitask/scripts/finetune_deespeed_sensevoice.sh:25), 'linear' (EncoderProjectorConcat, "
@@ -196,7 +212,11 @@ def model_factory(train_config, model_config, **kwargs):
         # decodes in fp32 (inference_batch.py:113-117); this path has ONE arithmetic: bf16 autocast semantics
         logger.warning("train_config.use_fp16 is false: the MI355X path still computes with bf16-autocast semantics "
                        "(bf16 GEMM operands, fp32 accumulation / residual stream / norms / loss)")
-    geo = geometry_from_config(model_config)
+    raw = not train_config.get("ctc_posterior", True)
+    if raw and projector == "cross-attention":
+        raise NotImplementedError("ctc_posterior=false with the cross-attention projector: the reference's raw-feature branch "
+                                  "(ps-slm.py:515-523) calls the projector with one argument, EncoderProjectorCTCCA needs two")
+    geo = geometry_from_config(model_config, raw_features=raw)
     geo.projector = projector
     geo.projector_ds_rate = int(model_config.get("encoder_projector_ds_rate", 1) or 1) if projector in ("linear", "cov1d-linear") else 1
     tokenizer = setup_tokenizer(train_config, model_config, geo, **kwargs)
@@ -211,7 +231,7 @@ def model_factory(train_config, model_config, **kwargs):
         ops = HipOps()
     core = TasuModel(geo, ops, device, keep_logits=bool(kwargs.get("keep_logits", True)))
     llm_path = str(model_config.get("llm_path", ""))
-    need_encoder = not train_config.get("gt_emb", False) or bool(kwargs.get("with_encoder", False))
+    need_encoder = not train_config.get("gt_emb", False) or raw or bool(kwargs.get("with_encoder", False))
     if llm_path.startswith("synthetic:"):
         core.init_random(seed=int(kwargs.get("init_seed", 1234)), with_encoder=need_encoder)
     else:
@@ -283,8 +303,8 @@ class slam_model_asr:
             raise NotImplementedError("voca_trans / top1_emb: the reference's branch (Multitask/model/ps-slm.py:485-514) reads an "
                                       "unassigned `encoder_outs` and raises UnboundLocalError as shipped; not built")
         if not self.ctc_posterior:
-            raise NotImplementedError("ctc_posterior=false (raw encoder features into the projector, ps-slm.py:515-523) is not the "
-                                      "TASU recipe (Multitask/scripts/finetune_deespeed_sensevoice.sh:31-35); not built")
+            # the raw-feature branch (ps-slm.py:515-523) never looks at gt_emb: the encoder always runs
+            self.gt_emb = False
         # knobs of ctc_pseudo_posterior_noise (ps-slm.py:372-375), overridable as attributes like in the reference
         self.drop_prob, self.insert_prob, self.smooth_low, self.smooth_high = 0.05, 0.0, 0.0, 0.1
         self.training = True

@@ -49,7 +49,7 @@ def random_state_dict(geo: Geometry, seed: int, with_encoder=True, scale=0.05):
     sd["llm.model.norm.weight"] = near_one(D)
     if not geo.tied:
         sd["llm.lm_head.weight"] = rn(V, D)
-    K, Hb = geo.ctc_vocab, geo.bottleneck
+    K, Hb = geo.pin, geo.bottleneck                     # projector input width: the CTC vocabulary, or enc_dim for raw features
     if geo.projector == "cross-attention":              # EncoderProjectorCTCCA: one matrix, W_q [llm_dim, K], no bias
         sd["encoder_projector.W_q.weight"] = rn(D, K, s=1.0 / math.sqrt(K))
     elif geo.projector == "cov1d-linear":                 # EncoderProjectorCov1d: Conv1d(K, K, k, stride k) -> ReLU -> Linear -> ReLU -> Linear

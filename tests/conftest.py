@@ -134,3 +134,21 @@ def linear_projector_case(k):
     batch = synthetic_text_batch(geo, 3, seed=int(z["seed_b"]), prompt_len=9, n_audio=22, target_len=17, speech_pos=4,
                                  feat_frames=12, noise=False, ragged=True)
     return geo, sd, batch, z
+
+
+def mid_audio_raw_case(kind, k):
+    """The inputs of tests/golden/mid_audio_raw_<kind>_k<k>.npz (oracle/make_golden_raw.py): the encoder, CTC head and features
+    of mid_audio_psd (PSD decisions stable under bf16 rounding) with a projector that reads the encoder's output states
+    (train_config.ctc_posterior=false): (geo, state dict, batch, fixture)."""
+    import dataclasses
+
+    from ps_slm_amd.model import Geometry
+    from ps_slm_amd.synthetic import random_state_dict
+
+    geo0, sd, batch, _ = mid_audio_psd_case()
+    z = load_npz(f"mid_audio_raw_{kind}_k{k}")
+    geo = dataclasses.replace(geo0, projector=kind, projector_ds_rate=k, proj_in=geo0.enc_dim,
+                              bottleneck=2048 if kind == "linear" else geo0.bottleneck)
+    sd = {n: v for n, v in sd.items() if not n.startswith("encoder_projector.")}
+    sd.update({n: v for n, v in random_state_dict(geo, int(z["seed_p"]), with_encoder=False).items() if n.startswith("encoder_projector.")})
+    return geo, sd, batch, z

@@ -507,7 +507,7 @@ class FakeOps:
         o = out[: B * Tout].view(B, Tout, -1)
         o.zero_()
         for b in range(B):
-            for j in range(int(new_lens[b])):
+            for j in range(min(int(new_lens[b]), Tout)):
                 s0, ln = int(seg_start.view(B, T)[b, j]), int(seg_len.view(B, T)[b, j])
                 seg = p[b, s0:s0 + ln, :V]
                 o[b, j, :V] = seg[0] if ln == 1 else seg.sum(0) / ln

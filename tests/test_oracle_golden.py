@@ -390,3 +390,41 @@ def test_cross_attention_projector_vs_reference():
     cols = torch.from_numpy(z["cols"])
     close(out["logits"][:, :, cols], z["logits_cols"], rtol=2e-4, atol=2e-5)
     close(grads["encoder_projector.W_q.weight"], z["grad.W_q.weight"], rtol=5e-4, atol=1e-8)
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/Multitask"), reason="needs the reference tree (build container only)")
+def test_reference_cannot_run_its_q_former():
+    """FINDING behind the plugin's NotImplementedError for encoder_projector='q-former': the REAL reference (imported) builds
+    EncoderProjectorQFormer but its slam_model_asr.forward cannot call it -- the projector's forward needs `atts`
+    (Multitask/model/projector.py:91), every call site passes one argument and reads `.k` (ps-slm.py:482); with cross_attn the
+    embedding table lands in `atts` and the merge fails.  Nothing to pin an implementation against."""
+    import contextlib
+    import dataclasses
+    import io
+
+    from oracle.ref_import import Cfg, build_reference_model, load_reference
+    from ps_slm_amd.model import Geometry
+    from ps_slm_amd.synthetic import MID_GEOMETRY, synthetic_text_batch
+    _, _, proj = load_reference()
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    model = build_reference_model(dataclasses.asdict(geo), 0, dict(gt_emb=True, gt_emb_noise=False))
+    model.encoder_projector = proj.EncoderProjectorQFormer(Cfg(encoder_projector="q-former", encoder_dim=geo.ctc_vocab, llm_dim=geo.llm_dim,
+                                                               qformer_layers=1, query_len=8))
+    assert not hasattr(model.encoder_projector, "k")
+    batch = synthetic_text_batch(geo, 2, seed=1, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12, noise=False)
+    call = dict(input_ids=batch["input_ids"], input_features=batch["input_features"], attention_mask=batch["attention_mask"],
+                input_feature_length=batch["input_feature_length"], GT=[" ".join(map(str, p)) for p in batch["post_ids"]],
+                labels=batch["labels"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.cross_attn = False
+        with pytest.raises(TypeError, match="atts"):
+            model(**call)
+        model.cross_attn = True
+        with pytest.raises((RuntimeError, ValueError, TypeError, AttributeError)):
+            model(**call)
+    from fake_ops import FakeOps
+    from ps_slm_amd.config import ModelConfig, TrainConfig
+    from ps_slm_amd.ps_slm import model_factory
+    with pytest.raises(NotImplementedError, match="q-former"):
+        model_factory(TrainConfig(freeze_llm=True, gt_emb=True, ctc_posterior=True), ModelConfig(llm_path="synthetic:mid", encoder_projector="q-former", llm_dim=256),
+                      device="cpu", ops=FakeOps())
