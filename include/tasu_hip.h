@@ -322,6 +322,7 @@ int tasu_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stre
  * >= p * 2^32; kept values are scaled by 1 / (1 - p) (fp32) and rounded to bf16 once.  Stateless: the backward calls
  * tasu_lora_dropout on the gradient with the same (stream_id, step) and gets the forward's mask.  The draws are this
  * library's own -- torch's Philox stream is not reproduced (PARITY UNPINNED for the mask; pinned for a GIVEN mask).
+ * tasu_lora_dropout takes a [M, C] matrix with leading dimensions (C, ld % 8 == 0; element index m * C + c).
  * tasu_lora_dropout_norm: the same on the fp32 RMSNorm output g * (x * rstd) recomputed from the saved row scales.
  * tasu_rng_advance: step += 1 (a launch, so that a replayed hipGraph draws fresh masks).                                   */
 /* Rank-sized GEMM (csrc/gemm_rank.hip): C[M, N] = A[M, K] . B[N, K]^T for N <= 64 -- the adapters' u = xd A^T and du = dy (sB),
@@ -340,10 +341,19 @@ int tasu_scale_bf16(const void* src, void* dst, float s, int64_t n, void* stream
  * forward applied to that input (element index m * N + n).  R % 64 == 0 (zero-padded rank), N % 8 == 0, ld* % 8 == 0.           */
 int tasu_lora_apply(void* y, int ldy, const void* u, int ldu, const void* W, int ldw, int M, int N, int R, float s, float p,
                     const void* rng, int stream_id, const float* x_in, float* x_out, int ldx, void* stream);
-int tasu_lora_dropout(const void* src, void* dst, int64_t n, float p, const void* rng, int stream_id, void* stream);
+int tasu_lora_dropout(const void* src, int ld_src, void* dst, int ld_dst, int M, int C, float p, const void* rng, int stream_id,
+                      void* stream);
 int tasu_lora_dropout_norm(const float* x, const float* w, const float* rstd, void* dst, int M, int D, float p, const void* rng,
                            int stream_id, void* stream);
 int tasu_rng_advance(void* rng, void* stream);
+/* Pieces of the K-extended forward of the adapted Linears, y = [x | us] [W | B]^T (one GEMM = base + low-rank branch, the fused
+ * epilogues of the frozen recipe kept): the producers of x write into the wider operand buffer.
+ * tasu_rmsnorm_fwd_ld: tasu_rmsnorm_fwd with a leading dimension for y; tasu_gemm_gate_up_swiglu_ld: tasu_gemm_gate_up_swiglu_ws
+ * with a leading dimension for act; tasu_copy_rows_bf16: dst[m, 0:C] = src[m, 0:C] (C, ld % 8 == 0).                         */
+int tasu_rmsnorm_fwd_ld(const float* x, const float* w, void* y, int ldy, float* rstd, int M, int D, float eps, void* stream);
+int tasu_gemm_gate_up_swiglu_ld(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int ld_act, int M, int I, int K,
+                                void* workspace, int64_t workspace_bytes, void* stream);
+int tasu_copy_rows_bf16(const void* src, int ld_src, void* dst, int ld_dst, int M, int C, void* stream);
 /* tasu_lora_refresh: every working copy of every adapter in ONE launch (after a load / an optimizer step).  `pb` is the bucket's
  * bf16 image; `table` (device, int64 [n_entries][8]) lists 2-D copies out of it: {source offset in elements, destination address,
  * rows, cols, destination leading dimension, transpose (0 / 1), scale (float bits in the low 32), first tile}; destination =

@@ -48,9 +48,12 @@ PROTOTYPES = {
     "tasu_lora_add": [vp, vp, f32, vp, vp, i64, vp],
     "tasu_scale_bf16": [vp, vp, f32, i64, vp],
     "tasu_lora_apply": [vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, i32, vp, vp, i32, vp],
-    "tasu_lora_dropout": [vp, vp, i64, f32, vp, i32, vp],
+    "tasu_lora_dropout": [vp, i32, vp, i32, i32, i32, f32, vp, i32, vp],
     "tasu_lora_dropout_norm": [vp, vp, vp, vp, i32, i32, f32, vp, i32, vp],
     "tasu_rng_advance": [vp, vp],
+    "tasu_rmsnorm_fwd_ld": [vp, vp, vp, i32, vp, i32, i32, f32, vp],
+    "tasu_gemm_gate_up_swiglu_ld": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
+    "tasu_copy_rows_bf16": [vp, i32, vp, i32, i32, i32, vp],
     "tasu_lora_refresh": [vp, vp, i32, i32, vp],
     "tasu_ce_fwd_bwd": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp],
     "tasu_ce_reduce": [vp, vp, vp, i32, vp, vp],

@@ -521,6 +521,10 @@ int& relu_next() {
   static thread_local int flag = 0;
   return flag;
 }
+int& act_ld_next() {
+  static int v = 0;
+  return v;
+}
 }  // namespace tasu_gemm
 
 extern "C" int tasu_relu_fwd(const void* x, void* y, int64_t n, void* stream);

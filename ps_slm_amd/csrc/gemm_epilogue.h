@@ -41,11 +41,14 @@ struct Args {
   float* sk_partial = nullptr;
   int* sk_flags = nullptr;
   double sk_rem = -2.0;  // host side only: sk_plan's max_rem for this launch (-2 = the library default / TASU_GEMM_SK*)
+  int act_ld = 0;        // OUT_GU_SWIGLU: leading dimension of act (0 = N); tasu_gemm_gate_up_swiglu_ld writes act into a wider buffer
   int relu = 0;          // TASU_GEMM_OUT_BF16 only: C = bf16(max(acc + bias, 0)) (tasu_gemm_bias_relu_bf16: PositionwiseFeedForward w_1)
 };
 
 // set by tasu_gemm_bias_relu_bf16 around its call of the dispatcher (host; the dispatchers copy it into Args::relu)
 int& relu_next();
+// likewise for tasu_gemm_gate_up_swiglu_ld: the act leading dimension of the next gate|up launch (0 = I)
+int& act_ld_next();
 
 // The work-item list of a workgroup of the 256 x 256 kernel (gemm_pp.hip), as one piece of host / device code so that the
 // schedule can be checked on the CPU (tasu_streamk_schedule, tests/test_cabi.py).  Whole tiles (and K-range slabs) are dealt
@@ -166,7 +169,7 @@ __device__ __forceinline__ void store_gu_swiglu(const Args& p, f32x4 (&acc)[MI][
           if (INTERIOR || (m < p.M && n < p.N)) {                   // N % 8 == 0: all eight or none
             *(u32x4*)(gu + (size_t)m * (2 * (size_t)p.N) + n) = u32x4{g0.u[0], g0.u[1], g1.u[0], g1.u[1]};
             *(u32x4*)(gu + (size_t)m * (2 * (size_t)p.N) + p.N + n) = u32x4{u0.u[0], u0.u[1], u1.u[0], u1.u[1]};
-            *(u32x4*)(p.act + (size_t)m * p.N + n) = u32x4{a0.u[0], a0.u[1], a1.u[0], a1.u[1]};
+            *(u32x4*)(p.act + (size_t)m * (size_t)(p.act_ld ? p.act_ld : p.N) + n) = u32x4{a0.u[0], a0.u[1], a1.u[0], a1.u[1]};
           }
         }
       };
@@ -190,7 +193,7 @@ __device__ __forceinline__ void store_gu_swiglu(const Args& p, f32x4 (&acc)[MI][
       for (int r = 0; r < 4; ++r) a4[r] = (bf16)(bf16_round(silu_f((float)g4[r])) * (float)u4[r]);
       *(bf16x4*)(gu + (size_t)m * (2 * (size_t)p.N) + n) = g4;
       *(bf16x4*)(gu + (size_t)m * (2 * (size_t)p.N) + p.N + n) = u4;
-      *(bf16x4*)(p.act + (size_t)m * p.N + n) = a4;
+      *(bf16x4*)(p.act + (size_t)m * (size_t)(p.act_ld ? p.act_ld : p.N) + n) = a4;
     }
   }
 }

@@ -360,6 +360,7 @@ extern "C" int tasu_gemm_gate_up_swiglu_ws(const void* A, int lda, const void* W
     a.ldc = 2 * I;
     a.tiles_m = a.tiles_n = 0;
     a.act = (bf16*)act;
+    a.act_ld = tasu_gemm::act_ld_next();
     a.ksplit = 1;
     a.split_stride = 0;
     a.n0 = n0;
@@ -405,6 +406,16 @@ extern "C" int tasu_gemm_gate_up_swiglu_ws(const void* A, int lda, const void* W
     }
   }
   return pipe_range(0);
+}
+
+// act with a leading dimension (the LoRA recipe keeps [act | rank activations] side by side as the down projection's operand)
+extern "C" int tasu_gemm_gate_up_swiglu_ld(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int ld_act, int M,
+                                           int I, int K, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (ld_act < I || ld_act % 8) return TASU_ERR_ARG;
+  tasu_gemm::act_ld_next() = ld_act == I ? 0 : ld_act;
+  const int rc = tasu_gemm_gate_up_swiglu_ws(A, lda, Wgu, ldw, gu, act, M, I, K, workspace, workspace_bytes, stream);
+  tasu_gemm::act_ld_next() = 0;
+  return rc;
 }
 
 extern "C" int tasu_gemm_gate_up_swiglu(const void* A, int lda, const void* Wgu, int ldw, void* gu, void* act, int M, int I,

@@ -335,7 +335,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(Args p) {
 #pragma nounroll
       for (int j = wg + 1; j < G && ub(j) < tile_end; ++j) {
         if (threadIdx.x == 0) {
-          while (__hip_atomic_load(p.sk_flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+          // bounded: the producer of range j is workgroup j's FIRST item, so on a healthy launch the flag is up within
+          // microseconds.  If it is not there after ~2 s (a grid that was not co-resident and got dispatched out of order, a
+          // second GEMM sharing the workspace from another stream), abort the launch -- the host sees a launch failure --
+          // instead of hanging the GPU silently.
+          long long spins = 0;
+          while (__hip_atomic_load(p.sk_flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1ll << 25)) __builtin_trap();
+          }
           __hip_atomic_store(p.sk_flags + j, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left at 0 for the next launch
         }
         __builtin_amdgcn_s_barrier();
@@ -517,6 +525,7 @@ int tasu_gemm_pp_gu_dispatch(const void* A, int lda, const void* Wgu, int ldw, v
   a.ldc = 2 * I;
   a.tiles_m = a.tiles_n = 0;
   a.act = (bf16*)act;
+  a.act_ld = tasu_gemm::act_ld_next();
   a.ksplit = 1;
   a.split_stride = 0;
   return launch<OUT_GU_SWIGLU, false>(a, st);

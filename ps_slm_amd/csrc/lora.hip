@@ -68,15 +68,17 @@ __device__ __forceinline__ float keep_scale(uint64_t key, int64_t idx, uint32_t 
   return (uint32_t)(z >> 32) >= thr ? inv : 0.f;
 }
 
-__global__ __launch_bounds__(256) void dropout_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int64_t nvec,
-                                                           uint32_t thr, float inv, const int64_t* __restrict__ rng, int sid) {
+__global__ __launch_bounds__(256) void dropout_bf16_kernel(const bf16* __restrict__ src, int ld_src, bf16* __restrict__ dst, int ld_dst,
+                                                           int M, int C8, uint32_t thr, float inv, const int64_t* __restrict__ rng, int sid) {
   const uint64_t key = mask_key(rng, sid);
+  const int64_t nvec = (int64_t)M * C8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const bf16x8 a = *(const bf16x8*)(src + i * 8);
+    const int m = (int)(i / C8), c = (int)(i - (int64_t)m * C8) * 8;
+    const bf16x8 a = *(const bf16x8*)(src + (size_t)m * ld_src + c);
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] * keep_scale(key, i * 8 + j, thr, inv));
-    *(bf16x8*)(dst + i * 8) = o;
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] * keep_scale(key, i * 8 + j, thr, inv));   // element index m * C + c + j
+    *(bf16x8*)(dst + (size_t)m * ld_dst + c) = o;
   }
 }
 
@@ -229,6 +231,15 @@ __global__ __launch_bounds__(256) void lora_refresh_kernel(const bf16* __restric
   }
 }
 
+// dst[m, 0:C] = src[m, 0:C] for two row-major bf16 matrices with their own leading dimensions (C % 8 == 0)
+__global__ __launch_bounds__(256) void copy_rows_kernel(const bf16* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, int M, int C8) {
+  const int64_t nvec = (int64_t)M * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / C8), c = (int)(i - (int64_t)m * C8) * 8;
+    *(bf16x8*)(dst + (size_t)m * ldd + c) = *(const bf16x8*)(src + (size_t)m * lds_ + c);
+  }
+}
+
 __global__ void rng_advance_kernel(int64_t* rng) {
   if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;
 }
@@ -258,12 +269,15 @@ extern "C" int tasu_scale_bf16(const void* src, void* dst, float s, int64_t n, v
   return TASU_OK;
 }
 
-extern "C" int tasu_lora_dropout(const void* src, void* dst, int64_t n, float p, const void* rng, int stream_id, void* stream) {
+extern "C" int tasu_lora_dropout(const void* src, int ld_src, void* dst, int ld_dst, int M, int C, float p, const void* rng, int stream_id,
+                                 void* stream) {
   uint32_t thr;
   float inv;
-  if (!src || !dst || !rng || n <= 0 || n % 8 || stream_id < 0 || !drop_args(p, &thr, &inv)) return TASU_ERR_ARG;
-  TASU_LAUNCH(dropout_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, n / 8, thr, inv,
-              (const int64_t*)rng, stream_id);
+  if (!src || !dst || !rng || M <= 0 || C <= 0 || C % 8 || ld_src < C || ld_dst < C || ld_src % 8 || ld_dst % 8 || stream_id < 0 ||
+      !drop_args(p, &thr, &inv))
+    return TASU_ERR_ARG;
+  TASU_LAUNCH(dropout_bf16_kernel, dim3(grid_for((int64_t)M * C / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src, (bf16*)dst,
+              ld_dst, M, C / 8, thr, inv, (const int64_t*)rng, stream_id);
   return TASU_OK;
 }
 
@@ -309,5 +323,12 @@ extern "C" int tasu_lora_apply(void* y, int ldy, const void* u, int ldu, const v
 extern "C" int tasu_lora_refresh(const void* pb, const void* table, int n_entries, int total_tiles, void* stream) {
   if (!pb || !table || n_entries <= 0 || total_tiles <= 0) return TASU_ERR_ARG;
   TASU_LAUNCH(lora_refresh_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16*)pb, (const int64_t*)table, n_entries);
+  return TASU_OK;
+}
+
+extern "C" int tasu_copy_rows_bf16(const void* src, int ld_src, void* dst, int ld_dst, int M, int C, void* stream) {
+  if (!src || !dst || M <= 0 || C <= 0 || C % 8 || ld_src < C || ld_dst < C || ld_src % 8 || ld_dst % 8) return TASU_ERR_ARG;
+  TASU_LAUNCH(copy_rows_kernel, dim3(grid_for((int64_t)M * C / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src, (bf16*)dst,
+              ld_dst, M, C / 8);
   return TASU_OK;
 }

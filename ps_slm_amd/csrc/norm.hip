@@ -16,13 +16,13 @@ __device__ __forceinline__ size_t frag_offset(int row, int c) {
 }
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ src,
                                                           const float* __restrict__ w, bf16* __restrict__ y,
-                                                          float* __restrict__ rstd, int M, int D, float eps, int frag) {
+                                                          float* __restrict__ rstd, int M, int D, float eps, int frag, int ldy) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
   const int srow = src ? src[row] : row;
   if (srow < 0) {
-    for (int c = lane * 4; c < D; c += 256) *(bf16x4*)(y + (size_t)row * D + c) = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    for (int c = lane * 4; c < D; c += 256) *(bf16x4*)(y + (size_t)row * ldy + c) = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
     if (lane == 0 && rstd) rstd[row] = 0.f;
     return;
   }
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
   ss = wave_sum(ss);
   const float r = rsqrtf(ss / (float)D + eps);
   if (lane == 0 && rstd) rstd[row] = r;
-  bf16* yr = y + (size_t)row * D;
+  bf16* yr = y + (size_t)row * ldy;
   for (int c = lane * 4; c < D; c += 256) {
     const f32x4 v = *(const f32x4*)(xr + c);
     const f32x4 g = *(const f32x4*)(w + c);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 template <int NG>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __restrict__ x, const int32_t* __restrict__ src,
                                                               const float* __restrict__ w, bf16* __restrict__ y,
-                                                              float* __restrict__ rstd, int M, float eps, int frag) {
+                                                              float* __restrict__ rstd, int M, float eps, int frag, int ldy) {
   constexpr int D = NG * 256;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __res
   if (srow < 0) {
 #pragma unroll
     for (int g = 0; g < NG; ++g)
-      *(bf16x4*)(y + (size_t)row * D + lane * 4 + g * 256) = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+      *(bf16x4*)(y + (size_t)row * ldy + lane * 4 + g * 256) = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
     if (lane == 0 && rstd) rstd[row] = 0.f;
     return;
   }
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __res
   ss = wave_sum(ss);
   const float r = rsqrtf(ss / (float)D + eps);
   if (lane == 0 && rstd) rstd[row] = r;
-  bf16* yr = y + (size_t)row * D + lane * 4;
+  bf16* yr = y + (size_t)row * ldy + lane * 4;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     f32x4 o;
@@ -345,15 +345,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
 }  // namespace
 
 static int rmsnorm_fwd_any(const float* x, const int32_t* src, const float* w, void* y, float* rstd, int M, int D, float eps,
-                           void* stream, int frag = 0) {
+                           void* stream, int frag = 0, int ldy = 0) {
   if (!x || !w || !y || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
+  if (ldy == 0) ldy = D;
+  if (ldy < D || ldy % 4 || (frag && ldy != D)) return TASU_ERR_ARG;
   const dim3 grid((M + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
-  if (D == 1536) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<6>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag);
-  else if (D == 3584) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<14>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag);
-  else if (D == 256) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<1>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag);
-  else TASU_LAUNCH(rmsnorm_fwd_kernel, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, D, eps, frag);
+  if (D == 1536) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<6>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag, ldy);
+  else if (D == 3584) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<14>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag, ldy);
+  else if (D == 256) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<1>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag, ldy);
+  else TASU_LAUNCH(rmsnorm_fwd_kernel, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, D, eps, frag, ldy);
   return TASU_OK;
+}
+extern "C" int tasu_rmsnorm_fwd_ld(const float* x, const float* w, void* y, int ldy, float* rstd, int M, int D, float eps, void* stream) {
+  return rmsnorm_fwd_any(x, nullptr, w, y, rstd, M, D, eps, stream, 0, ldy);
 }
 extern "C" int tasu_rmsnorm_fwd_frag(const float* x, const float* w, void* y_frag, int M, int D, float eps, void* stream) {
   if (M > 64 || D % 32) return TASU_ERR_ARG;

@@ -99,10 +99,10 @@ class LoraParams:
                     raise NotImplementedError(f"LoRA on {t}: dimension {n} is not a multiple of 64")
         self.groups = [(g, tuple(t for t in ts if t in cfg.target_modules)) for g, ts in GROUPS]
         self.groups = [(g, ts) for g, ts in self.groups if ts]
-        self.slot = {}                                     # target -> index of its rp-wide column block in the group's u / du buffers
-        for _, ts in self.groups:
+        self.slot, self.group_of = {}, {}                  # target -> index of its rp-wide column block in the group's us / du buffers
+        for g, ts in self.groups:
             for i, t in enumerate(ts):
-                self.slot[t] = i
+                self.slot[t], self.group_of[t] = i, g
         L = geo.llm_layers
         self.base = proj.numel
         self.offsets, self.layer_range = {}, {}
@@ -123,14 +123,21 @@ class LoraParams:
         # s = alpha / r is folded into them so that no activation-sized pass ever multiplies by it (exact for the shipped
         # s = 2^-2; one more bf16 rounding of a WEIGHT otherwise):
         #   as_ [r, in]   = s A      forward   us = xd (sA)^T               (the scaled rank activations)
-        #   bp  [out, rp] = B        forward   y += us B^T                  (rank padded to 64 with zero columns)
+        #   (B itself sits in the K-extended weights wext: forward  y = [x | us] [W | B]^T)
         #   bts [r, out]  = s B^T    backward  du = dy (sB)                 (d(loss)/d(xd A^T) . s)
         #   at  [in, rp]  = A^T      backward  dxd = du A ;  dA = du^T xd,  dB = dy^T us
         keys = [(l, t) for l in range(L) for t in cfg.target_modules]
         self.as_ = {k: torch.zeros(self.r, self.dims[k[1]][0], **bf) for k in keys}
         self.bts = {k: torch.zeros(self.r, self.dims[k[1]][1], **bf) for k in keys}
         self.at = {k: torch.zeros(self.dims[k[1]][0], self.rp, **bf) for k in keys}
-        self.bp = {k: torch.zeros(self.dims[k[1]][1], self.rp, **bf) for k in keys} if self.rp != self.r else {}
+        # K-extended forward operands: an adapted group's Linear runs as ONE GEMM  y = [x | us_1 | us_2 ..] [W | B_1 | B_2 ..]^T
+        # (B_t in the rows of its member, zero elsewhere; K padded to 128).  wext[(l, g)] holds [W | B..]; build_ext() fills it.
+        D, I, H, G = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads
+        self.kbase = {"qkv": D, "o": H * HD, "gu": D, "down": I}
+        self.nout = {"qkv": (H + 2 * G) * HD, "o": D, "gu": 2 * I, "down": D}
+        self.wname = {"qkv": "wqkv", "o": "wo", "gu": "wgu", "down": "wd"}
+        self.kext = {g: rup(self.kbase[g] + len(ts) * self.rp, 128) for g, ts in self.groups}
+        self.wext = {}
         self.rng = torch.zeros(2, dtype=torch.int64, device=device)          # {seed, step} of the dropout masks (csrc/lora.hip)
         self.version = 0                                   # bumped whenever the adapters change (load, optimizer step)
         self._table = None                                 # device table of tasu_lora_refresh, built on first use
@@ -141,8 +148,22 @@ class LoraParams:
         off, shp = self.offsets[(l, t, which)]
         return flat[off:off + shp[0] * shp[1]].view(*shp)
 
-    def b_bf(self, l, t):
-        return self.bp[(l, t)] if self.bp else self.view(self.proj.pb, l, t, "B")   # [out, rp]
+    def b_ext(self, l, g, t):
+        """Where B_t lives: rows of member t, the rank columns of its slot, inside the group's K-extended weight."""
+        c0, o = self.cols[t], self.dims[t][1]
+        k0 = self.kbase[g] + self.slot[t] * self.rp
+        return self.wext[(l, g)][c0:c0 + o, k0:k0 + self.r]
+
+    def build_ext(self, llm):
+        """(Re)builds the K-extended weights from the frozen base weights (at enable_lora and after the LLM was reloaded)."""
+        for l, w in enumerate(llm.layers):
+            for g, _ in self.groups:
+                t = self.wext.get((l, g))
+                if t is None:
+                    t = self.wext[(l, g)] = torch.zeros(self.nout[g], self.kext[g], dtype=torch.bfloat16, device=self.device)
+                t.zero_()
+                t[:, : self.kbase[g]].copy_(w[self.wname[g]])
+        self._table = None                                 # destination addresses may be new
 
     def num_parameters(self):
         return sum(int(np.prod(s)) for _, s in self.offsets.values())
@@ -206,8 +227,7 @@ class LoraParams:
                 add(oa, self.as_[(l, t)], self.r, i, 0, sbits)                            # s A
                 add(ob, self.bts[(l, t)], o, self.r, 1, sbits)                            # s B^T  [r, out]
                 add(oa, self.at[(l, t)], self.r, i, 1, one)                               # A^T    [in, rp] (pad columns stay zero)
-                if self.bp:
-                    add(ob, self.bp[(l, t)], o, self.r, 0, one)                           # B      [out, rp]
+                add(ob, self.b_ext(l, self.group_of[t], t), o, self.r, 0, one)            # B into [W | B] (rows of t, its rank columns)
         return torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows), tiles
 
     def refresh_working_copies(self, ops):
@@ -226,8 +246,7 @@ class LoraParams:
                 ops.transpose(b, self.bts[(l, t)], o, self.r, o, self.r)                  # [out, r] -> [r, out]
                 ops.scale_bf16(self.bts[(l, t)], self.bts[(l, t)], sc)                    # s B^T
                 ops.transpose(a, self.at[(l, t)], self.r, i, self.rp, i)                  # [r, in] -> [in, rp] (zero pad)
-                if self.bp:
-                    self.bp[(l, t)][:, : self.r].copy_(b)
+                self.b_ext(l, self.group_of[t], t).copy_(b)
 
 
 def merged_llm(model):
@@ -280,12 +299,14 @@ class LoraRunner:
     """The adapted decoder layer: forward and backward of one layer with the low-rank branches in place.  Called by
     TasuModel.forward_llm / backward_llm when ``model.lora`` is set; uses the model's named workspace buffers.
 
-    Per adapted Linear the forward is  us = xd (sA)^T  (tasu_gemm_nt_rank) and  y = bf16(y + bf16(us B^T))  (tasu_lora_apply: the
-    rank-64 product, the accumulate and -- for o / down -- the residual add in ONE pass over y); the backward is  du = dy (sB),
-    dxd = mask . (du A) accumulated into the base path's gradient (tasu_lora_apply again), dB = dy^T us and dA = du^T xd (rank GEMMs
-    on transposed operands, fp32, straight into the bucket).  Kept from the forward for the backward, per layer: us, and the
-    adapters' bf16 inputs xd (the dropped copies per target in training mode, the plain norm / attention / SwiGLU outputs
-    otherwise) -- nothing is recomputed and no mask is regenerated except inside the backward's fused accumulate."""
+    Forward: per adapted group ONE GEMM  y = [x | us] [W | B]^T  with K extended by the members' ranks (padded to 128): the
+    producers of x (RMSNorm, the SwiGLU epilogue; a row copy for the attention output) write into the head of the operand, the
+    members' us = xd (sA)^T (tasu_gemm_nt_rank) into its tail, and the frozen recipe's fused epilogues (bias + RoPE, SwiGLU,
+    residual add) stay.  Rounding: ONE bf16 rounding of base + low-rank sum instead of the reference's three (base, branch,
+    sum) -- within the tolerance of every bf16 comparison here, and not a difference in fp32.  Backward: du = dy (sB),
+    dxd = mask . (du A) accumulated into the base path's gradient in one pass (tasu_lora_apply), dB = dy^T us and dA = du^T xd
+    (rank GEMMs on transposed operands, fp32, straight into the bucket).  Kept from the forward, per layer: the operands [x | us]
+    and, in training mode with dropout, every member's dropped input -- nothing is recomputed."""
 
     def __init__(self, model):
         self.m = model
@@ -321,26 +342,27 @@ class LoraRunner:
     def _sid(self, l, t):
         return l * 8 + TARGETS.index(t)
 
-    def _us(self, gname, nt, M):
-        return self._zbuf("lora_us_" + gname, (self.m.geo.llm_layers, M, nt * self.lp.rp))
+    def _ax(self, gname, M):
+        """The group's K-extended activation operand, kept per layer: [L, M, kext] = [x | us of every member | zero pad]."""
+        return self._zbuf("lora_ax_" + gname, (self.m.geo.llm_layers, M, self.lp.kext[gname]))
 
     def _xin(self, name, M, width):
-        """Per-layer store of an adapter input: [L, M, width] bf16."""
+        """Per-layer store of a member's dropped input: [L, M, width] bf16 (training mode with dropout only)."""
         return self.m._buf("lora_x_" + name, (self.m.geo.llm_layers, M, width), torch.bfloat16)
 
-    # ---- forward of one group: y[:, cols_t] (bf16, the base result incl. bias) += us_t B_t^T for every adapted member
-    def group_fwd(self, l, gname, targets, y, M, xd_of, x_in=None, x_out=None):
-        """xd_of(t) -> the bf16 [M, in] input of target t's adapter (stored for the backward by the caller).  With x_in / x_out
-        (single-member groups: o, down) the residual add rides on the accumulate."""
-        lp, ops = self.lp, self.m.ops
-        r, rp = lp.r, lp.rp
-        us_all = self._us(gname, len(targets), M)
+    def _us_view(self, gname, l, M, nt):
+        K = self.lp.kbase[gname]
+        return self._ax(gname, M)[l][:, K:K + nt * self.lp.rp]
+
+    # ---- forward of one group: the rank activations of every member into the tail of the group's operand
+    def group_us(self, l, gname, targets, M, xd_of):
+        """us_t = bf16(xd_t (s A_t)^T) into columns [K + slot * rp, +r) of the K-extended operand; the caller then runs ONE GEMM
+        [x | us] [W | B]^T with the frozen recipe's epilogue.  xd_of(t): the bf16 [M, in] input of member t's adapter."""
+        lp = self.lp
+        us = self._us_view(gname, l, M, len(targets))
         for t in targets:
-            i, o = lp.dims[t]
-            k, c0 = lp.slot[t], lp.cols[t]
-            us = us_all[l][:, k * rp: k * rp + rp]
-            self.rank(xd_of(t), lp.as_[(l, t)], us, M, r, i)                       # us = bf16(xd (sA)^T)            [M, r]
-            ops.lora_apply(y[:, c0:c0 + o], us, lp.b_bf(l, t), M, o, rp, x_in=x_in, x_out=x_out)
+            k = lp.slot[t]
+            self.rank(xd_of(t), lp.as_[(l, t)], us[:, k * lp.rp: k * lp.rp + lp.rp], M, lp.r, lp.dims[t][0])
 
     # ---- backward of one group
     def group_bwd(self, l, gname, targets, dy, width, M, xd_of, dx_base, drop):
@@ -352,7 +374,7 @@ class LoraRunner:
         Mp = rup(M, 64)
         nt = len(targets)
         inn = lp.dims[targets[0]][0]
-        us_all = m._ws["lora_us_" + gname][: L * M * nt * rp].view(L, M, nt * rp)
+        us_l = self._us_view(gname, l, M, nt)                   # [M, nt * rp], a column slice of the forward's operand
         self._wait_side(gname)
         du = self._zbuf("lora_du_" + gname, (M, nt * rp))
         for t in targets:
@@ -367,7 +389,7 @@ class LoraRunner:
 
         def wgrads():
             us_t = m._buf("lora_us_t", (nt * rp, Mp), bf)
-            ops.transpose(us_all[l], us_t, M, nt * rp, Mp, nt * rp)
+            ops.transpose(us_l, us_t, M, nt * rp, Mp, nt * rp)
             du_tr = m._buf("lora_du_t", (nt * rp, Mp), bf)
             ops.transpose(du, du_tr, M, nt * rp, Mp, nt * rp)
             xd_t = m._buf("lora_xd_t", (inn, Mp), bf)
@@ -410,14 +432,13 @@ class LoraRunner:
         m, lp, ops, geo = self.m, self.lp, self.m.ops, self.m.geo
         B, S, M = st.B, st.S, st.M
         D, I, H, G = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads
-        LDQ, scale, eps, p = (H + 2 * G) * HD, HD ** -0.5, geo.rms_eps, lp.cfg.lora_dropout
-        bf = torch.bfloat16
+        scale, eps, p = HD ** -0.5, geo.rms_eps, lp.cfg.lora_dropout
         xs, rstd, qkv, ao, lse, gu, xn, act, cos, sin = (bufs[k] for k in ("xs", "rstd", "qkv", "ao", "lse", "gu", "xn", "act", "cos", "sin"))
         x_in, x_mid, x_out = xs[2 * l], xs[2 * l + 1], xs[2 * l + 2]
         groups = dict(lp.groups)
         sid = lambda t: self._sid(l, t)
 
-        def dropped_norm(x, wn, rs):                        # target -> its own dropped copy of the norm's fp32 output, kept per layer
+        def dropped_norm(x, wn, rs):                        # member -> its own dropped copy of the norm's fp32 output, kept per layer
             def f(t):
                 dst = self._xin(t, M, D)[l]
                 ops.lora_dropout_norm(x, wn, rs, dst, M, D, p, lp.rng, sid(t))
@@ -432,38 +453,38 @@ class LoraRunner:
             return f
 
         # ---- attention block
-        keep1 = "qkv" in groups and not drop               # the norm's output IS the adapters' input: write it into the per-layer store
-        xn1 = self._xin("qkv", M, D)[l] if keep1 else xn
-        ops.rmsnorm_fwd(x_in, w["ln1"], xn1, rstd[2 * l], eps)
         if "qkv" in groups:
-            ops.gemm(xn1, w["wqkv"], qkv[l], M, LDQ, D, bias=w["bqkv"])
-            self.group_fwd(l, "qkv", groups["qkv"], qkv[l], M, dropped_norm(x_in, w["ln1"], rstd[2 * l]) if drop else (lambda t: xn1))
-            ops.rope_fwd(qkv[l], cos, sin, None, None, None, B, S, H, G)
+            a = self._ax("qkv", M)[l]
+            x1 = a[:, :D]                                   # the norm writes straight into the head of the operand
+            ops.rmsnorm_fwd(x_in, w["ln1"], x1, rstd[2 * l], eps)
+            self.group_us(l, "qkv", groups["qkv"], M, dropped_norm(x_in, w["ln1"], rstd[2 * l]) if drop else (lambda t: x1))
+            ops.gemm_qkv_rope(a, lp.wext[(l, "qkv")], w["bqkv"], qkv[l], cos, sin, M, H, G, lp.kext["qkv"])
         else:
-            ops.gemm_qkv_rope(xn1, w["wqkv"], w["bqkv"], qkv[l], cos, sin, M, H, G, D)
+            ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], eps)
+            ops.gemm_qkv_rope(xn, w["wqkv"], w["bqkv"], qkv[l], cos, sin, M, H, G, D)
         ops.attn_fwd(qkv[l], None, st.dev["key_mask"], ao[l], lse[l], B, S, H, G, scale, True)
         if "o" in groups:
-            y = m._buf("lora_y", (M, D), bf)
-            ops.gemm(ao[l], w["wo"], y, M, D, H * HD)
-            self.group_fwd(l, "o", groups["o"], y, M, dropped(ao[l], H * HD) if drop else (lambda t: ao[l]), x_in=x_in, x_out=x_mid)
+            a = self._ax("o", M)[l]
+            ops.copy_rows(ao[l], a, M, H * HD)              # (the attention kernels write a dense [M, H * 128])
+            self.group_us(l, "o", groups["o"], M, dropped(ao[l], H * HD) if drop else (lambda t: ao[l]))
+            ops.gemm(a, lp.wext[(l, "o")], x_mid, M, D, lp.kext["o"], resid=x_in, mode=GEMM_RESID)
         else:
             ops.gemm(ao[l], w["wo"], x_mid, M, D, H * HD, resid=x_in, mode=GEMM_RESID)
-        # ---- MLP block
-        keep2 = "gu" in groups and not drop
-        xn2 = self._xin("gu", M, D)[l] if keep2 else xn
-        ops.rmsnorm_fwd(x_mid, w["ln2"], xn2, rstd[2 * l + 1], eps)
-        keep3 = "down" in groups and not drop
-        act_l = self._xin("down", M, I)[l] if keep3 else act
+        # ---- MLP block: the SwiGLU epilogue writes act into the head of the down projection's operand
+        ad = self._ax("down", M)[l] if "down" in groups else None
+        act_l = ad[:, :I] if ad is not None else act
         if "gu" in groups:
-            ops.gemm(xn2, w["wgu"], gu[l], M, 2 * I, D)
-            self.group_fwd(l, "gu", groups["gu"], gu[l], M, dropped_norm(x_mid, w["ln2"], rstd[2 * l + 1]) if drop else (lambda t: xn2))
-            ops.swiglu_fwd(gu[l], act_l, M, I)
+            a = self._ax("gu", M)[l]
+            x2 = a[:, :D]
+            ops.rmsnorm_fwd(x_mid, w["ln2"], x2, rstd[2 * l + 1], eps)
+            self.group_us(l, "gu", groups["gu"], M, dropped_norm(x_mid, w["ln2"], rstd[2 * l + 1]) if drop else (lambda t: x2))
+            ops.gemm_gate_up_swiglu(a, lp.wext[(l, "gu")], gu[l], act_l, M, I, lp.kext["gu"])
         else:
-            ops.gemm_gate_up_swiglu(xn2, w["wgu"], gu[l], act_l, M, I, D)
+            ops.rmsnorm_fwd(x_mid, w["ln2"], xn, rstd[2 * l + 1], eps)
+            ops.gemm_gate_up_swiglu(xn, w["wgu"], gu[l], act_l, M, I, D)
         if "down" in groups:
-            y = m._buf("lora_y", (M, D), bf)
-            ops.gemm(act_l, w["wd"], y, M, D, I)
-            self.group_fwd(l, "down", groups["down"], y, M, dropped(act_l, I) if drop else (lambda t: act_l), x_in=x_mid, x_out=x_out)
+            self.group_us(l, "down", groups["down"], M, dropped(act_l, I) if drop else (lambda t: act_l))
+            ops.gemm(ad, lp.wext[(l, "down")], x_out, M, D, lp.kext["down"], resid=x_mid, mode=GEMM_RESID)
         else:
             ops.gemm(act_l, w["wd"], x_out, M, D, I, resid=x_mid, mode=GEMM_RESID)
 
@@ -479,12 +500,12 @@ class LoraRunner:
         groups = dict(lp.groups)
 
         def stored(gname, width, shared=None):
-            """target -> the input its adapter saw in the forward (the dropped copy per target, or the group's shared input)."""
+            """member -> the input its adapter saw in the forward: its dropped copy, or the head of the group's forward operand."""
             if drop:
                 return lambda t: self._xin(t, M, width)[l]
             if shared is not None:
                 return lambda t: shared
-            buf = self._xin(gname, M, width)[l]
+            buf = self._ax(gname, M)[l][:, :width]
             return lambda t: buf
 
         if "down" in groups:

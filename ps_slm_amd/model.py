@@ -391,6 +391,8 @@ class TasuModel:
     def load_reference_state_dict(self, sd):
         """sd: reference-named tensors (``llm.*``, ``encoder_projector.*``, optionally ``encoder.*``)."""
         self.llm.load_reference_state_dict(sd)
+        if self.lora is not None:
+            self.lora.build_ext(self.llm)                  # [W | B] copies of the adapted Linears follow the new base weights
         for n in self.proj.names:
             self.proj.load(n, sd["encoder_projector." + n].to(self.device, torch.float32))
         self.sync_projector_copies()
@@ -401,6 +403,8 @@ class TasuModel:
 
     def init_random(self, seed=1234, with_encoder=False):
         self.llm.init_random(seed)
+        if self.lora is not None:
+            self.lora.build_ext(self.llm)
         self.init_projector_default(seed + 1)
         if with_encoder:
             from .encoder import EncoderWeights
@@ -462,6 +466,7 @@ class TasuModel:
         if self.lora is not None:
             raise RuntimeError("LoRA is already enabled on this model")
         self.lora = LoraParams(self.geo, cfg, self.proj, self.device)
+        self.lora.build_ext(self.llm)
         self.lora.init_default(seed)
         self.lora.seed_dropout(seed)
         self._lora_run = LoraRunner(self)

@@ -99,6 +99,9 @@ class HipOps:
 
     def gemm_gate_up_swiglu(self, a, wgu, gu, act, M, I, K):
         """gu[M,2I] = a @ wgu^T and act[M,I] = swiglu(gu) in one launch (training step)."""
+        if act.stride(0) != I:                          # act is the head of a wider operand buffer
+            return self._chk(self.lib.tasu_gemm_gate_up_swiglu_ld(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), act.stride(0), M, I,
+                                                                  K, _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()), "tasu_gemm_gate_up_swiglu_ld")
         self._chk(self.lib.tasu_gemm_gate_up_swiglu_ws(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), M, I, K,
                                                        _p(self.gemm_ws), GEMM_WS_BYTES, self._stream()),
                   "tasu_gemm_gate_up_swiglu_ws")
@@ -197,6 +200,8 @@ class HipOps:
     # ------------------------------------------------------------------ norms
     def rmsnorm_fwd(self, x, w, y, rstd, eps):
         M, D = x.shape
+        if y.stride(0) != D:                            # y is the head of a wider operand buffer ([x | rank activations])
+            return self._chk(self.lib.tasu_rmsnorm_fwd_ld(_p(x), _p(w), _p(y), y.stride(0), _p(rstd), M, D, eps, self._stream()), "tasu_rmsnorm_fwd_ld")
         self._chk(self.lib.tasu_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), M, D, eps, self._stream()), "tasu_rmsnorm_fwd")
 
     def rmsnorm_bwd(self, dy, x, w, rstd, dx, dx_bf16, accumulate):
@@ -326,11 +331,18 @@ class HipOps:
         self._chk(self.lib.tasu_scale_bf16(_p(src), _p(dst), float(s), src.numel(), self._stream()), "tasu_scale_bf16")
 
     def lora_dropout(self, src, dst, p, rng, sid):
-        self._chk(self.lib.tasu_lora_dropout(_p(src), _p(dst), src.numel(), float(p), _p(rng), int(sid), self._stream()), "tasu_lora_dropout")
+        """dst = dropout(src) for [M, C] matrices (row strides honoured; a 1-D tensor is one row); mask index m * C + c."""
+        M, C = (1, src.numel()) if src.dim() == 1 else src.shape
+        lds, ldd = (C, C) if src.dim() == 1 else (src.stride(0), dst.stride(0))
+        self._chk(self.lib.tasu_lora_dropout(_p(src), lds, _p(dst), ldd, M, C, float(p), _p(rng), int(sid), self._stream()), "tasu_lora_dropout")
 
     def lora_dropout_norm(self, x, w, rstd, dst, M, D, p, rng, sid):
         self._chk(self.lib.tasu_lora_dropout_norm(_p(x), _p(w), _p(rstd), _p(dst), M, D, float(p), _p(rng), int(sid), self._stream()),
                   "tasu_lora_dropout_norm")
+
+    def copy_rows(self, src, dst, M, C):
+        """dst[:M, :C] = src[:M, :C] (bf16, both with their own row strides)."""
+        self._chk(self.lib.tasu_copy_rows_bf16(_p(src), src.stride(0), _p(dst), dst.stride(0), M, C, self._stream()), "tasu_copy_rows_bf16")
 
     def lora_refresh(self, pb, table, n_entries, total_tiles):
         self._chk(self.lib.tasu_lora_refresh(_p(pb), _p(table), n_entries, total_tiles, self._stream()), "tasu_lora_refresh")

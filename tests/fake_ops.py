@@ -311,6 +311,9 @@ class FakeOps:
         if x_in is not None:
             x_out[:M, :N] = x_in[:M, :N] + y[:M, :N].float()
 
+    def copy_rows(self, src, dst, M, C):
+        dst[:M, :C] = src[:M, :C]
+
     def scale_bf16(self, src, dst, s):
         dst.copy_(_bf(src.float() * float(s)))
 

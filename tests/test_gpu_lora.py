@@ -53,6 +53,12 @@ def test_lora_elementwise_kernels_bit_exact(ops):
         f.lora_dropout_norm(x, w, rstd, dc2, M, D, p, rng, sid)
         ops.lora_dropout_norm(x.cuda(), w.cuda(), rstd.cuda(), dg2, M, D, p, rng_g, sid)
         assert torch.equal(dg2.cpu(), dc2)
+    # a column slice of a wider buffer as the source (the SwiGLU output inside the down projection's K-extended operand)
+    wide = torch.randn(M, D + 64, generator=g).bfloat16()
+    dc3, dg3 = torch.empty(M, D, dtype=torch.bfloat16), torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    f.lora_dropout(wide[:, :D], dc3, 0.25, rng, 9)
+    ops.lora_dropout(wide.cuda()[:, :D], dg3, 0.25, rng_g, 9)
+    assert torch.equal(dg3.cpu(), dc3)
     ops.rng_advance(rng_g)
     assert rng_g.cpu().tolist() == [123456789, 5]
     # a different step or stream draws a different mask; the same (seed, step, stream) the same one
@@ -216,7 +222,7 @@ def test_lora_apply_bit_exact_vs_double(ops, M, N, R):
 @pytest.mark.parametrize("name", ["mid_text_lora", "mid_text_lora_qv"])
 def test_lora_refresh_one_launch_equals_the_copies(ops, name):
     """tasu_lora_refresh (all working copies of all adapters from the bucket's bf16 image in one launch) against the copies
-    built one by one: s A, s B^T, A^T (zero-padded to the 64-wide rank), and the padded B when r % 64 != 0."""
+    built one by one: s A, s B^T, A^T (zero-padded to the 64-wide rank), and B inside the K-extended weights [W | B]."""
     z, geo, cfg, sd, lsd, batch = golden_case(name)
     gm = build(geo, cfg, sd, lsd, ops, "cuda")
     lp, pb, sc = gm.lora, gm.proj.pb, cfg.scaling
@@ -226,5 +232,14 @@ def test_lora_refresh_one_launch_equals_the_copies(ops, name):
             assert torch.equal(lp.as_[(l, t)], (a * sc).bfloat16()), (l, t)
             assert torch.equal(lp.bts[(l, t)], (b.t() * sc).bfloat16()), (l, t)
             assert torch.equal(lp.at[(l, t)][:, : lp.r], a.t().bfloat16()) and (lp.rp == lp.r or float(lp.at[(l, t)][:, lp.r:].abs().max()) == 0)
-            if lp.bp:
-                assert torch.equal(lp.bp[(l, t)][:, : lp.r], b.bfloat16()) and float(lp.bp[(l, t)][:, lp.r:].abs().max()) == 0
+            assert torch.equal(lp.b_ext(l, lp.group_of[t], t), b.bfloat16()), (l, t)
+    # the K-extended weights: the frozen base weight in the head, every B in its member's rows / rank columns, zeros elsewhere
+    for (l, g), we in lp.wext.items():
+        K = lp.kbase[g]
+        assert torch.equal(we[:, :K], gm.llm.layers[l][lp.wname[g]])
+        tail = we[:, K:].clone()
+        for t in dict(lp.groups)[g]:
+            c0, o = lp.cols[t], lp.dims[t][1]
+            k0 = lp.slot[t] * lp.rp
+            tail[c0:c0 + o, k0:k0 + lp.r] = 0
+        assert float(tail.abs().max()) == 0.0, (l, g)
