@@ -280,12 +280,14 @@ def encoder_gemm_flops_per_utt(geo, frames):
     return 2 * frames * ((layers - 1) * per_layer + first + E * V)
 
 
-def lora_gemm_flops_per_utt(geo, S, cfg):
-    """The adapters' GEMM FLOPs of one utterance: per adapted Linear, forward u = x A^T and v = u B^T (2 S r (in + out)),
-    backward du, dx, dB, dA (twice that)."""
-    from ps_slm_amd.lora import target_dims
-    dims = target_dims(geo)
-    return geo.llm_layers * sum(3 * 2 * S * cfg.r * (dims[t][0] + dims[t][1]) for t in cfg.target_modules)
+def lora_flops_per_utt(geo, S, lp):
+    """The adapters' FLOPs of one utterance, split by where they run: (inside the timed base GEMMs, elsewhere).  Inside: the rank
+    columns of the K-extended forward GEMMs, 2 S N (kext - K) per adapted group (padding included: executed work).  Elsewhere
+    (tasu_gemm_nt_rank, tasu_lora_apply): forward us = x A^T (2 S r in), backward du, dx, dB, dA (2 S r (in + out) each pair)."""
+    L = geo.llm_layers
+    ext = L * sum(2 * S * lp.nout[g] * (lp.kext[g] - lp.kbase[g]) for g, _ in lp.groups)
+    rank = L * sum(2 * S * lp.r * lp.dims[t][0] + 2 * 2 * S * lp.r * (lp.dims[t][0] + lp.dims[t][1]) for t in lp.cfg.target_modules)
+    return ext, rank
 
 
 def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank, want_decode, device=None, ops=None,
@@ -421,10 +423,10 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         n_head = st.nLp / B                             # lm_head rows executed per utterance (labelled positions, padded to 64)
         enc = encoder_gemm_flops_per_utt(geo, raw["input_features"].shape[1] + 4) if audio else 0
         tail = "xout_tail" in st.dev                    # last layer's MLP ran on the labelled rows only (TasuModel.tail_rows)
-        lo = lora_gemm_flops_per_utt(geo, S, core.lora.cfg) if core.lora is not None else 0
-        gemm_flops_step = (gemm_flops_per_utt(geo, S, n_audio, n_head, tail) + enc + lo) * B
-        executed_step = (total_flops_per_utt(geo, S, n_audio, n_head, tail) + enc + lo) * B
-        survey_step = (total_flops_per_utt(geo, S, n_audio) + enc + lo) * B
+        lo_in, lo_out = lora_flops_per_utt(geo, S, core.lora) if core.lora is not None else (0, 0)
+        gemm_flops_step = (gemm_flops_per_utt(geo, S, n_audio, n_head, tail) + enc + lo_in) * B      # the timed GEMM calls only
+        executed_step = (total_flops_per_utt(geo, S, n_audio, n_head, tail) + enc + lo_in + lo_out) * B
+        survey_step = (total_flops_per_utt(geo, S, n_audio) + enc + lo_in + lo_out) * B
         if timed.replay_ms is not None:
             gemm_ms, n_launch = timed.replay_ms[0] * steps, timed.replay_ms[1] * steps
         else:

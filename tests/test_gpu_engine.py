@@ -214,3 +214,34 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas():
     torch.cuda.synchronize()
     assert torch.equal(model.core.proj.p.cpu(), r0["p1"]), "the 2-rank update is not the AdamW step on the averaged gradient"
     assert torch.equal(r0["p1"], r1["p1"])
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_lora_bucket_exchange_on_rccl_is_bit_identical(nccl_group, graphs):
+    """use_peft=true through the same machinery: the adapters' range (complete when the decoder's backward -- with its
+    side-stream weight-gradient chains joined -- is) exchanged first, then the projector's ranges; losses, the whole bucket and
+    Adam moments bit-identical to the step without exchange (no dropout: the mask counter is not part of this comparison)."""
+    def build_lora(force, chunks):
+        tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True,
+                         use_fp16=True, use_peft=True)
+        tc.peft_config.r, tc.peft_config.lora_dropout = 16, 0.0
+        mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+        model, _ = model_factory(tc, mc, device="cuda:0", init_seed=1234, keep_logits=False)
+        model.core.use_graphs = graphs
+        cfg = load_ds_config(DEFAULT_DS_CONFIG)
+        cfg["lr"] = 1e-3
+        eng = TasuEngine(model, cfg, force_exchange=force, w1_chunks=chunks)
+        eng.sched_iter = 10
+        return model, eng
+    m0, e0 = build_lora(False, None)
+    want = run_steps(m0, e0)
+    m1, e1 = build_lora(True, 4)
+    lp = m1.core.lora
+    seen = []
+    issue = e1._issue
+    e1._issue = lambda g, lo, hi: (seen.append((lo, hi)), issue(g, lo, hi))[1]
+    got = run_steps(m1, e1)
+    assert seen[0] == (lp.base, m1.core.proj.numel) and len(seen) == 4 * 7       # adapters first, then the projector's six ranges
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert float(m1.core.proj.p[lp.base:].abs().max()) > 0 and float(want[0][-1]) < float(want[0][0])
