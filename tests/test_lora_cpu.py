@@ -344,3 +344,31 @@ def test_generate_with_adapters_vs_reference_tokens():
     toks2 = generate_text(z, ids, am, word_ids)
     assert z.lora._merged.layers[0]["wqkv"].data_ptr() == ptr and not torch.equal(z.lora._merged.layers[0]["wqkv"], before)
     assert np.array_equal(toks2, toks)
+
+
+def test_lora_on_the_audio_path_and_with_other_projectors():
+    """The adapters sit in the decoder, so every front end keeps working under use_peft: the audio branch (encoder -> PSD ->
+    projector) and the alternate projectors; one engine step each moves projector and adapters and lowers the loss."""
+    from conftest import mid_audio_psd_case
+    geo, sd, batch, z = mid_audio_psd_case()
+    cfg = LoraConfig(r=16, lora_alpha=32, lora_dropout=0.1)
+    m = build(geo, cfg, sd, random_lora_state_dict(geo, cfg, 3), FakeOps(), "cpu")
+    losses = []
+    for step in range(1, 4):
+        st = m.prepare_audio(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["input_features"], batch["input_feature_length"])
+        m.forward_llm(st)
+        m.backward(st)
+        assert np.array_equal(st.dev["psd_lens"], z["psd_lens"])
+        losses.append(float(st.dev["loss_out"][0]))
+        g = m.proj.g
+        assert torch.isfinite(g).all() and float(g[m.lora.base:].abs().max()) > 0 and float(g[: m.lora.base].abs().max()) > 0
+        m.ops.adamw(m.proj.p, m.proj.g, m.proj.m, m.proj.v, m.proj.pb, torch.tensor([2e-3]), 0.9, 0.999, 1e-6, 0.0, step, 1.0)
+        m.refresh_working_copies()
+    assert losses[-1] < losses[0]
+    # the cross-attention projector (its keys / values are the frozen embedding table) next to adapters
+    from conftest import ca_projector_case
+    geo2, sd2, batch2, _ = ca_projector_case()
+    cfg2 = LoraConfig(r=8, lora_alpha=8, lora_dropout=0.0, target_modules=("q_proj", "v_proj", "up_proj"))
+    m2 = build(geo2, cfg2, sd2, random_lora_state_dict(geo2, cfg2, 4), FakeOps(), "cpu")
+    st2 = run_text(m2, batch2)
+    assert torch.isfinite(st2.dev["loss_out"]).all() and float(m2.proj.g[m2.lora.base:].abs().max()) > 0
