@@ -473,6 +473,13 @@ class TasuModel:
         self._graphs, self._graph_seen = {}, {}
         self.sync_projector_copies()
 
+    def lora_spans(self, n=7):
+        """The decoder's layers as at most ``n`` spans (hi, lo), last layers first: the units of the adapters' gradient exchange."""
+        L = self.geo.llm_layers
+        n = max(1, min(n, L))
+        cuts = [L - (L * i) // n for i in range(n + 1)]
+        return [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i] > cuts[i + 1]]
+
     def lora_state_dict(self):
         return {} if self.lora is None else self.lora.state_dict()
 
@@ -836,9 +843,10 @@ class TasuModel:
         self.backward_llm(st)
         self.backward_projector(st, on_ready, w1_chunks)
 
-    def backward_llm(self, st: StepState):
+    def backward_llm(self, st: StepState, span=None):
         """lm_head dgrad, final norm, 28 decoder layers (dgrad only: the LLM is frozen).  Leaves d(loss)/d(inputs_embeds)
-        in the fp32 workspace buffer ``dx``."""
+        in the fp32 workspace buffer ``dx``.  ``span`` = (hi, lo): only layers hi - 1 .. lo (the loss head with the span that
+        starts at the last layer) -- the adapters' gradient exchange cuts the backward into such spans (run_backward)."""
         ops, geo, llm = self.ops, self.geo, self.llm
         B, S, M = st.B, st.S, st.M
         D, I, H, G, V = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_vocab
@@ -858,8 +866,11 @@ class TasuModel:
         dqkv = self._buf("dqkv", (M, LDQ), bf)
         dkp = self._buf("dkp", (M, H * HD), f32)
         dvp = self._buf("dvp", (M, H * HD), f32)
+        l_hi, l_lo = span if span is not None else (L, 0)
         # lm_head dgrad (K = Vpad: dlogits pad columns are zero) and final norm
-        if d.get("labelled_only"):
+        if l_hi < L:
+            pass                                               # a later span: the loss head ran with the first one
+        elif d.get("labelled_only"):
             dn_c = self._buf("dn_lab", (st.nLp, D), bf)
             # [nLp, D] outputs in 128 x 192 tiles behind K = Vp: when they cover at most half of the 256 CUs the K range is
             # split so that every CU works (2048 labelled rows x 1536: 128 tiles x 2 ranges)
@@ -891,7 +902,7 @@ class TasuModel:
             ops.rmsnorm_bwd(dn, xs[2 * L], llm.norm, rstd[2 * L], dx, dxb, False)
         lora = self._lora_run
         bb = dict(dx=dx, dxb=dxb, dn=dn, dact=dact, dgu=dgu, dao=dao, delta=delta, dqkv=dqkv, dkp=dkp, dvp=dvp)
-        for l in range(L - 1, -1, -1):
+        for l in range(l_hi - 1, l_lo - 1, -1):
             w = llm.layers[l]
             if lora is not None:
                 lora.layer_bwd(st, l, w, bb, bool(getattr(st, "lora_drop", False)))
@@ -919,7 +930,8 @@ class TasuModel:
         exactly."""
         pr = self.proj
         end = pr.numel if self.lora is None else self.lora.base            # the projector's own tensors end here
-        head = [] if self.lora is None else [(self.lora.base, pr.numel)]   # the adapters: complete when the decoder's backward is
+        # the adapters: one range per span of decoder layers, in the order the backward completes them (last layers first)
+        head = [] if self.lora is None else [(self.lora.layer_range[hi - 1][0], self.lora.layer_range[lo][1]) for hi, lo in self.lora_spans()]
         if pr.is_ca:
             return head + [(0, end)]
         o_w1, o_b1 = pr.offsets[pr.n_w1][0], pr.offsets[pr.n_b1][0]
@@ -940,7 +952,7 @@ class TasuModel:
         bf, f32 = torch.bfloat16, torch.float32
         ranges = self.grad_ranges(w1_chunks)
         if self.lora is not None:
-            ranges = ranges[1:]                        # (the adapters' range belongs to backward_llm: run_backward reports it)
+            ranges = ranges[len(self.lora_spans()):]   # (the adapters' ranges belong to backward_llm: run_backward reports them)
         # merge backward: gradient rows that hold audio -> projector output gradient
         Rap, K, Kp, Hb, Do = st.Rap, pr.K, pr.Kp, pr.Hb, pr.Do
         kKp = pr.kin * Kp                                     # input width of the first Linear
@@ -1072,9 +1084,15 @@ class TasuModel:
         if on_ready is None:
             self._graphed(self._shape_key(st, "bwd"), lambda: self.backward(st), st)
         else:
-            self._graphed(self._shape_key(st, "bwd_llm"), lambda: self.backward_llm(st), st)
-            if self.lora is not None:
-                on_ready(self.lora.base, self.proj.numel)      # every adapter gradient is complete: exchanged under the projector's backward
+            if self.lora is None:
+                self._graphed(self._shape_key(st, "bwd_llm"), lambda: self.backward_llm(st), st)
+            else:
+                # use_peft: the decoder's backward as one graph per span of layers; after each span its adapters' gradients --
+                # a contiguous range of the bucket (the layers are laid out in completion order) -- go on the wire under the
+                # remaining spans (513 MB per step travel in this recipe, against the projector's 218)
+                for hi, lo in self.lora_spans():
+                    self._graphed(self._shape_key(st, ("bwd_llm", hi, lo)), lambda hi=hi, lo=lo: self.backward_llm(st, (hi, lo)), st)
+                    on_ready(self.lora.layer_range[hi - 1][0], self.lora.layer_range[lo][1])
             self.backward_projector(st, on_ready, w1_chunks)
 
     # ------------------------------------------------------------------------------------------ results

@@ -241,7 +241,7 @@ def test_lora_bucket_exchange_on_rccl_is_bit_identical(nccl_group, graphs):
     issue = e1._issue
     e1._issue = lambda g, lo, hi: (seen.append((lo, hi)), issue(g, lo, hi))[1]
     got = run_steps(m1, e1)
-    assert seen[0] == (lp.base, m1.core.proj.numel) and len(seen) == 4 * 7       # adapters first, then the projector's six ranges
+    assert seen[0] == lp.layer_range[1] and seen[1] == lp.layer_range[0] and len(seen) == 4 * 8   # the adapters per span of layers, then the projector's six ranges
     for a, b in zip(want, got):
         assert torch.equal(a, b)
     assert float(m1.core.proj.p[lp.base:].abs().max()) > 0 and float(want[0][-1]) < float(want[0][0])

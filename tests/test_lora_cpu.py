@@ -95,7 +95,7 @@ def test_lora_bucket_layout_and_keys():
     # the gradient ranges still tile the bucket; the adapters' range comes first (the decoder's backward completes it)
     for chunks in (1, 4):
         rs = m.grad_ranges(chunks)
-        assert rs[0] == (lp.base, m.proj.numel)
+        assert rs[0] == lp.layer_range[1] and rs[1] == lp.layer_range[0] and rs[0][0] == lp.base and rs[1][1] == m.proj.numel
         cover = sorted(rs)
         assert cover[0][0] == 0 and cover[-1][1] == m.proj.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
     # peft's initialisation: B = 0 (the adapted model starts as the base model), A uniform within 1 / sqrt(in)
@@ -272,8 +272,8 @@ def _dp_worker(rank, world, port, ret):
     out, _ = eng(**to_call(raw))
     eng.backward(out.loss)
     lp = model.core.lora
-    assert len(eng._pending) == eng.w1_chunks + 3                             # adapters, tail, 4 row blocks of dW1, LayerNorm params
-    assert (eng._pending[0][0], eng._pending[0][1]) == (lp.base, model.core.proj.numel)
+    assert len(eng._pending) == eng.w1_chunks + 4                 # the adapters of layer 1, of layer 0; tail, 4 row blocks of dW1, LayerNorm params
+    assert (eng._pending[0][0], eng._pending[0][1]) == lp.layer_range[1] and (eng._pending[1][0], eng._pending[1][1]) == lp.layer_range[0]
     assert sum(hi - lo for lo, hi, _ in eng._pending) == model.core.proj.numel
     eng.step()
     ret[rank] = dict(grad=g_local, param=model.core.proj.p.clone())
@@ -281,8 +281,8 @@ def _dp_worker(rank, world, port, ret):
 
 
 def test_lora_data_parallel_two_ranks_gloo():
-    """The adapters' gradients travel in the same flat bucket: one more range, exchanged first; replicas stay equal and the update
-    is AdamW on the rank-averaged gradient."""
+    """The adapters' gradients travel in the same flat bucket: one range per span of decoder layers, issued as the backward
+    completes them (before the projector's ranges); replicas stay equal and the update is AdamW on the rank-averaged gradient."""
     world, port = 2, 31000 + os.getpid() % 2000
     mgr = mp.Manager()
     ret = mgr.dict()
