@@ -511,10 +511,14 @@ int tasu_decode_step_prologue(const float* table, const int32_t* ids, float* x, 
  * ps-slm.py:475-480): Q = W_q(posterior) (tasu_gemm_nt_bf16), then per head h of 8 (width d = llm_dim / 8, a multiple of 64):
  * scores = Q_h . E_h^T (tasu_gemm_nt_bf16 over the V2 rows of the LLM's embedding table, K = d), P below, z_h = P . E_h
  * (tasu_gemm_nt_bf16 against the transposed table, K = ld).  The row kernels between the two contractions:
- *   tasu_scale_softmax_rows_bf16   P[r, :V] = bf16(softmax(bf16(S[r, :V] * scale))), P[r, V:ld] = 0   (S, P bf16 [R, ld])
- *   tasu_softmax_bwd_rows_bf16     dS[r, :V] = bf16(bf16(P o (dP - sum_c P o dP)) * scale), dS[r, V:ld] = 0 */
-int tasu_scale_softmax_rows_bf16(const void* s, void* p, int R, int V, int ld, float scale, void* stream);
-int tasu_softmax_bwd_rows_bf16(const void* p, const void* dp, void* ds, int R, int V, int ld, float scale, void* stream);
+ *   tasu_scale_softmax_rows_bf16   P[r, :V] = bf16(softmax(bf16(S[r, :V] / denom))), P[r, V:ld] = 0   (S, P bf16 [R, ld]);
+ *                                  stats (optional, fp32 [R, 2]) receives the row's (max, 1 / sum) for the backward
+ *   tasu_softmax_bwd_rows_bf16     dS[r, :V] = bf16(bf16(P32 o (dP - sum_c P32 o dP)) / denom), dS[r, V:ld] = 0, with P32 the fp32
+ *                                  softmax output recomputed from the saved scores S and stats (what autograd saves; the bf16 P
+ *                                  of the forward is only the einsum's operand)                                              */
+int tasu_scale_softmax_rows_bf16(const void* s, void* p, float* stats, int R, int V, int ld, float denom, void* stream);
+int tasu_softmax_bwd_rows_bf16(const void* s, const float* stats, const void* dp, void* ds, int R, int V, int ld, float denom,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------ RCCL (one process per GPU)
  * Replaces the gradient exchange of the DeepSpeed engine (Multitask/finetune_deepspeed.py:147-149; ZeRO-2 reduce-scatter +

@@ -101,8 +101,8 @@ PROTOTYPES = {
 }
 RESTYPE_I64 = set()
 PROTOTYPES.update({
-    "tasu_scale_softmax_rows_bf16": [vp, vp, i32, i32, i32, f32, vp],
-    "tasu_softmax_bwd_rows_bf16": [vp, vp, vp, i32, i32, i32, f32, vp],
+    "tasu_scale_softmax_rows_bf16": [vp, vp, vp, i32, i32, i32, f32, vp],
+    "tasu_softmax_bwd_rows_bf16": [vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "tasu_gemm_gate_up_swiglu_ws": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, i64, vp],
     "tasu_gemm_qkv_rope": [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "tasu_gemm_dswiglu": [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, i64, vp],

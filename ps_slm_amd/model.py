@@ -677,7 +677,8 @@ class TasuModel:
 
     def _forward_cross_attention(self, st):
         """Q = W_q(posterior rows); per head: P = softmax(Q_h E_h^T / sqrt(d)) over the V2 embedding rows, z_h = P E_h; the
-        projector output is the heads side by side.  P is kept for the backward (8 x [rows, V2] bf16)."""
+        projector output is the heads side by side.  Kept for the backward: the bf16 scores (8 x [rows, V2]) and the rows' softmax
+        statistics, from which the fp32 probabilities autograd would have saved are recomputed."""
         ops, pr, geo, d = self.ops, self.proj, self.geo, st.dev
         bf = torch.bfloat16
         Fap, Rap, Kp, D = st.Fap, st.Rap, pr.Kp, pr.Do
@@ -686,39 +687,42 @@ class TasuModel:
         if D % H or dh % 64:
             raise NotImplementedError(f"cross-attention projector: head width llm_dim / {H} = {D / H:g} must be a multiple of 64 "
                                       "(the K dimension of the score GEMMs)")
-        scale = dh ** -0.5
+        denom = float(dh) ** 0.5                               # `/ (d ** 0.5)` of projector.py:120
         xn = self._buf("xn", (Fap, Kp), bf)
         ops.cast_bf16(d["post"], xn)                           # autocast: the Linear rounds its input to bf16
         q = self._buf("ca_q", (Rap, D), bf)
         ops.gemm(xn, pr.view(pr.pb, "W_q.weight"), q, Rap, D, Kp)
         E, ET = self._ca_tables()
-        sc = self._buf("ca_s", (Rap, Vp), bf)
-        P = self._buf("ca_p", (H, Rap, Vp), bf)
+        # kept for the backward: the bf16 SCORES of every head and the rows' softmax statistics -- autograd saves the softmax's
+        # fp32 output, which the backward recomputes from them; the bf16 P is only the second einsum's operand (transient)
+        S = self._buf("ca_s", (H, Rap, Vp), bf)
+        stats = self._buf("ca_stats", (H, Rap, 2), torch.float32)
+        P = self._buf("ca_p", (Rap, Vp), bf)
         y2 = self._buf("y2", (Rap, D), bf)
         for h in range(H):
             hs = slice(h * dh, (h + 1) * dh)
-            ops.gemm(q[:, hs], E[:, hs], sc, Rap, V, dh)       # scores of head h against every embedding row
-            ops.scale_softmax_rows(sc, P[h], Rap, V, scale)
-            ops.gemm(P[h], ET[hs], y2[:, hs], Rap, dh, Vp)
-        d.update(xn=xn, ca_q=q, ca_p=P, y2=y2)
+            ops.gemm(q[:, hs], E[:, hs], S[h], Rap, V, dh)     # scores of head h against every embedding row
+            ops.scale_softmax_rows(S[h], P, Rap, V, denom, stats[h])
+            ops.gemm(P, ET[hs], y2[:, hs], Rap, dh, Vp)
+        d.update(xn=xn, ca_q=q, ca_s=S, ca_stats=stats, y2=y2)
 
     def _backward_cross_attention(self, st, on_ready):
         ops, pr, geo, d = self.ops, self.proj, self.geo, st.dev
         bf, f32 = torch.bfloat16, torch.float32
         Rap, Kp, D = st.Rap, pr.Kp, pr.Do
         V, Vp, H = geo.llm_vocab, rup(geo.llm_vocab, 64), geo.ca_heads
-        dh, scale = D // H, (D // H) ** -0.5
+        dh, denom = D // H, float(D // H) ** 0.5
         audio_rows = d["audio_rows_pad"] if "audio_rows_pad" in d else self._pad_rows(st)
         dy2 = self._buf("dy2", (Rap, D), bf)
         ops.merge_bwd(d["dx"], audio_rows, dy2, Rap, D)
         E, ET = self._ca_tables()
-        dp = self._buf("ca_s", (Rap, Vp), bf)
+        dp = self._buf("ca_p", (Rap, Vp), bf)                  # (the forward's transient P buffer)
         ds = self._buf("ca_ds", (Rap, Vp), bf)
         dq = self._buf("ca_dq", (Rap, D), bf)
         for h in range(H):
             hs = slice(h * dh, (h + 1) * dh)
             ops.gemm(dy2[:, hs], E[:, hs], dp, Rap, V, dh)     # dP = dz_h E_h^T
-            ops.softmax_bwd_rows(d["ca_p"][h], dp, ds, Rap, V, scale)
+            ops.softmax_bwd_rows(d["ca_s"][h], d["ca_stats"][h], dp, ds, Rap, V, denom)
             ops.gemm(ds, ET[hs], dq[:, hs], Rap, dh, Vp)       # dQ_h = dS E_h
         dq_t = self._buf("ca_dq_t", (D, Rap), bf)
         xn_t = self._buf("xn_t", (Kp, Rap), bf)

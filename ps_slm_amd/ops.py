@@ -227,13 +227,15 @@ class HipOps:
         self._chk(self.lib.tasu_rmsnorm_bwd_rows_resid(_p(dy), _p(x), _p(w), _p(rstd), _p(slot), _p(resid), _p(dx), _p(dx_bf16), M, D,
                                                        self._stream()), "tasu_rmsnorm_bwd_rows_resid")
 
-    def scale_softmax_rows(self, s, p, R, V, scale):
-        """p[r, :V] = bf16(softmax(bf16(s[r, :V] * scale))), pad columns zero (cross-attention projector)."""
-        self._chk(self.lib.tasu_scale_softmax_rows_bf16(_p(s), _p(p), R, V, s.stride(0), scale, self._stream()),
+    def scale_softmax_rows(self, s, p, R, V, denom, stats=None):
+        """p[r, :V] = bf16(softmax(bf16(s[r, :V] / denom))), pad columns zero (cross-attention projector); stats [R, 2] fp32
+        receives the row's (max, 1 / sum) for softmax_bwd_rows."""
+        self._chk(self.lib.tasu_scale_softmax_rows_bf16(_p(s), _p(p), _p(stats), R, V, s.stride(0), denom, self._stream()),
                   "tasu_scale_softmax_rows_bf16")
 
-    def softmax_bwd_rows(self, p, dp, ds, R, V, scale):
-        self._chk(self.lib.tasu_softmax_bwd_rows_bf16(_p(p), _p(dp), _p(ds), R, V, p.stride(0), scale, self._stream()),
+    def softmax_bwd_rows(self, s, stats, dp, ds, R, V, denom):
+        """ds = bf16(bf16(P32 * (dp - sum(P32 * dp))) / denom) with P32 = the fp32 softmax recomputed from the saved scores s."""
+        self._chk(self.lib.tasu_softmax_bwd_rows_bf16(_p(s), _p(stats), _p(dp), _p(ds), R, V, s.stride(0), denom, self._stream()),
                   "tasu_softmax_bwd_rows_bf16")
 
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, R, D, eps):

@@ -104,15 +104,22 @@ class FakeOps:
         if dx_bf16 is not None:
             dx_bf16.copy_(_bf(dx))
 
-    def scale_softmax_rows(self, s, p, R, V, scale):
-        z = _bf(s[:R, :V].float() * scale)
+    def scale_softmax_rows(self, s, p, R, V, denom, stats=None):
+        z = _bf(s[:R, :V].float() / denom).float()
+        m = z.max(-1, keepdim=True).values
+        e = torch.exp(z - m)
+        inv = 1.0 / e.sum(-1, keepdim=True)
         p.zero_()
-        p[:R, :V] = _bf(torch.softmax(z, -1))
+        p[:R, :V] = _bf(e * inv)
+        if stats is not None:
+            stats[:R, 0], stats[:R, 1] = m[:, 0], inv[:, 0]
 
-    def softmax_bwd_rows(self, p, dp, ds, R, V, scale):
-        P, dP = p[:R, :V].float(), dp[:R, :V].float()
+    def softmax_bwd_rows(self, s, stats, dp, ds, R, V, denom):
+        z = _bf(s[:R, :V].float() / denom).float()
+        P = torch.exp(z - stats[:R, 0:1]) * stats[:R, 1:2]        # the fp32 softmax output autograd saves
+        dP = dp[:R, :V].float()
         ds.zero_()
-        ds[:R, :V] = _bf(_bf(P * (dP - (P * dP).sum(-1, keepdim=True))) * scale)
+        ds[:R, :V] = _bf(_bf(P * (dP - (P * dP).sum(-1, keepdim=True))).float() / denom)
 
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, R, D, eps):
         xr = x[:R, :D]
