@@ -243,3 +243,34 @@ def test_lora_refresh_one_launch_equals_the_copies(ops, name):
             k0 = lp.slot[t] * lp.rp
             tail[c0:c0 + o, k0:k0 + lp.r] = 0
         assert float(tail.abs().max()) == 0.0, (l, g)
+
+
+def test_integration_md_lora_stub_runs_as_written():
+    """The ctypes stub INTEGRATION.md shows for peft's lora.Linear.forward, executed verbatim (extracted from the document) on
+    the C-ABI: result = base(x) + lora_B(lora_A(x)) * scaling against an fp32 product of the same bf16 operands."""
+    import ctypes
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    base = next(b for b in blocks if "def linear(" in b)
+    lora = next(b for b in blocks if "def lora_linear(" in b)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)                                              # the stub loads "ps_slm_amd/libtasu_hip.so" relative to the repo
+    try:
+        exec(base, ns)
+        exec(lora, ns)
+    finally:
+        os.chdir(cwd)
+    g = torch.Generator().manual_seed(0)
+    M, K, N, r, s = 333, 256, 512, 64, 0.25
+    x = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.1).bfloat16().cuda()
+    a = (torch.randn(r, K, generator=g) * 0.1).bfloat16().cuda()
+    b = (torch.randn(N, r, generator=g) * 0.1).bfloat16().cuda()
+    y = ns["lora_linear"](x, w, a, b, s)
+    torch.cuda.synchronize()
+    ref = x.float() @ w.float().t() + (x.float() @ a.float().t()) @ b.float().t() * s
+    assert float((y.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
