@@ -313,9 +313,7 @@ int tasu_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stre
  * The use_peft=true recipe (Multitask/model/ps-slm.py:114-117; PeftConfig r / lora_alpha / lora_dropout / target_modules at
  * Multitask/aispeech_asr_config.py:41-50).  peft 0.6.0 is not part of the reference tree; its lora.Linear.forward,
  *     result = base(x);  result += lora_B(lora_A(dropout(x))) * scaling,
- * is restated by the host (ps_slm_amd/lora.py) on tasu_gemm_bf16 calls; these entry points are what sits between the GEMMs.
- * tasu_lora_add: y = bf16(y + bf16(t * s)) over n bf16 values (n % 8 == 0); with x_in / x_out (both or neither) also the
- * decoder's residual add x_out = x_in + float(y) (fp32).  s = 1 makes it a plain bf16 accumulate (dgrad sums).
+ * is restated by the host (ps_slm_amd/lora.py) on the GEMM entry points above plus the ones of this section.
  * tasu_scale_bf16: dst = bf16(src * s).
  * Dropout: `rng` is int64[2] in device memory = {seed, step}; element idx of dropout stream `stream_id` is kept iff the
  * upper 32 bits of splitmix64-finalize((seed ^ step * 0x9E3779B97F4A7C15 ^ stream_id << 44) + idx * 0xD1B54A32D192ED03) are
@@ -332,7 +330,6 @@ int tasu_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stre
  * aligned.                                                                                                                  */
 int tasu_gemm_nt_rank(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int out_f32,
                       int transposed, void* stream);
-int tasu_lora_add(void* y, const void* t, float s, const float* x_in, float* x_out, int64_t n, void* stream);
 int tasu_scale_bf16(const void* src, void* dst, float s, int64_t n, void* stream);
 /* tasu_lora_apply: y[M, N] = bf16(y + mask . bf16(s . bf16(u[M, R] W[N, R]^T))) and, with x_in / x_out (fp32, leading dimension
  * ldx), x_out = x_in + float(y): an adapter's rank-R GEMM with the accumulate into the base result fused (one read + one write of

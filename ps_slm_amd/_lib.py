@@ -45,7 +45,6 @@ PROTOTYPES = {
     "tasu_relu_bwd": [vp, vp, vp, i64, vp],
     "tasu_relu_fwd": [vp, vp, i64, vp],
     "tasu_gemm_nt_rank": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
-    "tasu_lora_add": [vp, vp, f32, vp, vp, i64, vp],
     "tasu_scale_bf16": [vp, vp, f32, i64, vp],
     "tasu_lora_apply": [vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, i32, vp, vp, i32, vp],
     "tasu_lora_dropout": [vp, i32, vp, i32, i32, i32, f32, vp, i32, vp],

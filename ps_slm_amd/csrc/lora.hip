@@ -1,8 +1,10 @@
-// Elementwise pieces of the LoRA recipe (use_peft=true: Multitask/model/ps-slm.py:114-117, PeftConfig at
+// Pieces of the LoRA recipe (use_peft=true: Multitask/model/ps-slm.py:114-117, PeftConfig at
 // Multitask/aispeech_asr_config.py:41-50; peft 0.6.0 lora.Linear.forward, absent from the reference tree:
 //     result = base(x);  result += lora_B(lora_A(dropout(x))) * scaling
 // under torch.autocast(bfloat16): base(x), lora_A(.), lora_B(.) are bf16 GEMM results, `* scaling` and `+=` round to bf16).
-// The GEMMs themselves run on the existing NT kernels (gemm.hip); this file holds what sits between them.  All HBM-bound.
+// The rank-sized GEMMs are in gemm_rank.hip, the base GEMMs in gemm*.hip; this file holds the fused low-rank accumulate
+// (tasu_lora_apply), the counter-based dropout, the one-launch refresh of the working copies and two layout helpers.  All
+// HBM-bound.
 #include "common.h"
 #include "../../include/tasu_hip.h"
 
@@ -13,33 +15,6 @@ inline int grid_for(int64_t nvec) {
   if (b > 4096) b = 4096;
   if (b < 1) b = 1;
   return (int)b;
-}
-
-// y = bf16(y + bf16(t * s));  RESID: x_out = x_in + float(y_new)  (the decoder's residual add: fp32 stream + bf16 branch)
-template <bool RESID>
-__global__ __launch_bounds__(256) void lora_add_kernel(bf16* __restrict__ y, const bf16* __restrict__ t, float s,
-                                                       const float* __restrict__ x_in, float* __restrict__ x_out, int64_t nvec) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const bf16x8 a = *(const bf16x8*)(y + i * 8), b = *(const bf16x8*)(t + i * 8);
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float d = (float)(bf16)((float)b[j] * s);
-      o[j] = (bf16)((float)a[j] + d);
-    }
-    *(bf16x8*)(y + i * 8) = o;
-    if constexpr (RESID) {
-      const f32x4 r0 = *(const f32x4*)(x_in + i * 8), r1 = *(const f32x4*)(x_in + i * 8 + 4);
-      f32x4 q0, q1;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        q0[j] = r0[j] + (float)o[j];
-        q1[j] = r1[j] + (float)o[4 + j];
-      }
-      *(f32x4*)(x_out + i * 8) = q0;
-      *(f32x4*)(x_out + i * 8 + 4) = q1;
-    }
-  }
 }
 
 __global__ __launch_bounds__(256) void scale_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, float s, int64_t nvec) {
@@ -253,15 +228,6 @@ inline bool drop_args(float p, uint32_t* thr, float* inv) {
 }
 
 }  // namespace
-
-extern "C" int tasu_lora_add(void* y, const void* t, float s, const float* x_in, float* x_out, int64_t n, void* stream) {
-  if (!y || !t || n <= 0 || n % 8 || ((x_in == nullptr) != (x_out == nullptr))) return TASU_ERR_ARG;
-  if (x_in)
-    TASU_LAUNCH(lora_add_kernel<true>, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (bf16*)y, (const bf16*)t, s, x_in, x_out, n / 8);
-  else
-    TASU_LAUNCH(lora_add_kernel<false>, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (bf16*)y, (const bf16*)t, s, x_in, x_out, n / 8);
-  return TASU_OK;
-}
 
 extern "C" int tasu_scale_bf16(const void* src, void* dst, float s, int64_t n, void* stream) {
   if (!src || !dst || n <= 0 || n % 8) return TASU_ERR_ARG;

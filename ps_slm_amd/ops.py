@@ -319,10 +319,6 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_nt_rank(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), M, N, K, int(f32), int(transposed),
                                              self._stream()), "tasu_gemm_nt_rank")
 
-    def lora_add(self, y, t, s=1.0, x_in=None, x_out=None):
-        """y = bf16(y + bf16(t * s)); with x_in / x_out also x_out = x_in + float(y)."""
-        self._chk(self.lib.tasu_lora_add(_p(y), _p(t), float(s), _p(x_in), _p(x_out), y.numel(), self._stream()), "tasu_lora_add")
-
     def lora_apply(self, y, u, w, M, N, R, s=1.0, p=0.0, rng=None, sid=0, x_in=None, x_out=None):
         """y[M, N] = bf16(y + mask * bf16(s * bf16(u[M, R] @ w[N, R]^T))) [, x_out = x_in + y] in one pass over y (tasu_lora_apply)."""
         self._chk(self.lib.tasu_lora_apply(_p(y), y.stride(0), _p(u), u.stride(0), _p(w), w.stride(0), M, N, R, float(s), float(p), _p(rng),

@@ -305,11 +305,6 @@ class FakeOps:
         else:
             c[:M, :N] = out
 
-    def lora_add(self, y, t, s=1.0, x_in=None, x_out=None):
-        y.copy_(_bf(y.float() + _bf(t.float() * float(s)).float()))
-        if x_in is not None:
-            x_out.copy_(x_in + y.float())
-
     def lora_apply(self, y, u, w, M, N, R, s=1.0, p=0.0, rng=None, sid=0, x_in=None, x_out=None):
         d = _bf(_bf(u[:M, :R].float() @ w[:N, :R].float().t()).float() * float(s)).float()
         if p > 0.0:

@@ -22,18 +22,7 @@ def test_lora_elementwise_kernels_bit_exact(ops):
     M, D = 37, 256
     n = M * D
     y = torch.randn(n, generator=g).bfloat16()
-    t = torch.randn(n, generator=g).bfloat16()
-    xin = torch.randn(n, generator=g)
     for s in (0.25, 2.0, 0.3):
-        yc, xo = y.clone(), torch.empty(n)
-        f.lora_add(yc, t, s, xin, xo)
-        yg, xg = y.cuda(), torch.empty(n, device="cuda")
-        ops.lora_add(yg, t.cuda(), s, xin.cuda(), xg)
-        assert torch.equal(yg.cpu(), yc) and torch.equal(xg.cpu(), xo)
-        yc2, yg2 = y.clone(), y.cuda()
-        f.lora_add(yc2, t, s)
-        ops.lora_add(yg2, t.cuda(), s)
-        assert torch.equal(yg2.cpu(), yc2)
         dc, dg = torch.empty_like(y), torch.empty(n, dtype=torch.bfloat16, device="cuda")
         f.scale_bf16(y, dc, s)
         ops.scale_bf16(y.cuda(), dg, s)
