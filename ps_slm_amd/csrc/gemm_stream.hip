@@ -20,7 +20,7 @@
 //        E_SLAB    fp32 partial tile into slab[blockIdx.y] (K split over workgroups for K too long for registers: the down
 //                  projection, K = 8960 = 5 x 1792; skinny_reduce_norm finishes it together with residual and next norm)
 //     -- the same arithmetic and rounding points as gemm_skinny.hip's kernels + finish kernels.
-// K range per workgroup = 8 waves x KS x 32 (KS = 1, 2, 6, 7: 256, 512, 1536, 1792); anything else stays on gemm_skinny.
+// K range per workgroup = 8 waves x KS x 32 (KS = 1, 2, 5, 6, 7: 256, 512, 1280, 1536, 1792); anything else stays on gemm_skinny.
 //
 // FRAGMENT-ORDER OPERANDS.  A lane's MFMA operand is 8 k-values of ONE matrix row, and the 16 lanes of a lane group hold 16
 // different rows: read straight from a row-major matrix, one wave instruction touches 16 rows x 64 B -- half-used cache lines,
@@ -67,6 +67,7 @@ int launch_ks(Args a, int ksplit, dim3 grid3, hipStream_t st) {
   switch (ks) {
     case 1: TASU_LAUNCH((stream_gemm_kernel<1, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
     case 2: TASU_LAUNCH((stream_gemm_kernel<2, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
+    case 5: TASU_LAUNCH((stream_gemm_kernel<5, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
     case 6: TASU_LAUNCH((stream_gemm_kernel<6, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
     case 7: TASU_LAUNCH((stream_gemm_kernel<7, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
     default: return TASU_ERR_ARG;
@@ -84,8 +85,11 @@ int launch(const Args& a, int ksplit, hipStream_t st) {
   // blockIdx.z (2 x 32 rows) so that twice as many workgroups each load half of the activations.
   const int cus = cu_count();
   const int row_tiles = (a.M + 15) / 16;
-  // (K-range slabs: always -- 7 k-steps x 4 row tiles of activations per wave would not leave registers for the weight ring)
-  const bool split_rows = row_tiles > 2 && (EPI == E_SLAB || a.tiles * ksplit * 2 <= cus + cus / 4);
+  // (K-range slabs of 1792: always -- 7 k-steps x 4 row tiles of activations per wave would not leave registers for the weight
+  //  ring, so the two row halves each stream the weights (the second read comes from the XCD's L2).  Slabs of 1280 (5 k-steps,
+  //  K = 8960 as 7 ranges) keep all 64 rows in one workgroup: every weight byte is read once.)
+  const int kr = a.K / ksplit;
+  const bool split_rows = row_tiles > 2 && ((EPI == E_SLAB && kr > 1280) || (EPI != E_SLAB && a.tiles * ksplit * 2 <= cus + cus / 4));
   const int zs = split_rows ? 2 : 1;
   const int per_split = cus / (ksplit * zs) > 0 ? cus / (ksplit * zs) : 1;
   const dim3 grid(a.tiles < per_split ? a.tiles : per_split, ksplit, zs);
@@ -95,7 +99,7 @@ int launch(const Args& a, int ksplit, hipStream_t st) {
 bool k_supported(int K, int ksplit) {
   if (ksplit < 1 || K % ksplit) return false;
   const int kr = K / ksplit;
-  return kr == 256 || kr == 512 || kr == 1536 || kr == 1792;
+  return kr == 256 || kr == 512 || kr == 1280 || kr == 1536 || kr == 1792;
 }
 
 }  // namespace tasu_stream

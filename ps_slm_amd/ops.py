@@ -41,6 +41,7 @@ class HipOps:
         self.dec_frag = False          # set by begin_decode(): decode activations travel in fragment order
         self.dec_frag_act = False      # ... including the MLP activation that feeds the down projection
         self.dec_down_slabs = True     # down projection as K-range slabs + tasu_stream_finish_norm (False: split-K kernels)
+        self.dec_split_order = (1, 7, 5, 2, 3, 4, 6, 8)   # K ranges tried in this order (K = 8960: 7 x 1280 before 5 x 1792; A/B: swap)
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
         self.dec_prologue = True       # the position's five set-up launches as one (tasu_decode_step_prologue)
 
@@ -123,7 +124,7 @@ class HipOps:
         """K ranges the streaming kernels can take this K in (0 = not served)."""
         if not self.use_stream:
             return 0
-        for ks in (1, 5, 7, 2, 3, 4, 6, 8):
+        for ks in self.dec_split_order:
             if K % ks == 0 and self.lib.tasu_stream_supported(K, ks):
                 return ks
         return 0
