@@ -424,6 +424,15 @@ int tasu_psd_plan(const int32_t* frame_id, const float* frame_blank, const int32
 int tasu_psd_gather(const float* post, int ldp, const int32_t* seg_start, const int32_t* seg_len,
                     const int32_t* new_lens, float* out, int ldo, int B, int T, int bstride, int Tout, int V,
                     void* stream);
+/* PSD straight from the CTC head's bf16 logits (round 4): the fp32 posterior of every frame is never materialised.
+ * tasu_psd_logit_stats: per frame argmax id (-1 past the utterance's length), blank probability and the softmax statistics
+ * frame_stat[bt] = (max, 1 / sum); tasu_psd_gather_softmax: out[b, j, :] = mean over the frames of kept segment j of
+ * softmax(logits[frame]) evaluated from those statistics (rows j >= new_lens[b] and columns [V, ldo) zero).  logits bf16
+ * [B * bstride, ld], ld % 8 == 0, 16-byte aligned; tasu_psd_plan sits between the two as before.                          */
+int tasu_psd_logit_stats(const void* logits, int ld, const int32_t* lens, int32_t* frame_id, float* frame_blank, float* frame_stat,
+                         int B, int T, int bstride, int V, int blank_id, void* stream);
+int tasu_psd_gather_softmax(const void* logits, int ld, const float* frame_stat, const int32_t* seg_start, const int32_t* seg_len,
+                            const int32_t* new_lens, float* out, int ldo, int B, int T, int bstride, int Tout, int V, void* stream);
 
 /* ------------------------------------------------------------------------------------------- decode loop
  * ps-slm.py:660-675 -> HF GenerationMixin beam search (num_beams 4, max_new_tokens 200, greedy-beam) with a KV cache.

@@ -69,6 +69,8 @@ PROTOTYPES = {
     "tasu_psd_frame_stats": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "tasu_psd_plan": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "tasu_psd_gather": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tasu_psd_logit_stats": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "tasu_psd_gather_softmax": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tasu_kv_fill": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tasu_kv_append": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "tasu_gemm_skinny_norm": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, f32, i32, vp, i64, vp],

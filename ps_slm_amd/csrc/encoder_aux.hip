@@ -172,32 +172,155 @@ __global__ __launch_bounds__(256) void psd_frame_stats_kernel(const float* __res
   }
 }
 
-// one thread per utterance: run-length segments of equal non-blank ids (blank frames stay single), blank filter.
-__global__ void psd_plan_kernel(const int32_t* __restrict__ fid, const float* __restrict__ fblank,
-                                const int32_t* __restrict__ lens, int32_t* __restrict__ seg_start, int32_t* __restrict__ seg_len,
-                                int32_t* __restrict__ new_lens, int B, int T, int blank_id, float thr) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// PSD straight from the CTC head's bf16 LOGITS (round 4): the fp32 posterior of every frame ([B x 504, 25055] = 808 MB written by
+// the softmax, read again by the frame statistics) is never materialised -- PSD keeps ~100 of 500 frames of a trained encoder.
+// Per frame: argmax (of the logits = of the posterior; first index on ties), the softmax statistics (max, 1 / sum) and the blank
+// probability; the gather below evaluates the softmax only for the frames PSD keeps.  grid B*T blocks.
+__global__ __launch_bounds__(256) void psd_logit_stats_kernel(const bf16* __restrict__ logits, int ld, const int32_t* __restrict__ lens,
+                                                              int32_t* __restrict__ fid, float* __restrict__ fblank,
+                                                              float* __restrict__ fstat, int T, int bstride, int V, int blank_id) {
+  __shared__ float rv[4];
+  __shared__ int ri[4];
+  __shared__ float red[4];
+  const int bt = blockIdx.x;
+  const int b = bt / T, t = bt - b * T;
+  if (t >= lens[b]) {
+    if (threadIdx.x == 0) {
+      fid[bt] = -1;
+      fblank[bt] = 0.f;
+      fstat[2 * bt] = 0.f, fstat[2 * bt + 1] = 0.f;
+    }
+    return;
+  }
+  const bf16* xr = logits + ((size_t)b * bstride + t) * ld;
+  const int V8 = V & ~7;
+  float best = -__builtin_inff();
+  int arg = 0x7fffffff;
+  for (int c = threadIdx.x * 8; c < V8; c += 2048) {
+    const bf16x8 v = *(const bf16x8*)(xr + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)v[j];
+      if (f > best) best = f, arg = c + j;
+    }
+  }
+  for (int c = V8 + threadIdx.x; c < V; c += 256) {
+    const float f = (float)xr[c];
+    if (f > best) best = f, arg = c;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oa = __shfl_xor(arg, o, 64);
+    if (ob > best || (ob == best && oa < arg)) best = ob, arg = oa;
+  }
+  if ((threadIdx.x & 63) == 0) rv[threadIdx.x >> 6] = best, ri[threadIdx.x >> 6] = arg;
+  __syncthreads();
+  best = rv[0], arg = ri[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (rv[i] > best || (rv[i] == best && ri[i] < arg)) best = rv[i], arg = ri[i];
+  const float m = best;
+  float sum = 0.f;
+  for (int c = threadIdx.x * 8; c < V8; c += 2048) {
+    const bf16x8 v = *(const bf16x8*)(xr + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += expf((float)v[j] - m);
+  }
+  for (int c = V8 + threadIdx.x; c < V; c += 256) sum += expf((float)xr[c] - m);
+  sum = block_sum<4>(sum, red);
+  if (threadIdx.x == 0) {
+    const float inv = 1.f / sum;
+    fid[bt] = arg;
+    fstat[2 * bt] = m, fstat[2 * bt + 1] = inv;
+    fblank[bt] = expf((float)xr[blank_id] - m) * inv;
+  }
+}
+
+// out[b, j, :] = mean over the frames of kept segment j of softmax(logits[frame]) (j < new_lens[b]) else 0.   grid (Tout, B)
+__global__ __launch_bounds__(256) void psd_gather_softmax_kernel(const bf16* __restrict__ logits, int ld, const float* __restrict__ fstat,
+                                                                 const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
+                                                                 const int32_t* __restrict__ new_lens, float* __restrict__ out, int ldo,
+                                                                 int T, int bstride, int Tout, int V) {
+  const int j = blockIdx.x, b = blockIdx.y;
+  float* o = out + ((size_t)b * Tout + j) * ldo;
+  if (j >= new_lens[b]) {
+    for (int c = threadIdx.x * 4; c < ldo; c += 1024) *(f32x4*)(o + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const int s0 = seg_start[(size_t)b * T + j], len = seg_len[(size_t)b * T + j];
+  const bf16* x0 = logits + ((size_t)b * bstride + s0) * ld;
+  const float* st = fstat + 2 * ((size_t)b * T + s0);
+  for (int c = threadIdx.x * 8; c < ldo; c += 2048) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int t = 0; t < len; ++t) {
+      const bf16x8 v = *(const bf16x8*)(x0 + (size_t)t * ld + c);
+      const float m = st[2 * t], inv = st[2 * t + 1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += expf((float)v[e] - m) * inv;
+    }
+    f32x4 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o0[e] = c + e < V ? (len > 1 ? acc[e] / (float)len : acc[e]) : 0.f;
+      o1[e] = c + 4 + e < V ? (len > 1 ? acc[4 + e] / (float)len : acc[4 + e]) : 0.f;
+    }
+    *(f32x4*)(o + c) = o0;
+    *(f32x4*)(o + c + 4) = o1;
+  }
+}
+
+// one 256-thread block per utterance: run-length segments of equal non-blank ids (blank frames stay single), blank filter.
+// A frame STARTS a segment iff it is the first, differs from its predecessor, or is blank (blank_id < 0: every frame); the thread
+// of a start frame walks its run (same summation order as a sequential scan), and the kept segments are numbered by a block-wide
+// prefix count per chunk of 256 frames.  (Was one THREAD per utterance: 213 us of dependent global loads for 500 frames.)
+__global__ __launch_bounds__(256) void psd_plan_kernel(const int32_t* __restrict__ fid, const float* __restrict__ fblank,
+                                                       const int32_t* __restrict__ lens, int32_t* __restrict__ seg_start,
+                                                       int32_t* __restrict__ seg_len, int32_t* __restrict__ new_lens, int B, int T,
+                                                       int blank_id, float thr) {
+  __shared__ int wsum[4];
+  __shared__ int base_s;
+  const int b = blockIdx.x;
   const int L = lens[b];
   const int32_t* id = fid + (size_t)b * T;
   const float* bp = fblank + (size_t)b * T;
-  int n = 0, start = 0;
-  for (int end = 1; end <= L; ++end) {
-    if (end == L || id[end] != id[start] || id[start] == blank_id || blank_id < 0) {
-      // (blank frames: every frame closes its own segment; blank_id < 0: no merging at all = do_psd false)
-      const int len = end - start;
-      float s = 0.f;
-      for (int t = start; t < end; ++t) s += bp[t];
-      const float mean = len == 1 ? s : s / (float)len;
-      if (mean < thr) {
-        seg_start[(size_t)b * T + n] = start;
-        seg_len[(size_t)b * T + n] = len;
-        ++n;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < L; c0 += 256) {
+    const int t = c0 + threadIdx.x;
+    int keep = 0, len = 0;
+    if (t < L) {
+      const int me = id[t];
+      const bool start = t == 0 || blank_id < 0 || me == blank_id || me != id[t - 1];
+      if (start) {
+        int end = t + 1;
+        if (!(blank_id < 0 || me == blank_id))
+          while (end < L && id[end] == me) ++end;
+        len = end - t;
+        float sm = 0.f;
+        for (int u = t; u < end; ++u) sm += bp[u];
+        const float mean = len == 1 ? sm : sm / (float)len;
+        keep = mean < thr ? 1 : 0;
       }
-      start = end;
     }
+    const unsigned long long mask = __ballot(keep);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = __popcll(mask);
+    __syncthreads();
+    int off = base_s;
+    for (int i = 0; i < w; ++i) off += wsum[i];
+    if (keep) {
+      seg_start[(size_t)b * T + off + before] = t;
+      seg_len[(size_t)b * T + off + before] = len;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
   }
-  new_lens[b] = n;
+  if (threadIdx.x == 0) new_lens[b] = base_s;
 }
 
 // out[b, j, :] = mean of post rows seg_start..+len (j < new_lens[b]) else 0.   grid (Tout, B)
@@ -270,7 +393,7 @@ extern "C" int tasu_psd_plan(const int32_t* frame_id, const float* frame_blank, 
                              int32_t* seg_len, int32_t* new_lens, int B, int T, int blank_id, float threshold,
                              void* stream) {
   if (!frame_id || !frame_blank || !lens || !seg_start || !seg_len || !new_lens || B <= 0 || T <= 0) return TASU_ERR_ARG;
-  TASU_LAUNCH(psd_plan_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, frame_id, frame_blank, lens,
+  TASU_LAUNCH(psd_plan_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, frame_id, frame_blank, lens,
                      seg_start, seg_len, new_lens, B, T, blank_id, threshold);
   return TASU_OK;
 }
@@ -281,5 +404,25 @@ extern "C" int tasu_psd_gather(const float* post, int ldp, const int32_t* seg_st
     return TASU_ERR_ARG;
   TASU_LAUNCH(psd_gather_kernel, dim3(Tout, B), dim3(256), 0, (hipStream_t)stream, post, ldp, seg_start, seg_len,
                      new_lens, out, ldo, T, bstride, Tout, V);
+  return TASU_OK;
+}
+
+extern "C" int tasu_psd_logit_stats(const void* logits, int ld, const int32_t* lens, int32_t* frame_id, float* frame_blank,
+                                    float* frame_stat, int B, int T, int bstride, int V, int blank_id, void* stream) {
+  if (!logits || !lens || !frame_id || !frame_blank || !frame_stat || B <= 0 || T <= 0 || bstride < T || V <= 0 || blank_id < 0 ||
+      blank_id >= V || ld < V || ld % 8 || ((uintptr_t)logits & 15))
+    return TASU_ERR_ARG;
+  TASU_LAUNCH(psd_logit_stats_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ld, lens, frame_id,
+              frame_blank, frame_stat, T, bstride, V, blank_id);
+  return TASU_OK;
+}
+extern "C" int tasu_psd_gather_softmax(const void* logits, int ld, const float* frame_stat, const int32_t* seg_start,
+                                       const int32_t* seg_len, const int32_t* new_lens, float* out, int ldo, int B, int T, int bstride,
+                                       int Tout, int V, void* stream) {
+  if (!logits || !frame_stat || !seg_start || !seg_len || !new_lens || !out || B <= 0 || T <= 0 || bstride < T || Tout <= 0 || V <= 0 ||
+      ldo < V || ldo % 8 || ld < ldo || ld % 8 || (((uintptr_t)logits | (uintptr_t)out) & 15))
+    return TASU_ERR_ARG;
+  TASU_LAUNCH(psd_gather_softmax_kernel, dim3(Tout, B), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ld, frame_stat, seg_start,
+              seg_len, new_lens, out, ldo, T, bstride, Tout, V);
   return TASU_OK;
 }

@@ -83,9 +83,11 @@ class EncoderWeights:
 QUERY_ROWS = (0, 1, 2, 2)   # language, event, emotion, textnorm query ids (ps-slm.py:430-442)
 
 
-def encoder_posterior(model, feats, feat_lens):
+def encoder_posterior(model, feats, feat_lens, want_post=True):
     """feats [B, T, F] float (host or device), feat_lens [B].  Returns (post fp32 [B*Te, Kp] device, Te, lens int32
-    device [B]) where row b*Te + 4 + t is frame t of utterance b (first 4 rows = query tokens)."""
+    device [B]) where row b*Te + 4 + t is frame t of utterance b (first 4 rows = query tokens).  ``want_post=False`` (the
+    training / decode step): the CTC head's bf16 LOGITS [B*Te, Kp] are returned instead -- PSD works from them
+    (psd_on_device(logits=True)) and the fp32 posterior of all frames (808 MB per 16 x 504 frames) is never written."""
     ops, geo, enc, dev = model.ops, model.geo, model.encoder, model.device
     if enc is None:
         raise RuntimeError("the audio path needs encoder weights (model_factory(..., with_encoder=True) or encoder_path)")
@@ -109,11 +111,14 @@ def encoder_posterior(model, feats, feat_lens):
     # everything below is a fixed launch sequence for a given (B, T): ~12 launches x 70 blocks, replayed as one hipGraph
     # when the model runs with graphs (the uploads above stay outside the captured region)
     out = {}
-    model.graphed_region(("encoder", B, T), lambda: out.update(post=_encoder_body(model, x0, lens, key_mask, B, T)))
+    model.graphed_region(("encoder", B, T, bool(want_post)),
+                         lambda: out.update(post=_encoder_body(model, x0, lens, key_mask, B, T, want_post)))
+    if not want_post:
+        return model._buf("enc_ctc_logits", (M, Kp), bf), Te, lens
     return model._buf("enc_post", (M, Kp), f32), Te, lens
 
 
-def _encoder_body(model, x0, lens, key_mask, B, T):
+def _encoder_body(model, x0, lens, key_mask, B, T, want_post=True):
     ops, geo, enc = model.ops, model.geo, model.encoder
     Fd = geo.feat_dim
     E, Hh, Ff, V = geo.enc_dim, geo.enc_heads, geo.enc_ffn, geo.ctc_vocab
@@ -167,15 +172,19 @@ def _encoder_body(model, x0, lens, key_mask, B, T):
         ops.layernorm_fwd(cur, enc.tp_norm[0], enc.tp_norm[1], encb, None, None, M, E, 1e-5)     # tp_norm, bf16 for the CTC GEMM
     logits = buf("enc_ctc_logits", (M, Kp), bf)
     ops.gemm(encb, enc.ctc_w, logits, M, V, E, bias=enc.ctc_b)
+    if not want_post:
+        return logits
     post = buf("enc_post", (M, Kp), f32)
     ops.softmax_rows(logits, post, M, V)
     return post
 
 
-def psd_on_device(model, post, B, T, Te, feat_lens_dev, do_psd=True, k=1, feats=None):
+def psd_on_device(model, post, B, T, Te, feat_lens_dev, do_psd=True, k=1, feats=None, logits=False):
     """PSD over frames 4.. of every utterance.  The decisions (run merging, blank filter) come from the posterior; the rows that
     are kept / averaged are the posterior's (``feats`` None) or those of ``feats`` (fp32 [B * Te, width]: the raw-feature
     branch).  ``k``: frames per projector row -- the batch tensor's trailing Lmax % k frames are dropped (projector.py:41-45).
+    ``logits``: ``post`` holds the CTC head's bf16 logits; per-frame argmax / blank probability / softmax statistics come from
+    them and the posterior is evaluated for the kept frames only.
     Returns (rows fp32 [rup(B * Lmax, 64 k), width padded to 64], new_lens host int64 [B] (untruncated), Lmax)."""
     ops, geo = model.ops, model.geo
     V = geo.ctc_vocab
@@ -186,7 +195,11 @@ def psd_on_device(model, post, B, T, Te, feat_lens_dev, do_psd=True, k=1, feats=
     ss = buf("psd_ss", (B * T,), torch.int32)
     sl = buf("psd_sl", (B * T,), torch.int32)
     nl = buf("psd_nl", (B,), torch.int32)
-    ops.psd_frame_stats(body, feat_lens_dev, fid, fbl, B, T, Te, V, geo.blank_id)
+    if logits:
+        fst = buf("psd_fstat", (B * T, 2), torch.float32)
+        ops.psd_logit_stats(body, feat_lens_dev, fid, fbl, fst, B, T, Te, V, geo.blank_id)
+    else:
+        ops.psd_frame_stats(body, feat_lens_dev, fid, fbl, B, T, Te, V, geo.blank_id)
     thr = 0.90 if do_psd else 2.0                    # do_psd=false keeps every frame (ps-slm.py:472-473)
     blank = geo.blank_id if do_psd else -2           # ... and merges nothing
     ops.psd_plan(fid, fbl, feat_lens_dev, ss, sl, nl, B, T, blank, thr)
@@ -201,5 +214,8 @@ def psd_on_device(model, post, B, T, Te, feat_lens_dev, do_psd=True, k=1, feats=
     rows = buf("post", (Fap, Wp), torch.float32)
     if Fap > B * Lmax:
         rows[B * Lmax:].zero_()
-    ops.psd_gather(src, ss, sl, nl, rows, B, T, Te, Lmax, W)
+    if logits and feats is None:
+        ops.psd_gather_softmax(body, fst, ss, sl, nl, rows, B, T, Te, Lmax, V)
+    else:
+        ops.psd_gather(src, ss, sl, nl, rows, B, T, Te, Lmax, W)
     return rows, new_lens, Lmax

@@ -553,12 +553,12 @@ class TasuModel:
         gives every utterance len // k rows (projector.py:41-45, ps-slm.py:482)."""
         from .encoder import encoder_posterior, psd_on_device
         B, T, _ = input_features.shape
-        post, Te, _ = encoder_posterior(self, input_features, input_feature_length)
+        post, Te, _ = encoder_posterior(self, input_features, input_feature_length, want_post=False)   # the CTC head's logits
         fl = np.asarray(input_feature_length.cpu() if isinstance(input_feature_length, torch.Tensor) else input_feature_length)
         fl_dev = self._upload("feat_lens", fl.astype(np.int32))
         kk = self.proj.k
         src = self._ws["enc_outf"][: post.shape[0] * self.geo.enc_dim].view(post.shape[0], self.geo.enc_dim) if self.raw_features else None
-        rows, new_lens, Lmax = psd_on_device(self, post, B, T, Te, fl_dev, do_psd, k=kk, feats=src)
+        rows, new_lens, Lmax = psd_on_device(self, post, B, T, Te, fl_dev, do_psd, k=kk, feats=src, logits=True)
         st = self._finish_prepare(input_ids, attention_mask, labels, np.minimum(new_lens, Lmax) // kk, Lmax // kk)
         st.Fap = rows.shape[0]
         st.Ra, st.Rap = B * Lmax // kk, st.Fap // kk

@@ -400,6 +400,14 @@ class HipOps:
         self._chk(self.lib.tasu_psd_gather(_p(post), post.stride(0), _p(seg_start), _p(seg_len), _p(new_lens), _p(out),
                                            out.stride(0), B, T, bstride, Tout, V, self._stream()), "tasu_psd_gather")
 
+    def psd_logit_stats(self, logits, lens, fid, fblank, fstat, B, T, bstride, V, blank_id):
+        self._chk(self.lib.tasu_psd_logit_stats(_p(logits), logits.stride(0), _p(lens), _p(fid), _p(fblank), _p(fstat), B, T, bstride, V,
+                                                blank_id, self._stream()), "tasu_psd_logit_stats")
+
+    def psd_gather_softmax(self, logits, fstat, seg_start, seg_len, new_lens, out, B, T, bstride, Tout, V):
+        self._chk(self.lib.tasu_psd_gather_softmax(_p(logits), logits.stride(0), _p(fstat), _p(seg_start), _p(seg_len), _p(new_lens),
+                                                   _p(out), out.stride(0), B, T, bstride, Tout, V, self._stream()), "tasu_psd_gather_softmax")
+
     # ------------------------------------------------------------------ decode loop
     def kv_fill(self, qkv, kc, vc, B, S, H, G, nb, ctx):
         self._chk(self.lib.tasu_kv_fill(_p(qkv), _p(kc), _p(vc), B, S, H, G, nb, ctx, self._stream()), "tasu_kv_fill")

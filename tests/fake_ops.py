@@ -490,6 +490,28 @@ class FakeOps:
         fid.view(B, T).copy_(torch.where(live, ids, torch.full_like(ids, -1)))
         fblank.view(B, T).copy_(torch.where(live, p[..., blank_id], torch.zeros(B, T)))
 
+    def psd_logit_stats(self, logits, lens, fid, fblank, fstat, B, T, bstride, V, blank_id):
+        x = self._post3(logits, B, T, bstride)[..., :V].float()
+        m = x.max(-1).values
+        inv = 1.0 / torch.exp(x - m[..., None]).sum(-1)
+        ids = x.argmax(-1).to(torch.int32)
+        live = torch.arange(T)[None] < lens[:, None]
+        fid.view(B, T).copy_(torch.where(live, ids, torch.full_like(ids, -1)))
+        fblank.view(B, T).copy_(torch.where(live, torch.exp(x[..., blank_id] - m) * inv, torch.zeros(B, T)))
+        fstat.view(B, T, 2)[..., 0] = torch.where(live, m, torch.zeros(B, T))
+        fstat.view(B, T, 2)[..., 1] = torch.where(live, inv, torch.zeros(B, T))
+
+    def psd_gather_softmax(self, logits, fstat, seg_start, seg_len, new_lens, out, B, T, bstride, Tout, V):
+        x = self._post3(logits, B, T, bstride)[..., :V].float()
+        st = fstat.view(B, T, 2)
+        o = out[: B * Tout].view(B, Tout, -1)
+        o.zero_()
+        for b in range(B):
+            for j in range(min(int(new_lens[b]), Tout)):
+                s0, ln = int(seg_start.view(B, T)[b, j]), int(seg_len.view(B, T)[b, j])
+                p = torch.exp(x[b, s0:s0 + ln] - st[b, s0:s0 + ln, 0:1]) * st[b, s0:s0 + ln, 1:2]
+                o[b, j, :V] = p[0] if ln == 1 else p.sum(0) / ln
+
     def psd_plan(self, fid, fblank, lens, seg_start, seg_len, new_lens, B, T, blank_id, thr):
         ss, sl = seg_start.view(B, T), seg_len.view(B, T)
         for b in range(B):

@@ -290,7 +290,10 @@ def test_full_geometry_audio_sft_step(full):
         loss, g = st.dev["loss_out"].clone(), m.proj.g.clone()
         assert torch.isfinite(loss).all() and torch.isfinite(g).all() and float(g.norm()) > 0
         T, Te, V = batch["input_features"].shape[1], batch["input_features"].shape[1] + 4, geo.ctc_vocab
-        post = m._buf("enc_post", (16 * Te, (V + 63) // 64 * 64), F32).view(16, Te, -1)    # the posterior prepare_audio left
+        # the CTC head's bf16 logits prepare_audio left (the step never materialises the fp32 posterior): its softmax is the
+        # posterior the reference's psd() would see
+        logits = m._buf("enc_ctc_logits", (16 * Te, (V + 63) // 64 * 64), torch.bfloat16).view(16, Te, -1)
+        post = torch.softmax(logits[:, :, :V].float(), -1)
         got = np.asarray(st.dev["psd_lens"])
         for b in (0, 3, 7, 15):
             body = post[b:b + 1, 4:, :V].cpu()

@@ -462,7 +462,8 @@ def test_encoder_graph_replay_matches_eager():
         gm.run_backward(st)
         torch.cuda.synchronize()
         Te = b["input_features"].shape[1] + 4
-        post = gm._buf("enc_post", (b["input_features"].shape[0] * Te, rup64(geo.ctc_vocab)), torch.float32).clone()
+        # (the step's audio front end works from the CTC head's bf16 logits; the fp32 posterior is not materialised)
+        post = gm._buf("enc_ctc_logits", (b["input_features"].shape[0] * Te, rup64(geo.ctc_vocab)), torch.bfloat16).clone()
         return post, np.array(st.dev["psd_lens"]).copy(), st.dev["loss_out"].clone()
 
     def rup64(v):

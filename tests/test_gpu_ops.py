@@ -762,6 +762,56 @@ def test_psd_kernels_random_batches_vs_reference(hip):
         torch.testing.assert_close(rows.view(B, Tout, ld)[:, :, :V].cpu(), torch.from_numpy(z[f"c{c}_out"]), rtol=1e-5, atol=1e-7)
 
 
+def test_psd_from_logits_equals_the_posterior_path(hip, fake):
+    """Round 4: PSD works from the CTC head's bf16 logits (tasu_psd_logit_stats -> tasu_psd_plan -> tasu_psd_gather_softmax) and the
+    fp32 posterior of all frames is never written.  Against the posterior path (softmax_rows -> psd_frame_stats -> psd_plan ->
+    psd_gather) on peaky random logits with a strong blank: the same frame ids and lengths, blank probabilities and merged rows
+    within fp32 rounding; ragged lengths, a ld wider than V, an all-blank utterance (zero rows); and against the CPU double."""
+    g = torch.Generator().manual_seed(11)
+    B, T, V, ld = 5, 97, 203, 256
+    x = torch.randn(B, T, V, generator=g) * 2.0
+    seg = torch.randint(0, V, (B, 20), generator=g).repeat_interleave(5, dim=1)[:, :T]
+    x.scatter_add_(2, seg[..., None], torch.full((B, T, 1), 9.0))
+    x[:, :, 0] += torch.where(torch.rand(B, T, generator=g) < 0.5, 12.0, 0.0)     # blank frames
+    x[3, :, 0] += 40.0                                                             # an utterance PSD removes completely
+    logits = torch.zeros(B * T, ld, dtype=BF)
+    logits[:, :V] = x.reshape(B * T, V).to(BF)
+    lens = torch.tensor([97, 60, 1, 97, 33], dtype=I32)
+    lg, ln = logits.cuda(), lens.cuda()
+    z32 = lambda *s_: torch.zeros(*s_, device="cuda")
+    zi = lambda *s_: torch.zeros(*s_, dtype=I32, device="cuda")
+    # posterior path
+    post = z32(B * T, ld)
+    hip.softmax_rows(lg, post, B * T, V)
+    fid0, fbl0, ss0, sl0, nl0 = zi(B * T), z32(B * T), zi(B * T), zi(B * T), zi(B)
+    hip.psd_frame_stats(post, ln, fid0, fbl0, B, T, T, V, 0)
+    hip.psd_plan(fid0, fbl0, ln, ss0, sl0, nl0, B, T, 0, 0.9)
+    # logits path
+    fid1, fbl1, fst, ss1, sl1, nl1 = zi(B * T), z32(B * T), z32(B * T, 2), zi(B * T), zi(B * T), zi(B)
+    hip.psd_logit_stats(lg, ln, fid1, fbl1, fst, B, T, T, V, 0)
+    hip.psd_plan(fid1, fbl1, ln, ss1, sl1, nl1, B, T, 0, 0.9)
+    torch.cuda.synchronize()
+    assert torch.equal(fid0, fid1) and float((fbl0 - fbl1).abs().max()) < 1e-6
+    assert torch.equal(nl0, nl1) and int(nl1[3]) == 0 and int(nl1.max()) > 10
+    n = nl1.cpu()
+    for b in range(B):
+        assert torch.equal(ss0.view(B, T)[b, : n[b]], ss1.view(B, T)[b, : n[b]]) and torch.equal(sl0.view(B, T)[b, : n[b]], sl1.view(B, T)[b, : n[b]])
+    Tout = int(n.max())
+    r0, r1 = torch.ones(B * Tout, ld, device="cuda"), torch.ones(B * Tout, ld, device="cuda")
+    hip.psd_gather(post, ss0, sl0, nl0, r0, B, T, T, Tout, V)
+    hip.psd_gather_softmax(lg, fst, ss1, sl1, nl1, r1, B, T, T, Tout, V)
+    torch.cuda.synchronize()
+    assert float((r0 - r1).abs().max()) < 2e-6 and float(r1[:, V:].abs().max()) == 0.0
+    assert float(r1.view(B, Tout, ld)[3].abs().max()) == 0.0 and abs(float(r1.view(B, Tout, ld)[0, 0].sum()) - 1.0) < 1e-4
+    # the CPU double
+    fidc, fblc, fstc, ssc, slc, nlc = torch.zeros(B * T, dtype=I32), torch.zeros(B * T), torch.zeros(B * T, 2), torch.zeros(B * T, dtype=I32), torch.zeros(B * T, dtype=I32), torch.zeros(B, dtype=I32)
+    fake.psd_logit_stats(logits, lens, fidc, fblc, fstc, B, T, T, V, 0)
+    fake.psd_plan(fidc, fblc, lens, ssc, slc, nlc, B, T, 0, 0.9)
+    rc = torch.ones(B * Tout, ld)
+    fake.psd_gather_softmax(logits, fstc, ssc, slc, nlc, rc, B, T, T, Tout, V)
+    assert torch.equal(fidc, fid1.cpu()) and torch.equal(nlc, n) and float((rc - r1.cpu()).abs().max()) < 2e-6
+
+
 # ------------------------------------------------------------------------------------------------ decode loop
 def test_decode_kernels(hip, fake):
     B, S, H, G, nb, ctx = 2, 40, 4, 2, 3, 64
