@@ -463,7 +463,7 @@ def test_encoder_graph_replay_matches_eager():
         torch.cuda.synchronize()
         Te = b["input_features"].shape[1] + 4
         # (the step's audio front end works from the CTC head's bf16 logits; the fp32 posterior is not materialised)
-        post = gm._buf("enc_ctc_logits", (b["input_features"].shape[0] * Te, rup64(geo.ctc_vocab)), torch.bfloat16).clone()
+        post = gm._buf("enc_ctc_logits", (b["input_features"].shape[0] * Te, rup64(geo.ctc_vocab)), torch.bfloat16)[:, : geo.ctc_vocab].clone()
         return post, np.array(st.dev["psd_lens"]).copy(), st.dev["loss_out"].clone()
 
     def rup64(v):
