@@ -10,14 +10,17 @@ here from the published algorithm,
 with ``lora_A`` initialised kaiming-uniform(a = sqrt 5) (= U(-1/sqrt(in), 1/sqrt(in))) and ``lora_B`` zero, and pinned against
 that formula applied by hand to the reference's own HF decoder (oracle/make_golden_lora.py -> tests/golden/mid_text_lora.npz).
 
-MI355X form.  The adapters are NEVER merged into the bf16 base weights (a rank-64 update of relative size 1e-3 does not survive
-a bf16 rounding of W): every adapted Linear runs base GEMM + two low-rank GEMMs on the existing NT kernels, the rounding points
-being the reference's under autocast (u = bf16(xd A^T), v = bf16(u B^T), y = bf16(base + bf16(v * s))).  All A / B tensors live
-behind the projector in the ONE flat fp32 bucket (master, grad, Adam m / v, bf16 working copy), a layer's tensors contiguous and
-the layers in the order the backward completes them (last layer first), so that AdamW and the gradient exchange see one more
-range per layer.  Weight gradients are plain NT GEMMs on transposed operands (dB = (s dy)^T u, dA = du^T xd) written straight
-into the bucket.  Nothing of the forward is recomputed except the adapters' bf16 inputs (norm outputs, SwiGLU product), which the
-frozen recipe never stored.
+MI355X form.  The adapters are NEVER merged into the bf16 base weights for training (a rank-64 update of relative size 1e-3
+does not survive a bf16 rounding of W).  Forward: per adapted group (q|k|v, o, gate|up, down) ONE GEMM whose K is extended by the
+members' ranks, y = [x | us] [W | B]^T with us = bf16(xd (sA)^T) from the rank GEMM (csrc/gemm_rank.hip) -- the frozen recipe's
+fused epilogues stay, base + branch are rounded to bf16 once (the reference rounds base, branch and sum separately: inside
+every bf16 tolerance, identical in fp32).  Backward: du = dy (sB) (rank GEMM), the adapter's input gradient mask . (du A)
+accumulated into the base path's in one pass (tasu_lora_apply, csrc/lora.hip), dB = dy^T us and dA = du^T xd as rank GEMMs on
+transposed operands, fp32, straight into the bucket, on a side stream.  All A / B tensors live behind the projector in the ONE
+flat fp32 bucket (master, grad, Adam m / v, bf16 image), a layer's tensors contiguous and the layers in the order the backward
+completes them (last layer first): AdamW stays one launch, the gradient exchange gets one range per span of layers.  Nothing
+of the forward is recomputed: the operands [x | us] and every member's dropped input are kept per layer.  Decode runs on merged
+weights (merged_llm).  DESIGN.md 4g has the measurements.
 """
 import math
 from dataclasses import dataclass
