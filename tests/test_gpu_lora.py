@@ -263,3 +263,15 @@ def test_integration_md_lora_stub_runs_as_written():
     torch.cuda.synchronize()
     ref = x.float() @ w.float().t() + (x.float() @ a.float().t()) @ b.float().t() * s
     assert float((y.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+def test_lora_rank_above_64_hip_vs_double(ops):
+    """r = 128: rank GEMMs on the tile policy (N > 64), two 64-wide rank blocks in the K-extended operands and in tasu_lora_apply."""
+    from test_lora_cpu import rank_gt64_case
+    geo, cfg, sd, lsd, batch = rank_gt64_case()
+    gm, cm = build(geo, cfg, sd, lsd, ops, "cuda"), build(geo, cfg, sd, lsd, FakeOps(), "cpu")
+    sg, sc = run_text(gm, batch), run_text(cm, batch)
+    torch.cuda.synchronize()
+    assert abs(float(sg.dev["loss_out"][0]) - float(sc.dev["loss_out"][0])) < 2e-3
+    for (k, g1), (_, g2) in zip(sorted(gm.lora_grads().items()), sorted(cm.lora_grads().items())):
+        assert cosine(g1, g2) > 0.9995, k

@@ -372,3 +372,37 @@ def test_lora_on_the_audio_path_and_with_other_projectors():
     m2 = build(geo2, cfg2, sd2, random_lora_state_dict(geo2, cfg2, 4), FakeOps(), "cpu")
     st2 = run_text(m2, batch2)
     assert torch.isfinite(st2.dev["loss_out"]).all() and float(m2.proj.g[m2.lora.base:].abs().max()) > 0
+
+
+def rank_gt64_case():
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    cfg = LoraConfig(r=128, lora_alpha=64, lora_dropout=0.0, target_modules=("q_proj", "k_proj", "o_proj", "down_proj"))
+    sd = random_state_dict(geo, 2026, with_encoder=False)
+    lsd = random_lora_state_dict(geo, cfg, 12, b_scale=0.03)
+    batch = synthetic_text_batch(geo, 2, seed=8, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=12, noise=False, ragged=True)
+    return geo, cfg, sd, lsd, batch
+
+
+def test_lora_rank_above_64_against_torch_autograd():
+    """r = 128 (two 64-wide rank blocks per member; the rank GEMMs fall back to the tile policy above N = 64): the adapters'
+    gradients of the double against torch autograd through the SAME decoder restated with the LoRA formula (oracle, fp32)."""
+    import dataclasses
+    from oracle import tasu_oracle as O
+    geo, cfg, sd, lsd, batch = rank_gt64_case()
+    m = build(geo, cfg, sd, lsd, FakeOps(), "cpu")
+    st = run_text(m, batch)
+    # oracle: fold the adapters into fp32 weights W + s B A and differentiate with respect to A and B
+    W = {k: v.clone() for k, v in sd.items()}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in lsd.items()}
+    from ps_slm_amd.lora import key_of
+    for l in range(geo.llm_layers):
+        for t in cfg.target_modules:
+            parent = "self_attn" if t in ("q_proj", "k_proj", "v_proj", "o_proj") else "mlp"
+            name = f"llm.model.layers.{l}.{parent}.{t}.weight"
+            W[name] = sd[name] + cfg.scaling * leaves[key_of(l, t, "B")] @ leaves[key_of(l, t, "A")]
+    out = O.forward_text(W, batch, dataclasses.asdict(geo), "fp32")
+    grads = torch.autograd.grad(out["loss"], list(leaves.values()))
+    assert abs(float(st.dev["loss_out"][0]) - float(out["loss"])) < 2e-2
+    mine = m.lora_grads()
+    for k, g in zip(leaves, grads):
+        assert cosine(mine[k], g) > 0.99, k
