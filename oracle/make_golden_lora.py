@@ -60,7 +60,10 @@ def main():
             if n != "ffn.0.weight":
                 arrs["grad." + n] = prm.grad.clone()
         for k, prm in lparams.items():
-            arrs["lgrad." + k] = prm.grad.clone().half()          # fp16 storage: compared by cosine / relative norm
+            g_ = prm.grad.clone()
+            if r >= 64:
+                g_ = g_[::2, ::2]                                  # r = 64 fixtures: every 2nd row / column (fixture size)
+            arrs["lgrad." + k] = g_.half()                         # fp16 storage: compared by cosine / relative norm
         save(name, **arrs)
         print(name, "loss", float(out.loss), "acc", float(acc))
 

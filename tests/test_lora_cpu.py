@@ -65,6 +65,8 @@ def check_against_golden(model, st, z, cos_min=0.995):
     n = 0
     for k, g in lg_.items():
         ref = torch.from_numpy(z["lgrad." + k].astype(np.float32))
+        if g.shape != ref.shape:                                  # the r = 64 fixtures keep every 2nd row / column
+            g = g[::2, ::2]
         assert g.shape == ref.shape
         assert cosine(g, ref) > cos_min, k
         assert abs(float(g.norm() / ref.norm()) - 1.0) < 5e-2, k
