@@ -131,6 +131,12 @@ class TasuEngine:
         self.module = module
         self.core = module.core
         self.cfg = ds_config
+        tc = getattr(module, "train_config", None)
+        if tc is not None and not tc.get("freeze_encoder", False) and not getattr(module, "gt_emb", True):
+            # the reference then leaves the SenseVoice encoder's parameters trainable (ps-slm.py:31-40); this engine has no
+            # backward through the encoder -- say so instead of silently training less than was asked for
+            raise NotImplementedError("train_config.freeze_encoder=false with the audio branch: training the SenseVoice encoder is not "
+                                      "built (Multitask/scripts/finetune_deespeed_sensevoice.sh:44 ships freeze_encoder=true)")
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
@@ -216,7 +222,8 @@ class TasuEngine:
             self.core.run_backward(st)
             self._g_acc.add_(self.core.proj.g, alpha=1.0 / (self.ga * self.ga))
             if self.micro_steps % self.ga == 0 and self.exchange:
-                self._issue(self._g_acc, 0, self._g_acc.numel())
+                lo0 = self.core.lora.base if (self.core.freeze_projector and self.core.lora is not None) else 0
+                self._issue(self._g_acc, lo0, self._g_acc.numel())
             return
         if self.exchange:
             g = self.core.proj.g
@@ -234,7 +241,8 @@ class TasuEngine:
         self.global_steps += 1
         lr = self.get_lr()[0]
         g = self._g_acc if self.ga > 1 else pr.g
-        ranges = self._pending if self._pending else [(0, pr.numel, None)]
+        lo0 = self.core.lora.base if (self.core.freeze_projector and self.core.lora is not None) else 0   # frozen projector: adapters only
+        ranges = self._pending if self._pending else [(lo0, pr.numel, None)]
         for lo, hi, work in ranges:
             if work is not None:
                 timed = self.time_exchange and self.comm_stream is not None
@@ -298,6 +306,6 @@ class TasuEngine:
     #      checkpoint_handler.py:169-182, ps-slm.py:163-170)
     def save_checkpoint(self, path):
         if self.rank == 0:
-            torch.save({k: v.cpu() for k, v in {**self.core.projector_state_dict(), **self.core.lora_state_dict()}.items()}, path)
+            torch.save({k: v.cpu() for k, v in self.module.state_dict().items()}, path)          # the trainable tensors
         if self.world > 1:
             dist.barrier(group=self.pg)

@@ -384,6 +384,8 @@ class TasuModel:
         self._dec_graphs, self._dec_seen = collections.OrderedDict(), {}   # decode-step graphs (ps_slm_amd/decode.py): small LRU
         self._done_host = None         # pinned "decode finished" word the beam-update kernel writes
         self.lora = None               # ps_slm_amd.lora.LoraParams once enable_lora() ran (use_peft=true)
+        self.freeze_projector = False  # train_config.freeze_projector (ps-slm.py:50-54): the projector's weight gradients, exchange and
+                                       # optimizer update are skipped; only the adapters train (the plugin refuses it without use_peft)
         self.raw_features = geo.proj_in not in (0, geo.ctc_vocab)   # ctc_posterior=false: the projector reads encoder states
         self._lora_run = None
 
@@ -845,7 +847,8 @@ class TasuModel:
     def backward(self, st: StepState, on_ready=None, w1_chunks=1):
         """dgrad-only through the frozen decoder, then wgrad of the projector into the flat grad buffer."""
         self.backward_llm(st)
-        self.backward_projector(st, on_ready, w1_chunks)
+        if not self.freeze_projector:
+            self.backward_projector(st, on_ready, w1_chunks)
 
     def backward_llm(self, st: StepState, span=None):
         """lm_head dgrad, final norm, 28 decoder layers (dgrad only: the LLM is frozen).  Leaves d(loss)/d(inputs_embeds)
@@ -936,6 +939,8 @@ class TasuModel:
         end = pr.numel if self.lora is None else self.lora.base            # the projector's own tensors end here
         # the adapters: one range per span of decoder layers, in the order the backward completes them (last layers first)
         head = [] if self.lora is None else [(self.lora.layer_range[hi - 1][0], self.lora.layer_range[lo][1]) for hi, lo in self.lora_spans()]
+        if self.freeze_projector:
+            return head                                                    # the projector's part of the bucket is not touched
         if pr.is_ca:
             return head + [(0, end)]
         o_w1, o_b1 = pr.offsets[pr.n_w1][0], pr.offsets[pr.n_b1][0]
@@ -1083,7 +1088,7 @@ class TasuModel:
         """Backward of the last forward, graph-replayed when enabled.  With a gradient-exchange hook (``on_ready``, N > 1) only
         the decoder part is replayed as a graph; the projector tail (~20 launches) is launched eagerly so that the hook can
         chain its collectives between the wgrad kernels."""
-        if "audio_rows_pad" not in st.dev:
+        if "audio_rows_pad" not in st.dev and not self.freeze_projector:
             self._pad_rows(st)                       # H2D upload stays outside the captured region
         if on_ready is None:
             self._graphed(self._shape_key(st, "bwd"), lambda: self.backward(st), st)
@@ -1097,7 +1102,8 @@ class TasuModel:
                 for hi, lo in self.lora_spans():
                     self._graphed(self._shape_key(st, ("bwd_llm", hi, lo)), lambda hi=hi, lo=lo: self.backward_llm(st, (hi, lo)), st)
                     on_ready(self.lora.layer_range[hi - 1][0], self.lora.layer_range[lo][1])
-            self.backward_projector(st, on_ready, w1_chunks)
+            if not self.freeze_projector:
+                self.backward_projector(st, on_ready, w1_chunks)
 
     # ------------------------------------------------------------------------------------------ results
     def logits_view(self, st):

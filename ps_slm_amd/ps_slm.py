@@ -241,6 +241,13 @@ def model_factory(train_config, model_config, **kwargs):
         enc_pt = os.path.join(str(model_config.get("encoder_path", "")), "model.pt")
         if need_encoder:
             core.load_encoder_checkpoint(enc_pt)
+    # train_config.freeze_projector (the shipped script carries the knob, finetune_deespeed_sensevoice.sh:46,80): the reference
+    # honours it for the linear-silu projector only (ps-slm.py:47-54) and then trains whatever else requires a gradient
+    frozen_proj = bool(train_config.get("freeze_projector", False)) and projector == "linear-silu"
+    if frozen_proj and not train_config.get("use_peft", False):
+        raise ValueError("freeze_projector=true with use_peft=false leaves nothing to train (freeze_llm and freeze_encoder are fixed "
+                         "here): the reference's optimizer would receive an empty parameter list")
+    core.freeze_projector = frozen_proj
     if train_config.get("use_peft", False):
         from ps_slm_amd.lora import LoraConfig
         core.enable_lora(LoraConfig.from_peft_config(train_config.get("peft_config", {}) or {}), seed=int(train_config.get("seed", 42)) + 7)
@@ -336,7 +343,7 @@ class slam_model_asr:
                 v = v[: r[0]]
             elif v.dim() == 2 and len(r) == 2 and not (n == pr.n_w1 and pr.kin > 1):
                 v = v[:, : r[1]]
-            yield "encoder_projector." + n, v.requires_grad_(True)
+            yield "encoder_projector." + n, v.requires_grad_(not self.core.freeze_projector)
         if self.core.lora is not None:                 # use_peft=true: lora_A / lora_B of every adapted Linear, peft's key names
             for key, k in self.core.lora.names():
                 yield key, self.core.lora.view(flat, *k).requires_grad_(True)
@@ -347,7 +354,8 @@ class slam_model_asr:
     def state_dict(self):
         """The trainable tensors (what the reference's checkpoint keeps: checkpoint_handler.py:169-182 saves with
         exclude_frozen_parameters): the projector and, with use_peft, the adapters."""
-        return {**self.core.projector_state_dict(), **self.core.lora_state_dict()}
+        proj = {} if self.core.freeze_projector else self.core.projector_state_dict()
+        return {**proj, **self.core.lora_state_dict()}
 
     def load_state_dict(self, sd, strict=False):
         missing = []

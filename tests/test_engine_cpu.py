@@ -346,3 +346,17 @@ def test_train_loop_and_checkpoint_roundtrip(tmp_path):
     m2, _ = model_factory(tc, mc, device="cpu", ops=FakeOps(), init_seed=999, ckpt_path=path)
     for k, v in m2.state_dict().items():
         torch.testing.assert_close(v, sd[k])
+
+
+def test_engine_refuses_to_train_less_than_asked():
+    """freeze_encoder=false on the audio branch would, in the reference, leave the SenseVoice encoder trainable
+    (ps-slm.py:31-40); this engine has no encoder backward and says so instead of silently training the projector only.  On the
+    text-only branch (gt_emb=true) the encoder is not on the path and the flag is irrelevant."""
+    mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=False, gt_emb=False, ctc_posterior=True, do_psd=True)
+    model, _ = model_factory(tc, mc, device="cpu", ops=FakeOps(), init_seed=1)
+    with pytest.raises(NotImplementedError, match="freeze_encoder"):
+        TasuEngine(model, load_ds_config(DEFAULT_DS_CONFIG))
+    tc2 = TrainConfig(freeze_llm=True, freeze_encoder=False, gt_emb=True, ctc_posterior=True, do_psd=True)
+    model2, _ = model_factory(tc2, mc, device="cpu", ops=FakeOps(), init_seed=1)
+    TasuEngine(model2, load_ds_config(DEFAULT_DS_CONFIG))

@@ -408,3 +408,46 @@ def test_lora_rank_above_64_against_torch_autograd():
     mine = m.lora_grads()
     for k, g in zip(leaves, grads):
         assert cosine(mine[k], g) > 0.99, k
+
+
+def test_freeze_projector_trains_the_adapters_only(tmp_path):
+    """train_config.freeze_projector=true (the shipped script's knob, honoured for linear-silu like ps-slm.py:47-54) next to
+    use_peft: the projector's tensors carry requires_grad=False, get no weight gradient, no exchange range and no optimizer
+    update, and the checkpoint holds the adapters only (what exclude_frozen_parameters keeps); a stage-1 projector checkpoint
+    still loads.  Without use_peft nothing would be left to train: ValueError."""
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True, use_peft=True,
+                     freeze_projector=True)
+    tc.peft_config.r, tc.peft_config.lora_dropout = 16, 0.0
+    mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+    model, _ = model_factory(tc, mc, device="cpu", ops=FakeOps(), init_seed=1234)
+    core, lp = model.core, model.core.lora
+    cfg = load_ds_config(DEFAULT_DS_CONFIG)
+    cfg["lr"] = 1e-3
+    eng = TasuEngine(model, cfg)
+    eng.sched_iter = 10
+    named = dict(model.named_parameters())
+    assert all(p.requires_grad == ("lora_" in k) for k, p in named.items())
+    assert sorted(model.state_dict()) == sorted(k for k in named if "lora_" in k)
+    assert [r[0] for r in core.grad_ranges(4)][0] == lp.base and sum(hi - lo for lo, hi in core.grad_ranges(4)) == lp.numel
+    raw = synthetic_text_batch(core.geo, 2, seed=5, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8, noise=False)
+    p0 = core.proj.p.clone()
+    for _ in range(3):
+        out, _ = eng(**to_call(raw))
+        eng.backward(out.loss)
+        eng.step()
+    assert torch.equal(core.proj.p[: lp.base], p0[: lp.base]) and not torch.equal(core.proj.p[lp.base:], p0[lp.base:])
+    assert float(core.proj.g[: lp.base].abs().max()) == 0.0                      # no projector weight gradient was ever computed
+    path = str(tmp_path / "adapters.bin")
+    eng.save_checkpoint(path)
+    assert all("lora_" in k for k in torch.load(path))
+    # a stage-1 projector checkpoint loads into the frozen projector (strict=False, like ps-slm.py:163-170)
+    stage1 = {"encoder_projector." + n: core.proj.export(n) + 0.5 for n in core.proj.names}
+    missing, unexpected = model.load_state_dict(stage1)
+    assert not unexpected and all("lora_" in k for k in missing)
+    assert torch.equal(core.proj.export("ffn.2.bias"), stage1["encoder_projector.ffn.2.bias"])
+    with pytest.raises(ValueError, match="nothing to train"):
+        model_factory(TrainConfig(freeze_llm=True, gt_emb=True, ctc_posterior=True, freeze_projector=True), mc, device="cpu", ops=FakeOps())
+    # the flag is the reference's for linear-silu only: another projector ignores it
+    m2, _ = model_factory(TrainConfig(freeze_llm=True, gt_emb=True, ctc_posterior=True, freeze_projector=True),
+                          ModelConfig(llm_path="synthetic:mid", encoder_projector="linear", encoder_projector_ds_rate=1, llm_dim=256), device="cpu", ops=FakeOps())
+    assert m2.core.freeze_projector is False
