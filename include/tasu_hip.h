@@ -412,6 +412,10 @@ int tasu_sinusoid_pe(const float* x, float* y, int B, int T, int D, float scale,
  * out fp32 [B*T, D] (added to the attention output by the caller through `accumulate`).                  */
 int tasu_fsmn_fwd(const void* v, int ldv, const float* w, const int32_t* lens, float* out, int B, int T, int D,
                   int ksize, int accumulate, void* stream);
+/* x += fsmn(v) followed by xn = LayerNorm(x) (bf16, pad columns [D, ldy) zero) in one launch where a wave owns whole rows
+ * (D = 512, kernel 11: SenseVoiceSmall); bit-identical to tasu_fsmn_fwd(accumulate = 1) + tasu_layernorm_fwd, which other sizes run. */
+int tasu_fsmn_ln_fwd(const void* v, int ldv, const float* w, const int32_t* lens, float* x, const float* gamma, const float* beta,
+                     void* xn, int ldy, int B, int T, int D, int ksize, float eps, void* stream);
 /* row softmax over V columns, fp32 or bf16 in / fp32 out, pad columns [V, ldy) zeroed (ps-slm.py:451).   */
 int tasu_softmax_rows(const void* x, int x_is_bf16, int ldx, float* y, int ldy, int R, int V, void* stream);
 /* PSD (ps-slm.py:237-317) on device, three launches: per-frame argmax + blank prob; per-utterance segment

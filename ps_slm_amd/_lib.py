@@ -65,6 +65,7 @@ PROTOTYPES = {
     "tasu_adamw": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
     "tasu_sinusoid_pe": [vp, vp, i32, i32, i32, f32, vp],
     "tasu_fsmn_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "tasu_fsmn_ln_fwd": [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp],
     "tasu_softmax_rows": [vp, i32, i32, vp, i32, i32, i32, vp],
     "tasu_psd_frame_stats": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "tasu_psd_plan": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],

@@ -105,6 +105,96 @@ __global__ __launch_bounds__(256) void fsmn_rows_kernel(const bf16* __restrict__
   }
 }
 
+// FSMN memory block + the LayerNorm that follows it (SANM layer: x += fsmn(v); xn = norm2(x)) for D = 512, one wave per 4 frames of
+// one utterance: the wave owns whole rows, so the norm's statistics are wave reductions over values still in registers and the
+// separate LayerNorm launch (one more read of the 16.5-MB fp32 stream per layer) disappears.  A lane owns channels lane*4..+3 and
+// 256+lane*4..+3 -- the element-to-lane map of layernorm_fwd_wave_kernel (norm.hip) -- and the sums run in that kernel's order:
+// bit-identical to tasu_fsmn_fwd followed by tasu_layernorm_fwd.
+template <int KS>
+__global__ __launch_bounds__(256) void fsmn_ln_rows_kernel(const bf16* __restrict__ v, int ldv, const float* __restrict__ w,
+                                                           const int32_t* __restrict__ lens, float* __restrict__ out,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           bf16* __restrict__ y, int ldy, int T, float eps) {
+  constexpr int D = 512, FR = 4, LEFT = (KS - 1) / 2, NR = KS + FR - 1;
+  const int b = blockIdx.y, len = lens[b];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = blockIdx.x * (4 * FR) + wave * FR;
+  if (t0 >= T) return;
+  f32x4 res[FR][2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int c = lane * 4 + g * 256;
+    float wt[4][KS];
+    {
+      const float* wp = w + (size_t)c * KS;
+      float flat[4 * KS];
+#pragma unroll
+      for (int i = 0; i < 4 * KS / 4; ++i) *(f32x4*)(flat + 4 * i) = *(const f32x4*)(wp + 4 * i);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < KS; ++j) wt[q][j] = flat[q * KS + j];
+    }
+    const bf16* base = v + ((size_t)b * T) * ldv + c;
+    bf16x4 x[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int tt = t0 - LEFT + i;
+      x[i] = (tt >= 0 && tt < len) ? *(const bf16x4*)(base + (size_t)tt * ldv) : bf16x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+      const int t = t0 + f;
+      float r[4] = {0.f, 0.f, 0.f, 0.f};
+      if (t < T && t < len) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          const int tt = t + j - LEFT;
+          if (tt < 0 || tt >= len) continue;                     // (the same terms, in the same order, as fsmn_rows_kernel)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) r[q] += wt[q][j] * (float)x[f + j][q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] += (float)x[f + LEFT][q];
+      }
+      f32x4 o = f32x4{r[0], r[1], r[2], r[3]};
+      if (t < T) {
+        float* op = out + ((size_t)b * T + t) * D + c;
+        o += *(const f32x4*)op;                                  // x += fsmn(v)  (accumulate form only)
+        *(f32x4*)op = o;
+      }
+      res[f][g] = o;
+    }
+  }
+  const f32x4 ga0 = *(const f32x4*)(gamma + lane * 4), ga1 = *(const f32x4*)(gamma + 256 + lane * 4);
+  const f32x4 be0 = *(const f32x4*)(beta + lane * 4), be1 = *(const f32x4*)(beta + 256 + lane * 4);
+#pragma unroll
+  for (int f = 0; f < FR; ++f) {
+    const int t = t0 + f;
+    if (t >= T) break;                                            // (wave-uniform)
+    float sm = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) sm += res[f][g][0] + res[f][g][1] + res[f][g][2] + res[f][g][3];
+    const float mu = wave_sum(sm) / (float)D;
+    float q2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q2 += (res[f][g][j] - mu) * (res[f][g][j] - mu);
+    const float rs = rsqrtf(wave_sum(q2) / (float)D + eps);
+    bf16* yr = y + ((size_t)b * T + t) * ldy;
+    f32x4 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o0[j] = (res[f][0][j] - mu) * rs * ga0[j] + be0[j];
+      o1[j] = (res[f][1][j] - mu) * rs * ga1[j] + be1[j];
+    }
+    *(bf16x4*)(yr + lane * 4) = __builtin_convertvector(o0, bf16x4);
+    *(bf16x4*)(yr + 256 + lane * 4) = __builtin_convertvector(o1, bf16x4);
+    for (int c = D + lane; c < ldy; c += 64) yr[c] = (bf16)0.f;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                            int V) {
@@ -425,4 +515,21 @@ extern "C" int tasu_psd_gather_softmax(const void* logits, int ld, const float* 
   TASU_LAUNCH(psd_gather_softmax_kernel, dim3(Tout, B), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ld, frame_stat, seg_start,
               seg_len, new_lens, out, ldo, T, bstride, Tout, V);
   return TASU_OK;
+}
+
+extern "C" int tasu_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int y_is_f32,
+                                  float* mean, float* rstd, int R, int D, float eps, void* stream);
+// x += fsmn(v) and xn = LayerNorm(x) (bf16) -- one launch for the SANM layer's D = 512 / kernel 11; other sizes: the two kernels
+extern "C" int tasu_fsmn_ln_fwd(const void* v, int ldv, const float* w, const int32_t* lens, float* x, const float* gamma,
+                                const float* beta, void* xn, int ldy, int B, int T, int D, int ksize, float eps, void* stream) {
+  if (!v || !w || !lens || !x || !gamma || !beta || !xn || B <= 0 || T <= 0 || D <= 0 || ksize <= 0 || ldy < D) return TASU_ERR_ARG;
+  const bool fused = D == 512 && ksize == 11 && ldv % 4 == 0 && ldy % 4 == 0 &&
+                     !(((uintptr_t)v | (uintptr_t)xn) & 7) && !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)gamma | (uintptr_t)beta) & 15);
+  if (fused) {
+    TASU_LAUNCH(fsmn_ln_rows_kernel<11>, dim3((T + 15) / 16, B), dim3(256), 0, (hipStream_t)stream, (const bf16*)v, ldv, w, lens, x, gamma,
+                beta, (bf16*)xn, ldy, T, eps);
+    return TASU_OK;
+  }
+  const int rc = tasu_fsmn_fwd(v, ldv, w, lens, x, B, T, D, ksize, 1, stream);
+  return rc ? rc : tasu_layernorm_fwd(x, D, gamma, beta, xn, ldy, 0, nullptr, nullptr, B * T, D, eps, stream);
 }

@@ -151,9 +151,8 @@ def _encoder_body(model, x0, lens, key_mask, B, T, want_post=True):
         mid = xa if cur is not xa else xb
         resid = cur if w["in_dim"] == E else zero_res                           # no residual on layer 0 (:372-389)
         ops.gemm(ao, w["wout"], mid, M, E, E, bias=w["bout"], resid=resid, mode=GEMM_RESID)
-        ops.fsmn_fwd(qkv[:, 2 * E:], 3 * E, w["fsmn"], lens, mid, B, Te, E, geo.enc_kernel, True)
         xn2 = buf("enc_xn2", (M, E), bf)
-        ops.layernorm_fwd(mid, w["n2"][0], w["n2"][1], xn2, None, None, M, E, 1e-5)
+        ops.fsmn_ln_fwd(qkv[:, 2 * E:], 3 * E, w["fsmn"], lens, mid, w["n2"][0], w["n2"][1], xn2, B, Te, E, geo.enc_kernel, 1e-5)   # x += fsmn(v); norm2
         ops.gemm_bias_relu(xn2, w["w1"], h, M, Ff, E, w["b1"])                  # w_1 + ReLU: the ReLU in the GEMM's epilogue
         out = xb if mid is xa else xa
         ops.gemm(h, w["w2"], out, M, E, Ff, bias=w["b2"], resid=mid, mode=GEMM_RESID)

@@ -384,6 +384,11 @@ class HipOps:
         self._chk(self.lib.tasu_fsmn_fwd(_p(v), ldv, _p(w), _p(lens), _p(out), B, T, D, ksize, int(accumulate),
                                          self._stream()), "tasu_fsmn_fwd")
 
+    def fsmn_ln_fwd(self, v, ldv, w, lens, x, gamma, beta, xn, B, T, D, ksize, eps):
+        """x += fsmn(v); xn = LayerNorm(x) (bf16) -- one launch for D = 512 / kernel 11 (tasu_fsmn_ln_fwd)."""
+        self._chk(self.lib.tasu_fsmn_ln_fwd(_p(v), ldv, _p(w), _p(lens), _p(x), _p(gamma), _p(beta), _p(xn), xn.stride(0), B, T, D, ksize,
+                                            eps, self._stream()), "tasu_fsmn_ln_fwd")
+
     def softmax_rows(self, x, y, R, V):
         self._chk(self.lib.tasu_softmax_rows(_p(x), int(x.dtype == torch.bfloat16), x.stride(0), _p(y), y.stride(0), R, V,
                                              self._stream()), "tasu_softmax_rows")

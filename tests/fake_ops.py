@@ -461,6 +461,10 @@ class FakeOps:
         pe = torch.cat([st.sin(), st.cos()], 1)
         y.view(B, T, D).copy_(x.view(B, T, D) * scale + pe[None])
 
+    def fsmn_ln_fwd(self, v, ldv, w, lens, x, gamma, beta, xn, B, T, D, ksize, eps):
+        self.fsmn_fwd(v, ldv, w, lens, x, B, T, D, ksize, True)
+        self.layernorm_fwd(x, gamma, beta, xn, None, None, B * T, D, eps)
+
     def fsmn_fwd(self, v, ldv, w, lens, out, B, T, D, ksize, accumulate):
         vv = v.reshape(B, T, -1)[..., :D].float()
         mask = (torch.arange(T)[None] < lens[:, None]).float()[..., None]

@@ -710,6 +710,39 @@ def test_encoder_fsmn_and_ffn_relu_at_sensevoice_size(hip, fake):
         assert torch.equal(out, ref) and float(out.float().min()) == 0.0 and float((out == 0).float().mean()) > 0.2
 
 
+def test_fsmn_layernorm_one_launch_is_bit_identical(hip):
+    """tasu_fsmn_ln_fwd (x += fsmn(v); xn = LayerNorm(x) in one launch: a wave owns 4 whole 512-channel rows) against
+    tasu_fsmn_fwd + tasu_layernorm_fwd: the same bits in x and xn; ragged lengths, T not a multiple of the 16-frame block, a wider
+    ldy with zero pad columns; and the fallback (another width) through the two kernels."""
+    B, T, E, ks = 4, 501, 512, 11
+    qkv = randn(B * T, 3 * E, dtype=BF, seed=31).cuda()
+    w = randn(E, ks, seed=32, scale=0.2).cuda()
+    lens = torch.tensor([501, 333, 7, 0], dtype=I32).cuda()
+    x0 = randn(B * T, E, seed=33).cuda()
+    ga, be = (1 + 0.1 * randn(E, seed=34)).cuda(), (0.1 * randn(E, seed=35)).cuda()
+    x_a, x_b = x0.clone(), x0.clone()
+    y_a = torch.full((B * T, E + 64), 3.0, dtype=BF, device="cuda")
+    y_b = torch.full((B * T, E + 64), 3.0, dtype=BF, device="cuda")
+    hip.fsmn_fwd(qkv[:, 2 * E:], 3 * E, w, lens, x_a, B, T, E, ks, True)
+    hip.layernorm_fwd(x_a, ga, be, y_a, None, None, B * T, E, 1e-5)
+    hip.fsmn_ln_fwd(qkv[:, 2 * E:], 3 * E, w, lens, x_b, ga, be, y_b, B, T, E, ks, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(x_a, x_b) and torch.equal(y_a, y_b) and float(y_b[:, E:].abs().max()) == 0.0
+    assert not torch.equal(x_b, x0)
+    # a width the fused kernel does not serve: the two kernels behind the same entry point
+    E2 = 256
+    v2 = randn(B * T, E2, dtype=BF, seed=36).cuda()
+    w2, g2, b2 = randn(E2, ks, seed=37, scale=0.2).cuda(), torch.ones(E2).cuda(), torch.zeros(E2).cuda()
+    xa, xb = randn(B * T, E2, seed=38).cuda(), None
+    xb = xa.clone()
+    ya, yb = torch.zeros(B * T, E2, dtype=BF, device="cuda"), torch.zeros(B * T, E2, dtype=BF, device="cuda")
+    hip.fsmn_fwd(v2, E2, w2, lens, xa, B, T, E2, ks, True)
+    hip.layernorm_fwd(xa, g2, b2, ya, None, None, B * T, E2, 1e-5)
+    hip.fsmn_ln_fwd(v2, E2, w2, lens, xb, g2, b2, yb, B, T, E2, ks, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(xa, xb) and torch.equal(ya, yb)
+
+
 def test_psd_kernels(hip, fake):
     from conftest import load_npz
     z = load_npz("psd_crafted")
