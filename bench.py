@@ -490,7 +490,7 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
             rec["collective"] = engine.comm_info()      # ranks = ncclCommCount of the communicator the exchange ran on
             rec["allreduce_exposed_ms"] = round(exposed_ms, 3)
             rec["allreduce_note"] = (f"per step, max over ranks: time the compute stream waited for gradient ranges in step() "
-                                     f"(event pairs around every wait); bucket exchanged in {engine.w1_chunks + 2} ranges.  Expected "
+                                     f"(event pairs around every wait); bucket exchanged in {len(core.grad_ranges(engine.w1_chunks))} ranges.  Expected "
                                      f"on 8 xGMI-connected GPUs: ~0.35 ms (the last 51-MB row block of the Linear1 weight gradient at "
                                      f"the ~300 GB/s bus bandwidth RCCL reaches; the whole 218-MB bucket would be ~1.3 ms), DESIGN.md 6")
         if want_decode:

@@ -24,7 +24,9 @@ def _worker(rank, world, port, ret):
         from fake_ops import FakeOps
         args = SimpleNamespace(drop_prob=0.0, no_graphs=True)
         rec = bench.train_leg(args, "mid", "text", 2, 2, 1, world, rank, 0, False, device="cpu", ops=FakeOps())
+        lrec = bench.train_leg(args, "mid", "text", 2, 2, 1, world, rank, 0, False, device="cpu", ops=FakeOps(), lora=True)   # --lora at N > 1
         ret[rank] = rec
+        ret[10 + rank] = lrec
     finally:
         dist.destroy_process_group()
 
@@ -42,6 +44,11 @@ def test_train_leg_two_ranks_over_gloo():
     assert r0["allreduce_exposed_ms"] >= 0.0 and "Expected on 8 xGMI-connected GPUs" in r0["allreduce_note"]
     assert r0["roofline"]["bound"] == "mfma" and r0["config"]["seq_len"] == 256
     assert 0.0 < r0["config"]["final_loss"] < 20.0
+    # the use_peft recipe through the same bookkeeping: the adapters' ranges ride in the exchange, FLOPs include the rank columns
+    l0 = ret[10]
+    assert ret[11] is None and "LoRA recipe" in l0["config"]["workload"] and l0["config"]["parallelism"] == "dp2"
+    assert l0["allreduce_exposed_ms"] >= 0.0 and 0.0 < l0["config"]["final_loss"] < 20.0
+    assert "bucket exchanged in" in l0["allreduce_note"]
 
 
 def test_launch_check_refuses_a_mismatched_world():
