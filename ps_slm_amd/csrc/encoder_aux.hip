@@ -284,44 +284,55 @@ __global__ __launch_bounds__(256) void psd_logit_stats_kernel(const bf16* __rest
   }
   const bf16* xr = logits + ((size_t)b * bstride + t) * ld;
   const int V8 = V & ~7;
-  float best = -__builtin_inff();
+  // ONE pass over the row (401 MB of logits per 16 x 500 frames; a second pass went to the fabric again, profiles/
+  // r04_new_kernels_pmc.json): per thread a running (max, sum of exp) pair rescaled when the max moves, and the argmax
+  float best = -__builtin_inff(), sum = 0.f;
   int arg = 0x7fffffff;
   for (int c = threadIdx.x * 8; c < V8; c += 2048) {
     const bf16x8 v = *(const bf16x8*)(xr + c);
+    float f[8], cm = -__builtin_inff();
+    int ca = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float f = (float)v[j];
-      if (f > best) best = f, arg = c + j;
+    for (int j2 = 0; j2 < 8; ++j2) {
+      f[j2] = (float)v[j2];
+      if (f[j2] > cm) cm = f[j2], ca = c + j2;
     }
+    if (cm > best) {
+      sum *= expf(best - cm);                          // (best = -inf: sum is 0)
+      best = cm, arg = ca;
+    }
+#pragma unroll
+    for (int j2 = 0; j2 < 8; ++j2) sum += expf(f[j2] - best);
   }
   for (int c = V8 + threadIdx.x; c < V; c += 256) {
     const float f = (float)xr[c];
-    if (f > best) best = f, arg = c;
+    if (f > best) {
+      sum *= expf(best - f);
+      best = f, arg = c;
+    }
+    sum += expf(f - best);
   }
+  // block reduction of (max, argmax [first index on ties], sum at that max)
+  float tmax = best;
+  int targ = arg;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const float ob = __shfl_xor(best, o, 64);
-    const int oa = __shfl_xor(arg, o, 64);
-    if (ob > best || (ob == best && oa < arg)) best = ob, arg = oa;
+    const float ob = __shfl_xor(tmax, o, 64);
+    const int oa = __shfl_xor(targ, o, 64);
+    if (ob > tmax || (ob == tmax && oa < targ)) tmax = ob, targ = oa;
   }
-  if ((threadIdx.x & 63) == 0) rv[threadIdx.x >> 6] = best, ri[threadIdx.x >> 6] = arg;
+  if ((threadIdx.x & 63) == 0) rv[threadIdx.x >> 6] = tmax, ri[threadIdx.x >> 6] = targ;
   __syncthreads();
-  best = rv[0], arg = ri[0];
+  float m = rv[0];
+  int am = ri[0];
 #pragma unroll
   for (int i = 1; i < 4; ++i)
-    if (rv[i] > best || (rv[i] == best && ri[i] < arg)) best = rv[i], arg = ri[i];
-  const float m = best;
-  float sum = 0.f;
-  for (int c = threadIdx.x * 8; c < V8; c += 2048) {
-    const bf16x8 v = *(const bf16x8*)(xr + c);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sum += expf((float)v[j] - m);
-  }
-  for (int c = V8 + threadIdx.x; c < V; c += 256) sum += expf((float)xr[c] - m);
+    if (rv[i] > m || (rv[i] == m && ri[i] < am)) m = rv[i], am = ri[i];
+  sum = best == -__builtin_inff() ? 0.f : sum * expf(best - m);        // this thread's sum at the row's max
   sum = block_sum<4>(sum, red);
   if (threadIdx.x == 0) {
     const float inv = 1.f / sum;
-    fid[bt] = arg;
+    fid[bt] = am;
     fstat[2 * bt] = m, fstat[2 * bt + 1] = inv;
     fblank[bt] = expf((float)xr[blank_id] - m) * inv;
   }
