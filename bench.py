@@ -365,11 +365,15 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         blank_note = f"CTC blank bias raised by {mid_b:.2f}: PSD keeps {kept:.0f} rows per utterance (padded to the batch maximum)"
     seen_shapes = set()
     step_no = [0]
+    ahead = audio and not getattr(args, "no_encoder_ahead", False)
+    ahead_hits = [0]
 
     def step():
         b = batches[step_no[0] % len(batches)]
         step_no[0] += 1
         out, acc = engine(**b)
+        if ahead:                                       # the next batch's frozen encoder pass under this batch's decoder step
+            ahead_hits[0] += bool(engine.prefetch(**batches[step_no[0] % len(batches)]))
         seen_shapes.add((engine._last_state.S, engine._last_state.Ra))
         engine.backward(out.loss)
         engine.step()
@@ -450,6 +454,9 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                      f"utterances / wall time over all shapes; S, FLOPs and roofline describe the LAST step's shape only")
         if blank_note:
             what += "; " + blank_note
+        if audio and ahead_hits[0]:
+            what += ("; the frozen encoder runs ONE BATCH AHEAD on a side stream (every step = the encoder pass of batch i + 1 under "
+                     "the PSD / projector / LLM step of batch i; same kernels, same results: TasuModel.prefetch_encoder)")
         if core.lora is not None:
             c = core.lora.cfg
             what += (f"; LoRA recipe (use_peft=true): r={c.r}, alpha={c.lora_alpha:g}, dropout {c.lora_dropout:g} on {len(c.target_modules)} "
@@ -529,6 +536,8 @@ def main():
                     help="--path audio: raise the CTC blank bias until PSD keeps ~100 frames per utterance (a trained encoder's regime)")
     ap.add_argument("--blank-bias", type=float, default=None,
                     help="--path audio --blank-biased: use this bias instead of searching for it (profiled runs: no search passes in the trace)")
+    ap.add_argument("--no-encoder-ahead", action="store_true",
+                    help="audio path: run every batch's frozen encoder pass in front of its own step instead of one batch ahead on a side stream")
     ap.add_argument("--lora", action="store_true", help="the use_peft=true recipe (LoRA r=64 on the decoder's 7 Linears) as the measured workload")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-4 (audio-SFT) and config-5 (Qwen2.5-7B) sub-records")
     args = ap.parse_args()

@@ -179,6 +179,12 @@ class TasuEngine:
         self._last_state = self.module.last_state
         return out
 
+    def prefetch(self, **batch) -> bool:
+        """The next batch's frozen encoder pass under this batch's decoder step (slam_model_asr.prefetch); call it between
+        ``engine(**batch)`` and ``engine.backward()`` with the batch the next ``engine(**...)`` call will get."""
+        fn = getattr(self.module, "prefetch", None)
+        return bool(fn(**batch)) if fn is not None else False
+
     def parameters(self):
         return self.module.parameters()
 

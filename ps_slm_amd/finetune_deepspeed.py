@@ -159,12 +159,17 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
         engine.train()
         it = iter(dataset)
         epoch_step = 0                                         # the reference's `step + 1` (per epoch, :190, :248)
+        nxt = next(it, None)
+        nxt_batch = dataset.collator(nxt) if nxt is not None else None
         while True:
-            raw = next(it, None)
+            raw, batch = nxt, nxt_batch
             if not engine.all_have_data(raw is not None):      # replaces deepspeed_join's gloo monitored_barrier
                 break
-            batch = dataset.collator(raw)
+            nxt = next(it, None)                               # one batch of lookahead: its frozen encoder pass runs on a side
+            nxt_batch = dataset.collator(nxt) if nxt is not None else None    # stream under this batch's decoder step
             outputs, acc = engine(**batch)
+            if nxt_batch is not None:
+                engine.prefetch(**nxt_batch)
             loss = outputs.loss
             engine.backward(loss)
             engine.step()

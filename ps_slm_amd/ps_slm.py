@@ -437,6 +437,15 @@ class slam_model_asr:
 
     __call__ = forward
 
+    def prefetch(self, input_features=None, input_feature_length=None, **unused) -> bool:
+        """Optional, audio branch only: start the frozen encoder pass of the NEXT batch now, on a side stream under the current
+        batch's decoder step (TasuModel.prefetch_encoder).  Takes the collator's batch dict like forward(); the forward() of that
+        very batch then skips its own encoder pass.  Results do not change; a batch that was not announced (or the text branch,
+        or the CPU double) runs as before and the call returns False."""
+        if self.gt_emb or input_features is None:
+            return False
+        return self.core.prefetch_encoder(input_features, input_feature_length)
+
     @torch.no_grad()
     def generate(self, input_ids=None, input_features=None, attention_mask=None, input_feature_length=None,
                  targets=None, **kwargs):

@@ -348,6 +348,36 @@ def test_train_loop_and_checkpoint_roundtrip(tmp_path):
         torch.testing.assert_close(v, sd[k])
 
 
+def test_train_loop_announces_the_next_batch():
+    """The loop holds one batch of lookahead and hands it to engine.prefetch() between forward and backward (on the GPU the audio
+    branch then runs that batch's frozen encoder pass on a side stream, TasuModel.prefetch_encoder): every batch but the first is
+    announced exactly once, right before it is consumed; the last step announces nothing.  On the CPU double prefetch() does
+    nothing and returns False."""
+    from ps_slm_amd.config import LogConfig
+    from ps_slm_amd.finetune_deepspeed import SyntheticDataset, train
+    model, tok, eng = make(lr=1e-3)
+    ds = SyntheticDataset(model.core.geo, 2, 4, 0)
+    import ps_slm_amd.synthetic as syn
+    real = syn.synthetic_text_batch
+    syn.synthetic_text_batch = lambda geo, B, seed, noise=False: real(geo, B, seed=seed, prompt_len=9, n_audio=21, target_len=17,
+                                                                       speech_pos=4, feat_frames=8, noise=noise)
+    events = []
+    fwd, pre = eng.module.forward, eng.module.prefetch
+    eng.module.__class__.__call__ = lambda self, **b: (events.append(("fwd", id(b["input_ids"]))), fwd(**b))[1]
+    eng.module.prefetch = lambda **b: (events.append(("pre", id(b["input_ids"]))), pre(**b))[1]
+    try:
+        res = train(eng, ds, TrainConfig(num_epochs=1, batching_strategy="dynamic"), LogConfig(log_interval=10), 0, 1)
+    finally:
+        syn.synthetic_text_batch = real
+        eng.module.__class__.__call__ = eng.module.__class__.forward
+    assert res["steps"] == 4
+    kinds = [k for k, _ in events]
+    assert kinds == ["fwd", "pre", "fwd", "pre", "fwd", "pre", "fwd"]
+    for n in range(1, len(events) - 1, 2):
+        assert events[n][1] == events[n + 1][1]              # the announced batch is the very object the next forward gets
+    assert eng.prefetch(**ds.collator(next(iter(ds)))) is False
+
+
 def test_engine_refuses_to_train_less_than_asked():
     """freeze_encoder=false on the audio branch would, in the reference, leave the SenseVoice encoder trainable
     (ps-slm.py:31-40); this engine has no encoder backward and says so instead of silently training the projector only.  On the

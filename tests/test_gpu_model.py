@@ -477,3 +477,47 @@ def test_encoder_graph_replay_matches_eager():
     for (p0, n0, l0), (p1, n1, l1) in zip(want, got):
         assert torch.equal(p0, p1) and np.array_equal(n0, n1) and torch.equal(l0, l1)
     assert not torch.equal(want[0][0], want[3][0])     # the variants really differ
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_encoder_one_batch_ahead_changes_nothing(graphs):
+    """TasuModel.prefetch_encoder: the frozen encoder pass of batch i + 1 on a side stream under batch i's decoder step.  Same
+    kernels on the same data: logits, PSD lengths, loss and gradients are bit-identical to the in-line order -- for announced
+    batches, for a batch that was NOT the announced one (falls back in line, after the pending pass), and after a decode call."""
+    from conftest import mid_audio_psd_case
+    from ps_slm_amd.ops import HipOps
+    geo, sd, batch, _ = mid_audio_psd_case()
+    g = torch.Generator().manual_seed(11)
+    variants = [dict(batch, input_features=batch["input_features"] + 0.3 * i * torch.randn(batch["input_features"].shape, generator=g))
+                for i in range(5)]
+    order = [0, 1, 2, 3, 4, 1, 3]
+    zd = load_npz("mid_generate_beam4")
+    dec_ids, dec_am = torch.from_numpy(zd["input_ids"]), torch.from_numpy(zd["attention_mask"])
+
+    def run(ahead):
+        gm = TasuModel(geo, HipOps(), "cuda")
+        gm.load_reference_state_dict(sd)
+        gm.use_graphs = graphs
+        outs, hits = [], 0
+        for n, i in enumerate(order):
+            b = variants[i]
+            st = gm.prepare_audio(b["input_ids"], b["attention_mask"], b["labels"], b["input_features"], b["input_feature_length"])
+            gm.run_forward_llm(st)
+            if ahead and n + 1 < len(order):
+                # step 4 announces the WRONG batch (variant 0 instead of 1); step 5 announces the right one but a decode call on
+                # another batch comes in between and takes over the encoder's workspace
+                nb = variants[0] if n == 4 else variants[order[n + 1]]
+                hits += bool(gm.prefetch_encoder(nb["input_features"], nb["input_feature_length"]))
+            gm.run_backward(st)
+            if n == 5:                                 # an inference front end (other batch, B = 2) between two training steps
+                gm.prepare_audio(dec_ids, dec_am, None, variants[2]["input_features"][:2], batch["input_feature_length"][:2])
+            torch.cuda.synchronize()
+            outs.append((np.array(st.dev["psd_lens"]).copy(), st.dev["loss_out"].clone(), gm.proj.g.clone()))
+        return outs, hits
+
+    want, _ = run(False)
+    got, hits = run(True)
+    assert hits >= (3 if graphs else 4)                # the first passes of a shape allocate (and capture) in line
+    for (n0, l0, g0), (n1, l1, g1) in zip(want, got):
+        assert np.array_equal(n0, n1) and torch.equal(l0, l1) and torch.equal(g0, g1)
+    assert not torch.equal(want[0][1], want[1][1])
