@@ -111,8 +111,9 @@ def encoder_posterior(model, feats, feat_lens, want_post=True):
     # everything below is a fixed launch sequence for a given (B, T): ~12 launches x 70 blocks, replayed as one hipGraph
     # when the model runs with graphs (the uploads above stay outside the captured region)
     out = {}
-    model.graphed_region(("encoder", B, T, bool(want_post)),
-                         lambda: out.update(post=_encoder_body(model, x0, lens, key_mask, B, T, want_post)))
+    with ops.alt_workspace("encoder"):     # its own split-K workspace: the pass may run on a side stream (TasuModel.prefetch_encoder)
+        model.graphed_region(("encoder", B, T, bool(want_post)),
+                             lambda: out.update(post=_encoder_body(model, x0, lens, key_mask, B, T, want_post)))
     if not want_post:
         return model._buf("enc_ctc_logits", (M, Kp), bf), Te, lens
     return model._buf("enc_post", (M, Kp), f32), Te, lens

@@ -413,7 +413,7 @@ class LoraRunner:
         fork = torch.cuda.Event()
         fork.record(main)                                           # dy_t, du, us, xd are complete
         self.side.wait_event(fork)
-        with torch.cuda.stream(self.side):
+        with torch.cuda.stream(self.side), ops.alt_workspace("lora"):      # (ranks above 64 run on the tile kernels: own workspace)
             wgrads()
             done = torch.cuda.Event()
             done.record(self.side)

@@ -5,6 +5,7 @@ caller-allocated).  There is no eager/PyTorch fallback: construction fails if th
 The method set is the operator interface of the model code (ps_slm_amd/model.py); tests exercise the same
 model code on CPU by injecting tests/fake_ops.py, a torch-CPU double with identical signatures.
 """
+import contextlib
 import os
 
 import torch
@@ -34,6 +35,7 @@ class HipOps:
         # split-K workspace of tasu_gemm_nt_bf16_ws: zeroed arrival counters + fp32 partial tiles (include/tasu_hip.h).
         # Allocated up front (never inside a hipGraph capture); all GEMMs of one HipOps run on one stream.
         self.gemm_ws = torch.zeros(GEMM_WS_BYTES, dtype=torch.uint8, device="cuda")
+        self._gemm_ws_alt = {}         # further ones for launch sequences that may run on another stream (alt_workspace)
         self.topk_ws = torch.empty(1024 * 16 * 34, dtype=torch.float32, device="cuda")   # tasu_logprob_topk partials, M <= 1024
         # decode-step GEMMs: the single-launch weight-streaming kernels (csrc/gemm_stream.hip) where they serve the shape,
         # the split-K + finish kernels (csrc/gemm_skinny.hip) otherwise.
@@ -46,6 +48,21 @@ class HipOps:
         self.dec_prologue = True       # the position's five set-up launches as one (tasu_decode_step_prologue)
 
     # ------------------------------------------------------------------ plumbing
+    @contextlib.contextmanager
+    def alt_workspace(self, who):
+        """GEMMs issued inside use the split-K / stream-K workspace named ``who`` instead of the common one.  include/tasu_hip.h:
+        launches sharing a workspace must be ordered on one stream -- the frozen encoder's pass may run on a side stream next to the
+        decoder step's GEMMs (TasuModel.prefetch_encoder), and so do the adapters' weight gradients (ps_slm_amd/lora.py; ranks
+        above 64 go through the tile kernels), so their launches (eager or captured) never touch the workspace of the rest.
+        Allocated on first use, which is an eager pass (never inside a capture: the first pass of a shape is eager)."""
+        if who not in self._gemm_ws_alt:
+            self._gemm_ws_alt[who] = torch.zeros(GEMM_WS_BYTES, dtype=torch.uint8, device="cuda")
+        keep, self.gemm_ws = self.gemm_ws, self._gemm_ws_alt[who]
+        try:
+            yield
+        finally:
+            self.gemm_ws = keep
+
     @staticmethod
     def _stream():
         return torch.cuda.current_stream().cuda_stream

@@ -3,6 +3,7 @@ interface of ps_slm_amd/ops.py with the same signatures and the same rounding po
 It lets the CPU test-suite drive the REAL host code (merge plan, buffer bookkeeping, forward/backward
 schedule, engine, DP) end to end and compare it with the oracle, so that the only thing left to check on
 the GPU is the kernels themselves (tests/test_gpu_*.py compare HipOps with this double op by op)."""
+import contextlib
 import math
 
 import numpy as np
@@ -25,6 +26,11 @@ class FakeOps:
     name = "fake-cpu"
 
     # ---------------------------------------------------------------- GEMM & layout
+    @contextlib.contextmanager
+    def alt_workspace(self, who):
+        """HipOps.alt_workspace: the double has no GEMM workspace."""
+        yield
+
     def gemm(self, a, b, c, M, N, K, bias=None, resid=None, mode=GEMM_BF16, lda=None, ldb=None, ldc=None):
         assert K % 64 == 0, "K must be a multiple of 64 (layout contract of tasu_gemm_nt_bf16)"
         A = a.reshape(-1, a.shape[-1])[:M, :K].float()
