@@ -303,6 +303,19 @@ def test_full_geometry_audio_sft_step(full):
         assert st.S == 24 + int(got.max()) + 128
         st2 = run()
         assert torch.equal(st2.dev["loss_out"], loss) and torch.equal(m.proj.g, g)
+        # the frozen encoder one batch ahead (TasuModel.prefetch_encoder): the next pass runs on a side stream UNDER this step's
+        # decoder GEMMs (256-CU grids on both streams, separate split-K workspaces) -- same bits, for the step it overlaps and
+        # for the step that consumes it
+        st3 = m.prepare_audio(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["input_features"], lens, do_psd=True)
+        m.forward_llm(st3)
+        assert m.prefetch_encoder(batch["input_features"], lens)
+        m.backward(st3)
+        torch.cuda.synchronize()
+        assert torch.equal(st3.dev["loss_out"], loss) and torch.equal(m.proj.g, g)
+        assert m._enc_ahead is not None
+        st4 = run()                                                                # consumes the prefetched pass
+        assert m._enc_ahead is None
+        assert torch.equal(st4.dev["loss_out"], loss) and torch.equal(m.proj.g, g) and np.array_equal(np.asarray(st4.dev["psd_lens"]), got)
     finally:
         m.encoder.ctc_w.copy_(saved_w)
         m.encoder.ctc_b.copy_(saved_b)
