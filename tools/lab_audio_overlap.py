@@ -13,6 +13,7 @@ from ps_slm_amd.synthetic import synthetic_text_batch
 ap = argparse.ArgumentParser()
 ap.add_argument("--bias", type=float, default=13.0)
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--prio", type=int, nargs="*", default=[0, -1])
 a = ap.parse_args()
 B = 16
 tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=False, gt_emb_noise=False, ctc_posterior=True, do_psd=True, use_fp16=True,
@@ -50,13 +51,28 @@ cached = real(core, feats, fl, want_post=False)
 encmod.encoder_posterior = lambda m, f, l, want_post=True: cached
 for _ in range(2): step()
 res["step_without_encoder_ms"] = round(timeit(step, a.steps), 3)
-side = torch.cuda.Stream()
-def overlapped():
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        real(core, feats, fl, want_post=False)
-    step()
-    torch.cuda.current_stream().wait_stream(side)
-for _ in range(2): overlapped()
-res["step_with_encoder_on_side_stream_ms"] = round(timeit(overlapped, a.steps), 3)
+for prio in a.prio:
+    side = torch.cuda.Stream(priority=prio)
+    def overlapped():
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            real(core, feats, fl, want_post=False)
+        step()
+        torch.cuda.current_stream().wait_stream(side)
+    for _ in range(2): overlapped()
+    res[f"step_with_encoder_on_side_stream_prio{prio}_ms"] = round(timeit(overlapped, a.steps), 3)
+# the reverse: the decoder step on a high-priority stream, the encoder on the default one
+hi = torch.cuda.Stream(priority=-1)
+def overlapped2():
+    cur = torch.cuda.current_stream()
+    hi.wait_stream(cur)
+    real(core, feats, fl, want_post=False)
+    with torch.cuda.stream(hi):
+        step()
+    cur.wait_stream(hi)
+try:
+    for _ in range(3): overlapped2()
+    res["decoder_step_on_high_priority_stream_ms"] = round(timeit(overlapped2, a.steps), 3)
+except Exception as e:
+    res["decoder_step_on_high_priority_stream_ms"] = str(e)[:200]
 print(json.dumps(res))
