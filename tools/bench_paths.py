@@ -12,8 +12,9 @@ from ps_slm_amd.decode import beam_search_generate
 
 what = sys.argv[1] if len(sys.argv) > 1 else "decode"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+MODEL = sys.argv[3] if len(sys.argv) > 3 else "qwen2.5-1.5b"          # or qwen2.5-7b
 tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=(what == "decode"), gt_emb_noise=False, ctc_posterior=True, do_psd=True)
-mc = ModelConfig(llm_path="synthetic:qwen2.5-1.5b", encoder_projector="linear-silu", encoder_dim=25055, llm_dim=1536)
+mc = ModelConfig(llm_path=f"synthetic:{MODEL}", encoder_projector="linear-silu", encoder_dim=25055, llm_dim={"qwen2.5-1.5b": 1536, "qwen2.5-7b": 3584}[MODEL])
 model, tok = model_factory(tc, mc, device="cuda:0", init_seed=1234, keep_logits=False, with_encoder=(what != "decode"))
 core = model.core
 geo = core.geo
@@ -22,7 +23,7 @@ if what == "decode":
     # prompt without targets: 24 prompt ids + <speech> -> S_p = 24 + 104 = 128, beams 4, 200 forced new tokens
     ids = raw["input_ids"][:, :25]
     am = torch.ones_like(ids, dtype=torch.bool)
-    new = 200
+    new = 200 if MODEL == "qwen2.5-1.5b" else 64
     def run():
         st = core.prepare_text(ids, am, None, raw["post_ids"], None, None)
         core.forward_projector_text(st)
