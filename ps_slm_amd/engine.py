@@ -27,6 +27,8 @@ import math
 import torch
 import torch.distributed as dist
 
+from .streams import side_stream
+
 
 class RcclExchange:
     """The data-path collective on the GPU: one RCCL communicator per process behind the C-ABI (csrc/comm.hip).  The unique id
@@ -146,7 +148,8 @@ class TasuEngine:
         self.sched_iter = -1           # WarmupCosineLR.last_batch_iteration (scheduler steps AFTER the optimizer)
         self.micro_steps = 0
         dev = self.core.device
-        self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # (a stream on its own hardware queue: ps_slm_amd/streams.py; only when gradients are exchanged)
+        self.comm_stream = side_stream(dev) if self.exchange else None
         # the collective: RCCL through the C-ABI when the ranks were launched with the nccl backend (one GPU per rank); a gloo
         # group (CPU double; two ranks sharing one GPU in tests) keeps torch.distributed's all_reduce
         self.rccl = None

@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 from .ops import GEMM_F32, GEMM_RESID
+from .streams import side_stream
 
 HD = 128
 TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
@@ -317,7 +318,7 @@ class LoraRunner:
         # the weight-gradient chain of a group (three operand transposes + 2 rank GEMMs per member) feeds nothing of the backward's
         # critical path: it runs on a side stream under the next kernels of the dgrad chain (also inside a captured hipGraph: a
         # fork / join of the capturing stream).  Its workgroup counts (96-560) leave most of the chip to the main stream's GEMMs.
-        self.side = torch.cuda.Stream(device=model.device) if model.device.type == "cuda" else None
+        self.side = side_stream(model.device)              # on its own hardware queue (ps_slm_amd/streams.py); None on the CPU double
         self._side_done = {}                               # group -> event: the side chain that read this group's buffers has finished
 
     # ---- workspace

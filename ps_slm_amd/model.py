@@ -615,7 +615,8 @@ class TasuModel:
         if self.use_graphs and ("region", "encoder", B, T, False) not in self._graphs:
             return False
         if self._enc_stream is None:
-            self._enc_stream = torch.cuda.Stream(device=self.device)
+            from .streams import side_stream
+            self._enc_stream = side_stream(self.device)   # a stream on another hardware queue than the current one
         side = self._enc_stream
         if self._psd_done is not None:
             side.wait_event(self._psd_done)               # PSD of the batch in flight has read the logits / encoder states

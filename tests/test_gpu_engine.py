@@ -245,3 +245,18 @@ def test_lora_bucket_exchange_on_rccl_is_bit_identical(nccl_group, graphs):
     for a, b in zip(want, got):
         assert torch.equal(a, b)
     assert float(m1.core.proj.p[lp.base:].abs().max()) > 0 and float(want[0][-1]) < float(want[0][0])
+
+
+def test_side_streams_run_next_to_the_main_stream():
+    """ps_slm_amd/streams.py: HIP maps streams onto a few hardware queues in creation order, and every fourth pooled torch stream
+    shares the default stream's queue (strictly serial execution).  side_stream() probes with spin kernels: what it hands out
+    overlaps with the current stream and with the side streams handed out before -- whatever the process created earlier."""
+    from ps_slm_amd.streams import runs_concurrently, side_stream
+    junk = [torch.cuda.Stream() for _ in range(5)]                 # shift torch's round-robin pool position
+    main = torch.cuda.current_stream()
+    a, b = side_stream("cuda"), side_stream("cuda")
+    assert a is not b
+    assert runs_concurrently(main, a) and runs_concurrently(main, b) and runs_concurrently(a, b)
+    assert not runs_concurrently(a, a)                             # the probe itself: one queue = one after the other
+    assert side_stream("cpu") is None
+    del junk
