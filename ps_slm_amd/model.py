@@ -604,16 +604,16 @@ class TasuModel:
         prepare_audio() of a batch whose ``input_features`` is this very tensor (unmodified, same lengths) waits for the pass and
         skips its own; any other batch runs the encoder as before (after waiting: the workspace is shared).  Same kernels on the
         same data: results are bit-identical with and without the call.  Returns False (and does nothing) on the CPU double,
-        and for a batch shape whose workspace / step graph does not exist yet (the first passes of a shape allocate and capture
-        on the main stream)."""
+        and -- with hipGraph replay on -- for a batch shape whose encoder graph does not exist yet (the first passes of a shape
+        allocate and capture on the main stream)."""
         from .encoder import encoder_posterior
         if self.device.type != "cuda" or self.encoder is None or input_features is None:
             return False
         B, T, _ = input_features.shape
-        if self._enc_shapes.get((B, T)) != self._buf_gen:
-            return False
-        if self.use_graphs and ("region", "encoder", B, T, False) not in self._graphs:
-            return False
+        if self.use_graphs and (self._enc_shapes.get((B, T)) != self._buf_gen or ("region", "encoder", B, T, False) not in self._graphs):
+            return False                                  # graph replay: the first passes of a shape allocate and capture in line
+        # (eager launches: any shape -- dynamic batching gives every batch its own.  A workspace buffer that has to grow is
+        #  re-allocated inside the pass; every reader of the encoder's buffers is ordered against it by the two events)
         if self._enc_stream is None:
             from .streams import side_stream
             self._enc_stream = side_stream(self.device)   # a stream on another hardware queue than the current one

@@ -491,6 +491,13 @@ def test_encoder_one_batch_ahead_changes_nothing(graphs):
     variants = [dict(batch, input_features=batch["input_features"] + 0.3 * i * torch.randn(batch["input_features"].shape, generator=g))
                 for i in range(5)]
     order = [0, 1, 2, 3, 4, 1, 3]
+    if not graphs:
+        # eager launches prefetch ANY shape (dynamic batching): a batch of twice the frames makes the encoder's workspace grow
+        # inside a prefetched pass, a batch of two utterances follows it
+        f5 = torch.cat([variants[1]["input_features"], variants[2]["input_features"]], 1)
+        variants.append(dict(batch, input_features=f5, input_feature_length=batch["input_feature_length"] + f5.shape[1] // 2))
+        variants.append({k: (v[:2] if isinstance(v, torch.Tensor) else v) for k, v in variants[3].items()})
+        order = [0, 1, 5, 2, 4, 1, 6, 5, 3]
     zd = load_npz("mid_generate_beam4")
     dec_ids, dec_am = torch.from_numpy(zd["input_ids"]), torch.from_numpy(zd["attention_mask"])
 
