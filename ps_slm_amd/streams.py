@@ -47,6 +47,8 @@ def side_stream(device):
     if device.type != "cuda":
         return None
     idx = device.index if device.index is not None else torch.cuda.current_device()
+    if not hasattr(torch.cuda, "_sleep"):                 # (no spin kernel to probe with: any stream)
+        return torch.cuda.Stream(device=idx)
     with torch.cuda.device(idx):
         st = _state.setdefault(idx, dict(candidates=[], taken=[]))
         main = torch.cuda.current_stream()
