@@ -406,8 +406,19 @@ class TasuModel:
         self.sync_projector_copies()
         if any(k.startswith("encoder.") for k in sd):
             from .encoder import EncoderWeights
+            self._encoder_replaced()
             self.encoder = EncoderWeights(self.geo, self.device)
             self.encoder.load_reference_state_dict(sd)
+
+    def _encoder_replaced(self):
+        """New encoder weights are about to be installed: a prefetched pass and the captured encoder graphs refer to the old
+        tensors."""
+        if self._enc_ahead is not None:
+            self._enc_ahead["ready"].synchronize()
+            self._enc_ahead = None
+        for k in [k for k in self._graphs if k[:2] == ("region", "encoder")]:
+            del self._graphs[k]
+            self._graph_seen.pop(k, None)
 
     def init_random(self, seed=1234, with_encoder=False):
         self.llm.init_random(seed)
@@ -416,6 +427,7 @@ class TasuModel:
         self.init_projector_default(seed + 1)
         if with_encoder:
             from .encoder import EncoderWeights
+            self._encoder_replaced()
             self.encoder = EncoderWeights(self.geo, self.device)
             self.encoder.init_random(seed + 2)
 
@@ -454,6 +466,7 @@ class TasuModel:
         raw = torch.load(path, map_location="cpu")
         raw = raw.get("state_dict", raw)
         sd = {"encoder." + k: v.float() for k, v in raw.items()}
+        self._encoder_replaced()
         self.encoder = EncoderWeights(self.geo, self.device)
         self.encoder.load_reference_state_dict(sd)
 
