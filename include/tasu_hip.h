@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 7
+#define TASU_ABI_VERSION 8
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -330,6 +330,13 @@ int tasu_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stre
  * aligned.                                                                                                                  */
 int tasu_gemm_nt_rank(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int out_f32,
                       int transposed, void* stream);
+/* The same product with A given K-MAJOR, C[M, N] = At[K, M]^T . B[N, K]^T (fp32): a weight gradient straight from the step's
+ * row-major tensors -- dB = dy^T u with At = dy [rows, out], dA^T = xd^T du with At = xd [rows, in] (torch autograd of
+ * peft's lora_B(lora_A(dropout(x))), cf. Multitask/model/ps-slm.py:114-117) -- without a transposed copy of the big operand
+ * (hardware transpose reads from LDS).  M % 16 == 0, K % 64 == 0, ldat >= M, ldat / ldb % 8 == 0; sums in the order of
+ * tasu_gemm_nt_rank up to the order of the 32 products inside one MFMA. */
+int tasu_gemm_tn_rank(const void* At, int ldat, const void* B, int ldb, float* C, int ldc, int M, int N, int K, int transposed,
+                      void* stream);
 int tasu_scale_bf16(const void* src, void* dst, float s, int64_t n, void* stream);
 /* tasu_lora_apply: y[M, N] = bf16(y + mask . bf16(s . bf16(u[M, R] W[N, R]^T))) and, with x_in / x_out (fp32, leading dimension
  * ldx), x_out = x_in + float(y): an adapter's rank-R GEMM with the accumulate into the base result fused (one read + one write of

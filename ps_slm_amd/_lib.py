@@ -45,6 +45,7 @@ PROTOTYPES = {
     "tasu_relu_bwd": [vp, vp, vp, i64, vp],
     "tasu_relu_fwd": [vp, vp, i64, vp],
     "tasu_gemm_nt_rank": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tasu_gemm_tn_rank": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "tasu_scale_bf16": [vp, vp, f32, i64, vp],
     "tasu_lora_apply": [vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, i32, vp, vp, i32, vp],
     "tasu_lora_dropout": [vp, i32, vp, i32, i32, i32, f32, vp, i32, vp],
@@ -121,7 +122,7 @@ PROTOTYPES.update({
     "tasu_allreduce_min_i32": [vp, vp, i64, vp],
 })
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

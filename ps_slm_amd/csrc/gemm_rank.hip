@@ -1,8 +1,8 @@
 // C[M, N] = A[M, K] . B[N, K]^T for N <= 64: the rank-sized GEMMs of the LoRA recipe (ps_slm_amd/lora.py) --
 //   u  = xd A^T          [rows, r]     K = in        (forward)
 //   du = dy (sB)         [rows, r]     K = out       (backward, through lora_B)
-//   dB = dy^T u          [out, r]      K = rows      (weight gradient, fp32; operands transposed by the caller)
-//   dA = (xd^T du)^T     [r, in]       K = rows      (weight gradient, fp32, stored transposed)
+//   dB = dy^T u          [out, r]      K = rows      (weight gradient, fp32; tasu_gemm_tn_rank: dy K-major as it lies)
+//   dA = (xd^T du)^T     [r, in]       K = rows      (weight gradient, fp32, stored transposed; xd K-major)
 // On the tile policy of gemm.hip these are ONE column of 128-row tiles: 32 of 256 CUs walk the whole K range at one
 // latency-bound K-step (~0.7 us) after the other -- 16-77 us.  What was tried first (measured on MI355X, kept here as the reason
 // for this design): (a) fragments straight from global memory, 16 waves splitting K: adjacent lanes hold different ROWS of an
@@ -25,7 +25,14 @@ typedef const __attribute__((address_space(1))) void glb_void;
 constexpr int NW = 8;
 constexpr int REGION = 10240;                           // per wave: A 16 x 128 B, then B 64 x 128 B
 
-template <bool F32OUT, bool TSTORE>
+// AT: A is given K-MAJOR, At[K, M] (a weight gradient's big operand in its natural layout: K = the step's rows).  Its chunk is then
+// staged as 64 k-rows of 32 bytes (the tile's 16 columns) and comes back as the MFMA operand through the hardware transpose read
+// (ds_read_tr16_b64: a 16-lane group reads 4 k-rows x 16 columns and every lane gets one column's 4 k-values) -- k-slots
+// {4q..4q+3, 16+4q..16+4q+3} of a 32-block for lane group q, so B's fragment is read as the two matching 8-byte halves.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <bool F32OUT, bool TSTORE, bool AT>
 __global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
                                                                void* __restrict__ Cv, int ldc, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -39,8 +46,13 @@ __global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __res
   const bf16* gb[8];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int r = i * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-    ga[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * 8;
+    if constexpr (AT) {
+      // piece i = k-rows i * 32 .. +31 of the chunk, 32 B each: lane -> k-row lane >> 1, 16-byte half lane & 1 (M % 16 == 0)
+      ga[i] = A + (size_t)(i * 32 + (lane >> 1)) * lda + m0 + (lane & 1) * 8;
+    } else {
+      const int r = i * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+      ga[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * 8;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -58,7 +70,8 @@ __global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __res
   for (int c = wave; c < nchunks; c += NW) {
     const int koff = c << 6;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(mine + i * 1024), 16, 0, 0);
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + (AT ? (size_t)koff * lda : (size_t)koff)), (lds_void*)(mine + i * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       if (i * 8 < N) __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(mine + 2048 + i * 1024), 16, 0, 0);
@@ -66,10 +79,29 @@ __global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __res
     bf16x8 fa[2], fb[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      fa[kk] = *(const bf16x8*)(mine + roff[kk]);
+      if constexpr (AT) {
+        // k-rows kk * 32 + 4 q + (0..3) and + 16: lane -> row 4 q + ((lane >> 2) & 3), 8-byte column quad lane & 3
+        const int q = lane >> 4, r0 = kk * 32 + 4 * q + ((lane >> 2) & 3);
+        union { s16x4 h[2]; bf16x8 b; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(mine + r0 * 32 + (lane & 3) * 8));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(mine + (r0 + 16) * 32 + (lane & 3) * 8));
+        fa[kk] = u.b;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < ntn) fb[kk][j] = *(const bf16x8*)(mine + 2048 + j * 2048 + roff[kk]);
+        for (int j = 0; j < 4; ++j)
+          if (j < ntn) {
+            // B row (lane & 15) of column group j: k = kk * 32 + 4 q .. +3 and + 16 .. (bytes 8 q and 32 + 8 q of the 64-byte half)
+            const char* row = mine + 2048 + j * 2048 + (lane & 15) * 128;
+            union { bf16x4 h[2]; bf16x8 b; } v;
+            v.h[0] = *(const bf16x4*)(row + ((((kk * 4 + (q >> 1)) ^ sw)) << 4) + (q & 1) * 8);
+            v.h[1] = *(const bf16x4*)(row + ((((kk * 4 + 2 + (q >> 1)) ^ sw)) << 4) + (q & 1) * 8);
+            fb[kk][j] = v.b;
+          }
+      } else {
+        fa[kk] = *(const bf16x8*)(mine + roff[kk]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < ntn) fb[kk][j] = *(const bf16x8*)(mine + 2048 + j * 2048 + roff[kk]);
+      }
     }
     // the weight-side fragment goes in as the MFMA's A operand: acc[j][r] = C[m0 + (lane & 15)][j * 16 + (lane >> 4) * 4 + r]
 #pragma unroll
@@ -104,15 +136,15 @@ __global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __res
   }
 }
 
-template <bool F32OUT, bool TSTORE>
+template <bool F32OUT, bool TSTORE, bool AT = false>
 int launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, hipStream_t st) {
   constexpr int LDS = NW * REGION;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)rank_gemm_kernel<F32OUT, TSTORE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)rank_gemm_kernel<F32OUT, TSTORE, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  TASU_LAUNCH((rank_gemm_kernel<F32OUT, TSTORE>), dim3((M + 15) / 16), dim3(64 * NW), LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, C,
+  TASU_LAUNCH((rank_gemm_kernel<F32OUT, TSTORE, AT>), dim3((M + 15) / 16), dim3(64 * NW), LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, C,
               ldc, M, N, K);
   return TASU_OK;
 }
@@ -127,4 +159,16 @@ extern "C" int tasu_gemm_nt_rank(const void* A, int lda, const void* B, int ldb,
   hipStream_t st = (hipStream_t)stream;
   if (out_f32) return transposed ? launch<true, true>(A, lda, B, ldb, C, ldc, M, N, K, st) : launch<true, false>(A, lda, B, ldb, C, ldc, M, N, K, st);
   return transposed ? launch<false, true>(A, lda, B, ldb, C, ldc, M, N, K, st) : launch<false, false>(A, lda, B, ldb, C, ldc, M, N, K, st);
+}
+
+// The same product with A given K-major: C[M, N] = At[K, M]^T . B[N, K]^T -- a weight gradient straight from the step's row-major
+// activations / gradients (At = dy [rows, out] or xd [rows, in]), no transposed copy of the big operand.  fp32 output.
+extern "C" int tasu_gemm_tn_rank(const void* At, int ldat, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                 int transposed, void* stream) {
+  if (!At || !B || !C || M <= 0 || M % 16 || N <= 0 || N > 64 || K <= 0 || K % 64 || ldat % 8 || ldb % 8 || ldat < M || ldb < K)
+    return TASU_ERR_ARG;
+  if (((uintptr_t)At & 15) || ((uintptr_t)B & 15)) return TASU_ERR_ARG;
+  if (ldc < (transposed ? M : N)) return TASU_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  return transposed ? launch<true, true, true>(At, ldat, B, ldb, C, ldc, M, N, K, st) : launch<true, false, true>(At, ldat, B, ldb, C, ldc, M, N, K, st);
 }

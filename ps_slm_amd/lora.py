@@ -15,8 +15,8 @@ does not survive a bf16 rounding of W).  Forward: per adapted group (q|k|v, o, g
 members' ranks, y = [x | us] [W | B]^T with us = bf16(xd (sA)^T) from the rank GEMM (csrc/gemm_rank.hip) -- the frozen recipe's
 fused epilogues stay, base + branch are rounded to bf16 once (the reference rounds base, branch and sum separately: inside
 every bf16 tolerance, identical in fp32).  Backward: du = dy (sB) (rank GEMM), the adapter's input gradient mask . (du A)
-accumulated into the base path's in one pass (tasu_lora_apply, csrc/lora.hip), dB = dy^T us and dA = du^T xd as rank GEMMs on
-transposed operands, fp32, straight into the bucket, on a side stream.  All A / B tensors live behind the projector in the ONE
+accumulated into the base path's in one pass (tasu_lora_apply, csrc/lora.hip), dB = dy^T us and dA = du^T xd as rank GEMMs that
+read dy / xd K-major as they lie (tasu_gemm_tn_rank), fp32, straight into the bucket, on a side stream.  All A / B tensors live behind the projector in the ONE
 flat fp32 bucket (master, grad, Adam m / v, bf16 image), a layer's tensors contiguous and the layers in the order the backward
 completes them (last layer first): AdamW stays one launch, the gradient exchange gets one range per span of layers.  Nothing
 of the forward is recomputed: the operands [x | us] and every member's dropped input are kept per layer.  Decode runs on merged
@@ -387,22 +387,31 @@ class LoraRunner:
             du_t = du[:, k * rp: k * rp + rp]
             self.rank(dy[:, c0:c0 + o], lp.bts[(l, t)], du_t, M, r, o)             # du = bf16(dy (sB))              [M, r]
             ops.lora_apply(dx_base, du_t, lp.at[(l, t)], M, i, rp, p=p if drop else 0.0, rng=lp.rng, sid=self._sid(l, t))
-        # weight gradients: dB_t = dy_t^T us_t [out, r],  dA_t = du_t^T xd_t [r, in]  (K = the M rows, zero-padded to 64)
-        dy_t = m._buf("lora_dy_t_" + gname, (width, Mp), bf)        # per group: the side chain of the previous layer may still read it
-        ops.transpose(dy, dy_t, M, width, Mp, width)
+        # weight gradients: dB_t = dy_t^T us_t [out, r],  dA_t = du_t^T xd_t [r, in]  (K = the M rows).  The big operands (dy, xd) are
+        # read K-major as they are (tasu_gemm_tn_rank: hardware transpose reads); only the rank-sized ones are transposed
+        # (zero-padded to Mp = 64-row multiples; the padding rows of dy / xd are never read when M itself is a multiple of 64).
+        tn = M % 64 == 0 and r <= 64 and hasattr(ops, "gemm_rank_tn")
+        dy_t = None
+        if not tn:
+            dy_t = m._buf("lora_dy_t_" + gname, (width, Mp), bf)    # per group: the side chain of the previous layer may still read it
+            ops.transpose(dy, dy_t, M, width, Mp, width)
 
         def wgrads():
             us_t = m._buf("lora_us_t", (nt * rp, Mp), bf)
             ops.transpose(us_l, us_t, M, nt * rp, Mp, nt * rp)
             du_tr = m._buf("lora_du_t", (nt * rp, Mp), bf)
             ops.transpose(du, du_tr, M, nt * rp, Mp, nt * rp)
-            xd_t = m._buf("lora_xd_t", (inn, Mp), bf)
+            xd_t = None if tn else m._buf("lora_xd_t", (inn, Mp), bf)
             last = None
             for t in targets:
                 i, o = lp.dims[t]
                 c0, k = lp.cols[t], lp.slot[t]
-                self.rank(dy_t[c0:c0 + o], us_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "B"), o, r, Mp, f32=True)
                 xd = xd_of(t)
+                if tn:
+                    ops.gemm_rank_tn(dy[:, c0:c0 + o], us_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "B"), o, r, M)
+                    ops.gemm_rank_tn(xd, du_tr[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "A"), i, r, M, transposed=True)
+                    continue
+                self.rank(dy_t[c0:c0 + o], us_t[k * rp: k * rp + r], lp.view(lp.proj.g, l, t, "B"), o, r, Mp, f32=True)
                 if xd is not last:                          # members of a group share their input unless dropout gave each its own
                     ops.transpose(xd, xd_t, M, i, Mp, i)
                     last = xd
@@ -512,22 +521,29 @@ class LoraRunner:
             buf = self._ax(gname, M)[l][:, :width]
             return lambda t: buf
 
+        # The weight-gradient chains on the side stream read the group's output gradient IN PLACE (dxb, dgu, dqkv: no transposed
+        # copy, tasu_gemm_tn_rank): the main stream waits for a group's chain right before the kernel that rewrites that buffer.
         if "down" in groups:
             ops.gemm(dxb, w["wd_t"], dact, M, I, D)
             self.group_bwd(l, "down", groups["down"], dxb, D, M, stored("down", I), dact, drop)
+            self._wait_side("gu")                                     # (the previous layer's chain over dgu)
             ops.swiglu_bwd(dact, d["gu"][l], dgu, M, I)
         else:
+            self._wait_side("gu")
             ops.gemm_dswiglu(dxb, w["wd_t"], d["gu"][l], dgu, dact, M, I, D)
         ops.gemm(dgu, w["wgu_t"], dn, M, D, 2 * I)
         if "gu" in groups:
             self.group_bwd(l, "gu", groups["gu"], dgu, 2 * I, M, stored("gu", D), dn, drop)
+        self._wait_side("down")                                       # its chain read dxb
         ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
         ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)
         if "o" in groups:
             self.group_bwd(l, "o", groups["o"], dxb, D, M, stored("o", H * HD, shared=d["ao"][l]), dao, drop)
         ops.attn_bwd_prep(dao, d["ao"][l], delta, None, B, S, H)
+        self._wait_side("qkv")                                        # (the previous layer's chain over dqkv)
         ops.attn_bwd_rope(d["qkv"][l], d["key_mask"], dao, d["lse"][l], delta, cos, sin, dqkv, dkp, dvp, B, S, H, G, scale, True)
         ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)
         if "qkv" in groups:
             self.group_bwd(l, "qkv", groups["qkv"], dqkv, LDQ, M, stored("qkv", D), dn, drop)
+        self._wait_side("o")                                          # its chain read dxb
         ops.rmsnorm_bwd(dn, x_in, w["ln1"], rstd[2 * l], dx, dxb, True)

@@ -337,6 +337,11 @@ class HipOps:
         self._chk(self.lib.tasu_gemm_nt_rank(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), M, N, K, int(f32), int(transposed),
                                              self._stream()), "tasu_gemm_nt_rank")
 
+    def gemm_rank_tn(self, at, b, c, M, N, K, transposed=False):
+        """c[M, N] (fp32) = at[K, M]^T @ b[N, K]^T for N <= 64: A given K-major (tasu_gemm_tn_rank); ``transposed``: c holds C^T."""
+        self._chk(self.lib.tasu_gemm_tn_rank(_p(at), at.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), M, N, K, int(transposed),
+                                             self._stream()), "tasu_gemm_tn_rank")
+
     def lora_apply(self, y, u, w, M, N, R, s=1.0, p=0.0, rng=None, sid=0, x_in=None, x_out=None):
         """y[M, N] = bf16(y + mask * bf16(s * bf16(u[M, R] @ w[N, R]^T))) [, x_out = x_in + y] in one pass over y (tasu_lora_apply)."""
         self._chk(self.lib.tasu_lora_apply(_p(y), y.stride(0), _p(u), u.stride(0), _p(w), w.stride(0), M, N, R, float(s), float(p), _p(rng),

@@ -311,6 +311,14 @@ class FakeOps:
         else:
             c[:M, :N] = out
 
+    def gemm_rank_tn(self, at, b, c, M, N, K, transposed=False):
+        assert N <= 64 and K % 64 == 0 and M % 16 == 0
+        acc = at[:K, :M].float().t() @ b[:N, :K].float().t()
+        if transposed:
+            c[:N, :M] = acc.t()
+        else:
+            c[:M, :N] = acc
+
     def lora_apply(self, y, u, w, M, N, R, s=1.0, p=0.0, rng=None, sid=0, x_in=None, x_out=None):
         d = _bf(_bf(u[:M, :R].float() @ w[:N, :R].float().t()).float() * float(s)).float()
         if p > 0.0:

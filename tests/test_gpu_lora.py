@@ -179,6 +179,32 @@ def test_gemm_rank_vs_fp32(ops, M, N, K):
     assert torch.equal(c2, c[:, 8:8 + N])                                                              # deterministic
 
 
+@pytest.mark.parametrize("M,N,K", [(1536, 64, 4096), (8960, 64, 4096), (256, 64, 4096), (64, 16, 64), (1536, 64, 1984), (512, 40, 640)])
+def test_gemm_rank_tn_vs_fp32_and_the_transposed_path(ops, M, N, K):
+    """tasu_gemm_tn_rank (the adapters' weight gradients with the big operand K-major as the step leaves it: hardware transpose
+    reads) against an fp32 product and against tasu_gemm_nt_rank on a transposed copy (same chunks, same wave order: equal up to
+    the order of the 32 products inside one MFMA); strided operands (column slices), plain / transposed store, nothing outside C."""
+    g = torch.Generator().manual_seed(M + N + K)
+    at_full = (torch.randn(K, M + 128, generator=g) * 0.5).bfloat16().cuda()
+    b_full = (torch.randn(N, K + 8, generator=g) * 0.5).bfloat16().cuda()
+    at, b = at_full[:, 64:64 + M], b_full[:, :K]
+    ref = at.float().t() @ b.float().t()
+    tol = 2e-3 * float(ref.abs().max()) + 1e-6
+    c = torch.full((M, N + 16), 7.0, dtype=torch.float32, device="cuda")
+    ops.gemm_rank_tn(at, b, c[:, 8:8 + N], M, N, K)
+    assert float((c[:, 8:8 + N] - ref).abs().max()) < tol
+    assert float((c[:, :8] - 7).abs().max()) == 0 and float((c[:, 8 + N:] - 7).abs().max()) == 0
+    nt = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ops.gemm_rank(at.t().contiguous(), b, nt, M, N, K, f32=True)
+    assert float((c[:, 8:8 + N] - nt).abs().max()) <= 1e-5 * float(ref.abs().max())
+    ct = torch.full((N, M + 3), 7.0, dtype=torch.float32, device="cuda")
+    ops.gemm_rank_tn(at, b, ct, M, N, K, transposed=True)
+    assert torch.equal(ct[:, :M], c[:, 8:8 + N].t()) and float((ct[:, M:] - 7).abs().max()) == 0
+    c2 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ops.gemm_rank_tn(at, b, c2, M, N, K)
+    assert torch.equal(c2, c[:, 8:8 + N])                                                              # deterministic
+
+
 @pytest.mark.parametrize("M,N,R", [(4096, 1536, 64), (333, 512, 64), (64, 128, 128), (141, 256, 64), (200, 8960, 64), (70, 264, 64)])
 def test_lora_apply_bit_exact_vs_double(ops, M, N, R):
     """tasu_lora_apply (rank-R product + scale + dropout mask + accumulate + residual add in one pass over y) against the CPU
