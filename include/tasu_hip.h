@@ -333,7 +333,7 @@ int tasu_gemm_nt_rank(const void* A, int lda, const void* B, int ldb, void* C, i
 /* The same product with A given K-MAJOR, C[M, N] = At[K, M]^T . B[N, K]^T (fp32): a weight gradient straight from the step's
  * row-major tensors -- dB = dy^T u with At = dy [rows, out], dA^T = xd^T du with At = xd [rows, in] (torch autograd of
  * peft's lora_B(lora_A(dropout(x))), cf. Multitask/model/ps-slm.py:114-117) -- without a transposed copy of the big operand
- * (hardware transpose reads from LDS).  M % 16 == 0, K % 64 == 0, ldat >= M, ldat / ldb % 8 == 0; sums in the order of
+ * (hardware transpose reads from LDS; 64 x 64 tiles).  M % 64 == 0, K % 64 == 0, ldat >= M, ldat / ldb % 8 == 0; sums in the order of
  * tasu_gemm_nt_rank up to the order of the 32 products inside one MFMA. */
 int tasu_gemm_tn_rank(const void* At, int ldat, const void* B, int ldb, float* C, int ldc, int M, int N, int K, int transposed,
                       void* stream);

@@ -1,7 +1,7 @@
 // C[M, N] = A[M, K] . B[N, K]^T for N <= 64: the rank-sized GEMMs of the LoRA recipe (ps_slm_amd/lora.py) --
 //   u  = xd A^T          [rows, r]     K = in        (forward)
 //   du = dy (sB)         [rows, r]     K = out       (backward, through lora_B)
-//   dB = dy^T u          [out, r]      K = rows      (weight gradient, fp32; tasu_gemm_tn_rank: dy K-major as it lies)
+//   dB = dy^T u          [out, r]      K = rows      (weight gradient, fp32: rank_gemm_tn_kernel below, dy K-major as it lies)
 //   dA = (xd^T du)^T     [r, in]       K = rows      (weight gradient, fp32, stored transposed; xd K-major)
 // On the tile policy of gemm.hip these are ONE column of 128-row tiles: 32 of 256 CUs walk the whole K range at one
 // latency-bound K-step (~0.7 us) after the other -- 16-77 us.  What was tried first (measured on MI355X, kept here as the reason
@@ -25,14 +25,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 constexpr int NW = 8;
 constexpr int REGION = 10240;                           // per wave: A 16 x 128 B, then B 64 x 128 B
 
-// AT: A is given K-MAJOR, At[K, M] (a weight gradient's big operand in its natural layout: K = the step's rows).  Its chunk is then
-// staged as 64 k-rows of 32 bytes (the tile's 16 columns) and comes back as the MFMA operand through the hardware transpose read
-// (ds_read_tr16_b64: a 16-lane group reads 4 k-rows x 16 columns and every lane gets one column's 4 k-values) -- k-slots
-// {4q..4q+3, 16+4q..16+4q+3} of a 32-block for lane group q, so B's fragment is read as the two matching 8-byte halves.
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-template <bool F32OUT, bool TSTORE, bool AT>
+template <bool F32OUT, bool TSTORE>
 __global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
                                                                void* __restrict__ Cv, int ldc, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -46,13 +39,8 @@ __global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __res
   const bf16* gb[8];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    if constexpr (AT) {
-      // piece i = k-rows i * 32 .. +31 of the chunk, 32 B each: lane -> k-row lane >> 1, 16-byte half lane & 1 (M % 16 == 0)
-      ga[i] = A + (size_t)(i * 32 + (lane >> 1)) * lda + m0 + (lane & 1) * 8;
-    } else {
-      const int r = i * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-      ga[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * 8;
-    }
+    const int r = i * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+    ga[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * 8;
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -70,8 +58,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __res
   for (int c = wave; c < nchunks; c += NW) {
     const int koff = c << 6;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + (AT ? (size_t)koff * lda : (size_t)koff)), (lds_void*)(mine + i * 1024), 16, 0, 0);
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff), (lds_void*)(mine + i * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       if (i * 8 < N) __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(mine + 2048 + i * 1024), 16, 0, 0);
@@ -79,29 +66,10 @@ __global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __res
     bf16x8 fa[2], fb[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      if constexpr (AT) {
-        // k-rows kk * 32 + 4 q + (0..3) and + 16: lane -> row 4 q + ((lane >> 2) & 3), 8-byte column quad lane & 3
-        const int q = lane >> 4, r0 = kk * 32 + 4 * q + ((lane >> 2) & 3);
-        union { s16x4 h[2]; bf16x8 b; } u;
-        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(mine + r0 * 32 + (lane & 3) * 8));
-        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(mine + (r0 + 16) * 32 + (lane & 3) * 8));
-        fa[kk] = u.b;
+      fa[kk] = *(const bf16x8*)(mine + roff[kk]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < ntn) {
-            // B row (lane & 15) of column group j: k = kk * 32 + 4 q .. +3 and + 16 .. (bytes 8 q and 32 + 8 q of the 64-byte half)
-            const char* row = mine + 2048 + j * 2048 + (lane & 15) * 128;
-            union { bf16x4 h[2]; bf16x8 b; } v;
-            v.h[0] = *(const bf16x4*)(row + ((((kk * 4 + (q >> 1)) ^ sw)) << 4) + (q & 1) * 8);
-            v.h[1] = *(const bf16x4*)(row + ((((kk * 4 + 2 + (q >> 1)) ^ sw)) << 4) + (q & 1) * 8);
-            fb[kk][j] = v.b;
-          }
-      } else {
-        fa[kk] = *(const bf16x8*)(mine + roff[kk]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < ntn) fb[kk][j] = *(const bf16x8*)(mine + 2048 + j * 2048 + roff[kk]);
-      }
+      for (int j = 0; j < 4; ++j)
+        if (j < ntn) fb[kk][j] = *(const bf16x8*)(mine + 2048 + j * 2048 + roff[kk]);
     }
     // the weight-side fragment goes in as the MFMA's A operand: acc[j][r] = C[m0 + (lane & 15)][j * 16 + (lane >> 4) * 4 + r]
 #pragma unroll
@@ -136,16 +104,131 @@ __global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __res
   }
 }
 
-template <bool F32OUT, bool TSTORE, bool AT = false>
+template <bool F32OUT, bool TSTORE>
 int launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, hipStream_t st) {
   constexpr int LDS = NW * REGION;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)rank_gemm_kernel<F32OUT, TSTORE, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)rank_gemm_kernel<F32OUT, TSTORE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  TASU_LAUNCH((rank_gemm_kernel<F32OUT, TSTORE, AT>), dim3((M + 15) / 16), dim3(64 * NW), LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, C,
+  TASU_LAUNCH((rank_gemm_kernel<F32OUT, TSTORE>), dim3((M + 15) / 16), dim3(64 * NW), LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, C,
               ldc, M, N, K);
+  return TASU_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The weight gradients' form: C[M, N] = At[K, M]^T . B[N, K]^T with the big operand K-MAJOR (dy [rows, out] / xd [rows, in] as the
+// step leaves them; no transposed copy).  64 x 64 tiles (a k-row of the tile is one whole 128-byte line -- the first version took
+// 16 columns = 32-byte pieces of a line per k-row and ran at a third of the speed), eight waves split K as above; a wave stages
+// its chunk's 64 k-rows of At and 64 rows of B into its private 16-KiB region with LDS-DMA and reads At back as MFMA operands
+// through the hardware transpose read (ds_read_tr16_b64: a 16-lane group reads 4 k-rows x 16 columns, every lane receives one
+// column's 4 k-values) -- k-slots {4q..4q+3, 16+4q..16+4q+3} of a 32-block for lane group q, so B's fragment is read as the two
+// matching 8-byte halves.  16-byte chunk c of k-row r sits at chunk c ^ (r & 7) (swizzle on the DMA's source side).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+constexpr int TN_REGION = 16384;                        // per wave: At 64 k-rows x 128 B, then B 64 x 128 B
+
+template <bool TSTORE>
+__global__ __launch_bounds__(64 * NW, 1) void rank_gemm_tn_kernel(const bf16* __restrict__ At, int ldat, const bf16* __restrict__ B, int ldb,
+                                                                  float* __restrict__ C, int ldc, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m0 = blockIdx.x * 64;                       // M % 64 == 0
+  const int ntn = (N + 15) >> 4;
+  char* mine = smem + wave * TN_REGION;
+  const bf16* ga[8];
+  const bf16* gb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int kr = i * 8 + (lane >> 3), c = (lane & 7) ^ (kr & 7);
+    ga[i] = At + (size_t)kr * ldat + m0 + c * 8;
+    const int r = i * 8 + (lane >> 3), cb = (lane & 7) ^ ((r >> 1) & 7);
+    gb[i] = B + (size_t)min(r, N - 1) * ldb + cb * 8;
+  }
+  const int l15 = lane & 15, q = lane >> 4, pp = lane & 3;
+  const int sw = (lane >> 1) & 7;                       // B rows: the swizzle of the kernel above
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nchunks = K >> 6;
+  for (int c = wave; c < nchunks; c += NW) {
+    const size_t koff = (size_t)c << 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + koff * ldat), (lds_void*)(mine + i * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i * 8 < N) __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + koff), (lds_void*)(mine + 8192 + i * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+      const int r0 = kk * 32 + 4 * q + ((lane >> 2) & 3), r1 = r0 + 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = i * 2 + (pp >> 1), inner = (pp & 1) * 8;
+        union { s16x4 h[2]; bf16x8 b; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(mine + r0 * 128 + ((ch ^ (r0 & 7)) << 4) + inner));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(mine + r1 * 128 + ((ch ^ (r1 & 7)) << 4) + inner));
+        fa[i] = u.b;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < ntn) {
+          const char* row = mine + 8192 + j * 2048 + l15 * 128;
+          union { bf16x4 h[2]; bf16x8 b; } v;
+          v.h[0] = *(const bf16x4*)(row + (((kk * 4 + (q >> 1)) ^ sw) << 4) + (q & 1) * 8);
+          v.h[1] = *(const bf16x4*)(row + (((kk * 4 + 2 + (q >> 1)) ^ sw) << 4) + (q & 1) * 8);
+          fb[j] = v.b;
+        }
+      // acc[i][j][r] = C[m0 + i * 16 + (lane & 15)][j * 16 + (lane >> 4) * 4 + r]
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < ntn) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this chunk's fragment reads are done before the next DMA lands on them
+  }
+  // partial tiles -> LDS (own region), summed in wave order: wave w finishes fragments 2 w and 2 w + 1
+  f32x4* part = (f32x4*)mine;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[(i * 4 + j) * 64 + lane] = acc[i][j];
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int f = wave * 2 + h, i = f >> 2, j = f & 3;
+    if (j >= ntn) continue;
+    f32x4 s = ((const f32x4*)smem)[f * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const f32x4 v = ((const f32x4*)(smem + w * TN_REGION))[f * 64 + lane];
+      s[0] += v[0], s[1] += v[1], s[2] += v[2], s[3] += v[3];
+    }
+    const int m = m0 + i * 16 + l15, n0 = j * 16 + q * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + r;
+      if (n >= N) break;
+      C[TSTORE ? (size_t)n * ldc + m : (size_t)m * ldc + n] = s[r];
+    }
+  }
+}
+
+template <bool TSTORE>
+int launch_tn(const void* At, int ldat, const void* B, int ldb, float* C, int ldc, int M, int N, int K, hipStream_t st) {
+  constexpr int LDS = NW * TN_REGION;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)rank_gemm_tn_kernel<TSTORE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  TASU_LAUNCH((rank_gemm_tn_kernel<TSTORE>), dim3(M / 64), dim3(64 * NW), LDS, st, (const bf16*)At, ldat, (const bf16*)B, ldb, C, ldc, M, N, K);
   return TASU_OK;
 }
 
@@ -161,14 +244,13 @@ extern "C" int tasu_gemm_nt_rank(const void* A, int lda, const void* B, int ldb,
   return transposed ? launch<false, true>(A, lda, B, ldb, C, ldc, M, N, K, st) : launch<false, false>(A, lda, B, ldb, C, ldc, M, N, K, st);
 }
 
-// The same product with A given K-major: C[M, N] = At[K, M]^T . B[N, K]^T -- a weight gradient straight from the step's row-major
-// activations / gradients (At = dy [rows, out] or xd [rows, in]), no transposed copy of the big operand.  fp32 output.
+// C[M, N] = At[K, M]^T . B[N, K]^T, A given K-major (include/tasu_hip.h): the adapters' weight gradients from the row-major dy / xd.
 extern "C" int tasu_gemm_tn_rank(const void* At, int ldat, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                                  int transposed, void* stream) {
-  if (!At || !B || !C || M <= 0 || M % 16 || N <= 0 || N > 64 || K <= 0 || K % 64 || ldat % 8 || ldb % 8 || ldat < M || ldb < K)
+  if (!At || !B || !C || M <= 0 || M % 64 || N <= 0 || N > 64 || K <= 0 || K % 64 || ldat % 8 || ldb % 8 || ldat < M || ldb < K)
     return TASU_ERR_ARG;
   if (((uintptr_t)At & 15) || ((uintptr_t)B & 15)) return TASU_ERR_ARG;
   if (ldc < (transposed ? M : N)) return TASU_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  return transposed ? launch<true, true, true>(At, ldat, B, ldb, C, ldc, M, N, K, st) : launch<true, false, true>(At, ldat, B, ldb, C, ldc, M, N, K, st);
+  return transposed ? launch_tn<true>(At, ldat, B, ldb, C, ldc, M, N, K, st) : launch_tn<false>(At, ldat, B, ldb, C, ldc, M, N, K, st);
 }

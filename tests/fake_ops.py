@@ -312,7 +312,7 @@ class FakeOps:
             c[:M, :N] = out
 
     def gemm_rank_tn(self, at, b, c, M, N, K, transposed=False):
-        assert N <= 64 and K % 64 == 0 and M % 16 == 0
+        assert N <= 64 and K % 64 == 0 and M % 64 == 0
         acc = at[:K, :M].float().t() @ b[:N, :K].float().t()
         if transposed:
             c[:N, :M] = acc.t()

@@ -179,7 +179,7 @@ def test_gemm_rank_vs_fp32(ops, M, N, K):
     assert torch.equal(c2, c[:, 8:8 + N])                                                              # deterministic
 
 
-@pytest.mark.parametrize("M,N,K", [(1536, 64, 4096), (8960, 64, 4096), (256, 64, 4096), (64, 16, 64), (1536, 64, 1984), (512, 40, 640)])
+@pytest.mark.parametrize("M,N,K", [(1536, 64, 4096), (8960, 64, 4096), (256, 64, 4096), (64, 16, 64), (1536, 64, 1984), (512, 40, 640), (128, 64, 512)])
 def test_gemm_rank_tn_vs_fp32_and_the_transposed_path(ops, M, N, K):
     """tasu_gemm_tn_rank (the adapters' weight gradients with the big operand K-major as the step leaves it: hardware transpose
     reads) against an fp32 product and against tasu_gemm_nt_rank on a transposed copy (same chunks, same wave order: equal up to
