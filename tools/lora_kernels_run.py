@@ -11,6 +11,10 @@ for K in (1536, 8960):                                            # rank GEMM u 
     a = torch.randn(M, K, device="cuda").to(bf); b = torch.randn(64, K, device="cuda").to(bf)
     c = torch.empty(M, 64, dtype=bf, device="cuda")
     for _ in range(3): ops.gemm_rank(a, b, c, M, 64, K)
+for Mo in (1536, 8960):                                           # weight gradient dB = dy^T u from the row-major dy (K = the step's rows)
+    at = torch.randn(M, Mo, device="cuda").to(bf); b = torch.randn(64, M, device="cuda").to(bf)
+    c = torch.empty(Mo, 64, dtype=f32, device="cuda")
+    for _ in range(3): ops.gemm_rank_tn(at, b, c, Mo, 64, M)
 for N in (1536, 8960):                                            # fused accumulate dx += mask . (du A)
     y = torch.randn(M, N, device="cuda").to(bf); u = torch.randn(M, 64, device="cuda").to(bf); w = torch.randn(N, 64, device="cuda").to(bf)
     for _ in range(3): ops.lora_apply(y, u, w, M, N, 64, p=0.05, rng=rng, sid=3)
