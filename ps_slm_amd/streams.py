@@ -13,7 +13,7 @@ import time
 import torch
 
 _SPIN_CYCLES = 400_000            # ~0.17 ms at 2.4 GHz: long against launch latency, short enough to probe a dozen pairs
-_state = {}                       # device index -> dict(candidates=[...], taken=[...])
+_state = {}                       # device index -> dict(reps=[one stream per hardware queue other than the main one], next=round-robin position)
 
 
 def _pair_seconds(a, b):
@@ -40,9 +40,31 @@ def runs_concurrently(a, b):
     return pair < 1.5 * one
 
 
+def _classes(idx):
+    """The pooled candidates grouped by hardware queue (probed once per device): one representative stream per queue that is NOT
+    the current stream's queue."""
+    st = _state.get(idx)
+    if st is not None:
+        return st
+    main = torch.cuda.current_stream()
+    reps = []
+    for _ in range(12):
+        c = torch.cuda.Stream(device=idx)
+        if not runs_concurrently(main, c):
+            continue                                      # shares the main stream's queue
+        if all(runs_concurrently(r, c) for r in reps):
+            reps.append(c)                                # a queue not seen yet
+        if len(reps) == 3:                                # 4 hardware queues per device: main + 3
+            break
+    st = _state[idx] = dict(reps=reps, next=0)
+    return st
+
+
 def side_stream(device):
-    """A stream for work that is to overlap with the CURRENT stream of ``device`` (and with the side streams handed out before).
-    None on a CPU device.  Never call inside a hipGraph capture (it launches and synchronises)."""
+    """A stream for work that is to overlap with the CURRENT stream of ``device``: callers get the device's other hardware
+    queues in turn (the first three calls three different queues -- gradient exchange, adapters' weight gradients, encoder ahead --
+    later calls share them round-robin).  None on a CPU device.  Never call inside a hipGraph capture (the first call per device
+    launches probe kernels and synchronises)."""
     device = torch.device(device)
     if device.type != "cuda":
         return None
@@ -50,23 +72,9 @@ def side_stream(device):
     if not hasattr(torch.cuda, "_sleep"):                 # (no spin kernel to probe with: any stream)
         return torch.cuda.Stream(device=idx)
     with torch.cuda.device(idx):
-        st = _state.setdefault(idx, dict(candidates=[], taken=[]))
-        main = torch.cuda.current_stream()
-        best = None
-        for n in range(12):
-            if n >= len(st["candidates"]):
-                st["candidates"].append(torch.cuda.Stream(device=idx))
-            c = st["candidates"][n]
-            if any(c is t for t in st["taken"]):
-                continue
-            if not runs_concurrently(main, c):
-                continue
-            if best is None:
-                best = c                                  # overlaps with the main stream at least
-            if all(runs_concurrently(t, c) for t in st["taken"]):
-                best = c
-                break
-        if best is None:                                  # (a runtime with one hardware queue: overlap is then impossible anyway)
-            best = torch.cuda.Stream(device=idx)
-        st["taken"].append(best)
-        return best
+        st = _classes(idx)
+        if not st["reps"]:                                # (a runtime with one hardware queue: overlap is impossible anyway)
+            return torch.cuda.Stream(device=idx)
+        s_ = st["reps"][st["next"] % len(st["reps"])]
+        st["next"] += 1
+        return s_
