@@ -439,9 +439,9 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         # HBM-side bytes per GEMM launch are NOT measured by this run (PMC counters need their own rocprofv3 --pmc passes):
         # the offline per-shape figures are in the cited file
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_gemm_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r04_gemm_pmc.json")
         if os.path.isfile(pmc) and model_name == "qwen2.5-1.5b" and B == 16 and not audio and not variable:
-            traffic_src = ("not measured by this run; offline: profiles/r03_gemm_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+            traffic_src = ("not measured by this run; offline: profiles/r04_gemm_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                            f"passes over tools/gemm_shapes_run.py, gfx950 x2 fetch correction): "
                            f"{json.load(open(pmc)).get('traffic_bytes_per_launch')} bytes per launch, launch-count-weighted")
         what = ("audio-SFT step (500 feature frames -> SANM encoder -> CTC posterior -> PSD -> projector -> LLM fwd+dgrad bwd+"
