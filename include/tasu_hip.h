@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 8
+#define TASU_ABI_VERSION 9
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -292,10 +292,32 @@ int tasu_attn_bwd(const void* qkv, const void* qt, const void* kt, const uint8_t
 #define TASU_ATTN_KERNEL_POLICY 0
 #define TASU_ATTN_KERNEL_PER_HEAD 1
 #define TASU_ATTN_KERNEL_GQA 2
+#define TASU_ATTN_KERNEL_SP 3
 int tasu_attn_gqa_supported(int S, int H, int G);
 int tasu_attn_bwd_rope(const void* qkv, const uint8_t* key_mask, const void* dout, const float* lse, const float* delta,
                        const float* cos_tab, const float* sin_tab, void* dqkv, float* dk_part, float* dv_part, int B, int S,
                        int H, int G, float scale, int causal, int kernel, void* stream);
+/* Round 5: single-pass kernels for sequences of at most 256 (padded) positions (csrc/attention_sp.hip) -- the alignment step's
+ * decoder attention (SDPA in Qwen2Attention.forward, modeling_qwen2.py:150-172, via /root/reference/Multitask/model/ps-slm.py:530).
+ * The whole K / V (forward, dQ) or Q / dO (dK / dV) of one (batch, head) is resident in LDS (128 KiB, one LDS-DMA burst): QK^T
+ * against every visible key, ONE softmax, ONE P.V -- no key-tile loop, no online rescale.  Same results as the tiled kernels up
+ * to the association of the fp32 sums (softmax denominators, dK / dV over the heads of a group).
+ *   tasu_attn_sp_supported  1 when Spad <= 256, H % G == 0 and G <= 16
+ *   tasu_attn_fwd_kernel    tasu_attn_fwd on a chosen kernel: TASU_ATTN_KERNEL_PER_HEAD = the tiled kernel (any S), _SP = the
+ *                           single-pass kernel (bad argument when unsupported), _POLICY = single-pass where supported; tasu_attn_fwd
+ *                           is the _POLICY form
+ *   tasu_attn_bwd_fused     the WHOLE attention backward: delta = rowsum(dO . O) (tasu_attn_bwd_prep), dQ / dK / dV and the rotary
+ *                           embedding's backward; `out` = the forward's output.  _SP: two launches (delta is computed inside the
+ *                           kernel, `delta` is not touched; dk_part / dv_part = fp32 [M, H * 128] each: one partial per QUERY head,
+ *                           summed over the group's heads, un-rotated and rounded by the second launch); _PER_HEAD / _GQA:
+ *                           tasu_attn_bwd_prep + tasu_attn_bwd_rope with that kernel (`delta` [B, H, Spad] scratch required);
+ *                           _POLICY: _SP where supported, else tasu_attn_bwd_rope's policy                                   */
+int tasu_attn_sp_supported(int S, int H, int G);
+int tasu_attn_fwd_kernel(const void* qkv, const uint8_t* key_mask, void* out, float* lse, int B, int S, int H, int G, float scale,
+                         int causal, int kernel, void* stream);
+int tasu_attn_bwd_fused(const void* qkv, const uint8_t* key_mask, const void* dout, const void* out, const float* lse, float* delta,
+                        const float* cos_tab, const float* sin_tab, void* dqkv, float* dk_part, float* dv_part, int B, int S, int H,
+                        int G, float scale, int causal, int kernel, void* stream);
 
 /* -------------------------------------------------------------------------------------------- SwiGLU
  * act = bf16(bf16(silu(gate)) * up) on the fused [M, 2I] gate|up activation (modeling_qwen2.py:46-48),

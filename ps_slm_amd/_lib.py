@@ -37,6 +37,9 @@ PROTOTYPES = {
     "tasu_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "tasu_attn_gqa_supported": [i32, i32, i32],
     "tasu_attn_bwd_rope": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp],
+    "tasu_attn_sp_supported": [i32, i32, i32],
+    "tasu_attn_fwd_kernel": [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp],
+    "tasu_attn_bwd_fused": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp],
     "tasu_attn_bwd_dkv": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "tasu_swiglu_fwd": [vp, vp, i32, i32, vp],
     "tasu_swiglu_bwd": [vp, vp, vp, i32, i32, vp],
@@ -122,7 +125,7 @@ PROTOTYPES.update({
     "tasu_allreduce_min_i32": [vp, vp, i64, vp],
 })
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 

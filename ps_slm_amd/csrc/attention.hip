@@ -463,10 +463,38 @@ int tasu_attn_bwd_gqa_launch(const void* qkv, const uint8_t* key_mask, const voi
                              const float* cos_tab, const float* sin_tab, void* dqkv, int B, int S, int H, int G, float scale, int causal,
                              hipStream_t stream);
 
+// attention_sp.hip
+extern "C" int tasu_attn_sp_supported(int S, int H, int G);
+int tasu_attn_sp_fwd_launch(const void* qkv, const uint8_t* key_mask, void* out, float* lse, int B, int S, int H, int G, float scale,
+                            int causal, hipStream_t stream);
+int tasu_attn_sp_bwd_launch(const void* qkv, const uint8_t* key_mask, const void* dout, const void* out, const float* lse,
+                            const float* cos_tab, const float* sin_tab, void* dqkv, float* dk_part, float* dv_part, int B, int S, int H,
+                            int G, float scale, int causal, hipStream_t stream);
+
+static int attn_fwd_tiled(const void* qkv, const uint8_t* key_mask, void* out, float* lse, int B, int S, int H, int G, float scale,
+                          int causal, void* stream);
+
+extern "C" int tasu_attn_fwd_kernel(const void* qkv, const uint8_t* key_mask, void* out, float* lse, int B, int S, int H, int G,
+                                    float scale, int causal, int kernel, void* stream) {
+  if (!qkv || !key_mask || !out || !lse || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
+  if (kernel != TASU_ATTN_KERNEL_POLICY && kernel != TASU_ATTN_KERNEL_PER_HEAD && kernel != TASU_ATTN_KERNEL_SP) return TASU_ERR_ARG;
+  const bool sp_ok = tasu_attn_sp_supported(S, H, G) != 0;
+  if (kernel == TASU_ATTN_KERNEL_SP && !sp_ok) return TASU_ERR_ARG;
+  // policy: the single-pass kernel wherever it serves (at most 256 padded positions: the alignment step's decoder)
+  if (kernel == TASU_ATTN_KERNEL_SP || (kernel == TASU_ATTN_KERNEL_POLICY && sp_ok))
+    return tasu_attn_sp_fwd_launch(qkv, key_mask, out, lse, B, S, H, G, scale, causal, (hipStream_t)stream);
+  return attn_fwd_tiled(qkv, key_mask, out, lse, B, S, H, G, scale, causal, stream);
+}
+
 extern "C" int tasu_attn_fwd(const void* qkv, const void* vt, const uint8_t* key_mask, void* out, float* lse, int B,
                              int S, int H, int G, float scale, int causal, void* stream) {
   (void)vt;                                              // unused since round 2: V^T is read out of the V tile in LDS
-  if (!qkv || !key_mask || !out || !lse || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
+  return tasu_attn_fwd_kernel(qkv, key_mask, out, lse, B, S, H, G, scale, causal, TASU_ATTN_KERNEL_POLICY, stream);
+}
+
+static int attn_fwd_tiled(const void* qkv, const uint8_t* key_mask, void* out, float* lse, int B, int S, int H, int G, float scale,
+                          int causal, void* stream) {
+  const void* vt = nullptr;
   static const int qw2_from = [] { const char* e = tasu_lab_env("TASU_ATTN_QW2_FROM"); return e ? atoi(e) : 1 << 30; }();
   if (S >= qw2_from) {
     // two query sub-tiles per wave (128-query blocks): half the LDS traffic per FLOP of the one-sub-tile form.  Measured at the
@@ -558,4 +586,26 @@ extern "C" int tasu_attn_bwd_rope(const void* qkv, const uint8_t* key_mask, cons
   const int rc = tasu_attn_bwd(qkv, nullptr, nullptr, key_mask, dout, nullptr, lse, delta, dqkv, dk_part, dv_part, B, S, H, G, scale,
                                causal, stream);
   return rc ? rc : tasu_rope_bwd(dqkv, dk_part, dv_part, cos_tab, sin_tab, B, S, H, G, stream);
+}
+
+// The whole attention backward behind one entry point: delta = rowsum(dO . O), dQ / dK / dV, the rotary embedding's backward.
+// `kernel`: TASU_ATTN_KERNEL_SP = the single-pass kernels of attention_sp.hip (two launches, delta computed inside, `delta`
+// untouched); _PER_HEAD / _GQA = tasu_attn_bwd_prep + tasu_attn_bwd_rope with that kernel; _POLICY = single-pass where it serves
+// (Spad <= 256), else tasu_attn_bwd_rope's own policy.  dk_part / dv_part: fp32 [M, H * 128] each.
+extern "C" int tasu_attn_bwd_fused(const void* qkv, const uint8_t* key_mask, const void* dout, const void* out, const float* lse,
+                                   float* delta, const float* cos_tab, const float* sin_tab, void* dqkv, float* dk_part, float* dv_part,
+                                   int B, int S, int H, int G, float scale, int causal, int kernel, void* stream) {
+  if (!qkv || !key_mask || !dout || !out || !lse || !cos_tab || !sin_tab || !dqkv || bad_geo(B, S, H, G)) return TASU_ERR_ARG;
+  if (kernel < TASU_ATTN_KERNEL_POLICY || kernel > TASU_ATTN_KERNEL_SP) return TASU_ERR_ARG;
+  const bool sp_ok = tasu_attn_sp_supported(S, H, G) != 0;
+  if (kernel == TASU_ATTN_KERNEL_SP && !sp_ok) return TASU_ERR_ARG;
+  if (kernel == TASU_ATTN_KERNEL_SP || (kernel == TASU_ATTN_KERNEL_POLICY && sp_ok)) {
+    if (!dk_part || !dv_part) return TASU_ERR_ARG;
+    return tasu_attn_sp_bwd_launch(qkv, key_mask, dout, out, lse, cos_tab, sin_tab, dqkv, dk_part, dv_part, B, S, H, G, scale, causal,
+                                   (hipStream_t)stream);
+  }
+  if (!delta) return TASU_ERR_ARG;
+  const int rc = tasu_attn_bwd_prep(dout, out, delta, nullptr, B, S, H, stream);
+  return rc ? rc : tasu_attn_bwd_rope(qkv, key_mask, dout, lse, delta, cos_tab, sin_tab, dqkv, dk_part, dv_part, B, S, H, G, scale, causal,
+                                      kernel, stream);
 }

@@ -539,9 +539,8 @@ class LoraRunner:
         ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)
         if "o" in groups:
             self.group_bwd(l, "o", groups["o"], dxb, D, M, stored("o", H * HD, shared=d["ao"][l]), dao, drop)
-        ops.attn_bwd_prep(dao, d["ao"][l], delta, None, B, S, H)
         self._wait_side("qkv")                                        # (the previous layer's chain over dqkv)
-        ops.attn_bwd_rope(d["qkv"][l], d["key_mask"], dao, d["lse"][l], delta, cos, sin, dqkv, dkp, dvp, B, S, H, G, scale, True)
+        ops.attn_bwd_fused(d["qkv"][l], d["key_mask"], dao, d["ao"][l], d["lse"][l], delta, cos, sin, dqkv, dkp, dvp, B, S, H, G, scale, True)
         ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)
         if "qkv" in groups:
             self.group_bwd(l, "qkv", groups["qkv"], dqkv, LDQ, M, stored("qkv", D), dn, drop)

@@ -991,10 +991,9 @@ class TasuModel:
                 ops.gemm(dgu, w["wgu_t"], dn, M, D, 2 * I)
                 ops.rmsnorm_bwd(dn, x_mid, w["ln2"], rstd[2 * l + 1], dx, dxb, True)
             ops.gemm(dxb, w["wo_t"], dao, M, H * HD, D)
-            ops.attn_bwd_prep(dao, d["ao"][l], delta, None, B, S, H)
-            # dQ, dK / dV and the rotary embedding's backward: one launch on the GQA kernels (dK / dV complete in their
-            # workgroups, the rotation in the epilogues); dkp / dvp are the per-head kernels' fp32 partials (H == G geometries)
-            ops.attn_bwd_rope(d["qkv"][l], d["key_mask"], dao, d["lse"][l], delta, cos, sin, dqkv, dkp, dvp, B, S, H, G, scale, True)
+            # delta = rowsum(dO . O), dQ, dK / dV and the rotary embedding's backward behind one entry point: the single-pass kernels
+            # for Spad <= 256 (delta inside the kernel; dkp / dvp = one fp32 partial per query head), else the tiled kernels
+            ops.attn_bwd_fused(d["qkv"][l], d["key_mask"], dao, d["ao"][l], d["lse"][l], delta, cos, sin, dqkv, dkp, dvp, B, S, H, G, scale, True)
             ops.gemm(dqkv, w["wqkv_t"], dn, M, D, LDQ)
             ops.rmsnorm_bwd(dn, x_in, w["ln1"], rstd[2 * l], dx, dxb, True)
         if lora is not None:
@@ -1143,15 +1142,23 @@ class TasuModel:
     def _shape_key(self, st, tag):
         return (tag, st.path, st.B, st.S, st.Ra, st.Rap, st.Fap, st.nLp, self.keep_logits, self.lora is not None and self.training)
 
+    def _mark_dropout(self, st):
+        """Whether THIS step's forward draws LoRA dropout masks -- recorded on the step state by host code that runs on every
+        call.  forward_llm sets the same flag, but its Python body only runs at capture time: on a hipGraph replay a fresh
+        StepState would keep the default False, and a backward captured then would regenerate no masks."""
+        st.lora_drop = bool(self._lora_run is not None and self._lora_run._drop_on(self.training))
+
     def run_forward_text(self, st, compute_loss=True, need_backward=True):
         """forward_projector_text + forward_llm, graph-replayed when enabled."""
         def fn():
             self.forward_projector_text(st)
             self.forward_llm(st, compute_loss=compute_loss, need_backward=need_backward)
+        self._mark_dropout(st)
         self._graphed(self._shape_key(st, ("fwd_text", compute_loss, need_backward)), fn, st)
 
     def run_forward_llm(self, st, compute_loss=True, need_backward=True):
         """forward_llm alone (audio branch: the projector has already run eagerly behind the host-side PSD plan)."""
+        self._mark_dropout(st)
         self._graphed(self._shape_key(st, ("fwd_llm", compute_loss, need_backward)),
                       lambda: self.forward_llm(st, compute_loss=compute_loss, need_backward=need_backward), st)
 

@@ -286,6 +286,21 @@ class HipOps:
         self._chk(self.lib.tasu_attn_fwd(_p(qkv), _p(vt), _p(key_mask), _p(out), _p(lse), B, S, H, G, scale, int(causal),
                                          self._stream()), "tasu_attn_fwd")
 
+    ATTN_KERNELS = {"policy": 0, "tiled": 1, "gqa": 2, "sp": 3}
+
+    def attn_fwd_on(self, kernel, qkv, key_mask, out, lse, B, S, H, G, scale, causal):
+        """attn_fwd on a NAMED kernel (tasu_attn_fwd_kernel): "tiled" (attention.hip) or "sp" (single pass, Spad <= 256)."""
+        self._chk(self.lib.tasu_attn_fwd_kernel(_p(qkv), _p(key_mask), _p(out), _p(lse), B, S, H, G, scale, int(causal),
+                                                self.ATTN_KERNELS[kernel], self._stream()), "tasu_attn_fwd_kernel")
+
+    def attn_bwd_fused(self, qkv, key_mask, dout, out, lse, delta, cos, sin, dqkv, dk_part, dv_part, B, S, H, G, scale, causal,
+                       kernel="policy"):
+        """The whole attention backward (delta, dQ / dK / dV, rotary backward) behind one entry point (tasu_attn_bwd_fused): the
+        single-pass kernels where Spad <= 256, else attn_bwd_prep + attn_bwd_rope.  dk_part / dv_part: fp32 [M, H * 128]."""
+        self._chk(self.lib.tasu_attn_bwd_fused(_p(qkv), _p(key_mask), _p(dout), _p(out), _p(lse), _p(delta), _p(cos), _p(sin), _p(dqkv),
+                                               _p(dk_part), _p(dv_part), B, S, H, G, scale, int(causal), self.ATTN_KERNELS[kernel],
+                                               self._stream()), "tasu_attn_bwd_fused")
+
     def attn_bwd_prep(self, dout, out, delta, dout_t, B, S, H):
         self._chk(self.lib.tasu_attn_bwd_prep(_p(dout), _p(out), _p(delta), _p(dout_t), B, S, H, self._stream()),
                   "tasu_attn_bwd_prep")

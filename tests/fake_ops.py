@@ -267,6 +267,14 @@ class FakeOps:
         self.attn_bwd(qkv, None, None, key_mask, dout, None, lse, delta, dqkv, dk_part, dv_part, B, S, H, G, scale, causal)
         self.rope_bwd(dqkv, dk_part, dv_part, cos, sin, B, S, H, G)
 
+    def attn_fwd_on(self, kernel, qkv, key_mask, out, lse, B, S, H, G, scale, causal):
+        self.attn_fwd(qkv, None, key_mask, out, lse, B, S, H, G, scale, causal)
+
+    def attn_bwd_fused(self, qkv, key_mask, dout, out, lse, delta, cos, sin, dqkv, dk_part, dv_part, B, S, H, G, scale, causal,
+                       kernel="policy"):
+        self.attn_bwd_prep(dout, out, delta, None, B, S, H)
+        self.attn_bwd_rope(qkv, key_mask, dout, lse, delta, cos, sin, dqkv, dk_part, dv_part, B, S, H, G, scale, causal)
+
     def swiglu_fwd(self, gu, act, M, I):
         g, u = gu[:, :I].float(), gu[:, I:].float()
         act.copy_(_bf(_bf(F.silu(g)).float() * u))

@@ -509,6 +509,75 @@ def test_attention_bwd_gqa_kernel_equals_per_head_kernels(hip, fake, B, S, H, G,
     assert torch.equal(r0, r2 if takes_gqa else r1)
 
 
+@pytest.mark.parametrize("B,S,H,G", [(2, 100, 4, 2), (2, 256, 12, 2), (3, 64, 2, 1), (1, 192, 4, 4), (1, 19, 6, 2), (2, 130, 10, 2),
+                                     (1, 256, 28, 4), (2, 249, 12, 2), (16, 256, 12, 2)])
+@pytest.mark.parametrize("mask_kind", ["right", "left", "none"])
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_single_pass_kernels(hip, fake, B, S, H, G, mask_kind, causal):
+    """csrc/attention_sp.hip (Spad <= 256: the whole K / V or Q / dO of a (batch, head) resident in LDS, one softmax, delta inside
+    the backward kernel, per-query-head dK / dV partials + the reduce / rotary launch) against the torch double AND against the
+    tiled kernels: forward out / lse, and the finished gradient of the unrotated q | k | v projection, for ragged lengths (S not
+    a multiple of 16 / 32 / 64 / 128), 1-7 heads per group, left / right key padding, causal and bidirectional."""
+    if B == 16 and (mask_kind != "none" or not causal):
+        pytest.skip("the benchmark shape once")
+    M, LD, Spad = B * S, (H + 2 * G) * HD, (S + 63) // 64 * 64
+    scale = HD ** -0.5
+    assert hip.lib.tasu_attn_sp_supported(S, H, G) == 1 and hip.lib.tasu_attn_sp_supported(257, H, G) == 0
+    qkv = randn(M, LD, dtype=BF, seed=21)
+    km = make_mask(B, S, mask_kind)
+    live = km[:, :S].bool()
+    pos = torch.arange(S, dtype=I32).repeat(B)
+    cos, sin = torch.zeros(M, 64), torch.zeros(M, 64)
+    fake.rope_table(pos, cos, sin, HD, 1e6)
+    # forward: double, tiled kernel, single-pass kernel
+    oc, lc = torch.zeros(M, H * HD, dtype=BF), torch.zeros(B * H * Spad)
+    fake.attn_fwd(qkv, None, km, oc, lc, B, S, H, G, scale, causal)
+    res = {}
+    for kernel in ("tiled", "sp"):
+        o, l = torch.full((M, H * HD), 3.0, dtype=BF).cuda(), torch.zeros(B * H * Spad).cuda()
+        hip.attn_fwd_on(kernel, qkv.cuda(), km.cuda(), o, l, B, S, H, G, scale, causal)
+        res[kernel] = (o.cpu(), l.cpu())
+    lm = live[:, None, :].expand(B, H, S)
+    for kernel in ("tiled", "sp"):
+        o, l = res[kernel]
+        assert rel_err(o.view(B, S, H, HD)[live], oc.view(B, S, H, HD)[live]) < 2e-2, kernel
+        assert float((l.view(B, H, Spad)[..., :S] - lc.view(B, H, Spad)[..., :S])[lm].abs().max()) < 2e-3, kernel
+    # the two kernels differ in where P is rounded to bf16 (against the running / the final row maximum) and in the association
+    # of the sums: a few bf16 steps of the largest element
+    a, c = res["sp"][0].view(B, S, H, HD)[live].float(), res["tiled"][0].view(B, S, H, HD)[live].float()
+    assert rel_err(a, c) < 2 ** -6
+    # the policy entry point takes the single-pass kernel here
+    o, l = torch.zeros(M, H * HD, dtype=BF).cuda(), torch.zeros(B * H * Spad).cuda()
+    hip.attn_fwd(qkv.cuda(), None, km.cuda(), o, l, B, S, H, G, scale, causal)
+    assert torch.equal(o.cpu().view(B, S, H, HD)[live], res["sp"][0].view(B, S, H, HD)[live])
+    # backward: the whole chain behind one entry point
+    dout = randn(M, H * HD, dtype=BF, seed=22)
+    dout.view(B, S, H, HD)[~live] = 0
+    out_g, lse_g = res["sp"][0], res["sp"][1]
+    want = torch.zeros(M, LD, dtype=BF)
+    fake.attn_bwd_fused(qkv, km, dout, out_g, lse_g, torch.zeros(B * H * Spad), cos, sin, want, torch.zeros(M, H * HD),
+                        torch.zeros(M, H * HD), B, S, H, G, scale, causal)
+    got = {}
+    for kernel in ("tiled", "sp", "policy"):
+        dq = torch.full((M, LD), 7.0, dtype=BF).cuda()
+        hip.attn_bwd_fused(qkv.cuda(), km.cuda(), dout.cuda(), out_g.cuda(), lse_g.cuda(), torch.zeros(B * H * Spad).cuda(), cos.cuda(),
+                           sin.cuda(), dq, torch.zeros(M, H * HD).cuda(), torch.zeros(M, H * HD).cuda(), B, S, H, G, scale, causal, kernel)
+        got[kernel] = dq.cpu().view(B, S, LD)[live]
+    w = want.view(B, S, LD)[live]
+    assert torch.isfinite(got["sp"].float()).all()
+    for lo, hi in ((0, H * HD), (H * HD, (H + G) * HD), ((H + G) * HD, (H + 2 * G) * HD)):
+        for kernel in ("tiled", "sp"):
+            assert rel_err(got[kernel][:, lo:hi], w[:, lo:hi]) < 2e-2, (kernel, lo)
+        a, c = got["sp"][:, lo:hi].float(), got["tiled"][:, lo:hi].float()
+        assert rel_err(a, c) < 2 ** -6                     # the same products in another fp32 association
+    assert torch.equal(got["policy"], got["sp"])
+    # bitwise repeatable (no atomics anywhere in the chain)
+    dq2 = torch.zeros(M, LD, dtype=BF).cuda()
+    hip.attn_bwd_fused(qkv.cuda(), km.cuda(), dout.cuda(), out_g.cuda(), lse_g.cuda(), None, cos.cuda(), sin.cuda(), dq2,
+                       torch.zeros(M, H * HD).cuda(), torch.zeros(M, H * HD).cuda(), B, S, H, G, scale, causal, "sp")
+    assert torch.equal(dq2.cpu().view(B, S, LD)[live], got["sp"])
+
+
 def test_attention_online_softmax_rescale(hip, fake):
     """Force the running-max rescale branch: one late key dominates every earlier tile."""
     B, S, H, G = 1, 256, 2, 1
@@ -519,9 +588,10 @@ def test_attention_online_softmax_rescale(hip, fake):
     km = make_mask(B, S, "none")
     qt, kt, vt = (torch.zeros(B * n * HD * Spad, dtype=BF) for n in (H, G, G))
     fake.rope_fwd(qkv, torch.ones(M, 64), torch.zeros(M, 64), qt, kt, vt, B, S, H, G)
-    (oc, lc), (og, lg) = run_pair(hip, fake, "attn_fwd", [qkv, vt, km, torch.zeros(M, H * HD, dtype=BF), torch.zeros(B * H * Spad),
-                                                          B, S, H, G, HD ** -0.5, True], [3, 4])
-    assert rel_err(og, oc) < 2e-2 and float((lg - lc).abs().max()) < 2e-3
+    for kernel in ("tiled", "sp"):                             # (the single-pass kernel has no rescale: the same answer)
+        (oc, lc), (og, lg) = run_pair(hip, fake, "attn_fwd_on", [kernel, qkv, km, torch.zeros(M, H * HD, dtype=BF), torch.zeros(B * H * Spad),
+                                                                 B, S, H, G, HD ** -0.5, True], [3, 4])
+        assert rel_err(og, oc) < 2e-2 and float((lg - lc).abs().max()) < 2e-3
 
 
 @pytest.mark.parametrize("D", [256, 1536, 3584, 512])

@@ -451,3 +451,22 @@ def test_freeze_projector_trains_the_adapters_only(tmp_path):
     m2, _ = model_factory(TrainConfig(freeze_llm=True, gt_emb=True, ctc_posterior=True, freeze_projector=True),
                           ModelConfig(llm_path="synthetic:mid", encoder_projector="linear", encoder_projector_ds_rate=1, llm_dim=256), device="cpu", ops=FakeOps())
     assert m2.core.freeze_projector is False
+
+
+def test_dropout_flag_survives_a_graph_replay_of_the_forward():
+    """``st.lora_drop`` was set inside forward_llm, i.e. only when the Python body ran.  A hipGraph replay of the
+    forward (no Python) left a fresh StepState at False, and a backward captured right then regenerated no dropout masks for that
+    shape -- silently wrong adapter gradients from then on.  The flag is now recorded by run_forward_* outside the captured
+    region: emulate a replay (``_graphed`` that does not call its function) and check the step state."""
+    z, geo, cfg, sd, lsd, _ = golden_case("mid_text_lora_drop")
+    model = build(geo, cfg, sd, lsd, FakeOps(), "cpu", rng=z["rng"])
+    model.training = True
+    calls = []
+    model._graphed = lambda key, fn, st: calls.append(key)                 # a replay: the captured launches run, Python does not
+    st = type("St", (), {"lora_drop": False, "dev": {}, "path": "text", "B": 1, "S": 1, "Ra": 0, "Rap": 0, "Fap": 0, "nLp": 0})()
+    model.run_forward_text(st)
+    assert calls and st.lora_drop is True
+    model.training = False
+    st2 = type("St", (), {"lora_drop": True, "dev": {}, "path": "text", "B": 1, "S": 1, "Ra": 0, "Rap": 0, "Fap": 0, "nLp": 0})()
+    model.run_forward_llm(st2)
+    assert st2.lora_drop is False                                          # eval mode: no masks, whatever the state held before
