@@ -27,6 +27,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from ps_slm_amd.streams import ensure_hw_queues, report as stream_report     # noqa: E402
+
+ensure_hw_queues()                     # before the first HIP call: a hardware queue each for the main stream and the side-stream roles
+
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
@@ -500,6 +504,8 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                                      f"(event pairs around every wait); bucket exchanged in {len(core.grad_ranges(engine.w1_chunks))} ranges.  Expected "
                                      f"on 8 xGMI-connected GPUs: ~0.35 ms (the last 51-MB row block of the Linear1 weight gradient at "
                                      f"the ~300 GB/s bus bandwidth RCCL reaches; the whole 218-MB bucket would be ~1.3 ms), DESIGN.md 6")
+        if on_gpu and (core.lora is not None or audio or world > 1):
+            rec["side_streams"] = stream_report(device)   # which hardware queue every overlap role got (ps_slm_amd/streams.py)
         if want_decode:
             rec["decode"] = decode_leg(core, raw, B, new_tokens=200 if model_name != "qwen2.5-7b" else 64)
     engine.destroy()                                    # RCCL communicator, before the process group goes

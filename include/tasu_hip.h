@@ -304,14 +304,16 @@ int tasu_attn_bwd_rope(const void* qkv, const uint8_t* key_mask, const void* dou
  * to the association of the fp32 sums (softmax denominators, dK / dV over the heads of a group).
  *   tasu_attn_sp_supported  1 when Spad <= 256, H % G == 0 and G <= 16
  *   tasu_attn_fwd_kernel    tasu_attn_fwd on a chosen kernel: TASU_ATTN_KERNEL_PER_HEAD = the tiled kernel (any S), _SP = the
- *                           single-pass kernel (bad argument when unsupported), _POLICY = single-pass where supported; tasu_attn_fwd
- *                           is the _POLICY form
+ *                           single-pass kernel (bad argument when unsupported), _POLICY = single-pass where measured faster (its
+ *                           grid of B * H one-per-CU workgroups about one or two whole rounds of the chip); tasu_attn_fwd is the
+ *                           _POLICY form
  *   tasu_attn_bwd_fused     the WHOLE attention backward: delta = rowsum(dO . O) (tasu_attn_bwd_prep), dQ / dK / dV and the rotary
  *                           embedding's backward; `out` = the forward's output.  _SP: two launches (delta is computed inside the
  *                           kernel, `delta` is not touched; dk_part / dv_part = fp32 [M, H * 128] each: one partial per QUERY head,
  *                           summed over the group's heads, un-rotated and rounded by the second launch); _PER_HEAD / _GQA:
  *                           tasu_attn_bwd_prep + tasu_attn_bwd_rope with that kernel (`delta` [B, H, Spad] scratch required);
- *                           _POLICY: _SP where supported, else tasu_attn_bwd_rope's policy                                   */
+ *                           _POLICY: _SP where measured faster (Spad <= 256 and 3 B H <= 320: small batches), else
+ *                           tasu_attn_bwd_rope's policy                                                                      */
 int tasu_attn_sp_supported(int S, int H, int G);
 int tasu_attn_fwd_kernel(const void* qkv, const uint8_t* key_mask, void* out, float* lse, int B, int S, int H, int G, float scale,
                          int causal, int kernel, void* stream);

@@ -480,8 +480,12 @@ extern "C" int tasu_attn_fwd_kernel(const void* qkv, const uint8_t* key_mask, vo
   if (kernel != TASU_ATTN_KERNEL_POLICY && kernel != TASU_ATTN_KERNEL_PER_HEAD && kernel != TASU_ATTN_KERNEL_SP) return TASU_ERR_ARG;
   const bool sp_ok = tasu_attn_sp_supported(S, H, G) != 0;
   if (kernel == TASU_ATTN_KERNEL_SP && !sp_ok) return TASU_ERR_ARG;
-  // policy: the single-pass kernel wherever it serves (at most 256 padded positions: the alignment step's decoder)
-  if (kernel == TASU_ATTN_KERNEL_SP || (kernel == TASU_ATTN_KERNEL_POLICY && sp_ok))
+  // policy (tools/bench_attn_sp.py, us per layer, tiled -> single pass): 16 x 256 x 12 heads 18.9 -> 18.0, 16 x 256 x 28 heads
+  // 35.5 -> 34.9, 8 x 256 x 12 13.4 -> 15.6, 32 x 256 x 12 33.7 -> 35.2: one workgroup per (batch, head) with 128 KiB of LDS is one
+  // per CU, so the single-pass kernel wins (narrowly) only when its grid is about one or two whole rounds of the 256 CUs
+  const int nwg = B * H;
+  const bool sp_take = sp_ok && ((nwg >= 176 && nwg <= 256) || (nwg >= 432 && nwg <= 512));
+  if (kernel == TASU_ATTN_KERNEL_SP || (kernel == TASU_ATTN_KERNEL_POLICY && sp_take))
     return tasu_attn_sp_fwd_launch(qkv, key_mask, out, lse, B, S, H, G, scale, causal, (hipStream_t)stream);
   return attn_fwd_tiled(qkv, key_mask, out, lse, B, S, H, G, scale, causal, stream);
 }
@@ -590,8 +594,8 @@ extern "C" int tasu_attn_bwd_rope(const void* qkv, const uint8_t* key_mask, cons
 
 // The whole attention backward behind one entry point: delta = rowsum(dO . O), dQ / dK / dV, the rotary embedding's backward.
 // `kernel`: TASU_ATTN_KERNEL_SP = the single-pass kernels of attention_sp.hip (two launches, delta computed inside, `delta`
-// untouched); _PER_HEAD / _GQA = tasu_attn_bwd_prep + tasu_attn_bwd_rope with that kernel; _POLICY = single-pass where it serves
-// (Spad <= 256), else tasu_attn_bwd_rope's own policy.  dk_part / dv_part: fp32 [M, H * 128] each.
+// untouched); _PER_HEAD / _GQA = tasu_attn_bwd_prep + tasu_attn_bwd_rope with that kernel; _POLICY = single-pass where it is
+// measured faster (Spad <= 256 and 3 B H <= 320), else tasu_attn_bwd_rope's own policy.  dk_part / dv_part: fp32 [M, H * 128] each.
 extern "C" int tasu_attn_bwd_fused(const void* qkv, const uint8_t* key_mask, const void* dout, const void* out, const float* lse,
                                    float* delta, const float* cos_tab, const float* sin_tab, void* dqkv, float* dk_part, float* dv_part,
                                    int B, int S, int H, int G, float scale, int causal, int kernel, void* stream) {
@@ -599,7 +603,12 @@ extern "C" int tasu_attn_bwd_fused(const void* qkv, const uint8_t* key_mask, con
   if (kernel < TASU_ATTN_KERNEL_POLICY || kernel > TASU_ATTN_KERNEL_SP) return TASU_ERR_ARG;
   const bool sp_ok = tasu_attn_sp_supported(S, H, G) != 0;
   if (kernel == TASU_ATTN_KERNEL_SP && !sp_ok) return TASU_ERR_ARG;
-  if (kernel == TASU_ATTN_KERNEL_SP || (kernel == TASU_ATTN_KERNEL_POLICY && sp_ok)) {
+  // policy (tools/bench_attn_sp.py, us per layer, prep + tiled + rotary -> single pass): 8 x 256 x 12 heads 47.1 -> 35.6, but
+  // 16 x 256 x 12 58.1 -> 65.5 and 32 x 256 x 12 106.7 -> 131.6: the three roles are 3 B H workgroups of one per CU, each of which
+  // spends ~10 us on its 190-320 KiB of operand ingest (~50 GB/s per CU) and runs its steps with one wave per SIMD; they win only
+  // while they fit one round of the chip
+  const bool sp_take = sp_ok && 3 * B * H <= 320;
+  if (kernel == TASU_ATTN_KERNEL_SP || (kernel == TASU_ATTN_KERNEL_POLICY && sp_take)) {
     if (!dk_part || !dv_part) return TASU_ERR_ARG;
     return tasu_attn_sp_bwd_launch(qkv, key_mask, dout, out, lse, cos_tab, sin_tab, dqkv, dk_part, dv_part, B, S, H, G, scale, causal,
                                    (hipStream_t)stream);

@@ -149,7 +149,7 @@ class TasuEngine:
         self.micro_steps = 0
         dev = self.core.device
         # (a stream on its own hardware queue: ps_slm_amd/streams.py; only when gradients are exchanged)
-        self.comm_stream = side_stream(dev) if self.exchange else None
+        self.comm_stream = side_stream(dev, "gradient exchange") if self.exchange else None
         # the collective: RCCL through the C-ABI when the ranks were launched with the nccl backend (one GPU per rank); a gloo
         # group (CPU double; two ranks sharing one GPU in tests) keeps torch.distributed's all_reduce
         self.rccl = None

@@ -26,6 +26,7 @@ import torch.distributed as dist
 
 from .config import DEFAULT_DS_CONFIG, load_ds_config, parse_args
 from .engine import TasuEngine
+from .streams import ensure_hw_queues
 
 logger = logging.getLogger(__name__)
 
@@ -214,6 +215,7 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
 
 
 def main(argv=None):
+    ensure_hw_queues()                   # (before the first HIP call: ps_slm_amd/streams.py)
     cfg = parse_args(sys.argv[1:] if argv is None else argv)
     train_config, model_config, log_config, dataset_config = cfg.train_config, cfg.model_config, cfg.log_config, cfg.dataset_config
     logging.basicConfig(level=logging.INFO, format="[%(asctime)s][%(name)s][%(levelname)s] - %(message)s")

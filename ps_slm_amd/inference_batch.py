@@ -21,6 +21,8 @@ logger = logging.getLogger(__name__)
 
 
 def main(argv=None):
+    from .streams import ensure_hw_queues
+    ensure_hw_queues()                   # (before the first HIP call: ps_slm_amd/streams.py)
     cfg = parse_args(sys.argv[1:] if argv is None else argv)
     train_config, model_config, dataset_config = cfg.train_config, cfg.model_config, cfg.dataset_config
     logging.basicConfig(level=logging.INFO, format="[%(asctime)s][%(name)s][%(levelname)s] - %(message)s")

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # as the entrypoints do (ps_slm_amd/streams.py:ensure_hw_queues): before the first HIP call
+
 import numpy as np
 import pytest
 import torch

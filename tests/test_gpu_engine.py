@@ -249,14 +249,23 @@ def test_lora_bucket_exchange_on_rccl_is_bit_identical(nccl_group, graphs):
 
 def test_side_streams_run_next_to_the_main_stream():
     """ps_slm_amd/streams.py: HIP maps streams onto a few hardware queues in creation order, and every fourth pooled torch stream
-    shares the default stream's queue (strictly serial execution).  side_stream() probes with spin kernels: what it hands out
-    overlaps with the current stream and with the side streams handed out before -- whatever the process created earlier."""
-    from ps_slm_amd.streams import runs_concurrently, side_stream
+    shares the default stream's queue (strictly serial execution).  side_stream() probes with spin kernels and DEVICE timestamps
+    (round 5: no host clock in the verdict): what it hands out overlaps with the current stream and with the side streams handed
+    out before -- whatever the process created earlier -- every caller gets its own stream object, and the verdicts are reported."""
+    import ps_slm_amd.streams as streams
+    from ps_slm_amd.streams import report, runs_concurrently, side_stream
+    streams._state.clear()                                         # (streams handed to earlier tests of this process are gone with their owners)
     junk = [torch.cuda.Stream() for _ in range(5)]                 # shift torch's round-robin pool position
     main = torch.cuda.current_stream()
-    a, b = side_stream("cuda"), side_stream("cuda")
-    assert a is not b
+    before = len(report("cuda"))
+    a, b, c = side_stream("cuda", "test a"), side_stream("cuda", "test b"), side_stream("cuda", "test c")
+    assert a is not b and b is not c and a is not c
     assert runs_concurrently(main, a) and runs_concurrently(main, b) and runs_concurrently(a, b)
+    assert runs_concurrently(main, c) and runs_concurrently(a, c) and runs_concurrently(b, c)   # main + three roles: four queues
     assert not runs_concurrently(a, a)                             # the probe itself: one queue = one after the other
+    for _ in range(5):                                             # the verdict does not flicker (device timestamps, not the host clock)
+        assert runs_concurrently(main, a) and not runs_concurrently(b, b)
+    rep = report("cuda")
+    assert len(rep) == before + 3 and [r["verdict"] for r in rep if r.get("role", "").startswith("test")] == ["own queue"] * 3
     assert side_stream("cpu") is None
     del junk

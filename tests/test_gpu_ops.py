@@ -546,10 +546,11 @@ def test_attention_single_pass_kernels(hip, fake, B, S, H, G, mask_kind, causal)
     # of the sums: a few bf16 steps of the largest element
     a, c = res["sp"][0].view(B, S, H, HD)[live].float(), res["tiled"][0].view(B, S, H, HD)[live].float()
     assert rel_err(a, c) < 2 ** -6
-    # the policy entry point takes the single-pass kernel here
+    # the policy entry point: the single-pass kernel when its grid is about one or two rounds of the chip
     o, l = torch.zeros(M, H * HD, dtype=BF).cuda(), torch.zeros(B * H * Spad).cuda()
     hip.attn_fwd(qkv.cuda(), None, km.cuda(), o, l, B, S, H, G, scale, causal)
-    assert torch.equal(o.cpu().view(B, S, H, HD)[live], res["sp"][0].view(B, S, H, HD)[live])
+    takes_sp = 176 <= B * H <= 256 or 432 <= B * H <= 512
+    assert torch.equal(o.cpu().view(B, S, H, HD)[live], res["sp" if takes_sp else "tiled"][0].view(B, S, H, HD)[live])
     # backward: the whole chain behind one entry point
     dout = randn(M, H * HD, dtype=BF, seed=22)
     dout.view(B, S, H, HD)[~live] = 0
@@ -570,7 +571,7 @@ def test_attention_single_pass_kernels(hip, fake, B, S, H, G, mask_kind, causal)
             assert rel_err(got[kernel][:, lo:hi], w[:, lo:hi]) < 2e-2, (kernel, lo)
         a, c = got["sp"][:, lo:hi].float(), got["tiled"][:, lo:hi].float()
         assert rel_err(a, c) < 2 ** -6                     # the same products in another fp32 association
-    assert torch.equal(got["policy"], got["sp"])
+    assert torch.equal(got["policy"], got["sp" if 3 * B * H <= 320 else "tiled"])
     # bitwise repeatable (no atomics anywhere in the chain)
     dq2 = torch.zeros(M, LD, dtype=BF).cuda()
     hip.attn_bwd_fused(qkv.cuda(), km.cuda(), dout.cuda(), out_g.cuda(), lse_g.cuda(), None, cos.cuda(), sin.cuda(), dq2,
