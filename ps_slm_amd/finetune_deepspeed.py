@@ -150,7 +150,12 @@ def evaluation(engine, train_config, eval_dataset, rank, world):
 
 def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=None):
     """Loop body of Multitask/utils/deepspeed_utils.py:190-246 (uneven-data join, forward, backward, step, logging) and
-    the validation / save-on-improvement block behind it (:248-290)."""
+    the validation / save-on-improvement block behind it (:248-290).
+
+    Deviation (stated): the loop holds ONE batch of lookahead -- batch i + 1 is fetched and collated before the forward of batch i
+    -- so the dataset's `random.choice` prompt draws of batch i + 1 come before any draws a validation pass at step i makes.
+    Where validation draws prompts from the same global RNG, runs are therefore not seed-for-seed comparable with the
+    reference's loop across a validation point (the batches themselves, and every run without validation, are identical)."""
     results = {}
     total_loss, total_acc, steps, utts = 0.0, 0.0, 0, 0
     best_val_loss, best_val_acc = float("inf"), 0.0
@@ -169,8 +174,10 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
             nxt = next(it, None)                               # one batch of lookahead: its frozen encoder pass runs on a side
             nxt_batch = dataset.collator(nxt) if nxt is not None else None    # stream under this batch's decoder step
             outputs, acc = engine(**batch)
-            if nxt_batch is not None:
-                engine.prefetch(**nxt_batch)
+            val_now = eval_dataset is not None and train_config.run_validation and \
+                (epoch_step + 1) % train_config.validation_interval == 0
+            if nxt_batch is not None and not val_now:          # (a validation pass would run in between and discard the prefetched
+                engine.prefetch(**nxt_batch)                   #  encoder output: the pass would run twice for that batch)
             loss = outputs.loss
             engine.backward(loss)
             engine.step()
@@ -178,8 +185,6 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
             epoch_step += 1
             utts += batch["input_ids"].shape[0]
             log_now = steps % max(1, log_config.log_interval) == 0
-            val_now = eval_dataset is not None and train_config.run_validation and \
-                epoch_step % train_config.validation_interval == 0
             if log_now and val_now:
                 # loss / acc are views into the step's result buffer, which the validation forwards below overwrite:
                 # read them first

@@ -187,9 +187,11 @@ def test_peft_config_overrides_and_rejections():
     # the reference's defaults (aispeech_asr_config.py:41-50)
     d = LoraConfig.from_peft_config(TrainConfig().peft_config)
     assert (d.r, d.lora_alpha, d.lora_dropout, len(d.target_modules)) == (64, 16.0, 0.05, 7)
-    for bad in (dict(peft_method="prefix"), dict(bias="all"), dict(target_modules=["lm_head"]), dict(r=12)):
-        with pytest.raises(NotImplementedError):
+    for bad in (dict(peft_method="prefix"), dict(bias="all"), dict(target_modules=["lm_head"]), dict(r=12),
+                dict(inference_mode=True), dict(modules_to_save=["lm_head"]), dict(fan_in_fan_out=True), dict(task_type="SEQ_CLS")):
+        with pytest.raises(NotImplementedError):           # peft's LoraConfig(**params) would act on every one of these keys
             LoraConfig.from_peft_config(bad)
+    assert LoraConfig.from_peft_config(dict(task_type="CAUSAL_LM", inference_mode=False, r=8)).r == 8
     with pytest.raises(NotImplementedError, match="freeze_llm"):
         model_factory(TrainConfig(freeze_llm=False, gt_emb=True, ctc_posterior=True), ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256),
                       device="cpu", ops=FakeOps())

@@ -1,5 +1,5 @@
 # LDS counters of the attention kernels (one shape), for the current build and, if given, another library
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+set -euo pipefail; cd "${GRAFT_REPO_ROOT:?run through gpurun (it exports GRAFT_REPO_ROOT)}"; export TMPDIR=/tmp; set +e   # (the runs below report their own exit codes)
 O=gpurun_out/pmc_attn; mkdir -p $O
 cat > /tmp/one_shape.py <<'PY'
 import os, sys

@@ -1,5 +1,5 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-R=${R:-r04}
+set -euo pipefail; cd "${GRAFT_REPO_ROOT:?run through gpurun (it exports GRAFT_REPO_ROOT)}"; export TMPDIR=/tmp; set +e   # (the runs below report their own exit codes)
+R=${R:-r05}
 rm -rf gpurun_out/art; mkdir -p gpurun_out/art
 timeout 1500 python bench.py > gpurun_out/art/bench_$R.json 2> gpurun_out/art/bench_$R.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/art/prof_bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-extra --no-graphs > gpurun_out/art/${R}_bench_under_rocprof.json 2> gpurun_out/art/prof_bench.err
