@@ -295,7 +295,7 @@ def lora_flops_per_utt(geo, S, lp):
 
 
 def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank, want_decode, device=None, ops=None,
-              variable=False, blank_biased=False, lora=False):
+              variable=False, blank_biased=False, lora=False, force_exchange=False):
     """One training workload (path: "text" = the text-only CPS recipe of configs 2/3/5, "audio" = config 4: 500 feature frames
     through the SenseVoice encoder, CTC posterior, PSD, projector, LLM).  Returns the fields of a bench record.
     ``device`` / ``ops``: tests/test_bench_cpu.py drives this function over gloo with the CPU operator double (the N > 1
@@ -304,7 +304,9 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
     the training entrypoint's buckets (``++graph_buckets=16,8,256``) so that the LRU of captured step graphs gets hits: the
     throughput of real dynamic batching, where no two steps need have the same shape.  ``blank_biased`` (audio path): the CTC
     head's blank bias is raised until PSD keeps ~100 of the 500 frames (a trained encoder's regime; the random-init posterior
-    keeps ~476)."""
+    keeps ~476).  ``force_exchange`` (N = 1): the chunked gradient exchange runs all the same, through a ONE-rank RCCL communicator
+    -- every all-reduce launch, event chain and wait of the N > 1 step with nothing on the wire: a sanity figure for
+    ``allreduce_exposed_ms`` from hardware."""
     import torch.distributed as dist
 
     from ps_slm_amd.config import DEFAULT_DS_CONFIG, ModelConfig, TrainConfig, load_ds_config
@@ -330,8 +332,9 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         core.shape_buckets = (16, 8, 256)
     timed = TimedOps(core.ops)
     core.ops = timed
-    engine = TasuEngine(model, load_ds_config(DEFAULT_DS_CONFIG))
+    engine = TasuEngine(model, load_ds_config(DEFAULT_DS_CONFIG), force_exchange=force_exchange)
     engine.train()
+    exchanging = world > 1 or (force_exchange and engine.exchange)
     geo = core.geo
     def make_batch(seed, **shape):
         raw = synthetic_text_batch(geo, B, seed=seed, noise=False, **shape)
@@ -392,7 +395,7 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
     # hipGraph replay cannot carry per-launch event pairs, so with graphs the GEMM launches are timed in a second,
     # eager pass over the same number of steps right after the timed region (same kernels, same shapes, same data).
     timed.enabled = on_gpu and rank == 0 and not core.use_graphs
-    engine.time_exchange = world > 1
+    engine.time_exchange = exchanging
     engine.exposed_events = []
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -403,7 +406,7 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
     sync()
     dt = time.perf_counter() - t0
     timed.enabled = False
-    exposed_ms = engine.exposed_ms() / max(steps, 1) if world > 1 else 0.0
+    exposed_ms = engine.exposed_ms() / max(steps, 1) if exchanging else 0.0
     engine.time_exchange = False
     if world > 1:
         t = torch.tensor([dt, exposed_ms], device=device, dtype=torch.float64)
@@ -497,14 +500,14 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                                        "whole_step_frac_at_survey_flops prices the same utterances/s at SURVEY 8d's algorithmic "
                                        "FLOPs, which count them"},
         }
-        if world > 1:
+        if exchanging:
             rec["collective"] = engine.comm_info()      # ranks = ncclCommCount of the communicator the exchange ran on
             rec["allreduce_exposed_ms"] = round(exposed_ms, 3)
             rec["allreduce_note"] = (f"per step, max over ranks: time the compute stream waited for gradient ranges in step() "
                                      f"(event pairs around every wait); bucket exchanged in {len(core.grad_ranges(engine.w1_chunks))} ranges.  Expected "
                                      f"on 8 xGMI-connected GPUs: ~0.35 ms (the last 51-MB row block of the Linear1 weight gradient at "
                                      f"the ~300 GB/s bus bandwidth RCCL reaches; the whole 218-MB bucket would be ~1.3 ms), DESIGN.md 6")
-        if on_gpu and (core.lora is not None or audio or world > 1):
+        if on_gpu and (core.lora is not None or audio or exchanging):
             rec["side_streams"] = stream_report(device)   # which hardware queue every overlap role got (ps_slm_amd/streams.py)
         if want_decode:
             rec["decode"] = decode_leg(core, raw, B, new_tokens=200 if model_name != "qwen2.5-7b" else 64)
@@ -576,6 +579,19 @@ def main():
         extras["qwen2.5-7b"] = train_leg(args, "qwen2.5-7b", "text", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank,
                                           want_decode=not args.no_decode)     # + the 7B decode leg (split-K GEMV kernels: no streaming
                                                                               # kernels exist for K = 3584 / 18944 yet)
+        # the N > 1 step's exchange on hardware with ONE rank: the headline step again with the chunked
+        # all-reduce of the gradient bucket through a one-rank RCCL communicator, side stream and event chain included
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local_rank}"))
+            extras["exchange_1rank"] = train_leg(args, "qwen2.5-1.5b", "text", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank,
+                                                 False, force_exchange=True)
+        except Exception as e:                          # (a record of the failure, never the loss of the whole line)
+            extras["exchange_1rank"] = {"value": None, "error": repr(e)[:300]}
+        finally:
+            if dist.is_initialized():
+                dist.destroy_process_group()
     if rank == 0:
         line = {"metric": "train utterances/sec (Qwen2.5-1.5B align)" if args.model != "qwen2.5-7b" else "train utterances/sec (Qwen2.5-7B align)",
                 "value": main_rec["value"], "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -586,7 +602,9 @@ def main():
             rec["metric"] = "train utterances/sec" + {"audio_sft": " (audio-SFT, config 4)", "qwen2.5-7b": " (Qwen2.5-7B align, config 5)",
                                                       "variable_S": " (text-only, variable shapes: CPS drop 0.05, bucketed hipGraphs)",
                                                       "audio_sft_blank_biased": " (audio-SFT, config 4, ~100 audio tokens per utterance)",
-                                                      "lora_r64": " (text-only, use_peft=true: LoRA r=64 on the decoder + projector)"}[name]
+                                                      "lora_r64": " (text-only, use_peft=true: LoRA r=64 on the decoder + projector)",
+                                                      "exchange_1rank": " (headline step with the N > 1 gradient exchange forced through a 1-rank RCCL "
+                                                                        "communicator: allreduce_exposed_ms is the sanity figure)"}[name]
             line[name] = rec
         if world == 1 and not args.no_cpu_baseline and headline:
             line["cpu_baseline"] = cpu_baseline("train1")

@@ -106,7 +106,11 @@ def audio_num_samples(path):
             return int(total.value)
         return len(read_flac(path)[1])
     if ":" in os.path.basename(path):
-        return len(read_audio(path)[1])
+        fname, off = path.rsplit(":", 1)                                   # wav-in-ark: the RIFF header says it (no sample is read)
+        with open(fname, "rb") as f:
+            f.seek(int(off))
+            with wave.open(f, "rb") as w:
+                return w.getnframes()
     with wave.open(path, "rb") as w:
         return w.getnframes()
 

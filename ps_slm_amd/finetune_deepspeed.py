@@ -12,6 +12,7 @@ The dataset plugin (``dataset_config.file = "<file>.py:<func>"``, Multitask/util
 ``dataset_config.file=synthetic`` yields fixed-length synthetic batches in the collator's schema (the reference's
 jsonl/fbank loader is SURVEY section 8f "next").
 """
+import contextlib
 import importlib.machinery
 import importlib.util
 import logging
@@ -148,6 +149,73 @@ def evaluation(engine, train_config, eval_dataset, rank, world):
     return ppl, loss, acc
 
 
+class BatchReader:
+    """The reference feeds its loop from DataLoader worker PROCESSES (Multitask/finetune_deepspeed.py:185-208, num_workers 4 in
+    finetune_deespeed_sensevoice.sh:92).  Here ONE reader THREAD does that work -- jsonl line -> audio container (tmpfs / page
+    cache read, FLAC decode in libtasu_hip.so: ctypes and numpy release the GIL) -> front end (two HIP launches per utterance on
+    the reader's OWN stream) -> tokenisation -> collate -- and hands finished batches over a bounded queue, in dataset order.
+    Forked workers are not an option (a process that has initialised HIP must not fork) and are not needed: the features are
+    made on the device, so what the host moves per 30-s utterance is 0.96 MB of PCM.  The consumer waits for the batch's event
+    on its own stream before touching device tensors.  ``depth`` batches of lookahead bound the memory."""
+
+    _END = object()
+
+    def __init__(self, dataset, device, depth=3):
+        import queue
+        import threading
+        self.dataset, self.device = dataset, torch.device(device)
+        self.q = queue.Queue(maxsize=depth)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.thread = threading.Thread(target=self._run, name="tasu-batch-reader", daemon=True)
+        self.stopped = False
+        self.thread.start()
+
+    def _run(self):
+        try:
+            if self.stream is not None:
+                torch.cuda.set_device(self.device)
+            ctx = torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+            with ctx:
+                for raw in self.dataset:
+                    if self.stopped:
+                        return
+                    batch = self.dataset.collator(raw)
+                    ev = None
+                    if self.stream is not None and isinstance(batch.get("input_features"), torch.Tensor) and batch["input_features"].is_cuda:
+                        ev = torch.cuda.Event()
+                        ev.record(self.stream)
+                    self.q.put((raw, batch, ev))
+            self.q.put((self._END, None, None))
+        except BaseException as e:                       # hand the failure to the training thread instead of dying silently
+            self.q.put((e, None, None))
+
+    def __iter__(self):
+        while True:
+            raw, batch, ev = self.q.get()
+            if raw is self._END:
+                return
+            if isinstance(raw, BaseException):
+                raise raw
+            if ev is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                batch["input_features"].record_stream(cur)   # (allocated on the reader's stream, consumed on this one)
+            yield raw, batch
+
+    def close(self):
+        self.stopped = True
+        while self.thread.is_alive():                    # unblock a producer waiting on a full queue
+            try:
+                self.q.get_nowait()
+            except Exception:
+                self.thread.join(timeout=0.05)
+
+
+def _inline_batches(dataset):
+    for raw in dataset:
+        yield raw, dataset.collator(raw)
+
+
 def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=None):
     """Loop body of Multitask/utils/deepspeed_utils.py:190-246 (uneven-data join, forward, backward, step, logging) and
     the validation / save-on-improvement block behind it (:248-290).
@@ -161,18 +229,23 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
     best_val_loss, best_val_acc = float("inf"), 0.0
     val_loss, val_ppl, val_acc = [], [], []
     t0 = time.perf_counter()
+    # num_workers_dataloader > 0 (the reference's recipe asks for 4 worker processes): one reader thread, see BatchReader;
+    # 0 = read and collate on the training thread, like a DataLoader without workers
+    threaded = int(getattr(train_config, "num_workers_dataloader", 0) or 0) > 0 and hasattr(dataset, "collator")
+    epoch_rates = []
     for epoch in range(train_config.num_epochs):
         engine.train()
-        it = iter(dataset)
+        reader = BatchReader(dataset, engine.core.device) if threaded else None
+        it = iter(reader) if reader is not None else _inline_batches(dataset)
         epoch_step = 0                                         # the reference's `step + 1` (per epoch, :190, :248)
-        nxt = next(it, None)
-        nxt_batch = dataset.collator(nxt) if nxt is not None else None
+        e_t0, e_utts = time.perf_counter(), 0
+        nxt, nxt_batch = next(it, (None, None))
         while True:
             raw, batch = nxt, nxt_batch
             if not engine.all_have_data(raw is not None):      # replaces deepspeed_join's gloo monitored_barrier
                 break
-            nxt = next(it, None)                               # one batch of lookahead: its frozen encoder pass runs on a side
-            nxt_batch = dataset.collator(nxt) if nxt is not None else None    # stream under this batch's decoder step
+            nxt, nxt_batch = next(it, (None, None))            # one batch of lookahead: its frozen encoder pass runs on a side
+                                                               # stream under this batch's decoder step
             outputs, acc = engine(**batch)
             val_now = eval_dataset is not None and train_config.run_validation and \
                 (epoch_step + 1) % train_config.validation_interval == 0
@@ -184,6 +257,7 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
             steps += 1
             epoch_step += 1
             utts += batch["input_ids"].shape[0]
+            e_utts += batch["input_ids"].shape[0]
             log_now = steps % max(1, log_config.log_interval) == 0
             if log_now and val_now:
                 # loss / acc are views into the step's result buffer, which the validation forwards below overwrite:
@@ -208,6 +282,12 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
                 if rank == 0:
                     logger.info("epoch %d step %d loss %.4f acc %.4f lr %.3e  %.1f utt/s", epoch + 1, steps, l, a,
                                 engine.get_lr()[0], world * utts / (time.perf_counter() - t0))
+        if reader is not None:
+            reader.close()
+        if engine.core.device.type == "cuda":
+            torch.cuda.synchronize()
+        epoch_rates.append(world * e_utts / max(time.perf_counter() - e_t0, 1e-9))
+    results["epoch_utterances_per_s"] = epoch_rates            # (per epoch, device drained: the first epoch carries the warm-up)
     n_logged = max(1, steps // max(1, log_config.log_interval))
     sl, sa = engine.reduce_scalars(total_loss / n_logged, total_acc / n_logged)
     results["avg_train_loss"], results["avg_train_acc"] = sl / world, sa / world

@@ -47,7 +47,9 @@ DEFAULT_IGNORE_TOKEN = -100
 # ------------------------------------------------------------------------------------------------ tokenizers
 class SyntheticLLMTokenizer:
     """Stand-in used when ``llm_path`` holds no tokenizer files (the benchmark box has none): whitespace-separated
-    integer strings <-> ids.  Exposes what the model and the entrypoints read (ps-slm.py:27,133-140,672-674)."""
+    integer strings <-> ids; any other word -> a deterministic ordinary id (so that cleaned training targets, which hold letters
+    only -- speech_dataset_large.py:164 -- still have one token per word).  Exposes what the model and the entrypoints read
+    (ps-slm.py:27,133-140,672-674)."""
 
     def __init__(self, geo: Geometry):
         self.eos_token_id = geo.eos_id
@@ -58,7 +60,8 @@ class SyntheticLLMTokenizer:
         self.vocab_size = geo.llm_vocab
 
     def encode(self, text):
-        return [int(t) for t in text.split() if t.lstrip("-").isdigit()]
+        top = max(2, min(self.eos_token_id, self.vocab_size))          # ordinary ids: below the special tokens
+        return [int(t) if t.lstrip("-").isdigit() else 1 + (sum((i + 1) * ord(c) for i, c in enumerate(t)) % (top - 1)) for t in text.split()]
 
     def batch_decode(self, ids, skip_special_tokens=True, **kw):
         out = []

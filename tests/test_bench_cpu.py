@@ -25,8 +25,10 @@ def _worker(rank, world, port, ret):
         args = SimpleNamespace(drop_prob=0.0, no_graphs=True)
         rec = bench.train_leg(args, "mid", "text", 2, 2, 1, world, rank, 0, False, device="cpu", ops=FakeOps())
         lrec = bench.train_leg(args, "mid", "text", 2, 2, 1, world, rank, 0, False, device="cpu", ops=FakeOps(), lora=True)   # --lora at N > 1
+        arec = bench.train_leg(args, "mid", "audio", 2, 2, 1, world, rank, 0, False, device="cpu", ops=FakeOps())              # --path audio at N > 1
         ret[rank] = rec
         ret[10 + rank] = lrec
+        ret[20 + rank] = arec
     finally:
         dist.destroy_process_group()
 
@@ -49,6 +51,10 @@ def test_train_leg_two_ranks_over_gloo():
     assert ret[11] is None and "LoRA recipe" in l0["config"]["workload"] and l0["config"]["parallelism"] == "dp2"
     assert l0["allreduce_exposed_ms"] >= 0.0 and 0.0 < l0["config"]["final_loss"] < 20.0
     assert "bucket exchanged in" in l0["allreduce_note"]
+    # config 4's path (audio-SFT: encoder -> PSD -> projector -> LLM) through the same bookkeeping
+    a0 = ret[20]
+    assert ret[21] is None and "audio-SFT step" in a0["config"]["workload"] and a0["config"]["parallelism"] == "dp2"
+    assert a0["allreduce_exposed_ms"] >= 0.0 and 0.0 < a0["config"]["final_loss"] < 20.0
 
 
 def test_launch_check_refuses_a_mismatched_world():

@@ -390,3 +390,40 @@ def test_engine_refuses_to_train_less_than_asked():
     tc2 = TrainConfig(freeze_llm=True, freeze_encoder=False, gt_emb=True, ctc_posterior=True, do_psd=True)
     model2, _ = model_factory(tc2, mc, device="cpu", ops=FakeOps(), init_seed=1)
     TasuEngine(model2, load_ds_config(DEFAULT_DS_CONFIG))
+
+
+def test_batch_reader_thread_keeps_order_hands_over_failures_and_stops():
+    """ps_slm_amd.finetune_deepspeed.BatchReader (one reader thread in place of the reference's DataLoader worker processes,
+    Multitask/finetune_deepspeed.py:185-208): batches arrive collated and in dataset order, an exception in the reader surfaces in
+    the consumer, and close() unblocks a producer that waits on the full queue."""
+    import threading
+    import time as _time
+
+    from ps_slm_amd.finetune_deepspeed import BatchReader
+
+    class DS:
+        def __init__(self, n, fail_at=None):
+            self.n, self.fail_at, self.reader_thread = n, fail_at, None
+
+        def __iter__(self):
+            self.reader_thread = threading.current_thread().name
+            for i in range(self.n):
+                if i == self.fail_at:
+                    raise RuntimeError("corrupt utterance")
+                yield [i, i + 100]
+
+        def collator(self, raw):
+            return {"input_ids": torch.tensor(raw), "input_features": None}
+
+    ds = DS(20)
+    got = [(raw, batch["input_ids"].tolist()) for raw, batch in BatchReader(ds, "cpu", depth=2)]
+    assert got == [([i, i + 100], [i, i + 100]) for i in range(20)] and ds.reader_thread == "tasu-batch-reader"
+    with pytest.raises(RuntimeError, match="corrupt utterance"):
+        for _ in BatchReader(DS(10, fail_at=3), "cpu"):
+            pass
+    r = BatchReader(DS(10 ** 9), "cpu", depth=2)           # an endless source: the producer blocks on the full queue
+    it = iter(r)
+    next(it)
+    t0 = _time.perf_counter()
+    r.close()
+    assert not r.thread.is_alive() and _time.perf_counter() - t0 < 5.0
