@@ -549,6 +549,8 @@ def main():
                     help="audio path: run every batch's frozen encoder pass in front of its own step instead of one batch ahead on a side stream")
     ap.add_argument("--lora", action="store_true", help="the use_peft=true recipe (LoRA r=64 on the decoder's 7 Linears) as the measured workload")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-4 (audio-SFT) and config-5 (Qwen2.5-7B) sub-records")
+    ap.add_argument("--no-data-path", action="store_true",
+                    help="skip the data_path sub-record (the training entrypoint on a generated 2048-utterance wav-in-ark corpus in tmpfs)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.cpu_baseline_worker)
@@ -592,6 +594,36 @@ def main():
         finally:
             if dist.is_initialized():
                 dist.destroy_process_group()
+    data_path = None
+    if world == 1 and headline and not args.no_extra and not args.no_data_path:
+        # SURVEY 8f item 1 / VERDICT r4 item 5: the REAL data path next to the synthetic-input figures -- the training entrypoint
+        # (ps_slm_amd.finetune_deepspeed.main: jsonl -> wav-in-ark read -> HIP fbank / LFR / CMVN -> collate -> dynamic batching ->
+        # reader thread -> step, hipGraph replay) on 2048 generated 30-second utterances in tmpfs; second epoch's rate
+        try:
+            import shutil
+            import tempfile
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_data_path as dp
+            base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+            croot = tempfile.mkdtemp(prefix="tasu_corpus_", dir=base)
+            try:
+                tr = dp.make_corpus(os.path.join(croot, "ark"), 2048, "ark")
+                t_only = dp.run(os.path.join(croot, "ark"), tr, True, 2, 1)
+                t_audio = dp.run(os.path.join(croot, "ark"), tr, False, 2, 1)
+            finally:
+                shutil.rmtree(croot, ignore_errors=True)
+            data_path = {"corpus": "2048 x 30 s, 16-bit wav-in-ark in " + base + ", 16 utterances per batch by the frame budget (4200, ds_rate 5)",
+                         "text_only_utterances_per_s": t_only["epoch_utterances_per_s"][-1],
+                         "text_only_vs_synthetic": round(t_only["epoch_utterances_per_s"][-1] / main_rec["value"], 3),
+                         "audio_wav_utterances_per_s": t_audio["epoch_utterances_per_s"][-1],
+                         "audio_wav_vs_synthetic_audio_sft": (round(t_audio["epoch_utterances_per_s"][-1] / extras["audio_sft"]["value"], 3)
+                                                              if extras.get("audio_sft") else None),
+                         "note": "ps_slm_amd.finetune_deepspeed.main, num_workers_dataloader=1 (one reader thread + 4 decode threads), "
+                                 "++use_graphs=true; text_only reads only the audio lengths (the model never looks at the features); "
+                                 "audio: random-init encoder, PSD keeps ~476 of 500 frames (S = 628, as audio_sft); FLAC and the "
+                                 "in-line loop: profiles/r05_data_path.json (tools/bench_data_path.py)"}
+        except Exception as e:                          # (never the loss of the whole line)
+            data_path = {"error": repr(e)[:300]}
     if rank == 0:
         line = {"metric": "train utterances/sec (Qwen2.5-1.5B align)" if args.model != "qwen2.5-7b" else "train utterances/sec (Qwen2.5-7B align)",
                 "value": main_rec["value"], "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -606,6 +638,8 @@ def main():
                                                       "exchange_1rank": " (headline step with the N > 1 gradient exchange forced through a 1-rank RCCL "
                                                                         "communicator: allreduce_exposed_ms is the sanity figure)"}[name]
             line[name] = rec
+        if data_path is not None:
+            line["data_path"] = data_path
         if world == 1 and not args.no_cpu_baseline and headline:
             line["cpu_baseline"] = cpu_baseline("train1")
             line["cpu_baselines"] = {"train_B16": cpu_baseline("train16", 300), "decode_B1": cpu_baseline("decode1", 240),
@@ -626,6 +660,8 @@ def main():
             digest[name] = brief(rec)
             if isinstance(rec.get("decode"), dict):
                 digest[name + "_decode"] = brief(rec["decode"])
+        if data_path is not None and "error" not in data_path:
+            digest["data_path"] = {k: data_path[k] for k in ("text_only_utterances_per_s", "audio_wav_utterances_per_s")}
         line["digest"] = digest
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -114,6 +114,7 @@ class DataConfig(_Section):
     test_scp_file_path: str = ""
     inference_mode: bool = False
     text_only: bool = False          # ps_slm_amd/dataset.py: read audio lengths only (text-only alignment recipe)
+    decode_threads: int = 4          # ps_slm_amd/dataset.py: threads that read + decode the next utterances' audio (0 / 1: in line)
 
 
 @dataclass
