@@ -585,7 +585,11 @@ def main():
         # all-reduce of the gradient bucket through a one-rank RCCL communicator, side stream and event chain included
         try:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:      # a port nobody listens on right now
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local_rank}"))
             extras["exchange_1rank"] = train_leg(args, "qwen2.5-1.5b", "text", args.batch, max(5, args.steps // 2), 2, 1, 0, local_rank,
                                                  False, force_exchange=True)

@@ -7,6 +7,15 @@ import numpy as np
 import pytest
 import torch
 
+
+def free_port():
+    """A TCP port nobody listens on right now (bind to 0, read it back): rendezvous ports derived from the pid collided between
+    a module fixture's group and a test's own two-rank group once in a while (EADDRINUSE)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -10,6 +10,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+from conftest import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -34,7 +35,7 @@ def _worker(rank, world, port, ret):
 
 
 def test_train_leg_two_ranks_over_gloo():
-    world, port = 2, 29100 + os.getpid() % 700
+    world, port = 2, free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)

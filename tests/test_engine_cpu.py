@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import golden_batch, load_npz
+from conftest import golden_batch, load_npz, free_port
 from fake_ops import FakeOps
 from oracle import tasu_oracle as O
 from ps_slm_amd.config import DEFAULT_DS_CONFIG, ModelConfig, RunConfig, TrainConfig, apply_overrides, load_ds_config
@@ -239,7 +239,7 @@ def _dp_worker(rank, world, port, ret):
 
 def test_data_parallel_two_ranks_gloo():
     """DeepSpeed semantics: each rank's mean-CE gradient, AVERAGED over ranks, then one AdamW step; replicas stay equal."""
-    world, port = 2, 29000 + os.getpid() % 2000
+    world, port = 2, free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_dp_worker, args=(world, port, ret), nprocs=world, join=True)

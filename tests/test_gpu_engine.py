@@ -12,6 +12,7 @@ from ps_slm_amd.config import DEFAULT_DS_CONFIG, ModelConfig, TrainConfig, load_
 from ps_slm_amd.engine import TasuEngine
 from ps_slm_amd.ps_slm import model_factory
 from ps_slm_amd.synthetic import synthetic_text_batch
+from conftest import free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +20,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def nccl_group():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    os.environ["MASTER_PORT"] = str(free_port())
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     yield
@@ -184,7 +185,7 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas():
     hardware: replicas stay bit-identical over 4 steps, both ranks train, and the update equals the single-process step on the
     averaged gradient."""
     import torch.multiprocessing as mp
-    world, port = 2, 29600 + os.getpid() % 300
+    world, port = 2, free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_two_rank_worker, args=(world, port, ret), nprocs=world, join=True)
