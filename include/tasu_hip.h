@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 9
+#define TASU_ABI_VERSION 10
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -191,6 +191,19 @@ int tasu_gemm_stream_slabs(const void* A, int lda, const void* W, int ldw, float
                            int K, int ksplit, int a_frag, int w_frag, void* stream);
 int tasu_stream_finish_norm(const float* slabs, int ksplit, float* C, const float* resid, int M, int N, const float* norm_w,
                             void* y, float eps, int y_frag, void* stream);
+/* Round 5: the projection, the residual add AND the RMSNorm of the finished rows in ONE launch (csrc/stream_body.h: norm_tail) --
+ * a decode layer's two norm launches (tasu_rmsnorm_fwd_frag behind the o projection, tasu_stream_finish_norm behind the down
+ * projection's slabs: Qwen2DecoderLayer, modeling_qwen2.py:269-298, through /root/reference/Multitask/model/ps-slm.py:660-675) move into
+ * their producers: the projection's workgroups store write-through, take a ticket, and the last min(workgroups, M) arrivers each
+ * normalise rows of the complete result (agent-scope hand-off, no grid barrier).
+ *   C [M, N] fp32 = resid + bf16(A W^T);  y = bf16(norm_w * C * rstd), row-major [M, N] or (y_frag) fragment order.
+ *   ksplit = 1: K in one range (tasu_gemm_stream_bf16's RESID form + tasu_rmsnorm_fwd[_frag]); ksplit > 1: K-range slabs in
+ *   `slabs` ([ksplit][64][N] fp32, slab_floats >= ksplit * 64 * N) summed in slab order (tasu_gemm_stream_slabs +
+ *   tasu_stream_finish_norm).  N = 256 or 1536, M <= 64, tasu_stream_supported(K, ksplit).  `sync`: 8 bytes of device memory,
+ *   zero before the FIRST call; every call (and hipGraph replay) leaves them zero.  The same bits as the two-launch forms. */
+int tasu_gemm_stream_norm(const void* A, int lda, const void* W, int ldw, float* C, const float* resid, int M, int N, int K,
+                          int ksplit, float* slabs, int64_t slab_floats, const float* norm_w, void* y, float eps, int a_frag,
+                          int w_frag, int y_frag, void* sync, void* stream);
 /* y_f = rmsnorm(x, w) written in fragment order (M <= 64, D % 32 == 0): the decode step's first / post-attention norm. */
 int tasu_rmsnorm_fwd_frag(const float* x, const float* w, void* y_frag, int M, int D, float eps, void* stream);
 int tasu_to_fragment_order(const void* W, int ldw, void* out, int kind, int N, int K, int H, int G, void* stream);

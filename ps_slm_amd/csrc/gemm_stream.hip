@@ -46,6 +46,17 @@ __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_kernel(Args p) {
   stream_gemm_body<KS, EPI, MT, FRAG, false>(p, red, bx, p.gx, by, bz);
 }
 
+// The projection and, in the same launch, the RMSNorm of its complete rows (norm_tail, stream_body.h): E_RESID (o projection +
+// residual -> post-attention norm) or E_SLAB (down projection's K-range slabs -> sum + residual + the next layer's input norm).
+template <int KS, int EPI, int MT, bool FRAG, int NG>
+__global__ __launch_bounds__(64 * NW, 2) void stream_gemm_norm_kernel(Args p, NormTail t) {
+  __shared__ __attribute__((aligned(16))) float red[2 * NW * MT * 256];
+  int bx, by, bz;
+  if (!grid_position((int)blockIdx.x, p.gx, p.gy, p.gz, bx, by, bz)) return;
+  stream_gemm_body<KS, EPI, MT, FRAG, true>(p, red, bx, p.gx, by, bz);
+  norm_tail<NG, EPI>(p, t, red, p.gx * p.gy * p.gz);
+}
+
 int cu_count() {
   static const int n = [] {
     int dev = 0, cus = 256;
@@ -94,6 +105,37 @@ int launch(const Args& a, int ksplit, hipStream_t st) {
   const int per_split = cus / (ksplit * zs) > 0 ? cus / (ksplit * zs) : 1;
   const dim3 grid(a.tiles < per_split ? a.tiles : per_split, ksplit, zs);
   return split_rows ? launch_mt<EPI, 2>(a, ksplit, grid, st) : launch_mt<EPI, 4>(a, ksplit, grid, st);
+}
+
+// launch geometry of launch<EPI> for the fused-norm kernels (the same decisions)
+template <int EPI, int NG>
+int launch_norm(Args a, const NormTail& t, int ksplit, hipStream_t st) {
+  const int cus = cu_count();
+  const int row_tiles = (a.M + 15) / 16;
+  const int kr = a.K / ksplit;
+  const bool split_rows = row_tiles > 2 && ((EPI == E_SLAB && kr > 1280) || (EPI != E_SLAB && a.tiles * ksplit * 2 <= cus + cus / 4));
+  const int zs = split_rows ? 2 : 1;
+  const int per_split = cus / (ksplit * zs) > 0 ? cus / (ksplit * zs) : 1;
+  a.gx = a.tiles < per_split ? a.tiles : per_split, a.gy = ksplit, a.gz = zs;
+  const int per = 8 * a.gz;
+  const dim3 grid((a.gx * a.gy * a.gz + per - 1) / per * per);
+  if (a.a_frag != a.w_frag) return TASU_ERR_ARG;
+  const int ks = kr / (NW * 32);
+#define TASU_NL(KSV, MTV, FR)                                                                                              \
+  do {                                                                                                                     \
+    TASU_LAUNCH((stream_gemm_norm_kernel<KSV, EPI, MTV, FR, NG>), grid, dim3(64 * NW), 0, st, a, t);                       \
+    return TASU_OK;                                                                                                        \
+  } while (0)
+#define TASU_NL_KS(KSV)                                                                                                    \
+  case KSV:                                                                                                                \
+    if (split_rows) { if (a.a_frag) TASU_NL(KSV, 2, true); else TASU_NL(KSV, 2, false); }                                   \
+    else { if (a.a_frag) TASU_NL(KSV, 4, true); else TASU_NL(KSV, 4, false); }
+  switch (ks) {
+    TASU_NL_KS(1) TASU_NL_KS(2) TASU_NL_KS(5) TASU_NL_KS(6) TASU_NL_KS(7)
+    default: return TASU_ERR_ARG;
+  }
+#undef TASU_NL_KS
+#undef TASU_NL
 }
 
 bool k_supported(int K, int ksplit) {
@@ -193,6 +235,39 @@ extern "C" int tasu_gemm_stream_slabs(const void* A, int lda, const void* W, int
   a.tiles = N / 16;
   a.a_frag = a_frag, a.w_frag = w_frag;
   return launch<E_SLAB>(a, ksplit, (hipStream_t)stream);
+}
+
+// Round 5: projection + residual + RMSNorm of the result in ONE launch (norm_tail, stream_body.h).  C (fp32) = resid + bf16(A W^T);
+// y = rmsnorm(C, norm_w) (bf16; y_frag: fragment order).  ksplit = 1: the o projection's form (K in one range); ksplit > 1: the
+// down projection's K-range slabs, summed by the finishing workgroups (`slabs`: [ksplit][64][N] fp32 scratch).  N = 256 or 1536;
+// `sync`: two zero-initialised words (the kernel leaves them zero).  Same bits as tasu_gemm_stream_bf16(RESID) + tasu_rmsnorm_fwd[_frag]
+// resp. tasu_gemm_stream_slabs + tasu_stream_finish_norm.
+extern "C" int tasu_gemm_stream_norm(const void* A, int lda, const void* W, int ldw, float* C, const float* resid, int M, int N, int K,
+                                     int ksplit, float* slabs, int64_t slab_floats, const float* norm_w, void* y, float eps, int a_frag,
+                                     int w_frag, int y_frag, void* sync, void* stream) {
+  using namespace tasu_stream;
+  if (!A || !W || !C || !resid || !norm_w || !y || !sync || M <= 0 || M > 64 || (N != 256 && N != 1536) || !k_supported(K, ksplit) || lda % 8 ||
+      ldw % 8)
+    return TASU_ERR_ARG;
+  if (!aligned16(A) || !aligned16(W) || !aligned16(C) || !aligned16(resid) || ((uintptr_t)y & 7)) return TASU_ERR_ARG;
+  if (ksplit > 1 && (!slabs || !aligned16(slabs) || (int64_t)ksplit * (N / 16) * 1024 > slab_floats)) return TASU_ERR_ARG;
+  Args a{};
+  a.A = (const bf16*)A;
+  a.W = (const bf16*)W;
+  a.M = M, a.N = N, a.K = K, a.lda = lda, a.ldw = ldw, a.ldc = N;
+  a.tiles = N / 16;
+  a.a_frag = a_frag, a.w_frag = w_frag;
+  NormTail t{};
+  t.nw = norm_w, t.y = (bf16*)y, t.eps = eps, t.y_frag = y_frag, t.sync = (unsigned*)sync, t.ksplit = ksplit;
+  hipStream_t st = (hipStream_t)stream;
+  if (ksplit == 1) {
+    a.C = C, a.R = resid;
+    t.C = C;
+    return N == 1536 ? launch_norm<E_RESID, 6>(a, t, 1, st) : launch_norm<E_RESID, 1>(a, t, 1, st);
+  }
+  a.C = slabs;
+  t.slabs = slabs, t.C = C, t.R = resid;
+  return N == 1536 ? launch_norm<E_SLAB, 6>(a, t, ksplit, st) : launch_norm<E_SLAB, 1>(a, t, ksplit, st);
 }
 
 namespace tasu_stream {

@@ -336,18 +336,32 @@ __device__ __forceinline__ size_t frag_index(int row, int c) {
   return ((((size_t)(c >> 5) * 4 + (row >> 4)) * 64 + ((c & 31) >> 3) * 16 + (row & 15)) << 3) + (c & 7);
 }
 
+// 16 bytes of a row another workgroup of the SAME launch may have written (write-through stores, st_out<true>): SC1 = read past
+// this CU's L1 at agent scope (buffer_load_dwordx4 ... sc1 through a descriptor on the row: MI355X_MICROARCH.md, "Valid forms":
+// every store of the handed-off bytes sc1 and drained before the ticket, every load of them an sc1 load behind the poll).
+template <bool SC1>
+__device__ __forceinline__ f32x4 ld_row_f32x4(const float* row_base, int elem) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (SC1) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row_base, 0, 0x7fffffff, 0x00020000);
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, elem * 4, 0, 16);
+    return __builtin_bit_cast(f32x4, r);
+  }
+#endif
+  return *(const f32x4*)(row_base + elem);
+}
+
 // One WAVE: y[row, :] = bf16(w * (x[row, :] * rstd)) in fragment order, D = NG * 256 -- the arithmetic and summation order of
 // norm.hip's rmsnorm_fwd_reg_kernel (lane owns columns 4 * lane + 256 * g).
-template <int NG, bool WT>
+template <int NG, bool WT, bool SC1 = false>
 __device__ __forceinline__ void norm_row_frag_ptr(const float* __restrict__ xrow, const float* __restrict__ w, bf16* __restrict__ y,
-                                                  int row, float eps) {
-  // xrow: the row's D fp32 values; row (< 64): its position in the fragment-order output
+                                                  int row, float eps, int y_frag = 1) {
+  // xrow: the row's D fp32 values (wave-uniform pointer); row (< 64): its position in the fragment-order output
   constexpr int D = NG * 256;
   const int lane = threadIdx.x & 63;
-  const float* xr = xrow + lane * 4;
   f32x4 v[NG], gw[NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) v[g] = *(const f32x4*)(xr + g * 256);
+  for (int g = 0; g < NG; ++g) v[g] = ld_row_f32x4<SC1>(xrow, lane * 4 + g * 256);
 #pragma unroll
   for (int g = 0; g < NG; ++g) gw[g] = *(const f32x4*)(w + lane * 4 + g * 256);
   float ss = 0.f;
@@ -360,7 +374,8 @@ __device__ __forceinline__ void norm_row_frag_ptr(const float* __restrict__ xrow
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = gw[g][j] * (v[g][j] * r);
-    st_out<WT>((bf16x4*)(y + frag_index(row, lane * 4 + g * 256)), __builtin_convertvector(o, bf16x4));
+    bf16* dst = y_frag ? y + frag_index(row, lane * 4 + g * 256) : y + (size_t)row * D + lane * 4 + g * 256;
+    st_out<WT>((bf16x4*)dst, __builtin_convertvector(o, bf16x4));
   }
 }
 
@@ -373,7 +388,7 @@ __device__ __forceinline__ void norm_row_frag(const float* __restrict__ x, const
 // One WAVE: row-wise finish of the E_SLAB partial tiles for a projection that feeds an RMSNorm (the down projection of a decode
 // layer), N = NG * 256 columns:  C[m, :] = R[m, :] + bf16(sum of the slabs in slab order);  y[m, :] = bf16(w * (C[m, :] * rstd)),
 // lane owns columns 4 * lane + 256 * g like norm_row_frag.  slabs: [ksplit][64 rows][N] (E_SLAB's layout).
-template <int NG, bool WT>
+template <int NG, bool WT, bool SC1 = false>
 __device__ __forceinline__ void finish_norm_row(const float* __restrict__ slabs, int ksplit, float* __restrict__ C,
                                                 const float* __restrict__ R, const float* __restrict__ nw, bf16* __restrict__ y,
                                                 float eps, int y_frag, int m) {
@@ -398,7 +413,8 @@ __device__ __forceinline__ void finish_norm_row(const float* __restrict__ slabs,
     for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int j = 0; j < KC; ++j)
-        t[g][j] = k0 + j < ksplit ? *(const f32x4*)(slabs + (size_t)(k0 + j) * 64 * N + e[g]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        t[g][j] = k0 + j < ksplit ? ld_row_f32x4<SC1>(slabs + (size_t)(k0 + j) * 64 * N + (size_t)m * N, lane * 4 + g * 256)
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -424,6 +440,63 @@ __device__ __forceinline__ void finish_norm_row(const float* __restrict__ slabs,
     bf16* dst = y_frag ? y + frag_index(m, n) : y + (size_t)m * N + n;
     st_out<WT>((bf16x4*)dst, __builtin_convertvector(o, bf16x4));
   }
+}
+
+// ---- Norm in the producer's launch (round 5).  The two RMSNorm launches of a decode layer are pure latency: a launch boundary,
+// one memory round trip for < 1 MB, a store (4.9 + 5.1 us per layer of 55.6: profiles/r04_decode_kernel_stats.csv).  Here the
+// workgroups of the projection store their tiles WRITE-THROUGH (st_out<true>), drain them, and ONE lane takes a ticket; the last
+// F = min(workgroups, rows) arrivers are the finishers: they wait for the last arrival (one lane polls the counter with sc1
+// loads), then finisher f normalises rows f, f + F, ... one per wave -- reading what the other workgroups wrote with sc1 loads
+// only -- with exactly the arithmetic of the separate kernels (norm_row_frag_ptr / finish_norm_row): the same bits.  The hand-off
+// is MI355X_MICROARCH.md's first measured row (one lane per storing workgroup adds to one counter behind every wave's
+// vmcnt(0) + the workgroup barrier; the consumer polls that counter; sc1 stores and loads).  State: two words {arrivals, done},
+// zero at allocation; the last finisher to leave resets both, so every launch and every hipGraph replay starts from zero.  No
+// deadlock: only the <= 64 LAST arrivers ever wait, and what they wait for are workgroups that are running or can still be
+// scheduled (a finisher holds one of >= 512 workgroup slots).
+struct NormTail {
+  const float* nw;         // norm weight [N]
+  bf16* y;                 // normed output (row-major [M, N] or fragment order)
+  float eps;
+  int y_frag;
+  const float* slabs;      // E_SLAB: the partial slabs [ksplit][64][N] (== Args::C), ksplit of them
+  int ksplit;
+  float* C;                // E_SLAB: fp32 output rows;  E_RESID: the rows the projection wrote (== Args::C)
+  const float* R;          // E_SLAB: residual rows
+  unsigned* sync;          // {arrivals, finishers done}
+};
+
+template <int NG, int EPI>
+__device__ __forceinline__ void norm_tail(const Args& p, const NormTail& t, float* red, int n_wg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: its write-through stores have left
+  __syncthreads();
+  int* s_i = (int*)red;
+  if (threadIdx.x == 0) s_i[0] = (int)__hip_atomic_fetch_add(t.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int ticket = s_i[0];
+  const int F = n_wg < p.M ? n_wg : p.M;
+  const int fi = ticket - (n_wg - F);
+  if (fi < 0) return;
+  if (threadIdx.x == 0) {                                // a finisher: wait for the last arrival
+    unsigned spins = 0;
+    while (__hip_atomic_load(t.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_wg && ++spins < (1u << 26))
+      __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  for (int row = fi + wave * F; row < p.M; row += NW * F) {
+    if constexpr (EPI == E_RESID) norm_row_frag_ptr<NG, false, true>((const float*)t.C + (size_t)row * (NG * 256), t.nw, t.y, row, t.eps, t.y_frag);
+    else finish_norm_row<NG, false, true>(t.slabs, t.ksplit, t.C, t.R, t.nw, t.y, t.eps, t.y_frag, row);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned d = __hip_atomic_fetch_add(t.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == (unsigned)F - 1) {                          // every finisher is past its poll: back to zero for the next launch
+      __hip_atomic_store(t.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(t.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#endif
 }
 
 }  // namespace tasu_stream

@@ -46,6 +46,12 @@ class HipOps:
         self.dec_split_order = (1, 7, 5, 2, 3, 4, 6, 8)   # K ranges tried in this order (K = 8960: 7 x 1280 before 5 x 1792; A/B: swap)
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
         self.dec_prologue = True       # the position's five set-up launches as one (tasu_decode_step_prologue)
+        # the RMSNorm behind the o / down projection inside the projection's launch (tasu_gemm_stream_norm: write-through tiles, a
+        # ticket per workgroup, the last arrivers normalise the rows).  Bit-identical, 5 launches per layer instead of 7 -- and
+        # SLOWER: 1.776 against 1.702 ms per position (MI355X, round 5): ~100-250 returning atomics on one counter, the poll and
+        # the sc1 round trip for the row cost what the launch boundary they replace costs.  Off; kept for A/B runs.
+        self.dec_fused_norm = False
+        self.norm_sync = torch.zeros(4, dtype=torch.int32, device="cuda")     # its two ticket words (zero between launches)
 
     # ------------------------------------------------------------------ plumbing
     @contextlib.contextmanager
@@ -468,6 +474,13 @@ class HipOps:
             ks = 0                                          # split-K kernels of gemm_skinny.hip (see begin_decode; the slab
                                                             # finish serves N = 256 * {1, 2, 6, 7} -- not the 7B's 3584)
         wf, wflag = (self._wf(b) if a_frag else (b, 0))
+        if self.dec_fused_norm and ks >= 1 and N in (256, 1536) and c.stride(0) == N and y.stride(0) == N and \
+                (ks == 1 or (ws is not None and ws.numel() >= ks * (N // 16) * 1024)):
+            # one launch: projection + residual (+ slab sum) + the norm of the finished rows by the last workgroups to arrive
+            return self._chk(self.lib.tasu_gemm_stream_norm(_p(a), a.stride(0), _p(wf), b.stride(0), _p(c), _p(resid), M, N, K, ks,
+                                                            _p(ws) if ks > 1 else None, ws.numel() if (ks > 1 and ws is not None) else 0,
+                                                            _p(norm_w), _p(y), eps, a_frag, wflag, y_frag, _p(self.norm_sync), self._stream()),
+                             "tasu_gemm_stream_norm")
         if ks == 1:
             # one launch for the projection + residual add, one for the norm (the sum of squares needs the whole row)
             self._chk(self.lib.tasu_gemm_stream_bf16(_p(a), a.stride(0), _p(wf), b.stride(0), _p(c), N, None, _p(resid), M, N, K,

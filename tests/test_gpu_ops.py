@@ -689,6 +689,42 @@ def test_cross_entropy_in_place(hip, fake):
         assert rel_err(buf, want_d) < 1e-2
 
 
+def test_cross_entropy_row_in_registers_in_place(hip, fake):
+    """Round 5: the training step's call (dlogits given, no argmax buffer, V >= 8192) runs on ce_reg_kernel -- the row's chunks
+    stay in registers between the statistics and the gradient pass (one read of the logits).  Full vocabulary incl. the pad
+    columns of the lm_head's Vpad, in place (dlogits aliasing logits), labels in the first and the last chunk, ignored rows:
+    loss, hits and gradient against the double; twice the same bits."""
+    M, V, ldv = 96, 151936, 151936
+    lg = randn(M, ldv, dtype=BF, seed=21, scale=3.0)
+    lab = torch.randint(0, V, (M,), dtype=I32)
+    lab[::2] = torch.randint(V - 8, V, (M // 2,), dtype=I32)
+    lab[1::4] = torch.randint(0, 8, (M // 4,), dtype=I32)
+    lab[::5] = -100
+    lab[3] = int(lg[3, :V].float().argmax())
+    inv = torch.tensor([1.0 / float((lab >= 0).sum())])
+    want_l, want_h, want_d = torch.zeros(M), torch.zeros(M, dtype=I32), torch.zeros(M, ldv, dtype=BF)
+    fake.ce_fwd_bwd(lg.clone(), lab, M, V, want_l, want_h, None, want_d, inv)
+    outs = []
+    for _ in range(2):
+        buf, rl, rh = lg.cuda(), torch.zeros(M, device="cuda"), torch.zeros(M, dtype=I32, device="cuda")
+        hip.ce_fwd_bwd(buf, lab.cuda(), M, V, rl, rh, None, buf, inv.cuda())
+        torch.cuda.synchronize()
+        assert float((rl.cpu() - want_l).abs().max()) < 1e-4 * float(want_l.abs().max())
+        assert torch.equal(rh.cpu(), want_h) and int(want_h.sum()) >= 1
+        assert rel_err(buf, want_d) < 1e-2
+        outs.append((buf.cpu(), rl.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # a narrower padded row (V not a multiple of 8 inside ldv): the pad columns get zero gradient
+    V2, ld2 = 9001, 9088
+    lg2 = torch.zeros(8, ld2, dtype=BF)
+    lg2[:, :V2] = randn(8, V2, dtype=BF, seed=22, scale=2.0)
+    lab2 = torch.randint(0, V2, (8,), dtype=I32)
+    inv2 = torch.tensor([1.0 / 8])
+    (lc, hc, dc), (lg_, hg, dg) = run_pair(hip, fake, "ce_fwd_bwd", [lg2, lab2, 8, V2, torch.zeros(8), torch.zeros(8, dtype=I32), None,
+                                                                       torch.ones(8, ld2, dtype=BF), inv2], [4, 5, 7])
+    assert rel_err(lg_, lc) < 1e-4 and torch.equal(hg, hc) and rel_err(dg, dc) < 1e-2 and float(dg[:, V2:].float().abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------------ front end
 def test_posterior_merge_adamw(hip, fake):
     R, V, ld = 40, 203, 256
@@ -1009,6 +1045,54 @@ def test_gemm_skinny_norm(hip_both, fake, M, N, K):
     (cc, yc), (cg, yg) = run_pair(hip, fake, "gemm_skinny_norm", [a, b, torch.zeros(M, N), r, M, N, K, w, torch.zeros(M, N, dtype=BF),
                                                                   1e-6, ws], [2, 8])
     assert rel_err(cg, cc) < 1e-2 and rel_err(yg, yc) < 2e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 1536, 8960), (64, 1536, 1536), (33, 256, 512), (64, 256, 256), (1, 1536, 1536), (48, 1536, 8960),
+                                   (7, 256, 1280)])
+def test_gemm_stream_norm_in_one_launch_equals_the_two_launch_forms(hip, fake, M, N, K):
+    """Round 5, tasu_gemm_stream_norm: the projection's workgroups store write-through, take a ticket, and the last arrivers
+    normalise the finished rows inside the SAME launch (agent-scope hand-off, csrc/stream_body.h: norm_tail) -- against the
+    two-launch forms (projection / slabs, then the norm kernel): the SAME BITS for the fp32 rows and the bf16 norm output, for
+    one K range (the o projection) and K-range slabs (the down projection), ragged row counts, and 200 back-to-back launches plus
+    a hipGraph replay loop (the ticket words must be back at zero after every launch)."""
+    a = randn(M, K, dtype=BF, seed=1).cuda()
+    b = randn(N, K, dtype=BF, seed=2, scale=1.0 / math.sqrt(K)).cuda()
+    r = randn(M, N, seed=3).cuda()
+    w = (randn(N, seed=4).abs() + 0.5).cuda()
+    ws = torch.zeros(32 * 64 * ((N + 95) // 96 * 96)).cuda()
+
+    def run(fused):
+        hip.dec_fused_norm = fused
+        c, y = torch.full((M, N), 7.0).cuda(), torch.full((M, N), 7.0, dtype=BF).cuda()
+        hip.gemm_skinny_norm(a, b, c, r, M, N, K, w, y, 1e-6, ws)
+        torch.cuda.synchronize()
+        return c, y
+    try:
+        c0, y0 = run(False)
+        c1, y1 = run(True)
+        assert torch.equal(c0, c1) and torch.equal(y0, y1)
+        assert int(hip.norm_sync.abs().sum()) == 0
+        cc, yc = torch.zeros(M, N), torch.zeros(M, N, dtype=BF)
+        fake.gemm_skinny_norm(a.cpu(), b.cpu(), cc, r.cpu(), M, N, K, w.cpu(), yc, 1e-6, None)
+        assert rel_err(c1, cc) < 1e-2 and rel_err(y1, yc) < 2e-2
+        hip.dec_fused_norm = True
+        c, y = torch.zeros(M, N).cuda(), torch.zeros(M, N, dtype=BF).cuda()
+        for i in range(200):                                                   # uneven arrival orders, launch after launch
+            hip.gemm_skinny_norm(a, b, c, r, M, N, K, w, y, 1e-6, ws)
+            if i % 50 == 49:
+                torch.cuda.synchronize()
+                assert torch.equal(c, c1) and torch.equal(y, y1) and int(hip.norm_sync.abs().sum()) == 0
+        g = torch.cuda.CUDAGraph()
+        y.zero_()
+        with torch.cuda.graph(g):
+            for _ in range(4):
+                hip.gemm_skinny_norm(a, b, c, r, M, N, K, w, y, 1e-6, ws)
+        for _ in range(25):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(c, c1) and torch.equal(y, y1) and int(hip.norm_sync.abs().sum()) == 0
+    finally:
+        hip.dec_fused_norm = False
 
 
 @pytest.mark.parametrize("M,H,G,K", [(64, 12, 2, 1536), (10, 4, 2, 256), (33, 2, 1, 128)])
