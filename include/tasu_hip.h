@@ -300,8 +300,9 @@ int tasu_attn_bwd(const void* qkv, const void* qt, const void* kt, const uint8_t
  *                              Q / dO tiles a workgroup stages (LDS-DMA, four deep), dK / dV are complete in their workgroup (no
  *                              partials: dk_part / dv_part untouched, may be NULL), the rotation runs in the epilogues.  dq: the
  *                              same bits as the per-head kernels; dk / dv: the same products in another fp32 association
- *   TASU_ATTN_KERNEL_POLICY    the GQA kernel where it is measured faster (H / G >= 7 or at least eight 64-token tiles:
- *                              Qwen2.5-7B, audio-SFT sequences), the per-head kernels otherwise (dk_part / dv_part required) */
+ *   TASU_ATTN_KERNEL_POLICY    the GQA kernel wherever it is served (round 5: faster or equal at every measured shape once both
+ *                              families got the cheaper softmax arithmetic), the per-head kernels otherwise (H == G;
+ *                              dk_part / dv_part required) */
 #define TASU_ATTN_KERNEL_POLICY 0
 #define TASU_ATTN_KERNEL_PER_HEAD 1
 #define TASU_ATTN_KERNEL_GQA 2
@@ -317,9 +318,8 @@ int tasu_attn_bwd_rope(const void* qkv, const uint8_t* key_mask, const void* dou
  * to the association of the fp32 sums (softmax denominators, dK / dV over the heads of a group).
  *   tasu_attn_sp_supported  1 when Spad <= 256, H % G == 0 and G <= 16
  *   tasu_attn_fwd_kernel    tasu_attn_fwd on a chosen kernel: TASU_ATTN_KERNEL_PER_HEAD = the tiled kernel (any S), _SP = the
- *                           single-pass kernel (bad argument when unsupported), _POLICY = single-pass where measured faster (its
- *                           grid of B * H one-per-CU workgroups about one or two whole rounds of the chip); tasu_attn_fwd is the
- *                           _POLICY form
+ *                           single-pass kernel (bad argument when unsupported), _POLICY = the tiled kernel (measured faster at
+ *                           every shape tried, tools/bench_attn_sp.py); tasu_attn_fwd is the _POLICY form
  *   tasu_attn_bwd_fused     the WHOLE attention backward: delta = rowsum(dO . O) (tasu_attn_bwd_prep), dQ / dK / dV and the rotary
  *                           embedding's backward; `out` = the forward's output.  _SP: two launches (delta is computed inside the
  *                           kernel, `delta` is not touched; dk_part / dv_part = fp32 [M, H * 128] each: one partial per QUERY head,

@@ -34,9 +34,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
                                                           const uint8_t* __restrict__ kmask, bf16* __restrict__ out,
                                                           float* __restrict__ lse, int S, int Spad, int H, int G,
                                                           float scale, int causal) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * ROW_TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[2 * ROW_TILE_BYTES + 256];
   char* sK = smem;
   char* sV = smem + ROW_TILE_BYTES;
+  float* sBias = (float*)(smem + 2 * ROW_TILE_BYTES);   // additive key bias of the staged tile (attn_tiles.h)
+  const float scale2 = scale * LOG2E;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // grid (H, B, query tiles): the late query tiles, which meet the most key tiles under the causal mask, are dispatched
   // first, so that a multi-round grid ends on the short ones
@@ -71,23 +73,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   const int nkt_all = (S + 63) >> 6;
   const int nkt = causal ? min(nkt_all, (qt + 1) * QW) : nkt_all;
   TileRegs rK, rVt;
-  uint32_t mk_next[4], mkw[4];                    // key-mask words of the tile, prefetched with it (no load -> use stall)
+  uint8_t mb_next = 0;                            // threads 0..63: the key-mask byte of the tile's key, prefetched with the tile
   fetch_row_tile(rK, kbase, LD, 0, S);
   fetch_row_tile(rVt, vbase, LD, 0, S);
+  if (threadIdx.x < 64) mb_next = mrow[threadIdx.x];
+  int qfirst[QW];                                 // first query of the unit (wave-uniform): tiles whose keys all precede it need no causal compare
 #pragma unroll
-  for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + st * 16 + 4 * qp);
+  for (int u = 0; u < QW; ++u) qfirst[u] = q0 + u * 16;
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     commit_row_tile(sK, rK);
     commit_row_tile(sV, rVt);
-#pragma unroll
-    for (int st = 0; st < 4; ++st) mkw[st] = mk_next[st];
+    if (threadIdx.x < 64) sBias[threadIdx.x] = mask_bias(mb_next);
     __syncthreads();
     if (kt + 1 < nkt) {
       fetch_row_tile(rK, kbase, LD, (kt + 1) * 64, S);
       fetch_row_tile(rVt, vbase, LD, (kt + 1) * 64, S);
-#pragma unroll
-      for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + (kt + 1) * 64 + st * 16 + 4 * qp);
+      if (threadIdx.x < 64) mb_next = mrow[(kt + 1) * 64 + threadIdx.x];
     }
 
     f32x4 s[QW][4];
@@ -106,16 +108,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
         for (int u = 0; u < QW; ++u) a[u] = mfma16(kfrag, qf[u][ks], a[u]);
       }
       const int key0 = kt * 64 + st * 16 + 4 * qp;
-      const uint32_t mk = mkw[st];
+      const f32x4 kb = *(const f32x4*)(sBias + st * 16 + 4 * qp);
 #pragma unroll
       for (int u = 0; u < QW; ++u) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = key0 + r;
-          const bool ok = ((mk >> (8 * r)) & 0xff) && (!causal || key <= qpos[u]);
-          a[u][r] = ok ? a[u][r] * scale : NEG_INF;
-          tmax[u] = fmaxf(tmax[u], a[u][r]);
+        for (int r = 0; r < 4; ++r) a[u][r] = __builtin_fmaf(a[u][r], scale2, kb[r]);
+        if (causal && kt * 64 + 63 > qfirst[u]) {        // the tile reaches past the unit's first query: per-element compare
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[u][r] = key0 + r <= qpos[u] ? a[u][r] : NEG_INF;
         }
+        tmax[u] = fmaxf(tmax[u], fmaxf(fmaxf(a[u][0], a[u][1]), fmaxf(a[u][2], a[u][3])));
         s[u][st] = a[u];
       }
     }
@@ -126,13 +128,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
       tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
       const float m_new = fmaxf(m_run[u], tm);
       const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      const float alpha = __expf(m_run[u] - m_use);  // m_run = -inf -> 0
+      const float alpha = exp2_fast(m_run[u] - m_use);  // m_run = -inf -> 0
       float psum = 0.f;
 #pragma unroll
       for (int st = 0; st < 4; ++st)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __expf(s[u][st][r] - m_use);
+          const float p = exp2_fast(s[u][st][r] - m_use);
           s[u][st][r] = p;
           psum += p;
         }
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
         const f32x4 v = o[u][nt] * inv;
         *(bf16x4*)(orow + nt * 16 + 4 * qp) = __builtin_convertvector(v, bf16x4);
       }
-      if (qp == 0) lse[((size_t)b * H + h) * Spad + qpos[u]] = l_tot > 0.f ? m_run[u] + __logf(l_tot) : 0.f;
+      if (qp == 0) lse[((size_t)b * H + h) * Spad + qpos[u]] = l_tot > 0.f ? (m_run[u] + __log2f(l_tot)) * LN2 : 0.f;   // (base-2 running max)
     }
   }
 }
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16* __restri
 }
 
 // =============================================================================== backward: dQ
-constexpr int DQ_LDS = 2 * ROW_TILE_BYTES;
+constexpr int DQ_LDS = 2 * ROW_TILE_BYTES + 768;      // K and V tiles + (at + 512, behind the dK / dV role's floats) the tile's key bias
 __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, const bf16* __restrict__ kt_g,
                                                  const uint8_t* __restrict__ kmask, const bf16* __restrict__ dout,
                                                  const float* __restrict__ lse, const float* __restrict__ delta,
@@ -223,6 +225,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, c
                                                  int causal, int bx, int by, int bz, char* smem) {
   char* sK = smem;
   char* sV = smem + ROW_TILE_BYTES;
+  float* sBias = (float*)(smem + 2 * ROW_TILE_BYTES + 512);   // (behind the dK / dV role's lse / delta floats of the merged kernel)
+  const float scale2 = scale * LOG2E;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qt = bx, h = by, b = bz;
   const int g = h / (H / G);
@@ -237,7 +241,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, c
   bf16x8 qf[4], dof[4];
   load_row_frags(qf, qbase, LD, qc, lane);
   load_row_frags(dof, dout + (size_t)b * S * (H * HD) + h * HD, H * HD, qc, lane);
-  const float lse_q = lse[((size_t)b * H + h) * Spad + qc];
+  const float lse2_q = lse[((size_t)b * H + h) * Spad + qc] * LOG2E;
   const float dl_q = delta[((size_t)b * H + h) * Spad + qc];
 
   f32x4 dq[8];
@@ -246,24 +250,22 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, c
 
   const int nkt = causal ? (qt + 1) : ((S + 63) >> 6);
   TileRegs rK, rV;
-  uint32_t mk_next[4], mkw[4];
+  uint8_t mb_next = 0;
   fetch_row_tile(rK, kbase, LD, 0, S);
   fetch_row_tile(rV, vbase, LD, 0, S);
-#pragma unroll
-  for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + st * 16 + 4 * qp);
+  if (threadIdx.x < 64) mb_next = mrow[threadIdx.x];
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     commit_row_tile(sK, rK);
     commit_row_tile(sV, rV);
-#pragma unroll
-    for (int st = 0; st < 4; ++st) mkw[st] = mk_next[st];
+    if (threadIdx.x < 64) sBias[threadIdx.x] = mask_bias(mb_next);
     __syncthreads();
     if (kt + 1 < nkt) {
       fetch_row_tile(rK, kbase, LD, (kt + 1) * 64, S);
       fetch_row_tile(rV, vbase, LD, (kt + 1) * 64, S);
-#pragma unroll
-      for (int st = 0; st < 4; ++st) mk_next[st] = *(const uint32_t*)(mrow + (kt + 1) * 64 + st * 16 + 4 * qp);
+      if (threadIdx.x < 64) mb_next = mrow[(kt + 1) * 64 + threadIdx.x];
     }
+    const bool diag = causal && kt == qt;                 // the only key tile that reaches past the block's first query
     f32x4 ds[4];
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
@@ -275,12 +277,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, c
         dp = mfma16(frag_row(sV, st, ks, lane), dof[ks], dp);
       }
       const int key0 = kt * 64 + st * 16 + 4 * qp;
-      const uint32_t mk = mkw[st];
+      const f32x4 kb = *(const f32x4*)(sBias + st * 16 + 4 * qp);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = key0 + r;
-        const bool ok = ((mk >> (8 * r)) & 0xff) && (!causal || key <= qpos);
-        const float p = ok ? __expf(a[r] * scale - lse_q) : 0.f;
+        float p = prob2(a[r], scale2, kb[r] - lse2_q);
+        if (diag) p = key0 + r <= qpos ? p : 0.f;
         ds[st][r] = p * (dp[r] - dl_q);
       }
     }
@@ -307,7 +308,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16* __restrict__ qkv, c
 // dK^T / dV^T accumulate in registers over the HPB heads x the (causal) query tiles, and only H/HPB fp32 partials
 // per kv head go to memory (HPB = TASU_ATTN_DKV_HPB(H/G): 3 for Qwen2.5-1.5B -> 2 partials per kv head; writing one
 // partial per QUERY head cost 50 MB of fp32 stores per call and dominated the kernel).  tasu_rope_bwd sums them.
-constexpr int DKV_LDS = 2 * ROW_TILE_BYTES + 128 * 4;   // Q and dO tiles + lse[64] + delta[64]
+constexpr int DKV_LDS = 2 * ROW_TILE_BYTES + 128 * 4 + 256;   static_assert(DKV_LDS == DQ_LDS, "the merged kernel's two roles share one LDS layout");   // Q and dO tiles + lse[64] + delta[64] (+ the dQ role's key bias row)
 __device__ __forceinline__ void attn_bwd_dkv_body(const bf16* __restrict__ qkv, const bf16* __restrict__ qt_g,
                                                   const uint8_t* __restrict__ kmask, const bf16* __restrict__ dout,
                                                   const bf16* __restrict__ dout_t, const float* __restrict__ lse,
@@ -328,6 +329,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16* __restrict__ qkv, 
   const int kc = min(kpos, S - 1);
   const int qp = lane >> 4;
   const bool kvalid = kpos < S && kmask[(size_t)b * Spad + kc] != 0;
+  const float kbias = kvalid ? 0.f : NEG_INF;
+  const float scale2 = scale * LOG2E;
   bf16x8 kf[4], vf[4];
   load_row_frags(kf, kbase, LD, kc, lane);
   load_row_frags(vf, vbase, LD, kc, lane);
@@ -347,8 +350,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16* __restrict__ qkv, 
     const int h = h0 + it / per_head, qtile = q_first + it % per_head;
     fetch_row_tile(rQ, qkv + (size_t)b * S * LD + h * HD, LD, qtile * 64, S);
     fetch_row_tile(rdO, dout + (size_t)b * S * (H * HD) + h * HD, H * HD, qtile * 64, S);
-    if (threadIdx.x < 128)
+    if (threadIdx.x < 128) {
       r_ld = (threadIdx.x < 64 ? lse : delta)[((size_t)b * H + h) * Spad + qtile * 64 + (threadIdx.x & 63)];
+      // lse in the base-2 domain; +inf for query rows past the sequence (their probabilities are exp2(-inf) = 0)
+      if (threadIdx.x < 64) r_ld = qtile * 64 + (int)threadIdx.x < S ? r_ld * LOG2E : __builtin_inff();
+    }
   };
   TileRegs rQ, rdO;
   if (n_it > 0) fetch(rQ, rdO, 0);
@@ -376,13 +382,13 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16* __restrict__ qkv, 
         const int q0 = qtile * 64 + qs * 16 + 4 * qp;  // < Spad
         const f32x4 l4 = *(const f32x4*)(s_ld + qs * 16 + 4 * qp);
         const f32x4 d4 = *(const f32x4*)(s_ld + 64 + qs * 16 + 4 * qp);
+        const bool diag = causal && qtile == ktile;     // the only query tile that does not lie wholly behind the keys
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = q0 + r;
-          const bool ok = kvalid && q < S && (!causal || kpos <= q);
-          const float p = ok ? __expf(a[r] * scale - l4[r]) : 0.f;
+          float p = prob2(a[r], scale2, kbias - l4[r]);
+          if (diag) p = kpos <= q0 + r ? p : 0.f;
           pv[q2][r] = p;
-          ds[q2][r] = ok ? p * (dp[r] - d4[r]) : 0.f;
+          ds[q2][r] = p * (dp[r] - d4[r]);
         }
       }
       const bf16x8 pf = pack_pair(pv[0], pv[1]);
@@ -480,11 +486,10 @@ extern "C" int tasu_attn_fwd_kernel(const void* qkv, const uint8_t* key_mask, vo
   if (kernel != TASU_ATTN_KERNEL_POLICY && kernel != TASU_ATTN_KERNEL_PER_HEAD && kernel != TASU_ATTN_KERNEL_SP) return TASU_ERR_ARG;
   const bool sp_ok = tasu_attn_sp_supported(S, H, G) != 0;
   if (kernel == TASU_ATTN_KERNEL_SP && !sp_ok) return TASU_ERR_ARG;
-  // policy (tools/bench_attn_sp.py, us per layer, tiled -> single pass): 16 x 256 x 12 heads 18.9 -> 18.0, 16 x 256 x 28 heads
-  // 35.5 -> 34.9, 8 x 256 x 12 13.4 -> 15.6, 32 x 256 x 12 33.7 -> 35.2: one workgroup per (batch, head) with 128 KiB of LDS is one
-  // per CU, so the single-pass kernel wins (narrowly) only when its grid is about one or two whole rounds of the 256 CUs
-  const int nwg = B * H;
-  const bool sp_take = sp_ok && ((nwg >= 176 && nwg <= 256) || (nwg >= 432 && nwg <= 512));
+  // policy (tools/bench_attn_sp.py, us per layer, tiled / single pass, after the tiled kernel got the cheaper softmax arithmetic of
+  // attn_tiles.h): 16 x 256 x 12 heads 17.3 / 18.0, 8 x 256 x 12 12.0 / 15.6, 32 x 256 x 12 32.3 / 35.2, 16 x 256 x 28 33.5 / 34.6 --
+  // the tiled kernel everywhere; the single-pass forward stays reachable by name (TASU_ATTN_KERNEL_SP)
+  const bool sp_take = false;
   if (kernel == TASU_ATTN_KERNEL_SP || (kernel == TASU_ATTN_KERNEL_POLICY && sp_take))
     return tasu_attn_sp_fwd_launch(qkv, key_mask, out, lse, B, S, H, G, scale, causal, (hipStream_t)stream);
   return attn_fwd_tiled(qkv, key_mask, out, lse, B, S, H, G, scale, causal, stream);
@@ -580,10 +585,11 @@ extern "C" int tasu_attn_bwd_rope(const void* qkv, const uint8_t* key_mask, cons
   if (kernel != TASU_ATTN_KERNEL_POLICY && kernel != TASU_ATTN_KERNEL_PER_HEAD && kernel != TASU_ATTN_KERNEL_GQA) return TASU_ERR_ARG;
   const bool gqa_ok = tasu_attn_gqa_supported(S, H, G) != 0;
   if (kernel == TASU_ATTN_KERNEL_GQA && !gqa_ok) return TASU_ERR_ARG;
-  // policy (tools/bench_attn_gqa.py): the GQA kernel where the per-head kernels' fp32 partials or their per-head staging cost
-  // most -- seven or more query heads per kv head (Qwen2.5-7B: 152.6 -> 103.4 us per layer) or eight or more 64-token tiles
-  // (audio-SFT sequences: 171.5 -> 156.0); the 1.5B training shape (6 heads, 4 tiles) is a tie (59.1 vs 61.2) and stays
-  const bool take = kernel == TASU_ATTN_KERNEL_GQA || (kernel == TASU_ATTN_KERNEL_POLICY && gqa_ok && (H / G >= 7 || (S + 63) / 64 >= 8));
+  // policy (tools/bench_attn_sp.py, us per layer incl. tasu_attn_bwd_prep, per-head kernels + tasu_rope_bwd -> the GQA kernel;
+  // round 5, both with the softmax arithmetic of attn_tiles.h -- the GQA kernel gained 9.6 us from it at the training shape, the
+  // per-head kernels nothing): 16 x 256 x 12 / 2 heads 58.1 -> 51.1, 32 x 256 x 12 / 2 107.6 -> 78.3, 16 x 256 x 28 / 4 152.8 -> 92.2,
+  // 8 x 256 x 12 / 2 47.5 -> 47.6: the GQA kernel wherever it is served (at least two query heads per kv head)
+  const bool take = kernel == TASU_ATTN_KERNEL_GQA || (kernel == TASU_ATTN_KERNEL_POLICY && gqa_ok);
   if (take)
     return tasu_attn_bwd_gqa_launch(qkv, key_mask, dout, lse, delta, cos_tab, sin_tab, dqkv, B, S, H, G, scale, causal, (hipStream_t)stream);
   if (!dk_part || !dv_part) return TASU_ERR_ARG;

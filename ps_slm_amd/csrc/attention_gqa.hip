@@ -161,7 +161,7 @@ __device__ __forceinline__ void dq_body(const bf16* __restrict__ qkv, const uint
   const int qpos = qt * 64 + sub * 16 + (lane & 15);
   const int qc = min(qpos, S - 1);
   const int qp = lane >> 4;
-  const float scale = p.scale;
+  const float scale = p.scale, scale2 = p.scale * LOG2E;
   const int causal = p.causal;
 
   for (int h0 = 0; h0 < p.hp; h0 += 3) {
@@ -170,7 +170,7 @@ __device__ __forceinline__ void dq_body(const bf16* __restrict__ qkv, const uint
     bf16x8 qf[4], dof[4];
     load_row_frags(qf, qkv + (size_t)b * S * LD + h * HD, LD, qc, lane);
     load_row_frags(dof, dout + (size_t)b * S * (H * HD) + h * HD, H * HD, qc, lane);
-    const float lse_q = lse[((size_t)b * H + h) * Spad + qc];
+    const float lse_q = lse[((size_t)b * H + h) * Spad + qc] * LOG2E;         // base-2 domain (attn_tiles.h: prob2)
     const float dl_q = delta[((size_t)b * H + h) * Spad + qc];
     f32x4 dq[8];
 #pragma unroll
@@ -205,8 +205,8 @@ __device__ __forceinline__ void dq_body(const bf16* __restrict__ qkv, const uint
         const uint32_t mk = *(const uint32_t*)(sMask + key0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool ok = ((mk >> (8 * r)) & 0xff) && (!causal || key0 + r <= qpos);
-          const float pr = ok ? __expf(a[r] * scale - lse_q) : 0.f;
+          float pr = prob2(a[r], scale2, mask_bias((mk >> (8 * r)) & 0xff) - lse_q);     // the per-head kernel's arithmetic: the same bits
+          if (causal) pr = key0 + r <= qpos ? pr : 0.f;
           ds[st][r] = pr * (dp[r] - dl_q);
         }
       }
@@ -262,7 +262,8 @@ __device__ __forceinline__ void dkv_body(const bf16* __restrict__ qkv, const uin
   const int kc = min(kpos, S - 1);
   const int qp = lane >> 4;
   const bool kvalid = kpos < S && kmask[(size_t)b * Spad + kc] != 0;
-  const float scale = p.scale;
+  const float kbias = kvalid ? 0.f : NEG_INF;
+  const float scale = p.scale, scale2 = p.scale * LOG2E;
   const int causal = p.causal;
   bf16x8 kf[4], vf[4];
   load_row_frags(kf, kbase, LD, kc, lane);
@@ -324,10 +325,10 @@ __device__ __forceinline__ void dkv_body(const bf16* __restrict__ qkv, const uin
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int q = q0 + r;
-        const bool ok = kvalid && q < S && (!causal || kpos <= q);
-        const float pr = ok ? __expf(a[r] * scale - l4[r]) : 0.f;
+        float pr = prob2(a[r], scale2, kbias - l4[r] * LOG2E);
+        pr = (q < S && (!causal || kpos <= q)) ? pr : 0.f;
         pv[q2][r] = pr;
-        ds[q2][r] = ok ? pr * (dp[r] - d4[r]) : 0.f;
+        ds[q2][r] = pr * (dp[r] - d4[r]);
       }
     }
     const bf16x8 pf = pack_pair(pv[0], pv[1]);

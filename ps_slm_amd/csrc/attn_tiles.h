@@ -82,6 +82,17 @@ __device__ __forceinline__ void load_row_frags(bf16x8 f[4], const bf16* g, int l
 
 constexpr float NEG_INF = -__builtin_inff();
 
+// Softmax arithmetic shared by the tiled kernels (attention.hip), the GQA backward (attention_gqa.hip) and the single-pass kernels
+// (attention_sp.hip), round 5: scores live in the base-2 domain, t = s * (scale * log2 e) + bias, with the key-padding mask as an
+// ADDITIVE bias (0 = attend, -inf = masked: exp2(-inf) = 0 exactly) -- one fused multiply-add per element where rounds 1-4 spent a
+// byte extract, two compares, a select, a multiply and expf's own multiply (the tiled kernels' softmax was ~1200 vector-ALU cycles
+// per wave and key tile against 512 matrix-pipe cycles).  The causal compare runs only on tiles that straddle the diagonal.
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float mask_bias(unsigned byte) { return byte ? 0.f : NEG_INF; }
+// probability of one score in the backward kernels: exp2(s * scale2 + (bias - lse * log2 e))
+__device__ __forceinline__ float prob2(float s, float scale2, float bias_minus_lse2) { return exp2_fast(__builtin_fmaf(s, scale2, bias_minus_lse2)); }
+
 // rotate-half RoPE backward of one pair (forward: y1 = x1 c - x2 s, y2 = x2 c + x1 s  =>  dx1 = dy1 c + dy2 s, dx2 = dy2 c - dy1 s).
 // Explicit FMAs (as rope_pair_f): tasu_rope_bwd and the epilogues of the GQA backward kernel share this text -- the same bits.
 __device__ __forceinline__ void rope_pair_bwd_f(float dy1, float dy2, float c, float s, float& dx1, float& dx2) {

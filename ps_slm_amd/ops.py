@@ -46,6 +46,7 @@ class HipOps:
         self.dec_split_order = (1, 7, 5, 2, 3, 4, 6, 8)   # K ranges tried in this order (K = 8960: 7 x 1280 before 5 x 1792; A/B: swap)
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
         self.dec_prologue = True       # the position's five set-up launches as one (tasu_decode_step_prologue)
+        self.attn_kernel = {"fwd": "policy", "bwd": "policy"}     # tools / tests: force an attention kernel family for A/B runs
         # the RMSNorm behind the o / down projection inside the projection's launch (tasu_gemm_stream_norm: write-through tiles, a
         # ticket per workgroup, the last arrivers normalise the rows).  Bit-identical, 5 launches per layer instead of 7 -- and
         # SLOWER: 1.776 against 1.702 ms per position (MI355X, round 5): ~100-250 returning atomics on one counter, the poll and
@@ -289,6 +290,8 @@ class HipOps:
                                          self._stream()), "tasu_rope_bwd")
 
     def attn_fwd(self, qkv, vt, key_mask, out, lse, B, S, H, G, scale, causal):
+        if self.attn_kernel["fwd"] != "policy":
+            return self.attn_fwd_on(self.attn_kernel["fwd"], qkv, key_mask, out, lse, B, S, H, G, scale, causal)
         self._chk(self.lib.tasu_attn_fwd(_p(qkv), _p(vt), _p(key_mask), _p(out), _p(lse), B, S, H, G, scale, int(causal),
                                          self._stream()), "tasu_attn_fwd")
 
@@ -300,9 +303,10 @@ class HipOps:
                                                 self.ATTN_KERNELS[kernel], self._stream()), "tasu_attn_fwd_kernel")
 
     def attn_bwd_fused(self, qkv, key_mask, dout, out, lse, delta, cos, sin, dqkv, dk_part, dv_part, B, S, H, G, scale, causal,
-                       kernel="policy"):
+                       kernel=None):
         """The whole attention backward (delta, dQ / dK / dV, rotary backward) behind one entry point (tasu_attn_bwd_fused): the
         single-pass kernels where Spad <= 256, else attn_bwd_prep + attn_bwd_rope.  dk_part / dv_part: fp32 [M, H * 128]."""
+        kernel = kernel or self.attn_kernel["bwd"]
         self._chk(self.lib.tasu_attn_bwd_fused(_p(qkv), _p(key_mask), _p(dout), _p(out), _p(lse), _p(delta), _p(cos), _p(sin), _p(dqkv),
                                                _p(dk_part), _p(dv_part), B, S, H, G, scale, int(causal), self.ATTN_KERNELS[kernel],
                                                self._stream()), "tasu_attn_bwd_fused")

@@ -271,7 +271,7 @@ class FakeOps:
         self.attn_fwd(qkv, None, key_mask, out, lse, B, S, H, G, scale, causal)
 
     def attn_bwd_fused(self, qkv, key_mask, dout, out, lse, delta, cos, sin, dqkv, dk_part, dv_part, B, S, H, G, scale, causal,
-                       kernel="policy"):
+                       kernel=None):
         self.attn_bwd_prep(dout, out, delta, None, B, S, H)
         self.attn_bwd_rope(qkv, key_mask, dout, lse, delta, cos, sin, dqkv, dk_part, dv_part, B, S, H, G, scale, causal)
 
