@@ -33,9 +33,11 @@ constexpr int TILE = ROW_TILE_BYTES;     // 64 tokens x 128 d, bf16
 constexpr int PAIR = 2 * TILE;           // K + V, or Q + dO
 constexpr int NS = 4;                    // ring slots
 constexpr int EXTRA = 2048;              // per slot: lse[64], delta[64] of the slot's query tile (+ the other issuing waves' duplicates)
-constexpr int MASK_MAX = 4096;           // key-mask bytes kept in LDS (Spad <= MASK_MAX)
+constexpr int MASK_MAX = 4096;           // keys whose additive mask bias (one float each: attn_tiles.h) is kept in LDS (Spad <= MASK_MAX)
 constexpr int DUMMY = 4096;              // where the non-issuing waves' zero-record DMAs land (every wave issues the same count)
-constexpr int LDS_BYTES = NS * PAIR + NS * EXTRA + MASK_MAX + DUMMY;
+constexpr int BIAS_BYTES = MASK_MAX * 4;
+constexpr int LDS_BYTES = NS * PAIR + NS * EXTRA + BIAS_BYTES + DUMMY;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -131,7 +133,7 @@ struct KvRing {
   __device__ __forceinline__ void issue(int t) const {     // t >= nkt: a dummy (zero records)
     // waves 8..11 issue four zero-record DMAs into the scratch area: the same count on every wave, no branch around a DMA
     const bool real = wave < 8;
-    char* slot = real ? smem + (t % NS) * PAIR + (wave >> 2) * TILE : smem + NS * PAIR + NS * EXTRA + MASK_MAX - (wave & 3) * 4096;
+    char* slot = real ? smem + (t % NS) * PAIR + (wave >> 2) * TILE : smem + NS * PAIR + NS * EXTRA + BIAS_BYTES - (wave & 3) * 4096;
     const int rows = (real && t < nkt) ? S - t * 64 : 0;
     dma_tile((wave < 4 ? kbase : vbase) + (size_t)t * 64 * (ld_bytes >> 1), ld_bytes, rows, slot, wave & 3, voff);
   }
@@ -147,9 +149,9 @@ __device__ __forceinline__ void dq_body(const bf16* __restrict__ qkv, const uint
   const int S = p.S, Spad = p.Spad, H = p.H, G = p.G;
   const int rep = H / G, LD = (H + 2 * G) * HD;
   const int h_first = g * rep + part * p.hp;
-  char* sMask = smem + NS * PAIR + NS * EXTRA;
+  float* sBias = (float*)(smem + NS * PAIR + NS * EXTRA);
   const uint8_t* mrow = kmask + (size_t)b * Spad;
-  for (int i = threadIdx.x * 4; i < Spad; i += NWAVES * 256) *(uint32_t*)(sMask + i) = *(const uint32_t*)(mrow + i);
+  for (int i = threadIdx.x; i < Spad; i += NWAVES * 64) sBias[i] = mask_bias(mrow[i]);
   KvRing ring;
   ring.kbase = qkv + (size_t)b * S * LD + (H + g) * HD;
   ring.vbase = qkv + (size_t)b * S * LD + (H + G + g) * HD;
@@ -191,6 +193,7 @@ __device__ __forceinline__ void dq_body(const bf16* __restrict__ qkv, const uint
       if (!active) continue;
       const char* sK = smem + (kt % NS) * PAIR;
       const char* sV = sK + TILE;
+      const bool diag = causal && kt == qt;              // the only key tile that reaches past the block's first query
       f32x4 ds[4];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
@@ -202,11 +205,11 @@ __device__ __forceinline__ void dq_body(const bf16* __restrict__ qkv, const uint
           dp = mfma16(frag_row(sV, st, ks, lane), dof[ks], dp);
         }
         const int key0 = kt * 64 + st * 16 + 4 * qp;
-        const uint32_t mk = *(const uint32_t*)(sMask + key0);
+        const f32x4 kb = *(const f32x4*)(sBias + key0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float pr = prob2(a[r], scale2, mask_bias((mk >> (8 * r)) & 0xff) - lse_q);     // the per-head kernel's arithmetic: the same bits
-          if (causal) pr = key0 + r <= qpos ? pr : 0.f;
+          float pr = prob2(a[r], scale2, kb[r] - lse_q);        // the per-head kernel's arithmetic: the same bits
+          if (diag) pr = key0 + r <= qpos ? pr : 0.f;
           ds[st][r] = pr * (dp[r] - dl_q);
         }
       }
@@ -284,13 +287,13 @@ __device__ __forceinline__ void dkv_body(const bf16* __restrict__ qkv, const uin
     const int itc = it < n_it ? it : 0;
     const int h = g * rep + itc / per_head, qtile = q_first + itc % per_head;
     const int rows = valid ? S - qtile * 64 : 0;
-    char* slot = worker ? smem + (it % NS) * PAIR + (wave >> 2) * TILE : smem + NS * PAIR + NS * EXTRA + MASK_MAX - (wave & 3) * 4096;
+    char* slot = worker ? smem + (it % NS) * PAIR + (wave >> 2) * TILE : smem + NS * PAIR + NS * EXTRA + BIAS_BYTES - (wave & 3) * 4096;
     const bf16* org = wave < 4 ? qkv + ((size_t)b * S + qtile * 64) * LD + h * HD
                                : dout + ((size_t)b * S + qtile * 64) * (H * HD) + h * HD;
     dma_tile(org, (wave < 4 ? LD : H * HD) * 2, rows, slot, wave & 3, voff);
     // lse / delta of the slot's 64 queries: waves 0 / 1 (the other waves write duplicates: every wave has 5 DMAs per slot)
     const float* src = ((wave & 1) ? delta : lse) + ((size_t)b * H + h) * Spad + qtile * 64;
-    char* fdst = smem + NS * PAIR + (worker ? (it % NS) * EXTRA + (wave & 1) * 256 + (wave >> 1) * 512 : NS * EXTRA + MASK_MAX);
+    char* fdst = smem + NS * PAIR + (worker ? (it % NS) * EXTRA + (wave & 1) * 256 + (wave >> 1) * 512 : NS * EXTRA + BIAS_BYTES);
     dma_floats64(src, valid, fdst, lane);
   };
   __builtin_amdgcn_sched_barrier(0);      // K / V fragment loads first, the DMAs behind them
@@ -307,6 +310,8 @@ __device__ __forceinline__ void dkv_body(const bf16* __restrict__ qkv, const uin
     if (!worker) continue;
     const char* sQ = smem + (it % NS) * PAIR;
     const char* sdO = sQ + TILE;
+    // per-element checks only where they can fail: the diagonal query tile (causal) and a tile that holds rows past the sequence
+    const bool edge = (causal && qtile == ktile) || qtile * 64 + 63 >= S;
     const float* s_ld = (const float*)(smem + NS * PAIR + (it % NS) * EXTRA);      // [0,64) lse, [64,128) delta
     f32x4 pv[2], ds[2];
 #pragma unroll
@@ -324,9 +329,8 @@ __device__ __forceinline__ void dkv_body(const bf16* __restrict__ qkv, const uin
       const f32x4 d4 = *(const f32x4*)(s_ld + 64 + qs * 16 + 4 * qp);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int q = q0 + r;
         float pr = prob2(a[r], scale2, kbias - l4[r] * LOG2E);
-        pr = (q < S && (!causal || kpos <= q)) ? pr : 0.f;
+        if (edge) pr = (q0 + r < S && (!causal || kpos <= q0 + r)) ? pr : 0.f;
         pv[q2][r] = pr;
         ds[q2][r] = pr * (dp[r] - d4[r]);
       }
