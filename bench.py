@@ -102,11 +102,16 @@ class TimedOps:
         """The recorded GEMM calls of one step, captured in launch order as ONE hipGraph and replayed: the sum of the GEMM launch
         durations without host gaps (an eager event pair around a C call that launches two kernels also times the host between
         them).  Same kernels, shapes and buffers as the step; operands are whatever the last step left in them."""
+        import gc
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for fn, a, k in self.calls:
-                fn(*a, **k)
+        gc.disable()                                       # (no cyclic collection inside a capture: TasuModel._graphed)
+        try:
+            with torch.cuda.graph(g):
+                for fn, a, k in self.calls:
+                    fn(*a, **k)
+        finally:
+            gc.enable()
         g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -512,8 +517,13 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         if want_decode:
             rec["decode"] = decode_leg(core, raw, B, new_tokens=200 if model_name != "qwen2.5-7b" else 64)
     engine.destroy()                                    # RCCL communicator, before the process group goes
+    core._graphs.clear()                                # this leg's captured graphs go NOW, with nothing capturing
+    getattr(core, "_dec_graphs", {}).clear()
     del engine, model, core, timed
+    import gc
+    gc.collect()
     if on_gpu:
+        torch.cuda.synchronize()
         torch.cuda.empty_cache()
     return rec
 

@@ -316,8 +316,15 @@ def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_pena
             return device_step()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            device_step()
+        import gc
+        gc_was = gc.isenabled()
+        gc.disable()                                             # (no cyclic collection inside a capture: TasuModel._graphed)
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                device_step()
+        finally:
+            if gc_was:
+                gc.enable()
         graphs[key] = g
         while len(graphs) > DECODE_GRAPH_CACHE:
             old, _ = graphs.popitem(last=False)

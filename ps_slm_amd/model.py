@@ -1121,8 +1121,25 @@ class TasuModel:
         graph = torch.cuda.CUDAGraph()
         before = set(st.dev)
         gen = self._buf_gen
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may call into HIP
-            fn()
+        # The cyclic garbage collector must not run inside a capture: an unreachable CUDAGraph of an earlier model (a cycle freed
+        # at a moment of the collector's choosing) would be destroyed while this stream is capturing -- hipGraphDestroy then fails
+        # with "operation not permitted when stream is capturing" inside a destructor and takes the process down (seen in bench.py
+        # between two legs).  torch.cuda.graph collects once before the capture begins; nothing may be collected until it ends.
+        import gc
+        gc_was = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may call into HIP
+                try:
+                    fn()
+                except BaseException:
+                    # an exception that unwinds out of a capture takes the process down in ~CUDAGraph: say what it was first
+                    import traceback
+                    traceback.print_exc()
+                    raise
+        finally:
+            if gc_was:
+                gc.enable()
         if gen != self._buf_gen:                      # a buffer grew DURING the capture: do not keep the graph
             return
         self._graphs[key] = (graph, {k: v for k, v in st.dev.items() if k not in before}, gen)
