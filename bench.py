@@ -567,6 +567,13 @@ def main():
 
     import torch.distributed as dist
 
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes a version banner to the C stdout at communicator
+    # creation, which C stdio flushes at process exit -- AFTER the JSON line.  File descriptor 1 is therefore pointed at stderr for
+    # the whole run and the line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -677,7 +684,7 @@ def main():
         if data_path is not None and "error" not in data_path:
             digest["data_path"] = {k: data_path[k] for k in ("text_only_utterances_per_s", "audio_wav_utterances_per_s")}
         line["digest"] = digest
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
