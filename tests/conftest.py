@@ -105,6 +105,31 @@ def decode_margin_cases():
     return geo, sd, cases
 
 
+def decode_lora_margin_cases():
+    """(geo, LoraConfig, state dict, adapter state dict, cases) of tests/golden/mid_generate_lora_margin.npz
+    (oracle/make_golden_generate_lora_margin.py): rounding-stable decode cases of the LoRA-ADAPTED model.  tokens = the REAL
+    reference's generate() with the LoRA formula applied by hand; tokens_base = what the un-adapted model decodes (different)."""
+    from ps_slm_amd.lora import LoraConfig
+    from ps_slm_amd.model import Geometry
+    from ps_slm_amd.synthetic import MID_GEOMETRY, decode_fixture_state_dict, random_lora_state_dict
+
+    z = load_npz("mid_generate_lora_margin")
+    assert int(z["double_disagreements"]) == 0
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    cfg = LoraConfig(r=int(z["r"]), lora_alpha=float(z["alpha"]), lora_dropout=0.0, target_modules=tuple(str(z["targets"]).split(",")))
+    sd = decode_fixture_state_dict(geo, int(z["seed_w"]))
+    lsd = random_lora_state_dict(geo, cfg, int(z["seed_l"]), b_scale=float(z["b_scale"]))
+    cases = []
+    for n in range(int(z["n_cases"])):
+        nb, new, min_len = (int(v) for v in z[f"c{n}_kw"])
+        cases.append(dict(ids=torch.from_numpy(z[f"c{n}_input_ids"]), am=torch.from_numpy(z[f"c{n}_attention_mask"]),
+                          post_ids=split_flat(z[f"c{n}_post_ids_flat"], z[f"c{n}_post_lens"]), tokens=z[f"c{n}_tokens"],
+                          tokens_base=z[f"c{n}_tokens_base"],
+                          kw=dict(num_beams=nb, max_new_tokens=new, min_length=min_len,
+                                  length_penalty=float(z[f"c{n}_length_penalty"]))))
+    return geo, cfg, sd, lsd, cases
+
+
 def ca_projector_case():
     """(geo, state dict, batch, fixture) of tests/golden/mid512_text_ca.npz (oracle/make_golden_ca.py): the alternate
     ``encoder_projector="cross-attention"`` (EncoderProjectorCTCCA) at llm_dim 512 (8 heads of 64)."""

@@ -94,6 +94,18 @@ def test_generate_with_adapters_on_gpu(ops):
     assert gm._lora_run is not None and gm.llm is not gm.lora._merged
 
 
+def test_generate_with_adapters_margin_cases_exact_on_gpu(ops):
+    """token ids are index work.  On the 7 rounding-stable decode cases of the ADAPTED model
+    (tests/golden/mid_generate_lora_margin.npz: reference fp32 with hand-applied LoRA == bf16 oracle on the merged weights == 8
+    jittered runs == the CPU double) the HIP decode path on the merged weights (hi/lo-split MFMA merge, streaming decode kernels,
+    beam kernels) must EQUAL the reference's tokens."""
+    from conftest import decode_lora_margin_cases
+    from test_lora_cpu import decode_lora_margin
+    geo, cfg, sd, lsd, cases = decode_lora_margin_cases()
+    gm = build(geo, cfg, sd, lsd, ops, "cuda")
+    assert not decode_lora_margin(gm, geo, cases)
+
+
 def test_lora_step_at_benchmark_shape(ops):
     """The use_peft=true step bench.py --lora times: Qwen2.5-1.5B geometry, 16 utterances x S = 256, r = 64 on all seven Linears,
     dropout 0.05.  Properties: peft's zero-B start (dA == 0 exactly, dB != 0, loss = the frozen model's); with non-zero adapters

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_npz
+from conftest import free_port, load_npz
 from fake_ops import FakeOps
 from ps_slm_amd.lora import LoraConfig, key_of
 from ps_slm_amd.model import Geometry, TasuModel
@@ -287,7 +287,7 @@ def _dp_worker(rank, world, port, ret):
 def test_lora_data_parallel_two_ranks_gloo():
     """The adapters' gradients travel in the same flat bucket: one range per span of decoder layers, issued as the backward
     completes them (before the projector's ranges); replicas stay equal and the update is AdamW on the rank-averaged gradient."""
-    world, port = 2, 31000 + os.getpid() % 2000
+    world, port = 2, free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_dp_worker, args=(world, port, ret), nprocs=world, join=True)
@@ -472,3 +472,38 @@ def test_dropout_flag_survives_a_graph_replay_of_the_forward():
     st2 = type("St", (), {"lora_drop": True, "dev": {}, "path": "text", "B": 1, "S": 1, "Ra": 0, "Rap": 0, "Fap": 0, "nLp": 0})()
     model.run_forward_llm(st2)
     assert st2.lora_drop is False                                          # eval mode: no masks, whatever the state held before
+
+
+def decode_lora_margin(model, geo, cases):
+    """[(case, got, want)] of the cases of tests/golden/mid_generate_lora_margin.npz whose tokens differ from the reference's."""
+    from ps_slm_amd.decode import beam_search_generate
+    bad = []
+    for n, c in enumerate(cases):
+        st = model.prepare_text(c["ids"], c["am"], None, c["post_ids"], None, None)
+        model.forward_projector_text(st)
+        toks = beam_search_generate(model, st, eos_token_id=geo.eos_id, pad_token_id=geo.eos_id, **c["kw"]).numpy()
+        if toks.shape != c["tokens"].shape or not np.array_equal(toks, c["tokens"]):
+            bad.append((n, toks.tolist(), c["tokens"].tolist()))
+    return bad
+
+
+def test_generate_with_adapters_margin_cases_exact_on_the_double():
+    """the decode of the ADAPTED model (merged weights W' = bf16(W + s B A), ps_slm_amd/lora.py:merged_llm) must
+    EQUAL the tokens of the reference's generate() with the LoRA formula applied by hand, on the 7 rounding-stable cases of
+    oracle/make_golden_generate_lora_margin.py (1-4 beams, min_length, length penalties, a 40-position case).  Every case decodes
+    to something else without the adapters, so equality says the adapters are in the decode."""
+    from conftest import decode_lora_margin_cases
+    geo, cfg, sd, lsd, cases = decode_lora_margin_cases()
+    assert len(cases) == 7 and all(c["tokens"].shape != c["tokens_base"].shape or not np.array_equal(c["tokens"], c["tokens_base"])
+                                   for c in cases)
+    m = build(geo, cfg, sd, lsd, FakeOps(), "cpu")
+    assert not decode_lora_margin(m, geo, cases)
+    base = TasuModel(geo, FakeOps(), "cpu")
+    base.load_reference_state_dict(sd)
+    assert len(decode_lora_margin(base, geo, cases)) == len(cases)            # (and the fixture's tokens_base are the base model's)
+    for c in cases:
+        st = base.prepare_text(c["ids"], c["am"], None, c["post_ids"], None, None)
+        base.forward_projector_text(st)
+        from ps_slm_amd.decode import beam_search_generate
+        tb = beam_search_generate(base, st, eos_token_id=geo.eos_id, pad_token_id=geo.eos_id, **c["kw"]).numpy()
+        assert np.array_equal(tb, c["tokens_base"])

@@ -337,6 +337,32 @@ def test_generate_margin_cases_vs_reference(mode):
         assert np.array_equal(toks.numpy(), c["tokens"]), (n, toks, c["tokens"])
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_generate_lora_margin_cases_vs_reference(mode):
+    """The 7 rounding-stable decode cases of the LoRA-ADAPTED model (oracle/make_golden_generate_lora_margin.py): the oracle's
+    beam search on the weights with W + s B A merged in reproduces the tokens of the REAL reference's generate() with the LoRA
+    formula applied by hand to its decoder (Multitask/ps-slm.py:199-216, 640-673) -- in fp32 on the fp32 merge and in bf16 mode on
+    the product's arithmetic (bf16 base weight + fp32 B A, rounded once more)."""
+    import dataclasses
+
+    from conftest import decode_lora_margin_cases
+    from ps_slm_amd.lora import key_of
+    geo, cfg, sd, lsd, cases = decode_lora_margin_cases()
+    gd = dataclasses.asdict(geo)
+    sdm = dict(sd)
+    for l in range(geo.llm_layers):
+        for t in cfg.target_modules:
+            k = f"llm.model.layers.{l}.{'mlp' if t in ('gate_proj', 'up_proj', 'down_proj') else 'self_attn'}.{t}.weight"
+            w = sd[k].double() if mode == "fp32" else sd[k].bfloat16().double()
+            sdm[k] = (w + cfg.scaling * (lsd[key_of(l, t, "B")].double() @ lsd[key_of(l, t, "A")].double())).float()
+    for n, c in enumerate(cases):
+        post, plen = O.pseudo_posterior(c["post_ids"], geo.ctc_vocab)
+        emb, mask, _, _ = O.merge(O.projector(sd, post, mode), plen, sd["llm.model.embed_tokens.weight"][c["ids"]], c["ids"],
+                                  c["am"], None, geo.speech_id)
+        toks = O.beam_search_generate(sdm, emb.detach(), mask, gd, mode=mode, **c["kw"])
+        assert np.array_equal(toks.numpy(), c["tokens"]), (n, toks, c["tokens"])
+
+
 @pytest.mark.parametrize("k", [1, 2])
 def test_linear_projector_vs_reference(k):
     """encoder_projector="linear" (EncoderProjectorConcat, projector.py:28-49), ds_rate 1 and 2, through the REAL reference at
