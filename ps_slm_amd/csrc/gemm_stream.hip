@@ -37,9 +37,10 @@
 #include "../../include/tasu_hip.h"
 
 namespace tasu_stream {
+bool k_ranges(int K, int ksplit, int& kr, int& rem);
 
 template <int KS, int EPI, int MT, bool FRAG>
-__global__ __launch_bounds__(64 * NW, 2) void stream_gemm_kernel(Args p) {
+__global__ __launch_bounds__(64 * NW, KS > 8 ? 1 : 2) void stream_gemm_kernel(Args p) {
   __shared__ __attribute__((aligned(16))) float red[2 * NW * MT * 256];
   int bx, by, bz;
   if (!grid_position((int)blockIdx.x, p.gx, p.gy, p.gz, bx, by, bz)) return;
@@ -70,28 +71,35 @@ int cu_count() {
 }
 
 template <int EPI, int MT, bool FRAG>
-int launch_ks(Args a, int ksplit, dim3 grid3, hipStream_t st) {
+int launch_ks(Args a, int kr, dim3 grid3, hipStream_t st) {
   a.gx = grid3.x, a.gy = grid3.y, a.gz = grid3.z;
   const int per = 8 * a.gz;                              // whole groups of (8 XCDs x row splits): grid_position
   const dim3 grid((a.gx * a.gy * a.gz + per - 1) / per * per);
-  const int ks = a.K / ksplit / (NW * 32);
+  const int ks = kr / (NW * 32);
   switch (ks) {
     case 1: TASU_LAUNCH((stream_gemm_kernel<1, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
     case 2: TASU_LAUNCH((stream_gemm_kernel<2, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
     case 5: TASU_LAUNCH((stream_gemm_kernel<5, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
     case 6: TASU_LAUNCH((stream_gemm_kernel<6, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
     case 7: TASU_LAUNCH((stream_gemm_kernel<7, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
+    case 14:                                              // K = 3584 in one range: row halves only (registers; stream_body.h)
+      if constexpr (MT == 2 && EPI != E_SLAB) {
+        TASU_LAUNCH((stream_gemm_kernel<14, EPI, 2, FRAG>), grid, dim3(64 * NW), 0, st, a);
+        return TASU_OK;
+      }
+      return TASU_ERR_ARG;
     default: return TASU_ERR_ARG;
   }
 }
 template <int EPI, int MT>
-int launch_mt(const Args& a, int ksplit, dim3 grid, hipStream_t st) {
+int launch_mt(const Args& a, int kr, dim3 grid, hipStream_t st) {
   if (a.a_frag != a.w_frag) return TASU_ERR_ARG;         // the operands travel in fragment order together or not at all
-  return a.a_frag ? launch_ks<EPI, MT, true>(a, ksplit, grid, st) : launch_ks<EPI, MT, false>(a, ksplit, grid, st);
+  return a.a_frag ? launch_ks<EPI, MT, true>(a, kr, grid, st) : launch_ks<EPI, MT, false>(a, kr, grid, st);
 }
 
+// ksplit ranges of kr_ (0: K / ksplit) starting at a.kstep0 / a.slab0
 template <int EPI>
-int launch(const Args& a, int ksplit, hipStream_t st) {
+int launch(const Args& a, int ksplit, hipStream_t st, int kr_ = 0) {
   // Rows per workgroup: all 64 when the column tiles alone give every CU work; otherwise the row tiles are split over
   // blockIdx.z (2 x 32 rows) so that twice as many workgroups each load half of the activations.
   const int cus = cu_count();
@@ -99,12 +107,13 @@ int launch(const Args& a, int ksplit, hipStream_t st) {
   // (K-range slabs of 1792: always -- 7 k-steps x 4 row tiles of activations per wave would not leave registers for the weight
   //  ring, so the two row halves each stream the weights (the second read comes from the XCD's L2).  Slabs of 1280 (5 k-steps,
   //  K = 8960 as 7 ranges) keep all 64 rows in one workgroup: every weight byte is read once.)
-  const int kr = a.K / ksplit;
-  const bool split_rows = row_tiles > 2 && ((EPI == E_SLAB && kr > 1280) || (EPI != E_SLAB && a.tiles * ksplit * 2 <= cus + cus / 4));
+  const int kr = kr_ ? kr_ : a.K / ksplit;
+  // (one range of 3584 = 14 k-steps per wave: two row tiles of activations are all the registers hold, for any row count)
+  const bool split_rows = kr > 1792 || (row_tiles > 2 && ((EPI == E_SLAB && kr > 1280) || (EPI != E_SLAB && a.tiles * ksplit * 2 <= cus + cus / 4)));
   const int zs = split_rows ? 2 : 1;
   const int per_split = cus / (ksplit * zs) > 0 ? cus / (ksplit * zs) : 1;
   const dim3 grid(a.tiles < per_split ? a.tiles : per_split, ksplit, zs);
-  return split_rows ? launch_mt<EPI, 2>(a, ksplit, grid, st) : launch_mt<EPI, 4>(a, ksplit, grid, st);
+  return split_rows ? launch_mt<EPI, 2>(a, kr, grid, st) : launch_mt<EPI, 4>(a, kr, grid, st);
 }
 
 // launch geometry of launch<EPI> for the fused-norm kernels (the same decisions)
@@ -138,10 +147,33 @@ int launch_norm(Args a, const NormTail& t, int ksplit, hipStream_t st) {
 #undef TASU_NL
 }
 
+static bool range_ok(int kr) { return kr == 256 || kr == 512 || kr == 1280 || kr == 1536 || kr == 1792; }
+
+// The K ranges of a split: ksplit equal ranges, or (K not a multiple) ksplit - 1 ranges of `kr` and a shorter last one of `rem`,
+// e.g. Qwen2.5-7B's down projection K = 18944 = 12 x 1536 + 512.  The ragged form is unique: the largest served range size whose
+// remainder is a served size too.  One range (ksplit = 1) may also be 3584 (14 k-steps per wave, row halves).
+bool k_ranges(int K, int ksplit, int& kr, int& rem) {
+  kr = rem = 0;
+  if (ksplit < 1 || K <= 0) return false;
+  if (K % ksplit == 0) {
+    kr = K / ksplit;
+    return range_ok(kr) || (ksplit == 1 && kr == 3584);
+  }
+  if (ksplit < 2) return false;
+  static const int sizes[] = {1792, 1536, 1280, 512};
+  for (int c : sizes) {
+    const int r = K - (ksplit - 1) * c;
+    if (r > 0 && r < c && range_ok(r)) {
+      kr = c, rem = r;
+      return true;
+    }
+  }
+  return false;
+}
+
 bool k_supported(int K, int ksplit) {
-  if (ksplit < 1 || K % ksplit) return false;
-  const int kr = K / ksplit;
-  return kr == 256 || kr == 512 || kr == 1280 || kr == 1536 || kr == 1792;
+  int kr, rem;
+  return k_ranges(K, ksplit, kr, rem);
 }
 
 }  // namespace tasu_stream
@@ -234,7 +266,14 @@ extern "C" int tasu_gemm_stream_slabs(const void* A, int lda, const void* W, int
   a.M = M, a.N = N, a.K = K, a.lda = lda, a.ldw = ldw, a.ldc = N;
   a.tiles = N / 16;
   a.a_frag = a_frag, a.w_frag = w_frag;
-  return launch<E_SLAB>(a, ksplit, (hipStream_t)stream);
+  int kr, rem;
+  k_ranges(K, ksplit, kr, rem);
+  if (!rem) return launch<E_SLAB>(a, ksplit, (hipStream_t)stream);
+  // ragged: ksplit - 1 ranges of kr, then the short last range into the last slab (two launches back to back, each over the whole chip; they write different slabs)
+  const int rc = launch<E_SLAB>(a, ksplit - 1, (hipStream_t)stream, kr);
+  if (rc != TASU_OK) return rc;
+  a.kstep0 = (ksplit - 1) * (kr / 32), a.slab0 = ksplit - 1;
+  return launch<E_SLAB>(a, 1, (hipStream_t)stream, rem);
 }
 
 // Round 5: projection + residual + RMSNorm of the result in ONE launch (norm_tail, stream_body.h).  C (fp32) = resid + bf16(A W^T);
@@ -246,7 +285,7 @@ extern "C" int tasu_gemm_stream_norm(const void* A, int lda, const void* W, int 
                                      int ksplit, float* slabs, int64_t slab_floats, const float* norm_w, void* y, float eps, int a_frag,
                                      int w_frag, int y_frag, void* sync, void* stream) {
   using namespace tasu_stream;
-  if (!A || !W || !C || !resid || !norm_w || !y || !sync || M <= 0 || M > 64 || (N != 256 && N != 1536) || !k_supported(K, ksplit) || lda % 8 ||
+  if (!A || !W || !C || !resid || !norm_w || !y || !sync || M <= 0 || M > 64 || (N != 256 && N != 1536) || ksplit < 1 || K % ksplit || !k_supported(K, ksplit) || lda % 8 ||
       ldw % 8)
     return TASU_ERR_ARG;
   if (!aligned16(A) || !aligned16(W) || !aligned16(C) || !aligned16(resid) || ((uintptr_t)y & 7)) return TASU_ERR_ARG;
@@ -271,13 +310,83 @@ extern "C" int tasu_gemm_stream_norm(const void* A, int lda, const void* W, int 
 }
 
 namespace tasu_stream {
-// Row-wise finish of tasu_gemm_stream_slabs (finish_norm_row, stream_body.h): one wave per row, 4 rows per block.
+// Row-wise finish of tasu_gemm_stream_slabs (finish_norm_row, stream_body.h): one wave per row, blockDim.x / 64 rows per block.
 template <int NG>
 __global__ __launch_bounds__(256) void stream_finish_norm_kernel(const float* __restrict__ slabs, int ksplit, float* __restrict__ C,
                                                                  const float* __restrict__ R, int M, const float* __restrict__ nw,
                                                                  bf16* __restrict__ y, float eps, int y_frag) {
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (m < M) finish_norm_row<NG, false>(slabs, ksplit, C, R, nw, y, eps, y_frag, m);
+}
+
+// N = 2 * NGH * 256 columns (3584: Qwen2.5-7B's down projection): a row's slab chunks in flight do not fit one wave's registers, so
+// TWO waves share a row -- wave half h owns the column groups h * NGH .. + NGH - 1 -- and the sum of squares passes through LDS in
+// the one-wave kernels' order (per lane the groups 0 .. NG - 1 in sequence, then the wave reduction).  blockDim.x / 128 rows per block (1 or 2).
+template <int NGH>
+__global__ __launch_bounds__(256) void stream_finish_norm_pair_kernel(const float* __restrict__ slabs, int ksplit, float* __restrict__ C,
+                                                                      const float* __restrict__ R, int M, const float* __restrict__ nw,
+                                                                      bf16* __restrict__ y, float eps, int y_frag) {
+  constexpr int N = 2 * NGH * 256, KC = 4;
+  __shared__ float xch[2][64];
+  __shared__ float rsx[2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rp = wave >> 1, h = wave & 1;
+  const int m = blockIdx.x * (blockDim.x >> 7) + rp;
+  const bool live = m < M;
+  const int mm = live ? m : M - 1;                       // (a block's spare row pair repeats the last row and stores nothing)
+  f32x4 v[NGH], s[NGH];
+#pragma unroll
+  for (int g = 0; g < NGH; ++g) {
+    v[g] = *(const f32x4*)(R + (size_t)mm * N + lane * 4 + (h * NGH + g) * 256);
+    s[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int k0 = 0; k0 < ksplit; k0 += KC) {
+    f32x4 t[NGH][KC];
+#pragma unroll
+    for (int g = 0; g < NGH; ++g)
+#pragma unroll
+      for (int j = 0; j < KC; ++j)
+        t[g][j] = k0 + j < ksplit ? *(const f32x4*)(slabs + (size_t)(k0 + j) * 64 * N + (size_t)mm * N + lane * 4 + (h * NGH + g) * 256)
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NGH; ++g)
+#pragma unroll
+      for (int j = 0; j < KC; ++j) s[g] += t[g][j];
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int g = 0; g < NGH; ++g) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[g][q] = v[g][q] + bf16_round(s[g][q]);
+    if (live) *(f32x4*)(C + (size_t)m * N + lane * 4 + (h * NGH + g) * 256) = v[g];
+  }
+  if (h == 1) ss = 0.f;
+  if (h == 0) {
+#pragma unroll
+    for (int g = 0; g < NGH; ++g) ss += v[g][0] * v[g][0] + v[g][1] * v[g][1] + v[g][2] * v[g][2] + v[g][3] * v[g][3];
+    xch[rp][lane] = ss;
+  }
+  __syncthreads();
+  if (h == 1) {
+    ss = xch[rp][lane];
+#pragma unroll
+    for (int g = 0; g < NGH; ++g) ss += v[g][0] * v[g][0] + v[g][1] * v[g][1] + v[g][2] * v[g][2] + v[g][3] * v[g][3];
+    ss = wave_sum(ss);
+    if (lane == 0) rsx[rp] = rsqrtf(ss / (float)N + eps);
+  }
+  __syncthreads();
+  const float rs = rsx[rp];
+  if (!live) return;
+#pragma unroll
+  for (int g = 0; g < NGH; ++g) {
+    const int n = lane * 4 + (h * NGH + g) * 256;
+    const f32x4 w = *(const f32x4*)(nw + n);
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = w[q] * (v[g][q] * rs);
+    bf16* dst = y_frag ? y + frag_index(m, n) : y + (size_t)m * N + n;
+    *(bf16x4*)dst = __builtin_convertvector(o, bf16x4);
+  }
 }
 
 // Re-lays a row-major weight matrix out in fragment order, one 16-row column tile at a time in the row order of the tile's
@@ -298,15 +407,25 @@ __global__ __launch_bounds__(256) void to_fragment_order_kernel(Args p, bf16* __
 extern "C" int tasu_stream_finish_norm(const float* slabs, int ksplit, float* C, const float* resid, int M, int N,
                                        const float* norm_w, void* y, float eps, int y_frag, void* stream) {
   if (!slabs || !C || !resid || !norm_w || !y || ksplit < 1 || M <= 0 || M > 64 || N <= 0 || N % 256) return TASU_ERR_ARG;
-  const dim3 grid((M + 3) / 4);
+  // rows per block: the finish is bound by what ONE CU ingests (ksplit slabs x N x 4 B per row), so the rows are spread over as
+  // many CUs as there are rows (TASU_FINISH_ROWS: A/B runs; round 4 ran 4 rows per block)
+  static const int rows_env = [] { const char* e = getenv("TASU_FINISH_ROWS"); return e ? atoi(e) : 0; }();
+  const int rows = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : 1;
+  const dim3 grid((M + rows - 1) / rows);
   hipStream_t st = (hipStream_t)stream;
 #define TASU_FIN(NG)                                                                                                              \
   case NG:                                                                                                                        \
-    TASU_LAUNCH(tasu_stream::stream_finish_norm_kernel<NG>, grid, dim3(256), 0, st, slabs, ksplit, C, resid, M, norm_w, (bf16*)y, \
+    TASU_LAUNCH(tasu_stream::stream_finish_norm_kernel<NG>, grid, dim3(64 * rows), 0, st, slabs, ksplit, C, resid, M, norm_w, (bf16*)y, \
                 eps, y_frag);                                                                                                     \
     return TASU_OK;
   switch (N / 256) {
     TASU_FIN(1) TASU_FIN(2) TASU_FIN(6) TASU_FIN(7)
+    case 14: {
+      const int pr = rows >= 2 ? 2 : 1;
+      TASU_LAUNCH(tasu_stream::stream_finish_norm_pair_kernel<7>, dim3((M + pr - 1) / pr), dim3(128 * pr), 0, st, slabs, ksplit, C, resid, M,
+                  norm_w, (bf16*)y, eps, y_frag);
+      return TASU_OK;
+    }
     default: return TASU_ERR_ARG;
   }
 #undef TASU_FIN

@@ -17,7 +17,7 @@ __device__ __forceinline__ size_t frag_offset(int row, int c) {
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ src,
                                                           const float* __restrict__ w, bf16* __restrict__ y,
                                                           float* __restrict__ rstd, int M, int D, float eps, int frag, int ldy) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
   const int srow = src ? src[row] : row;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __res
                                                               const float* __restrict__ w, bf16* __restrict__ y,
                                                               float* __restrict__ rstd, int M, float eps, int frag, int ldy) {
   constexpr int D = NG * 256;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
   const int srow = src ? src[row] : row;
@@ -349,12 +349,16 @@ static int rmsnorm_fwd_any(const float* x, const int32_t* src, const float* w, v
   if (!x || !w || !y || M <= 0 || D <= 0 || D % 4) return TASU_ERR_ARG;
   if (ldy == 0) ldy = D;
   if (ldy < D || ldy % 4 || (frag && ldy != D)) return TASU_ERR_ARG;
-  const dim3 grid((M + 3) / 4);
+  // one wave per row.  A decode step's <= 64 rows go one per workgroup (64 CUs instead of 16: the kernel is one memory round trip
+  // and a workgroup's rows share a CU's load path); the training step's thousands of rows four per workgroup.  TASU_NORM_ROWS: A/B.
+  static const int rows_env = [] { const char* e = getenv("TASU_NORM_ROWS"); return e ? atoi(e) : 0; }();
+  const int rows = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : (M <= 64 ? 1 : 4);
+  const dim3 grid((M + rows - 1) / rows), block(64 * rows);
   hipStream_t st = (hipStream_t)stream;
-  if (D == 1536) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<6>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag, ldy);
-  else if (D == 3584) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<14>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag, ldy);
-  else if (D == 256) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<1>, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag, ldy);
-  else TASU_LAUNCH(rmsnorm_fwd_kernel, grid, dim3(256), 0, st, x, src, w, (bf16*)y, rstd, M, D, eps, frag, ldy);
+  if (D == 1536) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<6>, grid, block, 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag, ldy);
+  else if (D == 3584) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<14>, grid, block, 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag, ldy);
+  else if (D == 256) TASU_LAUNCH(rmsnorm_fwd_reg_kernel<1>, grid, block, 0, st, x, src, w, (bf16*)y, rstd, M, eps, frag, ldy);
+  else TASU_LAUNCH(rmsnorm_fwd_kernel, grid, block, 0, st, x, src, w, (bf16*)y, rstd, M, D, eps, frag, ldy);
   return TASU_OK;
 }
 extern "C" int tasu_rmsnorm_fwd_ld(const float* x, const float* w, void* y, int ldy, float* rstd, int M, int D, float eps, void* stream) {

@@ -35,6 +35,8 @@ struct Args {
   bf16* vc;
   const int32_t* pos;
   int gx, gy, gz;         // the virtual grid [column-tile walkers][K ranges][row splits] (grid_position)
+  int kstep0, slab0;      // E_SLAB, ragged K (tasu_gemm_stream_slabs: K = n * range + a shorter last range, launched apart): the
+                          // launch's first k-step (of 32) inside K and its first slab; 0 otherwise
 };
 
 // Position of linear workgroup `lin` in the virtual grid (gx, gy, gz); false: no work (the launch is rounded up).  Workgroups
@@ -96,11 +98,11 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
   const int krange = NW * KS * 32;
-  const int k0 = by * krange + wave * (KS * 32) + lq * 8;      // this lane's first k of step 0
+  const int k0 = p.kstep0 * 32 + by * krange + wave * (KS * 32) + lq * 8;      // this lane's first k of step 0
 
   // ---- activations: this wave's K slice of all 64 rows, as MFMA B operands (rows beyond M are clamped; masked at the store)
   bf16x8 a[MT][KS];
-  const int cg0 = (by * NW + wave) * KS;                   // this wave's first global k-step
+  const int cg0 = p.kstep0 + (by * NW + wave) * KS;        // this wave's first global k-step
   if (FRAG) {
 #pragma unroll
     for (int c = 0; c < KS; ++c)
@@ -176,7 +178,7 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
     if (EPI == E_SLAB) {
       // row-major [K range][64 rows][N]: 64-byte pieces here (spread over ~250 workgroups), so that the row-wise finish, which
       // runs on few CUs, reads whole contiguous rows (against per-tile slabs a row is 16 bytes every 256: 13 of its 18 us)
-      float* slab = (float*)p.C + (size_t)by * 64 * p.N;
+      float* slab = (float*)p.C + (size_t)(p.slab0 + by) * 64 * p.N;
       st_out<WT>((f32x4*)(slab + (size_t)m * p.N + t * 16 + 4 * lq), s);
       return;
     }
@@ -299,6 +301,92 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
     else finish(i, load_epi(i));
   };
 
+  if constexpr (KS > 8) {
+    // K = 3584 in ONE range (Qwen2.5-7B's q|k|v, o and gate|up: 14 k-steps per wave; MT = 2, one workgroup per CU = 256 registers
+    // per lane, 112 of them activations).  A tile's 14 KiB per wave travel as two HALVES of 7 k-steps on a ring of three half-tile
+    // register sets (84 registers): one tile per wave in flight behind the one being multiplied (8 waves x 14 KiB per CU), the
+    // same branch-free ring as below with the tile boundary on every second slot -- three tiles per trip.
+    static_assert(KS % 2 == 0, "two halves");
+    constexpr int KH = KS / 2;
+    auto load_h = [&](bf16x8 (&w)[KH], int hidx) {
+      const int i = hidx >> 1, part = hidx & 1;
+      if (FRAG) {
+        const bf16* wr = p.W + (((size_t)tile_of(i) * ksteps_all + cg0 + part * KH) * 64 + lane) * 8;
+#pragma unroll
+        for (int c = 0; c < KH; ++c) w[c] = __builtin_nontemporal_load((const bf16x8*)(wr + c * 512));
+      } else {
+        const bf16* wr = p.W + (size_t)min(weight_row<EPI>(p, tile_of(i), l15), (EPI == E_SWIGLU ? 2 * p.I : p.N) - 1) * p.ldw + k0 + part * KH * 32;
+#pragma unroll
+        for (int c = 0; c < KH; ++c) w[c] = __builtin_nontemporal_load((const bf16x8*)(wr + c * 32));
+      }
+    };
+    f32x4 acc[MT];
+    auto mma_h = [&](const bf16x8 (&w)[KH], int part) {
+      if (part == 0) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int c = 0; c < KH; ++c)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = mfma16(w[c], part ? a[t][KH + c] : a[t][c], acc[t]);
+    };
+    auto meet = [&](int i) {                                   // the tile's partial sums meet in LDS; waves 0..MT-1 finish it
+      const int buf = i & 1;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) *(f32x4*)(red + (((buf * NW + wave) * MT + t) * 64 + lane) * 4) = acc[t];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      finish(i, load_epi(i));
+    };
+    bf16x8 h0[KH], h1[KH], h2[KH];
+    load_h(h0, 0);
+    load_h(h1, 1);
+    if (ntl <= 2) {
+      // one or two tiles (q|k|v, o): nothing is read twice, the epilogue operands travel with the weights
+      if (ntl == 2) load_h(h2, 2);
+      const Epi e0 = load_epi(0), e1 = load_epi(1);
+      auto meet_pre = [&](int i, const Epi& ep) {
+        const int buf = i & 1;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) *(f32x4*)(red + (((buf * NW + wave) * MT + t) * 64 + lane) * 4) = acc[t];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        finish(i, ep);
+      };
+      mma_h(h0, 0);
+      if (ntl == 2) load_h(h0, 3);
+      mma_h(h1, 1);
+      meet_pre(0, e0);
+      if (ntl == 2) {
+        mma_h(h2, 0);
+        mma_h(h0, 1);
+        meet_pre(1, e1);
+      }
+      return;
+    }
+    for (int i = 0; i < ntl; i += 3) {
+      const int h = 2 * i;
+      load_h(h2, h + 2);
+      mma_h(h0, 0);
+      load_h(h0, h + 3);
+      mma_h(h1, 1);
+      meet(i);
+      load_h(h1, h + 4);
+      mma_h(h2, 0);
+      load_h(h2, h + 5);
+      mma_h(h0, 1);
+      meet(i + 1);
+      load_h(h0, h + 6);
+      mma_h(h1, 0);
+      load_h(h1, h + 7);
+      mma_h(h2, 1);
+      meet(i + 2);
+    }
+    return;
+  }
   bf16x8 w0[KS], w1[KS], w2[KS];
   TASU_STREAM_STAMP(0);
   load_w(w0, 0);

@@ -43,7 +43,10 @@ class HipOps:
         self.dec_frag = False          # set by begin_decode(): decode activations travel in fragment order
         self.dec_frag_act = False      # ... including the MLP activation that feeds the down projection
         self.dec_down_slabs = True     # down projection as K-range slabs + tasu_stream_finish_norm (False: split-K kernels)
-        self.dec_split_order = (1, 7, 5, 2, 3, 4, 6, 8)   # K ranges tried in this order (K = 8960: 7 x 1280 before 5 x 1792; A/B: swap)
+        self.dec_split_order = (1, 7, 5, 2, 3, 4, 6, 8, 13)   # K ranges tried in this order (K = 8960: 7 x 1280 before 5 x 1792; A/B: swap;
+                                                              # 13: Qwen2.5-7B's K = 18944 = 12 x 1536 + 512, a ragged split)
+        self.dec_stream_7b = True      # K = 3584 in one range / K = 18944 as a ragged split on the streaming kernels (False: A/B runs,
+                                       # the split-K kernels of gemm_skinny.hip as before round 5)
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
         self.dec_prologue = True       # the position's five set-up launches as one (tasu_decode_step_prologue)
         self.attn_kernel = {"fwd": "policy", "bwd": "policy"}     # tools / tests: force an attention kernel family for A/B runs
@@ -146,10 +149,10 @@ class HipOps:
     # ------------------------------------------------------------------ decode-step GEMMs
     def _stream_split(self, K):
         """K ranges the streaming kernels can take this K in (0 = not served)."""
-        if not self.use_stream:
+        if not self.use_stream or (not self.dec_stream_7b and K in (3584, 18944)):
             return 0
         for ks in self.dec_split_order:
-            if K % ks == 0 and self.lib.tasu_stream_supported(K, ks):
+            if self.lib.tasu_stream_supported(K, ks):        # (equal ranges, or ks - 1 equal ranges and a shorter last one)
                 return ks
         return 0
 
@@ -474,9 +477,9 @@ class HipOps:
         # the down projection, whose input layout is dec_frag_act
         a_frag = int(self.dec_frag if ks == 1 else self.dec_frag_act)
         y_frag = int(self.dec_frag)
-        if ks > 1 and (not (self.dec_down_slabs or a_frag) or N % 256 or N // 256 not in (1, 2, 6, 7)):
+        if ks > 1 and (not (self.dec_down_slabs or a_frag) or N % 256 or N // 256 not in (1, 2, 6, 7, 14)):
             ks = 0                                          # split-K kernels of gemm_skinny.hip (see begin_decode; the slab
-                                                            # finish serves N = 256 * {1, 2, 6, 7} -- not the 7B's 3584)
+                                                            # finish serves N = 256 * {1, 2, 6, 7, 14})
         wf, wflag = (self._wf(b) if a_frag else (b, 0))
         if self.dec_fused_norm and ks >= 1 and N in (256, 1536) and c.stride(0) == N and y.stride(0) == N and \
                 (ks == 1 or (ws is not None and ws.numel() >= ks * (N // 16) * 1024)):

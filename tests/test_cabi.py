@@ -40,6 +40,20 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.tasu_adamw(None, None, None, None, None, 0, 5e-5, 0.9, 0.999, 1e-6, 0.0, 1, 1.0, None) == 1
 
 
+def test_stream_k_ranges_equal_and_ragged():
+    """tasu_stream_supported (host code): the K ranges the weight-streaming decode GEMMs take -- equal ranges of 256 / 512 / 1280 /
+    1536 / 1792, ONE range of 3584 (Qwen2.5-7B's hidden size: 14 k-steps per wave on row halves), or n - 1 equal ranges and a
+    shorter last one (the 7B's down projection K = 18944 = 12 x 1536 + 512)."""
+    from ps_slm_amd import _lib
+    lib = _lib.load()
+    yes = [(256, 1), (1536, 1), (1792, 1), (3584, 1), (3584, 2), (8960, 7), (8960, 5), (18944, 13), (18944, 37), (512, 2)]
+    no = [(3584, 4), (18944, 12), (18944, 1), (7168, 1), (1000, 1), (8960, 3), (1536, 0), (2048, 1)]
+    for K, ks in yes:
+        assert lib.tasu_stream_supported(K, ks) == 1, (K, ks)
+    for K, ks in no:
+        assert lib.tasu_stream_supported(K, ks) == 0, (K, ks)
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from ps_slm_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

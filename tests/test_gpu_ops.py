@@ -1005,7 +1005,8 @@ def test_logprob_topk_full_vocab(hip, fake):
 
 
 @pytest.mark.parametrize("M,N,K,mode,bias", [(64, 1536, 8960, 2, False), (64, 2048, 1536, 0, True), (40, 17920, 1536, 0, False),
-                                             (64, 1000, 256, 1, True), (4, 151936, 1536, 0, False), (64, 1536, 1536, 2, False)])
+                                             (64, 1000, 256, 1, True), (4, 151936, 1536, 0, False), (64, 1536, 1536, 2, False),
+                                             (64, 5000, 3584, 0, True), (33, 3584, 3584, 2, False), (64, 3584, 18944, 2, False)])
 def test_gemm_skinny(hip_both, fake, M, N, K, mode, bias):
     hip = hip_both
     ldc = (N + 63) // 64 * 64
@@ -1027,7 +1028,7 @@ def test_gemm_skinny(hip_both, fake, M, N, K, mode, bias):
     assert torch.equal(gc, g2)
 
 
-@pytest.mark.parametrize("M,I,K", [(64, 8960, 1536), (40, 200, 128), (64, 96, 4096)])
+@pytest.mark.parametrize("M,I,K", [(64, 8960, 1536), (40, 200, 128), (64, 96, 4096), (64, 2400, 3584), (17, 18944, 3584)])
 def test_gemm_skinny_swiglu(hip_both, fake, M, I, K):
     hip = hip_both
     a = randn(M, K, dtype=BF, seed=1)
@@ -1040,7 +1041,8 @@ def test_gemm_skinny_swiglu(hip_both, fake, M, I, K):
     assert rel_err(ga, ca) < 2e-2
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 1536, 8960), (64, 1536, 1536), (33, 256, 512), (64, 17920, 128)])
+@pytest.mark.parametrize("M,N,K", [(64, 1536, 8960), (64, 1536, 1536), (33, 256, 512), (64, 17920, 128), (64, 3584, 18944), (40, 3584, 3584),
+                                   (1, 3584, 18944)])
 def test_gemm_skinny_norm(hip_both, fake, M, N, K):
     hip = hip_both
     a = randn(M, K, dtype=BF, seed=1)
@@ -1151,7 +1153,8 @@ def test_beam_update_kernel_is_exact(hip, nb, lpw, min_len, quantise):
 
 
 @pytest.mark.parametrize("M,D,I,H,G,V", [(64, 1536, 8960, 12, 2, 4000), (40, 256, 512, 2, 1, 1000), (64, 512, 1792, 4, 2, 520),
-                                         (1, 1536, 8960, 12, 2, 4000), (17, 1536, 8960, 12, 2, 700)])
+                                         (1, 1536, 8960, 12, 2, 4000), (17, 1536, 8960, 12, 2, 700),
+                                         (64, 3584, 18944, 28, 4, 2000), (23, 3584, 18944, 28, 4, 600)])
 def test_decode_layer_chain_in_fragment_order(hip, fake, M, D, I, H, G, V):
     """One decode layer + lm_head on the streaming kernels with every operand in FRAGMENT ORDER (weights re-laid out by
     tasu_to_fragment_order, activations written in that order by the norm / attention / SwiGLU producers) against the same
@@ -1178,7 +1181,7 @@ def test_decode_layer_chain_in_fragment_order(hip, fake, M, D, I, H, G, V):
             ops.register_decode_weight(w["wqkv"], "qkv", LD, H, G)
             ops.register_decode_weight(w["wo"], "plain", D)
             ops.register_decode_weight(w["wgu"], "swiglu", I)
-            ops.register_decode_weight(w["wd"], "plain", D, slabs_ok=True)      # K = 8960: five K-range slabs
+            ops.register_decode_weight(w["wd"], "plain", D, slabs_ok=True)      # K = 8960: K-range slabs (18944: 12 x 1536 + 512)
             ops.register_decode_weight(w["head"], "plain", V)
             assert ops.begin_decode(D, HHD, I)
         Mp = 64
