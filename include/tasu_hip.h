@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 10
+#define TASU_ABI_VERSION 11
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -164,7 +164,9 @@ int tasu_gemm_skinny_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw,
 
 /* Second-generation decode-step GEMMs (csrc/gemm_stream.hip): activations in registers, weights global -> registers,
  * persistent column tiles, the consuming op's epilogue in the SAME launch (no split-K finish launch).  M <= 64;
- * K (per K range) in {256, 512, 1536, 1792} -- tasu_stream_supported(K, ksplit) says whether a shape is served; other
+ * K (per K range) in {256, 512, 1280, 1536, 1792}, ONE range of 3584 (Qwen2.5-7B: 14 k-steps per wave on row halves), or ksplit - 1
+ * equal ranges and a shorter last one (the 7B's down projection: 18944 = 12 x 1536 + 512) -- tasu_stream_supported(K, ksplit) says
+ * whether a shape is served; other
  * shapes stay on the tasu_gemm_skinny_* entry points, whose arithmetic and rounding points these reproduce:
  *   tasu_gemm_stream_bf16      C = bf16(A W^T + bias)  (out_mode TASU_GEMM_OUT_BF16; lm_head) or
  *                              C(fp32) = resid + bf16(A W^T)  (TASU_GEMM_OUT_F32_RESID_BF16R; o projection + residual)
@@ -172,7 +174,7 @@ int tasu_gemm_skinny_qkv_rope(const void* A, int lda, const void* Wqkv, int ldw,
  *   tasu_gemm_stream_qkv_rope  qkv = rope(A Wqkv^T + bias), k and v appended to the cache at pos[m]  (:189-208, :91-135)
  *   tasu_gemm_stream_slabs     K split over workgroups (K = ksplit * {256..1792}: the down projection, 8960 = 5 x 1792):
  *                              fp32 partial results, row-major [ksplit][64][N] (slab_floats >= ksplit * 64 * N);
- *                              tasu_stream_finish_norm (N a multiple of 256, N / 256 in {1, 2, 6, 7}) adds them in order,
+ *                              tasu_stream_finish_norm (N a multiple of 256, N / 256 in {1, 2, 6, 7, 14}) adds them in order,
  *                              then C(fp32) = resid + bf16(sum) and y = rmsnorm(C, norm_w) for the next layer       */
 int tasu_stream_supported(int K, int ksplit);
 /* a_frag / w_frag / out_frag / y_frag = 1: that operand is in FRAGMENT ORDER (the order mfma_f32_16x16x32_bf16 consumes it
@@ -191,6 +193,22 @@ int tasu_gemm_stream_slabs(const void* A, int lda, const void* W, int ldw, float
                            int K, int ksplit, int a_frag, int w_frag, void* stream);
 int tasu_stream_finish_norm(const float* slabs, int ksplit, float* C, const float* resid, int M, int N, const float* norm_w,
                             void* y, float eps, int y_frag, void* stream);
+/* Round 5: the post-attention RMSNorm of a decode layer WITHOUT a launch of its own (Qwen2DecoderLayer, modeling_qwen2.py:269-298,
+ * through /root/reference/Multitask/model/ps-slm.py:660-675).  rstd is a per-row scalar, so
+ *     (norm_w . x . rstd) Wgu^T  =  rstd . ((norm_w . x) Wgu^T):
+ *   tasu_gemm_stream_resid_prenorm  the o projection + residual (C fp32 = resid + bf16(A W^T), as tasu_gemm_stream_bf16's RESID form)
+ *                                   also writes yw = bf16(norm_w . C) (row-major [M, N] or, yw_frag, fragment order) and, per
+ *                                   16-column tile, the sum of squares of the tile's C values of every row: sumsq[N / 16][64] fp32
+ *                                   (rows >= M are not written: keep the buffer zero-initialised);
+ *   tasu_gemm_stream_swiglu_rstd    tasu_gemm_stream_swiglu on A = yw whose accumulators are scaled by
+ *                                   rstd[m] = rsqrt(sum_t sumsq[t][m] / K + eps) (n_part = N / 16 partials) before the SwiGLU.
+ * Against the separate norm kernel the bf16 rounding of the normed activation happens before the multiplication by rstd instead of
+ * after it: the same size of error, not the same bits (tests: tolerance against the two-launch form, exact tokens on the
+ * rounding-stable decode cases).  M <= 64, N % 16 == 0, tasu_stream_supported(K, 1).                                              */
+int tasu_gemm_stream_resid_prenorm(const void* A, int lda, const void* W, int ldw, float* C, const float* resid, int M, int N, int K,
+                                   const float* norm_w, void* yw, int yw_frag, float* sumsq, int a_frag, int w_frag, void* stream);
+int tasu_gemm_stream_swiglu_rstd(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,
+                                 const float* sumsq, int n_part, float eps, int a_frag, int w_frag, int out_frag, void* stream);
 /* Round 5: the projection, the residual add AND the RMSNorm of the finished rows in ONE launch (csrc/stream_body.h: norm_tail) --
  * a decode layer's two norm launches (tasu_rmsnorm_fwd_frag behind the o projection, tasu_stream_finish_norm behind the down
  * projection's slabs: Qwen2DecoderLayer, modeling_qwen2.py:269-298, through /root/reference/Multitask/model/ps-slm.py:660-675) move into

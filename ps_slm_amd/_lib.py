@@ -89,6 +89,8 @@ PROTOTYPES = {
     "tasu_stream_supported": [i32, i32],
     "tasu_gemm_stream_bf16": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tasu_gemm_stream_swiglu": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tasu_gemm_stream_resid_prenorm": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp],
+    "tasu_gemm_stream_swiglu_rstd": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, i32, i32, i32, vp],
     "tasu_gemm_stream_qkv_rope": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "tasu_gemm_stream_slabs": [vp, i32, vp, i32, vp, i64, i32, i32, i32, i32, i32, i32, vp],
     "tasu_stream_finish_norm": [vp, i32, vp, vp, i32, i32, vp, vp, f32, i32, vp],
@@ -126,7 +128,7 @@ PROTOTYPES.update({
     "tasu_allreduce_min_i32": [vp, vp, i64, vp],
 })
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 
 

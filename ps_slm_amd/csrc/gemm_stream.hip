@@ -41,7 +41,7 @@ bool k_ranges(int K, int ksplit, int& kr, int& rem);
 
 template <int KS, int EPI, int MT, bool FRAG>
 __global__ __launch_bounds__(64 * NW, KS > 8 ? 1 : 2) void stream_gemm_kernel(Args p) {
-  __shared__ __attribute__((aligned(16))) float red[2 * NW * MT * 256];
+  __shared__ __attribute__((aligned(16))) float red[2 * NW * MT * 256 + NW * 64];
   int bx, by, bz;
   if (!grid_position((int)blockIdx.x, p.gx, p.gy, p.gz, bx, by, bz)) return;
   stream_gemm_body<KS, EPI, MT, FRAG, false>(p, red, bx, p.gx, by, bz);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64 * NW, KS > 8 ? 1 : 2) void stream_gemm_kernel(Ar
 // residual -> post-attention norm) or E_SLAB (down projection's K-range slabs -> sum + residual + the next layer's input norm).
 template <int KS, int EPI, int MT, bool FRAG, int NG>
 __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_norm_kernel(Args p, NormTail t) {
-  __shared__ __attribute__((aligned(16))) float red[2 * NW * MT * 256];
+  __shared__ __attribute__((aligned(16))) float red[2 * NW * MT * 256 + NW * 64];
   int bx, by, bz;
   if (!grid_position((int)blockIdx.x, p.gx, p.gy, p.gz, bx, by, bz)) return;
   stream_gemm_body<KS, EPI, MT, FRAG, true>(p, red, bx, p.gx, by, bz);
@@ -249,6 +249,48 @@ extern "C" int tasu_gemm_stream_qkv_rope(const void* A, int lda, const void* Wqk
   a.tiles = (H + 2 * G) * 8;
   a.a_frag = a_frag, a.w_frag = w_frag;
   return launch<E_QKV>(a, 1, (hipStream_t)stream);
+}
+
+// Round 5: the post-attention RMSNorm without a launch of its own (Args::ssq_out / ssq_in, stream_body.h).
+extern "C" int tasu_gemm_stream_resid_prenorm(const void* A, int lda, const void* W, int ldw, float* C, const float* resid, int M, int N,
+                                              int K, const float* norm_w, void* yw, int yw_frag, float* sumsq, int a_frag, int w_frag,
+                                              void* stream) {
+  using namespace tasu_stream;
+  if (!A || !W || !C || !resid || !norm_w || !yw || !sumsq || M <= 0 || M > 64 || N <= 0 || N % 16 || !k_supported(K, 1) || lda % 8 ||
+      ldw % 8)
+    return TASU_ERR_ARG;
+  if (!aligned16(A) || !aligned16(W) || !aligned16(C) || !aligned16(resid) || !aligned16(norm_w) || ((uintptr_t)yw & 7)) return TASU_ERR_ARG;
+  Args a{};
+  a.A = (const bf16*)A;
+  a.W = (const bf16*)W;
+  a.C = C;
+  a.R = resid;
+  a.M = M, a.N = N, a.K = K, a.lda = lda, a.ldw = ldw, a.ldc = N;
+  a.tiles = N / 16;
+  a.a_frag = a_frag, a.w_frag = w_frag;
+  a.nw = norm_w, a.yw = (bf16*)yw, a.yw_frag = yw_frag, a.ssq_out = sumsq;
+  return launch<E_RESID>(a, 1, (hipStream_t)stream);
+}
+
+extern "C" int tasu_gemm_stream_swiglu_rstd(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,
+                                            const float* sumsq, int n_part, float eps, int a_frag, int w_frag, int out_frag,
+                                            void* stream) {
+  using namespace tasu_stream;
+  if (!A || !Wgu || !act || !sumsq || n_part != K / 16 || M <= 0 || M > 64 || I <= 0 || I % 8 || !k_supported(K, 1) || lda % 8 || ldw % 8 ||
+      ldact % 4)
+    return TASU_ERR_ARG;
+  if (!aligned16(A) || !aligned16(Wgu) || ((uintptr_t)act & 7)) return TASU_ERR_ARG;
+  Args a{};
+  a.A = (const bf16*)A;
+  a.W = (const bf16*)Wgu;
+  a.C = act;
+  a.M = M, a.N = I, a.K = K, a.lda = lda, a.ldw = ldw, a.ldc = ldact;
+  a.I = I;
+  a.tiles = I / 8;
+  a.a_frag = a_frag, a.w_frag = w_frag, a.out_frag = out_frag;
+  a.ssq_in = sumsq, a.n_part = n_part, a.eps = eps;
+  if (out_frag && I % 32) return TASU_ERR_ARG;
+  return launch<E_SWIGLU>(a, 1, (hipStream_t)stream);
 }
 
 // K split over workgroups: fp32 partial results, row-major [ksplit][64 rows][N] in `slabs` (rows >= M: unspecified);

@@ -35,6 +35,16 @@ struct Args {
   bf16* vc;
   const int32_t* pos;
   int gx, gy, gz;         // the virtual grid [column-tile walkers][K ranges][row splits] (grid_position)
+  // The post-attention RMSNorm without a launch (round 5): E_RESID with ssq_out also writes yw = bf16(nw . C) (the consumer's
+  // operand; yw_frag: fragment order) and, per column tile, the sum of squares of its 16 values of every row: ssq_out[tile][64].
+  // E_SWIGLU with ssq_in sums the n_part partials of a row, rstd = rsqrt(sum / K + eps), and scales its accumulators by it -- rstd
+  // is a per-row scalar, so (nw . x . rstd) W^T = rstd . ((nw . x) W^T).
+  const float* nw;
+  bf16* yw;
+  float* ssq_out;
+  const float* ssq_in;
+  int n_part, yw_frag;
+  float eps;
   int kstep0, slab0;      // E_SLAB, ragged K (tasu_gemm_stream_slabs: K = n * range + a shorter last range, launched apart): the
                           // launch's first k-step (of 32) inside K and its first slab; 0 otherwise
 };
@@ -50,6 +60,11 @@ __device__ __forceinline__ bool grid_position(int lin, int gx, int gy, int gz, i
   bx = r % gx;
   by = r / gx;
   return r < gx * gy;
+}
+
+// element (row, c) of a [<= 64, K] activation in fragment order (gemm_stream.hip header; the same map as norm.hip's frag_offset)
+__device__ __forceinline__ size_t frag_index(int row, int c) {
+  return ((((size_t)(c >> 5) * 4 + (row >> 4)) * 64 + ((c & 31) >> 3) * 16 + (row & 15)) << 3) + (c & 7);
 }
 
 // first weight row (of 16) that lane group row r = l & 15 of tile t reads
@@ -91,7 +106,7 @@ __device__ __forceinline__ void st_out(T* dst, T v) {
 // WT: outputs are stored write-through at agent scope (st_out), for a consumer on another XCD inside the SAME launch (round 2's
 // persistent layer-loop kernel); the kernels of gemm_stream.hip pass false.
 // bx / nbx, by, bz: the workgroup's position in the (virtual) grid [column-tile walkers][K ranges][row splits];
-// red: LDS, 2 * NW * MT * 256 floats -- partial tiles [2 buffers][NW waves][MT row tiles][64 lanes] f32x4.
+// red: LDS, 2 * NW * MT * 256 floats -- partial tiles [2 buffers][NW waves][MT row tiles][64 lanes] f32x4 -- + NW * 64 floats (rsq).
 template <int KS, int EPI, int MT, bool FRAG, bool WT>
 __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restrict__ red, int bx, int nbx, int by, int bz) {
   const int mt0 = bz * MT;                              // first row tile of this workgroup
@@ -116,6 +131,30 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
       for (int c = 0; c < KS; ++c) a[t][c] = *(const bf16x8*)(ar + c * 32);
     }
   }
+
+  // E_SWIGLU behind a pre-normed o projection: the rows' sums of squares from the producer's per-tile partials.  K / 16 = 16 KS
+  // partials per row; wave w requests tiles w, w + 8, ... for the workgroup's 16 MT rows (lane = row; MT = 2: two lane halves share the
+  // tiles) NOW, ahead of
+  // the weight ring, sums them once the first weights are in flight (rsq_publish) and leaves the sum in LDS; the finishing waves add
+  // the eight wave sums in wave order after the first tile's barrier.
+  constexpr int ROWS = MT * 16, LPR = 64 / ROWS;        // lanes per row: MT = 2 splits a wave's tiles over two lane halves
+  constexpr int QN = KS * 2 / LPR;
+  float qv[QN];
+  float* rsq = red + 2 * NW * MT * 256;                 // [NW][64]: lane = half * ROWS + row
+  if (EPI == E_SWIGLU && p.ssq_in) {
+    const float* sp = p.ssq_in + mt0 * 16 + (lane & (ROWS - 1));
+    const int t0 = wave + NW * (lane / ROWS);
+#pragma unroll
+    for (int j = 0; j < QN; ++j) qv[j] = sp[(size_t)(t0 + NW * LPR * j) * 64];
+  }
+  auto rsq_publish = [&]() {
+    if (EPI == E_SWIGLU && p.ssq_in) {
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < QN; ++j) q += qv[j];
+      rsq[wave * 64 + lane] = q;
+    }
+  };
 
   const int ntl = (p.tiles - bx + nbx - 1) / nbx;     // tiles this workgroup walks
   auto tile_of = [&](int i) { return bx + min(i, ntl - 1) * nbx; };   // clamped: loads past the end re-read
@@ -148,6 +187,7 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
     if (EPI == E_RESID) {
       const int n = t * 16 + 4 * lq;
       if (m < p.M && n + 4 <= p.N) ep.r4 = *(const f32x4*)(p.R + (size_t)m * p.ldc + n);
+      if (p.ssq_out && n + 4 <= p.N) ep.cs = *(const f32x4*)(p.nw + n);          // (cs: unused by this epilogue otherwise)
     }
     if (EPI == E_QKV) {
       const int rot_tiles = (p.H + p.G) * 8;
@@ -184,6 +224,14 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
     }
     if (EPI == E_SWIGLU) {
       // lanes lq < 2 hold gate columns t*8 + 4*lq + r, lanes lq + 2 the up values of the same columns
+      if (p.ssq_in) {
+        float q = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2)
+#pragma unroll
+          for (int h = 0; h < LPR; ++h) q += rsq[w2 * 64 + h * ROWS + wave * 16 + l15];
+        s *= rsqrtf(q / (float)p.K + p.eps);
+      }
       f32x4 u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) u[r] = __shfl_xor(s[r], 32, 64);
@@ -260,6 +308,17 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = old[r] + bf16_round(s[r]);
         st_out<WT>((f32x4*)dst, o);
+        if (p.ssq_out) {
+          bf16x4 yv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yv[r] = (bf16)(ep.cs[r] * o[r]);
+          st_out<WT>((bf16x4*)(p.yw_frag ? p.yw + frag_index(m, n) : p.yw + (size_t)m * p.N + n), yv);
+          // the row's 16 columns of this tile sit in the four lanes l15 + 16 * {0..3} (all active: N is a multiple of 16 here)
+          float q = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
+          q += __shfl_xor(q, 16, 64);
+          q += __shfl_xor(q, 32, 64);
+          if (lq == 0) p.ssq_out[(size_t)t * 64 + (m & 63)] = q;
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -340,6 +399,7 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
       asm volatile("" ::: "memory");
       finish(i, load_epi(i));
     };
+    rsq_publish();                                           // (before the ring: its registers are all this kernel has)
     bf16x8 h0[KH], h1[KH], h2[KH];
     load_h(h0, 0);
     load_h(h1, 1);
@@ -393,6 +453,7 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
   if (ntl <= 2) {
     // one or two tiles (the q|k|v, o and down projections): no ring, nothing loaded twice
     if (ntl == 2) load_w(w1, 1);
+    rsq_publish();
     const Epi e0 = load_epi(0), e1 = load_epi(1);
     TASU_STREAM_STAMP(1);
     compute(w0, 0, &e0);
@@ -405,6 +466,7 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
   // bodies re-read the last tile and skip their epilogue), so that the compiler's vmcnt bookkeeping sees one straight ring
   // and waits for the oldest tile only.
   load_w(w1, 1);
+  rsq_publish();
   TASU_STREAM_STAMP(1);
   for (int i = 0; i < ntl; i += 3) {
     load_w(w2, i + 2);
@@ -419,10 +481,6 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
   }
 }
 
-// element (row, c) of a [<= 64, K] activation in fragment order (gemm_stream.hip header; the same map as norm.hip's frag_offset)
-__device__ __forceinline__ size_t frag_index(int row, int c) {
-  return ((((size_t)(c >> 5) * 4 + (row >> 4)) * 64 + ((c & 31) >> 3) * 16 + (row & 15)) << 3) + (c & 7);
-}
 
 // 16 bytes of a row another workgroup of the SAME launch may have written (write-through stores, st_out<true>): SC1 = read past
 // this CU's L1 at agent scope (buffer_load_dwordx4 ... sc1 through a descriptor on the row: MI355X_MICROARCH.md, "Valid forms":

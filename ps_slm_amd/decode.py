@@ -203,6 +203,7 @@ def layers_per_gemm(ops, geo, layers, final_norm, x, x2, xn, qkv, ao, act, cos, 
     # (the weights are then streamed once per chunk; K/V, attention and top-k are not chunked)
     chunks = [(m0, min(64, M - m0)) for m0 in range(0, M, 64)]
     kcv, vcv = kc.view(L, M, ctx * W), vc.view(L, M, ctx * W)
+    prenorm = bool(getattr(ops, "prenorm_ok", None) and ops.prenorm_ok(D, H * HD, I))
     if not normed:                                                               # (the step prologue has done it already)
         for m0, mc in chunks:
             ops.dec_rmsnorm(x[m0:m0 + mc], layers[0]["ln1"], xn[m0:m0 + mc], geo.rms_eps)
@@ -215,8 +216,13 @@ def layers_per_gemm(ops, geo, layers, final_norm, x, x2, xn, qkv, ao, act, cos, 
         ops.attn_decode(qkv, kc[l], vc[l], index, kstart, lens, ao, M, H, G, ctx, scale)
         for m0, mc in chunks:                                                    # projections with residual + next norm fused
             r = slice(m0, m0 + mc)
-            ops.gemm_skinny_norm(ao[r], w["wo"], x2[r], x[r], mc, D, H * HD, w["ln2"], xn[r], geo.rms_eps, ws)
-            ops.gemm_skinny_swiglu(xn[r], w["wgu"], act[r], mc, I, D, ws)
+            if prenorm:
+                # o projection + residual; the post-attention norm travels inside it and gate|up (no launch of its own)
+                ssq = ops.gemm_skinny_prenorm(ao[r], w["wo"], x2[r], x[r], mc, D, H * HD, w["ln2"], xn[r])
+                ops.gemm_skinny_swiglu(xn[r], w["wgu"], act[r], mc, I, D, ws, sumsq=ssq, eps=geo.rms_eps)
+            else:
+                ops.gemm_skinny_norm(ao[r], w["wo"], x2[r], x[r], mc, D, H * HD, w["ln2"], xn[r], geo.rms_eps, ws)
+                ops.gemm_skinny_swiglu(xn[r], w["wgu"], act[r], mc, I, D, ws)
             ops.gemm_skinny_norm(act[r], w["wd"], x[r], x2[r], mc, D, I, next_norm, xn[r], geo.rms_eps, ws)
 
 

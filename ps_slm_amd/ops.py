@@ -45,6 +45,12 @@ class HipOps:
         self.dec_down_slabs = True     # down projection as K-range slabs + tasu_stream_finish_norm (False: split-K kernels)
         self.dec_split_order = (1, 7, 5, 2, 3, 4, 6, 8, 13)   # K ranges tried in this order (K = 8960: 7 x 1280 before 5 x 1792; A/B: swap;
                                                               # 13: Qwen2.5-7B's K = 18944 = 12 x 1536 + 512, a ragged split)
+        # the post-attention norm without a launch: the o projection writes bf16(norm_w . x) + per-tile sums of squares, gate|up scales
+        # its accumulators by rstd (tasu_gemm_stream_resid_prenorm / _swiglu_rstd): 6 launches per layer, 1.684 -> 1.620 ms per
+        # position at 1.5B (MI355X, alternating processes on one box).  No hand-off inside a launch (the variant below lost to that).
+        # False / TASU_DEC_PRENORM=0: the separate norm launch (A/B, tests).
+        self.dec_prenorm = os.environ.get("TASU_DEC_PRENORM", "1") != "0"
+        self.dec_sumsq = None
         self.dec_stream_7b = True      # K = 3584 in one range / K = 18944 as a ragged split on the streaming kernels (False: A/B runs,
                                        # the split-K kernels of gemm_skinny.hip as before round 5)
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
@@ -165,6 +171,8 @@ class HipOps:
         # kernels -- in one K range, or (K = 8960 = 5 x 1792) as K-range slabs + tasu_stream_finish_norm.  The slabs are the
         # default since the two row halves of a K range share an XCD's L2 and the slabs are row-major (1.89 vs 2.0 ms per
         # position at 1.5B against the split-K kernels of gemm_skinny.hip; the dec_down_slabs attribute selects, for A/B runs).
+        if self.dec_prenorm and self.dec_sumsq is None:    # (here, not at first use: a decode step may be under hipGraph capture)
+            self.dec_sumsq = torch.zeros(4096 // 16 * 64, dtype=torch.float32, device="cuda")
         ks_down = self._stream_split(I)
         self.dec_frag_act = bool(self.dec_frag and I % 32 == 0 and (ks_down == 1 or (ks_down > 1 and self.dec_down_slabs)))
         return self.dec_frag
@@ -515,8 +523,29 @@ class HipOps:
                                                      0 if ws is None else ws.numel(), self._stream()),
                   "tasu_gemm_skinny_qkv_rope")
 
-    def gemm_skinny_swiglu(self, a, wgu, act, M, I, K, ws):
-        """act[M, I] = swiglu(a[M,K] @ wgu[2I,K]^T) in one launch (decode step)."""
+    def prenorm_ok(self, D, HHD, I):
+        """decode.py asks: may the post-attention norm travel inside its neighbours (gemm_skinny_prenorm + gemm_skinny_swiglu(sumsq=))?"""
+        return bool(self.dec_prenorm and self.dec_frag and D % 16 == 0 and I % 8 == 0 and self._stream_split(HHD) == 1 and self._stream_split(D) == 1)
+
+    def gemm_skinny_prenorm(self, a, b, c, resid, M, N, K, norm_w, yw):
+        """c (fp32) = resid + bf16(a @ b^T); yw = bf16(norm_w * c) in the consumer's operand order; returns the per-tile sums of
+        squares [N / 16][64] for gemm_skinny_swiglu(sumsq=...)."""
+        if self.dec_sumsq is None:
+            self.dec_sumsq = torch.zeros(4096 // 16 * 64, dtype=torch.float32, device=c.device)
+        wf, wflag = self._wf(b)
+        self._chk(self.lib.tasu_gemm_stream_resid_prenorm(_p(a), a.stride(0), _p(wf), b.stride(0), _p(c), _p(resid), M, N, K, _p(norm_w), _p(yw),
+                                                          int(self.dec_frag), _p(self.dec_sumsq), int(self.dec_frag), wflag, self._stream()),
+                  "tasu_gemm_stream_resid_prenorm")
+        return self.dec_sumsq
+
+    def gemm_skinny_swiglu(self, a, wgu, act, M, I, K, ws, sumsq=None, eps=0.0):
+        """act[M, I] = swiglu(a[M,K] @ wgu[2I,K]^T) in one launch (decode step).  sumsq: a is gemm_skinny_prenorm's yw; the rows'
+        rstd comes from the K / 16 partial sums of squares."""
+        if sumsq is not None:
+            wf, wflag = self._wf(wgu)
+            return self._chk(self.lib.tasu_gemm_stream_swiglu_rstd(_p(a), a.stride(0), _p(wf), wgu.stride(0), _p(act), act.stride(0), M, I, K,
+                                                                   _p(sumsq), K // 16, eps, int(self.dec_frag), wflag,
+                                                                   int(self.dec_frag_act), self._stream()), "tasu_gemm_stream_swiglu_rstd")
         if self._stream_split(K) == 1 and I % 8 == 0 and act.stride(0) % 4 == 0:
             wf, wflag = self._wf(wgu)
             return self._chk(self.lib.tasu_gemm_stream_swiglu(_p(a), a.stride(0), _p(wf), wgu.stride(0), _p(act), act.stride(0), M, I,

@@ -1152,6 +1152,18 @@ def test_beam_update_kernel_is_exact(hip, nb, lpw, min_len, quantise):
     assert np.array_equal(got, fake) and calls == calls_f
 
 
+def unfrag(t, K):
+    """[64, K] bf16 activation written in FRAGMENT ORDER ([K/32][4 row tiles][64 lanes][8]) back to row-major."""
+    return t.reshape(-1)[:64 * K].view(K // 32, 4, 4, 16, 8).permute(1, 3, 0, 2, 4).reshape(64, K)
+
+
+def ao_frag(a, K):
+    """row-major [M <= 64, K] -> the fragment-order image of its 64-row chunk (rows >= M zero)."""
+    full = torch.zeros(64, K, dtype=a.dtype)
+    full[:a.shape[0]] = a
+    return full.view(4, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous().view(64, K)
+
+
 @pytest.mark.parametrize("M,D,I,H,G,V", [(64, 1536, 8960, 12, 2, 4000), (40, 256, 512, 2, 1, 1000), (64, 512, 1792, 4, 2, 520),
                                          (1, 1536, 8960, 12, 2, 4000), (17, 1536, 8960, 12, 2, 700),
                                          (64, 3584, 18944, 28, 4, 2000), (23, 3584, 18944, 28, 4, 600)])
@@ -1214,6 +1226,65 @@ def test_decode_layer_chain_in_fragment_order(hip, fake, M, D, I, H, G, V):
     for name, a, b, c in zip(("qkv", "kc", "vc", "x_mid", "x_out", "logits"), row, frg, cpu):
         assert torch.equal(a, b), name
         assert rel_err(a, c) < 3e-2, name
+
+
+@pytest.mark.parametrize("M,D,HHD,I", [(64, 1536, 1536, 8960), (37, 1536, 1536, 8960), (64, 256, 256, 512), (1, 512, 512, 1792), (64, 3584, 3584, 2400)])
+def test_post_attention_norm_inside_its_neighbours(hip, fake, M, D, HHD, I):
+    """tasu_gemm_stream_resid_prenorm + tasu_gemm_stream_swiglu_rstd (o projection -> [norm] -> gate|up + SwiGLU with no norm launch)
+    against the three-launch form (o projection + residual, RMSNorm, gate|up + SwiGLU) and the CPU double:
+      * the fp32 residual stream c is BIT-identical (the projection's arithmetic is untouched);
+      * the per-tile sums of squares add up to the rows' sums of squares of c (fp32 tolerance), rows >= M stay zero;
+      * yw == bf16(norm_w * c) exactly;
+      * the MLP activation agrees with the three-launch form like two bf16 evaluations of one expression (the rounding of the normed
+        activation moves in front of the multiplication by rstd), in row-major and in fragment order (bit-identical to each other)."""
+    g = torch.Generator().manual_seed(D + I + M)
+    rn = lambda *sh, k=1.0: (torch.randn(*sh, generator=g) * k)
+    ao, wo, wgu = rn(M, HHD).to(BF), rn(D, HHD, k=HHD ** -0.5).to(BF), rn(2 * I, D, k=D ** -0.5).to(BF)
+    x, ln2 = rn(M, D) * 3.0, 1 + 0.1 * rn(D)
+    outs = {}
+    for frag in (False, True):
+        w = dict(wo=wo.cuda(), wgu=wgu.cuda())
+        hip.use_stream = True
+        if frag:
+            hip.register_decode_weight(w["wo"], "plain", D)
+            hip.register_decode_weight(w["wgu"], "swiglu", I)
+            wd = torch.zeros(D, I, dtype=BF, device="cuda")
+            hip.register_decode_weight(wd, "plain", D, slabs_ok=True)
+            assert hip.begin_decode(D, HHD, I)
+        try:
+            aod = torch.zeros(64, HHD, dtype=BF, device="cuda")
+            if frag:
+                aod.view(-1)[:] = ao_frag(ao, HHD).cuda().view(-1)
+            else:
+                aod[:M] = ao.cuda()
+            c3, xn3, act3 = torch.zeros(M, D, device="cuda"), torch.zeros(64, D, dtype=BF, device="cuda"), torch.zeros(64, I, dtype=BF, device="cuda")
+            hip.gemm_skinny_norm(aod[:M], w["wo"], c3, x.cuda(), M, D, HHD, ln2.cuda(), xn3[:M], 1e-6, None)
+            hip.gemm_skinny_swiglu(xn3[:M], w["wgu"], act3[:M], M, I, D, None)
+            c2, yw, act2 = torch.zeros(M, D, device="cuda"), torch.zeros(64, D, dtype=BF, device="cuda"), torch.zeros(64, I, dtype=BF, device="cuda")
+            hip.dec_sumsq = None
+            ssq = hip.gemm_skinny_prenorm(aod[:M], w["wo"], c2, x.cuda(), M, D, HHD, ln2.cuda(), yw[:M])
+            hip.gemm_skinny_swiglu(yw[:M], w["wgu"], act2[:M], M, I, D, None, sumsq=ssq, eps=1e-6)
+            torch.cuda.synchronize()
+            act_frag = bool(hip.dec_frag_act)
+        finally:
+            if frag:
+                hip.end_decode()
+        assert torch.equal(c2, c3)
+        part = ssq[:D // 16 * 64].view(D // 16, 64).cpu()
+        want = (c2.cpu().double() ** 2).sum(1)
+        assert torch.allclose(part[:, :M].double().sum(0), want, rtol=1e-5) and float(part[:, M:].abs().max() if M < 64 else 0.0) == 0.0
+        ywr = unfrag(yw.cpu(), D)[:M] if frag else yw.cpu()[:M]
+        assert torch.equal(ywr, (ln2 * c2.cpu()).to(BF))
+        a2, a3 = (unfrag(t.cpu(), I)[:M] if act_frag else t.cpu()[:M] for t in (act2, act3))
+        assert torch.isfinite(a2.float()).all() and rel_err(a2, a3) < 1.5e-2
+        outs[frag] = (c2.cpu(), ywr, a2)
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b)
+    # the CPU double's three ops
+    cc, xnc, actc = torch.zeros(M, D), torch.zeros(M, D, dtype=BF), torch.zeros(M, I, dtype=BF)
+    fake.gemm_skinny_norm(ao, wo, cc, x, M, D, HHD, ln2, xnc, 1e-6, None)
+    fake.gemm_skinny_swiglu(xnc, wgu, actc, M, I, D, None)
+    assert rel_err(outs[True][2], actc) < 2e-2
 
 
 @pytest.mark.parametrize("H,G,ctx,frag", [(12, 2, 1100, 1), (2, 1, 700, 0), (28, 4, 530, 0), (12, 2, 40, 1)])
