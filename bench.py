@@ -448,14 +448,16 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         else:
             gemm_ms, n_launch = timed.total_ms(), len(timed.events)
         achieved = gemm_flops_step * steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        # HBM-side bytes per GEMM launch are NOT measured by this run (PMC counters need their own rocprofv3 --pmc passes):
-        # the offline per-shape figures are in the cited file
+        # HBM-side bytes per GEMM call come from the round's own PMC passes (counters need their own rocprofv3 --pmc runs, FETCH_SIZE and
+        # WRITE_SIZE apart: tools/make_round_artifacts.sh PART=pmc): the call-count-weighted mean over the step's GEMM shapes, cold
+        # rotating operands, gfx950 x2 fetch correction.  Only for the configuration those passes ran.
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r04_gemm_pmc.json")
-        if os.path.isfile(pmc) and model_name == "qwen2.5-1.5b" and B == 16 and not audio and not variable:
-            traffic_src = ("not measured by this run; offline: profiles/r04_gemm_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                           f"passes over tools/gemm_shapes_run.py, gfx950 x2 fetch correction): "
-                           f"{json.load(open(pmc)).get('traffic_bytes_per_launch')} bytes per launch, launch-count-weighted")
+        pmc = os.path.join(ROOT, "profiles", "r05_gemm_pmc.json")
+        if os.path.isfile(pmc) and model_name == "qwen2.5-1.5b" and B == 16 and not audio and not variable and core.lora is None:
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+            traffic_src = ("bytes per GEMM call, profiles/r05_gemm_pmc.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                           "tools/gemm_shapes_run.py (the step's GEMM shapes, cold rotating operands), fetch x2 (gfx950 tallies 16-B/lane "
+                           "streaming reads at half), call-count-weighted over one step; fabric side of the L2s (Infinity-Cache hits included)")
         what = ("audio-SFT step (500 feature frames -> SANM encoder -> CTC posterior -> PSD -> projector -> LLM fwd+dgrad bwd+"
                 "projector wgrad+AdamW)" if audio else
                 "text-only CPS alignment step (fwd+dgrad bwd+projector wgrad+AdamW), frozen encoder pass skipped")

@@ -13,7 +13,8 @@ if [ "$PART" = all ] || [ "$PART" = stats ]; then
   timeout 600 $RP --stats -d $A/prof_decode -- python3 tools/bench_paths.py decode 16 > $A/${R}_decode_under_rocprof.json 2> $A/prof_decode.err
   timeout 600 $RP --stats -d $A/prof_audio -- python3 bench.py --path audio --blank-biased --blank-bias 13.0 --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-extra --no-graphs > $A/${R}_audio_under_rocprof.json 2> $A/prof_audio.err
   timeout 600 $RP --stats -d $A/prof_lora -- python3 bench.py --lora --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-extra --no-graphs > $A/${R}_lora_under_rocprof.json 2> $A/prof_lora.err
-  for p in bench decode audio lora; do f=$(find $A/prof_$p -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $A/${R}_${p}_kernel_stats.csv; done
+  timeout 600 $RP --stats -d $A/prof_decode7b -- python3 tools/bench_paths.py decode 16 qwen2.5-7b > $A/${R}_decode7b_under_rocprof.json 2> $A/prof_decode7b.err
+  for p in bench decode audio lora decode7b; do f=$(find $A/prof_$p -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $A/${R}_${p}_kernel_stats.csv; done
 fi
 if [ "$PART" = all ] || [ "$PART" = pmc ]; then
   # per-shape GEMM traffic (cold rotating operands), FETCH and WRITE in separate passes
@@ -27,7 +28,7 @@ if [ "$PART" = all ] || [ "$PART" = pmc ]; then
   # the decode step's kernels
   timeout 600 $RP --pmc FETCH_SIZE -d $A/pmc_dec_f -- python3 tools/bench_paths.py decode 16 > /dev/null 2> $A/pmc_dec_f.err
   timeout 600 $RP --pmc WRITE_SIZE -d $A/pmc_dec_w -- python3 tools/bench_paths.py decode 16 > /dev/null 2> $A/pmc_dec_w.err
-  python tools/pmc_kernels.py $A/pmc_dec_f $A/pmc_dec_w 'stream_gemm_kernel<[^>]*>|stream_finish_norm_kernel<[^>]*>|attn_decode[a-z_]*|topk_[a-z]+_kernel|beam_update_kernel|rmsnorm_fwd_reg_kernel<[^>]*>|decode_step_prologue[a-z_]*' $A/${R}_decode_pmc.json "rocprofv3 --pmc FETCH_SIZE (resp. WRITE_SIZE) --kernel-trace --output-format csv -- python3 tools/bench_paths.py decode 16 (two passes)" > /dev/null 2> $A/pmc_dec.err
+  python tools/pmc_kernels.py $A/pmc_dec_f $A/pmc_dec_w 'stream_gemm_kernel<[^>]*>|stream_finish_norm[a-z_]*kernel<[^>]*>|attn_decode[a-z_]*|topk_[a-z]+_kernel|beam_update_kernel|rmsnorm_fwd_reg_kernel<[^>]*>|decode_step_prologue[a-z_]*' $A/${R}_decode_pmc.json "rocprofv3 --pmc FETCH_SIZE (resp. WRITE_SIZE) --kernel-trace --output-format csv -- python3 tools/bench_paths.py decode 16 (two passes)" > /dev/null 2> $A/pmc_dec.err
   # the audio-SFT step (encoder GEMMs, SANM attention, FSMN, PSD, frontend)
   timeout 600 $RP --pmc FETCH_SIZE -d $A/pmc_aud_f -- python3 bench.py --path audio --blank-biased --blank-bias 13.0 --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-extra --no-graphs > /dev/null 2> $A/pmc_aud_f.err
   timeout 600 $RP --pmc WRITE_SIZE -d $A/pmc_aud_w -- python3 bench.py --path audio --blank-biased --blank-bias 13.0 --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-extra --no-graphs > /dev/null 2> $A/pmc_aud_w.err
