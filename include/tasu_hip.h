@@ -204,7 +204,8 @@ int tasu_stream_finish_norm(const float* slabs, int ksplit, float* C, const floa
  *                                   rstd[m] = rsqrt(sum_t sumsq[t][m] / K + eps) (n_part = N / 16 partials) before the SwiGLU.
  * Against the separate norm kernel the bf16 rounding of the normed activation happens before the multiplication by rstd instead of
  * after it: the same size of error, not the same bits (tests: tolerance against the two-launch form, exact tokens on the
- * rounding-stable decode cases).  M <= 64, N % 16 == 0, tasu_stream_supported(K, 1).                                              */
+ * rounding-stable decode cases).  M <= 64, N % 16 == 0, tasu_stream_supported(K, 1) and K <= 2048 (at K = 3584 the kernels have no
+ * register to spare: the 7B geometry keeps the norm launch).                                              */
 int tasu_gemm_stream_resid_prenorm(const void* A, int lda, const void* W, int ldw, float* C, const float* resid, int M, int N, int K,
                                    const float* norm_w, void* yw, int yw_frag, float* sumsq, int a_frag, int w_frag, void* stream);
 int tasu_gemm_stream_swiglu_rstd(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,

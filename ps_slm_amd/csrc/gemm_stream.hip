@@ -39,19 +39,19 @@
 namespace tasu_stream {
 bool k_ranges(int K, int ksplit, int& kr, int& rem);
 
-template <int KS, int EPI, int MT, bool FRAG>
+template <int KS, int EPI, int MT, bool FRAG, bool PN = false>
 __global__ __launch_bounds__(64 * NW, KS > 8 ? 1 : 2) void stream_gemm_kernel(Args p) {
-  __shared__ __attribute__((aligned(16))) float red[2 * NW * MT * 256 + NW * 64];
+  __shared__ __attribute__((aligned(16))) float red[2 * NW * MT * 256 + (PN ? NW * 64 : 0)];
   int bx, by, bz;
   if (!grid_position((int)blockIdx.x, p.gx, p.gy, p.gz, bx, by, bz)) return;
-  stream_gemm_body<KS, EPI, MT, FRAG, false>(p, red, bx, p.gx, by, bz);
+  stream_gemm_body<KS, EPI, MT, FRAG, false, PN>(p, red, bx, p.gx, by, bz);
 }
 
 // The projection and, in the same launch, the RMSNorm of its complete rows (norm_tail, stream_body.h): E_RESID (o projection +
 // residual -> post-attention norm) or E_SLAB (down projection's K-range slabs -> sum + residual + the next layer's input norm).
 template <int KS, int EPI, int MT, bool FRAG, int NG>
 __global__ __launch_bounds__(64 * NW, 2) void stream_gemm_norm_kernel(Args p, NormTail t) {
-  __shared__ __attribute__((aligned(16))) float red[2 * NW * MT * 256 + NW * 64];
+  __shared__ __attribute__((aligned(16))) float red[2 * NW * MT * 256];
   int bx, by, bz;
   if (!grid_position((int)blockIdx.x, p.gx, p.gy, p.gz, bx, by, bz)) return;
   stream_gemm_body<KS, EPI, MT, FRAG, true>(p, red, bx, p.gx, by, bz);
@@ -76,6 +76,19 @@ int launch_ks(Args a, int kr, dim3 grid3, hipStream_t st) {
   const int per = 8 * a.gz;                              // whole groups of (8 XCDs x row splits): grid_position
   const dim3 grid((a.gx * a.gy * a.gz + per - 1) / per * per);
   const int ks = kr / (NW * 32);
+  if (a.ssq_out || a.ssq_in) {                           // the post-attention norm inside (PN): one range of K <= 2048
+    if constexpr (EPI == E_RESID || EPI == E_SWIGLU) {
+      switch (ks) {
+        case 1: TASU_LAUNCH((stream_gemm_kernel<1, EPI, MT, FRAG, true>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
+        case 2: TASU_LAUNCH((stream_gemm_kernel<2, EPI, MT, FRAG, true>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
+        case 5: TASU_LAUNCH((stream_gemm_kernel<5, EPI, MT, FRAG, true>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
+        case 6: TASU_LAUNCH((stream_gemm_kernel<6, EPI, MT, FRAG, true>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
+        case 7: TASU_LAUNCH((stream_gemm_kernel<7, EPI, MT, FRAG, true>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
+        default: return TASU_ERR_ARG;
+      }
+    }
+    return TASU_ERR_ARG;
+  }
   switch (ks) {
     case 1: TASU_LAUNCH((stream_gemm_kernel<1, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
     case 2: TASU_LAUNCH((stream_gemm_kernel<2, EPI, MT, FRAG>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
@@ -256,8 +269,8 @@ extern "C" int tasu_gemm_stream_resid_prenorm(const void* A, int lda, const void
                                               int K, const float* norm_w, void* yw, int yw_frag, float* sumsq, int a_frag, int w_frag,
                                               void* stream) {
   using namespace tasu_stream;
-  if (!A || !W || !C || !resid || !norm_w || !yw || !sumsq || M <= 0 || M > 64 || N <= 0 || N % 16 || !k_supported(K, 1) || lda % 8 ||
-      ldw % 8)
+  if (!A || !W || !C || !resid || !norm_w || !yw || !sumsq || M <= 0 || M > 64 || N <= 0 || N % 16 || !k_supported(K, 1) || K > 2048 ||
+      lda % 8 || ldw % 8)
     return TASU_ERR_ARG;
   if (!aligned16(A) || !aligned16(W) || !aligned16(C) || !aligned16(resid) || !aligned16(norm_w) || ((uintptr_t)yw & 7)) return TASU_ERR_ARG;
   Args a{};
@@ -276,8 +289,8 @@ extern "C" int tasu_gemm_stream_swiglu_rstd(const void* A, int lda, const void* 
                                             const float* sumsq, int n_part, float eps, int a_frag, int w_frag, int out_frag,
                                             void* stream) {
   using namespace tasu_stream;
-  if (!A || !Wgu || !act || !sumsq || n_part != K / 16 || M <= 0 || M > 64 || I <= 0 || I % 8 || !k_supported(K, 1) || lda % 8 || ldw % 8 ||
-      ldact % 4)
+  if (!A || !Wgu || !act || !sumsq || n_part != K / 16 || M <= 0 || M > 64 || I <= 0 || I % 8 || !k_supported(K, 1) || K > 2048 || lda % 8 ||
+      ldw % 8 || ldact % 4)
     return TASU_ERR_ARG;
   if (!aligned16(A) || !aligned16(Wgu) || ((uintptr_t)act & 7)) return TASU_ERR_ARG;
   Args a{};

@@ -103,11 +103,13 @@ __device__ __forceinline__ void st_out(T* dst, T v) {
 // 1-2 column tiles per workgroup the 64 activation rows dominate it).
 // FRAG: both operands in fragment order (compile-time: a run-time layout test inside the load lambdas splits the ring loop
 // into branches across which the compiler drains vmcnt).
+// PN (E_RESID / E_SWIGLU, KS <= 8): the post-attention norm travels with this GEMM (Args::ssq_out / ssq_in); a template flag so that
+// the other kernels carry none of it (at KS = 14 every register counts).
 // WT: outputs are stored write-through at agent scope (st_out), for a consumer on another XCD inside the SAME launch (round 2's
 // persistent layer-loop kernel); the kernels of gemm_stream.hip pass false.
 // bx / nbx, by, bz: the workgroup's position in the (virtual) grid [column-tile walkers][K ranges][row splits];
 // red: LDS, 2 * NW * MT * 256 floats -- partial tiles [2 buffers][NW waves][MT row tiles][64 lanes] f32x4 -- + NW * 64 floats (rsq).
-template <int KS, int EPI, int MT, bool FRAG, bool WT>
+template <int KS, int EPI, int MT, bool FRAG, bool WT, bool PN = false>
 __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restrict__ red, int bx, int nbx, int by, int bz) {
   const int mt0 = bz * MT;                              // first row tile of this workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -141,14 +143,14 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
   constexpr int QN = KS * 2 / LPR;
   float qv[QN];
   float* rsq = red + 2 * NW * MT * 256;                 // [NW][64]: lane = half * ROWS + row
-  if (EPI == E_SWIGLU && p.ssq_in) {
+  if constexpr (PN && EPI == E_SWIGLU) {
     const float* sp = p.ssq_in + mt0 * 16 + (lane & (ROWS - 1));
     const int t0 = wave + NW * (lane / ROWS);
 #pragma unroll
     for (int j = 0; j < QN; ++j) qv[j] = sp[(size_t)(t0 + NW * LPR * j) * 64];
   }
   auto rsq_publish = [&]() {
-    if (EPI == E_SWIGLU && p.ssq_in) {
+    if constexpr (PN && EPI == E_SWIGLU) {
       float q = 0.f;
 #pragma unroll
       for (int j = 0; j < QN; ++j) q += qv[j];
@@ -187,7 +189,7 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
     if (EPI == E_RESID) {
       const int n = t * 16 + 4 * lq;
       if (m < p.M && n + 4 <= p.N) ep.r4 = *(const f32x4*)(p.R + (size_t)m * p.ldc + n);
-      if (p.ssq_out && n + 4 <= p.N) ep.cs = *(const f32x4*)(p.nw + n);          // (cs: unused by this epilogue otherwise)
+      if (PN && n + 4 <= p.N) ep.cs = *(const f32x4*)(p.nw + n);          // (cs: unused by this epilogue otherwise)
     }
     if (EPI == E_QKV) {
       const int rot_tiles = (p.H + p.G) * 8;
@@ -224,7 +226,7 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
     }
     if (EPI == E_SWIGLU) {
       // lanes lq < 2 hold gate columns t*8 + 4*lq + r, lanes lq + 2 the up values of the same columns
-      if (p.ssq_in) {
+      if constexpr (PN) {
         float q = 0.f;
 #pragma unroll
         for (int w2 = 0; w2 < NW; ++w2)
@@ -308,7 +310,7 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = old[r] + bf16_round(s[r]);
         st_out<WT>((f32x4*)dst, o);
-        if (p.ssq_out) {
+        if constexpr (PN) {
           bf16x4 yv;
 #pragma unroll
           for (int r = 0; r < 4; ++r) yv[r] = (bf16)(ep.cs[r] * o[r]);
@@ -399,7 +401,6 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
       asm volatile("" ::: "memory");
       finish(i, load_epi(i));
     };
-    rsq_publish();                                           // (before the ring: its registers are all this kernel has)
     bf16x8 h0[KH], h1[KH], h2[KH];
     load_h(h0, 0);
     load_h(h1, 1);

@@ -525,7 +525,9 @@ class HipOps:
 
     def prenorm_ok(self, D, HHD, I):
         """decode.py asks: may the post-attention norm travel inside its neighbours (gemm_skinny_prenorm + gemm_skinny_swiglu(sumsq=))?"""
-        return bool(self.dec_prenorm and self.dec_frag and D % 16 == 0 and I % 8 == 0 and self._stream_split(HHD) == 1 and self._stream_split(D) == 1)
+        # (K <= 2048 only: at K = 3584 the streaming kernels have no register to spare -- measured slower with it, DESIGN.md 4h)
+        return bool(self.dec_prenorm and self.dec_frag and D % 16 == 0 and I % 8 == 0 and max(D, HHD) <= 2048 and
+                    self._stream_split(HHD) == 1 and self._stream_split(D) == 1)
 
     def gemm_skinny_prenorm(self, a, b, c, resid, M, N, K, norm_w, yw):
         """c (fp32) = resid + bf16(a @ b^T); yw = bf16(norm_w * c) in the consumer's operand order; returns the per-tile sums of

@@ -19,17 +19,18 @@ am = torch.ones_like(ids, dtype=torch.bool)
 NEW = 96
 
 
-def run(stream, new):
+def run(stream, new, prenorm=True):
     core.ops.dec_stream_7b = stream
+    core.ops.dec_prenorm = prenorm
     core._dec_graphs.clear(); core._dec_seen.clear()
     st = core.prepare_text(ids, am, None, raw["post_ids"], None, None)
     core.forward_projector_text(st)
     return beam_search_generate(core, st, num_beams=4, max_new_tokens=new, eos_token_id=-1, pad_token_id=0)
 
 
-def timed(stream, new):
+def timed(stream, new, prenorm=True):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    o = run(stream, new)
+    o = run(stream, new, prenorm)
     torch.cuda.synchronize()
     return time.perf_counter() - t0, o
 
@@ -43,3 +44,10 @@ for rep in range(3):
         t_half, _ = timed(s, NEW // 2)
         print(f"{'streaming' if s else 'split-K  '}: {(t_full - t_half) / (NEW - NEW // 2) * 1e3:.3f} ms/position "
               f"(whole call {t_full / NEW * 1e3:.3f} ms/position incl. prefill)   tokens equal to the other path: {same:.3f}", flush=True)
+
+# the post-attention norm inside its neighbours (tasu_gemm_stream_resid_prenorm / _swiglu_rstd) at this geometry
+for rep in range(3):
+    for pn in (True, False):
+        t_full, _ = timed(True, NEW, pn)
+        t_half, _ = timed(True, NEW // 2, pn)
+        print(f"streaming, prenorm {'on ' if pn else 'off'}: {(t_full - t_half) / (NEW - NEW // 2) * 1e3:.3f} ms/position", flush=True)
