@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 11
+#define TASU_ABI_VERSION 12
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -210,6 +210,15 @@ int tasu_gemm_stream_resid_prenorm(const void* A, int lda, const void* W, int ld
                                    const float* norm_w, void* yw, int yw_frag, float* sumsq, int a_frag, int w_frag, void* stream);
 int tasu_gemm_stream_swiglu_rstd(const void* A, int lda, const void* Wgu, int ldw, void* act, int ldact, int M, int I, int K,
                                  const float* sumsq, int n_part, float eps, int a_frag, int w_frag, int out_frag, void* stream);
+/* The same for a layer's INPUT norm behind the down projection's K-range slabs: tasu_stream_finish_prenorm is tasu_stream_finish_norm
+ * without the norm's whole-row dependency (C = resid + bf16(sum of the slabs); yw = bf16(norm_w . C); sumsq[N / 16][64] partials; a wave
+ * per 256 columns of a row instead of a wave per row), tasu_gemm_stream_qkv_rope_rstd is tasu_gemm_stream_qkv_rope on A = yw with the
+ * accumulators scaled by rstd before bias and RoPE.  N % 256 == 0; K <= 2048.                                                        */
+int tasu_stream_finish_prenorm(const float* slabs, int ksplit, float* C, const float* resid, int M, int N, const float* norm_w, void* yw,
+                               int yw_frag, float* sumsq, void* stream);
+int tasu_gemm_stream_qkv_rope_rstd(const void* A, int lda, const void* Wqkv, int ldw, const void* bias, void* qkv, int M, int H, int G,
+                                   int K, const float* cos_tab, const float* sin_tab, void* kcache, void* vcache, const int32_t* pos,
+                                   int ctx, const float* sumsq, int n_part, float eps, int a_frag, int w_frag, void* stream);
 /* Round 5: the projection, the residual add AND the RMSNorm of the finished rows in ONE launch (csrc/stream_body.h: norm_tail) --
  * a decode layer's two norm launches (tasu_rmsnorm_fwd_frag behind the o projection, tasu_stream_finish_norm behind the down
  * projection's slabs: Qwen2DecoderLayer, modeling_qwen2.py:269-298, through /root/reference/Multitask/model/ps-slm.py:660-675) move into

@@ -94,6 +94,8 @@ PROTOTYPES = {
     "tasu_gemm_stream_qkv_rope": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "tasu_gemm_stream_slabs": [vp, i32, vp, i32, vp, i64, i32, i32, i32, i32, i32, i32, vp],
     "tasu_stream_finish_norm": [vp, i32, vp, vp, i32, i32, vp, vp, f32, i32, vp],
+    "tasu_stream_finish_prenorm": [vp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp],
+    "tasu_gemm_stream_qkv_rope_rstd": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, f32, i32, i32, vp],
     "tasu_gemm_stream_norm": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp, vp, f32, i32, i32, i32, vp, vp],
     "tasu_rmsnorm_fwd_frag": [vp, vp, vp, i32, i32, f32, vp],
     "tasu_to_fragment_order": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
@@ -128,7 +130,7 @@ PROTOTYPES.update({
     "tasu_allreduce_min_i32": [vp, vp, i64, vp],
 })
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 
 

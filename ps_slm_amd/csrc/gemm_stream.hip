@@ -77,7 +77,7 @@ int launch_ks(Args a, int kr, dim3 grid3, hipStream_t st) {
   const dim3 grid((a.gx * a.gy * a.gz + per - 1) / per * per);
   const int ks = kr / (NW * 32);
   if (a.ssq_out || a.ssq_in) {                           // the post-attention norm inside (PN): one range of K <= 2048
-    if constexpr (EPI == E_RESID || EPI == E_SWIGLU) {
+    if constexpr (EPI == E_RESID || EPI == E_SWIGLU || EPI == E_QKV) {
       switch (ks) {
         case 1: TASU_LAUNCH((stream_gemm_kernel<1, EPI, MT, FRAG, true>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
         case 2: TASU_LAUNCH((stream_gemm_kernel<2, EPI, MT, FRAG, true>), grid, dim3(64 * NW), 0, st, a); return TASU_OK;
@@ -306,6 +306,34 @@ extern "C" int tasu_gemm_stream_swiglu_rstd(const void* A, int lda, const void* 
   return launch<E_SWIGLU>(a, 1, (hipStream_t)stream);
 }
 
+// tasu_gemm_stream_qkv_rope on A = bf16(norm_w . x) (tasu_stream_finish_prenorm): the accumulators are scaled by the rows' rstd from the
+// K / 16 partial sums of squares before bias and RoPE.
+extern "C" int tasu_gemm_stream_qkv_rope_rstd(const void* A, int lda, const void* Wqkv, int ldw, const void* bias, void* qkv, int M, int H,
+                                              int G, int K, const float* cos_tab, const float* sin_tab, void* kcache, void* vcache,
+                                              const int32_t* pos, int ctx, const float* sumsq, int n_part, float eps, int a_frag, int w_frag,
+                                              void* stream) {
+  using namespace tasu_stream;
+  if (!A || !Wqkv || !qkv || !cos_tab || !sin_tab || !kcache || !vcache || !pos || !sumsq || n_part != K / 16 || M <= 0 || M > 64 || H <= 0 ||
+      G <= 0 || !k_supported(K, 1) || K > 2048 || lda % 8 || ldw % 8 || ctx <= 0)
+    return TASU_ERR_ARG;
+  if (!aligned16(A) || !aligned16(Wqkv) || !aligned16(qkv) || !aligned16(cos_tab) || !aligned16(sin_tab) || !aligned16(kcache) ||
+      !aligned16(vcache))
+    return TASU_ERR_ARG;
+  Args a{};
+  a.A = (const bf16*)A;
+  a.W = (const bf16*)Wqkv;
+  a.C = qkv;
+  a.bias = (const bf16*)bias;
+  a.M = M, a.N = (H + 2 * G) * 128, a.K = K, a.lda = lda, a.ldw = ldw, a.ldc = a.N;
+  a.H = H, a.G = G, a.ctx = ctx;
+  a.cos_t = cos_tab, a.sin_t = sin_tab;
+  a.kc = (bf16*)kcache, a.vc = (bf16*)vcache, a.pos = pos;
+  a.tiles = (H + 2 * G) * 8;
+  a.a_frag = a_frag, a.w_frag = w_frag;
+  a.ssq_in = sumsq, a.n_part = n_part, a.eps = eps;
+  return launch<E_QKV>(a, 1, (hipStream_t)stream);
+}
+
 // K split over workgroups: fp32 partial results, row-major [ksplit][64 rows][N] in `slabs` (rows >= M: unspecified);
 // tasu_stream_finish_norm sums them.
 extern "C" int tasu_gemm_stream_slabs(const void* A, int lda, const void* W, int ldw, float* slabs, int64_t slab_floats, int M,
@@ -372,6 +400,43 @@ __global__ __launch_bounds__(256) void stream_finish_norm_kernel(const float* __
                                                                  bf16* __restrict__ y, float eps, int y_frag) {
   const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (m < M) finish_norm_row<NG, false>(slabs, ksplit, C, R, nw, y, eps, y_frag, m);
+}
+
+// The slab finish WITHOUT the norm's row dependency (round 5): C = R + bf16(sum of the slabs), yw = bf16(nw . C) in the consumer's
+// operand order, and one sum of squares per (16-column tile, row) -- the consuming q|k|v projection applies rstd to its accumulators
+// (tasu_gemm_stream_qkv_rope_rstd).  No whole-row reduction, so a wave takes 256 columns of one row: M * N / 256 waves.
+__global__ __launch_bounds__(256) void stream_finish_prenorm_kernel(const float* __restrict__ slabs, int ksplit, float* __restrict__ C,
+                                                                    const float* __restrict__ R, int M, int N, const float* __restrict__ nw,
+                                                                    bf16* __restrict__ yw, int yw_frag, float* __restrict__ ssq) {
+  const int ng = N >> 8;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wid >= M * ng) return;
+  const int m = wid / ng, g = wid - m * ng;
+  const int n = g * 256 + lane * 4;
+  const size_t e = (size_t)m * N + n;
+  const f32x4 v = *(const f32x4*)(R + e), w = *(const f32x4*)(nw + n);
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int KC = 8;
+  for (int k0 = 0; k0 < ksplit; k0 += KC) {
+    f32x4 t[KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) t[j] = k0 + j < ksplit ? *(const f32x4*)(slabs + (size_t)(k0 + j) * 64 * N + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KC; ++j) s += t[j];
+  }
+  f32x4 c;
+  bf16x4 y;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    c[q] = v[q] + bf16_round(s[q]);
+    y[q] = (bf16)(w[q] * c[q]);
+  }
+  *(f32x4*)(C + e) = c;
+  *(bf16x4*)(yw_frag ? yw + frag_index(m, n) : yw + e) = y;
+  float q2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];   // a 16-column tile = the 4 lanes 4j .. 4j + 3
+  q2 += __shfl_xor(q2, 1, 64);
+  q2 += __shfl_xor(q2, 2, 64);
+  if ((lane & 3) == 0) ssq[(size_t)(g * 16 + (lane >> 2)) * 64 + m] = q2;
 }
 
 // N = 2 * NGH * 256 columns (3584: Qwen2.5-7B's down projection): a row's slab chunks in flight do not fit one wave's registers, so
@@ -484,6 +549,15 @@ extern "C" int tasu_stream_finish_norm(const float* slabs, int ksplit, float* C,
     default: return TASU_ERR_ARG;
   }
 #undef TASU_FIN
+}
+
+extern "C" int tasu_stream_finish_prenorm(const float* slabs, int ksplit, float* C, const float* resid, int M, int N, const float* norm_w,
+                                          void* yw, int yw_frag, float* sumsq, void* stream) {
+  if (!slabs || !C || !resid || !norm_w || !yw || !sumsq || ksplit < 1 || M <= 0 || M > 64 || N <= 0 || N % 256) return TASU_ERR_ARG;
+  const int waves = M * (N / 256);
+  TASU_LAUNCH(tasu_stream::stream_finish_prenorm_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, slabs, ksplit, C, resid,
+              M, N, norm_w, (bf16*)yw, yw_frag, sumsq);
+  return TASU_OK;
 }
 
 extern "C" int tasu_to_fragment_order(const void* W, int ldw, void* out, int kind, int N, int K, int H, int G, void* stream) {

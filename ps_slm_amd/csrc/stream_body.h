@@ -103,7 +103,7 @@ __device__ __forceinline__ void st_out(T* dst, T v) {
 // 1-2 column tiles per workgroup the 64 activation rows dominate it).
 // FRAG: both operands in fragment order (compile-time: a run-time layout test inside the load lambdas splits the ring loop
 // into branches across which the compiler drains vmcnt).
-// PN (E_RESID / E_SWIGLU, KS <= 8): the post-attention norm travels with this GEMM (Args::ssq_out / ssq_in); a template flag so that
+// PN (E_RESID / E_SWIGLU / E_QKV, KS <= 8): a layer norm travels with this GEMM (Args::ssq_out / ssq_in); a template flag so that
 // the other kernels carry none of it (at KS = 14 every register counts).
 // WT: outputs are stored write-through at agent scope (st_out), for a consumer on another XCD inside the SAME launch (round 2's
 // persistent layer-loop kernel); the kernels of gemm_stream.hip pass false.
@@ -143,14 +143,14 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
   constexpr int QN = KS * 2 / LPR;
   float qv[QN];
   float* rsq = red + 2 * NW * MT * 256;                 // [NW][64]: lane = half * ROWS + row
-  if constexpr (PN && EPI == E_SWIGLU) {
+  if constexpr (PN && (EPI == E_SWIGLU || EPI == E_QKV)) {
     const float* sp = p.ssq_in + mt0 * 16 + (lane & (ROWS - 1));
     const int t0 = wave + NW * (lane / ROWS);
 #pragma unroll
     for (int j = 0; j < QN; ++j) qv[j] = sp[(size_t)(t0 + NW * LPR * j) * 64];
   }
   auto rsq_publish = [&]() {
-    if constexpr (PN && EPI == E_SWIGLU) {
+    if constexpr (PN && (EPI == E_SWIGLU || EPI == E_QKV)) {
       float q = 0.f;
 #pragma unroll
       for (int j = 0; j < QN; ++j) q += qv[j];
@@ -259,6 +259,14 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
       return;
     }
     if (EPI == E_QKV) {
+      if constexpr (PN) {                                  // the input norm's rstd (the slab finish left bf16(w . x) + partials)
+        float q = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2)
+#pragma unroll
+          for (int h = 0; h < LPR; ++h) q += rsq[w2 * 64 + h * ROWS + wave * 16 + l15];
+        s *= rsqrtf(q / (float)p.K + p.eps);
+      }
       const int rot_tiles = (p.H + p.G) * 8;
       const int W = p.G * 128;
       bf16* out = (bf16*)p.C + (size_t)m * p.ldc;

@@ -204,17 +204,23 @@ def layers_per_gemm(ops, geo, layers, final_norm, x, x2, xn, qkv, ao, act, cos, 
     chunks = [(m0, min(64, M - m0)) for m0 in range(0, M, 64)]
     kcv, vcv = kc.view(L, M, ctx * W), vc.view(L, M, ctx * W)
     prenorm = bool(getattr(ops, "prenorm_ok", None) and ops.prenorm_ok(D, H * HD, I))
+    prenorm_in = bool(prenorm and ops.prenorm_in_ok(D, I) and len(chunks) <= 8)
+    in_ssq = [None] * len(chunks)                                               # per chunk: the input norm's partial sums of squares
     if not normed:                                                               # (the step prologue has done it already)
         for m0, mc in chunks:
             ops.dec_rmsnorm(x[m0:m0 + mc], layers[0]["ln1"], xn[m0:m0 + mc], geo.rms_eps)
     for l, w in enumerate(layers):
         next_norm = layers[l + 1]["ln1"] if l + 1 < L else final_norm            # the norm that consumes this layer's output
-        for m0, mc in chunks:                                                    # qkv projection + bias + RoPE + cache append
+        for ci, (m0, mc) in enumerate(chunks):                                   # qkv projection + bias + RoPE + cache append
             r = slice(m0, m0 + mc)
-            ops.gemm_skinny_qkv_rope(xn[r], w["wqkv"], w["bqkv"], qkv[r], mc, H, G, D, cos[r], sin[r], kcv[l, r], vcv[l, r],
-                                     slot[r], ctx, ws)
+            if in_ssq[ci] is not None:        # xn = bf16(ln1 . x) from the previous layer's slab finish: rstd on the accumulators
+                ops.gemm_skinny_qkv_rope(xn[r], w["wqkv"], w["bqkv"], qkv[r], mc, H, G, D, cos[r], sin[r], kcv[l, r], vcv[l, r],
+                                         slot[r], ctx, ws, sumsq=in_ssq[ci], eps=geo.rms_eps)
+            else:
+                ops.gemm_skinny_qkv_rope(xn[r], w["wqkv"], w["bqkv"], qkv[r], mc, H, G, D, cos[r], sin[r], kcv[l, r], vcv[l, r],
+                                         slot[r], ctx, ws)
         ops.attn_decode(qkv, kc[l], vc[l], index, kstart, lens, ao, M, H, G, ctx, scale)
-        for m0, mc in chunks:                                                    # projections with residual + next norm fused
+        for ci, (m0, mc) in enumerate(chunks):                                   # projections with residual + next norm fused
             r = slice(m0, m0 + mc)
             if prenorm:
                 # o projection + residual; the post-attention norm travels inside it and gate|up (no launch of its own)
@@ -223,7 +229,11 @@ def layers_per_gemm(ops, geo, layers, final_norm, x, x2, xn, qkv, ao, act, cos, 
             else:
                 ops.gemm_skinny_norm(ao[r], w["wo"], x2[r], x[r], mc, D, H * HD, w["ln2"], xn[r], geo.rms_eps, ws)
                 ops.gemm_skinny_swiglu(xn[r], w["wgu"], act[r], mc, I, D, ws)
-            ops.gemm_skinny_norm(act[r], w["wd"], x[r], x2[r], mc, D, I, next_norm, xn[r], geo.rms_eps, ws)
+            if prenorm_in and l + 1 < L:      # the next layer's input norm travels with the slab finish and that layer's q|k|v
+                in_ssq[ci] = ops.gemm_skinny_norm(act[r], w["wd"], x[r], x2[r], mc, D, I, next_norm, xn[r], geo.rms_eps, ws, prenorm_slot=ci)
+            else:
+                ops.gemm_skinny_norm(act[r], w["wd"], x[r], x2[r], mc, D, I, next_norm, xn[r], geo.rms_eps, ws)
+                in_ssq[ci] = None
 
 
 def _decode_after_prefill(model, st, nb, max_new_tokens, min_length, length_penalty, eos, pad):

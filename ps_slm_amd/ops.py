@@ -50,7 +50,9 @@ class HipOps:
         # position at 1.5B (MI355X, alternating processes on one box).  No hand-off inside a launch (the variant below lost to that).
         # False / TASU_DEC_PRENORM=0: the separate norm launch (A/B, tests).
         self.dec_prenorm = os.environ.get("TASU_DEC_PRENORM", "1") != "0"
+        self.dec_prenorm_in = os.environ.get("TASU_DEC_PRENORM_IN", "1") != "0"     # ... and the input norm (slab finish -> q|k|v)
         self.dec_sumsq = None
+        self.dec_sumsq_in = None
         self.dec_stream_7b = True      # K = 3584 in one range / K = 18944 as a ragged split on the streaming kernels (False: A/B runs,
                                        # the split-K kernels of gemm_skinny.hip as before round 5)
         self._frag = {}                # row-major weight address -> (fragment-order copy, the row-major tensor)
@@ -173,6 +175,7 @@ class HipOps:
         # position at 1.5B against the split-K kernels of gemm_skinny.hip; the dec_down_slabs attribute selects, for A/B runs).
         if self.dec_prenorm and self.dec_sumsq is None:    # (here, not at first use: a decode step may be under hipGraph capture)
             self.dec_sumsq = torch.zeros(4096 // 16 * 64, dtype=torch.float32, device="cuda")
+            self.dec_sumsq_in = torch.zeros(8, 4096 // 16 * 64, dtype=torch.float32, device="cuda")    # per 64-row chunk (input norms)
         ks_down = self._stream_split(I)
         self.dec_frag_act = bool(self.dec_frag and I % 32 == 0 and (ks_down == 1 or (ks_down > 1 and self.dec_down_slabs)))
         return self.dec_frag
@@ -478,8 +481,10 @@ class HipOps:
     def kv_append(self, qkv, kc, vc, pos, M, H, G, ctx):
         self._chk(self.lib.tasu_kv_append(_p(qkv), _p(kc), _p(vc), _p(pos), M, H, G, ctx, self._stream()), "tasu_kv_append")
 
-    def gemm_skinny_norm(self, a, b, c, resid, M, N, K, norm_w, y, eps, ws):
-        """c (fp32) = resid + bf16(a @ b^T); y = rmsnorm(c, norm_w) -- decode-step projection with the next norm fused."""
+    def gemm_skinny_norm(self, a, b, c, resid, M, N, K, norm_w, y, eps, ws, prenorm_slot=None):
+        """c (fp32) = resid + bf16(a @ b^T); y = rmsnorm(c, norm_w) -- decode-step projection with the next norm fused.
+        prenorm_slot (int; the K-range-slab route only, prenorm_in_ok): y = bf16(norm_w * c) WITHOUT rstd, and the per-tile sums of
+        squares are returned for gemm_skinny_qkv_rope(sumsq=...) (tasu_stream_finish_prenorm); else returns None."""
         ks = self._stream_split(K) if N % 16 == 0 else 0
         # layout of the INPUT: a one-range K reads a buffer written in the layer's activation order (dec_frag); a longer K is
         # the down projection, whose input layout is dec_frag_act
@@ -504,14 +509,26 @@ class HipOps:
         if ks > 1 and ws is not None and ws.numel() >= ks * (N // 16) * 1024:
             self._chk(self.lib.tasu_gemm_stream_slabs(_p(a), a.stride(0), _p(wf), b.stride(0), _p(ws), ws.numel(), M, N, K, ks,
                                                       a_frag, wflag, self._stream()), "tasu_gemm_stream_slabs")
+            if prenorm_slot is not None:
+                ssq = self.dec_sumsq_in[prenorm_slot]
+                self._chk(self.lib.tasu_stream_finish_prenorm(_p(ws), ks, _p(c), _p(resid), M, N, _p(norm_w), _p(y), y_frag, _p(ssq),
+                                                              self._stream()), "tasu_stream_finish_prenorm")
+                return ssq
             return self._chk(self.lib.tasu_stream_finish_norm(_p(ws), ks, _p(c), _p(resid), M, N, _p(norm_w), _p(y), eps, y_frag,
                                                               self._stream()), "tasu_stream_finish_norm")
         self._chk(self.lib.tasu_gemm_skinny_norm(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), _p(resid), M, N, K, _p(norm_w),
                                                  _p(y), eps, y_frag, _p(ws), 0 if ws is None else ws.numel(), self._stream()),
                   "tasu_gemm_skinny_norm")
 
-    def gemm_skinny_qkv_rope(self, a, wqkv, bias, qkv, M, H, G, K, cos, sin, kc, vc, pos, ctx, ws):
-        """qkv = rope(a @ wqkv^T + bias); k, v appended to the cache at pos -- one call per decode-step layer."""
+    def gemm_skinny_qkv_rope(self, a, wqkv, bias, qkv, M, H, G, K, cos, sin, kc, vc, pos, ctx, ws, sumsq=None, eps=0.0):
+        """qkv = rope(a @ wqkv^T + bias); k, v appended to the cache at pos -- one call per decode-step layer.  sumsq: a is the slab
+        finish's bf16(norm_w * x); the rows' rstd comes from the K / 16 partial sums of squares."""
+        if sumsq is not None:
+            wf, wflag = self._wf(wqkv)
+            return self._chk(self.lib.tasu_gemm_stream_qkv_rope_rstd(_p(a), a.stride(0), _p(wf), wqkv.stride(0), _p(bias), _p(qkv), M, H, G, K,
+                                                                     _p(cos), _p(sin), _p(kc), _p(vc), _p(pos), ctx, _p(sumsq), K // 16, eps,
+                                                                     int(self.dec_frag), wflag, self._stream()),
+                             "tasu_gemm_stream_qkv_rope_rstd")
         if self._stream_split(K) == 1:
             wf, wflag = self._wf(wqkv)
             return self._chk(self.lib.tasu_gemm_stream_qkv_rope(_p(a), a.stride(0), _p(wf), wqkv.stride(0), _p(bias), _p(qkv), M, H,
@@ -528,6 +545,13 @@ class HipOps:
         # (K <= 2048 only: at K = 3584 the streaming kernels have no register to spare -- measured slower with it, DESIGN.md 4h)
         return bool(self.dec_prenorm and self.dec_frag and D % 16 == 0 and I % 8 == 0 and max(D, HHD) <= 2048 and
                     self._stream_split(HHD) == 1 and self._stream_split(D) == 1)
+
+    def prenorm_in_ok(self, D, I):
+        """... and the layer's INPUT norm inside the slab finish and the q|k|v projection (gemm_skinny_norm(prenorm_slot=) +
+        gemm_skinny_qkv_rope(sumsq=)): the down projection must run as K-range slabs."""
+        ks = self._stream_split(I)
+        return bool(self.dec_prenorm and self.dec_prenorm_in and self.dec_frag and self.dec_frag_act and self.dec_down_slabs and ks > 1 and
+                    D % 256 == 0 and D <= 2048 and self._stream_split(D) == 1)
 
     def gemm_skinny_prenorm(self, a, b, c, resid, M, N, K, norm_w, yw):
         """c (fp32) = resid + bf16(a @ b^T); yw = bf16(norm_w * c) in the consumer's operand order; returns the per-tile sums of

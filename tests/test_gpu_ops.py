@@ -1287,6 +1287,54 @@ def test_post_attention_norm_inside_its_neighbours(hip, fake, M, D, HHD, I):
     assert rel_err(outs[True][2], actc) < 2e-2
 
 
+@pytest.mark.parametrize("M,D,I,H,G", [(64, 1536, 8960, 12, 2), (23, 1536, 8960, 12, 2), (64, 512, 2560, 4, 2), (1, 1536, 8960, 12, 2)])
+def test_input_norm_inside_the_slab_finish_and_qkv(hip, fake, M, D, I, H, G):
+    """tasu_stream_finish_prenorm + tasu_gemm_stream_qkv_rope_rstd (down-projection slabs -> [input norm of the next layer] -> q|k|v + bias
+    + RoPE + cache append, the norm without a whole-row kernel) against tasu_stream_finish_norm + tasu_gemm_stream_qkv_rope: the fp32
+    residual stream is BIT-identical, yw == bf16(norm_w * c), the partial sums of squares add up to the rows', and q|k|v / the appended
+    cache rows agree like two bf16 evaluations of one expression."""
+    ctx, LD, W, HHD = 12, (H + 2 * G) * HD, G * HD, H * HD
+    g = torch.Generator().manual_seed(D + I + M)
+    rn = lambda *sh, k=1.0: (torch.randn(*sh, generator=g) * k)
+    wqkv, bq, wd = rn(LD, D, k=D ** -0.5).to(BF).cuda(), rn(LD).to(BF).cuda(), rn(D, I, k=I ** -0.5).to(BF).cuda()
+    wo, wgu = torch.zeros(D, HHD, dtype=BF, device="cuda"), torch.zeros(2 * I, D, dtype=BF, device="cuda")
+    act, x2, ln = rn(M, I).to(BF), rn(M, D) * 3.0, 1 + 0.1 * rn(D)
+    ang = rn(M, 64)
+    cos, sin = torch.cos(ang).cuda(), torch.sin(ang).cuda()
+    pos = (3 + torch.arange(M) % 5).to(I32).cuda()
+    hip.use_stream = hip.dec_down_slabs = True
+    hip.register_decode_weight(wqkv, "qkv", LD, H, G)
+    hip.register_decode_weight(wo, "plain", D)
+    hip.register_decode_weight(wgu, "swiglu", I)
+    hip.register_decode_weight(wd, "plain", D, slabs_ok=True)
+    assert hip.begin_decode(D, HHD, I)
+    try:
+        assert hip.prenorm_in_ok(D, I)
+        actd = ao_frag(act, I).cuda()
+        ws = torch.zeros(32 * 64 * ((2 * I + 95) // 96 * 96), device="cuda")
+        outs = []
+        for pre in (False, True):
+            c, xn = torch.zeros(M, D, device="cuda"), torch.zeros(64, D, dtype=BF, device="cuda")
+            qkv = torch.zeros(M, LD, dtype=BF, device="cuda")
+            kc, vc = torch.zeros(M * ctx * W, dtype=BF, device="cuda"), torch.zeros(M * ctx * W, dtype=BF, device="cuda")
+            ssq = hip.gemm_skinny_norm(actd[:M], wd, c, x2.cuda(), M, D, I, ln.cuda(), xn[:M], 1e-6, ws, prenorm_slot=0 if pre else None)
+            assert (ssq is not None) == pre
+            kw = dict(sumsq=ssq, eps=1e-6) if pre else {}
+            hip.gemm_skinny_qkv_rope(xn[:M], wqkv, bq, qkv, M, H, G, D, cos, sin, kc, vc, pos, ctx, ws, **kw)
+            torch.cuda.synchronize()
+            outs.append((c.cpu(), unfrag(xn.cpu(), D)[:M], qkv.cpu(), kc.cpu(), vc.cpu(), None if ssq is None else ssq.cpu()))
+    finally:
+        hip.end_decode()
+    (c3, xn3, q3, k3, v3, _), (c2, yw, q2, k2, v2, ssq) = outs
+    assert torch.equal(c2, c3)
+    assert torch.equal(yw, (ln * c2).to(BF))
+    part = ssq[:D // 16 * 64].view(D // 16, 64)
+    assert torch.allclose(part[:, :M].double().sum(0), (c2.double() ** 2).sum(1), rtol=1e-5)
+    for a, b in ((q2, q3), (k2, k3), (v2, v3)):
+        assert torch.isfinite(a.float()).all() and rel_err(a, b) < 1.5e-2
+    assert ((k2 != 0) == (k3 != 0)).all()                     # the same cache slots were written
+
+
 @pytest.mark.parametrize("H,G,ctx,frag", [(12, 2, 1100, 1), (2, 1, 700, 0), (28, 4, 530, 0), (12, 2, 40, 1)])
 def test_attn_decode_long_ragged_contexts(hip, fake, H, G, ctx, frag):
     """Cache attention beyond what a wave prefetches (3 K chunks / 2 V blocks per wave = 384 / 512 keys): ragged visible ranges
