@@ -528,8 +528,8 @@ extern "C" int tasu_stream_finish_norm(const float* slabs, int ksplit, float* C,
                                        const float* norm_w, void* y, float eps, int y_frag, void* stream) {
   if (!slabs || !C || !resid || !norm_w || !y || ksplit < 1 || M <= 0 || M > 64 || N <= 0 || N % 256) return TASU_ERR_ARG;
   // rows per block: the finish is bound by what ONE CU ingests (ksplit slabs x N x 4 B per row), so the rows are spread over as
-  // many CUs as there are rows (TASU_FINISH_ROWS: A/B runs; round 4 ran 4 rows per block)
-  static const int rows_env = [] { const char* e = getenv("TASU_FINISH_ROWS"); return e ? atoi(e) : 0; }();
+  // many CUs as there are rows (TASU_FINISH_ROWS in the lab build: A/B runs; round 4 ran 4 rows per block)
+  static const int rows_env = [] { const char* e = tasu_lab_env("TASU_FINISH_ROWS"); return e ? atoi(e) : 0; }();
   const int rows = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : 1;
   const dim3 grid((M + rows - 1) / rows);
   hipStream_t st = (hipStream_t)stream;

@@ -350,8 +350,8 @@ static int rmsnorm_fwd_any(const float* x, const int32_t* src, const float* w, v
   if (ldy == 0) ldy = D;
   if (ldy < D || ldy % 4 || (frag && ldy != D)) return TASU_ERR_ARG;
   // one wave per row.  A decode step's <= 64 rows go one per workgroup (64 CUs instead of 16: the kernel is one memory round trip
-  // and a workgroup's rows share a CU's load path); the training step's thousands of rows four per workgroup.  TASU_NORM_ROWS: A/B.
-  static const int rows_env = [] { const char* e = getenv("TASU_NORM_ROWS"); return e ? atoi(e) : 0; }();
+  // and a workgroup's rows share a CU's load path); the training step's thousands of rows four per workgroup.  TASU_NORM_ROWS (lab build): A/B.
+  static const int rows_env = [] { const char* e = tasu_lab_env("TASU_NORM_ROWS"); return e ? atoi(e) : 0; }();
   const int rows = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : (M <= 64 ? 1 : 4);
   const dim3 grid((M + rows - 1) / rows), block(64 * rows);
   hipStream_t st = (hipStream_t)stream;

@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of the rows-per-workgroup of the decode step's row-wise kernels (norm, slab finish): ms per position, separate processes
+# A/B of the rows-per-workgroup of the decode step's row-wise kernels (norm, slab finish): ms per position, separate processes.
+# The switches exist in the LAB build only: make -C ps_slm_amd/csrc lab; export TASU_LIB_PATH=ps_slm_amd/libtasu_hip_lab.so
 set -euo pipefail
 cd "${GRAFT_REPO_ROOT:?run through gpurun}"
 for rep in 1 2; do
