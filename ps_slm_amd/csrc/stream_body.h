@@ -3,6 +3,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef TASU_TOUCH_MASK
+#define TASU_TOUCH_MASK 0
+#endif
+
 namespace tasu_stream {
 
 enum { E_BF16 = 0, E_RESID = 1, E_SWIGLU = 2, E_QKV = 3, E_SLAB = 4 };
@@ -120,19 +124,42 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
   // ---- activations: this wave's K slice of all 64 rows, as MFMA B operands (rows beyond M are clamped; masked at the store)
   bf16x8 a[MT][KS];
   const int cg0 = p.kstep0 + (by * NW + wave) * KS;        // this wave's first global k-step
-  if (FRAG) {
-#pragma unroll
-    for (int c = 0; c < KS; ++c)
-#pragma unroll
-      for (int t = 0; t < MT; ++t) a[t][c] = *(const bf16x8*)(p.A + (((size_t)(cg0 + c) * 4 + mt0 + t) * 64 + lane) * 8);
-  } else {
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const bf16* ar = p.A + (size_t)min((mt0 + t) * 16 + l15, p.M - 1) * p.lda + k0;
-#pragma unroll
-      for (int c = 0; c < KS; ++c) a[t][c] = *(const bf16x8*)(ar + c * 32);
+  // FIRST TOUCH (compile-time experiment, -DTASU_TOUCH_MASK=<bit per EPI>): the ~32 workgroups of an XCD read the same
+  // activation image at the same moment and the L2 does not merge concurrent misses of one line.  With the flag each workgroup first
+  // pulls ITS share of the image through the XCD's L2 (requested here, ahead of the first weight tiles); the operand loads follow
+  // once those have arrived (late_acts), and hit.
+  constexpr bool TOUCH = FRAG && ((TASU_TOUCH_MASK >> EPI) & 1) != 0;
+  if constexpr (TOUCH) {
+    const int nper = ((int)gridDim.x + 7) >> 3, rank = (int)blockIdx.x >> 3;
+    const int total16 = (p.K >> 5) * 4 * 64;              // 16-byte pieces of [K / 32][4 row tiles][64 lanes][8]
+    const int per = (total16 + nper - 1) / nper;
+    for (int i = rank * per + (int)threadIdx.x; i < min((rank + 1) * per, total16); i += 64 * NW) {
+      const bf16x8 v = *(const bf16x8*)(p.A + (size_t)i * 8);
+      asm volatile("" ::"v"(v));
     }
   }
+  auto load_acts = [&]() {
+    if (FRAG) {
+#pragma unroll
+      for (int c = 0; c < KS; ++c)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[t][c] = *(const bf16x8*)(p.A + (((size_t)(cg0 + c) * 4 + mt0 + t) * 64 + lane) * 8);
+    } else {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const bf16* ar = p.A + (size_t)min((mt0 + t) * 16 + l15, p.M - 1) * p.lda + k0;
+#pragma unroll
+        for (int c = 0; c < KS; ++c) a[t][c] = *(const bf16x8*)(ar + c * 32);
+      }
+    }
+  };
+  auto late_acts = [&]() {
+    if constexpr (TOUCH) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      load_acts();
+    }
+  };
+  if constexpr (!TOUCH) load_acts();
 
   // E_SWIGLU behind a pre-normed o projection: the rows' sums of squares from the producer's per-tile partials.  K / 16 = 16 KS
   // partials per row; wave w requests tiles w, w + 8, ... for the workgroup's 16 MT rows (lane = row; MT = 2: two lane halves share the
@@ -412,6 +439,7 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
     bf16x8 h0[KH], h1[KH], h2[KH];
     load_h(h0, 0);
     load_h(h1, 1);
+    late_acts();
     if (ntl <= 2) {
       // one or two tiles (q|k|v, o): nothing is read twice, the epilogue operands travel with the weights
       if (ntl == 2) load_h(h2, 2);
@@ -462,6 +490,7 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
   if (ntl <= 2) {
     // one or two tiles (the q|k|v, o and down projections): no ring, nothing loaded twice
     if (ntl == 2) load_w(w1, 1);
+    late_acts();
     rsq_publish();
     const Epi e0 = load_epi(0), e1 = load_epi(1);
     TASU_STREAM_STAMP(1);
@@ -475,6 +504,7 @@ __device__ __forceinline__ void stream_gemm_body(const Args& p, float* __restric
   // bodies re-read the last tile and skip their epilogue), so that the compiler's vmcnt bookkeeping sees one straight ring
   // and waits for the oldest tile only.
   load_w(w1, 1);
+  late_acts();
   rsq_publish();
   TASU_STREAM_STAMP(1);
   for (int i = 0; i < ntl; i += 3) {
