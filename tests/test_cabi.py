@@ -38,6 +38,14 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.tasu_gemm_nt_bf16(None, 64, None, 64, None, 64, None, None, 64, 64, 64, 0, None) == 1
     assert lib.tasu_rmsnorm_fwd(None, None, None, None, 4, 6, 1e-6, None) == 1
     assert lib.tasu_adamw(None, None, None, None, None, 0, 5e-5, 0.9, 0.999, 1e-6, 0.0, 1, 1.0, None) == 1
+    # round 5's decode entry points: null operands, and the in-GEMM norms' K <= 2048 rule (checked before the pointers are looked at
+    # only for the null case here: no device memory on this box)
+    assert lib.tasu_gemm_stream_resid_prenorm(None, 1536, None, 1536, None, None, 64, 1536, 1536, None, None, 1, None, 1, 1, None) == 1
+    assert lib.tasu_gemm_stream_swiglu_rstd(None, 1536, None, 1536, None, 8960, 64, 8960, 1536, None, 96, 1e-6, 1, 1, 1, None) == 1
+    assert lib.tasu_stream_finish_prenorm(None, 7, None, None, 64, 1536, None, None, 1, None, None) == 1
+    assert lib.tasu_gemm_stream_qkv_rope_rstd(None, 1536, None, 1536, None, None, 64, 12, 2, 1536, None, None, None, None, None, 328, None, 96,
+                                              1e-6, 1, 1, None) == 1
+    assert lib.tasu_stream_finish_norm(None, 13, None, None, 64, 3584, None, None, 1e-6, 1, None) == 1
 
 
 def test_stream_k_ranges_equal_and_ragged():
