@@ -10,6 +10,8 @@ ops = HipOps()
 bf = torch.bfloat16
 SHAPES = {"d_gate_up": (4096, 1536, 17920), "gate_up_plain": (4096, 17920, 1536), "down": (4096, 1536, 8960), "d_down": (4096, 8960, 1536),
           "qkv": (4096, 2048, 1536)}
+if len(sys.argv) > 1 and sys.argv[1] == "encoder":          # the SANM encoder's GEMMs (16 x 504 frames)
+    SHAPES = {"enc_qkv": (8064, 1536, 512), "enc_out": (8064, 512, 512), "enc_w1": (8064, 2048, 512), "enc_w2": (8064, 512, 2048)}
 NSETS = 6
 
 
