@@ -551,6 +551,116 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
     return rec
 
 
+SUB_METRICS = {"audio_sft": " (audio-SFT, config 4)", "qwen2.5-7b": " (Qwen2.5-7B align, config 5)",
+               "variable_S": " (text-only, variable shapes: CPS drop 0.05, bucketed hipGraphs)",
+               "audio_sft_blank_biased": " (audio-SFT, config 4, ~100 audio tokens per utterance)",
+               "lora_r64": " (text-only, use_peft=true: LoRA r=64 on the decoder + projector)",
+               "exchange_1rank": " (headline step with the N > 1 gradient exchange forced through a 1-rank RCCL "
+                                 "communicator: allreduce_exposed_ms is the sanity figure)"}
+
+STDOUT_LINE_LIMIT = 8000           # the driver's record keeps ~8,000 characters of stdout and parses the line from them
+_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step", "kernel_launches_per_step",
+              "avg_launch_us", "gemm_ms_per_step", "launch", "whole_step_frac", "whole_step_frac_at_survey_flops")
+
+
+def _clip(s, n=120):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + "..."
+
+
+def _brief(r):
+    """value / ms_per_step / roofline fractions of a sub-record."""
+    if not isinstance(r, dict) or r.get("value") is None:
+        return None
+    out = {"value": r["value"], "unit": r.get("unit"), "ms_per_step": r.get("ms_per_step")}
+    roof = r.get("roofline")
+    if isinstance(roof, dict):
+        out["roofline_frac"] = roof.get("frac")
+        if "whole_step_frac_at_survey_flops" in roof:
+            out["whole_step_frac_at_survey_flops"] = roof["whole_step_frac_at_survey_flops"]
+    if "allreduce_exposed_ms" in r:
+        out["allreduce_exposed_ms"] = r["allreduce_exposed_ms"]
+    return out
+
+
+def compact_line(full, full_path="profiles/bench_r06_full.json"):
+    """The ONE stdout line: the contract's top-level keys, ``roofline`` and ``cpu_baseline`` as plain numbers and short names, and
+    ``digest`` (value / ms_per_step / roofline fractions of every sub-record) -- no prose, every string <= 120 characters, the whole
+    line < STDOUT_LINE_LIMIT bytes.  The complete record (sub-record bodies, notes, sources) goes to stderr and to ``full_path``."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: full.get(k) for k in top}
+    cfg = full.get("config") or {}
+    model = "Qwen2.5-7B" if "7B" in str(full.get("metric")) else "Qwen2.5-1.5B"
+    what = "audio-SFT step" if "audio-SFT" in str(cfg.get("workload")) else "text-only CPS alignment step"
+    if "LoRA recipe" in str(cfg.get("workload")):
+        what += " + LoRA r=64"
+    line["config"] = {"workload": _clip(f"{what} (fwd + dgrad bwd + projector wgrad + AdamW), {model}, "
+                                        f"{cfg.get('per_gpu_batch')} utt/GPU x S={cfg.get('seq_len')}"),
+                      "per_gpu_batch": cfg.get("per_gpu_batch"), "seq_len": cfg.get("seq_len"), "parallelism": cfg.get("parallelism"),
+                      "final_loss": cfg.get("final_loss")}
+    roof = full.get("roofline") or {}
+    line["roofline"] = {k: _clip(roof[k]) for k in _ROOF_KEYS if k in roof}
+    if "kernel" in line["roofline"]:
+        line["roofline"]["kernel"] = "gemm_pp_kernel + gemm_pipe_kernel (all MFMA GEMM launches of the step)"
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": _clip(_short_sample(cb.get("sample")))}
+    if "allreduce_exposed_ms" in full:
+        coll = full.get("collective") or {}
+        line["collective"] = {"ranks": coll.get("ranks"), "library": _clip(coll.get("library"), 60)} if isinstance(coll, dict) else None
+        line["allreduce_exposed_ms"] = full["allreduce_exposed_ms"]
+    digest = {"train_1p5b" if "7B" not in str(full.get("metric")) else "train_7b": _brief(full), "decode": _brief(full.get("decode"))}
+    for name in SUB_METRICS:
+        rec = full.get(name)
+        if isinstance(rec, dict):
+            digest[name] = _brief(rec) or {"error": _clip(rec.get("error"))}
+            if isinstance(rec.get("decode"), dict):
+                digest[name + "_decode"] = _brief(rec["decode"])
+    dp = full.get("data_path")
+    if isinstance(dp, dict):
+        digest["data_path"] = ({k: dp.get(k) for k in ("text_only_utterances_per_s", "audio_wav_utterances_per_s")} if "error" not in dp
+                               else {"error": _clip(dp["error"])})
+    for k, rec in (full.get("cpu_baselines") or {}).items():
+        if isinstance(rec, dict):
+            digest["cpu_" + k] = {"value": rec.get("value"), "unit": rec.get("unit"), "cores": rec.get("cores")}
+    line["digest"] = {k: v for k, v in digest.items() if v is not None}
+    if "wall_seconds" in full:
+        line["wall_seconds"] = full["wall_seconds"]
+    line["full_record"] = full_path
+    return line
+
+
+def _short_sample(s):
+    """cpu_baseline.sample in <= 120 characters: what was timed, batch, iterations, threads."""
+    if not isinstance(s, str):
+        return s
+    import re
+    m = re.search(r"B=(\d+).*?(\d+) timed iteration\(s\) after (\d+) warm-up.*?(\d+) threads", s)
+    if m:
+        return f"oracle port fp32, B={m.group(1)}, S=256, fwd+bwd+AdamW, {m.group(2)} timed iter after {m.group(3)} warm-up, {m.group(4)} threads"
+    return s
+
+
+def emit(full, fd, full_path):
+    """Full record -> stderr + ``full_path`` (best effort); compact line (< STDOUT_LINE_LIMIT bytes, checked) -> the real stdout."""
+    text = json.dumps(full)
+    sys.stderr.write("FULL_RECORD " + text + "\n")
+    sys.stderr.flush()
+    try:
+        os.makedirs(os.path.dirname(os.path.join(ROOT, full_path)), exist_ok=True)
+        with open(os.path.join(ROOT, full_path), "w") as f:
+            f.write(text + "\n")
+    except OSError:
+        pass
+    out = json.dumps(compact_line(full, full_path))
+    if len(out.encode()) >= STDOUT_LINE_LIMIT:            # (cannot happen with the fixed key set; never print an unparsable line)
+        slim = compact_line(full, full_path)
+        slim.pop("wall_seconds", None)
+        slim["digest"] = {k: v for k, v in slim["digest"].items() if k.startswith(("train", "decode"))}
+        out = json.dumps(slim)
+    os.write(fd, (out + "\n").encode())
+
+
 def check_launch(world, gpus):
     """``--gpus N`` must be launched as N processes (torch.distributed.run, one per GPU): anything else would print a line whose
     n_gpus does not describe the run."""
@@ -584,6 +694,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the config-4 (audio-SFT) and config-5 (Qwen2.5-7B) sub-records")
     ap.add_argument("--no-data-path", action="store_true",
                     help="skip the data_path sub-record (the training entrypoint on a generated 2048-utterance wav-in-ark corpus in tmpfs)")
+    ap.add_argument("--full-record", default="profiles/bench_r06_full.json",
+                    help="where the complete record (every sub-record's body and notes) is written, relative to the repo; stdout carries "
+                         "only the compact line")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.cpu_baseline_worker)
@@ -689,12 +802,7 @@ def main():
                 "dtype": "bf16", "data": "synthetic"}
         line.update({k: v for k, v in main_rec.items() if k not in ("value", "unit", "ms_per_step")})
         for name, rec in extras.items():
-            rec["metric"] = "train utterances/sec" + {"audio_sft": " (audio-SFT, config 4)", "qwen2.5-7b": " (Qwen2.5-7B align, config 5)",
-                                                      "variable_S": " (text-only, variable shapes: CPS drop 0.05, bucketed hipGraphs)",
-                                                      "audio_sft_blank_biased": " (audio-SFT, config 4, ~100 audio tokens per utterance)",
-                                                      "lora_r64": " (text-only, use_peft=true: LoRA r=64 on the decoder + projector)",
-                                                      "exchange_1rank": " (headline step with the N > 1 gradient exchange forced through a 1-rank RCCL "
-                                                                        "communicator: allreduce_exposed_ms is the sanity figure)"}[name]
+            rec["metric"] = "train utterances/sec" + SUB_METRICS[name]
             line[name] = rec
         if data_path is not None:
             line["data_path"] = data_path
@@ -705,26 +813,7 @@ def main():
             line["cpu_baselines"] = {"train_B16": side["train16"], "decode_B1": side["decode1"], "decode_B16": side["decode16"]}
             lap("cpu_baselines_B16_decode")
         line["wall_seconds"] = wall                     # where this run's wall clock went (the timed regions are a small part of it)
-        # LAST key of the line: the headline numbers of every sub-record in a few hundred bytes, so that a reader who keeps only
-        # the tail of a long line (the driver's record does) still sees them
-        def brief(r):
-            if not isinstance(r, dict) or r.get("value") is None:
-                return None
-            out = {"value": r["value"], "unit": r.get("unit"), "ms_per_step": r.get("ms_per_step")}
-            if isinstance(r.get("roofline"), dict):
-                out["roofline_frac"] = r["roofline"].get("frac")
-                if "whole_step_frac_at_survey_flops" in r["roofline"]:
-                    out["whole_step_frac_at_survey_flops"] = r["roofline"]["whole_step_frac_at_survey_flops"]
-            return out
-        digest = {"train_1p5b": brief(dict(main_rec, unit="utterances/s")), "decode_1p5b": brief(main_rec.get("decode"))}
-        for name, rec in extras.items():
-            digest[name] = brief(rec)
-            if isinstance(rec.get("decode"), dict):
-                digest[name + "_decode"] = brief(rec["decode"])
-        if data_path is not None and "error" not in data_path:
-            digest["data_path"] = {k: data_path[k] for k in ("text_only_utterances_per_s", "audio_wav_utterances_per_s")}
-        line["digest"] = digest
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        emit(line, real_stdout, args.full_record)
     if world > 1:
         dist.destroy_process_group()
 
