@@ -451,7 +451,7 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         if rank == 0:
             timed.time_replay(steps)
         core.use_graphs = True
-    loss = float(out.loss)
+    loss = float(out.loss.detach())
     rec = None
     if rank == 0:
         st = engine._last_state

@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16* __restri
   }
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
-  if (part == 0 && tok < S) delta[((size_t)b * H + h) * Spad + tok] = acc;
+  // rows in [S, Spad) get an explicit 0: the dK/dV kernels read delta for the whole padded tile, and the buffer comes from an
+  // uninitialised allocation (0 * NaN would poison dK)
+  if (part == 0 && tok < Spad) delta[((size_t)b * H + h) * Spad + tok] = tok < S ? acc : 0.f;
   if (!dout_t) return;                                   // the backward kernels transpose in LDS (frag_tr_row): delta only
   __syncthreads();
   // transposed write: thread -> d = tid>>1, 32 tokens
@@ -353,7 +355,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16* __restrict__ qkv, 
     if (threadIdx.x < 128) {
       r_ld = (threadIdx.x < 64 ? lse : delta)[((size_t)b * H + h) * Spad + qtile * 64 + (threadIdx.x & 63)];
       // lse in the base-2 domain; +inf for query rows past the sequence (their probabilities are exp2(-inf) = 0)
+      // ... and delta 0 there: p = 0 times a stale NaN would still be NaN
       if (threadIdx.x < 64) r_ld = qtile * 64 + (int)threadIdx.x < S ? r_ld * LOG2E : __builtin_inff();
+      else r_ld = qtile * 64 + (int)(threadIdx.x & 63) < S ? r_ld : 0.f;
     }
   };
   TileRegs rQ, rdO;

@@ -330,9 +330,14 @@ __device__ __forceinline__ void dkv_body(const bf16* __restrict__ qkv, const uin
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float pr = prob2(a[r], scale2, kbias - l4[r] * LOG2E);
-        if (edge) pr = (q0 + r < S && (!causal || kpos <= q0 + r)) ? pr : 0.f;
+        float dsr = pr * (dp[r] - d4[r]);
+        if (edge) {                          // (select BOTH: lse / delta of rows past S are whatever the allocation held, 0 * NaN = NaN)
+          const bool ok = q0 + r < S && (!causal || kpos <= q0 + r);
+          pr = ok ? pr : 0.f;
+          dsr = ok ? dsr : 0.f;
+        }
         pv[q2][r] = pr;
-        ds[q2][r] = pr * (dp[r] - d4[r]);
+        ds[q2][r] = dsr;
       }
     }
     const bf16x8 pf = pack_pair(pv[0], pv[1]);

@@ -227,6 +227,7 @@ class TasuEngine:
         if st is None:
             raise RuntimeError("backward() called before a forward pass")
         self.micro_steps += 1
+        st.backward_ran = True                         # (outputs.loss.backward() of the same step would be a second pass: _HipStep refuses)
         if self.ga > 1:
             self.core.run_backward(st)
             self._g_acc.add_(self.core.proj.g, alpha=1.0 / (self.ga * self.ga))

@@ -262,7 +262,7 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
             if log_now and val_now:
                 # loss / acc are views into the step's result buffer, which the validation forwards below overwrite:
                 # read them first
-                loss, acc = float(loss), float(acc)
+                loss, acc = float(loss.detach()), float(acc)
             if val_now:
                 ppl, el, ea = evaluation(engine, train_config, eval_dataset, rank, world)
                 if train_config.save_model and (el < best_val_loss or ea > best_val_acc) and \
@@ -277,7 +277,7 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
                 val_ppl.append(ppl)
                 val_acc.append(ea)
             if log_now:
-                l, a = float(loss), float(acc)                 # the only host sync of the loop, every log_interval steps
+                l, a = float(loss.detach() if torch.is_tensor(loss) else loss), float(acc)                 # the only host sync of the loop, every log_interval steps
                 total_loss, total_acc = total_loss + l, total_acc + a
                 if rank == 0:
                     logger.info("epoch %d step %d loss %.4f acc %.4f lr %.3e  %.1f utt/s", epoch + 1, steps, l, a,

@@ -351,6 +351,7 @@ class StepState:
     out: object = None
     path: str = "text"   # "text" (pseudo-posterior) or "audio" (encoder + PSD): part of the graph keys, the buffers differ
     lora_drop: bool = False   # this step's forward drew LoRA dropout masks (the backward regenerates them)
+    backward_ran: bool = False   # the step's backward has run (TasuEngine.backward or outputs.loss.backward(): ps_slm._HipStep)
 
 
 class TasuModel:

@@ -4,20 +4,22 @@ Multitask/utils/model_utils.py:9-33).  Same names, argument meaning and error be
 the HIP kernels of libtasu_hip.so through ps_slm_amd.model.TasuModel.
 
 What callers get (Multitask/utils/deepspeed_utils.py:205-236, Multitask/inference_batch.py:139-151):
-  model(**batch) -> (outputs, acc)   outputs.loss (0-dim device tensor, ``EngineLoss``), outputs.logits [B,S,V] (bf16 view)
+  model(**batch) -> (outputs, acc)   outputs.loss (0-dim fp32 device tensor with a grad_fn in training mode), outputs.logits [B,S,V] (bf16 view)
   model.generate(**batch) -> LongTensor [B, n_new]
   model.parameters() / named_parameters() / train() / eval() / state_dict() / load_state_dict(strict=False) with the
   reference's checkpoint keys ``encoder_projector.{norm,ffn.0,ffn.2}.{weight,bias}`` (Multitask/utils/checkpoint_handler.py:169-182)
 
-DEVIATION from the reference contract (Multitask/finetune_deepspeed.py:127-149, Multitask/utils/deepspeed_utils.py:205-236),
-stated here, in INTEGRATION.md and in include/tasu_hip.h, and pinned by tests/test_engine_cpu.py: the model is not an
-``nn.Module`` and ``outputs.loss`` carries NO autograd graph -- the backward pass is hand-scheduled HIP
-(``TasuModel.run_backward``), so the only engine that can train this model is ``ps_slm_amd.engine.TasuEngine``
-(``backward(loss)`` / ``step()``, the DeepSpeed engine's surface).  ``parameters()`` lists the trainable projector tensors
-(views of the flat fp32 master buffer, ``requires_grad=True`` like the reference's unfrozen projector; the frozen LLM and
-encoder weights live in kernel layouts and are not listed), so a foreign engine gets as far as building its optimizer; its
-first ``loss.backward()`` / ``engine.backward(loss)`` then raises ``EngineLoss``'s RuntimeError naming TasuEngine --
-never a silent no-op step.
+Autograd glue (Multitask/finetune_deepspeed.py:127-149, Multitask/utils/deepspeed_utils.py:205-236): the model is not
+an ``nn.Module`` (the frozen LLM and encoder weights live in kernel layouts and are not listed), but in training mode
+``outputs.loss`` IS the result of a ``torch.autograd.Function`` over the trainable leaves ``parameters()`` lists (views of the flat
+fp32 master buffer under the reference's names, the SAME objects on every call).  ``loss.backward()`` -- directly or through any
+engine -- runs the hand-scheduled HIP backward (``TasuModel.run_backward``) once and hands each leaf its slice of the flat
+gradient bucket, scaled by the incoming gradient; an optimizer built over ``model.parameters()`` then updates the masters in
+place and the next ``forward`` / ``generate`` refreshes the bf16 working copies.  So the reference's loop body trains this plugin
+with ``torch.optim.AdamW`` or DeepSpeed as it stands.  ``ps_slm_amd.engine.TasuEngine`` (the DeepSpeed engine's surface:
+``backward(loss)`` / ``step()``) stays the FAST path: it ignores the graph, overlaps the gradient exchange with the backward and
+runs the fused AdamW kernel.  A loss computed in eval mode has no saved activations behind it: it is an ``EngineLoss`` whose
+``backward()`` raises and says so.
 """
 import json
 import logging
@@ -265,23 +267,49 @@ def model_factory(train_config, model_config, **kwargs):
 
 
 # ------------------------------------------------------------------------------------------------ the model
-ENGINE_ONLY_MSG = ("ps_slm_amd: outputs.loss carries no autograd graph -- the backward pass of the MI355X path is hand-scheduled HIP "
-                   "behind ps_slm_amd.engine.TasuEngine.backward(loss) / .step() (the surface of the DeepSpeed engine of "
-                   "Multitask/finetune_deepspeed.py:147-149); torch.autograd, DeepSpeed or any other engine cannot train this "
-                   "model.  Launch training with `python -m ps_slm_amd.finetune_deepspeed ...` (INTEGRATION.md)")
+NO_GRAPH_MSG = ("ps_slm_amd: this loss was computed in eval mode (model.eval() / need_backward=False): the step kept no activations "
+                "for a backward pass.  Call model.train() before the forward whose loss you want to differentiate")
 
 
 class EngineLoss(torch.Tensor):
-    """``outputs.loss``: the 0-dim fp32 device tensor the step's CE kernel wrote.  It behaves like any tensor (``loss / k``,
-    ``.detach().float()``, ``.item()`` of Multitask/utils/deepspeed_utils.py:206-232) and results of arithmetic on it stay
-    ``EngineLoss``, but ``backward()`` raises: there is no autograd graph behind it (module docstring, DEVIATION)."""
+    """``outputs.loss`` of an EVAL-mode forward: the 0-dim fp32 device tensor the step's CE kernel wrote.  It behaves like any
+    tensor (``loss / k``, ``.detach().float()``, ``.item()`` of Multitask/utils/deepspeed_utils.py:283-293), results of arithmetic on
+    it stay ``EngineLoss``, and ``backward()`` raises: no activations were saved.  (The TRAINING-mode loss is an ordinary tensor
+    with a grad_fn: ``_HipStep`` below.)"""
 
     @staticmethod
     def __new__(cls, t):
         return torch.Tensor._make_subclass(cls, t.detach(), False)
 
     def backward(self, *args, **kwargs):
-        raise RuntimeError(ENGINE_ONLY_MSG)
+        raise RuntimeError(NO_GRAPH_MSG)
+
+
+class _HipStep(torch.autograd.Function):
+    """The autograd node behind ``outputs.loss``: forward = the loss the HIP step already computed; backward = the hand-scheduled HIP
+    backward of that step (``TasuModel.run_backward``: dgrad through the frozen decoder, wgrad of the projector / the adapters into
+    the flat fp32 bucket ``core.proj.g``), each leaf receiving ``grad_output x`` its slice of the bucket.  Nothing of the arithmetic
+    runs in torch; the Function only shuttles pointers (SURVEY 8b "Autograd glue")."""
+
+    @staticmethod
+    def forward(ctx, loss_dev, model, st, *leaves):
+        ctx.model, ctx.st = model, st
+        return loss_dev.detach().clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model, st = ctx.model, ctx.st
+        if model.last_state is not st:
+            raise RuntimeError("ps_slm_amd: loss.backward() of an OLDER step -- the activations of a forward pass live in the model's "
+                               "workspace until the next forward; differentiate each loss before running the next batch")
+        if getattr(st, "backward_ran", False):
+            raise RuntimeError("ps_slm_amd: this step's backward has already run (the workspace does not keep a graph for a second pass)")
+        model.core.run_backward(st)
+        st.backward_ran = True
+        model._masters_touched = True                   # an optimizer is about to write the masters: refresh the bf16 copies next forward
+        g = model.core.proj.g
+        scale = grad_out.to(g.dtype)
+        return (None, None, None) + tuple(v * scale for _, v in model._trainable_views(g))
 
 
 class CausalLMOutput:
@@ -319,6 +347,13 @@ class slam_model_asr:
         self.drop_prob, self.insert_prob, self.smooth_low, self.smooth_high = 0.05, 0.0, 0.0, 0.1
         self.training = True
         self.last_state = None
+        self._leaves = None                            # (key, [(name, leaf)]): named_parameters()
+        self._masters_touched = False                  # a foreign optimizer may have written the masters since the last refresh
+
+    def _refresh_if_touched(self):
+        if self._masters_touched:
+            self.core.sync_projector_copies()          # masters -> bf16 working copies + their transposes (TasuEngine.step() does this itself)
+            self._masters_touched = False
 
     # ---- nn.Module-like surface
     def train(self, mode=True):
@@ -332,13 +367,10 @@ class slam_model_asr:
     def to(self, *a, **k):
         return self
 
-    def named_parameters(self):
-        """The trainable tensors under the reference's names (``encoder_projector.*``; what
-        ``filter(lambda p: p.requires_grad, model.parameters())`` of Multitask/finetune_deepspeed.py:129 keeps): leaf views
-        of the flat fp32 master buffer (K padding sliced off where that is a plain column slice), ``requires_grad=True``.
-        They are containers: gradients live in ``core.proj.g`` and are written by the wgrad kernels, ``.grad`` stays None."""
+    def _views(self, flat):
+        """(name, view of ``flat``, trainable) for every tensor ``named_parameters()`` lists: ``flat`` is the fp32 master buffer or the
+        gradient bucket (same layout); K padding is sliced off where that is a plain column slice."""
         pr = self.core.proj
-        flat = pr.p.detach()
         for n in pr.names:
             v = pr.view(flat, n)
             r = pr.real[n]
@@ -346,10 +378,25 @@ class slam_model_asr:
                 v = v[: r[0]]
             elif v.dim() == 2 and len(r) == 2 and not (n == pr.n_w1 and pr.kin > 1):
                 v = v[:, : r[1]]
-            yield "encoder_projector." + n, v.requires_grad_(not self.core.freeze_projector)
+            yield "encoder_projector." + n, v, not self.core.freeze_projector
         if self.core.lora is not None:                 # use_peft=true: lora_A / lora_B of every adapted Linear, peft's key names
             for key, k in self.core.lora.names():
-                yield key, self.core.lora.view(flat, *k).requires_grad_(True)
+                yield key, self.core.lora.view(flat, *k), True
+
+    def _trainable_views(self, flat):
+        return [(n, v) for n, v, t in self._views(flat) if t]
+
+    def named_parameters(self):
+        """The trainable tensors under the reference's names (``encoder_projector.*``; what
+        ``filter(lambda p: p.requires_grad, model.parameters())`` of Multitask/finetune_deepspeed.py:129 keeps): leaf views
+        of the flat fp32 master buffer, ``requires_grad=True``, the SAME objects on every call (an optimizer built over them
+        updates the masters in place; ``loss.backward()`` fills their ``.grad`` from the gradient bucket: ``_HipStep``)."""
+        pr = self.core.proj
+        key = (pr.p.data_ptr(), pr.p.numel(), self.core.lora is not None, bool(self.core.freeze_projector))
+        if self._leaves is None or self._leaves[0] != key:
+            flat = pr.p.detach()
+            self._leaves = (key, [(n, v.requires_grad_(t)) for n, v, t in self._views(flat)])
+        return iter(self._leaves[1])
 
     def parameters(self):
         return (p for _, p in self.named_parameters())
@@ -416,6 +463,7 @@ class slam_model_asr:
     def forward(self, input_ids=None, input_features=None, attention_mask=None, input_feature_length=None, GT=None,
                 labels=None, **unused):
         core = self.core
+        self._refresh_if_touched()
         if self.gt_emb:
             ids_list = [self.encoder_tokenizer.encode(t) for t in GT]
             alphas = keeps = row_alphas = None
@@ -436,7 +484,12 @@ class slam_model_asr:
         if labels is None:
             return CausalLMOutput(None, core.logits_view(st)), -1
         res = st.dev["loss_out"]
-        return CausalLMOutput(EngineLoss(res[0]), core.logits_view(st)), (res[1] if self.metric else -1)
+        if self.training:
+            leaves = [p for _, p in self.named_parameters() if p.requires_grad]
+            loss = _HipStep.apply(res[0], self, st, *leaves)
+        else:
+            loss = EngineLoss(res[0])
+        return CausalLMOutput(loss, core.logits_view(st)), (res[1] if self.metric else -1)
 
     __call__ = forward
 
@@ -454,6 +507,7 @@ class slam_model_asr:
                  targets=None, **kwargs):
         from ps_slm_amd.decode import beam_search_generate
         core = self.core
+        self._refresh_if_touched()
         # the decode loop is HF beam search with do_sample=False (ps-slm.py:660-675 defaults): a sampling / penalty knob set to
         # anything else would silently be ignored, so it is rejected
         for name, default in (("do_sample", False), ("top_p", 1.0), ("repetition_penalty", 1.0), ("temperature", 1.0)):

@@ -71,39 +71,86 @@ def test_factory_surface_and_errors():
         model(**call)
 
 
-def test_foreign_engine_fails_loudly_not_silently():
-    """The stated deviation from the reference's model contract (ps_slm.py module docstring): the reference's
-    own train loop (Multitask/finetune_deepspeed.py:127-149, Multitask/utils/deepspeed_utils.py:205-236) filters
-    ``model.parameters()`` by ``requires_grad``, hands them to an optimizer and calls ``engine.backward(loss)`` -- here the
-    parameter list is the projector (non-empty, leaf tensors an optimizer accepts), the loss behaves like a tensor, and
-    the first backward raises a RuntimeError naming TasuEngine instead of stepping an optimizer over ``.grad is None``."""
+def test_reference_loop_body_trains_the_plugin_through_autograd():
+    """SURVEY 8b "Autograd glue" / VERDICT r5 item 6.  The reference's own loop (Multitask/finetune_deepspeed.py:127-149,
+    Multitask/utils/deepspeed_utils.py:205-236) filters ``model.parameters()`` by ``requires_grad``, hands them to an optimizer,
+    calls ``model(**batch)``, divides the loss and calls ``backward`` on it.  Here that works as it stands: ``outputs.loss`` is the
+    result of a torch.autograd.Function whose backward runs the hand-scheduled HIP backward once and hands each leaf its slice of
+    the flat gradient bucket.  ``torch.optim.AdamW`` over ``model.parameters()`` + ``loss.backward()`` reproduces TasuEngine's
+    update (same lr schedule, betas, eps, decay) step for step."""
     from ps_slm_amd.ps_slm import EngineLoss
-    model, _, eng = make()
+    model, _, _ = make(seed=77)
+    ref_model, _, eng = make(seed=77)
     named = dict(model.named_parameters())
     assert sorted(named) == sorted(model.state_dict())
     params = list(filter(lambda p: p.requires_grad, model.parameters()))
     assert len(params) == 6 and all(p.is_leaf for p in params)
+    assert all(a is b for a, b in zip(params, model.parameters()))              # the SAME leaves on every call
     assert sum(p.numel() for p in params) == model.core.proj.num_parameters()
     for k, v in model.state_dict().items():                  # views of the master buffer, reference shapes
         assert named[k].shape == v.shape and torch.equal(named[k].detach(), v)
-    opt = torch.optim.AdamW(params, lr=1e-3)                 # what a foreign engine would build: accepted ...
+    c = eng.cfg
+    opt = torch.optim.AdamW(params, lr=c["lr"], betas=tuple(c["betas"]), eps=c["eps"], weight_decay=c["weight_decay"])
+    geo = model.core.geo
+    eng.sched_iter = eng.cfg["warmup_num_steps"] + 5         # past the warm-up (the schedule's very first ratio is 0)
+    for step in range(4):
+        raw = synthetic_text_batch(geo, 2, seed=30 + step, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8, noise=False)
+        # the engine of this path
+        out_e, _ = eng(**to_call(raw))
+        lr = eng.get_lr()[0]                                 # the rate eng.step() is about to use
+        eng.backward(out_e.loss)
+        eng.step()
+        # the reference's loop body on the twin
+        for g in opt.param_groups:
+            g["lr"] = lr
+        out, acc = model(**to_call(raw))
+        assert out.loss.requires_grad and out.loss.grad_fn is not None and not isinstance(out.loss, EngineLoss)
+        assert float(out.loss.detach()) == pytest.approx(float(out_e.loss.detach()), rel=1e-5)
+        loss = out.loss / 2                                  # deepspeed_utils.py:210 (gradient_accumulation_steps = 2 there)
+        opt.zero_grad()
+        (loss * 2).backward()                                # ... whose factor the engine's 1/k would undo
+        assert all(p.grad is not None and p.grad.shape == p.shape for p in params)
+        for (n, p), (_, gv) in zip(model.named_parameters(), model._trainable_views(model.core.proj.g)):
+            assert torch.allclose(p.grad, gv, rtol=1e-6, atol=0), n        # .grad = the bucket's slice x the incoming gradient
+        opt.step()
+        sd, sd_e = model.state_dict(), ref_model.state_dict()
+        for k in sd:
+            assert torch.allclose(sd[k], sd_e[k], rtol=2e-5, atol=2e-7), (step, k)
+    # the optimizer wrote the masters behind the model's back: the next forward refreshed the bf16 working copies (the losses above
+    # agree step after step only if it did), and the masters are what state_dict() exports
+    # a second backward of the same step, or the backward of an older step, says what is wrong
+    out, _ = model(**to_call(raw))
+    out.loss.backward()
+    from ps_slm_amd.ps_slm import _HipStep
+    st = model.last_state
+    with pytest.raises(RuntimeError, match="already run"):
+        _HipStep.apply(st.dev["loss_out"][0], model, st, *params).backward()
+    old, _ = model(**to_call(raw))
+    model(**to_call(raw))
+    with pytest.raises(RuntimeError, match="OLDER step"):
+        old.loss.backward()
+    # the engine's fast path and the autograd path do not mix on one step
+    out3, _ = eng(**to_call(raw))
+    eng.backward(out3.loss)
+    with pytest.raises(RuntimeError, match="already run"):
+        out3.loss.backward()
+    eng.step()
+
+
+def test_eval_mode_loss_and_generate_knobs_fail_loudly():
+    """An eval-mode forward keeps no activations: its loss is an ``EngineLoss`` whose backward raises and says why (never a
+    silent no-op); generate() rejects sampling / penalty knobs other than the reference's defaults instead of ignoring them."""
+    from ps_slm_amd.ps_slm import EngineLoss
+    model, _, eng = make()
     raw = synthetic_text_batch(model.core.geo, 2, seed=3, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8, noise=False)
+    model.eval()
     out, acc = model(**to_call(raw))
-    loss = out.loss / 2                                      # deepspeed_utils.py:210
+    loss = out.loss / 2
     assert isinstance(out.loss, EngineLoss) and isinstance(loss, EngineLoss) and loss.dim() == 0
     assert math.isfinite(float(loss.detach().float())) and not loss.requires_grad
-    with pytest.raises(RuntimeError, match="TasuEngine"):    # ... and the first backward says which engine trains this model
+    with pytest.raises(RuntimeError, match="eval mode"):
         loss.backward()
-    with pytest.raises(RuntimeError, match="TasuEngine"):
-        out.loss.backward()
-    assert all(p.grad is None for p in params)
-    before = model.core.proj.p.clone()
-    opt.step()                                               # (a step over .grad None changes nothing: it must never get here silently)
-    assert torch.equal(before, model.core.proj.p)
-    out2, _ = eng(**to_call(raw))
-    eng.backward(out2.loss)                                  # the engine of this path takes the same loss object
-    eng.step()
-    # generate(): sampling / penalty knobs other than the reference's defaults are rejected, not ignored
+    model.train()
     for kw in (dict(do_sample=True), dict(top_p=0.9), dict(repetition_penalty=1.2), dict(temperature=0.7)):
         with pytest.raises(NotImplementedError, match=next(iter(kw))):
             model.generate(**to_call(raw), targets=["a"] * 2, **kw)
@@ -156,7 +203,7 @@ def test_engine_steps_match_oracle_adamw_and_schedule():
         out, acc = eng(**to_call(raw))
         eng.backward(out.loss)
         eng.step()
-        losses.append(float(out.loss))
+        losses.append(float(out.loss.detach()))
         o_out, grads = O.loss_and_projector_grads(sd, raw, gd, "bf16")
         assert abs(losses[-1] - float(o_out["loss"])) < 1e-2, step
         lr = O.lr_for_optimizer_step(step, 2e-3, warmup_num_steps=4)
@@ -232,8 +279,8 @@ def _dp_worker(rank, world, port, ret):
     assert sorted((lo, hi) for lo, hi, _ in eng._pending)[0][0] == 0
     assert sum(hi - lo for lo, hi, _ in eng._pending) == model.core.proj.numel   # the ranges tile the bucket
     eng.step()
-    ret[rank] = dict(loss=float(out.loss), grad=g_local, param=model.core.proj.p.clone(),
-                     reduced=eng.reduce_scalars(float(out.loss)), joined=eng.all_have_data(rank == 0))
+    ret[rank] = dict(loss=float(out.loss.detach()), grad=g_local, param=model.core.proj.p.clone(),
+                     reduced=eng.reduce_scalars(float(out.loss.detach())), joined=eng.all_have_data(rank == 0))
     dist.destroy_process_group()
 
 

@@ -508,6 +508,47 @@ def test_attention_bwd_gqa_kernel_equals_per_head_kernels(hip, fake, B, S, H, G,
     assert torch.equal(r0, r2)                                  # the policy: the GQA kernel wherever it is served
 
 
+@pytest.mark.parametrize("B,S,H,G", [(2, 100, 4, 2), (1, 19, 6, 2), (2, 130, 10, 2), (1, 70, 28, 4)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_bwd_ignores_stale_bits_in_the_padding_rows(hip, fake, B, S, H, G, causal):
+    """lse / delta are [B, H, Spad] buffers out of an uninitialised allocation (model.py ``_buf`` = torch.empty) and
+    only rows < S are ever written by the forward / tasu_attn_bwd_prep.  With NaN in every word beforehand (what an int -100
+    label word reads as in fp32), S % 64 != 0: the per-head kernels, the GQA kernel and the single-pass kernels must give finite
+    gradients, bit-identical to the run on zero-filled buffers."""
+    M, LD, Spad = B * S, (H + 2 * G) * HD, (S + 63) // 64 * 64
+    scale = HD ** -0.5
+    qkv = randn(M, LD, dtype=BF, seed=21).cuda()
+    km = make_mask(B, S, "right").cuda()
+    cos, sin = torch.zeros(M, 64).cuda(), torch.zeros(M, 64).cuda()
+    hip.rope_table(torch.arange(S, dtype=I32).repeat(B).cuda(), cos, sin, HD, 1e6)
+    dout = randn(M, H * HD, dtype=BF, seed=22).cuda()
+    dout.view(B, S, H * HD)[~km[:, :S].bool()] = 0
+    res = {}
+    for fill in (0.0, float("nan")):
+        out, lse = torch.zeros(M, H * HD, dtype=BF).cuda(), torch.full((B * H * Spad,), fill).cuda()
+        hip.attn_fwd(qkv, None, km, out, lse, B, S, H, G, scale, causal)
+        delta = torch.full((B * H * Spad,), fill).cuda()
+        hip.attn_bwd_prep(dout, out, delta, None, B, S, H)
+        assert torch.isfinite(delta).all()                      # the padding rows of delta are written (0), not skipped
+        for kernel in (1, 2):                                   # TASU_ATTN_KERNEL_PER_HEAD, _GQA
+            dqkv = torch.zeros(M, LD, dtype=BF).cuda()
+            dkp, dvp = torch.zeros(M, H * HD).cuda(), torch.zeros(M, H * HD).cuda()
+            delta_k = delta.clone()
+            delta_k.view(B, H, Spad)[..., S:] = fill            # a caller that never ran prep over the padding (older ABI behaviour)
+            hip.attn_bwd_rope(qkv, km, dout, lse, delta_k, cos, sin, dqkv, dkp, dvp, B, S, H, G, scale, causal, kernel)
+            res[(fill == 0.0, kernel)] = dqkv
+        if hip.lib.tasu_attn_sp_supported(S, H, G) == 1:
+            dqkv = torch.zeros(M, LD, dtype=BF).cuda()
+            dkp, dvp = torch.zeros(M, H * HD).cuda(), torch.zeros(M, H * HD).cuda()
+            hip.attn_bwd_fused(qkv, km, dout, out, lse, torch.full((B * H * Spad,), fill).cuda(), cos, sin, dqkv, dkp, dvp, B, S, H, G,
+                               scale, causal, "sp")
+            res[(fill == 0.0, 3)] = dqkv
+    torch.cuda.synchronize()
+    for (clean, kernel), g in res.items():
+        assert torch.isfinite(g.float()).all(), (clean, kernel)
+        assert torch.equal(g, res[(True, kernel)]), kernel
+
+
 @pytest.mark.parametrize("B,S,H,G", [(2, 100, 4, 2), (2, 256, 12, 2), (3, 64, 2, 1), (1, 192, 4, 4), (1, 19, 6, 2), (2, 130, 10, 2),
                                      (1, 256, 28, 4), (2, 249, 12, 2), (16, 256, 12, 2)])
 @pytest.mark.parametrize("mask_kind", ["right", "left", "none"])

@@ -209,7 +209,7 @@ def test_lora_engine_steps_and_checkpoint_roundtrip(tmp_path):
     losses = []
     for step in range(6):
         out, _ = eng(**to_call(raw))
-        losses.append(float(out.loss))
+        losses.append(float(out.loss.detach()))
         eng.backward(out.loss)
         eng.step()
         now = lp.state_dict()
@@ -250,7 +250,7 @@ def test_lora_engine_steps_and_checkpoint_roundtrip(tmp_path):
     model.eval(), m2.eval()
     o1, _ = model(**to_call(raw))
     o2, _ = m2(**to_call(raw))
-    assert float(o1.loss) == float(o2.loss)
+    assert float(o1.loss.detach()) == float(o2.loss.detach())
     # a projector-only checkpoint loads into the adapted model with the adapters reported missing (strict=False), and is refused strictly
     proj_only = {k: v for k, v in sd.items() if k.startswith("encoder_projector.")}
     missing, unexpected = m2.load_state_dict(proj_only)

@@ -61,4 +61,4 @@ else:
     dt = (time.perf_counter() - t0) / n
     st = eng._last_state
     print(json.dumps({"what": "audio_sft_step", "B": B, "encoder_frames": 504, "psd_audio_tokens_mean": float(np.mean(st.dev["psd_lens"])),
-                      "S": st.S, "ms_per_step": round(dt * 1e3, 2), "utt_per_s": round(B / dt, 1), "loss": float(out.loss)}))
+                      "S": st.S, "ms_per_step": round(dt * 1e3, 2), "utt_per_s": round(B / dt, 1), "loss": float(out.loss.detach())}))
