@@ -8,11 +8,12 @@
  * every declaration.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
  *
  * TRAINING CONTRACT.  These entry points are forward AND backward kernels called in a hand-scheduled order by
- * ps_slm_amd.model.TasuModel; no autograd graph exists across this boundary.  The reference's loop
- * (Multitask/finetune_deepspeed.py:127-149, Multitask/utils/deepspeed_utils.py:205-236: `deepspeed.initialize` over
- * `model.parameters()`, `engine.backward(loss)`, `engine.step()`) therefore cannot train the plugin: the engine that does is
- * ps_slm_amd.engine.TasuEngine (same backward / step surface; tasu_adamw + tasu_comm_* / tasu_allreduce_f32 below).  A foreign
- * engine's first `loss.backward()` raises a RuntimeError naming TasuEngine (tests/test_engine_cpu.py).
+ * ps_slm_amd.model.TasuModel; no torch operator runs across this boundary.  The reference's loop
+ * (Multitask/finetune_deepspeed.py:127-149, Multitask/utils/deepspeed_utils.py:205-236: an optimizer / `deepspeed.initialize` over
+ * `model.parameters()`, `engine.backward(loss)`, `engine.step()`) reaches them through ONE autograd node: `outputs.loss` is the result
+ * of ps_slm_amd.ps_slm._HipStep, whose backward runs the whole hand-scheduled backward and hands the trainable leaves their slices of
+ * the flat gradient bucket (tests/test_engine_cpu.py, tests/test_gpu_engine.py).  ps_slm_amd.engine.TasuEngine (same backward / step
+ * surface; tasu_adamw + tasu_comm_* / tasu_allreduce_f32 below) is the fast path: overlapped RCCL exchange, fused AdamW.
  *
  * Conventions
  *   - plain pointers + sizes only; every pointer is DEVICE memory unless stated; no ownership transfer;

@@ -365,6 +365,39 @@ def qwen2_hidden(W, emb, mask, position_ids, n_heads, n_kv, theta=1e6, mode="fp3
     return (x, kvs) if return_kv else x
 
 
+def qwen2_hidden_step(W, x, kvs, key_mask, position_ids, n_heads, n_kv, theta=1e6, mode="fp32", pre="llm."):
+    """One decode position with a KV cache -- what HF ``generate`` runs per step (``use_cache=True`` is transformers' default; the
+    reference's call, Multitask/model/ps-slm.py:660-675, does not turn it off): x [R, 1, D] is the new token's embedding,
+    ``kvs[l] = (k, v)`` the rotated keys / values of the earlier positions [R, n_kv, T, hd], ``key_mask`` [R, T + 1] (prompt padding
+    + the new position), ``position_ids`` [R, 1].  Same arithmetic per row as ``qwen2_hidden``'s last position.  Returns
+    (hidden [R, 1, D], the extended cache)."""
+    R = x.shape[0]
+    hd = W[pre + "model.layers.0.self_attn.q_proj.weight"].shape[0] // n_heads
+    cos, sin = rope_tables(position_ids, hd, theta)
+    allow = key_mask.bool()[:, None, None, :]
+    rep = n_heads // n_kv
+    out = []
+    for l in range(qwen2_geometry(W, pre)):
+        p = f"{pre}model.layers.{l}."
+        h = rms_norm(x, W[p + "input_layernorm.weight"])
+        q = linear(h, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"], mode)
+        k = linear(h, W[p + "self_attn.k_proj.weight"], W[p + "self_attn.k_proj.bias"], mode)
+        v = linear(h, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"], mode)
+        q = rbf(apply_rope(q.view(R, 1, n_heads, hd).transpose(1, 2), cos, sin), mode)
+        k = torch.cat([kvs[l][0], rbf(apply_rope(k.view(R, 1, n_kv, hd).transpose(1, 2), cos, sin), mode)], 2)
+        v = torch.cat([kvs[l][1], v.view(R, 1, n_kv, hd).transpose(1, 2)], 2)
+        out.append((k, v))
+        sc = (q @ k.repeat_interleave(rep, dim=1).transpose(-1, -2)) * hd ** (-0.5)
+        pr = torch.softmax(sc.masked_fill(~allow, float("-inf")), dim=-1)
+        a = rbf(rbf(pr, mode) @ v.repeat_interleave(rep, dim=1), mode).transpose(1, 2).reshape(R, 1, n_heads * hd)
+        x = x + linear(a, W[p + "self_attn.o_proj.weight"], None, mode)
+        h = rms_norm(x, W[p + "post_attention_layernorm.weight"])
+        g = linear(h, W[p + "mlp.gate_proj.weight"], None, mode)
+        u = linear(h, W[p + "mlp.up_proj.weight"], None, mode)
+        x = x + linear(rbf(rbf(F.silu(g), mode) * u, mode), W[p + "mlp.down_proj.weight"], None, mode)
+    return rms_norm(x, W[pre + "model.norm.weight"]), out
+
+
 def lm_head_weight(W, pre="llm."):
     return W[pre + "lm_head.weight"] if (pre + "lm_head.weight") in W else W[pre + "model.embed_tokens.weight"]
 
@@ -487,14 +520,17 @@ def bf16_ulp_jitter(seed, prob=0.15):
 
 def beam_search_generate(W, emb, mask, geo, num_beams=4, max_new_tokens=200, min_length=1, length_penalty=1.0,
                          eos_token_id=None, pad_token_id=None, mode="fp32", logit_jitter=None, logits_trace=None,
-                         logits_replay=None):
+                         logits_replay=None, kv_cache=False, step_times=None):
     """slam_model_asr.generate's decode loop (Multitask/model/ps-slm.py:660-675): HF ``generate(inputs_embeds=...,
     num_beams=4, do_sample=False, early_stopping=False)`` restated (transformers generation/utils.py ``_beam_search``,
     un-vendored dependency): every step keeps the 2*num_beams best continuations, the first num_beams non-finished
     ones keep running, finished ones (EOS or max length) among the top num_beams compete for the num_beams result
     slots with score / (generated_length ** length_penalty); the loop ends when no running beam can beat the worst
-    kept result (heuristic on the current length) or every continuation hit a stopping criterion.  No KV cache here:
-    the whole sequence is re-run every step (CPU oracle, tiny sizes).  Returns new tokens only, [B, n_new].
+    kept result (heuristic on the current length) or every continuation hit a stopping criterion.  By default the whole
+    sequence is re-run every step (the parity fixtures: tiny sizes, one code path for the network); ``kv_cache=True`` runs the
+    prompt once and then ``qwen2_hidden_step`` per position on a cache that follows the beams (what HF generate does: the CPU
+    baseline of bench.py times this form; ``step_times``, a list, receives the wall-clock time after every position's network
+    pass).  Returns new tokens only, [B, n_new].
 
     ``logit_jitter`` (optional callable logits -> logits) perturbs every step's logits; the fixture generator
     oracle/make_golden_generate_margin.py uses it to keep only decode cases whose tokens survive random one-ulp flips of the
@@ -528,12 +564,28 @@ def beam_search_generate(W, emb, mask, geo, num_beams=4, max_new_tokens=200, min
             if cur >= len(logits_replay) or not torch.equal(logits_replay[cur][1], toks):
                 return None
             logits = logits_replay[cur][0].clone()
+        elif kv_cache:
+            m = torch.cat([mask_b.bool(), torch.ones(B * nb, cur, dtype=torch.bool)], 1)
+            if cur == 0:
+                pos = (m.long().cumsum(-1) - 1).masked_fill(~m, 1)
+                hid, cache = qwen2_hidden(W, emb_b, m, pos, geo["llm_heads"], geo["llm_kv_heads"], geo.get("rope_theta", 1e6), mode,
+                                          return_kv=True)
+            else:
+                rows = (torch.arange(B)[:, None] * nb + parents).view(-1)          # the cache follows the beams
+                cache = [(k[rows], v[rows]) for k, v in cache]
+                pos = m.long().sum(-1, keepdim=True) - 1
+                hid, cache = qwen2_hidden_step(W, table[toks[:, -1:]], cache, m, pos, geo["llm_heads"], geo["llm_kv_heads"],
+                                               geo.get("rope_theta", 1e6), mode)
+            logits = linear(hid[:, -1], lm_head_weight(W), None, mode).float()
         else:
             x = torch.cat([emb_b, table[toks]], 1)
             m = torch.cat([mask_b.bool(), torch.ones(B * nb, cur, dtype=torch.bool)], 1)
             pos = (m.long().cumsum(-1) - 1).masked_fill(~m, 1)
             hid = qwen2_hidden(W, x, m, pos, geo["llm_heads"], geo["llm_kv_heads"], geo.get("rope_theta", 1e6), mode)
             logits = linear(hid[:, -1], lm_head_weight(W), None, mode).float()
+        if step_times is not None:
+            import time
+            step_times.append(time.perf_counter())
         if logits_trace is not None:
             logits_trace.append((logits.clone(), toks.clone()))
         if logit_jitter is not None:
@@ -552,6 +604,7 @@ def beam_search_generate(W, emb, mask, geo, num_beams=4, max_new_tokens=200, min
         nxt = torch.topk(run_lp, nb)[1]
         run_seq = torch.gather(cand, 1, nxt[:, :, None].expand(-1, -1, max_new_tokens))
         run_scores = torch.gather(run_lp, 1, nxt)
+        parents = torch.gather(beam_ix, 1, nxt)                  # the beam each running hypothesis continues (kv_cache)
         # finished beams
         just = stop & top_mask[None]
         sc = top_lp / ((cur + 1) ** length_penalty)

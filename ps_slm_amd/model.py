@@ -335,6 +335,67 @@ class LLMWeights:
         self.set_embed(emb, emb if geo.tied else rn(geo.llm_vocab, D), ones)
 
 
+class UploadPack:
+    """The step's small host -> device inputs (merge plan, labels, masks, pseudo-posterior ids: 14 arrays, < 1 MB) as ONE
+    asynchronous copy.  Every name owns a fixed slot of one device buffer (stable addresses: captured hipGraphs keep reading them);
+    ``put`` writes the array into the same offset of a PINNED host buffer, ``flush`` issues one H2D copy per run of adjacent slots
+    on the current stream.  Round-6 trace of the graph-replayed step (tools/trace_gaps.py): the 14 per-array copies out of pageable
+    memory were synchronous -- the host waited for the stream to drain, then paid ~32 us per copy with the GPU idle: 0.48 ms of a
+    28.4-ms step.  The pinned buffers form a ring: a buffer is rewritten only after the copy that last read it has completed."""
+    RING = 4
+
+    def __init__(self, model, capacity=32 << 20):
+        self.model, self.cap = model, capacity
+        self.dev = torch.empty(capacity, dtype=torch.uint8, device=model.device)
+        self.host = [torch.empty(capacity, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+        self.done = [None] * self.RING
+        self.cur, self.open, self.end = 0, False, 0
+        self.slots = {}                                  # name -> (offset, capacity in bytes)
+        self.pending = []                                # (offset, bytes, slot capacity) since the last flush
+
+    def put(self, name, arr):
+        arr = np.ascontiguousarray(arr)
+        t = torch.from_numpy(arr)
+        nb = arr.nbytes
+        if nb == 0:
+            return torch.empty(arr.shape, dtype=t.dtype, device=self.model.device)
+        slot = self.slots.get(name)
+        if slot is None or slot[1] < nb:
+            cap = rup(nb if slot is None else 2 * nb, 256)
+            if self.end + cap > self.cap:
+                raise RuntimeError(f"UploadPack: {self.end + cap} bytes of step inputs exceed the {self.cap}-byte pack")
+            if slot is not None:
+                self.model._buf_gen += 1                 # the name moved: graphs captured on the old address are dead
+            slot = self.slots[name] = (self.end, cap)
+            self.end += cap
+        if not self.open:                                # first array since the last flush: the next pinned buffer of the ring
+            self.cur = (self.cur + 1) % self.RING
+            if self.done[self.cur] is not None:
+                self.done[self.cur].synchronize()        # (four flushes ago: long complete)
+            self.open = True
+        off = slot[0]
+        self.host[self.cur][off:off + nb].numpy()[:] = arr.reshape(-1).view(np.uint8)
+        self.pending.append((off, nb, slot[1]))
+        return self.dev[off:off + nb].view(t.dtype).view(arr.shape)
+
+    def flush(self):
+        if not self.pending:
+            return
+        runs = []
+        for off, nb, cap in sorted(self.pending):
+            if runs and runs[-1][2] == off:              # begins where the previous array's SLOT ends: one copy covers both
+                runs[-1] = (runs[-1][0], off + nb, off + cap)
+            else:
+                runs.append((off, off + nb, off + cap))
+        h = self.host[self.cur]
+        for lo, hi, _ in runs:
+            self.dev[lo:hi].copy_(h[lo:hi], non_blocking=True)
+        ev = self.done[self.cur] or torch.cuda.Event()
+        ev.record()
+        self.done[self.cur] = ev
+        self.pending, self.open = [], False
+
+
 @dataclass
 class StepState:
     """Everything one training step needs between forward and backward (device tensors + the host plan)."""
@@ -362,6 +423,7 @@ class TasuModel:
         self.encoder = None            # ps_slm_amd.encoder.EncoderWeights (audio path)
         self.keep_logits = keep_logits
         self._ws = {}
+        self._pack = None               # UploadPack: the step's host -> device inputs (created on the first upload on a GPU)
         self.training = True
         # hipGraph replay of the (shape-static) forward / backward launch sequences: ~700 launches per step collapse
         # into two graph launches.  Keyed by the shapes baked into kernel arguments; the first call of a key runs
@@ -562,9 +624,12 @@ class TasuModel:
             elif alphas is not None:
                 pal[u * Lmax: u * Lmax + n] = float(alphas[u])
         st = self._finish_prepare(input_ids, attention_mask, labels, lens // kk, Lmax // kk)
-        st.dev["post_ids"] = self._upload("post_ids", pid)
-        st.dev["post_alpha"] = self._upload("post_alpha", pal)
+        st.dev["post_ids"] = self._upload("post_ids", pid, flush=False)
+        st.dev["post_alpha"] = self._upload("post_alpha", pal, flush=False)
         st.Ra, st.Rap, st.Fap = Fa // kk, Fap // kk, Fap
+        if labels is not None and not self.freeze_projector:
+            self._pad_rows(st, flush=False)              # (the projector backward's row index travels with the rest)
+        self._flush_uploads()                            # ONE H2D copy for the step's integer inputs
         return st
 
     def prepare_audio(self, input_ids, attention_mask, labels, input_features, input_feature_length, do_psd=True) -> StepState:
@@ -590,6 +655,9 @@ class TasuModel:
         st.Fap = rows.shape[0]
         st.Ra, st.Rap = B * Lmax // kk, st.Fap // kk
         st.path = "audio"
+        if labels is not None and not self.freeze_projector:
+            self._pad_rows(st, flush=False)
+        self._flush_uploads()
         st.dev["post"] = rows
         st.dev["psd_lens"] = new_lens
         self._projector_from_posterior(st)
@@ -642,11 +710,25 @@ class TasuModel:
         self._enc_ahead = dict(feats=input_features, version=input_features._version, lens=lens, post=post, Te=Te, ready=ready)
         return True
 
-    def _upload(self, name, arr):
-        t = torch.from_numpy(np.ascontiguousarray(arr))
-        d = self._buf("in_" + name, t.shape, t.dtype)
-        d.copy_(t, non_blocking=True)
+    def _upload(self, name, arr, flush=True):
+        """Host array -> its named device buffer (valid until the next upload under that name).  On the GPU through the pinned
+        pack (UploadPack); ``flush=False`` defers the copy to the next ``_flush_uploads()`` (the prepare_* functions batch the
+        step's 14 arrays into one copy)."""
+        if self.device.type != "cuda" or os.environ.get("TASU_UPLOAD_PACK", "1") == "0":     # (=0: the per-array copies, for A/B runs)
+            t = torch.from_numpy(np.ascontiguousarray(arr))
+            d = self._buf("in_" + name, t.shape, t.dtype)
+            d.copy_(t, non_blocking=True)
+            return d
+        if self._pack is None:
+            self._pack = UploadPack(self)
+        d = self._pack.put(name, arr)
+        if flush:
+            self._pack.flush()
         return d
+
+    def _flush_uploads(self):
+        if self._pack is not None:
+            self._pack.flush()
 
     def _finish_prepare(self, input_ids, attention_mask, labels, num_audio, Lmax) -> StepState:
         to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
@@ -665,13 +747,13 @@ class TasuModel:
                 lab_np = np.concatenate([lab_np, np.full((B0, extra), -100, dtype=lab_np.dtype)], 1)
         plan = build_merge_plan(ids_np, am_np, lab_np, num_audio, self.geo.speech_id, Lmax)
         st = StepState(plan=plan, B=plan.B, S=plan.S, M=plan.B * plan.S)
-        st.dev["kind"] = self._upload("kind", plan.src_kind)
-        st.dev["idx"] = self._upload("idx", plan.src_idx)
-        st.dev["key_mask"] = self._upload("key_mask", plan.key_mask)
-        st.dev["pos"] = self._upload("pos", plan.position_ids)
-        st.dev["shift_labels"] = self._upload("shift_labels", plan.shift_labels)
-        st.dev["audio_rows"] = self._upload("audio_rows", plan.audio_rows)
-        st.dev["inv_count"] = self._upload("inv_count", np.array([1.0 / max(plan.count, 1)], dtype=np.float32))
+        st.dev["kind"] = self._upload("kind", plan.src_kind, flush=False)
+        st.dev["idx"] = self._upload("idx", plan.src_idx, flush=False)
+        st.dev["key_mask"] = self._upload("key_mask", plan.key_mask, flush=False)
+        st.dev["pos"] = self._upload("pos", plan.position_ids, flush=False)
+        st.dev["shift_labels"] = self._upload("shift_labels", plan.shift_labels, flush=False)
+        st.dev["audio_rows"] = self._upload("audio_rows", plan.audio_rows, flush=False)
+        st.dev["inv_count"] = self._upload("inv_count", np.array([1.0 / max(plan.count, 1)], dtype=np.float32), flush=False)
         if labels is not None:
             # compact index of the labelled positions: the training step's lm_head, CE and lm_head dgrad only run over these
             # rows (forward_llm, "labelled rows"); rows -> positions, slot = the inverse map, labels in compact order
@@ -684,10 +766,10 @@ class TasuModel:
             lab_c[: st.nL] = sl[rows]
             slot = np.full(st.M, -1, dtype=np.int32)
             slot[rows] = np.arange(st.nL, dtype=np.int32)
-            st.dev["lab_rows"] = self._upload("lab_rows", lab_rows)
-            st.dev["lab_rows0"] = self._upload("lab_rows0", np.maximum(lab_rows, 0))      # padding slots read row 0 (their results are ignored)
-            st.dev["lab_compact"] = self._upload("lab_compact", lab_c)
-            st.dev["lab_slot"] = self._upload("lab_slot", slot)
+            st.dev["lab_rows"] = self._upload("lab_rows", lab_rows, flush=False)
+            st.dev["lab_rows0"] = self._upload("lab_rows0", np.maximum(lab_rows, 0))      # padding slots read row 0 (their results are ignored, flush=False)
+            st.dev["lab_compact"] = self._upload("lab_compact", lab_c, flush=False)
+            st.dev["lab_slot"] = self._upload("lab_slot", slot, flush=False)
         return st
 
     # ------------------------------------------------------------------------------------------ forward
@@ -1091,14 +1173,15 @@ class TasuModel:
         if on_ready is not None:
             on_ready(*ranges[-1])
 
-    def _pad_rows(self, st):
+    def _pad_rows(self, st, flush=True):
         rows = np.full(st.Rap, -1, dtype=np.int32)
         rows[: st.Ra] = st.plan.audio_rows
-        st.dev["audio_rows_pad"] = self._upload("audio_rows_pad", rows)
+        st.dev["audio_rows_pad"] = self._upload("audio_rows_pad", rows, flush=flush)
         return st.dev["audio_rows_pad"]
 
     # ------------------------------------------------------------------------------------------ hipGraph replay
     def _graphed(self, key, fn, st):
+        self._flush_uploads()                           # (no-op unless a caller deferred an upload and forgot it)
         if not (self.use_graphs and self.device.type == "cuda"):
             return fn()
         g = self._graphs.get(key)

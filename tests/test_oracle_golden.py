@@ -302,9 +302,12 @@ def test_psd_random_batches_vs_reference():
         close(out, z[f"c{n}_out"], rtol=1e-6, atol=1e-7)
 
 
-def test_generate_random_cases_vs_reference(geo, tiny_weights):
+@pytest.mark.parametrize("kv_cache", [False, True])
+def test_generate_random_cases_vs_reference(geo, tiny_weights, kv_cache):
     """14 decode cases of the REAL reference's generate() (oracle/make_golden_generate.py): 1-3 left-padded utterances,
-    1-4 beams, several max_new_tokens / min_length / length_penalty settings -- token ids must be identical."""
+    1-4 beams, several max_new_tokens / min_length / length_penalty settings -- token ids must be identical, for the oracle's
+    whole-sequence form and for its KV-cache form (``qwen2_hidden_step`` on a cache that follows the beams: what HF generate runs,
+    and what bench.py's CPU decode baseline times)."""
     from conftest import split_flat
     z = load_npz("generate_random")
     for n in range(int(z["n_cases"])):
@@ -315,7 +318,7 @@ def test_generate_random_cases_vs_reference(geo, tiny_weights):
         proj = O.projector(tiny_weights, post)
         emb, mask, _, _ = O.merge(proj, plen, tiny_weights["llm.model.embed_tokens.weight"][ids], ids, am, None, geo["speech_id"])
         toks = O.beam_search_generate(tiny_weights, emb, mask, geo, num_beams=nb, max_new_tokens=new, min_length=min_len,
-                                      length_penalty=float(z[f"c{n}_length_penalty"]))
+                                      length_penalty=float(z[f"c{n}_length_penalty"]), kv_cache=kv_cache)
         assert np.array_equal(toks.numpy(), z[f"c{n}_tokens"]), (n, toks, z[f"c{n}_tokens"])
 
 
@@ -335,6 +338,9 @@ def test_generate_margin_cases_vs_reference(mode):
                                   c["am"], None, geo.speech_id)
         toks = O.beam_search_generate(sd, emb.detach(), mask, gd, mode=mode, **c["kw"])
         assert np.array_equal(toks.numpy(), c["tokens"]), (n, toks, c["tokens"])
+        if n < 4:                                               # ... and the KV-cache form on the first cases
+            toks = O.beam_search_generate(sd, emb.detach(), mask, gd, mode=mode, kv_cache=True, **c["kw"])
+            assert np.array_equal(toks.numpy(), c["tokens"]), (n, toks, c["tokens"])
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
