@@ -339,9 +339,12 @@ class UploadPack:
     """The step's small host -> device inputs (merge plan, labels, masks, pseudo-posterior ids: 14 arrays, < 1 MB) as ONE
     asynchronous copy.  Every name owns a fixed slot of one device buffer (stable addresses: captured hipGraphs keep reading them);
     ``put`` writes the array into the same offset of a PINNED host buffer, ``flush`` issues one H2D copy per run of adjacent slots
-    on the current stream.  Round-6 trace of the graph-replayed step (tools/trace_gaps.py): the 14 per-array copies out of pageable
-    memory were synchronous -- the host waited for the stream to drain, then paid ~32 us per copy with the GPU idle: 0.48 ms of a
-    28.4-ms step.  The pinned buffers form a ring: a buffer is rewritten only after the copy that last read it has completed."""
+    on the current stream, with no host synchronisation (a copy out of pageable memory makes the host wait for the stream to
+    drain: the host could never run ahead of the device, e.g. to collate the next batch).  MEASURED: under rocprofv3 the 14
+    per-array copies showed up as 0.48 ms of idle GPU per 28.4-ms step (tools/trace_gaps.py), but that is the profiler's own
+    serialisation -- without it the step time is the same either way (alternating processes on one box, tools/ab_env.sh
+    TASU_UPLOAD_PACK 0 1: 28.12 / 28.06 / 28.14 against 28.07 / 28.18 / 28.11 ms).  Kept for the host-side property only.
+    The pinned buffers form a ring: a buffer is rewritten only after the copy that last read it has completed."""
     RING = 4
 
     def __init__(self, model, capacity=32 << 20):
