@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 12
+#define TASU_ABI_VERSION 13
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -625,6 +625,45 @@ int tasu_comm_library(char* out, int n);                         /* HOST string:
 int tasu_comm_count(void* comm, int* count);                     /* ncclCommCount: ranks RCCL itself sees in the communicator */
 int tasu_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
 int tasu_allreduce_min_i32(void* comm, int32_t* buf, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------ fp32 arithmetic mode (decode)
+ * train_config.use_fp16 = false: the reference decodes with fp32 weights and no autocast (Multitask/inference_batch.py:113-117,146:
+ * `model.eval()`, no `.half()`, `model.generate(**batch)`; Multitask/model/ps-slm.py:660-675 -> HF generate on the fp32 Qwen2).
+ * Every pointer below is fp32 device memory; nothing is rounded to bf16 (csrc/fp32.hip).  These replace, for that mode, the spans
+ * of the bf16 entry points above: projector Linears (Multitask/model/projector.py:128-151), Qwen2DecoderLayer.forward
+ * (transformers modeling_qwen2.py:41-48 RMSNorm, :91-135 RoPE, :150-172 attention, Qwen2MLP), lm_head + log_softmax + top-k of
+ * GenerationMixin._beam_search.  The KV cache has the layout of tasu_kv_fill (rows = beams, position-major, fp32) and shares
+ * tasu_kv_index_init / tasu_kv_index_reorder, tasu_rope_table, tasu_embed_rows, tasu_beam_update with the bf16 path.
+ *
+ * tasu_f32_gemm_nt: C[M, N] = [resid +] act(A[M, K] . W[N, K]^T + bias), act 0 = none, 1 = SiLU (x / (1 + exp(-x)));
+ * v_mfma_f32_16x16x4_f32, K % 16 == 0, lda / ldw % 4 == 0, 16-byte aligned operands; resid may alias C.  With a workspace,
+ * outputs of fewer than 128 tiles of 64 x 64 are computed as up to 16 K-range slabs (ksplit * M * N floats) summed in ascending
+ * order by a second launch -- deterministic.                                                                                     */
+int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
+                     int M, int N, int K, int act, float* workspace, int64_t workspace_floats, void* stream);
+/* y = w * (x * rsqrt(mean(x^2) + eps)) per row of x [M, D] */
+int tasu_f32_rmsnorm(const float* x, const float* w, float* y, int M, int D, float eps, void* stream);
+/* q and k heads of qkv [M, (H+2G)*128] rotated in place (tables [M, 64] of tasu_rope_table; x*cos + rotate_half(x)*sin with the two
+ * products rounded separately like torch eager); kcache != NULL: the rotated k and the v of row m also go to cache[m, slot[m]].  */
+int tasu_f32_rope(float* qkv, const float* cos_tab, const float* sin_tab, int M, int H, int G, float* kcache, float* vcache,
+                  const int32_t* slot, int ctx, void* stream);
+/* K / V of a (rotated) prefill activation [B*S, (H+2G)*128] -> cache row b * n_beams, positions 0 .. S-1 (cache [B*n_beams, ctx, G*128]) */
+int tasu_f32_kv_fill(const float* qkv, float* kcache, float* vcache, int B, int S, int H, int G, int n_beams, int ctx, void* stream);
+/* causal GQA attention of the prompt: query s of batch row b attends keys [kstart[b], s] (left padding masked; rows s < kstart[b]
+ * get zeros); out [B*S, H*128].  S <= 2048.                                                                                      */
+int tasu_f32_attn_prefill(const float* qkv, const int32_t* kstart, float* out, int B, int S, int H, int G, float scale, void* stream);
+/* single-token GQA attention over the fp32 cache: semantics of tasu_attn_decode (row_index required); out [M, H*128]; ctx <= 2048 */
+int tasu_f32_attn_decode(const float* qkv, const float* kcache, const float* vcache, const int32_t* row_index, const int32_t* kstart,
+                         const int32_t* lens, float* out, int M, int H, int G, int ctx, float scale, void* stream);
+/* act[M, I] = silu(gu[:, :I]) * gu[:, I:] */
+int tasu_f32_swiglu(const float* gu, float* act, int M, int I, void* stream);
+/* tasu_embed_merge_fwd with an fp32 projector output proj [*, ldp] */
+int tasu_f32_embed_merge(const float* table, const float* proj, int ldp, const int32_t* src_kind, const int32_t* src_idx, float* x,
+                         int M, int D, void* stream);
+/* tasu_logprob_topk on fp32 logits: out_val = (x - max) - log(sum exp(x - max)) of the k best selectable columns (value descending,
+ * column ascending), k <= 16; fewer than k selectable columns: (-inf, 0x7fffffff).                                               */
+int tasu_f32_logprob_topk(const float* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned, float* out_val,
+                          int32_t* out_idx, void* stream);
 
 /* ------------------------------------------------------------------------------------------ FLAC (host)
  * The reference reads ``.flac`` entries with torchaudio.load (speech_dataset_large.py:123-127: [C, T] float

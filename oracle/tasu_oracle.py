@@ -541,6 +541,12 @@ def beam_search_generate(W, emb, mask, geo, num_beams=4, max_new_tokens=200, min
     trajectory has already shown the case to be unstable."""
     B, S, D = emb.shape
     nb, V = num_beams, lm_head_weight(W).shape[0]
+    # HF counts ``min_length`` INCLUDING the prompt, and under ``inputs_embeds`` subtracts the embedded prompt's length from it
+    # (transformers generation/utils.py GenerationMixin._prepare_generated_length: ``min_length = max(min_length -
+    # inputs_tensor.shape[1], 0)``; the reference passes inputs_embeds + min_length, ps-slm.py:660-668): EOS is banned only for
+    # the first max(min_length - S, 0) generated positions -- with the reference's default min_length = 1 never.  (Pinned by
+    # tests/golden/mid_generate_fp32.npz; rounds 1-5 banned the first min_length positions.)
+    min_length = max(int(min_length) - S, 0)
     eos = geo["eos_id"] if eos_token_id is None else eos_token_id
     pad = eos if pad_token_id is None else pad_token_id
     K = 2 * nb

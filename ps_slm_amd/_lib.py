@@ -128,9 +128,19 @@ PROTOTYPES.update({
     "tasu_comm_count": [vp, vp],
     "tasu_allreduce_f32": [vp, vp, i64, vp],
     "tasu_allreduce_min_i32": [vp, vp, i64, vp],
+    # fp32 arithmetic mode of the decode path (csrc/fp32.hip)
+    "tasu_f32_gemm_nt": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
+    "tasu_f32_rmsnorm": [vp, vp, vp, i32, i32, f32, vp],
+    "tasu_f32_rope": [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp],
+    "tasu_f32_kv_fill": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tasu_f32_attn_prefill": [vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "tasu_f32_attn_decode": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "tasu_f32_swiglu": [vp, vp, i32, i32, vp],
+    "tasu_f32_embed_merge": [vp, vp, i32, vp, vp, vp, i32, i32, vp],
+    "tasu_f32_logprob_topk": [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp],
 })
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 

@@ -1,0 +1,427 @@
+// fp32 arithmetic mode of the decode path (train_config.use_fp16 = false at inference: the reference loads the LLM and the
+// projector in fp32 and calls HF generate without autocast -- Multitask/inference_batch.py:113-117,146, Multitask/model/ps-slm.py:660-675).
+// Every tensor here is fp32: weights, residual stream, q|k|v, KV cache, logits.  The step is HBM-bound on the fp32 weights
+// (6.2 GB per generated position at Qwen2.5-1.5B), so the kernels are simple: one tiled MFMA GEMM
+// (v_mfma_f32_16x16x4_f32, fp32 products and accumulation) with deterministic K-range slabs for the narrow projections, and
+// wave-per-row VALU kernels for the rest.  Summation orders differ from the reference's CPU BLAS; nothing is rounded to bf16.
+#include "common.h"
+#include "../../include/tasu_hip.h"
+
+namespace tasu_f32 {
+
+constexpr int HD = 128;
+constexpr int BM = 64, BN = 64, BK = 16, LDS_LD = BK + 1;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float silu_exact(float x) { return x / (1.f + expf(-x)); }
+
+// C[m, n] (+)= sum_k A[m, k] W[n, k] over the K range of blockIdx.z.  ksplit == 1: C = [resid +] act(acc + bias).
+// ksplit > 1: the raw partial goes to slab blockIdx.z ([M, N] each, row stride N); f32_sum_slabs_kernel finishes.
+// 256 threads = 2 x 2 waves of 32 x 32; the weight fragment is the MFMA's first operand, so a lane ends up with 4 consecutive
+// output columns of one row: acc[i][j][r] = C[m0 + wm*32 + i*16 + (lane & 15)][n0 + wn*32 + j*16 + (lane >> 4)*4 + r].
+__global__ __launch_bounds__(256) void f32_gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                       float* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                                       const float* __restrict__ resid, int M, int N, int K, int kchunk, int act,
+                                                       int ksplit) {
+  __shared__ float sA[2][BM][LDS_LD];
+  __shared__ float sW[2][BN][LDS_LD];
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
+  const int k_lo = z * kchunk, k_hi = min(K, k_lo + kchunk);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int lr = t >> 2, lc = (t & 3) * 4;                       // this thread's row and first column of the 64 x 16 tiles
+  const float* ap = A + (size_t)min(m0 + lr, M - 1) * lda + lc;
+  const float* wp = W + (size_t)min(n0 + lr, N - 1) * ldw + lc;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 ra = *(const f32x4*)(ap + k_lo), rw = *(const f32x4*)(wp + k_lo);
+  int buf = 0;
+  for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sA[buf][lr][lc + c] = ra[c], sW[buf][lr][lc + c] = rw[c];
+    __syncthreads();
+    if (k0 + BK < k_hi) ra = *(const f32x4*)(ap + k0 + BK), rw = *(const f32x4*)(wp + k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      float fa[2], fw[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = sA[buf][wm * 32 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fw[j] = sW[buf][wn * 32 + j * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma4(fw[j], fa[i], acc[i][j]);
+    }
+    buf ^= 1;                                         // (the other buffer was last read before the barrier above)
+  }
+  float* out = ksplit > 1 ? C + (size_t)z * M * N : C;
+  const int ldo = ksplit > 1 ? N : ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 32 + i * 16 + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 32 + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n + r >= N) continue;
+        float v = acc[i][j][r];
+        if (ksplit == 1) {
+          if (bias) v += bias[n + r];
+          if (act == 1) v = silu_exact(v);
+          if (resid) v = resid[(size_t)m * ldc + n + r] + v;
+        }
+        out[(size_t)m * ldo + n + r] = v;
+      }
+    }
+  }
+}
+
+// C = [resid +] act(bias + slab 0 + slab 1 + ...): the K ranges in ascending order, the same order on every run
+__global__ __launch_bounds__(256) void f32_sum_slabs_kernel(const float* __restrict__ slabs, int ksplit, float* __restrict__ C, int ldc,
+                                                            const float* __restrict__ bias, const float* __restrict__ resid, int M,
+                                                            int N, int act) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx - (size_t)m * N);
+  float v = slabs[idx];
+  for (int s = 1; s < ksplit; ++s) v += slabs[(size_t)s * M * N + idx];
+  if (bias) v += bias[n];
+  if (act == 1) v = silu_exact(v);
+  if (resid) v = resid[(size_t)m * ldc + n] + v;
+  C[(size_t)m * ldc + n] = v;
+}
+
+// Qwen2RMSNorm in fp32 (modeling_qwen2.py:41-48): y = w * (x * rsqrt(mean(x^2) + eps)); one 256-thread block per row
+__global__ __launch_bounds__(256) void f32_rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                          int D, float eps) {
+  __shared__ float red[4];
+  const float* xr = x + (size_t)blockIdx.x * D;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < D; c += 256) s += xr[c] * xr[c];
+  s = block_sum<4>(s, red);
+  const float rs = rsqrtf(s / (float)D + eps);
+  for (int c = threadIdx.x; c < D; c += 256) y[(size_t)blockIdx.x * D + c] = w[c] * (xr[c] * rs);
+}
+
+// apply_rotary_pos_emb (modeling_qwen2.py:91-135) on the q and k heads of qkv [M, (H + 2G) * 128], in place:
+// out = x * cos + rotate_half(x) * sin with the products rounded separately (torch eager); optionally the rotated k and v rows
+// go to cache[row, slot[row]] (decode step: Cache.update).  One thread per rotation pair.
+__global__ __launch_bounds__(256) void f32_rope_kernel(float* __restrict__ qkv, const float* __restrict__ ct, const float* __restrict__ st,
+                                                       int M, int H, int G, float* __restrict__ kc, float* __restrict__ vc,
+                                                       const int32_t* __restrict__ slot, int ctx) {
+  const int LD = (H + 2 * G) * HD, Wd = G * HD;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = (H + 2 * G) * 64;
+  if (idx >= (size_t)M * per_row) return;
+  const int m = (int)(idx / per_row), rest = (int)(idx - (size_t)m * per_row), hh = rest >> 6, d = rest & 63;
+  float* row = qkv + (size_t)m * LD + hh * HD;
+  float y1 = row[d], y2 = row[d + 64];
+  if (hh < H + G) {
+    const float c = ct[(size_t)m * 64 + d], s = st[(size_t)m * 64 + d];
+    const float x1 = y1, x2 = y2;
+    y1 = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, s));
+    y2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, s));
+    row[d] = y1;
+    row[d + 64] = y2;
+  }
+  if (kc && hh >= H) {
+    float* dst = (hh < H + G ? kc : vc) + ((size_t)m * ctx + slot[m]) * Wd + (hh - (hh < H + G ? H : H + G)) * HD;
+    dst[d] = y1;
+    dst[d + 64] = y2;
+  }
+}
+
+// prompt K / V of a prefill qkv activation [B * S, LD] -> cache row b * n_beams, positions 0 .. S - 1
+__global__ __launch_bounds__(256) void f32_kv_fill_kernel(const float* __restrict__ qkv, float* __restrict__ kc, float* __restrict__ vc,
+                                                          int B, int S, int H, int G, int nb, int ctx) {
+  const int LD = (H + 2 * G) * HD, Wd = G * HD;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)B * S * Wd) return;
+  const int c = (int)(idx % Wd);
+  const size_t bs = idx / Wd;
+  const int b = (int)(bs / S), s = (int)(bs - (size_t)b * S);
+  const size_t dst = ((size_t)(b * nb) * ctx + s) * Wd + c;
+  kc[dst] = qkv[bs * LD + H * HD + c];
+  vc[dst] = qkv[bs * LD + (H + G) * HD + c];
+}
+
+// softmax(q . K^T * scale + mask) . V for ONE query row and head per wave, fp32 (eager attention of modeling_qwen2.py:150-172).
+// Keys come through a functor (prefill: rows of the qkv activation; decode: cache rows through the beam index).
+// Phase 1: lane = key (the whole 128-dim dot product per lane, q broadcast from LDS); phase 2: lane = two output dims.
+constexpr int F32_ATTN_MAX_KEYS = 2048;
+template <typename KeyAt, typename ValAt>
+__device__ void f32_attn_row(const float* q, int k_lo, int k_hi, float scale, float* out, float* sq, float* sp, KeyAt key_at, ValAt val_at) {
+  const int lane = threadIdx.x & 63;
+  sq[lane] = q[lane];
+  sq[lane + 64] = q[lane + 64];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (one wave owns sq / sp: its LDS operations complete in order)
+  __builtin_amdgcn_wave_barrier();
+  float mx = -__builtin_inff();
+  for (int j0 = k_lo; j0 < k_hi; j0 += 64) {
+    const int j = j0 + lane;
+    float sc = -__builtin_inff();
+    if (j < k_hi) {
+      const f32x4* kr = (const f32x4*)key_at(j);
+      float a = 0.f;
+#pragma unroll 8
+      for (int c = 0; c < HD / 4; ++c) {
+        const f32x4 kv = kr[c], qv = *(const f32x4*)(sq + c * 4);
+        a += kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
+      }
+      sc = a * scale;
+    }
+    if (j < k_hi) sp[j - k_lo] = sc;
+    mx = fmaxf(mx, sc);
+  }
+  mx = wave_max(mx);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  float sum = 0.f;
+  for (int j = k_lo + lane; j < k_hi; j += 64) {
+    const float e = expf(sp[j - k_lo] - mx);
+    sp[j - k_lo] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  float o0 = 0.f, o1 = 0.f;
+  const float inv = 1.f / sum;
+  for (int j = k_lo; j < k_hi; ++j) {
+    const float p = sp[j - k_lo] * inv;
+    const float* vr = val_at(j);
+    o0 += p * vr[lane];
+    o1 += p * vr[lane + 64];
+  }
+  out[lane] = o0;
+  out[lane + 64] = o1;
+}
+
+// prefill: grid = B * S * H waves (4 per block); query s of batch row b sees keys [kstart[b], s] (causal, left padding masked)
+__global__ __launch_bounds__(256) void f32_attn_prefill_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ kstart,
+                                                               float* __restrict__ out, int B, int S, int H, int G, float scale) {
+  extern __shared__ float smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long id = (long long)blockIdx.x * 4 + wave;
+  if (id >= (long long)B * S * H) return;
+  const int h = (int)(id % H);
+  const long long bs = id / H;
+  const int b = (int)(bs / S), s = (int)(bs - (long long)b * S);
+  const int LD = (H + 2 * G) * HD, g = h / (H / G);
+  float* sq = smem + wave * (HD + F32_ATTN_MAX_KEYS);
+  float* sp = sq + HD;
+  float* o = out + (size_t)bs * (H * HD) + h * HD;
+  const int k_lo = kstart[b];
+  if (s < k_lo) {                                   // a padding position: no visible key; its output is never read
+    o[lane] = 0.f;
+    o[lane + 64] = 0.f;
+    return;
+  }
+  const float* base = qkv + (size_t)b * S * LD;
+  f32_attn_row(base + (size_t)s * LD + h * HD, k_lo, s + 1, scale, o, sq, sp,
+               [&](int j) { return base + (size_t)j * LD + (H + g) * HD; },
+               [&](int j) { return base + (size_t)j * LD + (H + G + g) * HD; });
+}
+
+// decode: one wave per (beam row, head); key i of row m lives in cache row index[m, i] (tasu_kv_index_*), keys [kstart[m], lens[m])
+__global__ __launch_bounds__(256) void f32_attn_decode_kernel(const float* __restrict__ qkv, const float* __restrict__ kc,
+                                                              const float* __restrict__ vc, const int32_t* __restrict__ index,
+                                                              const int32_t* __restrict__ kstart, const int32_t* __restrict__ lens,
+                                                              float* __restrict__ out, int M, int H, int G, int ctx, float scale) {
+  extern __shared__ float smem[];
+  const int wave = threadIdx.x >> 6;
+  const int id = blockIdx.x * 4 + wave;
+  if (id >= M * H) return;
+  const int h = id % H, m = id / H;
+  const int LD = (H + 2 * G) * HD, Wd = G * HD, g = h / (H / G);
+  float* sq = smem + wave * (HD + F32_ATTN_MAX_KEYS);
+  float* sp = sq + HD;
+  const int32_t* ix = index + (size_t)m * ctx;
+  f32_attn_row(qkv + (size_t)m * LD + h * HD, kstart[m], lens[m], scale, out + (size_t)m * (H * HD) + h * HD, sq, sp,
+               [&](int j) { return kc + ((size_t)ix[j] * ctx + j) * Wd + g * HD; },
+               [&](int j) { return vc + ((size_t)ix[j] * ctx + j) * Wd + g * HD; });
+}
+
+// Qwen2MLP: act = silu(gate) * up over gu [M, 2I] (gate columns first), fp32
+__global__ __launch_bounds__(256) void f32_swiglu_kernel(const float* __restrict__ gu, float* __restrict__ act, int M, int I) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)M * I) return;
+  const size_t m = idx / I, c = idx - m * I;
+  act[idx] = __fmul_rn(silu_exact(gu[m * 2 * I + c]), gu[m * 2 * I + I + c]);
+}
+
+// x[m, :] = table[idx] | proj[idx] | 0 (tasu_embed_merge_fwd with an fp32 projector output)
+__global__ __launch_bounds__(256) void f32_embed_merge_kernel(const float* __restrict__ table, const float* __restrict__ proj, int ldp,
+                                                              const int32_t* __restrict__ kind, const int32_t* __restrict__ src,
+                                                              float* __restrict__ x, int M, int D) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)M * D) return;
+  const int m = (int)(idx / D), c = (int)(idx - (size_t)m * D);
+  const int k = kind[m];
+  x[idx] = k == 1 ? table[(size_t)src[m] * D + c] : (k == 2 ? proj[(size_t)src[m] * ldp + c] : 0.f);
+}
+
+// log_softmax + top-k of one fp32 logits row per 1024-thread block: (x - max) - log(sum exp(x - max)) like torch.log_softmax,
+// then k rounds of "the best column after the previous pick" in the order (value descending, column ascending); banned columns
+// never qualify (MinLengthLogitsProcessor sets them to -inf after the softmax).
+__global__ __launch_bounds__(1024) void f32_logprob_topk_kernel(const float* __restrict__ logits, int ld, int V, int k,
+                                                                const int32_t* __restrict__ banned, int n_banned,
+                                                                float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+  __shared__ float red[16];
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const float* x = logits + (size_t)blockIdx.x * ld;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float m = -__builtin_inff();
+  for (int c = t; c < V; c += 1024) m = fmaxf(m, x[c]);
+  m = block_max<16>(m, red);
+  float s = 0.f;
+  for (int c = t; c < V; c += 1024) s += expf(x[c] - m);
+  s = block_sum<16>(s, red);
+  const float lse = logf(s);
+  float pv = __builtin_inff();
+  int pi = -1;
+  for (int r = 0; r < k; ++r) {
+    float best = -__builtin_inff();
+    int bid = 0x7fffffff;
+    for (int c = t; c < V; c += 1024) {
+      const float v = x[c];
+      const bool after = v < pv || (v == pv && c > pi);
+      if (!after || v < best || (v == best && c > bid)) continue;
+      bool ban = false;
+      for (int b = 0; b < n_banned; ++b) ban |= banned[b] == c;
+      if (!ban) best = v, bid = c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bid, o, 64);
+      if (ov > best || (ov == best && oi < bid)) best = ov, bid = oi;
+    }
+    __syncthreads();
+    if (lane == 0) bv[wave] = best, bi[wave] = bid;
+    __syncthreads();
+    best = bv[0], bid = bi[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < bid)) best = bv[w], bid = bi[w];
+    pv = best, pi = bid;
+    if (t == 0) {
+      out_val[(size_t)blockIdx.x * k + r] = bid == 0x7fffffff ? -__builtin_inff() : (best - m) - lse;
+      out_idx[(size_t)blockIdx.x * k + r] = bid;
+    }
+    if (bid == 0x7fffffff) pv = -__builtin_inff();     // fewer than k selectable columns: the remaining picks are empty too
+  }
+}
+
+}  // namespace tasu_f32
+
+using namespace tasu_f32;
+
+extern "C" int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
+                                int M, int N, int K, int act, float* workspace, int64_t workspace_floats, void* stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K % BK || lda % 4 || ldw % 4 || ldc < N || act < 0 || act > 1) return TASU_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)W) & 15) return TASU_ERR_ARG;
+  const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
+  // narrow outputs behind a long K (o / down / q|k|v at <= 64 beam rows: 24-32 tiles): K-range slabs so that the whole chip streams
+  int ksplit = 1;
+  if (workspace && tiles < 128) {
+    ksplit = 256 / tiles;
+    if (ksplit > 16) ksplit = 16;
+    while (ksplit > 1 && ((K / BK) % ksplit || (int64_t)ksplit * M * N > workspace_floats)) --ksplit;
+  }
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, ksplit);
+  TASU_LAUNCH(f32_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, W, ldw, ksplit > 1 ? workspace : C, ldc, bias, resid, M, N,
+              K, K / ksplit, act, ksplit);
+  if (ksplit > 1) {
+    const size_t n = (size_t)M * N;
+    TASU_LAUNCH(f32_sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, ksplit, C, ldc, bias,
+                resid, M, N, act);
+  }
+  return TASU_OK;
+}
+
+extern "C" int tasu_f32_rmsnorm(const float* x, const float* w, float* y, int M, int D, float eps, void* stream) {
+  if (!x || !w || !y || M <= 0 || D <= 0) return TASU_ERR_ARG;
+  TASU_LAUNCH(f32_rmsnorm_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, w, y, D, eps);
+  return TASU_OK;
+}
+
+extern "C" int tasu_f32_rope(float* qkv, const float* cos_tab, const float* sin_tab, int M, int H, int G, float* kcache, float* vcache,
+                             const int32_t* slot, int ctx, void* stream) {
+  if (!qkv || !cos_tab || !sin_tab || M <= 0 || H <= 0 || G <= 0 || H % G) return TASU_ERR_ARG;
+  if (kcache && (!vcache || !slot || ctx <= 0)) return TASU_ERR_ARG;
+  const size_t n = (size_t)M * (H + 2 * G) * 64;
+  TASU_LAUNCH(f32_rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qkv, cos_tab, sin_tab, M, H, G, kcache,
+              vcache, slot, ctx);
+  return TASU_OK;
+}
+
+extern "C" int tasu_f32_kv_fill(const float* qkv, float* kcache, float* vcache, int B, int S, int H, int G, int n_beams, int ctx,
+                                void* stream) {
+  if (!qkv || !kcache || !vcache || B <= 0 || S <= 0 || S > ctx || n_beams <= 0) return TASU_ERR_ARG;
+  const size_t n = (size_t)B * S * G * HD;
+  TASU_LAUNCH(f32_kv_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qkv, kcache, vcache, B, S, H, G,
+              n_beams, ctx);
+  return TASU_OK;
+}
+
+static int f32_attn_lds() {
+  static bool set = false;
+  constexpr int LDS = 4 * (HD + F32_ATTN_MAX_KEYS) * 4;
+  if (!set) {
+    (void)hipFuncSetAttribute((const void*)f32_attn_prefill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)f32_attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    set = true;
+  }
+  return LDS;
+}
+
+extern "C" int tasu_f32_attn_prefill(const float* qkv, const int32_t* kstart, float* out, int B, int S, int H, int G, float scale,
+                                     void* stream) {
+  if (!qkv || !kstart || !out || B <= 0 || S <= 0 || S > F32_ATTN_MAX_KEYS || H <= 0 || G <= 0 || H % G) return TASU_ERR_ARG;
+  const long long waves = (long long)B * S * H;
+  TASU_LAUNCH(f32_attn_prefill_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), f32_attn_lds(), (hipStream_t)stream, qkv, kstart, out,
+              B, S, H, G, scale);
+  return TASU_OK;
+}
+
+extern "C" int tasu_f32_attn_decode(const float* qkv, const float* kcache, const float* vcache, const int32_t* row_index,
+                                    const int32_t* kstart, const int32_t* lens, float* out, int M, int H, int G, int ctx, float scale,
+                                    void* stream) {
+  if (!qkv || !kcache || !vcache || !row_index || !kstart || !lens || !out || M <= 0 || H <= 0 || G <= 0 || H % G || ctx <= 0 ||
+      ctx > F32_ATTN_MAX_KEYS)
+    return TASU_ERR_ARG;
+  TASU_LAUNCH(f32_attn_decode_kernel, dim3((M * H + 3) / 4), dim3(256), f32_attn_lds(), (hipStream_t)stream, qkv, kcache, vcache, row_index,
+              kstart, lens, out, M, H, G, ctx, scale);
+  return TASU_OK;
+}
+
+extern "C" int tasu_f32_swiglu(const float* gu, float* act, int M, int I, void* stream) {
+  if (!gu || !act || M <= 0 || I <= 0) return TASU_ERR_ARG;
+  const size_t n = (size_t)M * I;
+  TASU_LAUNCH(f32_swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gu, act, M, I);
+  return TASU_OK;
+}
+
+extern "C" int tasu_f32_embed_merge(const float* table, const float* proj, int ldp, const int32_t* src_kind, const int32_t* src_idx,
+                                    float* x, int M, int D, void* stream) {
+  if (!table || !proj || !src_kind || !src_idx || !x || M <= 0 || D <= 0 || ldp < D) return TASU_ERR_ARG;
+  const size_t n = (size_t)M * D;
+  TASU_LAUNCH(f32_embed_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, proj, ldp, src_kind,
+              src_idx, x, M, D);
+  return TASU_OK;
+}
+
+extern "C" int tasu_f32_logprob_topk(const float* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned, float* out_val,
+                                     int32_t* out_idx, void* stream) {
+  if (!logits || !out_val || !out_idx || M <= 0 || V <= 0 || ld < V || k <= 0 || k > 16 || n_banned < 0 || (n_banned > 0 && !banned))
+    return TASU_ERR_ARG;
+  TASU_LAUNCH(f32_logprob_topk_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, logits, ld, V, k, banned, n_banned, out_val, out_idx);
+  return TASU_OK;
+}

@@ -146,6 +146,16 @@ class DeviceBeam:
 DONE_POLL_DEPTH = 2      # generated positions the device may run ahead of the host's look at the "done" word
 
 
+def effective_min_length(min_length, S):
+    """Generated positions during which EOS is banned.  HF counts ``min_length`` INCLUDING the prompt and, when the prompt arrives
+    as ``inputs_embeds`` (what the reference passes, Multitask/model/ps-slm.py:660-668), subtracts the embedded prompt's length S
+    (padding included) from it: transformers generation/utils.py ``GenerationMixin._prepare_generated_length``,
+    ``min_length = max(min_length - inputs_tensor.shape[1], 0)``.  With the reference's default ``min_length=1`` EOS is never
+    banned.  (Rounds 1-5 banned the first ``min_length`` generated positions; found in round 6 on an unfiltered decode case whose
+    reference output is an immediate EOS: tests/golden/mid_generate_fp32.npz.)"""
+    return max(int(min_length) - int(S), 0)
+
+
 def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, min_length=1, length_penalty=1.0,
                          eos_token_id=None, pad_token_id=None):
     """st: a prepared state whose projector output (st.dev['y2']) is ready.  Returns LongTensor [B, n_new] (CPU)."""
@@ -160,6 +170,7 @@ def beam_search_generate(model, st: StepState, num_beams=4, max_new_tokens=200, 
             model.llm, model._lora_run = keep
     ops, geo, llm = model.ops, model.geo, model.llm
     B, S, nb = st.B, st.S, num_beams
+    min_length = effective_min_length(min_length, S)
     # limits of the device beam search (tasu_beam_update, tasu_decode_step_prologue: include/tasu_hip.h), checked BEFORE the prefill
     if not 1 <= nb <= BEAM_MAX_NB:
         raise ValueError(f"num_beams={nb}: the device beam search serves 1..{BEAM_MAX_NB} beams")

@@ -242,6 +242,10 @@ class LLMWeights:
         self.norm = None       # fp32 [D]
         self._decode_ready = False
         self._stale_ptrs = []  # row-major weight addresses whose fragment-order copies (ops._frag) belong to replaced weights
+        # fp32 arithmetic mode of the decode path (train_config.use_fp16 = false, ps_slm_amd/decode_fp32.py): fp32 copies of the
+        # fused weights next to the bf16 ones, {"layers": [{wqkv, bqkv, wo, wgu, wd}], "head"}; set keep_f32 BEFORE loading
+        self.keep_f32 = False
+        self.f32 = None
 
     def _drop_weights(self):
         """Before a reload: remember which registered decode copies die with the old tensors."""
@@ -250,6 +254,7 @@ class LLMWeights:
         if self.head is not None:
             self._stale_ptrs.append(self.head.data_ptr())
         self.layers = []
+        self.f32 = {"layers": [], "head": None} if self.keep_f32 else None
         self._decode_ready = False
 
     @staticmethod
@@ -268,6 +273,12 @@ class LLMWeights:
             ln1=ln1.to(dev, torch.float32).contiguous(), ln2=ln2.to(dev, torch.float32).contiguous(),
             wqkv=wqkv, wqkv_t=wqkv_t, bqkv=torch.cat([bq, bk, bv], 0).to(dev, torch.bfloat16).contiguous(),
             wo=wo_b, wo_t=wo_t, wgu=wgu, wgu_t=wgu_t, wd=wd_b, wd_t=wd_t))
+        if self.keep_f32:
+            if self.f32 is None:
+                self.f32 = {"layers": [], "head": None}
+            c = lambda t: t.to(dev, torch.float32).contiguous()
+            self.f32["layers"].append(dict(wqkv=c(torch.cat([wq, wk, wv], 0)), bqkv=c(torch.cat([bq, bk, bv], 0)), wo=c(wo),
+                                           wgu=c(torch.cat([wg, wu], 0)), wd=c(wd)))
 
     def set_embed(self, embed, head, norm):
         geo, dev = self.geo, self.device
@@ -279,6 +290,10 @@ class LLMWeights:
         self.head_t = torch.zeros(D, Vp, dtype=torch.bfloat16, device=dev)
         self.head_t[:, :V].copy_(hb.t())
         self.norm = norm.to(dev, torch.float32).contiguous()
+        if self.keep_f32:
+            if self.f32 is None:
+                self.f32 = {"layers": [], "head": None}
+            self.f32["head"] = self.embed if head is embed else head.to(dev, torch.float32).contiguous()   # tied: one copy
 
     def prepare_decode(self, ops):
         """Decode-step copies of the frozen weights in the order the weight-streaming kernels consume them
@@ -427,6 +442,7 @@ class TasuModel:
         self.keep_logits = keep_logits
         self._ws = {}
         self._pack = None               # UploadPack: the step's host -> device inputs (created on the first upload on a GPU)
+        self.arith = "bf16"             # arithmetic of generate(): "bf16" (autocast semantics) or "fp32" (ps_slm_amd/decode_fp32.py)
         self.training = True
         # hipGraph replay of the (shape-static) forward / backward launch sequences: ~700 launches per step collapse
         # into two graph launches.  Keyed by the shapes baked into kernel arguments; the first call of a key runs
@@ -770,7 +786,7 @@ class TasuModel:
             slot = np.full(st.M, -1, dtype=np.int32)
             slot[rows] = np.arange(st.nL, dtype=np.int32)
             st.dev["lab_rows"] = self._upload("lab_rows", lab_rows, flush=False)
-            st.dev["lab_rows0"] = self._upload("lab_rows0", np.maximum(lab_rows, 0))      # padding slots read row 0 (their results are ignored, flush=False)
+            st.dev["lab_rows0"] = self._upload("lab_rows0", np.maximum(lab_rows, 0), flush=False)   # padding slots read row 0 (their results are ignored)
             st.dev["lab_compact"] = self._upload("lab_compact", lab_c, flush=False)
             st.dev["lab_slot"] = self._upload("lab_slot", slot, flush=False)
         return st

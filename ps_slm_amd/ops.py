@@ -628,6 +628,40 @@ class HipOps:
                                             bs.B, bs.nb, bs.max_new, bs.eos, bs.min_length, bs.S, int(first), self._stream()),
                   "tasu_beam_update")
 
+    # ------------------------------------------------------------------ fp32 arithmetic mode of the decode path (csrc/fp32.hip)
+    def f32_gemm(self, a, w, c, M, N, K, bias=None, resid=None, act=0, ws=None):
+        """c[M, N] = [resid +] act(a[M, K] @ w[N, K]^T + bias), everything fp32 (tasu_f32_gemm_nt); ``ws``: fp32 workspace for the
+        K-range slabs of narrow outputs (16 * M * N floats cover every split)."""
+        self._chk(self.lib.tasu_f32_gemm_nt(_p(a), a.stride(0), _p(w), w.stride(0), _p(c), c.stride(0), _p(bias), _p(resid), M, N, K, act,
+                                            _p(ws), ws.numel() if ws is not None else 0, self._stream()), "tasu_f32_gemm_nt")
+
+    def f32_rmsnorm(self, x, w, y, M, D, eps):
+        self._chk(self.lib.tasu_f32_rmsnorm(_p(x), _p(w), _p(y), M, D, eps, self._stream()), "tasu_f32_rmsnorm")
+
+    def f32_rope(self, qkv, cos, sin, M, H, G, kc=None, vc=None, slot=None, ctx=0):
+        self._chk(self.lib.tasu_f32_rope(_p(qkv), _p(cos), _p(sin), M, H, G, _p(kc), _p(vc), _p(slot), ctx, self._stream()), "tasu_f32_rope")
+
+    def f32_kv_fill(self, qkv, kc, vc, B, S, H, G, nb, ctx):
+        self._chk(self.lib.tasu_f32_kv_fill(_p(qkv), _p(kc), _p(vc), B, S, H, G, nb, ctx, self._stream()), "tasu_f32_kv_fill")
+
+    def f32_attn_prefill(self, qkv, kstart, out, B, S, H, G, scale):
+        self._chk(self.lib.tasu_f32_attn_prefill(_p(qkv), _p(kstart), _p(out), B, S, H, G, scale, self._stream()), "tasu_f32_attn_prefill")
+
+    def f32_attn_decode(self, qkv, kc, vc, index, kstart, lens, out, M, H, G, ctx, scale):
+        self._chk(self.lib.tasu_f32_attn_decode(_p(qkv), _p(kc), _p(vc), _p(index), _p(kstart), _p(lens), _p(out), M, H, G, ctx, scale,
+                                                self._stream()), "tasu_f32_attn_decode")
+
+    def f32_swiglu(self, gu, act, M, I):
+        self._chk(self.lib.tasu_f32_swiglu(_p(gu), _p(act), M, I, self._stream()), "tasu_f32_swiglu")
+
+    def f32_embed_merge(self, table, proj, kind, idx, x, M, D):
+        self._chk(self.lib.tasu_f32_embed_merge(_p(table), _p(proj), proj.stride(0), _p(kind), _p(idx), _p(x), M, D, self._stream()),
+                  "tasu_f32_embed_merge")
+
+    def f32_logprob_topk(self, logits, M, V, k, banned, n_banned, out_val, out_idx):
+        self._chk(self.lib.tasu_f32_logprob_topk(_p(logits), logits.stride(0), M, V, k, _p(banned), n_banned, _p(out_val), _p(out_idx),
+                                                 self._stream()), "tasu_f32_logprob_topk")
+
     # ------------------------------------------------------------------ audio front end
     def fbank(self, wave, n_samples, scale, win, shift, window, mel, n_mels, preemph, out):
         self._chk(self.lib.tasu_fbank(_p(wave), n_samples, scale, win, shift, _p(window), _p(mel), n_mels, preemph, _p(out),

@@ -212,11 +212,14 @@ def model_factory(train_config, model_config, **kwargs):
     if kwargs.get("peft_ckpt", None):
         raise NotImplementedError("peft_ckpt (a peft adapter DIRECTORY, ps-slm.py:110-112): load the adapters from the training "
                                   "checkpoint with ckpt_path instead -- it holds them under the reference's own key names")
-    if not train_config.get("use_fp16", False):
-        # the reference computes in fp32 unless use_fp16 wraps the step in bf16 autocast (deepspeed_utils.py:160,205) and
-        # decodes in fp32 (inference_batch.py:113-117); this path has ONE arithmetic: bf16 autocast semantics
-        logger.warning("train_config.use_fp16 is false: the MI355X path still computes with bf16-autocast semantics "
-                       "(bf16 GEMM operands, fp32 accumulation / residual stream / norms / loss)")
+    fp32_mode = not train_config.get("use_fp16", False)
+    if fp32_mode:
+        # the reference computes in fp32 unless use_fp16 wraps the step in bf16 autocast (deepspeed_utils.py:160,205) and ALWAYS
+        # decodes in fp32 (inference_batch.py:113-117).  generate() then runs the fp32 path (ps_slm_amd/decode_fp32.py: fp32 weights,
+        # cache and logits); the TRAINING step has one arithmetic, bf16 autocast semantics
+        logger.warning("train_config.use_fp16 is false: generate() decodes in fp32 (the reference's inference arithmetic); a training "
+                       "step would still compute with bf16-autocast semantics (bf16 GEMM operands, fp32 accumulation / residual "
+                       "stream / norms / loss)")
     raw = not train_config.get("ctc_posterior", True)
     if raw and projector == "cross-attention":
         raise NotImplementedError("ctc_posterior=false with the cross-attention projector: the reference's raw-feature branch "
@@ -235,6 +238,9 @@ def model_factory(train_config, model_config, **kwargs):
         from ps_slm_amd.ops import HipOps     # raises if libtasu_hip.so is missing or there is no GPU: no fallback
         ops = HipOps()
     core = TasuModel(geo, ops, device, keep_logits=bool(kwargs.get("keep_logits", True)))
+    if fp32_mode and device != "cpu" and not str(device).startswith("cpu") and projector == "linear-silu" and not train_config.get("use_peft", False):
+        core.arith = "fp32"
+        core.llm.keep_f32 = True                       # fp32 copies of the frozen weights next to the bf16 ones (before loading)
     llm_path = str(model_config.get("llm_path", ""))
     need_encoder = not train_config.get("gt_emb", False) or raw or bool(kwargs.get("with_encoder", False))
     if llm_path.startswith("synthetic:"):
@@ -519,10 +525,13 @@ class slam_model_asr:
             texts = [re.sub(r"[^A-Za-z\s.,!?]+", "", t).lower().strip() for t in targets]
             ids_list = [self.encoder_tokenizer.encode(t) for t in texts]
             st = core.prepare_text(input_ids, attention_mask, None, ids_list, None, None)
-            core.forward_projector_text(st)
+            if core.arith != "fp32":                       # (the fp32 path runs its own fp32 projector)
+                core.forward_projector_text(st)
         else:
             st = core.prepare_audio(input_ids, attention_mask, None, input_features, input_feature_length,
                                     do_psd=self.do_psd)
+        if core.arith == "fp32":                           # use_fp16 = false: the reference's own decode arithmetic
+            from ps_slm_amd.decode_fp32 import beam_search_generate_fp32 as beam_search_generate
         return beam_search_generate(core, st, num_beams=kwargs.get("num_beams", 4),
                                     max_new_tokens=kwargs.get("max_new_tokens", 200),
                                     min_length=kwargs.get("min_length", 1),

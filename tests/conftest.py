@@ -105,6 +105,26 @@ def decode_margin_cases():
     return geo, sd, cases
 
 
+def decode_fp32_cases():
+    """(geo, state dict, cases, bf16_oracle_agrees) of tests/golden/mid_generate_fp32.npz (oracle/make_golden_generate_fp32.py):
+    24 UNFILTERED random decode cases with the REAL reference's fp32 ``generate`` tokens -- every prompt the seeded generator drew,
+    rounding-sensitive or not (the fp32 decode path is pinned on them; 8 of the 24 decode differently under bf16 rounding)."""
+    from ps_slm_amd.model import Geometry
+    from ps_slm_amd.synthetic import MID_GEOMETRY, decode_fixture_state_dict
+
+    z = load_npz("mid_generate_fp32")
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    sd = decode_fixture_state_dict(geo, int(z["seed_w"]))
+    cases = []
+    for n in range(int(z["n_cases"])):
+        nb, new, min_len = (int(v) for v in z[f"c{n}_kw"])
+        cases.append(dict(ids=torch.from_numpy(z[f"c{n}_input_ids"]), am=torch.from_numpy(z[f"c{n}_attention_mask"]),
+                          post_ids=split_flat(z[f"c{n}_post_ids_flat"], z[f"c{n}_post_lens"]), tokens=z[f"c{n}_tokens"],
+                          kw=dict(num_beams=nb, max_new_tokens=new, min_length=min_len,
+                                  length_penalty=float(z[f"c{n}_length_penalty"]))))
+    return geo, sd, cases, [bool(v) for v in z["bf16_oracle_agrees"]]
+
+
 def decode_lora_margin_cases():
     """(geo, LoraConfig, state dict, adapter state dict, cases) of tests/golden/mid_generate_lora_margin.npz
     (oracle/make_golden_generate_lora_margin.py): rounding-stable decode cases of the LoRA-ADAPTED model.  tokens = the REAL

@@ -343,6 +343,32 @@ def test_generate_margin_cases_vs_reference(mode):
             assert np.array_equal(toks.numpy(), c["tokens"]), (n, toks, c["tokens"])
 
 
+def test_generate_unfiltered_cases_vs_reference_fp32():
+    """tests/golden/mid_generate_fp32.npz: 24 random decode cases kept WITHOUT any stability selection, tokens of the REAL
+    reference's fp32 ``generate``.  The fp32-mode oracle reproduces every one (whole-sequence form; the KV-cache form on every
+    third case); the bf16-mode oracle only the ones the generator recorded -- the set does contain rounding-sensitive cases.
+    Case 5's first utterance pins HF's ``min_length`` semantics under ``inputs_embeds`` (EOS banned for max(min_length - S, 0)
+    positions only: the reference emits EOS at once although min_length = 6)."""
+    import dataclasses
+
+    from conftest import decode_fp32_cases
+    geo, sd, cases, bf16_agrees = decode_fp32_cases()
+    gd = dataclasses.asdict(geo)
+    assert len(cases) == 24 and 0 < sum(bf16_agrees) < len(cases)
+    assert cases[5]["kw"]["min_length"] == 6 and (cases[5]["tokens"][0] == geo.eos_id).all()
+    for n, c in enumerate(cases):
+        post, plen = O.pseudo_posterior(c["post_ids"], geo.ctc_vocab)
+        for mode in ("fp32", "bf16"):
+            emb, mask, _, _ = O.merge(O.projector(sd, post, mode), plen, sd["llm.model.embed_tokens.weight"][c["ids"]], c["ids"], c["am"],
+                                      None, geo.speech_id)
+            toks = O.beam_search_generate(sd, emb.detach(), mask, gd, mode=mode, **c["kw"])
+            same = toks.shape == c["tokens"].shape and np.array_equal(toks.numpy(), c["tokens"])
+            assert same == (True if mode == "fp32" else bf16_agrees[n]), (n, mode, toks, c["tokens"])
+            if mode == "fp32" and n % 3 == 0:
+                toks = O.beam_search_generate(sd, emb.detach(), mask, gd, mode=mode, kv_cache=True, **c["kw"])
+                assert np.array_equal(toks.numpy(), c["tokens"]), (n, "kv_cache", toks, c["tokens"])
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_generate_lora_margin_cases_vs_reference(mode):
     """The 7 rounding-stable decode cases of the LoRA-ADAPTED model (oracle/make_golden_generate_lora_margin.py): the oracle's
