@@ -309,6 +309,54 @@ def decode_leg(core, raw, B, new_tokens=200, beams=4):
                                  "wall time per position (prefill included in the wall time)"}}
 
 
+def decode_fp32_leg(local_rank, B, new_tokens=200, beams=4):
+    """The reference's OWN decode arithmetic (train_config.use_fp16 = false: fp32 weights, cache and logits; Multitask/inference_batch.py:
+    113-117) on the fp32 path (ps_slm_amd/decode_fp32.py): same prompt, beams and length as decode_leg."""
+    from ps_slm_amd.config import ModelConfig, TrainConfig
+    from ps_slm_amd.decode_fp32 import beam_search_generate_fp32
+    from ps_slm_amd.ps_slm import model_factory
+    from ps_slm_amd.synthetic import synthetic_text_batch
+
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True, use_fp16=False,
+                     batching_strategy="dynamic")
+    mc = ModelConfig(llm_path="synthetic:qwen2.5-1.5b", encoder_projector="linear-silu", encoder_dim=25055, llm_dim=1536)
+    model, _ = model_factory(tc, mc, device=f"cuda:{local_rank}", init_seed=1234, keep_logits=False, with_encoder=False)
+    core = model.core
+    geo = core.geo
+    raw = synthetic_text_batch(geo, B, seed=1234, noise=False)
+    ids = raw["input_ids"][:, :25]
+    am = torch.ones_like(ids, dtype=torch.bool)
+
+    def run():
+        st = core.prepare_text(ids, am, None, raw["post_ids"], None, None)
+        return beam_search_generate_fp32(core, st, num_beams=beams, max_new_tokens=new_tokens, eos_token_id=-1, pad_token_id=0)
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_new = int(out.shape[1])
+    weight_bytes = 4 * (sum(int(f[k].numel()) for f in core.llm.f32["layers"] for k in ("wqkv", "wo", "wgu", "wd")) + int(core.llm.f32["head"].numel()))
+    kv_bytes = geo.llm_layers * 2 * geo.llm_kv_heads * 128 * 4 * (128 + (n_new - 1) / 2.0) * B * beams
+    per_pos = dt / n_new
+    rec = {"metric": "decode tokens/sec (beam 4, emitted tokens, fp32 arithmetic: use_fp16=false)", "value": round(B * n_new / dt, 1),
+           "unit": "tokens/s", "ms_per_step": round(per_pos * 1e3, 3),
+           "config": {"utterances": B, "beams": beams, "prefill_len": 128, "new_tokens": n_new, "dtype": "f32"},
+           "roofline": {"bound": "hbm", "achieved": round((weight_bytes + kv_bytes) / per_pos / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round((weight_bytes + kv_bytes) / per_pos / 8e12, 4), "weight_bytes_per_position": weight_bytes,
+                        "kv_bytes_per_position_avg": int(kv_bytes),
+                        "note": "(fp32 weight bytes streamed once + fp32 K/V bytes read by the 64 beam rows) per generated position / wall "
+                                "time per position (fp32 prefill included in the wall time)"}}
+    core._dec_graphs.clear()
+    del model, core
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
+
+
 def encoder_gemm_flops_per_utt(geo, frames):
     """GEMM FLOPs of the frozen SANM encoder + CTC head per utterance (forward only; SURVEY 8d: 2 x 3,145,728 per frame-layer
     for the 512-wide layers, layer 0 reads 560 features, CTC head 2 x 512 x 25055 per frame; attention not counted here)."""
@@ -565,7 +613,8 @@ SUB_METRICS = {"audio_sft": " (audio-SFT, config 4)", "qwen2.5-7b": " (Qwen2.5-7
                "audio_sft_blank_biased": " (audio-SFT, config 4, ~100 audio tokens per utterance)",
                "lora_r64": " (text-only, use_peft=true: LoRA r=64 on the decoder + projector)",
                "exchange_1rank": " (headline step with the N > 1 gradient exchange forced through a 1-rank RCCL "
-                                 "communicator: allreduce_exposed_ms is the sanity figure)"}
+                                 "communicator: allreduce_exposed_ms is the sanity figure)",
+               "decode_fp32": None}                     # (carries its own metric: decode tokens/s in the reference's fp32 arithmetic)
 
 STDOUT_LINE_LIMIT = 8000           # the driver's record keeps ~8,000 characters of stdout and parses the line from them
 _ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step", "kernel_launches_per_step",
@@ -755,6 +804,12 @@ def main():
                                           want_decode=not args.no_decode)     # + the 7B decode leg (weight-streaming kernels
                                                                               # for K = 3584 / 18944 since round 5)
         lap("qwen2.5-7b+decode")
+        if not args.no_decode:
+            try:
+                extras["decode_fp32"] = decode_fp32_leg(local_rank, args.batch)
+            except Exception as e:                      # (never the loss of the whole line)
+                extras["decode_fp32"] = {"value": None, "error": repr(e)[:300]}
+            lap("decode_fp32")
         # the N > 1 step's exchange on hardware with ONE rank: the headline step again with the chunked
         # all-reduce of the gradient bucket through a one-rank RCCL communicator, side stream and event chain included
         try:
@@ -811,7 +866,8 @@ def main():
                 "dtype": "bf16", "data": "synthetic"}
         line.update({k: v for k, v in main_rec.items() if k not in ("value", "unit", "ms_per_step")})
         for name, rec in extras.items():
-            rec["metric"] = "train utterances/sec" + SUB_METRICS[name]
+            if SUB_METRICS[name] is not None:
+                rec["metric"] = "train utterances/sec" + SUB_METRICS[name]
             line[name] = rec
         if data_path is not None:
             line["data_path"] = data_path

@@ -10,7 +10,7 @@
 namespace tasu_f32 {
 
 constexpr int HD = 128;
-constexpr int BM = 64, BN = 64, BK = 16, LDS_LD = BK + 1;
+constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 1;
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.f + expf(-x)); }
@@ -28,21 +28,30 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(const float* __restrict__
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
   const int k_lo = z * kchunk, k_hi = min(K, k_lo + kchunk);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-  const int lr = t >> 2, lc = (t & 3) * 4;                       // this thread's row and first column of the 64 x 16 tiles
-  const float* ap = A + (size_t)min(m0 + lr, M - 1) * lda + lc;
-  const float* wp = W + (size_t)min(n0 + lr, N - 1) * ldw + lc;
+  const int lr = t >> 3, lc = (t & 7) * 4;                       // this thread's rows lr, lr + 32 and first column of the 64 x 32 tiles
+  const float* ap0 = A + (size_t)min(m0 + lr, M - 1) * lda + lc;
+  const float* ap1 = A + (size_t)min(m0 + lr + 32, M - 1) * lda + lc;
+  const float* wp0 = W + (size_t)min(n0 + lr, N - 1) * ldw + lc;
+  const float* wp1 = W + (size_t)min(n0 + lr + 32, N - 1) * ldw + lc;
   f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 ra = *(const f32x4*)(ap + k_lo), rw = *(const f32x4*)(wp + k_lo);
+  f32x4 ra0 = *(const f32x4*)(ap0 + k_lo), ra1 = *(const f32x4*)(ap1 + k_lo);
+  f32x4 rw0 = *(const f32x4*)(wp0 + k_lo), rw1 = *(const f32x4*)(wp1 + k_lo);
   int buf = 0;
   for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) sA[buf][lr][lc + c] = ra[c], sW[buf][lr][lc + c] = rw[c];
+    for (int c = 0; c < 4; ++c) {
+      sA[buf][lr][lc + c] = ra0[c], sA[buf][lr + 32][lc + c] = ra1[c];
+      sW[buf][lr][lc + c] = rw0[c], sW[buf][lr + 32][lc + c] = rw1[c];
+    }
     __syncthreads();
-    if (k0 + BK < k_hi) ra = *(const f32x4*)(ap + k0 + BK), rw = *(const f32x4*)(wp + k0 + BK);
+    if (k0 + BK < k_hi) {                              // the next K-step's 16 KiB are in flight under this one's MFMAs
+      ra0 = *(const f32x4*)(ap0 + k0 + BK), ra1 = *(const f32x4*)(ap1 + k0 + BK);
+      rw0 = *(const f32x4*)(wp0 + k0 + BK), rw1 = *(const f32x4*)(wp1 + k0 + BK);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
       float fa[2], fw[2];
@@ -150,101 +159,156 @@ __global__ __launch_bounds__(256) void f32_kv_fill_kernel(const float* __restric
   vc[dst] = qkv[bs * LD + (H + G) * HD + c];
 }
 
-// softmax(q . K^T * scale + mask) . V for ONE query row and head per wave, fp32 (eager attention of modeling_qwen2.py:150-172).
-// Keys come through a functor (prefill: rows of the qkv activation; decode: cache rows through the beam index).
-// Phase 1: lane = key (the whole 128-dim dot product per lane, q broadcast from LDS); phase 2: lane = two output dims.
+// softmax(q . K^T * scale + mask) . V for ONE query row and ONE KV head per 256-thread workgroup, fp32 (eager attention of
+// modeling_qwen2.py:150-172): the REP = H / G query heads of the group share every K / V row that is loaded, and the four waves
+// split the keys (a single wave's chain of dependent loads is what bounds this kernel: 56 -> 111 us per layer were measured for one
+// wave per group / per head).  Keys come through functors (prefill: rows of the qkv activation; decode: cache rows through the beam
+// index).  Phase 1: thread = key (the 128-dim dot products of all REP heads, q broadcast from LDS); phase 2: wave = a quarter of
+// the keys, lane = two output dims, partial outputs added in wave order (deterministic).
+// LDS: sq REP * 128 | sp REP * MAX_KEYS | part 4 * REP * 128 | red 4 * REP floats.
 constexpr int F32_ATTN_MAX_KEYS = 2048;
-template <typename KeyAt, typename ValAt>
-__device__ void f32_attn_row(const float* q, int k_lo, int k_hi, float scale, float* out, float* sq, float* sp, KeyAt key_at, ValAt val_at) {
-  const int lane = threadIdx.x & 63;
-  sq[lane] = q[lane];
-  sq[lane + 64] = q[lane + 64];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (one wave owns sq / sp: its LDS operations complete in order)
-  __builtin_amdgcn_wave_barrier();
-  float mx = -__builtin_inff();
-  for (int j0 = k_lo; j0 < k_hi; j0 += 64) {
-    const int j = j0 + lane;
-    float sc = -__builtin_inff();
-    if (j < k_hi) {
-      const f32x4* kr = (const f32x4*)key_at(j);
-      float a = 0.f;
-#pragma unroll 8
-      for (int c = 0; c < HD / 4; ++c) {
-        const f32x4 kv = kr[c], qv = *(const f32x4*)(sq + c * 4);
-        a += kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
+constexpr int F32_ATTN_MAX_REP = 8;
+template <int REP>
+__host__ __device__ constexpr int f32_attn_lds_floats() { return REP * HD + REP * F32_ATTN_MAX_KEYS + 4 * REP * HD + 4 * REP; }
+template <int REP, typename KeyAt, typename ValAt>
+__device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, float* out, float* smem, KeyAt key_at, ValAt val_at) {
+  float* sq = smem;
+  float* sp = sq + REP * HD;
+  float* part = sp + REP * F32_ATTN_MAX_KEYS;
+  float* red = part + 4 * REP * HD;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nk = k_hi - k_lo;
+  for (int i = t; i < REP * HD; i += 256) sq[i] = q[i];
+  __syncthreads();
+  float mx[REP];
+#pragma unroll
+  for (int h = 0; h < REP; ++h) mx[h] = -__builtin_inff();
+  for (int j = t; j < nk; j += 256) {
+    const f32x4* kr = (const f32x4*)key_at(k_lo + j);
+    float a[REP];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) a[h] = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < HD / 4; ++c) {
+      const f32x4 kv = kr[c];
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        const f32x4 qv = *(const f32x4*)(sq + h * HD + c * 4);
+        a[h] += kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
       }
-      sc = a * scale;
     }
-    if (j < k_hi) sp[j - k_lo] = sc;
-    mx = fmaxf(mx, sc);
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      const float sc = a[h] * scale;
+      sp[h * F32_ATTN_MAX_KEYS + j] = sc;
+      mx[h] = fmaxf(mx[h], sc);
+    }
   }
-  mx = wave_max(mx);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  float sum = 0.f;
-  for (int j = k_lo + lane; j < k_hi; j += 64) {
-    const float e = expf(sp[j - k_lo] - mx);
-    sp[j - k_lo] = e;
-    sum += e;
+#pragma unroll
+  for (int h = 0; h < REP; ++h) {
+    mx[h] = wave_max(mx[h]);
+    if (lane == 0) red[wave * REP + h] = mx[h];
   }
-  sum = wave_sum(sum);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  float o0 = 0.f, o1 = 0.f;
-  const float inv = 1.f / sum;
-  for (int j = k_lo; j < k_hi; ++j) {
-    const float p = sp[j - k_lo] * inv;
-    const float* vr = val_at(j);
-    o0 += p * vr[lane];
-    o1 += p * vr[lane + 64];
+  __syncthreads();
+  float inv[REP];
+#pragma unroll
+  for (int h = 0; h < REP; ++h) mx[h] = fmaxf(fmaxf(red[h], red[REP + h]), fmaxf(red[2 * REP + h], red[3 * REP + h]));
+  __syncthreads();                                     // (red is rewritten below)
+#pragma unroll
+  for (int h = 0; h < REP; ++h) {
+    float sum = 0.f;
+    for (int j = t; j < nk; j += 256) {
+      const float e = expf(sp[h * F32_ATTN_MAX_KEYS + j] - mx[h]);
+      sp[h * F32_ATTN_MAX_KEYS + j] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave * REP + h] = sum;
   }
-  out[lane] = o0;
-  out[lane + 64] = o1;
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < REP; ++h) inv[h] = 1.f / (((red[h] + red[REP + h]) + red[2 * REP + h]) + red[3 * REP + h]);
+  float o0[REP], o1[REP];
+#pragma unroll
+  for (int h = 0; h < REP; ++h) o0[h] = o1[h] = 0.f;
+  // this wave's quarter of the keys, sixteen V rows per trip (their loads are in flight together)
+  const int q4 = (nk + 3) >> 2, j_lo = wave * q4, j_hi = min(nk, j_lo + q4);
+  constexpr int UNR = 16;
+  int j = j_lo;
+  for (; j + UNR <= j_hi; j += UNR) {
+    float va[UNR], vb[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const float* vr = val_at(k_lo + j + u);
+      va[u] = vr[lane], vb[u] = vr[lane + 64];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        const float p = sp[h * F32_ATTN_MAX_KEYS + j + u] * inv[h];
+        o0[h] += p * va[u];
+        o1[h] += p * vb[u];
+      }
+  }
+  for (; j < j_hi; ++j) {
+    const float* vr = val_at(k_lo + j);
+    const float va = vr[lane], vb = vr[lane + 64];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      const float p = sp[h * F32_ATTN_MAX_KEYS + j] * inv[h];
+      o0[h] += p * va;
+      o1[h] += p * vb;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < REP; ++h) {
+    part[(wave * REP + h) * HD + lane] = o0[h];
+    part[(wave * REP + h) * HD + lane + 64] = o1[h];
+  }
+  __syncthreads();
+  for (int i = t; i < REP * HD; i += 256) out[i] = ((part[i] + part[REP * HD + i]) + part[2 * REP * HD + i]) + part[3 * REP * HD + i];
 }
 
-// prefill: grid = B * S * H waves (4 per block); query s of batch row b sees keys [kstart[b], s] (causal, left padding masked)
+// prefill: one workgroup per (batch row, position, KV head); query s of batch row b sees keys [kstart[b], s] (causal, left padding masked)
+template <int REP>
 __global__ __launch_bounds__(256) void f32_attn_prefill_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ kstart,
                                                                float* __restrict__ out, int B, int S, int H, int G, float scale) {
   extern __shared__ float smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long id = (long long)blockIdx.x * 4 + wave;
-  if (id >= (long long)B * S * H) return;
-  const int h = (int)(id % H);
-  const long long bs = id / H;
+  const long long id = blockIdx.x;
+  const int g = (int)(id % G);
+  const long long bs = id / G;
   const int b = (int)(bs / S), s = (int)(bs - (long long)b * S);
-  const int LD = (H + 2 * G) * HD, g = h / (H / G);
-  float* sq = smem + wave * (HD + F32_ATTN_MAX_KEYS);
-  float* sp = sq + HD;
-  float* o = out + (size_t)bs * (H * HD) + h * HD;
+  const int LD = (H + 2 * G) * HD;
+  float* o = out + (size_t)bs * (H * HD) + g * REP * HD;
   const int k_lo = kstart[b];
   if (s < k_lo) {                                   // a padding position: no visible key; its output is never read
-    o[lane] = 0.f;
-    o[lane + 64] = 0.f;
+    for (int i = threadIdx.x; i < REP * HD; i += 256) o[i] = 0.f;
     return;
   }
   const float* base = qkv + (size_t)b * S * LD;
-  f32_attn_row(base + (size_t)s * LD + h * HD, k_lo, s + 1, scale, o, sq, sp,
-               [&](int j) { return base + (size_t)j * LD + (H + g) * HD; },
-               [&](int j) { return base + (size_t)j * LD + (H + G + g) * HD; });
+  f32_attn_group<REP>(base + (size_t)s * LD + g * REP * HD, k_lo, s + 1, scale, o, smem,
+                      [&](int j) { return base + (size_t)j * LD + (H + g) * HD; },
+                      [&](int j) { return base + (size_t)j * LD + (H + G + g) * HD; });
 }
 
-// decode: one wave per (beam row, head); key i of row m lives in cache row index[m, i] (tasu_kv_index_*), keys [kstart[m], lens[m])
+// decode: one workgroup per (beam row, KV head); key i of row m lives in cache row index[m, i] (tasu_kv_index_*), keys
+// [kstart[m], lens[m]); the row's index entries are staged in LDS first (one round trip in front of the K / V loads, not one per key)
+template <int REP>
 __global__ __launch_bounds__(256) void f32_attn_decode_kernel(const float* __restrict__ qkv, const float* __restrict__ kc,
                                                               const float* __restrict__ vc, const int32_t* __restrict__ index,
                                                               const int32_t* __restrict__ kstart, const int32_t* __restrict__ lens,
                                                               float* __restrict__ out, int M, int H, int G, int ctx, float scale) {
   extern __shared__ float smem[];
-  const int wave = threadIdx.x >> 6;
-  const int id = blockIdx.x * 4 + wave;
-  if (id >= M * H) return;
-  const int h = id % H, m = id / H;
-  const int LD = (H + 2 * G) * HD, Wd = G * HD, g = h / (H / G);
-  float* sq = smem + wave * (HD + F32_ATTN_MAX_KEYS);
-  float* sp = sq + HD;
-  const int32_t* ix = index + (size_t)m * ctx;
-  f32_attn_row(qkv + (size_t)m * LD + h * HD, kstart[m], lens[m], scale, out + (size_t)m * (H * HD) + h * HD, sq, sp,
-               [&](int j) { return kc + ((size_t)ix[j] * ctx + j) * Wd + g * HD; },
-               [&](int j) { return vc + ((size_t)ix[j] * ctx + j) * Wd + g * HD; });
+  const int g = blockIdx.x % G, m = blockIdx.x / G;
+  const int LD = (H + 2 * G) * HD, Wd = G * HD;
+  int* six = (int*)(smem + f32_attn_lds_floats<REP>());
+  const int k_lo = kstart[m], k_hi = lens[m];
+  for (int i = k_lo + threadIdx.x; i < k_hi; i += 256) six[i] = index[(size_t)m * ctx + i];
+  __syncthreads();
+  f32_attn_group<REP>(qkv + (size_t)m * LD + g * REP * HD, k_lo, k_hi, scale, out + (size_t)m * (H * HD) + g * REP * HD, smem,
+                      [&](int j) { return kc + ((size_t)six[j] * ctx + j) * Wd + g * HD; },
+                      [&](int j) { return vc + ((size_t)six[j] * ctx + j) * Wd + g * HD; });
 }
 
 // Qwen2MLP: act = silu(gate) * up over gu [M, 2I] (gate columns first), fp32
@@ -266,24 +330,88 @@ __global__ __launch_bounds__(256) void f32_embed_merge_kernel(const float* __res
   x[idx] = k == 1 ? table[(size_t)src[m] * D + c] : (k == 2 ? proj[(size_t)src[m] * ldp + c] : 0.f);
 }
 
-// log_softmax + top-k of one fp32 logits row per 1024-thread block: (x - max) - log(sum exp(x - max)) like torch.log_softmax,
-// then k rounds of "the best column after the previous pick" in the order (value descending, column ascending); banned columns
-// never qualify (MinLengthLogitsProcessor sets them to -inf after the softmax).
+// log_softmax + top-k of one fp32 logits row per 1024-thread block: (x - max) - log(sum exp(x - max)) like torch.log_softmax; the k
+// best selectable columns in the order (value descending, column ascending); banned columns never qualify
+// (MinLengthLogitsProcessor sets them to -inf after the softmax).  Threshold form (three passes over the row instead of 2 + k):
+// tau = the k-th largest of the 1024 per-thread maxima over selectable columns -- at least k columns are >= tau, so the k best all
+// are; the columns >= tau (a handful) are collected in LDS during the sum-of-exp pass and ranked.  More than CAND of them (massive
+// ties): the round-by-round form below takes over.
+constexpr int F32_TOPK_CAND = 512;
 __global__ __launch_bounds__(1024) void f32_logprob_topk_kernel(const float* __restrict__ logits, int ld, int V, int k,
                                                                 const int32_t* __restrict__ banned, int n_banned,
                                                                 float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
   __shared__ float red[16];
   __shared__ float bv[16];
   __shared__ int bi[16];
+  __shared__ float cand_v[F32_TOPK_CAND];
+  __shared__ int cand_i[F32_TOPK_CAND];
+  __shared__ int cand_n;
   const float* x = logits + (size_t)blockIdx.x * ld;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  float m = -__builtin_inff();
-  for (int c = t; c < V; c += 1024) m = fmaxf(m, x[c]);
+  auto is_banned = [&](int c) {
+    bool ban = false;
+    for (int b = 0; b < n_banned; ++b) ban |= banned[b] == c;
+    return ban;
+  };
+  if (t == 0) cand_n = 0;
+  float m = -__builtin_inff(), msel = -__builtin_inff();
+  for (int c = t; c < V; c += 1024) {
+    const float v = x[c];
+    m = fmaxf(m, v);
+    if (v > msel && !is_banned(c)) msel = v;
+  }
   m = block_max<16>(m, red);
+  // tau: k rounds of (block maximum of the per-thread selectable maxima, retire one thread that holds it)
+  float mine = msel, tau = -__builtin_inff();
+  for (int r = 0; r < k; ++r) {
+    float best = mine;
+    int who = t;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int ow = __shfl_xor(who, o, 64);
+      if (ov > best || (ov == best && ow < who)) best = ov, who = ow;
+    }
+    __syncthreads();
+    if (lane == 0) bv[wave] = best, bi[wave] = who;
+    __syncthreads();
+    best = bv[0], who = bi[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < who)) best = bv[w], who = bi[w];
+    tau = best;
+    if (t == who) mine = -__builtin_inff();
+  }
   float s = 0.f;
-  for (int c = t; c < V; c += 1024) s += expf(x[c] - m);
-  s = block_sum<16>(s, red);
+  for (int c = t; c < V; c += 1024) {
+    const float v = x[c];
+    s += expf(v - m);
+    if (v >= tau && v > -__builtin_inff() && !is_banned(c)) {
+      const int slot = atomicAdd(&cand_n, 1);
+      if (slot < F32_TOPK_CAND) cand_v[slot] = v, cand_i[slot] = c;
+    }
+  }
+  s = block_sum<16>(s, red);                         // (its barriers also publish the candidates)
   const float lse = logf(s);
+  const int n_cand = cand_n;
+  if (n_cand <= F32_TOPK_CAND) {
+    if (t < n_cand) {
+      const float v = cand_v[t];
+      const int id = cand_i[t];
+      int rank = 0;
+      for (int d = 0; d < n_cand; ++d) rank += (cand_v[d] > v || (cand_v[d] == v && cand_i[d] < id)) ? 1 : 0;
+      if (rank < k) {
+        out_val[(size_t)blockIdx.x * k + rank] = (v - m) - lse;
+        out_idx[(size_t)blockIdx.x * k + rank] = id;
+      }
+    }
+    if (t >= n_cand && t < k) {                      // fewer than k selectable columns
+      out_val[(size_t)blockIdx.x * k + t] = -__builtin_inff();
+      out_idx[(size_t)blockIdx.x * k + t] = 0x7fffffff;
+    }
+    return;
+  }
+  // general form: k rounds of "the best column after the previous pick"
   float pv = __builtin_inff();
   int pi = -1;
   for (int r = 0; r < k; ++r) {
@@ -293,9 +421,7 @@ __global__ __launch_bounds__(1024) void f32_logprob_topk_kernel(const float* __r
       const float v = x[c];
       const bool after = v < pv || (v == pv && c > pi);
       if (!after || v < best || (v == best && c > bid)) continue;
-      bool ban = false;
-      for (int b = 0; b < n_banned; ++b) ban |= banned[b] == c;
-      if (!ban) best = v, bid = c;
+      if (!is_banned(c)) best = v, bid = c;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -328,10 +454,11 @@ extern "C" int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K % BK || lda % 4 || ldw % 4 || ldc < N || act < 0 || act > 1) return TASU_ERR_ARG;
   if (((uintptr_t)A | (uintptr_t)W) & 15) return TASU_ERR_ARG;
   const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
-  // narrow outputs behind a long K (o / down / q|k|v at <= 64 beam rows: 24-32 tiles): K-range slabs so that the whole chip streams
+  // outputs of fewer than 1024 tiles (every projection at <= 64 beam rows except the lm_head): K-range slabs until ~1024 workgroups
+  // stream (a workgroup keeps 16 KiB in flight; the chip needs a few per CU to reach the HBM rate)
   int ksplit = 1;
-  if (workspace && tiles < 128) {
-    ksplit = 256 / tiles;
+  if (workspace && tiles < 1024) {
+    ksplit = (1024 + tiles - 1) / tiles;
     if (ksplit > 16) ksplit = 16;
     while (ksplit > 1 && ((K / BK) % ksplit || (int64_t)ksplit * M * N > workspace_floats)) --ksplit;
   }
@@ -371,35 +498,49 @@ extern "C" int tasu_f32_kv_fill(const float* qkv, float* kcache, float* vcache, 
   return TASU_OK;
 }
 
-static int f32_attn_lds() {
-  static bool set = false;
-  constexpr int LDS = 4 * (HD + F32_ATTN_MAX_KEYS) * 4;
-  if (!set) {
-    (void)hipFuncSetAttribute((const void*)f32_attn_prefill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute((const void*)f32_attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    set = true;
+template <int REP>
+static int f32_attn_launch(bool decode, const float* qkv, const float* kc, const float* vc, const int32_t* index, const int32_t* kstart,
+                           const int32_t* lens, float* out, int rows, int S, int H, int G, int ctx, float scale, hipStream_t st) {
+  const int lds = (f32_attn_lds_floats<REP>() + (decode ? F32_ATTN_MAX_KEYS : 0)) * 4;
+  static bool set[2] = {false, false};
+  if (!set[decode]) {
+    if (decode) (void)hipFuncSetAttribute((const void*)f32_attn_decode_kernel<REP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else (void)hipFuncSetAttribute((const void*)f32_attn_prefill_kernel<REP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    set[decode] = true;
   }
-  return LDS;
+  if (decode) {
+    TASU_LAUNCH(f32_attn_decode_kernel<REP>, dim3(rows * G), dim3(256), lds, st, qkv, kc, vc, index, kstart, lens, out, rows, H, G, ctx, scale);
+  } else {
+    TASU_LAUNCH(f32_attn_prefill_kernel<REP>, dim3((unsigned)((long long)rows * G)), dim3(256), lds, st, qkv, kstart, out, rows / S, S, H, G,
+                scale);
+  }
+  return TASU_OK;
+}
+static int f32_attn_dispatch(bool decode, const float* qkv, const float* kc, const float* vc, const int32_t* index, const int32_t* kstart,
+                             const int32_t* lens, float* out, int rows, int S, int H, int G, int ctx, float scale, hipStream_t st) {
+  switch (H / G) {
+#define F32_ATTN_CASE(R) \
+  case R: return f32_attn_launch<R>(decode, qkv, kc, vc, index, kstart, lens, out, rows, S, H, G, ctx, scale, st);
+    F32_ATTN_CASE(1) F32_ATTN_CASE(2) F32_ATTN_CASE(3) F32_ATTN_CASE(4) F32_ATTN_CASE(5) F32_ATTN_CASE(6) F32_ATTN_CASE(7) F32_ATTN_CASE(8)
+#undef F32_ATTN_CASE
+    default: return TASU_ERR_ARG;
+  }
 }
 
 extern "C" int tasu_f32_attn_prefill(const float* qkv, const int32_t* kstart, float* out, int B, int S, int H, int G, float scale,
                                      void* stream) {
-  if (!qkv || !kstart || !out || B <= 0 || S <= 0 || S > F32_ATTN_MAX_KEYS || H <= 0 || G <= 0 || H % G) return TASU_ERR_ARG;
-  const long long waves = (long long)B * S * H;
-  TASU_LAUNCH(f32_attn_prefill_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), f32_attn_lds(), (hipStream_t)stream, qkv, kstart, out,
-              B, S, H, G, scale);
-  return TASU_OK;
+  if (!qkv || !kstart || !out || B <= 0 || S <= 0 || S > F32_ATTN_MAX_KEYS || H <= 0 || G <= 0 || H % G || H / G > F32_ATTN_MAX_REP)
+    return TASU_ERR_ARG;
+  return f32_attn_dispatch(false, qkv, nullptr, nullptr, nullptr, kstart, nullptr, out, B * S, S, H, G, 0, scale, (hipStream_t)stream);
 }
 
 extern "C" int tasu_f32_attn_decode(const float* qkv, const float* kcache, const float* vcache, const int32_t* row_index,
                                     const int32_t* kstart, const int32_t* lens, float* out, int M, int H, int G, int ctx, float scale,
                                     void* stream) {
-  if (!qkv || !kcache || !vcache || !row_index || !kstart || !lens || !out || M <= 0 || H <= 0 || G <= 0 || H % G || ctx <= 0 ||
-      ctx > F32_ATTN_MAX_KEYS)
+  if (!qkv || !kcache || !vcache || !row_index || !kstart || !lens || !out || M <= 0 || H <= 0 || G <= 0 || H % G ||
+      H / G > F32_ATTN_MAX_REP || ctx <= 0 || ctx > F32_ATTN_MAX_KEYS)
     return TASU_ERR_ARG;
-  TASU_LAUNCH(f32_attn_decode_kernel, dim3((M * H + 3) / 4), dim3(256), f32_attn_lds(), (hipStream_t)stream, qkv, kcache, vcache, row_index,
-              kstart, lens, out, M, H, G, ctx, scale);
-  return TASU_OK;
+  return f32_attn_dispatch(true, qkv, kcache, vcache, row_index, kstart, lens, out, M, 1, H, G, ctx, scale, (hipStream_t)stream);
 }
 
 extern "C" int tasu_f32_swiglu(const float* gu, float* act, int M, int I, void* stream) {

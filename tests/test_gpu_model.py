@@ -402,6 +402,35 @@ def test_generate_fp32_mode_text_and_audio_fixture():
     assert ((a[:, :n] == z["tokens_audio"][:, :n]).cumprod(1).sum(1) >= 8).all(), (a, z["tokens_audio"])
 
 
+def test_use_fp16_false_selects_the_fp32_decode_through_the_plugin():
+    """The reference's own flag picks the arithmetic (Multitask/scripts/decode_sensevoice.sh runs with use_fp16 unset = false):
+    ``model_factory(train_config.use_fp16=false)`` keeps fp32 copies of the frozen weights and ``model.generate`` runs the fp32
+    path -- the same tokens as calling it directly, and the bf16 path is what ``use_fp16=true`` gets."""
+    from ps_slm_amd.config import ModelConfig, TrainConfig
+    from ps_slm_amd.decode_fp32 import beam_search_generate_fp32
+    from ps_slm_amd.ps_slm import model_factory
+    outs = {}
+    for fp16 in (False, True):
+        tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True, use_fp16=fp16)
+        mc = ModelConfig(llm_path="synthetic:mid", encoder_projector="linear-silu", llm_dim=256)
+        model, tok = model_factory(tc, mc, device="cuda:0", init_seed=77)
+        core = model.core
+        assert core.arith == ("bf16" if fp16 else "fp32") and (core.llm.f32 is None) == fp16
+        raw = synthetic_text_batch(core.geo, 2, seed=5, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8, noise=False)
+        ids = raw["input_ids"][:, :10]
+        am = torch.ones_like(ids, dtype=torch.bool)
+        targets = [" ".join(map(str, p)) for p in raw["post_ids"]]
+        model.eval()
+        outs[fp16] = model.generate(input_ids=ids, attention_mask=am, targets=targets, num_beams=4, max_new_tokens=12).numpy()
+        if not fp16:
+            ids_list = [model.encoder_tokenizer.encode(t) for t in targets]
+            st = core.prepare_text(ids, am, None, ids_list, None, None)
+            direct = beam_search_generate_fp32(core, st, num_beams=4, max_new_tokens=12, eos_token_id=tok.eos_token_id,
+                                               pad_token_id=tok.pad_token_id).numpy()
+            assert np.array_equal(outs[False], direct)
+    assert outs[True].shape[0] == outs[False].shape[0] == 2
+
+
 @pytest.mark.parametrize("nb,min_len,lpw", [(2, 6, 2.0), (3, 4, 0.5), (1, 1, 1.0)])
 def test_generate_other_settings_on_gpu(setup, nb, min_len, lpw):
     """Other beam counts, a minimum length (EOS banned in the log-prob/top-k kernel for the first positions) and length
