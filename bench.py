@@ -31,6 +31,7 @@ from ps_slm_amd.streams import ensure_hw_queues, report as stream_report     # n
 
 ensure_hw_queues()                     # before the first HIP call: a hardware queue each for the main stream and the side-stream roles
 
+PMC_FILE = "r06_gemm_pmc.json"          # this round's counter passes (tools/make_round_artifacts.sh PART=pmc -> tools/pmc_shapes.py)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
@@ -530,12 +531,19 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         # WRITE_SIZE apart: tools/make_round_artifacts.sh PART=pmc): the call-count-weighted mean over the step's GEMM shapes, cold
         # rotating operands, gfx950 x2 fetch correction.  Only for the configuration those passes ran.
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r05_gemm_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", PMC_FILE)
         if os.path.isfile(pmc) and model_name == "qwen2.5-1.5b" and B == 16 and not audio and not variable and core.lora is None:
-            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-            traffic_src = ("bytes per GEMM call, profiles/r05_gemm_pmc.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
-                           "tools/gemm_shapes_run.py (the step's GEMM shapes, cold rotating operands), fetch x2 (gfx950 tallies 16-B/lane "
-                           "streaming reads at half), call-count-weighted over one step; fabric side of the L2s (Infinity-Cache hits included)")
+            from ps_slm_amd._lib import gemm_source_hash
+            rec_pmc = json.load(open(pmc))
+            if rec_pmc.get("gemm_source_hash") == gemm_source_hash():     # the counters describe the kernels that just ran
+                traffic = rec_pmc.get("traffic_bytes_per_launch")
+                traffic_src = (f"bytes per GEMM call, profiles/{PMC_FILE} (gemm_source_hash {rec_pmc['gemm_source_hash']} = this library's "
+                               "kernels): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/gemm_shapes_run.py (the step's "
+                               "GEMM shapes, cold rotating operands), fetch x2 (gfx950 tallies 16-B/lane streaming reads at half), "
+                               "call-count-weighted over one step; fabric side of the L2s (Infinity-Cache hits included)")
+            else:
+                traffic_src = (f"null: profiles/{PMC_FILE} was collected on other GEMM kernel sources (its gemm_source_hash "
+                               f"{rec_pmc.get('gemm_source_hash')} != {gemm_source_hash()}); re-run tools/make_round_artifacts.sh PART=pmc")
         what = ("audio-SFT step (500 feature frames -> SANM encoder -> CTC posterior -> PSD -> projector -> LLM fwd+dgrad bwd+"
                 "projector wgrad+AdamW)" if audio else
                 "text-only CPS alignment step (fwd+dgrad bwd+projector wgrad+AdamW), frozen encoder pass skipped")

@@ -143,6 +143,20 @@ PROTOTYPES.update({
 ABI_VERSION = 13
 _lib = None
 
+GEMM_SOURCES = ("common.h", "gemm_epilogue.h", "gemm.hip", "gemm_pipe.hip", "gemm_pp.hip")
+
+
+def gemm_source_hash():
+    """sha256 (16 hex digits) over the training GEMM kernels' sources: profiles/*_gemm_pmc.json records it, and bench.py reports the
+    counters' ``roofline.traffic`` only while it still describes the kernels that ran (the figure used to go stale
+    silently when the kernels changed)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in GEMM_SOURCES:
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
 
 class TasuLibraryError(RuntimeError):
     pass

@@ -357,7 +357,13 @@ __device__ __forceinline__ void store_tile(const Args& p, f32x4 (&acc)[MI][NI], 
     // before the first use -- one memory round trip per IB row blocks instead of one per fragment; with one tile per CU
     // (N = 1536: o and down projections) nothing else hides this latency
     if ((p.ldc & 3) == 0 && (p.N & 3) == 0 && (((uintptr_t)p.R | (uintptr_t)p.C) & 15) == 0) {
-      constexpr int IB = 2;                       // (the 256-row tiles have no registers to spare: fragment-wise path below)
+      // (IB = 4 -- all four row blocks of a 128-row tile in ONE round trip, 216 instead of 200 VGPRs -- was measured in round 6 with
+      // -DTASU_RESID_IB=4: o 26.7 -> 26.4 us, down 106.0 -> 105.7 us on 28 rotating weight sets: the residual rows' round trips are
+      // not what this epilogue costs; its 2 x 25 MB of fp32 traffic in lock-step on all CUs are)
+#ifndef TASU_RESID_IB
+#define TASU_RESID_IB 2
+#endif
+      constexpr int IB = TASU_RESID_IB;           // (the 256-row tiles have no registers to spare: fragment-wise path below)
       static_assert(MI % IB == 0, "row blocks are processed in groups of IB");
 #pragma unroll
       for (int i0 = 0; i0 < MI; i0 += IB) {

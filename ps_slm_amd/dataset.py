@@ -20,6 +20,7 @@ import io
 import json
 import os
 import random
+import threading
 import re
 import struct
 import sys
@@ -137,6 +138,9 @@ def _unescape(text):
         return text
 
 
+_TOKENIZER_LOCK = threading.Lock()
+
+
 class MultiTaskDataset(IterableDataset):
     """One sample per ``multitask.jsonl`` line of this rank's (and DataLoader worker's) share."""
 
@@ -155,6 +159,10 @@ class MultiTaskDataset(IterableDataset):
         self.max_audio_length = cfg.get("max_audio_length", 30)
         self.sample_rate = SAMPLE_RATE
         self.frontend = frontend                    # callable(waveform float32) -> (features [T, D] tensor, T)
+        # prompt draws: the GLOBAL ``random`` stream like the reference (speech_dataset_large.py:151) unless the caller hands the
+        # split its own generator (``dataset.rng = random.Random(seed)``: the training entrypoint does, so that a reader THREAD and a
+        # validation pass on the main thread never interleave draws on one stream -- ADVICE r5)
+        self.rng = random
         if frontend is None:
             from ps_slm_amd.frontend import WavFrontend
             self.frontend = WavFrontend.from_encoder_path(cfg.get("encoder_path", None))
@@ -185,14 +193,16 @@ class MultiTaskDataset(IterableDataset):
         task, target = item["task"], item["target"]
         feats, n_frames = self._audio(item["path"], decoded)
         # the prompt is drawn from the task's list with the GLOBAL random stream, after the audio has been read
-        text = self.prompt_template.format(random.choice(self.multitask_prompt_list[task]))
+        text = self.prompt_template.format(self.rng.choice(self.multitask_prompt_list[task]))
         if task in self.append_info_tasks:
             text = text.format(item[task])
-        head = self.tokenizer.encode(text)
+        with _TOKENIZER_LOCK:                       # (HF fast tokenizers raise "Already borrowed" under concurrent use: the reader
+            head = self.tokenizer.encode(text)      #  thread tokenises the next training batch while a validation pass runs)
         ids = list(head)
         if not self.inference_mode:
             target = _TARGET_JUNK.sub("", target).lower().strip()
-            ids += self.tokenizer.encode(target) + [self.tokenizer.eos_token_id]
+            with _TOKENIZER_LOCK:
+                ids += self.tokenizer.encode(target) + [self.tokenizer.eos_token_id]
         ids = torch.tensor(ids)
         sample = dict(input_ids=ids, attention_mask=ids.ge(-1), input_features=feats, input_feature_length=n_frames,
                       key=item["key"], target=target, GT=_unescape(item.get("GT", "")))

@@ -149,7 +149,7 @@ class TasuEngine:
         self.micro_steps = 0
         dev = self.core.device
         # (a stream on its own hardware queue: ps_slm_amd/streams.py; only when gradients are exchanged)
-        self.comm_stream = side_stream(dev, "gradient exchange") if self.exchange else None
+        self.comm_stream = side_stream(dev, "gradient exchange", owner=self) if self.exchange else None
         # the collective: RCCL through the C-ABI when the ranks were launched with the nccl backend (one GPU per rank); a gloo
         # group (CPU double; two ranks sharing one GPU in tests) keeps torch.distributed's all_reduce
         self.rccl = None
@@ -287,6 +287,9 @@ class TasuEngine:
         if self.rccl is not None:
             self.rccl.close()
             self.rccl = None
+        if self.comm_stream is not None:
+            from .streams import release
+            release(self.comm_stream)                   # (the engine may be kept alive by a caller's reference: do not wait for gc)
 
     def comm_info(self):
         """What the data-path collective runs on: {"backend", "ranks" (RCCL's own ncclCommCount), "library"}."""

@@ -220,10 +220,11 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
     """Loop body of Multitask/utils/deepspeed_utils.py:190-246 (uneven-data join, forward, backward, step, logging) and
     the validation / save-on-improvement block behind it (:248-290).
 
-    Deviation (stated): the loop holds ONE batch of lookahead -- batch i + 1 is fetched and collated before the forward of batch i
-    -- so the dataset's `random.choice` prompt draws of batch i + 1 come before any draws a validation pass at step i makes.
-    Where validation draws prompts from the same global RNG, runs are therefore not seed-for-seed comparable with the
-    reference's loop across a validation point (the batches themselves, and every run without validation, are identical)."""
+    Deviation (stated): the loop runs AHEAD of the step -- batch i + 1 is fetched and collated before the forward of batch i, and
+    with the reader thread (BatchReader, the default) up to ``depth`` + 2 batches are in flight.  The prompt draws of those batches
+    therefore come before the draws a validation pass at step i makes; ``main`` gives each split its own ``random.Random`` so that
+    the two never share a stream (a fixed seed reproduces a run, with or without validation), but the draws are not those of the
+    reference's loop, whose DataLoader workers each own a forked copy of the global generator."""
     results = {}
     total_loss, total_acc, steps, utts = 0.0, 0.0, 0, 0
     best_val_loss, best_val_acc = float("inf"), 0.0
@@ -331,6 +332,12 @@ def main(argv=None):
     if train_config.run_validation:
         eval_dataset = get_dataset(dataset_config, tokenizer, "val", model.core.geo, rank,
                                    steps=int(cfg.get("synthetic_eval_steps", 2)), batch_size=int(cfg.get("synthetic_batch", 16)))
+    # every split draws its prompts from its OWN generator: the reader thread (training split) and a validation pass (main thread)
+    # would otherwise interleave draws on the global stream in a timing-dependent order
+    for k, ds in enumerate((dataset, eval_dataset)):
+        inner = getattr(ds, "dp", ds)                  # (MultiTaskDynamicBatchDataset wraps the sample dataset)
+        if inner is not None and hasattr(inner, "rng"):
+            inner.rng = random.Random(int(train_config.seed) * 1000003 + 7919 * rank + k)
     results = train(engine, dataset, train_config, log_config, rank, world, eval_dataset)
     if rank == 0:
         for k, v in results.items():

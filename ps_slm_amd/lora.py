@@ -345,7 +345,7 @@ class LoraRunner:
         # the weight-gradient chain of a group (three operand transposes + 2 rank GEMMs per member) feeds nothing of the backward's
         # critical path: it runs on a side stream under the next kernels of the dgrad chain (also inside a captured hipGraph: a
         # fork / join of the capturing stream).  Its workgroup counts (96-560) leave most of the chip to the main stream's GEMMs.
-        self.side = side_stream(model.device, "adapter weight gradients")              # on its own hardware queue (ps_slm_amd/streams.py); None on the CPU double
+        self.side = side_stream(model.device, "adapter weight gradients", owner=self)              # on its own hardware queue (ps_slm_amd/streams.py); None on the CPU double
         self._side_done = {}                               # group -> event: the side chain that read this group's buffers has finished
 
     # ---- workspace

@@ -717,7 +717,7 @@ class TasuModel:
         #  re-allocated inside the pass; every reader of the encoder's buffers is ordered against it by the two events)
         if self._enc_stream is None:
             from .streams import side_stream
-            self._enc_stream = side_stream(self.device, "encoder one batch ahead")   # a stream on another hardware queue than the current one
+            self._enc_stream = side_stream(self.device, "encoder one batch ahead", owner=self)   # a stream on another hardware queue than the current one
         side = self._enc_stream
         if self._psd_done is not None:
             side.wait_event(self._psd_done)               # PSD of the batch in flight has read the logits / encoder states

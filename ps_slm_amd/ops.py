@@ -177,8 +177,16 @@ class HipOps:
             self.dec_sumsq = torch.zeros(4096 // 16 * 64, dtype=torch.float32, device="cuda")
             self.dec_sumsq_in = torch.zeros(8, 4096 // 16 * 64, dtype=torch.float32, device="cuda")    # per 64-row chunk (input norms)
         ks_down = self._stream_split(I)
-        self.dec_frag_act = bool(self.dec_frag and I % 32 == 0 and (ks_down == 1 or (ks_down > 1 and self.dec_down_slabs)))
+        # (the same predicate gemm_skinny_norm routes by: a K-split down projection reads a fragment-order activation only on the
+        # slab route, whose finish serves N = D in 256 * {1, 2, 6, 7, 14} -- ADVICE r5: any other geometry keeps row-major)
+        self.dec_frag_act = bool(self.dec_frag and I % 32 == 0 and
+                                 (ks_down == 1 or (ks_down > 1 and self.dec_down_slabs and self._slab_finish_serves(D))))
         return self.dec_frag
+
+    @staticmethod
+    def _slab_finish_serves(N):
+        """Output widths tasu_stream_finish_norm / _prenorm serve (a wave per 256 columns of a row)."""
+        return N % 256 == 0 and N // 256 in (1, 2, 6, 7, 14)
 
     def end_decode(self):
         self.dec_frag = self.dec_frag_act = False
@@ -490,7 +498,12 @@ class HipOps:
         # the down projection, whose input layout is dec_frag_act
         a_frag = int(self.dec_frag if ks == 1 else self.dec_frag_act)
         y_frag = int(self.dec_frag)
-        if ks > 1 and (not (self.dec_down_slabs or a_frag) or N % 256 or N // 256 not in (1, 2, 6, 7, 14)):
+        need = ks * (N // 16) * 1024 if ks > 1 else 0
+        if ks > 1 and (not (self.dec_down_slabs or a_frag) or not self._slab_finish_serves(N) or ws is None or ws.numel() < need):
+            if a_frag:
+                # begin_decode promised the producer a fragment-order reader: the row-major split-K kernel below would misread it
+                raise TasuOpError(f"gemm_skinny_norm: the activation is in fragment order but the K-range-slab route cannot run "
+                                  f"(N={N}, K={K}, {ks} ranges, workspace {0 if ws is None else ws.numel()} of {need} floats)")
             ks = 0                                          # split-K kernels of gemm_skinny.hip (see begin_decode; the slab
                                                             # finish serves N = 256 * {1, 2, 6, 7, 14})
         wf, wflag = (self._wf(b) if a_frag else (b, 0))

@@ -18,12 +18,21 @@ free queue; what was decided is kept in ``report()`` and goes into the bench rec
 ``GPU_MAX_HW_QUEUES`` to 8 before the first HIP call (``ensure_hw_queues``), which gives main + three roles a queue each with room
 to spare; the probe stays as the check that it did."""
 import os
+import weakref
 
 import torch
 
 _SPIN_CYCLES = 400_000            # ~0.17 ms at 2.4 GHz: long against launch latency, short enough to probe a dozen pairs
 _MAX_TRIES = 12                   # pooled candidates looked at per request
-_state = {}                       # device index -> dict(handed=[(role, stream, verdict)])
+_state = {}                       # device index -> dict(handed=[(role, stream, verdict, weakref to the owner or None)])
+
+
+def _live(st):
+    """(role, stream, verdict) of the handed-out streams whose OWNER is alive; entries of dead owners (an engine, a LoRA runner
+    or a model that was destroyed) are pruned, so that they neither cost probe launches nor show up in the report (ADVICE r5:
+    the list used to grow for the life of the process; torch streams cannot be weakly referenced, their owners can)."""
+    st["handed"] = [h for h in st["handed"] if h[3] is None or h[3]() is not None]
+    return [(r, s, v) for r, s, v, _ in st["handed"]]
 
 
 def ensure_hw_queues(n=8):
@@ -60,37 +69,46 @@ def runs_concurrently(a, b):
     return min(_overlap_fraction(a, b), _overlap_fraction(b, a)) > 0.5
 
 
-def side_stream(device, role="side"):
+def side_stream(device, role="side", owner=None):
     """A NEW stream for work that is to overlap with the CURRENT stream of ``device`` (None on a CPU device): one that runs next
     to the current stream and next to every side stream handed out before on this device.  When the hardware has no free queue
-    left the caller still gets its own stream object, next to the main stream if possible, and ``report()`` says so.  Never call
-    inside a hipGraph capture (probe kernels are launched and the device is synchronised)."""
+    left the caller still gets its own stream object, next to the main stream if possible, and ``report()`` says so.  ``owner``:
+    the object that will hold the stream (engine, model, LoRA runner); when it dies the stream stops counting (``release`` does the
+    same explicitly).  Never call inside a hipGraph capture (probe kernels are launched and the device is synchronised)."""
     device = torch.device(device)
     if device.type != "cuda":
         return None
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _state.setdefault(idx, dict(handed=[]))
+    own = weakref.ref(owner) if owner is not None else None
     if not hasattr(torch.cuda, "_sleep"):                 # (no spin kernel to probe with: any stream)
         s_ = torch.cuda.Stream(device=idx)
-        st["handed"].append((role, s_, "unprobed"))
+        st["handed"].append((role, s_, "unprobed", own))
         return s_
     with torch.cuda.device(idx):
         main = torch.cuda.current_stream()
         fallback = None
+        others = [h for _, h, _ in _live(st)]             # only streams somebody still holds
         for _ in range(_MAX_TRIES):
             c = torch.cuda.Stream(device=idx)
             if not runs_concurrently(main, c):
                 continue                                  # shares the main stream's queue
-            if all(runs_concurrently(h, c) for _, h, _ in st["handed"]):
-                st["handed"].append((role, c, "own queue"))
+            if all(runs_concurrently(h, c) for h in others):
+                st["handed"].append((role, c, "own queue", own))
                 return c
             fallback = fallback or c
         if fallback is not None:
-            st["handed"].append((role, fallback, "next to main, shares a queue with another side stream"))
+            st["handed"].append((role, fallback, "next to main, shares a queue with another side stream", own))
             return fallback
         c = torch.cuda.Stream(device=idx)                 # (a runtime with one hardware queue: overlap is impossible anyway)
-        st["handed"].append((role, c, "shares the main stream's queue"))
+        st["handed"].append((role, c, "shares the main stream's queue", own))
         return c
+
+
+def release(stream):
+    """The holder is done with ``stream`` (TasuEngine.destroy()): it no longer takes part in probes or in the report."""
+    for st in _state.values():
+        st["handed"] = [h for h in st["handed"] if h[1] is not stream]
 
 
 def report(device=None):
@@ -98,5 +116,5 @@ def report(device=None):
     if not torch.cuda.is_available():
         return []
     idx = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
-    return [dict(role=r, verdict=v) for r, _, v in _state.get(idx, dict(handed=[]))["handed"]] + \
+    return [dict(role=r, verdict=v) for r, _, v in _live(_state.get(idx, dict(handed=[])))] + \
            [dict(GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"))]

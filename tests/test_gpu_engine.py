@@ -269,7 +269,20 @@ def test_side_streams_run_next_to_the_main_stream():
     rep = report("cuda")
     assert len(rep) == before + 3 and [r["verdict"] for r in rep if r.get("role", "").startswith("test")] == ["own queue"] * 3
     assert side_stream("cpu") is None
-    del junk
+    # a dead owner's stream stops counting (no probe against it, not in the report); release() does the same explicitly
+    class Owner:
+        pass
+    o1, o2 = Owner(), Owner()
+    s1, s2 = side_stream("cuda", "owned 1", owner=o1), side_stream("cuda", "owned 2", owner=o2)
+    roles = lambda: [r.get("role") for r in report("cuda") if "role" in r]
+    assert roles()[-2:] == ["owned 1", "owned 2"]
+    del o1
+    import gc
+    gc.collect()
+    assert "owned 1" not in roles() and "owned 2" in roles()
+    streams.release(s2)
+    assert "owned 2" not in roles() and roles()[:3] == ["test a", "test b", "test c"]
+    del junk, s1
 
 
 @pytest.mark.parametrize("graphs", [False, True])

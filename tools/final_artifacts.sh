@@ -1,6 +1,6 @@
 # Last pass of a round: decode kernel statistics (1.5B, 7B), the bench line (timed), the same-process A/B logs.  Run through gpurun.
 set -uo pipefail; cd "${GRAFT_REPO_ROOT:?run through gpurun}"; export TMPDIR=/tmp
-A=gpurun_out/art; mkdir -p $A; R=${R:-r05}
+A=gpurun_out/art; mkdir -p $A; R=${R:-r06}
 RP="rocprofv3 --kernel-trace --output-format csv"
 rm -rf $A/prof_decode7b $A/prof_decode
 timeout 600 $RP --stats -d $A/prof_decode7b -- python3 tools/bench_paths.py decode 16 qwen2.5-7b > $A/${R}_decode7b_under_rocprof.json 2> $A/prof_decode7b.err

@@ -1,7 +1,7 @@
 set -euo pipefail; cd "${GRAFT_REPO_ROOT:?run through gpurun (it exports GRAFT_REPO_ROOT)}"; export TMPDIR=/tmp; set +e   # (the runs below report their own exit codes)
 # Round artifacts in one GPU call: the bench line, rocprofv3 kernel statistics of the four measured programs, and the PMC passes
 # (counters in their own runs, --kernel-trace only: never combined with the trace domains).  PART=bench|stats|pmc|all
-R=${R:-r05}; PART=${PART:-all}
+R=${R:-r06}; PART=${PART:-all}
 A=gpurun_out/art; mkdir -p $A
 RP="rocprofv3 --kernel-trace --output-format csv"
 if [ "$PART" = all ] || [ "$PART" = bench ]; then

@@ -41,6 +41,9 @@ for i, (name, m, n, k, mode, sw) in enumerate(SHAPES):
 per_layer = {"qkv", "o", "gate_up+swiglu", "down", "d_down", "d_gate_up", "d_o", "d_qkv"}
 tot = sum((28 if k in per_layer else 1) * (v["fetch_bytes"] + v["write_bytes"]) for k, v in out["shapes"].items())
 cnt = sum(28 if k in per_layer else 1 for k in out["shapes"])
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ps_slm_amd._lib import gemm_source_hash  # noqa: E402
+out["gemm_source_hash"] = gemm_source_hash()            # the kernels these counters describe (bench.py checks it)
 out["traffic_bytes_per_launch"] = int(tot / cnt)       # per GEMM CALL (a split call is two kernel launches): call-count-weighted mean of one step's GEMMs
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
