@@ -67,6 +67,7 @@ class TimedOps:
         self.recording = False         # collect the GEMM calls of a step (for the GEMM-only graph replay)
         self.calls = []
         self.replay_ms = None          # (ms per replay of the recorded calls, number of calls)
+        self.kernel_launches = None    # GEMM kernel launches of the recorded step (tasu_gemm_launch_count difference)
 
     def __getattr__(self, name):
         return getattr(self._ops, name)
@@ -503,9 +504,14 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         step()
         sync()
         timed.recording = rank == 0
+        lib = getattr(core.ops, "lib", None)
+        k0 = int(lib.tasu_gemm_launch_count()) if lib is not None else 0
         step()
         sync()
         timed.recording = False
+        # kernel launches behind this step's GEMM calls (a column-split call is two; lm_head split-K adds its own) -- counted by the
+        # library itself; the encoder's GEMMs of an audio step that runs one batch ahead are launched by the same step() call
+        timed.kernel_launches = (int(lib.tasu_gemm_launch_count()) - k0) if lib is not None else None
         if rank == 0:
             timed.time_replay(steps)
         core.use_graphs = True
@@ -527,6 +533,7 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         else:
             gemm_ms, n_launch = timed.total_ms(), len(timed.events)
         achieved = gemm_flops_step * steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        k_launch = timed.kernel_launches if timed.kernel_launches else n_launch // max(steps, 1)
         # HBM-side bytes per GEMM call come from the round's own PMC passes (counters need their own rocprofv3 --pmc runs, FETCH_SIZE and
         # WRITE_SIZE apart: tools/make_round_artifacts.sh PART=pmc): the call-count-weighted mean over the step's GEMM shapes, cold
         # rotating operands, gfx950 x2 fetch correction.  Only for the configuration those passes ran.
@@ -572,9 +579,10 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "kernel": "tasu_pp::gemm_pp_kernel + tasu_pipe::gemm_pipe_kernel (tasu_gemm_nt_bf16_ws, tasu_gemm_gate_up_swiglu, tasu_gemm_qkv_rope, tasu_gemm_dswiglu, tasu_gemm_nt_bf16_splitk)",
-                         "launches_per_step": n_launch // max(steps, 1),
-                         "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
-                         "algorithmic_gflop_per_launch": round(gemm_flops_step * steps / max(n_launch, 1) / 1e9, 2),
+                         # launches = KERNEL launches (what rocprofv3's per-kernel average counts); calls = C-ABI GEMM calls
+                         "launches_per_step": k_launch, "calls_per_step": n_launch // max(steps, 1),
+                         "avg_launch_us": round(gemm_ms * 1e3 / max(steps, 1) / max(k_launch, 1), 2),
+                         "algorithmic_gflop_per_launch": round(gemm_flops_step / max(k_launch, 1) / 1e9, 2),
                          "gemm_ms_per_step": round(gemm_ms / max(steps, 1), 3),
                          "launch": "hipGraph replay" if core.use_graphs else "eager",
                          "passes_note": ("value / ms_per_step: hipGraph replay of the timed steps; achieved / avg_launch_us: the step's "
@@ -625,7 +633,7 @@ SUB_METRICS = {"audio_sft": " (audio-SFT, config 4)", "qwen2.5-7b": " (Qwen2.5-7
                "decode_fp32": None}                     # (carries its own metric: decode tokens/s in the reference's fp32 arithmetic)
 
 STDOUT_LINE_LIMIT = 8000           # the driver's record keeps ~8,000 characters of stdout and parses the line from them
-_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step", "kernel_launches_per_step",
+_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step", "calls_per_step",
               "avg_launch_us", "gemm_ms_per_step", "launch", "whole_step_frac", "whole_step_frac_at_survey_flops")
 
 

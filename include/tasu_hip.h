@@ -626,6 +626,11 @@ int tasu_comm_count(void* comm, int* count);                     /* ncclCommCoun
 int tasu_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
 int tasu_allreduce_min_i32(void* comm, int32_t* buf, int64_t n, void* stream);
 
+/* HOST: kernel launches of the bf16 GEMM kernel families (gemm_nt / gemm_pipe / gemm_pp) since the library was loaded.  bench.py
+ * takes the difference around one eager step: a GEMM CALL whose columns are split over two tile shapes is two launches, and
+ * roofline.avg_launch_us is quoted per kernel launch, the unit of rocprofv3's per-kernel average (profiles/r06_bench_summary.md).  */
+int64_t tasu_gemm_launch_count(void);
+
 /* ------------------------------------------------------------------------------------------ fp32 arithmetic mode (decode)
  * train_config.use_fp16 = false: the reference decodes with fp32 weights and no autocast (Multitask/inference_batch.py:113-117,146:
  * `model.eval()`, no `.half()`, `model.generate(**batch)`; Multitask/model/ps-slm.py:660-675 -> HF generate on the fp32 Qwen2).

@@ -110,7 +110,7 @@ PROTOTYPES = {
     "tasu_embed_rows": [vp, vp, vp, i32, i32, vp],
     "tasu_decode_step_prologue": [vp, vp, vp, vp, vp, f32, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp],
 }
-RESTYPE_I64 = set()
+RESTYPE_I64 = {"tasu_gemm_launch_count"}
 PROTOTYPES.update({
     "tasu_scale_softmax_rows_bf16": [vp, vp, vp, i32, i32, i32, f32, vp],
     "tasu_softmax_bwd_rows_bf16": [vp, vp, vp, vp, i32, i32, i32, f32, vp],
@@ -128,6 +128,7 @@ PROTOTYPES.update({
     "tasu_comm_count": [vp, vp],
     "tasu_allreduce_f32": [vp, vp, i64, vp],
     "tasu_allreduce_min_i32": [vp, vp, i64, vp],
+    "tasu_gemm_launch_count": [],
     # fp32 arithmetic mode of the decode path (csrc/fp32.hip)
     "tasu_f32_gemm_nt": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "tasu_f32_rmsnorm": [vp, vp, vp, i32, i32, f32, vp],

@@ -280,6 +280,7 @@ int launch(GemmArgs a, hipStream_t st) {
   }
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
+  ++tasu_gemm::gemm_launches();
   TASU_LAUNCH((gemm_nt_kernel<BM, BN, NWM, NWN, OUT_MODE, HAS_BIAS, SCHED, SPLITK>),
               dim3(a.tiles_m * a.tiles_n * (SPLITK ? a.ksplit : 1)), dim3(64 * NWM * NWN), LDS, st, a);
   return TASU_OK;
@@ -517,6 +518,10 @@ static int gemm_policy(const void* A, int lda, const void* B, int ldb, void* C, 
 }
 
 namespace tasu_gemm {
+long long& gemm_launches() {
+  static long long n = 0;
+  return n;
+}
 int& relu_next() {
   static thread_local int flag = 0;
   return flag;
@@ -526,6 +531,8 @@ int& act_ld_next() {
   return v;
 }
 }  // namespace tasu_gemm
+
+extern "C" int64_t tasu_gemm_launch_count(void) { return (int64_t)tasu_gemm::gemm_launches(); }
 
 extern "C" int tasu_relu_fwd(const void* x, void* y, int64_t n, void* stream);
 // C = bf16(relu(bf16(A . B^T + bias))): PositionwiseFeedForward's w_1 + ReLU (SenseVoice.py:71-73) in one launch -- the ReLU in

@@ -45,6 +45,10 @@ struct Args {
   int relu = 0;          // TASU_GEMM_OUT_BF16 only: C = bf16(max(acc + bias, 0)) (tasu_gemm_bias_relu_bf16: PositionwiseFeedForward w_1)
 };
 
+// kernel launches of the three GEMM kernel families since the library was loaded (tasu_gemm_launch_count: bench.py counts the
+// launches behind its GEMM CALLS -- a column-split call is two -- so that roofline.avg_launch_us is per kernel launch, the unit
+// rocprofv3's per-kernel average has)
+long long& gemm_launches();
 // set by tasu_gemm_bias_relu_bf16 around its call of the dispatcher (host; the dispatchers copy it into Args::relu)
 int& relu_next();
 // likewise for tasu_gemm_gate_up_swiglu_ld: the act leading dimension of the next gate|up launch (0 = I)

@@ -269,6 +269,7 @@ int launch(Args a, hipStream_t st) {
   a.tiles_n = OUT_MODE == OUT_GU_SWIGLU ? (n_end - a.n0 + 63) / 64 : (n_end - a.n0 + BN - 1) / BN;
   const int ntiles = a.tiles_m * a.tiles_n * a.ksplit;
   const int grid = ntiles < cu_count() ? ntiles : cu_count();
+  ++tasu_gemm::gemm_launches();
   TASU_LAUNCH((gemm_pipe_kernel<BM, BN, OUT_MODE, HAS_BIAS>), dim3(grid), dim3(512), LDS, st, a);
   return TASU_OK;
 }

@@ -443,6 +443,7 @@ int launch(Args a, hipStream_t st) {
   a.sk_tiles = a.ksplit == 1 && (long long)ntiles * (a.K / 128) < (1 << 22) ? sk_plan(ntiles, a.K / 128, G, a.sk_flags && a.sk_partial, a.sk_rem > -1.5 ? a.sk_rem : sk_max_rem()) : 0;
   if (!a.sk_tiles) a.sk_flags = nullptr, a.sk_partial = nullptr;
   const int grid = a.sk_tiles || ntiles >= G ? G : ntiles;
+  ++tasu_gemm::gemm_launches();
   TASU_LAUNCH((gemm_pp_kernel<OUT_MODE, HAS_BIAS>), dim3(grid), dim3(512), LDS, st, a);
   return TASU_OK;
 }

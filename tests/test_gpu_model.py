@@ -419,11 +419,12 @@ def test_use_fp16_false_selects_the_fp32_decode_through_the_plugin():
         raw = synthetic_text_batch(core.geo, 2, seed=5, prompt_len=9, n_audio=21, target_len=17, speech_pos=4, feat_frames=8, noise=False)
         ids = raw["input_ids"][:, :10]
         am = torch.ones_like(ids, dtype=torch.bool)
-        targets = [" ".join(map(str, p)) for p in raw["post_ids"]]
+        targets = ["ab cde f ghij kl m", "no pq rst uvw"]       # (generate() strips everything but letters: ps-slm.py:592-596)
         model.eval()
         outs[fp16] = model.generate(input_ids=ids, attention_mask=am, targets=targets, num_beams=4, max_new_tokens=12).numpy()
         if not fp16:
             ids_list = [model.encoder_tokenizer.encode(t) for t in targets]
+            assert all(len(p) > 0 for p in ids_list)
             st = core.prepare_text(ids, am, None, ids_list, None, None)
             direct = beam_search_generate_fp32(core, st, num_beams=4, max_new_tokens=12, eos_token_id=tok.eos_token_id,
                                                pad_token_id=tok.pad_token_id).numpy()
