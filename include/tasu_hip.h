@@ -640,8 +640,8 @@ int64_t tasu_gemm_launch_count(void);
  * GenerationMixin._beam_search.  The KV cache has the layout of tasu_kv_fill (rows = beams, position-major, fp32) and shares
  * tasu_kv_index_init / tasu_kv_index_reorder, tasu_rope_table, tasu_embed_rows, tasu_beam_update with the bf16 path.
  *
- * tasu_f32_gemm_nt: C[M, N] = [resid +] act(A[M, K] . W[N, K]^T + bias), act 0 = none, 1 = SiLU (x / (1 + exp(-x)));
- * v_mfma_f32_16x16x4_f32, K % 16 == 0, lda / ldw % 4 == 0, 16-byte aligned operands; resid may alias C.  With a workspace,
+ * tasu_f32_gemm_nt: C[M, N] = [resid +] act(A[M, K] . W[N, K]^T + bias), act 0 = none, 1 = SiLU (x / (1 + exp(-x))), 2 = ReLU;
+ * v_mfma_f32_16x16x4_f32, K % 32 == 0, lda / ldw % 4 == 0, 16-byte aligned operands; resid may alias C.  With a workspace,
  * outputs of fewer than 128 tiles of 64 x 64 are computed as up to 16 K-range slabs (ksplit * M * N floats) summed in ascending
  * order by a second launch -- deterministic.                                                                                     */
 int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
@@ -654,9 +654,14 @@ int tasu_f32_rope(float* qkv, const float* cos_tab, const float* sin_tab, int M,
                   const int32_t* slot, int ctx, void* stream);
 /* K / V of a (rotated) prefill activation [B*S, (H+2G)*128] -> cache row b * n_beams, positions 0 .. S-1 (cache [B*n_beams, ctx, G*128]) */
 int tasu_f32_kv_fill(const float* qkv, float* kcache, float* vcache, int B, int S, int H, int G, int n_beams, int ctx, void* stream);
-/* causal GQA attention of the prompt: query s of batch row b attends keys [kstart[b], s] (left padding masked; rows s < kstart[b]
- * get zeros); out [B*S, H*128].  S <= 2048.                                                                                      */
-int tasu_f32_attn_prefill(const float* qkv, const int32_t* kstart, float* out, int B, int S, int H, int G, float scale, void* stream);
+/* attention over a whole sequence, out [B*S, H*128], S <= 2048.  klen == NULL: the decoder's causal prompt pass, query s of batch
+ * row b attends keys [kstart[b], s] (left padding masked; rows s < kstart[b] get zeros).  klen != NULL: bidirectional with key
+ * padding (the SANM encoder, Multitask/model/SenseVoice.py:209-228): every query s < klen[b] attends keys [0, klen[b]).            */
+int tasu_f32_attn_prefill(const float* qkv, const int32_t* kstart, const int32_t* klen, float* out, int B, int S, int H, int G,
+                          float scale, void* stream);
+/* FSMN memory block in fp32 (SenseVoice.py:124-140): out[b, t, :] += conv_k(masked v) + masked v for t < lens[b] (tasu_fsmn_fwd with
+ * accumulate = 1 on an fp32 v of row stride ldv).                                                                                */
+int tasu_f32_fsmn(const float* v, int ldv, const float* w, const int32_t* lens, float* out, int B, int T, int D, int ksize, void* stream);
 /* single-token GQA attention over the fp32 cache: semantics of tasu_attn_decode (row_index required); out [M, H*128]; ctx <= 2048 */
 int tasu_f32_attn_decode(const float* qkv, const float* kcache, const float* vcache, const int32_t* row_index, const int32_t* kstart,
                          const int32_t* lens, float* out, int M, int H, int G, int ctx, float scale, void* stream);

@@ -134,7 +134,8 @@ PROTOTYPES.update({
     "tasu_f32_rmsnorm": [vp, vp, vp, i32, i32, f32, vp],
     "tasu_f32_rope": [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp],
     "tasu_f32_kv_fill": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
-    "tasu_f32_attn_prefill": [vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "tasu_f32_attn_prefill": [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "tasu_f32_fsmn": [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
     "tasu_f32_attn_decode": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "tasu_f32_swiglu": [vp, vp, i32, i32, vp],
     "tasu_f32_embed_merge": [vp, vp, i32, vp, vp, vp, i32, i32, vp],

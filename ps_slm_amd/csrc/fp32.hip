@@ -14,6 +14,7 @@ constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 1;
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.f + expf(-x)); }
+__device__ __forceinline__ float act_f(float v, int act) { return act == 1 ? silu_exact(v) : (act == 2 ? fmaxf(v, 0.f) : v); }
 
 // C[m, n] (+)= sum_k A[m, k] W[n, k] over the K range of blockIdx.z.  ksplit == 1: C = [resid +] act(acc + bias).
 // ksplit > 1: the raw partial goes to slab blockIdx.z ([M, N] each, row stride N); f32_sum_slabs_kernel finishes.
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(const float* __restrict__
         float v = acc[i][j][r];
         if (ksplit == 1) {
           if (bias) v += bias[n + r];
-          if (act == 1) v = silu_exact(v);
+          v = act_f(v, act);
           if (resid) v = resid[(size_t)m * ldc + n + r] + v;
         }
         out[(size_t)m * ldo + n + r] = v;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void f32_sum_slabs_kernel(const float* __restr
   float v = slabs[idx];
   for (int s = 1; s < ksplit; ++s) v += slabs[(size_t)s * M * N + idx];
   if (bias) v += bias[n];
-  if (act == 1) v = silu_exact(v);
+  v = act_f(v, act);
   if (resid) v = resid[(size_t)m * ldc + n] + v;
   C[(size_t)m * ldc + n] = v;
 }
@@ -273,7 +274,8 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
 // prefill: one workgroup per (batch row, position, KV head); query s of batch row b sees keys [kstart[b], s] (causal, left padding masked)
 template <int REP>
 __global__ __launch_bounds__(256) void f32_attn_prefill_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ kstart,
-                                                               float* __restrict__ out, int B, int S, int H, int G, float scale) {
+                                                               const int32_t* __restrict__ klen, float* __restrict__ out, int B, int S,
+                                                               int H, int G, float scale) {
   extern __shared__ float smem[];
   const long long id = blockIdx.x;
   const int g = (int)(id % G);
@@ -281,13 +283,16 @@ __global__ __launch_bounds__(256) void f32_attn_prefill_kernel(const float* __re
   const int b = (int)(bs / S), s = (int)(bs - (long long)b * S);
   const int LD = (H + 2 * G) * HD;
   float* o = out + (size_t)bs * (H * HD) + g * REP * HD;
-  const int k_lo = kstart[b];
-  if (s < k_lo) {                                   // a padding position: no visible key; its output is never read
+  // klen == NULL: causal decoder prompt, keys [kstart[b], s]; else bidirectional with key padding (SANM encoder,
+  // SenseVoice.py:209-228): every query sees keys [0, klen[b])
+  const int k_lo = klen ? 0 : kstart[b];
+  const int k_hi = klen ? klen[b] : s + 1;
+  if (s < k_lo || k_hi <= k_lo || (klen && s >= k_hi)) {   // a padding position: its output is never read
     for (int i = threadIdx.x; i < REP * HD; i += 256) o[i] = 0.f;
     return;
   }
   const float* base = qkv + (size_t)b * S * LD;
-  f32_attn_group<REP>(base + (size_t)s * LD + g * REP * HD, k_lo, s + 1, scale, o, smem,
+  f32_attn_group<REP>(base + (size_t)s * LD + g * REP * HD, k_lo, k_hi, scale, o, smem,
                       [&](int j) { return base + (size_t)j * LD + (H + g) * HD; },
                       [&](int j) { return base + (size_t)j * LD + (H + G + g) * HD; });
 }
@@ -445,13 +450,35 @@ __global__ __launch_bounds__(1024) void f32_logprob_topk_kernel(const float* __r
   }
 }
 
+// FSMN memory block of the SANM layer in fp32 (SenseVoice.py:124-140; tasu_fsmn_fwd with an fp32 v): out[b, t, :] += depthwise
+// conv over time (ksize taps, centred) of the masked v + the masked v itself, frames t >= lens[b] untouched.  v: column block of
+// the fused q|k|v activation (row stride ldv).
+__global__ __launch_bounds__(256) void f32_fsmn_kernel(const float* __restrict__ v, int ldv, const float* __restrict__ w,
+                                                       const int32_t* __restrict__ lens, float* __restrict__ out, int T, int D, int ksize,
+                                                       long long total) {
+  const int left = (ksize - 1) / 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int d = (int)(i % D);
+  const long long bt = i / D;
+  const int t = (int)(bt % T), b = (int)(bt / T), len = lens[b];
+  if (t >= len) return;
+  float r = 0.f;
+  for (int j = 0; j < ksize; ++j) {
+    const int tt = t + j - left;
+    if (tt >= 0 && tt < len) r += w[d * ksize + j] * v[((size_t)b * T + tt) * ldv + d];
+  }
+  r += v[((size_t)b * T + t) * ldv + d];
+  out[i] += r;
+}
+
 }  // namespace tasu_f32
 
 using namespace tasu_f32;
 
 extern "C" int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
                                 int M, int N, int K, int act, float* workspace, int64_t workspace_floats, void* stream) {
-  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K % BK || lda % 4 || ldw % 4 || ldc < N || act < 0 || act > 1) return TASU_ERR_ARG;
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K % BK || lda % 4 || ldw % 4 || ldc < N || act < 0 || act > 2) return TASU_ERR_ARG;
   if (((uintptr_t)A | (uintptr_t)W) & 15) return TASU_ERR_ARG;
   const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
   // outputs of fewer than 1024 tiles (every projection at <= 64 beam rows except the lm_head): K-range slabs until ~1024 workgroups
@@ -501,6 +528,7 @@ extern "C" int tasu_f32_kv_fill(const float* qkv, float* kcache, float* vcache, 
 template <int REP>
 static int f32_attn_launch(bool decode, const float* qkv, const float* kc, const float* vc, const int32_t* index, const int32_t* kstart,
                            const int32_t* lens, float* out, int rows, int S, int H, int G, int ctx, float scale, hipStream_t st) {
+  // (prefill: `lens` = klen [B] or NULL)
   const int lds = (f32_attn_lds_floats<REP>() + (decode ? F32_ATTN_MAX_KEYS : 0)) * 4;
   static bool set[2] = {false, false};
   if (!set[decode]) {
@@ -511,8 +539,8 @@ static int f32_attn_launch(bool decode, const float* qkv, const float* kc, const
   if (decode) {
     TASU_LAUNCH(f32_attn_decode_kernel<REP>, dim3(rows * G), dim3(256), lds, st, qkv, kc, vc, index, kstart, lens, out, rows, H, G, ctx, scale);
   } else {
-    TASU_LAUNCH(f32_attn_prefill_kernel<REP>, dim3((unsigned)((long long)rows * G)), dim3(256), lds, st, qkv, kstart, out, rows / S, S, H, G,
-                scale);
+    TASU_LAUNCH(f32_attn_prefill_kernel<REP>, dim3((unsigned)((long long)rows * G)), dim3(256), lds, st, qkv, kstart, lens, out, rows / S, S,
+                H, G, scale);
   }
   return TASU_OK;
 }
@@ -527,11 +555,12 @@ static int f32_attn_dispatch(bool decode, const float* qkv, const float* kc, con
   }
 }
 
-extern "C" int tasu_f32_attn_prefill(const float* qkv, const int32_t* kstart, float* out, int B, int S, int H, int G, float scale,
-                                     void* stream) {
-  if (!qkv || !kstart || !out || B <= 0 || S <= 0 || S > F32_ATTN_MAX_KEYS || H <= 0 || G <= 0 || H % G || H / G > F32_ATTN_MAX_REP)
+extern "C" int tasu_f32_attn_prefill(const float* qkv, const int32_t* kstart, const int32_t* klen, float* out, int B, int S, int H, int G,
+                                     float scale, void* stream) {
+  if (!qkv || (!kstart && !klen) || !out || B <= 0 || S <= 0 || S > F32_ATTN_MAX_KEYS || H <= 0 || G <= 0 || H % G ||
+      H / G > F32_ATTN_MAX_REP)
     return TASU_ERR_ARG;
-  return f32_attn_dispatch(false, qkv, nullptr, nullptr, nullptr, kstart, nullptr, out, B * S, S, H, G, 0, scale, (hipStream_t)stream);
+  return f32_attn_dispatch(false, qkv, nullptr, nullptr, nullptr, kstart, klen, out, B * S, S, H, G, 0, scale, (hipStream_t)stream);
 }
 
 extern "C" int tasu_f32_attn_decode(const float* qkv, const float* kcache, const float* vcache, const int32_t* row_index,
@@ -541,6 +570,15 @@ extern "C" int tasu_f32_attn_decode(const float* qkv, const float* kcache, const
       H / G > F32_ATTN_MAX_REP || ctx <= 0 || ctx > F32_ATTN_MAX_KEYS)
     return TASU_ERR_ARG;
   return f32_attn_dispatch(true, qkv, kcache, vcache, row_index, kstart, lens, out, M, 1, H, G, ctx, scale, (hipStream_t)stream);
+}
+
+extern "C" int tasu_f32_fsmn(const float* v, int ldv, const float* w, const int32_t* lens, float* out, int B, int T, int D, int ksize,
+                             void* stream) {
+  if (!v || !w || !lens || !out || B <= 0 || T <= 0 || D <= 0 || ksize <= 0 || ldv < D) return TASU_ERR_ARG;
+  const long long total = (long long)B * T * D;
+  TASU_LAUNCH(f32_fsmn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, ldv, w, lens, out, T, D, ksize,
+              total);
+  return TASU_OK;
 }
 
 extern "C" int tasu_f32_swiglu(const float* gu, float* act, int M, int I, void* stream) {

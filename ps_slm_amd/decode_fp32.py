@@ -8,8 +8,10 @@ weights), fp32 embeddings and residual stream, fp32 q|k|v / RoPE / attention / M
 fp32 KV cache, fp32 logits, log-softmax and top-k -- csrc/fp32.hip through the C-ABI (``tasu_f32_*``).  The beam search itself is the
 same device-side bookkeeping as the bf16 path's (``tasu_beam_update``, the cache row index, ``DeviceBeam``), and a generated
 position is one hipGraph replay.  Nothing is rounded to bf16; sums run in another order than the reference's CPU BLAS (fp32 MFMA,
-K ascending, K-range slabs added in ascending order: deterministic).  The frozen SenseVoice encoder of the audio branch stays on
-the bf16 kernels (the reference runs it in fp32 too: not built; the text branch, which BASELINE's configs decode, is all fp32).
+K ascending, K-range slabs added in ascending order: deterministic).  The audio branch runs the frozen SenseVoice encoder, the CTC
+softmax and PSD in fp32 as well (ps_slm_amd/encoder.py: encoder_posterior_fp32; TasuModel.prepare_audio takes it when
+``arith == "fp32"`` and no labels are given).  Pinned by exact token equality with the REAL reference on 24 unfiltered random cases,
+the 17 rounding-stable ones and the text + audio fixture (tests/test_gpu_model.py).
 
 HBM-bound like the bf16 step, on twice the bytes: 6.2 GB of fp32 weights per generated position at Qwen2.5-1.5B.
 """

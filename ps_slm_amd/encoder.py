@@ -22,8 +22,9 @@ def rup(x, m):
 
 
 class EncoderWeights:
-    def __init__(self, geo, device):
+    def __init__(self, geo, device, keep_f32=False):
         self.geo, self.device = geo, torch.device(device)
+        self.keep_f32 = bool(keep_f32)        # fp32 copies next to the bf16 ones (fp32 arithmetic mode of generate(): encoder_posterior_fp32)
         if geo.enc_dim // geo.enc_heads != HD:
             raise ValueError("the gfx950 attention kernel needs d_k = 128 (SenseVoiceSmall: 512 / 4)")
         self.layers = []
@@ -38,15 +39,23 @@ class EncoderWeights:
             wp = torch.zeros(w.shape[0], kpad, device=dev)
             wp[:, : w.shape[1]] = w
             w = wp
+        if self.keep_f32:
+            self._f32_last = (w.contiguous(), b.to(dev, torch.float32).contiguous())
         return w.to(torch.bfloat16).contiguous(), b.to(dev, torch.bfloat16).contiguous()
 
     def _add_layer(self, sd, p, in_dim):
         dev, f32 = self.device, torch.float32
         kp = rup(in_dim, 64)
-        wqkv, bqkv = self._lin(sd[p + "self_attn.linear_q_k_v.weight"], sd[p + "self_attn.linear_q_k_v.bias"], kp)
-        wout, bout = self._lin(sd[p + "self_attn.linear_out.weight"], sd[p + "self_attn.linear_out.bias"])
-        w1, b1 = self._lin(sd[p + "feed_forward.w_1.weight"], sd[p + "feed_forward.w_1.bias"])
-        w2, b2 = self._lin(sd[p + "feed_forward.w_2.weight"], sd[p + "feed_forward.w_2.bias"])
+        f32w = {}
+        def lin(tag, w, b, kpad=None):
+            out = self._lin(w, b, kpad)
+            if self.keep_f32:
+                f32w["w" + tag], f32w["b" + tag] = self._f32_last
+            return out
+        wqkv, bqkv = lin("qkv", sd[p + "self_attn.linear_q_k_v.weight"], sd[p + "self_attn.linear_q_k_v.bias"], kp)
+        wout, bout = lin("out", sd[p + "self_attn.linear_out.weight"], sd[p + "self_attn.linear_out.bias"])
+        w1, b1 = lin("1", sd[p + "feed_forward.w_1.weight"], sd[p + "feed_forward.w_1.bias"])
+        w2, b2 = lin("2", sd[p + "feed_forward.w_2.weight"], sd[p + "feed_forward.w_2.bias"])
 
         def ln(name, n):
             g = torch.zeros(rup(n, 64), device=dev)
@@ -58,7 +67,7 @@ class EncoderWeights:
         E, ks = self.geo.enc_dim, self.geo.enc_kernel
         self.layers.append(dict(in_dim=in_dim, kp=kp, n1=ln("norm1", in_dim), n2=ln("norm2", E), wqkv=wqkv, bqkv=bqkv,
                                 wout=wout, bout=bout, w1=w1, b1=b1, w2=w2, b2=b2,
-                                fsmn=sd[p + "self_attn.fsmn_block.weight"].to(dev, f32).reshape(E, ks).contiguous()))
+                                fsmn=sd[p + "self_attn.fsmn_block.weight"].to(dev, f32).reshape(E, ks).contiguous(), f32=f32w))
 
     def load_reference_state_dict(self, sd, pre="encoder."):
         geo, dev, f32 = self.geo, self.device, torch.float32
@@ -73,6 +82,7 @@ class EncoderWeights:
         self.after_norm = (sd[pre + "encoder.after_norm.weight"].to(dev, f32), sd[pre + "encoder.after_norm.bias"].to(dev, f32))
         self.tp_norm = (sd[pre + "encoder.tp_norm.weight"].to(dev, f32), sd[pre + "encoder.tp_norm.bias"].to(dev, f32))
         self.ctc_w, self.ctc_b = self._lin(sd[pre + "ctc.ctc_lo.weight"], sd[pre + "ctc.ctc_lo.bias"])
+        self.ctc_f32 = self._f32_last if self.keep_f32 else None
 
     def init_random(self, seed):
         from .synthetic import random_state_dict
@@ -177,6 +187,68 @@ def _encoder_body(model, x0, lens, key_mask, B, T, want_post=True):
     post = buf("enc_post", (M, Kp), f32)
     ops.softmax_rows(logits, post, M, V)
     return post
+
+
+def encoder_posterior_fp32(model, feats, feat_lens):
+    """The frozen encoder + CTC head + softmax in fp32 (train_config.use_fp16 = false: the reference's inference runs
+    SenseVoiceEncoderSmall.forward without autocast, Multitask/model/ps-slm.py:430-454 under inference_batch.py:113-117): fp32
+    LayerNorms, fp32 GEMMs (tasu_f32_gemm_nt on fp32 copies of the weights), fp32 bidirectional attention and FSMN (csrc/fp32.hip).
+    Returns (posterior fp32 [B * Te, Kp], Te, lens int32 device [B]) like encoder_posterior(want_post=True)."""
+    ops, geo, enc, dev = model.ops, model.geo, model.encoder, model.device
+    if enc is None or not enc.keep_f32:
+        raise RuntimeError("fp32 audio decode needs the encoder's fp32 weight copies (train_config.use_fp16=false before loading)")
+    B, T, Fd = feats.shape
+    E, Hh, Ff, V = geo.enc_dim, geo.enc_heads, geo.enc_ffn, geo.ctc_vocab
+    Te, Kp = T + 4, rup(V, 64)
+    M = B * Te
+    f32 = torch.float32
+    buf = model._buf
+    x0 = buf("enc_x0", (B, Te, Fd), f32)
+    x0[:, :4].copy_(enc.embed[list(QUERY_ROWS)].unsqueeze(0).expand(B, -1, -1))
+    x0[:, 4:].copy_(feats.to(dev, f32, non_blocking=True))
+    lens_h = (np.asarray(feat_lens.cpu() if isinstance(feat_lens, torch.Tensor) else feat_lens).astype(np.int64) + 4)
+    lens = model._upload("enc_lens", lens_h.astype(np.int32))
+    ws = buf("f32_gemm_ws", (16 * 128 * 4096,), f32)
+    x = buf("enc_x", (M, Fd), f32)
+    ops.sinusoid_pe(x0.view(M, Fd), x, B, Te, Fd, float(E) ** 0.5)
+    qkv = buf("f32_enc_qkv", (M, 3 * E), f32)
+    ao = buf("f32_enc_ao", (M, E), f32)
+    xa, xb = buf("enc_xa", (M, E), f32), buf("enc_xb", (M, E), f32)
+    h = buf("f32_enc_h", (M, Ff), f32)
+    scale = HD ** -0.5
+    cur = x
+    for li, w in enumerate(enc.layers):
+        f = w["f32"]
+        if li == enc.n_main:
+            nxt = xa if cur is not xa else xb
+            ops.layernorm_fwd(cur, enc.after_norm[0], enc.after_norm[1], nxt, None, None, M, E, 1e-5)
+            cur = nxt
+        xn = buf("f32_enc_xn", (M, w["kp"]), f32)
+        ops.layernorm_fwd(cur, w["n1"][0], w["n1"][1], xn, None, None, M, w["in_dim"], 1e-5)
+        ops.f32_gemm(xn, f["wqkv"], qkv, M, 3 * E, w["kp"], bias=f["bqkv"], ws=ws)
+        ops.f32_attn_prefill(qkv, None, ao, B, Te, Hh, Hh, scale, klen=lens)
+        mid = xa if cur is not xa else xb
+        ops.f32_gemm(ao, f["wout"], mid, M, E, E, bias=f["bout"], resid=cur if w["in_dim"] == E else None, ws=ws)   # no residual on layer 0
+        ops.f32_fsmn(qkv[:, 2 * E:], 3 * E, w["fsmn"], lens, mid, B, Te, E, geo.enc_kernel)                      # x += fsmn(v)
+        xn2 = buf("f32_enc_xn2", (M, E), f32)
+        ops.layernorm_fwd(mid, w["n2"][0], w["n2"][1], xn2, None, None, M, E, 1e-5)
+        ops.f32_gemm(xn2, f["w1"], h, M, Ff, E, bias=f["b1"], act=2, ws=ws)
+        out = xb if mid is xa else xa
+        ops.f32_gemm(h, f["w2"], out, M, E, Ff, bias=f["b2"], resid=mid, ws=ws)
+        cur = out
+    if len(enc.layers) == enc.n_main:
+        nxt = xa if cur is not xa else xb
+        ops.layernorm_fwd(cur, enc.after_norm[0], enc.after_norm[1], nxt, None, None, M, E, 1e-5)
+        cur = nxt
+    encf = buf("enc_outf", (M, E), f32)
+    ops.layernorm_fwd(cur, enc.tp_norm[0], enc.tp_norm[1], encf, None, None, M, E, 1e-5)
+    logits = buf("f32_enc_logits", (M, Kp), f32)
+    if Kp > V:
+        logits[:, V:].zero_()
+    ops.f32_gemm(encf, enc.ctc_f32[0], logits, M, V, E, bias=enc.ctc_f32[1], ws=ws)
+    post = buf("enc_post", (M, Kp), f32)
+    ops.softmax_rows(logits, post, M, V)
+    return post, Te, lens
 
 
 def psd_on_device(model, post, B, T, Te, feat_lens_dev, do_psd=True, k=1, feats=None, logits=False):

@@ -489,7 +489,7 @@ class TasuModel:
         if any(k.startswith("encoder.") for k in sd):
             from .encoder import EncoderWeights
             self._encoder_replaced()
-            self.encoder = EncoderWeights(self.geo, self.device)
+            self.encoder = EncoderWeights(self.geo, self.device, keep_f32=self.llm.keep_f32)
             self.encoder.load_reference_state_dict(sd)
 
     def _encoder_replaced(self):
@@ -510,7 +510,7 @@ class TasuModel:
         if with_encoder:
             from .encoder import EncoderWeights
             self._encoder_replaced()
-            self.encoder = EncoderWeights(self.geo, self.device)
+            self.encoder = EncoderWeights(self.geo, self.device, keep_f32=self.llm.keep_f32)
             self.encoder.init_random(seed + 2)
 
     def init_projector_default(self, seed=42):
@@ -549,7 +549,7 @@ class TasuModel:
         raw = raw.get("state_dict", raw)
         sd = {"encoder." + k: v.float() for k, v in raw.items()}
         self._encoder_replaced()
-        self.encoder = EncoderWeights(self.geo, self.device)
+        self.encoder = EncoderWeights(self.geo, self.device, keep_f32=self.llm.keep_f32)
         self.encoder.load_reference_state_dict(sd)
 
     def sync_projector_copies(self):
@@ -659,13 +659,18 @@ class TasuModel:
         gives every utterance len // k rows (projector.py:41-45, ps-slm.py:482)."""
         from .encoder import psd_on_device
         B, T, _ = input_features.shape
-        post, Te = self._encoder_output(input_features, input_feature_length)      # the CTC head's logits
+        fp32 = self.arith == "fp32" and labels is None                             # generate() with use_fp16 = false: fp32 encoder too
+        if fp32:
+            from .encoder import encoder_posterior_fp32
+            post, Te, _ = encoder_posterior_fp32(self, input_features, input_feature_length)      # the fp32 posterior
+        else:
+            post, Te = self._encoder_output(input_features, input_feature_length)  # the CTC head's logits
         fl = np.asarray(input_feature_length.cpu() if isinstance(input_feature_length, torch.Tensor) else input_feature_length)
         fl_dev = self._upload("feat_lens", fl.astype(np.int32))
         kk = self.proj.k
         src = self._ws["enc_outf"][: post.shape[0] * self.geo.enc_dim].view(post.shape[0], self.geo.enc_dim) if self.raw_features else None
         try:
-            rows, new_lens, Lmax = psd_on_device(self, post, B, T, Te, fl_dev, do_psd, k=kk, feats=src, logits=True)
+            rows, new_lens, Lmax = psd_on_device(self, post, B, T, Te, fl_dev, do_psd, k=kk, feats=src, logits=not fp32)
         finally:
             if self.device.type == "cuda":             # the encoder's output buffers are free for the next pass from here on
                 self._psd_done = self._psd_done or torch.cuda.Event()

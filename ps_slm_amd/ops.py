@@ -657,8 +657,13 @@ class HipOps:
     def f32_kv_fill(self, qkv, kc, vc, B, S, H, G, nb, ctx):
         self._chk(self.lib.tasu_f32_kv_fill(_p(qkv), _p(kc), _p(vc), B, S, H, G, nb, ctx, self._stream()), "tasu_f32_kv_fill")
 
-    def f32_attn_prefill(self, qkv, kstart, out, B, S, H, G, scale):
-        self._chk(self.lib.tasu_f32_attn_prefill(_p(qkv), _p(kstart), _p(out), B, S, H, G, scale, self._stream()), "tasu_f32_attn_prefill")
+    def f32_attn_prefill(self, qkv, kstart, out, B, S, H, G, scale, klen=None):
+        """klen None: causal over keys [kstart[b], s]; else bidirectional over keys [0, klen[b]) (the SANM encoder)."""
+        self._chk(self.lib.tasu_f32_attn_prefill(_p(qkv), _p(kstart), _p(klen), _p(out), B, S, H, G, scale, self._stream()),
+                  "tasu_f32_attn_prefill")
+
+    def f32_fsmn(self, v, ldv, w, lens, out, B, T, D, ksize):
+        self._chk(self.lib.tasu_f32_fsmn(_p(v), ldv, _p(w), _p(lens), _p(out), B, T, D, ksize, self._stream()), "tasu_f32_fsmn")
 
     def f32_attn_decode(self, qkv, kc, vc, index, kstart, lens, out, M, H, G, ctx, scale):
         self._chk(self.lib.tasu_f32_attn_decode(_p(qkv), _p(kc), _p(vc), _p(index), _p(kstart), _p(lens), _p(out), M, H, G, ctx, scale,
