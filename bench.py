@@ -480,6 +480,8 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
     # hipGraph replay cannot carry per-launch event pairs, so with graphs the GEMM launches are timed in a second,
     # eager pass over the same number of steps right after the timed region (same kernels, same shapes, same data).
     timed.enabled = on_gpu and rank == 0 and not core.use_graphs
+    lib0 = getattr(core.ops, "lib", None)
+    k_eager0 = int(lib0.tasu_gemm_launch_count()) if (timed.enabled and lib0 is not None) else None
     engine.time_exchange = exchanging
     engine.exposed_events = []
     t0 = time.perf_counter()
@@ -490,6 +492,8 @@ def train_leg(args, model_name, path, B, steps, warmup, world, rank, local_rank,
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    if k_eager0 is not None:                            # eager launches: the GEMM kernel launches of the timed steps themselves
+        timed.kernel_launches = (int(lib0.tasu_gemm_launch_count()) - k_eager0) // max(steps, 1)
     timed.enabled = False
     exposed_ms = engine.exposed_ms() / max(steps, 1) if exchanging else 0.0
     engine.time_exchange = False

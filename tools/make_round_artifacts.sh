@@ -14,7 +14,11 @@ if [ "$PART" = all ] || [ "$PART" = stats ]; then
   timeout 600 $RP --stats -d $A/prof_audio -- python3 bench.py --path audio --blank-biased --blank-bias 13.0 --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-extra --no-graphs > $A/${R}_audio_under_rocprof.json 2> $A/prof_audio.err
   timeout 600 $RP --stats -d $A/prof_lora -- python3 bench.py --lora --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-extra --no-graphs > $A/${R}_lora_under_rocprof.json 2> $A/prof_lora.err
   timeout 600 $RP --stats -d $A/prof_decode7b -- python3 tools/bench_paths.py decode 16 qwen2.5-7b > $A/${R}_decode7b_under_rocprof.json 2> $A/prof_decode7b.err
-  for p in bench decode audio lora decode7b; do f=$(find $A/prof_$p -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $A/${R}_${p}_kernel_stats.csv; done
+  timeout 600 $RP --stats -d $A/prof_decodef32 -- python3 tools/bench_decode_fp32.py > $A/${R}_decodef32_under_rocprof.json 2> $A/prof_decodef32.err
+  for p in bench decode audio lora decode7b decodef32; do f=$(find $A/prof_$p -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $A/${R}_${p}_kernel_stats.csv; done
+  # the graph-replayed step's timeline: kernel time against idle time between kernels (tools/trace_gaps.py)
+  timeout 600 $RP -d $A/prof_gaps -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-decode --no-extra > /dev/null 2> $A/prof_gaps.err
+  python tools/trace_gaps.py $A/prof_gaps 5 > $A/${R}_step_gaps.txt 2>&1
 fi
 if [ "$PART" = all ] || [ "$PART" = pmc ]; then
   # per-shape GEMM traffic (cold rotating operands), FETCH and WRITE in separate passes
