@@ -5,7 +5,7 @@
 //     only.  Each K-step is two phases of 32 (24) MFMAs; every phase carries the 12 (11) ds_read_b128 of the NEXT phase,
 //     interleaved with sched_group_barrier, so a wave hides its own LDS latency; one raw s_barrier per K-step sits
 //     between the phases.
-//   * waves 4..7 ("loader waves") do nothing but fill a 3-slot LDS ring two K-steps ahead with
+//   * waves 4..7 ("loader waves") do nothing but fill an NS-slot LDS ring NS - 1 K-steps ahead (NS = 3, ring_slots) with
 //     buffer_load_dwordx4 ... lds (base = the tile's first A / B row in a buffer descriptor, per-lane 32-bit offset fixed
 //     per tile, K offset in an SGPR) and wait for it with a counted vmcnt that leaves the newest slot in flight.
 //     Why separate waves: an LDS-DMA costs its issuing wave ~100 cycles of address processing during which that wave's
@@ -17,9 +17,9 @@
 //     noise on the decoder shapes (the per-tile cost that remains, ~4 us of a 25-us K = 1536 tile, is the epilogue's own
 //     issue time plus the write of C itself: time = 35 us + K * 0.115 us for 4096 x 17920, i.e. 1.27 PFLOP/s asymptotic).
 //
-// Ring safety: slot (q+2)%3 == (q-1)%3 is refilled after barrier(q-1), before which every MFMA wave waited for its last
+// Ring safety: slot (q+NS-1)%NS == (q-1)%NS is refilled after barrier(q-1), before which every MFMA wave waited for its last
 // reads of step q-1 (lgkmcnt(0)); step q+1 is complete in LDS before barrier(q) because every loader waited for its own
-// share first.  The LDS image is lane-linear per 1-KiB piece (8 rows x 128 B), so the bank swizzle (16-B chunk c of row r
+// share first (a counted vmcnt that leaves only the YOUNGER steps' pieces in flight: loads complete in order).  The LDS image is lane-linear per 1-KiB piece (8 rows x 128 B), so the bank swizzle (16-B chunk c of row r
 // at chunk c ^ ((r>>1)&7)) is applied on the per-lane SOURCE offset and again on the ds_read_b128 address.
 #include <stdlib.h>
 
@@ -31,11 +31,25 @@ using namespace tasu_gemm;
 
 constexpr int BK = 64;
 
+// Slots of the LDS ring: the loader waves run NS - 1 K-steps ahead of the MFMA waves.  Three everywhere.  A fourth slot fits the
+// CU's 160 KiB for the 128 x 192 tile (4 x 40 KiB) and was measured in round 6 (-DTASU_PIPE_NS4): one more K-step of lookahead for
+// the cold weight panels changes nothing -- o 26.7 -> 27.0-27.9 us, down 106.8 -> 107.2 us (tools/lab_resid_gemms.py, 28 rotating
+// weight sets), the step 28.27 / 28.32 / 28.34 -> 28.43 / 28.35 / 28.41 ms (alternating processes, one box).  So the K loop is
+// not waiting for operands that a deeper ring would have brought earlier; the ring depth stays a parameter.
+__host__ __device__ constexpr int ring_slots(int bm, int bn) {
+#ifdef TASU_PIPE_NS4
+  return 4 * (bm + bn) * BK * 2 <= 160 * 1024 ? 4 : 3;
+#else
+  return 3;
+#endif
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 
 template <int BM, int BN, int OUT_MODE, bool HAS_BIAS>
 __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int NS = ring_slots(BM, BN);           // LDS ring slots (3; see ring_slots)
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
   constexpr int PA = BM / 32, PB = BN / 32;       // LDS-DMA pieces per loader wave per K-step: 8 + 4 (or 3)
   constexpr int NG = PA + PB;                      // vmcnt units per K-step per loader wave
@@ -120,30 +134,43 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
         if (ld_tile < ntiles) setup(ld_tile);
       }
     };
-    auto wait_keep_one_step = [&]() {              // all but the newest K-step's pieces have landed
-      if constexpr (NG == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if constexpr (NG == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    // "all but the newest KEEP K-steps' pieces have landed" (counted vmcnt: KEEP * NG pieces stay in flight)
+    auto wait_keep = [&](auto keep_tag) {
+      constexpr int N = decltype(keep_tag)::value * NG;
+      if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+      else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else static_assert(N == 0, "add the immediate");
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    // before barrier(q) step q + 1 must be complete; the steps behind it that exist (at most NS - 2) stay in flight
+    auto wait_for_step = [&](int newest_issued, int needed) {
+      const int keep = newest_issued - needed;       // wave-uniform
+      if (NS == 4 && keep >= 2) wait_keep(K2{});
+      else if (keep >= 1) wait_keep(K1{});
+      else wait_keep(K0{});
     };
     setup(ld_tile);
-    issue(0);
-    if (total > 1) {
-      issue(1);
-      wait_keep_one_step();
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    int issued = 0;                                  // K-steps issued so far (the stream position of the next issue)
+    for (; issued < NS - 1 && issued < total; ++issued) issue(issued);
+    wait_for_step(issued - 1, 0);
     __builtin_amdgcn_s_barrier();
-    int slot2 = 2;                                 // ring slot of step q+2
+    int slot_new = NS - 1;                           // ring slot of step q + NS - 1
     for (int q = 0; q < total; ++q) {
-      if (q + 2 < total) {
-        issue(slot2);
-        wait_keep_one_step();
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (issued < total) {
+        issue(slot_new);
+        ++issued;
       }
-      __builtin_amdgcn_s_barrier();                // step q+1 is in LDS; slot (q-1)%3 is free (see "Ring safety" above)
-      slot2 = slot2 == 2 ? 0 : slot2 + 1;
+      if (q + 1 < total) wait_for_step(issued - 1, q + 1);
+      else wait_keep(K0{});
+      __builtin_amdgcn_s_barrier();                // step q+1 is in LDS; slot (q-1) % NS is free (see "Ring safety" above)
+      slot_new = slot_new == NS - 1 ? 0 : slot_new + 1;
     }
 #endif
     return;
@@ -190,7 +217,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(Args p) {
   // Straight-line code (no branches inside) so that sched_group_barrier can interleave across the whole phase.
   auto kstep = [&](auto more_tag, int cur) {
     constexpr bool MORE = decltype(more_tag)::value;
-    const int nxt = cur == 2 ? 0 : cur + 1;
+    const int nxt = cur == NS - 1 ? 0 : cur + 1;
     // ---------------- phase 1: MFMA(q, k-half 0)  ||  reads (q, k-half 1)
     read_frags(fa1, fb1, cur, 1);
     mma(fa0, fb0);
@@ -257,7 +284,7 @@ int cu_count() {
 
 template <int BM, int BN, int OUT_MODE, bool HAS_BIAS>
 int launch(Args a, hipStream_t st) {
-  constexpr int LDS = 3 * (BM + BN) * BK * 2;
+  constexpr int LDS = ring_slots(BM, BN) * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<BM, BN, OUT_MODE, HAS_BIAS>,
