@@ -191,3 +191,49 @@ def test_decode_entrypoint_on_a_corpus(tmp_path):
     assert [p[0] for p in pred] == keys and [g[1] for g in gt] == targets
     assert [p[1] for p in pred] == texts
     assert any(p[1] for p in pred)                                    # something was decoded
+
+
+def test_upload_pack_slots_growth_and_ring():
+    """TasuModel.UploadPack (round 6): the step's host -> device inputs travel as one pinned asynchronous copy.  Named slots keep their
+    device addresses while an array fits (captured graphs keep reading them), a name that outgrows its slot moves (and bumps the
+    workspace generation so that graphs captured on the old address die), non-adjacent puts flush as separate copies, deferred
+    puts are invisible until the flush, and the pinned ring survives many more flushes than it has buffers."""
+    import numpy as np
+    from ps_slm_amd.model import Geometry, TasuModel
+    from ps_slm_amd.ops import HipOps
+    from ps_slm_amd.synthetic import MID_GEOMETRY
+    m = TasuModel(Geometry.from_dict(MID_GEOMETRY), HipOps(), "cuda")
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 1000, 100).astype(np.int32)
+    b = rng.random(33).astype(np.float32)
+    c = (rng.random((4, 7)) > 0.5)
+    da, db = m._upload("a", a, flush=False), m._upload("b", b, flush=False)
+    dc = m._upload("c", c)                                                  # flushes all three: adjacent slots, one copy
+    torch.cuda.synchronize()
+    assert np.array_equal(da.cpu().numpy(), a) and np.array_equal(db.cpu().numpy(), b) and np.array_equal(dc.cpu().numpy(), c)
+    assert da.dtype == torch.int32 and db.dtype == torch.float32 and dc.dtype == torch.bool and dc.shape == (4, 7)
+    ptr_a, gen = da.data_ptr(), m._buf_gen
+    # same name, smaller array: same address; a middle name alone: its own copy, the neighbours untouched
+    a2 = a[:40] + 1
+    da2 = m._upload("a", a2)
+    b2 = b * 2
+    db2 = m._upload("b", b2)
+    torch.cuda.synchronize()
+    assert da2.data_ptr() == ptr_a and m._buf_gen == gen
+    assert np.array_equal(da2.cpu().numpy(), a2) and np.array_equal(db2.cpu().numpy(), b2) and np.array_equal(dc.cpu().numpy(), c)
+    assert np.array_equal(da.cpu().numpy()[40:], a[40:])                       # the tail of the old, longer array is still there
+    # a name that outgrows its slot moves and invalidates captured graphs
+    big = rng.integers(0, 1000, 5000).astype(np.int32)
+    dbig = m._upload("a", big)
+    torch.cuda.synchronize()
+    assert dbig.data_ptr() != ptr_a and m._buf_gen == gen + 1 and np.array_equal(dbig.cpu().numpy(), big)
+    # many flushes (ring of four pinned buffers) while the device is busy: every upload arrives intact
+    x = torch.randn(4096, 4096, device="cuda")
+    outs = []
+    for i in range(12):
+        x = x @ x * 1e-3                                                        # keeps the stream busy: the copies queue behind it
+        arr = np.full(257, i, dtype=np.int32)
+        outs.append((i, m._upload(f"r{i % 3}", arr).clone()))
+    torch.cuda.synchronize()
+    assert all(int(t[0]) == i and int(t[-1]) == i for i, t in outs)
+    assert m._upload("empty", np.zeros((0, 3), dtype=np.float32)).shape == (0, 3)

@@ -1,0 +1,233 @@
+"""The fp32 decode family (csrc/fp32.hip, ``tasu_f32_*``) kernel by kernel against plain PyTorch fp32 / float64 on the same inputs.
+Tolerances: these kernels round nowhere to bf16; what differs from torch is the order of fp32 sums, so results agree to a few
+fp32 ulps of the largest term (1e-5 relative to the tensor's scale; top-k INDICES are exact).  The assembled path is pinned
+token for token against the real reference in tests/test_gpu_model.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HD = 128
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ps_slm_amd.ops import HipOps
+    return HipOps()
+
+
+def randn(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def close(a, b, tol=1e-5):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) < tol
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 1536, 1536), (64, 1536, 8960), (7, 2048, 1536), (64, 17920, 1536), (300, 520, 96), (1, 64, 32),
+                                   (130, 200, 25088)])
+@pytest.mark.parametrize("act,bias,resid", [(0, False, False), (1, True, False), (2, True, True), (0, True, True)])
+def test_gemm_fp32(ops, M, N, K, act, bias, resid):
+    """C = [resid +] act(A W^T + bias) against float64: tiles of 64 x 64 x 32 with ragged edges, one K range and K-range slabs
+    (narrow outputs get a workspace and split), in-place residual."""
+    a, w = randn(M, K, seed=1), randn(N, K, seed=2, scale=K ** -0.5)
+    b = randn(N, seed=3) if bias else None
+    r = randn(M, N, seed=4) if resid else None
+    ref = a.double() @ w.double().t()
+    if bias:
+        ref = ref + b.double()
+    if act == 1:
+        ref = ref / (1 + torch.exp(-ref))
+    elif act == 2:
+        ref = ref.clamp_min(0)
+    if resid:
+        ref = ref + r.double()
+    ws = torch.empty(16 * 128 * 4096, device="cuda")
+    for use_ws in (False, True):
+        c = r.clone() if resid else torch.full((M, N), float("nan"), device="cuda")
+        ops.f32_gemm(a, w, c, M, N, K, bias=b, resid=c if resid else None, act=act, ws=ws if use_ws else None)   # resid aliases C
+        torch.cuda.synchronize()
+        assert close(c, ref, 2e-5), (use_ws, float((c.double() - ref).abs().max()))
+    # the slab route is deterministic: two runs, the same bits
+    c1, c2 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.f32_gemm(a, w, c1, M, N, K, bias=b, act=act, ws=ws)
+    ops.f32_gemm(a, w, c2, M, N, K, bias=b, act=act, ws=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2)
+
+
+@pytest.mark.parametrize("M,D", [(64, 1536), (5, 256), (130, 3584)])
+def test_rmsnorm_fp32(ops, M, D):
+    x, w = randn(M, D, seed=5, scale=3.0), randn(D, seed=6) + 1.0
+    y = torch.empty_like(x)
+    ops.f32_rmsnorm(x, w, y, M, D, 1e-6)
+    ref = w.double() * (x.double() * torch.rsqrt(x.double().pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert close(y, ref)
+
+
+@pytest.mark.parametrize("M,H,G", [(64, 12, 2), (9, 2, 1), (33, 28, 4)])
+def test_rope_and_cache_append_fp32(ops, M, H, G):
+    """q and k heads rotated in place like transformers' apply_rotary_pos_emb (x * cos + rotate_half(x) * sin, fp32), v untouched;
+    with a cache the rotated k and the v rows land at cache[row, slot[row]]."""
+    LD, W, ctx = (H + 2 * G) * HD, G * HD, 40
+    qkv0 = randn(M, LD, seed=7)
+    pos = torch.randint(0, 500, (M,), dtype=torch.int32).cuda()
+    cos, sin = torch.empty(M, 64, device="cuda"), torch.empty(M, 64, device="cuda")
+    ops.rope_table(pos, cos, sin, HD, 1e6)
+    c, s = torch.cat([cos, cos], -1)[:, None, :], torch.cat([sin, sin], -1)[:, None, :]
+    x = qkv0.view(M, H + 2 * G, HD).clone()
+    rot = torch.cat([-x[..., 64:], x[..., :64]], -1)
+    ref = x.clone()
+    ref[:, : H + G] = x[:, : H + G] * c + rot[:, : H + G] * s
+    qkv = qkv0.clone()
+    ops.f32_rope(qkv, cos, sin, M, H, G)
+    assert torch.equal(qkv.view(M, H + 2 * G, HD)[:, H + G:], x[:, H + G:])          # v: not touched
+    assert close(qkv, ref.view(M, LD), 1e-6)
+    kc, vc = torch.zeros(M * ctx * W, device="cuda"), torch.zeros(M * ctx * W, device="cuda")
+    slot = torch.randint(0, ctx, (M,), dtype=torch.int32).cuda()
+    qkv2 = qkv0.clone()
+    ops.f32_rope(qkv2, cos, sin, M, H, G, kc, vc, slot, ctx)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv2, qkv)
+    kcv, vcv = kc.view(M, ctx, W), vc.view(M, ctx, W)
+    rows = torch.arange(M).cuda()
+    assert torch.equal(kcv[rows, slot.long()], qkv[:, H * HD:(H + G) * HD]) and torch.equal(vcv[rows, slot.long()], qkv[:, (H + G) * HD:])
+    assert float(kc.abs().sum()) == pytest.approx(float(qkv[:, H * HD:(H + G) * HD].abs().sum()), rel=1e-5)     # nothing else written
+
+
+def _attn_ref(q, k, v, allow, scale):
+    """q [H, Sq, d], k / v [G, Sk, d], allow bool [Sq, Sk] -> [H, Sq, d] in float64 (GQA: head h uses KV head h // (H / G))."""
+    H, G = q.shape[0], k.shape[0]
+    rep = H // G
+    kk, vv = k.double().repeat_interleave(rep, 0), v.double().repeat_interleave(rep, 0)
+    sc = (q.double() @ kk.transpose(-1, -2)) * scale
+    sc = sc.masked_fill(~allow[None], float("-inf"))
+    return torch.softmax(sc, -1) @ vv
+
+
+@pytest.mark.parametrize("B,S,H,G", [(2, 70, 12, 2), (1, 256, 2, 1), (3, 33, 28, 4), (2, 300, 4, 4)])
+def test_attention_prefill_fp32(ops, B, S, H, G):
+    """Causal prompt attention with left padding, and the bidirectional form with key lengths (the SANM encoder's)."""
+    LD = (H + 2 * G) * HD
+    qkv = randn(B * S, LD, seed=8)
+    scale = HD ** -0.5
+    kstart = torch.tensor([(7 * b) % max(S // 3, 1) for b in range(B)], dtype=torch.int32).cuda()
+    out = torch.empty(B * S, H * HD, device="cuda")
+    ops.f32_attn_prefill(qkv, kstart, out, B, S, H, G, scale)
+    x = qkv.view(B, S, H + 2 * G, HD)
+    for b in range(B):
+        ks = int(kstart[b])
+        q, k, v = x[b, :, :H].transpose(0, 1), x[b, :, H:H + G].transpose(0, 1), x[b, :, H + G:].transpose(0, 1)
+        idx = torch.arange(S).cuda()
+        allow = (idx[None, :] <= idx[:, None]) & (idx[None, :] >= ks)
+        ref = _attn_ref(q, k, v, allow, scale).transpose(0, 1).reshape(S, H * HD)
+        got = out.view(B, S, H * HD)[b]
+        assert close(got[ks:], ref[ks:]), b
+        assert float(got[:ks].abs().sum()) == 0.0                                         # padding rows: zeros
+    klen = torch.tensor([S - (5 * b) % (S // 2) for b in range(B)], dtype=torch.int32).cuda()
+    ops.f32_attn_prefill(qkv, None, out, B, S, H, G, scale, klen=klen)
+    for b in range(B):
+        n = int(klen[b])
+        q, k, v = x[b, :, :H].transpose(0, 1), x[b, :, H:H + G].transpose(0, 1), x[b, :, H + G:].transpose(0, 1)
+        allow = (torch.arange(S).cuda()[None, :] < n).expand(S, S)
+        ref = _attn_ref(q, k, v, allow, scale).transpose(0, 1).reshape(S, H * HD)
+        assert close(out.view(B, S, H * HD)[b, :n], ref[:n]), b
+
+
+@pytest.mark.parametrize("B,nb,S,new,H,G", [(2, 4, 20, 9, 12, 2), (1, 3, 5, 30, 2, 1), (3, 2, 11, 4, 28, 4)])
+def test_attention_decode_fp32_through_the_beam_index(ops, B, nb, S, new, H, G):
+    """Single-token attention over the fp32 cache: key i of beam row m is read from cache row index[m, i] (the prompt lives in
+    the utterance's first beam row, later positions wherever the reorders left them), keys [kstart, lens)."""
+    M, ctx, W, LD = B * nb, S + new, G * HD, (H + 2 * G) * HD
+    kc, vc = randn(M, ctx, W, seed=9), randn(M, ctx, W, seed=10)
+    qkv = randn(M, LD, seed=11)
+    g = torch.Generator().manual_seed(12)
+    index = torch.empty(M, ctx, dtype=torch.int32)
+    for m in range(M):
+        b = m // nb
+        index[m, :S] = b * nb
+        index[m, S:] = torch.randint(b * nb, (b + 1) * nb, (new,), generator=g).int()
+    index = index.cuda()
+    kstart = torch.tensor([(3 * (m // nb)) % S for m in range(M)], dtype=torch.int32).cuda()
+    lens = torch.tensor([S + 1 + (m % new) for m in range(M)], dtype=torch.int32).cuda()
+    out = torch.empty(M, H * HD, device="cuda")
+    scale = HD ** -0.5
+    ops.f32_attn_decode(qkv, kc.view(-1), vc.view(-1), index, kstart, lens, out, M, H, G, ctx, scale)
+    for m in range(M):
+        lo, hi = int(kstart[m]), int(lens[m])
+        pos = torch.arange(lo, hi).cuda()
+        rows = index[m, lo:hi].long()
+        k = kc[rows, pos].view(hi - lo, G, HD).transpose(0, 1)
+        v = vc[rows, pos].view(hi - lo, G, HD).transpose(0, 1)
+        q = qkv[m, : H * HD].view(H, 1, HD)
+        ref = _attn_ref(q, k, v, torch.ones(1, hi - lo, dtype=torch.bool).cuda(), scale).reshape(H * HD)
+        assert close(out[m], ref), m
+
+
+def test_swiglu_embed_merge_kv_fill_fsmn_fp32(ops):
+    M, I = 37, 520
+    gu = randn(M, 2 * I, seed=13, scale=2.0)
+    act = torch.empty(M, I, device="cuda")
+    ops.f32_swiglu(gu, act, M, I)
+    g, u = gu[:, :I].double(), gu[:, I:].double()
+    assert close(act, g / (1 + torch.exp(-g)) * u, 1e-6)
+    # embedding merge
+    V, D, R = 50, 256, 9
+    table, proj = randn(V, D, seed=14), randn(R, D + 64, seed=15)
+    kind = torch.tensor([0, 1, 2, 2, 1, 0, 2], dtype=torch.int32).cuda()
+    src = torch.tensor([0, 7, 3, 8, 49, 0, 0], dtype=torch.int32).cuda()
+    x = torch.empty(7, D, device="cuda")
+    ops.f32_embed_merge(table, proj, kind, src, x, 7, D)
+    ref = torch.stack([torch.zeros(D).cuda() if k == 0 else (table[s] if k == 1 else proj[s, :D]) for k, s in zip(kind.tolist(), src.tolist())])
+    assert torch.equal(x, ref)
+    # prompt K / V into the cache rows of the first beams
+    B, S, H, G, nb, ctx = 2, 6, 4, 2, 3, 10
+    W, LD = G * HD, (H + 2 * G) * HD
+    qkv = randn(B * S, LD, seed=16)
+    kc, vc = torch.zeros(B * nb, ctx, W, device="cuda"), torch.zeros(B * nb, ctx, W, device="cuda")
+    ops.f32_kv_fill(qkv, kc.view(-1), vc.view(-1), B, S, H, G, nb, ctx)
+    for b in range(B):
+        assert torch.equal(kc[b * nb, :S], qkv.view(B, S, LD)[b, :, H * HD:(H + G) * HD]) and torch.equal(vc[b * nb, :S], qkv.view(B, S, LD)[b, :, (H + G) * HD:])
+    assert float(kc[1].abs().sum()) == 0.0
+    # FSMN memory block (SenseVoice.py:124-140) against a conv1d restatement
+    B, T, Dm, ks = 2, 23, 64, 11
+    v = randn(B * T, 3 * Dm, seed=17)
+    w = randn(Dm, ks, seed=18)
+    lens = torch.tensor([23, 15], dtype=torch.int32).cuda()
+    out0 = randn(B * T, Dm, seed=19)
+    out = out0.clone()
+    ops.f32_fsmn(v[:, 2 * Dm:], 3 * Dm, w, lens, out, B, T, Dm, ks)
+    vv = v[:, 2 * Dm:].reshape(B, T, Dm).double()
+    mask = (torch.arange(T).cuda()[None, :] < lens[:, None]).double()[..., None]
+    xin = (vv * mask).transpose(1, 2)
+    mem = torch.nn.functional.conv1d(torch.nn.functional.pad(xin, ((ks - 1) // 2, ks - 1 - (ks - 1) // 2)), w.double()[:, None, :], groups=Dm)
+    ref = out0.double().view(B, T, Dm) + ((mem.transpose(1, 2) + vv * mask) * mask)
+    assert close(out.view(B, T, Dm), ref)
+
+
+@pytest.mark.parametrize("M,V,k", [(64, 151936, 8), (3, 1000, 2), (5, 70, 8), (2, 4097, 16)])
+def test_logprob_topk_fp32(ops, M, V, k):
+    """(x - max) - log(sum exp(x - max)) of the k best selectable columns: values against torch.log_softmax in fp32, indices exact
+    (ties: smaller column first), banned columns skipped; a row of massive ties takes the round-by-round form."""
+    logits = randn(M, V, seed=20, scale=4.0)
+    logits[0] = 0.5                                                                    # row 0: one winner, then V - 1 columns tied
+    logits[0, 5] = 99.0                                                                # (more than the candidate list holds when V is large)
+    banned = torch.tensor([int(logits[1 % M].argmax()), 3], dtype=torch.int32).cuda()
+    for nban in (0, 2):
+        val, idx = torch.empty(M, k, device="cuda"), torch.empty(M, k, dtype=torch.int32, device="cuda")
+        ops.f32_logprob_topk(logits, M, V, k, banned, nban, val, idx)
+        torch.cuda.synchronize()
+        x64 = logits.double().cpu()
+        lp32 = torch.log_softmax(logits, -1).cpu()
+        if nban:
+            x64[:, banned.cpu().long()] = float("-inf")
+        # reference order: logit descending (log_softmax is monotone), column ascending
+        order = torch.from_numpy(np.lexsort((np.arange(V)[None, :].repeat(M, 0), -x64.numpy()), axis=-1)[:, :k].copy())
+        n_sel = V - nban
+        kk = min(k, n_sel)
+        assert torch.equal(idx.cpu().long()[:, :kk], order[:, :kk]), nban
+        want = torch.gather(lp32, 1, order[:, :kk])
+        assert float((val.cpu()[:, :kk] - want).abs().max()) < 2e-5

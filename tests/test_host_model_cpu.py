@@ -633,3 +633,16 @@ def test_shape_buckets_pad_without_changing_the_step(mid):
         torch.testing.assert_close(sp.dev["loss_out"][:3], sb.dev["loss_out"][:3], rtol=1e-6, atol=1e-7)
         assert float((plain.proj.g - bucketed.proj.g).norm() / plain.proj.g.norm()) < 5e-3
     assert len(keys) == 1, keys
+
+
+def test_effective_min_length_is_hfs_under_inputs_embeds():
+    """HF counts ``min_length`` including the prompt and subtracts the embedded prompt's length when the prompt arrives as
+    ``inputs_embeds`` (GenerationMixin._prepare_generated_length; swept against the real reference in DESIGN.md 5): EOS is banned for
+    max(min_length - S, 0) generated positions.  The product's decode entry points and the oracle apply the same rule."""
+    from ps_slm_amd.decode import BeamState, effective_min_length
+    assert [effective_min_length(ml, 20) for ml in (1, 6, 20, 21, 22, 24, 27)] == [0, 0, 0, 1, 2, 4, 7]
+    assert effective_min_length(6, 0) == 6 and effective_min_length(0, 5) == 0
+    bs = BeamState(1, 2, 8, eos=9, pad=9, min_length=effective_min_length(6, 20))
+    assert not bs.ban_eos()                                                    # the reference's default (and any min_length <= S): never banned
+    bs = BeamState(1, 2, 8, eos=9, pad=9, min_length=effective_min_length(23, 20))
+    assert bs.ban_eos() and bs.min_length == 3
