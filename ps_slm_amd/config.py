@@ -120,6 +120,10 @@ class DataConfig(_Section):
 @dataclass
 class LogConfig(_Section):
     use_wandb: bool = False
+    wandb_dir: str = "tmp/test_wandb"
+    wandb_entity_name: str = "project_name"
+    wandb_project_name: str = "project_name"
+    wandb_exp_name: str = "exp_name"
     log_file: str = "tmp/test.log"
     log_interval: int = 5
 

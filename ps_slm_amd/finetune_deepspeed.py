@@ -211,12 +211,55 @@ class BatchReader:
                 self.thread.join(timeout=0.05)
 
 
+class MetricsLog:
+    """``log_config.use_wandb``: the records of the reference's ``wandb.log`` calls under the same keys and step numbering --
+    ``train_inner/train_inner_{loss,accuracy}`` every ``log_interval`` steps (Multitask/utils/deepspeed_utils.py:213-230),
+    ``valid/{val_epoch_loss,val_perplexity,best_val_loss,val_accuracy,val_best_accuracy}`` after every validation pass (:283-293),
+    ``train/{train_perplexity,train_epoch_loss,train_epoch_acc}`` per epoch (:334-351) -- on rank 0.  They go to wandb itself when
+    the package is importable (``wandb.init`` with the reference's arguments, Multitask/finetune_deepspeed.py:118-124) and ALWAYS
+    to ``<wandb_dir>/metrics.jsonl``, one JSON object per call (this image has no wandb).  Deviation (stated): the loop reads loss
+    and accuracy from the device only every ``log_interval`` steps (the reference's ``total_loss += loss`` is a host sync per
+    step), so the per-epoch figures average the logged steps."""
+
+    def __init__(self, log_config, rank, run_config=None):
+        self.on = bool(getattr(log_config, "use_wandb", False)) and rank == 0
+        self.wandb, self.f = None, None
+        if not self.on:
+            return
+        os.makedirs(log_config.wandb_dir, exist_ok=True)
+        self.path = os.path.join(log_config.wandb_dir, "metrics.jsonl")
+        self.f = open(self.path, "a")
+        try:
+            import wandb
+            wandb.init(dir=log_config.wandb_dir, entity=log_config.wandb_entity_name, project=log_config.wandb_project_name,
+                       name=log_config.wandb_exp_name, config=run_config)
+            self.wandb = wandb
+        except ImportError:
+            logger.info("log_config.use_wandb: wandb is not installed, the records go to %s only", self.path)
+
+    def log(self, record, step=None):
+        if not self.on:
+            return
+        import json
+        self.f.write(json.dumps(dict(record, **({"_step": int(step)} if step is not None else {}))) + "\n")
+        self.f.flush()
+        if self.wandb is not None:
+            self.wandb.log(record, step=step)
+
+    def finish(self):
+        if self.f is not None:
+            self.f.close()
+            self.f = None
+        if self.wandb is not None:
+            self.wandb.finish()
+
+
 def _inline_batches(dataset):
     for raw in dataset:
         yield raw, dataset.collator(raw)
 
 
-def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=None):
+def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=None, metrics=None):
     """Loop body of Multitask/utils/deepspeed_utils.py:190-246 (uneven-data join, forward, backward, step, logging) and
     the validation / save-on-improvement block behind it (:248-290).
 
@@ -234,8 +277,12 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
     # 0 = read and collate on the training thread, like a DataLoader without workers
     threaded = int(getattr(train_config, "num_workers_dataloader", 0) or 0) > 0 and hasattr(dataset, "collator")
     epoch_rates = []
+    metrics = metrics if metrics is not None else MetricsLog(log_config, rank)
+    ga = max(1, int(getattr(engine, "ga", 1)))
+    dynamic = train_config.batching_strategy == "dynamic"
     for epoch in range(train_config.num_epochs):
         engine.train()
+        ep_loss, ep_acc, ep_n = 0.0, 0.0, 0
         reader = BatchReader(dataset, engine.core.device) if threaded else None
         it = iter(reader) if reader is not None else _inline_batches(dataset)
         epoch_step = 0                                         # the reference's `step + 1` (per epoch, :190, :248)
@@ -277,9 +324,15 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
                 val_loss.append(el)
                 val_ppl.append(ppl)
                 val_acc.append(ea)
+                metrics.log({"valid/val_epoch_loss": el, "valid/val_perplexity": ppl, "valid/best_val_loss": best_val_loss,
+                             "valid/val_accuracy": ea, "valid/val_best_accuracy": best_val_acc})
             if log_now:
                 l, a = float(loss.detach() if torch.is_tensor(loss) else loss), float(acc)                 # the only host sync of the loop, every log_interval steps
                 total_loss, total_acc = total_loss + l, total_acc + a
+                ep_loss, ep_acc, ep_n = ep_loss + l / ga, ep_acc + a / ga, ep_n + 1
+                # (the reference's step index: `step + 1` under dynamic batching, else epoch * total_length + step: :213-230)
+                metrics.log({"train_inner/train_inner_loss": l / ga, "train_inner/train_inner_accuracy": a / ga},
+                            step=epoch_step if dynamic else steps - 1)
                 if rank == 0:
                     logger.info("epoch %d step %d loss %.4f acc %.4f lr %.3e  %.1f utt/s", epoch + 1, steps, l, a,
                                 engine.get_lr()[0], world * utts / (time.perf_counter() - t0))
@@ -288,6 +341,11 @@ def train(engine, dataset, train_config, log_config, rank, world, eval_dataset=N
         if engine.core.device.type == "cuda":
             torch.cuda.synchronize()
         epoch_rates.append(world * e_utts / max(time.perf_counter() - e_t0, 1e-9))
+        if ep_n:
+            import math
+            el_, ea_ = engine.reduce_scalars(ep_loss / ep_n, ep_acc / ep_n)
+            el_, ea_ = el_ / world, ea_ / world
+            metrics.log({"train/train_perplexity": math.exp(min(el_, 80.0)), "train/train_epoch_loss": el_, "train/train_epoch_acc": ea_})
     results["epoch_utterances_per_s"] = epoch_rates            # (per epoch, device drained: the first epoch carries the warm-up)
     n_logged = max(1, steps // max(1, log_config.log_interval))
     sl, sa = engine.reduce_scalars(total_loss / n_logged, total_acc / n_logged)
@@ -338,7 +396,12 @@ def main(argv=None):
         inner = getattr(ds, "dp", ds)                  # (MultiTaskDynamicBatchDataset wraps the sample dataset)
         if inner is not None and hasattr(inner, "rng"):
             inner.rng = random.Random(int(train_config.seed) * 1000003 + 7919 * rank + k)
-    results = train(engine, dataset, train_config, log_config, rank, world, eval_dataset)
+    metrics = MetricsLog(log_config, rank, run_config={"train_config": vars(train_config), "model_config": vars(model_config),
+                                                         "log_config": vars(log_config)})
+    try:
+        results = train(engine, dataset, train_config, log_config, rank, world, eval_dataset, metrics=metrics)
+    finally:
+        metrics.finish()
     if rank == 0:
         for k, v in results.items():
             logger.info("Key: %s, Value: %s", k, v)

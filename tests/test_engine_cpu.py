@@ -377,9 +377,22 @@ def test_train_loop_and_checkpoint_roundtrip(tmp_path):
         # validation every 2 steps on a 2-batch eval split; improvement -> <output_dir>/<model_name>_epoch_1_step_2/
         tcfg = TrainConfig(num_epochs=1, run_validation=True, validation_interval=2, save_model=True,
                            output_dir=str(tmp_path / "out"), batching_strategy="dynamic")
-        res = train(eng, ds, tcfg, LogConfig(log_interval=1), 0, 1, eval_dataset=SyntheticDataset(core.geo, 2, 2, 0))
+        # use_wandb: the reference's wandb.log records (same keys / step numbering) in <wandb_dir>/metrics.jsonl (no wandb on the image)
+        lcfg = LogConfig(log_interval=1, use_wandb=True, wandb_dir=str(tmp_path / "wandb"))
+        res = train(eng, ds, tcfg, lcfg, 0, 1, eval_dataset=SyntheticDataset(core.geo, 2, 2, 0))
     finally:
         syn.synthetic_text_batch = real
+    import json
+    recs = [json.loads(l) for l in open(tmp_path / "wandb" / "metrics.jsonl")]
+    inner = [r for r in recs if "train_inner/train_inner_loss" in r]
+    assert [r["_step"] for r in inner] == [1, 2, 3] and all(0 <= r["train_inner/train_inner_accuracy"] <= 1 for r in inner)   # dynamic: step + 1
+    valid = [r for r in recs if "valid/val_epoch_loss" in r]
+    assert len(valid) == 1 and set(valid[0]) == {"valid/val_epoch_loss", "valid/val_perplexity", "valid/best_val_loss", "valid/val_accuracy",
+                                                 "valid/val_best_accuracy"}
+    assert valid[0]["valid/val_perplexity"] == pytest.approx(math.exp(valid[0]["valid/val_epoch_loss"]), rel=1e-6)
+    ep = [r for r in recs if "train/train_epoch_loss" in r]
+    assert len(ep) == 1 and ep[0]["train/train_epoch_loss"] == pytest.approx(sum(r["train_inner/train_inner_loss"] for r in inner) / 3, rel=1e-5)
+    assert ep[0]["train/train_perplexity"] == pytest.approx(math.exp(ep[0]["train/train_epoch_loss"]), rel=1e-6)
     assert res["steps"] == 3 and res["avg_train_loss"] > 0
     assert res["avg_eval_loss"] > 0 and res["avg_eval_prep"] == pytest.approx(math.exp(res["avg_eval_loss"]), rel=1e-6)
     assert os.path.isfile(tmp_path / "out" / "asr_model_epoch_1_step_2" / "pytorch_model.bin")
