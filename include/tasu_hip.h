@@ -646,6 +646,20 @@ int64_t tasu_gemm_launch_count(void);
  * order by a second launch -- deterministic.                                                                                     */
 int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
                      int M, int N, int K, int act, float* workspace, int64_t workspace_floats, void* stream);
+/* The decode step's three GEMMs that carry the NEXT row-wise kernel in the launch that sums their K-range slabs (one launch less
+ * each; the same sums in the same order as tasu_f32_gemm_nt followed by that kernel -- the same bits; problems that do not split,
+ * i.e. the prompt pass, run the two kernels):
+ *   tasu_f32_gemm_resid_rmsnorm   x = resid + A W^T [+ bias] (resid may alias x);  y = w * (x * rsqrt(mean(x^2) + eps))
+ *   tasu_f32_gemm_swiglu          act[M, I] = silu(A Wg^T) * (A Wu^T), Wgu = [Wg; Wu]; gu [M, 2I]: scratch of the unsplit route
+ *   tasu_f32_gemm_qkv_rope        qkv = A Wqkv^T + bias, rotary embedding on the q / k heads, k / v to cache[m, slot[m]] (kcache may be NULL) */
+int tasu_f32_gemm_resid_rmsnorm(const float* A, int lda, const float* W, int ldw, float* x, int ldx, const float* bias, const float* resid,
+                                const float* norm_w, float* y, int M, int N, int K, float eps, float* workspace, int64_t workspace_floats,
+                                void* stream);
+int tasu_f32_gemm_swiglu(const float* A, int lda, const float* Wgu, int ldw, float* gu, float* act, int M, int I, int K, float* workspace,
+                         int64_t workspace_floats, void* stream);
+int tasu_f32_gemm_qkv_rope(const float* A, int lda, const float* Wqkv, int ldw, const float* bias, float* qkv, const float* cos_tab,
+                           const float* sin_tab, int M, int H, int G, int K, float* kcache, float* vcache, const int32_t* slot, int ctx,
+                           float* workspace, int64_t workspace_floats, void* stream);
 /* y = w * (x * rsqrt(mean(x^2) + eps)) per row of x [M, D] */
 int tasu_f32_rmsnorm(const float* x, const float* w, float* y, int M, int D, float eps, void* stream);
 /* q and k heads of qkv [M, (H+2G)*128] rotated in place (tables [M, 64] of tasu_rope_table; x*cos + rotate_half(x)*sin with the two

@@ -132,6 +132,9 @@ PROTOTYPES.update({
     # fp32 arithmetic mode of the decode path (csrc/fp32.hip)
     "tasu_f32_gemm_nt": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "tasu_f32_rmsnorm": [vp, vp, vp, i32, i32, f32, vp],
+    "tasu_f32_gemm_resid_rmsnorm": [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
+    "tasu_f32_gemm_swiglu": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, i64, vp],
+    "tasu_f32_gemm_qkv_rope": [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, i64, vp],
     "tasu_f32_rope": [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp],
     "tasu_f32_kv_fill": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tasu_f32_attn_prefill": [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],

@@ -14,6 +14,16 @@ constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 1;
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.f + expf(-x)); }
+// x * cos + rotate_half(x) * sin with the two products and the sum rounded separately, like torch eager (apply_rotary_pos_emb):
+// -ffp-contract=fast would otherwise fuse one product into the sum, and not the same one at every call site
+__device__ __forceinline__ void rope_pair_eager(float x1, float x2, float c, float s, float& y1, float& y2) {
+  // (every product passes through an empty asm before it is used: a pragma `fp contract(off)` here did not survive inlining into
+  // f32_sum_slabs_rope_kernel, which came out with a v_pk_fma_f32 where f32_rope_kernel has mul + add)
+  float a1 = x1 * c, b1 = x2 * s, a2 = x2 * c, b2 = x1 * s;
+  asm volatile("" : "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2));
+  y1 = a1 - b1;
+  y2 = a2 + b2;
+}
 __device__ __forceinline__ float act_f(float v, int act) { return act == 1 ? silu_exact(v) : (act == 2 ? fmaxf(v, 0.f) : v); }
 
 // C[m, n] (+)= sum_k A[m, k] W[n, k] over the K range of blockIdx.z.  ksplit == 1: C = [resid +] act(acc + bias).
@@ -106,16 +116,85 @@ __global__ __launch_bounds__(256) void f32_sum_slabs_kernel(const float* __restr
   C[(size_t)m * ldc + n] = v;
 }
 
-// Qwen2RMSNorm in fp32 (modeling_qwen2.py:41-48): y = w * (x * rsqrt(mean(x^2) + eps)); one 256-thread block per row
-__global__ __launch_bounds__(256) void f32_rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-                                                          int D, float eps) {
-  __shared__ float red[4];
+// The three finishers of the decode step's K-range-slab GEMMs that carry the NEXT row-wise kernel with them (one launch instead
+// of two; same sums in the same order as f32_sum_slabs_kernel followed by that kernel, so the same bits):
+//   f32_sum_slabs_norm_kernel    x = resid + (slab 0 + slab 1 + ...) [+ bias];  y = w * (x * rsqrt(mean(x^2) + eps))   (block per row)
+//   f32_sum_slabs_swiglu_kernel  act = silu(sum of the gate slabs) * (sum of the up slabs)                            (gu never stored)
+//   f32_sum_slabs_rope_kernel    qkv = sum + bias, q / k heads rotated, k / v appended to the cache                    (thread per pair)
+__global__ __launch_bounds__(1024) void f32_sum_slabs_norm_kernel(const float* __restrict__ slabs, int ksplit, float* __restrict__ x, int ldx,
+                                                                  const float* __restrict__ bias, const float* __restrict__ resid,
+                                                                  const float* __restrict__ w, float* __restrict__ y, int M, int N, float eps) {
+  // 1024 threads per row: a thread owns one or two columns and requests all of a column's slabs together (with 256 threads and
+  // the slabs one after the other this kernel took longer than the two it replaces: 64 rows are only 64 workgroups)
+  __shared__ float red[16];
+  const int m = blockIdx.x;
+  float ss = 0.f;
+  for (int n = threadIdx.x; n < N; n += 1024) {
+    const size_t idx = (size_t)m * N + n;
+    float part[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) part[s] = s < ksplit ? slabs[(size_t)s * M * N + idx] : 0.f;
+    float v = part[0];
+#pragma unroll
+    for (int s = 1; s < 16; ++s)
+      if (s < ksplit) v += part[s];                  // (ascending, like f32_sum_slabs_kernel: the same bits)
+    if (bias) v += bias[n];
+    if (resid) v = resid[(size_t)m * ldx + n] + v;
+    x[(size_t)m * ldx + n] = v;
+    ss += v * v;
+  }
+  ss = block_sum<16>(ss, red);
+  const float rs = rsqrtf(ss / (float)N + eps);
+  for (int n = threadIdx.x; n < N; n += 1024) y[(size_t)m * N + n] = w[n] * (x[(size_t)m * ldx + n] * rs);
+}
+
+__global__ __launch_bounds__(256) void f32_sum_slabs_swiglu_kernel(const float* __restrict__ slabs, int ksplit, float* __restrict__ act, int M,
+                                                                   int I) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)M * I) return;
+  const size_t m = idx / I, c = idx - m * I;
+  const size_t gi = m * 2 * I + c, stride = (size_t)M * 2 * I;
+  float g = slabs[gi], u = slabs[gi + I];
+  for (int s = 1; s < ksplit; ++s) g += slabs[s * stride + gi], u += slabs[s * stride + gi + I];
+  act[idx] = __fmul_rn(silu_exact(g), u);
+}
+
+__global__ __launch_bounds__(256) void f32_sum_slabs_rope_kernel(const float* __restrict__ slabs, int ksplit, float* __restrict__ qkv,
+                                                                 const float* __restrict__ bias, const float* __restrict__ ct,
+                                                                 const float* __restrict__ st, int M, int H, int G, float* __restrict__ kc,
+                                                                 float* __restrict__ vc, const int32_t* __restrict__ slot, int ctx) {
+  const int LD = (H + 2 * G) * HD, Wd = G * HD;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = (H + 2 * G) * 64;
+  if (idx >= (size_t)M * per_row) return;
+  const int m = (int)(idx / per_row), rest = (int)(idx - (size_t)m * per_row), hh = rest >> 6, d = rest & 63;
+  const size_t i1 = (size_t)m * LD + hh * HD + d, i2 = i1 + 64, stride = (size_t)M * LD;
+  float y1 = slabs[i1], y2 = slabs[i2];
+  for (int s = 1; s < ksplit; ++s) y1 += slabs[s * stride + i1], y2 += slabs[s * stride + i2];
+  if (bias) y1 += bias[hh * HD + d], y2 += bias[hh * HD + d + 64];
+  if (hh < H + G) {
+    const float c = ct[(size_t)m * 64 + d], sn = st[(size_t)m * 64 + d];
+    rope_pair_eager(y1, y2, c, sn, y1, y2);
+  }
+  qkv[i1] = y1;
+  qkv[i2] = y2;
+  if (kc && hh >= H) {
+    float* dst = (hh < H + G ? kc : vc) + ((size_t)m * ctx + slot[m]) * Wd + (hh - (hh < H + G ? H : H + G)) * HD;
+    dst[d] = y1;
+    dst[d + 64] = y2;
+  }
+}
+
+// Qwen2RMSNorm in fp32 (modeling_qwen2.py:41-48): y = w * (x * rsqrt(mean(x^2) + eps)); one 1024-thread block per row
+__global__ __launch_bounds__(1024) void f32_rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                           int D, float eps) {
+  __shared__ float red[16];
   const float* xr = x + (size_t)blockIdx.x * D;
   float s = 0.f;
-  for (int c = threadIdx.x; c < D; c += 256) s += xr[c] * xr[c];
-  s = block_sum<4>(s, red);
+  for (int c = threadIdx.x; c < D; c += 1024) s += xr[c] * xr[c];          // (the order f32_sum_slabs_norm_kernel sums in)
+  s = block_sum<16>(s, red);
   const float rs = rsqrtf(s / (float)D + eps);
-  for (int c = threadIdx.x; c < D; c += 256) y[(size_t)blockIdx.x * D + c] = w[c] * (xr[c] * rs);
+  for (int c = threadIdx.x; c < D; c += 1024) y[(size_t)blockIdx.x * D + c] = w[c] * (xr[c] * rs);
 }
 
 // apply_rotary_pos_emb (modeling_qwen2.py:91-135) on the q and k heads of qkv [M, (H + 2G) * 128], in place:
@@ -133,9 +212,7 @@ __global__ __launch_bounds__(256) void f32_rope_kernel(float* __restrict__ qkv, 
   float y1 = row[d], y2 = row[d + 64];
   if (hh < H + G) {
     const float c = ct[(size_t)m * 64 + d], s = st[(size_t)m * 64 + d];
-    const float x1 = y1, x2 = y2;
-    y1 = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, s));
-    y2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, s));
+    rope_pair_eager(y1, y2, c, s, y1, y2);
     row[d] = y1;
     row[d + 64] = y2;
   }
@@ -476,33 +553,85 @@ __global__ __launch_bounds__(256) void f32_fsmn_kernel(const float* __restrict__
 
 using namespace tasu_f32;
 
-extern "C" int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
-                                int M, int N, int K, int act, float* workspace, int64_t workspace_floats, void* stream) {
-  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K % BK || lda % 4 || ldw % 4 || ldc < N || act < 0 || act > 2) return TASU_ERR_ARG;
-  if (((uintptr_t)A | (uintptr_t)W) & 15) return TASU_ERR_ARG;
+// the K-range split of a problem (1 = none): outputs of fewer than 1024 tiles (every projection at <= 64 beam rows except the
+// lm_head) run as K-range slabs until ~1024 workgroups stream (a workgroup keeps 16 KiB in flight; the chip needs a few per CU to
+// reach the HBM rate)
+static int f32_ksplit(int M, int N, int K, const float* workspace, int64_t workspace_floats) {
   const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
-  // outputs of fewer than 1024 tiles (every projection at <= 64 beam rows except the lm_head): K-range slabs until ~1024 workgroups
-  // stream (a workgroup keeps 16 KiB in flight; the chip needs a few per CU to reach the HBM rate)
   int ksplit = 1;
   if (workspace && tiles < 1024) {
     ksplit = (1024 + tiles - 1) / tiles;
     if (ksplit > 16) ksplit = 16;
     while (ksplit > 1 && ((K / BK) % ksplit || (int64_t)ksplit * M * N > workspace_floats)) --ksplit;
   }
+  return ksplit;
+}
+static bool f32_gemm_args_ok(const float* A, int lda, const float* W, int ldw, const float* C, int ldc, int M, int N, int K) {
+  return A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 4 == 0 && ldw % 4 == 0 && ldc >= N &&
+         !(((uintptr_t)A | (uintptr_t)W) & 15);
+}
+static int f32_gemm_launch(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid, int M,
+                           int N, int K, int act, int ksplit, hipStream_t st) {
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, ksplit);
-  TASU_LAUNCH(f32_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, W, ldw, ksplit > 1 ? workspace : C, ldc, bias, resid, M, N,
-              K, K / ksplit, act, ksplit);
-  if (ksplit > 1) {
-    const size_t n = (size_t)M * N;
-    TASU_LAUNCH(f32_sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, ksplit, C, ldc, bias,
-                resid, M, N, act);
+  TASU_LAUNCH(f32_gemm_kernel, grid, dim3(256), 0, st, A, lda, W, ldw, C, ldc, bias, resid, M, N, K, K / ksplit, act, ksplit);
+  return TASU_OK;
+}
+
+extern "C" int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
+                                int M, int N, int K, int act, float* workspace, int64_t workspace_floats, void* stream) {
+  if (!f32_gemm_args_ok(A, lda, W, ldw, C, ldc, M, N, K) || act < 0 || act > 2) return TASU_ERR_ARG;
+  const int ksplit = f32_ksplit(M, N, K, workspace, workspace_floats);
+  const int rc = f32_gemm_launch(A, lda, W, ldw, ksplit > 1 ? workspace : C, ldc, bias, resid, M, N, K, act, ksplit, (hipStream_t)stream);
+  if (rc || ksplit == 1) return rc;
+  const size_t n = (size_t)M * N;
+  TASU_LAUNCH(f32_sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, ksplit, C, ldc, bias,
+              resid, M, N, act);
+  return TASU_OK;
+}
+
+// x = resid + A W^T [+ bias];  y = RMSNorm(x, norm_w): the o / down projection of a decoder layer with the norm that consumes it
+extern "C" int tasu_f32_gemm_resid_rmsnorm(const float* A, int lda, const float* W, int ldw, float* x, int ldx, const float* bias,
+                                           const float* resid, const float* norm_w, float* y, int M, int N, int K, float eps,
+                                           float* workspace, int64_t workspace_floats, void* stream) {
+  if (!f32_gemm_args_ok(A, lda, W, ldw, x, ldx, M, N, K) || !norm_w || !y) return TASU_ERR_ARG;
+  const int ksplit = f32_ksplit(M, N, K, workspace, workspace_floats);
+  if (ksplit == 1) {                                  // (whole-K tiles: the prompt pass) GEMM, then the norm
+    const int rc = f32_gemm_launch(A, lda, W, ldw, x, ldx, bias, resid, M, N, K, 0, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    if (ldx != N) return TASU_ERR_ARG;
+    TASU_LAUNCH(f32_rmsnorm_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, x, norm_w, y, N, eps);
+    return TASU_OK;
   }
+  const int rc = f32_gemm_launch(A, lda, W, ldw, workspace, ldx, bias, resid, M, N, K, 0, ksplit, (hipStream_t)stream);
+  if (rc) return rc;
+  TASU_LAUNCH(f32_sum_slabs_norm_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, workspace, ksplit, x, ldx, bias, resid, norm_w, y, M, N,
+              eps);
+  return TASU_OK;
+}
+
+// act = silu(A Wg^T) * (A Wu^T) with Wgu = [Wg; Wu] ([2I, K]); gu: [M, 2I] scratch for the unsplit route (may be NULL when the
+// problem splits: M <= 64 rows at the decoder's widths)
+extern "C" int tasu_f32_gemm_swiglu(const float* A, int lda, const float* Wgu, int ldw, float* gu, float* act, int M, int I, int K,
+                                    float* workspace, int64_t workspace_floats, void* stream) {
+  if (!f32_gemm_args_ok(A, lda, Wgu, ldw, act, 2 * I, M, 2 * I, K) || I <= 0) return TASU_ERR_ARG;
+  const int ksplit = f32_ksplit(M, 2 * I, K, workspace, workspace_floats);
+  const size_t n = (size_t)M * I;
+  if (ksplit == 1) {
+    if (!gu) return TASU_ERR_ARG;
+    const int rc = f32_gemm_launch(A, lda, Wgu, ldw, gu, 2 * I, nullptr, nullptr, M, 2 * I, K, 0, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    TASU_LAUNCH(f32_swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gu, act, M, I);
+    return TASU_OK;
+  }
+  const int rc = f32_gemm_launch(A, lda, Wgu, ldw, workspace, 2 * I, nullptr, nullptr, M, 2 * I, K, 0, ksplit, (hipStream_t)stream);
+  if (rc) return rc;
+  TASU_LAUNCH(f32_sum_slabs_swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, ksplit, act, M, I);
   return TASU_OK;
 }
 
 extern "C" int tasu_f32_rmsnorm(const float* x, const float* w, float* y, int M, int D, float eps, void* stream) {
   if (!x || !w || !y || M <= 0 || D <= 0) return TASU_ERR_ARG;
-  TASU_LAUNCH(f32_rmsnorm_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, w, y, D, eps);
+  TASU_LAUNCH(f32_rmsnorm_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, x, w, y, D, eps);
   return TASU_OK;
 }
 
@@ -513,6 +642,29 @@ extern "C" int tasu_f32_rope(float* qkv, const float* cos_tab, const float* sin_
   const size_t n = (size_t)M * (H + 2 * G) * 64;
   TASU_LAUNCH(f32_rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qkv, cos_tab, sin_tab, M, H, G, kcache,
               vcache, slot, ctx);
+  return TASU_OK;
+}
+
+// qkv = A Wqkv^T + bias, q / k heads rotated, k / v appended to the cache (kcache may be NULL: the prompt pass stores with tasu_f32_kv_fill)
+extern "C" int tasu_f32_gemm_qkv_rope(const float* A, int lda, const float* Wqkv, int ldw, const float* bias, float* qkv, const float* cos_tab,
+                                      const float* sin_tab, int M, int H, int G, int K, float* kcache, float* vcache, const int32_t* slot,
+                                      int ctx, float* workspace, int64_t workspace_floats, void* stream) {
+  const int N = (H + 2 * G) * HD;
+  if (H <= 0 || G <= 0 || H % G || !f32_gemm_args_ok(A, lda, Wqkv, ldw, qkv, N, M, N, K) || !cos_tab || !sin_tab) return TASU_ERR_ARG;
+  if (kcache && (!vcache || !slot || ctx <= 0)) return TASU_ERR_ARG;
+  const int ksplit = f32_ksplit(M, N, K, workspace, workspace_floats);
+  const size_t n = (size_t)M * (H + 2 * G) * 64;
+  if (ksplit == 1) {
+    const int rc = f32_gemm_launch(A, lda, Wqkv, ldw, qkv, N, bias, nullptr, M, N, K, 0, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    TASU_LAUNCH(f32_rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qkv, cos_tab, sin_tab, M, H, G, kcache,
+                vcache, slot, ctx);
+    return TASU_OK;
+  }
+  const int rc = f32_gemm_launch(A, lda, Wqkv, ldw, workspace, N, nullptr, nullptr, M, N, K, 0, ksplit, (hipStream_t)stream);
+  if (rc) return rc;
+  TASU_LAUNCH(f32_sum_slabs_rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, ksplit, qkv, bias,
+              cos_tab, sin_tab, M, H, G, kcache, vcache, slot, ctx);
   return TASU_OK;
 }
 

@@ -83,17 +83,18 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
     ws = buf("f32_gemm_ws", (16 * 128 * 4096,), f32)
     y2 = project_fp32(model, st)
 
-    def layer(l, x, xn, qkv, ao, gu, act, rows, attend):
-        f = llm.f32["layers"][l]
-        w = llm.layers[l]
-        ops.f32_rmsnorm(x, w["ln1"], xn, rows, D, geo.rms_eps)
-        ops.f32_gemm(xn, f["wqkv"], qkv, rows, LDQ, D, bias=f["bqkv"], ws=ws)
+    def layer(l, x, xn, qkv, ao, gu, act, rows, cos_t, sin_t, attend, cache=None):
+        """One decoder layer; in: xn = RMSNorm(x, ln1[l]); out: x updated, xn = the NEXT norm of it (ln1[l + 1], or the final norm).
+        Every projection carries the row-wise kernel behind it in the launch that sums its K-range slabs (tasu_f32_gemm_qkv_rope,
+        _resid_rmsnorm, _swiglu): 9 launches per layer at <= 64 beam rows instead of 13."""
+        f, w = llm.f32["layers"][l], llm.layers[l]
+        next_norm = llm.layers[l + 1]["ln1"] if l + 1 < L else llm.norm
+        kc_l, vc_l, slot = cache if cache is not None else (None, None, None)
+        ops.f32_gemm_qkv_rope(xn, f["wqkv"], f["bqkv"], qkv, cos_t, sin_t, rows, H, G, D, ws, kc=kc_l, vc=vc_l, slot=slot, ctx=ctx)
         attend(l, qkv, ao)
-        ops.f32_gemm(ao, f["wo"], x, rows, D, H * HD, resid=x, ws=ws)
-        ops.f32_rmsnorm(x, w["ln2"], xn, rows, D, geo.rms_eps)
-        ops.f32_gemm(xn, f["wgu"], gu, rows, 2 * I, D, ws=ws)
-        ops.f32_swiglu(gu, act, rows, I)
-        ops.f32_gemm(act, f["wd"], x, rows, D, I, resid=x, ws=ws)
+        ops.f32_gemm_resid_rmsnorm(ao, f["wo"], x, w["ln2"], xn, rows, D, H * HD, geo.rms_eps, ws, resid=x)
+        ops.f32_gemm_swiglu(xn, f["wgu"], gu, act, rows, I, D, ws)
+        ops.f32_gemm_resid_rmsnorm(act, f["wd"], x, next_norm, xn, rows, D, I, geo.rms_eps, ws, resid=x)
 
     # ---- KV cache (fp32) + the beam row index of the bf16 path
     kc = buf("f32_kc", (L, M * ctx * W), f32)
@@ -114,17 +115,15 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
     gu0, act0 = buf("f32_gu0", (M0, 2 * I), f32), buf("f32_act0", (M0, I), f32)
 
     def attend_prompt(l, qkv, ao):
-        ops.f32_rope(qkv, cos0, sin0, M0, H, G)
         ops.f32_kv_fill(qkv, kc[l], vc[l], B, S, H, G, nb, ctx)
         ops.f32_attn_prefill(qkv, kstart_b, ao, B, S, H, G, scale)
 
+    ops.f32_rmsnorm(x0, llm.layers[0]["ln1"], xn0, M0, D, geo.rms_eps)
     for l in range(L):
-        layer(l, x0, xn0, qkv0, ao0, gu0, act0, M0, attend_prompt)
-    xl = buf("f32_xlast", (B, D), f32)
-    ops.embed_rows(x0, last_rows, xl, B, D)                     # last prompt position of every utterance
+        layer(l, x0, xn0, qkv0, ao0, gu0, act0, M0, cos0, sin0, attend_prompt)
     x, xn = buf("f32_x", (M, D), f32), buf("f32_xn", (M, D), f32)
     logits = buf("f32_logits", (M, V), f32)
-    ops.f32_rmsnorm(xl, llm.norm, xn, B, D, geo.rms_eps)
+    ops.embed_rows(xn0, last_rows, xn, B, D)                    # the final-normed last prompt position of every utterance
     ops.f32_gemm(xn, llm.f32["head"], logits, B, V, D, ws=ws)
     tv, ti = buf("dec_topv", (M, K), f32), buf("dec_topi", (M, K), i32)
     bs = DeviceBeam(model, B, nb, max_new_tokens, eos, length_penalty, min_length, S, valid)
@@ -137,7 +136,6 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
     kcv, vcv = kc.view(L, M * ctx * W), vc.view(L, M * ctx * W)
 
     def attend_cache(l, qkv_, ao_):
-        ops.f32_rope(qkv_, cos, sin, M, H, G, kcv[l], vcv[l], bs.next_slot, ctx)
         ops.f32_attn_decode(qkv_, kcv[l], vcv[l], index, kstart, bs.next_lens, ao_, M, H, G, ctx, scale)
 
     def device_step():
@@ -146,10 +144,10 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
         ops.kv_index_reorder(index_tmp, index, None, bs.next_slot, M, ctx)
         ops.embed_rows(llm.embed, bs.next_ids, x, M, D)
         ops.rope_table(bs.next_pos, cos, sin, HD, geo.rope_theta)
+        ops.f32_rmsnorm(x, llm.layers[0]["ln1"], xn, M, D, geo.rms_eps)
         for l in range(L):
-            layer(l, x, xn, qkv, ao, gu, act, M, attend_cache)
-        ops.f32_rmsnorm(x, llm.norm, xn, M, D, geo.rms_eps)
-        ops.f32_gemm(xn, llm.f32["head"], logits, M, V, D, ws=ws)
+            layer(l, x, xn, qkv, ao, gu, act, M, cos, sin, attend_cache, cache=(kcv[l], vcv[l], bs.next_slot))
+        ops.f32_gemm(xn, llm.f32["head"], logits, M, V, D, ws=ws)                      # xn: the final norm, from the last layer's finisher
         ops.f32_logprob_topk(logits, M, V, K, bs.banned, 1, tv, ti)
         ops.beam_update(tv, ti, bs, False)
 

@@ -648,6 +648,22 @@ class HipOps:
         self._chk(self.lib.tasu_f32_gemm_nt(_p(a), a.stride(0), _p(w), w.stride(0), _p(c), c.stride(0), _p(bias), _p(resid), M, N, K, act,
                                             _p(ws), ws.numel() if ws is not None else 0, self._stream()), "tasu_f32_gemm_nt")
 
+    def f32_gemm_resid_rmsnorm(self, a, w, x, norm_w, y, M, N, K, eps, ws, resid=None, bias=None):
+        """x = resid + a @ w^T (+ bias); y = rmsnorm(x, norm_w): a decoder layer's o / down projection with the norm behind it
+        (tasu_f32_gemm_resid_rmsnorm: one launch for the slab sum and the norm when the problem splits)."""
+        self._chk(self.lib.tasu_f32_gemm_resid_rmsnorm(_p(a), a.stride(0), _p(w), w.stride(0), _p(x), x.stride(0), _p(bias), _p(resid),
+                                                       _p(norm_w), _p(y), M, N, K, eps, _p(ws), ws.numel() if ws is not None else 0,
+                                                       self._stream()), "tasu_f32_gemm_resid_rmsnorm")
+
+    def f32_gemm_swiglu(self, a, wgu, gu, act, M, I, K, ws):
+        self._chk(self.lib.tasu_f32_gemm_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), M, I, K, _p(ws),
+                                                ws.numel() if ws is not None else 0, self._stream()), "tasu_f32_gemm_swiglu")
+
+    def f32_gemm_qkv_rope(self, a, wqkv, bias, qkv, cos, sin, M, H, G, K, ws, kc=None, vc=None, slot=None, ctx=0):
+        self._chk(self.lib.tasu_f32_gemm_qkv_rope(_p(a), a.stride(0), _p(wqkv), wqkv.stride(0), _p(bias), _p(qkv), _p(cos), _p(sin), M, H, G,
+                                                  K, _p(kc), _p(vc), _p(slot), ctx, _p(ws), ws.numel() if ws is not None else 0,
+                                                  self._stream()), "tasu_f32_gemm_qkv_rope")
+
     def f32_rmsnorm(self, x, w, y, M, D, eps):
         self._chk(self.lib.tasu_f32_rmsnorm(_p(x), _p(w), _p(y), M, D, eps, self._stream()), "tasu_f32_rmsnorm")
 

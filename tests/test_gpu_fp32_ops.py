@@ -85,7 +85,7 @@ def test_rope_and_cache_append_fp32(ops, M, H, G):
     qkv = qkv0.clone()
     ops.f32_rope(qkv, cos, sin, M, H, G)
     assert torch.equal(qkv.view(M, H + 2 * G, HD)[:, H + G:], x[:, H + G:])          # v: not touched
-    assert close(qkv, ref.view(M, LD), 1e-6)
+    assert torch.equal(qkv, ref.view(M, LD))                                          # the same roundings as torch eager: bit-identical
     kc, vc = torch.zeros(M * ctx * W, device="cuda"), torch.zeros(M * ctx * W, device="cuda")
     slot = torch.randint(0, ctx, (M,), dtype=torch.int32).cuda()
     qkv2 = qkv0.clone()
@@ -231,3 +231,51 @@ def test_logprob_topk_fp32(ops, M, V, k):
         assert torch.equal(idx.cpu().long()[:, :kk], order[:, :kk]), nban
         want = torch.gather(lp32, 1, order[:, :kk])
         assert float((val.cpu()[:, :kk] - want).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("M", [64, 5, 700])
+def test_fused_slab_finishers_equal_the_two_kernel_forms(ops, M):
+    """tasu_f32_gemm_resid_rmsnorm / _swiglu / _qkv_rope: the projection with the next row-wise kernel in the launch that sums its
+    K-range slabs (M <= 64: the decode step) or, where the problem does not split (M = 700), as the two kernels -- the SAME BITS
+    as tasu_f32_gemm_nt followed by tasu_f32_rmsnorm / tasu_f32_swiglu / tasu_f32_rope either way."""
+    D, I, H, G, ctx = 1536, 2048, 12, 2, 16
+    LD, W = (H + 2 * G) * HD, G * HD
+    ws = torch.empty(16 * 128 * 4096, device="cuda")
+    a = randn(M, H * HD, seed=30)
+    wo, x0, nw = randn(D, H * HD, seed=31, scale=0.03), randn(M, D, seed=32), randn(D, seed=33) + 1.0
+    # resid + norm
+    x_ref = x0.clone()
+    ops.f32_gemm(a, wo, x_ref, M, D, H * HD, resid=x_ref, ws=ws)
+    y_ref = torch.empty(M, D, device="cuda")
+    ops.f32_rmsnorm(x_ref, nw, y_ref, M, D, 1e-6)
+    x, y = x0.clone(), torch.empty(M, D, device="cuda")
+    ops.f32_gemm_resid_rmsnorm(a, wo, x, nw, y, M, D, H * HD, 1e-6, ws, resid=x)
+    torch.cuda.synchronize()
+    assert torch.equal(x, x_ref) and torch.equal(y, y_ref)
+    # gate|up + SwiGLU
+    h, wgu = randn(M, D, seed=34), randn(2 * I, D, seed=35, scale=0.03)
+    gu, act_ref = torch.empty(M, 2 * I, device="cuda"), torch.empty(M, I, device="cuda")
+    ops.f32_gemm(h, wgu, gu, M, 2 * I, D, ws=ws)
+    ops.f32_swiglu(gu, act_ref, M, I)
+    act = torch.empty(M, I, device="cuda")
+    ops.f32_gemm_swiglu(h, wgu, torch.empty(M, 2 * I, device="cuda"), act, M, I, D, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(act, act_ref)
+    # q|k|v + bias + RoPE + cache append
+    wqkv, bq = randn(LD, D, seed=36, scale=0.03), randn(LD, seed=37)
+    pos = torch.randint(0, 300, (M,), dtype=torch.int32).cuda()
+    cos, sin = torch.empty(M, 64, device="cuda"), torch.empty(M, 64, device="cuda")
+    ops.rope_table(pos, cos, sin, HD, 1e6)
+    slot = torch.randint(0, ctx, (M,), dtype=torch.int32).cuda()
+    outs = []
+    for fused in (False, True):
+        qkv = torch.empty(M, LD, device="cuda")
+        kc, vc = torch.zeros(M * ctx * W, device="cuda"), torch.zeros(M * ctx * W, device="cuda")
+        if fused:
+            ops.f32_gemm_qkv_rope(h, wqkv, bq, qkv, cos, sin, M, H, G, D, ws, kc=kc, vc=vc, slot=slot, ctx=ctx)
+        else:
+            ops.f32_gemm(h, wqkv, qkv, M, LD, D, bias=bq, ws=ws)
+            ops.f32_rope(qkv, cos, sin, M, H, G, kc, vc, slot, ctx)
+        outs.append((qkv, kc, vc))
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, q) for p, q in zip(*outs))
