@@ -10,7 +10,7 @@
 namespace tasu_f32 {
 
 constexpr int HD = 128;
-constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 1;
+constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 4;     // row pitch 36 floats: 16-byte aligned rows, conflict-free b128 fragment reads
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.f + expf(-x)); }
@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(const float* __restrict__
                                                        float* __restrict__ C, int ldc, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, int M, int N, int K, int kchunk, int act,
                                                        int ksplit) {
-  __shared__ float sA[2][BM][LDS_LD];
-  __shared__ float sW[2][BN][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float sA[2][BM][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float sW[2][BN][LDS_LD];
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
   const int k_lo = z * kchunk, k_hi = min(K, k_lo + kchunk);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
@@ -53,27 +53,28 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(const float* __restrict__
   f32x4 rw0 = *(const f32x4*)(wp0 + k_lo), rw1 = *(const f32x4*)(wp1 + k_lo);
   int buf = 0;
   for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      sA[buf][lr][lc + c] = ra0[c], sA[buf][lr + 32][lc + c] = ra1[c];
-      sW[buf][lr][lc + c] = rw0[c], sW[buf][lr + 32][lc + c] = rw1[c];
-    }
+    *(f32x4*)&sA[buf][lr][lc] = ra0, *(f32x4*)&sA[buf][lr + 32][lc] = ra1;
+    *(f32x4*)&sW[buf][lr][lc] = rw0, *(f32x4*)&sW[buf][lr + 32][lc] = rw1;
     __syncthreads();
     if (k0 + BK < k_hi) {                              // the next K-step's 16 KiB are in flight under this one's MFMAs
       ra0 = *(const f32x4*)(ap0 + k0 + BK), ra1 = *(const f32x4*)(ap1 + k0 + BK);
       rw0 = *(const f32x4*)(wp0 + k0 + BK), rw1 = *(const f32x4*)(wp1 + k0 + BK);
     }
+    // fragments as 16-byte reads: lane group g = lane >> 4 takes k = h * 16 + 4 g .. + 3 of its row; MFMA (h, e) then contracts
+    // k = h * 16 + 4 g + e of both operands -- every k of the step exactly once (4x fewer LDS instructions than one float per MFMA)
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      float fa[2], fw[2];
+    for (int h = 0; h < 2; ++h) {
+      f32x4 fa[2], fw[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = sA[buf][wm * 32 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+      for (int i = 0; i < 2; ++i) fa[i] = *(const f32x4*)&sA[buf][wm * 32 + i * 16 + (lane & 15)][h * 16 + 4 * (lane >> 4)];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fw[j] = sW[buf][wn * 32 + j * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+      for (int j = 0; j < 2; ++j) fw[j] = *(const f32x4*)&sW[buf][wn * 32 + j * 16 + (lane & 15)][h * 16 + 4 * (lane >> 4)];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma4(fw[j], fa[i], acc[i][j]);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma4(fw[j][e], fa[i][e], acc[i][j]);
     }
     buf ^= 1;                                         // (the other buffer was last read before the barrier above)
   }
