@@ -684,6 +684,12 @@ int tasu_f32_swiglu(const float* gu, float* act, int M, int I, void* stream);
 /* tasu_embed_merge_fwd with an fp32 projector output proj [*, ldp] */
 int tasu_f32_embed_merge(const float* table, const float* proj, int ldp, const int32_t* src_kind, const int32_t* src_idx, float* x,
                          int M, int D, void* stream);
+/* Shifted CE of the eval-mode fp32 forward (Multitask/utils/deepspeed_utils.py:394-498 with use_fp16 = false; the loss of
+ * transformers' ForCausalLMLoss, ignore_index -100): per row m with shift_labels[m] >= 0: row_loss = logsumexp(logits[m]) -
+ * logits[m, label], row_hit = (argmax == label) (ties: first column); other rows 0.  row_argmax / row_lse optional.  Feed
+ * tasu_ce_reduce with row_loss / row_hit.                                                                                        */
+int tasu_f32_ce(const float* logits, int ld, const int32_t* shift_labels, int M, int V, float* row_loss, int32_t* row_hit,
+                int32_t* row_argmax, float* row_lse, void* stream);
 /* tasu_logprob_topk on fp32 logits: out_val = (x - max) - log(sum exp(x - max)) of the k best selectable columns (value descending,
  * column ascending), k <= 16; fewer than k selectable columns: (-inf, 0x7fffffff).                                               */
 int tasu_f32_logprob_topk(const float* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned, float* out_val,

@@ -143,6 +143,7 @@ PROTOTYPES.update({
     "tasu_f32_swiglu": [vp, vp, i32, i32, vp],
     "tasu_f32_embed_merge": [vp, vp, i32, vp, vp, vp, i32, i32, vp],
     "tasu_f32_logprob_topk": [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp],
+    "tasu_f32_ce": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp],
 })
 
 ABI_VERSION = 13

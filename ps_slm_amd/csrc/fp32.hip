@@ -550,6 +550,49 @@ __global__ __launch_bounds__(256) void f32_fsmn_kernel(const float* __restrict__
   out[i] += r;
 }
 
+// Shifted cross entropy of one fp32 logits row per 1024-thread block (the eval-mode forward in fp32: loss_utils' CE over the rows
+// whose shifted label is >= 0, ignore_index -100): lse = max + log(sum exp(x - max)), row_loss = lse - x[label], row_hit =
+// (argmax == label), argmax ties -> the first column (torch.argmax).  Rows without a label: loss 0, hit 0 (lse / argmax still written).
+__global__ __launch_bounds__(1024) void f32_ce_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ labels, int V,
+                                                      float* __restrict__ row_loss, int32_t* __restrict__ row_hit,
+                                                      int32_t* __restrict__ row_argmax, float* __restrict__ row_lse) {
+  __shared__ float red[16];
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const int m = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* x = logits + (size_t)m * ld;
+  float best = -__builtin_inff();
+  int bid = 0x7fffffff;
+  for (int c = t; c < V; c += 1024) {
+    const float v = x[c];
+    if (v > best) best = v, bid = c;                 // (ascending c per thread: the first maximum wins)
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bid, o, 64);
+    if (ov > best || (ov == best && oi < bid)) best = ov, bid = oi;
+  }
+  if (lane == 0) bv[wave] = best, bi[wave] = bid;
+  __syncthreads();
+  best = bv[0], bid = bi[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w)
+    if (bv[w] > best || (bv[w] == best && bi[w] < bid)) best = bv[w], bid = bi[w];
+  float s = 0.f;
+  for (int c = t; c < V; c += 1024) s += expf(x[c] - best);
+  s = block_sum<16>(s, red);
+  if (t == 0) {
+    const float lse = best + logf(s);
+    const int lab = labels[m];
+    const bool on = lab >= 0 && lab < V;
+    row_loss[m] = on ? lse - x[lab] : 0.f;
+    row_hit[m] = on && bid == lab ? 1 : 0;
+    if (row_argmax) row_argmax[m] = bid;
+    if (row_lse) row_lse[m] = lse;
+  }
+}
+
 }  // namespace tasu_f32
 
 using namespace tasu_f32;
@@ -747,6 +790,13 @@ extern "C" int tasu_f32_embed_merge(const float* table, const float* proj, int l
   const size_t n = (size_t)M * D;
   TASU_LAUNCH(f32_embed_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, proj, ldp, src_kind,
               src_idx, x, M, D);
+  return TASU_OK;
+}
+
+extern "C" int tasu_f32_ce(const float* logits, int ld, const int32_t* shift_labels, int M, int V, float* row_loss, int32_t* row_hit,
+                           int32_t* row_argmax, float* row_lse, void* stream) {
+  if (!logits || !shift_labels || !row_loss || !row_hit || M <= 0 || V <= 0 || ld < V) return TASU_ERR_ARG;
+  TASU_LAUNCH(f32_ce_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, logits, ld, shift_labels, V, row_loss, row_hit, row_argmax, row_lse);
   return TASU_OK;
 }
 

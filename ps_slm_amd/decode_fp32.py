@@ -48,15 +48,102 @@ def project_fp32(model, st: StepState):
     return y2
 
 
+def _layer_fp32(model, l, x, xn, qkv, ao, gu, act, rows, cos_t, sin_t, attend, ws, cache=None, ctx=0):
+    """One decoder layer; in: xn = RMSNorm(x, ln1[l]); out: x updated, xn = the NEXT norm of it (ln1[l + 1], or the final norm).
+    Every projection carries the row-wise kernel behind it in the launch that sums its K-range slabs (tasu_f32_gemm_qkv_rope,
+    _resid_rmsnorm, _swiglu): 9 launches per layer at <= 64 beam rows instead of 13."""
+    ops, geo, llm = model.ops, model.geo, model.llm
+    D, I, H, G, L = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_layers
+    f, w = llm.f32["layers"][l], llm.layers[l]
+    next_norm = llm.layers[l + 1]["ln1"] if l + 1 < L else llm.norm
+    kc_l, vc_l, slot = cache if cache is not None else (None, None, None)
+    ops.f32_gemm_qkv_rope(xn, f["wqkv"], f["bqkv"], qkv, cos_t, sin_t, rows, H, G, D, ws, kc=kc_l, vc=vc_l, slot=slot, ctx=ctx)
+    attend(l, qkv, ao)
+    ops.f32_gemm_resid_rmsnorm(ao, f["wo"], x, w["ln2"], xn, rows, D, H * HD, geo.rms_eps, ws, resid=x)
+    ops.f32_gemm_swiglu(xn, f["wgu"], gu, act, rows, I, D, ws)
+    ops.f32_gemm_resid_rmsnorm(act, f["wd"], x, next_norm, xn, rows, D, I, geo.rms_eps, ws, resid=x)
+
+
+def _need_f32(model):
+    if model.lora is not None:
+        raise NotImplementedError("the fp32 path of a LoRA-adapted model is not built (the merged weights exist in bf16 only)")
+    if not getattr(model.llm, "f32", None):
+        raise RuntimeError("the fp32 path needs the fp32 copies of the LLM weights: build the model with train_config.use_fp16=false "
+                           "(model_factory sets LLMWeights.keep_f32 before loading)")
+
+
+def prompt_pass_fp32(model, st: StepState, on_layer=None):
+    """The decoder over the merged prompt in fp32: projector -> embedding merge -> 28 layers (causal attention; a batch's padding is
+    on one side: left-padded prompts mask their first ``S - valid`` keys, right-padded training batches need no key mask under the
+    causal one -- their padded QUERY rows hold garbage nobody reads).  ``on_layer(l, qkv)``: called with the layer's rotated q|k|v
+    (generate() fills its cache there).  Returns (xn0 = the final-normed hidden states [B * S, D], x0 = the residual stream)."""
+    ops, geo, llm = model.ops, model.geo, model.llm
+    _need_f32(model)
+    B, S = st.B, st.S
+    if S > F32_MAX_CTX:
+        raise ValueError(f"sequence length {S} exceeds the fp32 attention's limit {F32_MAX_CTX}")
+    km = np.asarray(st.plan.key_mask)[:, :S].astype(bool)
+    valid = km.sum(1).astype(np.int64)
+    left = all(km[b, S - valid[b]:].all() for b in range(B))
+    right = all(km[b, :valid[b]].all() for b in range(B))
+    if not (left or right):
+        raise ValueError("the fp32 path expects every row's padding on one side (left: inference collator, right: training collator)")
+    M0 = B * S
+    D, I, H, G, L = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_layers
+    LDQ = (H + 2 * G) * HD
+    scale = HD ** -0.5
+    f32 = torch.float32
+    buf, d = model._buf, st.dev
+    ws = buf("f32_gemm_ws", (16 * 128 * 4096,), f32)
+    y2 = project_fp32(model, st)
+    kstart_b = model._upload("f32_kstart_b", ((S - valid) if left else np.zeros(B, dtype=np.int64)).astype(np.int32))
+    x0 = buf("f32_x0", (M0, D), f32)
+    ops.f32_embed_merge(llm.embed, y2, d["kind"], d["idx"], x0, M0, D)
+    cos0, sin0 = buf("f32_cos0", (M0, HD // 2), f32), buf("f32_sin0", (M0, HD // 2), f32)
+    ops.rope_table(d["pos"], cos0, sin0, HD, geo.rope_theta)
+    xn0, qkv0, ao0 = buf("f32_xn0", (M0, D), f32), buf("f32_qkv0", (M0, LDQ), f32), buf("f32_ao0", (M0, H * HD), f32)
+    gu0, act0 = buf("f32_gu0", (M0, 2 * I), f32), buf("f32_act0", (M0, I), f32)
+
+    def attend_prompt(l, qkv, ao):
+        if on_layer is not None:
+            on_layer(l, qkv)
+        ops.f32_attn_prefill(qkv, kstart_b, ao, B, S, H, G, scale)
+
+    ops.f32_rmsnorm(x0, llm.layers[0]["ln1"], xn0, M0, D, geo.rms_eps)
+    for l in range(L):
+        _layer_fp32(model, l, x0, xn0, qkv0, ao0, gu0, act0, M0, cos0, sin0, attend_prompt, ws)
+    return xn0, x0, valid, left
+
+
+def forward_fp32(model, st: StepState, compute_loss=True):
+    """The eval-mode forward in the reference's fp32 arithmetic (``train_config.use_fp16 = false``: ``evaluation()`` of
+    Multitask/utils/deepspeed_utils.py:394-498 and any ``model(**batch)`` outside autocast): fp32 logits for every position
+    (``st.dev['logits']`` [B * S, V]), the shifted CE over the labelled rows and the token accuracy (``st.dev['loss_out']`` =
+    [mean loss, accuracy, count, 1 / count]).  No activations are kept: there is no fp32 backward."""
+    ops, geo, llm = model.ops, model.geo, model.llm
+    xn0, _, _, _ = prompt_pass_fp32(model, st)
+    M0, D, V = st.B * st.S, geo.llm_dim, geo.llm_vocab
+    f32, i32 = torch.float32, torch.int32
+    buf, d = model._buf, st.dev
+    ws = buf("f32_gemm_ws", (16 * 128 * 4096,), f32)
+    logits = buf("f32_logits_all", (M0, V), f32)
+    ops.f32_gemm(xn0, llm.f32["head"], logits, M0, V, D, ws=ws)
+    d.update(logits=logits)
+    if not compute_loss:
+        return
+    row_loss, row_hit = buf("row_loss", (M0,), f32), buf("row_hit", (M0,), i32)
+    row_arg, row_lse = buf("row_arg", (M0,), i32), buf("f32_row_lse", (M0,), f32)
+    ops.f32_ce(logits, d["shift_labels"], M0, V, row_loss, row_hit, row_arg, row_lse)
+    res = buf("loss_out", (4,), f32)
+    ops.ce_reduce(row_loss, row_hit, d["shift_labels"], M0, res)
+    d.update(loss_out=res, row_arg=row_arg, row_lse=row_lse)
+
+
 def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=200, min_length=1, length_penalty=1.0,
                               eos_token_id=None, pad_token_id=None):
     """st: a prepared state (prepare_text / prepare_audio).  Returns LongTensor [B, n_new] (CPU)."""
     ops, geo, llm = model.ops, model.geo, model.llm
-    if model.lora is not None:
-        raise NotImplementedError("fp32 decode of a LoRA-adapted model is not built (the merged weights exist in bf16 only)")
-    if not getattr(llm, "f32", None):
-        raise RuntimeError("fp32 decode needs the fp32 copies of the LLM weights: build the model with train_config.use_fp16=false "
-                           "(model_factory sets LLMWeights.keep_f32 before loading)")
+    _need_f32(model)
     B, S, nb = st.B, st.S, num_beams
     min_length = effective_min_length(min_length, S)
     if not 1 <= nb <= BEAM_MAX_NB:
@@ -68,10 +155,6 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
     ctx = S + max_new_tokens
     if ctx > F32_MAX_CTX:
         raise ValueError(f"prompt {S} + max_new_tokens {max_new_tokens} exceeds the fp32 attention's context limit {F32_MAX_CTX}")
-    km = np.asarray(st.plan.key_mask)[:, :S].astype(bool)
-    valid = km.sum(1).astype(np.int64)
-    if not all(km[b, S - valid[b]:].all() for b in range(B)):
-        raise ValueError("fp32 decode expects left-padded prompts (what the reference's inference collator builds)")
     M0, M, K = B * S, B * nb, 2 * nb
     D, I, H, G, V, L = geo.llm_dim, geo.llm_inter, geo.llm_heads, geo.llm_kv_heads, geo.llm_vocab, geo.llm_layers
     LDQ, W = (H + 2 * G) * HD, G * HD
@@ -81,20 +164,6 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
     f32, i32 = torch.float32, torch.int32
     buf, d = model._buf, st.dev
     ws = buf("f32_gemm_ws", (16 * 128 * 4096,), f32)
-    y2 = project_fp32(model, st)
-
-    def layer(l, x, xn, qkv, ao, gu, act, rows, cos_t, sin_t, attend, cache=None):
-        """One decoder layer; in: xn = RMSNorm(x, ln1[l]); out: x updated, xn = the NEXT norm of it (ln1[l + 1], or the final norm).
-        Every projection carries the row-wise kernel behind it in the launch that sums its K-range slabs (tasu_f32_gemm_qkv_rope,
-        _resid_rmsnorm, _swiglu): 9 launches per layer at <= 64 beam rows instead of 13."""
-        f, w = llm.f32["layers"][l], llm.layers[l]
-        next_norm = llm.layers[l + 1]["ln1"] if l + 1 < L else llm.norm
-        kc_l, vc_l, slot = cache if cache is not None else (None, None, None)
-        ops.f32_gemm_qkv_rope(xn, f["wqkv"], f["bqkv"], qkv, cos_t, sin_t, rows, H, G, D, ws, kc=kc_l, vc=vc_l, slot=slot, ctx=ctx)
-        attend(l, qkv, ao)
-        ops.f32_gemm_resid_rmsnorm(ao, f["wo"], x, w["ln2"], xn, rows, D, H * HD, geo.rms_eps, ws, resid=x)
-        ops.f32_gemm_swiglu(xn, f["wgu"], gu, act, rows, I, D, ws)
-        ops.f32_gemm_resid_rmsnorm(act, f["wd"], x, next_norm, xn, rows, D, I, geo.rms_eps, ws, resid=x)
 
     # ---- KV cache (fp32) + the beam row index of the bf16 path
     kc = buf("f32_kc", (L, M * ctx * W), f32)
@@ -103,24 +172,12 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
     index_tmp = buf("dec_index_tmp", (M, ctx), i32)
     ops.kv_index_init(index, B, nb, S, ctx)
     ops.kv_index_init(index_tmp, B, nb, S, ctx)
-    kstart_b = model._upload("f32_kstart_b", (S - valid).astype(np.int32), flush=False)
+    # ---- prompt pass; every layer's rotated K / V go to the cache row of the utterance's first beam
+    xn0, _, valid, left = prompt_pass_fp32(model, st, on_layer=lambda l, qkv_l: ops.f32_kv_fill(qkv_l, kc[l], vc[l], B, S, H, G, nb, ctx))
+    if not left:
+        raise ValueError("fp32 decode expects left-padded prompts (what the reference's inference collator builds)")
     kstart = model._upload("dec_kstart", np.repeat(S - valid, nb).astype(np.int32), flush=False)
     last_rows = model._upload("dec_last_rows", (np.arange(B, dtype=np.int32) + 1) * S - 1)
-    # ---- prefill
-    x0 = buf("f32_x0", (M0, D), f32)
-    ops.f32_embed_merge(llm.embed, y2, d["kind"], d["idx"], x0, M0, D)
-    cos0, sin0 = buf("f32_cos0", (M0, HD // 2), f32), buf("f32_sin0", (M0, HD // 2), f32)
-    ops.rope_table(d["pos"], cos0, sin0, HD, geo.rope_theta)
-    xn0, qkv0, ao0 = buf("f32_xn0", (M0, D), f32), buf("f32_qkv0", (M0, LDQ), f32), buf("f32_ao0", (M0, H * HD), f32)
-    gu0, act0 = buf("f32_gu0", (M0, 2 * I), f32), buf("f32_act0", (M0, I), f32)
-
-    def attend_prompt(l, qkv, ao):
-        ops.f32_kv_fill(qkv, kc[l], vc[l], B, S, H, G, nb, ctx)
-        ops.f32_attn_prefill(qkv, kstart_b, ao, B, S, H, G, scale)
-
-    ops.f32_rmsnorm(x0, llm.layers[0]["ln1"], xn0, M0, D, geo.rms_eps)
-    for l in range(L):
-        layer(l, x0, xn0, qkv0, ao0, gu0, act0, M0, cos0, sin0, attend_prompt)
     x, xn = buf("f32_x", (M, D), f32), buf("f32_xn", (M, D), f32)
     logits = buf("f32_logits", (M, V), f32)
     ops.embed_rows(xn0, last_rows, xn, B, D)                    # the final-normed last prompt position of every utterance
@@ -146,7 +203,7 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
         ops.rope_table(bs.next_pos, cos, sin, HD, geo.rope_theta)
         ops.f32_rmsnorm(x, llm.layers[0]["ln1"], xn, M, D, geo.rms_eps)
         for l in range(L):
-            layer(l, x, xn, qkv, ao, gu, act, M, cos, sin, attend_cache, cache=(kcv[l], vcv[l], bs.next_slot))
+            _layer_fp32(model, l, x, xn, qkv, ao, gu, act, M, cos, sin, attend_cache, ws, cache=(kcv[l], vcv[l], bs.next_slot), ctx=ctx)
         ops.f32_gemm(xn, llm.f32["head"], logits, M, V, D, ws=ws)                      # xn: the final norm, from the last layer's finisher
         ops.f32_logprob_topk(logits, M, V, K, bs.banned, 1, tv, ti)
         ops.beam_update(tv, ti, bs, False)

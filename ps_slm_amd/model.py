@@ -651,7 +651,7 @@ class TasuModel:
         self._flush_uploads()                            # ONE H2D copy for the step's integer inputs
         return st
 
-    def prepare_audio(self, input_ids, attention_mask, labels, input_features, input_feature_length, do_psd=True) -> StepState:
+    def prepare_audio(self, input_ids, attention_mask, labels, input_features, input_feature_length, do_psd=True, fp32=None) -> StepState:
         """Audio branch (ps-slm.py:430-454, :469-473, :482): encoder -> CTC posterior -> PSD -> projector; with ``raw_features``
         (train_config.ctc_posterior=false, ps-slm.py:515-523) PSD's decisions still come from the posterior but the rows it keeps /
         averages are the encoder's output states, and those feed the projector.  A projector that concatenates k frames per row
@@ -659,7 +659,8 @@ class TasuModel:
         gives every utterance len // k rows (projector.py:41-45, ps-slm.py:482)."""
         from .encoder import psd_on_device
         B, T, _ = input_features.shape
-        fp32 = self.arith == "fp32" and labels is None                             # generate() with use_fp16 = false: fp32 encoder too
+        if fp32 is None:                                                           # generate() with use_fp16 = false: fp32 encoder too
+            fp32 = self.arith == "fp32" and labels is None                         # (an eval-mode forward asks for it explicitly)
         if fp32:
             from .encoder import encoder_posterior_fp32
             post, Te, _ = encoder_posterior_fp32(self, input_features, input_feature_length)      # the fp32 posterior

@@ -692,6 +692,10 @@ class HipOps:
         self._chk(self.lib.tasu_f32_embed_merge(_p(table), _p(proj), proj.stride(0), _p(kind), _p(idx), _p(x), M, D, self._stream()),
                   "tasu_f32_embed_merge")
 
+    def f32_ce(self, logits, labels, M, V, row_loss, row_hit, row_argmax=None, row_lse=None):
+        self._chk(self.lib.tasu_f32_ce(_p(logits), logits.stride(0), _p(labels), M, V, _p(row_loss), _p(row_hit), _p(row_argmax),
+                                       _p(row_lse), self._stream()), "tasu_f32_ce")
+
     def f32_logprob_topk(self, logits, M, V, k, banned, n_banned, out_val, out_idx):
         self._chk(self.lib.tasu_f32_logprob_topk(_p(logits), logits.stride(0), M, V, k, _p(banned), n_banned, _p(out_val), _p(out_idx),
                                                  self._stream()), "tasu_f32_logprob_topk")

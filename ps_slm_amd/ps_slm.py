@@ -470,6 +470,9 @@ class slam_model_asr:
                 labels=None, **unused):
         core = self.core
         self._refresh_if_touched()
+        # use_fp16 = false outside training: the reference's fp32 arithmetic (evaluation(), deepspeed_utils.py:394-498, or any
+        # model(**batch) under no autocast) -- fp32 projector / encoder / decoder / logits / CE (ps_slm_amd/decode_fp32.py)
+        fp32_eval = core.arith == "fp32" and not self.training
         if self.gt_emb:
             ids_list = [self.encoder_tokenizer.encode(t) for t in GT]
             alphas = keeps = row_alphas = None
@@ -478,14 +481,19 @@ class slam_model_asr:
             elif self.gt_emb_noise:
                 alphas, keeps = self.draw_noise(ids_list)
             st = core.prepare_text(input_ids, attention_mask, labels, ids_list, alphas, keeps, row_alphas=row_alphas)
-            core.run_forward_text(st, compute_loss=labels is not None, need_backward=self.training)
+            if not fp32_eval:
+                core.run_forward_text(st, compute_loss=labels is not None, need_backward=self.training)
         else:
             if input_features is None:
                 raise ValueError("the audio branch needs input_features: dataset_config.text_only=true is only valid with "
                                  "train_config.gt_emb=true (text pseudo-posterior instead of the encoder)")
             st = core.prepare_audio(input_ids, attention_mask, labels, input_features, input_feature_length,
-                                    do_psd=self.do_psd)
-            core.run_forward_llm(st, compute_loss=labels is not None, need_backward=self.training)
+                                    do_psd=self.do_psd, fp32=fp32_eval)
+            if not fp32_eval:
+                core.run_forward_llm(st, compute_loss=labels is not None, need_backward=self.training)
+        if fp32_eval:
+            from ps_slm_amd.decode_fp32 import forward_fp32
+            forward_fp32(core, st, compute_loss=labels is not None)
         self.last_state = st
         if labels is None:
             return CausalLMOutput(None, core.logits_view(st)), -1

@@ -402,6 +402,53 @@ def test_generate_fp32_mode_text_and_audio_fixture():
     assert np.array_equal(a, z["tokens_audio"]), (a, z["tokens_audio"])
 
 
+def test_eval_forward_in_fp32_equals_the_reference_to_fp32_rounding():
+    """train_config.use_fp16 = false outside training (the reference's evaluation(), Multitask/utils/deepspeed_utils.py:394-498, runs
+    without autocast): ps_slm_amd.decode_fp32.forward_fp32.  Goldens = the REAL reference's fp32 forward
+    (tests/golden/mid_text_clean.npz, mid_audio_psd.npz).  Where the bf16 step is held to |dloss| <= 2e-2 and 3 % of the logit range,
+    the fp32 forward is held to what summation order leaves: |dloss| <= 2e-5, logits and log-sum-exp within 2e-5 of their scale,
+    the same argmax on every position the reference's tie-free rows allow, the same accuracy, and (audio) the same PSD lengths."""
+    from conftest import mid_audio_psd_case
+    from ps_slm_amd.decode_fp32 import forward_fp32
+    geo = Geometry.from_dict(MID_GEOMETRY)
+    # text branch
+    z = load_npz("mid_text_clean")
+    sd = random_state_dict(geo, int(z["seed_w"]), with_encoder=False)
+    batch = synthetic_text_batch(geo, 3, seed=int(z["seed_b"]), prompt_len=9, n_audio=21, target_len=17, speech_pos=4,
+                                 feat_frames=12, noise=True, drop_prob=0.15, ragged=True)
+    batch["post_ids"] = [list(np.asarray(p)[np.asarray(k, dtype=bool)]) for p, k in zip(batch["post_ids"], batch["keeps"])]
+    gm = fp32_model(geo, sd)
+    st = gm.prepare_text(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["post_ids"], None, None)
+    forward_fp32(gm, st)
+    torch.cuda.synchronize()
+
+    def check(st, z, argmax=True):
+        res = st.dev["loss_out"].cpu()
+        assert abs(float(res[0]) - float(z["loss"])) < 2e-5 * max(1.0, abs(float(z["loss"]))), (float(res[0]), float(z["loss"]))
+        assert abs(float(res[1]) - float(z["acc"])) < 1e-6
+        valid = torch.from_numpy(st.plan.key_mask[:, : st.S].astype(bool))
+        lg = gm.logits_view(st).cpu()
+        assert lg.dtype == torch.float32
+        ref = torch.from_numpy(z["logits_cols"])
+        assert float((lg[:, :, torch.from_numpy(z["cols"])] - ref)[valid].abs().max() / ref[valid].abs().max()) < 2e-5
+        lse = st.dev["row_lse"].cpu().view(st.B, st.S)
+        assert float((lse - torch.from_numpy(z["lse"]))[valid].abs().max()) < 2e-5 * float(np.abs(z["lse"]).max())
+        if argmax and "argmax" in z:
+            am = st.dev["row_arg"].cpu().view(st.B, st.S).long()
+            assert torch.equal(am[valid], torch.from_numpy(z["argmax"]).long()[valid])
+
+    check(st, z)
+    # audio branch: fp32 encoder -> CTC softmax -> PSD (merging + blank filter) -> fp32 projector -> decoder
+    geo_a, sd_a, batch_a, za = mid_audio_psd_case()
+    gm = fp32_model(geo_a, sd_a)
+    st = gm.prepare_audio(batch_a["input_ids"], batch_a["attention_mask"], batch_a["labels"], batch_a["input_features"],
+                          batch_a["input_feature_length"], fp32=True)
+    assert np.array_equal(st.dev["psd_lens"], za["psd_lens"])
+    forward_fp32(gm, st)
+    torch.cuda.synchronize()
+    check(st, za, argmax=False)
+
+
 def test_use_fp16_false_selects_the_fp32_decode_through_the_plugin():
     """The reference's own flag picks the arithmetic (Multitask/scripts/decode_sensevoice.sh runs with use_fp16 unset = false):
     ``model_factory(train_config.use_fp16=false)`` keeps fp32 copies of the frozen weights and ``model.generate`` runs the fp32
@@ -423,6 +470,15 @@ def test_use_fp16_false_selects_the_fp32_decode_through_the_plugin():
         model.eval()
         outs[fp16] = model.generate(input_ids=ids, attention_mask=am, targets=targets, num_beams=4, max_new_tokens=12).numpy()
         if not fp16:
+            # ... and an eval-mode model(**batch) runs the fp32 forward (fp32 logits, no autograd node)
+            call = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"], input_features=None,
+                        input_feature_length=None, GT=[" ".join(map(str, p)) for p in raw["post_ids"]])
+            out, acc = model(**call)
+            assert out.logits.dtype == torch.float32 and not out.loss.requires_grad and 0.0 < float(out.loss.detach()) < 20.0
+            model.train()
+            out_t, _ = model(**call)                            # training mode keeps the bf16 step (and its autograd node)
+            assert out_t.loss.requires_grad and abs(float(out_t.loss.detach()) - float(out.loss.detach())) < 5e-2
+            model.eval()
             ids_list = [model.encoder_tokenizer.encode(t) for t in targets]
             assert all(len(p) > 0 for p in ids_list)
             st = core.prepare_text(ids, am, None, ids_list, None, None)
