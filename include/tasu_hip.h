@@ -665,7 +665,7 @@ int tasu_f32_rmsnorm(const float* x, const float* w, float* y, int M, int D, flo
 /* q and k heads of qkv [M, (H+2G)*128] rotated in place (tables [M, 64] of tasu_rope_table; x*cos + rotate_half(x)*sin with the two
  * products rounded separately like torch eager); kcache != NULL: the rotated k and the v of row m also go to cache[m, slot[m]].  */
 int tasu_f32_rope(float* qkv, const float* cos_tab, const float* sin_tab, int M, int H, int G, float* kcache, float* vcache,
-                  const int32_t* slot, int ctx, void* stream);
+                  const int32_t* slot, int ctx, int inverse, void* stream);   /* inverse = 1: the rotation's backward (sin negated) */
 /* K / V of a (rotated) prefill activation [B*S, (H+2G)*128] -> cache row b * n_beams, positions 0 .. S-1 (cache [B*n_beams, ctx, G*128]) */
 int tasu_f32_kv_fill(const float* qkv, float* kcache, float* vcache, int B, int S, int H, int G, int n_beams, int ctx, void* stream);
 /* attention over a whole sequence, out [B*S, H*128], S <= 2048.  klen == NULL: the decoder's causal prompt pass, query s of batch
@@ -687,9 +687,36 @@ int tasu_f32_embed_merge(const float* table, const float* proj, int ldp, const i
 /* Shifted CE of the eval-mode fp32 forward (Multitask/utils/deepspeed_utils.py:394-498 with use_fp16 = false; the loss of
  * transformers' ForCausalLMLoss, ignore_index -100): per row m with shift_labels[m] >= 0: row_loss = logsumexp(logits[m]) -
  * logits[m, label], row_hit = (argmax == label) (ties: first column); other rows 0.  row_argmax / row_lse optional.  Feed
- * tasu_ce_reduce with row_loss / row_hit.                                                                                        */
+ * tasu_ce_reduce with row_loss / row_hit.  dlogits (optional, may alias logits; inv_count = DEVICE float 1 / #labelled rows):
+ * the mean loss's gradient, (softmax - onehot) * inv_count on labelled rows, 0 elsewhere and in the pad columns [V, ld).          */
 int tasu_f32_ce(const float* logits, int ld, const int32_t* shift_labels, int M, int V, float* row_loss, int32_t* row_hit,
-                int32_t* row_argmax, float* row_lse, void* stream);
+                int32_t* row_argmax, float* row_lse, float* dlogits, const float* inv_count, void* stream);
+
+/* ------------------------------------------------------------------------------------------ fp32 training step (backward)
+ * train_config.use_fp16 = false DURING TRAINING (the shipped recipe, Multitask/scripts/finetune_deespeed_sensevoice.sh:37: forward and
+ * backward without autocast, Multitask/utils/deepspeed_utils.py:160,205-236).  csrc/fp32_train.hip: the backward of every non-GEMM
+ * operator of the text-only step; the GEMMs are tasu_f32_gemm_nt on transposed fp32 weight copies (dgrad) and on transposed
+ * activations (wgrad: tasu_f32_transpose).  All fp32, deterministic.
+ *   tasu_f32_rmsnorm_bwd            dx (+)= rstd (w . dy) - x rstd^3 / D sum(w dy x)            (modeling_qwen2.py:41-48 differentiated)
+ *   tasu_f32_swiglu_bwd             dgu[M, 2I] from dact[M, I] and the saved gate|up
+ *   tasu_f32_silu                   out = silu(x) (dy NULL) or dy * silu'(x)
+ *   tasu_f32_colsum                 out[c] = sum_r x[r, c]
+ *   tasu_f32_layernorm_bwd_params   dgamma / dbeta of the projector's LayerNorm from an fp32 dy (tasu_layernorm_bwd_params)
+ *   tasu_f32_transpose              dst[c, r] = src[r, c], rows [R, Rpad) zero
+ *   tasu_f32_gather_rows            out[r, :] = dx[rows[r], :] (rows[r] < 0: zeros): tasu_merge_bwd in fp32
+ *   tasu_f32_attn_bwd               causal GQA attention backward over the prompt from the saved (rotated) q|k|v and dO [B*S, H*128]:
+ *                                   dqkv [B*S, (H+2G)*128] in the rotated space (tasu_f32_rope(inverse = 1) takes it back);
+ *                                   lse_ws / delta_ws: B * H * S floats each; S <= 2048; probabilities are recomputed, no [S, S] buffers */
+int tasu_f32_rmsnorm_bwd(const float* dy, const float* x, const float* w, float* dx, int M, int D, float eps, int accumulate, void* stream);
+int tasu_f32_swiglu_bwd(const float* dact, const float* gu, float* dgu, int M, int I, void* stream);
+int tasu_f32_silu(const float* x, const float* dy, float* out, int64_t n, void* stream);
+int tasu_f32_colsum(const float* x, int ld, float* out, int R, int C, void* stream);
+int tasu_f32_layernorm_bwd_params(const float* dy, int lddy, const float* x, int ldx, const float* mean, const float* rstd, float* dgamma,
+                                  float* dbeta, int R, int D, void* stream);
+int tasu_f32_transpose(const float* src, int lds, float* dst, int ldd, int R, int C, int Rpad, void* stream);
+int tasu_f32_gather_rows(const float* dx, const int32_t* rows, float* out, int n, int D, void* stream);
+int tasu_f32_attn_bwd(const float* qkv, const float* dout, const int32_t* kstart, float* dqkv, float* lse_ws, float* delta_ws, int B, int S,
+                      int H, int G, float scale, void* stream);
 /* tasu_logprob_topk on fp32 logits: out_val = (x - max) - log(sum exp(x - max)) of the k best selectable columns (value descending,
  * column ascending), k <= 16; fewer than k selectable columns: (-inf, 0x7fffffff).                                               */
 int tasu_f32_logprob_topk(const float* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned, float* out_val,

@@ -135,7 +135,7 @@ PROTOTYPES.update({
     "tasu_f32_gemm_resid_rmsnorm": [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
     "tasu_f32_gemm_swiglu": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, i64, vp],
     "tasu_f32_gemm_qkv_rope": [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, i64, vp],
-    "tasu_f32_rope": [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp],
+    "tasu_f32_rope": [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, vp],
     "tasu_f32_kv_fill": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tasu_f32_attn_prefill": [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "tasu_f32_fsmn": [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
@@ -143,7 +143,16 @@ PROTOTYPES.update({
     "tasu_f32_swiglu": [vp, vp, i32, i32, vp],
     "tasu_f32_embed_merge": [vp, vp, i32, vp, vp, vp, i32, i32, vp],
     "tasu_f32_logprob_topk": [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp],
-    "tasu_f32_ce": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp],
+    "tasu_f32_ce": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    # fp32 training step: backward kernels (csrc/fp32_train.hip)
+    "tasu_f32_rmsnorm_bwd": [vp, vp, vp, vp, i32, i32, f32, i32, vp],
+    "tasu_f32_swiglu_bwd": [vp, vp, vp, i32, i32, vp],
+    "tasu_f32_silu": [vp, vp, vp, i64, vp],
+    "tasu_f32_colsum": [vp, i32, vp, i32, i32, vp],
+    "tasu_f32_layernorm_bwd_params": [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp],
+    "tasu_f32_transpose": [vp, i32, vp, i32, i32, i32, i32, vp],
+    "tasu_f32_gather_rows": [vp, vp, vp, i32, i32, vp],
+    "tasu_f32_attn_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
 })
 
 ABI_VERSION = 13

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(1024) void f32_rmsnorm_kernel(const float* __restri
 // go to cache[row, slot[row]] (decode step: Cache.update).  One thread per rotation pair.
 __global__ __launch_bounds__(256) void f32_rope_kernel(float* __restrict__ qkv, const float* __restrict__ ct, const float* __restrict__ st,
                                                        int M, int H, int G, float* __restrict__ kc, float* __restrict__ vc,
-                                                       const int32_t* __restrict__ slot, int ctx) {
+                                                       const int32_t* __restrict__ slot, int ctx, int inverse) {
   const int LD = (H + 2 * G) * HD, Wd = G * HD;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int per_row = (H + 2 * G) * 64;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void f32_rope_kernel(float* __restrict__ qkv, 
   float* row = qkv + (size_t)m * LD + hh * HD;
   float y1 = row[d], y2 = row[d + 64];
   if (hh < H + G) {
-    const float c = ct[(size_t)m * 64 + d], s = st[(size_t)m * 64 + d];
+    const float c = ct[(size_t)m * 64 + d], s = inverse ? -st[(size_t)m * 64 + d] : st[(size_t)m * 64 + d];   // inverse: the backward
     rope_pair_eager(y1, y2, c, s, y1, y2);
     row[d] = y1;
     row[d + 64] = y2;
@@ -555,7 +555,8 @@ __global__ __launch_bounds__(256) void f32_fsmn_kernel(const float* __restrict__
 // (argmax == label), argmax ties -> the first column (torch.argmax).  Rows without a label: loss 0, hit 0 (lse / argmax still written).
 __global__ __launch_bounds__(1024) void f32_ce_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ labels, int V,
                                                       float* __restrict__ row_loss, int32_t* __restrict__ row_hit,
-                                                      int32_t* __restrict__ row_argmax, float* __restrict__ row_lse) {
+                                                      int32_t* __restrict__ row_argmax, float* __restrict__ row_lse,
+                                                      float* __restrict__ dlogits, const float* __restrict__ inv_count) {
   __shared__ float red[16];
   __shared__ float bv[16];
   __shared__ int bi[16];
@@ -590,6 +591,14 @@ __global__ __launch_bounds__(1024) void f32_ce_kernel(const float* __restrict__ 
     row_hit[m] = on && bid == lab ? 1 : 0;
     if (row_argmax) row_argmax[m] = bid;
     if (row_lse) row_lse[m] = lse;
+  }
+  if (dlogits) {                                     // d(mean CE) / d logits = (softmax - onehot) / count on labelled rows, 0 elsewhere
+    const float lse = best + logf(s);
+    const int lab = labels[m];
+    const bool on = lab >= 0 && lab < V;
+    const float k = on ? inv_count[0] : 0.f;
+    float* d = dlogits + (size_t)m * ld;
+    for (int c = t; c < ld; c += 1024) d[c] = c < V ? k * (expf(x[c] - lse) - (c == lab ? 1.f : 0.f)) : 0.f;   // (may alias the logits: own row, own columns)
   }
 }
 
@@ -680,12 +689,12 @@ extern "C" int tasu_f32_rmsnorm(const float* x, const float* w, float* y, int M,
 }
 
 extern "C" int tasu_f32_rope(float* qkv, const float* cos_tab, const float* sin_tab, int M, int H, int G, float* kcache, float* vcache,
-                             const int32_t* slot, int ctx, void* stream) {
+                             const int32_t* slot, int ctx, int inverse, void* stream) {
   if (!qkv || !cos_tab || !sin_tab || M <= 0 || H <= 0 || G <= 0 || H % G) return TASU_ERR_ARG;
   if (kcache && (!vcache || !slot || ctx <= 0)) return TASU_ERR_ARG;
   const size_t n = (size_t)M * (H + 2 * G) * 64;
   TASU_LAUNCH(f32_rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qkv, cos_tab, sin_tab, M, H, G, kcache,
-              vcache, slot, ctx);
+              vcache, slot, ctx, inverse);
   return TASU_OK;
 }
 
@@ -702,7 +711,7 @@ extern "C" int tasu_f32_gemm_qkv_rope(const float* A, int lda, const float* Wqkv
     const int rc = f32_gemm_launch(A, lda, Wqkv, ldw, qkv, N, bias, nullptr, M, N, K, 0, 1, (hipStream_t)stream);
     if (rc) return rc;
     TASU_LAUNCH(f32_rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qkv, cos_tab, sin_tab, M, H, G, kcache,
-                vcache, slot, ctx);
+                vcache, slot, ctx, 0);
     return TASU_OK;
   }
   const int rc = f32_gemm_launch(A, lda, Wqkv, ldw, workspace, N, nullptr, nullptr, M, N, K, 0, ksplit, (hipStream_t)stream);
@@ -794,9 +803,10 @@ extern "C" int tasu_f32_embed_merge(const float* table, const float* proj, int l
 }
 
 extern "C" int tasu_f32_ce(const float* logits, int ld, const int32_t* shift_labels, int M, int V, float* row_loss, int32_t* row_hit,
-                           int32_t* row_argmax, float* row_lse, void* stream) {
-  if (!logits || !shift_labels || !row_loss || !row_hit || M <= 0 || V <= 0 || ld < V) return TASU_ERR_ARG;
-  TASU_LAUNCH(f32_ce_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, logits, ld, shift_labels, V, row_loss, row_hit, row_argmax, row_lse);
+                           int32_t* row_argmax, float* row_lse, float* dlogits, const float* inv_count, void* stream) {
+  if (!logits || !shift_labels || !row_loss || !row_hit || M <= 0 || V <= 0 || ld < V || (dlogits && !inv_count)) return TASU_ERR_ARG;
+  TASU_LAUNCH(f32_ce_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, logits, ld, shift_labels, V, row_loss, row_hit, row_argmax, row_lse,
+              dlogits, inv_count);
   return TASU_OK;
 }
 

@@ -431,6 +431,7 @@ class StepState:
     path: str = "text"   # "text" (pseudo-posterior) or "audio" (encoder + PSD): part of the graph keys, the buffers differ
     lora_drop: bool = False   # this step's forward drew LoRA dropout masks (the backward regenerates them)
     backward_ran: bool = False   # the step's backward has run (TasuEngine.backward or outputs.loss.backward(): ps_slm._HipStep)
+    fp32: bool = False           # the forward ran on the fp32 training path (train_fp32.forward_train_fp32): so must the backward
 
 
 class TasuModel:
@@ -1294,6 +1295,9 @@ class TasuModel:
         chain its collectives between the wgrad kernels."""
         if "audio_rows_pad" not in st.dev and not self.freeze_projector:
             self._pad_rows(st)                       # H2D upload stays outside the captured region
+        if getattr(st, "fp32", False):               # train_config.use_fp16 = false: the fp32 step (ps_slm_amd/train_fp32.py), eager
+            from .train_fp32 import backward_fp32
+            return backward_fp32(self, st, on_ready)
         if on_ready is None:
             self._graphed(self._shape_key(st, "bwd"), lambda: self.backward(st), st)
         else:

@@ -667,8 +667,9 @@ class HipOps:
     def f32_rmsnorm(self, x, w, y, M, D, eps):
         self._chk(self.lib.tasu_f32_rmsnorm(_p(x), _p(w), _p(y), M, D, eps, self._stream()), "tasu_f32_rmsnorm")
 
-    def f32_rope(self, qkv, cos, sin, M, H, G, kc=None, vc=None, slot=None, ctx=0):
-        self._chk(self.lib.tasu_f32_rope(_p(qkv), _p(cos), _p(sin), M, H, G, _p(kc), _p(vc), _p(slot), ctx, self._stream()), "tasu_f32_rope")
+    def f32_rope(self, qkv, cos, sin, M, H, G, kc=None, vc=None, slot=None, ctx=0, inverse=False):
+        self._chk(self.lib.tasu_f32_rope(_p(qkv), _p(cos), _p(sin), M, H, G, _p(kc), _p(vc), _p(slot), ctx, int(inverse), self._stream()),
+                  "tasu_f32_rope")
 
     def f32_kv_fill(self, qkv, kc, vc, B, S, H, G, nb, ctx):
         self._chk(self.lib.tasu_f32_kv_fill(_p(qkv), _p(kc), _p(vc), B, S, H, G, nb, ctx, self._stream()), "tasu_f32_kv_fill")
@@ -692,9 +693,36 @@ class HipOps:
         self._chk(self.lib.tasu_f32_embed_merge(_p(table), _p(proj), proj.stride(0), _p(kind), _p(idx), _p(x), M, D, self._stream()),
                   "tasu_f32_embed_merge")
 
-    def f32_ce(self, logits, labels, M, V, row_loss, row_hit, row_argmax=None, row_lse=None):
+    def f32_ce(self, logits, labels, M, V, row_loss, row_hit, row_argmax=None, row_lse=None, dlogits=None, inv_count=None):
         self._chk(self.lib.tasu_f32_ce(_p(logits), logits.stride(0), _p(labels), M, V, _p(row_loss), _p(row_hit), _p(row_argmax),
-                                       _p(row_lse), self._stream()), "tasu_f32_ce")
+                                       _p(row_lse), _p(dlogits), _p(inv_count), self._stream()), "tasu_f32_ce")
+
+    # fp32 training step: backward kernels (csrc/fp32_train.hip)
+    def f32_rmsnorm_bwd(self, dy, x, w, dx, M, D, eps, accumulate):
+        self._chk(self.lib.tasu_f32_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(dx), M, D, eps, int(accumulate), self._stream()), "tasu_f32_rmsnorm_bwd")
+
+    def f32_swiglu_bwd(self, dact, gu, dgu, M, I):
+        self._chk(self.lib.tasu_f32_swiglu_bwd(_p(dact), _p(gu), _p(dgu), M, I, self._stream()), "tasu_f32_swiglu_bwd")
+
+    def f32_silu(self, x, out, dy=None):
+        self._chk(self.lib.tasu_f32_silu(_p(x), _p(dy), _p(out), x.numel(), self._stream()), "tasu_f32_silu")
+
+    def f32_colsum(self, x, out, R, Cn):
+        self._chk(self.lib.tasu_f32_colsum(_p(x), x.stride(0), _p(out), R, Cn, self._stream()), "tasu_f32_colsum")
+
+    def f32_layernorm_bwd_params(self, dy, x, mean, rstd, dgamma, dbeta, R, D):
+        self._chk(self.lib.tasu_f32_layernorm_bwd_params(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(mean), _p(rstd), _p(dgamma), _p(dbeta),
+                                                         R, D, self._stream()), "tasu_f32_layernorm_bwd_params")
+
+    def f32_transpose(self, src, dst, R, Cn, Rpad):
+        self._chk(self.lib.tasu_f32_transpose(_p(src), src.stride(0), _p(dst), dst.stride(0), R, Cn, Rpad, self._stream()), "tasu_f32_transpose")
+
+    def f32_gather_rows(self, dx, rows, out, n, D):
+        self._chk(self.lib.tasu_f32_gather_rows(_p(dx), _p(rows), _p(out), n, D, self._stream()), "tasu_f32_gather_rows")
+
+    def f32_attn_bwd(self, qkv, dout, kstart, dqkv, lse_ws, delta_ws, B, S, H, G, scale):
+        self._chk(self.lib.tasu_f32_attn_bwd(_p(qkv), _p(dout), _p(kstart), _p(dqkv), _p(lse_ws), _p(delta_ws), B, S, H, G, scale,
+                                             self._stream()), "tasu_f32_attn_bwd")
 
     def f32_logprob_topk(self, logits, M, V, k, banned, n_banned, out_val, out_idx):
         self._chk(self.lib.tasu_f32_logprob_topk(_p(logits), logits.stride(0), M, V, k, _p(banned), n_banned, _p(out_val), _p(out_idx),

@@ -217,9 +217,9 @@ def model_factory(train_config, model_config, **kwargs):
         # the reference computes in fp32 unless use_fp16 wraps the step in bf16 autocast (deepspeed_utils.py:160,205) and ALWAYS
         # decodes in fp32 (inference_batch.py:113-117).  generate() then runs the fp32 path (ps_slm_amd/decode_fp32.py: fp32 weights,
         # cache and logits); the TRAINING step has one arithmetic, bf16 autocast semantics
-        logger.warning("train_config.use_fp16 is false: generate() decodes in fp32 (the reference's inference arithmetic); a training "
-                       "step would still compute with bf16-autocast semantics (bf16 GEMM operands, fp32 accumulation / residual "
-                       "stream / norms / loss)")
+        logger.warning("train_config.use_fp16 is false: the reference's fp32 arithmetic -- generate(), evaluation and the training step run on "
+                       "the fp32 kernels (correctness mode: the training step is ~25x slower than with use_fp16=true, which selects the "
+                       "bf16-autocast path the benchmarks measure); LoRA and the non-default projectors have the bf16 path only")
     raw = not train_config.get("ctc_posterior", True)
     if raw and projector == "cross-attention":
         raise NotImplementedError("ctc_posterior=false with the cross-attention projector: the reference's raw-feature branch "
@@ -473,6 +473,7 @@ class slam_model_asr:
         # use_fp16 = false outside training: the reference's fp32 arithmetic (evaluation(), deepspeed_utils.py:394-498, or any
         # model(**batch) under no autocast) -- fp32 projector / encoder / decoder / logits / CE (ps_slm_amd/decode_fp32.py)
         fp32_eval = core.arith == "fp32" and not self.training
+        fp32_train = core.arith == "fp32" and self.training and labels is not None      # the shipped recipe trains in fp32 too (train_fp32.py)
         if self.gt_emb:
             ids_list = [self.encoder_tokenizer.encode(t) for t in GT]
             alphas = keeps = row_alphas = None
@@ -481,17 +482,20 @@ class slam_model_asr:
             elif self.gt_emb_noise:
                 alphas, keeps = self.draw_noise(ids_list)
             st = core.prepare_text(input_ids, attention_mask, labels, ids_list, alphas, keeps, row_alphas=row_alphas)
-            if not fp32_eval:
+            if not (fp32_eval or fp32_train):
                 core.run_forward_text(st, compute_loss=labels is not None, need_backward=self.training)
         else:
             if input_features is None:
                 raise ValueError("the audio branch needs input_features: dataset_config.text_only=true is only valid with "
                                  "train_config.gt_emb=true (text pseudo-posterior instead of the encoder)")
             st = core.prepare_audio(input_ids, attention_mask, labels, input_features, input_feature_length,
-                                    do_psd=self.do_psd, fp32=fp32_eval)
-            if not fp32_eval:
+                                    do_psd=self.do_psd, fp32=fp32_eval or fp32_train)
+            if not (fp32_eval or fp32_train):
                 core.run_forward_llm(st, compute_loss=labels is not None, need_backward=self.training)
-        if fp32_eval:
+        if fp32_train:
+            from ps_slm_amd.train_fp32 import forward_train_fp32
+            forward_train_fp32(core, st)
+        elif fp32_eval:
             from ps_slm_amd.decode_fp32 import forward_fp32
             forward_fp32(core, st, compute_loss=labels is not None)
         self.last_state = st

@@ -279,3 +279,118 @@ def test_fused_slab_finishers_equal_the_two_kernel_forms(ops, M):
         outs.append((qkv, kc, vc))
     torch.cuda.synchronize()
     assert all(torch.equal(p, q) for p, q in zip(*outs))
+
+
+# ------------------------------------------------------------------------------------------ fp32 training step: backward kernels
+def test_rowwise_backward_kernels_fp32(ops):
+    """RMSNorm / SwiGLU / SiLU backward, column sums, LayerNorm parameter gradients, transpose and row gather against torch autograd
+    in float64 (csrc/fp32_train.hip)."""
+    M, D, I = 37, 1536, 520
+    x, w, dy = randn(M, D, seed=40, scale=2.0), randn(D, seed=41) + 1.0, randn(M, D, seed=42)
+    xd = x.double().requires_grad_(True)
+    y = w.double() * (xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-6))
+    (gx,) = torch.autograd.grad(y, xd, dy.double())
+    dx0 = randn(M, D, seed=43)
+    dx = dx0.clone()
+    ops.f32_rmsnorm_bwd(dy, x, w, dx, M, D, 1e-6, True)
+    assert close(dx, dx0.double() + gx)
+    ops.f32_rmsnorm_bwd(dy, x, w, dx, M, D, 1e-6, False)
+    assert close(dx, gx)
+    # SwiGLU
+    gu, dact = randn(M, 2 * I, seed=44, scale=2.0), randn(M, I, seed=45)
+    gud = gu.double().requires_grad_(True)
+    act = torch.nn.functional.silu(gud[:, :I]) * gud[:, I:]
+    (ggu,) = torch.autograd.grad(act, gud, dact.double())
+    dgu = torch.empty(M, 2 * I, device="cuda")
+    ops.f32_swiglu_bwd(dact, gu, dgu, M, I)
+    assert close(dgu, ggu)
+    # SiLU forward / backward
+    h = randn(M, I, seed=46, scale=3.0)
+    out = torch.empty_like(h)
+    ops.f32_silu(h, out)
+    assert close(out, torch.nn.functional.silu(h.double()), 1e-6)
+    hd = h.double().requires_grad_(True)
+    (gh,) = torch.autograd.grad(torch.nn.functional.silu(hd), hd, dact.double())
+    d_in = dact.clone()
+    ops.f32_silu(h, d_in, dy=d_in)                                                      # in place
+    assert close(d_in, gh)
+    # column sums, transpose, gather
+    cs = torch.empty(I, device="cuda")
+    ops.f32_colsum(h, cs, M, I)
+    assert close(cs, h.double().sum(0))
+    Rp = 64
+    tt = torch.full((I, Rp), float("nan"), device="cuda")
+    ops.f32_transpose(h, tt, M, I, Rp)
+    assert torch.equal(tt[:, :M], h.t()) and float(tt[:, M:].abs().sum()) == 0.0
+    rows = torch.tensor([3, -1, 0, 36, -1, 7], dtype=torch.int32).cuda()
+    g = torch.empty(6, D, device="cuda")
+    ops.f32_gather_rows(x, rows, g, 6, D)
+    assert torch.equal(g[0], x[3]) and torch.equal(g[3], x[36]) and float(g[1].abs().sum()) == 0.0 and float(g[4].abs().sum()) == 0.0
+    # LayerNorm parameter gradients
+    R, K, Kp = 50, 203, 256
+    xin, dyn = randn(R, Kp, seed=47), randn(R, Kp, seed=48)
+    gam, bet = randn(Kp, seed=49) + 1.0, randn(Kp, seed=50)
+    yn = torch.empty(R, Kp, device="cuda")
+    mean, rstd = torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
+    ops.layernorm_fwd(xin, gam, bet, yn, mean, rstd, R, K, 1e-5)
+    gd, bd = gam[:K].double().requires_grad_(True), bet[:K].double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xin[:, :K].double(), (K,), gd, bd, 1e-5)
+    assert close(yn[:, :K], yr)
+    gg, gb = torch.autograd.grad(yr, (gd, bd), dyn[:, :K].double())
+    dgam, dbet = torch.empty(K, device="cuda"), torch.empty(K, device="cuda")
+    ops.f32_layernorm_bwd_params(dyn, xin, mean, rstd, dgam, dbet, R, K)
+    assert close(dgam, gg) and close(dbet, gb)
+
+
+@pytest.mark.parametrize("B,S,H,G", [(2, 70, 12, 2), (1, 130, 2, 1), (2, 33, 28, 4)])
+def test_attention_backward_fp32(ops, B, S, H, G):
+    """tasu_f32_attn_bwd (probabilities recomputed from the saved q|k|v, two launches) against autograd of the float64 attention,
+    with left padding; and the rotation's backward = tasu_f32_rope(inverse)."""
+    LD = (H + 2 * G) * HD
+    qkv = randn(B * S, LD, seed=51)
+    dout = randn(B * S, H * HD, seed=52)
+    scale = HD ** -0.5
+    kstart = torch.tensor([(5 * b) % max(S // 3, 1) for b in range(B)], dtype=torch.int32).cuda()
+    dqkv = torch.full((B * S, LD), float("nan"), device="cuda")
+    lse, delta = torch.empty(B * H * S, device="cuda"), torch.empty(B * H * S, device="cuda")
+    ops.f32_attn_bwd(qkv, dout, kstart, dqkv, lse, delta, B, S, H, G, scale)
+    for b in range(B):
+        ks = int(kstart[b])
+        x = qkv.view(B, S, H + 2 * G, HD)[b].double().requires_grad_(True)
+        q, k, v = x[:, :H].transpose(0, 1), x[:, H:H + G].transpose(0, 1), x[:, H + G:].transpose(0, 1)
+        idx = torch.arange(S).cuda()
+        allow = (idx[None, :] <= idx[:, None]) & (idx[None, :] >= ks)
+        o = _attn_ref(q[:, ks:], k, v, allow[ks:], scale).transpose(0, 1).reshape(S - ks, H * HD)   # (padding queries: no visible key, no gradient)
+        do = dout.view(B, S, H * HD)[b].double()
+        (gx,) = torch.autograd.grad(o, x, do[ks:])
+        got = dqkv.view(B, S, H + 2 * G, HD)[b]
+        assert close(got[ks:], gx[ks:], 2e-5), b
+        assert float(got[:ks].abs().sum()) == 0.0
+    # RoPE backward: the inverse rotation undoes the forward one (orthogonal), and equals autograd of the forward
+    M = B * S
+    pos = torch.randint(0, 400, (M,), dtype=torch.int32).cuda()
+    cos, sin = torch.empty(M, 64, device="cuda"), torch.empty(M, 64, device="cuda")
+    ops.rope_table(pos, cos, sin, HD, 1e6)
+    y = qkv.clone()
+    ops.f32_rope(y, cos, sin, M, H, G)
+    ops.f32_rope(y, cos, sin, M, H, G, inverse=True)
+    assert close(y, qkv, 1e-6)
+
+
+def test_ce_gradient_fp32(ops):
+    """tasu_f32_ce with dlogits (in place): the mean CE's gradient against autograd, pad columns zero, rows without a label zero."""
+    M, V, ld = 9, 1000, 1024
+    logits = randn(M, ld, seed=53, scale=3.0)
+    labels = torch.tensor([5, -100, 999, 0, -100, 17, 3, 3, 500], dtype=torch.int32).cuda()
+    n = int((labels >= 0).sum())
+    inv = torch.tensor([1.0 / n], device="cuda")
+    xd = logits[:, :V].double().requires_grad_(True)
+    lab = labels.long().clone()
+    loss = torch.nn.functional.cross_entropy(xd, lab, ignore_index=-100, reduction="mean")
+    (gx,) = torch.autograd.grad(loss, xd)
+    row_loss, row_hit = torch.empty(M, device="cuda"), torch.empty(M, dtype=torch.int32, device="cuda")
+    buf = logits.clone()
+    ops.f32_ce(buf, labels, M, V, row_loss, row_hit, dlogits=buf, inv_count=inv)
+    torch.cuda.synchronize()
+    assert close(buf[:, :V], gx, 1e-5) and float(buf[:, V:].abs().sum()) == 0.0
+    assert abs(float(row_loss.sum()) / n - float(loss)) < 1e-5 and float(buf[1].abs().sum()) == 0.0
