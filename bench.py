@@ -359,6 +359,56 @@ def decode_fp32_leg(local_rank, B, new_tokens=200, beams=4):
     return rec
 
 
+def train_fp32_leg(local_rank, B, steps=3):
+    """The reference's SHIPPED training arithmetic (train_config.use_fp16 = false: forward and backward outside autocast) on the fp32
+    path (ps_slm_amd/train_fp32.py): the headline batch, a few steps, through TasuEngine.  A correctness mode: reported so that
+    nobody has to guess what it costs."""
+    from ps_slm_amd.config import DEFAULT_DS_CONFIG, ModelConfig, TrainConfig, load_ds_config
+    from ps_slm_amd.engine import TasuEngine
+    from ps_slm_amd.ps_slm import model_factory
+    from ps_slm_amd.synthetic import synthetic_text_batch
+
+    tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True, use_fp16=False,
+                     batching_strategy="dynamic")
+    mc = ModelConfig(llm_path="synthetic:qwen2.5-1.5b", encoder_projector="linear-silu", encoder_dim=25055, llm_dim=1536)
+    model, _ = model_factory(tc, mc, device=f"cuda:{local_rank}", init_seed=1234, keep_logits=False, with_encoder=False)
+    eng = TasuEngine(model, load_ds_config(DEFAULT_DS_CONFIG))
+    eng.train()
+    raw = synthetic_text_batch(model.core.geo, B, seed=1234, noise=False)
+    batch = dict(input_ids=raw["input_ids"], attention_mask=raw["attention_mask"], labels=raw["labels"], input_features=None,
+                 input_feature_length=None, GT=[" ".join(map(str, p)) for p in raw["post_ids"]])
+
+    def step():
+        out, _ = eng(**batch)
+        eng.backward(out.loss)
+        eng.step()
+        return out
+
+    step()                                                  # warm-up: allocations, the transposed fp32 weight copies
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    geo = model.core.geo
+    st = eng._last_state
+    flops = total_flops_per_utt(geo, st.S, st.Ra / B) * B
+    rec = {"metric": "train utterances/sec (fp32 arithmetic: use_fp16=false, the reference's shipped recipe)", "value": round(B / dt, 2),
+           "unit": "utterances/s", "ms_per_step": round(dt * 1e3, 2),
+           "config": {"per_gpu_batch": B, "seq_len": st.S, "dtype": "f32", "final_loss": round(float(out.loss.detach()), 4)},
+           "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": round(flops / dt / 1e12 / 157.3, 4),
+                        "note": "SURVEY 8d's algorithmic FLOPs of the step (all positions through the lm_head: the fp32 step has no "
+                                "labelled-rows shortcut) against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)"}}
+    eng.destroy()
+    del eng, model
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
+
+
 def encoder_gemm_flops_per_utt(geo, frames):
     """GEMM FLOPs of the frozen SANM encoder + CTC head per utterance (forward only; SURVEY 8d: 2 x 3,145,728 per frame-layer
     for the 512-wide layers, layer 0 reads 560 features, CTC head 2 x 512 x 25055 per frame; attention not counted here)."""
@@ -634,7 +684,7 @@ SUB_METRICS = {"audio_sft": " (audio-SFT, config 4)", "qwen2.5-7b": " (Qwen2.5-7
                "lora_r64": " (text-only, use_peft=true: LoRA r=64 on the decoder + projector)",
                "exchange_1rank": " (headline step with the N > 1 gradient exchange forced through a 1-rank RCCL "
                                  "communicator: allreduce_exposed_ms is the sanity figure)",
-               "decode_fp32": None}                     # (carries its own metric: decode tokens/s in the reference's fp32 arithmetic)
+               "decode_fp32": None, "train_fp32": None}                     # (carries its own metric: decode tokens/s in the reference's fp32 arithmetic)
 
 STDOUT_LINE_LIMIT = 8000           # the driver's record keeps ~8,000 characters of stdout and parses the line from them
 _ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step", "calls_per_step",
@@ -830,6 +880,11 @@ def main():
             except Exception as e:                      # (never the loss of the whole line)
                 extras["decode_fp32"] = {"value": None, "error": repr(e)[:300]}
             lap("decode_fp32")
+            try:
+                extras["train_fp32"] = train_fp32_leg(local_rank, args.batch)
+            except Exception as e:
+                extras["train_fp32"] = {"value": None, "error": repr(e)[:300]}
+            lap("train_fp32")
         # the N > 1 step's exchange on hardware with ONE rank: the headline step again with the chunked
         # all-reduce of the gradient bucket through a one-rank RCCL communicator, side stream and event chain included
         try:
