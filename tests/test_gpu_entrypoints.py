@@ -125,6 +125,7 @@ def test_training_entrypoint_with_graph_replay_on_a_corpus(tmp_path):
     base = ["++model_config.file=ps_slm_amd/ps_slm.py:model_factory", "++model_config.llm_path=synthetic:qwen2.5-1.5b", "++model_config.llm_dim=1536",
             "++model_config.encoder_dim=25055", "++model_config.encoder_projector=linear-silu", "++train_config.freeze_llm=true",
             "++train_config.freeze_encoder=true", "++train_config.gt_emb=false", "++train_config.ctc_posterior=true",
+            "++train_config.use_fp16=true",                       # the bf16-autocast step (use_fp16=false would train on the fp32 path, eagerly)
             "++train_config.do_psd=true", "++train_config.num_epochs=2", "++dataset_config.file=ps_slm_amd/dataset.py:get_speech_dataset",
             f"++dataset_config.train_scp_file_path={dirs['train']}", f"++dataset_config.multitask_prompt_path={tmp_path}/multiprompt.jsonl",
             "++dataset_config.prompt_style={} 151665", "++dataset_config.train_max_frame_length=40", "++dataset_config.ds_rate=8",

@@ -16,7 +16,7 @@ with tempfile.TemporaryDirectory() as root:
     res = main(["++model_config.file=ps_slm_amd/ps_slm.py:model_factory", "++model_config.llm_path=synthetic:qwen2.5-1.5b",
                 "++model_config.llm_dim=1536", "++model_config.encoder_dim=25055", "++model_config.encoder_projector=linear-silu",
                 "++train_config.freeze_llm=true", "++train_config.freeze_encoder=true", "++train_config.gt_emb=false",
-                "++train_config.ctc_posterior=true", "++train_config.do_psd=true", "++train_config.num_epochs=1",
+                "++train_config.ctc_posterior=true", "++train_config.do_psd=true", "++train_config.num_epochs=1", "++train_config.use_fp16=true",
                 "++dataset_config.file=ps_slm_amd/dataset.py:get_speech_dataset", f"++dataset_config.train_scp_file_path={dirs['train']}",
                 f"++dataset_config.multitask_prompt_path={root}/multiprompt.jsonl", "++dataset_config.prompt_style={} 151665",
                 "++dataset_config.train_max_frame_length=40", "++dataset_config.ds_rate=8", "++metric=acc", "++log_config.log_interval=1"])
