@@ -215,8 +215,9 @@ def model_factory(train_config, model_config, **kwargs):
     fp32_mode = not train_config.get("use_fp16", False)
     if fp32_mode:
         # the reference computes in fp32 unless use_fp16 wraps the step in bf16 autocast (deepspeed_utils.py:160,205) and ALWAYS
-        # decodes in fp32 (inference_batch.py:113-117).  generate() then runs the fp32 path (ps_slm_amd/decode_fp32.py: fp32 weights,
-        # cache and logits); the TRAINING step has one arithmetic, bf16 autocast semantics
+        # decodes in fp32 (inference_batch.py:113-117).  use_fp16 = false therefore selects the fp32 kernels for generate()
+        # (ps_slm_amd/decode_fp32.py), the eval-mode forward and the training step (ps_slm_amd/train_fp32.py); use_fp16 = true
+        # selects bf16 autocast semantics, the path the benchmarks measure
         logger.warning("train_config.use_fp16 is false: the reference's fp32 arithmetic -- generate(), evaluation and the training step run on "
                        "the fp32 kernels (correctness mode: the training step is ~25x slower than with use_fp16=true, which selects the "
                        "bf16-autocast path the benchmarks measure); LoRA and the non-default projectors have the bf16 path only")
