@@ -2,7 +2,7 @@
 // Multitask/scripts/finetune_deespeed_sensevoice.sh:37, runs forward AND backward without autocast).  The forward is the fp32 prompt
 // pass of fp32.hip with its activations kept; this file holds the backward of every non-GEMM operator (the GEMMs are
 // tasu_f32_gemm_nt on transposed fp32 weight copies) and the small reductions of the projector's weight gradients.  Correctness
-// mode: one thread per element / one workgroup per row, fp32 everywhere, deterministic sums; ~25x slower than the bf16 step.
+// mode: one thread per element / one workgroup per row, fp32 everywhere, deterministic sums; 11x slower than the bf16 step.
 #include "common.h"
 #include "../../include/tasu_hip.h"
 
