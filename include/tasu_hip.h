@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 13
+#define TASU_ABI_VERSION 14
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -643,9 +643,17 @@ int64_t tasu_gemm_launch_count(void);
  * tasu_f32_gemm_nt: C[M, N] = [resid +] act(A[M, K] . W[N, K]^T + bias), act 0 = none, 1 = SiLU (x / (1 + exp(-x))), 2 = ReLU;
  * v_mfma_f32_16x16x4_f32, K % 32 == 0, lda / ldw % 4 == 0, 16-byte aligned operands; resid may alias C.  With a workspace,
  * outputs of fewer than 128 tiles of 64 x 64 are computed as up to 16 K-range slabs (ksplit * M * N floats) summed in ascending
- * order by a second launch -- deterministic.                                                                                     */
+ * order by a second launch -- deterministic.
+ * At most 64 rows (the decode step's beam rows) against a matrix of 32 MB or more, K % 128 == 0: the weight-streaming kernel
+ * (f32_stream_kernel: one 8-wave workgroup per CU walks 16-column weight tiles, each wave a K slice of 16 ks with its slice of
+ * the activation rows in registers, the waves' partial tiles meet in LDS in wave order; K ranges of 128 ks as slabs).  The split
+ * is a function of (N, K) only, so a row's bits do not depend on how many rows travel with it.
+ * tasu_f32_gemm_stream: the same product forced onto that kernel with a given ks (1..6, K % (128 ks) == 0, K / (128 ks) <= 16
+ * slabs in the workspace) -- tests and tools; TASU_ERR_ARG when the problem does not fit it.                                     */
 int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
                      int M, int N, int K, int act, float* workspace, int64_t workspace_floats, void* stream);
+int tasu_f32_gemm_stream(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
+                         int M, int N, int K, int act, int ks, float* workspace, int64_t workspace_floats, void* stream);
 /* The decode step's three GEMMs that carry the NEXT row-wise kernel in the launch that sums their K-range slabs (one launch less
  * each; the same sums in the same order as tasu_f32_gemm_nt followed by that kernel -- the same bits; problems that do not split,
  * i.e. the prompt pass, run the two kernels):

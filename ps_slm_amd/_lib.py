@@ -131,6 +131,7 @@ PROTOTYPES.update({
     "tasu_gemm_launch_count": [],
     # fp32 arithmetic mode of the decode path (csrc/fp32.hip)
     "tasu_f32_gemm_nt": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
+    "tasu_f32_gemm_stream": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp],
     "tasu_f32_rmsnorm": [vp, vp, vp, i32, i32, f32, vp],
     "tasu_f32_gemm_resid_rmsnorm": [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
     "tasu_f32_gemm_swiglu": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, i64, vp],
@@ -155,7 +156,7 @@ PROTOTYPES.update({
     "tasu_f32_attn_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
 })
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 
 GEMM_SOURCES = ("common.h", "gemm_epilogue.h", "gemm.hip", "gemm_pipe.hip", "gemm_pp.hip")

@@ -4,6 +4,8 @@
 // (6.2 GB per generated position at Qwen2.5-1.5B), so the kernels are simple: one tiled MFMA GEMM
 // (v_mfma_f32_16x16x4_f32, fp32 products and accumulation) with deterministic K-range slabs for the narrow projections, and
 // wave-per-row VALU kernels for the rest.  Summation orders differ from the reference's CPU BLAS; nothing is rounded to bf16.
+#include <algorithm>
+#include <utility>
 #include "common.h"
 #include "../../include/tasu_hip.h"
 
@@ -100,6 +102,182 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(const float* __restrict__
       }
     }
   }
+}
+
+// The decode step's GEMM: at most 64 rows (beam rows) against a weight matrix that is read exactly once.  The tile kernel above
+// stages both operands through LDS and keeps one K-step in flight per workgroup; at 64 rows that leaves the matrix pipes at a
+// third of their rate (1.8 TB/s of weights, where 64 rows of fp32 MFMA can take 4.9).  This kernel is the fp32 sibling of
+// stream_body.h (the bf16 decode GEMMs):
+//   * one 8-wave workgroup per CU walks 16-column weight tiles (tile bx, bx + nbx, ...) for ONE K range of 128 KS; wave w owns the
+//     slice [16 KS w, 16 KS (w + 1)) of that range and keeps its slice of all 64 activation rows in registers (16 KS of them), so a
+//     tile is KS 16-byte loads per lane -- lane (n = lane & 15, g = lane >> 4) reads W[16 tile + n][k + 4 g .. + 3], straight into
+//     the MFMA's operand registers, three tiles in flight per wave on a branch-free ring -- and 16 KS MFMAs with no LDS read;
+//   * the eight waves' partial tiles meet in LDS (two buffers, one raw s_barrier per tile: the loads stay in flight across it) and
+//     waves 0 .. RB - 1 add them in wave order = ascending k: deterministic, like the K-range slabs the finishers add;
+//   * K ranges (grid y) write slabs [range][M][N] for the same finishers as the tile kernel's; the balance unit is one 16-column
+//     tile (gate|up: 1120 tiles x 2 ranges over 256 workgroups = 8.75 +- 0.25 tiles each).
+// RB = row blocks of 16 (ceil(M / 16)): 32 beam rows pay half the MFMAs of 64.
+constexpr int SW_NW = 8;
+// tiles in flight per wave (register slots of 4 KS each).  Three: deeper rings measured SLOWER (KS = 6: 4 slots 392 us against 366 on
+// the lm_head, KS = 5: 6 slots 34 us against 29 on the down projection) -- the step is not waiting on a latency a longer queue
+// would cover: at 64 rows the matrix pipes (2.6 us per tile) and the memory system (2.5 us at 4.8 TB/s) are both near their rates.
+template <int KS, int RB>
+constexpr int SW_RING = 3;
+template <int KS, int RB, int DBG = 0>     // DBG (tools/bench_f32_stream.py, TASU_F32_STREAM_DBG): 1 = no weight loads, 2 = no MFMAs
+__global__ __launch_bounds__(64 * SW_NW) void f32_stream_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                                float* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                                                const float* __restrict__ resid, int M, int N, int act, int ksplit,
+                                                                int tiles, int nbx) {
+  extern __shared__ __attribute__((aligned(16))) float red[];                // [2 buffers][SW_NW waves][RB][64 lanes] f32x4
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 15, g = lane >> 4;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  const int k0 = (by * SW_NW + wave) * (KS * 16) + 4 * g;                    // this lane's first k
+  // Activations: this wave's K slice of every row as MFMA operands, a[rb][c] = x[16 rb + nl][slice + 16 c + 4 g .. + 3].  Read that
+  // way from the row-major matrix a wave instruction touches 16 rows x 64 B and the 24 loads of a 64-row slice took ~10 us of every
+  // workgroup (o projection, one tile: 16.9 us with the MFMAs compiled out).  So the slice is read in row order -- 16 KS floats of a
+  // row are 4 KS consecutive lanes -- into a wave-private LDS image (32 rows at a time, pitch 16 KS + 4) and comes back as fragments.
+  f32x4 a[RB][KS];
+  auto stage_acts = [&]() {
+    constexpr int P4 = 4 * KS, PITCH = 16 * KS + 4, HR = RB >= 2 ? 32 : 16, NH = (16 * RB) / HR, PER = HR * P4 / 64;   // 16-byte pieces per row; rows per half
+    static_assert(HR * P4 % 64 == 0, "whole wave instructions");
+    float* img = red + (size_t)wave * HR * PITCH;
+    const float* as = A + (by * SW_NW + wave) * (KS * 16);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      f32x4 v[PER];
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int f = j * 64 + lane, row = f / P4, c4 = f - row * P4;
+        v[j] = *(const f32x4*)(as + (size_t)min(h * HR + row, M - 1) * lda + c4 * 4);   // (rows beyond M: clamped here, masked at the store)
+      }
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int f = j * 64 + lane, row = f / P4, c4 = f - row * P4;
+        *(f32x4*)(img + row * PITCH + c4 * 4) = v[j];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // wave-private image: its own writes have landed
+#pragma unroll
+      for (int rl = 0; rl < HR / 16; ++rl)
+#pragma unroll
+        for (int c = 0; c < KS; ++c) a[h * (HR / 16) + rl][c] = *(const f32x4*)(img + (rl * 16 + nl) * PITCH + c * 16 + 4 * g);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // ... and are read before the next half overwrites them
+    }
+    __syncthreads();                                                        // the images overlay the partial-tile buffers
+  };
+  const int ntl = (tiles - bx + nbx - 1) / nbx;                              // tiles this workgroup walks (>= 1: nbx <= tiles)
+  auto tile_of = [&](int i) { return bx + min(i, ntl - 1) * nbx; };          // clamped: loads past the end re-read the last tile
+  auto load_w = [&](f32x4 (&w)[KS], int i) {
+    if constexpr (DBG == 1) {
+#pragma unroll
+      for (int c = 0; c < KS; ++c) w[c] = f32x4{1.f + i, 2.f, 3.f, 4.f};
+      return;
+    }
+    // (inline asm: the compiler's own vmcnt bookkeeping drains the ring once per trip -- at the loop head it waits for the tile
+    // behind the one it needs as well, 4-5 us per three tiles at the loaded-memory latency; the waits are counted by hand in arrive())
+    if constexpr (DBG == 4) {                              // timing probe: real operand bits, no traffic (tiles 0 .. NR - 2 are loaded once)
+      if (i >= SW_RING<KS, RB> - 1) {
+#pragma unroll
+        for (int c = 0; c < KS; ++c) asm volatile("s_nop 0" : "+v"(w[c]));
+        return;
+      }
+    }
+    if constexpr (DBG == 3) {                              // timing probe: the same bytes read as if W were in fragment order (wrong values)
+      const float* wr = W + (((size_t)tile_of(i) * (ldw / 16) + (by * SW_NW + wave) * KS) * 64 + lane) * 4;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(w[c]) : "v"(wr + (c >> 1) * 512), "n"((c & 1) * 1024) : "memory");
+      return;
+    }
+    const float* wr = W + (size_t)min(tile_of(i) * 16 + nl, N - 1) * ldw + k0;
+#pragma unroll
+    for (int c = 0; c < KS; ++c) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(w[c]) : "v"(wr), "n"(c * 64) : "memory");
+  };
+  // piece c of the tile that has `behind` tiles of loads issued after it: loads return in order, so it is there once at most
+  // behind * KS + (KS - 1 - c) operations are outstanding (a finishing wave's store in between only makes the wait longer)
+  auto arrive = [&](f32x4& wc, auto behind, auto c) {
+    if constexpr (DBG == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wc)::"memory");
+    else if constexpr (DBG != 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wc) : "n"(decltype(behind)::value * KS + KS - 1 - decltype(c)::value) : "memory");
+  };
+  auto finish = [&](int i) {
+    if (wave >= RB) return;
+    const float* src = red + ((size_t)((i & 1) * SW_NW) * RB + wave) * 256 + lane * 4;
+    f32x4 s = *(const f32x4*)src;
+#pragma unroll
+    for (int w = 1; w < SW_NW; ++w) {
+      const f32x4 v = *(const f32x4*)(src + (size_t)w * RB * 256);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] += v[r];
+    }
+    const int m = wave * 16 + nl, n = tile_of(i) * 16 + 4 * g;
+    if (m >= M || n >= N) return;
+    if (ksplit > 1) {
+      float* dst = C + ((size_t)by * M + m) * N + n;
+      if (n + 4 <= N && !(N & 3)) {
+        *(f32x4*)dst = s;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) dst[r] = s[r];
+      }
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n + r >= N) continue;
+      float v = s[r];
+      if (bias) v += bias[n + r];
+      v = act_f(v, act);
+      if (resid) v = resid[(size_t)m * ldc + n + r] + v;
+      C[(size_t)m * ldc + n + r] = v;
+    }
+  };
+  auto compute = [&](f32x4 (&w)[KS], int i, auto behind) {
+    if (i >= ntl) return;                                  // (workgroup-uniform: a spare slot of the last trip; its loads were issued)
+    f32x4 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    [&]<int... C>(std::integer_sequence<int, C...>) {
+      (
+          [&] {
+            arrive(w[C], behind, std::integral_constant<int, C>{});
+            if constexpr (DBG == 2) {
+#pragma unroll
+              for (int rb = 0; rb < RB; ++rb) acc[rb] += w[C] * a[rb][C];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(w[C][e], a[rb][C][e], acc[rb]);
+            }
+          }(),
+          ...);
+    }(std::make_integer_sequence<int, KS>{});
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) *(f32x4*)(red + ((size_t)(((i & 1) * SW_NW + wave) * RB + rb) * 64 + lane) * 4) = acc[rb];
+    // my partial tile is in LDS; everybody's is after the barrier.  Raw s_barrier: the weight loads of the next tiles stay in
+    // flight across it.  Buffer (i & 1) is written again at tile i + 2, which every wave reaches only after the barrier of tile
+    // i + 1, i.e. after the finishing waves' reads of tile i.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    finish(i);
+  };
+  // NR tiles in flight per wave: slot s holds tile i + s while tile i is multiplied, and is refilled with tile i + NR right after.
+  // The trip count is rounded up to a multiple of NR: spare slots re-read the last tile (so that the hand-counted waits stay true)
+  // and skip their MFMAs.
+  constexpr int NR = SW_RING<KS, RB>;
+  f32x4 w[NR][KS];
+  constexpr std::integral_constant<int, NR - 1> behind{};
+#pragma unroll
+  for (int sl = 0; sl < NR - 1; ++sl) load_w(w[sl], sl);
+  stage_acts();                                            // (behind the first weight requests; its waits drain them, once)
+  for (int i = 0; i < ntl; i += NR) {
+#pragma unroll
+    for (int sl = 0; sl < NR; ++sl) {
+      load_w(w[(sl + NR - 1) % NR], i + sl + NR - 1);
+      compute(w[sl], i + sl, behind);
+    }
+  }
+  if constexpr (DBG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the spare tiles' loads land before the registers die)
 }
 
 // C = [resid +] act(bias + slab 0 + slab 1 + ...): the K ranges in ascending order, the same order on every run
@@ -238,49 +416,81 @@ __global__ __launch_bounds__(256) void f32_kv_fill_kernel(const float* __restric
   vc[dst] = qkv[bs * LD + (H + G) * HD + c];
 }
 
-// softmax(q . K^T * scale + mask) . V for ONE query row and ONE KV head per 256-thread workgroup, fp32 (eager attention of
-// modeling_qwen2.py:150-172): the REP = H / G query heads of the group share every K / V row that is loaded, and the four waves
+// softmax(q . K^T * scale + mask) . V for ONE query row and ONE KV head per workgroup, fp32 (eager attention of
+// modeling_qwen2.py:150-172): the REP = H / G query heads of the group share every K / V row that is loaded, and the waves
 // split the keys (a single wave's chain of dependent loads is what bounds this kernel: 56 -> 111 us per layer were measured for one
 // wave per group / per head).  Keys come through functors (prefill: rows of the qkv activation; decode: cache rows through the beam
-// index).  Phase 1: thread = key (the 128-dim dot products of all REP heads, q broadcast from LDS); phase 2: wave = a quarter of
-// the keys, lane = two output dims, partial outputs added in wave order (deterministic).
-// LDS: sq REP * 128 | sp REP * MAX_KEYS | part 4 * REP * 128 | red 4 * REP floats.
+// index).  Phase 1: the 128-dim dot products of all REP heads, q from LDS; phase 2: wave = its share of the keys, lane = two
+// output dims, partial outputs added in wave order (deterministic).
+// LDS: sq REP * 128 | sp REP * MAX_KEYS | part NW * REP * 128 | red NW * REP floats.
+// NW waves per workgroup: 4 for the prompt pass (one workgroup per query position: thousands of them), 16 for a generated position
+// (one per beam row and KV head: 128 workgroups on 256 CUs -- with four waves each the step waited on 512 waves' dependent loads).
+// Phase 1: EIGHT LANES PER KEY, 16 dims each (a key row is 512 contiguous bytes over 8 adjacent lanes; one thread per key read its
+// row 16 bytes at a time, every lane of a load instruction in a different row), the eight partial dots added by lane shuffles.
 constexpr int F32_ATTN_MAX_KEYS = 2048;
 constexpr int F32_ATTN_MAX_REP = 8;
-template <int REP>
-__host__ __device__ constexpr int f32_attn_lds_floats() { return REP * HD + REP * F32_ATTN_MAX_KEYS + 4 * REP * HD + 4 * REP; }
-template <int REP, typename KeyAt, typename ValAt>
+constexpr int F32_PREFILL_NW = 4, F32_DECODE_NW = 8, F32_DECODE_VPRE = 32;
+template <int REP, int NW>
+__host__ __device__ constexpr int f32_attn_lds_floats() { return REP * HD + REP * F32_ATTN_MAX_KEYS + NW * REP * HD + NW * REP; }
+template <int REP, int NW, int VPRE, typename KeyAt, typename ValAt>
 __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, float* out, float* smem, KeyAt key_at, ValAt val_at) {
+  constexpr int NT = 64 * NW;
   float* sq = smem;
   float* sp = sq + REP * HD;
   float* part = sp + REP * F32_ATTN_MAX_KEYS;
-  float* red = part + 4 * REP * HD;
+  float* red = part + NW * REP * HD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nk = k_hi - k_lo;
-  for (int i = t; i < REP * HD; i += 256) sq[i] = q[i];
+  for (int i = t; i < REP * HD; i += NT) sq[i] = q[i];
   __syncthreads();
   float mx[REP];
 #pragma unroll
   for (int h = 0; h < REP; ++h) mx[h] = -__builtin_inff();
-  for (int j = t; j < nk; j += 256) {
-    const f32x4* kr = (const f32x4*)key_at(k_lo + j);
-    float a[REP];
+  // this wave's share of the keys for phase 2; its first VPRE value rows are requested NOW, together with the key rows (they do
+  // not depend on the scores: one round trip fewer on a generated position's critical path, which is made of round trips)
+  const int qn = (nk + NW - 1) / NW, j_lo = min(nk, wave * qn), j_hi = min(nk, j_lo + qn);
+  float pva[VPRE > 0 ? VPRE : 1], pvb[VPRE > 0 ? VPRE : 1];      // VPRE = 0 (the prompt pass: throughput, not round trips): none
 #pragma unroll
-    for (int h = 0; h < REP; ++h) a[h] = 0.f;
-#pragma unroll 4
-    for (int c = 0; c < HD / 4; ++c) {
-      const f32x4 kv = kr[c];
+  for (int u = 0; u < VPRE; ++u) {
+    const float* vr = val_at(k_lo + min(j_lo + u, nk - 1));
+    pva[u] = vr[lane], pvb[u] = vr[lane + 64];
+  }
+  {
+    const int seg = t & 7;                               // this lane's 16 dims of every key it visits
+    auto dots = [&](const f32x4 (&kv)[4], int j) {
+      float a[REP];
 #pragma unroll
       for (int h = 0; h < REP; ++h) {
-        const f32x4 qv = *(const f32x4*)(sq + h * HD + c * 4);
-        a[h] += kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
-      }
-    }
+        a[h] = 0.f;
 #pragma unroll
-    for (int h = 0; h < REP; ++h) {
-      const float sc = a[h] * scale;
-      sp[h * F32_ATTN_MAX_KEYS + j] = sc;
-      mx[h] = fmaxf(mx[h], sc);
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 qv = *(const f32x4*)(sq + h * HD + seg * 16 + c * 4);
+          a[h] += kv[c][0] * qv[0] + kv[c][1] * qv[1] + kv[c][2] * qv[2] + kv[c][3] * qv[3];
+        }
+        a[h] += __shfl_xor(a[h], 1, 64);
+        a[h] += __shfl_xor(a[h], 2, 64);
+        a[h] += __shfl_xor(a[h], 4, 64);
+      }
+      if (j < nk) {
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+          const float sc = a[h] * scale;
+          if (seg == 0) sp[h * F32_ATTN_MAX_KEYS + j] = sc;
+          mx[h] = fmaxf(mx[h], sc);
+        }
+      }
+    };
+    for (int j0 = 0; j0 < nk; j0 += NT / 4) {            // two keys per lane group and trip, both rows in flight together
+      const int ja = j0 + (t >> 3), jb = ja + NT / 8;
+      const f32x4* ka = (const f32x4*)key_at(k_lo + min(ja, nk - 1)) + seg * 4;
+      const f32x4* kb = (const f32x4*)key_at(k_lo + min(jb, nk - 1)) + seg * 4;
+      f32x4 kva[4], kvb[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) kva[c] = ka[c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) kvb[c] = kb[c];
+      dots(kva, ja);
+      if (j0 + NT / 8 < nk) dots(kvb, jb);               // (workgroup-uniform)
     }
   }
 #pragma unroll
@@ -291,12 +501,17 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
   __syncthreads();
   float inv[REP];
 #pragma unroll
-  for (int h = 0; h < REP; ++h) mx[h] = fmaxf(fmaxf(red[h], red[REP + h]), fmaxf(red[2 * REP + h], red[3 * REP + h]));
+  for (int h = 0; h < REP; ++h) {
+    float m = red[h];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w * REP + h]);
+    mx[h] = m;
+  }
   __syncthreads();                                     // (red is rewritten below)
 #pragma unroll
   for (int h = 0; h < REP; ++h) {
     float sum = 0.f;
-    for (int j = t; j < nk; j += 256) {
+    for (int j = t; j < nk; j += NT) {
       const float e = expf(sp[h * F32_ATTN_MAX_KEYS + j] - mx[h]);
       sp[h * F32_ATTN_MAX_KEYS + j] = e;
       sum += e;
@@ -306,14 +521,30 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
   }
   __syncthreads();
 #pragma unroll
-  for (int h = 0; h < REP; ++h) inv[h] = 1.f / (((red[h] + red[REP + h]) + red[2 * REP + h]) + red[3 * REP + h]);
+  for (int h = 0; h < REP; ++h) {
+    float sum = red[h];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) sum += red[w * REP + h];          // (wave order: deterministic)
+    inv[h] = 1.f / sum;
+  }
   float o0[REP], o1[REP];
 #pragma unroll
   for (int h = 0; h < REP; ++h) o0[h] = o1[h] = 0.f;
-  // this wave's quarter of the keys, sixteen V rows per trip (their loads are in flight together)
-  const int q4 = (nk + 3) >> 2, j_lo = wave * q4, j_hi = min(nk, j_lo + q4);
-  constexpr int UNR = 16;
+  // the prefetched value rows first (key order, like everything after them), then eight rows per trip
   int j = j_lo;
+#pragma unroll
+  for (int u = 0; u < VPRE; ++u) {
+    if (j_lo + u < j_hi) {
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        const float p = sp[h * F32_ATTN_MAX_KEYS + j_lo + u] * inv[h];
+        o0[h] += p * pva[u];
+        o1[h] += p * pvb[u];
+      }
+    }
+  }
+  j = min(j_hi, j_lo + VPRE);
+  constexpr int UNR = 8;
   for (; j + UNR <= j_hi; j += UNR) {
     float va[UNR], vb[UNR];
 #pragma unroll
@@ -346,7 +577,12 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
     part[(wave * REP + h) * HD + lane + 64] = o1[h];
   }
   __syncthreads();
-  for (int i = t; i < REP * HD; i += 256) out[i] = ((part[i] + part[REP * HD + i]) + part[2 * REP * HD + i]) + part[3 * REP * HD + i];
+  for (int i = t; i < REP * HD; i += NT) {
+    float v = part[i];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += part[w * REP * HD + i];      // (wave order = ascending keys)
+    out[i] = v;
+  }
 }
 
 // prefill: one workgroup per (batch row, position, KV head); query s of batch row b sees keys [kstart[b], s] (causal, left padding masked)
@@ -370,7 +606,7 @@ __global__ __launch_bounds__(256) void f32_attn_prefill_kernel(const float* __re
     return;
   }
   const float* base = qkv + (size_t)b * S * LD;
-  f32_attn_group<REP>(base + (size_t)s * LD + g * REP * HD, k_lo, k_hi, scale, o, smem,
+  f32_attn_group<REP, F32_PREFILL_NW, 0>(base + (size_t)s * LD + g * REP * HD, k_lo, k_hi, scale, o, smem,
                       [&](int j) { return base + (size_t)j * LD + (H + g) * HD; },
                       [&](int j) { return base + (size_t)j * LD + (H + G + g) * HD; });
 }
@@ -378,18 +614,18 @@ __global__ __launch_bounds__(256) void f32_attn_prefill_kernel(const float* __re
 // decode: one workgroup per (beam row, KV head); key i of row m lives in cache row index[m, i] (tasu_kv_index_*), keys
 // [kstart[m], lens[m]); the row's index entries are staged in LDS first (one round trip in front of the K / V loads, not one per key)
 template <int REP>
-__global__ __launch_bounds__(256) void f32_attn_decode_kernel(const float* __restrict__ qkv, const float* __restrict__ kc,
+__global__ __launch_bounds__(64 * F32_DECODE_NW) void f32_attn_decode_kernel(const float* __restrict__ qkv, const float* __restrict__ kc,
                                                               const float* __restrict__ vc, const int32_t* __restrict__ index,
                                                               const int32_t* __restrict__ kstart, const int32_t* __restrict__ lens,
                                                               float* __restrict__ out, int M, int H, int G, int ctx, float scale) {
   extern __shared__ float smem[];
   const int g = blockIdx.x % G, m = blockIdx.x / G;
   const int LD = (H + 2 * G) * HD, Wd = G * HD;
-  int* six = (int*)(smem + f32_attn_lds_floats<REP>());
+  int* six = (int*)(smem + f32_attn_lds_floats<REP, F32_DECODE_NW>());
   const int k_lo = kstart[m], k_hi = lens[m];
-  for (int i = k_lo + threadIdx.x; i < k_hi; i += 256) six[i] = index[(size_t)m * ctx + i];
+  for (int i = k_lo + threadIdx.x; i < k_hi; i += 64 * F32_DECODE_NW) six[i] = index[(size_t)m * ctx + i];
   __syncthreads();
-  f32_attn_group<REP>(qkv + (size_t)m * LD + g * REP * HD, k_lo, k_hi, scale, out + (size_t)m * (H * HD) + g * REP * HD, smem,
+  f32_attn_group<REP, F32_DECODE_NW, F32_DECODE_VPRE>(qkv + (size_t)m * LD + g * REP * HD, k_lo, k_hi, scale, out + (size_t)m * (H * HD) + g * REP * HD, smem,
                       [&](int j) { return kc + ((size_t)six[j] * ctx + j) * Wd + g * HD; },
                       [&](int j) { return vc + ((size_t)six[j] * ctx + j) * Wd + g * HD; });
 }
@@ -606,10 +842,9 @@ __global__ __launch_bounds__(1024) void f32_ce_kernel(const float* __restrict__ 
 
 using namespace tasu_f32;
 
-// the K-range split of a problem (1 = none): outputs of fewer than 1024 tiles (every projection at <= 64 beam rows except the
-// lm_head) run as K-range slabs until ~1024 workgroups stream (a workgroup keeps 16 KiB in flight; the chip needs a few per CU to
-// reach the HBM rate)
-static int f32_ksplit(int M, int N, int K, const float* workspace, int64_t workspace_floats) {
+// the K-range split of a problem (1 = none) on the tile kernel: outputs of fewer than 1024 tiles run as K-range slabs until ~1024
+// workgroups stream (a workgroup keeps 16 KiB in flight; the chip needs a few per CU to reach the HBM rate)
+static int f32_tile_ksplit(int M, int N, int K, const float* workspace, int64_t workspace_floats) {
   const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
   int ksplit = 1;
   if (workspace && tiles < 1024) {
@@ -619,12 +854,111 @@ static int f32_ksplit(int M, int N, int K, const float* workspace, int64_t works
   }
   return ksplit;
 }
+// ... and on the streaming kernel (M <= 64, K a multiple of 128): a workgroup's K range is 128 KS, so ksplit = K / (128 KS).  The
+// KS that costs least under a two-term model -- matrix pipes (a tile is KS x 4 x RB MFMAs of 32 cycles per wave, two waves per pipe;
+// a workgroup walks ceil(tiles / nbx) tiles) against HBM (the weights once, every slab written and read once, ~5 TB/s).  Few slabs
+// for the wide projections (gate|up: KS = 6, 2 slabs), more for the narrow ones.
+constexpr int SW_KS_MAX = 6;
+struct F32StreamPlan {
+  int ks = 0, ksplit = 1, nbx = 1;
+};
+static int f32_stream_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+static int f32_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static F32StreamPlan f32_stream_plan(int M, int N, int K, const float* workspace, int64_t workspace_floats) {
+  static const int off = f32_env_int("TASU_F32_STREAM", 1) == 0, forced = f32_env_int("TASU_F32_STREAM_KS", 0);   // (tools: A/B runs, KS sweeps)
+  F32StreamPlan best;
+  // (matrices under 32 MB -- q|k|v, o at 1.5B -- stay on the tile kernel: one or two tiles per workgroup do not repay the 64-row
+  // activation slice every workgroup stages; measured 12.7 / 13.8 us there against 13-17 here, tools/prof_f32_stream.sh)
+  if (off || M > 64 || K % (16 * SW_NW) || (int64_t)N * K < (8 << 20)) return best;
+  // (the plan is that of 64 rows whatever M is: a row's bits do not depend on how many rows travel with it)
+  const int kq = K / (16 * SW_NW), tiles = (N + 15) / 16, cus = f32_stream_cus(), rb = 4;
+  double best_cost = 1e30;
+  for (int ks = 1; ks <= SW_KS_MAX; ++ks) {
+    if (kq % ks || (forced > 0 && ks != forced)) continue;
+    const int s = kq / ks;
+    if (s > 16 || (s > 1 && (!workspace || (int64_t)s * 64 * N > workspace_floats))) continue;
+    const int nbx = std::max(1, std::min(tiles, cus / s));
+    const double t_mfma = (double)((tiles + nbx - 1) / nbx) * ks * rb * 0.107;                         // us
+    const double t_hbm = ((double)N * K * 4 + (s > 1 ? 2.0 * s * 64 * N * 4 : 0.0)) / 5.0e6;          // us
+    const double cost = (t_mfma > t_hbm ? t_mfma : t_hbm) + 0.05 * s;                                 // (ties: fewer slabs)
+    if (cost < best_cost) best_cost = cost, best = F32StreamPlan{ks, s, nbx};
+  }
+  return best;
+}
+static int f32_ksplit(int M, int N, int K, const float* workspace, int64_t workspace_floats) {
+  const F32StreamPlan sp = f32_stream_plan(M, N, K, workspace, workspace_floats);
+  return sp.ks ? sp.ksplit : f32_tile_ksplit(M, N, K, workspace, workspace_floats);
+}
 static bool f32_gemm_args_ok(const float* A, int lda, const float* W, int ldw, const float* C, int ldc, int M, int N, int K) {
   return A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 4 == 0 && ldw % 4 == 0 && ldc >= N &&
          !(((uintptr_t)A | (uintptr_t)W) & 15);
 }
+template <int KS, int RB>
+static int f32_stream_launch(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid, int M,
+                             int N, int act, const F32StreamPlan& sp, hipStream_t st) {
+  const int lds = std::max(2 * SW_NW * RB * 256, SW_NW * (RB >= 2 ? 32 : 16) * (16 * KS + 4)) * 4;     // partial tiles | activation images
+  static bool set = false;
+  if (!set) {
+    (void)hipFuncSetAttribute((const void*)f32_stream_kernel<KS, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    set = true;
+  }
+  TASU_LAUNCH((f32_stream_kernel<KS, RB>), dim3(sp.nbx, sp.ksplit), dim3(64 * SW_NW), lds, st, A, lda, W, ldw, C, ldc, bias, resid, M, N, act,
+              sp.ksplit, (N + 15) / 16, sp.nbx);
+  return TASU_OK;
+}
+template <int KS>
+static int f32_stream_launch_rb(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
+                                int M, int N, int act, const F32StreamPlan& sp, hipStream_t st) {
+  switch ((M + 15) / 16) {
+    case 1: return f32_stream_launch<KS, 1>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
+    case 2: return f32_stream_launch<KS, 2>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
+    default: return f32_stream_launch<KS, 4>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);      // (33-48 rows run as 64)
+  }
+}
+static int f32_stream_dispatch(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid, int M,
+                               int N, int act, const F32StreamPlan& sp, hipStream_t st) {
+  switch (sp.ks) {
+    case 1: return f32_stream_launch_rb<1>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
+    case 2: return f32_stream_launch_rb<2>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
+    case 3: return f32_stream_launch_rb<3>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
+    case 4: return f32_stream_launch_rb<4>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
+    case 5: return f32_stream_launch_rb<5>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
+    default: {
+      static const int dbg = f32_env_int("TASU_F32_STREAM_DBG", 0);          // (tools/prof_f32_stream.sh: timing probes, wrong results)
+      if (dbg >= 1 && dbg <= 4 && M > 48) {
+        const int lds = std::max(2 * SW_NW * 4 * 256, SW_NW * 32 * (16 * 6 + 4)) * 4;
+        auto probe = [&](auto kernel) {
+          (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          TASU_LAUNCH(kernel, dim3(sp.nbx, sp.ksplit), dim3(64 * SW_NW), lds, st, A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp.ksplit,
+                      (N + 15) / 16, sp.nbx);
+          return TASU_OK;
+        };
+        if (dbg == 1) return probe(f32_stream_kernel<6, 4, 1>);
+        if (dbg == 2) return probe(f32_stream_kernel<6, 4, 2>);
+        if (dbg == 3) return probe(f32_stream_kernel<6, 4, 3>);
+        return probe(f32_stream_kernel<6, 4, 4>);
+      }
+      return f32_stream_launch_rb<6>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
+    }
+  }
+}
+// `ksplit` is what f32_ksplit returned for this problem (the caller chose its finisher by it)
 static int f32_gemm_launch(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid, int M,
-                           int N, int K, int act, int ksplit, hipStream_t st) {
+                           int N, int K, int act, int ksplit, const float* workspace, int64_t workspace_floats, hipStream_t st) {
+  const F32StreamPlan sp = f32_stream_plan(M, N, K, workspace, workspace_floats);
+  if (sp.ks && sp.ksplit == ksplit) return f32_stream_dispatch(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, ksplit);
   TASU_LAUNCH(f32_gemm_kernel, grid, dim3(256), 0, st, A, lda, W, ldw, C, ldc, bias, resid, M, N, K, K / ksplit, act, ksplit);
   return TASU_OK;
@@ -634,10 +968,30 @@ extern "C" int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw
                                 int M, int N, int K, int act, float* workspace, int64_t workspace_floats, void* stream) {
   if (!f32_gemm_args_ok(A, lda, W, ldw, C, ldc, M, N, K) || act < 0 || act > 2) return TASU_ERR_ARG;
   const int ksplit = f32_ksplit(M, N, K, workspace, workspace_floats);
-  const int rc = f32_gemm_launch(A, lda, W, ldw, ksplit > 1 ? workspace : C, ldc, bias, resid, M, N, K, act, ksplit, (hipStream_t)stream);
+  const int rc = f32_gemm_launch(A, lda, W, ldw, ksplit > 1 ? workspace : C, ldc, bias, resid, M, N, K, act, ksplit, workspace, workspace_floats, (hipStream_t)stream);
   if (rc || ksplit == 1) return rc;
   const size_t n = (size_t)M * N;
   TASU_LAUNCH(f32_sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, ksplit, C, ldc, bias,
+              resid, M, N, act);
+  return TASU_OK;
+}
+
+// tasu_f32_gemm_nt on the streaming kernel with a given K slice per wave (tests and tools: the dispatcher above only sends matrices
+// of 32 MB and more there); TASU_ERR_ARG when the problem does not fit it (M > 64, K not a multiple of 128 ks, slabs > workspace)
+extern "C" int tasu_f32_gemm_stream(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
+                                    int M, int N, int K, int act, int ks, float* workspace, int64_t workspace_floats, void* stream) {
+  if (!f32_gemm_args_ok(A, lda, W, ldw, C, ldc, M, N, K) || act < 0 || act > 2 || M > 64 || ks < 1 || ks > SW_KS_MAX || K % (16 * SW_NW * ks))
+    return TASU_ERR_ARG;
+  F32StreamPlan sp;
+  sp.ks = ks;
+  sp.ksplit = K / (16 * SW_NW * ks);
+  const int tiles = (N + 15) / 16;
+  sp.nbx = std::max(1, std::min(tiles, f32_stream_cus() / sp.ksplit));
+  if (sp.ksplit > 16 || (sp.ksplit > 1 && (!workspace || (int64_t)sp.ksplit * M * N > workspace_floats))) return TASU_ERR_ARG;
+  const int rc = f32_stream_dispatch(A, lda, W, ldw, sp.ksplit > 1 ? workspace : C, ldc, bias, resid, M, N, act, sp, (hipStream_t)stream);
+  if (rc || sp.ksplit == 1) return rc;
+  const size_t n = (size_t)M * N;
+  TASU_LAUNCH(f32_sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, sp.ksplit, C, ldc, bias,
               resid, M, N, act);
   return TASU_OK;
 }
@@ -649,13 +1003,13 @@ extern "C" int tasu_f32_gemm_resid_rmsnorm(const float* A, int lda, const float*
   if (!f32_gemm_args_ok(A, lda, W, ldw, x, ldx, M, N, K) || !norm_w || !y) return TASU_ERR_ARG;
   const int ksplit = f32_ksplit(M, N, K, workspace, workspace_floats);
   if (ksplit == 1) {                                  // (whole-K tiles: the prompt pass) GEMM, then the norm
-    const int rc = f32_gemm_launch(A, lda, W, ldw, x, ldx, bias, resid, M, N, K, 0, 1, (hipStream_t)stream);
+    const int rc = f32_gemm_launch(A, lda, W, ldw, x, ldx, bias, resid, M, N, K, 0, 1, workspace, workspace_floats, (hipStream_t)stream);
     if (rc) return rc;
     if (ldx != N) return TASU_ERR_ARG;
     TASU_LAUNCH(f32_rmsnorm_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, x, norm_w, y, N, eps);
     return TASU_OK;
   }
-  const int rc = f32_gemm_launch(A, lda, W, ldw, workspace, ldx, bias, resid, M, N, K, 0, ksplit, (hipStream_t)stream);
+  const int rc = f32_gemm_launch(A, lda, W, ldw, workspace, ldx, bias, resid, M, N, K, 0, ksplit, workspace, workspace_floats, (hipStream_t)stream);
   if (rc) return rc;
   TASU_LAUNCH(f32_sum_slabs_norm_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, workspace, ksplit, x, ldx, bias, resid, norm_w, y, M, N,
               eps);
@@ -671,12 +1025,12 @@ extern "C" int tasu_f32_gemm_swiglu(const float* A, int lda, const float* Wgu, i
   const size_t n = (size_t)M * I;
   if (ksplit == 1) {
     if (!gu) return TASU_ERR_ARG;
-    const int rc = f32_gemm_launch(A, lda, Wgu, ldw, gu, 2 * I, nullptr, nullptr, M, 2 * I, K, 0, 1, (hipStream_t)stream);
+    const int rc = f32_gemm_launch(A, lda, Wgu, ldw, gu, 2 * I, nullptr, nullptr, M, 2 * I, K, 0, 1, workspace, workspace_floats, (hipStream_t)stream);
     if (rc) return rc;
     TASU_LAUNCH(f32_swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gu, act, M, I);
     return TASU_OK;
   }
-  const int rc = f32_gemm_launch(A, lda, Wgu, ldw, workspace, 2 * I, nullptr, nullptr, M, 2 * I, K, 0, ksplit, (hipStream_t)stream);
+  const int rc = f32_gemm_launch(A, lda, Wgu, ldw, workspace, 2 * I, nullptr, nullptr, M, 2 * I, K, 0, ksplit, workspace, workspace_floats, (hipStream_t)stream);
   if (rc) return rc;
   TASU_LAUNCH(f32_sum_slabs_swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, ksplit, act, M, I);
   return TASU_OK;
@@ -708,13 +1062,13 @@ extern "C" int tasu_f32_gemm_qkv_rope(const float* A, int lda, const float* Wqkv
   const int ksplit = f32_ksplit(M, N, K, workspace, workspace_floats);
   const size_t n = (size_t)M * (H + 2 * G) * 64;
   if (ksplit == 1) {
-    const int rc = f32_gemm_launch(A, lda, Wqkv, ldw, qkv, N, bias, nullptr, M, N, K, 0, 1, (hipStream_t)stream);
+    const int rc = f32_gemm_launch(A, lda, Wqkv, ldw, qkv, N, bias, nullptr, M, N, K, 0, 1, workspace, workspace_floats, (hipStream_t)stream);
     if (rc) return rc;
     TASU_LAUNCH(f32_rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qkv, cos_tab, sin_tab, M, H, G, kcache,
                 vcache, slot, ctx, 0);
     return TASU_OK;
   }
-  const int rc = f32_gemm_launch(A, lda, Wqkv, ldw, workspace, N, nullptr, nullptr, M, N, K, 0, ksplit, (hipStream_t)stream);
+  const int rc = f32_gemm_launch(A, lda, Wqkv, ldw, workspace, N, nullptr, nullptr, M, N, K, 0, ksplit, workspace, workspace_floats, (hipStream_t)stream);
   if (rc) return rc;
   TASU_LAUNCH(f32_sum_slabs_rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, ksplit, qkv, bias,
               cos_tab, sin_tab, M, H, G, kcache, vcache, slot, ctx);
@@ -734,7 +1088,7 @@ template <int REP>
 static int f32_attn_launch(bool decode, const float* qkv, const float* kc, const float* vc, const int32_t* index, const int32_t* kstart,
                            const int32_t* lens, float* out, int rows, int S, int H, int G, int ctx, float scale, hipStream_t st) {
   // (prefill: `lens` = klen [B] or NULL)
-  const int lds = (f32_attn_lds_floats<REP>() + (decode ? F32_ATTN_MAX_KEYS : 0)) * 4;
+  const int lds = decode ? (f32_attn_lds_floats<REP, F32_DECODE_NW>() + F32_ATTN_MAX_KEYS) * 4 : f32_attn_lds_floats<REP, F32_PREFILL_NW>() * 4;
   static bool set[2] = {false, false};
   if (!set[decode]) {
     if (decode) (void)hipFuncSetAttribute((const void*)f32_attn_decode_kernel<REP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -742,7 +1096,7 @@ static int f32_attn_launch(bool decode, const float* qkv, const float* kc, const
     set[decode] = true;
   }
   if (decode) {
-    TASU_LAUNCH(f32_attn_decode_kernel<REP>, dim3(rows * G), dim3(256), lds, st, qkv, kc, vc, index, kstart, lens, out, rows, H, G, ctx, scale);
+    TASU_LAUNCH(f32_attn_decode_kernel<REP>, dim3(rows * G), dim3(64 * F32_DECODE_NW), lds, st, qkv, kc, vc, index, kstart, lens, out, rows, H, G, ctx, scale);
   } else {
     TASU_LAUNCH(f32_attn_prefill_kernel<REP>, dim3((unsigned)((long long)rows * G)), dim3(256), lds, st, qkv, kstart, lens, out, rows / S, S,
                 H, G, scale);

@@ -26,6 +26,12 @@ from .model import HD, StepState, rup
 F32_MAX_CTX = 2048          # tasu_f32_attn_*: keys per query row
 
 
+def _gemm_ws(model):
+    """The fp32 GEMMs' slab workspace: 16 K-range slabs of the widest narrow projection, or the lm_head's two slabs at 64 beam rows
+    (csrc/fp32.hip f32_stream_plan: a problem whose slabs do not fit runs unsplit on the tile kernel)."""
+    return model._buf("f32_gemm_ws", (max(16 * 128 * 4096, 2 * 64 * model.geo.llm_vocab),), torch.float32)
+
+
 def project_fp32(model, st: StepState):
     """EncoderProjectorLinearSiLU (Multitask/model/projector.py:128-151) in fp32 on the master weights: st.dev['y2_f32'] [Rap, D]."""
     ops, pr = model.ops, model.proj
@@ -37,7 +43,7 @@ def project_fp32(model, st: StepState):
         post = model._buf("post", (Fap, Kp), f32)
         ops.posterior_build(st.dev["post_ids"], st.dev["post_alpha"], post, Fap, K)
         st.dev["post"] = post
-    ws = model._buf("f32_gemm_ws", (16 * 128 * 4096,), f32)
+    ws = _gemm_ws(model)
     xn = model._buf("f32_proj_xn", (Fap, Kp), f32)
     ops.layernorm_fwd(st.dev["post"], pr.view(pr.p, "norm.weight"), pr.view(pr.p, "norm.bias"), xn, None, None, Fap, K, model.geo.ln_eps)
     h = model._buf("f32_proj_h", (Rap, Hb), f32)
@@ -94,7 +100,7 @@ def prompt_pass_fp32(model, st: StepState, on_layer=None):
     scale = HD ** -0.5
     f32 = torch.float32
     buf, d = model._buf, st.dev
-    ws = buf("f32_gemm_ws", (16 * 128 * 4096,), f32)
+    ws = _gemm_ws(model)
     y2 = project_fp32(model, st)
     kstart_b = model._upload("f32_kstart_b", ((S - valid) if left else np.zeros(B, dtype=np.int64)).astype(np.int32))
     x0 = buf("f32_x0", (M0, D), f32)
@@ -125,7 +131,7 @@ def forward_fp32(model, st: StepState, compute_loss=True):
     M0, D, V = st.B * st.S, geo.llm_dim, geo.llm_vocab
     f32, i32 = torch.float32, torch.int32
     buf, d = model._buf, st.dev
-    ws = buf("f32_gemm_ws", (16 * 128 * 4096,), f32)
+    ws = _gemm_ws(model)
     logits = buf("f32_logits_all", (M0, V), f32)
     ops.f32_gemm(xn0, llm.f32["head"], logits, M0, V, D, ws=ws)
     d.update(logits=logits)
@@ -163,7 +169,7 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
     scale = HD ** -0.5
     f32, i32 = torch.float32, torch.int32
     buf, d = model._buf, st.dev
-    ws = buf("f32_gemm_ws", (16 * 128 * 4096,), f32)
+    ws = _gemm_ws(model)
 
     # ---- KV cache (fp32) + the beam row index of the bf16 path
     kc = buf("f32_kc", (L, M * ctx * W), f32)

@@ -648,6 +648,12 @@ class HipOps:
         self._chk(self.lib.tasu_f32_gemm_nt(_p(a), a.stride(0), _p(w), w.stride(0), _p(c), c.stride(0), _p(bias), _p(resid), M, N, K, act,
                                             _p(ws), ws.numel() if ws is not None else 0, self._stream()), "tasu_f32_gemm_nt")
 
+    def f32_gemm_stream(self, a, w, c, M, N, K, ks, bias=None, resid=None, act=0, ws=None):
+        """f32_gemm forced onto the weight-streaming kernel of the decode step (M <= 64) with K slices of 16 ks per wave
+        (tasu_f32_gemm_stream: tests and tools)."""
+        self._chk(self.lib.tasu_f32_gemm_stream(_p(a), a.stride(0), _p(w), w.stride(0), _p(c), c.stride(0), _p(bias), _p(resid), M, N, K, act,
+                                                ks, _p(ws), ws.numel() if ws is not None else 0, self._stream()), "tasu_f32_gemm_stream")
+
     def f32_gemm_resid_rmsnorm(self, a, w, x, norm_w, y, M, N, K, eps, ws, resid=None, bias=None):
         """x = resid + a @ w^T (+ bias); y = rmsnorm(x, norm_w): a decoder layer's o / down projection with the norm behind it
         (tasu_f32_gemm_resid_rmsnorm: one launch for the slab sum and the norm when the problem splits)."""

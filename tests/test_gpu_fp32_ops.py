@@ -59,6 +59,59 @@ def test_gemm_fp32(ops, M, N, K, act, bias, resid):
     assert torch.equal(c1, c2)
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(64, 1536, 1536, 6), (64, 1536, 1536, 1), (33, 1000, 640, 5), (17, 48, 128, 1), (1, 16, 768, 6),
+                                      (48, 2048, 256, 2), (64, 18992, 1536, 4), (16, 20, 384, 3), (64, 1536, 8960, 5), (64, 4000, 1536, 3),
+                                      (32, 1536, 8960, 5), (64, 17920, 1536, 6)])
+def test_gemm_fp32_at_beam_rows_streams_the_weights(ops, M, N, K, ks):
+    """At most 64 rows: the weight-streaming kernel (f32_stream_kernel: register-resident activations staged through a wave-private
+    LDS image, 16-column tiles walked by one workgroup per CU on a ring of three, waves split K, K ranges of 128 ks as slabs,
+    hand-counted vmcnt).  Forced onto it with every ks (tasu_f32_gemm_stream; the dispatcher sends matrices >= 32 MB there: the
+    last case and the lm_head).  Against float64: one K range (K = 128 ks) and slabs, ragged N (1000, 20: a partial last tile and
+    a partial 4-column store), walks shorter and longer than the ring (1-75 tiles per workgroup), every row-block count, bias /
+    activation / in-place residual; the same bits on every run; and a row alone has the bits it has among 64."""
+    a, w = randn(M, K, seed=11), randn(N, K, seed=12, scale=K ** -0.5)
+    b, r = randn(N, seed=13), randn(M, N, seed=14)
+    ws = torch.empty(16 * 64 * N, device="cuda")
+    base = a.double() @ w.double().t()
+    for act, bias, resid in ((0, False, False), (1, True, True), (2, True, False)):
+        ref = base + b.double() if bias else base
+        ref = ref / (1 + torch.exp(-ref)) if act == 1 else (ref.clamp_min(0) if act == 2 else ref)
+        ref = ref + r.double() if resid else ref
+        c = r.clone() if resid else torch.full((M, N), float("nan"), device="cuda")
+        ws.fill_(float("nan"))                                  # (nothing of an earlier call's slabs is read)
+        ops.f32_gemm_stream(a, w, c, M, N, K, ks, bias=b if bias else None, resid=c if resid else None, act=act, ws=ws)
+        torch.cuda.synchronize()
+        assert close(c, ref, 2e-5), (act, float((c.double() - ref).abs().max()))
+    c1, c2 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.f32_gemm_stream(a, w, c1, M, N, K, ks, ws=ws)
+    ops.f32_gemm_stream(a, w, c2, M, N, K, ks, ws=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2)
+    if M > 16:
+        c3 = torch.empty(1, N, device="cuda")
+        ops.f32_gemm_stream(a[M - 1:], w, c3, 1, N, K, ks, ws=ws)
+        torch.cuda.synchronize()
+        assert torch.equal(c3[0], c1[M - 1])
+    # the dispatcher's choice (this kernel or the tile kernel) for the same problem: same product, and batch-independent too
+    c4, c5 = torch.empty(M, N, device="cuda"), torch.empty(1, N, device="cuda")
+    ops.f32_gemm(a, w, c4, M, N, K, ws=ws)
+    ops.f32_gemm(a[M - 1:], w, c5, 1, N, K, ws=ws)
+    torch.cuda.synchronize()
+    assert close(c4, base, 2e-5) and torch.equal(c5[0], c4[M - 1])
+
+
+def test_gemm_stream_refuses_what_it_cannot_serve(ops):
+    from ps_slm_amd.ops import TasuOpError
+    a, w, c = randn(65, 256), randn(32, 256), torch.empty(65, 32, device="cuda")
+    ws = torch.empty(1 << 20, device="cuda")
+    with pytest.raises(TasuOpError):
+        ops.f32_gemm_stream(a, w, c, 65, 32, 256, 1, ws=ws)                 # 65 rows
+    with pytest.raises(TasuOpError):
+        ops.f32_gemm_stream(a[:8], w, c[:8], 8, 32, 256, 3, ws=ws)          # 256 is not a multiple of 384
+    with pytest.raises(TasuOpError):
+        ops.f32_gemm_stream(a[:8], w, c[:8], 8, 32, 256, 1, ws=None)        # two slabs, no workspace
+
+
 @pytest.mark.parametrize("M,D", [(64, 1536), (5, 256), (130, 3584)])
 def test_rmsnorm_fp32(ops, M, D):
     x, w = randn(M, D, seed=5, scale=3.0), randn(D, seed=6) + 1.0
