@@ -881,7 +881,8 @@ static F32StreamPlan f32_stream_plan(int M, int N, int K, const float* workspace
   F32StreamPlan best;
   // (matrices under 32 MB -- q|k|v, o at 1.5B -- stay on the tile kernel: one or two tiles per workgroup do not repay the 64-row
   // activation slice every workgroup stages; measured 12.7 / 13.8 us there against 13-17 here, tools/prof_f32_stream.sh)
-  if (off || M > 64 || K % (16 * SW_NW) || (int64_t)N * K < (8 << 20)) return best;
+  static const int min_mb = f32_env_int("TASU_F32_STREAM_MIN_MB", 32);
+  if (off || M > 64 || K % (16 * SW_NW) || (int64_t)N * K * 4 < ((int64_t)min_mb << 20)) return best;
   // (the plan is that of 64 rows whatever M is: a row's bits do not depend on how many rows travel with it)
   const int kq = K / (16 * SW_NW), tiles = (N + 15) / 16, cus = f32_stream_cus(), rb = 4;
   double best_cost = 1e30;
