@@ -654,6 +654,14 @@ int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C,
                      int M, int N, int K, int act, float* workspace, int64_t workspace_floats, void* stream);
 int tasu_f32_gemm_stream(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid,
                          int M, int N, int K, int act, int ks, float* workspace, int64_t workspace_floats, void* stream);
+/* Fragment-order weights for the streaming kernel: out[((t * K/16 + k16) * 64 + lane) * 4 + e] = W[16 t + (lane & 15)][16 k16 + 4 (lane >> 4) + e]
+ * (rows >= N zero; out: ceil(N / 16) * 16 * K floats) -- a wave instruction of the kernel then reads 1 KiB contiguous instead of 16 rows x
+ * 64 B.  Every tasu_f32_gemm_* entry point takes the copy with ldw = TASU_F32_LDW_FRAGMENT where the streaming kernel serves the
+ * problem (tasu_f32_gemm_streams(M, N, K, workspace_floats) == 1), and returns TASU_ERR_ARG for it elsewhere.  Same bits as the
+ * row-major matrix on that kernel.                                                                                               */
+#define TASU_F32_LDW_FRAGMENT (-1)
+int tasu_f32_to_fragment_order(const float* W, int ldw, float* out, int N, int K, void* stream);
+int tasu_f32_gemm_streams(int M, int N, int K, int64_t workspace_floats);
 /* The decode step's three GEMMs that carry the NEXT row-wise kernel in the launch that sums their K-range slabs (one launch less
  * each; the same sums in the same order as tasu_f32_gemm_nt followed by that kernel -- the same bits; problems that do not split,
  * i.e. the prompt pass, run the two kernels):

@@ -132,6 +132,8 @@ PROTOTYPES.update({
     # fp32 arithmetic mode of the decode path (csrc/fp32.hip)
     "tasu_f32_gemm_nt": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "tasu_f32_gemm_stream": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp],
+    "tasu_f32_to_fragment_order": [vp, i32, vp, i32, i32, vp],
+    "tasu_f32_gemm_streams": [i32, i32, i32, i64],
     "tasu_f32_rmsnorm": [vp, vp, vp, i32, i32, f32, vp],
     "tasu_f32_gemm_resid_rmsnorm": [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
     "tasu_f32_gemm_swiglu": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, i64, vp],

@@ -127,7 +127,8 @@ template <int KS, int RB, int DBG = 0>     // DBG (tools/bench_f32_stream.py, TA
 __global__ __launch_bounds__(64 * SW_NW) void f32_stream_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
                                                                 float* __restrict__ C, int ldc, const float* __restrict__ bias,
                                                                 const float* __restrict__ resid, int M, int N, int act, int ksplit,
-                                                                int tiles, int nbx) {
+                                                                int tiles, int nbx, int kfrag) {
+  // ldw < 0: W is in fragment order, [tile][kfrag = K / 16][64 lanes][4]
   extern __shared__ __attribute__((aligned(16))) float red[];                // [2 buffers][SW_NW waves][RB][64 lanes] f32x4
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 15, g = lane >> 4;
   const int bx = blockIdx.x, by = blockIdx.y;
@@ -181,10 +182,26 @@ __global__ __launch_bounds__(64 * SW_NW) void f32_stream_kernel(const float* __r
         return;
       }
     }
+    // (inline asm: the compiler's own vmcnt bookkeeping drains the ring once per trip -- at the loop head it waits for the tile
+    // behind the one it needs as well, 4-5 us per three tiles at the loaded-memory latency; the waits are counted by hand in arrive())
+    if constexpr (DBG == 4) {                              // timing probe: real operand bits, no traffic (tiles 0 .. NR - 2 are loaded once)
+      if (i >= SW_RING<KS, RB> - 1) {
+#pragma unroll
+        for (int c = 0; c < KS; ++c) asm volatile("s_nop 0" : "+v"(w[c]));
+        return;
+      }
+    }
     if constexpr (DBG == 3) {                              // timing probe: the same bytes read as if W were in fragment order (wrong values)
       const float* wr = W + (((size_t)tile_of(i) * (ldw / 16) + (by * SW_NW + wave) * KS) * 64 + lane) * 4;
 #pragma unroll
       for (int c = 0; c < KS; ++c) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(w[c]) : "v"(wr + (c >> 1) * 512), "n"((c & 1) * 1024) : "memory");
+      return;
+    }
+    if (ldw < 0) {                                         // fragment order (tasu_f32_to_fragment_order): a wave instruction reads 1 KiB
+      const float* wr = W + (((size_t)tile_of(i) * kfrag + (by * SW_NW + wave) * KS) * 64 + lane) * 4;
+#pragma unroll
+      for (int c = 0; c < KS; ++c)
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(w[c]) : "v"(wr + (c >> 1) * 512), "n"((c & 1) * 1024) : "memory");
       return;
     }
     const float* wr = W + (size_t)min(tile_of(i) * 16 + nl, N - 1) * ldw + k0;
@@ -902,9 +919,10 @@ static int f32_ksplit(int M, int N, int K, const float* workspace, int64_t works
   const F32StreamPlan sp = f32_stream_plan(M, N, K, workspace, workspace_floats);
   return sp.ks ? sp.ksplit : f32_tile_ksplit(M, N, K, workspace, workspace_floats);
 }
+// ldw == TASU_F32_LDW_FRAGMENT (-1): W is the fragment-order copy (tasu_f32_to_fragment_order) -- served by the streaming kernel only
 static bool f32_gemm_args_ok(const float* A, int lda, const float* W, int ldw, const float* C, int ldc, int M, int N, int K) {
-  return A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 4 == 0 && ldw % 4 == 0 && ldc >= N &&
-         !(((uintptr_t)A | (uintptr_t)W) & 15);
+  return A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 4 == 0 && (ldw == TASU_F32_LDW_FRAGMENT || (ldw >= K && ldw % 4 == 0)) &&
+         ldc >= N && !(((uintptr_t)A | (uintptr_t)W) & 15);
 }
 template <int KS, int RB>
 static int f32_stream_launch(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* resid, int M,
@@ -916,7 +934,7 @@ static int f32_stream_launch(const float* A, int lda, const float* W, int ldw, f
     set = true;
   }
   TASU_LAUNCH((f32_stream_kernel<KS, RB>), dim3(sp.nbx, sp.ksplit), dim3(64 * SW_NW), lds, st, A, lda, W, ldw, C, ldc, bias, resid, M, N, act,
-              sp.ksplit, (N + 15) / 16, sp.nbx);
+              sp.ksplit, (N + 15) / 16, sp.nbx, sp.ks * sp.ksplit * SW_NW);
   return TASU_OK;
 }
 template <int KS>
@@ -938,17 +956,16 @@ static int f32_stream_dispatch(const float* A, int lda, const float* W, int ldw,
     case 5: return f32_stream_launch_rb<5>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
     default: {
       static const int dbg = f32_env_int("TASU_F32_STREAM_DBG", 0);          // (tools/prof_f32_stream.sh: timing probes, wrong results)
-      if (dbg >= 1 && dbg <= 4 && M > 48) {
+      if ((dbg == 1 || dbg == 2 || dbg == 4) && M > 48) {
         const int lds = std::max(2 * SW_NW * 4 * 256, SW_NW * 32 * (16 * 6 + 4)) * 4;
         auto probe = [&](auto kernel) {
           (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           TASU_LAUNCH(kernel, dim3(sp.nbx, sp.ksplit), dim3(64 * SW_NW), lds, st, A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp.ksplit,
-                      (N + 15) / 16, sp.nbx);
+                      (N + 15) / 16, sp.nbx, sp.ks * sp.ksplit * SW_NW);
           return TASU_OK;
         };
         if (dbg == 1) return probe(f32_stream_kernel<6, 4, 1>);
         if (dbg == 2) return probe(f32_stream_kernel<6, 4, 2>);
-        if (dbg == 3) return probe(f32_stream_kernel<6, 4, 3>);
         return probe(f32_stream_kernel<6, 4, 4>);
       }
       return f32_stream_launch_rb<6>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
@@ -960,6 +977,7 @@ static int f32_gemm_launch(const float* A, int lda, const float* W, int ldw, flo
                            int N, int K, int act, int ksplit, const float* workspace, int64_t workspace_floats, hipStream_t st) {
   const F32StreamPlan sp = f32_stream_plan(M, N, K, workspace, workspace_floats);
   if (sp.ks && sp.ksplit == ksplit) return f32_stream_dispatch(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
+  if (ldw < 0) return TASU_ERR_ARG;                       // (fragment order: the streaming kernel does not serve this problem)
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, ksplit);
   TASU_LAUNCH(f32_gemm_kernel, grid, dim3(256), 0, st, A, lda, W, ldw, C, ldc, bias, resid, M, N, K, K / ksplit, act, ksplit);
   return TASU_OK;
@@ -975,6 +993,33 @@ extern "C" int tasu_f32_gemm_nt(const float* A, int lda, const float* W, int ldw
   TASU_LAUNCH(f32_sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, ksplit, C, ldc, bias,
               resid, M, N, act);
   return TASU_OK;
+}
+
+// out[((t * (K / 16) + k16) * 64 + lane) * 4 + e] = W[16 t + (lane & 15)][16 k16 + 4 (lane >> 4) + e], rows >= N zero: a wave's operand
+// pieces of a 16-row tile, contiguous in the order the streaming kernel requests them
+__global__ __launch_bounds__(256) void f32_to_fragment_order_kernel(const float* __restrict__ W, int ldw, float* __restrict__ out, int N, int K) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;                // one 16-byte piece per thread
+  const int k16n = K / 16;
+  const size_t total = (size_t)((N + 15) / 16) * k16n * 64;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  const size_t tk = idx >> 6;
+  const int k16 = (int)(tk % k16n), t = (int)(tk / k16n);
+  const int n = t * 16 + (lane & 15);
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (n < N) v = *(const f32x4*)(W + (size_t)n * ldw + k16 * 16 + 4 * (lane >> 4));
+  *(f32x4*)(out + idx * 4) = v;
+}
+extern "C" int tasu_f32_to_fragment_order(const float* W, int ldw, float* out, int N, int K, void* stream) {
+  if (!W || !out || N <= 0 || K <= 0 || K % 16 || ldw < K || ldw % 4 || (((uintptr_t)W | (uintptr_t)out) & 15)) return TASU_ERR_ARG;
+  const size_t total = (size_t)((N + 15) / 16) * (K / 16) * 64;
+  TASU_LAUNCH(f32_to_fragment_order_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, out, N, K);
+  return TASU_OK;
+}
+// 1 if a product of M rows with an [N, K] matrix runs on the streaming kernel (and may therefore be given the fragment-order copy)
+extern "C" int tasu_f32_gemm_streams(int M, int N, int K, int64_t workspace_floats) {
+  static float dummy;
+  return f32_stream_plan(M, N, K, workspace_floats > 0 ? &dummy : nullptr, workspace_floats).ks > 0 ? 1 : 0;
 }
 
 // tasu_f32_gemm_nt on the streaming kernel with a given K slice per wave (tests and tools: the dispatcher above only sends matrices

@@ -32,6 +32,21 @@ def _gemm_ws(model):
     return model._buf("f32_gemm_ws", (max(16 * 128 * 4096, 2 * 64 * model.geo.llm_vocab),), torch.float32)
 
 
+def _fragments(model):
+    """Fragment-order copies of the matrices the decode step STREAMS (gate|up, down, lm_head: csrc/fp32.hip f32_stream_kernel reads
+    1 KiB per wave instruction from them instead of 16 rows x 64 B), made at the first generate(): +5.3 GB at Qwen2.5-1.5B.
+    ``TASU_F32_FRAGMENTS=0``: A/B runs on the row-major matrices (the same bits)."""
+    import os
+    llm = model.llm
+    if os.environ.get("TASU_F32_FRAGMENTS", "1") == "0" or not hasattr(model.ops, "f32_to_fragments"):
+        return None
+    fr = llm.f32.get("frag")
+    if fr is None:
+        to = model.ops.f32_to_fragments
+        fr = llm.f32["frag"] = dict(layers=[dict(wgu=to(f["wgu"]), wd=to(f["wd"])) for f in llm.f32["layers"]], head=to(llm.f32["head"]))
+    return fr
+
+
 def project_fp32(model, st: StepState):
     """EncoderProjectorLinearSiLU (Multitask/model/projector.py:128-151) in fp32 on the master weights: st.dev['y2_f32'] [Rap, D]."""
     ops, pr = model.ops, model.proj
@@ -54,7 +69,7 @@ def project_fp32(model, st: StepState):
     return y2
 
 
-def _layer_fp32(model, l, x, xn, qkv, ao, gu, act, rows, cos_t, sin_t, attend, ws, cache=None, ctx=0):
+def _layer_fp32(model, l, x, xn, qkv, ao, gu, act, rows, cos_t, sin_t, attend, ws, cache=None, ctx=0, frag=None):
     """One decoder layer; in: xn = RMSNorm(x, ln1[l]); out: x updated, xn = the NEXT norm of it (ln1[l + 1], or the final norm).
     Every projection carries the row-wise kernel behind it in the launch that sums its K-range slabs (tasu_f32_gemm_qkv_rope,
     _resid_rmsnorm, _swiglu): 9 launches per layer at <= 64 beam rows instead of 13."""
@@ -66,8 +81,9 @@ def _layer_fp32(model, l, x, xn, qkv, ao, gu, act, rows, cos_t, sin_t, attend, w
     ops.f32_gemm_qkv_rope(xn, f["wqkv"], f["bqkv"], qkv, cos_t, sin_t, rows, H, G, D, ws, kc=kc_l, vc=vc_l, slot=slot, ctx=ctx)
     attend(l, qkv, ao)
     ops.f32_gemm_resid_rmsnorm(ao, f["wo"], x, w["ln2"], xn, rows, D, H * HD, geo.rms_eps, ws, resid=x)
-    ops.f32_gemm_swiglu(xn, f["wgu"], gu, act, rows, I, D, ws)
-    ops.f32_gemm_resid_rmsnorm(act, f["wd"], x, next_norm, xn, rows, D, I, geo.rms_eps, ws, resid=x)
+    wgu, wd = (f["wgu"], f["wd"]) if frag is None else (ops.f32_weight(frag["layers"][l]["wgu"], rows, ws), ops.f32_weight(frag["layers"][l]["wd"], rows, ws))
+    ops.f32_gemm_swiglu(xn, wgu, gu, act, rows, I, D, ws)
+    ops.f32_gemm_resid_rmsnorm(act, wd, x, next_norm, xn, rows, D, I, geo.rms_eps, ws, resid=x)
 
 
 def _need_f32(model):
@@ -170,6 +186,8 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
     f32, i32 = torch.float32, torch.int32
     buf, d = model._buf, st.dev
     ws = _gemm_ws(model)
+    frag = _fragments(model)
+    head = llm.f32["head"] if frag is None else ops.f32_weight(frag["head"], M, ws)
 
     # ---- KV cache (fp32) + the beam row index of the bf16 path
     kc = buf("f32_kc", (L, M * ctx * W), f32)
@@ -209,8 +227,8 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
         ops.rope_table(bs.next_pos, cos, sin, HD, geo.rope_theta)
         ops.f32_rmsnorm(x, llm.layers[0]["ln1"], xn, M, D, geo.rms_eps)
         for l in range(L):
-            _layer_fp32(model, l, x, xn, qkv, ao, gu, act, M, cos, sin, attend_cache, ws, cache=(kcv[l], vcv[l], bs.next_slot), ctx=ctx)
-        ops.f32_gemm(xn, llm.f32["head"], logits, M, V, D, ws=ws)                      # xn: the final norm, from the last layer's finisher
+            _layer_fp32(model, l, x, xn, qkv, ao, gu, act, M, cos, sin, attend_cache, ws, cache=(kcv[l], vcv[l], bs.next_slot), ctx=ctx, frag=frag)
+        ops.f32_gemm(xn, head, logits, M, V, D, ws=ws)                                 # xn: the final norm, from the last layer's finisher
         ops.f32_logprob_topk(logits, M, V, K, bs.banned, 1, tv, ti)
         ops.beam_update(tv, ti, bs, False)
 

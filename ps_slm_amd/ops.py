@@ -17,6 +17,21 @@ GEMM_WS_BYTES = (64 << 20) + 4096 * 4          # tasu_gemm_nt_bf16_ws workspace:
 LN_BWD_SPLIT = 16
 
 
+class F32Fragments:
+    """An fp32 weight matrix [N, K] re-laid for the decode step's streaming GEMM (tasu_f32_to_fragment_order); the f32_gemm*
+    wrappers pass it with ldw = TASU_F32_LDW_FRAGMENT.  ``rows``: the row-major matrix it was made from (problems the streaming
+    kernel does not serve -- more than 64 rows -- take that one: ``HipOps.f32_weight``)."""
+    __slots__ = ("t", "N", "K", "rows")
+
+    def __init__(self, t, N, K, rows):
+        self.t, self.N, self.K, self.rows = t, N, K, rows
+
+
+def _wl(w):
+    """(pointer, leading dimension) of an fp32 weight operand"""
+    return (_p(w.t), -1) if isinstance(w, F32Fragments) else (_p(w), w.stride(0))
+
+
 class TasuOpError(RuntimeError):
     pass
 
@@ -645,28 +660,42 @@ class HipOps:
     def f32_gemm(self, a, w, c, M, N, K, bias=None, resid=None, act=0, ws=None):
         """c[M, N] = [resid +] act(a[M, K] @ w[N, K]^T + bias), everything fp32 (tasu_f32_gemm_nt); ``ws``: fp32 workspace for the
         K-range slabs of narrow outputs (16 * M * N floats cover every split)."""
-        self._chk(self.lib.tasu_f32_gemm_nt(_p(a), a.stride(0), _p(w), w.stride(0), _p(c), c.stride(0), _p(bias), _p(resid), M, N, K, act,
+        self._chk(self.lib.tasu_f32_gemm_nt(_p(a), a.stride(0), *_wl(w), _p(c), c.stride(0), _p(bias), _p(resid), M, N, K, act,
                                             _p(ws), ws.numel() if ws is not None else 0, self._stream()), "tasu_f32_gemm_nt")
+
+    def f32_to_fragments(self, w):
+        """The fragment-order copy of an fp32 [N, K] matrix (K % 16 == 0) for the decode step's streaming GEMM."""
+        N, K = w.shape
+        out = torch.empty(((N + 15) // 16) * 16 * K, device=w.device, dtype=torch.float32)
+        self._chk(self.lib.tasu_f32_to_fragment_order(_p(w), w.stride(0), _p(out), N, K, self._stream()), "tasu_f32_to_fragment_order")
+        return F32Fragments(out, N, K, w)
+
+    def f32_weight(self, w, M, ws):
+        """The operand to hand an f32_gemm* wrapper for a product with M rows: the fragment-order copy where the streaming kernel
+        serves the problem (tasu_f32_gemm_streams), the row-major matrix otherwise."""
+        if isinstance(w, F32Fragments):
+            return w if self.lib.tasu_f32_gemm_streams(M, w.N, w.K, ws.numel() if ws is not None else 0) == 1 else w.rows
+        return w
 
     def f32_gemm_stream(self, a, w, c, M, N, K, ks, bias=None, resid=None, act=0, ws=None):
         """f32_gemm forced onto the weight-streaming kernel of the decode step (M <= 64) with K slices of 16 ks per wave
         (tasu_f32_gemm_stream: tests and tools)."""
-        self._chk(self.lib.tasu_f32_gemm_stream(_p(a), a.stride(0), _p(w), w.stride(0), _p(c), c.stride(0), _p(bias), _p(resid), M, N, K, act,
+        self._chk(self.lib.tasu_f32_gemm_stream(_p(a), a.stride(0), *_wl(w), _p(c), c.stride(0), _p(bias), _p(resid), M, N, K, act,
                                                 ks, _p(ws), ws.numel() if ws is not None else 0, self._stream()), "tasu_f32_gemm_stream")
 
     def f32_gemm_resid_rmsnorm(self, a, w, x, norm_w, y, M, N, K, eps, ws, resid=None, bias=None):
         """x = resid + a @ w^T (+ bias); y = rmsnorm(x, norm_w): a decoder layer's o / down projection with the norm behind it
         (tasu_f32_gemm_resid_rmsnorm: one launch for the slab sum and the norm when the problem splits)."""
-        self._chk(self.lib.tasu_f32_gemm_resid_rmsnorm(_p(a), a.stride(0), _p(w), w.stride(0), _p(x), x.stride(0), _p(bias), _p(resid),
+        self._chk(self.lib.tasu_f32_gemm_resid_rmsnorm(_p(a), a.stride(0), *_wl(w), _p(x), x.stride(0), _p(bias), _p(resid),
                                                        _p(norm_w), _p(y), M, N, K, eps, _p(ws), ws.numel() if ws is not None else 0,
                                                        self._stream()), "tasu_f32_gemm_resid_rmsnorm")
 
     def f32_gemm_swiglu(self, a, wgu, gu, act, M, I, K, ws):
-        self._chk(self.lib.tasu_f32_gemm_swiglu(_p(a), a.stride(0), _p(wgu), wgu.stride(0), _p(gu), _p(act), M, I, K, _p(ws),
+        self._chk(self.lib.tasu_f32_gemm_swiglu(_p(a), a.stride(0), *_wl(wgu), _p(gu), _p(act), M, I, K, _p(ws),
                                                 ws.numel() if ws is not None else 0, self._stream()), "tasu_f32_gemm_swiglu")
 
     def f32_gemm_qkv_rope(self, a, wqkv, bias, qkv, cos, sin, M, H, G, K, ws, kc=None, vc=None, slot=None, ctx=0):
-        self._chk(self.lib.tasu_f32_gemm_qkv_rope(_p(a), a.stride(0), _p(wqkv), wqkv.stride(0), _p(bias), _p(qkv), _p(cos), _p(sin), M, H, G,
+        self._chk(self.lib.tasu_f32_gemm_qkv_rope(_p(a), a.stride(0), *_wl(wqkv), _p(bias), _p(qkv), _p(cos), _p(sin), M, H, G,
                                                   K, _p(kc), _p(vc), _p(slot), ctx, _p(ws), ws.numel() if ws is not None else 0,
                                                   self._stream()), "tasu_f32_gemm_qkv_rope")
 

@@ -100,6 +100,43 @@ def test_gemm_fp32_at_beam_rows_streams_the_weights(ops, M, N, K, ks):
     assert close(c4, base, 2e-5) and torch.equal(c5[0], c4[M - 1])
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(64, 1536, 1536, 6), (33, 1000, 640, 5), (1, 16, 768, 2), (64, 17920, 1536, 6), (16, 1536, 8960, 5)])
+def test_gemm_stream_on_fragment_order_weights(ops, M, N, K, ks):
+    """tasu_f32_to_fragment_order lays a wave's operand pieces of every 16-row tile out contiguously ([tile][K / 16][64 lanes][4],
+    rows past N zero); the streaming kernel on that copy gives the BITS it gives on the row-major matrix (same products, same order),
+    through the forced entry and -- for a matrix of 32 MB and more -- through the dispatcher; a problem the streaming kernel does
+    not serve refuses the copy, and HipOps.f32_weight hands such a problem the row-major matrix."""
+    from ps_slm_amd.ops import TasuOpError
+    a, w = randn(M, K, seed=21), randn(N, K, seed=22, scale=K ** -0.5)
+    fr = ops.f32_to_fragments(w)
+    torch.cuda.synchronize()
+    T = (N + 15) // 16
+    wp = torch.zeros(T * 16, K, device="cuda")
+    wp[:N] = w
+    want = wp.view(T, 16, K // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)      # [t][k16][g = lane >> 4][n = lane & 15][e]
+    assert torch.equal(fr.t, want)
+    ws = torch.empty(16 * 64 * N, device="cuda")
+    c1, c2 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.f32_gemm_stream(a, w, c1, M, N, K, ks, ws=ws)
+    ops.f32_gemm_stream(a, fr, c2, M, N, K, ks, ws=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2)
+    served = ops.lib.tasu_f32_gemm_streams(M, N, K, ws.numel()) == 1
+    assert served == (N * K * 4 >= 32 << 20)
+    c3, c4 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.f32_gemm(a, w, c3, M, N, K, ws=ws)
+    if served:
+        ops.f32_gemm(a, fr, c4, M, N, K, ws=ws)
+        assert ops.f32_weight(fr, M, ws) is fr
+    else:
+        with pytest.raises(TasuOpError):
+            ops.f32_gemm(a, fr, c4, M, N, K, ws=ws)
+        assert ops.f32_weight(fr, M, ws) is w
+        ops.f32_gemm(a, ops.f32_weight(fr, M, ws), c4, M, N, K, ws=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(c3, c4)
+
+
 def test_gemm_stream_refuses_what_it_cannot_serve(ops):
     from ps_slm_amd.ops import TasuOpError
     a, w, c = randn(65, 256), randn(32, 256), torch.empty(65, 32, device="cuda")
