@@ -137,6 +137,33 @@ def test_gemm_stream_on_fragment_order_weights(ops, M, N, K, ks):
     assert torch.equal(c3, c4)
 
 
+def test_gemm_stream_random_shapes(ops):
+    """Forty random problems on the streaming kernel -- rows 1..64, ragged N, every ks with 1..16 K ranges, padded leading
+    dimensions of both operands and of the output, row-major and fragment-order weights -- against float64, bits equal between
+    the two weight layouts."""
+    rng = np.random.default_rng(20261004)
+    for case in range(40):
+        M = int(rng.integers(1, 65))
+        N = int(rng.integers(1, 2500))
+        ks = int(rng.integers(1, 7))
+        nsl = int(rng.integers(1, 17))
+        K = 128 * ks * nsl
+        lda, ldw, ldc = K + 4 * int(rng.integers(0, 3)), K + 4 * int(rng.integers(0, 3)), N + int(rng.integers(0, 5))
+        a_full, w_full = randn(M, lda, seed=100 + case), randn(N, ldw, seed=200 + case, scale=K ** -0.5)
+        a, w = a_full[:, :K], w_full[:, :K]
+        c = torch.full((M, ldc), float("nan"), device="cuda")
+        ws = torch.empty(16 * 64 * N, device="cuda")
+        ops.f32_gemm_stream(a, w, c[:, :N], M, N, K, ks, ws=ws)
+        fr = ops.f32_to_fragments(w)
+        c2 = torch.full((M, ldc), float("nan"), device="cuda")
+        ops.f32_gemm_stream(a, fr, c2[:, :N], M, N, K, ks, ws=ws)
+        torch.cuda.synchronize()
+        ref = a.double() @ w.double().t()
+        assert close(c[:, :N], ref, 2e-5), (case, M, N, K, ks)
+        assert torch.equal(c[:, :N], c2[:, :N]), (case, M, N, K, ks)
+        assert torch.isnan(c[:, N:]).all()                      # nothing written past the N columns
+
+
 def test_gemm_stream_refuses_what_it_cannot_serve(ops):
     from ps_slm_amd.ops import TasuOpError
     a, w, c = randn(65, 256), randn(32, 256), torch.empty(65, 32, device="cuda")
