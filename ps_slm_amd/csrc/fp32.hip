@@ -889,8 +889,9 @@ static int f32_stream_cus() {
   }
   return cus;
 }
+// (lab build only -- common.h tasu_lab_env: the shipped library reads no tuning variable)
 static int f32_env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
+  const char* e = tasu_lab_env(name);
   return e ? atoi(e) : dflt;
 }
 static F32StreamPlan f32_stream_plan(int M, int N, int K, const float* workspace, int64_t workspace_floats) {
@@ -955,6 +956,7 @@ static int f32_stream_dispatch(const float* A, int lda, const float* W, int ldw,
     case 4: return f32_stream_launch_rb<4>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
     case 5: return f32_stream_launch_rb<5>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
     default: {
+#ifdef TASU_LAB
       static const int dbg = f32_env_int("TASU_F32_STREAM_DBG", 0);          // (tools/prof_f32_stream.sh: timing probes, wrong results)
       if ((dbg == 1 || dbg == 2 || dbg == 4) && M > 48) {
         const int lds = std::max(2 * SW_NW * 4 * 256, SW_NW * 32 * (16 * 6 + 4)) * 4;
@@ -968,6 +970,7 @@ static int f32_stream_dispatch(const float* A, int lda, const float* W, int ldw,
         if (dbg == 2) return probe(f32_stream_kernel<6, 4, 2>);
         return probe(f32_stream_kernel<6, 4, 4>);
       }
+#endif
       return f32_stream_launch_rb<6>(A, lda, W, ldw, C, ldc, bias, resid, M, N, act, sp, st);
     }
   }

@@ -1,6 +1,7 @@
 """fp32 decode-step GEMMs alone, on rotating (cold) weight copies: microseconds and weight TB/s per shape.
 
     python tools/bench_f32_stream.py [rows]          # rows: beam rows (default 64)
+The switches below exist in the LAB build (make -C ps_slm_amd/csrc lab; TASU_LIB_PATH=ps_slm_amd/libtasu_hip_lab.so):
     TASU_F32_STREAM=0 python tools/bench_f32_stream.py     # the tile kernel (csrc/fp32.hip f32_gemm_kernel) on the same shapes
     TASU_F32_STREAM_KS=3 python tools/bench_f32_stream.py  # force the streaming kernel's K slice (ksplit = K / (128 KS))
 

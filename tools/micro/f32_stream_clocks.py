@@ -1,4 +1,5 @@
 """Clock and power while the fp32 lm_head GEMM (64 rows) runs back to back for a few seconds: is the fp32 decode step power-bound?
+    (lab build: make -C ps_slm_amd/csrc lab; TASU_LIB_PATH=ps_slm_amd/libtasu_hip_lab.so)
     TASU_F32_STREAM_DBG={0,1,2,4} python tools/micro/f32_stream_clocks.py      # 1 = no weight loads, 2 = no MFMAs, 4 = real bits, no traffic
 Samples `rocm-smi --showclocks --showpower` from a thread while the stream is busy."""
 import json

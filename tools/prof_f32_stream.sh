@@ -1,6 +1,8 @@
 # kernel-only times of the fp32 decode-step GEMMs per shape (rocprofv3 kernel trace of tools/bench_f32_stream.py), one run per
+# (the switches live in the lab build: make -C ps_slm_amd/csrc lab; the script loads ps_slm_amd/libtasu_hip_lab.so)
 # setting: DBGS="0 1 2" (TASU_F32_STREAM_DBG probes) and/or KSS="1 2 3" (TASU_F32_STREAM_KS); TILE=1 adds the tile kernel.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+make -C ps_slm_amd/csrc lab > /dev/null 2>&1; export TASU_LIB_PATH=$GRAFT_REPO_ROOT/ps_slm_amd/libtasu_hip_lab.so
 run() {   # tag, env assignment
   env $2 true
   ( export $2; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/f32s -o $1 -- python3 tools/bench_f32_stream.py > gpurun_out/f32s_$1.log 2>&1 )
