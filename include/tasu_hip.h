@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 14
+#define TASU_ABI_VERSION 15
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -396,6 +396,10 @@ int tasu_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stre
  * aligned.                                                                                                                  */
 int tasu_gemm_nt_rank(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int out_f32,
                       int transposed, void* stream);
+/* The same product (bf16 out, not transposed) for the 1..4 members of an adapted group in ONE launch: problem t = (A[t], lda[t],
+ * B[t], ldb[t], C[t], K[t]); M, N and ldc are shared (ps_slm_amd/lora.py: the members' rank activations / their gradients). */
+int tasu_gemm_nt_rank_group(int n_members, const void* const* A, const int* lda, const void* const* B, const int* ldb, void* const* C, int ldc,
+                            int M, int N, const int* K, void* stream);
 /* The same product with A given K-MAJOR, C[M, N] = At[K, M]^T . B[N, K]^T (fp32): a weight gradient straight from the step's
  * row-major tensors -- dB = dy^T u with At = dy [rows, out], dA^T = xd^T du with At = xd [rows, in] (torch autograd of
  * peft's lora_B(lora_A(dropout(x))), cf. Multitask/model/ps-slm.py:114-117) -- without a transposed copy of the big operand
@@ -411,6 +415,13 @@ int tasu_scale_bf16(const void* src, void* dst, float s, int64_t n, void* stream
  * forward applied to that input (element index m * N + n).  R % 64 == 0 (zero-padded rank), N % 8 == 0, ld* % 8 == 0.           */
 int tasu_lora_apply(void* y, int ldy, const void* u, int ldu, const void* W, int ldw, int M, int N, int R, float s, float p,
                     const void* rng, int stream_id, const float* x_in, float* x_out, int ldx, void* stream);
+/* tasu_lora_apply (R = 64, no residual output) for the 1..4 members of a group in ONE pass over y, members applied in the order
+ * given: the roundings of the member-by-member launches, the same bits.  tasu_lora_dropout_norm_group: tasu_lora_dropout_norm for
+ * every member of a group (each its own mask stream) from one evaluation of the norm. */
+int tasu_lora_apply_group(void* y, int ldy, int n_members, const void* const* u, int ldu, const void* const* W, int ldw, const int* stream_ids,
+                          int M, int N, int R, float s, float p, const void* rng, void* stream);
+int tasu_lora_dropout_norm_group(const float* x, const float* w, const float* rstd, int n_members, void* const* dst, const int* stream_ids,
+                                 int M, int D, float p, const void* rng, void* stream);
 int tasu_lora_dropout(const void* src, int ld_src, void* dst, int ld_dst, int M, int C, float p, const void* rng, int stream_id,
                       void* stream);
 int tasu_lora_dropout_norm(const float* x, const float* w, const float* rstd, void* dst, int M, int D, float p, const void* rng,

@@ -48,6 +48,9 @@ PROTOTYPES = {
     "tasu_relu_bwd": [vp, vp, vp, i64, vp],
     "tasu_relu_fwd": [vp, vp, i64, vp],
     "tasu_gemm_nt_rank": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tasu_gemm_nt_rank_group": [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],
+    "tasu_lora_apply_group": [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, f32, f32, vp, vp],
+    "tasu_lora_dropout_norm_group": [vp, vp, vp, i32, vp, vp, i32, i32, f32, vp, vp],
     "tasu_gemm_tn_rank": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "tasu_scale_bf16": [vp, vp, f32, i64, vp],
     "tasu_lora_apply": [vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, i32, vp, vp, i32, vp],
@@ -158,7 +161,7 @@ PROTOTYPES.update({
     "tasu_f32_attn_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
 })
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 
 GEMM_SOURCES = ("common.h", "gemm_epilogue.h", "gemm.hip", "gemm_pipe.hip", "gemm_pp.hip")

@@ -26,8 +26,8 @@ constexpr int NW = 8;
 constexpr int REGION = 10240;                           // per wave: A 16 x 128 B, then B 64 x 128 B
 
 template <bool F32OUT, bool TSTORE>
-__global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
-                                                               void* __restrict__ Cv, int ldc, int M, int N, int K) {
+__device__ __forceinline__ void rank_gemm_body(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
+                                               void* __restrict__ Cv, int ldc, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m0 = blockIdx.x * 16;
@@ -102,6 +102,25 @@ __global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __res
     if constexpr (F32OUT) ((float*)Cv)[off] = s[r];
     else ((bf16*)Cv)[off] = (bf16)s[r];
   }
+}
+
+template <bool F32OUT, bool TSTORE>
+__global__ __launch_bounds__(64 * NW, 2) void rank_gemm_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
+                                                               void* __restrict__ Cv, int ldc, int M, int N, int K) {
+  rank_gemm_body<F32OUT, TSTORE>(A, lda, B, ldb, Cv, ldc, M, N, K);
+}
+// the members of an adapted group in one launch (grid y = member): same M, N and output leading dimension, each member its own
+// operands and K -- bf16 out, the arithmetic of rank_gemm_kernel<false, false> per member
+constexpr int RANK_GROUP_MAX = 4;
+struct RankGroup {
+  const bf16* A[RANK_GROUP_MAX];
+  const bf16* B[RANK_GROUP_MAX];
+  bf16* C[RANK_GROUP_MAX];
+  int lda[RANK_GROUP_MAX], ldb[RANK_GROUP_MAX], K[RANK_GROUP_MAX];
+};
+__global__ __launch_bounds__(64 * NW, 2) void rank_gemm_group_kernel(RankGroup g, int ldc, int M, int N) {
+  const int t = blockIdx.y;
+  rank_gemm_body<false, false>(g.A[t], g.lda[t], g.B[t], g.ldb[t], g.C[t], ldc, M, N, g.K[t]);
 }
 
 template <bool F32OUT, bool TSTORE>
@@ -242,6 +261,28 @@ extern "C" int tasu_gemm_nt_rank(const void* A, int lda, const void* B, int ldb,
   hipStream_t st = (hipStream_t)stream;
   if (out_f32) return transposed ? launch<true, true>(A, lda, B, ldb, C, ldc, M, N, K, st) : launch<true, false>(A, lda, B, ldb, C, ldc, M, N, K, st);
   return transposed ? launch<false, true>(A, lda, B, ldb, C, ldc, M, N, K, st) : launch<false, false>(A, lda, B, ldb, C, ldc, M, N, K, st);
+}
+
+// tasu_gemm_nt_rank (bf16 out) for n_members problems that share M, N and ldc, in one launch
+extern "C" int tasu_gemm_nt_rank_group(int n_members, const void* const* A, const int* lda, const void* const* B, const int* ldb, void* const* C,
+                                       int ldc, int M, int N, const int* K, void* stream) {
+  if (n_members < 1 || n_members > RANK_GROUP_MAX || !A || !lda || !B || !ldb || !C || !K || M <= 0 || N <= 0 || N > 64 || ldc < N)
+    return TASU_ERR_ARG;
+  RankGroup g{};
+  for (int t = 0; t < n_members; ++t) {
+    if (!A[t] || !B[t] || !C[t] || K[t] <= 0 || K[t] % 64 || lda[t] % 8 || ldb[t] % 8 || lda[t] < K[t] || ldb[t] < K[t] ||
+        (((uintptr_t)A[t] | (uintptr_t)B[t]) & 15))
+      return TASU_ERR_ARG;
+    g.A[t] = (const bf16*)A[t], g.B[t] = (const bf16*)B[t], g.C[t] = (bf16*)C[t], g.lda[t] = lda[t], g.ldb[t] = ldb[t], g.K[t] = K[t];
+  }
+  constexpr int LDS = NW * REGION;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)rank_gemm_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  TASU_LAUNCH(rank_gemm_group_kernel, dim3((M + 15) / 16, n_members), dim3(64 * NW), LDS, (hipStream_t)stream, g, ldc, M, N);
+  return TASU_OK;
 }
 
 // C[M, N] = At[K, M]^T . B[N, K]^T, A given K-major (include/tasu_hip.h): the adapters' weight gradients from the row-major dy / xd.

@@ -215,6 +215,125 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16* __restrict__
   }
 }
 
+// ---- one launch per adapted GROUP (q|k|v: three members, gate|up: two) instead of one per member --------------------------------
+constexpr int GROUP_MAX = 4;
+struct ApplyGroup {
+  const bf16* u[GROUP_MAX];
+  const bf16* W[GROUP_MAX];
+  int sid[GROUP_MAX];
+  int n;
+};
+// tasu_lora_apply for every member of a group in ONE pass over y: y = bf16(y + mask_t . bf16(s . bf16(u_t W_t^T))) for t = 0, 1, ...
+// in that order -- the roundings of the member-by-member launches, the same bits -- with the 64 x 256 tile of y held in registers
+// across the members (one read and one write of y instead of one per member).  R = 64.
+template <bool MASK>
+__global__ __launch_bounds__(256, 2) void lora_apply_group_kernel(bf16* __restrict__ y, int ldy, ApplyGroup g, int ldu, int ldw, int M, int N,
+                                                                  float s, uint32_t thr, float inv, const int64_t* __restrict__ rng) {
+  __shared__ __attribute__((aligned(16))) char smem[AP_BN * 128 + AP_BM * 128];
+  char* wt = smem;
+  char* ut = smem + AP_BN * 128;
+  char* vt = smem;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = blockIdx.x * AP_BM, n0 = blockIdx.y * AP_BN;
+  const int sw = (lane >> 1) & 7;
+  const int cch = (tid & 31) * 8, n = n0 + cch;
+  const bool live = n < N;
+  bf16x8 yv[8];
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int m = m0 + pass * 8 + (tid >> 5);
+    yv[pass] = (live && m < M) ? *(const bf16x8*)(y + (size_t)m * ldy + n) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  for (int t = 0; t < g.n; ++t) {
+    f32x4 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int pc = wave * 8 + i, r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+      const bf16* src = g.W[t] + (size_t)min(n0 + r, N - 1) * ldw + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(wt + pc * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave * 2 + i, r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+      const bf16* src = g.u[t] + (size_t)min(m0 + r, M - 1) * ldu + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(ut + pc * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int roff = (lane & 15) * 128 + (((kk * 4 + (lane >> 4)) ^ sw) << 4);
+      const bf16x8 fa = *(const bf16x8*)(ut + wave * 2048 + roff);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const bf16x8 fb = *(const bf16x8*)(wt + j * 2048 + roff);
+        acc[j] = mfma16(fb, fa, acc[j]);
+      }
+    }
+    __syncthreads();
+    {
+      char* row = vt + (wave * 16 + (lane & 15)) * AP_VLD + (lane >> 4) * 8;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) *(bf16x4*)(row + j * 32) = __builtin_convertvector(acc[j], bf16x4);
+    }
+    __syncthreads();
+    uint64_t key = 0;
+    if constexpr (MASK) key = mask_key(rng, g.sid[t]);
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int r = pass * 8 + (tid >> 5), m = m0 + r;
+      const bf16x8 vv = *(const bf16x8*)(vt + r * AP_VLD + cch * 2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float d = (float)(bf16)((float)vv[e] * s);
+        if constexpr (MASK) d = (float)(bf16)(d * keep_scale(key, (int64_t)m * N + n + e, thr, inv));
+        yv[pass][e] = (bf16)((float)yv[pass][e] + d);
+      }
+    }
+    __syncthreads();                                     // the v image is the next member's operand space
+  }
+  if (!live) return;
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int m = m0 + pass * 8 + (tid >> 5);
+    if (m < M) *(bf16x8*)(y + (size_t)m * ldy + n) = yv[pass];
+  }
+}
+
+struct DropGroup {
+  bf16* dst[GROUP_MAX];
+  int sid[GROUP_MAX];
+  int n;
+};
+// tasu_lora_dropout_norm for every member of a group: the norm's fp32 output is computed once, each member's mask applied to it
+__global__ __launch_bounds__(256) void dropout_norm_group_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ rstd, DropGroup g, int M, int D, uint32_t thr,
+                                                                 float inv, const int64_t* __restrict__ rng) {
+  uint64_t key[GROUP_MAX];
+#pragma unroll
+  for (int t = 0; t < GROUP_MAX; ++t) key[t] = t < g.n ? mask_key(rng, g.sid[t]) : 0;
+  const int64_t nvec = (int64_t)M * D / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t e = i * 4;
+    const int row = (int)(e / D), c = (int)(e - (int64_t)row * D);
+    const f32x4 v = *(const f32x4*)(x + e), gw = *(const f32x4*)(w + c);
+    const float r = rstd[row];
+    float nv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nv[j] = gw[j] * (v[j] * r);
+#pragma unroll
+    for (int t = 0; t < GROUP_MAX; ++t) {
+      if (t >= g.n) break;
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16)(nv[j] * keep_scale(key[t], e + j, thr, inv));
+      *(bf16x4*)(g.dst[t] + e) = o;
+    }
+  }
+}
+
 __global__ void rng_advance_kernel(int64_t* rng) {
   if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;
 }
@@ -283,6 +402,45 @@ extern "C" int tasu_lora_apply(void* y, int ldy, const void* u, int ldu, const v
   else if (mask) TASU_LAUNCH((lora_apply_kernel<true, false>), grid, block, 0, st, yy, ldy, uu, ldu, ww, ldw, M, N, R, s, thr, inv, rg, stream_id, x_in, x_out, ldx);
   else if (x_in) TASU_LAUNCH((lora_apply_kernel<false, true>), grid, block, 0, st, yy, ldy, uu, ldu, ww, ldw, M, N, R, s, thr, inv, rg, stream_id, x_in, x_out, ldx);
   else TASU_LAUNCH((lora_apply_kernel<false, false>), grid, block, 0, st, yy, ldy, uu, ldu, ww, ldw, M, N, R, s, thr, inv, rg, stream_id, x_in, x_out, ldx);
+  return TASU_OK;
+}
+
+extern "C" int tasu_lora_apply_group(void* y, int ldy, int n_members, const void* const* u, int ldu, const void* const* W, int ldw,
+                                     const int* stream_ids, int M, int N, int R, float s, float p, const void* rng, void* stream) {
+  if (!y || !u || !W || !stream_ids || n_members < 1 || n_members > GROUP_MAX || M <= 0 || N <= 0 || N % 8 || R != 64 || ldy % 8 || ldu % 8 ||
+      ldw % 8 || ldu < R || ldw < R || ldy < N || ((uintptr_t)y & 15) || p < 0.f)
+    return TASU_ERR_ARG;
+  ApplyGroup g{};
+  g.n = n_members;
+  for (int t = 0; t < n_members; ++t) {
+    if (!u[t] || !W[t] || stream_ids[t] < 0 || (((uintptr_t)u[t] | (uintptr_t)W[t]) & 15)) return TASU_ERR_ARG;
+    g.u[t] = (const bf16*)u[t], g.W[t] = (const bf16*)W[t], g.sid[t] = stream_ids[t];
+  }
+  const bool mask = p > 0.f;
+  uint32_t thr = 0;
+  float inv = 1.f;
+  if (mask && (!rng || !drop_args(p, &thr, &inv))) return TASU_ERR_ARG;
+  const dim3 grid((M + AP_BM - 1) / AP_BM, (N + AP_BN - 1) / AP_BN), block(256);
+  if (mask) TASU_LAUNCH((lora_apply_group_kernel<true>), grid, block, 0, (hipStream_t)stream, (bf16*)y, ldy, g, ldu, ldw, M, N, s, thr, inv, (const int64_t*)rng);
+  else TASU_LAUNCH((lora_apply_group_kernel<false>), grid, block, 0, (hipStream_t)stream, (bf16*)y, ldy, g, ldu, ldw, M, N, s, thr, inv, (const int64_t*)rng);
+  return TASU_OK;
+}
+
+extern "C" int tasu_lora_dropout_norm_group(const float* x, const float* w, const float* rstd, int n_members, void* const* dst,
+                                            const int* stream_ids, int M, int D, float p, const void* rng, void* stream) {
+  uint32_t thr;
+  float inv;
+  if (!x || !w || !rstd || !dst || !stream_ids || !rng || n_members < 1 || n_members > GROUP_MAX || M <= 0 || D <= 0 || D % 4 ||
+      !drop_args(p, &thr, &inv))
+    return TASU_ERR_ARG;
+  DropGroup g{};
+  g.n = n_members;
+  for (int t = 0; t < n_members; ++t) {
+    if (!dst[t] || stream_ids[t] < 0) return TASU_ERR_ARG;
+    g.dst[t] = (bf16*)dst[t], g.sid[t] = stream_ids[t];
+  }
+  TASU_LAUNCH(dropout_norm_group_kernel, dim3(grid_for((int64_t)M * D / 4)), dim3(256), 0, (hipStream_t)stream, x, w, rstd, g, M, D, thr, inv,
+              (const int64_t*)rng);
   return TASU_OK;
 }
 

@@ -289,7 +289,7 @@ class TasuEngine:
             self.rccl = None
         if self.comm_stream is not None:
             from .streams import release
-            release(self.comm_stream)                   # (the engine may be kept alive by a caller's reference: do not wait for gc)
+            release(self.comm_stream, owner=self)       # (the engine may be kept alive by a caller's reference: do not wait for gc)
 
     def comm_info(self):
         """What the data-path collective runs on: {"backend", "ranks" (RCCL's own ncclCommCount), "library"}."""

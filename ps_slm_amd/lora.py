@@ -367,6 +367,12 @@ class LoraRunner:
             return ops.gemm(b, a, c, N, M, K, mode=GEMM_F32 if f32 else 0)
         return ops.gemm(a, b, c, M, N, K, mode=GEMM_F32 if f32 else 0)
 
+    @staticmethod
+    def _grouped(ops):
+        """One launch per adapted group instead of one per member (HipOps; TASU_LORA_GROUPED=0 for A/B runs; the CPU double keeps the loop)."""
+        import os
+        return hasattr(ops, "lora_apply_group") and os.environ.get("TASU_LORA_GROUPED", "1") != "0"
+
     def _drop_on(self, training):
         return bool(training and self.lp.cfg.lora_dropout > 0.0)
 
@@ -389,11 +395,14 @@ class LoraRunner:
     def group_us(self, l, gname, targets, M, xd_of):
         """us_t = bf16(xd_t (s A_t)^T) into columns [K + slot * rp, +r) of the K-extended operand; the caller then runs ONE GEMM
         [x | us] [W | B]^T with the frozen recipe's epilogue.  xd_of(t): the bf16 [M, in] input of member t's adapter."""
-        lp = self.lp
+        lp, ops = self.lp, self.m.ops
         us = self._us_view(gname, l, M, len(targets))
-        for t in targets:
-            k = lp.slot[t]
-            self.rank(xd_of(t), lp.as_[(l, t)], us[:, k * lp.rp: k * lp.rp + lp.rp], M, lp.r, lp.dims[t][0])
+        outs = [us[:, lp.slot[t] * lp.rp: lp.slot[t] * lp.rp + lp.rp] for t in targets]
+        if len(targets) > 1 and lp.r <= 64 and self._grouped(ops):    # one launch for the group (grid y = member)
+            return ops.gemm_rank_group([xd_of(t) for t in targets], [lp.as_[(l, t)] for t in targets], outs, M, lp.r,
+                                       [lp.dims[t][0] for t in targets])
+        for t, out in zip(targets, outs):
+            self.rank(xd_of(t), lp.as_[(l, t)], out, M, lp.r, lp.dims[t][0])
 
     # ---- backward of one group
     def group_bwd(self, l, gname, targets, dy, width, M, xd_of, dx_base, drop):
@@ -408,12 +417,18 @@ class LoraRunner:
         us_l = self._us_view(gname, l, M, nt)                   # [M, nt * rp], a column slice of the forward's operand
         self._wait_side(gname)
         du = self._zbuf("lora_du_" + gname, (M, nt * rp))
-        for t in targets:
-            i, o = lp.dims[t]
-            c0, k = lp.cols[t], lp.slot[t]
-            du_t = du[:, k * rp: k * rp + rp]
-            self.rank(dy[:, c0:c0 + o], lp.bts[(l, t)], du_t, M, r, o)             # du = bf16(dy (sB))              [M, r]
-            ops.lora_apply(dx_base, du_t, lp.at[(l, t)], M, i, rp, p=p if drop else 0.0, rng=lp.rng, sid=self._sid(l, t))
+        dus = [du[:, lp.slot[t] * rp: lp.slot[t] * rp + rp] for t in targets]
+        if nt > 1 and r <= 64 and rp == 64 and self._grouped(ops):       # the group's members in one launch each (the same bits as the loop below)
+            ops.gemm_rank_group([dy[:, lp.cols[t]:lp.cols[t] + lp.dims[t][1]] for t in targets], [lp.bts[(l, t)] for t in targets], dus, M, r,
+                                [lp.dims[t][1] for t in targets])
+            ops.lora_apply_group(dx_base, dus, [lp.at[(l, t)] for t in targets], M, inn, rp, [self._sid(l, t) for t in targets],
+                                 p=p if drop else 0.0, rng=lp.rng)
+        else:
+            for t, du_t in zip(targets, dus):
+                i, o = lp.dims[t]
+                c0 = lp.cols[t]
+                self.rank(dy[:, c0:c0 + o], lp.bts[(l, t)], du_t, M, r, o)             # du = bf16(dy (sB))              [M, r]
+                ops.lora_apply(dx_base, du_t, lp.at[(l, t)], M, i, rp, p=p if drop else 0.0, rng=lp.rng, sid=self._sid(l, t))
         # weight gradients: dB_t = dy_t^T us_t [out, r],  dA_t = du_t^T xd_t [r, in]  (K = the M rows).  The big operands (dy, xd) are
         # read K-major as they are (tasu_gemm_tn_rank: hardware transpose reads); only the rank-sized ones are transposed
         # (zero-padded to Mp = 64-row multiples; the padding rows of dy / xd are never read when M itself is a multiple of 64).
@@ -478,7 +493,12 @@ class LoraRunner:
         groups = dict(lp.groups)
         sid = lambda t: self._sid(l, t)
 
-        def dropped_norm(x, wn, rs):                        # member -> its own dropped copy of the norm's fp32 output, kept per layer
+        def dropped_norm(x, wn, rs, targets):               # member -> its own dropped copy of the norm's fp32 output, kept per layer
+            if len(targets) > 1 and self._grouped(ops):      # the norm evaluated once for the group, every member's mask applied to it
+                dsts = {t: self._xin(t, M, D)[l] for t in targets}
+                ops.lora_dropout_norm_group(x, wn, rs, [dsts[t] for t in targets], M, D, p, lp.rng, [sid(t) for t in targets])
+                return lambda t: dsts[t]
+
             def f(t):
                 dst = self._xin(t, M, D)[l]
                 ops.lora_dropout_norm(x, wn, rs, dst, M, D, p, lp.rng, sid(t))
@@ -497,7 +517,7 @@ class LoraRunner:
             a = self._ax("qkv", M)[l]
             x1 = a[:, :D]                                   # the norm writes straight into the head of the operand
             ops.rmsnorm_fwd(x_in, w["ln1"], x1, rstd[2 * l], eps)
-            self.group_us(l, "qkv", groups["qkv"], M, dropped_norm(x_in, w["ln1"], rstd[2 * l]) if drop else (lambda t: x1))
+            self.group_us(l, "qkv", groups["qkv"], M, dropped_norm(x_in, w["ln1"], rstd[2 * l], groups["qkv"]) if drop else (lambda t: x1))
             ops.gemm_qkv_rope(a, lp.wext[(l, "qkv")], w["bqkv"], qkv[l], cos, sin, M, H, G, lp.kext["qkv"])
         else:
             ops.rmsnorm_fwd(x_in, w["ln1"], xn, rstd[2 * l], eps)
@@ -517,7 +537,7 @@ class LoraRunner:
             a = self._ax("gu", M)[l]
             x2 = a[:, :D]
             ops.rmsnorm_fwd(x_mid, w["ln2"], x2, rstd[2 * l + 1], eps)
-            self.group_us(l, "gu", groups["gu"], M, dropped_norm(x_mid, w["ln2"], rstd[2 * l + 1]) if drop else (lambda t: x2))
+            self.group_us(l, "gu", groups["gu"], M, dropped_norm(x_mid, w["ln2"], rstd[2 * l + 1], groups["gu"]) if drop else (lambda t: x2))
             ops.gemm_gate_up_swiglu(a, lp.wext[(l, "gu")], gu[l], act_l, M, I, lp.kext["gu"])
         else:
             ops.rmsnorm_fwd(x_mid, w["ln2"], xn, rstd[2 * l + 1], eps)

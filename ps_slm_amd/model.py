@@ -449,6 +449,7 @@ class TasuModel:
         # into two graph launches.  Keyed by the shapes baked into kernel arguments; the first call of a key runs
         # eagerly (allocates the workspace), the second is captured, later ones replay.
         self.use_graphs = False
+        self.lora_bwd_graphs = os.environ.get("TASU_LORA_BWD_GRAPH", "0") == "1"      # (A/B: the adapted backward as a hipGraph; see run_backward)
         # (token-column multiple, posterior-row multiple, labelled-row multiple) or None.  Real data gives every batch its own shape
         # (CPS drops, frame-budget batching), and eagerly launched steps run ~10 % slower than graph replay (measured: 34.2 vs
         # 30.8 ms).  With buckets the training batch is padded to the next multiple -- masked token columns, zero posterior rows,
@@ -1298,8 +1299,16 @@ class TasuModel:
         if getattr(st, "fp32", False):               # train_config.use_fp16 = false: the fp32 step (ps_slm_amd/train_fp32.py), eager
             from .train_fp32 import backward_fp32
             return backward_fp32(self, st, on_ready)
+        # use_peft: the adapters' weight-gradient chains fork onto a side stream 112 times per backward.  Captured into a hipGraph
+        # those forks become branches that the runtime places on streams of ITS choosing, and whether they then run next to the
+        # main branch depended on what the process had done before: 45 ms per step as the fifth leg of bench.py, 82 ms as the first
+        # workload of a process (tools/lab_lora_graph_order.py), 46 ms with eager launches wherever it ran.  The adapted backward is
+        # therefore launched eagerly (its ~900 launches hide under 30 ms of kernels); the forward, which forks nothing, stays a graph.
+        run = getattr(self, "_lora_run", None)
+        eager = self.lora is not None and run is not None and getattr(run, "side", None) is not None and not self.lora_bwd_graphs
+        graphed = (lambda key, fn: fn()) if eager else (lambda key, fn: self._graphed(key, fn, st))
         if on_ready is None:
-            self._graphed(self._shape_key(st, "bwd"), lambda: self.backward(st), st)
+            graphed(self._shape_key(st, "bwd"), lambda: self.backward(st))
         else:
             if self.lora is None:
                 self._graphed(self._shape_key(st, "bwd_llm"), lambda: self.backward_llm(st), st)
@@ -1308,7 +1317,7 @@ class TasuModel:
                 # a contiguous range of the bucket (the layers are laid out in completion order) -- go on the wire under the
                 # remaining spans (513 MB per step travel in this recipe, against the projector's 218)
                 for hi, lo in self.lora_spans():
-                    self._graphed(self._shape_key(st, ("bwd_llm", hi, lo)), lambda hi=hi, lo=lo: self.backward_llm(st, (hi, lo)), st)
+                    graphed(self._shape_key(st, ("bwd_llm", hi, lo)), lambda hi=hi, lo=lo: self.backward_llm(st, (hi, lo)))
                     on_ready(self.lora.layer_range[hi - 1][0], self.lora.layer_range[lo][1])
             if not self.freeze_projector:
                 self.backward_projector(st, on_ready, w1_chunks)

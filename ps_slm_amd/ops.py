@@ -6,6 +6,7 @@ The method set is the operator interface of the model code (ps_slm_amd/model.py)
 model code on CPU by injecting tests/fake_ops.py, a torch-CPU double with identical signatures.
 """
 import contextlib
+import ctypes
 import os
 
 import torch
@@ -409,6 +410,35 @@ class HipOps:
         self._chk(self.lib.tasu_lora_apply(_p(y), y.stride(0), _p(u), u.stride(0), _p(w), w.stride(0), M, N, R, float(s), float(p), _p(rng),
                                            int(sid), _p(x_in), _p(x_out), 0 if x_in is None else x_in.stride(0), self._stream()),
                   "tasu_lora_apply")
+
+    # ---- one launch per adapted group (csrc/lora.hip, csrc/gemm_rank.hip: the members' kernels batched)
+    @staticmethod
+    def _ptrs(ts):
+        return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+    @staticmethod
+    def _ints(vs):
+        return (ctypes.c_int * len(vs))(*[int(v) for v in vs])
+
+    def gemm_rank_group(self, As, Bs, Cs, M, N, Ks):
+        """Cs[t][M, N] = bf16(As[t][M, Ks[t]] @ Bs[t][N, Ks[t]]^T) for the members t of a group in one launch (tasu_gemm_nt_rank_group);
+        the Cs share their row stride."""
+        ldc = Cs[0].stride(0)
+        assert all(c.stride(0) == ldc for c in Cs)
+        self._chk(self.lib.tasu_gemm_nt_rank_group(len(As), self._ptrs(As), self._ints([a.stride(0) for a in As]), self._ptrs(Bs),
+                                                   self._ints([b.stride(0) for b in Bs]), self._ptrs(Cs), ldc, M, N, self._ints(Ks),
+                                                   self._stream()), "tasu_gemm_nt_rank_group")
+
+    def lora_apply_group(self, y, us, ws, M, N, R, sids, s=1.0, p=0.0, rng=None):
+        """lora_apply for the members of a group, in order, in one pass over y (tasu_lora_apply_group: the same bits)."""
+        ldu, ldw = us[0].stride(0), ws[0].stride(0)
+        assert all(u.stride(0) == ldu for u in us) and all(w.stride(0) == ldw for w in ws)
+        self._chk(self.lib.tasu_lora_apply_group(_p(y), y.stride(0), len(us), self._ptrs(us), ldu, self._ptrs(ws), ldw, self._ints(sids), M, N, R,
+                                                 float(s), float(p), _p(rng), self._stream()), "tasu_lora_apply_group")
+
+    def lora_dropout_norm_group(self, x, w, rstd, dsts, M, D, p, rng, sids):
+        self._chk(self.lib.tasu_lora_dropout_norm_group(_p(x), _p(w), _p(rstd), len(dsts), self._ptrs(dsts), self._ints(sids), M, D, float(p),
+                                                        _p(rng), self._stream()), "tasu_lora_dropout_norm_group")
 
     def scale_bf16(self, src, dst, s):
         self._chk(self.lib.tasu_scale_bf16(_p(src), _p(dst), float(s), src.numel(), self._stream()), "tasu_scale_bf16")

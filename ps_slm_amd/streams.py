@@ -81,34 +81,55 @@ def side_stream(device, role="side", owner=None):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _state.setdefault(idx, dict(handed=[]))
     own = weakref.ref(owner) if owner is not None else None
+    # ONE stream per (device, role) for the life of the process (round 6).  Every request used to create a new stream -- plus the
+    # probe's rejected candidates -- and HIP places streams on hardware queues in creation order: after four workloads in one
+    # process the adapters' stream had a verdict of "own queue" from the probe and the LoRA step still ran at 75-85 ms instead of
+    # 45 (tools/lab_lora_graph_order.py).  A later model of the same kind reuses the role's stream (two live models that share a
+    # role serialise on it, which is correct, and rare).
+    cached = st.setdefault("by_role", {}).get(role)
+    if cached is not None:
+        st["handed"].append((role, cached[0], cached[1], own))
+        return cached[0]
     if not hasattr(torch.cuda, "_sleep"):                 # (no spin kernel to probe with: any stream)
         s_ = torch.cuda.Stream(device=idx)
         st["handed"].append((role, s_, "unprobed", own))
+        st["by_role"][role] = (s_, "unprobed")
         return s_
     with torch.cuda.device(idx):
         main = torch.cuda.current_stream()
         fallback = None
-        others = [h for _, h, _ in _live(st)]             # only streams somebody still holds
+        others = [c_[0] for r_, c_ in st["by_role"].items() if r_ != role]     # the other roles' streams
         for _ in range(_MAX_TRIES):
             c = torch.cuda.Stream(device=idx)
             if not runs_concurrently(main, c):
                 continue                                  # shares the main stream's queue
             if all(runs_concurrently(h, c) for h in others):
                 st["handed"].append((role, c, "own queue", own))
+                st["by_role"][role] = (c, "own queue")
                 return c
             fallback = fallback or c
         if fallback is not None:
             st["handed"].append((role, fallback, "next to main, shares a queue with another side stream", own))
+            st["by_role"][role] = (fallback, "next to main, shares a queue with another side stream")
             return fallback
         c = torch.cuda.Stream(device=idx)                 # (a runtime with one hardware queue: overlap is impossible anyway)
         st["handed"].append((role, c, "shares the main stream's queue", own))
+        st["by_role"][role] = (c, "shares the main stream's queue")
         return c
 
 
-def release(stream):
-    """The holder is done with ``stream`` (TasuEngine.destroy()): it no longer takes part in probes or in the report."""
+def release(stream, owner=None):
+    """The holder ``owner`` is done with ``stream`` (TasuEngine.destroy()): its entry leaves the report.  The stream itself stays
+    the role's stream of the process (another holder may be using it; the next one will)."""
     for st in _state.values():
-        st["handed"] = [h for h in st["handed"] if h[1] is not stream]
+        kept, dropped = [], False
+        for h in reversed(st["handed"]):                    # (without an owner: the most recent holder's entry)
+            mine = h[1] is stream and (h[3] is None or h[3]() is None or owner is None or h[3]() is owner)
+            if mine and (owner is not None or not dropped):
+                dropped = True
+                continue
+            kept.append(h)
+        st["handed"] = kept[::-1]
 
 
 def report(device=None):

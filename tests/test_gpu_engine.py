@@ -269,6 +269,10 @@ def test_side_streams_run_next_to_the_main_stream():
     rep = report("cuda")
     assert len(rep) == before + 3 and [r["verdict"] for r in rep if r.get("role", "").startswith("test")] == ["own queue"] * 3
     assert side_stream("cpu") is None
+    # round 6: a role has ONE stream per process (every new stream shifts HIP's queue placement of the later ones)
+    assert side_stream("cuda", "test a") is a and len(report("cuda")) == before + 4
+    streams.release(a)                                             # (one holder's entry; the other stays)
+    assert len(report("cuda")) == before + 3
     # a dead owner's stream stops counting (no probe against it, not in the report); release() does the same explicitly
     class Owner:
         pass
