@@ -59,6 +59,55 @@ def test_lora_elementwise_kernels_bit_exact(ops):
     assert torch.equal(a, b) and not torch.equal(a, c)
 
 
+@pytest.mark.parametrize("M,n_members,drop", [(4096, 3, True), (100, 2, False), (64, 1, True), (333, 4, True)])
+def test_lora_group_launches_have_the_bits_of_the_member_launches(ops, M, n_members, drop):
+    """One launch per adapted GROUP (round 6) against one per member: the members' rank GEMMs with their own operands and K
+    (tasu_gemm_nt_rank_group), the fused accumulate applied member after member in one pass over y (tasu_lora_apply_group) and
+    the dropped norm copies from one evaluation of the norm (tasu_lora_dropout_norm_group) -- bit-identical to the loops."""
+    g = torch.Generator().manual_seed(7)
+    dev = "cuda"
+    rnd = lambda *sh, scale=1.0: (torch.randn(*sh, generator=g) * scale).to(dev)
+    rng = torch.tensor([987654321, 3], dtype=torch.int64, device=dev)
+    p = 0.1 if drop else 0.0
+    sids = [5 + 8 * t for t in range(n_members)]
+    # rank GEMMs: members read column slices of one wide matrix (the q|k|v / gate|up gradient), each with its own K
+    Ks = [256, 64, 512, 128][:n_members]
+    wide = rnd(M, sum(Ks) + 16).bfloat16()
+    offs = np.cumsum([0] + Ks)
+    As = [wide[:, offs[t]:offs[t] + Ks[t]] for t in range(n_members)]
+    Bs = [rnd(64, Ks[t], scale=Ks[t] ** -0.5).bfloat16() for t in range(n_members)]
+    du_g, du_l = torch.zeros(M, n_members * 64, dtype=torch.bfloat16, device=dev), torch.zeros(M, n_members * 64, dtype=torch.bfloat16, device=dev)
+    ops.gemm_rank_group(As, Bs, [du_g[:, 64 * t:64 * t + 64] for t in range(n_members)], M, 64, Ks)
+    for t in range(n_members):
+        ops.gemm_rank(As[t], Bs[t], du_l[:, 64 * t:64 * t + 64], M, 64, Ks[t])
+    torch.cuda.synchronize()
+    assert torch.equal(du_g, du_l) and float(du_g.float().abs().max()) > 0
+    # accumulate: y += mask_t . bf16(s . bf16(du_t W_t^T)), member after member
+    N = 520
+    Ws = [rnd(N, 64, scale=0.2).bfloat16() for _ in range(n_members)]
+    y0 = rnd(M, N + 8).bfloat16()
+    yg, yl = y0.clone(), y0.clone()
+    us = [du_g[:, 64 * t:64 * t + 64] for t in range(n_members)]
+    ops.lora_apply_group(yg[:, :N], us, Ws, M, N, 64, sids, s=0.25, p=p, rng=rng)
+    for t in range(n_members):
+        ops.lora_apply(yl[:, :N], us[t], Ws[t], M, N, 64, s=0.25, p=p, rng=rng, sid=sids[t])
+    torch.cuda.synchronize()
+    assert torch.equal(yg, yl) and not torch.equal(yg, y0) and torch.equal(yg[:, N:], y0[:, N:])
+    # dropped norm copies
+    if drop:
+        D = 512
+        x, w = rnd(M, D), 1 + 0.1 * rnd(D)
+        rstd = torch.rsqrt(x.pow(2).mean(-1) + 1e-6)
+        dg = [torch.empty(M, D, dtype=torch.bfloat16, device=dev) for _ in range(n_members)]
+        dl = [torch.empty(M, D, dtype=torch.bfloat16, device=dev) for _ in range(n_members)]
+        ops.lora_dropout_norm_group(x, w, rstd, dg, M, D, p, rng, sids)
+        for t in range(n_members):
+            ops.lora_dropout_norm(x, w, rstd, dl[t], M, D, p, rng, sids[t])
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(dg, dl))
+        assert n_members == 1 or not torch.equal(dg[0], dg[1])      # every member its own mask
+
+
 @pytest.mark.parametrize("name", ["mid_text_lora", "mid_text_lora_qv", "mid_text_lora_drop"])
 def test_lora_step_hip_vs_double_and_reference_golden(ops, name):
     z, geo, cfg, sd, lsd, batch = golden_case(name)
