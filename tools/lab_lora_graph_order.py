@@ -1,6 +1,6 @@
 """Is the graph-replayed LoRA step's time a property of the step or of what the process did before?  (round 6: 44.5 ms inside the
 full bench run, 77 ms as the first leg of a process, 44.7 ms with eager launches)
-    python tools/lab_lora_graph_order.py first|after_text|after_decode|after_variable|after_audio|after_all|eager"""
+    python tools/lab_lora_graph_order.py first|after_text|after_decode|after_variable|after_audio|after_all|eager|exchange_first"""
 import argparse
 import json
 import os
@@ -21,6 +21,11 @@ out = {}
 if mode == "after_text":
     r = bench.train_leg(args, "qwen2.5-1.5b", "text", 16, 6, 2, 1, 0, 0, False)
     out["text_ms"] = r["ms_per_step"]
+if mode == "exchange_first":                       # the N > 1 gradient-exchange stream (1-rank RCCL) as the first workload of a process
+    args.lora = False
+    r = bench.train_leg(args, "qwen2.5-1.5b", "text", 16, 10, 3, 1, 0, 0, False, force_exchange=True)
+    print(json.dumps({"mode": mode, "exchange_ms": r["ms_per_step"], "exposed_ms": r.get("allreduce_exposed_ms"), "side_streams": r.get("side_streams")}))
+    sys.exit(0)
 if mode == "after_decode":
     r = bench.train_leg(args, "qwen2.5-1.5b", "text", 16, 6, 2, 1, 0, 0, True)
     out["text_ms"] = r["ms_per_step"]
