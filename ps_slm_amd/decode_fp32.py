@@ -42,7 +42,11 @@ def _fragments(model):
         return None
     fr = llm.f32.get("frag")
     if fr is None:
-        to = model.ops.f32_to_fragments
+        ops, nws = model.ops, _gemm_ws(model).numel()
+
+        def to(w):                                         # only what the streaming kernel will read (Qwen2.5-7B's down projection,
+            N, K = w.shape                                 # K = 18944, has no K slice it serves: no copy)
+            return ops.f32_to_fragments(w) if ops.lib.tasu_f32_gemm_streams(64, N, K, nws) == 1 else w
         fr = llm.f32["frag"] = dict(layers=[dict(wgu=to(f["wgu"]), wd=to(f["wd"])) for f in llm.f32["layers"]], head=to(llm.f32["head"]))
     return fr
 
