@@ -212,6 +212,11 @@ def test_lora_step_at_benchmark_shape(ops):
     assert torch.equal(outs[1][0], l3) and torch.equal(outs[1][1], g3)                   # captured + replayed, masks of step 5
     _, l6, g6 = train_step(step=6)
     assert torch.equal(outs[3][0], l6) and torch.equal(outs[3][1], g6)                   # a later replay == eager at the same mask step
+    # round 6: the adapted BACKWARD is launched eagerly (its side-stream forks, captured, ran at 82 ms as a process's first workload);
+    # the forward is the graph that was captured above
+    tags = [k[0] if not isinstance(k[0], tuple) else k[0][0] for k in m._graphs]
+    assert any(str(t).startswith("fwd") for t in tags) and not any(str(t).startswith("bwd") for t in tags), tags
+    assert m._lora_run.side is not None and not m.lora_bwd_graphs
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 64, 1536), (4096, 64, 8960), (1536, 64, 4096), (8960, 64, 4096), (141, 16, 256), (333, 24, 192),
