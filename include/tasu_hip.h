@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TASU_ABI_VERSION 15
+#define TASU_ABI_VERSION 16
 int tasu_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- GEMM
@@ -745,9 +745,10 @@ int tasu_f32_gather_rows(const float* dx, const int32_t* rows, float* out, int n
 int tasu_f32_attn_bwd(const float* qkv, const float* dout, const int32_t* kstart, float* dqkv, float* lse_ws, float* delta_ws, int B, int S,
                       int H, int G, float scale, void* stream);
 /* tasu_logprob_topk on fp32 logits: out_val = (x - max) - log(sum exp(x - max)) of the k best selectable columns (value descending,
- * column ascending), k <= 16; fewer than k selectable columns: (-inf, 0x7fffffff).                                               */
+ * column ascending), k <= 16; fewer than k selectable columns: (-inf, 0x7fffffff).  workspace (M * 16 * (2 + 2 k) floats, may be NULL):
+ * with it the row is split over 16 workgroups + a merge launch (a decode step's 64 rows are too few workgroups for one per row).        */
 int tasu_f32_logprob_topk(const float* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned, float* out_val,
-                          int32_t* out_idx, void* stream);
+                          int32_t* out_idx, float* workspace, int64_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------ FLAC (host)
  * The reference reads ``.flac`` entries with torchaudio.load (speech_dataset_large.py:123-127: [C, T] float

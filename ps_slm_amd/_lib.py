@@ -148,7 +148,7 @@ PROTOTYPES.update({
     "tasu_f32_attn_decode": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "tasu_f32_swiglu": [vp, vp, i32, i32, vp],
     "tasu_f32_embed_merge": [vp, vp, i32, vp, vp, vp, i32, i32, vp],
-    "tasu_f32_logprob_topk": [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp],
+    "tasu_f32_logprob_topk": [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i64, vp],
     "tasu_f32_ce": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     # fp32 training step: backward kernels (csrc/fp32_train.hip)
     "tasu_f32_rmsnorm_bwd": [vp, vp, vp, vp, i32, i32, f32, i32, vp],
@@ -161,7 +161,7 @@ PROTOTYPES.update({
     "tasu_f32_attn_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
 })
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 
 GEMM_SOURCES = ("common.h", "gemm_epilogue.h", "gemm.hip", "gemm_pipe.hip", "gemm_pp.hip")

@@ -803,6 +803,160 @@ __global__ __launch_bounds__(256) void f32_fsmn_kernel(const float* __restrict__
   out[i] += r;
 }
 
+// The same selection with the row split over F32_TOPK_PARTS workgroups (a generated position's 64 rows are 64 workgroups for the
+// kernel above: a quarter of the CUs, three dependent passes over 600 KB each -- 132 us per position).  Stage 1, grid (rows, parts),
+// 256 threads: a part's columns live in registers (one read); its maximum and sum of exp(x - max), and its k best selectable columns
+// by the threshold form (tau = the largest over the four waves of the wave's k-th largest per-thread maximum) or, on massive ties,
+// by k rounds of block argmax over the registers.  Stage 2, one wave per row: lse = log sum_p s_p exp(m_p - M) and the k best of the
+// parts' candidates, (value descending, column ascending) as everywhere.
+constexpr int F32_TOPK_PARTS = 16, F32_TOPK_MAXC = 10, F32_TOPK_PCAND = 64;
+__global__ __launch_bounds__(256) void f32_topk_part_kernel(const float* __restrict__ logits, int ld, int V, int k,
+                                                            const int32_t* __restrict__ banned, int n_banned, float* __restrict__ pm,
+                                                            float* __restrict__ ps, float* __restrict__ pv, int32_t* __restrict__ pi) {
+  __shared__ float red[4];
+  __shared__ float wtau[4];
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  __shared__ float cand_v[F32_TOPK_PCAND];
+  __shared__ int cand_i[F32_TOPK_PCAND];
+  __shared__ int cand_n;
+  const int row = blockIdx.x, part = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* x = logits + (size_t)row * ld;
+  const int nv4 = (V + 3) >> 2, per4 = (nv4 + F32_TOPK_PARTS - 1) / F32_TOPK_PARTS;
+  const int v0 = part * per4, v1 = min(nv4, v0 + per4);
+  auto is_banned = [&](int c) {
+    bool ban = false;
+    for (int b = 0; b < n_banned; ++b) ban |= banned[b] == c;
+    return ban;
+  };
+  if (t == 0) cand_n = 0;
+  f32x4 xs[F32_TOPK_MAXC];
+#pragma unroll
+  for (int i = 0; i < F32_TOPK_MAXC; ++i) {
+    const int c4 = v0 + t + i * 256;
+    xs[i] = c4 < v1 ? *(const f32x4*)(x + (size_t)c4 * 4) : f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c4 * 4 + j >= V) xs[i][j] = -__builtin_inff();         // (columns past V: padding of the leading dimension)
+  }
+  float m = -__builtin_inff(), msel = -__builtin_inff();
+#pragma unroll
+  for (int i = 0; i < F32_TOPK_MAXC; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = xs[i][j];
+      m = fmaxf(m, v);
+      if (v > msel && !is_banned((v0 + t + i * 256) * 4 + j)) msel = v;
+    }
+  m = block_max<4>(m, red);
+  float mine = msel, kth = -__builtin_inff();
+  for (int r = 0; r < k; ++r) {
+    kth = wave_max(mine);
+    const unsigned long long holders = __ballot(mine == kth);
+    if (lane == __ffsll((long long)holders) - 1) mine = -__builtin_inff();
+  }
+  if (lane == 0) wtau[wave] = kth;
+  __syncthreads();
+  const float tau = fmaxf(fmaxf(wtau[0], wtau[1]), fmaxf(wtau[2], wtau[3]));
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < F32_TOPK_MAXC; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = xs[i][j];
+      const int c = (v0 + t + i * 256) * 4 + j;
+      if (v > -__builtin_inff()) {
+        s += expf(v - m);
+        if (v >= tau && !is_banned(c)) {
+          const int slot = atomicAdd(&cand_n, 1);
+          if (slot < F32_TOPK_PCAND) cand_v[slot] = v, cand_i[slot] = c;
+        }
+      }
+    }
+  s = block_sum<4>(s, red);                              // (its barriers also publish the candidates)
+  const size_t slot0 = (size_t)row * F32_TOPK_PARTS + part;
+  if (t == 0) pm[slot0] = m, ps[slot0] = s;
+  const int n_cand = cand_n;
+  if (n_cand <= F32_TOPK_PCAND) {
+    if (wave == 0) {
+      const bool live = lane < n_cand;
+      const float v = live ? cand_v[lane] : -__builtin_inff();
+      const int id = live ? cand_i[lane] : 0x7fffffff;
+      int rank = 0;
+      for (int d = 0; d < n_cand; ++d) {
+        const float dv = __shfl(v, d, 64);
+        const int di = __shfl(id, d, 64);
+        rank += (dv > v || (dv == v && di < id)) ? 1 : 0;
+      }
+      if (live && rank < k) pv[slot0 * k + rank] = v, pi[slot0 * k + rank] = id;
+      if (lane >= n_cand && lane < k) pv[slot0 * k + lane] = -__builtin_inff(), pi[slot0 * k + lane] = 0x7fffffff;
+    }
+    return;
+  }
+  // massive ties: k rounds of "the best column after the previous pick" over the registers
+  float pvv = __builtin_inff();
+  int pii = -1;
+  for (int r = 0; r < k; ++r) {
+    float best = -__builtin_inff();
+    int bid = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < F32_TOPK_MAXC; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = xs[i][j];
+        const int c = (v0 + t + i * 256) * 4 + j;
+        if (!(v > -__builtin_inff())) continue;
+        const bool after = v < pvv || (v == pvv && c > pii);
+        if (!after || v < best || (v == best && c > bid)) continue;
+        if (!is_banned(c)) best = v, bid = c;
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bid, o, 64);
+      if (ov > best || (ov == best && oi < bid)) best = ov, bid = oi;
+    }
+    __syncthreads();
+    if (lane == 0) bv[wave] = best, bi[wave] = bid;
+    __syncthreads();
+    best = bv[0], bid = bi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < bid)) best = bv[w], bid = bi[w];
+    if (t == 0) pv[slot0 * k + r] = bid == 0x7fffffff ? -__builtin_inff() : best, pi[slot0 * k + r] = bid;
+    pvv = best, pii = bid;
+    if (bid == 0x7fffffff) pvv = -__builtin_inff(), pii = 0x7fffffff;
+  }
+}
+__global__ __launch_bounds__(64) void f32_topk_merge_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
+                                                            const float* __restrict__ pv, const int32_t* __restrict__ pi, int k,
+                                                            float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+  __shared__ float cv[F32_TOPK_PARTS * 16];
+  __shared__ int ci[F32_TOPK_PARTS * 16];
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const bool lp = lane < F32_TOPK_PARTS;
+  const float mp = lp ? pm[(size_t)row * F32_TOPK_PARTS + lane] : -__builtin_inff();
+  const float sp = lp ? ps[(size_t)row * F32_TOPK_PARTS + lane] : 0.f;
+  const float M = wave_max(mp);
+  const float S = wave_sum(lp && mp > -__builtin_inff() ? sp * expf(mp - M) : 0.f);
+  const float lse = logf(S);
+  const int n = F32_TOPK_PARTS * k;
+  for (int i = lane; i < n; i += 64) cv[i] = pv[(size_t)row * n + i], ci[i] = pi[(size_t)row * n + i];
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) {
+    const float v = cv[i];
+    const int id = ci[i];
+    if (id == 0x7fffffff) continue;
+    int rank = 0;
+    for (int d = 0; d < n; ++d) rank += (cv[d] > v || (cv[d] == v && ci[d] < id)) ? 1 : 0;
+    if (rank < k) out_val[(size_t)row * k + rank] = (v - M) - lse, out_idx[(size_t)row * k + rank] = id;
+  }
+  // fewer than k selectable columns in the row: the tail keeps (-inf, 0x7fffffff)
+  int valid = 0;
+  for (int d = 0; d < n; ++d) valid += ci[d] != 0x7fffffff ? 1 : 0;
+  if (lane >= valid && lane < k) out_val[(size_t)row * k + lane] = -__builtin_inff(), out_idx[(size_t)row * k + lane] = 0x7fffffff;
+}
+
 // Shifted cross entropy of one fp32 logits row per 1024-thread block (the eval-mode forward in fp32: loss_utils' CE over the rows
 // whose shifted label is >= 0, ignore_index -100): lse = max + log(sum exp(x - max)), row_loss = lse - x[label], row_hit =
 // (argmax == label), argmax ties -> the first column (torch.argmax).  Rows without a label: loss 0, hit 0 (lse / argmax still written).
@@ -1214,9 +1368,24 @@ extern "C" int tasu_f32_ce(const float* logits, int ld, const int32_t* shift_lab
 }
 
 extern "C" int tasu_f32_logprob_topk(const float* logits, int ld, int M, int V, int k, const int32_t* banned, int n_banned, float* out_val,
-                                     int32_t* out_idx, void* stream) {
+                                     int32_t* out_idx, float* workspace, int64_t workspace_floats, void* stream) {
   if (!logits || !out_val || !out_idx || M <= 0 || V <= 0 || ld < V || k <= 0 || k > 16 || n_banned < 0 || (n_banned > 0 && !banned))
     return TASU_ERR_ARG;
+  // with a workspace of M * 16 * (2 + 2 k) floats, 16-byte aligned rows and a vocabulary the parts hold in registers: two launches,
+  // the row split over 16 workgroups; otherwise one workgroup per row
+  const size_t slots = (size_t)M * F32_TOPK_PARTS;
+  const int per4 = (((V + 3) >> 2) + F32_TOPK_PARTS - 1) / F32_TOPK_PARTS;
+  if (workspace && (size_t)workspace_floats >= slots * (2 + 2 * (size_t)k) && ld % 4 == 0 && !((uintptr_t)logits & 15) &&
+      per4 <= 256 * F32_TOPK_MAXC && M > 1) {
+    float* pm = workspace;
+    float* ps = pm + slots;
+    float* pv = ps + slots;
+    int32_t* pi = (int32_t*)(pv + slots * k);
+    TASU_LAUNCH(f32_topk_part_kernel, dim3(M, F32_TOPK_PARTS), dim3(256), 0, (hipStream_t)stream, logits, ld, V, k, banned, n_banned, pm, ps, pv,
+                pi);
+    TASU_LAUNCH(f32_topk_merge_kernel, dim3(M), dim3(64), 0, (hipStream_t)stream, pm, ps, pv, pi, k, out_val, out_idx);
+    return TASU_OK;
+  }
   TASU_LAUNCH(f32_logprob_topk_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, logits, ld, V, k, banned, n_banned, out_val, out_idx);
   return TASU_OK;
 }

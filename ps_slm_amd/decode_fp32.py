@@ -213,7 +213,8 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
     tv, ti = buf("dec_topv", (M, K), f32), buf("dec_topi", (M, K), i32)
     bs = DeviceBeam(model, B, nb, max_new_tokens, eos, length_penalty, min_length, S, valid)
     model._last_beam = bs
-    ops.f32_logprob_topk(logits, B, V, K, bs.banned, 1, tv, ti)
+    topk_ws = buf("f32_topk_ws", (M * 16 * (2 + 2 * K),), f32)               # the row split over 16 workgroups (tasu_f32_logprob_topk)
+    ops.f32_logprob_topk(logits, B, V, K, bs.banned, 1, tv, ti, ws=topk_ws)
     ops.beam_update(tv, ti, bs, True)
     qkv, ao = buf("f32_qkv", (M, LDQ), f32), buf("f32_ao", (M, H * HD), f32)
     gu, act = buf("f32_gu", (M, 2 * I), f32), buf("f32_act", (M, I), f32)
@@ -233,7 +234,7 @@ def beam_search_generate_fp32(model, st: StepState, num_beams=4, max_new_tokens=
         for l in range(L):
             _layer_fp32(model, l, x, xn, qkv, ao, gu, act, M, cos, sin, attend_cache, ws, cache=(kcv[l], vcv[l], bs.next_slot), ctx=ctx, frag=frag)
         ops.f32_gemm(xn, head, logits, M, V, D, ws=ws)                                 # xn: the final norm, from the last layer's finisher
-        ops.f32_logprob_topk(logits, M, V, K, bs.banned, 1, tv, ti)
+        ops.f32_logprob_topk(logits, M, V, K, bs.banned, 1, tv, ti, ws=topk_ws)
         ops.beam_update(tv, ti, bs, False)
 
     use_graphs = model.decode_graphs and model.device.type == "cuda"

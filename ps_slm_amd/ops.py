@@ -789,9 +789,10 @@ class HipOps:
         self._chk(self.lib.tasu_f32_attn_bwd(_p(qkv), _p(dout), _p(kstart), _p(dqkv), _p(lse_ws), _p(delta_ws), B, S, H, G, scale,
                                              self._stream()), "tasu_f32_attn_bwd")
 
-    def f32_logprob_topk(self, logits, M, V, k, banned, n_banned, out_val, out_idx):
+    def f32_logprob_topk(self, logits, M, V, k, banned, n_banned, out_val, out_idx, ws=None):
+        """``ws``: M * 16 * (2 + 2 k) floats -- with it the row is split over 16 workgroups (the decode step's 64 rows)."""
         self._chk(self.lib.tasu_f32_logprob_topk(_p(logits), logits.stride(0), M, V, k, _p(banned), n_banned, _p(out_val), _p(out_idx),
-                                                 self._stream()), "tasu_f32_logprob_topk")
+                                                 _p(ws), ws.numel() if ws is not None else 0, self._stream()), "tasu_f32_logprob_topk")
 
     # ------------------------------------------------------------------ audio front end
     def fbank(self, wave, n_samples, scale, win, shift, window, mel, n_mels, preemph, out):

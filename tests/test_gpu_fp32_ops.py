@@ -325,7 +325,7 @@ def test_swiglu_embed_merge_kv_fill_fsmn_fp32(ops):
     assert close(out.view(B, T, Dm), ref)
 
 
-@pytest.mark.parametrize("M,V,k", [(64, 151936, 8), (3, 1000, 2), (5, 70, 8), (2, 4097, 16)])
+@pytest.mark.parametrize("M,V,k", [(64, 151936, 8), (3, 1000, 2), (5, 70, 8), (2, 4097, 16), (4, 152064, 6), (7, 12, 16)])
 def test_logprob_topk_fp32(ops, M, V, k):
     """(x - max) - log(sum exp(x - max)) of the k best selectable columns: values against torch.log_softmax in fp32, indices exact
     (ties: smaller column first), banned columns skipped; a row of massive ties takes the round-by-round form."""
@@ -333,9 +333,11 @@ def test_logprob_topk_fp32(ops, M, V, k):
     logits[0] = 0.5                                                                    # row 0: one winner, then V - 1 columns tied
     logits[0, 5] = 99.0                                                                # (more than the candidate list holds when V is large)
     banned = torch.tensor([int(logits[1 % M].argmax()), 3], dtype=torch.int32).cuda()
-    for nban in (0, 2):
+    ws = torch.empty(M * 16 * (2 + 2 * k), device="cuda")
+    for nban, split in ((0, False), (2, False), (0, True), (2, True)):      # split: the row over 16 workgroups + a merge launch (workspace given)
         val, idx = torch.empty(M, k, device="cuda"), torch.empty(M, k, dtype=torch.int32, device="cuda")
-        ops.f32_logprob_topk(logits, M, V, k, banned, nban, val, idx)
+        ws.fill_(float("nan"))
+        ops.f32_logprob_topk(logits, M, V, k, banned, nban, val, idx, ws=ws if split else None)
         torch.cuda.synchronize()
         x64 = logits.double().cpu()
         lp32 = torch.log_softmax(logits, -1).cpu()
@@ -345,7 +347,7 @@ def test_logprob_topk_fp32(ops, M, V, k):
         order = torch.from_numpy(np.lexsort((np.arange(V)[None, :].repeat(M, 0), -x64.numpy()), axis=-1)[:, :k].copy())
         n_sel = V - nban
         kk = min(k, n_sel)
-        assert torch.equal(idx.cpu().long()[:, :kk], order[:, :kk]), nban
+        assert torch.equal(idx.cpu().long()[:, :kk], order[:, :kk]), (nban, split)
         want = torch.gather(lp32, 1, order[:, :kk])
         assert float((val.cpu()[:, :kk] - want).abs().max()) < 2e-5
 
