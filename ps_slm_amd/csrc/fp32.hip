@@ -928,33 +928,37 @@ __global__ __launch_bounds__(256) void f32_topk_part_kernel(const float* __restr
     if (bid == 0x7fffffff) pvv = -__builtin_inff(), pii = 0x7fffffff;
   }
 }
-__global__ __launch_bounds__(64) void f32_topk_merge_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
-                                                            const float* __restrict__ pv, const int32_t* __restrict__ pi, int k,
-                                                            float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+__global__ __launch_bounds__(256) void f32_topk_merge_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
+                                                             const float* __restrict__ pv, const int32_t* __restrict__ pi, int k,
+                                                             float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
   __shared__ float cv[F32_TOPK_PARTS * 16];
   __shared__ int ci[F32_TOPK_PARTS * 16];
-  const int row = blockIdx.x, lane = threadIdx.x;
-  const bool lp = lane < F32_TOPK_PARTS;
-  const float mp = lp ? pm[(size_t)row * F32_TOPK_PARTS + lane] : -__builtin_inff();
-  const float sp = lp ? ps[(size_t)row * F32_TOPK_PARTS + lane] : 0.f;
-  const float M = wave_max(mp);
-  const float S = wave_sum(lp && mp > -__builtin_inff() ? sp * expf(mp - M) : 0.f);
-  const float lse = logf(S);
-  const int n = F32_TOPK_PARTS * k;
-  for (int i = lane; i < n; i += 64) cv[i] = pv[(size_t)row * n + i], ci[i] = pi[(size_t)row * n + i];
+  __shared__ float stat[2];
+  __shared__ int nvalid;
+  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63;
+  const int n = F32_TOPK_PARTS * k;                      // <= 256: one candidate per thread
+  if (t == 0) nvalid = 0;
+  float v = -__builtin_inff();
+  int id = 0x7fffffff;
+  if (t < n) v = pv[(size_t)row * n + t], id = pi[(size_t)row * n + t];
+  cv[t] = v, ci[t] = id;
+  if (t < 64) {                                          // wave 0: the row's log-sum-exp from the parts' (max, sum)
+    const bool lp = lane < F32_TOPK_PARTS;
+    const float mp = lp ? pm[(size_t)row * F32_TOPK_PARTS + lane] : -__builtin_inff();
+    const float sp = lp ? ps[(size_t)row * F32_TOPK_PARTS + lane] : 0.f;
+    const float M = wave_max(mp);
+    const float S = wave_sum(lp && mp > -__builtin_inff() ? sp * expf(mp - M) : 0.f);
+    if (lane == 0) stat[0] = M, stat[1] = logf(S);
+  }
   __syncthreads();
-  for (int i = lane; i < n; i += 64) {
-    const float v = cv[i];
-    const int id = ci[i];
-    if (id == 0x7fffffff) continue;
+  if (id != 0x7fffffff) {
+    atomicAdd(&nvalid, 1);
     int rank = 0;
     for (int d = 0; d < n; ++d) rank += (cv[d] > v || (cv[d] == v && ci[d] < id)) ? 1 : 0;
-    if (rank < k) out_val[(size_t)row * k + rank] = (v - M) - lse, out_idx[(size_t)row * k + rank] = id;
+    if (rank < k) out_val[(size_t)row * k + rank] = (v - stat[0]) - stat[1], out_idx[(size_t)row * k + rank] = id;
   }
-  // fewer than k selectable columns in the row: the tail keeps (-inf, 0x7fffffff)
-  int valid = 0;
-  for (int d = 0; d < n; ++d) valid += ci[d] != 0x7fffffff ? 1 : 0;
-  if (lane >= valid && lane < k) out_val[(size_t)row * k + lane] = -__builtin_inff(), out_idx[(size_t)row * k + lane] = 0x7fffffff;
+  __syncthreads();
+  if (t >= nvalid && t < k) out_val[(size_t)row * k + t] = -__builtin_inff(), out_idx[(size_t)row * k + t] = 0x7fffffff;   // fewer than k selectable columns
 }
 
 // Shifted cross entropy of one fp32 logits row per 1024-thread block (the eval-mode forward in fp32: loss_utils' CE over the rows
@@ -1383,7 +1387,7 @@ extern "C" int tasu_f32_logprob_topk(const float* logits, int ld, int M, int V, 
     int32_t* pi = (int32_t*)(pv + slots * k);
     TASU_LAUNCH(f32_topk_part_kernel, dim3(M, F32_TOPK_PARTS), dim3(256), 0, (hipStream_t)stream, logits, ld, V, k, banned, n_banned, pm, ps, pv,
                 pi);
-    TASU_LAUNCH(f32_topk_merge_kernel, dim3(M), dim3(64), 0, (hipStream_t)stream, pm, ps, pv, pi, k, out_val, out_idx);
+    TASU_LAUNCH(f32_topk_merge_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, pm, ps, pv, pi, k, out_val, out_idx);
     return TASU_OK;
   }
   TASU_LAUNCH(f32_logprob_topk_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, logits, ld, V, k, banned, n_banned, out_val, out_idx);
