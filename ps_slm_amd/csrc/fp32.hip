@@ -1017,14 +1017,22 @@ __global__ __launch_bounds__(1024) void f32_ce_kernel(const float* __restrict__ 
 
 using namespace tasu_f32;
 
+// (lab build only -- common.h tasu_lab_env: the shipped library reads no tuning variable)
+static int f32_env_int(const char* name, int dflt) {
+  const char* e = tasu_lab_env(name);
+  return e ? atoi(e) : dflt;
+}
 // the K-range split of a problem (1 = none) on the tile kernel: outputs of fewer than 1024 tiles run as K-range slabs until ~1024
-// workgroups stream (a workgroup keeps 16 KiB in flight; the chip needs a few per CU to reach the HBM rate)
+// workgroups stream (a workgroup keeps 16 KiB in flight; the chip needs a few per CU to reach the HBM rate), eight slabs at most
 static int f32_tile_ksplit(int M, int N, int K, const float* workspace, int64_t workspace_floats) {
   const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
   int ksplit = 1;
   if (workspace && tiles < 1024) {
+    // at most 8 slabs: q|k|v and o of a decode step measured 4.41 / 4.41 / 4.28 / 4.31 / 4.45 ms per position with caps of 16 / 12 / 8 / 6 / 4
+    // (fewer slabs for the finisher to read against fewer workgroups streaming; TASU_F32_TILE_KSPLIT_MAX in the lab build)
+    static const int cap = std::max(1, std::min(16, f32_env_int("TASU_F32_TILE_KSPLIT_MAX", 8)));
     ksplit = (1024 + tiles - 1) / tiles;
-    if (ksplit > 16) ksplit = 16;
+    if (ksplit > cap) ksplit = cap;
     while (ksplit > 1 && ((K / BK) % ksplit || (int64_t)ksplit * M * N > workspace_floats)) --ksplit;
   }
   return ksplit;
@@ -1046,11 +1054,6 @@ static int f32_stream_cus() {
               ? prop.multiProcessorCount : 256;
   }
   return cus;
-}
-// (lab build only -- common.h tasu_lab_env: the shipped library reads no tuning variable)
-static int f32_env_int(const char* name, int dflt) {
-  const char* e = tasu_lab_env(name);
-  return e ? atoi(e) : dflt;
 }
 static F32StreamPlan f32_stream_plan(int M, int N, int K, const float* workspace, int64_t workspace_floats) {
   static const int off = f32_env_int("TASU_F32_STREAM", 1) == 0, forced = f32_env_int("TASU_F32_STREAM_KS", 0);   // (tools: A/B runs, KS sweeps)
