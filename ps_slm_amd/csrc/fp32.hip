@@ -447,14 +447,16 @@ __global__ __launch_bounds__(256) void f32_kv_fill_kernel(const float* __restric
 constexpr int F32_ATTN_MAX_KEYS = 2048;
 constexpr int F32_ATTN_MAX_REP = 8;
 constexpr int F32_PREFILL_NW = 4, F32_DECODE_NW = 8, F32_DECODE_VPRE = 32;
+// kst: the score rows' stride = the launch's longest key range rounded up to 64 (LDS sized for the sequence at hand: with rows of
+// MAX_KEYS the prompt pass held two workgroups per CU)
 template <int REP, int NW>
-__host__ __device__ constexpr int f32_attn_lds_floats() { return REP * HD + REP * F32_ATTN_MAX_KEYS + NW * REP * HD + NW * REP; }
+__host__ __device__ constexpr int f32_attn_lds_floats(int kst) { return REP * HD + REP * kst + NW * REP * HD + NW * REP; }
 template <int REP, int NW, int VPRE, typename KeyAt, typename ValAt>
-__device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, float* out, float* smem, KeyAt key_at, ValAt val_at) {
+__device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, float* out, float* smem, int kst, KeyAt key_at, ValAt val_at) {
   constexpr int NT = 64 * NW;
   float* sq = smem;
   float* sp = sq + REP * HD;
-  float* part = sp + REP * F32_ATTN_MAX_KEYS;
+  float* part = sp + REP * kst;
   float* red = part + NW * REP * HD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nk = k_hi - k_lo;
@@ -492,7 +494,7 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
 #pragma unroll
         for (int h = 0; h < REP; ++h) {
           const float sc = a[h] * scale;
-          if (seg == 0) sp[h * F32_ATTN_MAX_KEYS + j] = sc;
+          if (seg == 0) sp[h * kst + j] = sc;
           mx[h] = fmaxf(mx[h], sc);
         }
       }
@@ -529,8 +531,8 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
   for (int h = 0; h < REP; ++h) {
     float sum = 0.f;
     for (int j = t; j < nk; j += NT) {
-      const float e = expf(sp[h * F32_ATTN_MAX_KEYS + j] - mx[h]);
-      sp[h * F32_ATTN_MAX_KEYS + j] = e;
+      const float e = expf(sp[h * kst + j] - mx[h]);
+      sp[h * kst + j] = e;
       sum += e;
     }
     sum = wave_sum(sum);
@@ -554,7 +556,7 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
     if (j_lo + u < j_hi) {
 #pragma unroll
       for (int h = 0; h < REP; ++h) {
-        const float p = sp[h * F32_ATTN_MAX_KEYS + j_lo + u] * inv[h];
+        const float p = sp[h * kst + j_lo + u] * inv[h];
         o0[h] += p * pva[u];
         o1[h] += p * pvb[u];
       }
@@ -573,7 +575,7 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
       for (int h = 0; h < REP; ++h) {
-        const float p = sp[h * F32_ATTN_MAX_KEYS + j + u] * inv[h];
+        const float p = sp[h * kst + j + u] * inv[h];
         o0[h] += p * va[u];
         o1[h] += p * vb[u];
       }
@@ -583,7 +585,7 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
     const float va = vr[lane], vb = vr[lane + 64];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
-      const float p = sp[h * F32_ATTN_MAX_KEYS + j] * inv[h];
+      const float p = sp[h * kst + j] * inv[h];
       o0[h] += p * va;
       o1[h] += p * vb;
     }
@@ -606,7 +608,7 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
 template <int REP>
 __global__ __launch_bounds__(256) void f32_attn_prefill_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ kstart,
                                                                const int32_t* __restrict__ klen, float* __restrict__ out, int B, int S,
-                                                               int H, int G, float scale) {
+                                                               int H, int G, float scale, int kst) {
   extern __shared__ float smem[];
   const long long id = blockIdx.x;
   const int g = (int)(id % G);
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(256) void f32_attn_prefill_kernel(const float* __re
     return;
   }
   const float* base = qkv + (size_t)b * S * LD;
-  f32_attn_group<REP, F32_PREFILL_NW, 0>(base + (size_t)s * LD + g * REP * HD, k_lo, k_hi, scale, o, smem,
+  f32_attn_group<REP, F32_PREFILL_NW, 0>(base + (size_t)s * LD + g * REP * HD, k_lo, k_hi, scale, o, smem, kst,
                       [&](int j) { return base + (size_t)j * LD + (H + g) * HD; },
                       [&](int j) { return base + (size_t)j * LD + (H + G + g) * HD; });
 }
@@ -634,15 +636,15 @@ template <int REP>
 __global__ __launch_bounds__(64 * F32_DECODE_NW) void f32_attn_decode_kernel(const float* __restrict__ qkv, const float* __restrict__ kc,
                                                               const float* __restrict__ vc, const int32_t* __restrict__ index,
                                                               const int32_t* __restrict__ kstart, const int32_t* __restrict__ lens,
-                                                              float* __restrict__ out, int M, int H, int G, int ctx, float scale) {
+                                                              float* __restrict__ out, int M, int H, int G, int ctx, float scale, int kst) {
   extern __shared__ float smem[];
   const int g = blockIdx.x % G, m = blockIdx.x / G;
   const int LD = (H + 2 * G) * HD, Wd = G * HD;
-  int* six = (int*)(smem + f32_attn_lds_floats<REP, F32_DECODE_NW>());
+  int* six = (int*)(smem + f32_attn_lds_floats<REP, F32_DECODE_NW>(kst));
   const int k_lo = kstart[m], k_hi = lens[m];
   for (int i = k_lo + threadIdx.x; i < k_hi; i += 64 * F32_DECODE_NW) six[i] = index[(size_t)m * ctx + i];
   __syncthreads();
-  f32_attn_group<REP, F32_DECODE_NW, F32_DECODE_VPRE>(qkv + (size_t)m * LD + g * REP * HD, k_lo, k_hi, scale, out + (size_t)m * (H * HD) + g * REP * HD, smem,
+  f32_attn_group<REP, F32_DECODE_NW, F32_DECODE_VPRE>(qkv + (size_t)m * LD + g * REP * HD, k_lo, k_hi, scale, out + (size_t)m * (H * HD) + g * REP * HD, smem, kst,
                       [&](int j) { return kc + ((size_t)six[j] * ctx + j) * Wd + g * HD; },
                       [&](int j) { return vc + ((size_t)six[j] * ctx + j) * Wd + g * HD; });
 }
@@ -1298,18 +1300,24 @@ template <int REP>
 static int f32_attn_launch(bool decode, const float* qkv, const float* kc, const float* vc, const int32_t* index, const int32_t* kstart,
                            const int32_t* lens, float* out, int rows, int S, int H, int G, int ctx, float scale, hipStream_t st) {
   // (prefill: `lens` = klen [B] or NULL)
-  const int lds = decode ? (f32_attn_lds_floats<REP, F32_DECODE_NW>() + F32_ATTN_MAX_KEYS) * 4 : f32_attn_lds_floats<REP, F32_PREFILL_NW>() * 4;
+  // score rows as long as this launch's longest key range (decode: the cache's ctx; prefill: S), rounded up to 64
+  const int kst = ((decode ? ctx : S) + 63) & ~63;
+  const int lds = decode ? (f32_attn_lds_floats<REP, F32_DECODE_NW>(kst) + kst) * 4 : f32_attn_lds_floats<REP, F32_PREFILL_NW>(kst) * 4;
   static bool set[2] = {false, false};
-  if (!set[decode]) {
-    if (decode) (void)hipFuncSetAttribute((const void*)f32_attn_decode_kernel<REP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    else (void)hipFuncSetAttribute((const void*)f32_attn_prefill_kernel<REP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (!set[decode]) {                                 // (the attribute: the largest the kernels may ask for, MAX_KEYS keys)
+    if (decode)
+      (void)hipFuncSetAttribute((const void*)f32_attn_decode_kernel<REP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (f32_attn_lds_floats<REP, F32_DECODE_NW>(F32_ATTN_MAX_KEYS) + F32_ATTN_MAX_KEYS) * 4);
+    else
+      (void)hipFuncSetAttribute((const void*)f32_attn_prefill_kernel<REP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                f32_attn_lds_floats<REP, F32_PREFILL_NW>(F32_ATTN_MAX_KEYS) * 4);
     set[decode] = true;
   }
   if (decode) {
-    TASU_LAUNCH(f32_attn_decode_kernel<REP>, dim3(rows * G), dim3(64 * F32_DECODE_NW), lds, st, qkv, kc, vc, index, kstart, lens, out, rows, H, G, ctx, scale);
+    TASU_LAUNCH(f32_attn_decode_kernel<REP>, dim3(rows * G), dim3(64 * F32_DECODE_NW), lds, st, qkv, kc, vc, index, kstart, lens, out, rows, H, G, ctx, scale, kst);
   } else {
     TASU_LAUNCH(f32_attn_prefill_kernel<REP>, dim3((unsigned)((long long)rows * G)), dim3(256), lds, st, qkv, kstart, lens, out, rows / S, S,
-                H, G, scale);
+                H, G, scale, kst);
   }
   return TASU_OK;
 }

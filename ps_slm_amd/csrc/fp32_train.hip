@@ -113,18 +113,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 //           dS = P (dP - delta);  dQ = scale * dS . K;  lse / delta are kept per (row, head) for the second launch
 //   bwd_kv  one workgroup per (batch row, key, KV head): for every query >= the key and every head of the group:
 //           P = exp(scale q.k - lse), dS = P (dO.v - delta);  dV = sum P dO,  dK = scale * sum dS q   (the group's heads summed)
-// Same structure as fp32.hip's forward: phase 1 thread = the other index (whole 128-dim dot products), phase 2 lanes = dims.
+// Same structure as fp32.hip's forward: phase 1 eight lanes per row of the other index (16 dims each, lane shuffles add the partial
+// dots), phase 2 lanes = dims.
 constexpr int MAXK = 2048;
 template <int REP>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const int32_t* __restrict__ kstart,
                                                          float* __restrict__ dqkv, float* __restrict__ lse_out, float* __restrict__ delta_out, int B,
-                                                         int S, int H, int G, float scale) {
+                                                         int S, int H, int G, float scale, int kst) {
   extern __shared__ float smem[];
   float* sq = smem;                                  // REP * 128 queries
   float* sdo = sq + REP * HD;                        // REP * 128 output gradients
-  float* sp = sdo + REP * HD;                        // REP * MAXK probabilities, then dS
-  float* sdp = sp + REP * MAXK;                      // REP * MAXK dP
-  float* part = sdp + REP * MAXK;                    // 4 * REP * 128 partial dQ
+  float* sp = sdo + REP * HD;                        // REP * kst probabilities, then dS (kst = S rounded up to 64: LDS sized for the
+  float* sdp = sp + REP * kst;                       // REP * kst dP             sequence, not for MAXK -- 117 KB held one workgroup per CU)
+  float* part = sdp + REP * kst;                     // 4 * REP * 128 partial dQ
   float* red = part + 4 * REP * HD;                  // 4 * REP
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int g = blockIdx.x % G;
@@ -147,28 +148,42 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   float mx[REP];
 #pragma unroll
   for (int h = 0; h < REP; ++h) mx[h] = -__builtin_inff();
-  for (int j = t; j < nk; j += 256) {
-    const f32x4* kr = (const f32x4*)(base + (size_t)(k_lo + j) * LD + (H + g) * HD);
-    const f32x4* vr = (const f32x4*)(base + (size_t)(k_lo + j) * LD + (H + G + g) * HD);
-    float a[REP], dp[REP];
-#pragma unroll
-    for (int h = 0; h < REP; ++h) a[h] = dp[h] = 0.f;
-#pragma unroll 4
-    for (int c = 0; c < HD / 4; ++c) {
-      const f32x4 kv = kr[c], vv = vr[c];
+  // EIGHT LANES PER KEY, 16 dims each (a K / V row is 512 contiguous bytes over 8 adjacent lanes; one thread per key read 16 bytes of
+  // a different row per lane), two keys per lane group and trip; the partial dots are added by lane shuffles (csrc/fp32.hip's forward)
+  {
+    const int seg = t & 7;
+    auto dots = [&](const f32x4 (&kv)[4], const f32x4 (&vv)[4], int j) {
 #pragma unroll
       for (int h = 0; h < REP; ++h) {
-        const f32x4 qv = *(const f32x4*)(sq + h * HD + c * 4), dv = *(const f32x4*)(sdo + h * HD + c * 4);
-        a[h] += kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
-        dp[h] += vv[0] * dv[0] + vv[1] * dv[1] + vv[2] * dv[2] + vv[3] * dv[3];
-      }
-    }
+        float a = 0.f, dp = 0.f;
 #pragma unroll
-    for (int h = 0; h < REP; ++h) {
-      const float sc = a[h] * scale;
-      sp[h * MAXK + j] = sc;
-      sdp[h * MAXK + j] = dp[h];
-      mx[h] = fmaxf(mx[h], sc);
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 qv = *(const f32x4*)(sq + h * HD + seg * 16 + c * 4), dv = *(const f32x4*)(sdo + h * HD + seg * 16 + c * 4);
+          a += kv[c][0] * qv[0] + kv[c][1] * qv[1] + kv[c][2] * qv[2] + kv[c][3] * qv[3];
+          dp += vv[c][0] * dv[0] + vv[c][1] * dv[1] + vv[c][2] * dv[2] + vv[c][3] * dv[3];
+        }
+        a += __shfl_xor(a, 1, 64), dp += __shfl_xor(dp, 1, 64);
+        a += __shfl_xor(a, 2, 64), dp += __shfl_xor(dp, 2, 64);
+        a += __shfl_xor(a, 4, 64), dp += __shfl_xor(dp, 4, 64);
+        if (j < nk) {
+          const float sc = a * scale;
+          if (seg == 0) sp[h * kst + j] = sc, sdp[h * kst + j] = dp;
+          mx[h] = fmaxf(mx[h], sc);
+        }
+      }
+    };
+    for (int j0 = 0; j0 < nk; j0 += 64) {
+      const int ja = j0 + (t >> 3), jb = ja + 32;
+      const float* ra = base + (size_t)(k_lo + min(ja, nk - 1)) * LD;
+      const float* rb = base + (size_t)(k_lo + min(jb, nk - 1)) * LD;
+      f32x4 ka[4], va[4], kb[4], vb[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        ka[c] = *(const f32x4*)(ra + (H + g) * HD + seg * 16 + c * 4), va[c] = *(const f32x4*)(ra + (H + G + g) * HD + seg * 16 + c * 4);
+        kb[c] = *(const f32x4*)(rb + (H + g) * HD + seg * 16 + c * 4), vb[c] = *(const f32x4*)(rb + (H + G + g) * HD + seg * 16 + c * 4);
+      }
+      dots(ka, va, ja);
+      if (j0 + 32 < nk) dots(kb, vb, jb);                // (workgroup-uniform)
     }
   }
 #pragma unroll
@@ -185,8 +200,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   for (int h = 0; h < REP; ++h) {
     float sum = 0.f;
     for (int j = t; j < nk; j += 256) {
-      const float e = expf(sp[h * MAXK + j] - mx[h]);
-      sp[h * MAXK + j] = e;
+      const float e = expf(sp[h * kst + j] - mx[h]);
+      sp[h * kst + j] = e;
       sum += e;
     }
     sum = wave_sum(sum);
@@ -205,7 +220,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
 #pragma unroll
   for (int h = 0; h < REP; ++h) {
     float sum = 0.f;
-    for (int j = t; j < nk; j += 256) sum += sp[h * MAXK + j] * inv[h] * sdp[h * MAXK + j];
+    for (int j = t; j < nk; j += 256) sum += sp[h * kst + j] * inv[h] * sdp[h * kst + j];
     sum = wave_sum(sum);
     if (lane == 0) red[wave * REP + h] = sum;
   }
@@ -219,19 +234,37 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   // dS (scaled) in place of P
 #pragma unroll
   for (int h = 0; h < REP; ++h)
-    for (int j = t; j < nk; j += 256) sp[h * MAXK + j] = sp[h * MAXK + j] * inv[h] * (sdp[h * MAXK + j] - dl[h]) * scale;
+    for (int j = t; j < nk; j += 256) sp[h * kst + j] = sp[h * kst + j] * inv[h] * (sdp[h * kst + j] - dl[h]) * scale;
   __syncthreads();
   // dQ_h = sum_j dS[h][j] K_j: this wave's quarter of the keys, lanes = dims
   float o0[REP], o1[REP];
 #pragma unroll
   for (int h = 0; h < REP; ++h) o0[h] = o1[h] = 0.f;
   const int q4 = (nk + 3) >> 2, j_lo = wave * q4, j_hi = min(nk, j_lo + q4);
-  for (int j = j_lo; j < j_hi; ++j) {
+  constexpr int UNR = 8;                               // eight K rows in flight per trip (two dependent 4-byte loads per trip were
+  int j = j_lo;                                        // what this phase waited on)
+  for (; j + UNR <= j_hi; j += UNR) {
+    float ka[UNR], kb[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const float* kr = base + (size_t)(k_lo + j + u) * LD + (H + g) * HD;
+      ka[u] = kr[lane], kb[u] = kr[lane + 64];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        const float d = sp[h * kst + j + u];
+        o0[h] += d * ka[u];
+        o1[h] += d * kb[u];
+      }
+  }
+  for (; j < j_hi; ++j) {
     const float* kr = base + (size_t)(k_lo + j) * LD + (H + g) * HD;
     const float ka = kr[lane], kb = kr[lane + 64];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
-      const float d = sp[h * MAXK + j];
+      const float d = sp[h * kst + j];
       o0[h] += d * ka;
       o1[h] += d * kb;
     }
@@ -248,13 +281,13 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
 template <int REP>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const int32_t* __restrict__ kstart,
                                                           const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
-                                                          int B, int S, int H, int G, float scale) {
+                                                          int B, int S, int H, int G, float scale, int kst) {
   extern __shared__ float smem[];
   float* sk = smem;                                  // 128: this key
   float* sv = sk + HD;                               // 128: this value
-  float* sp = sv + HD;                               // REP * MAXK: P[h][q]
-  float* sds = sp + REP * MAXK;                      // REP * MAXK: dS[h][q] (scaled)
-  float* part = sds + REP * MAXK;                    // 4 * 2 * 128 partial dK | dV
+  float* sp = sv + HD;                               // REP * kst: P[h][q]
+  float* sds = sp + REP * kst;                       // REP * kst: dS[h][q] (scaled)
+  float* part = sds + REP * kst;                     // 4 * 2 * 128 partial dK | dV
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int g = blockIdx.x % G;
   const long long bj = blockIdx.x / G;
@@ -270,35 +303,81 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
   if (t < HD) sk[t] = base[(size_t)j * LD + (H + g) * HD + t], sv[t] = base[(size_t)j * LD + (H + G + g) * HD + t];
   __syncthreads();
   const int nq = S - j;                              // queries j .. S - 1 see this key
-  for (int qi = t; qi < nq; qi += 256) {
-    const int q = j + qi;
+  // items = (query, head of the group); eight lanes per item, 16 dims each (a q / dO head row is 512 contiguous bytes over 8 lanes),
+  // two items per lane group and trip; this key's / value's 16 dims of the lane stay in registers
+  {
+    const int seg = t & 7, items = nq * REP;
+    f32x4 kseg[4], vseg[4];
 #pragma unroll
-    for (int h = 0; h < REP; ++h) {
-      const f32x4* qr = (const f32x4*)(base + (size_t)q * LD + (g * REP + h) * HD);
-      const f32x4* dor = (const f32x4*)(dout + ((size_t)b * S + q) * (H * HD) + (g * REP + h) * HD);
+    for (int c = 0; c < 4; ++c) kseg[c] = *(const f32x4*)(sk + seg * 16 + c * 4), vseg[c] = *(const f32x4*)(sv + seg * 16 + c * 4);
+    auto item = [&](const f32x4 (&qv)[4], const f32x4 (&dv4)[4], int it) {
       float a = 0.f, dp = 0.f;
-#pragma unroll 4
-      for (int c = 0; c < HD / 4; ++c) {
-        const f32x4 qv = qr[c], dv4 = dor[c], kv = *(const f32x4*)(sk + c * 4), vv = *(const f32x4*)(sv + c * 4);
-        a += kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
-        dp += vv[0] * dv4[0] + vv[1] * dv4[1] + vv[2] * dv4[2] + vv[3] * dv4[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a += kseg[c][0] * qv[c][0] + kseg[c][1] * qv[c][1] + kseg[c][2] * qv[c][2] + kseg[c][3] * qv[c][3];
+        dp += vseg[c][0] * dv4[c][0] + vseg[c][1] * dv4[c][1] + vseg[c][2] * dv4[c][2] + vseg[c][3] * dv4[c][3];
       }
-      const size_t sidx = ((size_t)b * H + g * REP + h) * S + q;
-      const float p = expf(a * scale - lse[sidx]);
-      sp[h * MAXK + qi] = p;
-      sds[h * MAXK + qi] = p * (dp - delta[sidx]) * scale;
+      a += __shfl_xor(a, 1, 64), dp += __shfl_xor(dp, 1, 64);
+      a += __shfl_xor(a, 2, 64), dp += __shfl_xor(dp, 2, 64);
+      a += __shfl_xor(a, 4, 64), dp += __shfl_xor(dp, 4, 64);
+      if (it < items && seg == 0) {
+        const int qi = it / REP, h = it - qi * REP;
+        const size_t sidx = ((size_t)b * H + g * REP + h) * S + j + qi;
+        const float p = expf(a * scale - lse[sidx]);
+        sp[h * kst + qi] = p;
+        sds[h * kst + qi] = p * (dp - delta[sidx]) * scale;
+      }
+    };
+    for (int i0 = 0; i0 < items; i0 += 64) {
+      const int ia = i0 + (t >> 3), ib = ia + 32;
+      const int ca = min(ia, items - 1), cb = min(ib, items - 1);
+      const int qa = ca / REP, ha = ca - qa * REP, qb = cb / REP, hb = cb - qb * REP;
+      const float* qra = base + (size_t)(j + qa) * LD + (g * REP + ha) * HD + seg * 16;
+      const float* dra = dout + ((size_t)b * S + j + qa) * (H * HD) + (g * REP + ha) * HD + seg * 16;
+      const float* qrb = base + (size_t)(j + qb) * LD + (g * REP + hb) * HD + seg * 16;
+      const float* drb = dout + ((size_t)b * S + j + qb) * (H * HD) + (g * REP + hb) * HD + seg * 16;
+      f32x4 q1[4], d1[4], q2[4], d2[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        q1[c] = *(const f32x4*)(qra + c * 4), d1[c] = *(const f32x4*)(dra + c * 4);
+        q2[c] = *(const f32x4*)(qrb + c * 4), d2[c] = *(const f32x4*)(drb + c * 4);
+      }
+      item(q1, d1, ia);
+      if (i0 + 32 < items) item(q2, d2, ib);            // (workgroup-uniform)
     }
   }
   __syncthreads();
   float k0 = 0.f, k1 = 0.f, v0 = 0.f, v1 = 0.f;
   const int q4 = (nq + 3) >> 2, q_lo = wave * q4, q_hi = min(nq, q_lo + q4);
-  for (int qi = q_lo; qi < q_hi; ++qi) {
+  int qi = q_lo;
+  for (; qi + 2 <= q_hi; qi += 2) {                    // two queries (2 x REP x 4 loads) in flight per trip
+    float qa[2][REP], qb[2][REP], da[2][REP], db[2][REP];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        const float* qr = base + (size_t)(j + qi + u) * LD + (g * REP + h) * HD;
+        const float* dor = dout + ((size_t)b * S + j + qi + u) * (H * HD) + (g * REP + h) * HD;
+        qa[u][h] = qr[lane], qb[u][h] = qr[lane + 64], da[u][h] = dor[lane], db[u][h] = dor[lane + 64];
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        const float p = sp[h * kst + qi + u], d = sds[h * kst + qi + u];
+        k0 += d * qa[u][h];
+        k1 += d * qb[u][h];
+        v0 += p * da[u][h];
+        v1 += p * db[u][h];
+      }
+  }
+  for (; qi < q_hi; ++qi) {
     const int q = j + qi;
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
       const float* qr = base + (size_t)q * LD + (g * REP + h) * HD;
       const float* dor = dout + ((size_t)b * S + q) * (H * HD) + (g * REP + h) * HD;
-      const float p = sp[h * MAXK + qi], d = sds[h * MAXK + qi];
+      const float p = sp[h * kst + qi], d = sds[h * kst + qi];
       k0 += d * qr[lane];
       k1 += d * qr[lane + 64];
       v0 += p * dor[lane];
@@ -368,17 +447,19 @@ extern "C" int tasu_f32_gather_rows(const float* dx, const int32_t* rows, float*
 template <int REP>
 static int attn_bwd_launch(const float* qkv, const float* dout, const int32_t* kstart, float* dqkv, float* lse, float* delta, int B, int S, int H,
                            int G, float scale, hipStream_t st) {
-  const int lds_q = (2 * REP * HD + 2 * REP * MAXK + 4 * REP * HD + 4 * REP) * 4;
-  const int lds_kv = (2 * HD + 2 * REP * MAXK + 8 * HD) * 4;
+  const int kst = (S + 63) & ~63;
+  const int lds_q = (2 * REP * HD + 2 * REP * kst + 4 * REP * HD + 4 * REP) * 4;
+  const int lds_kv = (2 * HD + 2 * REP * kst + 8 * HD) * 4;
   static bool set = false;
-  if (!set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<REP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<REP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+  if (!set) {                                         // (the attribute: the largest the kernels may ask for, S = MAXK)
+    (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<REP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (2 * REP * HD + 2 * REP * MAXK + 4 * REP * HD + 4 * REP) * 4);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<REP>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * HD + 2 * REP * MAXK + 8 * HD) * 4);
     set = true;
   }
   const unsigned grid = (unsigned)((long long)B * S * G);
-  TASU_LAUNCH(attn_bwd_q_kernel<REP>, dim3(grid), dim3(256), lds_q, st, qkv, dout, kstart, dqkv, lse, delta, B, S, H, G, scale);
-  TASU_LAUNCH(attn_bwd_kv_kernel<REP>, dim3(grid), dim3(256), lds_kv, st, qkv, dout, kstart, lse, delta, dqkv, B, S, H, G, scale);
+  TASU_LAUNCH(attn_bwd_q_kernel<REP>, dim3(grid), dim3(256), lds_q, st, qkv, dout, kstart, dqkv, lse, delta, B, S, H, G, scale, kst);
+  TASU_LAUNCH(attn_bwd_kv_kernel<REP>, dim3(grid), dim3(256), lds_kv, st, qkv, dout, kstart, lse, delta, dqkv, B, S, H, G, scale, kst);
   return TASU_OK;
 }
 
