@@ -219,7 +219,7 @@ def model_factory(train_config, model_config, **kwargs):
         # (ps_slm_amd/decode_fp32.py), the eval-mode forward and the training step (ps_slm_amd/train_fp32.py); use_fp16 = true
         # selects bf16 autocast semantics, the path the benchmarks measure
         logger.warning("train_config.use_fp16 is false: the reference's fp32 arithmetic -- generate(), evaluation and the training step run on "
-                       "the fp32 kernels (correctness mode: the training step is ~11x slower than with use_fp16=true, which selects the "
+                       "the fp32 kernels (correctness mode: the training step is ~10x slower than with use_fp16=true, which selects the "
                        "bf16-autocast path the benchmarks measure); LoRA and the non-default projectors have the bf16 path only")
     raw = not train_config.get("ctc_posterior", True)
     if raw and projector == "cross-attention":

@@ -11,7 +11,7 @@ Multitask/scripts/finetune_deespeed_sensevoice.sh:37 -- forward and backward out
             backward; attention probabilities are recomputed from the saved q|k|v) -> the audio rows' gradient -> projector weight
             gradients straight into the flat fp32 bucket ``proj.g`` (what TasuEngine's AdamW and the autograd boundary read).
 
-A correctness mode: 11x slower than the bf16 step at Qwen2.5-1.5B (302 against 28 ms per 16 utterances: the fp32 matrix rate is 1/16 of bf16's; the step runs at 0.55 of it); pinned on the
+A correctness mode: ~10x slower than the bf16 step at Qwen2.5-1.5B (271 against 28 ms per 16 utterances: the fp32 matrix rate is 1/16 of bf16's; the step runs at 0.61 of it); pinned on the
 real reference's fp32 goldens (loss within 2e-5, projector gradients within 2e-4 relative L2: tests/test_gpu_model.py).  Decoder weights stay
 frozen (dgrad only), like the bf16 step; LoRA and the non-default projectors train on the bf16 path only.
 """
