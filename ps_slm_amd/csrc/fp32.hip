@@ -452,7 +452,11 @@ constexpr int F32_PREFILL_NW = 4, F32_DECODE_NW = 8, F32_DECODE_VPRE = 32;
 template <int REP, int NW>
 __host__ __device__ constexpr int f32_attn_lds_floats(int kst) { return REP * HD + REP * kst + NW * REP * HD + NW * REP; }
 template <int REP, int NW, int VPRE, typename KeyAt, typename ValAt>
-__device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, float* out, float* smem, int kst, KeyAt key_at, ValAt val_at) {
+// The REP "heads" are rows q + h * qstride (query heads of a KV group: stride 128; or, bidirectional attention, REP consecutive QUERY
+// positions of one head: stride = the activation's leading dimension); rows h >= nvalid are computed on a copy of the last valid one
+// and stored as zeros; rows h >= nstore are not stored at all (a tile that sticks out of the sequence).
+__device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, float* out, float* smem, int kst, KeyAt key_at, ValAt val_at,
+                               int qstride = HD, int ostride = HD, int nvalid = REP, int nstore = REP) {
   constexpr int NT = 64 * NW;
   float* sq = smem;
   float* sp = sq + REP * HD;
@@ -460,7 +464,7 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
   float* red = part + NW * REP * HD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nk = k_hi - k_lo;
-  for (int i = t; i < REP * HD; i += NT) sq[i] = q[i];
+  for (int i = t; i < REP * HD; i += NT) sq[i] = q[(size_t)min(i / HD, nvalid - 1) * qstride + (i & (HD - 1))];
   __syncthreads();
   float mx[REP];
 #pragma unroll
@@ -600,7 +604,7 @@ __device__ void f32_attn_group(const float* q, int k_lo, int k_hi, float scale, 
     float v = part[i];
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += part[w * REP * HD + i];      // (wave order = ascending keys)
-    out[i] = v;
+    if (i / HD < nstore) out[(size_t)(i / HD) * ostride + (i & (HD - 1))] = i / HD < nvalid ? v : 0.f;
   }
 }
 
@@ -628,6 +632,30 @@ __global__ __launch_bounds__(256) void f32_attn_prefill_kernel(const float* __re
   f32_attn_group<REP, F32_PREFILL_NW, 0>(base + (size_t)s * LD + g * REP * HD, k_lo, k_hi, scale, o, smem, kst,
                       [&](int j) { return base + (size_t)j * LD + (H + g) * HD; },
                       [&](int j) { return base + (size_t)j * LD + (H + G + g) * HD; });
+}
+
+// bidirectional attention with key padding (the SANM encoder: SenseVoice.py:209-228, H = G): one workgroup per (batch row, tile of QT
+// consecutive query positions, head) -- the QT queries see the same keys [0, klen[b]) and share every K / V row that is loaded, the
+// way the query heads of a KV group do in the causal kernel (one workgroup per query position re-read the head's 504 K / V rows 504
+// times per utterance: 16 GB of L2 traffic per layer at 16 x 504 frames, 672 us).  Positions >= klen[b] get zeros.
+constexpr int F32_BIDIR_QT = 8;
+__global__ __launch_bounds__(64 * F32_PREFILL_NW) void f32_attn_bidir_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ klen,
+                                                                             float* __restrict__ out, int B, int S, int H, float scale, int kst) {
+  extern __shared__ float smem[];
+  const int tiles = (S + F32_BIDIR_QT - 1) / F32_BIDIR_QT;
+  const int head = blockIdx.x % H;
+  const int tile = (blockIdx.x / H) % tiles, b = blockIdx.x / (H * tiles);
+  const int LD = 3 * H * HD, s0 = tile * F32_BIDIR_QT;
+  const int k_hi = min(klen[b], S), rows = min(F32_BIDIR_QT, S - s0), nvalid = max(0, min(rows, k_hi - s0));
+  float* o = out + ((size_t)b * S + s0) * (H * HD) + head * HD;
+  if (nvalid == 0) {                                   // a tile of padding positions
+    for (int i = threadIdx.x; i < rows * HD; i += 64 * F32_PREFILL_NW) o[(size_t)(i / HD) * (H * HD) + (i & (HD - 1))] = 0.f;
+    return;
+  }
+  const float* base = qkv + (size_t)b * S * LD;
+  f32_attn_group<F32_BIDIR_QT, F32_PREFILL_NW, 0>(base + (size_t)s0 * LD + head * HD, 0, k_hi, scale, o, smem, kst,
+                                                  [&](int j) { return base + (size_t)j * LD + (H + head) * HD; },
+                                                  [&](int j) { return base + (size_t)j * LD + (2 * H + head) * HD; }, LD, H * HD, nvalid, rows);
 }
 
 // decode: one workgroup per (beam row, KV head); key i of row m lives in cache row index[m, i] (tasu_kv_index_*), keys
@@ -1315,6 +1343,17 @@ static int f32_attn_launch(bool decode, const float* qkv, const float* kc, const
   }
   if (decode) {
     TASU_LAUNCH(f32_attn_decode_kernel<REP>, dim3(rows * G), dim3(64 * F32_DECODE_NW), lds, st, qkv, kc, vc, index, kstart, lens, out, rows, H, G, ctx, scale, kst);
+  } else if (REP == 1 && lens) {                       // bidirectional with key padding, H = G: tiles of F32_BIDIR_QT queries per workgroup
+    const int lds_b = f32_attn_lds_floats<F32_BIDIR_QT, F32_PREFILL_NW>(kst) * 4;
+    static bool set_b = false;
+    if (!set_b) {
+      (void)hipFuncSetAttribute((const void*)f32_attn_bidir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                f32_attn_lds_floats<F32_BIDIR_QT, F32_PREFILL_NW>(F32_ATTN_MAX_KEYS) * 4);
+      set_b = true;
+    }
+    const int Bn = rows / S, tiles = (S + F32_BIDIR_QT - 1) / F32_BIDIR_QT;
+    TASU_LAUNCH(f32_attn_bidir_kernel, dim3((unsigned)((long long)Bn * tiles * H)), dim3(64 * F32_PREFILL_NW), lds_b, st, qkv, lens, out, Bn, S, H,
+                scale, kst);
   } else {
     TASU_LAUNCH(f32_attn_prefill_kernel<REP>, dim3((unsigned)((long long)rows * G)), dim3(256), lds, st, qkv, kstart, lens, out, rows / S, S,
                 H, G, scale, kst);

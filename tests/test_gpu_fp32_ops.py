@@ -225,7 +225,7 @@ def _attn_ref(q, k, v, allow, scale):
     return torch.softmax(sc, -1) @ vv
 
 
-@pytest.mark.parametrize("B,S,H,G", [(2, 70, 12, 2), (1, 256, 2, 1), (3, 33, 28, 4), (2, 300, 4, 4)])
+@pytest.mark.parametrize("B,S,H,G", [(2, 70, 12, 2), (1, 256, 2, 1), (3, 33, 28, 4), (2, 300, 4, 4), (5, 45, 4, 4), (2, 504, 4, 4)])
 def test_attention_prefill_fp32(ops, B, S, H, G):
     """Causal prompt attention with left padding, and the bidirectional form with key lengths (the SANM encoder's)."""
     LD = (H + 2 * G) * HD
@@ -252,6 +252,8 @@ def test_attention_prefill_fp32(ops, B, S, H, G):
         allow = (torch.arange(S).cuda()[None, :] < n).expand(S, S)
         ref = _attn_ref(q, k, v, allow, scale).transpose(0, 1).reshape(S, H * HD)
         assert close(out.view(B, S, H * HD)[b, :n], ref[:n]), b
+        if H == G:                                                                         # (the tiled kernel of the encoder's shape: zeros past the length)
+            assert float(out.view(B, S, H * HD)[b, n:].abs().sum()) == 0.0
 
 
 @pytest.mark.parametrize("B,nb,S,new,H,G", [(2, 4, 20, 9, 12, 2), (1, 3, 5, 30, 2, 1), (3, 2, 11, 4, 28, 4)])
