@@ -311,7 +311,7 @@ def decode_leg(core, raw, B, new_tokens=200, beams=4):
                                  "wall time per position (prefill included in the wall time)"}}
 
 
-def decode_fp32_leg(local_rank, B, new_tokens=200, beams=4):
+def decode_fp32_leg(local_rank, B, new_tokens=200, beams=4, model_name="qwen2.5-1.5b"):
     """The reference's OWN decode arithmetic (train_config.use_fp16 = false: fp32 weights, cache and logits; Multitask/inference_batch.py:
     113-117) on the fp32 path (ps_slm_amd/decode_fp32.py): same prompt, beams and length as decode_leg."""
     from ps_slm_amd.config import ModelConfig, TrainConfig
@@ -321,7 +321,8 @@ def decode_fp32_leg(local_rank, B, new_tokens=200, beams=4):
 
     tc = TrainConfig(freeze_llm=True, freeze_encoder=True, gt_emb=True, gt_emb_noise=False, ctc_posterior=True, do_psd=True, use_fp16=False,
                      batching_strategy="dynamic")
-    mc = ModelConfig(llm_path="synthetic:qwen2.5-1.5b", encoder_projector="linear-silu", encoder_dim=25055, llm_dim=1536)
+    mc = ModelConfig(llm_path=f"synthetic:{model_name}", encoder_projector="linear-silu", encoder_dim=25055,
+                     llm_dim=3584 if model_name == "qwen2.5-7b" else 1536)
     model, _ = model_factory(tc, mc, device=f"cuda:{local_rank}", init_seed=1234, keep_logits=False, with_encoder=False)
     core = model.core
     geo = core.geo
